@@ -1,0 +1,32 @@
+"""gb25_amd -- MI355X-native implementation of the time-step hot path of PRONTOLab/GB-25.
+
+Public names mirror `GordonBell25` (GB-25 src/GordonBell25.jl:3-4 and the un-exported helpers
+its scripts call); Julia's trailing `!` is dropped.  Kernels live in libgb25hip.so behind the
+C ABI of include/gb25.h; this package only sequences calls and moves host arrays.
+"""
+from .binding import GB25Error, HipBackend, LIB_PATH, load_library
+from .build import build_library
+from .correctness import approx_equal, compare_states, sync_states
+from .model import (Field, HydrostaticFreeSurfaceModel, baroclinic_instability_model, first_time_step, initialize,
+                    loop, resolution_to_points, set_baroclinic_instability, time_step, update_state,
+                    tupled_fill_halo_regions_workload, compute_tendencies_workload,
+                    compute_boundary_tendencies_workload, compute_interior_momentum_tendencies_workload,
+                    compute_interior_tracer_tendencies_workload, compute_auxiliaries_workload,
+                    fill_halo_regions_workload, ab2_step_workload,
+                    correct_velocities_and_cache_previous_tendencies_workload)
+from .sharding import factors
+
+
+class GPU:
+    """Architecture object: `baroclinic_instability_model(GPU(), Nx, Ny, Nz; dt=...)`
+    (the reference passes CPU() / GPU() / ReactantState(), correctness/..._run.jl:33-34)."""
+
+    def __init__(self, device=0):
+        self.device = device
+
+    def __call__(self, Nx, Ny, Nz, **kw):
+        kw.setdefault("device", self.device)
+        return HipBackend(Nx, Ny, Nz, **kw)
+
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,242 @@
+"""ctypes binding of libgb25hip.so (the C ABI in include/gb25.h).
+
+This is the only place the shared library is loaded.  There is no fallback: if the
+library is missing or no HIP device is visible, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgb25hip.so")
+
+FIELD_IDS = {
+    "u": 0, "v": 1, "w": 2, "T": 3, "S": 4, "pHY": 5,
+    "Gn.u": 6, "Gn.v": 7, "Gn.T": 8, "Gn.S": 9,
+    "Gm.u": 10, "Gm.v": 11, "Gm.T": 12, "Gm.S": 13,
+    "eta": 14, "U": 15, "V": 16,
+    "eta_bar": 17, "U_bar": 18, "V_bar": 19,
+    "Gn.U": 20, "Gn.V": 21,
+}
+METRIC_IDS = {"phif": 0, "phic": 1, "dxc": 2, "dxf": 3, "azc": 4, "azf": 5, "fcor": 6,
+              "zf": 7, "zc": 8, "dzc": 9, "dzf": 10}
+KERNEL_IDS = {"fill_halos": 0, "compute_w": 1, "compute_p": 2, "gu": 3, "gv": 4, "tracers": 5,
+              "ab2_velocities": 6, "ab2_tracers": 7, "barotropic": 8, "corrector": 9}
+
+# every symbol include/gb25.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "gb25_default_config", "gb25_create", "gb25_destroy", "gb25_last_error_string", "gb25_version",
+    "gb25_set_stream", "gb25_synchronize", "gb25_field_dims", "gb25_set_field", "gb25_get_field",
+    "gb25_field_device_ptr", "gb25_get_metric", "gb25_get_substepping", "gb25_set_baroclinic_instability",
+    "gb25_get_clock", "gb25_set_dt", "gb25_initialize", "gb25_mask_immersed_fields",
+    "gb25_fill_halo_regions", "gb25_compute_auxiliaries", "gb25_fill_diffusivity_halos",
+    "gb25_compute_momentum_tendencies", "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
+    "gb25_compute_tendencies", "gb25_ab2_step", "gb25_correct_velocities_and_cache_previous_tendencies",
+    "gb25_update_state", "gb25_first_time_step", "gb25_time_step", "gb25_loop",
+    "gb25_halo_buffer_elems", "gb25_halo_pack", "gb25_halo_unpack", "gb25_time_step_stage",
+    "gb25_update_state_local", "gb25_fill_halo_regions_local",
+    "gb25_profile_enable", "gb25_profile_reset", "gb25_profile_get",
+]
+
+
+class Config(C.Structure):
+    """gb25_config (include/gb25.h)."""
+    _fields_ = [
+        ("Nx", C.c_int32), ("Ny", C.c_int32), ("Nz", C.c_int32), ("halo", C.c_int32),
+        ("substeps", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32), ("device", C.c_int32),
+        ("dt", C.c_double), ("chi", C.c_double),
+        ("lat_south", C.c_double), ("lat_north", C.c_double), ("lon_west", C.c_double), ("lon_east", C.c_double),
+        ("depth", C.c_double), ("zexp_h", C.c_double),
+        ("g", C.c_double), ("Omega", C.c_double), ("radius", C.c_double), ("rho0", C.c_double),
+    ]
+
+
+class GB25Error(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Load libgb25hip.so; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GB25Error(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  gb25_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    lib.gb25_version.restype = C.c_char_p
+    lib.gb25_last_error_string.restype = C.c_char_p
+    lib.gb25_last_error_string.argtypes = [P]
+    lib.gb25_default_config.argtypes = [C.POINTER(Config), C.c_int32, C.c_int32, C.c_int32]
+    lib.gb25_default_config.restype = None
+    lib.gb25_create.argtypes = [C.POINTER(Config), C.POINTER(P)]
+    lib.gb25_destroy.argtypes = [P]
+    lib.gb25_destroy.restype = None
+    lib.gb25_set_stream.argtypes = [P, P]
+    lib.gb25_field_dims.argtypes = [P, C.c_int, C.c_int, C.POINTER(C.c_int32)]
+    lib.gb25_set_field.argtypes = [P, C.c_int, P, C.c_int]
+    lib.gb25_get_field.argtypes = [P, C.c_int, P, C.c_int]
+    lib.gb25_field_device_ptr.argtypes = [P, C.c_int, C.POINTER(P)]
+    lib.gb25_get_metric.argtypes = [P, C.c_int, C.c_int32, C.POINTER(C.c_double)]
+    lib.gb25_get_substepping.argtypes = [P, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.gb25_get_clock.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    lib.gb25_set_dt.argtypes = [P, C.c_double]
+    lib.gb25_ab2_step.argtypes = [P, C.c_double, C.c_int]
+    lib.gb25_correct_velocities_and_cache_previous_tendencies.argtypes = [P, C.c_double]
+    lib.gb25_loop.argtypes = [P, C.c_int32]
+    lib.gb25_halo_buffer_elems.argtypes = [P, C.c_int, C.POINTER(C.c_int64)]
+    lib.gb25_halo_pack.argtypes = [P, C.c_int, C.c_int, P]
+    lib.gb25_halo_unpack.argtypes = [P, C.c_int, C.c_int, P]
+    lib.gb25_time_step_stage.argtypes = [P, C.c_int, C.c_int]
+    lib.gb25_profile_enable.argtypes = [P, C.c_int]
+    lib.gb25_profile_get.argtypes = [P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    for name in ["gb25_synchronize", "gb25_set_baroclinic_instability", "gb25_initialize",
+                 "gb25_mask_immersed_fields", "gb25_fill_halo_regions", "gb25_compute_auxiliaries",
+                 "gb25_fill_diffusivity_halos", "gb25_compute_momentum_tendencies",
+                 "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
+                 "gb25_compute_tendencies", "gb25_update_state", "gb25_first_time_step", "gb25_time_step",
+                 "gb25_update_state_local", "gb25_fill_halo_regions_local", "gb25_profile_reset"]:
+        getattr(lib, name).argtypes = [P]
+    _lib = lib
+    return lib
+
+
+class HipBackend:
+    """One gb25_model handle.  Method names follow the phase list of
+    GB-25 src/precompile.jl:31-42 and the entry points of src/timestepping_utils.jl:21-45."""
+
+    dtype = np.float32
+
+    def __init__(self, Nx, Ny, Nz, *, dt, halo=8, substeps=30, device=0, rank=0, nranks=1, **overrides):
+        self.lib = load_library()
+        cfg = Config()
+        self.lib.gb25_default_config(C.byref(cfg), Nx, Ny, Nz)
+        cfg.halo, cfg.substeps, cfg.dt, cfg.device, cfg.rank, cfg.nranks = halo, substeps, dt, device, rank, nranks
+        for k, v in overrides.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown configuration field {k!r}")
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        st = self.lib.gb25_create(C.byref(cfg), C.byref(self.h))
+        if st != 0:
+            msg = self.lib.gb25_last_error_string(self.h).decode() if self.h else "gb25_create failed"
+            if self.h:
+                self.lib.gb25_destroy(self.h)
+                self.h = None
+            raise GB25Error(f"gb25_create: status {st}: {msg}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gb25_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st, what):
+        if st != 0:
+            raise GB25Error(f"{what}: status {st}: {self.lib.gb25_last_error_string(self.h).decode()}")
+
+    def _call(self, name, *args):
+        self._chk(getattr(self.lib, name)(self.h, *args), name)
+
+    # ---- fields
+    def field_dims(self, name, include_halos=True):
+        d = (C.c_int32 * 3)()
+        self._call("gb25_field_dims", FIELD_IDS[name], int(include_halos), d)
+        return tuple(d)
+
+    def get_field(self, name, include_halos=True):
+        """numpy array shaped like parent(field) / interior(field), index order [i, j, k]."""
+        d = self.field_dims(name, include_halos)
+        out = np.empty(d[::-1], dtype=np.float32)  # memory order is i fastest
+        self._call("gb25_get_field", FIELD_IDS[name], out.ctypes.data_as(C.c_void_p), int(include_halos))
+        return out.transpose(2, 1, 0)
+
+    def set_field(self, name, array, include_halos=True):
+        d = self.field_dims(name, include_halos)
+        a = np.asarray(array, dtype=np.float32)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        if a.shape != d:
+            raise ValueError(f"{name}: expected shape {d}, got {a.shape}")
+        buf = np.ascontiguousarray(a.transpose(2, 1, 0))
+        self._call("gb25_set_field", FIELD_IDS[name], buf.ctypes.data_as(C.c_void_p), int(include_halos))
+
+    def field_device_ptr(self, name):
+        p = C.c_void_p()
+        self._call("gb25_field_device_ptr", FIELD_IDS[name], C.byref(p))
+        return p.value
+
+    def metric(self, name, index):
+        v = C.c_double()
+        self._call("gb25_get_metric", METRIC_IDS[name], index, C.byref(v))
+        return v.value
+
+    def substepping(self):
+        n, frac = C.c_int32(), C.c_double()
+        w = (C.c_double * 4096)()
+        self._call("gb25_get_substepping", C.byref(n), C.byref(frac), w)
+        return n.value, frac.value, np.array(w[: n.value])
+
+    def clock(self):
+        t, it, dt = C.c_double(), C.c_int64(), C.c_double()
+        self._call("gb25_get_clock", C.byref(t), C.byref(it), C.byref(dt))
+        return t.value, it.value, dt.value
+
+    def set_dt(self, dt):
+        self._call("gb25_set_dt", float(dt))
+
+    def set_stream(self, stream_ptr):
+        self._call("gb25_set_stream", C.c_void_p(stream_ptr))
+
+    # ---- phases / composites (one ABI call each)
+    def synchronize(self): self._call("gb25_synchronize")
+    def set_baroclinic_instability(self): self._call("gb25_set_baroclinic_instability")
+    def initialize(self): self._call("gb25_initialize")
+    def mask_immersed_fields(self): self._call("gb25_mask_immersed_fields")
+    def fill_halo_regions(self): self._call("gb25_fill_halo_regions")
+    def fill_halo_regions_local(self): self._call("gb25_fill_halo_regions_local")
+    def compute_auxiliaries(self): self._call("gb25_compute_auxiliaries")
+    def fill_diffusivity_halos(self): self._call("gb25_fill_diffusivity_halos")
+    def compute_momentum_tendencies(self): self._call("gb25_compute_momentum_tendencies")
+    def compute_tracer_tendencies(self): self._call("gb25_compute_tracer_tendencies")
+    def compute_boundary_tendencies(self): self._call("gb25_compute_boundary_tendencies")
+    def compute_tendencies(self): self._call("gb25_compute_tendencies")
+    def ab2_step(self, dt, euler=False): self._call("gb25_ab2_step", float(dt), int(euler))
+    def correct_velocities_and_cache_previous_tendencies(self, dt=0.0):
+        self._call("gb25_correct_velocities_and_cache_previous_tendencies", float(dt))
+    def update_state(self): self._call("gb25_update_state")
+    def update_state_local(self): self._call("gb25_update_state_local")
+    def first_time_step(self): self._call("gb25_first_time_step")
+    def time_step(self): self._call("gb25_time_step")
+    def loop(self, n): self._call("gb25_loop", int(n))
+    def time_step_stage(self, stage, euler=False): self._call("gb25_time_step_stage", int(stage), int(euler))
+
+    # ---- slab exchange
+    def halo_buffer_elems(self, group):
+        n = C.c_int64()
+        self._call("gb25_halo_buffer_elems", int(group), C.byref(n))
+        return n.value
+
+    def halo_pack(self, group, side, dev_ptr): self._call("gb25_halo_pack", group, side, C.c_void_p(dev_ptr))
+    def halo_unpack(self, group, side, dev_ptr): self._call("gb25_halo_unpack", group, side, C.c_void_p(dev_ptr))
+
+    # ---- timers
+    def profile_enable(self, on=True): self._call("gb25_profile_enable", int(on))
+    def profile_reset(self): self._call("gb25_profile_reset")
+
+    def profile_get(self, kernel):
+        n, ms = C.c_int64(), C.c_double()
+        self._call("gb25_profile_get", KERNEL_IDS[kernel], C.byref(n), C.byref(ms))
+        return n.value, ms.value

@@ -1,0 +1,197 @@
+// device_common.hpp -- grid descriptor, indexing, WENO and TEOS-10 device functions (gfx950).
+//
+// Index convention on the device: 0-based interior indices.  Cell i spans faces i (west) and
+// i+1 (east); likewise j (south/north) and k (bottom/top).  Halo cells have negative indices
+// or indices >= N.  Arrays are Oceananigans `parent(field)` layouts: i fastest, then j, then k.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gb25 {
+
+struct Grid {
+  int Nx, Ny, Nz, H;      // LOCAL interior size and halo
+  int sx;                 // row pitch          = Nx + 2H
+  int pl_c, pl_v;         // plane strides      = sx*(Ny+2H), sx*(Ny+2H+1)
+  int sy_c, sy_v;         // parent y extents
+  int x_periodic;         // 1: single slab, x halos are filled by local periodic copy
+  float dy, g, rho0, Lz;
+  // metric tables, pointers are pre-offset so that index 0 is the first interior cell/face
+  const float *dxc, *dxf, *azc, *azf, *fcor, *phic;  // by j   (valid j: -H-2 .. Ny+H+2)
+  const float *zc, *dzc, *dzf;                       // by k   (valid k: -H-2 .. Nz+H+2)
+};
+
+// element offsets
+__device__ __forceinline__ int ic(const Grid& g, int i, int j, int k) {
+  return (i + g.H) + g.sx * (j + g.H) + g.pl_c * (k + g.H);
+}
+__device__ __forceinline__ int iv(const Grid& g, int i, int j, int k) {
+  return (i + g.H) + g.sx * (j + g.H) + g.pl_v * (k + g.H);
+}
+__device__ __forceinline__ int i2(const Grid& g, int i, int j) { return (i + g.H) + g.sx * (j + g.H); }
+
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// ---------------------------------------------------------------------------------------------
+// WENO reconstruction, Oceananigans flavour: uniform coefficients, Z-weights
+// alpha_s = C_s (1 + (tau/(beta_s+eps))^2), eps = 1e-8, integer-scaled smoothness indicators
+// (3x the Jiang-Shu ones), written here in the factored (cancellation-free) form.
+// Arguments run from the most-upwind value `a` to the most-downwind value `e`.
+// ---------------------------------------------------------------------------------------------
+constexpr float kWenoEps = 1e-8f;
+
+__device__ __forceinline__ float beta5_0(float c, float d, float e) {
+  float d1 = c - 2.f * d + e, d2 = 3.f * c - 4.f * d + e;
+  return 3.25f * d1 * d1 + 0.75f * d2 * d2;
+}
+__device__ __forceinline__ float beta5_1(float b, float c, float d) {
+  float d1 = b - 2.f * c + d, d2 = b - d;
+  return 3.25f * d1 * d1 + 0.75f * d2 * d2;
+}
+__device__ __forceinline__ float beta5_2(float a, float b, float c) {
+  float d1 = a - 2.f * b + c, d2 = a - 4.f * b + 3.f * c;
+  return 3.25f * d1 * d1 + 0.75f * d2 * d2;
+}
+// Z-weights alpha_s = C_s (1 + (tau/b_s)^2), b_s = beta_s + eps, evaluated as C_s (1 + (q rho_s)^2) with
+// q = min(tau/b_min, 1e9) and rho_s = b_min/b_s <= 1.  Identical in exact arithmetic; in fp32 the plain form
+// overflows (tau/b ~ 1e18 when one indicator cancels to zero next to area-weighted divergences ~1e8).
+constexpr float kZCap = 1e9f;
+__device__ __forceinline__ float weno5_combine(float a, float b, float c, float d, float e, float b0, float b1,
+                                               float b2) {
+  const float s6 = 1.f / 6.f;
+  float p0 = (2.f * c + 5.f * d - e) * s6;
+  float p1 = (-b + 5.f * c + 2.f * d) * s6;
+  float p2 = (2.f * a - 7.f * b + 11.f * c) * s6;
+  float tau = fabsf(b0 - b2);
+  b0 += kWenoEps;
+  b1 += kWenoEps;
+  b2 += kWenoEps;
+  float bmin = fminf(b0, fminf(b1, b2));
+  float q = fminf(tau * rcp(bmin), kZCap);
+  float r0 = q * (bmin * rcp(b0)), r1 = q * (bmin * rcp(b1)), r2 = q * (bmin * rcp(b2));
+  float a0 = 0.3f * (1.f + r0 * r0), a1 = 0.6f * (1.f + r1 * r1), a2 = 0.1f * (1.f + r2 * r2);
+  return (a0 * p0 + a1 * p1 + a2 * p2) * rcp(a0 + a1 + a2);
+}
+__device__ __forceinline__ float beta3(float x, float y) {
+  float d = x - y;
+  return d * d;
+}
+__device__ __forceinline__ float weno3_combine(float b, float c, float d, float b0, float b1) {
+  float p0 = 0.5f * (c + d);
+  float p1 = 0.5f * (3.f * c - b);
+  float tau = fabsf(b0 - b1);
+  b0 += kWenoEps;
+  b1 += kWenoEps;
+  float bmin = fminf(b0, b1);
+  float q = fminf(tau * rcp(bmin), kZCap);
+  float r0 = q * (bmin * rcp(b0)), r1 = q * (bmin * rcp(b1));
+  float a0 = (2.f / 3.f) * (1.f + r0 * r0), a1 = (1.f / 3.f) * (1.f + r1 * r1);
+  return (a0 * p0 + a1 * p1) * rcp(a0 + a1);
+}
+
+// Self-smoothness WENO5 of upwind-ordered values.
+__device__ __forceinline__ float weno5(float a, float b, float c, float d, float e) {
+  return weno5_combine(a, b, c, d, e, beta5_0(c, d, e), beta5_1(b, c, d), beta5_2(a, b, c));
+}
+
+// Upwind-biased reconstruction from six consecutive values q[0..5] (positions p..p+5).
+// Face target f:   p = f-3.   Centre target c: p = c-2.
+// left: use q[0..4]; right: use q[5..1] mirrored.  order in {5,3,1} (wall-adjacent reduction).
+// s: smoothness inputs (FunctionStencil) or nullptr-equivalent (pass q); t: second smoothness
+// set (VelocityStencil) averaged with s when TWO is true.
+template <bool TWO>
+__device__ __forceinline__ float biased6(int order, bool left, const float* q, const float* s, const float* t) {
+  float c = left ? q[2] : q[3];
+  if (order == 1) return c;
+  float b = left ? q[1] : q[4], d = left ? q[3] : q[2];
+  float sb = left ? s[1] : s[4], sc = left ? s[2] : s[3], sd = left ? s[3] : s[2];
+  float tb = 0, tc = 0, td = 0;
+  if (TWO) {
+    tb = left ? t[1] : t[4];
+    tc = left ? t[2] : t[3];
+    td = left ? t[3] : t[2];
+  }
+  if (order == 3) {
+    float b0 = beta3(sc, sd), b1 = beta3(sb, sc);
+    if (TWO) {
+      b0 = 0.5f * (b0 + beta3(tc, td));
+      b1 = 0.5f * (b1 + beta3(tb, tc));
+    }
+    return weno3_combine(b, c, d, b0, b1);
+  }
+  float a = left ? q[0] : q[5], e = left ? q[4] : q[1];
+  float sa = left ? s[0] : s[5], se = left ? s[4] : s[1];
+  float b0 = beta5_0(sc, sd, se), b1 = beta5_1(sb, sc, sd), b2 = beta5_2(sa, sb, sc);
+  if (TWO) {
+    float ta = left ? t[0] : t[5], te = left ? t[4] : t[1];
+    b0 = 0.5f * (b0 + beta5_0(tc, td, te));
+    b1 = 0.5f * (b1 + beta5_1(tb, tc, td));
+    b2 = 0.5f * (b2 + beta5_2(ta, tb, tc));
+  }
+  return weno5_combine(a, b, c, d, e, b0, b1, b2);
+}
+
+// wall-adjacent order reduction in a bounded direction of extent N (0-based target index)
+__device__ __forceinline__ int biased_order_face(int f, int N) {
+  return (f >= 3 && f <= N - 3) ? 5 : ((f >= 2 && f <= N - 2) ? 3 : 1);
+}
+__device__ __forceinline__ int biased_order_center(int c, int N) {
+  return (c >= 2 && c <= N - 3) ? 5 : ((c >= 1 && c <= N - 2) ? 3 : 1);
+}
+__device__ __forceinline__ bool sym4_face(int f, int N) { return f >= 3 && f <= N - 3; }
+__device__ __forceinline__ bool sym4_center(int c, int N) { return c >= 2 && c <= N - 3; }
+// centred interpolation from four consecutive values (target sits between q1 and q2)
+__device__ __forceinline__ float sym_interp(bool fourth, float q0, float q1, float q2, float q3) {
+  return fourth ? (7.f * (q1 + q2) - (q0 + q3)) * (1.f / 12.f) : 0.5f * (q1 + q2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// TEOS-10 55-term polynomial (Roquet et al. 2015) as used by SeawaterPolynomials'
+// TEOS10EquationOfState: rho(Theta, S_A, Z) = r0(zeta) + r'(tau, s, zeta).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float teos10_rho(float Theta, float Sa, float Z) {
+  const float t = Theta * 0.025f;
+  const float s = __builtin_sqrtf((Sa + 32.f) * (float)(0.875 / 35.16504));
+  const float z = -Z * 1e-4f;
+  const float R000 = 8.0189615746e+02f, R100 = 8.6672408165e+02f, R200 = -1.7864682637e+03f,
+              R300 = 2.0375295546e+03f, R400 = -1.2849161071e+03f, R500 = 4.3227585684e+02f,
+              R600 = -6.0579916612e+01f, R010 = 2.6010145068e+01f, R110 = -6.5281885265e+01f,
+              R210 = 8.1770425108e+01f, R310 = -5.6888046321e+01f, R410 = 1.7681814114e+01f,
+              R510 = -1.9193502195e+00f, R020 = -3.7074170417e+01f, R120 = 6.1548258127e+01f,
+              R220 = -6.0362551501e+01f, R320 = 2.9130021253e+01f, R420 = -5.4723692739e+00f,
+              R030 = 2.1661789529e+01f, R130 = -3.3449108469e+01f, R230 = 1.9717078466e+01f,
+              R330 = -3.1742946532e+00f, R040 = -8.3627885467e+00f, R140 = 1.1311538584e+01f,
+              R240 = -5.3563304045e+00f, R050 = 5.4048723791e-01f, R150 = 4.8169980163e-01f,
+              R060 = -1.9083568888e-01f, R001 = 1.9681925209e+01f, R101 = -4.2549998214e+01f,
+              R201 = 5.0774768218e+01f, R301 = -3.0938076334e+01f, R401 = 6.6051753097e+00f,
+              R011 = -1.3336301113e+01f, R111 = -4.4870114575e+00f, R211 = 5.0042598061e+00f,
+              R311 = -6.5399043664e-01f, R021 = 6.7080479603e+00f, R121 = 3.5063081279e+00f,
+              R221 = -1.8795372996e+00f, R031 = -2.4649669534e+00f, R131 = -5.5077101279e-01f,
+              R041 = 5.5927935970e-01f, R002 = 2.0660924175e+00f, R102 = -4.9527603989e+00f,
+              R202 = 2.5019633244e+00f, R012 = 2.0564311499e+00f, R112 = -2.1311365518e-01f,
+              R022 = -1.2419983026e+00f, R003 = -2.3342758797e-02f, R103 = -1.8507636718e-02f,
+              R013 = 3.7969820455e-01f;
+  const float R00 = 4.6494977072e+01f, R01 = -5.2099962525e+00f, R02 = 2.2601900708e-01f,
+              R03 = 6.4326772569e-02f, R04 = 1.5616995503e-02f, R05 = -1.7243708991e-03f;
+  float r3 = R013 * t + R103 * s + R003;
+  float r2 = (R022 * t + R112 * s + R012) * t + (R202 * s + R102) * s + R002;
+  float r1 = (((R041 * t + R131 * s + R031) * t + (R221 * s + R121) * s + R021) * t +
+              ((R311 * s + R211) * s + R111) * s + R011) * t +
+             (((R401 * s + R301) * s + R201) * s + R101) * s + R001;
+  float r0 = (((((R060 * t + R150 * s + R050) * t + (R240 * s + R140) * s + R040) * t +
+                ((R330 * s + R230) * s + R130) * s + R030) * t +
+               (((R420 * s + R320) * s + R220) * s + R120) * s + R020) * t +
+              ((((R510 * s + R410) * s + R310) * s + R210) * s + R110) * s + R010) * t +
+             (((((R600 * s + R500) * s + R400) * s + R300) * s + R200) * s + R100) * s + R000;
+  float rp = ((r3 * z + r2) * z + r1) * z + r0;
+  float rz = (((((R05 * z + R04) * z + R03) * z + R02) * z + R01) * z + R00) * z;
+  return rz + rp;
+}
+
+// XCD-aware remap of a linear block id: blocks b and b+8 share an XCD (round-robin dispatch),
+// so give each XCD one contiguous chunk of the logical tile sequence (bijective for any n).
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  int q = n >> 3, r = n & 7, x = b & 7, s = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+
+}  // namespace gb25

@@ -1,0 +1,788 @@
+// gb25_api.hip -- host side of libgb25hip.so: the C ABI declared in include/gb25.h.
+//
+// Owns the device state of one model (one x-slab on one GPU), builds the grid metrics,
+// sequences the kernels of kernels.hpp in the reference's phase order
+// (GB-25 src/precompile.jl:31-42) and exposes the per-phase entry points.
+// There is no CPU fallback: without a HIP device gb25_create fails with GB25_ERR_NO_DEVICE.
+#include "../../include/gb25.h"
+#include "kernels.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace gb25;
+
+namespace {
+
+constexpr int PAD = 2;  // metric tables extend 2 entries beyond the halo
+
+struct Field {
+  float* d = nullptr;
+  int nx = 0, ny = 0, nz = 0;  // parent dims
+  size_t elems() const { return (size_t)nx * ny * nz; }
+};
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct gb25_model {
+  gb25_config cfg;
+  int Nx = 0;  // local slab width
+  Grid g;
+  Field f[GB25_FIELD_COUNT];
+  Field pp[3];                   // ping-pong partners of eta, U, V
+  float* bars = nullptr;         // contiguous etabar | Ubar | Vbar
+  std::vector<float*> dev_tables;
+  std::vector<double> h_metric[11];
+  int metric_off_j = 0, metric_off_k = 0;
+  // substepping
+  int Ns = 0;
+  double dtau_frac = 0;
+  std::vector<double> weights;
+  // wide-halo barotropic work arrays (slab mode)
+  int W = 0;
+  Field wide[2][3];  // [pingpong][eta,U,V]
+  Field wideG[2];    // GU, GV
+  Field wideBar[3];  // running averages on the wide domain
+  // clock
+  double time = 0, last_dt = 0;
+  int64_t iteration = 0;
+  // streams / timing
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  bool profile = false;
+  std::vector<EventPair> pending[GB25_K_COUNT];
+  std::vector<EventPair> free_events;
+  int64_t prof_count[GB25_K_COUNT] = {0};
+  double prof_ms[GB25_K_COUNT] = {0};
+  std::string err;
+};
+
+namespace {
+
+gb25_status fail(gb25_model* m, gb25_status s, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (m) m->err = buf;
+  return s;
+}
+
+#define HIPCHK(call)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (call);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return fail(m, GB25_ERR_HIP, "%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+  } while (0)
+#define CHECK_MODEL(m) \
+  if (!(m)) return GB25_ERR_INVALID_ARGUMENT
+#define LAUNCHCHK() HIPCHK(hipGetLastError())
+
+bool is_v_shaped(int id) {
+  return id == GB25_V || id == GB25_GN_V || id == GB25_GM_V || id == GB25_BT_V || id == GB25_V_BAR ||
+         id == GB25_GN_BT_V;
+}
+bool is_2d(int id) { return id >= GB25_ETA; }
+
+// --- profiling helpers -----------------------------------------------------------------------
+struct Timed {
+  gb25_model* m;
+  int k;
+  EventPair ev;
+  bool on;
+  Timed(gb25_model* m_, int k_) : m(m_), k(k_), on(m_->profile) {
+    if (!on) return;
+    if (!m->free_events.empty()) {
+      ev = m->free_events.back();
+      m->free_events.pop_back();
+    } else {
+      hipEventCreate(&ev.a);
+      hipEventCreate(&ev.b);
+    }
+    hipEventRecord(ev.a, m->stream);
+  }
+  ~Timed() {
+    if (!on) return;
+    hipEventRecord(ev.b, m->stream);
+    m->pending[k].push_back(ev);
+  }
+};
+
+void resolve_profile(gb25_model* m) {
+  for (int k = 0; k < GB25_K_COUNT; k++) {
+    for (auto& ev : m->pending[k]) {
+      hipEventSynchronize(ev.b);
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+        m->prof_ms[k] += ms;
+        m->prof_count[k] += 1;
+      }
+      m->free_events.push_back(ev);
+    }
+    m->pending[k].clear();
+  }
+}
+
+// --- grid ------------------------------------------------------------------------------------
+// simple_latitude_longitude_grid (GB-25 src/model_utils.jl:56-65): regular lat-lon spacing,
+// exponential_z_faces(Nz, depth, h) vertical faces, spherical-shell metrics.
+gb25_status upload_table(gb25_model* m, const std::vector<double>& h, int off, const float** out) {
+  std::vector<float> f(h.size());
+  for (size_t a = 0; a < h.size(); a++) f[a] = (float)h[a];
+  float* d = nullptr;
+  HIPCHK(hipMalloc(&d, f.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(d, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+  m->dev_tables.push_back(d);
+  *out = d + off;
+  return GB25_OK;
+}
+
+gb25_status build_grid(gb25_model* m) {
+  const gb25_config& c = m->cfg;
+  const int H = c.halo, Ny = c.Ny, Nz = c.Nz;
+  const int nj = Ny + 2 * H + 2 * PAD + 2, nk = Nz + 2 * H + 2 * PAD + 2;
+  const int offj = H + PAD, offk = H + PAD;  // table index of 0-based logical index 0
+  m->metric_off_j = offj;
+  m->metric_off_k = offk;
+  const double d2r = M_PI / 180.0;
+  const double dlam = (c.lon_east - c.lon_west) / c.Nx, dphi = (c.lat_north - c.lat_south) / Ny, R = c.radius;
+  std::vector<double>&phif = m->h_metric[GB25_M_PHIF], &phic = m->h_metric[GB25_M_PHIC],
+  &dxc = m->h_metric[GB25_M_DXC], &dxf = m->h_metric[GB25_M_DXF], &azc = m->h_metric[GB25_M_AZC],
+  &azf = m->h_metric[GB25_M_AZF], &fcor = m->h_metric[GB25_M_FCOR];
+  phif.assign(nj, 0); phic.assign(nj, 0); dxc.assign(nj, 0); dxf.assign(nj, 0);
+  azc.assign(nj, 0); azf.assign(nj, 0); fcor.assign(nj, 0);
+  for (int a = 0; a < nj; a++) {
+    int j = a - offj;  // 0-based face / centre index
+    phif[a] = c.lat_south + j * dphi;
+    phic[a] = c.lat_south + (j + 0.5) * dphi;
+  }
+  for (int a = 0; a < nj; a++) {
+    dxc[a] = R * std::cos(phic[a] * d2r) * dlam * d2r;
+    dxf[a] = R * std::cos(phif[a] * d2r) * dlam * d2r;
+    fcor[a] = 2.0 * c.Omega * std::sin(phif[a] * d2r);
+    if (a + 1 < nj) azc[a] = R * R * dlam * d2r * (std::sin(phif[a + 1] * d2r) - std::sin(phif[a] * d2r));
+    if (a > 0) azf[a] = R * R * dlam * d2r * (std::sin(phic[a] * d2r) - std::sin(phic[a - 1] * d2r));
+  }
+  // vertical faces: z_k ~ exp(k/h), k = 1..Nz+1, mapped to [0, -depth] and reversed
+  std::vector<double> zint(Nz + 1);
+  const double h = c.zexp_h, e1 = std::exp(1.0 / h), eN = std::exp((Nz + 1.0) / h);
+  for (int k = 1; k <= Nz + 1; k++) zint[Nz + 1 - k] = -c.depth * (std::exp(k / h) - e1) / (eN - e1);
+  zint[Nz] = 0.0;
+  std::vector<double>&zf = m->h_metric[GB25_M_ZF], &zc = m->h_metric[GB25_M_ZC], &dzc = m->h_metric[GB25_M_DZC],
+  &dzf = m->h_metric[GB25_M_DZF];
+  zf.assign(nk + 1, 0); zc.assign(nk, 0); dzc.assign(nk, 0); dzf.assign(nk, 0);
+  const double dlo = zint[1] - zint[0], dhi = zint[Nz] - zint[Nz - 1];
+  for (int a = 0; a <= nk; a++) {
+    int k = a - offk;  // 0-based face index
+    zf[a] = k < 0 ? zint[0] + k * dlo : (k > Nz ? zint[Nz] + (k - Nz) * dhi : zint[k]);
+  }
+  for (int a = 0; a < nk; a++) zc[a] = 0.5 * (zf[a] + zf[a + 1]);
+  for (int a = 0; a < nk; a++) {
+    dzc[a] = zf[a + 1] - zf[a];
+    dzf[a] = a > 0 ? zc[a] - zc[a - 1] : zc[1] - zc[0];
+  }
+  Grid& g = m->g;
+  g.Nx = m->Nx; g.Ny = Ny; g.Nz = Nz; g.H = H;
+  g.sx = m->Nx + 2 * H;
+  g.sy_c = Ny + 2 * H; g.sy_v = Ny + 2 * H + 1;
+  g.pl_c = g.sx * g.sy_c; g.pl_v = g.sx * g.sy_v;
+  g.x_periodic = (c.nranks == 1);
+  g.dy = (float)(R * dphi * d2r);
+  g.g = (float)c.g; g.rho0 = (float)c.rho0; g.Lz = (float)(zint[Nz] - zint[0]);
+  gb25_status s;
+  if ((s = upload_table(m, dxc, offj, &g.dxc))) return s;
+  if ((s = upload_table(m, dxf, offj, &g.dxf))) return s;
+  if ((s = upload_table(m, azc, offj, &g.azc))) return s;
+  if ((s = upload_table(m, azf, offj, &g.azf))) return s;
+  if ((s = upload_table(m, fcor, offj, &g.fcor))) return s;
+  if ((s = upload_table(m, phic, offj, &g.phic))) return s;
+  if ((s = upload_table(m, zc, offk, &g.zc))) return s;
+  if ((s = upload_table(m, dzc, offk, &g.dzc))) return s;
+  if ((s = upload_table(m, dzf, offk, &g.dzf))) return s;
+  return GB25_OK;
+}
+
+// Split-explicit averaging weights (Oceananigans FixedSubstepNumber, restated): shape function
+// (p=2, q=4, r=0.18927) sampled at tau = 2m/Ns, truncated like searchsortedlast(w, 0, rev=true).
+void build_substeps(gb25_model* m) {
+  const int N = m->cfg.substeps;
+  std::vector<double> w(N + 1, 0.0);
+  const double p = 2, q = 4, r = 0.18927, tau0 = (p + 2) * (p + q + 2) / (p + 1) / (p + q + 1);
+  for (int k = 1; k <= N; k++) {
+    double x = (2.0 * k / N) / tau0;
+    w[k] = std::pow(x, p) * (1 - std::pow(x, q)) - r * x;
+  }
+  int lo = 0, hi = N + 1;
+  while (lo < hi - 1) {
+    int mid = lo + ((hi - lo) >> 1);
+    if (w[mid] < 0.0) hi = mid; else lo = mid;
+  }
+  double s = 0;
+  for (int k = 1; k <= lo; k++) s += w[k];
+  m->Ns = lo;
+  m->dtau_frac = 2.0 / N;
+  m->weights.resize(lo);
+  for (int k = 1; k <= lo; k++) m->weights[k - 1] = w[k] / s;
+}
+
+gb25_status alloc_field(gb25_model* m, Field& F, int nx, int ny, int nz) {
+  F.nx = nx; F.ny = ny; F.nz = nz;
+  hipError_t e = hipMalloc(&F.d, F.elems() * sizeof(float));
+  if (e != hipSuccess)
+    return fail(m, GB25_ERR_OUT_OF_MEMORY, "hipMalloc of %zu bytes failed: %s", F.elems() * sizeof(float),
+                hipGetErrorString(e));
+  HIPCHK(hipMemset(F.d, 0, F.elems() * sizeof(float)));
+  return GB25_OK;
+}
+
+inline dim3 grid2(int nx, int ny, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y); }
+
+Halo3 halo3(gb25_model* m) {
+  Halo3 h;
+  h.p[0] = m->f[GB25_U].d; h.p[1] = m->f[GB25_V].d; h.p[2] = m->f[GB25_T].d; h.p[3] = m->f[GB25_S].d;
+  return h;
+}
+Halo2 halo2_prognostic(gb25_model* m) {
+  Halo2 h;
+  h.p[0] = m->f[GB25_ETA].d; h.is_v[0] = 0;
+  h.p[1] = m->f[GB25_BT_U].d; h.is_v[1] = 0;
+  h.p[2] = m->f[GB25_BT_V].d; h.is_v[2] = 1;
+  h.n = 3;
+  return h;
+}
+
+// y/z boundary layers (always local) and, for a single slab, the periodic x copy.
+gb25_status fill_halos_impl(gb25_model* m, bool with_x) {
+  const Grid& g = m->g;
+  Timed t(m, GB25_K_FILL_HALOS);
+  Halo3 h3 = halo3(m);
+  Halo2 h2 = halo2_prognostic(m);
+  dim3 b(256);
+  hipLaunchKernelGGL(k_fill_y, dim3((g.Nx + 255) / 256, g.Nz + 1), b, 0, m->stream, g, h3, h2);
+  hipLaunchKernelGGL(k_fill_z, dim3((g.Nx + 255) / 256, g.Ny), b, 0, m->stream, g, h3);
+  if (with_x && g.x_periodic) {
+    int rows_c = g.sy_c * (g.Nz + 2 * g.H), rows_v = g.sy_v * (g.Nz + 2 * g.H);
+    long threads = (long)rows_v * 2 * g.H;
+    hipLaunchKernelGGL(k_fill_x, dim3((unsigned)((threads + 255) / 256), 4 + h2.n), b, 0, m->stream, g, h3, h2, rows_c,
+                       rows_v);
+  }
+  LAUNCHCHK();
+  return GB25_OK;
+}
+
+gb25_status fill_halos_2d(gb25_model* m, Halo2 h2) {
+  const Grid& g = m->g;
+  Halo3 none{};
+  dim3 b(256);
+  // Nz = 0 makes k_fill_y take its 2-D branch for blockIdx.y == 0; k_fill_x's 3-D slices
+  // (blockIdx.y < 4) see zero rows and fall through.
+  Grid g2 = g;
+  g2.Nz = 0;
+  hipLaunchKernelGGL(k_fill_y, dim3((g.Nx + 255) / 256, 1), b, 0, m->stream, g2, none, h2);
+  if (g.x_periodic) {
+    long threads = (long)g.sy_v * 2 * g.H;
+    hipLaunchKernelGGL(k_fill_x, dim3((unsigned)((threads + 255) / 256), 4 + h2.n), b, 0, m->stream, g2, none, h2, 0,
+                       0);
+  }
+  LAUNCHCHK();
+  return GB25_OK;
+}
+
+gb25_status compute_w_impl(gb25_model* m) {
+  const Grid& g = m->g;
+  Timed t(m, GB25_K_COMPUTE_W);
+  dim3 b(64, 4);
+  int ex = g.Nx + 2 * g.H - 2, ey = g.Ny + 2 * g.H - 2;
+  hipLaunchKernelGGL(k_compute_w, grid2(ex, ey, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                     m->f[GB25_W].d);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+gb25_status compute_p_impl(gb25_model* m) {
+  const Grid& g = m->g;
+  Timed t(m, GB25_K_COMPUTE_P);
+  dim3 b(64, 4);
+  int ex = g.Nx + 2 * g.H - 2, ey = g.Ny + 2 * g.H - 2;
+  hipLaunchKernelGGL(k_compute_p, grid2(ex, ey, b), b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d,
+                     m->f[GB25_PHY].d);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+
+void tile_grid(const Grid& g, int* nbx, int* nb) {
+  *nbx = (g.Nx + TX - 1) / TX;
+  int nby = (g.Ny + TY - 1) / TY;
+  *nb = *nbx * nby * g.Nz;
+}
+
+gb25_status momentum_impl(gb25_model* m) {
+  const Grid& g = m->g;
+  int nbx, nb;
+  tile_grid(g, &nbx, &nb);
+  dim3 b(TX, TY);
+  {
+    Timed t(m, GB25_K_GU);
+    hipLaunchKernelGGL(k_gu, dim3(nb), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_W].d,
+                       m->f[GB25_PHY].d, m->f[GB25_GN_U].d, nbx, nb);
+  }
+  {
+    Timed t(m, GB25_K_GV);
+    hipLaunchKernelGGL(k_gv, dim3(nb), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_W].d,
+                       m->f[GB25_PHY].d, m->f[GB25_GN_V].d, nbx, nb);
+  }
+  LAUNCHCHK();
+  return GB25_OK;
+}
+gb25_status tracers_impl(gb25_model* m) {
+  const Grid& g = m->g;
+  int nbx, nb;
+  tile_grid(g, &nbx, &nb);
+  Timed t(m, GB25_K_TRACERS);
+  hipLaunchKernelGGL(k_tracer_tendencies, dim3(nb), dim3(TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                     m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d, m->f[GB25_GN_S].d, nbx, nb);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+
+gb25_status ab2_local_impl(gb25_model* m, float dt, float chi) {
+  const Grid& g = m->g;
+  dim3 b(64, 4);
+  {
+    Timed t(m, GB25_K_AB2_VELOCITIES);
+    hipLaunchKernelGGL(k_ab2_velocities, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                       m->f[GB25_GN_U].d, m->f[GB25_GM_U].d, m->f[GB25_GN_V].d, m->f[GB25_GM_V].d,
+                       m->f[GB25_GN_BT_U].d, m->f[GB25_GN_BT_V].d, dt, chi);
+  }
+  {
+    Timed t(m, GB25_K_AB2_TRACERS);
+    const float C1 = 1.5f + chi, C2 = 0.5f + chi;
+    size_t off = (size_t)g.H * g.pl_c;
+    long n = (long)g.Nz * g.pl_c;
+    float *T = m->f[GB25_T].d + off, *S = m->f[GB25_S].d + off;
+    const float *a = m->f[GB25_GN_T].d + off, *bb = m->f[GB25_GM_T].d + off, *c = m->f[GB25_GN_S].d + off,
+                *d = m->f[GB25_GM_S].d + off;
+    bool aligned = (n % 4 == 0) && (((uintptr_t)T | (uintptr_t)S | (uintptr_t)a | (uintptr_t)bb | (uintptr_t)c |
+                                     (uintptr_t)d) % 16 == 0);
+    if (aligned) {
+      long n4 = n / 4;
+      int blocks = (int)std::min<long>((n4 + 255) / 256, 256 * 16);
+      hipLaunchKernelGGL(k_ab2_tracers4, dim3(blocks), dim3(256), 0, m->stream, (float4*)T, (float4*)S,
+                         (const float4*)a, (const float4*)bb, (const float4*)c, (const float4*)d, n4, dt, C1, C2);
+    } else {
+      int blocks = (int)std::min<long>((n + 255) / 256, 256 * 16);
+      hipLaunchKernelGGL(k_ab2_tracers1, dim3(blocks), dim3(256), 0, m->stream, T, S, a, bb, c, d, n, dt, C1, C2);
+    }
+  }
+  LAUNCHCHK();
+  return GB25_OK;
+}
+
+// step_free_surface! on a single slab with periodic x handled in-kernel
+gb25_status barotropic_impl(gb25_model* m, float dt) {
+  const Grid& g = m->g;
+  Timed t(m, GB25_K_BAROTROPIC);
+  size_t nbar = m->f[GB25_ETA_BAR].elems() + m->f[GB25_U_BAR].elems() + m->f[GB25_V_BAR].elems();
+  HIPCHK(hipMemsetAsync(m->bars, 0, nbar * sizeof(float), m->stream));
+  const float dtau = (float)m->dtau_frac * dt;
+  dim3 b(64, 4);
+  dim3 gr = grid2(g.Nx, g.Ny, b);
+  float* cur[3] = {m->f[GB25_ETA].d, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d};
+  float* nxt[3] = {m->pp[0].d, m->pp[1].d, m->pp[2].d};
+  for (int s = 0; s < m->Ns; s++) {
+    Baro bb;
+    bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
+    bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
+    bb.etab = m->f[GB25_ETA_BAR].d; bb.Ub = m->f[GB25_U_BAR].d; bb.Vb = m->f[GB25_V_BAR].d;
+    bb.GU = m->f[GB25_GN_BT_U].d; bb.GV = m->f[GB25_GN_BT_V].d;
+    hipLaunchKernelGGL(k_barotropic_substep, gr, b, 0, m->stream, g, bb, dtau, (float)m->weights[s]);
+    for (int q = 0; q < 3; q++) std::swap(cur[q], nxt[q]);
+  }
+  hipLaunchKernelGGL(k_barotropic_finalize, gr, b, 0, m->stream, g, m->f[GB25_ETA].d, m->f[GB25_BT_U].d,
+                     m->f[GB25_BT_V].d, m->f[GB25_ETA_BAR].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+
+gb25_status corrector_impl(gb25_model* m) {
+  const Grid& g = m->g;
+  {
+    Timed t(m, GB25_K_CORRECTOR);
+    dim3 b(64, 4);
+    hipLaunchKernelGGL(k_corrector, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                       m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d);
+    LAUNCHCHK();
+  }
+  // cache_previous_tendencies!: G^- <- G^n is a pointer exchange; the next tendency evaluation
+  // overwrites the (old G^-) buffers that now carry the G^n name.
+  for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);
+  return GB25_OK;
+}
+
+gb25_status update_state_impl(gb25_model* m) {
+  gb25_status s;
+  if ((s = fill_halos_impl(m, true))) return s;
+  if ((s = compute_w_impl(m))) return s;
+  if ((s = compute_p_impl(m))) return s;
+  if ((s = momentum_impl(m))) return s;
+  return tracers_impl(m);
+}
+
+gb25_status ab2_step_impl(gb25_model* m, double dt, int euler) {
+  gb25_status s;
+  const float chi = euler ? -0.5f : (float)m->cfg.chi;
+  if ((s = ab2_local_impl(m, (float)dt, chi))) return s;
+  Halo2 hG;
+  hG.p[0] = m->f[GB25_GN_BT_U].d; hG.is_v[0] = 0;
+  hG.p[1] = m->f[GB25_GN_BT_V].d; hG.is_v[1] = 1;
+  hG.p[2] = nullptr; hG.is_v[2] = 0;
+  hG.n = 2;
+  if ((s = fill_halos_2d(m, hG))) return s;
+  return barotropic_impl(m, (float)dt);
+}
+
+gb25_status time_step_impl(gb25_model* m, int euler) {
+  if (m->cfg.nranks != 1)
+    return fail(m, GB25_ERR_STATE, "gb25_time_step on a slab of a %d-rank decomposition: drive gb25_time_step_stage",
+                m->cfg.nranks);
+  gb25_status s;
+  const double dt = m->last_dt;
+  if ((s = ab2_step_impl(m, dt, euler))) return s;
+  m->time += dt;
+  m->iteration += 1;
+  if ((s = fill_halos_impl(m, true))) return s;
+  if ((s = corrector_impl(m))) return s;
+  return update_state_impl(m);
+}
+
+gb25_status initialize_impl(gb25_model* m) {
+  const Grid& g = m->g;
+  dim3 b(64, 4);
+  hipLaunchKernelGGL(k_barotropic_mode, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                     m->f[GB25_BT_U].d, m->f[GB25_BT_V].d);
+  LAUNCHCHK();
+  return fill_halos_2d(m, halo2_prognostic(m));
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* gb25_version(void) { return "gb25hip 0.1 (gfx950)"; }
+
+void gb25_default_config(gb25_config* c, int32_t Nx, int32_t Ny, int32_t Nz) {
+  memset(c, 0, sizeof *c);
+  c->Nx = Nx; c->Ny = Ny; c->Nz = Nz;
+  c->halo = 8; c->substeps = 30; c->rank = 0; c->nranks = 1; c->device = 0;
+  c->dt = 60.0; c->chi = 0.1;
+  c->lat_south = -80; c->lat_north = 80; c->lon_west = 0; c->lon_east = 360;
+  c->depth = 4000; c->zexp_h = 30;
+  c->g = 9.80665; c->Omega = 7.292115e-5; c->radius = 6371e3; c->rho0 = 1020.0;
+}
+
+gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
+  if (!cfg || !out) return GB25_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  gb25_model* m = new gb25_model();
+  *out = m;  // returned even on failure so the caller can read the error string, then destroy
+  m->cfg = *cfg;
+  if (cfg->Nx < 8 || cfg->Ny < 8 || cfg->Nz < 4 || cfg->halo < 4 || cfg->substeps < 1 || cfg->substeps > 4096 ||
+      cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks || cfg->Nx % cfg->nranks != 0)
+    return fail(m, GB25_ERR_INVALID_ARGUMENT,
+                "invalid configuration: need Nx,Ny >= 8, Nz >= 4, halo >= 4, 1 <= substeps <= 4096, Nx %% nranks == 0");
+  m->Nx = cfg->Nx / cfg->nranks;
+  if (m->Nx < cfg->halo) return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab narrower than the halo");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(m, GB25_ERR_NO_DEVICE, "no HIP device visible; libgb25hip has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(m, GB25_ERR_INVALID_ARGUMENT, "device ordinal %d out of range (%d devices)", cfg->device, ndev);
+  HIPCHK(hipSetDevice(cfg->device));
+  HIPCHK(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+  m->stream = m->own_stream;
+  m->last_dt = cfg->dt;
+  gb25_status s;
+  if ((s = build_grid(m))) return s;
+  build_substeps(m);
+  const int H = cfg->halo, sx = m->Nx + 2 * H;
+  for (int id = 0; id < GB25_FIELD_COUNT; id++) {
+    if (id >= GB25_ETA_BAR && id <= GB25_V_BAR) continue;  // allocated contiguously below
+    int ny = cfg->Ny + 2 * H + (is_v_shaped(id) ? 1 : 0);
+    int nz = is_2d(id) ? 1 : cfg->Nz + 2 * H + (id == GB25_W ? 1 : 0);
+    if ((s = alloc_field(m, m->f[id], sx, ny, nz))) return s;
+  }
+  {
+    size_t nc = (size_t)sx * (cfg->Ny + 2 * H), nv = (size_t)sx * (cfg->Ny + 2 * H + 1);
+    HIPCHK(hipMalloc(&m->bars, (2 * nc + nv) * sizeof(float)));
+    HIPCHK(hipMemset(m->bars, 0, (2 * nc + nv) * sizeof(float)));
+    Field& e = m->f[GB25_ETA_BAR]; e.d = m->bars; e.nx = sx; e.ny = cfg->Ny + 2 * H; e.nz = 1;
+    Field& u = m->f[GB25_U_BAR]; u.d = m->bars + nc; u.nx = sx; u.ny = cfg->Ny + 2 * H; u.nz = 1;
+    Field& v = m->f[GB25_V_BAR]; v.d = m->bars + 2 * nc; v.nx = sx; v.ny = cfg->Ny + 2 * H + 1; v.nz = 1;
+  }
+  for (int q = 0; q < 3; q++)
+    if ((s = alloc_field(m, m->pp[q], sx, m->f[GB25_ETA + q].ny, 1))) return s;
+  HIPCHK(hipDeviceSynchronize());
+  return GB25_OK;
+}
+
+void gb25_destroy(gb25_model* m) {
+  if (!m) return;
+  if (m->own_stream) hipStreamSynchronize(m->own_stream);
+  for (int id = 0; id < GB25_FIELD_COUNT; id++)
+    if (!(id >= GB25_ETA_BAR && id <= GB25_V_BAR) && m->f[id].d) hipFree(m->f[id].d);
+  if (m->bars) hipFree(m->bars);
+  for (auto& p : m->pp)
+    if (p.d) hipFree(p.d);
+  for (int a = 0; a < 2; a++) {
+    for (auto& w : m->wide[a])
+      if (w.d) hipFree(w.d);
+    if (m->wideG[a].d) hipFree(m->wideG[a].d);
+  }
+  for (auto& w : m->wideBar)
+    if (w.d) hipFree(w.d);
+  for (float* t : m->dev_tables) hipFree(t);
+  resolve_profile(m);
+  for (auto& ev : m->free_events) {
+    hipEventDestroy(ev.a);
+    hipEventDestroy(ev.b);
+  }
+  if (m->own_stream) hipStreamDestroy(m->own_stream);
+  delete m;
+}
+
+const char* gb25_last_error_string(const gb25_model* m) { return m ? m->err.c_str() : "null model"; }
+
+gb25_status gb25_set_stream(gb25_model* m, void* s) {
+  CHECK_MODEL(m);
+  m->stream = s ? (hipStream_t)s : m->own_stream;
+  return GB25_OK;
+}
+gb25_status gb25_synchronize(gb25_model* m) {
+  CHECK_MODEL(m);
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return GB25_OK;
+}
+
+gb25_status gb25_field_dims(const gb25_model* m, gb25_field id, int include_halos, int32_t d[3]) {
+  if (!m || id < 0 || id >= GB25_FIELD_COUNT || !d) return GB25_ERR_INVALID_ARGUMENT;
+  const Field& F = m->f[id];
+  const int H = m->cfg.halo;
+  if (include_halos) {
+    d[0] = F.nx; d[1] = F.ny; d[2] = F.nz;
+  } else {
+    d[0] = F.nx - 2 * H; d[1] = F.ny - 2 * H; d[2] = is_2d(id) ? 1 : F.nz - 2 * H;
+  }
+  return GB25_OK;
+}
+
+static gb25_status copy_field(gb25_model* m, gb25_field id, float* host, int include_halos, bool to_device) {
+  if (!m || id < 0 || id >= GB25_FIELD_COUNT || !host) return GB25_ERR_INVALID_ARGUMENT;
+  Field& F = m->f[id];
+  HIPCHK(hipStreamSynchronize(m->stream));
+  if (include_halos) {
+    if (to_device) HIPCHK(hipMemcpy(F.d, host, F.elems() * sizeof(float), hipMemcpyHostToDevice));
+    else HIPCHK(hipMemcpy(host, F.d, F.elems() * sizeof(float), hipMemcpyDeviceToHost));
+    return GB25_OK;
+  }
+  const int H = m->cfg.halo;
+  int32_t d[3];
+  gb25_field_dims(m, id, 0, d);
+  hipMemcpy3DParms p = {};
+  hipPitchedPtr dev = make_hipPitchedPtr(F.d, (size_t)F.nx * sizeof(float), F.nx, F.ny);
+  hipPitchedPtr hst = make_hipPitchedPtr(host, (size_t)d[0] * sizeof(float), d[0], d[1]);
+  hipPos dpos = make_hipPos((size_t)H * sizeof(float), H, is_2d(id) ? 0 : H), zero = make_hipPos(0, 0, 0);
+  p.extent = make_hipExtent((size_t)d[0] * sizeof(float), d[1], d[2]);
+  if (to_device) {
+    p.srcPtr = hst; p.srcPos = zero; p.dstPtr = dev; p.dstPos = dpos; p.kind = hipMemcpyHostToDevice;
+  } else {
+    p.srcPtr = dev; p.srcPos = dpos; p.dstPtr = hst; p.dstPos = zero; p.kind = hipMemcpyDeviceToHost;
+  }
+  HIPCHK(hipMemcpy3D(&p));
+  return GB25_OK;
+}
+gb25_status gb25_set_field(gb25_model* m, gb25_field f, const float* host, int include_halos) {
+  return copy_field(m, f, const_cast<float*>(host), include_halos, true);
+}
+gb25_status gb25_get_field(gb25_model* m, gb25_field f, float* host, int include_halos) {
+  return copy_field(m, f, host, include_halos, false);
+}
+gb25_status gb25_field_device_ptr(gb25_model* m, gb25_field id, void** dev) {
+  if (!m || id < 0 || id >= GB25_FIELD_COUNT || !dev) return GB25_ERR_INVALID_ARGUMENT;
+  *dev = m->f[id].d;
+  return GB25_OK;
+}
+gb25_status gb25_get_metric(const gb25_model* m, gb25_metric id, int32_t logical_index, double* v) {
+  if (!m || id < 0 || id > GB25_M_DZF || !v) return GB25_ERR_INVALID_ARGUMENT;
+  int off = (id <= GB25_M_FCOR) ? m->metric_off_j : m->metric_off_k;
+  long a = (long)logical_index - 1 + off;  // logical_index is 1-based like the Julia sources
+  if (a < 0 || a >= (long)m->h_metric[id].size()) return GB25_ERR_INVALID_ARGUMENT;
+  *v = (double)(float)m->h_metric[id][a];
+  return GB25_OK;
+}
+gb25_status gb25_get_substepping(const gb25_model* m, int32_t* n, double* frac, double* w) {
+  if (!m) return GB25_ERR_INVALID_ARGUMENT;
+  if (n) *n = m->Ns;
+  if (frac) *frac = m->dtau_frac;
+  if (w) for (int k = 0; k < m->Ns; k++) w[k] = (double)(float)m->weights[k];
+  return GB25_OK;
+}
+
+gb25_status gb25_set_baroclinic_instability(gb25_model* m) {
+  CHECK_MODEL(m);
+  const Grid& g = m->g;
+  hipLaunchKernelGGL(k_set_baroclinic_instability, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, m->stream, g,
+                     m->f[GB25_T].d, m->f[GB25_S].d);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+
+gb25_status gb25_get_clock(const gb25_model* m, double* time, int64_t* it, double* last_dt) {
+  if (!m) return GB25_ERR_INVALID_ARGUMENT;
+  if (time) *time = m->time;
+  if (it) *it = m->iteration;
+  if (last_dt) *last_dt = m->last_dt;
+  return GB25_OK;
+}
+gb25_status gb25_set_dt(gb25_model* m, double dt) {
+  CHECK_MODEL(m);
+  m->last_dt = dt;
+  return GB25_OK;
+}
+
+gb25_status gb25_initialize(gb25_model* m) { CHECK_MODEL(m); return initialize_impl(m); }
+gb25_status gb25_mask_immersed_fields(gb25_model* m) { CHECK_MODEL(m); return GB25_OK; }
+gb25_status gb25_fill_halo_regions(gb25_model* m) { CHECK_MODEL(m); return fill_halos_impl(m, true); }
+gb25_status gb25_fill_halo_regions_local(gb25_model* m) { CHECK_MODEL(m); return fill_halos_impl(m, false); }
+gb25_status gb25_compute_auxiliaries(gb25_model* m) {
+  CHECK_MODEL(m);
+  gb25_status s = compute_w_impl(m);
+  return s ? s : compute_p_impl(m);
+}
+gb25_status gb25_fill_diffusivity_halos(gb25_model* m) { CHECK_MODEL(m); return GB25_OK; }
+gb25_status gb25_compute_momentum_tendencies(gb25_model* m) { CHECK_MODEL(m); return momentum_impl(m); }
+gb25_status gb25_compute_tracer_tendencies(gb25_model* m) { CHECK_MODEL(m); return tracers_impl(m); }
+gb25_status gb25_compute_boundary_tendencies(gb25_model* m) { CHECK_MODEL(m); return GB25_OK; }
+gb25_status gb25_compute_tendencies(gb25_model* m) {
+  CHECK_MODEL(m);
+  gb25_status s = momentum_impl(m);
+  return s ? s : tracers_impl(m);
+}
+gb25_status gb25_ab2_step(gb25_model* m, double dt, int euler) {
+  CHECK_MODEL(m);
+  if (m->cfg.nranks != 1) return fail(m, GB25_ERR_STATE, "gb25_ab2_step needs the staged path on a multi-rank slab");
+  return ab2_step_impl(m, dt, euler);
+}
+gb25_status gb25_correct_velocities_and_cache_previous_tendencies(gb25_model* m, double) {
+  CHECK_MODEL(m);
+  return corrector_impl(m);
+}
+gb25_status gb25_update_state(gb25_model* m) {
+  CHECK_MODEL(m);
+  if (m->cfg.nranks != 1) return fail(m, GB25_ERR_STATE, "gb25_update_state needs gb25_update_state_local + exchange");
+  return update_state_impl(m);
+}
+gb25_status gb25_update_state_local(gb25_model* m) {
+  CHECK_MODEL(m);
+  gb25_status s;
+  if ((s = fill_halos_impl(m, false))) return s;
+  if ((s = compute_w_impl(m))) return s;
+  if ((s = compute_p_impl(m))) return s;
+  if ((s = momentum_impl(m))) return s;
+  return tracers_impl(m);
+}
+
+gb25_status gb25_first_time_step(gb25_model* m) {
+  CHECK_MODEL(m);
+  gb25_status s;
+  if ((s = initialize_impl(m))) return s;
+  if ((s = update_state_impl(m))) return s;
+  return time_step_impl(m, 1);
+}
+gb25_status gb25_time_step(gb25_model* m) { CHECK_MODEL(m); return time_step_impl(m, 0); }
+gb25_status gb25_loop(gb25_model* m, int32_t n) {
+  CHECK_MODEL(m);
+  for (int s = 0; s < n; s++) {
+    gb25_status st = time_step_impl(m, 0);
+    if (st) return st;
+  }
+  return GB25_OK;
+}
+
+// ---- slab exchange (group 0 only for now) ------------------------------------
+static void group_fields(gb25_model* m, int group, std::vector<Field*>& out) {
+  if (group == 0) {
+    for (int id : {GB25_U, GB25_V, GB25_T, GB25_S, GB25_ETA, GB25_BT_U, GB25_BT_V}) out.push_back(&m->f[id]);
+  } else {
+    for (int id : {GB25_GN_BT_U, GB25_GN_BT_V}) out.push_back(&m->f[id]);
+  }
+}
+gb25_status gb25_halo_buffer_elems(const gb25_model* m, int group, int64_t* n) {
+  if (!m || !n || group < 0 || group > 1) return GB25_ERR_INVALID_ARGUMENT;
+  std::vector<Field*> fs;
+  group_fields(const_cast<gb25_model*>(m), group, fs);
+  int64_t t = 0;
+  for (Field* F : fs) t += (int64_t)F->ny * F->nz * m->cfg.halo;
+  *n = t;
+  return GB25_OK;
+}
+static gb25_status pack_unpack(gb25_model* m, int group, int side, float* buf, bool pack) {
+  if (!m || !buf || group < 0 || group > 1 || side < 0 || side > 1) return GB25_ERR_INVALID_ARGUMENT;
+  std::vector<Field*> fs;
+  group_fields(m, group, fs);
+  const int H = m->cfg.halo, Nx = m->Nx;
+  // pack: west side -> interior columns [H, 2H) of the parent; east -> [Nx, Nx+H)
+  // unpack: west halo -> parent columns [0, H); east halo -> [Nx+H, Nx+2H)
+  const int i0 = pack ? (side == 0 ? H : Nx) : (side == 0 ? 0 : Nx + H);
+  size_t off = 0;
+  for (Field* F : fs) {
+    long rows = (long)F->ny * F->nz;
+    long n = rows * H;
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (pack) hipLaunchKernelGGL(k_pack_columns, dim3(blocks), dim3(256), 0, m->stream, F->d, buf + off, F->nx, H, i0, rows);
+    else hipLaunchKernelGGL(k_unpack_columns, dim3(blocks), dim3(256), 0, m->stream, F->d, buf + off, F->nx, H, i0, rows);
+    off += n;
+  }
+  LAUNCHCHK();
+  return GB25_OK;
+}
+gb25_status gb25_halo_pack(gb25_model* m, int group, int side, float* buf) { return pack_unpack(m, group, side, buf, true); }
+gb25_status gb25_halo_unpack(gb25_model* m, int group, int side, const float* buf) {
+  return pack_unpack(m, group, side, const_cast<float*>(buf), false);
+}
+gb25_status gb25_time_step_stage(gb25_model* m, int, int) {
+  CHECK_MODEL(m);
+  return fail(m, GB25_ERR_STATE, "staged multi-slab time step is not available in this build");
+}
+
+// ---- profiling ------------------------------------------------------------------------------
+gb25_status gb25_profile_enable(gb25_model* m, int on) {
+  CHECK_MODEL(m);
+  m->profile = on != 0;
+  return GB25_OK;
+}
+gb25_status gb25_profile_reset(gb25_model* m) {
+  CHECK_MODEL(m);
+  resolve_profile(m);
+  for (int k = 0; k < GB25_K_COUNT; k++) {
+    m->prof_count[k] = 0;
+    m->prof_ms[k] = 0;
+  }
+  return GB25_OK;
+}
+gb25_status gb25_profile_get(gb25_model* m, gb25_kernel k, int64_t* launches, double* total_ms) {
+  if (!m || k < 0 || k >= GB25_K_COUNT) return GB25_ERR_INVALID_ARGUMENT;
+  resolve_profile(m);
+  if (launches) *launches = m->prof_count[k];
+  if (total_ms) *total_ms = m->prof_ms[k];
+  return GB25_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,578 @@
+// kernels.hpp -- hand-written HIP kernels (gfx950) for the HydrostaticFreeSurfaceModel time step.
+//
+// Thread mapping used throughout: lanes run along i (the fastest-varying, coalesced axis), so
+// a wavefront is 64 consecutive i at one (j,k); everything that depends only on j or k
+// (wall-adjacent order reduction, metrics) is wave-uniform.  3-D tendency kernels use a 1-D grid
+// of (64 x 4) tiles ordered (i-tile, k, j-tile) and remapped so that every XCD sweeps one
+// contiguous latitude band bottom-to-top: the +-3 vertical stencil planes stay in that XCD's L2.
+// Column kernels (w, pressure, AB2 + vertical integral, corrector) give one thread a whole
+// (i,j) column and march in k.
+#pragma once
+#include "device_common.hpp"
+
+namespace gb25 {
+
+constexpr int TX = 64, TY = 4;
+
+struct TileIdx {
+  int i, j, k;
+  bool ok;
+};
+__device__ __forceinline__ TileIdx tile_index(const Grid& g, int nbx, int nb) {
+  int L = xcd_remap(blockIdx.x, nb);
+  int bx = L % nbx, r = L / nbx;
+  int k = r % g.Nz, by = r / g.Nz;
+  TileIdx t;
+  t.i = bx * TX + threadIdx.x;
+  t.j = by * TY + threadIdx.y;
+  t.k = k;
+  t.ok = (t.i < g.Nx) && (t.j < g.Ny);
+  return t;
+}
+
+// =============================================================================================
+// Halo filling: tupled_fill_halo_regions!(prognostic_fields) (GB-25 src/precompile.jl:44-46).
+// Bounded y / z: ONE halo layer (zero-gradient; wall-normal velocity = 0).  Periodic x: all H
+// columns over the whole parent (j,k) extent, filled last so corners are consistent.
+// =============================================================================================
+struct Halo3 {
+  float* p[4];  // u, v, T, S
+};
+struct Halo2 {
+  float* p[3];  // centre-y fields first, then the face-y field (is_v[])
+  int is_v[3];
+  int n;
+};
+
+// south/north layer of the four 3-D fields + all 2-D fields.  grid: (ceil(Nx/256), Nz + 1)
+__global__ void k_fill_y(Grid g, Halo3 f3, Halo2 f2) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.Nx) return;
+  int k = blockIdx.y;
+  if (k < g.Nz) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      float* c = f3.p[q];
+      if (q == 1) {  // v: faces 0 and Ny are walls
+        c[iv(g, i, 0, k)] = 0.f;
+        c[iv(g, i, g.Ny, k)] = 0.f;
+      } else {
+        c[ic(g, i, -1, k)] = c[ic(g, i, 0, k)];
+        c[ic(g, i, g.Ny, k)] = c[ic(g, i, g.Ny - 1, k)];
+      }
+    }
+  } else {
+    for (int q = 0; q < f2.n; q++) {
+      float* c = f2.p[q];
+      if (f2.is_v[q]) {
+        c[i2(g, i, 0)] = 0.f;
+        c[i2(g, i, g.Ny)] = 0.f;
+      } else {
+        c[i2(g, i, -1)] = c[i2(g, i, 0)];
+        c[i2(g, i, g.Ny)] = c[i2(g, i, g.Ny - 1)];
+      }
+    }
+  }
+}
+// bottom/top layer of the four 3-D fields.  grid: (ceil(Nx/256), Ny)
+__global__ void k_fill_z(Grid g, Halo3 f3) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.Nx) return;
+  int j = blockIdx.y;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    float* c = f3.p[q];
+    if (q == 1) {
+      c[iv(g, i, j, -1)] = c[iv(g, i, j, 0)];
+      c[iv(g, i, j, g.Nz)] = c[iv(g, i, j, g.Nz - 1)];
+    } else {
+      c[ic(g, i, j, -1)] = c[ic(g, i, j, 0)];
+      c[ic(g, i, j, g.Nz)] = c[ic(g, i, j, g.Nz - 1)];
+    }
+  }
+}
+// periodic x for one array of `rows` parent rows: thread = (q in 0..2H-1, row)
+__device__ __forceinline__ void periodic_row(const Grid& g, float* c, long row, int q) {
+  float* r = c + row * g.sx;
+  if (q < g.H) r[q] = r[g.Nx + q];                  // west halo <- east interior
+  else r[g.Nx + q] = r[q];                          // east halo (index H+Nx+(q-H)) <- west interior
+}
+// grid: (ceil(rows_max*2H/256), 4 + n2d)
+__global__ void k_fill_x(Grid g, Halo3 f3, Halo2 f2, int rows_c, int rows_v) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int q = t % (2 * g.H);
+  long row = t / (2 * g.H);
+  int f = blockIdx.y;
+  if (f < 4) {
+    long rows = (f == 1) ? rows_v : rows_c;
+    if (row < rows) periodic_row(g, f3.p[f], row, q);
+  } else {
+    int s = f - 4;
+    if (s < f2.n) {
+      long rows = f2.is_v[s] ? g.sy_v : g.sy_c;
+      if (row < rows) periodic_row(g, f2.p[s], row, q);
+    }
+  }
+}
+
+// =============================================================================================
+// compute_auxiliaries!: w from continuity and the hydrostatic pressure anomaly
+// (GB-25 src/precompile.jl:113-115).  One thread per column on the extended range
+// [-H+1, N+H-2] so that w and p are valid in the halos without any exchange.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_compute_w(Grid g, const float* __restrict__ u, const float* __restrict__ v,
+                                                   float* __restrict__ w) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x - g.H + 1;
+  int j = blockIdx.y * blockDim.y + threadIdx.y - g.H + 1;
+  if (i > g.Nx + g.H - 2 || j > g.Ny + g.H - 2) return;
+  const float dxs = g.dxf[j], dxn = g.dxf[j + 1], raz = 1.f / g.azc[j], dy = g.dy;
+  int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
+  float wk = 0.f;
+  w[o] = 0.f;
+  for (int k = 0; k < g.Nz; k++) {
+    float dz = g.dzc[k];
+    float Ax = dy * dz;
+    float div = (Ax * u[o + 1] - Ax * u[o]) + (dxn * dz * v[ov + g.sx] - dxs * dz * v[ov]);
+    wk = wk - div * raz;
+    o += g.pl_c;
+    ov += g.pl_v;
+    w[o] = wk;
+  }
+}
+
+__device__ __forceinline__ float buoyancy(const Grid& g, float T, float S, float Z) {
+  return -(g.g * (teos10_rho(T, S, Z) - g.rho0)) / g.rho0;
+}
+__global__ __launch_bounds__(256) void k_compute_p(Grid g, const float* __restrict__ T, const float* __restrict__ S,
+                                                   float* __restrict__ p) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x - g.H + 1;
+  int j = blockIdx.y * blockDim.y + threadIdx.y - g.H + 1;
+  if (i > g.Nx + g.H - 2 || j > g.Ny + g.H - 2) return;
+  const int Nz = g.Nz;
+  int o = ic(g, i, j, Nz);
+  // b in the first halo cell above the surface: mirrored geopotential height (Oceananigans Z^ccc)
+  float bup = buoyancy(g, T[o], S[o], g.zc[Nz - 1] - g.dzf[Nz - 1]);
+  float pk = 0.f;
+  for (int k = Nz - 1; k >= 0; k--) {
+    o -= g.pl_c;
+    float bk = buoyancy(g, T[o], S[o], g.zc[k]);
+    pk = pk - 0.5f * (bk + bup) * g.dzf[k + 1];
+    p[o] = pk;
+    bup = bk;
+  }
+}
+
+// =============================================================================================
+// Tracer tendencies: G_c = -div(U c), WENO(order=5) upwind-biased flux form
+// (compute_hydrostatic_free_surface_Gc!, GB-25 src/precompile.jl:75-111).  T and S in one pass.
+// =============================================================================================
+__device__ __forceinline__ float tracer_div(const Grid& g, const float* __restrict__ c, int o, float Ax, float uw,
+                                            float ue, float Ays, float Ayn, float vs, float vn, float Az, float wb,
+                                            float wt, int oys, int oyn, int ozb, int ozt) {
+  float q[7];
+#pragma unroll
+  for (int m = 0; m < 7; m++) q[m] = c[o + m - 3];
+  float fw = Ax * uw * biased6<false>(5, uw > 0.f, q, q, q);
+  float fe = Ax * ue * biased6<false>(5, ue > 0.f, q + 1, q + 1, q + 1);
+#pragma unroll
+  for (int m = 0; m < 7; m++) q[m] = c[o + (m - 3) * g.sx];
+  float fs = Ays * vs * biased6<false>(oys, vs > 0.f, q, q, q);
+  float fn = Ayn * vn * biased6<false>(oyn, vn > 0.f, q + 1, q + 1, q + 1);
+#pragma unroll
+  for (int m = 0; m < 7; m++) q[m] = c[o + (m - 3) * g.pl_c];
+  float fb = Az * wb * biased6<false>(ozb, wb > 0.f, q, q, q);
+  float ft = Az * wt * biased6<false>(ozt, wt > 0.f, q + 1, q + 1, q + 1);
+  return (fe - fw) + (fn - fs) + (ft - fb);
+}
+
+__global__ __launch_bounds__(256) void k_tracer_tendencies(Grid g, const float* __restrict__ u,
+                                                           const float* __restrict__ v, const float* __restrict__ w,
+                                                           const float* __restrict__ T, const float* __restrict__ S,
+                                                           float* __restrict__ GT, float* __restrict__ GS, int nbx,
+                                                           int nb) {
+  TileIdx t = tile_index(g, nbx, nb);
+  if (!t.ok) return;
+  const int i = t.i, j = t.j, k = t.k;
+  const int o = ic(g, i, j, k), ov = iv(g, i, j, k);
+  const float dz = g.dzc[k];
+  const float Ax = g.dy * dz, Ays = g.dxf[j] * dz, Ayn = g.dxf[j + 1] * dz, Az = g.azc[j];
+  const float uw = u[o], ue = u[o + 1], vs = v[ov], vn = v[ov + g.sx], wb = w[o], wt = w[o + g.pl_c];
+  const int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny);
+  const int ozb = biased_order_face(k, g.Nz), ozt = biased_order_face(k + 1, g.Nz);
+  const float rV = 1.f / (Az * dz);
+  GT[o] = -(tracer_div(g, T, o, Ax, uw, ue, Ays, Ayn, vs, vn, Az, wb, wt, oys, oyn, ozb, ozt) * rV);
+  GS[o] = -(tracer_div(g, S, o, Ax, uw, ue, Ays, Ayn, vs, vn, Az, wb, wt, oys, oyn, ozb, ozt) * rV);
+}
+
+// =============================================================================================
+// Momentum tendencies (compute_hydrostatic_momentum_tendencies!, GB-25 src/precompile.jl:63-73):
+// WENOVectorInvariant(order=5): vorticity flux upwinded with VelocityStencil smoothness,
+// self-upwinded divergence flux and kinetic-energy gradient (OnlySelfUpwinding, cross terms
+// centred 4th order), WENO5 vertical advection, enstrophy-conserving spherical Coriolis,
+// hydrostatic pressure gradient.  The barotropic pressure gradient lives in the sub-cycle.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_gu(Grid g, const float* __restrict__ u, const float* __restrict__ v,
+                                            const float* __restrict__ w, const float* __restrict__ p,
+                                            float* __restrict__ Gu, int nbx, int nb) {
+  TileIdx t = tile_index(g, nbx, nb);
+  if (!t.ok) return;
+  const int i = t.i, j = t.j, k = t.k;
+  const int o = ic(g, i, j, k), ov = iv(g, i, j, k);
+  const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
+  const float dy = g.dy, dz = g.dzc[k];
+  const float dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], dxc_j = g.dxc[j];
+
+  // advecting v at (f,c,c)
+  const float vhat =
+      (0.5f * (dxf_s * v[ov - 1] + dxf_n * v[ov - 1 + sx]) + 0.5f * (dxf_s * v[ov] + dxf_n * v[ov + sx])) * 0.5f / dxc_j;
+
+  // vorticity at faces j-2 .. j+3 of column i, plus the VelocityStencil smoothness inputs
+  float zq[6], uq[6], vq[6];
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    int jf = j - 2 + m;
+    float vc = v[ov + (m - 2) * sx], vw = v[ov - 1 + (m - 2) * sx];
+    float uc = u[o + (m - 2) * sx], us = u[o + (m - 3) * sx];
+    zq[m] = ((dy * vc - dy * vw) - (g.dxc[jf] * uc - g.dxc[jf - 1] * us)) / g.azf[jf];
+    uq[m] = 0.5f * (us + uc);
+    vq[m] = 0.5f * (vw + vc);
+  }
+  const float zetaR = biased6<true>(biased_order_center(j, g.Ny), vhat > 0.f, zq, uq, vq);
+  const float hadv = -vhat * zetaR;
+
+  // self-upwinded divergence flux
+  const float uhat = u[o];
+  float u7[7];
+#pragma unroll
+  for (int m = 0; m < 7; m++) u7[m] = u[o + m - 3];
+  const float Ax = dy * dz, Ays = dxf_s * dz, Ayn = dxf_n * dz;
+  float Du[6], Dv[6], Dd[6];
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    Du[m] = Ax * u7[m + 1] - Ax * u7[m];
+    Dv[m] = Ayn * v[ov + (m - 3) + sx] - Ays * v[ov + (m - 3)];
+    Dd[m] = Du[m] + Dv[m];
+  }
+  const float dvs = sym_interp(true, Dv[1], Dv[2], Dv[3], Dv[4]);
+  const float duR = biased6<false>(5, uhat > 0.f, Du, Dd, Dd);
+  const float phi = uhat * (dvs + duR);
+
+  // vertical advection of u
+  const float Az = g.azc[j];
+  float fz[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; tt++) {
+    int ow = o + tt * pc;
+    float wt = sym_interp(true, Az * w[ow - 2], Az * w[ow - 1], Az * w[ow], Az * w[ow + 1]);
+    float q[6];
+#pragma unroll
+    for (int m = 0; m < 6; m++) q[m] = u[o + (tt + m - 3) * pc];
+    fz[tt] = wt * biased6<false>(biased_order_face(k + tt, g.Nz), wt > 0.f, q, q, q);
+  }
+  const float vadv = (phi + (fz[1] - fz[0])) / (Az * dz);
+
+  // Bernoulli head
+  float Ku[6], su[6];
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    Ku[m] = 0.5f * u7[m + 1] * u7[m + 1] - 0.5f * u7[m] * u7[m];
+    su[m] = 0.5f * (u7[m] + u7[m + 1]);
+  }
+  const float dKu = biased6<false>(5, uhat > 0.f, Ku, su, su);
+  float a4[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    float vc = v[ov + (m - 1) * sx], vw = v[ov - 1 + (m - 1) * sx];
+    a4[m] = 0.5f * vc * vc - 0.5f * vw * vw;
+  }
+  const float dKv = sym_interp(sym4_center(j, g.Ny), a4[0], a4[1], a4[2], a4[3]);
+  const float bern = (dKu + dKv) / dxc_j;
+
+  const float cor = -0.5f * (g.fcor[j] + g.fcor[j + 1]) * vhat;
+  const float dpdx = (p[o] - p[o - 1]) / dxc_j;
+  Gu[o] = -(hadv + vadv + bern) - cor - dpdx;
+}
+
+__global__ __launch_bounds__(256) void k_gv(Grid g, const float* __restrict__ u, const float* __restrict__ v,
+                                            const float* __restrict__ w, const float* __restrict__ p,
+                                            float* __restrict__ Gv, int nbx, int nb) {
+  TileIdx t = tile_index(g, nbx, nb);
+  if (!t.ok) return;
+  const int i = t.i, j = t.j, k = t.k;
+  const int o = ic(g, i, j, k), ov = iv(g, i, j, k);
+  const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
+  const float dy = g.dy, dz = g.dzc[k];
+
+  // advecting u at (c,f,c)
+  const float uhat = (0.5f * (dy * u[o - sx] + dy * u[o - sx + 1]) + 0.5f * (dy * u[o] + dy * u[o + 1])) * 0.5f / dy;
+
+  // vorticity at faces i-2 .. i+3 of row j
+  const float dxc_j = g.dxc[j], dxc_s = g.dxc[j - 1], razf = 1.f / g.azf[j];
+  float zq[6], uq[6], vq[6];
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    float vc = v[ov + (m - 2)], vw = v[ov + (m - 3)];
+    float uc = u[o + (m - 2)], us = u[o + (m - 2) - sx];
+    zq[m] = ((dy * vc - dy * vw) - (dxc_j * uc - dxc_s * us)) * razf;
+    uq[m] = 0.5f * (us + uc);
+    vq[m] = 0.5f * (vw + vc);
+  }
+  const float zetaR = biased6<true>(5, uhat > 0.f, zq, uq, vq);
+  const float hadv = uhat * zetaR;
+
+  // self-upwinded divergence flux
+  const float vhat = v[ov];
+  float v7[7];
+#pragma unroll
+  for (int m = 0; m < 7; m++) v7[m] = v[ov + (m - 3) * sx];
+  const float Ax = dy * dz;
+  float Du[6], Dv[6], Dd[6];
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    int jc = j - 3 + m;
+    Du[m] = Ax * u[o + 1 + (m - 3) * sx] - Ax * u[o + (m - 3) * sx];
+    Dv[m] = g.dxf[jc + 1] * dz * v7[m + 1] - g.dxf[jc] * dz * v7[m];
+    Dd[m] = Du[m] + Dv[m];
+  }
+  const int of = biased_order_face(j, g.Ny);
+  const bool s4 = sym4_face(j, g.Ny);
+  const float dus = sym_interp(s4, Du[1], Du[2], Du[3], Du[4]);
+  const float dvR = biased6<false>(of, vhat > 0.f, Dv, Dd, Dd);
+  const float phi = vhat * (dus + dvR);
+
+  // vertical advection of v
+  float fz[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; tt++) {
+    int ow = o + tt * pc;
+    float wt = sym_interp(s4, g.azc[j - 2] * w[ow - 2 * sx], g.azc[j - 1] * w[ow - sx], g.azc[j] * w[ow],
+                          g.azc[j + 1] * w[ow + sx]);
+    float q[6];
+#pragma unroll
+    for (int m = 0; m < 6; m++) q[m] = v[ov + (tt + m - 3) * pv];
+    fz[tt] = wt * biased6<false>(biased_order_face(k + tt, g.Nz), wt > 0.f, q, q, q);
+  }
+  const float vadv = (phi + (fz[1] - fz[0])) / (g.azf[j] * dz);
+
+  // Bernoulli head
+  float Kv[6], sv[6];
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    Kv[m] = 0.5f * v7[m + 1] * v7[m + 1] - 0.5f * v7[m] * v7[m];
+    sv[m] = 0.5f * (v7[m] + v7[m + 1]);
+  }
+  const float dKv = biased6<false>(of, vhat > 0.f, Kv, sv, sv);
+  float a4[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    float un = u[o + (m - 1)], us = u[o + (m - 1) - sx];
+    a4[m] = 0.5f * un * un - 0.5f * us * us;
+  }
+  const float dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
+  const float bern = (dKv + dKu) / dy;
+
+  const float cor = g.fcor[j] * uhat;
+  const float dpdy = (p[o] - p[o - sx]) / dy;
+  Gv[ov] = -(hadv + vadv + bern) - cor - dpdy;
+}
+
+// =============================================================================================
+// ab2_step!: velocities + vertically integrated AB2 tendencies (barotropic forcing), one thread
+// per column (fuses ab2_step_field! x2 with _compute_integrated_ab2_tendencies!).
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, float* __restrict__ u, float* __restrict__ v,
+                                                        const float* __restrict__ Gnu, const float* __restrict__ Gmu,
+                                                        const float* __restrict__ Gnv, const float* __restrict__ Gmv,
+                                                        float* __restrict__ GU, float* __restrict__ GV, float dt,
+                                                        float chi) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const float C1 = 1.5f + chi, C2 = 0.5f + chi;
+  const float ne = (chi != -0.5f) ? 1.f : 0.f;
+  int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
+  float su = 0.f, sv = 0.f;
+  for (int k = 0; k < g.Nz; k++) {
+    float dz = g.dzc[k];
+    float gu = C1 * Gnu[o] - C2 * Gmu[o] * ne;
+    float gv = C1 * Gnv[ov] - C2 * Gmv[ov] * ne;
+    u[o] += dt * gu;
+    v[ov] += dt * gv;
+    su = (k == 0) ? dz * gu : su + dz * gu;
+    sv = (k == 0) ? dz * gv : sv + dz * gv;
+    o += g.pl_c;
+    ov += g.pl_v;
+  }
+  GU[i2(g, i, j)] = su;
+  GV[i2(g, i, j)] = (j == 0) ? 0.f : sv;  // the wall face is a peripheral node
+}
+
+// tracers: flat AXPY over the interior planes of a parent array (G halos are identically zero)
+__global__ void k_ab2_tracers4(float4* __restrict__ T, float4* __restrict__ S, const float4* __restrict__ GnT,
+                               const float4* __restrict__ GmT, const float4* __restrict__ GnS,
+                               const float4* __restrict__ GmS, long n4, float dt, float C1, float C2) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; t < n4; t += stride) {
+    float4 a = T[t], gn = GnT[t], gm = GmT[t];
+    a.x += dt * (C1 * gn.x - C2 * gm.x);
+    a.y += dt * (C1 * gn.y - C2 * gm.y);
+    a.z += dt * (C1 * gn.z - C2 * gm.z);
+    a.w += dt * (C1 * gn.w - C2 * gm.w);
+    T[t] = a;
+    float4 b = S[t], hn = GnS[t], hm = GmS[t];
+    b.x += dt * (C1 * hn.x - C2 * hm.x);
+    b.y += dt * (C1 * hn.y - C2 * hm.y);
+    b.z += dt * (C1 * hn.z - C2 * hm.z);
+    b.w += dt * (C1 * hn.w - C2 * hm.w);
+    S[t] = b;
+  }
+}
+__global__ void k_ab2_tracers1(float* __restrict__ T, float* __restrict__ S, const float* __restrict__ GnT,
+                               const float* __restrict__ GmT, const float* __restrict__ GnS,
+                               const float* __restrict__ GmS, long n, float dt, float C1, float C2) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; t < n; t += stride) {
+    T[t] += dt * (C1 * GnT[t] - C2 * GmT[t]);
+    S[t] += dt * (C1 * GnS[t] - C2 * GmS[t]);
+  }
+}
+
+// =============================================================================================
+// Split-explicit free surface (step_free_surface!, forward-backward): one fused launch per
+// substep.  eta is advanced with the old transports, then U,V with the NEW eta, exactly as the
+// reference's two kernels do; because the launch is fused, the new eta at (i,j), (i-1,j), (i,j-1)
+// is recomputed locally and the state is ping-ponged between two buffer sets.
+// Periodic x / wall y are handled in-kernel (topology-aware operators): no halo fills inside
+// the sub-cycle.
+// =============================================================================================
+struct Baro {
+  const float *eta0, *U0, *V0;  // state at substep m
+  float *eta1, *U1, *V1;        // state at substep m+1
+  float *etab, *Ub, *Vb;        // running time averages
+  const float *GU, *GV;
+};
+__device__ __forceinline__ float eta_step(const Grid& g, const Baro& b, int i, int j, float dtau) {
+  int ip = (i == g.Nx - 1) ? 0 : i + 1;
+  float dxU = g.dy * b.U0[i2(g, ip, j)] - g.dy * b.U0[i2(g, i, j)];
+  float dyV;
+  if (j == g.Ny - 1) dyV = -(g.dxf[j] * b.V0[i2(g, i, j)]);
+  else if (j == 0) dyV = g.dxf[1] * b.V0[i2(g, i, 1)];
+  else dyV = g.dxf[j + 1] * b.V0[i2(g, i, j + 1)] - g.dxf[j] * b.V0[i2(g, i, j)];
+  return b.eta0[i2(g, i, j)] - dtau * (dxU + dyV) / g.azc[j];
+}
+__global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, float dtau, float wgt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  int im = (i == 0) ? g.Nx - 1 : i - 1;
+  float e = eta_step(g, b, i, j, dtau);
+  float ew = eta_step(g, b, im, j, dtau);
+  float dxe = (e - ew) / g.dxc[j];
+  float dye = 0.f;
+  if (j > 0) dye = (e - eta_step(g, b, i, j - 1, dtau)) / g.dy;
+  int o = i2(g, i, j);
+  float Un = b.U0[o] + dtau * (-g.g * g.Lz * dxe + b.GU[o]);
+  float Vn = b.V0[o] + dtau * (-g.g * g.Lz * dye + b.GV[o]);
+  b.eta1[o] = e;
+  b.U1[o] = Un;
+  b.V1[o] = Vn;
+  b.etab[o] += wgt * e;
+  b.Ub[o] += wgt * Un;
+  b.Vb[o] += wgt * Vn;
+}
+__global__ void k_barotropic_finalize(Grid g, float* eta, float* U, float* V, const float* etab, const float* Ub,
+                                      const float* Vb) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  int o = i2(g, i, j);
+  eta[o] = etab[o];
+  U[o] = Ub[o];
+  V[o] = Vb[o];
+}
+
+// =============================================================================================
+// Barotropic mode and corrector (correct_velocities_and_cache_previous_tendencies!).
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const float* __restrict__ u,
+                                                         const float* __restrict__ v, float* __restrict__ U,
+                                                         float* __restrict__ V) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
+  float su = g.dzc[0] * u[o], sv = g.dzc[0] * v[ov];
+  for (int k = 1; k < g.Nz; k++) {
+    o += g.pl_c;
+    ov += g.pl_v;
+    su += g.dzc[k] * u[o];
+    sv += g.dzc[k] * v[ov];
+  }
+  U[i2(g, i, j)] = su;
+  V[i2(g, i, j)] = sv;
+}
+// Ubar,Vbar <- column integrals of u,v (work arrays, as in the reference), then
+// u += (U - Ubar)/H, v += (V - Vbar)/H.  The second sweep re-reads the column from L2.
+__global__ __launch_bounds__(256) void k_corrector(Grid g, float* __restrict__ u, float* __restrict__ v,
+                                                   const float* __restrict__ U, const float* __restrict__ V,
+                                                   float* __restrict__ Ub, float* __restrict__ Vb) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const int o0 = ic(g, i, j, 0), ov0 = iv(g, i, j, 0);
+  int o = o0, ov = ov0;
+  float su = g.dzc[0] * u[o], sv = g.dzc[0] * v[ov];
+  for (int k = 1; k < g.Nz; k++) {
+    o += g.pl_c;
+    ov += g.pl_v;
+    su += g.dzc[k] * u[o];
+    sv += g.dzc[k] * v[ov];
+  }
+  int o2 = i2(g, i, j);
+  Ub[o2] = su;
+  Vb[o2] = sv;
+  const float du = (U[o2] - su) / g.Lz, dv = (V[o2] - sv) / g.Lz;
+  o = o0;
+  ov = ov0;
+  for (int k = 0; k < g.Nz; k++) {
+    u[o] = u[o] + du;
+    v[ov] = v[ov] + dv;
+    o += g.pl_c;
+    ov += g.pl_v;
+  }
+}
+
+// set_baroclinic_instability!(model) (GB-25 src/model_utils.jl:83-87,99-110)
+__global__ void k_set_baroclinic_instability(Grid g, float* __restrict__ T, float* __restrict__ S) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = blockIdx.y;
+  int k = blockIdx.z;
+  if (i >= g.Nx) return;
+  float phi = g.phic[j], z = g.zc[k];
+  float step = (1.f - tanhf((fabsf(phi) - 40.f) / 5.f)) / 2.f;
+  int o = ic(g, i, j, k);
+  T[o] = (30.f + 1e-3f * z) * step;
+  S[o] = -5e-3f * z;
+}
+
+// x-slab halo exchange: pack H interior columns next to a slab edge / unpack into the halo.
+// buffer layout: [row][q] with q in 0..H-1, rows = all parent rows of the array.
+__global__ void k_pack_columns(const float* __restrict__ c, float* __restrict__ buf, int sx, int H, int i0, long rows) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * H) return;
+  int q = t % H;
+  long row = t / H;
+  buf[t] = c[row * sx + i0 + q];
+}
+__global__ void k_unpack_columns(float* __restrict__ c, const float* __restrict__ buf, int sx, int H, int i0,
+                                 long rows) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * H) return;
+  int q = t % H;
+  long row = t / H;
+  c[row * sx + i0 + q] = buf[t];
+}
+
+}  // namespace gb25

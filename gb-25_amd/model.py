@@ -1,0 +1,202 @@
+"""Host-side mirror of the GordonBell25 model API for the HydrostaticFreeSurfaceModel hot path.
+
+Mirrors (names, argument meaning, mutation-in-place semantics):
+  baroclinic_instability_model(arch, Nx, Ny, Nz; dt, halo, ...)  GB-25 src/baroclinic_instability_model.jl:17-85
+  first_time_step!(model) / time_step!(model) / loop!(model, Ninner)  src/timestepping_utils.jl:21-45
+  set_baroclinic_instability!(model)                              src/model_utils.jl:120-127
+  the *_workload! phase wrappers                                   src/precompile.jl:44-127
+Julia's `!` suffix is dropped.  The model object exposes Oceananigans-shaped accessors
+(model.velocities.u, model.tracers.T, model.free_surface.eta, model.timestepper.Gn.u,
+model.clock, model.grid) whose `parent` / `interior` arrays have the Oceananigans layout.
+
+The numerical engine is injected as a *backend* object (binding.HipBackend in the product).
+"""
+from types import SimpleNamespace
+
+import numpy as np
+
+
+class Field:
+    """View of one model field: `parent` includes halos (Oceananigans `parent(field)`),
+    `interior` does not.  Index order is [i, j, k]; arrays are copies fetched from the device."""
+
+    def __init__(self, backend, name, location):
+        self._b, self.name, self.location = backend, name, location
+
+    @property
+    def parent(self):
+        return self._b.get_field(self.name, True)
+
+    @property
+    def interior(self):
+        return self._b.get_field(self.name, False)
+
+    def set(self, array, include_halos=False):
+        a = np.asarray(array)
+        self._b.set_field(self.name, a, include_halos)
+
+    def set_parent(self, array):
+        self._b.set_field(self.name, array, True)
+
+    @property
+    def shape(self):
+        return self._b.field_dims(self.name, False)
+
+    def __repr__(self):
+        return f"Field({self.name!r} at {self.location}, interior {self.shape})"
+
+
+class Clock:
+    """model.clock (time, last_dt, iteration) -- src/model_utils.jl:150-155."""
+
+    def __init__(self, backend):
+        self._b = backend
+
+    @property
+    def time(self):
+        return self._b.clock()[0]
+
+    @property
+    def iteration(self):
+        return self._b.clock()[1]
+
+    @property
+    def last_dt(self):
+        return self._b.clock()[2]
+
+    @last_dt.setter
+    def last_dt(self, dt):
+        self._b.set_dt(dt)
+
+
+class LatitudeLongitudeGrid:
+    """simple_latitude_longitude_grid(arch, Nx, Ny, Nz; halo) -- src/model_utils.jl:56-65."""
+
+    def __init__(self, backend, Nx, Ny, Nz, halo):
+        self._b = backend
+        self.Nx, self.Ny, self.Nz = Nx, Ny, Nz
+        self.halo = (halo, halo, halo)
+        self.latitude, self.longitude = (-80, 80), (0, 360)
+
+    @property
+    def size(self):
+        return (self.Nx, self.Ny, self.Nz)
+
+    def metric(self, name, index):
+        """1-based index like the Julia sources; names: phif phic dxc dxf azc azf fcor zf zc dzc dzf."""
+        return self._b.metric(name, index)
+
+    def z_faces(self):
+        return np.array([self.metric("zf", k) for k in range(1, self.Nz + 2)])
+
+
+class HydrostaticFreeSurfaceModel:
+    """The object baroclinic_instability_model returns."""
+
+    def __init__(self, backend, Nx, Ny, Nz, halo):
+        b = self.backend = backend
+        self.grid = LatitudeLongitudeGrid(b, Nx, Ny, Nz, halo)
+        self.clock = Clock(b)
+        F = lambda n, loc: Field(b, n, loc)
+        self.velocities = SimpleNamespace(u=F("u", "fcc"), v=F("v", "cfc"), w=F("w", "ccf"))
+        self.tracers = SimpleNamespace(T=F("T", "ccc"), S=F("S", "ccc"))
+        self.pressure = SimpleNamespace(pHY=F("pHY", "ccc"))
+        self.free_surface = SimpleNamespace(
+            eta=F("eta", "ccf"),
+            barotropic_velocities=SimpleNamespace(U=F("U", "fc"), V=F("V", "cf")),
+            filtered_state=SimpleNamespace(eta=F("eta_bar", "ccf"), U=F("U_bar", "fc"), V=F("V_bar", "cf")),
+            substeps=30, gravitational_acceleration=9.80665)
+        G = lambda p: SimpleNamespace(u=F(p + ".u", "fcc"), v=F(p + ".v", "cfc"), T=F(p + ".T", "ccc"),
+                                      S=F(p + ".S", "ccc"))
+        Gn = G("Gn")
+        Gn.U, Gn.V = F("Gn.U", "fc"), F("Gn.V", "cf")
+        self.timestepper = SimpleNamespace(Gn=Gn, Gm=G("Gm"), chi=0.1)
+
+    # Oceananigans.fields(model): the set compare_states walks (src/correctness.jl:34-35)
+    def fields(self):
+        return {"u": self.velocities.u, "v": self.velocities.v, "w": self.velocities.w,
+                "eta": self.free_surface.eta, "T": self.tracers.T, "S": self.tracers.S}
+
+    def prognostic_fields(self):
+        fs = self.free_surface
+        return {"u": self.velocities.u, "v": self.velocities.v, "eta": fs.eta,
+                "U": fs.barotropic_velocities.U, "V": fs.barotropic_velocities.V,
+                "T": self.tracers.T, "S": self.tracers.S}
+
+    def set(self, **kw):
+        """set!(model, u=..., v=..., T=..., S=..., eta=...) with interior-shaped arrays."""
+        allf = {**self.fields()}
+        for k, v in kw.items():
+            allf[k].set(v)
+
+    def synchronize(self):
+        self.backend.synchronize()
+
+    def __repr__(self):
+        Nx, Ny, Nz = self.grid.size
+        return f"HydrostaticFreeSurfaceModel({Nx}x{Ny}x{Nz} LatitudeLongitudeGrid, halo {self.grid.halo}, fp32, MI355X)"
+
+
+def resolution_to_points(resolution):
+    """src/model_utils.jl:45-49."""
+    Nx, Ny = 384 / resolution, 192 / resolution
+    if Nx != int(Nx) or Ny != int(Ny):
+        raise ValueError("resolution must divide 384 and 192")
+    return int(Nx), int(Ny)
+
+
+def baroclinic_instability_model(arch, Nx=None, Ny=None, Nz=None, *, dt, halo=(8, 8, 8), grid_type="simple_lat_lon",
+                                 substeps=30, resolution=None, **backend_kw):
+    """baroclinic_instability_model(arch, Nx, Ny, Nz; dt, halo, grid_type, free_surface=SplitExplicit(substeps))
+    -- src/baroclinic_instability_model.jl:12-85.  `arch` is a backend factory: GPU() from this package
+    (or, in tests only, an oracle-backed factory).  Physics is fixed to the reference defaults:
+    TEOS-10 SeawaterBuoyancy, HydrostaticSphericalCoriolis, WENOVectorInvariant(order=5),
+    WENO(order=5), closure=nothing.  The initial state is all zeros, as in the reference
+    (set_baroclinic_instability! is commented out at :74-80)."""
+    if resolution is not None:
+        Nx, Ny = resolution_to_points(resolution)
+    if grid_type != "simple_lat_lon":
+        raise NotImplementedError("grid_type=:gaussian_islands (TripolarGrid + immersed boundary) is outside this "
+                                  "round's hot-path scope (SURVEY.md section 8f)")
+    H = halo[0] if isinstance(halo, (tuple, list)) else halo
+    if isinstance(halo, (tuple, list)) and len(set(halo)) != 1:
+        raise ValueError("halo must be the same in every direction")
+    backend = arch(Nx, Ny, Nz, dt=dt, halo=H, substeps=substeps, **backend_kw)
+    model = HydrostaticFreeSurfaceModel(backend, Nx, Ny, Nz, H)
+    model.free_surface.substeps = substeps
+    return model
+
+
+def set_baroclinic_instability(model):
+    """set_baroclinic_instability!(model) -- src/model_utils.jl:120-127."""
+    model.backend.set_baroclinic_instability()
+
+
+def first_time_step(model):
+    """first_time_step!(model) -- src/timestepping_utils.jl:21-27."""
+    model.backend.first_time_step()
+
+
+def time_step(model):
+    """time_step!(model) -- src/timestepping_utils.jl:29-35."""
+    model.backend.time_step()
+
+
+def loop(model, Ninner):
+    """loop!(model, Ninner) -- src/timestepping_utils.jl:37-45."""
+    model.backend.loop(int(Ninner))
+
+
+# ---- the per-phase workloads of src/precompile.jl:44-127 ----
+def tupled_fill_halo_regions_workload(model): model.backend.fill_halo_regions()
+def compute_tendencies_workload(model): model.backend.compute_tendencies()
+def compute_boundary_tendencies_workload(model): model.backend.compute_boundary_tendencies()
+def compute_interior_momentum_tendencies_workload(model): model.backend.compute_momentum_tendencies()
+def compute_interior_tracer_tendencies_workload(model): model.backend.compute_tracer_tendencies()
+def compute_auxiliaries_workload(model): model.backend.compute_auxiliaries()
+def fill_halo_regions_workload(model): model.backend.fill_diffusivity_halos()
+def ab2_step_workload(model, dt): model.backend.ab2_step(dt, False)
+def correct_velocities_and_cache_previous_tendencies_workload(model, dt):
+    model.backend.correct_velocities_and_cache_previous_tendencies(dt)
+def initialize(model): model.backend.initialize()
+def update_state(model): model.backend.update_state()

@@ -1,0 +1,170 @@
+/*
+ * gb25.h -- C ABI of libgb25hip.so: the MI355X (gfx950) implementation of the
+ * Oceananigans HydrostaticFreeSurfaceModel time-step loop that GB-25's
+ * baroclinic_instability_model drives.
+ *
+ * This is the drop-in boundary.  Each entry point names the reference interface it
+ * replaces (paths relative to the GB-25 tree).  A Julia host binds these with
+ * `ccall`; this repository binds them with ctypes
+ * (gb-25_amd/binding.py).  Plain pointers and sizes only; no exceptions cross the ABI:
+ * every call returns a gb25_status and the message is kept per handle.
+ *
+ * Layout contract (src/correctness.jl:4-15 compares `parent(field)` arrays):
+ * every field is stored exactly like `parent(field)` of the Oceananigans Field --
+ * column-major, i fastest, halo H on every side:
+ *     centre/centre/centre (T, S, pHY', u(*), G.u, G.T, G.S): (Nx+2H, Ny+2H,   Nz+2H)
+ *     v, G.v  (face in bounded y):                             (Nx+2H, Ny+2H+1, Nz+2H)
+ *     w       (face in bounded z):                             (Nx+2H, Ny+2H,   Nz+2H+1)
+ *     eta, U, etabar, Ubar, G.U:                               (Nx+2H, Ny+2H,   1)
+ *     V, Vbar, G.V:                                            (Nx+2H, Ny+2H+1, 1)
+ * (*) x is periodic, so u has Nx faces.  With an x-slab decomposition Nx is the
+ * LOCAL slab width (Nx_global / nranks) and the x halos hold the neighbours' columns.
+ * All data are fp32 (simulations/baroclinic_instability_simulation_run.jl:13).
+ */
+#ifndef GB25_H
+#define GB25_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gb25_model gb25_model; /* opaque; owns all device memory */
+
+typedef enum {
+  GB25_OK = 0,
+  GB25_ERR_INVALID_ARGUMENT = 1,
+  GB25_ERR_HIP = 2,          /* a HIP runtime call failed; see gb25_last_error_string */
+  GB25_ERR_OUT_OF_MEMORY = 3,
+  GB25_ERR_NO_DEVICE = 4,    /* no gfx950 device visible: there is NO CPU fallback */
+  GB25_ERR_STATE = 5
+} gb25_status;
+
+/* Field identifiers: the set compared by compare_states (src/correctness.jl:28-90)
+ * plus the diagnostic pressure and the barotropic work fields. */
+typedef enum {
+  GB25_U = 0, GB25_V, GB25_W, GB25_T, GB25_S, GB25_PHY,
+  GB25_GN_U, GB25_GN_V, GB25_GN_T, GB25_GN_S, /* timestepper.G^n */
+  GB25_GM_U, GB25_GM_V, GB25_GM_T, GB25_GM_S, /* timestepper.G^- */
+  GB25_ETA, GB25_BT_U, GB25_BT_V,             /* free_surface.eta, barotropic_velocities */
+  GB25_ETA_BAR, GB25_U_BAR, GB25_V_BAR,       /* free_surface.filtered_state */
+  GB25_GN_BT_U, GB25_GN_BT_V,                 /* timestepper.G^n.U, .V */
+  GB25_FIELD_COUNT
+} gb25_field;
+
+/* Model configuration = the keyword arguments of
+ * baroclinic_instability_model(arch, Nx, Ny, Nz; dt, halo, free_surface, ...)
+ * (src/baroclinic_instability_model.jl:17-40) and of simple_latitude_longitude_grid
+ * (src/model_utils.jl:56-65).  Fill with gb25_default_config, then override. */
+typedef struct {
+  int32_t Nx, Ny, Nz;   /* GLOBAL interior size */
+  int32_t halo;         /* H; 8 in every GB-25 script */
+  int32_t substeps;     /* SplitExplicitFreeSurface(substeps=30) */
+  int32_t rank, nranks; /* x-slab decomposition: this process owns columns
+                           [rank*Nx/nranks, (rank+1)*Nx/nranks); nranks=1: periodic x is local */
+  int32_t device;       /* HIP device ordinal */
+  double dt;            /* model.clock.last_dt (src/baroclinic_instability_model.jl:82) */
+  double chi;           /* QuasiAdamsBashforth2 chi = 0.1 */
+  double lat_south, lat_north; /* (-80, 80) */
+  double lon_west, lon_east;   /* (0, 360) */
+  double depth, zexp_h;        /* exponential_z_faces(Nz, depth=4000, h=30) */
+  double g, Omega, radius, rho0; /* 9.80665, 7.292115e-5, 6371e3, 1020 (TEOS-10 reference) */
+} gb25_config;
+
+/* Metric identifiers for gb25_get_metric (diagnostics / tests). */
+typedef enum {
+  GB25_M_PHIF = 0, GB25_M_PHIC, GB25_M_DXC, GB25_M_DXF, GB25_M_AZC, GB25_M_AZF, GB25_M_FCOR,
+  GB25_M_ZF, GB25_M_ZC, GB25_M_DZC, GB25_M_DZF
+} gb25_metric;
+
+/* Kernel identifiers for the built-in HIP-event timers (gb25_profile_*). */
+typedef enum {
+  GB25_K_FILL_HALOS = 0, GB25_K_COMPUTE_W, GB25_K_COMPUTE_P, GB25_K_GU, GB25_K_GV, GB25_K_TRACERS,
+  GB25_K_AB2_VELOCITIES, GB25_K_AB2_TRACERS, GB25_K_BAROTROPIC, GB25_K_CORRECTOR, GB25_K_COUNT
+} gb25_kernel;
+
+void gb25_default_config(gb25_config *cfg, int32_t Nx, int32_t Ny, int32_t Nz);
+
+/* ---- lifecycle: replaces baroclinic_instability_model(arch, Nx, Ny, Nz; dt, ...)
+ *      (src/baroclinic_instability_model.jl:17-85): builds the grid metrics, allocates every
+ *      field zeroed on the device and stores dt in the clock. */
+gb25_status gb25_create(const gb25_config *cfg, gb25_model **out);
+void gb25_destroy(gb25_model *m);
+const char *gb25_last_error_string(const gb25_model *m); /* valid until the next call on m */
+const char *gb25_version(void);
+
+/* Run all kernels of this model on the caller's HIP stream (a hipStream_t passed as void*;
+ * NULL = the model's own stream).  Lets a host framework order our kernels with its own work. */
+gb25_status gb25_set_stream(gb25_model *m, void *hip_stream);
+gb25_status gb25_synchronize(gb25_model *m);
+
+/* ---- fields: replaces parent(field)/interior(field)/set!(model, ...) and sync_states!
+ *      (src/correctness.jl:92-103).  dims = parent dims (include_halos != 0) or interior dims.
+ *      Host pointers are borrowed for the duration of the call. */
+gb25_status gb25_field_dims(const gb25_model *m, gb25_field f, int include_halos, int32_t dims[3]);
+gb25_status gb25_set_field(gb25_model *m, gb25_field f, const float *host, int include_halos);
+gb25_status gb25_get_field(gb25_model *m, gb25_field f, float *host, int include_halos);
+/* Device pointer of parent(field) for zero-copy wrapping (e.g. unsafe_wrap(ROCArray, ...)).
+ * G^n / G^- pointers are exchanged by correct_and_cache (a pointer swap replaces the copy). */
+gb25_status gb25_field_device_ptr(gb25_model *m, gb25_field f, void **dev);
+gb25_status gb25_get_metric(const gb25_model *m, gb25_metric id, int32_t logical_index, double *value);
+gb25_status gb25_get_substepping(const gb25_model *m, int32_t *n_effective, double *dtau_fraction,
+                                 double *weights /* >= substeps entries */);
+
+/* ---- initial conditions: set_baroclinic_instability!(model) (src/model_utils.jl:99-127) */
+gb25_status gb25_set_baroclinic_instability(gb25_model *m);
+
+/* ---- clock: model.clock fields (src/model_utils.jl:150-155) */
+gb25_status gb25_get_clock(const gb25_model *m, double *time, int64_t *iteration, double *last_dt);
+gb25_status gb25_set_dt(gb25_model *m, double dt);
+
+/* ---- the phases of one time step, in the reference's order (src/precompile.jl:31-42).
+ *      Each replaces the *_workload! wrapper cited. */
+gb25_status gb25_initialize(gb25_model *m);              /* Oceananigans.initialize!(model) (correctness/..._run.jl:50-51) */
+gb25_status gb25_mask_immersed_fields(gb25_model *m);    /* src/precompile.jl:34   (no-op on this grid) */
+gb25_status gb25_fill_halo_regions(gb25_model *m);       /* src/precompile.jl:35,40,44-46 tupled_fill_halo_regions_workload! */
+gb25_status gb25_compute_auxiliaries(gb25_model *m);     /* src/precompile.jl:36,113-115  compute_auxiliaries_workload! */
+gb25_status gb25_fill_diffusivity_halos(gb25_model *m);  /* src/precompile.jl:37,117-119  (closure=nothing: no-op) */
+gb25_status gb25_compute_momentum_tendencies(gb25_model *m); /* src/precompile.jl:63-73  */
+gb25_status gb25_compute_tracer_tendencies(gb25_model *m);   /* src/precompile.jl:75-111 */
+gb25_status gb25_compute_boundary_tendencies(gb25_model *m); /* src/precompile.jl:52-61 (default no-flux: no-op) */
+gb25_status gb25_compute_tendencies(gb25_model *m);      /* src/precompile.jl:38,48-50 compute_tendencies_workload! */
+gb25_status gb25_ab2_step(gb25_model *m, double dt, int euler); /* src/precompile.jl:39,121-123 ab2_step_workload! */
+gb25_status gb25_correct_velocities_and_cache_previous_tendencies(gb25_model *m, double dt); /* src/precompile.jl:41,125-127 */
+gb25_status gb25_update_state(gb25_model *m);            /* Oceananigans.TimeSteppers.update_state! (correctness/..._run.jl:53-54) */
+
+/* ---- composites: GordonBell25.first_time_step!/time_step!/loop! (src/timestepping_utils.jl:21-45).
+ *      dt is read from the clock, the model is mutated in place, nothing is returned. */
+gb25_status gb25_first_time_step(gb25_model *m);
+gb25_status gb25_time_step(gb25_model *m);
+gb25_status gb25_loop(gb25_model *m, int32_t n_inner);
+
+/* ---- x-slab halo exchange: pack the columns a neighbour needs into a
+ *      contiguous device buffer / unpack received columns into the halo.  The host moves the
+ *      buffers (RCCL send/recv via torch.distributed in this repository).
+ *      group: 0 = 3-D prognostic bundle (u,v,T,S) + 2-D (eta,U,V); 1 = barotropic forcing (G.U, G.V).
+ *      side: 0 = west, 1 = east.  For pack, `side` is the side of THIS slab whose interior
+ *      columns are packed; for unpack it is the halo side that is filled. */
+gb25_status gb25_halo_buffer_elems(const gb25_model *m, int group, int64_t *n_floats);
+gb25_status gb25_halo_pack(gb25_model *m, int group, int side, float *dev_buffer);
+gb25_status gb25_halo_unpack(gb25_model *m, int group, int side, const float *dev_buffer);
+/* The distributed time step split at its exchange points (the host calls these in order
+ * and exchanges between them; gb25_time_step does all of it when nranks == 1):
+ *   stage 0: barotropic forcing G.U,G.V (then exchange group 1)
+ *   stage 1: AB2 update of u,v,T,S + split-explicit substeps (then exchange group 0)
+ *   stage 2: corrector + cache, y/z halos, auxiliaries, tendencies */
+gb25_status gb25_time_step_stage(gb25_model *m, int stage, int euler);
+gb25_status gb25_update_state_local(gb25_model *m); /* update_state! without the x-halo fill */
+gb25_status gb25_fill_halo_regions_local(gb25_model *m); /* y/z boundary halos only */
+
+/* ---- built-in per-kernel HIP-event timing (bench.py's roofline numbers) */
+gb25_status gb25_profile_enable(gb25_model *m, int on);
+gb25_status gb25_profile_reset(gb25_model *m);
+gb25_status gb25_profile_get(gb25_model *m, gb25_kernel k, int64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GB25_H */

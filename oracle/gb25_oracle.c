@@ -1,0 +1,865 @@
+/*
+ * gb25_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the Oceananigans HydrostaticFreeSurfaceModel time step
+ * that GB-25's baroclinic_instability_model drives.  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load this library, and only as
+ * the checker.  The product (gb-25_amd/, libgb25hip.so) never links or calls it.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in un-vendored Julia packages
+ * (Oceananigans.jl =0.96.26, SeawaterPolynomials.jl 0.3.9, ClimaOcean.jl 0.5.10 --
+ * /root/reference/Project.toml:32,37,42); Julia is absent from this image and the
+ * reference commits no golden vectors.  Everything below
+ * restates the published algorithms of those packages as recalled, anchored on the
+ * reference's call sites:
+ *   configuration   /root/reference/src/baroclinic_instability_model.jl:17-85
+ *   grid / IC       /root/reference/src/model_utils.jl:56-65,83-110
+ *   phase order     /root/reference/src/precompile.jl:31-42
+ *   entry points    /root/reference/src/timestepping_utils.jl:21-45
+ *   compared set    /root/reference/src/correctness.jl:28-90
+ *
+ * Conventions: logical indices are 1-based like the Julia sources (face i is the
+ * west face of cell i; face j the south face; face k the bottom face).  Parent
+ * arrays are column-major (i fastest) with halo H on every side, exactly
+ * Oceananigans' `parent(field)` shapes (v has Ny+1 faces, w has Nz+1 faces).
+ *
+ * Compile twice: -DREAL=double -DSFX=_f64 and -DREAL=float -DSFX=_f32.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#ifndef REAL
+#define REAL double
+#define SFX _f64
+#endif
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+#define FN(name) CAT(CAT(gb25o_, name), SFX)
+
+#define MAX_SUBSTEPS 512
+#define PAD 2 /* extra metric padding beyond the halo */
+
+typedef struct {
+  int Nx, Ny, Nz, H;
+  int substeps;
+  double dt, chi;
+  double lat_south, lat_north, lon_west, lon_east;
+  double depth, zexp_h;
+  double g, Omega, radius, rho0;
+} gb25o_config;
+
+typedef struct {
+  REAL *p;
+  int sx, sy, sz; /* parent dims */
+} fld;
+
+enum {
+  F_U = 0, F_V, F_W, F_T, F_S, F_P,
+  F_GNU, F_GNV, F_GNT, F_GNS,
+  F_GMU, F_GMV, F_GMT, F_GMS,
+  F_ETA, F_BU, F_BV, F_ETAB, F_UB, F_VB, F_GBU, F_GBV,
+  F_COUNT
+};
+
+typedef struct {
+  int Nx, Ny, Nz, H;
+  REAL dt, chi, g, Omega, R, rho0, Lz;
+  int Ns;               /* effective substeps */
+  REAL dtau_frac;       /* barotropic step as a fraction of dt */
+  REAL wts[MAX_SUBSTEPS];
+  /* latitude metrics, index j-1+H+PAD */
+  REAL *phif, *phic, *dxc, *dxf, *azc, *azf, *fcor;
+  REAL dy;
+  /* vertical, index k-1+H+PAD */
+  REAL *zf, *zc, *dzc, *dzf;
+  fld f[F_COUNT];
+  double time;
+  long iter;
+} model;
+
+/* ---------------------------------------------------------------- accessors */
+#define HH (m->H)
+#define IDX3(F, i, j, k) \
+  (((long)(i)-1 + HH) + (long)(F).sx * (((long)(j)-1 + HH) + (long)(F).sy * ((long)(k)-1 + HH)))
+#define IDX2(F, i, j) (((long)(i)-1 + HH) + (long)(F).sx * ((long)(j)-1 + HH))
+#define A3(id, i, j, k) (m->f[id].p[IDX3(m->f[id], i, j, k)])
+#define A2(id, i, j) (m->f[id].p[IDX2(m->f[id], i, j)])
+#define MJ(arr, j) (m->arr[(j)-1 + HH + PAD])
+#define MK(arr, k) (m->arr[(k)-1 + HH + PAD])
+#define DXC(j) MJ(dxc, j) /* dx at centre latitudes: dx^fc = dx^cc */
+#define DXF(j) MJ(dxf, j) /* dx at face latitudes:   dx^cf = dx^ff */
+#define AZC(j) MJ(azc, j) /* Az^cc = Az^fc */
+#define AZF(j) MJ(azf, j) /* Az^cf = Az^ff */
+#define FCOR(j) MJ(fcor, j)
+#define DZC(k) MK(dzc, k)
+#define DZF(k) MK(dzf, k)
+
+static void alloc_field(model *m, int id, int extra_y, int extra_z, int twod) {
+  fld *F = &m->f[id];
+  F->sx = m->Nx + 2 * m->H;
+  F->sy = m->Ny + 2 * m->H + extra_y;
+  F->sz = twod ? 1 : m->Nz + 2 * m->H + extra_z;
+  F->p = (REAL *)calloc((size_t)F->sx * F->sy * F->sz, sizeof(REAL));
+}
+
+/* ---------------------------------------------------------------- grid
+ * simple_latitude_longitude_grid: /root/reference/src/model_utils.jl:56-65.
+ * exponential_z_faces (ClimaOcean 0.5.10, restated): k = 1..Nz+1,
+ *   z_k = exp(k/h) affinely mapped so z_1 = 0, z_{Nz+1} = -depth, then reversed.
+ * LatitudeLongitudeGrid metrics (Oceananigans, restated).
+ */
+static void build_grid(model *m, const gb25o_config *c) {
+  int H = m->H, Ny = m->Ny, Nz = m->Nz;
+  int nj = Ny + 2 * H + 2 * PAD + 2, nk = Nz + 2 * H + 2 * PAD + 2;
+  double *phif = (double *)calloc(nj, sizeof(double));
+  double *phic = (double *)calloc(nj, sizeof(double));
+  m->phif = (REAL *)calloc(nj, sizeof(REAL));
+  m->phic = (REAL *)calloc(nj, sizeof(REAL));
+  m->dxc = (REAL *)calloc(nj, sizeof(REAL));
+  m->dxf = (REAL *)calloc(nj, sizeof(REAL));
+  m->azc = (REAL *)calloc(nj, sizeof(REAL));
+  m->azf = (REAL *)calloc(nj, sizeof(REAL));
+  m->fcor = (REAL *)calloc(nj, sizeof(REAL));
+  const double d2r = M_PI / 180.0;
+  double dlam = (c->lon_east - c->lon_west) / m->Nx;
+  double dphi = (c->lat_north - c->lat_south) / Ny;
+  double R = c->radius;
+  for (int a = 0; a < nj; a++) {
+    int j = a + 1 - H - PAD; /* logical index */
+    phif[a] = c->lat_south + (j - 1) * dphi;
+    phic[a] = c->lat_south + (j - 0.5) * dphi;
+  }
+  for (int a = 0; a < nj; a++) {
+    m->phif[a] = (REAL)phif[a];
+    m->phic[a] = (REAL)phic[a];
+    m->dxc[a] = (REAL)(R * cos(phic[a] * d2r) * dlam * d2r);
+    m->dxf[a] = (REAL)(R * cos(phif[a] * d2r) * dlam * d2r);
+    m->fcor[a] = (REAL)(2.0 * c->Omega * sin(phif[a] * d2r));
+    if (a + 1 < nj)
+      m->azc[a] = (REAL)(R * R * dlam * d2r * (sin(phif[a + 1] * d2r) - sin(phif[a] * d2r)));
+    if (a > 0)
+      m->azf[a] = (REAL)(R * R * dlam * d2r * (sin(phic[a] * d2r) - sin(phic[a - 1] * d2r)));
+  }
+  m->dy = (REAL)(R * dphi * d2r);
+  free(phif);
+  free(phic);
+
+  /* vertical */
+  double *zf = (double *)calloc(nk + 1, sizeof(double));
+  double *zc = (double *)calloc(nk, sizeof(double));
+  double *zint = (double *)calloc(Nz + 1, sizeof(double));
+  double h = c->zexp_h;
+  double e1 = exp(1.0 / h), eN = exp((Nz + 1.0) / h);
+  for (int k = 1; k <= Nz + 1; k++) {
+    double zk = -c->depth * (exp(k / h) - e1) / (eN - e1); /* 0 at k=1, -depth at k=Nz+1 */
+    zint[Nz + 1 - k] = zk;                                 /* reversed: zint[0] = -depth */
+  }
+  zint[Nz] = 0.0;
+  /* faces incl. halos: constant extension with the first/last interior spacing */
+  int off = H + PAD; /* array index of logical k=1 */
+  double dlo = zint[1] - zint[0], dhi = zint[Nz] - zint[Nz - 1];
+  for (int a = 0; a <= nk; a++) {
+    int k = a + 1 - off; /* logical face index */
+    if (k < 1) zf[a] = zint[0] + (k - 1) * dlo;
+    else if (k > Nz + 1) zf[a] = zint[Nz] + (k - Nz - 1) * dhi;
+    else zf[a] = zint[k - 1];
+  }
+  for (int a = 0; a < nk; a++) zc[a] = 0.5 * (zf[a] + zf[a + 1]);
+  m->zf = (REAL *)calloc(nk + 1, sizeof(REAL));
+  m->zc = (REAL *)calloc(nk, sizeof(REAL));
+  m->dzc = (REAL *)calloc(nk, sizeof(REAL));
+  m->dzf = (REAL *)calloc(nk, sizeof(REAL));
+  for (int a = 0; a <= nk; a++) m->zf[a] = (REAL)zf[a];
+  for (int a = 0; a < nk; a++) {
+    m->zc[a] = (REAL)zc[a];
+    m->dzc[a] = (REAL)(zf[a + 1] - zf[a]);
+    m->dzf[a] = (REAL)(a > 0 ? zc[a] - zc[a - 1] : zc[1] - zc[0]);
+  }
+  m->Lz = (REAL)(zint[Nz] - zint[0]);
+  free(zf);
+  free(zc);
+  free(zint);
+}
+
+/* Split-explicit averaging weights (Oceananigans FixedSubstepNumber, restated;
+ * SURVEY.md appendix A.7): shape function with p=2, q=4, r=0.18927 sampled at
+ * tau = 2m/Ns, m=1..Ns; searchsortedlast(weights, 0, rev=true) truncation; normalised. */
+static double shape_fn(double tau) {
+  const double p = 2, q = 4, r = 0.18927;
+  double tau0 = (p + 2) * (p + q + 2) / (p + 1) / (p + q + 1);
+  double x = tau / tau0;
+  return pow(x, p) * (1 - pow(x, q)) - r * x;
+}
+static void build_substeps(model *m, int substeps) {
+  double w[MAX_SUBSTEPS + 1];
+  for (int k = 1; k <= substeps; k++) w[k] = shape_fn(2.0 * k / substeps);
+  /* binary search exactly as Julia's searchsortedlast with Reverse ordering */
+  int lo = 0, hi = substeps + 1;
+  while (lo < hi - 1) {
+    int mid = lo + ((hi - lo) >> 1);
+    if (w[mid] < 0.0) hi = mid; else lo = mid;
+  }
+  int idx = lo;
+  double s = 0;
+  for (int k = 1; k <= idx; k++) s += w[k];
+  m->Ns = idx;
+  m->dtau_frac = (REAL)(2.0 / substeps);
+  for (int k = 1; k <= idx; k++) m->wts[k - 1] = (REAL)(w[k] / s);
+}
+
+/* ---------------------------------------------------------------- lifecycle */
+void *FN(create)(const gb25o_config *c) {
+  if (c->substeps > MAX_SUBSTEPS || c->Nx < 8 || c->Ny < 8 || c->Nz < 4 || c->H < 4) return NULL;
+  model *m = (model *)calloc(1, sizeof(model));
+  m->Nx = c->Nx; m->Ny = c->Ny; m->Nz = c->Nz; m->H = c->H;
+  m->dt = (REAL)c->dt; m->chi = (REAL)c->chi; m->g = (REAL)c->g;
+  m->Omega = (REAL)c->Omega; m->R = (REAL)c->radius; m->rho0 = (REAL)c->rho0;
+  build_grid(m, c);
+  build_substeps(m, c->substeps);
+  for (int id = 0; id < F_COUNT; id++) {
+    int isv = (id == F_V || id == F_GNV || id == F_GMV || id == F_BV || id == F_VB || id == F_GBV);
+    int isw = (id == F_W);
+    int twod = id >= F_ETA;
+    alloc_field(m, id, isv, isw, twod);
+  }
+  return m;
+}
+void FN(destroy)(void *h) {
+  model *m = (model *)h;
+  if (!m) return;
+  for (int id = 0; id < F_COUNT; id++) free(m->f[id].p);
+  free(m->phif); free(m->phic); free(m->dxc); free(m->dxf); free(m->azc); free(m->azf);
+  free(m->fcor); free(m->zf); free(m->zc); free(m->dzc); free(m->dzf);
+  free(m);
+}
+REAL *FN(field_ptr)(void *h, int id) { return ((model *)h)->f[id].p; }
+void FN(field_dims)(void *h, int id, int *d) {
+  model *m = (model *)h;
+  d[0] = m->f[id].sx; d[1] = m->f[id].sy; d[2] = m->f[id].sz;
+}
+/* metric id: 0 phif 1 phic 2 dxc 3 dxf 4 azc 5 azf 6 fcor 7 zf 8 zc 9 dzc 10 dzf; value at logical index */
+double FN(metric)(void *h, int id, int idx) {
+  model *m = (model *)h;
+  REAL *a[] = {m->phif, m->phic, m->dxc, m->dxf, m->azc, m->azf, m->fcor, m->zf, m->zc, m->dzc, m->dzf};
+  return (double)a[id][idx - 1 + m->H + PAD];
+}
+double FN(dy)(void *h) { return (double)((model *)h)->dy; }
+int FN(substep_info)(void *h, double *dtau_frac, double *w) {
+  model *m = (model *)h;
+  *dtau_frac = m->dtau_frac;
+  for (int k = 0; k < m->Ns; k++) w[k] = m->wts[k];
+  return m->Ns;
+}
+void FN(set_dt)(void *h, double dt) { ((model *)h)->dt = (REAL)dt; }
+double FN(get_time)(void *h) { return ((model *)h)->time; }
+long FN(get_iteration)(void *h) { return ((model *)h)->iter; }
+
+/* ---------------------------------------------------------------- TEOS-10
+ * SeawaterPolynomials.TEOS10EquationOfState (Roquet et al. 2015, 55-term polynomial),
+ * restated from the published coefficient table.  rho = r0(zeta) + r'(tau, s, zeta),
+ * tau = Theta/40, s = sqrt((S_A + 32) * 0.875/35.16504), zeta = -Z/1e4;
+ * rho' = rho - reference_density (1020 kg/m3). */
+static inline REAL teos10_rho(REAL Theta, REAL Sa, REAL Z) {
+  const REAL t = Theta * (REAL)0.025;
+  const REAL s = (REAL)sqrt((double)((Sa + (REAL)32.0) * (REAL)(0.875 / 35.16504)));
+  const REAL z = -Z * (REAL)1e-4;
+  const REAL R000 = 8.0189615746e+02, R100 = 8.6672408165e+02, R200 = -1.7864682637e+03,
+             R300 = 2.0375295546e+03, R400 = -1.2849161071e+03, R500 = 4.3227585684e+02,
+             R600 = -6.0579916612e+01, R010 = 2.6010145068e+01, R110 = -6.5281885265e+01,
+             R210 = 8.1770425108e+01, R310 = -5.6888046321e+01, R410 = 1.7681814114e+01,
+             R510 = -1.9193502195e+00, R020 = -3.7074170417e+01, R120 = 6.1548258127e+01,
+             R220 = -6.0362551501e+01, R320 = 2.9130021253e+01, R420 = -5.4723692739e+00,
+             R030 = 2.1661789529e+01, R130 = -3.3449108469e+01, R230 = 1.9717078466e+01,
+             R330 = -3.1742946532e+00, R040 = -8.3627885467e+00, R140 = 1.1311538584e+01,
+             R240 = -5.3563304045e+00, R050 = 5.4048723791e-01, R150 = 4.8169980163e-01,
+             R060 = -1.9083568888e-01, R001 = 1.9681925209e+01, R101 = -4.2549998214e+01,
+             R201 = 5.0774768218e+01, R301 = -3.0938076334e+01, R401 = 6.6051753097e+00,
+             R011 = -1.3336301113e+01, R111 = -4.4870114575e+00, R211 = 5.0042598061e+00,
+             R311 = -6.5399043664e-01, R021 = 6.7080479603e+00, R121 = 3.5063081279e+00,
+             R221 = -1.8795372996e+00, R031 = -2.4649669534e+00, R131 = -5.5077101279e-01,
+             R041 = 5.5927935970e-01, R002 = 2.0660924175e+00, R102 = -4.9527603989e+00,
+             R202 = 2.5019633244e+00, R012 = 2.0564311499e+00, R112 = -2.1311365518e-01,
+             R022 = -1.2419983026e+00, R003 = -2.3342758797e-02, R103 = -1.8507636718e-02,
+             R013 = 3.7969820455e-01;
+  const REAL R00 = 4.6494977072e+01, R01 = -5.2099962525e+00, R02 = 2.2601900708e-01,
+             R03 = 6.4326772569e-02, R04 = 1.5616995503e-02, R05 = -1.7243708991e-03;
+  REAL r3 = R013 * t + R103 * s + R003;
+  REAL r2 = (R022 * t + R112 * s + R012) * t + (R202 * s + R102) * s + R002;
+  REAL r1 = (((R041 * t + R131 * s + R031) * t + (R221 * s + R121) * s + R021) * t +
+             ((R311 * s + R211) * s + R111) * s + R011) * t +
+            (((R401 * s + R301) * s + R201) * s + R101) * s + R001;
+  REAL r0 = (((((R060 * t + R150 * s + R050) * t + (R240 * s + R140) * s + R040) * t +
+               ((R330 * s + R230) * s + R130) * s + R030) * t +
+              (((R420 * s + R320) * s + R220) * s + R120) * s + R020) * t +
+             ((((R510 * s + R410) * s + R310) * s + R210) * s + R110) * s + R010) * t +
+            (((((R600 * s + R500) * s + R400) * s + R300) * s + R200) * s + R100) * s + R000;
+  REAL rp = ((r3 * z + r2) * z + r1) * z + r0;
+  REAL rz = (((((R05 * z + R04) * z + R03) * z + R02) * z + R01) * z + R00) * z;
+  return rz + rp;
+}
+double FN(teos10_rho)(double T, double S, double Z) { return (double)teos10_rho((REAL)T, (REAL)S, (REAL)Z); }
+
+/* geopotential height of a cell centre, mirrored through the boundary outside 1..Nz
+ * (Oceananigans Z^ccc, restated). */
+static inline REAL Zccc(const model *m, int k) {
+  if (k < 1) return MK(zc, 1) + (REAL)(1 - k) * DZF(1);
+  if (k > m->Nz) return MK(zc, m->Nz) - (REAL)(k - m->Nz) * DZF(m->Nz);
+  return MK(zc, k);
+}
+/* buoyancy perturbation b = -g rho'/rho0 at (i,j,k) (SeawaterBuoyancy, restated) */
+static inline REAL buoyancy(const model *m, int i, int j, int k) {
+  REAL rho = teos10_rho(A3(F_T, i, j, k), A3(F_S, i, j, k), Zccc(m, k));
+  return -(m->g * (rho - m->rho0)) / m->rho0;
+}
+
+/* ---------------------------------------------------------------- WENO
+ * Oceananigans WENO{N} with uniform coefficients and Z-weights (appendix A.9).
+ * Inputs are ordered from most-upwind (a) to most-downwind (e); left/right bias only
+ * changes which grid points are gathered.  Smoothness uses the expanded quadratic
+ * form with integer coefficients; eps = 1e-8. */
+#define WENO_EPS ((REAL)1e-8)
+static inline REAL beta5_0(REAL c, REAL d, REAL e) { /* (10,-31,11,25,-19,4) */
+  return c * ((REAL)10 * c - (REAL)31 * d + (REAL)11 * e) + d * ((REAL)25 * d - (REAL)19 * e) + (REAL)4 * e * e;
+}
+static inline REAL beta5_1(REAL b, REAL c, REAL d) { /* (4,-13,5,13,-13,4) */
+  return b * ((REAL)4 * b - (REAL)13 * c + (REAL)5 * d) + c * ((REAL)13 * c - (REAL)13 * d) + (REAL)4 * d * d;
+}
+static inline REAL beta5_2(REAL a, REAL b, REAL c) { /* (4,-19,11,25,-31,10) */
+  return a * ((REAL)4 * a - (REAL)19 * b + (REAL)11 * c) + b * ((REAL)25 * b - (REAL)31 * c) + (REAL)10 * c * c;
+}
+/* Z-weights alpha_s = C_s (1 + (tau/(beta_s+eps))^2), evaluated as C_s (1 + (q rho_s)^2) with
+ * q = tau/b_min and rho_s = b_min/b_s <= 1 so that q can be capped: in fp32 tau/b reaches 1e18 when one
+ * indicator cancels to zero next to area-weighted divergences of O(1e8), and its square overflows.
+ * The cap never binds in fp64 (exact same weights); in fp32 it changes weights below round-off. */
+#define ZCAP ((REAL)(sizeof(REAL) == 4 ? 1e9 : 1e100))
+static inline REAL zq(REAL tau, REAL bmin) {
+  REAL q = tau / bmin;
+  return q < ZCAP ? q : ZCAP;
+}
+/* v[0..4] = a..e values to reconstruct; b0,b1,b2 smoothness indicators */
+static inline REAL weno5_combine(const REAL *v, REAL b0, REAL b1, REAL b2) {
+  REAL a = v[0], b = v[1], c = v[2], d = v[3], e = v[4];
+  REAL p0 = ((REAL)2 * c + (REAL)5 * d - e) / (REAL)6;
+  REAL p1 = (-b + (REAL)5 * c + (REAL)2 * d) / (REAL)6;
+  REAL p2 = ((REAL)2 * a - (REAL)7 * b + (REAL)11 * c) / (REAL)6;
+  REAL tau = (REAL)fabs((double)(b0 - b2));
+  /* the expanded quadratic forms can round to small negative numbers: clamp (a no-op in exact arithmetic) */
+  b0 = (b0 > 0 ? b0 : 0) + WENO_EPS; b1 = (b1 > 0 ? b1 : 0) + WENO_EPS; b2 = (b2 > 0 ? b2 : 0) + WENO_EPS;
+  REAL bmin = b0 < b1 ? (b0 < b2 ? b0 : b2) : (b1 < b2 ? b1 : b2);
+  REAL q = zq(tau, bmin);
+  REAL r0 = q * (bmin / b0), r1 = q * (bmin / b1), r2 = q * (bmin / b2);
+  REAL a0 = (REAL)0.3 * ((REAL)1 + r0 * r0), a1 = (REAL)0.6 * ((REAL)1 + r1 * r1), a2 = (REAL)0.1 * ((REAL)1 + r2 * r2);
+  return (a0 * p0 + a1 * p1 + a2 * p2) / (a0 + a1 + a2);
+}
+static inline REAL weno3_combine(const REAL *v, REAL b0, REAL b1) {
+  REAL b = v[1], c = v[2], d = v[3];
+  REAL p0 = (c + d) / (REAL)2;
+  REAL p1 = (-b + (REAL)3 * c) / (REAL)2;
+  REAL tau = (REAL)fabs((double)(b0 - b1));
+  b0 = (b0 > 0 ? b0 : 0) + WENO_EPS; b1 = (b1 > 0 ? b1 : 0) + WENO_EPS;
+  REAL bmin = b0 < b1 ? b0 : b1;
+  REAL q = zq(tau, bmin);
+  REAL r0 = q * (bmin / b0), r1 = q * (bmin / b1);
+  REAL a0 = (REAL)(2.0 / 3.0) * ((REAL)1 + r0 * r0), a1 = (REAL)(1.0 / 3.0) * ((REAL)1 + r1 * r1);
+  return (a0 * p0 + a1 * p1) / (a0 + a1);
+}
+static inline REAL beta3(REAL x, REAL y) { return x * (x - (REAL)2 * y) + y * y; } /* (1,-2,1) */
+
+double FN(weno5)(double a, double b, double c, double d, double e) {
+  REAL v[5] = {(REAL)a, (REAL)b, (REAL)c, (REAL)d, (REAL)e};
+  return (double)weno5_combine(v, beta5_0(v[2], v[3], v[4]), beta5_1(v[1], v[2], v[3]), beta5_2(v[0], v[1], v[2]));
+}
+double FN(weno3)(double b, double c, double d) {
+  REAL v[5] = {0, (REAL)b, (REAL)c, (REAL)d, 0};
+  return (double)weno3_combine(v, beta3(v[2], v[3]), beta3(v[1], v[2]));
+}
+
+/* ---------------------------------------------------------------- stencil functions */
+typedef REAL (*fn3)(const model *, int, int, int);
+static REAL f_u(const model *m, int i, int j, int k) { return A3(F_U, i, j, k); }
+static REAL f_v(const model *m, int i, int j, int k) { return A3(F_V, i, j, k); }
+static REAL f_T(const model *m, int i, int j, int k) { return A3(F_T, i, j, k); }
+static REAL f_S(const model *m, int i, int j, int k) { return A3(F_S, i, j, k); }
+static REAL f_Azw(const model *m, int i, int j, int k) { return AZC(j) * A3(F_W, i, j, k); }
+/* vertical vorticity zeta at (f,f,c) */
+static REAL f_zeta(const model *m, int i, int j, int k) {
+  REAL circ = (m->dy * A3(F_V, i, j, k) - m->dy * A3(F_V, i - 1, j, k)) -
+              (DXC(j) * A3(F_U, i, j, k) - DXC(j - 1) * A3(F_U, i, j - 1, k));
+  return circ / AZF(j);
+}
+/* VelocityStencil smoothness inputs at (f,f,c) */
+static REAL f_uy(const model *m, int i, int j, int k) { return (A3(F_U, i, j - 1, k) + A3(F_U, i, j, k)) / (REAL)2; }
+static REAL f_vx(const model *m, int i, int j, int k) { return (A3(F_V, i - 1, j, k) + A3(F_V, i, j, k)) / (REAL)2; }
+/* delta_x(Ax u), delta_y(Ay v) at (c,c,c) */
+static REAL f_dxU(const model *m, int i, int j, int k) {
+  REAL Ax = m->dy * DZC(k);
+  return Ax * A3(F_U, i + 1, j, k) - Ax * A3(F_U, i, j, k);
+}
+static REAL f_dyV(const model *m, int i, int j, int k) {
+  return DXF(j + 1) * DZC(k) * A3(F_V, i, j + 1, k) - DXF(j) * DZC(k) * A3(F_V, i, j, k);
+}
+static REAL f_div(const model *m, int i, int j, int k) { return f_dxU(m, i, j, k) + f_dyV(m, i, j, k); }
+static inline REAL half_sq(REAL x) { return x * x / (REAL)2; }
+static REAL f_dxu2(const model *m, int i, int j, int k) { return half_sq(A3(F_U, i + 1, j, k)) - half_sq(A3(F_U, i, j, k)); }
+static REAL f_dyv2(const model *m, int i, int j, int k) { return half_sq(A3(F_V, i, j + 1, k)) - half_sq(A3(F_V, i, j, k)); }
+static REAL f_dxv2(const model *m, int i, int j, int k) { return half_sq(A3(F_V, i, j, k)) - half_sq(A3(F_V, i - 1, j, k)); }
+static REAL f_dyu2(const model *m, int i, int j, int k) { return half_sq(A3(F_U, i, j, k)) - half_sq(A3(F_U, i, j - 1, k)); }
+static REAL f_usm(const model *m, int i, int j, int k) { return (A3(F_U, i, j, k) + A3(F_U, i + 1, j, k)) / (REAL)2; }
+static REAL f_vsm(const model *m, int i, int j, int k) { return (A3(F_V, i, j, k) + A3(F_V, i, j + 1, k)) / (REAL)2; }
+
+enum { DX = 0, DY = 1, DZ = 2 };
+enum { TO_FACE = 0, TO_CENTER = 1 };
+
+static inline REAL at_dir(const model *m, fn3 f, int dir, int i, int j, int k, int p) {
+  return dir == DX ? f(m, p, j, k) : dir == DY ? f(m, i, p, k) : f(m, i, j, p);
+}
+
+/* Upwind-biased reconstruction of psi along `dir` to a face / centre with index idx
+ * (the component of (i,j,k) along dir).  left != 0: LeftBias (advecting velocity > 0).
+ * s1/s2: optional smoothness functions (FunctionStencil: s1; VelocityStencil: s1,s2).
+ * Bounded directions (y, z) drop to WENO3 and first-order upwind next to the walls
+ * (topologically conditional interpolation, restated). */
+static REAL biased_interp(const model *m, int dir, int target, int i, int j, int k, int left, fn3 psi, fn3 s1, fn3 s2) {
+  int idx = dir == DX ? i : dir == DY ? j : k;
+  int N = dir == DX ? m->Nx : dir == DY ? m->Ny : m->Nz;
+  int order = 5;
+  if (dir != DX) {
+    if (target == TO_FACE) order = (idx >= 4 && idx <= N - 2) ? 5 : (idx >= 3 && idx <= N - 1) ? 3 : 1;
+    else order = (idx >= 3 && idx <= N - 2) ? 5 : (idx >= 2 && idx <= N - 1) ? 3 : 1;
+  }
+  int c0 = target == TO_FACE ? (left ? idx - 1 : idx) : (left ? idx : idx + 1);
+  int sg = left ? 1 : -1;
+  if (order == 1) return at_dir(m, psi, dir, i, j, k, c0);
+  REAL v[5] = {0, 0, 0, 0, 0}, x[5], y[5];
+  int q0 = order == 5 ? -2 : -1, q1 = order == 5 ? 2 : 1;
+  for (int q = q0; q <= q1; q++) v[q + 2] = at_dir(m, psi, dir, i, j, k, c0 + sg * q);
+  const REAL *bs = v;
+  if (s1) {
+    for (int q = q0; q <= q1; q++) x[q + 2] = at_dir(m, s1, dir, i, j, k, c0 + sg * q);
+    bs = x;
+  }
+  if (s2)
+    for (int q = q0; q <= q1; q++) y[q + 2] = at_dir(m, s2, dir, i, j, k, c0 + sg * q);
+  if (order == 5) {
+    REAL b0 = beta5_0(bs[2], bs[3], bs[4]), b1 = beta5_1(bs[1], bs[2], bs[3]), b2 = beta5_2(bs[0], bs[1], bs[2]);
+    if (s2) {
+      b0 = (b0 + beta5_0(y[2], y[3], y[4])) / (REAL)2;
+      b1 = (b1 + beta5_1(y[1], y[2], y[3])) / (REAL)2;
+      b2 = (b2 + beta5_2(y[0], y[1], y[2])) / (REAL)2;
+    }
+    return weno5_combine(v, b0, b1, b2);
+  } else {
+    REAL b0 = beta3(bs[2], bs[3]), b1 = beta3(bs[1], bs[2]);
+    if (s2) {
+      b0 = (b0 + beta3(y[2], y[3])) / (REAL)2;
+      b1 = (b1 + beta3(y[1], y[2])) / (REAL)2;
+    }
+    return weno3_combine(v, b0, b1);
+  }
+}
+
+/* Symmetric (centred) interpolation used for advecting velocities / cross terms:
+ * the WENO5 scheme's advecting_velocity_scheme is Centered(order=4); next to walls in
+ * bounded directions it drops to second order. */
+static REAL sym_interp(const model *m, int dir, int target, int i, int j, int k, fn3 psi) {
+  int idx = dir == DX ? i : dir == DY ? j : k;
+  int N = dir == DX ? m->Nx : dir == DY ? m->Ny : m->Nz;
+  int order = 4;
+  if (dir != DX) {
+    if (target == TO_FACE) order = (idx >= 4 && idx <= N - 2) ? 4 : 2;
+    else order = (idx >= 3 && idx <= N - 2) ? 4 : 2;
+  }
+  int b = target == TO_FACE ? idx - 1 : idx; /* the lower of the two central points */
+  if (order == 2) return (at_dir(m, psi, dir, i, j, k, b) + at_dir(m, psi, dir, i, j, k, b + 1)) / (REAL)2;
+  return (-at_dir(m, psi, dir, i, j, k, b - 1) + (REAL)7 * at_dir(m, psi, dir, i, j, k, b) +
+          (REAL)7 * at_dir(m, psi, dir, i, j, k, b + 1) - at_dir(m, psi, dir, i, j, k, b + 2)) / (REAL)12;
+}
+
+/* ---------------------------------------------------------------- halos
+ * tupled_fill_halo_regions!(prognostic_fields(model), ...) -- /root/reference/src/precompile.jl:35,40,44-46.
+ * Default boundary conditions (appendix A.3): bounded y / z fill ONE halo layer
+ * (zero-gradient for centre-located axes, zero wall-normal velocity); periodic x is
+ * filled last over the whole parent extent so corners are consistent. */
+static void fill_periodic_x(const model *m, fld *F) {
+  int H = m->H, Nx = m->Nx;
+  for (long r = 0; r < (long)F->sy * F->sz; r++) {
+    REAL *row = F->p + r * F->sx;
+    for (int q = 0; q < H; q++) {
+      row[q] = row[Nx + q];         /* west halo  <- east interior */
+      row[H + Nx + q] = row[H + q]; /* east halo  <- west interior */
+    }
+  }
+}
+static void fill_halo_3d(model *m, int id, int is_v) {
+  int Nx = m->Nx, Ny = m->Ny, Nz = m->Nz;
+  for (int k = 1; k <= Nz; k++)
+    for (int i = 1; i <= Nx; i++) {
+      if (is_v) {
+        A3(id, i, 1, k) = 0;
+        A3(id, i, Ny + 1, k) = 0;
+      } else {
+        A3(id, i, 0, k) = A3(id, i, 1, k);
+        A3(id, i, Ny + 1, k) = A3(id, i, Ny, k);
+      }
+    }
+  for (int j = 1; j <= Ny; j++)
+    for (int i = 1; i <= Nx; i++) {
+      A3(id, i, j, 0) = A3(id, i, j, 1);
+      A3(id, i, j, Nz + 1) = A3(id, i, j, Nz);
+    }
+  fill_periodic_x(m, &m->f[id]);
+}
+static void fill_halo_2d(model *m, int id, int is_v) {
+  int Nx = m->Nx, Ny = m->Ny;
+  for (int i = 1; i <= Nx; i++) {
+    if (is_v) {
+      A2(id, i, 1) = 0;
+      A2(id, i, Ny + 1) = 0;
+    } else {
+      A2(id, i, 0) = A2(id, i, 1);
+      A2(id, i, Ny + 1) = A2(id, i, Ny);
+    }
+  }
+  fill_periodic_x(m, &m->f[id]);
+}
+void FN(fill_halos)(void *h) {
+  model *m = (model *)h;
+  fill_halo_3d(m, F_U, 0);
+  fill_halo_3d(m, F_V, 1);
+  fill_halo_3d(m, F_T, 0);
+  fill_halo_3d(m, F_S, 0);
+  fill_halo_2d(m, F_ETA, 0);
+  fill_halo_2d(m, F_BU, 0);
+  fill_halo_2d(m, F_BV, 1);
+}
+
+/* ---------------------------------------------------------------- auxiliaries
+ * compute_auxiliaries!(model) -- /root/reference/src/precompile.jl:36,113-115.
+ * Both kernels run on the extended range -H+2 : N+H-1 in x and y (appendix A.5). */
+void FN(compute_w)(void *h) {
+  model *m = (model *)h;
+  int H = m->H;
+#pragma omp parallel for schedule(static)
+  for (int j = -H + 2; j <= m->Ny + H - 1; j++)
+    for (int i = -H + 2; i <= m->Nx + H - 1; i++) {
+      A3(F_W, i, j, 1) = 0;
+      for (int k = 2; k <= m->Nz + 1; k++) {
+        REAL dh = f_div(m, i, j, k - 1) / AZC(j);
+        A3(F_W, i, j, k) = A3(F_W, i, j, k - 1) - dh;
+      }
+    }
+}
+void FN(compute_p)(void *h) {
+  model *m = (model *)h;
+  int H = m->H, Nz = m->Nz;
+#pragma omp parallel for schedule(static)
+  for (int j = -H + 2; j <= m->Ny + H - 1; j++)
+    for (int i = -H + 2; i <= m->Nx + H - 1; i++) {
+      REAL bup = buoyancy(m, i, j, Nz + 1);
+      REAL bk = buoyancy(m, i, j, Nz);
+      A3(F_P, i, j, Nz) = -((bk + bup) / (REAL)2) * DZF(Nz + 1);
+      for (int k = Nz - 1; k >= 1; k--) {
+        bup = bk;
+        bk = buoyancy(m, i, j, k);
+        A3(F_P, i, j, k) = A3(F_P, i, j, k + 1) - ((bk + bup) / (REAL)2) * DZF(k + 1);
+      }
+    }
+}
+void FN(compute_auxiliaries)(void *h) {
+  FN(compute_w)(h);
+  FN(compute_p)(h);
+}
+
+/* ---------------------------------------------------------------- tendencies
+ * compute_tendencies!(model, callbacks) -- /root/reference/src/precompile.jl:38,48-50,63-111.
+ * Momentum: WENOVectorInvariant(order=5) with VelocityStencil vorticity smoothness and
+ * OnlySelfUpwinding(cross_scheme = WENO5) (appendix A.11), HydrostaticSphericalCoriolis
+ * (enstrophy conserving), hydrostatic pressure gradient.  Tracers: WENO(order=5) flux form. */
+static REAL Gu_at(const model *m, int i, int j, int k) {
+  /* advecting v at (f,c,c) */
+  REAL vhat = ((DXF(j) * A3(F_V, i - 1, j, k) + DXF(j + 1) * A3(F_V, i - 1, j + 1, k)) / (REAL)2 +
+               (DXF(j) * A3(F_V, i, j, k) + DXF(j + 1) * A3(F_V, i, j + 1, k)) / (REAL)2) / (REAL)2 / DXC(j);
+  REAL zetaR = biased_interp(m, DY, TO_CENTER, i, j, k, vhat > 0, f_zeta, f_uy, f_vx);
+  REAL hadv = -vhat * zetaR;
+  /* vertical advection: upwinded divergence flux + vertical flux divergence */
+  REAL uhat = A3(F_U, i, j, k);
+  REAL dvs = sym_interp(m, DX, TO_FACE, i, j, k, f_dyV);
+  REAL duR = biased_interp(m, DX, TO_FACE, i, j, k, uhat > 0, f_dxU, f_div, NULL);
+  REAL phi = uhat * (dvs + duR);
+  REAL fz[2];
+  for (int t = 0; t < 2; t++) {
+    int kk = k + t;
+    REAL wt = sym_interp(m, DX, TO_FACE, i, j, kk, f_Azw);
+    REAL uR = biased_interp(m, DZ, TO_FACE, i, j, kk, wt > 0, f_u, NULL, NULL);
+    fz[t] = wt * uR;
+  }
+  REAL vadv = (phi + (fz[1] - fz[0])) / (AZC(j) * DZC(k));
+  /* Bernoulli head */
+  REAL dKu = biased_interp(m, DX, TO_FACE, i, j, k, uhat > 0, f_dxu2, f_usm, NULL);
+  REAL dKv = sym_interp(m, DY, TO_CENTER, i, j, k, f_dxv2);
+  REAL bern = (dKu + dKv) / DXC(j);
+  /* Coriolis: x_f_cross_U = -Iy(f) * vhat */
+  REAL fbar = (FCOR(j) + FCOR(j + 1)) / (REAL)2;
+  REAL cor = -fbar * vhat;
+  REAL dpdx = (A3(F_P, i, j, k) - A3(F_P, i - 1, j, k)) / DXC(j);
+  return -(hadv + vadv + bern) - cor - dpdx;
+}
+static REAL Gv_at(const model *m, int i, int j, int k) {
+  /* advecting u at (c,f,c) */
+  REAL uhat = ((m->dy * A3(F_U, i, j - 1, k) + m->dy * A3(F_U, i + 1, j - 1, k)) / (REAL)2 +
+               (m->dy * A3(F_U, i, j, k) + m->dy * A3(F_U, i + 1, j, k)) / (REAL)2) / (REAL)2 / m->dy;
+  REAL zetaR = biased_interp(m, DX, TO_CENTER, i, j, k, uhat > 0, f_zeta, f_uy, f_vx);
+  REAL hadv = uhat * zetaR;
+  REAL vhat = A3(F_V, i, j, k);
+  REAL dus = sym_interp(m, DY, TO_FACE, i, j, k, f_dxU);
+  REAL dvR = biased_interp(m, DY, TO_FACE, i, j, k, vhat > 0, f_dyV, f_div, NULL);
+  REAL phi = vhat * (dus + dvR);
+  REAL fz[2];
+  for (int t = 0; t < 2; t++) {
+    int kk = k + t;
+    REAL wt = sym_interp(m, DY, TO_FACE, i, j, kk, f_Azw);
+    REAL vR = biased_interp(m, DZ, TO_FACE, i, j, kk, wt > 0, f_v, NULL, NULL);
+    fz[t] = wt * vR;
+  }
+  REAL vadv = (phi + (fz[1] - fz[0])) / (AZF(j) * DZC(k));
+  REAL dKv = biased_interp(m, DY, TO_FACE, i, j, k, vhat > 0, f_dyv2, f_vsm, NULL);
+  REAL dKu = sym_interp(m, DX, TO_CENTER, i, j, k, f_dyu2);
+  REAL bern = (dKv + dKu) / m->dy;
+  REAL cor = FCOR(j) * uhat;
+  REAL dpdy = (A3(F_P, i, j, k) - A3(F_P, i, j - 1, k)) / m->dy;
+  return -(hadv + vadv + bern) - cor - dpdy;
+}
+void FN(compute_momentum_tendencies)(void *h) {
+  model *m = (model *)h;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int k = 1; k <= m->Nz; k++)
+    for (int j = 1; j <= m->Ny; j++)
+      for (int i = 1; i <= m->Nx; i++) {
+        A3(F_GNU, i, j, k) = Gu_at(m, i, j, k);
+        A3(F_GNV, i, j, k) = Gv_at(m, i, j, k);
+      }
+}
+static REAL tracer_flux(const model *m, int dir, int i, int j, int k, fn3 c) {
+  if (dir == DX) {
+    REAL u = A3(F_U, i, j, k);
+    return m->dy * DZC(k) * u * biased_interp(m, DX, TO_FACE, i, j, k, u > 0, c, NULL, NULL);
+  } else if (dir == DY) {
+    REAL v = A3(F_V, i, j, k);
+    return DXF(j) * DZC(k) * v * biased_interp(m, DY, TO_FACE, i, j, k, v > 0, c, NULL, NULL);
+  } else {
+    REAL w = A3(F_W, i, j, k);
+    return AZC(j) * w * biased_interp(m, DZ, TO_FACE, i, j, k, w > 0, c, NULL, NULL);
+  }
+}
+static void tracer_tendency(model *m, int gid, fn3 c) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int k = 1; k <= m->Nz; k++)
+    for (int j = 1; j <= m->Ny; j++)
+      for (int i = 1; i <= m->Nx; i++) {
+        REAL div = (tracer_flux(m, DX, i + 1, j, k, c) - tracer_flux(m, DX, i, j, k, c)) +
+                   (tracer_flux(m, DY, i, j + 1, k, c) - tracer_flux(m, DY, i, j, k, c)) +
+                   (tracer_flux(m, DZ, i, j, k + 1, c) - tracer_flux(m, DZ, i, j, k, c));
+        A3(gid, i, j, k) = -(div / (AZC(j) * DZC(k)));
+      }
+}
+void FN(compute_tracer_tendencies)(void *h) {
+  model *m = (model *)h;
+  tracer_tendency(m, F_GNT, f_T);
+  tracer_tendency(m, F_GNS, f_S);
+}
+void FN(compute_tendencies)(void *h) {
+  FN(compute_momentum_tendencies)(h);
+  FN(compute_tracer_tendencies)(h);
+}
+/* update_state!(model; compute_tendencies=true): phases 1-5 of /root/reference/src/precompile.jl:34-38
+ * (mask_immersed and diffusivity halos are no-ops for this configuration). */
+void FN(update_state)(void *h) {
+  FN(fill_halos)(h);
+  FN(compute_auxiliaries)(h);
+  FN(compute_tendencies)(h);
+}
+
+/* ---------------------------------------------------------------- AB2 + free surface
+ * ab2_step!(model, dt) -- /root/reference/src/precompile.jl:39,121-123 (appendix A.4, A.7). */
+static void barotropic_mode(model *m, int idU, int idV) {
+#pragma omp parallel for schedule(static)
+  for (int j = 1; j <= m->Ny; j++)
+    for (int i = 1; i <= m->Nx; i++) {
+      REAL su = DZC(1) * A3(F_U, i, j, 1), sv = DZC(1) * A3(F_V, i, j, 1);
+      for (int k = 2; k <= m->Nz; k++) {
+        su += DZC(k) * A3(F_U, i, j, k);
+        sv += DZC(k) * A3(F_V, i, j, k);
+      }
+      A2(idU, i, j) = su;
+      A2(idV, i, j) = sv;
+    }
+}
+static inline REAL ab2_G(const model *m, int gn, int gm, int i, int j, int k, REAL chi) {
+  REAL C1 = (REAL)1.5 + chi, C2 = (REAL)0.5 + chi;
+  REAL not_euler = (C2 != 0) ? (REAL)1 : (REAL)0;
+  return C1 * A3(gn, i, j, k) - A3(gm, i, j, k) * C2 * not_euler;
+}
+static void free_surface_tendency(model *m, REAL chi) {
+#pragma omp parallel for schedule(static)
+  for (int j = 1; j <= m->Ny; j++)
+    for (int i = 1; i <= m->Nx; i++) {
+      REAL su = DZC(1) * ab2_G(m, F_GNU, F_GMU, i, j, 1, chi);
+      REAL sv = (j == 1) ? 0 : DZC(1) * ab2_G(m, F_GNV, F_GMV, i, j, 1, chi);
+      for (int k = 2; k <= m->Nz; k++) {
+        su += DZC(k) * ab2_G(m, F_GNU, F_GMU, i, j, k, chi);
+        sv += (j == 1) ? 0 : DZC(k) * ab2_G(m, F_GNV, F_GMV, i, j, k, chi);
+      }
+      A2(F_GBU, i, j) = su;
+      A2(F_GBV, i, j) = sv;
+    }
+  fill_halo_2d(m, F_GBU, 0);
+  fill_halo_2d(m, F_GBV, 1);
+}
+static void ab2_field(model *m, int id, int gn, int gm, REAL dt, REAL chi, int velocity) {
+  REAL C1 = (REAL)1.5 + chi, C2 = (REAL)0.5 + chi;
+  REAL not_euler = (chi != (REAL)-0.5) ? (REAL)1 : (REAL)0;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int k = 1; k <= m->Nz; k++)
+    for (int j = 1; j <= m->Ny; j++)
+      for (int i = 1; i <= m->Nx; i++) {
+        if (velocity) {
+          REAL G = C1 * A3(gn, i, j, k) - C2 * A3(gm, i, j, k) * not_euler;
+          A3(id, i, j, k) += dt * G;
+        } else {
+          REAL G = C1 * A3(gn, i, j, k) - C2 * A3(gm, i, j, k);
+          A3(id, i, j, k) = A3(id, i, j, k) + dt * G;
+        }
+      }
+}
+static void step_free_surface(model *m, REAL dt) {
+  int Nx = m->Nx, Ny = m->Ny;
+  REAL dtau = m->dtau_frac * dt;
+  REAL Hc = m->Lz;
+  for (int id = F_ETAB; id <= F_VB; id++)
+    memset(m->f[id].p, 0, sizeof(REAL) * (size_t)m->f[id].sx * m->f[id].sy);
+  for (int s = 0; s < m->Ns; s++) {
+    REAL wgt = m->wts[s];
+#pragma omp parallel for schedule(static)
+    for (int j = 1; j <= Ny; j++)
+      for (int i = 1; i <= Nx; i++) {
+        int ip = (i == Nx) ? 1 : i + 1;
+        REAL dxU = m->dy * A2(F_BU, ip, j) - m->dy * A2(F_BU, i, j);
+        REAL dyV = (j == Ny) ? -(DXF(j) * A2(F_BV, i, j))
+                 : (j == 1)  ? DXF(2) * A2(F_BV, i, 2)
+                             : DXF(j + 1) * A2(F_BV, i, j + 1) - DXF(j) * A2(F_BV, i, j);
+        A2(F_ETA, i, j) -= dtau * (dxU + dyV) / AZC(j);
+      }
+#pragma omp parallel for schedule(static)
+    for (int j = 1; j <= Ny; j++)
+      for (int i = 1; i <= Nx; i++) {
+        int im = (i == 1) ? Nx : i - 1;
+        REAL dxe = (A2(F_ETA, i, j) - A2(F_ETA, im, j)) / DXC(j);
+        REAL dye = (j == 1) ? 0 : (A2(F_ETA, i, j) - A2(F_ETA, i, j - 1)) / m->dy;
+        REAL Un = A2(F_BU, i, j) + dtau * (-m->g * Hc * dxe + A2(F_GBU, i, j));
+        REAL Vn = A2(F_BV, i, j) + dtau * (-m->g * Hc * dye + A2(F_GBV, i, j));
+        A2(F_ETAB, i, j) += wgt * A2(F_ETA, i, j);
+        A2(F_UB, i, j) += wgt * Un;
+        A2(F_VB, i, j) += wgt * Vn;
+        A2(F_BU, i, j) = Un;
+        A2(F_BV, i, j) = Vn;
+      }
+  }
+  for (int j = 1; j <= Ny; j++)
+    for (int i = 1; i <= Nx; i++) {
+      A2(F_ETA, i, j) = A2(F_ETAB, i, j);
+      A2(F_BU, i, j) = A2(F_UB, i, j);
+      A2(F_BV, i, j) = A2(F_VB, i, j);
+    }
+}
+void FN(ab2_step)(void *h, double dt_, int euler) {
+  model *m = (model *)h;
+  REAL dt = (REAL)dt_;
+  REAL chi = euler ? (REAL)-0.5 : m->chi;
+  free_surface_tendency(m, chi);
+  ab2_field(m, F_U, F_GNU, F_GMU, dt, chi, 1);
+  ab2_field(m, F_V, F_GNV, F_GMV, dt, chi, 1);
+  ab2_field(m, F_T, F_GNT, F_GMT, dt, chi, 0);
+  ab2_field(m, F_S, F_GNS, F_GMS, dt, chi, 0);
+  step_free_surface(m, dt);
+}
+/* correct_velocities_and_cache_previous_tendencies!(model, dt) --
+ * /root/reference/src/precompile.jl:41,125-127 (appendix A.8). */
+void FN(correct_and_cache)(void *h) {
+  model *m = (model *)h;
+  barotropic_mode(m, F_UB, F_VB);
+  REAL Hc = m->Lz;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int k = 1; k <= m->Nz; k++)
+    for (int j = 1; j <= m->Ny; j++)
+      for (int i = 1; i <= m->Nx; i++) {
+        A3(F_U, i, j, k) = A3(F_U, i, j, k) + (A2(F_BU, i, j) - A2(F_UB, i, j)) / Hc;
+        A3(F_V, i, j, k) = A3(F_V, i, j, k) + (A2(F_BV, i, j) - A2(F_VB, i, j)) / Hc;
+      }
+  for (int q = 0; q < 4; q++)
+    for (int k = 1; k <= m->Nz; k++)
+      for (int j = 1; j <= m->Ny; j++)
+        for (int i = 1; i <= m->Nx; i++) A3(F_GMU + q, i, j, k) = A3(F_GNU + q, i, j, k);
+}
+/* initialize!(model): barotropic velocities from the 3-D velocities + their halos */
+void FN(initialize)(void *h) {
+  model *m = (model *)h;
+  barotropic_mode(m, F_BU, F_BV);
+  fill_halo_2d(m, F_BU, 0);
+  fill_halo_2d(m, F_BV, 1);
+  fill_halo_2d(m, F_ETA, 0);
+}
+/* time_step!(model, dt; euler) -- /root/reference/src/timestepping_utils.jl:29-35 */
+void FN(time_step_euler)(void *h, int euler) {
+  model *m = (model *)h;
+  FN(ab2_step)(h, (double)m->dt, euler);
+  m->time += (double)m->dt;
+  m->iter += 1;
+  FN(fill_halos)(h);
+  FN(correct_and_cache)(h);
+  FN(update_state)(h);
+}
+void FN(time_step)(void *h) { FN(time_step_euler)(h, 0); }
+/* first_time_step!(model) -- /root/reference/src/timestepping_utils.jl:21-27 */
+void FN(first_time_step)(void *h) {
+  FN(initialize)(h);
+  FN(update_state)(h);
+  FN(time_step_euler)(h, 1);
+}
+/* loop!(model, Ninner) -- /root/reference/src/timestepping_utils.jl:37-45 */
+void FN(loop)(void *h, int n) {
+  for (int s = 0; s < n; s++) FN(time_step_euler)(h, 0);
+}
+
+/* set_baroclinic_instability!(model) -- /root/reference/src/model_utils.jl:83-87,99-127 */
+void FN(set_baroclinic_instability)(void *h) {
+  model *m = (model *)h;
+  for (int k = 1; k <= m->Nz; k++)
+    for (int j = 1; j <= m->Ny; j++)
+      for (int i = 1; i <= m->Nx; i++) {
+        double phi = (double)MJ(phic, j), z = (double)MK(zc, k);
+        double step = (1.0 - tanh((fabs(phi) - 40.0) / 5.0)) / 2.0;
+        A3(F_T, i, j, k) = (REAL)((30.0 + 1e-3 * z) * step);
+        A3(F_S, i, j, k) = (REAL)(-5e-3 * z);
+      }
+}
+
+/* diagnostics for tests: the individual terms of G_u at (i,j,k) (1-based) */
+void FN(debug_gu_terms)(void *h, int i, int j, int k, double *out) {
+  const model *m = (const model *)h;
+  REAL vhat = ((DXF(j) * A3(F_V, i - 1, j, k) + DXF(j + 1) * A3(F_V, i - 1, j + 1, k)) / (REAL)2 +
+               (DXF(j) * A3(F_V, i, j, k) + DXF(j + 1) * A3(F_V, i, j + 1, k)) / (REAL)2) / (REAL)2 / DXC(j);
+  REAL uhat = A3(F_U, i, j, k);
+  out[0] = vhat;
+  out[1] = biased_interp(m, DY, TO_CENTER, i, j, k, vhat > 0, f_zeta, f_uy, f_vx);
+  out[2] = sym_interp(m, DX, TO_FACE, i, j, k, f_dyV);
+  out[3] = biased_interp(m, DX, TO_FACE, i, j, k, uhat > 0, f_dxU, f_div, NULL);
+  for (int t = 0; t < 2; t++) {
+    REAL wt = sym_interp(m, DX, TO_FACE, i, j, k + t, f_Azw);
+    out[4 + t] = wt * biased_interp(m, DZ, TO_FACE, i, j, k + t, wt > 0, f_u, NULL, NULL);
+  }
+  out[6] = biased_interp(m, DX, TO_FACE, i, j, k, uhat > 0, f_dxu2, f_usm, NULL);
+  out[7] = sym_interp(m, DY, TO_CENTER, i, j, k, f_dxv2);
+  out[8] = (A3(F_P, i, j, k) - A3(F_P, i - 1, j, k)) / DXC(j);
+}

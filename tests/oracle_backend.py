@@ -1,0 +1,206 @@
+"""Test-side adapter: drives the CPU oracle (oracle/gb25_oracle.c) through the same backend
+interface the product's HipBackend offers, so parity tests read like the reference's
+correctness script (two models, same calls, compare_states).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under gb-25_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+FIELD_IDS = {
+    "u": 0, "v": 1, "w": 2, "T": 3, "S": 4, "pHY": 5,
+    "Gn.u": 6, "Gn.v": 7, "Gn.T": 8, "Gn.S": 9,
+    "Gm.u": 10, "Gm.v": 11, "Gm.T": 12, "Gm.S": 13,
+    "eta": 14, "U": 15, "V": 16, "eta_bar": 17, "U_bar": 18, "V_bar": 19, "Gn.U": 20, "Gn.V": 21,
+}
+METRIC_IDS = {"phif": 0, "phic": 1, "dxc": 2, "dxf": 3, "azc": 4, "azf": 5, "fcor": 6,
+              "zf": 7, "zc": 8, "dzc": 9, "dzf": 10}
+
+
+class OConfig(C.Structure):
+    _fields_ = [("Nx", C.c_int), ("Ny", C.c_int), ("Nz", C.c_int), ("H", C.c_int), ("substeps", C.c_int),
+                ("dt", C.c_double), ("chi", C.c_double),
+                ("lat_south", C.c_double), ("lat_north", C.c_double), ("lon_west", C.c_double),
+                ("lon_east", C.c_double), ("depth", C.c_double), ("zexp_h", C.c_double),
+                ("g", C.c_double), ("Omega", C.c_double), ("radius", C.c_double), ("rho0", C.c_double)]
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+_libs = {}
+
+
+def oracle_lib(precision):
+    if precision not in _libs:
+        path = os.path.join(ORACLE_DIR, "_build", f"libgb25_oracle_{precision}.so")
+        src = os.path.join(ORACLE_DIR, "gb25_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            build_oracle()
+        _libs[precision] = C.CDLL(path)
+    return _libs[precision]
+
+
+class OracleBackend:
+    """Same duck-typed interface as gb25_amd.binding.HipBackend."""
+
+    def __init__(self, Nx, Ny, Nz, *, dt, halo=8, substeps=30, precision="f64", **overrides):
+        self.sfx = "_" + precision
+        self.lib = oracle_lib(precision)
+        self.dtype = np.float64 if precision == "f64" else np.float32
+        self.ctype = C.c_double if precision == "f64" else C.c_float
+        cfg = OConfig(Nx, Ny, Nz, halo, substeps, dt, 0.1, -80, 80, 0, 360, 4000, 30, 9.80665, 7.292115e-5, 6371e3,
+                      1020.0)
+        for k, v in overrides.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        f = self._fn("create")
+        f.restype = C.c_void_p
+        f.argtypes = [C.POINTER(OConfig)]
+        self.h = f(C.byref(cfg))
+        if not self.h:
+            raise RuntimeError("oracle create failed")
+        self._fn("field_ptr").restype = C.POINTER(self.ctype)
+        self._fn("field_ptr").argtypes = [C.c_void_p, C.c_int]
+        self._fn("field_dims").argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        self._fn("metric").restype = C.c_double
+        self._fn("metric").argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self._fn("ab2_step").argtypes = [C.c_void_p, C.c_double, C.c_int]
+        self._fn("loop").argtypes = [C.c_void_p, C.c_int]
+        self._fn("set_dt").argtypes = [C.c_void_p, C.c_double]
+        self._fn("get_time").restype = C.c_double
+        self._fn("get_iteration").restype = C.c_long
+        self._fn("time_step_euler").argtypes = [C.c_void_p, C.c_int]
+        self._dt = dt
+        self.H = halo
+
+    def _fn(self, name):
+        return getattr(self.lib, "gb25o_" + name + self.sfx)
+
+    def _call(self, name, *a):
+        f = self._fn(name)
+        if f.argtypes is None:
+            f.argtypes = [C.c_void_p]
+        f(self.h, *a)
+
+    def close(self):
+        if getattr(self, "h", None):
+            f = self._fn("destroy")
+            f.argtypes = [C.c_void_p]
+            f(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- fields
+    def _view(self, name):
+        d = (C.c_int * 3)()
+        self._fn("field_dims")(self.h, FIELD_IDS[name], d)
+        p = self._fn("field_ptr")(self.h, FIELD_IDS[name])
+        a = np.ctypeslib.as_array(p, shape=(d[2], d[1], d[0]))
+        return a.transpose(2, 1, 0)  # [i, j, k] view of the oracle's memory
+
+    def field_dims(self, name, include_halos=True):
+        v = self._view(name)
+        if include_halos:
+            return v.shape
+        H = self.H
+        return (v.shape[0] - 2 * H, v.shape[1] - 2 * H, 1 if v.shape[2] == 1 else v.shape[2] - 2 * H)
+
+    def _interior(self, v):
+        H = self.H
+        if v.shape[2] == 1:
+            return v[H:-H, H:-H, :]
+        return v[H:-H, H:-H, H:-H]
+
+    def get_field(self, name, include_halos=True):
+        v = self._view(name)
+        return np.array(v if include_halos else self._interior(v))
+
+    def set_field(self, name, array, include_halos=True):
+        v = self._view(name)
+        a = np.asarray(array)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        tgt = v if include_halos else self._interior(v)
+        if a.shape != tgt.shape:
+            raise ValueError(f"{name}: expected {tgt.shape}, got {a.shape}")
+        tgt[...] = a
+
+    def metric(self, name, index):
+        return self._fn("metric")(self.h, METRIC_IDS[name], index)
+
+    def substepping(self):
+        w = (C.c_double * 4096)()
+        frac = C.c_double()
+        f = self._fn("substep_info")
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        n = f(self.h, C.byref(frac), w)
+        return n, frac.value, np.array(w[:n])
+
+    def clock(self):
+        return self._fn("get_time")(C.c_void_p(self.h)), self._fn("get_iteration")(C.c_void_p(self.h)), self._dt
+
+    def set_dt(self, dt):
+        self._dt = dt
+        self._fn("set_dt")(self.h, dt)
+
+    # ---- phases
+    def synchronize(self): pass
+    def set_baroclinic_instability(self): self._call("set_baroclinic_instability")
+    def initialize(self): self._call("initialize")
+    def mask_immersed_fields(self): pass
+    def fill_halo_regions(self): self._call("fill_halos")
+    def compute_auxiliaries(self): self._call("compute_auxiliaries")
+    def fill_diffusivity_halos(self): pass
+    def compute_momentum_tendencies(self): self._call("compute_momentum_tendencies")
+    def compute_tracer_tendencies(self): self._call("compute_tracer_tendencies")
+    def compute_boundary_tendencies(self): pass
+    def compute_tendencies(self): self._call("compute_tendencies")
+    def ab2_step(self, dt, euler=False): self._fn("ab2_step")(self.h, float(dt), int(euler))
+    def correct_velocities_and_cache_previous_tendencies(self, dt=0.0): self._call("correct_and_cache")
+    def update_state(self): self._call("update_state")
+    def first_time_step(self): self._call("first_time_step")
+    def time_step(self): self._call("time_step")
+    def loop(self, n): self._fn("loop")(self.h, int(n))
+
+    # unit functions
+    def weno5(self, a, b, c, d, e):
+        f = self._fn("weno5")
+        f.restype = C.c_double
+        f.argtypes = [C.c_double] * 5
+        return f(a, b, c, d, e)
+
+    def weno3(self, b, c, d):
+        f = self._fn("weno3")
+        f.restype = C.c_double
+        f.argtypes = [C.c_double] * 3
+        return f(b, c, d)
+
+    def teos10_rho(self, T, S, Z):
+        f = self._fn("teos10_rho")
+        f.restype = C.c_double
+        f.argtypes = [C.c_double] * 3
+        return f(T, S, Z)
+
+
+class CPU:
+    """Oracle-backed architecture object for tests: baroclinic_instability_model(CPU(), ...)."""
+
+    def __init__(self, precision="f64"):
+        self.precision = precision
+
+    def __call__(self, Nx, Ny, Nz, **kw):
+        kw.pop("device", None)
+        return OracleBackend(Nx, Ny, Nz, precision=self.precision, **kw)
