@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Headline benchmark: model time-steps/s of the HydrostaticFreeSurfaceModel hot path.
+
+Protocol (SURVEY.md section 8d, GB-25 sharding/sharded_baroclinic_instability_simulation_run.jl:145-164):
+build the model, first_time_step!, W untimed warm-up steps, then exactly K time steps bracketed by
+barrier + device synchronisation; the metric is K / wall (max over ranks).  A "step" is one time_step! over
+the whole grid.  Inputs are synthetic (deterministic baroclinic-instability IC + seeded velocity noise) and are
+resident in HBM before the timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size Nx Ny Nz] [--no-cpu-baseline]
+N > 1 is launched by the driver with torch.distributed.run, one rank per GPU (x-slab decomposition).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic fp32 field accesses per interior cell per launch, x 4 bytes
+ALGORITHMIC_BYTES_PER_CELL = {
+    "gu": 5 * 4, "gv": 5 * 4, "tracers": 10 * 4, "compute_w": 3 * 4, "compute_p": 3 * 4,
+    "ab2_velocities": 12 * 4, "ab2_tracers": 8 * 4, "corrector": 6 * 4,
+}
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+
+def counter_rng(shape, seed, salt):
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        x = (np.arange(n, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)
+             + np.uint64(salt) * np.uint64(0xD1B54A32D192ED03))
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return ((x >> np.uint64(11)).astype(np.float64) / float(1 << 53)).reshape(shape, order="F")
+
+
+def cpu_baseline(Nx, Ny, Nz, dt, budget_s=25.0):
+    """The oracle (fp32 build, OpenMP) timed on this host on a bounded sample of the same workload.
+    kind = "port": the reference's Julia CPU path cannot run here (no Julia)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gb25_amd as gb
+    from oracle_backend import CPU
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    m = gb.baroclinic_instability_model(CPU("f32"), Nx, Ny, Nz, dt=dt)
+    gb.set_baroclinic_instability(m)
+    m.set(u=(1e-3 * counter_rng(m.velocities.u.shape, 42, 1)).astype(np.float32),
+          v=(1e-3 * counter_rng(m.velocities.v.shape, 42, 2)).astype(np.float32))
+    gb.first_time_step(m)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        gb.time_step(m)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50 or el / n * (n + 1) > 1.6 * budget_s:
+            break
+    m.backend.close()
+    return {"value": n / el, "unit": "steps/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
+            "sample": f"{n} time steps of the same {Nx}x{Ny}x{Nz} workload after first_time_step (fp32 C oracle, OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, nargs=3, default=[1440, 720, 48], metavar=("Nx", "Ny", "Nz"))
+    ap.add_argument("--dt", type=float, default=240.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timers")
+    args = ap.parse_args()
+
+    import torch
+    import gb25_amd as gb
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    Nx, Ny, Nz = args.size
+
+    if world > 1:
+        import torch.distributed as dist
+        from gb25_amd.distributed import SlabModel
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # weak scaling: every rank owns one Nx x Ny x Nz slab of a (world*Nx) x Ny x Nz global grid
+        model = SlabModel(world * Nx, Ny, Nz, dt=args.dt, rank=rank, nranks=world, device=local_rank)
+        barrier = dist.barrier
+    else:
+        model = gb.baroclinic_instability_model(gb.GPU(local_rank), Nx, Ny, Nz, dt=args.dt)
+        barrier = lambda: None
+    b = model.backend
+
+    # synthetic inputs, resident in HBM before timing
+    gb.set_baroclinic_instability(model)
+    ush, vsh = model.velocities.u.shape, model.velocities.v.shape
+    model.set(u=(1e-3 * counter_rng(ush, 42 + rank, 1)).astype(np.float32),
+              v=(1e-3 * counter_rng(vsh, 42 + rank, 2)).astype(np.float32))
+    gb.first_time_step(model)
+    for _ in range(args.warmup):
+        gb.time_step(model)
+    b.synchronize()
+    if not args.no_profile:
+        b.profile_enable(True)
+        b.profile_reset()
+
+    barrier(); b.synchronize(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gb.loop(model, args.steps)
+    b.synchronize(); torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    finite = bool(np.isfinite(model.free_surface.eta.interior).all())
+    kernels = {}
+    if not args.no_profile:
+        for k in ("fill_halos", "compute_w", "compute_p", "gu", "gv", "tracers", "ab2_velocities", "ab2_tracers",
+                  "barotropic", "corrector"):
+            n, ms = b.profile_get(k)
+            if n:
+                kernels[k] = {"launches": n, "avg_ms": ms / n, "total_ms": ms}
+
+    if rank == 0:
+        cells = Nx * Ny * Nz
+        steps_per_s = args.steps / elapsed
+        out = {
+            "metric": "model time-steps/sec", "value": steps_per_s, "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"baroclinic_instability_model {world * Nx}x{Ny}x{Nz} LatitudeLongitudeGrid, "
+                                   f"halo 8, SplitExplicit(30), WENO5, TEOS10, dt={args.dt:g}s",
+                       "grid": [world * Nx, Ny, Nz], "cells_per_gpu": cells,
+                       "parallelism": f"x-slab x{world}" if world > 1 else "single GPU",
+                       "simulated_years_per_day": steps_per_s * args.dt / 365.0},
+            "finite": finite,
+        }
+        if kernels:
+            timed = {k: v for k, v in kernels.items() if k in ALGORITHMIC_BYTES_PER_CELL}
+            dom = max(timed, key=lambda k: timed[k]["total_ms"])
+            launches_per_step = timed[dom]["launches"] / args.steps
+            bytes_per_launch = ALGORITHMIC_BYTES_PER_CELL[dom] * cells
+            achieved = bytes_per_launch / (timed[dom]["avg_ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "avg_launch_ms": timed[dom]["avg_ms"], "launches_per_step": launches_per_step,
+                               "algorithmic_bytes_per_launch": bytes_per_launch,
+                               "whole_step_achieved_GBps": 240.0 * cells * steps_per_s / 1e9}
+            out["kernels_ms_per_step"] = {k: v["total_ms"] / args.steps for k, v in kernels.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(Nx, Ny, Nz, args.dt)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""CPU-side checks of the C-ABI boundary: the library builds for gfx950, loads, and exports every symbol
+include/gb25.h declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import gb25_amd as gb
+from gb25_amd import binding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    gb.build_library()
+    return binding.load_library()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gb25.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gb25_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(binding.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_config_struct_layout_matches_header(lib):
+    cfg = binding.Config()
+    lib.gb25_default_config(ctypes.byref(cfg), 1440, 720, 48)
+    assert (cfg.Nx, cfg.Ny, cfg.Nz, cfg.halo, cfg.substeps, cfg.nranks) == (1440, 720, 48, 8, 30, 1)
+    assert (cfg.lat_south, cfg.lat_north, cfg.depth, cfg.zexp_h) == (-80.0, 80.0, 4000.0, 30.0)
+    assert (cfg.g, cfg.Omega, cfg.radius, cfg.rho0, cfg.chi) == (9.80665, 7.292115e-5, 6371e3, 1020.0, 0.1)
+    assert lib.gb25_version().decode().startswith("gb25hip")
+
+
+def test_no_cpu_fallback_without_device(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(binding.GB25Error, match="no HIP device"):
+        gb.baroclinic_instability_model(gb.GPU(), 32, 16, 8, dt=1.0)
+
+
+def test_code_object_targets_gfx950(lib):
+    blob = open(binding.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"k_gu" in blob

@@ -1,0 +1,94 @@
+"""Size-independent properties at BASELINE.json's full single-GPU size (1440x720x48), where the oracle
+is too slow to run: state of rest, discrete consistency of continuity + tracer advection, zonal symmetry
+and exact x-translation invariance of the periodic direction, finiteness."""
+import numpy as np
+import pytest
+
+import gb25_amd as gb
+from helpers import counter_rng
+
+pytestmark = pytest.mark.gpu
+NX, NY, NZ = 1440, 720, 48
+
+
+@pytest.fixture(scope="module")
+def model():
+    m = gb.baroclinic_instability_model(gb.GPU(), NX, NY, NZ, dt=240.0)
+    yield m
+    m.backend.close()
+
+
+def _reset(m):
+    for n in ("u", "v", "w", "T", "S", "pHY", "Gn.u", "Gn.v", "Gn.T", "Gn.S", "Gm.u", "Gm.v", "Gm.T", "Gm.S",
+              "eta", "U", "V", "eta_bar", "U_bar", "V_bar", "Gn.U", "Gn.V"):
+        d = m.backend.field_dims(n, True)
+        m.backend.set_field(n, np.zeros(d, np.float32), True)
+
+
+def test_state_of_rest(model):
+    m = model
+    _reset(m)
+    zc = np.array([m.grid.metric("zc", k) for k in range(1, NZ + 1)], np.float32)
+    T = np.broadcast_to(10 + 5e-3 * zc, (NX, NY, NZ)).astype(np.float32)
+    S = np.broadcast_to(35 - 1e-3 * zc, (NX, NY, NZ)).astype(np.float32)
+    m.set(T=T, S=S)
+    gb.first_time_step(m)
+    gb.loop(m, 2)
+    for name in ("u", "v", "w", "eta"):
+        assert np.abs(m.fields()[name].interior).max() == 0.0, name
+    assert np.abs(m.timestepper.Gn.u.interior).max() == 0.0
+    assert np.abs(m.timestepper.Gn.v.interior[:, 1:, :]).max() == 0.0
+    assert np.array_equal(m.tracers.T.interior, T)
+
+
+def test_constant_tracer_and_budget(model):
+    m = model
+    _reset(m)
+    u0 = (0.2 * (counter_rng((NX, NY, NZ), 1, 1) - 0.5)).astype(np.float32)
+    v0 = (0.2 * (counter_rng((NX, NY + 1, NZ), 1, 2) - 0.5)).astype(np.float32)
+    m.set(u=u0, v=v0, T=np.full((NX, NY, NZ), 7.0, np.float32),
+          S=(35 + counter_rng((NX, NY, NZ), 1, 3)).astype(np.float32))
+    gb.update_state(m)
+    w = m.velocities.w.interior
+    assert np.isfinite(w).all() and np.abs(w).max() > 0
+    GT = m.timestepper.Gn.T.interior
+    # c * (sum of six fluxes)/V with |flux|/V ~ |u|/dx ~ 1e-5 1/s: fp32 round-off of a constant field
+    assert np.abs(GT).max() < 7.0 * 1e-5 * 5e-6
+    az = np.array([m.grid.metric("azc", j) for j in range(1, NY + 1)])
+    dz = np.array([m.grid.metric("dzc", k) for k in range(1, NZ + 1)])
+    GS = m.timestepper.Gn.S.interior.astype(np.float64)
+    vol = az[None, :, None] * dz[None, None, :]
+    total = (vol * GS).sum()
+    Sp = m.tracers.S.parent
+    H = 8
+    wtop = w[:, :, NZ].astype(np.float64)
+    c_in, c_halo = Sp[H:-H, H:-H, H + NZ - 1], Sp[H:-H, H:-H, H + NZ]
+    top = (az[None, :] * wtop * np.where(wtop > 0, c_in, c_halo)).sum()
+    assert abs(total + top) < 2e-6 * np.abs(vol * GS).sum()
+
+
+def test_zonal_symmetry_and_translation_invariance(model):
+    m = model
+    _reset(m)
+    gb.set_baroclinic_instability(m)          # zonally symmetric
+    gb.first_time_step(m)
+    gb.loop(m, 3)
+    for name in ("v", "T", "eta", "w"):
+        a = m.fields()[name].interior
+        assert np.isfinite(a).all(), name
+        assert np.array_equal(a, np.broadcast_to(a[:1], a.shape)), name      # every longitude identical
+    assert np.abs(m.velocities.v.interior).max() > 1e-3
+
+    # periodic x: shifting the initial state by s columns shifts the result by s columns, bit for bit
+    s = 517
+    u0 = (1e-2 * counter_rng((NX, NY, NZ), 42, 1)).astype(np.float32)
+    results = []
+    for shift in (0, s):
+        _reset(m)
+        gb.set_baroclinic_instability(m)
+        m.set(u=np.roll(u0, shift, axis=0))
+        gb.first_time_step(m)
+        gb.loop(m, 2)
+        results.append({n: m.fields()[n].interior for n in ("u", "v", "T", "eta")})
+    for n in results[0]:
+        assert np.array_equal(np.roll(results[0][n], s, axis=0), results[1][n]), n

@@ -1,0 +1,254 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle -- the tests proper.
+
+Model of the reference's own test (correctness/correctness_baroclinic_instability_simulation_run.jl):
+two models with one configuration, `rmodel` on the accelerator and `vmodel` on the CPU, the same
+calls on both, compare_states at checkpoints with rtol = sqrt(eps(Float32)), atol = 0, halos included.
+"""
+import numpy as np
+import pytest
+
+import gb25_amd as gb
+from helpers import (SQRT_EPS32, assert_states_close, counter_rng, make_pair, set_noisy_velocities)
+
+pytestmark = pytest.mark.gpu
+
+ALL_FIELDS = ["u", "v", "w", "T", "S", "pHY", "Gn.u", "Gn.v", "Gn.T", "Gn.S", "Gm.u", "Gm.v", "Gm.T", "Gm.S",
+              "eta", "U", "V", "eta_bar", "U_bar", "V_bar", "Gn.U", "Gn.V"]
+
+
+def sync_all(rmodel, vmodel, names=ALL_FIELDS):
+    """Copy every parent array of the CPU model into the GPU model (rounded to fp32) and back,
+    so that both start a phase from bit-identical fp32-representable inputs."""
+    for n in names:
+        a = vmodel.backend.get_field(n, True).astype(np.float32)
+        rmodel.backend.set_field(n, a, True)
+        vmodel.backend.set_field(n, a.astype(vmodel.backend.dtype), True)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    n = max(np.linalg.norm(a.ravel()), np.linalg.norm(b.ravel()))
+    return 0.0 if n == 0 else float(np.linalg.norm((a - b).ravel()) / n)
+
+
+def baroclinic_state(rmodel, vmodel, amplitude=1e-3):
+    gb.set_baroclinic_instability(vmodel)
+    set_noisy_velocities(vmodel, amplitude)
+    sync_all(rmodel, vmodel)
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_field_roundtrip_and_layout():
+    r, v = make_pair(24, 16, 6, dt=60.0)
+    for name in ("u", "v", "w", "T", "eta", "V"):
+        dims = r.backend.field_dims(name, True)
+        assert dims == v.backend.field_dims(name, True), name
+        a = counter_rng(dims, 7, hash(name) % 97).astype(np.float32)
+        r.backend.set_field(name, a, True)
+        assert np.array_equal(r.backend.get_field(name, True), a)
+        H = 8
+        inner = a[H:-H, H:-H, H:-H] if dims[2] > 1 else a[H:-H, H:-H, :]
+        assert np.array_equal(r.backend.get_field(name, False), inner)
+        b = counter_rng(inner.shape, 9, 3).astype(np.float32)
+        r.backend.set_field(name, b, False)
+        assert np.array_equal(r.backend.get_field(name, False), b)
+        full = r.backend.get_field(name, True)
+        mask = np.ones(dims, bool)
+        if dims[2] > 1:
+            mask[H:-H, H:-H, H:-H] = False
+        else:
+            mask[H:-H, H:-H, :] = False
+        assert np.array_equal(full[mask], a[mask])          # halos untouched by an interior set
+
+
+def test_grid_metrics_and_substepping_match_oracle():
+    r, v = make_pair(128, 64, 8, dt=60.0)
+    for name, idxs in (("dxc", range(-5, 72)), ("dxf", range(-5, 72)), ("azc", range(-5, 71)), ("azf", range(-4, 72)),
+                       ("fcor", range(1, 66)), ("zc", range(-3, 13)), ("dzc", range(-3, 13)), ("dzf", range(-2, 13))):
+        for i in idxs:
+            assert r.backend.metric(name, i) == np.float32(v.backend.metric(name, i)), (name, i)
+    nr, fr, wr = r.backend.substepping()
+    nv, fv, wv = v.backend.substepping()
+    assert nr == nv == 21 and fr == fv
+    assert np.array_equal(wr, wv.astype(np.float32).astype(np.float64))
+
+
+def test_set_baroclinic_instability_kernel():
+    r, v = make_pair(48, 32, 8, dt=60.0)
+    gb.set_baroclinic_instability(r)
+    gb.set_baroclinic_instability(v)
+    assert rel(r.tracers.T.interior, v.tracers.T.interior) < 2e-7
+    assert rel(r.tracers.S.interior, v.tracers.S.interior) < 2e-7
+
+
+def test_phase_by_phase_against_oracle():
+    """Every phase of src/precompile.jl:31-42, each started from identical inputs."""
+    r, v = make_pair(48, 32, 8, dt=600.0)
+    baroclinic_state(r, v, amplitude=1e-2)
+    get = lambda m, n: m.backend.get_field(n, True)
+
+    # initialize!: barotropic velocities
+    for m in (r, v):
+        m.backend.initialize()
+    for n in ("U", "V"):
+        assert rel(get(r, n), get(v, n)) < 5e-7, n
+
+    # halo filling is pure data movement: bit-identical parents
+    sync_all(r, v)
+    for m in (r, v):
+        m.backend.fill_halo_regions()
+    for n in ("u", "v", "T", "S", "eta", "U", "V"):
+        assert np.array_equal(get(r, n), get(v, n).astype(np.float32)), n
+
+    # auxiliaries on the extended range
+    sync_all(r, v)
+    for m in (r, v):
+        m.backend.compute_auxiliaries()
+    H = 8
+    # kernels cover -H+2..N+H-1 in x and y; stencils only ever read the first halo ring, and on coarse
+    # test grids the deeper latitude halos lie beyond the pole (meaningless metrics), so compare ring 1
+    core = (slice(H - 1, -(H - 1)), slice(H - 1, -(H - 1)), slice(H, -H))
+    assert rel(get(r, "w")[core], get(v, "w")[core]) < 1e-5
+    assert rel(get(r, "pHY")[core], get(v, "pHY")[core]) < 5e-6
+    assert np.isfinite(get(r, "w")[1:-1, 1:-1]).all() and np.isfinite(get(r, "pHY")[1:-1, 1:-1]).all()
+    assert np.array_equal(get(r, "w")[:, :, H], np.zeros_like(get(r, "w")[:, :, H]))
+
+    # tendencies
+    sync_all(r, v)
+    for m in (r, v):
+        m.backend.compute_tendencies()
+    for n, tol in (("Gn.T", 2e-4), ("Gn.S", 2e-4), ("Gn.u", 5e-3), ("Gn.v", 5e-3)):
+        assert rel(get(r, n), get(v, n)) < tol, (n, rel(get(r, n), get(v, n)))
+
+    # ab2_step! incl. the split-explicit sub-cycle (AB2 and Euler variants)
+    for euler in (True, False):
+        sync_all(r, v)
+        for m in (r, v):
+            m.backend.ab2_step(600.0, euler)
+        for n in ("u", "v", "T", "S", "eta", "U", "V", "eta_bar", "U_bar", "V_bar", "Gn.U", "Gn.V"):
+            assert rel(get(r, n), get(v, n)) < 2e-5, (n, euler, rel(get(r, n), get(v, n)))
+
+    # corrector + cache
+    sync_all(r, v)
+    for m in (r, v):
+        m.backend.fill_halo_regions()
+        m.backend.correct_velocities_and_cache_previous_tendencies(600.0)
+    for n in ("u", "v", "U_bar", "V_bar"):
+        assert rel(get(r, n), get(v, n)) < 2e-6, n
+    for n in ("Gm.u", "Gm.v", "Gm.T", "Gm.S"):
+        assert np.array_equal(get(r, n), get(v, n).astype(np.float32)), n
+
+
+def test_momentum_tendencies_without_pressure_noise():
+    """T = S = 0 removes the hydrostatic-pressure round-off: the WENO vector-invariant advection,
+    Coriolis and metric arithmetic must then agree with fp64 to ~1e-5."""
+    r, v = make_pair(64, 48, 12, dt=60.0)
+    set_noisy_velocities(v, 0.1)
+    sync_all(r, v)
+    for m in (r, v):
+        gb.update_state(m)
+    for n in ("Gn.u", "Gn.v"):
+        a, b = r.backend.get_field(n, False), v.backend.get_field(n, False)
+        assert rel(a, b) < 3e-5, (n, rel(a, b))
+        # and element-wise, away from round-off of near-cancelling terms
+        assert np.max(np.abs(a - b)) < 2e-4 * np.max(np.abs(b)), n
+    assert rel(r.velocities.w.interior, v.velocities.w.interior) < 1e-5
+
+
+def test_smooth_flow_tendencies_elementwise():
+    """Smooth large-scale flow (all WENO stencils near their linear weights): element-wise agreement."""
+    Nx, Ny, Nz = 64, 48, 8
+    r, v = make_pair(Nx, Ny, Nz, dt=60.0)
+    lam = (np.arange(Nx) + 0.5) * 2 * np.pi / Nx
+    phi = np.linspace(-1, 1, Ny)
+    u0 = 0.5 * np.cos(lam)[:, None, None] * np.cos(phi * 1.3)[None, :, None] * np.linspace(0.2, 1, Nz)[None, None, :]
+    v0 = 0.3 * np.sin(2 * lam)[:, None, None] * np.sin(np.linspace(0, np.pi, Ny + 1))[None, :, None] * np.ones(Nz)
+    T0 = 10 + 5 * np.cos(lam)[:, None, None] * np.cos(phi)[None, :, None] * np.ones(Nz)
+    v.set(u=u0, v=v0, T=T0, S=35 + 0 * T0)
+    sync_all(r, v)
+    for m in (r, v):
+        gb.update_state(m)
+    for n, tol in (("Gn.T", 5e-5), ("Gn.u", 5e-3), ("Gn.v", 5e-3)):
+        a, b = r.backend.get_field(n, False), v.backend.get_field(n, False)
+        assert rel(a, b) < tol, (n, rel(a, b))
+
+
+def test_reference_correctness_protocol():
+    """The six checkpoints of correctness/correctness_baroclinic_instability_simulation_run.jl:46-102:
+    Nx = Ny = 128-16, Nz = 16, halo 8, dt = 1e-9, u,v = 1e-3 rand, T = S = 0, rtol = sqrt(eps(Float32)),
+    atol = 0, include_halos = true, throw_error = true."""
+    Nx = Ny = 128 - 16
+    r, v = make_pair(Nx, Ny, 16, dt=1e-9)
+    set_noisy_velocities(v)
+    gb.sync_states(r, v)
+    kw = dict(rtol=SQRT_EPS32, atol=0.0, include_halos=True, throw_error=True, verbose=False)
+    gb.compare_states(r, v, **kw)                       # at the beginning
+    for m in (r, v):
+        gb.initialize(m)
+        gb.update_state(m)
+    gb.compare_states(r, v, **kw)                       # after initialization and update state
+    gb.sync_states(r, v)
+    for m in (r, v):
+        gb.first_time_step(m)
+    gb.compare_states(r, v, **kw)                       # after first time step
+    for m in (r, v):
+        for _ in range(12):                             # 2 warm-up + 10 steps
+            gb.time_step(m)
+    gb.compare_states(r, v, **kw)                       # after 10 steps
+    gb.sync_states(r, v)
+    gb.update_state(r)
+    gb.compare_states(r, v, **kw)                       # after syncing and updating state again
+    for m in (r, v):
+        gb.loop(m, 100)
+    ok, report = gb.compare_states(r, v, **kw)          # after a loop of 100 steps
+    assert ok
+    assert r.clock.iteration == v.clock.iteration == 113
+
+
+def test_config1_baroclinic_run_100_steps():
+    """BASELINE.json configs[0]: 128x64x8, fp32, 100 AB2 steps, deterministic IC + velocity noise."""
+    r, v = make_pair(128, 64, 8, dt=1200.0)
+    baroclinic_state(r, v)
+    for m in (r, v):
+        gb.first_time_step(m)
+    assert_states_close(r, v, label="after first_time_step")
+    for m in (r, v):
+        gb.loop(m, 99)
+    rep = assert_states_close(r, v, label="after 100 steps")
+    assert abs(r.clock.time - 100 * 1200.0) < 1e-6 and r.clock.iteration == 100
+    assert np.isfinite(r.velocities.u.parent).all()
+    # the flow must have developed (this is not a trivial comparison of zeros)
+    assert np.abs(r.velocities.u.interior).max() > 0.1 and np.abs(r.free_surface.eta.interior).max() > 0.1
+
+
+def test_config2_shape_short_run():
+    """BASELINE.json configs[1] shape (360x180x24) for a few steps."""
+    r, v = make_pair(360, 180, 24, dt=600.0)
+    baroclinic_state(r, v)
+    for m in (r, v):
+        gb.first_time_step(m)
+        gb.loop(m, 4)
+    assert_states_close(r, v, label="360x180x24 after 5 steps")
+
+
+def test_ragged_sizes_not_multiples_of_the_tile():
+    """Nx, Ny that are not multiples of the 64x4 tile, minimum Nz for WENO5 order reduction."""
+    r, v = make_pair(52, 22, 6, dt=300.0)
+    baroclinic_state(r, v, amplitude=1e-2)
+    for m in (r, v):
+        gb.first_time_step(m)
+        gb.loop(m, 5)
+    assert_states_close(r, v, label="52x22x6")
+
+
+def test_error_paths():
+    from gb25_amd.binding import GB25Error
+    with pytest.raises(GB25Error):
+        gb.baroclinic_instability_model(gb.GPU(), 4, 4, 2, dt=1.0)          # too small
+    with pytest.raises(GB25Error):
+        gb.baroclinic_instability_model(gb.GPU(device=99), 32, 16, 8, dt=1.0)
+    m = gb.baroclinic_instability_model(gb.GPU(), 32, 16, 8, dt=1.0)
+    with pytest.raises(ValueError):
+        m.velocities.u.set(np.zeros((3, 3, 3)))
+    with pytest.raises(NotImplementedError):
+        gb.baroclinic_instability_model(gb.GPU(), 32, 16, 8, dt=1.0, grid_type="gaussian_islands")
