@@ -260,14 +260,16 @@ Halo2 halo2_prognostic(gb25_model* m) {
 }
 
 // y/z boundary layers (always local) and, for a single slab, the periodic x copy.
-gb25_status fill_halos_impl(gb25_model* m, bool with_x) {
+// extended: also treat the x-halo columns (slab mode, after the neighbours' columns were unpacked).
+gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false) {
   const Grid& g = m->g;
   Timed t(m, GB25_K_FILL_HALOS);
   Halo3 h3 = halo3(m);
   Halo2 h2 = halo2_prognostic(m);
   dim3 b(256);
-  hipLaunchKernelGGL(k_fill_y, dim3((g.Nx + 255) / 256, g.Nz + 1), b, 0, m->stream, g, h3, h2);
-  hipLaunchKernelGGL(k_fill_z, dim3((g.Nx + 255) / 256, g.Ny), b, 0, m->stream, g, h3);
+  const int i0 = extended ? -g.H : 0, ni = extended ? g.Nx + 2 * g.H : g.Nx;
+  hipLaunchKernelGGL(k_fill_y, dim3((ni + 255) / 256, g.Nz + 1), b, 0, m->stream, g, h3, h2, i0, ni);
+  hipLaunchKernelGGL(k_fill_z, dim3((ni + 255) / 256, g.Ny), b, 0, m->stream, g, h3, i0, ni);
   if (with_x && g.x_periodic) {
     int rows_c = g.sy_c * (g.Nz + 2 * g.H), rows_v = g.sy_v * (g.Nz + 2 * g.H);
     long threads = (long)rows_v * 2 * g.H;
@@ -286,7 +288,7 @@ gb25_status fill_halos_2d(gb25_model* m, Halo2 h2) {
   // (blockIdx.y < 4) see zero rows and fall through.
   Grid g2 = g;
   g2.Nz = 0;
-  hipLaunchKernelGGL(k_fill_y, dim3((g.Nx + 255) / 256, 1), b, 0, m->stream, g2, none, h2);
+  hipLaunchKernelGGL(k_fill_y, dim3((g.Nx + 255) / 256, 1), b, 0, m->stream, g2, none, h2, 0, g.Nx);
   if (g.x_periodic) {
     long threads = (long)g.sy_v * 2 * g.H;
     hipLaunchKernelGGL(k_fill_x, dim3((unsigned)((threads + 255) / 256), 4 + h2.n), b, 0, m->stream, g2, none, h2, 0,
@@ -385,28 +387,50 @@ gb25_status ab2_local_impl(gb25_model* m, float dt, float chi) {
   return GB25_OK;
 }
 
-// step_free_surface! on a single slab with periodic x handled in-kernel
+// step_free_surface!: Ns fused forward-backward substeps.  Single slab: canonical arrays, periodic x wrapped
+// in-kernel.  Slab of a decomposition: wide-halo work arrays (halo W >= Ns filled once by the exchange of
+// group 1), every substep computes on [-W+1, Nx+W-1) and the invalid rim never reaches the interior.
 gb25_status barotropic_impl(gb25_model* m, float dt) {
   const Grid& g = m->g;
   Timed t(m, GB25_K_BAROTROPIC);
-  size_t nbar = m->f[GB25_ETA_BAR].elems() + m->f[GB25_U_BAR].elems() + m->f[GB25_V_BAR].elems();
-  HIPCHK(hipMemsetAsync(m->bars, 0, nbar * sizeof(float), m->stream));
+  const bool wide = m->cfg.nranks > 1;
   const float dtau = (float)m->dtau_frac * dt;
   dim3 b(64, 4);
-  dim3 gr = grid2(g.Nx, g.Ny, b);
-  float* cur[3] = {m->f[GB25_ETA].d, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d};
-  float* nxt[3] = {m->pp[0].d, m->pp[1].d, m->pp[2].d};
-  for (int s = 0; s < m->Ns; s++) {
-    Baro bb;
-    bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
-    bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
+  Baro bb;
+  float *cur[3], *nxt[3];
+  if (!wide) {
+    size_t nbar = m->f[GB25_ETA_BAR].elems() + m->f[GB25_U_BAR].elems() + m->f[GB25_V_BAR].elems();
+    HIPCHK(hipMemsetAsync(m->bars, 0, nbar * sizeof(float), m->stream));
+    for (int q = 0; q < 3; q++) { cur[q] = m->f[GB25_ETA + q].d; nxt[q] = m->pp[q].d; }
     bb.etab = m->f[GB25_ETA_BAR].d; bb.Ub = m->f[GB25_U_BAR].d; bb.Vb = m->f[GB25_V_BAR].d;
     bb.GU = m->f[GB25_GN_BT_U].d; bb.GV = m->f[GB25_GN_BT_V].d;
+    bb.sx = g.sx; bb.xo = g.H; bb.ilo = 0; bb.ihi = g.Nx; bb.wrap = 1;
+  } else {
+    for (int q = 0; q < 3; q++) {
+      HIPCHK(hipMemsetAsync(m->wideBar[q].d, 0, m->wideBar[q].elems() * sizeof(float), m->stream));
+      cur[q] = m->wide[0][q].d; nxt[q] = m->wide[1][q].d;
+    }
+    bb.etab = m->wideBar[0].d; bb.Ub = m->wideBar[1].d; bb.Vb = m->wideBar[2].d;
+    bb.GU = m->wideG[0].d; bb.GV = m->wideG[1].d;
+    bb.sx = g.Nx + 2 * m->W; bb.xo = m->W; bb.ilo = -m->W + 1; bb.ihi = g.Nx + m->W - 1; bb.wrap = 0;
+  }
+  dim3 gr = grid2(bb.ihi - bb.ilo, g.Ny, b);
+  for (int s = 0; s < m->Ns; s++) {
+    bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
+    bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
     hipLaunchKernelGGL(k_barotropic_substep, gr, b, 0, m->stream, g, bb, dtau, (float)m->weights[s]);
     for (int q = 0; q < 3; q++) std::swap(cur[q], nxt[q]);
   }
-  hipLaunchKernelGGL(k_barotropic_finalize, gr, b, 0, m->stream, g, m->f[GB25_ETA].d, m->f[GB25_BT_U].d,
-                     m->f[GB25_BT_V].d, m->f[GB25_ETA_BAR].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d);
+  dim3 gi = grid2(g.Nx, g.Ny, b);
+  hipLaunchKernelGGL(k_barotropic_finalize, gi, b, 0, m->stream, g, m->f[GB25_ETA].d, m->f[GB25_BT_U].d,
+                     m->f[GB25_BT_V].d, bb.etab, bb.Ub, bb.Vb, bb.sx, bb.xo);
+  if (wide) {  // publish the averages in the canonical filtered-state arrays (compared by compare_states)
+    for (int q = 0; q < 3; q++) {
+      Field& dst = m->f[GB25_ETA_BAR + q];
+      hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, dst.ny), dim3(256), 0, m->stream, dst.d,
+                         dst.nx, g.H, m->wideBar[q].d, bb.sx, bb.xo, g.Nx, dst.ny);
+    }
+  }
   LAUNCHCHK();
   return GB25_OK;
 }
@@ -416,8 +440,10 @@ gb25_status corrector_impl(gb25_model* m) {
   {
     Timed t(m, GB25_K_CORRECTOR);
     dim3 b(64, 4);
-    hipLaunchKernelGGL(k_corrector, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                       m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d);
+    const bool ext = m->cfg.nranks > 1;
+    const int i0 = ext ? -g.H : 0, ni = ext ? g.Nx + 2 * g.H : g.Nx;
+    hipLaunchKernelGGL(k_corrector, grid2(ni, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                       m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, i0, ni);
     LAUNCHCHK();
   }
   // cache_previous_tendencies!: G^- <- G^n is a pointer exchange; the next tendency evaluation
@@ -529,6 +555,19 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   }
   for (int q = 0; q < 3; q++)
     if ((s = alloc_field(m, m->pp[q], sx, m->f[GB25_ETA + q].ny, 1))) return s;
+  if (cfg->nranks > 1) {
+    m->W = m->Ns + 1;
+    if (m->Nx < m->W)
+      return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab width %d is narrower than the barotropic halo %d", m->Nx, m->W);
+    const int wsx = m->Nx + 2 * m->W;
+    for (int a = 0; a < 2; a++)
+      for (int q = 0; q < 3; q++)
+        if ((s = alloc_field(m, m->wide[a][q], wsx, m->f[GB25_ETA + q].ny, 1))) return s;
+    for (int q = 0; q < 3; q++)
+      if ((s = alloc_field(m, m->wideBar[q], wsx, m->f[GB25_ETA + q].ny, 1))) return s;
+    if ((s = alloc_field(m, m->wideG[0], wsx, m->f[GB25_GN_BT_U].ny, 1))) return s;
+    if ((s = alloc_field(m, m->wideG[1], wsx, m->f[GB25_GN_BT_V].ny, 1))) return s;
+  }
   HIPCHK(hipDeviceSynchronize());
   return GB25_OK;
 }
@@ -692,7 +731,7 @@ gb25_status gb25_update_state(gb25_model* m) {
 gb25_status gb25_update_state_local(gb25_model* m) {
   CHECK_MODEL(m);
   gb25_status s;
-  if ((s = fill_halos_impl(m, false))) return s;
+  if ((s = fill_halos_impl(m, false, m->cfg.nranks > 1))) return s;
   if ((s = compute_w_impl(m))) return s;
   if ((s = compute_p_impl(m))) return s;
   if ((s = momentum_impl(m))) return s;
@@ -716,38 +755,66 @@ gb25_status gb25_loop(gb25_model* m, int32_t n) {
   return GB25_OK;
 }
 
-// ---- slab exchange (group 0 only for now) ------------------------------------
-static void group_fields(gb25_model* m, int group, std::vector<Field*>& out) {
+// ---- x-slab exchange -------------------------------------------------------------------------
+// group 0: H columns of u, v, T, S (all parent rows) and of eta, U, V -> the neighbour's x halo.
+// group 1: W columns of eta, U, V, G.U, G.V -> the neighbour's wide barotropic halo.
+struct Piece {
+  float* src;      // array that is packed from (canonical layout)
+  float* dst;      // array that is unpacked into
+  int src_sx, src_xo, dst_sx, dst_xo;
+  long rows;
+};
+static void group_pieces(gb25_model* m, int group, std::vector<Piece>& out, int* ncols) {
+  const int H = m->cfg.halo, sx = m->Nx + 2 * H;
   if (group == 0) {
-    for (int id : {GB25_U, GB25_V, GB25_T, GB25_S, GB25_ETA, GB25_BT_U, GB25_BT_V}) out.push_back(&m->f[id]);
+    *ncols = H;
+    for (int id : {GB25_U, GB25_V, GB25_T, GB25_S, GB25_ETA, GB25_BT_U, GB25_BT_V}) {
+      Field& F = m->f[id];
+      out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
+    }
   } else {
-    for (int id : {GB25_GN_BT_U, GB25_GN_BT_V}) out.push_back(&m->f[id]);
+    *ncols = m->W;
+    const int wsx = m->Nx + 2 * m->W;
+    for (int q = 0; q < 3; q++) {
+      Field& F = m->f[GB25_ETA + q];
+      out.push_back({F.d, m->wide[0][q].d, sx, H, wsx, m->W, (long)F.ny});
+    }
+    out.push_back({m->f[GB25_GN_BT_U].d, m->wideG[0].d, sx, H, wsx, m->W, (long)m->f[GB25_GN_BT_U].ny});
+    out.push_back({m->f[GB25_GN_BT_V].d, m->wideG[1].d, sx, H, wsx, m->W, (long)m->f[GB25_GN_BT_V].ny});
   }
 }
 gb25_status gb25_halo_buffer_elems(const gb25_model* m, int group, int64_t* n) {
   if (!m || !n || group < 0 || group > 1) return GB25_ERR_INVALID_ARGUMENT;
-  std::vector<Field*> fs;
-  group_fields(const_cast<gb25_model*>(m), group, fs);
+  if (m->cfg.nranks == 1) { *n = 0; return GB25_OK; }
+  std::vector<Piece> ps;
+  int nc = 0;
+  group_pieces(const_cast<gb25_model*>(m), group, ps, &nc);
   int64_t t = 0;
-  for (Field* F : fs) t += (int64_t)F->ny * F->nz * m->cfg.halo;
+  for (auto& p : ps) t += p.rows * nc;
   *n = t;
   return GB25_OK;
 }
 static gb25_status pack_unpack(gb25_model* m, int group, int side, float* buf, bool pack) {
   if (!m || !buf || group < 0 || group > 1 || side < 0 || side > 1) return GB25_ERR_INVALID_ARGUMENT;
-  std::vector<Field*> fs;
-  group_fields(m, group, fs);
-  const int H = m->cfg.halo, Nx = m->Nx;
-  // pack: west side -> interior columns [H, 2H) of the parent; east -> [Nx, Nx+H)
-  // unpack: west halo -> parent columns [0, H); east halo -> [Nx+H, Nx+2H)
-  const int i0 = pack ? (side == 0 ? H : Nx) : (side == 0 ? 0 : Nx + H);
+  if (m->cfg.nranks == 1) return fail(m, GB25_ERR_STATE, "halo pack/unpack on a single-slab model");
+  std::vector<Piece> ps;
+  int nc = 0;
+  group_pieces(m, group, ps, &nc);
   size_t off = 0;
-  for (Field* F : fs) {
-    long rows = (long)F->ny * F->nz;
-    long n = rows * H;
+  for (auto& p : ps) {
+    long n = p.rows * nc;
     unsigned blocks = (unsigned)((n + 255) / 256);
-    if (pack) hipLaunchKernelGGL(k_pack_columns, dim3(blocks), dim3(256), 0, m->stream, F->d, buf + off, F->nx, H, i0, rows);
-    else hipLaunchKernelGGL(k_unpack_columns, dim3(blocks), dim3(256), 0, m->stream, F->d, buf + off, F->nx, H, i0, rows);
+    if (pack) {
+      // west side: interior columns [0, nc); east side: [Nx-nc, Nx)
+      int i0 = p.src_xo + (side == 0 ? 0 : m->Nx - nc);
+      hipLaunchKernelGGL(k_pack_columns, dim3(blocks), dim3(256), 0, m->stream, p.src, buf + off, p.src_sx, nc, i0,
+                         p.rows);
+    } else {
+      // west halo: columns [-nc, 0); east halo: [Nx, Nx+nc)
+      int i0 = p.dst_xo + (side == 0 ? -nc : m->Nx);
+      hipLaunchKernelGGL(k_unpack_columns, dim3(blocks), dim3(256), 0, m->stream, p.dst, buf + off, p.dst_sx, nc, i0,
+                         p.rows);
+    }
     off += n;
   }
   LAUNCHCHK();
@@ -757,9 +824,43 @@ gb25_status gb25_halo_pack(gb25_model* m, int group, int side, float* buf) { ret
 gb25_status gb25_halo_unpack(gb25_model* m, int group, int side, const float* buf) {
   return pack_unpack(m, group, side, const_cast<float*>(buf), false);
 }
-gb25_status gb25_time_step_stage(gb25_model* m, int, int) {
+
+// The time step of one slab, cut at its two exchange points (see include/gb25.h).
+gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
   CHECK_MODEL(m);
-  return fail(m, GB25_ERR_STATE, "staged multi-slab time step is not available in this build");
+  if (m->cfg.nranks == 1) return fail(m, GB25_ERR_STATE, "gb25_time_step_stage on a single-slab model");
+  const Grid& g = m->g;
+  gb25_status s;
+  const double dt = m->last_dt;
+  const float chi = euler ? -0.5f : (float)m->cfg.chi;
+  if (stage == 0) {
+    // AB2 update of u,v,T,S and the barotropic forcing; the host then exchanges group 1
+    return ab2_local_impl(m, (float)dt, chi);
+  } else if (stage == 1) {
+    // group 1 has been unpacked into the wide halos: copy the interiors, sub-cycle, publish
+    std::vector<Piece> ps;
+    int nc = 0;
+    group_pieces(m, 1, ps, &nc);
+    for (auto& p : ps)
+      hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, (unsigned)p.rows), dim3(256), 0, m->stream,
+                         p.dst, p.dst_sx, p.dst_xo, p.src, p.src_sx, p.src_xo, g.Nx, (int)p.rows);
+    LAUNCHCHK();
+    if ((s = barotropic_impl(m, (float)dt))) return s;
+    m->time += dt;
+    m->iteration += 1;
+    // y/z boundary layers of the updated fields, so that the packed x columns carry them (group 0 next)
+    return fill_halos_impl(m, false, false);
+  } else if (stage == 2) {
+    // group 0 has been unpacked: corrector on interior + x-halo columns, then update_state without any
+    // further exchange (y/z layers re-filled over the extended x range; w and p recomputed in the halos)
+    if ((s = corrector_impl(m))) return s;
+    if ((s = fill_halos_impl(m, false, true))) return s;
+    if ((s = compute_w_impl(m))) return s;
+    if ((s = compute_p_impl(m))) return s;
+    if ((s = momentum_impl(m))) return s;
+    return tracers_impl(m);
+  }
+  return fail(m, GB25_ERR_INVALID_ARGUMENT, "stage must be 0, 1 or 2");
 }
 
 // ---- profiling ------------------------------------------------------------------------------

@@ -44,10 +44,12 @@ struct Halo2 {
   int n;
 };
 
-// south/north layer of the four 3-D fields + all 2-D fields.  grid: (ceil(Nx/256), Nz + 1)
-__global__ void k_fill_y(Grid g, Halo3 f3, Halo2 f2) {
+// south/north layer of the four 3-D fields + all 2-D fields over columns [i0, i0+ni).
+// grid: (ceil(ni/256), Nz + 1)
+__global__ void k_fill_y(Grid g, Halo3 f3, Halo2 f2, int i0, int ni) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= g.Nx) return;
+  if (i >= ni) return;
+  i += i0;
   int k = blockIdx.y;
   if (k < g.Nz) {
 #pragma unroll
@@ -74,10 +76,11 @@ __global__ void k_fill_y(Grid g, Halo3 f3, Halo2 f2) {
     }
   }
 }
-// bottom/top layer of the four 3-D fields.  grid: (ceil(Nx/256), Ny)
-__global__ void k_fill_z(Grid g, Halo3 f3) {
+// bottom/top layer of the four 3-D fields over columns [i0, i0+ni).  grid: (ceil(ni/256), Ny)
+__global__ void k_fill_z(Grid g, Halo3 f3, int i0, int ni) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= g.Nx) return;
+  if (i >= ni) return;
+  i += i0;
   int j = blockIdx.y;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -452,27 +455,31 @@ struct Baro {
   float *eta1, *U1, *V1;        // state at substep m+1
   float *etab, *Ub, *Vb;        // running time averages
   const float *GU, *GV;
+  // geometry of these 2-D arrays: row pitch, array column of i = 0, computed range [ilo, ihi), and
+  // whether i-1 / i+1 wrap around the periodic domain (single slab) or simply reach into the wide halo
+  int sx, xo, ilo, ihi, wrap;
 };
+__device__ __forceinline__ int bi(const Grid& g, const Baro& b, int i, int j) { return (i + b.xo) + b.sx * (j + g.H); }
 __device__ __forceinline__ float eta_step(const Grid& g, const Baro& b, int i, int j, float dtau) {
-  int ip = (i == g.Nx - 1) ? 0 : i + 1;
-  float dxU = g.dy * b.U0[i2(g, ip, j)] - g.dy * b.U0[i2(g, i, j)];
+  int ip = (b.wrap && i == g.Nx - 1) ? 0 : i + 1;
+  float dxU = g.dy * b.U0[bi(g, b, ip, j)] - g.dy * b.U0[bi(g, b, i, j)];
   float dyV;
-  if (j == g.Ny - 1) dyV = -(g.dxf[j] * b.V0[i2(g, i, j)]);
-  else if (j == 0) dyV = g.dxf[1] * b.V0[i2(g, i, 1)];
-  else dyV = g.dxf[j + 1] * b.V0[i2(g, i, j + 1)] - g.dxf[j] * b.V0[i2(g, i, j)];
-  return b.eta0[i2(g, i, j)] - dtau * (dxU + dyV) / g.azc[j];
+  if (j == g.Ny - 1) dyV = -(g.dxf[j] * b.V0[bi(g, b, i, j)]);
+  else if (j == 0) dyV = g.dxf[1] * b.V0[bi(g, b, i, 1)];
+  else dyV = g.dxf[j + 1] * b.V0[bi(g, b, i, j + 1)] - g.dxf[j] * b.V0[bi(g, b, i, j)];
+  return b.eta0[bi(g, b, i, j)] - dtau * (dxU + dyV) / g.azc[j];
 }
 __global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, float dtau, float wgt) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x + b.ilo;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny) return;
-  int im = (i == 0) ? g.Nx - 1 : i - 1;
+  if (i >= b.ihi || j >= g.Ny) return;
+  int im = (b.wrap && i == 0) ? g.Nx - 1 : i - 1;
   float e = eta_step(g, b, i, j, dtau);
   float ew = eta_step(g, b, im, j, dtau);
   float dxe = (e - ew) / g.dxc[j];
   float dye = 0.f;
   if (j > 0) dye = (e - eta_step(g, b, i, j - 1, dtau)) / g.dy;
-  int o = i2(g, i, j);
+  int o = bi(g, b, i, j);
   float Un = b.U0[o] + dtau * (-g.g * g.Lz * dxe + b.GU[o]);
   float Vn = b.V0[o] + dtau * (-g.g * g.Lz * dye + b.GV[o]);
   b.eta1[o] = e;
@@ -482,15 +489,24 @@ __global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, floa
   b.Ub[o] += wgt * Un;
   b.Vb[o] += wgt * Vn;
 }
+// eta, U, V <- time averages on the interior (source arrays may be the wide work arrays)
 __global__ void k_barotropic_finalize(Grid g, float* eta, float* U, float* V, const float* etab, const float* Ub,
-                                      const float* Vb) {
+                                      const float* Vb, int src_sx, int src_xo) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= g.Nx || j >= g.Ny) return;
-  int o = i2(g, i, j);
-  eta[o] = etab[o];
-  U[o] = Ub[o];
-  V[o] = Vb[o];
+  int o = i2(g, i, j), q = (i + src_xo) + src_sx * (j + g.H);
+  eta[o] = etab[q];
+  U[o] = Ub[q];
+  V[o] = Vb[q];
+}
+// copy columns [0, Nx) of whole rows between two 2-D arrays with different pitch / x-offset
+__global__ void k_copy_interior_columns(float* __restrict__ dst, int dsx, int dxo, const float* __restrict__ src,
+                                        int ssx, int sxo, int Nx, int rows) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int r = blockIdx.y;
+  if (i >= Nx || r >= rows) return;
+  dst[(i + dxo) + dsx * r] = src[(i + sxo) + ssx * r];
 }
 
 // =============================================================================================
@@ -515,12 +531,15 @@ __global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const float* __
 }
 // Ubar,Vbar <- column integrals of u,v (work arrays, as in the reference), then
 // u += (U - Ubar)/H, v += (V - Vbar)/H.  The second sweep re-reads the column from L2.
+// Columns [i0, i0+ni): a slab of a multi-GPU run also corrects its x-halo columns (same arithmetic as the
+// owning neighbour, so no second halo exchange is needed); Ubar/Vbar are stored for interior columns only.
 __global__ __launch_bounds__(256) void k_corrector(Grid g, float* __restrict__ u, float* __restrict__ v,
                                                    const float* __restrict__ U, const float* __restrict__ V,
-                                                   float* __restrict__ Ub, float* __restrict__ Vb) {
+                                                   float* __restrict__ Ub, float* __restrict__ Vb, int i0, int ni) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny) return;
+  if (i >= ni || j >= g.Ny) return;
+  i += i0;
   const int o0 = ic(g, i, j, 0), ov0 = iv(g, i, j, 0);
   int o = o0, ov = ov0;
   float su = g.dzc[0] * u[o], sv = g.dzc[0] * v[ov];
@@ -531,8 +550,10 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, float* __restrict__ u
     sv += g.dzc[k] * v[ov];
   }
   int o2 = i2(g, i, j);
-  Ub[o2] = su;
-  Vb[o2] = sv;
+  if (i >= 0 && i < g.Nx) {
+    Ub[o2] = su;
+    Vb[o2] = sv;
+  }
   const float du = (U[o2] - su) / g.Lz, dv = (V[o2] - sv) / g.Lz;
   o = o0;
   ov = ov0;
@@ -558,20 +579,21 @@ __global__ void k_set_baroclinic_instability(Grid g, float* __restrict__ T, floa
 }
 
 // x-slab halo exchange: pack H interior columns next to a slab edge / unpack into the halo.
-// buffer layout: [row][q] with q in 0..H-1, rows = all parent rows of the array.
-__global__ void k_pack_columns(const float* __restrict__ c, float* __restrict__ buf, int sx, int H, int i0, long rows) {
+// buffer layout: [row][q] with q in 0..ncols-1, rows = all parent rows of the array.
+__global__ void k_pack_columns(const float* __restrict__ c, float* __restrict__ buf, int sx, int ncols, int i0,
+                               long rows) {
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * H) return;
-  int q = t % H;
-  long row = t / H;
+  if (t >= rows * ncols) return;
+  int q = t % ncols;
+  long row = t / ncols;
   buf[t] = c[row * sx + i0 + q];
 }
-__global__ void k_unpack_columns(float* __restrict__ c, const float* __restrict__ buf, int sx, int H, int i0,
+__global__ void k_unpack_columns(float* __restrict__ c, const float* __restrict__ buf, int sx, int ncols, int i0,
                                  long rows) {
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * H) return;
-  int q = t % H;
-  long row = t / H;
+  if (t >= rows * ncols) return;
+  int q = t % ncols;
+  long row = t / ncols;
   c[row * sx + i0 + q] = buf[t];
 }
 

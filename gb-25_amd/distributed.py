@@ -1,0 +1,171 @@
+"""x-slab multi-GPU driver: one process (rank) per GPU, packed halo exchange between ring neighbours.
+
+Replaces what the reference gets from `Oceananigans.Distributed(arch; partition=Partition(Rx, Ry, 1))` + XLA's SPMD
+partitioner (GB-25 sharding/sharded_baroclinic_instability_simulation_run.jl:65-72): there the halos travel as
+XLA collective-permutes; here each time step has exactly two explicit exchanges:
+
+    stage 0   AB2 update of u,v,T,S + barotropic forcing G.U,G.V          (local)
+    exchange  group 1: W = Ns+1 columns of eta,U,V,G.U,G.V               -> wide barotropic halos
+    stage 1   Ns split-explicit substeps on the widened slab, y/z layers  (local, no exchange inside the sub-cycle)
+    exchange  group 0: H columns of u,v,T,S (+ eta,U,V)                  -> x halos
+    stage 2   barotropic corrector (also in the halo columns), w, p', tendencies   (local)
+
+No collective is needed: every rank talks to its west and east neighbour only (send/recv over xGMI via
+torch.distributed, backend "nccl" = RCCL).  The transport is injected so that the same sequencing code runs
+(a) across processes and (b) over several slabs inside one process (tests: decomposition invariance on one GPU).
+"""
+import numpy as np
+import torch
+
+from .binding import HipBackend
+from .model import HydrostaticFreeSurfaceModel
+from .sharding import slab_neighbours
+
+WEST, EAST = 0, 1
+
+
+class TorchDistributedTransport:
+    """Ring exchange with torch.distributed point-to-point ops.
+
+    Posting order is part of the protocol: sends [west pack, east pack], receives [east halo, west halo].
+    With two ranks both neighbours are the same peer and messages between one pair match in posting order,
+    so the peer's FIRST send (its west pack) must meet our FIRST receive (our east halo)."""
+
+    def __init__(self, rank, nranks, dist=None):
+        import torch.distributed as tdist
+        self.dist = dist or tdist
+        self.rank, self.nranks = rank, nranks
+        self.west, self.east = slab_neighbours(rank, nranks)
+
+    def exchange(self, send_west, send_east, recv_west, recv_east):
+        d = self.dist
+        ops = [d.P2POp(d.isend, send_west, self.west), d.P2POp(d.isend, send_east, self.east),
+               d.P2POp(d.irecv, recv_east, self.east), d.P2POp(d.irecv, recv_west, self.west)]
+        for req in d.batch_isend_irecv(ops):
+            req.wait()
+
+
+class LocalRingTransport:
+    """All slabs live in one process: `exchange_all` moves every slab's packs to its neighbours' receive buffers."""
+
+    @staticmethod
+    def exchange_all(steppers, group):
+        P = len(steppers)
+        for r, s in enumerate(steppers):
+            west, east = slab_neighbours(r, P)
+            steppers[west].recv[group][EAST].copy_(s.send[group][WEST])   # my west pack -> west nbr's east halo
+            steppers[east].recv[group][WEST].copy_(s.send[group][EAST])   # my east pack -> east nbr's west halo
+
+
+class SlabStepper:
+    """Sequencing of one slab: owns the pack buffers and cuts the step at the two exchange points.
+
+    The model's kernels are put on torch's current stream of the device, so pack kernels, the transport's
+    send/recv (or copies) and unpack kernels are ordered by the stream itself: no host synchronisation."""
+
+    def __init__(self, backend, device):
+        self.b = backend
+        self.send, self.recv = {}, {}
+        for group in (0, 1):
+            n = backend.halo_buffer_elems(group)
+            self.send[group] = [torch.empty(n, dtype=torch.float32, device=device) for _ in range(2)]
+            self.recv[group] = [torch.empty(n, dtype=torch.float32, device=device) for _ in range(2)]
+        if device.type == "cuda":
+            self.stream = torch.cuda.current_stream(device)
+            backend.set_stream(self.stream.cuda_stream)
+
+    def pack(self, group):
+        for side in (WEST, EAST):
+            self.b.halo_pack(group, side, self.send[group][side].data_ptr())
+
+    def unpack(self, group):
+        for side in (WEST, EAST):
+            self.b.halo_unpack(group, side, self.recv[group][side].data_ptr())
+
+
+def _run_stage(steppers, fn):
+    for s in steppers:
+        fn(s)
+
+
+def step_slabs(steppers, exchange, euler=False):
+    """One time step of a list of slabs (a single one in the multi-process case)."""
+    _run_stage(steppers, lambda s: (s.b.time_step_stage(0, euler), s.pack(1)))
+    exchange(1)
+    _run_stage(steppers, lambda s: (s.unpack(1), s.b.time_step_stage(1, euler), s.pack(0)))
+    exchange(0)
+    _run_stage(steppers, lambda s: (s.unpack(0), s.b.time_step_stage(2, euler)))
+
+
+def first_step_slabs(steppers, exchange):
+    """first_time_step!: initialize!, update_state!, then an Euler step (src/timestepping_utils.jl:21-27)."""
+    _run_stage(steppers, lambda s: (s.b.initialize(), s.b.fill_halo_regions_local(), s.pack(0)))
+    exchange(0)
+    _run_stage(steppers, lambda s: (s.unpack(0), s.b.update_state_local()))
+    step_slabs(steppers, exchange, euler=True)
+
+
+class SlabModel(HydrostaticFreeSurfaceModel):
+    """One rank's slab of a (Nx_global x Ny x Nz) model; same API as the single-GPU model.
+    Fields are the LOCAL slab (Nx_global / nranks columns)."""
+
+    def __init__(self, Nx_global, Ny, Nz, *, dt, rank, nranks, device=0, halo=8, substeps=30, transport=None, **kw):
+        backend = HipBackend(Nx_global, Ny, Nz, dt=dt, halo=halo, substeps=substeps, device=device, rank=rank,
+                             nranks=nranks, **kw)
+        super().__init__(_SlabBackendFacade(backend, self), Nx_global // nranks, Ny, Nz, halo)
+        self.rank, self.nranks = rank, nranks
+        self.stepper = SlabStepper(backend, torch.device("cuda", device))
+        self.transport = transport or TorchDistributedTransport(rank, nranks)
+
+    def _exchange(self, group):
+        s = self.stepper
+        self.transport.exchange(s.send[group][WEST], s.send[group][EAST], s.recv[group][WEST], s.recv[group][EAST])
+
+
+class _SlabBackendFacade:
+    """Gives model.first_time_step / time_step / loop (which call backend.*) the staged implementation,
+    and forwards everything else to the HipBackend."""
+
+    def __init__(self, backend, owner):
+        self._b, self._owner = backend, owner
+
+    def __getattr__(self, name):
+        return getattr(self._b, name)
+
+    def first_time_step(self):
+        first_step_slabs([self._owner.stepper], self._owner._exchange)
+
+    def time_step(self):
+        step_slabs([self._owner.stepper], self._owner._exchange)
+
+    def loop(self, n):
+        for _ in range(int(n)):
+            step_slabs([self._owner.stepper], self._owner._exchange)
+
+
+class LocalSlabEnsemble:
+    """P slabs of one global model stepped in lock-step inside ONE process on one GPU (tests)."""
+
+    def __init__(self, Nx_global, Ny, Nz, P, *, dt, device=0, **kw):
+        self.P, self.Nx_loc = P, Nx_global // P
+        self.backends = [HipBackend(Nx_global, Ny, Nz, dt=dt, device=device, rank=r, nranks=P, **kw) for r in range(P)]
+        dev = torch.device("cuda", device)
+        self.steppers = [SlabStepper(b, dev) for b in self.backends]
+        self._exchange = lambda group: LocalRingTransport.exchange_all(self.steppers, group)
+
+    def scatter(self, name, global_interior):
+        for r, b in enumerate(self.backends):
+            b.set_field(name, np.ascontiguousarray(global_interior[r * self.Nx_loc:(r + 1) * self.Nx_loc]), False)
+
+    def gather(self, name):
+        return np.concatenate([b.get_field(name, False) for b in self.backends], axis=0)
+
+    def first_time_step(self):
+        first_step_slabs(self.steppers, self._exchange)
+
+    def time_step(self):
+        step_slabs(self.steppers, self._exchange)
+
+    def loop(self, n):
+        for _ in range(n):
+            self.time_step()

@@ -109,7 +109,7 @@ def test_phase_by_phase_against_oracle():
     # test grids the deeper latitude halos lie beyond the pole (meaningless metrics), so compare ring 1
     core = (slice(H - 1, -(H - 1)), slice(H - 1, -(H - 1)), slice(H, -H))
     assert rel(get(r, "w")[core], get(v, "w")[core]) < 1e-5
-    assert rel(get(r, "pHY")[core], get(v, "pHY")[core]) < 5e-6
+    assert rel(get(r, "pHY")[core], get(v, "pHY")[core]) < 2e-5   # fp32 rho(T,S,z) ~ 1e3 kg/m3: ulp 1.2e-4
     assert np.isfinite(get(r, "w")[1:-1, 1:-1]).all() and np.isfinite(get(r, "pHY")[1:-1, 1:-1]).all()
     assert np.array_equal(get(r, "w")[:, :, H], np.zeros_like(get(r, "w")[:, :, H]))
 
