@@ -18,6 +18,9 @@ struct Grid {
   // metric tables, pointers are pre-offset so that index 0 is the first interior cell/face
   const float *dxc, *dxf, *azc, *azf, *fcor, *phic;  // by j   (valid j: -H-2 .. Ny+H+2)
   const float *zc, *dzc, *dzf;                       // by k   (valid k: -H-2 .. Nz+H+2)
+  // TEOS-10 folded per level: rho'(s,t) = sum_{i+j<=6} eos[k][idx(i,j)] s^i t^j, k = 0..Nz (Nz = mirrored halo level)
+  const double* eos;
+  const double* dzf_d;                               // dzf in fp64 for the hydrostatic integral, by k (0..Nz)
 };
 
 // element offsets
@@ -145,46 +148,21 @@ __device__ __forceinline__ float sym_interp(bool fourth, float q0, float q1, flo
 }
 
 // ---------------------------------------------------------------------------------------------
-// TEOS-10 55-term polynomial (Roquet et al. 2015) as used by SeawaterPolynomials'
-// TEOS10EquationOfState: rho(Theta, S_A, Z) = r0(zeta) + r'(tau, s, zeta).
+// TEOS-10 55-term polynomial (Roquet et al. 2015) as used by SeawaterPolynomials' TEOS10EquationOfState:
+// rho(Theta, S_A, Z) = r0(zeta) + r'(tau, s, zeta), tau = Theta/40, s = sqrt((S_A+32) 0.875/35.16504),
+// zeta = -Z/1e4.  The host folds the zeta dependence per model level (gb25_api.hip: build_eos_tables).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float teos10_rho(float Theta, float Sa, float Z) {
-  const float t = Theta * 0.025f;
-  const float s = __builtin_sqrtf((Sa + 32.f) * (float)(0.875 / 35.16504));
-  const float z = -Z * 1e-4f;
-  const float R000 = 8.0189615746e+02f, R100 = 8.6672408165e+02f, R200 = -1.7864682637e+03f,
-              R300 = 2.0375295546e+03f, R400 = -1.2849161071e+03f, R500 = 4.3227585684e+02f,
-              R600 = -6.0579916612e+01f, R010 = 2.6010145068e+01f, R110 = -6.5281885265e+01f,
-              R210 = 8.1770425108e+01f, R310 = -5.6888046321e+01f, R410 = 1.7681814114e+01f,
-              R510 = -1.9193502195e+00f, R020 = -3.7074170417e+01f, R120 = 6.1548258127e+01f,
-              R220 = -6.0362551501e+01f, R320 = 2.9130021253e+01f, R420 = -5.4723692739e+00f,
-              R030 = 2.1661789529e+01f, R130 = -3.3449108469e+01f, R230 = 1.9717078466e+01f,
-              R330 = -3.1742946532e+00f, R040 = -8.3627885467e+00f, R140 = 1.1311538584e+01f,
-              R240 = -5.3563304045e+00f, R050 = 5.4048723791e-01f, R150 = 4.8169980163e-01f,
-              R060 = -1.9083568888e-01f, R001 = 1.9681925209e+01f, R101 = -4.2549998214e+01f,
-              R201 = 5.0774768218e+01f, R301 = -3.0938076334e+01f, R401 = 6.6051753097e+00f,
-              R011 = -1.3336301113e+01f, R111 = -4.4870114575e+00f, R211 = 5.0042598061e+00f,
-              R311 = -6.5399043664e-01f, R021 = 6.7080479603e+00f, R121 = 3.5063081279e+00f,
-              R221 = -1.8795372996e+00f, R031 = -2.4649669534e+00f, R131 = -5.5077101279e-01f,
-              R041 = 5.5927935970e-01f, R002 = 2.0660924175e+00f, R102 = -4.9527603989e+00f,
-              R202 = 2.5019633244e+00f, R012 = 2.0564311499e+00f, R112 = -2.1311365518e-01f,
-              R022 = -1.2419983026e+00f, R003 = -2.3342758797e-02f, R103 = -1.8507636718e-02f,
-              R013 = 3.7969820455e-01f;
-  const float R00 = 4.6494977072e+01f, R01 = -5.2099962525e+00f, R02 = 2.2601900708e-01f,
-              R03 = 6.4326772569e-02f, R04 = 1.5616995503e-02f, R05 = -1.7243708991e-03f;
-  float r3 = R013 * t + R103 * s + R003;
-  float r2 = (R022 * t + R112 * s + R012) * t + (R202 * s + R102) * s + R002;
-  float r1 = (((R041 * t + R131 * s + R031) * t + (R221 * s + R121) * s + R021) * t +
-              ((R311 * s + R211) * s + R111) * s + R011) * t +
-             (((R401 * s + R301) * s + R201) * s + R101) * s + R001;
-  float r0 = (((((R060 * t + R150 * s + R050) * t + (R240 * s + R140) * s + R040) * t +
-                ((R330 * s + R230) * s + R130) * s + R030) * t +
-               (((R420 * s + R320) * s + R220) * s + R120) * s + R020) * t +
-              ((((R510 * s + R410) * s + R310) * s + R210) * s + R110) * s + R010) * t +
-             (((((R600 * s + R500) * s + R400) * s + R300) * s + R200) * s + R100) * s + R000;
-  float rp = ((r3 * z + r2) * z + r1) * z + r0;
-  float rz = (((((R05 * z + R04) * z + R03) * z + R02) * z + R01) * z + R00) * z;
-  return rz + rp;
+// rho - rho0 at one level from the folded table: 28 coefficients ordered j-major (t-power), i ascending (s-power):
+// [P_0(s): 7][P_1: 6][P_2: 5][P_3: 4][P_4: 3][P_5: 2][P_6: 1];  rho' = sum_j t^j P_j(s).  All in fp64.
+__device__ __forceinline__ double teos10_level(const double* __restrict__ c, double s, double t) {
+  double p0 = c[0] + s * (c[1] + s * (c[2] + s * (c[3] + s * (c[4] + s * (c[5] + s * c[6])))));
+  double p1 = c[7] + s * (c[8] + s * (c[9] + s * (c[10] + s * (c[11] + s * c[12]))));
+  double p2 = c[13] + s * (c[14] + s * (c[15] + s * (c[16] + s * c[17])));
+  double p3 = c[18] + s * (c[19] + s * (c[20] + s * c[21]));
+  double p4 = c[22] + s * (c[23] + s * c[24]);
+  double p5 = c[25] + s * c[26];
+  double p6 = c[27];
+  return p0 + t * (p1 + t * (p2 + t * (p3 + t * (p4 + t * (p5 + t * p6)))));
 }
 
 // XCD-aware remap of a linear block id: blocks b and b+8 share an XCD (round-robin dispatch),

@@ -210,6 +210,56 @@ gb25_status build_grid(gb25_model* m) {
   return GB25_OK;
 }
 
+// TEOS-10 (Roquet et al. 2015) coefficient table R[i][j][k] of s^i t^j zeta^k and the reference profile r0(zeta),
+// folded per model level: rho - rho0 = sum_{i+j<=6} C_ij(k) s^i t^j with
+// C_ij(k) = sum_m R_ijm zeta_k^m  (+ r0(zeta_k) - rho0 on the constant term).
+struct EosTerm { int i, j, k; double v; };
+const EosTerm kEos[] = {
+    {0,0,0, 8.0189615746e+02}, {1,0,0, 8.6672408165e+02}, {2,0,0,-1.7864682637e+03}, {3,0,0, 2.0375295546e+03},
+    {4,0,0,-1.2849161071e+03}, {5,0,0, 4.3227585684e+02}, {6,0,0,-6.0579916612e+01}, {0,1,0, 2.6010145068e+01},
+    {1,1,0,-6.5281885265e+01}, {2,1,0, 8.1770425108e+01}, {3,1,0,-5.6888046321e+01}, {4,1,0, 1.7681814114e+01},
+    {5,1,0,-1.9193502195e+00}, {0,2,0,-3.7074170417e+01}, {1,2,0, 6.1548258127e+01}, {2,2,0,-6.0362551501e+01},
+    {3,2,0, 2.9130021253e+01}, {4,2,0,-5.4723692739e+00}, {0,3,0, 2.1661789529e+01}, {1,3,0,-3.3449108469e+01},
+    {2,3,0, 1.9717078466e+01}, {3,3,0,-3.1742946532e+00}, {0,4,0,-8.3627885467e+00}, {1,4,0, 1.1311538584e+01},
+    {2,4,0,-5.3563304045e+00}, {0,5,0, 5.4048723791e-01}, {1,5,0, 4.8169980163e-01}, {0,6,0,-1.9083568888e-01},
+    {0,0,1, 1.9681925209e+01}, {1,0,1,-4.2549998214e+01}, {2,0,1, 5.0774768218e+01}, {3,0,1,-3.0938076334e+01},
+    {4,0,1, 6.6051753097e+00}, {0,1,1,-1.3336301113e+01}, {1,1,1,-4.4870114575e+00}, {2,1,1, 5.0042598061e+00},
+    {3,1,1,-6.5399043664e-01}, {0,2,1, 6.7080479603e+00}, {1,2,1, 3.5063081279e+00}, {2,2,1,-1.8795372996e+00},
+    {0,3,1,-2.4649669534e+00}, {1,3,1,-5.5077101279e-01}, {0,4,1, 5.5927935970e-01}, {0,0,2, 2.0660924175e+00},
+    {1,0,2,-4.9527603989e+00}, {2,0,2, 2.5019633244e+00}, {0,1,2, 2.0564311499e+00}, {1,1,2,-2.1311365518e-01},
+    {0,2,2,-1.2419983026e+00}, {0,0,3,-2.3342758797e-02}, {1,0,3,-1.8507636718e-02}, {0,1,3, 3.7969820455e-01}};
+const double kEosR0[6] = {4.6494977072e+01, -5.2099962525e+00, 2.2601900708e-01,
+                          6.4326772569e-02, 1.5616995503e-02, -1.7243708991e-03};
+
+gb25_status build_eos_tables(gb25_model* m) {
+  const int Nz = m->cfg.Nz, offk = m->metric_off_k;
+  const std::vector<double>&zc = m->h_metric[GB25_M_ZC], &dzf = m->h_metric[GB25_M_DZF];
+  std::vector<double> tab((size_t)28 * (Nz + 1), 0.0), dz(Nz + 1);
+  for (int k = 0; k <= Nz; k++) {
+    // geopotential height of level k; the halo level above the surface is mirrored (Oceananigans Z^ccc)
+    double Z = (k < Nz) ? zc[offk + k] : zc[offk + Nz - 1] - dzf[offk + Nz - 1];
+    double zeta = -Z * 1e-4;
+    double* c = &tab[(size_t)28 * k];
+    for (const EosTerm& t : kEos) {
+      int base = 0;
+      for (int j = 0; j < t.j; j++) base += 7 - j;
+      c[base + t.i] += t.v * std::pow(zeta, t.k);
+    }
+    double r0 = 0;
+    for (int q = 5; q >= 0; q--) r0 = (r0 + kEosR0[q]) * zeta;
+    c[0] += r0 - m->cfg.rho0;
+    dz[k] = dzf[offk + k];
+  }
+  double* d = nullptr;
+  HIPCHK(hipMalloc(&d, (tab.size() + dz.size()) * sizeof(double)));
+  HIPCHK(hipMemcpy(d, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d + tab.size(), dz.data(), dz.size() * sizeof(double), hipMemcpyHostToDevice));
+  m->dev_tables.push_back(reinterpret_cast<float*>(d));
+  m->g.eos = d;
+  m->g.dzf_d = d + tab.size();
+  return GB25_OK;
+}
+
 // Split-explicit averaging weights (Oceananigans FixedSubstepNumber, restated): shape function
 // (p=2, q=4, r=0.18927) sampled at tau = 2m/Ns, truncated like searchsortedlast(w, 0, rev=true).
 void build_substeps(gb25_model* m) {
@@ -537,6 +587,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   m->last_dt = cfg->dt;
   gb25_status s;
   if ((s = build_grid(m))) return s;
+  if ((s = build_eos_tables(m))) return s;
   build_substeps(m);
   const int H = cfg->halo, sx = m->Nx + 2 * H;
   for (int id = 0; id < GB25_FIELD_COUNT; id++) {

@@ -143,24 +143,29 @@ __global__ __launch_bounds__(256) void k_compute_w(Grid g, const float* __restri
   }
 }
 
-__device__ __forceinline__ float buoyancy(const Grid& g, float T, float S, float Z) {
-  return -(g.g * (teos10_rho(T, S, Z) - g.rho0)) / g.rho0;
-}
+// Hydrostatic pressure anomaly p'[k] = p'[k+1] - Iz(b)[k+1] dz^f[k+1], b = -g rho'(T,S,z)/rho0 (TEOS-10).
+// The state stays fp32, but the equation of state and the vertical integral run in fp64: rho ~ 1e3 kg/m3
+// has an fp32 ulp of 1.2e-4 kg/m3, which after integration is ~1e-3 of the horizontal pressure-gradient
+// signal (measured: fp32 EOS puts G.u, G.S, w 1e-3 away from an fp64 run; fp64 EOS brings every field
+// within sqrt(eps32)).  fp64 VALU is half rate on gfx950 and this kernel is a small share of the step; the
+// depth dependence of the 55-term polynomial is folded per level on the host (28 fp64 FMAs per cell).
 __global__ __launch_bounds__(256) void k_compute_p(Grid g, const float* __restrict__ T, const float* __restrict__ S,
                                                    float* __restrict__ p) {
   int i = blockIdx.x * blockDim.x + threadIdx.x - g.H + 1;
   int j = blockIdx.y * blockDim.y + threadIdx.y - g.H + 1;
   if (i > g.Nx + g.H - 2 || j > g.Ny + g.H - 2) return;
   const int Nz = g.Nz;
+  const double gr = -(double)g.g / (double)g.rho0;
+  const double sc = 0.875 / 35.16504;
   int o = ic(g, i, j, Nz);
-  // b in the first halo cell above the surface: mirrored geopotential height (Oceananigans Z^ccc)
-  float bup = buoyancy(g, T[o], S[o], g.zc[Nz - 1] - g.dzf[Nz - 1]);
-  float pk = 0.f;
+  // b in the first halo cell above the surface: mirrored geopotential height (table row Nz)
+  double bup = gr * teos10_level(g.eos + 28 * Nz, sqrt(((double)S[o] + 32.0) * sc), (double)T[o] * 0.025);
+  double pk = 0.0;
   for (int k = Nz - 1; k >= 0; k--) {
     o -= g.pl_c;
-    float bk = buoyancy(g, T[o], S[o], g.zc[k]);
-    pk = pk - 0.5f * (bk + bup) * g.dzf[k + 1];
-    p[o] = pk;
+    double bk = gr * teos10_level(g.eos + 28 * k, sqrt(((double)S[o] + 32.0) * sc), (double)T[o] * 0.025);
+    pk = pk - 0.5 * (bk + bup) * g.dzf_d[k + 1];
+    p[o] = (float)pk;
     bup = bk;
   }
 }

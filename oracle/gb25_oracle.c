@@ -261,11 +261,14 @@ long FN(get_iteration)(void *h) { return ((model *)h)->iter; }
  * restated from the published coefficient table.  rho = r0(zeta) + r'(tau, s, zeta),
  * tau = Theta/40, s = sqrt((S_A + 32) * 0.875/35.16504), zeta = -Z/1e4;
  * rho' = rho - reference_density (1020 kg/m3). */
-static inline REAL teos10_rho(REAL Theta, REAL Sa, REAL Z) {
-  const REAL t = Theta * (REAL)0.025;
-  const REAL s = (REAL)sqrt((double)((Sa + (REAL)32.0) * (REAL)(0.875 / 35.16504)));
-  const REAL z = -Z * (REAL)1e-4;
-  const REAL R000 = 8.0189615746e+02, R100 = 8.6672408165e+02, R200 = -1.7864682637e+03,
+#ifndef PREAL
+#define PREAL REAL /* precision of the equation of state and of the hydrostatic integral */
+#endif
+static inline PREAL teos10_rho(PREAL Theta, PREAL Sa, PREAL Z) {
+  const PREAL t = Theta * (PREAL)0.025;
+  const PREAL s = (PREAL)sqrt((double)((Sa + (PREAL)32.0) * (PREAL)(0.875 / 35.16504)));
+  const PREAL z = -Z * (PREAL)1e-4;
+  const PREAL R000 = 8.0189615746e+02, R100 = 8.6672408165e+02, R200 = -1.7864682637e+03,
              R300 = 2.0375295546e+03, R400 = -1.2849161071e+03, R500 = 4.3227585684e+02,
              R600 = -6.0579916612e+01, R010 = 2.6010145068e+01, R110 = -6.5281885265e+01,
              R210 = 8.1770425108e+01, R310 = -5.6888046321e+01, R410 = 1.7681814114e+01,
@@ -283,23 +286,23 @@ static inline REAL teos10_rho(REAL Theta, REAL Sa, REAL Z) {
              R202 = 2.5019633244e+00, R012 = 2.0564311499e+00, R112 = -2.1311365518e-01,
              R022 = -1.2419983026e+00, R003 = -2.3342758797e-02, R103 = -1.8507636718e-02,
              R013 = 3.7969820455e-01;
-  const REAL R00 = 4.6494977072e+01, R01 = -5.2099962525e+00, R02 = 2.2601900708e-01,
+  const PREAL R00 = 4.6494977072e+01, R01 = -5.2099962525e+00, R02 = 2.2601900708e-01,
              R03 = 6.4326772569e-02, R04 = 1.5616995503e-02, R05 = -1.7243708991e-03;
-  REAL r3 = R013 * t + R103 * s + R003;
-  REAL r2 = (R022 * t + R112 * s + R012) * t + (R202 * s + R102) * s + R002;
-  REAL r1 = (((R041 * t + R131 * s + R031) * t + (R221 * s + R121) * s + R021) * t +
+  PREAL r3 = R013 * t + R103 * s + R003;
+  PREAL r2 = (R022 * t + R112 * s + R012) * t + (R202 * s + R102) * s + R002;
+  PREAL r1 = (((R041 * t + R131 * s + R031) * t + (R221 * s + R121) * s + R021) * t +
              ((R311 * s + R211) * s + R111) * s + R011) * t +
             (((R401 * s + R301) * s + R201) * s + R101) * s + R001;
-  REAL r0 = (((((R060 * t + R150 * s + R050) * t + (R240 * s + R140) * s + R040) * t +
+  PREAL r0 = (((((R060 * t + R150 * s + R050) * t + (R240 * s + R140) * s + R040) * t +
                ((R330 * s + R230) * s + R130) * s + R030) * t +
               (((R420 * s + R320) * s + R220) * s + R120) * s + R020) * t +
              ((((R510 * s + R410) * s + R310) * s + R210) * s + R110) * s + R010) * t +
             (((((R600 * s + R500) * s + R400) * s + R300) * s + R200) * s + R100) * s + R000;
-  REAL rp = ((r3 * z + r2) * z + r1) * z + r0;
-  REAL rz = (((((R05 * z + R04) * z + R03) * z + R02) * z + R01) * z + R00) * z;
+  PREAL rp = ((r3 * z + r2) * z + r1) * z + r0;
+  PREAL rz = (((((R05 * z + R04) * z + R03) * z + R02) * z + R01) * z + R00) * z;
   return rz + rp;
 }
-double FN(teos10_rho)(double T, double S, double Z) { return (double)teos10_rho((REAL)T, (REAL)S, (REAL)Z); }
+double FN(teos10_rho)(double T, double S, double Z) { return (double)teos10_rho((PREAL)(REAL)T, (PREAL)(REAL)S, (PREAL)(REAL)Z); }
 
 /* geopotential height of a cell centre, mirrored through the boundary outside 1..Nz
  * (Oceananigans Z^ccc, restated). */
@@ -309,9 +312,9 @@ static inline REAL Zccc(const model *m, int k) {
   return MK(zc, k);
 }
 /* buoyancy perturbation b = -g rho'/rho0 at (i,j,k) (SeawaterBuoyancy, restated) */
-static inline REAL buoyancy(const model *m, int i, int j, int k) {
-  REAL rho = teos10_rho(A3(F_T, i, j, k), A3(F_S, i, j, k), Zccc(m, k));
-  return -(m->g * (rho - m->rho0)) / m->rho0;
+static inline PREAL buoyancy(const model *m, int i, int j, int k) {
+  PREAL rho = teos10_rho((PREAL)A3(F_T, i, j, k), (PREAL)A3(F_S, i, j, k), (PREAL)Zccc(m, k));
+  return -((PREAL)m->g * (rho - (PREAL)m->rho0)) / (PREAL)m->rho0;
 }
 
 /* ---------------------------------------------------------------- WENO
@@ -557,13 +560,15 @@ void FN(compute_p)(void *h) {
 #pragma omp parallel for schedule(static)
   for (int j = -H + 2; j <= m->Ny + H - 1; j++)
     for (int i = -H + 2; i <= m->Nx + H - 1; i++) {
-      REAL bup = buoyancy(m, i, j, Nz + 1);
-      REAL bk = buoyancy(m, i, j, Nz);
-      A3(F_P, i, j, Nz) = -((bk + bup) / (REAL)2) * DZF(Nz + 1);
+      PREAL bup = buoyancy(m, i, j, Nz + 1);
+      PREAL bk = buoyancy(m, i, j, Nz);
+      PREAL pk = -((bk + bup) / (PREAL)2) * (PREAL)DZF(Nz + 1);
+      A3(F_P, i, j, Nz) = (REAL)pk;
       for (int k = Nz - 1; k >= 1; k--) {
         bup = bk;
         bk = buoyancy(m, i, j, k);
-        A3(F_P, i, j, k) = A3(F_P, i, j, k + 1) - ((bk + bup) / (REAL)2) * DZF(k + 1);
+        pk = pk - ((bk + bup) / (PREAL)2) * (PREAL)DZF(k + 1);
+        A3(F_P, i, j, k) = (REAL)pk;
       }
     }
 }

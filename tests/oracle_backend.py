@@ -54,6 +54,7 @@ class OracleBackend:
     def __init__(self, Nx, Ny, Nz, *, dt, halo=8, substeps=30, precision="f64", **overrides):
         self.sfx = "_" + precision
         self.lib = oracle_lib(precision)
+        # "f32p64": fp32 state, equation of state + hydrostatic integral in fp64 (accuracy study)
         self.dtype = np.float64 if precision == "f64" else np.float32
         self.ctype = C.c_double if precision == "f64" else C.c_float
         cfg = OConfig(Nx, Ny, Nz, halo, substeps, dt, 0.1, -80, 80, 0, 360, 4000, 30, 9.80665, 7.292115e-5, 6371e3,

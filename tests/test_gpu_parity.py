@@ -109,7 +109,7 @@ def test_phase_by_phase_against_oracle():
     # test grids the deeper latitude halos lie beyond the pole (meaningless metrics), so compare ring 1
     core = (slice(H - 1, -(H - 1)), slice(H - 1, -(H - 1)), slice(H, -H))
     assert rel(get(r, "w")[core], get(v, "w")[core]) < 1e-5
-    assert rel(get(r, "pHY")[core], get(v, "pHY")[core]) < 2e-5   # fp32 rho(T,S,z) ~ 1e3 kg/m3: ulp 1.2e-4
+    assert rel(get(r, "pHY")[core], get(v, "pHY")[core]) < 5e-7   # fp64 EOS + integral, stored as fp32
     assert np.isfinite(get(r, "w")[1:-1, 1:-1]).all() and np.isfinite(get(r, "pHY")[1:-1, 1:-1]).all()
     assert np.array_equal(get(r, "w")[:, :, H], np.zeros_like(get(r, "w")[:, :, H]))
 
@@ -117,7 +117,7 @@ def test_phase_by_phase_against_oracle():
     sync_all(r, v)
     for m in (r, v):
         m.backend.compute_tendencies()
-    for n, tol in (("Gn.T", 2e-4), ("Gn.S", 2e-4), ("Gn.u", 5e-3), ("Gn.v", 5e-3)):
+    for n, tol in (("Gn.T", 2e-4), ("Gn.S", 2e-4), ("Gn.u", 2e-4), ("Gn.v", 2e-4)):
         assert rel(get(r, n), get(v, n)) < tol, (n, rel(get(r, n), get(v, n)))
 
     # ab2_step! incl. the split-explicit sub-cycle (AB2 and Euler variants)
@@ -168,7 +168,7 @@ def test_smooth_flow_tendencies_elementwise():
     sync_all(r, v)
     for m in (r, v):
         gb.update_state(m)
-    for n, tol in (("Gn.T", 5e-5), ("Gn.u", 5e-3), ("Gn.v", 5e-3)):
+    for n, tol in (("Gn.T", 5e-5), ("Gn.u", 2e-4), ("Gn.v", 2e-4)):
         a, b = r.backend.get_field(n, False), v.backend.get_field(n, False)
         assert rel(a, b) < tol, (n, rel(a, b))
 

@@ -248,15 +248,28 @@ def test_barotropic_gravity_wave_phase_speed():
     assert abs(amp - math.cos(omega * t)) < 0.03
 
 
-def test_fp32_oracle_tracks_fp64_oracle():
-    """The stated fp32 tolerances of the GPU parity tests (helpers.assert_states_close) are attainable by an
-    independent fp32 evaluation of the same algorithm: outputs at rtol = sqrt(eps(Float32)), tendencies at 5e-3."""
-    from helpers import assert_states_close
+def test_fp32_state_with_fp64_pressure_tracks_fp64_oracle():
+    """Why the GPU pressure kernel runs its equation of state in fp64: rho(T,S,z) ~ 1e3 kg/m3 has an fp32 ulp of
+    1.2e-4 kg/m3, which the hydrostatic integral turns into ~1e-3 of the pressure-gradient signal.  The all-fp32
+    oracle build (f32) misses rtol = sqrt(eps(Float32)) on G.u after one step; with rho and the integral in fp64
+    (build f32p64, state still fp32) the same field is >10x closer and every compared state field passes."""
+    from helpers import SQRT_EPS32, assert_states_close
     cfg = dict(Nx=48, Ny=32, Nz=8, dt=600.0)
-    m64, m32 = make_oracle(precision="f64", **cfg), make_oracle(precision="f32", **cfg)
-    for m in (m64, m32):
+    models = {}
+    for prec in ("f64", "f32", "f32p64"):
+        m = models[prec] = make_oracle(precision=prec, **cfg)
         gb.set_baroclinic_instability(m)
         set_noisy_velocities(m)
         gb.first_time_step(m)
+    rel = {}
+    for prec in ("f32", "f32p64"):
+        _, rep = gb.compare_states(models[prec], models["f64"], include_halos=True, verbose=False)
+        rel[prec] = {r["name"]: r["rel"] for r in rep}
+    assert rel["f32"]["Gn.u"] > SQRT_EPS32 and rel["f32"]["Gn.u"] < 1e-2
+    assert rel["f32p64"]["Gn.u"] < 0.1 * rel["f32"]["Gn.u"] and rel["f32p64"]["Gn.u"] < SQRT_EPS32
+    for m in models.values():
         gb.loop(m, 10)
-    assert_states_close(m32, m64, label="fp32 vs fp64 oracle after 11 steps")
+    # (the fp32 oracle keeps Oceananigans' expanded smoothness indicators, whose cancellation noise alone costs
+    #  ~4e-4 on G.S; the GPU kernels use the factored form and are held to sqrt(eps) on every field)
+    assert_states_close(models["f32p64"], models["f64"], tendency_rtol=1e-3,
+                        label="fp32 state + fp64 pressure vs fp64, 11 steps")
