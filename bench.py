@@ -46,8 +46,12 @@ def cpu_baseline(Nx, Ny, Nz, dt, budget_s=25.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import gb25_amd as gb
     from oracle_backend import CPU
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    try:
+        cores = len(os.sched_getaffinity(0))     # the cores this job may actually use, not the host's count
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, int(os.environ.get("GB25_CPU_BASELINE_CORES", "16")))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     m = gb.baroclinic_instability_model(CPU("f32"), Nx, Ny, Nz, dt=dt)
     gb.set_baroclinic_instability(m)
     m.set(u=(1e-3 * counter_rng(m.velocities.u.shape, 42, 1)).astype(np.float32),

@@ -27,7 +27,7 @@ KERNEL_IDS = {"fill_halos": 0, "compute_w": 1, "compute_p": 2, "gu": 3, "gv": 4,
 # every symbol include/gb25.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "gb25_default_config", "gb25_create", "gb25_destroy", "gb25_last_error_string", "gb25_version",
-    "gb25_set_stream", "gb25_synchronize", "gb25_field_dims", "gb25_set_field", "gb25_get_field",
+    "gb25_set_stream", "gb25_use_own_stream", "gb25_synchronize", "gb25_field_dims", "gb25_set_field", "gb25_get_field",
     "gb25_field_device_ptr", "gb25_get_metric", "gb25_get_substepping", "gb25_set_baroclinic_instability",
     "gb25_get_clock", "gb25_set_dt", "gb25_initialize", "gb25_mask_immersed_fields",
     "gb25_fill_halo_regions", "gb25_compute_auxiliaries", "gb25_fill_diffusivity_halos",
@@ -96,7 +96,7 @@ def load_library():
     lib.gb25_time_step_stage.argtypes = [P, C.c_int, C.c_int]
     lib.gb25_profile_enable.argtypes = [P, C.c_int]
     lib.gb25_profile_get.argtypes = [P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
-    for name in ["gb25_synchronize", "gb25_set_baroclinic_instability", "gb25_initialize",
+    for name in ["gb25_use_own_stream", "gb25_synchronize", "gb25_set_baroclinic_instability", "gb25_initialize",
                  "gb25_mask_immersed_fields", "gb25_fill_halo_regions", "gb25_compute_auxiliaries",
                  "gb25_fill_diffusivity_halos", "gb25_compute_momentum_tendencies",
                  "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
@@ -198,7 +198,11 @@ class HipBackend:
         self._call("gb25_set_dt", float(dt))
 
     def set_stream(self, stream_ptr):
-        self._call("gb25_set_stream", C.c_void_p(stream_ptr))
+        """stream_ptr: a hipStream_t as an integer (0 / None = HIP's default stream)."""
+        self._call("gb25_set_stream", C.c_void_p(stream_ptr or None))
+
+    def use_own_stream(self):
+        self._call("gb25_use_own_stream")
 
     # ---- phases / composites (one ABI call each)
     def synchronize(self): self._call("gb25_synchronize")

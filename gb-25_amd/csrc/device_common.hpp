@@ -17,7 +17,9 @@ struct Grid {
   float dy, g, rho0, Lz;
   // metric tables, pointers are pre-offset so that index 0 is the first interior cell/face
   const float *dxc, *dxf, *azc, *azf, *fcor, *phic;  // by j   (valid j: -H-2 .. Ny+H+2)
-  const float *zc, *dzc, *dzf;                       // by k   (valid k: -H-2 .. Nz+H+2)
+  const float *rdxc, *razc, *razf;                   // reciprocals (host-computed in fp64, rounded once)
+  const float *zc, *dzc, *dzf, *rdzc;                // by k   (valid k: -H-2 .. Nz+H+2)
+  float rdy, rLz;
   // TEOS-10 folded per level: rho'(s,t) = sum_{i+j<=6} eos[k][idx(i,j)] s^i t^j, k = 0..Nz (Nz = mirrored halo level)
   const double* eos;
   const double* dzf_d;                               // dzf in fp64 for the hydrostatic integral, by k (0..Nz)

@@ -204,6 +204,19 @@ gb25_status build_grid(gb25_model* m) {
   if ((s = upload_table(m, azf, offj, &g.azf))) return s;
   if ((s = upload_table(m, fcor, offj, &g.fcor))) return s;
   if ((s = upload_table(m, phic, offj, &g.phic))) return s;
+  {
+    auto recip = [](const std::vector<double>& a) {
+      std::vector<double> r(a.size());
+      for (size_t q = 0; q < a.size(); q++) r[q] = a[q] != 0.0 ? 1.0 / a[q] : 0.0;
+      return r;
+    };
+    if ((s = upload_table(m, recip(dxc), offj, &g.rdxc))) return s;
+    if ((s = upload_table(m, recip(azc), offj, &g.razc))) return s;
+    if ((s = upload_table(m, recip(azf), offj, &g.razf))) return s;
+    if ((s = upload_table(m, recip(dzc), offk, &g.rdzc))) return s;
+    g.rdy = (float)(1.0 / (R * dphi * d2r));
+    g.rLz = (float)(1.0 / (zint[Nz] - zint[0]));
+  }
   if ((s = upload_table(m, zc, offk, &g.zc))) return s;
   if ((s = upload_table(m, dzc, offk, &g.dzc))) return s;
   if ((s = upload_table(m, dzf, offk, &g.dzf))) return s;
@@ -652,7 +665,14 @@ const char* gb25_last_error_string(const gb25_model* m) { return m ? m->err.c_st
 
 gb25_status gb25_set_stream(gb25_model* m, void* s) {
   CHECK_MODEL(m);
-  m->stream = s ? (hipStream_t)s : m->own_stream;
+  HIPCHK(hipStreamSynchronize(m->stream));
+  m->stream = (hipStream_t)s;  // NULL = HIP's default stream
+  return GB25_OK;
+}
+gb25_status gb25_use_own_stream(gb25_model* m) {
+  CHECK_MODEL(m);
+  HIPCHK(hipStreamSynchronize(m->stream));
+  m->stream = m->own_stream;
   return GB25_OK;
 }
 gb25_status gb25_synchronize(gb25_model* m) {

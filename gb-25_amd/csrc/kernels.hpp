@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_compute_w(Grid g, const float* __restri
   int i = blockIdx.x * blockDim.x + threadIdx.x - g.H + 1;
   int j = blockIdx.y * blockDim.y + threadIdx.y - g.H + 1;
   if (i > g.Nx + g.H - 2 || j > g.Ny + g.H - 2) return;
-  const float dxs = g.dxf[j], dxn = g.dxf[j + 1], raz = 1.f / g.azc[j], dy = g.dy;
+  const float dxs = g.dxf[j], dxn = g.dxf[j + 1], raz = g.razc[j], dy = g.dy;
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
   float wk = 0.f;
   w[o] = 0.f;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_tracer_tendencies(Grid g, const float* 
   const float uw = u[o], ue = u[o + 1], vs = v[ov], vn = v[ov + g.sx], wb = w[o], wt = w[o + g.pl_c];
   const int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny);
   const int ozb = biased_order_face(k, g.Nz), ozt = biased_order_face(k + 1, g.Nz);
-  const float rV = 1.f / (Az * dz);
+  const float rV = g.razc[j] * g.rdzc[k];
   GT[o] = -(tracer_div(g, T, o, Ax, uw, ue, Ays, Ayn, vs, vn, Az, wb, wt, oys, oyn, ozb, ozt) * rV);
   GS[o] = -(tracer_div(g, S, o, Ax, uw, ue, Ays, Ayn, vs, vn, Az, wb, wt, oys, oyn, ozb, ozt) * rV);
 }
@@ -228,11 +228,11 @@ __global__ __launch_bounds__(256) void k_gu(Grid g, const float* __restrict__ u,
   const int o = ic(g, i, j, k), ov = iv(g, i, j, k);
   const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
   const float dy = g.dy, dz = g.dzc[k];
-  const float dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], dxc_j = g.dxc[j];
+  const float dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j];
 
   // advecting v at (f,c,c)
   const float vhat =
-      (0.5f * (dxf_s * v[ov - 1] + dxf_n * v[ov - 1 + sx]) + 0.5f * (dxf_s * v[ov] + dxf_n * v[ov + sx])) * 0.5f / dxc_j;
+      (0.5f * (dxf_s * v[ov - 1] + dxf_n * v[ov - 1 + sx]) + 0.5f * (dxf_s * v[ov] + dxf_n * v[ov + sx])) * 0.5f * rdxc_j;
 
   // vorticity at faces j-2 .. j+3 of column i, plus the VelocityStencil smoothness inputs
   float zq[6], uq[6], vq[6];
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_gu(Grid g, const float* __restrict__ u,
     int jf = j - 2 + m;
     float vc = v[ov + (m - 2) * sx], vw = v[ov - 1 + (m - 2) * sx];
     float uc = u[o + (m - 2) * sx], us = u[o + (m - 3) * sx];
-    zq[m] = ((dy * vc - dy * vw) - (g.dxc[jf] * uc - g.dxc[jf - 1] * us)) / g.azf[jf];
+    zq[m] = ((dy * vc - dy * vw) - (g.dxc[jf] * uc - g.dxc[jf - 1] * us)) * g.razf[jf];
     uq[m] = 0.5f * (us + uc);
     vq[m] = 0.5f * (vw + vc);
   }
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void k_gu(Grid g, const float* __restrict__ u,
     for (int m = 0; m < 6; m++) q[m] = u[o + (tt + m - 3) * pc];
     fz[tt] = wt * biased6<false>(biased_order_face(k + tt, g.Nz), wt > 0.f, q, q, q);
   }
-  const float vadv = (phi + (fz[1] - fz[0])) / (Az * dz);
+  const float vadv = (phi + (fz[1] - fz[0])) * (g.razc[j] * g.rdzc[k]);
 
   // Bernoulli head
   float Ku[6], su[6];
@@ -294,10 +294,10 @@ __global__ __launch_bounds__(256) void k_gu(Grid g, const float* __restrict__ u,
     a4[m] = 0.5f * vc * vc - 0.5f * vw * vw;
   }
   const float dKv = sym_interp(sym4_center(j, g.Ny), a4[0], a4[1], a4[2], a4[3]);
-  const float bern = (dKu + dKv) / dxc_j;
+  const float bern = (dKu + dKv) * rdxc_j;
 
   const float cor = -0.5f * (g.fcor[j] + g.fcor[j + 1]) * vhat;
-  const float dpdx = (p[o] - p[o - 1]) / dxc_j;
+  const float dpdx = (p[o] - p[o - 1]) * rdxc_j;
   Gu[o] = -(hadv + vadv + bern) - cor - dpdx;
 }
 
@@ -312,10 +312,10 @@ __global__ __launch_bounds__(256) void k_gv(Grid g, const float* __restrict__ u,
   const float dy = g.dy, dz = g.dzc[k];
 
   // advecting u at (c,f,c)
-  const float uhat = (0.5f * (dy * u[o - sx] + dy * u[o - sx + 1]) + 0.5f * (dy * u[o] + dy * u[o + 1])) * 0.5f / dy;
+  const float uhat = (0.5f * (dy * u[o - sx] + dy * u[o - sx + 1]) + 0.5f * (dy * u[o] + dy * u[o + 1])) * 0.5f * g.rdy;
 
   // vorticity at faces i-2 .. i+3 of row j
-  const float dxc_j = g.dxc[j], dxc_s = g.dxc[j - 1], razf = 1.f / g.azf[j];
+  const float dxc_j = g.dxc[j], dxc_s = g.dxc[j - 1], razf = g.razf[j];
   float zq[6], uq[6], vq[6];
 #pragma unroll
   for (int m = 0; m < 6; m++) {
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void k_gv(Grid g, const float* __restrict__ u,
     for (int m = 0; m < 6; m++) q[m] = v[ov + (tt + m - 3) * pv];
     fz[tt] = wt * biased6<false>(biased_order_face(k + tt, g.Nz), wt > 0.f, q, q, q);
   }
-  const float vadv = (phi + (fz[1] - fz[0])) / (g.azf[j] * dz);
+  const float vadv = (phi + (fz[1] - fz[0])) * (razf * g.rdzc[k]);
 
   // Bernoulli head
   float Kv[6], sv[6];
@@ -377,10 +377,10 @@ __global__ __launch_bounds__(256) void k_gv(Grid g, const float* __restrict__ u,
     a4[m] = 0.5f * un * un - 0.5f * us * us;
   }
   const float dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
-  const float bern = (dKv + dKu) / dy;
+  const float bern = (dKv + dKu) * g.rdy;
 
   const float cor = g.fcor[j] * uhat;
-  const float dpdy = (p[o] - p[o - sx]) / dy;
+  const float dpdy = (p[o] - p[o - sx]) * g.rdy;
   Gv[ov] = -(hadv + vadv + bern) - cor - dpdy;
 }
 
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, float* __restrict__ u
     Ub[o2] = su;
     Vb[o2] = sv;
   }
-  const float du = (U[o2] - su) / g.Lz, dv = (V[o2] - sv) / g.Lz;
+  const float du = (U[o2] - su) * g.rLz, dv = (V[o2] - sv) * g.rLz;
   o = o0;
   ov = ov0;
   for (int k = 0; k < g.Nz; k++) {

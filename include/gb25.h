@@ -95,9 +95,12 @@ void gb25_destroy(gb25_model *m);
 const char *gb25_last_error_string(const gb25_model *m); /* valid until the next call on m */
 const char *gb25_version(void);
 
-/* Run all kernels of this model on the caller's HIP stream (a hipStream_t passed as void*;
- * NULL = the model's own stream).  Lets a host framework order our kernels with its own work. */
+/* Run all kernels of this model on the caller's HIP stream (a hipStream_t passed as void*; NULL is HIP's
+ * default stream, which is what torch.cuda.current_stream() is unless the host changed it).  Lets a host
+ * framework order our kernels with its own work.  gb25_use_own_stream goes back to the model's private
+ * non-blocking stream (the state after gb25_create). */
 gb25_status gb25_set_stream(gb25_model *m, void *hip_stream);
+gb25_status gb25_use_own_stream(gb25_model *m);
 gb25_status gb25_synchronize(gb25_model *m);
 
 /* ---- fields: replaces parent(field)/interior(field)/set!(model, ...) and sync_states!
