@@ -27,6 +27,25 @@ ALGORITHMIC_BYTES_PER_CELL = {
     "ab2_velocities": 12 * 4, "ab2_tracers": 8 * 4, "corrector": 6 * 4,
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+KERNEL_SYMBOL = {"gu": "k_gu", "gv": "k_gv", "tracers": "k_tracer_tendencies", "compute_w": "k_compute_w",
+                 "compute_p": "k_compute_p", "ab2_velocities": "k_ab2_velocities", "ab2_tracers": "k_ab2_tracers4",
+                 "corrector": "k_corrector", "momentum": "k_momentum_tendencies"}
+
+
+def measured_traffic(kernel, size):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r*_hbm_traffic_<size>.json:
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, gfx950 corrections applied as the
+    microarchitecture guide prescribes).  None when no measurement of this kernel at this size is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic_{size[0]}x{size[1]}x{size[2]}.json")))
+    for f in reversed(files):
+        try:
+            k = json.load(open(f))["kernels"].get(KERNEL_SYMBOL.get(kernel, kernel))
+            if k:
+                return k["hbm_bytes"], os.path.basename(f)
+        except Exception:
+            pass
+    return None, None
 
 
 def counter_rng(shape, seed, salt):
@@ -96,7 +115,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         from gb25_amd.distributed import SlabModel
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # "nccl" IS RCCL on ROCm.  GB25_DIST_BACKEND=gloo + GB25_ALL_ON_DEVICE0=1 rehearse the multi-process path
+        # with every rank on one GPU (RCCL refuses two ranks per device); used by tests on the 1-GPU box only.
+        backend = os.environ.get("GB25_DIST_BACKEND", "nccl")
+        if os.environ.get("GB25_ALL_ON_DEVICE0") == "1":
+            local_rank = 0
+            torch.cuda.set_device(0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         # weak scaling: every rank owns one Nx x Ny x Nz slab of a (world*Nx) x Ny x Nz global grid
         model = SlabModel(world * Nx, Ny, Nz, dt=args.dt, rank=rank, nranks=world, device=local_rank)
         barrier = dist.barrier
@@ -158,8 +186,10 @@ def main():
             launches_per_step = timed[dom]["launches"] / args.steps
             bytes_per_launch = ALGORITHMIC_BYTES_PER_CELL[dom] * cells
             achieved = bytes_per_launch / (timed[dom]["avg_ms"] * 1e-3) / 1e9
+            traffic, traffic_src = measured_traffic(dom, (Nx, Ny, Nz))
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "traffic_source": traffic_src,
                                "avg_launch_ms": timed[dom]["avg_ms"], "launches_per_step": launches_per_step,
                                "algorithmic_bytes_per_launch": bytes_per_launch,
                                "whole_step_achieved_GBps": 240.0 * cells * steps_per_s / 1e9}

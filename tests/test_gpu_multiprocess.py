@@ -1,0 +1,50 @@
+"""The real multi-process path (SlabModel + torch.distributed point-to-point ring) rehearsed on ONE GPU:
+two ranks launched by torch.distributed.run, both on device 0, gloo transport (RCCL refuses two ranks per
+device; on the 8-GPU node the backend is "nccl" = RCCL).  Result must equal the single-domain run bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import gb25_amd as gb
+from helpers import counter_rng
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(args, extra_env, nproc=2):
+    env = dict(os.environ, GB25_DIST_BACKEND="gloo", GB25_ALL_ON_DEVICE0="1", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", "29531"] + args
+    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+
+
+def test_two_rank_slab_run_matches_single_domain(tmp_path):
+    Nx, Ny, Nz, nsteps = 128, 48, 8, 5
+    res = _launch([os.path.join(ROOT, "tests", "mp_slab_worker.py"), str(tmp_path), str(Nx), str(Ny), str(Nz),
+                   str(nsteps)], {})
+    assert res.returncode == 0, res.stderr[-3000:]
+    single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=600.0)
+    gb.set_baroclinic_instability(single)
+    single.set(u=(1e-2 * counter_rng((Nx, Ny, Nz), 42, 1)).astype(np.float32),
+               v=(1e-2 * counter_rng((Nx, Ny + 1, Nz), 42, 2)).astype(np.float32))
+    gb.first_time_step(single)
+    gb.loop(single, nsteps - 1)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    for n in parts[0].files:
+        got = np.concatenate([p[n] for p in parts], axis=0)
+        assert np.array_equal(got, single.backend.get_field(n, False)), n
+
+
+def test_bench_two_ranks_prints_contract_line():
+    res = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "64", "48",
+                   "8"], {})
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["finite"]
+    assert out["config"]["grid"] == [128, 48, 8] and out["value"] > 0
