@@ -109,6 +109,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if os.environ.get("GB25_ALL_ON_DEVICE0") == "1":   # 1-GPU rehearsal of the multi-process path (tests only)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     Nx, Ny, Nz = args.size
 
@@ -118,9 +120,6 @@ def main():
         # "nccl" IS RCCL on ROCm.  GB25_DIST_BACKEND=gloo + GB25_ALL_ON_DEVICE0=1 rehearse the multi-process path
         # with every rank on one GPU (RCCL refuses two ranks per device); used by tests on the 1-GPU box only.
         backend = os.environ.get("GB25_DIST_BACKEND", "nccl")
-        if os.environ.get("GB25_ALL_ON_DEVICE0") == "1":
-            local_rank = 0
-            torch.cuda.set_device(0)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:

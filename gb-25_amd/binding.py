@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgb25hip.so")
+LIB_PATH = os.environ.get("GB25_LIB") or os.path.join(_HERE, "libgb25hip.so")   # GB25_LIB: A/B builds while tuning
 
 FIELD_IDS = {
     "u": 0, "v": 1, "w": 2, "T": 3, "S": 4, "pHY": 5,

@@ -6,11 +6,14 @@
 // There is no CPU fallback: without a HIP device gb25_create fails with GB25_ERR_NO_DEVICE.
 #include "../../include/gb25.h"
 #include "kernels.hpp"
+#include "kernels_v2.hpp"
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -62,6 +65,8 @@ struct gb25_model {
   int64_t prof_count[GB25_K_COUNT] = {0};
   double prof_ms[GB25_K_COUNT] = {0};
   std::string err;
+  int variant_a = 1, variant_b = 1;  // tuning switches (GB25_VARIANT_A / _B), see momentum_impl / tracers_impl
+  int kernel_gen = 2;  // 2: LDS flux-sharing tendency kernels (kernels_v2.hpp); 1: direct-stencil kernels (GB25_KERNELS=v1)
 };
 
 namespace {
@@ -391,6 +396,18 @@ void tile_grid(const Grid& g, int* nbx, int* nb) {
 gb25_status momentum_impl(gb25_model* m) {
   const Grid& g = m->g;
   int nbx, nb;
+  if (m->kernel_gen >= 2) {
+    Timed t(m, GB25_K_GU);   // the fused G_u + G_v kernel is accounted under the "gu" timer
+    nbx = (g.Nx + V2_TX - 1) / V2_TX;
+    const int nby = (g.Ny + V2_TY - 1) / V2_TY;
+    const int kchunks = std::max(1, g.Nz / 12);
+    nb = nbx * nby * kchunks;
+    auto kern = m->variant_b ? k_momentum_tendencies_v2<4> : k_momentum_tendencies_v2<2>;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(V2_TX, V2_TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                       m->f[GB25_W].d, m->f[GB25_PHY].d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, nbx, kchunks, nb);
+    LAUNCHCHK();
+    return GB25_OK;
+  }
   tile_grid(g, &nbx, &nb);
   dim3 b(TX, TY);
   {
@@ -409,6 +426,19 @@ gb25_status momentum_impl(gb25_model* m) {
 gb25_status tracers_impl(gb25_model* m) {
   const Grid& g = m->g;
   int nbx, nb;
+  if (m->kernel_gen >= 2) {
+    Timed t(m, GB25_K_TRACERS);
+    nbx = (g.Nx + V2_TX - 1) / V2_TX;
+    const int nby = (g.Ny + V2_TY - 1) / V2_TY;
+    const int kchunks = std::max(1, g.Nz / 12);   // >= 12 levels per block: the z-carry start-up stays ~3 %
+    nb = nbx * nby * kchunks;
+    auto kern = m->variant_a ? k_tracer_tendencies_v2<true> : k_tracer_tendencies_v2<false>;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(V2_TX, V2_TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                       m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d, m->f[GB25_GN_S].d, nbx,
+                       kchunks, nb);
+    LAUNCHCHK();
+    return GB25_OK;
+  }
   tile_grid(g, &nbx, &nb);
   Timed t(m, GB25_K_TRACERS);
   hipLaunchKernelGGL(k_tracer_tendencies, dim3(nb), dim3(TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
@@ -598,6 +628,9 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   HIPCHK(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
   m->stream = m->own_stream;
   m->last_dt = cfg->dt;
+  if (const char* e = getenv("GB25_KERNELS")) m->kernel_gen = (strcmp(e, "v1") == 0) ? 1 : 2;
+  if (const char* e = getenv("GB25_VARIANT_A")) m->variant_a = atoi(e);
+  if (const char* e = getenv("GB25_VARIANT_B")) m->variant_b = atoi(e);
   gb25_status s;
   if ((s = build_grid(m))) return s;
   if ((s = build_eos_tables(m))) return s;

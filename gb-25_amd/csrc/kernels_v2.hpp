@@ -1,0 +1,449 @@
+// kernels_v2.hpp -- second-generation tendency kernels: each face flux / derived quantity is computed ONCE
+// per (i,j,k) and shared through LDS (x, y) or carried in registers while marching up the column (z).
+//
+// The v1 kernels (kernels.hpp) evaluate every face reconstruction from both adjacent cells; rocprof (profiles/
+// r01_v1_*) shows they are VALU-bound (~50 % VALU issue, HBM traffic within 1.1-1.3x of compulsory), so the lever
+// is instruction count, not bytes.  Results are identical to v1 up to the order of the final flux differences.
+#pragma once
+#include "device_common.hpp"
+
+namespace gb25 {
+
+constexpr int V2_TX = 64, V2_TY = 8;
+
+// =============================================================================================
+// Tracer tendencies, T and S together: block = (64 x 8) columns, marching k0 -> k1.
+// Per level every thread reconstructs its WEST, SOUTH and TOP face once per tracer; the east / north faces
+// come from the neighbour through LDS (one extra column of west faces is computed by wave 0, one extra row of
+// south faces by wave 1), the bottom face is the previous level's top face.  12 -> 6.25 reconstructions.
+// =============================================================================================
+struct TracerLds {
+  float fx[2][2][V2_TY][V2_TX + 1];   // [level parity][tracer][row][face i0..i0+64]
+  float fy[2][2][V2_TY + 1][V2_TX];   // [level parity][tracer][face j0..j0+TY][column]
+};
+
+// Stencil inputs of one level of one column, fetched one level AHEAD of their use: the marching loop is
+// latency-bound otherwise (one barrier per level; rocprof showed ~30 % VALU issue without the prefetch).
+struct TracerStencil {
+  float xT[6], yT[6], xS[6], yS[6];  // c[i-3..i+2, j, k] and c[i, j-3..j+2, k]
+  float u, v, w;                     // u[i,j,k], v[i,j,k], w[i,j,k+1]
+};
+__device__ __forceinline__ void load_stencil(TracerStencil& s, const Grid& g, const float* __restrict__ u,
+                                             const float* __restrict__ v, const float* __restrict__ w,
+                                             const float* __restrict__ T, const float* __restrict__ S, int o, int ov) {
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    s.xT[m] = T[o + m - 3];
+    s.xS[m] = S[o + m - 3];
+    s.yT[m] = T[o + (m - 3) * g.sx];
+    s.yS[m] = S[o + (m - 3) * g.sx];
+  }
+  s.u = u[o];
+  s.v = v[ov];
+  s.w = w[o + g.pl_c];
+}
+__device__ __forceinline__ float x_face_flux(const Grid& g, const float* __restrict__ c, int o, float Axu) {
+  float q[6];
+#pragma unroll
+  for (int m = 0; m < 6; m++) q[m] = c[o + m - 3];
+  return Axu * biased6<false>(5, Axu > 0.f, q, q, q);
+}
+__device__ __forceinline__ float y_face_flux(const Grid& g, const float* __restrict__ c, int o, float Ayv, int order) {
+  float q[6];
+#pragma unroll
+  for (int m = 0; m < 6; m++) q[m] = c[o + (m - 3) * g.sx];
+  return Ayv * biased6<false>(order, Ayv > 0.f, q, q, q);
+}
+
+template <bool PREFETCH>
+__global__ __launch_bounds__(V2_TX* V2_TY) void k_tracer_tendencies_v2(
+    Grid g, const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ w,
+    const float* __restrict__ T, const float* __restrict__ S, float* __restrict__ GT, float* __restrict__ GS, int nbx,
+    int kchunks, int nb) {
+  __shared__ TracerLds lds;
+  const int L = xcd_remap(blockIdx.x, nb);
+  const int bx = L % nbx, r = L / nbx;
+  const int kc = r % kchunks, by = r / kchunks;
+  const int klen = (g.Nz + kchunks - 1) / kchunks;
+  const int k0 = kc * klen, k1 = min(g.Nz, k0 + klen);
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int i0 = bx * V2_TX, j0 = by * V2_TY;
+  const int i = i0 + tx, j = j0 + ty;
+  const bool inside = (i < g.Nx) && (j < g.Ny);
+  const int pc = g.pl_c, pv = g.pl_v;
+
+  const float dy = g.dy, Az = g.azc[j], dxf_s = g.dxf[j], razc_j = g.razc[j];
+  const int oys = biased_order_face(j, g.Ny);
+  // the extra faces: wave 0 -> east faces (i0+64, j0+lane), lanes 0..TY-1; wave 1 -> north faces (i0+tx, j0+TY)
+  const int jx = j0 + (tx < V2_TY ? tx : 0);
+  const int oyn = biased_order_face(j0 + V2_TY, g.Ny);
+  const float dxf_n = g.dxf[j0 + V2_TY];
+
+  int o = ic(g, i, j, k0), ov = iv(g, i, j, k0);
+  // vertical windows c[k-3 .. k+3] of the own column
+  float tz[7], sz[7];
+#pragma unroll
+  for (int m = 0; m < 7; m++) {
+    tz[m] = T[o + (m - 3) * pc];
+    sz[m] = S[o + (m - 3) * pc];
+  }
+  // bottom face of the first level of this chunk
+  float fzT, fzS;
+  {
+    float Azw = Az * w[o];
+    int ord = biased_order_face(k0, g.Nz);
+    fzT = Azw * biased6<false>(ord, Azw > 0.f, tz, tz, tz);
+    fzS = Azw * biased6<false>(ord, Azw > 0.f, sz, sz, sz);
+  }
+
+  // one level: fluxes of the own west / south / top faces from the prefetched stencil `st`
+  auto level = [&](int k, const TracerStencil& st, float tnew, float snew) {
+    const int par = k & 1;
+    const float dz = g.dzc[k];
+    {
+      float Axu = dy * dz * st.u;
+      float Ayv = dxf_s * dz * st.v;
+      lds.fx[par][0][ty][tx] = Axu * biased6<false>(5, Axu > 0.f, st.xT, st.xT, st.xT);
+      lds.fx[par][1][ty][tx] = Axu * biased6<false>(5, Axu > 0.f, st.xS, st.xS, st.xS);
+      lds.fy[par][0][ty][tx] = Ayv * biased6<false>(oys, Ayv > 0.f, st.yT, st.yT, st.yT);
+      lds.fy[par][1][ty][tx] = Ayv * biased6<false>(oys, Ayv > 0.f, st.yS, st.yS, st.yS);
+    }
+    if (ty == 0) {  // wave-uniform: the column of east faces of the tile
+      if (tx < V2_TY) {
+        int oe = ic(g, i0 + V2_TX, jx, k);
+        float Axu = dy * dz * u[oe];
+        lds.fx[par][0][tx][V2_TX] = x_face_flux(g, T, oe, Axu);
+        lds.fx[par][1][tx][V2_TX] = x_face_flux(g, S, oe, Axu);
+      }
+    } else if (ty == 1) {  // wave-uniform: the row of north faces of the tile
+      int on = ic(g, i, j0 + V2_TY, k);
+      float Ayv = dxf_n * dz * v[iv(g, i, j0 + V2_TY, k)];
+      lds.fy[par][0][V2_TY][tx] = y_face_flux(g, T, on, Ayv, oyn);
+      lds.fy[par][1][V2_TY][tx] = y_face_flux(g, S, on, Ayv, oyn);
+    }
+    // top face from the vertical window (values k-2 .. k+3)
+    const float Azw = Az * st.w;
+    const int ozt = biased_order_face(k + 1, g.Nz);
+    const float ftT = Azw * biased6<false>(ozt, Azw > 0.f, tz + 1, tz + 1, tz + 1);
+    const float ftS = Azw * biased6<false>(ozt, Azw > 0.f, sz + 1, sz + 1, sz + 1);
+    __syncthreads();
+    if (inside) {
+      const float rV = razc_j * g.rdzc[k];
+      float dT = (lds.fx[par][0][ty][tx + 1] - lds.fx[par][0][ty][tx]) +
+                 (lds.fy[par][0][ty + 1][tx] - lds.fy[par][0][ty][tx]) + (ftT - fzT);
+      float dS = (lds.fx[par][1][ty][tx + 1] - lds.fx[par][1][ty][tx]) +
+                 (lds.fy[par][1][ty + 1][tx] - lds.fy[par][1][ty][tx]) + (ftS - fzS);
+      GT[o] = -(dT * rV);
+      GS[o] = -(dS * rV);
+    }
+    fzT = ftT;
+    fzS = ftS;
+    o += pc;
+    ov += pv;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      tz[m] = tz[m + 1];
+      sz[m] = sz[m + 1];
+    }
+    tz[6] = tnew;
+    sz[6] = snew;
+  };
+
+  if (!PREFETCH) {
+    for (int k = k0; k < k1; k++) {
+      TracerStencil A;
+      load_stencil(A, g, u, v, w, T, S, o, ov);
+      level(k, A, T[o + 4 * pc], S[o + 4 * pc]);
+    }
+    return;
+  }
+  // software pipeline, unrolled by two so that the prefetch buffers A / B never need to be copied
+  TracerStencil A, B;
+  load_stencil(A, g, u, v, w, T, S, o, ov);
+  for (int k = k0; k < k1; k += 2) {
+    const bool more1 = (k + 1 < k1);
+    float tn = T[o + 4 * pc], sn = S[o + 4 * pc];                     // enters the window after level k
+    if (more1) load_stencil(B, g, u, v, w, T, S, o + pc, ov + pv);    // level k+1, in flight during level k
+    level(k, A, tn, sn);
+    if (more1) {
+      tn = T[o + 4 * pc];
+      sn = S[o + 4 * pc];
+      if (k + 2 < k1) load_stencil(A, g, u, v, w, T, S, o + pc, ov + pv);
+      level(k + 1, B, tn, sn);
+    }
+  }
+}
+
+}  // namespace gb25
+
+namespace gb25 {
+
+// =============================================================================================
+// Momentum tendencies G_u and G_v fused: block = (64 x 8) columns marching in k.  Per level the block stages
+// the u, v (level k) and w (level k+1) tiles in LDS, derives vorticity zeta and its VelocityStencil inputs at the
+// (f,f,c) points and the area-weighted divergence pieces at the (c,c,c) points ONCE per point (v1 recomputed each
+// of them for 6-12 neighbouring cells), then every thread evaluates G_u and G_v of its cell from LDS.  The vertical
+// momentum fluxes are carried from level to level.  Arithmetic per term is that of k_gu / k_gv.
+// =============================================================================================
+constexpr int MU_X = V2_TX + 6, MU_Y = V2_TY + 6;   // u, v tiles: origin (i0-3, j0-3)
+constexpr int MW_X = V2_TX + 3, MW_Y = V2_TY + 3;   // w tile:     origin (i0-2, j0-2)
+constexpr int MD_X = V2_TX + 5, MD_Y = V2_TY + 5;   // derived tiles: ffc origin (i0-2, j0-2), ccc origin (i0-3, j0-3)
+
+struct MomentumLds {
+  float U[2][MU_Y][MU_X];
+  float V[2][MU_Y][MU_X];
+  float W[2][MW_Y][MW_X];
+  float Z[MD_Y][MD_X], UQ[MD_Y][MD_X], VQ[MD_Y][MD_X];  // (f,f,c)
+  float DU[MD_Y][MD_X], DV[MD_Y][MD_X];                 // (c,c,c)
+};
+
+template <int MINW>
+__global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
+    Grid g, const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ w,
+    const float* __restrict__ p, float* __restrict__ Gu, float* __restrict__ Gv, int nbx, int kchunks, int nb) {
+  __shared__ MomentumLds lds;
+  const int L = xcd_remap(blockIdx.x, nb);
+  const int bx = L % nbx, r = L / nbx;
+  const int kc = r % kchunks, by = r / kchunks;
+  const int klen = (g.Nz + kchunks - 1) / kchunks;
+  const int k0 = kc * klen, k1 = min(g.Nz, k0 + klen);
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * V2_TX + tx;
+  const int i0 = bx * V2_TX, j0 = by * V2_TY;
+  const int i = i0 + tx, j = j0 + ty;
+  const bool inside = (i < g.Nx) && (j < g.Ny);
+  const int sx = g.sx, pc = g.pl_c, pv = g.pl_v, H = g.H;
+  const float dy = g.dy;
+
+  // j-dependent metrics of this thread's row
+  const float dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j], razc_j = g.razc[j], razf_j = g.razf[j];
+  const float Az = g.azc[j], fcor_j = g.fcor[j], fbar = 0.5f * (g.fcor[j] + g.fcor[j + 1]);
+  const float az_m2 = g.azc[j - 2], az_m1 = g.azc[j - 1], az_p1 = g.azc[j + 1];
+  const int oc_y = biased_order_center(j, g.Ny), of_y = biased_order_face(j, g.Ny);
+  const bool s4c_y = sym4_center(j, g.Ny), s4f_y = sym4_face(j, g.Ny);
+
+  int o = ic(g, i, j, k0), ov = iv(g, i, j, k0);
+  float uz[7], vz[7];
+#pragma unroll
+  for (int m = 0; m < 7; m++) {
+    uz[m] = u[o + (m - 3) * pc];
+    vz[m] = v[ov + (m - 3) * pv];
+  }
+  // vertical momentum fluxes through the bottom face of the first level
+  float fzu, fzv;
+  {
+    const int ord = biased_order_face(k0, g.Nz);
+    float wu = sym_interp(true, Az * w[o - 2], Az * w[o - 1], Az * w[o], Az * w[o + 1]);
+    float wv = sym_interp(s4f_y, az_m2 * w[o - 2 * sx], az_m1 * w[o - sx], Az * w[o], az_p1 * w[o + sx]);
+    fzu = wu * biased6<false>(ord, wu > 0.f, uz, uz, uz);
+    fzv = wv * biased6<false>(ord, wv > 0.f, vz, vz, vz);
+  }
+
+  // Tile staging is software-pipelined: the global loads of level k+1 are issued before the arithmetic of level
+  // k and land in LDS (other parity) after it, so their latency hides behind phases 1-2 instead of in front of a
+  // barrier.  Each thread owns up to 2 elements of the u / v tiles and 2 of the w tile.
+  constexpr int NT = V2_TX * V2_TY;
+  const int e0 = tid, e1 = tid + NT;
+  const int e0y = e0 / MU_X, e0x = e0 - e0y * MU_X, e1y = e1 / MU_X, e1x = e1 - e1y * MU_X;
+  const bool has1 = e1 < MU_X * MU_Y;
+  const int w0y = e0 / MW_X, w0x = e0 - w0y * MW_X, w1y = e1 / MW_X, w1x = e1 - w1y * MW_X;
+  const bool hw0 = e0 < MW_X * MW_Y, hw1 = e1 < MW_X * MW_Y;
+  const int tile_u = (i0 - 3 + H) + sx * (j0 - 3 + H), tile_w = (i0 - 2 + H) + sx * (j0 - 2 + H);
+  float ru0, ru1 = 0.f, rv0, rv1 = 0.f, rw0 = 0.f, rw1 = 0.f, rp = 0.f, rpw = 0.f, rps = 0.f;
+  auto fetch = [&](int k, int oo) {
+    const int bu = tile_u + pc * (k + H), bv = tile_u + pv * (k + H), bw = tile_w + pc * (k + 1 + H);
+    ru0 = u[bu + e0x + sx * e0y];
+    rv0 = v[bv + e0x + sx * e0y];
+    if (has1) {
+      ru1 = u[bu + e1x + sx * e1y];
+      rv1 = v[bv + e1x + sx * e1y];
+    }
+    if (hw0) rw0 = w[bw + w0x + sx * w0y];
+    if (hw1) rw1 = w[bw + w1x + sx * w1y];
+    rp = p[oo];
+    rpw = p[oo - 1];
+    rps = p[oo - sx];
+  };
+  auto stash = [&](int par) {
+    lds.U[par][e0y][e0x] = ru0;
+    lds.V[par][e0y][e0x] = rv0;
+    if (has1) {
+      lds.U[par][e1y][e1x] = ru1;
+      lds.V[par][e1y][e1x] = rv1;
+    }
+    if (hw0) lds.W[par][w0y][w0x] = rw0;
+    if (hw1) lds.W[par][w1y][w1x] = rw1;
+  };
+  fetch(k0, o);
+  stash(k0 & 1);
+  float pc_ = rp, pw_ = rpw, ps_ = rps;   // pressure at (i,j), (i-1,j), (i,j-1) of the current level
+  __syncthreads();
+
+  for (int k = k0; k < k1; k++) {
+    const int par = k & 1;
+    const float dz = g.dzc[k];
+    // ---- phase 0: issue the loads of the next level's tiles (consumed at the end of this iteration)
+    const bool more = (k + 1 < k1);
+    if (more) fetch(k + 1, o + pc);
+    const float unew = u[o + 4 * pc], vnew = v[ov + 4 * pv];
+    // ---- phase 1: derived quantities, once per point
+    for (int e = tid; e < MD_X * MD_Y; e += V2_TX * V2_TY) {
+      int py = e / MD_X, px = e - py * MD_X;
+      // (f,f,c) point (i0-2+px, j0-2+py)
+      {
+        const int J = j0 - 2 + py;
+        float uc = lds.U[par][py + 1][px + 1], us = lds.U[par][py][px + 1];
+        float vc = lds.V[par][py + 1][px + 1], vw = lds.V[par][py + 1][px];
+        lds.Z[py][px] = ((dy * vc - dy * vw) - (g.dxc[J] * uc - g.dxc[J - 1] * us)) * g.razf[J];
+        lds.UQ[py][px] = 0.5f * (us + uc);
+        lds.VQ[py][px] = 0.5f * (vw + vc);
+      }
+      // (c,c,c) point (i0-3+px, j0-3+py)
+      {
+        const int J = j0 - 3 + py;
+        const float Ax = dy * dz;
+        lds.DU[py][px] = Ax * lds.U[par][py][px + 1] - Ax * lds.U[par][py][px];
+        lds.DV[py][px] = g.dxf[J + 1] * dz * lds.V[par][py + 1][px] - g.dxf[J] * dz * lds.V[par][py][px];
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: the two tendencies of cell (i,j,k)
+    // tile accessors relative to (i,j)
+#define UT(di, dj) lds.U[par][ty + 3 + (dj)][tx + 3 + (di)]
+#define VT(di, dj) lds.V[par][ty + 3 + (dj)][tx + 3 + (di)]
+#define WT(di, dj) lds.W[par][ty + 2 + (dj)][tx + 2 + (di)]
+#define ZF(A, di, dj) lds.A[ty + 2 + (dj)][tx + 2 + (di)]
+#define DC(A, di, dj) lds.A[ty + 3 + (dj)][tx + 3 + (di)]
+    float gu, gv;
+    const int ozt = biased_order_face(k + 1, g.Nz);
+    const float rdz = g.rdzc[k];
+    {  // ---------------- G_u at (f,c,c)
+      const float vws = VT(-1, 0), vwn = VT(-1, 1), vcs = VT(0, 0), vcn = VT(0, 1);
+      const float vhat = (0.5f * (dxf_s * vws + dxf_n * vwn) + 0.5f * (dxf_s * vcs + dxf_n * vcn)) * 0.5f * rdxc_j;
+      float zq[6], uq[6], vq[6];
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        zq[m] = ZF(Z, 0, m - 2);
+        uq[m] = ZF(UQ, 0, m - 2);
+        vq[m] = ZF(VQ, 0, m - 2);
+      }
+      const float hadv = -vhat * biased6<true>(oc_y, vhat > 0.f, zq, uq, vq);
+
+      const float uhat = uz[3];
+      float Du[6], Dd[6], Dv4[4];
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        Du[m] = DC(DU, m - 3, 0);
+        Dd[m] = Du[m] + DC(DV, m - 3, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++) Dv4[m] = DC(DV, m - 2, 0);
+      const float dvs = sym_interp(true, Dv4[0], Dv4[1], Dv4[2], Dv4[3]);
+      const float duR = biased6<false>(5, uhat > 0.f, Du, Dd, Dd);
+      const float phi = uhat * (dvs + duR);
+
+      const float wt = sym_interp(true, Az * WT(-2, 0), Az * WT(-1, 0), Az * WT(0, 0), Az * WT(1, 0));
+      const float ft = wt * biased6<false>(ozt, wt > 0.f, uz + 1, uz + 1, uz + 1);
+      const float vadv = (phi + (ft - fzu)) * (razc_j * rdz);
+      fzu = ft;
+
+      float u7[7], Ku[6], su[6];
+#pragma unroll
+      for (int m = 0; m < 7; m++) u7[m] = UT(m - 3, 0);
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        Ku[m] = 0.5f * u7[m + 1] * u7[m + 1] - 0.5f * u7[m] * u7[m];
+        su[m] = 0.5f * (u7[m] + u7[m + 1]);
+      }
+      const float dKu = biased6<false>(5, uhat > 0.f, Ku, su, su);
+      float a4[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        float vc = VT(0, m - 1), vw = VT(-1, m - 1);
+        a4[m] = 0.5f * vc * vc - 0.5f * vw * vw;
+      }
+      const float dKv = sym_interp(s4c_y, a4[0], a4[1], a4[2], a4[3]);
+      const float bern = (dKu + dKv) * rdxc_j;
+      const float cor = -fbar * vhat;
+      const float dpdx = (pc_ - pw_) * rdxc_j;
+      gu = -(hadv + vadv + bern) - cor - dpdx;
+    }
+    {  // ---------------- G_v at (c,f,c)
+      const float uhat =
+          (0.5f * (dy * UT(0, -1) + dy * UT(1, -1)) + 0.5f * (dy * UT(0, 0) + dy * UT(1, 0))) * 0.5f * g.rdy;
+      float zq[6], uq[6], vq[6];
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        zq[m] = ZF(Z, m - 2, 0);
+        uq[m] = ZF(UQ, m - 2, 0);
+        vq[m] = ZF(VQ, m - 2, 0);
+      }
+      const float hadv = uhat * biased6<true>(5, uhat > 0.f, zq, uq, vq);
+
+      const float vhat = vz[3];
+      float Dv[6], Dd[6], Du4[4];
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        Dv[m] = DC(DV, 0, m - 3);
+        Dd[m] = DC(DU, 0, m - 3) + Dv[m];
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++) Du4[m] = DC(DU, 0, m - 2);
+      const float dus = sym_interp(s4f_y, Du4[0], Du4[1], Du4[2], Du4[3]);
+      const float dvR = biased6<false>(of_y, vhat > 0.f, Dv, Dd, Dd);
+      const float phi = vhat * (dus + dvR);
+
+      const float wt = sym_interp(s4f_y, az_m2 * WT(0, -2), az_m1 * WT(0, -1), Az * WT(0, 0), az_p1 * WT(0, 1));
+      const float ft = wt * biased6<false>(ozt, wt > 0.f, vz + 1, vz + 1, vz + 1);
+      const float vadv = (phi + (ft - fzv)) * (razf_j * rdz);
+      fzv = ft;
+
+      float v7[7], Kv[6], sv[6];
+#pragma unroll
+      for (int m = 0; m < 7; m++) v7[m] = VT(0, m - 3);
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        Kv[m] = 0.5f * v7[m + 1] * v7[m + 1] - 0.5f * v7[m] * v7[m];
+        sv[m] = 0.5f * (v7[m] + v7[m + 1]);
+      }
+      const float dKv = biased6<false>(of_y, vhat > 0.f, Kv, sv, sv);
+      float a4[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        float un = UT(m - 1, 0), us = UT(m - 1, -1);
+        a4[m] = 0.5f * un * un - 0.5f * us * us;
+      }
+      const float dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
+      const float bern = (dKv + dKu) * g.rdy;
+      const float cor = fcor_j * uhat;
+      const float dpdy = (pc_ - ps_) * g.rdy;
+      gv = -(hadv + vadv + bern) - cor - dpdy;
+    }
+#undef UT
+#undef VT
+#undef WT
+#undef ZF
+#undef DC
+    if (inside) {
+      Gu[o] = gu;
+      Gv[ov] = gv;
+    }
+    o += pc;
+    ov += pv;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      uz[m] = uz[m + 1];
+      vz[m] = vz[m + 1];
+    }
+    uz[6] = unew;
+    vz[6] = vnew;
+    if (more) {
+      stash(par ^ 1);
+      pc_ = rp;
+      pw_ = rpw;
+      ps_ = rps;
+    }
+    __syncthreads();   // next tiles visible; derived arrays free for the next phase 1
+  }
+}
+
+}  // namespace gb25

@@ -39,10 +39,19 @@ class TorchDistributedTransport:
 
     def exchange(self, send_west, send_east, recv_west, recv_east):
         d = self.dist
+        stage = send_west.is_cuda and d.get_backend() != "nccl"
+        if stage:
+            # rehearsal transport (gloo has no device-memory point-to-point): bounce through host buffers
+            dev = (recv_west, recv_east)
+            send_west, send_east = send_west.cpu(), send_east.cpu()
+            recv_west, recv_east = torch.empty_like(send_west), torch.empty_like(send_east)
         ops = [d.P2POp(d.isend, send_west, self.west), d.P2POp(d.isend, send_east, self.east),
                d.P2POp(d.irecv, recv_east, self.east), d.P2POp(d.irecv, recv_west, self.west)]
         for req in d.batch_isend_irecv(ops):
             req.wait()
+        if stage:
+            dev[0].copy_(recv_west)
+            dev[1].copy_(recv_east)
 
 
 class LocalRingTransport:

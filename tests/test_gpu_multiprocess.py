@@ -20,7 +20,7 @@ def _launch(args, extra_env, nproc=2):
     env = dict(os.environ, GB25_DIST_BACKEND="gloo", GB25_ALL_ON_DEVICE0="1", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", "29531"] + args
-    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=150)
 
 
 def test_two_rank_slab_run_matches_single_domain(tmp_path):
