@@ -41,6 +41,8 @@ struct gb25_model {
   Grid g;
   Field f[GB25_FIELD_COUNT];
   Field pp[3];                   // ping-pong partners of eta, U, V
+  Field colsum[2];               // column integrals of u, v after the AB2 update (consumed by the corrector)
+  bool colsum_valid = false;
   float* bars = nullptr;         // contiguous etabar | Ubar | Vbar
   std::vector<float*> dev_tables;
   std::vector<double> h_metric[11];
@@ -65,6 +67,8 @@ struct gb25_model {
   int64_t prof_count[GB25_K_COUNT] = {0};
   double prof_ms[GB25_K_COUNT] = {0};
   std::string err;
+  int tracer_v3 = 1;                 // wave-autonomous tracer kernel (no LDS); GB25_TRACER_V3=0 selects the LDS one
+  int tile_rows = 8;                 // rows (= waves) per block of the v2 tendency kernels: 8 or 4 (GB25_TILE_ROWS)
   int variant_a = 1, variant_b = 1;  // tuning switches (GB25_VARIANT_A / _B), see momentum_impl / tracers_impl
   int kernel_gen = 2;  // 2: LDS flux-sharing tendency kernels (kernels_v2.hpp); 1: direct-stencil kernels (GB25_KERNELS=v1)
 };
@@ -399,11 +403,13 @@ gb25_status momentum_impl(gb25_model* m) {
   if (m->kernel_gen >= 2) {
     Timed t(m, GB25_K_GU);   // the fused G_u + G_v kernel is accounted under the "gu" timer
     nbx = (g.Nx + V2_TX - 1) / V2_TX;
-    const int nby = (g.Ny + V2_TY - 1) / V2_TY;
+    const int TY = m->tile_rows;
+    const int nby = (g.Ny + TY - 1) / TY;
     const int kchunks = std::max(1, g.Nz / 12);
     nb = nbx * nby * kchunks;
-    auto kern = m->variant_b ? k_momentum_tendencies_v2<4> : k_momentum_tendencies_v2<2>;
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(V2_TX, V2_TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+    auto kern = TY == 4 ? (m->variant_b ? k_momentum_tendencies_v2<4, 4> : k_momentum_tendencies_v2<2, 4>)
+                        : (m->variant_b ? k_momentum_tendencies_v2<4, 8> : k_momentum_tendencies_v2<2, 8>);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(V2_TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                        m->f[GB25_W].d, m->f[GB25_PHY].d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, nbx, kchunks, nb);
     LAUNCHCHK();
     return GB25_OK;
@@ -426,14 +432,28 @@ gb25_status momentum_impl(gb25_model* m) {
 gb25_status tracers_impl(gb25_model* m) {
   const Grid& g = m->g;
   int nbx, nb;
+  if (m->kernel_gen >= 2 && m->tracer_v3) {
+    Timed t(m, GB25_K_TRACERS);
+    nbx = (g.Nx + V3_OUT - 1) / V3_OUT;
+    const int nby = (g.Ny + 3) / 4;
+    const int kchunks = std::max(1, g.Nz / 12);
+    nb = nbx * nby * kchunks;
+    hipLaunchKernelGGL(k_tracer_tendencies_v3, dim3(nb), dim3(64, 4), 0, m->stream, g, m->f[GB25_U].d,
+                       m->f[GB25_V].d, m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d,
+                       m->f[GB25_GN_S].d, nbx, kchunks, nb);
+    LAUNCHCHK();
+    return GB25_OK;
+  }
   if (m->kernel_gen >= 2) {
     Timed t(m, GB25_K_TRACERS);
     nbx = (g.Nx + V2_TX - 1) / V2_TX;
-    const int nby = (g.Ny + V2_TY - 1) / V2_TY;
+    const int TY = m->tile_rows;
+    const int nby = (g.Ny + TY - 1) / TY;
     const int kchunks = std::max(1, g.Nz / 12);   // >= 12 levels per block: the z-carry start-up stays ~3 %
     nb = nbx * nby * kchunks;
-    auto kern = m->variant_a ? k_tracer_tendencies_v2<true> : k_tracer_tendencies_v2<false>;
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(V2_TX, V2_TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+    auto kern = TY == 4 ? (m->variant_a ? k_tracer_tendencies_v2<true, 4> : k_tracer_tendencies_v2<false, 4>)
+                        : (m->variant_a ? k_tracer_tendencies_v2<true, 8> : k_tracer_tendencies_v2<false, 8>);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(V2_TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                        m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d, m->f[GB25_GN_S].d, nbx,
                        kchunks, nb);
     LAUNCHCHK();
@@ -454,7 +474,8 @@ gb25_status ab2_local_impl(gb25_model* m, float dt, float chi) {
     Timed t(m, GB25_K_AB2_VELOCITIES);
     hipLaunchKernelGGL(k_ab2_velocities, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                        m->f[GB25_GN_U].d, m->f[GB25_GM_U].d, m->f[GB25_GN_V].d, m->f[GB25_GM_V].d,
-                       m->f[GB25_GN_BT_U].d, m->f[GB25_GN_BT_V].d, dt, chi);
+                       m->f[GB25_GN_BT_U].d, m->f[GB25_GN_BT_V].d, m->colsum[0].d, m->colsum[1].d, dt, chi);
+    m->colsum_valid = true;
   }
   {
     Timed t(m, GB25_K_AB2_TRACERS);
@@ -528,7 +549,8 @@ gb25_status barotropic_impl(gb25_model* m, float dt) {
   return GB25_OK;
 }
 
-gb25_status corrector_impl(gb25_model* m) {
+// use_colsum: only inside a composite time step, where nothing can have touched u, v since the AB2 kernel
+gb25_status corrector_impl(gb25_model* m, bool use_colsum = false) {
   const Grid& g = m->g;
   {
     Timed t(m, GB25_K_CORRECTOR);
@@ -536,7 +558,10 @@ gb25_status corrector_impl(gb25_model* m) {
     const bool ext = m->cfg.nranks > 1;
     const int i0 = ext ? -g.H : 0, ni = ext ? g.Nx + 2 * g.H : g.Nx;
     hipLaunchKernelGGL(k_corrector, grid2(ni, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                       m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, i0, ni);
+                       m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d,
+                       (use_colsum && m->colsum_valid) ? m->colsum[0].d : nullptr,
+                       (use_colsum && m->colsum_valid) ? m->colsum[1].d : nullptr, i0, ni);
+    m->colsum_valid = false;
     LAUNCHCHK();
   }
   // cache_previous_tendencies!: G^- <- G^n is a pointer exchange; the next tendency evaluation
@@ -577,7 +602,7 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   m->time += dt;
   m->iteration += 1;
   if ((s = fill_halos_impl(m, true))) return s;
-  if ((s = corrector_impl(m))) return s;
+  if ((s = corrector_impl(m, true))) return s;
   return update_state_impl(m);
 }
 
@@ -629,6 +654,8 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   m->stream = m->own_stream;
   m->last_dt = cfg->dt;
   if (const char* e = getenv("GB25_KERNELS")) m->kernel_gen = (strcmp(e, "v1") == 0) ? 1 : 2;
+  if (const char* e = getenv("GB25_TRACER_V3")) m->tracer_v3 = atoi(e);
+  if (const char* e = getenv("GB25_TILE_ROWS")) m->tile_rows = (atoi(e) == 4) ? 4 : 8;
   if (const char* e = getenv("GB25_VARIANT_A")) m->variant_a = atoi(e);
   if (const char* e = getenv("GB25_VARIANT_B")) m->variant_b = atoi(e);
   gb25_status s;
@@ -652,6 +679,8 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   }
   for (int q = 0; q < 3; q++)
     if ((s = alloc_field(m, m->pp[q], sx, m->f[GB25_ETA + q].ny, 1))) return s;
+  if ((s = alloc_field(m, m->colsum[0], sx, m->f[GB25_BT_U].ny, 1))) return s;
+  if ((s = alloc_field(m, m->colsum[1], sx, m->f[GB25_BT_V].ny, 1))) return s;
   if (cfg->nranks > 1) {
     m->W = m->Ns + 1;
     if (m->Nx < m->W)
@@ -676,6 +705,8 @@ void gb25_destroy(gb25_model* m) {
     if (!(id >= GB25_ETA_BAR && id <= GB25_V_BAR) && m->f[id].d) hipFree(m->f[id].d);
   if (m->bars) hipFree(m->bars);
   for (auto& p : m->pp)
+    if (p.d) hipFree(p.d);
+  for (auto& p : m->colsum)
     if (p.d) hipFree(p.d);
   for (int a = 0; a < 2; a++) {
     for (auto& w : m->wide[a])
@@ -728,6 +759,7 @@ gb25_status gb25_field_dims(const gb25_model* m, gb25_field id, int include_halo
 
 static gb25_status copy_field(gb25_model* m, gb25_field id, float* host, int include_halos, bool to_device) {
   if (!m || id < 0 || id >= GB25_FIELD_COUNT || !host) return GB25_ERR_INVALID_ARGUMENT;
+  if (to_device && (id == GB25_U || id == GB25_V)) m->colsum_valid = false;  // cached column integrals are stale
   Field& F = m->f[id];
   HIPCHK(hipStreamSynchronize(m->stream));
   if (include_halos) {
@@ -957,7 +989,7 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
   } else if (stage == 2) {
     // group 0 has been unpacked: corrector on interior + x-halo columns, then update_state without any
     // further exchange (y/z layers re-filled over the extended x range; w and p recomputed in the halos)
-    if ((s = corrector_impl(m))) return s;
+    if ((s = corrector_impl(m, true))) return s;
     if ((s = fill_halos_impl(m, false, true))) return s;
     if ((s = compute_w_impl(m))) return s;
     if ((s = compute_p_impl(m))) return s;

@@ -391,7 +391,8 @@ __global__ __launch_bounds__(256) void k_gv(Grid g, const float* __restrict__ u,
 __global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, float* __restrict__ u, float* __restrict__ v,
                                                         const float* __restrict__ Gnu, const float* __restrict__ Gmu,
                                                         const float* __restrict__ Gnv, const float* __restrict__ Gmv,
-                                                        float* __restrict__ GU, float* __restrict__ GV, float dt,
+                                                        float* __restrict__ GU, float* __restrict__ GV,
+                                                        float* __restrict__ Usum, float* __restrict__ Vsum, float dt,
                                                         float chi) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
@@ -399,20 +400,28 @@ __global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, float* __restric
   const float C1 = 1.5f + chi, C2 = 0.5f + chi;
   const float ne = (chi != -0.5f) ? 1.f : 0.f;
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
-  float su = 0.f, sv = 0.f;
+  float su = 0.f, sv = 0.f, iu = 0.f, iv_ = 0.f;
   for (int k = 0; k < g.Nz; k++) {
     float dz = g.dzc[k];
     float gu = C1 * Gnu[o] - C2 * Gmu[o] * ne;
     float gv = C1 * Gnv[ov] - C2 * Gmv[ov] * ne;
-    u[o] += dt * gu;
-    v[ov] += dt * gv;
+    float un = u[o] + dt * gu, vn = v[ov] + dt * gv;
+    u[o] = un;
+    v[ov] = vn;
     su = (k == 0) ? dz * gu : su + dz * gu;
     sv = (k == 0) ? dz * gv : sv + dz * gv;
+    // column integrals of the UPDATED velocities: the barotropic corrector needs them after the sub-cycle and
+    // they are in registers here (saves the corrector's first sweep over u and v)
+    iu = (k == 0) ? dz * un : iu + dz * un;
+    iv_ = (k == 0) ? dz * vn : iv_ + dz * vn;
     o += g.pl_c;
     ov += g.pl_v;
   }
-  GU[i2(g, i, j)] = su;
-  GV[i2(g, i, j)] = (j == 0) ? 0.f : sv;  // the wall face is a peripheral node
+  const int o2 = i2(g, i, j);
+  GU[o2] = su;
+  GV[o2] = (j == 0) ? 0.f : sv;  // the wall face is a peripheral node
+  Usum[o2] = iu;
+  Vsum[o2] = (j == 0) ? 0.f : iv_;  // v on the wall face is reset to zero by the halo fill before the corrector
 }
 
 // tracers: flat AXPY over the interior planes of a parent array (G halos are identically zero)
@@ -540,21 +549,31 @@ __global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const float* __
 // owning neighbour, so no second halo exchange is needed); Ubar/Vbar are stored for interior columns only.
 __global__ __launch_bounds__(256) void k_corrector(Grid g, float* __restrict__ u, float* __restrict__ v,
                                                    const float* __restrict__ U, const float* __restrict__ V,
-                                                   float* __restrict__ Ub, float* __restrict__ Vb, int i0, int ni) {
+                                                   float* __restrict__ Ub, float* __restrict__ Vb,
+                                                   const float* __restrict__ Usum, const float* __restrict__ Vsum,
+                                                   int i0, int ni) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= ni || j >= g.Ny) return;
   i += i0;
   const int o0 = ic(g, i, j, 0), ov0 = iv(g, i, j, 0);
+  const int o2 = i2(g, i, j);
   int o = o0, ov = ov0;
-  float su = g.dzc[0] * u[o], sv = g.dzc[0] * v[ov];
-  for (int k = 1; k < g.Nz; k++) {
-    o += g.pl_c;
-    ov += g.pl_v;
-    su += g.dzc[k] * u[o];
-    sv += g.dzc[k] * v[ov];
+  float su, sv;
+  if (Usum != nullptr && i >= 0 && i < g.Nx) {
+    // interior column: the integrals were accumulated by k_ab2_velocities (same summation order)
+    su = Usum[o2];
+    sv = Vsum[o2];
+  } else {
+    su = g.dzc[0] * u[o];
+    sv = g.dzc[0] * v[ov];
+    for (int k = 1; k < g.Nz; k++) {
+      o += g.pl_c;
+      ov += g.pl_v;
+      su += g.dzc[k] * u[o];
+      sv += g.dzc[k] * v[ov];
+    }
   }
-  int o2 = i2(g, i, j);
   if (i >= 0 && i < g.Nx) {
     Ub[o2] = su;
     Vb[o2] = sv;

@@ -9,7 +9,7 @@
 
 namespace gb25 {
 
-constexpr int V2_TX = 64, V2_TY = 8;
+constexpr int V2_TX = 64;   // tile width = one wavefront; tile height TY (rows = waves per block) is a template parameter
 
 // =============================================================================================
 // Tracer tendencies, T and S together: block = (64 x 8) columns, marching k0 -> k1.
@@ -17,9 +17,10 @@ constexpr int V2_TX = 64, V2_TY = 8;
 // come from the neighbour through LDS (one extra column of west faces is computed by wave 0, one extra row of
 // south faces by wave 1), the bottom face is the previous level's top face.  12 -> 6.25 reconstructions.
 // =============================================================================================
+template <int TY>
 struct TracerLds {
-  float fx[2][2][V2_TY][V2_TX + 1];   // [level parity][tracer][row][face i0..i0+64]
-  float fy[2][2][V2_TY + 1][V2_TX];   // [level parity][tracer][face j0..j0+TY][column]
+  float fx[2][2][TY][V2_TX + 1];   // [level parity][tracer][row][face i0..i0+64]
+  float fy[2][2][TY + 1][V2_TX];   // [level parity][tracer][face j0..j0+TY][column]
 };
 
 // Stencil inputs of one level of one column, fetched one level AHEAD of their use: the marching loop is
@@ -55,12 +56,12 @@ __device__ __forceinline__ float y_face_flux(const Grid& g, const float* __restr
   return Ayv * biased6<false>(order, Ayv > 0.f, q, q, q);
 }
 
-template <bool PREFETCH>
+template <bool PREFETCH, int V2_TY>
 __global__ __launch_bounds__(V2_TX* V2_TY) void k_tracer_tendencies_v2(
     Grid g, const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ w,
     const float* __restrict__ T, const float* __restrict__ S, float* __restrict__ GT, float* __restrict__ GS, int nbx,
     int kchunks, int nb) {
-  __shared__ TracerLds lds;
+  __shared__ TracerLds<V2_TY> lds;
   const int L = xcd_remap(blockIdx.x, nb);
   const int bx = L % nbx, r = L / nbx;
   const int kc = r % kchunks, by = r / kchunks;
@@ -185,11 +186,13 @@ namespace gb25 {
 // of them for 6-12 neighbouring cells), then every thread evaluates G_u and G_v of its cell from LDS.  The vertical
 // momentum fluxes are carried from level to level.  Arithmetic per term is that of k_gu / k_gv.
 // =============================================================================================
-constexpr int MU_X = V2_TX + 6, MU_Y = V2_TY + 6;   // u, v tiles: origin (i0-3, j0-3)
-constexpr int MW_X = V2_TX + 3, MW_Y = V2_TY + 3;   // w tile:     origin (i0-2, j0-2)
-constexpr int MD_X = V2_TX + 5, MD_Y = V2_TY + 5;   // derived tiles: ffc origin (i0-2, j0-2), ccc origin (i0-3, j0-3)
+constexpr int MU_X = V2_TX + 6;   // u, v tiles: origin (i0-3, j0-3), TY+6 rows
+constexpr int MW_X = V2_TX + 3;   // w tile:     origin (i0-2, j0-2), TY+3 rows
+constexpr int MD_X = V2_TX + 5;   // derived tiles: ffc origin (i0-2, j0-2), ccc origin (i0-3, j0-3), TY+5 rows
 
+template <int V2_TY>
 struct MomentumLds {
+  static constexpr int MU_Y = V2_TY + 6, MW_Y = V2_TY + 3, MD_Y = V2_TY + 5;
   float U[2][MU_Y][MU_X];
   float V[2][MU_Y][MU_X];
   float W[2][MW_Y][MW_X];
@@ -197,11 +200,12 @@ struct MomentumLds {
   float DU[MD_Y][MD_X], DV[MD_Y][MD_X];                 // (c,c,c)
 };
 
-template <int MINW>
+template <int MINW, int V2_TY>
 __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
     Grid g, const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ w,
     const float* __restrict__ p, float* __restrict__ Gu, float* __restrict__ Gv, int nbx, int kchunks, int nb) {
-  __shared__ MomentumLds lds;
+  __shared__ MomentumLds<V2_TY> lds;
+  constexpr int MU_Y = V2_TY + 6, MW_Y = V2_TY + 3, MD_Y = V2_TY + 5;
   const int L = xcd_remap(blockIdx.x, nb);
   const int bx = L % nbx, r = L / nbx;
   const int kc = r % kchunks, by = r / kchunks;
@@ -242,36 +246,52 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
   // k and land in LDS (other parity) after it, so their latency hides behind phases 1-2 instead of in front of a
   // barrier.  Each thread owns up to 2 elements of the u / v tiles and 2 of the w tile.
   constexpr int NT = V2_TX * V2_TY;
-  const int e0 = tid, e1 = tid + NT;
-  const int e0y = e0 / MU_X, e0x = e0 - e0y * MU_X, e1y = e1 / MU_X, e1x = e1 - e1y * MU_X;
-  const bool has1 = e1 < MU_X * MU_Y;
-  const int w0y = e0 / MW_X, w0x = e0 - w0y * MW_X, w1y = e1 / MW_X, w1x = e1 - w1y * MW_X;
-  const bool hw0 = e0 < MW_X * MW_Y, hw1 = e1 < MW_X * MW_Y;
+  constexpr int NEU = (MU_X * MU_Y + NT - 1) / NT, NEW = (MW_X * MW_Y + NT - 1) / NT;   // elements per thread
   const int tile_u = (i0 - 3 + H) + sx * (j0 - 3 + H), tile_w = (i0 - 2 + H) + sx * (j0 - 2 + H);
-  float ru0, ru1 = 0.f, rv0, rv1 = 0.f, rw0 = 0.f, rw1 = 0.f, rp = 0.f, rpw = 0.f, rps = 0.f;
+  int eu_off[NEU], eu_lds[NEU], ew_off[NEW], ew_lds[NEW];   // global offset within the tile plane / LDS index
+#pragma unroll
+  for (int q = 0; q < NEU; q++) {
+    int e = tid + q * NT;
+    int ey = e / MU_X, ex = e - ey * MU_X;
+    eu_off[q] = (e < MU_X * MU_Y) ? ex + sx * ey : -1;
+    eu_lds[q] = e;
+  }
+#pragma unroll
+  for (int q = 0; q < NEW; q++) {
+    int e = tid + q * NT;
+    int ey = e / MW_X, ex = e - ey * MW_X;
+    ew_off[q] = (e < MW_X * MW_Y) ? ex + sx * ey : -1;
+    ew_lds[q] = e;
+  }
+  float ru[NEU], rv[NEU], rw[NEW], rp = 0.f, rpw = 0.f, rps = 0.f;
   auto fetch = [&](int k, int oo) {
     const int bu = tile_u + pc * (k + H), bv = tile_u + pv * (k + H), bw = tile_w + pc * (k + 1 + H);
-    ru0 = u[bu + e0x + sx * e0y];
-    rv0 = v[bv + e0x + sx * e0y];
-    if (has1) {
-      ru1 = u[bu + e1x + sx * e1y];
-      rv1 = v[bv + e1x + sx * e1y];
-    }
-    if (hw0) rw0 = w[bw + w0x + sx * w0y];
-    if (hw1) rw1 = w[bw + w1x + sx * w1y];
+#pragma unroll
+    for (int q = 0; q < NEU; q++)
+      if (eu_off[q] >= 0) {
+        ru[q] = u[bu + eu_off[q]];
+        rv[q] = v[bv + eu_off[q]];
+      }
+#pragma unroll
+    for (int q = 0; q < NEW; q++)
+      if (ew_off[q] >= 0) rw[q] = w[bw + ew_off[q]];
     rp = p[oo];
     rpw = p[oo - 1];
     rps = p[oo - sx];
   };
   auto stash = [&](int par) {
-    lds.U[par][e0y][e0x] = ru0;
-    lds.V[par][e0y][e0x] = rv0;
-    if (has1) {
-      lds.U[par][e1y][e1x] = ru1;
-      lds.V[par][e1y][e1x] = rv1;
-    }
-    if (hw0) lds.W[par][w0y][w0x] = rw0;
-    if (hw1) lds.W[par][w1y][w1x] = rw1;
+    float* U0 = &lds.U[par][0][0];
+    float* V0 = &lds.V[par][0][0];
+    float* W0 = &lds.W[par][0][0];
+#pragma unroll
+    for (int q = 0; q < NEU; q++)
+      if (eu_off[q] >= 0) {
+        U0[eu_lds[q]] = ru[q];
+        V0[eu_lds[q]] = rv[q];
+      }
+#pragma unroll
+    for (int q = 0; q < NEW; q++)
+      if (ew_off[q] >= 0) W0[ew_lds[q]] = rw[q];
   };
   fetch(k0, o);
   stash(k0 & 1);
@@ -286,7 +306,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
     if (more) fetch(k + 1, o + pc);
     const float unew = u[o + 4 * pc], vnew = v[ov + 4 * pv];
     // ---- phase 1: derived quantities, once per point
-    for (int e = tid; e < MD_X * MD_Y; e += V2_TX * V2_TY) {
+    for (int e = tid; e < MD_X * MD_Y; e += NT) {
       int py = e / MD_X, px = e - py * MD_X;
       // (f,f,c) point (i0-2+px, j0-2+py)
       {
@@ -443,6 +463,99 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
       ps_ = rps;
     }
     __syncthreads();   // next tiles visible; derived arrays free for the next phase 1
+  }
+}
+
+}  // namespace gb25
+
+namespace gb25 {
+
+// =============================================================================================
+// Tracer tendencies, wave-autonomous variant ("v3"): no LDS, no barriers.  A wavefront owns 63 consecutive cells of
+// one row (lane 63 only supplies the east face of lane 62), marches up the column, reconstructs the WEST face once
+// (the east face arrives from lane+1 by a wave shuffle), the TOP face once (bottom = carried), and both y faces.
+// 8 reconstructions per cell instead of 12 (v1) with v1's latency tolerance (independent waves, high occupancy);
+// the LDS variant above does 6.25 but pays a block barrier per level.
+// =============================================================================================
+constexpr int V3_OUT = 63;   // outputs per wavefront
+
+__global__ __launch_bounds__(256) void k_tracer_tendencies_v3(Grid g, const float* __restrict__ u,
+                                                              const float* __restrict__ v,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ T, const float* __restrict__ S,
+                                                              float* __restrict__ GT, float* __restrict__ GS, int nbx,
+                                                              int kchunks, int nb) {
+  const int L = xcd_remap(blockIdx.x, nb);
+  const int bx = L % nbx, r = L / nbx;
+  const int kc = r % kchunks, by = r / kchunks;
+  const int klen = (g.Nz + kchunks - 1) / kchunks;
+  const int k0 = kc * klen, k1 = min(g.Nz, k0 + klen);
+  const int lane = threadIdx.x;
+  const int i = bx * V3_OUT + lane, j = by * blockDim.y + threadIdx.y;
+  if (j >= g.Ny) return;                       // whole wave (one row) leaves together: no barriers in this kernel
+  const bool writes = (lane < V3_OUT) && (i < g.Nx);
+  const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
+  const float dy = g.dy, Az = g.azc[j], dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], razc_j = g.razc[j];
+  const int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny);
+
+  int o = ic(g, i, j, k0), ov = iv(g, i, j, k0);
+  float tz[7], sz[7];
+#pragma unroll
+  for (int m = 0; m < 7; m++) {
+    tz[m] = T[o + (m - 3) * pc];
+    sz[m] = S[o + (m - 3) * pc];
+  }
+  float fzT, fzS;
+  {
+    float Azw = Az * w[o];
+    int ord = biased_order_face(k0, g.Nz);
+    fzT = Azw * biased6<false>(ord, Azw > 0.f, tz, tz, tz);
+    fzS = Azw * biased6<false>(ord, Azw > 0.f, sz, sz, sz);
+  }
+  for (int k = k0; k < k1; k++) {
+    const float dz = g.dzc[k];
+    const float Axu = dy * dz * u[o];
+    const float Ays = dxf_s * dz * v[ov], Ayn = dxf_n * dz * v[ov + sx];
+    const float Azw = Az * w[o + pc];
+    float q[7];
+    // ---- T
+#pragma unroll
+    for (int m = 0; m < 6; m++) q[m] = T[o + m - 3];
+    const float fxT = Axu * biased6<false>(5, Axu > 0.f, q, q, q);
+#pragma unroll
+    for (int m = 0; m < 7; m++) q[m] = T[o + (m - 3) * sx];
+    const float fsT = Ays * biased6<false>(oys, Ays > 0.f, q, q, q);
+    const float fnT = Ayn * biased6<false>(oyn, Ayn > 0.f, q + 1, q + 1, q + 1);
+    // ---- S
+#pragma unroll
+    for (int m = 0; m < 6; m++) q[m] = S[o + m - 3];
+    const float fxS = Axu * biased6<false>(5, Axu > 0.f, q, q, q);
+#pragma unroll
+    for (int m = 0; m < 7; m++) q[m] = S[o + (m - 3) * sx];
+    const float fsS = Ays * biased6<false>(oys, Ays > 0.f, q, q, q);
+    const float fnS = Ayn * biased6<false>(oyn, Ayn > 0.f, q + 1, q + 1, q + 1);
+    // ---- top faces from the vertical windows
+    const int ozt = biased_order_face(k + 1, g.Nz);
+    const float ftT = Azw * biased6<false>(ozt, Azw > 0.f, tz + 1, tz + 1, tz + 1);
+    const float ftS = Azw * biased6<false>(ozt, Azw > 0.f, sz + 1, sz + 1, sz + 1);
+    // east faces = west faces of the next lane
+    const float feT = __shfl_down(fxT, 1), feS = __shfl_down(fxS, 1);
+    if (writes) {
+      const float rV = razc_j * g.rdzc[k];
+      GT[o] = -(((feT - fxT) + (fnT - fsT) + (ftT - fzT)) * rV);
+      GS[o] = -(((feS - fxS) + (fnS - fsS) + (ftS - fzS)) * rV);
+    }
+    fzT = ftT;
+    fzS = ftS;
+    o += pc;
+    ov += pv;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      tz[m] = tz[m + 1];
+      sz[m] = sz[m + 1];
+    }
+    tz[6] = T[o + 3 * pc];
+    sz[6] = S[o + 3 * pc];
   }
 }
 

@@ -13,6 +13,16 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
+# The oracle is OpenMP code.  On the GPU box os.cpu_count() reports the whole host (256) while the job owns 16 cores:
+# an oversubscribed, spinning OpenMP team turns a 6 s test into minutes.  Size the team to the cores we may use,
+# BEFORE libgomp is loaded.
+try:
+    _cores = len(os.sched_getaffinity(0))
+except AttributeError:
+    _cores = os.cpu_count() or 1
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(_cores, 16))))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 FIELD_IDS = {
     "u": 0, "v": 1, "w": 2, "T": 3, "S": 4, "pHY": 5,
     "Gn.u": 6, "Gn.v": 7, "Gn.T": 8, "Gn.S": 9,
