@@ -67,6 +67,7 @@ struct gb25_model {
   int64_t prof_count[GB25_K_COUNT] = {0};
   double prof_ms[GB25_K_COUNT] = {0};
   std::string err;
+  int momentum_v4 = 0;               // GB25_MOMENTUM_V4=1: single-barrier pipelined momentum kernel
   int tracer_v3 = 1;                 // wave-autonomous tracer kernel (no LDS); GB25_TRACER_V3=0 selects the LDS one
   int tile_rows = 8;                 // rows (= waves) per block of the v2 tendency kernels: 8 or 4 (GB25_TILE_ROWS)
   int variant_a = 1, variant_b = 1;  // tuning switches (GB25_VARIANT_A / _B), see momentum_impl / tracers_impl
@@ -409,6 +410,7 @@ gb25_status momentum_impl(gb25_model* m) {
     nb = nbx * nby * kchunks;
     auto kern = TY == 4 ? (m->variant_b ? k_momentum_tendencies_v2<4, 4> : k_momentum_tendencies_v2<2, 4>)
                         : (m->variant_b ? k_momentum_tendencies_v2<4, 8> : k_momentum_tendencies_v2<2, 8>);
+    if (m->momentum_v4) kern = k_momentum_tendencies_v4<4, 8>;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(V2_TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                        m->f[GB25_W].d, m->f[GB25_PHY].d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, nbx, kchunks, nb);
     LAUNCHCHK();
@@ -655,6 +657,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   m->last_dt = cfg->dt;
   if (const char* e = getenv("GB25_KERNELS")) m->kernel_gen = (strcmp(e, "v1") == 0) ? 1 : 2;
   if (const char* e = getenv("GB25_TRACER_V3")) m->tracer_v3 = atoi(e);
+  if (const char* e = getenv("GB25_MOMENTUM_V4")) m->momentum_v4 = atoi(e);
   if (const char* e = getenv("GB25_TILE_ROWS")) m->tile_rows = (atoi(e) == 4) ? 4 : 8;
   if (const char* e = getenv("GB25_VARIANT_A")) m->variant_a = atoi(e);
   if (const char* e = getenv("GB25_VARIANT_B")) m->variant_b = atoi(e);

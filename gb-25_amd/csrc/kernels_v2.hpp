@@ -560,3 +560,302 @@ __global__ __launch_bounds__(256) void k_tracer_tendencies_v3(Grid g, const floa
 }
 
 }  // namespace gb25
+
+namespace gb25 {
+
+// =============================================================================================
+// Momentum tendencies, single-barrier pipeline ("v4").  Same arithmetic and the same LDS staging idea as
+// k_momentum_tendencies_v2, but (a) the derived (f,f,c) triple {zeta, uq, vq} is one float4 and the (c,c,c)
+// pair {DU, DV} one float2 per point, so a stencil point costs one ds_read_b128 / b64 instead of three / two
+// ds_read_b32, and (b) the level loop is software-pipelined two deep: iteration k evaluates the tendencies of
+// level k, derives the quantities of level k+1 and stages the tiles of level k+2, behind ONE barrier.
+// (v2 measured 50 % VALU issue with 34 % of wave time in s_waitcnt/barrier: profiles/r01_v2_pmc_sq3.csv.)
+// =============================================================================================
+template <int TY>
+struct MomentumLds4 {
+  static constexpr int MU_Y = TY + 6, MW_Y = TY + 3, MD_Y = TY + 5;
+  float U[3][MU_Y][MU_X];
+  float V[3][MU_Y][MU_X];
+  float W[3][MW_Y][MW_X];
+  float4 ZQ[2][MD_Y][MD_X];   // (f,f,c): x = zeta, y = uq, z = vq
+  float2 D2[2][MD_Y][MD_X];   // (c,c,c): x = DU, y = DV
+};
+
+template <int MINW, int TY>
+__global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
+    Grid g, const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ w,
+    const float* __restrict__ p, float* __restrict__ Gu, float* __restrict__ Gv, int nbx, int kchunks, int nb) {
+  __shared__ MomentumLds4<TY> lds;
+  constexpr int MU_Y = TY + 6, MW_Y = TY + 3, MD_Y = TY + 5;
+  const int L = xcd_remap(blockIdx.x, nb);
+  const int bx = L % nbx, r = L / nbx;
+  const int kc = r % kchunks, by = r / kchunks;
+  const int klen = (g.Nz + kchunks - 1) / kchunks;
+  const int k0 = kc * klen, k1 = min(g.Nz, k0 + klen);
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * V2_TX + tx;
+  const int i0 = bx * V2_TX, j0 = by * TY;
+  const int i = i0 + tx, j = j0 + ty;
+  const bool inside = (i < g.Nx) && (j < g.Ny);
+  const int sx = g.sx, pc = g.pl_c, pv = g.pl_v, H = g.H;
+  const float dy = g.dy;
+
+  const float dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j], razc_j = g.razc[j], razf_j = g.razf[j];
+  const float Az = g.azc[j], fcor_j = g.fcor[j], fbar = 0.5f * (g.fcor[j] + g.fcor[j + 1]);
+  const float az_m2 = g.azc[j - 2], az_m1 = g.azc[j - 1], az_p1 = g.azc[j + 1];
+  const int oc_y = biased_order_center(j, g.Ny), of_y = biased_order_face(j, g.Ny);
+  const bool s4c_y = sym4_center(j, g.Ny), s4f_y = sym4_face(j, g.Ny);
+
+  int o = ic(g, i, j, k0), ov = iv(g, i, j, k0);
+  float uz[7], vz[7];
+#pragma unroll
+  for (int m = 0; m < 7; m++) {
+    uz[m] = u[o + (m - 3) * pc];
+    vz[m] = v[ov + (m - 3) * pv];
+  }
+  float fzu, fzv;
+  {
+    const int ord = biased_order_face(k0, g.Nz);
+    float wu = sym_interp(true, Az * w[o - 2], Az * w[o - 1], Az * w[o], Az * w[o + 1]);
+    float wv = sym_interp(s4f_y, az_m2 * w[o - 2 * sx], az_m1 * w[o - sx], Az * w[o], az_p1 * w[o + sx]);
+    fzu = wu * biased6<false>(ord, wu > 0.f, uz, uz, uz);
+    fzv = wv * biased6<false>(ord, wv > 0.f, vz, vz, vz);
+  }
+
+  // ---- tile staging: each thread owns NEU elements of the u / v tiles and NEW of the w tile
+  constexpr int NT = V2_TX * TY;
+  constexpr int NEU = (MU_X * MU_Y + NT - 1) / NT, NEW = (MW_X * MW_Y + NT - 1) / NT;
+  const int tile_u = (i0 - 3 + H) + sx * (j0 - 3 + H), tile_w = (i0 - 2 + H) + sx * (j0 - 2 + H);
+  int eu_off[NEU], ew_off[NEW];
+#pragma unroll
+  for (int q = 0; q < NEU; q++) {
+    int e = tid + q * NT, ey = e / MU_X, ex = e - ey * MU_X;
+    eu_off[q] = (e < MU_X * MU_Y) ? ex + sx * ey : -1;
+  }
+#pragma unroll
+  for (int q = 0; q < NEW; q++) {
+    int e = tid + q * NT, ey = e / MW_X, ex = e - ey * MW_X;
+    ew_off[q] = (e < MW_X * MW_Y) ? ex + sx * ey : -1;
+  }
+  float ru[NEU], rv[NEU], rw[NEW];
+  auto fetch = [&](int k) {
+    const int bu = tile_u + pc * (k + H), bv = tile_u + pv * (k + H), bw = tile_w + pc * (k + 1 + H);
+#pragma unroll
+    for (int q = 0; q < NEU; q++)
+      if (eu_off[q] >= 0) {
+        ru[q] = u[bu + eu_off[q]];
+        rv[q] = v[bv + eu_off[q]];
+      }
+#pragma unroll
+    for (int q = 0; q < NEW; q++)
+      if (ew_off[q] >= 0) rw[q] = w[bw + ew_off[q]];
+  };
+  auto stash = [&](int b) {
+    float* U0 = &lds.U[b][0][0];
+    float* V0 = &lds.V[b][0][0];
+    float* W0 = &lds.W[b][0][0];
+#pragma unroll
+    for (int q = 0; q < NEU; q++)
+      if (eu_off[q] >= 0) {
+        U0[tid + q * NT] = ru[q];
+        V0[tid + q * NT] = rv[q];
+      }
+#pragma unroll
+    for (int q = 0; q < NEW; q++)
+      if (ew_off[q] >= 0) W0[tid + q * NT] = rw[q];
+  };
+  // derived quantities of one level, once per point: tiles[b] -> derived[par]
+  auto derive = [&](int k, int b, int par) {
+    const float dz = g.dzc[k];
+    for (int e = tid; e < MD_X * MD_Y; e += NT) {
+      int py = e / MD_X, px = e - py * MD_X;
+      {  // (f,f,c) point (i0-2+px, j0-2+py)
+        const int J = j0 - 2 + py;
+        float uc = lds.U[b][py + 1][px + 1], us = lds.U[b][py][px + 1];
+        float vc = lds.V[b][py + 1][px + 1], vw = lds.V[b][py + 1][px];
+        float4 zq;
+        zq.x = ((dy * vc - dy * vw) - (g.dxc[J] * uc - g.dxc[J - 1] * us)) * g.razf[J];
+        zq.y = 0.5f * (us + uc);
+        zq.z = 0.5f * (vw + vc);
+        zq.w = 0.f;
+        lds.ZQ[par][py][px] = zq;
+      }
+      {  // (c,c,c) point (i0-3+px, j0-3+py)
+        const int J = j0 - 3 + py;
+        const float Ax = dy * dz;
+        float2 d;
+        d.x = Ax * lds.U[b][py][px + 1] - Ax * lds.U[b][py][px];
+        d.y = g.dxf[J + 1] * dz * lds.V[b][py + 1][px] - g.dxf[J] * dz * lds.V[b][py][px];
+        lds.D2[par][py][px] = d;
+      }
+    }
+  };
+
+  // ---- prologue: tiles of k0 and k0+1, derived quantities of k0
+  int b0 = 0, b1 = 1, b2 = 2;   // LDS tile buffers of levels k, k+1, k+2
+  fetch(k0);
+  stash(b0);
+  if (k0 + 1 < k1) {
+    fetch(k0 + 1);
+    stash(b1);
+  }
+  float pc_ = p[o], pw_ = p[o - 1], ps_ = p[o - sx];
+  __syncthreads();
+  derive(k0, b0, k0 & 1);
+  __syncthreads();
+
+  for (int k = k0; k < k1; k++) {
+    const int par = k & 1;
+    const bool more1 = (k + 1 < k1), more2 = (k + 2 < k1);
+    if (more2) fetch(k + 2);
+    const float unew = u[o + 4 * pc], vnew = v[ov + 4 * pv];
+    float pcn = 0.f, pwn = 0.f, psn = 0.f;
+    if (more1) {
+      pcn = p[o + pc];
+      pwn = p[o + pc - 1];
+      psn = p[o + pc - sx];
+    }
+#define UT(di, dj) lds.U[b0][ty + 3 + (dj)][tx + 3 + (di)]
+#define VT(di, dj) lds.V[b0][ty + 3 + (dj)][tx + 3 + (di)]
+#define WT(di, dj) lds.W[b0][ty + 2 + (dj)][tx + 2 + (di)]
+#define ZQF(di, dj) lds.ZQ[par][ty + 2 + (dj)][tx + 2 + (di)]
+#define D2C(di, dj) lds.D2[par][ty + 3 + (dj)][tx + 3 + (di)]
+    float gu, gv;
+    const int ozt = biased_order_face(k + 1, g.Nz);
+    const float rdz = g.rdzc[k];
+    {  // ---------------- G_u at (f,c,c)
+      const float vws = VT(-1, 0), vwn = VT(-1, 1), vcs = VT(0, 0), vcn = VT(0, 1);
+      const float vhat = (0.5f * (dxf_s * vws + dxf_n * vwn) + 0.5f * (dxf_s * vcs + dxf_n * vcn)) * 0.5f * rdxc_j;
+      float zq[6], uq[6], vq[6];
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        float4 t = ZQF(0, m - 2);
+        zq[m] = t.x;
+        uq[m] = t.y;
+        vq[m] = t.z;
+      }
+      const float hadv = -vhat * biased6<true>(oc_y, vhat > 0.f, zq, uq, vq);
+
+      const float uhat = uz[3];
+      float Du[6], Dd[6], Dv6[6];
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        float2 d = D2C(m - 3, 0);
+        Du[m] = d.x;
+        Dv6[m] = d.y;
+        Dd[m] = d.x + d.y;
+      }
+      const float dvs = sym_interp(true, Dv6[1], Dv6[2], Dv6[3], Dv6[4]);
+      const float duR = biased6<false>(5, uhat > 0.f, Du, Dd, Dd);
+      const float phi = uhat * (dvs + duR);
+
+      const float wt = sym_interp(true, Az * WT(-2, 0), Az * WT(-1, 0), Az * WT(0, 0), Az * WT(1, 0));
+      const float ft = wt * biased6<false>(ozt, wt > 0.f, uz + 1, uz + 1, uz + 1);
+      const float vadv = (phi + (ft - fzu)) * (razc_j * rdz);
+      fzu = ft;
+
+      float u7[7], Ku[6], su[6];
+#pragma unroll
+      for (int m = 0; m < 7; m++) u7[m] = UT(m - 3, 0);
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        Ku[m] = 0.5f * u7[m + 1] * u7[m + 1] - 0.5f * u7[m] * u7[m];
+        su[m] = 0.5f * (u7[m] + u7[m + 1]);
+      }
+      const float dKu = biased6<false>(5, uhat > 0.f, Ku, su, su);
+      float a4[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        float vc = VT(0, m - 1), vw = VT(-1, m - 1);
+        a4[m] = 0.5f * vc * vc - 0.5f * vw * vw;
+      }
+      const float dKv = sym_interp(s4c_y, a4[0], a4[1], a4[2], a4[3]);
+      const float bern = (dKu + dKv) * rdxc_j;
+      const float cor = -fbar * vhat;
+      const float dpdx = (pc_ - pw_) * rdxc_j;
+      gu = -(hadv + vadv + bern) - cor - dpdx;
+    }
+    {  // ---------------- G_v at (c,f,c)
+      const float uhat =
+          (0.5f * (dy * UT(0, -1) + dy * UT(1, -1)) + 0.5f * (dy * UT(0, 0) + dy * UT(1, 0))) * 0.5f * g.rdy;
+      float zq[6], uq[6], vq[6];
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        float4 t = ZQF(m - 2, 0);
+        zq[m] = t.x;
+        uq[m] = t.y;
+        vq[m] = t.z;
+      }
+      const float hadv = uhat * biased6<true>(5, uhat > 0.f, zq, uq, vq);
+
+      const float vhat = vz[3];
+      float Dv[6], Dd[6], Du6[6];
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        float2 d = D2C(0, m - 3);
+        Du6[m] = d.x;
+        Dv[m] = d.y;
+        Dd[m] = d.x + d.y;
+      }
+      const float dus = sym_interp(s4f_y, Du6[1], Du6[2], Du6[3], Du6[4]);
+      const float dvR = biased6<false>(of_y, vhat > 0.f, Dv, Dd, Dd);
+      const float phi = vhat * (dus + dvR);
+
+      const float wt = sym_interp(s4f_y, az_m2 * WT(0, -2), az_m1 * WT(0, -1), Az * WT(0, 0), az_p1 * WT(0, 1));
+      const float ft = wt * biased6<false>(ozt, wt > 0.f, vz + 1, vz + 1, vz + 1);
+      const float vadv = (phi + (ft - fzv)) * (razf_j * rdz);
+      fzv = ft;
+
+      float v7[7], Kv[6], sv[6];
+#pragma unroll
+      for (int m = 0; m < 7; m++) v7[m] = VT(0, m - 3);
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        Kv[m] = 0.5f * v7[m + 1] * v7[m + 1] - 0.5f * v7[m] * v7[m];
+        sv[m] = 0.5f * (v7[m] + v7[m + 1]);
+      }
+      const float dKv = biased6<false>(of_y, vhat > 0.f, Kv, sv, sv);
+      float a4[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        float un = UT(m - 1, 0), us = UT(m - 1, -1);
+        a4[m] = 0.5f * un * un - 0.5f * us * us;
+      }
+      const float dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
+      const float bern = (dKv + dKu) * g.rdy;
+      const float cor = fcor_j * uhat;
+      const float dpdy = (pc_ - ps_) * g.rdy;
+      gv = -(hadv + vadv + bern) - cor - dpdy;
+    }
+#undef UT
+#undef VT
+#undef WT
+#undef ZQF
+#undef D2C
+    if (inside) {
+      Gu[o] = gu;
+      Gv[ov] = gv;
+    }
+    // ---- next level's derived quantities and the level after's tiles, then the single barrier
+    if (more1) derive(k + 1, b1, par ^ 1);
+    if (more2) stash(b2);
+    o += pc;
+    ov += pv;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      uz[m] = uz[m + 1];
+      vz[m] = vz[m + 1];
+    }
+    uz[6] = unew;
+    vz[6] = vnew;
+    pc_ = pcn;
+    pw_ = pwn;
+    ps_ = psn;
+    const int t = b0;
+    b0 = b1;
+    b1 = b2;
+    b2 = t;
+    __syncthreads();
+  }
+}
+
+}  // namespace gb25
