@@ -125,7 +125,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-        # weak scaling: every rank owns one Nx x Ny x Nz slab of a (world*Nx) x Ny x Nz global grid
+        # weak scaling: every rank owns one Nx x Ny x Nz slab of a (world*Nx) x Ny x Nz global grid.  The zonal
+        # spacing shrinks with the rank count, so the time step shrinks with it (constant barotropic Courant number,
+        # as the reference's resolution-dependent dt: simulations/ocean_climate_simulation.jl:50-51).
+        args.dt = args.dt / world
         model = SlabModel(world * Nx, Ny, Nz, dt=args.dt, rank=rank, nranks=world, device=local_rank)
         barrier = dist.barrier
     else:

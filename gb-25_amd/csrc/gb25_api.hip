@@ -67,6 +67,8 @@ struct gb25_model {
   int64_t prof_count[GB25_K_COUNT] = {0};
   double prof_ms[GB25_K_COUNT] = {0};
   std::string err;
+  int baro_rows = 16;                // tile height of the blocked barotropic kernel: 16 or 32 (GB25_BARO_ROWS)
+  int baro_block = 7;             // substeps per barotropic launch (GB25_BARO_BLOCK=1: one launch per substep)
   int momentum_v4 = 0;               // GB25_MOMENTUM_V4=1: single-barrier pipelined momentum kernel
   int tracer_v3 = 1;                 // wave-autonomous tracer kernel (no LDS); GB25_TRACER_V3=0 selects the LDS one
   int tile_rows = 8;                 // rows (= waves) per block of the v2 tendency kernels: 8 or 4 (GB25_TILE_ROWS)
@@ -530,12 +532,32 @@ gb25_status barotropic_impl(gb25_model* m, float dt) {
     bb.GU = m->wideG[0].d; bb.GV = m->wideG[1].d;
     bb.sx = g.Nx + 2 * m->W; bb.xo = m->W; bb.ilo = -m->W + 1; bb.ihi = g.Nx + m->W - 1; bb.wrap = 0;
   }
-  dim3 gr = grid2(bb.ihi - bb.ilo, g.Ny, b);
-  for (int s = 0; s < m->Ns; s++) {
-    bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
-    bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
-    hipLaunchKernelGGL(k_barotropic_substep, gr, b, 0, m->stream, g, bb, dtau, (float)m->weights[s]);
-    for (int q = 0; q < 3; q++) std::swap(cur[q], nxt[q]);
+  if (m->baro_block > 1) {
+    // temporally blocked: S substeps per launch on (64 x TY) tiles
+    const int S = std::min(m->baro_block, (int)BT_SMAX), TYb = m->baro_rows;
+    dim3 gm((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX, (g.Ny + TYb - 1) / TYb);
+    void (*kern)(Grid, BaroMulti, float) = nullptr;
+    if (TYb == 16) kern = S <= 3 ? k_barotropic_multi<3, 16> : (S <= 5 ? k_barotropic_multi<5, 16> : k_barotropic_multi<7, 16>);
+    else kern = S <= 3 ? k_barotropic_multi<3, 32> : (S <= 5 ? k_barotropic_multi<5, 32> : k_barotropic_multi<7, 32>);
+    const int Sk = S <= 3 ? 3 : (S <= 5 ? 5 : 7);
+    for (int s = 0; s < m->Ns; s += Sk) {
+      BaroMulti bm;
+      bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
+      bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
+      bm.b = bb;
+      bm.ns = std::min(Sk, m->Ns - s);
+      for (int q = 0; q < BT_SMAX; q++) bm.w[q] = (s + q < m->Ns) ? (float)m->weights[s + q] : 0.f;
+      hipLaunchKernelGGL(kern, gm, dim3(BT_NT), 0, m->stream, g, bm, dtau);
+      for (int q = 0; q < 3; q++) std::swap(cur[q], nxt[q]);
+    }
+  } else {
+    dim3 gr = grid2(bb.ihi - bb.ilo, g.Ny, b);
+    for (int s = 0; s < m->Ns; s++) {
+      bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
+      bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
+      hipLaunchKernelGGL(k_barotropic_substep, gr, b, 0, m->stream, g, bb, dtau, (float)m->weights[s]);
+      for (int q = 0; q < 3; q++) std::swap(cur[q], nxt[q]);
+    }
   }
   dim3 gi = grid2(g.Nx, g.Ny, b);
   hipLaunchKernelGGL(k_barotropic_finalize, gi, b, 0, m->stream, g, m->f[GB25_ETA].d, m->f[GB25_BT_U].d,
@@ -658,6 +680,8 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   if (const char* e = getenv("GB25_KERNELS")) m->kernel_gen = (strcmp(e, "v1") == 0) ? 1 : 2;
   if (const char* e = getenv("GB25_TRACER_V3")) m->tracer_v3 = atoi(e);
   if (const char* e = getenv("GB25_MOMENTUM_V4")) m->momentum_v4 = atoi(e);
+  if (const char* e = getenv("GB25_BARO_BLOCK")) m->baro_block = atoi(e);
+  if (const char* e = getenv("GB25_BARO_ROWS")) m->baro_rows = (atoi(e) == 32) ? 32 : 16;
   if (const char* e = getenv("GB25_TILE_ROWS")) m->tile_rows = (atoi(e) == 4) ? 4 : 8;
   if (const char* e = getenv("GB25_VARIANT_A")) m->variant_a = atoi(e);
   if (const char* e = getenv("GB25_VARIANT_B")) m->variant_b = atoi(e);

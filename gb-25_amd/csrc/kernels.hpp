@@ -503,6 +503,135 @@ __global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, floa
   b.Ub[o] += wgt * Un;
   b.Vb[o] += wgt * Vn;
 }
+// ---------------------------------------------------------------------------------------------
+// Temporally blocked sub-cycle: BT_S substeps per launch.  The one-substep kernel above moves ~60 MB per substep
+// through L2/Infinity Cache (14 array sweeps of 4.3 MB at 1440x720) and is bound by that; here a block loads its
+// (64 x 16) tile plus a ring of BT_S cells of eta, U, V, GU, GV into LDS once, advances BT_S substeps in LDS (the
+// ring absorbs the one-cell-per-substep growth of the dependency cone), keeps the running averages in registers
+// and writes everything back once.  Per-point arithmetic and summation order are those of k_barotropic_substep.
+// ---------------------------------------------------------------------------------------------
+constexpr int BT_TX = 64, BT_NT = 256, BT_SMAX = 8;
+struct BaroMulti {
+  Baro b;
+  float w[BT_SMAX];
+  int ns;  // substeps in this launch (1..BT_S)
+};
+template <int BT_S, int BT_TY>
+__global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm, float dtau) {
+  constexpr int BT_RX = BT_TX + 2 * BT_S, BT_RY = BT_TY + 2 * BT_S, BT_NP = BT_RX * BT_RY;
+  constexpr int BT_PPT = (BT_NP + BT_NT - 1) / BT_NT;
+  __shared__ float E[BT_RY][BT_RX], U[BT_RY][BT_RX], V[BT_RY][BT_RX], GUs[BT_RY][BT_RX], GVs[BT_RY][BT_RX];
+  __shared__ float Mdxf[BT_RY + 1], Mrazc[BT_RY], Mrdxc[BT_RY];   // row metrics: no global loads inside the sub-cycle
+  const Baro& b = bm.b;
+  const int tid = threadIdx.x;
+  const int i0 = b.ilo + blockIdx.x * BT_TX, j0 = blockIdx.y * BT_TY;
+  if (tid <= BT_RY) {
+    const int jg = j0 - BT_S + tid;
+    Mdxf[tid] = g.dxf[jg];
+    if (tid < BT_RY) {
+      Mrazc[tid] = g.razc[jg];
+      Mrdxc[tid] = g.rdxc[jg];
+    }
+  }
+  const float gH = g.g * g.Lz, rdy = g.rdy, dyc = g.dy;
+  const int lo = -b.xo, hi = b.sx - b.xo - 1;   // valid array columns (slab mode: clamp; garbage stays in the rim)
+  int pl[BT_PPT], pj[BT_PPT], po[BT_PPT];       // LDS index, global row, global element offset (-1: no such point)
+  bool own[BT_PPT];
+  float ae[BT_PPT], au[BT_PPT], av[BT_PPT];
+#pragma unroll
+  for (int q = 0; q < BT_PPT; q++) {
+    const int p = tid + q * BT_NT;
+    const int ly = p / BT_RX, lx = p - ly * BT_RX;
+    const int ig = i0 - BT_S + lx, jg = j0 - BT_S + ly;
+    pl[q] = p;
+    pj[q] = jg;
+    const bool exists = (p < BT_NP) && jg >= 0 && jg < g.Ny;
+    int ii = ig;
+    if (b.wrap) {
+      ii = ii % g.Nx;
+      if (ii < 0) ii += g.Nx;
+    } else {
+      ii = max(lo, min(hi, ii));
+    }
+    po[q] = exists ? bi(g, b, ii, jg) : -1;
+    own[q] = exists && lx >= BT_S && lx < BT_S + BT_TX && ly >= BT_S && ly < BT_S + BT_TY && ig < b.ihi;
+    float e = 0.f, u = 0.f, v = 0.f, gu = 0.f, gv = 0.f;
+    if (exists) {
+      e = b.eta0[po[q]];
+      u = b.U0[po[q]];
+      v = b.V0[po[q]];
+      gu = b.GU[po[q]];
+      gv = b.GV[po[q]];
+    }
+    if (p < BT_NP) {
+      (&E[0][0])[p] = e;
+      (&U[0][0])[p] = u;
+      (&V[0][0])[p] = v;
+      (&GUs[0][0])[p] = gu;
+      (&GVs[0][0])[p] = gv;
+    }
+    ae[q] = au[q] = av[q] = 0.f;
+    if (own[q]) {
+      ae[q] = b.etab[po[q]];
+      au[q] = b.Ub[po[q]];
+      av[q] = b.Vb[po[q]];
+    }
+  }
+  __syncthreads();
+  for (int s = 0; s < bm.ns; s++) {
+    const float wgt = bm.w[s];
+    // ---- eta with the old transports (needs U(i+1), V(j+1))
+#pragma unroll
+    for (int q = 0; q < BT_PPT; q++) {
+      const int p = pl[q], jg = pj[q];
+      const int ly = p / BT_RX, lx = p - ly * BT_RX;
+      if (po[q] >= 0 && lx < BT_RX - 1 && (ly < BT_RY - 1 || jg == g.Ny - 1)) {
+        float dxU = dyc * U[ly][lx + 1] - dyc * U[ly][lx];
+        float dyV;
+        if (jg == g.Ny - 1) dyV = -(Mdxf[ly] * V[ly][lx]);
+        else if (jg == 0) dyV = Mdxf[ly + 1] * V[ly + 1][lx];
+        else dyV = Mdxf[ly + 1] * V[ly + 1][lx] - Mdxf[ly] * V[ly][lx];
+        float e = E[ly][lx] - dtau * (dxU + dyV) * Mrazc[ly];
+        E[ly][lx] = e;
+        if (own[q]) ae[q] += wgt * e;
+      }
+    }
+    __syncthreads();
+    // ---- U, V with the new eta (needs eta(i-1), eta(j-1))
+#pragma unroll
+    for (int q = 0; q < BT_PPT; q++) {
+      const int p = pl[q], jg = pj[q];
+      const int ly = p / BT_RX, lx = p - ly * BT_RX;
+      if (po[q] >= 0 && lx >= 1 && (ly >= 1 || jg == 0)) {
+        float e = E[ly][lx];
+        float dxe = (e - E[ly][lx - 1]) * Mrdxc[ly];
+        float dye = 0.f;
+        if (jg > 0) dye = (e - E[ly - 1][lx]) * rdy;
+        float Un = U[ly][lx] + dtau * (GUs[ly][lx] - gH * dxe);
+        float Vn = V[ly][lx] + dtau * (GVs[ly][lx] - gH * dye);
+        U[ly][lx] = Un;
+        V[ly][lx] = Vn;
+        if (own[q]) {
+          au[q] += wgt * Un;
+          av[q] += wgt * Vn;
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < BT_PPT; q++)
+    if (own[q]) {
+      const int p = pl[q];
+      b.eta1[po[q]] = (&E[0][0])[p];
+      b.U1[po[q]] = (&U[0][0])[p];
+      b.V1[po[q]] = (&V[0][0])[p];
+      b.etab[po[q]] = ae[q];
+      b.Ub[po[q]] = au[q];
+      b.Vb[po[q]] = av[q];
+    }
+}
+
 // eta, U, V <- time averages on the interior (source arrays may be the wide work arrays)
 __global__ void k_barotropic_finalize(Grid g, float* eta, float* U, float* V, const float* etab, const float* Ub,
                                       const float* Vb, int src_sx, int src_xo) {
