@@ -442,7 +442,8 @@ gb25_status tracers_impl(gb25_model* m) {
     const int nby = (g.Ny + 3) / 4;
     const int kchunks = std::max(1, g.Nz / 12);
     nb = nbx * nby * kchunks;
-    hipLaunchKernelGGL(k_tracer_tendencies_v3, dim3(nb), dim3(64, 4), 0, m->stream, g, m->f[GB25_U].d,
+    auto kern = m->variant_a == 6 ? k_tracer_tendencies_v3<6> : (m->variant_a == 7 ? k_tracer_tendencies_v3<7> : k_tracer_tendencies_v3<5>);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(64, 4), 0, m->stream, g, m->f[GB25_U].d,
                        m->f[GB25_V].d, m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d,
                        m->f[GB25_GN_S].d, nbx, kchunks, nb);
     LAUNCHCHK();

@@ -479,7 +479,8 @@ namespace gb25 {
 // =============================================================================================
 constexpr int V3_OUT = 63;   // outputs per wavefront
 
-__global__ __launch_bounds__(256) void k_tracer_tendencies_v3(Grid g, const float* __restrict__ u,
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v3(Grid g, const float* __restrict__ u,
                                                               const float* __restrict__ v,
                                                               const float* __restrict__ w,
                                                               const float* __restrict__ T, const float* __restrict__ S,
