@@ -76,11 +76,15 @@ __global__ __launch_bounds__(V2_TX* V2_TY) void k_tracer_tendencies_v2(
   const float dy = g.dy, Az = g.azc[j], dxf_s = g.dxf[j], razc_j = g.razc[j];
   const int oys = biased_order_face(j, g.Ny);
   // the extra faces: wave 0 -> east faces (i0+64, j0+lane), lanes 0..TY-1; wave 1 -> north faces (i0+tx, j0+TY)
-  const int jx = j0 + (tx < V2_TY ? tx : 0);
-  const int oyn = biased_order_face(j0 + V2_TY, g.Ny);
-  const float dxf_n = g.dxf[j0 + V2_TY];
+  const int jx = min(j0 + (tx < V2_TY ? tx : 0), g.Ny);
+  const int ie = min(i0 + V2_TX, g.Nx), jn = min(j0 + V2_TY, g.Ny), icl = min(i, g.Nx);
+  const int oyn = biased_order_face(jn, g.Ny);
+  const float dxf_n = g.dxf[jn];
 
-  int o = ic(g, i, j, k0), ov = iv(g, i, j, k0);
+  // Threads of a ragged edge tile beyond column Nx / row Ny work on a clamped (duplicate) column so that every
+  // address stays in bounds; column Nx and row Ny themselves must stay exact: their west / south faces are the east /
+  // north faces of the last interior cells.
+  int o = ic(g, min(i, g.Nx), min(j, g.Ny), k0), ov = iv(g, min(i, g.Nx), min(j, g.Ny), k0);
   // vertical windows c[k-3 .. k+3] of the own column
   float tz[7], sz[7];
 #pragma unroll
@@ -111,14 +115,14 @@ __global__ __launch_bounds__(V2_TX* V2_TY) void k_tracer_tendencies_v2(
     }
     if (ty == 0) {  // wave-uniform: the column of east faces of the tile
       if (tx < V2_TY) {
-        int oe = ic(g, i0 + V2_TX, jx, k);
+        int oe = ic(g, ie, jx, k);
         float Axu = dy * dz * u[oe];
         lds.fx[par][0][tx][V2_TX] = x_face_flux(g, T, oe, Axu);
         lds.fx[par][1][tx][V2_TX] = x_face_flux(g, S, oe, Axu);
       }
     } else if (ty == 1) {  // wave-uniform: the row of north faces of the tile
-      int on = ic(g, i, j0 + V2_TY, k);
-      float Ayv = dxf_n * dz * v[iv(g, i, j0 + V2_TY, k)];
+      int on = ic(g, icl, jn, k);
+      float Ayv = dxf_n * dz * v[iv(g, icl, jn, k)];
       lds.fy[par][0][V2_TY][tx] = y_face_flux(g, T, on, Ayv, oyn);
       lds.fy[par][1][V2_TY][tx] = y_face_flux(g, S, on, Ayv, oyn);
     }
@@ -225,7 +229,8 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
   const int oc_y = biased_order_center(j, g.Ny), of_y = biased_order_face(j, g.Ny);
   const bool s4c_y = sym4_center(j, g.Ny), s4f_y = sym4_face(j, g.Ny);
 
-  int o = ic(g, i, j, k0), ov = iv(g, i, j, k0);
+  // threads of a ragged edge tile work on a clamped (duplicate) column so that every address stays in bounds
+  int o = ic(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0), ov = iv(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0);
   float uz[7], vz[7];
 #pragma unroll
   for (int m = 0; m < 7; m++) {
@@ -253,14 +258,15 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
   for (int q = 0; q < NEU; q++) {
     int e = tid + q * NT;
     int ey = e / MU_X, ex = e - ey * MU_X;
-    eu_off[q] = (e < MU_X * MU_Y) ? ex + sx * ey : -1;
+    // clamp to the parent array (ragged tiles): columns <= Nx+H-1, rows <= Ny+H-1 relative to the tile origin
+    eu_off[q] = (e < MU_X * MU_Y) ? min(ex, g.Nx + H + 2 - i0) + sx * min(ey, g.Ny + H + 2 - j0) : -1;
     eu_lds[q] = e;
   }
 #pragma unroll
   for (int q = 0; q < NEW; q++) {
     int e = tid + q * NT;
     int ey = e / MW_X, ex = e - ey * MW_X;
-    ew_off[q] = (e < MW_X * MW_Y) ? ex + sx * ey : -1;
+    ew_off[q] = (e < MW_X * MW_Y) ? min(ex, g.Nx + H + 1 - i0) + sx * min(ey, g.Ny + H + 1 - j0) : -1;
     ew_lds[q] = e;
   }
   float ru[NEU], rv[NEU], rw[NEW], rp = 0.f, rpw = 0.f, rps = 0.f;
@@ -499,7 +505,8 @@ __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v3(Grid g, cons
   const float dy = g.dy, Az = g.azc[j], dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], razc_j = g.razc[j];
   const int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny);
 
-  int o = ic(g, i, j, k0), ov = iv(g, i, j, k0);
+  // lanes past the east edge work on a clamped (duplicate) column: every address stays inside the parent array
+  int o = ic(g, min(i, g.Nx), j, k0), ov = iv(g, min(i, g.Nx), j, k0);
   float tz[7], sz[7];
 #pragma unroll
   for (int m = 0; m < 7; m++) {
@@ -606,7 +613,8 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
   const int oc_y = biased_order_center(j, g.Ny), of_y = biased_order_face(j, g.Ny);
   const bool s4c_y = sym4_center(j, g.Ny), s4f_y = sym4_face(j, g.Ny);
 
-  int o = ic(g, i, j, k0), ov = iv(g, i, j, k0);
+  // threads of a ragged edge tile work on a clamped (duplicate) column so that every address stays in bounds
+  int o = ic(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0), ov = iv(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0);
   float uz[7], vz[7];
 #pragma unroll
   for (int m = 0; m < 7; m++) {
@@ -630,12 +638,12 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
 #pragma unroll
   for (int q = 0; q < NEU; q++) {
     int e = tid + q * NT, ey = e / MU_X, ex = e - ey * MU_X;
-    eu_off[q] = (e < MU_X * MU_Y) ? ex + sx * ey : -1;
+    eu_off[q] = (e < MU_X * MU_Y) ? min(ex, g.Nx + H + 2 - i0) + sx * min(ey, g.Ny + H + 2 - j0) : -1;
   }
 #pragma unroll
   for (int q = 0; q < NEW; q++) {
     int e = tid + q * NT, ey = e / MW_X, ex = e - ey * MW_X;
-    ew_off[q] = (e < MW_X * MW_Y) ? ex + sx * ey : -1;
+    ew_off[q] = (e < MW_X * MW_Y) ? min(ex, g.Nx + H + 1 - i0) + sx * min(ey, g.Ny + H + 1 - j0) : -1;
   }
   float ru[NEU], rv[NEU], rw[NEW];
   auto fetch = [&](int k) {
