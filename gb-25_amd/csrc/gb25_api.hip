@@ -336,13 +336,22 @@ Halo2 halo2_prognostic(gb25_model* m) {
 
 // y/z boundary layers (always local) and, for a single slab, the periodic x copy.
 // extended: also treat the x-halo columns (slab mode, after the neighbours' columns were unpacked).
-gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false) {
+// which: 3 = 3-D and 2-D fields, 1 = the 3-D bundle only, 2 = the 2-D fields only (slab pipeline).
+gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, int which = 3) {
   const Grid& g = m->g;
   Timed t(m, GB25_K_FILL_HALOS);
   Halo3 h3 = halo3(m);
   Halo2 h2 = halo2_prognostic(m);
   dim3 b(256);
   const int i0 = extended ? -g.H : 0, ni = extended ? g.Nx + 2 * g.H : g.Nx;
+  if (which == 2) {
+    Grid g2 = g;
+    g2.Nz = 0;   // k_fill_y then runs its 2-D branch only
+    hipLaunchKernelGGL(k_fill_y, dim3((ni + 255) / 256, 1), b, 0, m->stream, g2, h3, h2, i0, ni);
+    LAUNCHCHK();
+    return GB25_OK;
+  }
+  if (which == 1) h2.n = 0;
   hipLaunchKernelGGL(k_fill_y, dim3((ni + 255) / 256, g.Nz + 1), b, 0, m->stream, g, h3, h2, i0, ni);
   hipLaunchKernelGGL(k_fill_z, dim3((ni + 255) / 256, g.Ny), b, 0, m->stream, g, h3, i0, ni);
   if (with_x && g.x_periodic) {
@@ -757,8 +766,7 @@ const char* gb25_last_error_string(const gb25_model* m) { return m ? m->err.c_st
 
 gb25_status gb25_set_stream(gb25_model* m, void* s) {
   CHECK_MODEL(m);
-  HIPCHK(hipStreamSynchronize(m->stream));
-  m->stream = (hipStream_t)s;  // NULL = HIP's default stream
+  m->stream = (hipStream_t)s;  // NULL = HIP's default stream; ordering between streams is the caller's business
   return GB25_OK;
 }
 gb25_status gb25_use_own_stream(gb25_model* m) {
@@ -930,11 +938,18 @@ struct Piece {
 };
 static void group_pieces(gb25_model* m, int group, std::vector<Piece>& out, int* ncols) {
   const int H = m->cfg.halo, sx = m->Nx + 2 * H;
-  if (group == 0) {
+  if (group == 0 || group == 2) {
     *ncols = H;
-    for (int id : {GB25_U, GB25_V, GB25_T, GB25_S, GB25_ETA, GB25_BT_U, GB25_BT_V}) {
-      Field& F = m->f[id];
-      out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
+    if (group == 0) {
+      for (int id : {GB25_U, GB25_V, GB25_T, GB25_S}) {
+        Field& F = m->f[id];
+        out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
+      }
+    } else {
+      for (int id : {GB25_ETA, GB25_BT_U, GB25_BT_V}) {
+        Field& F = m->f[id];
+        out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
+      }
     }
   } else {
     *ncols = m->W;
@@ -948,7 +963,7 @@ static void group_pieces(gb25_model* m, int group, std::vector<Piece>& out, int*
   }
 }
 gb25_status gb25_halo_buffer_elems(const gb25_model* m, int group, int64_t* n) {
-  if (!m || !n || group < 0 || group > 1) return GB25_ERR_INVALID_ARGUMENT;
+  if (!m || !n || group < 0 || group > 2) return GB25_ERR_INVALID_ARGUMENT;
   if (m->cfg.nranks == 1) { *n = 0; return GB25_OK; }
   std::vector<Piece> ps;
   int nc = 0;
@@ -959,7 +974,7 @@ gb25_status gb25_halo_buffer_elems(const gb25_model* m, int group, int64_t* n) {
   return GB25_OK;
 }
 static gb25_status pack_unpack(gb25_model* m, int group, int side, float* buf, bool pack) {
-  if (!m || !buf || group < 0 || group > 1 || side < 0 || side > 1) return GB25_ERR_INVALID_ARGUMENT;
+  if (!m || !buf || group < 0 || group > 2 || side < 0 || side > 1) return GB25_ERR_INVALID_ARGUMENT;
   if (m->cfg.nranks == 1) return fail(m, GB25_ERR_STATE, "halo pack/unpack on a single-slab model");
   std::vector<Piece> ps;
   int nc = 0;
@@ -998,8 +1013,10 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
   const double dt = m->last_dt;
   const float chi = euler ? -0.5f : (float)m->cfg.chi;
   if (stage == 0) {
-    // AB2 update of u,v,T,S and the barotropic forcing; the host then exchanges group 1
-    return ab2_local_impl(m, (float)dt, chi);
+    // AB2 update of u,v,T,S + barotropic forcing, then the y/z boundary layers of the 3-D bundle so that its packed
+    // x columns (group 0) can travel WHILE the sub-cycle runs; the host also exchanges group 1 now
+    if ((s = ab2_local_impl(m, (float)dt, chi))) return s;
+    return fill_halos_impl(m, false, false, 1);
   } else if (stage == 1) {
     // group 1 has been unpacked into the wide halos: copy the interiors, sub-cycle, publish
     std::vector<Piece> ps;
@@ -1012,8 +1029,8 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
     if ((s = barotropic_impl(m, (float)dt))) return s;
     m->time += dt;
     m->iteration += 1;
-    // y/z boundary layers of the updated fields, so that the packed x columns carry them (group 0 next)
-    return fill_halos_impl(m, false, false);
+    // y layer of the new eta, U, V; their x columns are group 2
+    return fill_halos_impl(m, false, false, 2);
   } else if (stage == 2) {
     // group 0 has been unpacked: corrector on interior + x-halo columns, then update_state without any
     // further exchange (y/z layers re-filled over the extended x range; w and p recomputed in the halos)

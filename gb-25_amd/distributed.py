@@ -2,13 +2,15 @@
 
 Replaces what the reference gets from `Oceananigans.Distributed(arch; partition=Partition(Rx, Ry, 1))` + XLA's SPMD
 partitioner (GB-25 sharding/sharded_baroclinic_instability_simulation_run.jl:65-72): there the halos travel as
-XLA collective-permutes; here each time step has exactly two explicit exchanges:
+XLA collective-permutes; here each time step has three explicit point-to-point exchanges,
+the large one hidden behind the barotropic sub-cycle on a second HIP stream:
 
-    stage 0   AB2 update of u,v,T,S + barotropic forcing G.U,G.V          (local)
-    exchange  group 1: W = Ns+1 columns of eta,U,V,G.U,G.V               -> wide barotropic halos
-    stage 1   Ns split-explicit substeps on the widened slab, y/z layers  (local, no exchange inside the sub-cycle)
-    exchange  group 0: H columns of u,v,T,S (+ eta,U,V)                  -> x halos
-    stage 2   barotropic corrector (also in the halo columns), w, p', tendencies   (local)
+    stage 0   AB2 update of u,v,T,S + barotropic forcing, y/z layers of the 3-D bundle            (compute stream)
+    group 0   H columns of u,v,T,S          -> x halos        packed + sent on the COMM stream, in flight during stage 1
+    group 1   W = Ns+1 columns of eta,U,V,G.U,G.V -> wide barotropic halos                        (compute stream)
+    stage 1   Ns split-explicit substeps on the widened slab (no exchange inside the sub-cycle)   (compute stream)
+    group 2   H columns of eta,U,V          -> x halos                                            (compute stream)
+    stage 2   [wait for group 0] corrector (also in the halo columns), w, p', tendencies          (compute stream)
 
 No collective is needed: every rank talks to its west and east neighbour only (send/recv over xGMI via
 torch.distributed, backend "nccl" = RCCL).  The transport is injected so that the same sequencing code runs
@@ -66,30 +68,58 @@ class LocalRingTransport:
             steppers[east].recv[group][WEST].copy_(s.send[group][EAST])   # my east pack -> east nbr's west halo
 
 
+GROUPS = (0, 1, 2)
+
+
 class SlabStepper:
-    """Sequencing of one slab: owns the pack buffers and cuts the step at the two exchange points.
+    """Sequencing of one slab: owns the pack buffers and cuts the step at its exchange points.
 
-    The model's kernels are put on torch's current stream of the device, so pack kernels, the transport's
-    send/recv (or copies) and unpack kernels are ordered by the stream itself: no host synchronisation."""
+    The model's kernels run on torch's current stream of the device (the compute stream), so pack kernels, the
+    transport's send/recv (or copies) and unpack kernels are ordered by the streams themselves: no host
+    synchronisation.  `comm` is the second stream on which the 3-D halo bundle travels during the sub-cycle."""
 
-    def __init__(self, backend, device):
+    def __init__(self, backend, device, comm_stream=None):
         self.b = backend
         self.send, self.recv = {}, {}
-        for group in (0, 1):
+        for group in GROUPS:
             n = backend.halo_buffer_elems(group)
             self.send[group] = [torch.empty(n, dtype=torch.float32, device=device) for _ in range(2)]
             self.recv[group] = [torch.empty(n, dtype=torch.float32, device=device) for _ in range(2)]
-        if device.type == "cuda":
-            self.stream = torch.cuda.current_stream(device)
-            backend.set_stream(self.stream.cuda_stream)
+        self.cuda = device.type == "cuda"
+        if self.cuda:
+            self.main = torch.cuda.current_stream(device)
+            self.comm = comm_stream or torch.cuda.Stream(device)
+            backend.set_stream(self.main.cuda_stream)
 
-    def pack(self, group):
+    def pack(self, group, on_comm=False):
+        if on_comm and self.cuda:
+            self.b.set_stream(self.comm.cuda_stream)
         for side in (WEST, EAST):
             self.b.halo_pack(group, side, self.send[group][side].data_ptr())
+        if on_comm and self.cuda:
+            self.b.set_stream(self.main.cuda_stream)
 
     def unpack(self, group):
         for side in (WEST, EAST):
             self.b.halo_unpack(group, side, self.recv[group][side].data_ptr())
+
+
+class _OnComm:
+    """Context: torch's current stream = the comm stream of the steppers (no-op on CPU test doubles)."""
+
+    def __init__(self, steppers):
+        self.s = steppers[0]
+        self.ctx = None
+
+    def __enter__(self):
+        if self.s.cuda:
+            self.s.comm.wait_stream(self.s.main)      # everything stage 0 wrote is visible to the comm stream
+            self.ctx = torch.cuda.stream(self.s.comm)
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 def _run_stage(steppers, fn):
@@ -100,17 +130,23 @@ def _run_stage(steppers, fn):
 def step_slabs(steppers, exchange, euler=False):
     """One time step of a list of slabs (a single one in the multi-process case)."""
     _run_stage(steppers, lambda s: (s.b.time_step_stage(0, euler), s.pack(1)))
-    exchange(1)
-    _run_stage(steppers, lambda s: (s.unpack(1), s.b.time_step_stage(1, euler), s.pack(0)))
-    exchange(0)
-    _run_stage(steppers, lambda s: (s.unpack(0), s.b.time_step_stage(2, euler)))
+    with _OnComm(steppers):                       # the 3-D bundle leaves on the second stream ...
+        _run_stage(steppers, lambda s: s.pack(0, on_comm=True))
+        exchange(0)
+    exchange(1)                                   # ... while the barotropic halos and the sub-cycle run here
+    _run_stage(steppers, lambda s: (s.unpack(1), s.b.time_step_stage(1, euler), s.pack(2)))
+    exchange(2)
+    if steppers[0].cuda:
+        steppers[0].main.wait_stream(steppers[0].comm)
+    _run_stage(steppers, lambda s: (s.unpack(2), s.unpack(0), s.b.time_step_stage(2, euler)))
 
 
 def first_step_slabs(steppers, exchange):
     """first_time_step!: initialize!, update_state!, then an Euler step (src/timestepping_utils.jl:21-27)."""
-    _run_stage(steppers, lambda s: (s.b.initialize(), s.b.fill_halo_regions_local(), s.pack(0)))
+    _run_stage(steppers, lambda s: (s.b.initialize(), s.b.fill_halo_regions_local(), s.pack(0), s.pack(2)))
     exchange(0)
-    _run_stage(steppers, lambda s: (s.unpack(0), s.b.update_state_local()))
+    exchange(2)
+    _run_stage(steppers, lambda s: (s.unpack(0), s.unpack(2), s.b.update_state_local()))
     step_slabs(steppers, exchange, euler=True)
 
 
@@ -159,7 +195,8 @@ class LocalSlabEnsemble:
         self.P, self.Nx_loc = P, Nx_global // P
         self.backends = [HipBackend(Nx_global, Ny, Nz, dt=dt, device=device, rank=r, nranks=P, **kw) for r in range(P)]
         dev = torch.device("cuda", device)
-        self.steppers = [SlabStepper(b, dev) for b in self.backends]
+        comm = torch.cuda.Stream(dev)
+        self.steppers = [SlabStepper(b, dev, comm_stream=comm) for b in self.backends]
         self._exchange = lambda group: LocalRingTransport.exchange_all(self.steppers, group)
 
     def scatter(self, name, global_interior):

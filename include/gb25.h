@@ -144,20 +144,23 @@ gb25_status gb25_first_time_step(gb25_model *m);
 gb25_status gb25_time_step(gb25_model *m);
 gb25_status gb25_loop(gb25_model *m, int32_t n_inner);
 
-/* ---- x-slab halo exchange: pack the columns a neighbour needs into a
- *      contiguous device buffer / unpack received columns into the halo.  The host moves the
- *      buffers (RCCL send/recv via torch.distributed in this repository).
- *      group: 0 = 3-D prognostic bundle (u,v,T,S) + 2-D (eta,U,V); 1 = barotropic forcing (G.U, G.V).
- *      side: 0 = west, 1 = east.  For pack, `side` is the side of THIS slab whose interior
- *      columns are packed; for unpack it is the halo side that is filled. */
+/* ---- x-slab halo exchange: pack the columns a neighbour needs into a contiguous device
+ *      buffer / unpack received columns into the halo.  The host moves the buffers (RCCL send/recv through
+ *      torch.distributed in this repository).  Kernels run on the stream given to gb25_set_stream.
+ *      group 0: H columns of the 3-D bundle u, v, T, S (all parent rows)      -> x halos
+ *      group 1: W = Ns+1 columns of eta, U, V, G.U, G.V                       -> wide barotropic halos
+ *      group 2: H columns of eta, U, V                                        -> x halos
+ *      side: 0 = west, 1 = east.  For pack, `side` is the side of THIS slab whose interior columns are packed;
+ *      for unpack it is the halo side that is filled. */
 gb25_status gb25_halo_buffer_elems(const gb25_model *m, int group, int64_t *n_floats);
 gb25_status gb25_halo_pack(gb25_model *m, int group, int side, float *dev_buffer);
 gb25_status gb25_halo_unpack(gb25_model *m, int group, int side, const float *dev_buffer);
-/* The distributed time step split at its exchange points (the host calls these in order
- * and exchanges between them; gb25_time_step does all of it when nranks == 1):
- *   stage 0: barotropic forcing G.U,G.V (then exchange group 1)
- *   stage 1: AB2 update of u,v,T,S + split-explicit substeps (then exchange group 0)
- *   stage 2: corrector + cache, y/z halos, auxiliaries, tendencies */
+/* The time step of one slab, cut at its exchange points (gb25_time_step does all of it when nranks == 1):
+ *   stage 0: AB2 update of u,v,T,S, barotropic forcing, y/z layers of the 3-D bundle
+ *            -> pack + exchange group 1 (critical path) and group 0 (overlaps with stage 1 on a second stream)
+ *   stage 1: [group 1 unpacked] split-explicit substeps on the widened slab; y layer of eta, U, V
+ *            -> pack + exchange group 2
+ *   stage 2: [groups 0 and 2 unpacked] corrector (also in the halo columns), w, p', tendencies: no further exchange */
 gb25_status gb25_time_step_stage(gb25_model *m, int stage, int euler);
 gb25_status gb25_update_state_local(gb25_model *m); /* update_state! without the x-halo fill */
 gb25_status gb25_fill_halo_regions_local(gb25_model *m); /* y/z boundary halos only */

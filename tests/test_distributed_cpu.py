@@ -92,19 +92,24 @@ def test_time_step_sequencing_and_local_ring():
     backs, steppers, exchange, log = _make_local_ring(P)
     step_slabs(steppers, exchange, euler=False)
     mine = [e[1:] for e in log if e[0] == 2]
-    assert mine == [("stage", 0, False), ("pack", 1, WEST), ("pack", 1, EAST),
-                    ("unpack", 1, WEST), ("unpack", 1, EAST), ("stage", 1, False), ("pack", 0, WEST), ("pack", 0, EAST),
-                    ("unpack", 0, WEST), ("unpack", 0, EAST), ("stage", 2, False)]
-    # exchanges happen once per group, between the pack of every slab and the unpack of any slab
+    assert mine == [("stage", 0, False), ("pack", 1, WEST), ("pack", 1, EAST), ("pack", 0, WEST), ("pack", 0, EAST),
+                    ("unpack", 1, WEST), ("unpack", 1, EAST), ("stage", 1, False), ("pack", 2, WEST), ("pack", 2, EAST),
+                    ("unpack", 2, WEST), ("unpack", 2, EAST), ("unpack", 0, WEST), ("unpack", 0, EAST),
+                    ("stage", 2, False)]
+    # exchanges happen once per group, between the pack of every slab and the unpack of any slab;
+    # the 3-D bundle (group 0) is posted first so that it is in flight during the sub-cycle (stage 1)
     ex = [i for i, e in enumerate(log) if e[0] == "exchange"]
-    assert [log[i][1] for i in ex] == [1, 0]
-    for i, grp in zip(ex, (1, 0)):
+    assert [log[i][1] for i in ex] == [0, 1, 2]
+    stage1 = min(i for i, e in enumerate(log) if e[0] != "exchange" and e[1:3] == ("stage", 1))
+    unpack0 = min(i for i, e in enumerate(log) if e[0] != "exchange" and e[1:3] == ("unpack", 0))
+    assert ex[0] < stage1 < unpack0
+    for i, grp in zip(ex, (0, 1, 2)):
         assert all(not (e[1] == "unpack" and e[2] == grp) for e in log[:i] if e[0] != "exchange")
         assert all(not (e[1] == "pack" and e[2] == grp) for e in log[i:] if e[0] != "exchange")
     # data: my west halo holds the west neighbour's EAST pack, my east halo the east neighbour's WEST pack
     for r, b in enumerate(backs):
         west, east = slab_neighbours(r, P)
-        for grp in (0, 1):
+        for grp in (0, 1, 2):
             assert b.unpacked[(grp, WEST)] == west * 100 + grp * 10 + EAST
             assert b.unpacked[(grp, EAST)] == east * 100 + grp * 10 + WEST
 
@@ -113,7 +118,8 @@ def test_first_time_step_sequencing():
     backs, steppers, exchange, log = _make_local_ring(2)
     first_step_slabs(steppers, exchange)
     mine = [e[1:] for e in log if e[0] == 0]
-    assert mine[:6] == [("initialize",), ("fill_local",), ("pack", 0, WEST), ("pack", 0, EAST),
-                        ("unpack", 0, WEST), ("unpack", 0, EAST)]
-    assert mine[6] == ("update_state_local",)
-    assert mine[7] == ("stage", 0, True) and mine[-1] == ("stage", 2, True)      # Euler first step
+    assert mine[:10] == [("initialize",), ("fill_local",), ("pack", 0, WEST), ("pack", 0, EAST), ("pack", 2, WEST),
+                         ("pack", 2, EAST), ("unpack", 0, WEST), ("unpack", 0, EAST), ("unpack", 2, WEST),
+                         ("unpack", 2, EAST)]
+    assert mine[10] == ("update_state_local",)
+    assert mine[11] == ("stage", 0, True) and mine[-1] == ("stage", 2, True)      # Euler first step
