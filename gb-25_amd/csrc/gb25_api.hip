@@ -72,6 +72,7 @@ struct gb25_model {
   int momentum_v4 = 0;               // GB25_MOMENTUM_V4=1: single-barrier pipelined momentum kernel
   int tracer_v3 = 1;                 // wave-autonomous tracer kernel (no LDS); GB25_TRACER_V3=0 selects the LDS one
   int tile_rows = 8;                 // rows (= waves) per block of the v2 tendency kernels: 8 or 4 (GB25_TILE_ROWS)
+  int variant_c = 1;                 // nontemporal tendency reads in the tracer AB2 stream (GB25_VARIANT_C)
   int variant_a = 1, variant_b = 1;  // tuning switches (GB25_VARIANT_A / _B), see momentum_impl / tracers_impl
   int kernel_gen = 2;  // 2: LDS flux-sharing tendency kernels (kernels_v2.hpp); 1: direct-stencil kernels (GB25_KERNELS=v1)
 };
@@ -504,7 +505,8 @@ gb25_status ab2_local_impl(gb25_model* m, float dt, float chi) {
     if (aligned) {
       long n4 = n / 4;
       int blocks = (int)std::min<long>((n4 + 255) / 256, 256 * 16);
-      hipLaunchKernelGGL(k_ab2_tracers4, dim3(blocks), dim3(256), 0, m->stream, (float4*)T, (float4*)S,
+      auto kern = m->variant_c ? k_ab2_tracers4<true> : k_ab2_tracers4<false>;
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, m->stream, (float4*)T, (float4*)S,
                          (const float4*)a, (const float4*)bb, (const float4*)c, (const float4*)d, n4, dt, C1, C2);
     } else {
       int blocks = (int)std::min<long>((n + 255) / 256, 256 * 16);
@@ -695,6 +697,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   if (const char* e = getenv("GB25_TILE_ROWS")) m->tile_rows = (atoi(e) == 4) ? 4 : 8;
   if (const char* e = getenv("GB25_VARIANT_A")) m->variant_a = atoi(e);
   if (const char* e = getenv("GB25_VARIANT_B")) m->variant_b = atoi(e);
+  if (const char* e = getenv("GB25_VARIANT_C")) m->variant_c = atoi(e);
   gb25_status s;
   if ((s = build_grid(m))) return s;
   if ((s = build_eos_tables(m))) return s;

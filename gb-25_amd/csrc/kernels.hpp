@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void k_compute_w(Grid g, const float* __restri
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
   float wk = 0.f;
   w[o] = 0.f;
+#pragma unroll 4
   for (int k = 0; k < g.Nz; k++) {
     float dz = g.dzc[k];
     float Ax = dy * dz;
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(256) void k_compute_p(Grid g, const float* __restri
   // b in the first halo cell above the surface: mirrored geopotential height (table row Nz)
   double bup = gr * teos10_level(g.eos + 28 * Nz, sqrt(((double)S[o] + 32.0) * sc), (double)T[o] * 0.025);
   double pk = 0.0;
+#pragma unroll 2
   for (int k = Nz - 1; k >= 0; k--) {
     o -= g.pl_c;
     double bk = gr * teos10_level(g.eos + 28 * k, sqrt(((double)S[o] + 32.0) * sc), (double)T[o] * 0.025);
@@ -401,6 +403,7 @@ __global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, float* __restric
   const float ne = (chi != -0.5f) ? 1.f : 0.f;
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
   float su = 0.f, sv = 0.f, iu = 0.f, iv_ = 0.f;
+#pragma unroll 4
   for (int k = 0; k < g.Nz; k++) {
     float dz = g.dzc[k];
     float gu = C1 * Gnu[o] - C2 * Gmu[o] * ne;
@@ -425,23 +428,35 @@ __global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, float* __restric
 }
 
 // tracers: flat AXPY over the interior planes of a parent array (G halos are identically zero)
-__global__ void k_ab2_tracers4(float4* __restrict__ T, float4* __restrict__ S, const float4* __restrict__ GnT,
-                               const float4* __restrict__ GmT, const float4* __restrict__ GnS,
-                               const float4* __restrict__ GmS, long n4, float dt, float C1, float C2) {
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+template <bool NT>
+__global__ void k_ab2_tracers4(float4* __restrict__ T_, float4* __restrict__ S_, const float4* __restrict__ GnT_,
+                               const float4* __restrict__ GmT_, const float4* __restrict__ GnS_,
+                               const float4* __restrict__ GmS_, long n4, float dt, float C1, float C2) {
+  f32x4* T = reinterpret_cast<f32x4*>(T_);
+  f32x4* S = reinterpret_cast<f32x4*>(S_);
+  const f32x4 *GnT = reinterpret_cast<const f32x4*>(GnT_), *GmT = reinterpret_cast<const f32x4*>(GmT_);
+  const f32x4 *GnS = reinterpret_cast<const f32x4*>(GnS_), *GmS = reinterpret_cast<const f32x4*>(GmS_);
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long stride = (long)gridDim.x * blockDim.x;
+  // pure stream: every byte is touched once per step, so the tendency reads bypass the caches (nontemporal)
   for (; t < n4; t += stride) {
-    float4 a = T[t], gn = GnT[t], gm = GmT[t];
-    a.x += dt * (C1 * gn.x - C2 * gm.x);
-    a.y += dt * (C1 * gn.y - C2 * gm.y);
-    a.z += dt * (C1 * gn.z - C2 * gm.z);
-    a.w += dt * (C1 * gn.w - C2 * gm.w);
+    f32x4 a = T[t], b = S[t];
+    f32x4 gn, gm, hn, hm;
+    if (NT) {
+      gn = __builtin_nontemporal_load(&GnT[t]);
+      gm = __builtin_nontemporal_load(&GmT[t]);
+      hn = __builtin_nontemporal_load(&GnS[t]);
+      hm = __builtin_nontemporal_load(&GmS[t]);
+    } else {
+      gn = GnT[t];
+      gm = GmT[t];
+      hn = GnS[t];
+      hm = GmS[t];
+    }
+    a += dt * (C1 * gn - C2 * gm);
+    b += dt * (C1 * hn - C2 * hm);
     T[t] = a;
-    float4 b = S[t], hn = GnS[t], hm = GmS[t];
-    b.x += dt * (C1 * hn.x - C2 * hm.x);
-    b.y += dt * (C1 * hn.y - C2 * hm.y);
-    b.z += dt * (C1 * hn.z - C2 * hm.z);
-    b.w += dt * (C1 * hn.w - C2 * hm.w);
     S[t] = b;
   }
 }
@@ -710,6 +725,7 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, float* __restrict__ u
   const float du = (U[o2] - su) * g.rLz, dv = (V[o2] - sv) * g.rLz;
   o = o0;
   ov = ov0;
+#pragma unroll 4
   for (int k = 0; k < g.Nz; k++) {
     u[o] = u[o] + du;
     v[ov] = v[ov] + dv;
