@@ -41,6 +41,7 @@ struct gb25_model {
   Grid g;
   Field f[GB25_FIELD_COUNT];
   Field pp[3];                   // ping-pong partners of eta, U, V
+  Field dpx, dpy;                // p'(i)-p'(i-1), p'(j)-p'(j-1), differenced in fp64 by k_compute_p, stored fp32
   Field colsum[2];               // column integrals of u, v after the AB2 update (consumed by the corrector)
   bool colsum_valid = false;
   float* bars = nullptr;         // contiguous etabar | Ubar | Vbar
@@ -397,9 +398,11 @@ gb25_status compute_p_impl(gb25_model* m) {
   const Grid& g = m->g;
   Timed t(m, GB25_K_COMPUTE_P);
   dim3 b(64, 4);
-  int ex = g.Nx + 2 * g.H - 2, ey = g.Ny + 2 * g.H - 2;
-  hipLaunchKernelGGL(k_compute_p, grid2(ex, ey, b), b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d,
-                     m->f[GB25_PHY].d);
+  const int ncol = g.Nx + 2 * g.H - 1;   // columns -H .. Nx+H-2 (the first one only as a west neighbour)
+  const int nrow = g.Ny + 2 * g.H - 2;   // rows -H+1 .. Ny+H-2
+  dim3 gr((ncol + 62) / 63, (nrow + PR * 4 - 1) / (PR * 4));
+  hipLaunchKernelGGL(k_compute_p, gr, b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_PHY].d, m->dpx.d,
+                     m->dpy.d);
   LAUNCHCHK();
   return GB25_OK;
 }
@@ -424,7 +427,7 @@ gb25_status momentum_impl(gb25_model* m) {
                         : (m->variant_b ? k_momentum_tendencies_v2<4, 8> : k_momentum_tendencies_v2<2, 8>);
     if (m->momentum_v4) kern = k_momentum_tendencies_v4<4, 8>;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(V2_TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                       m->f[GB25_W].d, m->f[GB25_PHY].d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, nbx, kchunks, nb);
+                       m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, nbx, kchunks, nb);
     LAUNCHCHK();
     return GB25_OK;
   }
@@ -433,12 +436,12 @@ gb25_status momentum_impl(gb25_model* m) {
   {
     Timed t(m, GB25_K_GU);
     hipLaunchKernelGGL(k_gu, dim3(nb), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_W].d,
-                       m->f[GB25_PHY].d, m->f[GB25_GN_U].d, nbx, nb);
+                       m->dpx.d, m->f[GB25_GN_U].d, nbx, nb);
   }
   {
     Timed t(m, GB25_K_GV);
     hipLaunchKernelGGL(k_gv, dim3(nb), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_W].d,
-                       m->f[GB25_PHY].d, m->f[GB25_GN_V].d, nbx, nb);
+                       m->dpy.d, m->f[GB25_GN_V].d, nbx, nb);
   }
   LAUNCHCHK();
   return GB25_OK;
@@ -719,6 +722,8 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   }
   for (int q = 0; q < 3; q++)
     if ((s = alloc_field(m, m->pp[q], sx, m->f[GB25_ETA + q].ny, 1))) return s;
+  if ((s = alloc_field(m, m->dpx, m->f[GB25_PHY].nx, m->f[GB25_PHY].ny, m->f[GB25_PHY].nz))) return s;
+  if ((s = alloc_field(m, m->dpy, m->f[GB25_PHY].nx, m->f[GB25_PHY].ny, m->f[GB25_PHY].nz))) return s;
   if ((s = alloc_field(m, m->colsum[0], sx, m->f[GB25_BT_U].ny, 1))) return s;
   if ((s = alloc_field(m, m->colsum[1], sx, m->f[GB25_BT_V].ny, 1))) return s;
   if (cfg->nranks > 1) {
@@ -744,6 +749,8 @@ void gb25_destroy(gb25_model* m) {
   for (int id = 0; id < GB25_FIELD_COUNT; id++)
     if (!(id >= GB25_ETA_BAR && id <= GB25_V_BAR) && m->f[id].d) hipFree(m->f[id].d);
   if (m->bars) hipFree(m->bars);
+  if (m->dpx.d) hipFree(m->dpx.d);
+  if (m->dpy.d) hipFree(m->dpy.d);
   for (auto& p : m->pp)
     if (p.d) hipFree(p.d);
   for (auto& p : m->colsum)
@@ -822,8 +829,17 @@ static gb25_status copy_field(gb25_model* m, gb25_field id, float* host, int inc
   HIPCHK(hipMemcpy3D(&p));
   return GB25_OK;
 }
+static gb25_status widen_phy(gb25_model* m) {   // the host uploaded pHY': rebuild the differences from it
+  long n = (long)m->f[GB25_PHY].elems();
+  hipLaunchKernelGGL(k_pressure_differences, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, m->g,
+                     m->f[GB25_PHY].d, m->dpx.d, m->dpy.d, n);
+  LAUNCHCHK();
+  return GB25_OK;
+}
 gb25_status gb25_set_field(gb25_model* m, gb25_field f, const float* host, int include_halos) {
-  return copy_field(m, f, const_cast<float*>(host), include_halos, true);
+  gb25_status s = copy_field(m, f, const_cast<float*>(host), include_halos, true);
+  if (s == GB25_OK && f == GB25_PHY) s = widen_phy(m);
+  return s;
 }
 gb25_status gb25_get_field(gb25_model* m, gb25_field f, float* host, int include_halos) {
   return copy_field(m, f, host, include_halos, false);

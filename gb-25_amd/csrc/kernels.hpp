@@ -145,31 +145,67 @@ __global__ __launch_bounds__(256) void k_compute_w(Grid g, const float* __restri
 }
 
 // Hydrostatic pressure anomaly p'[k] = p'[k+1] - Iz(b)[k+1] dz^f[k+1], b = -g rho'(T,S,z)/rho0 (TEOS-10).
-// The state stays fp32, but the equation of state and the vertical integral run in fp64: rho ~ 1e3 kg/m3
-// has an fp32 ulp of 1.2e-4 kg/m3, which after integration is ~1e-3 of the horizontal pressure-gradient
-// signal (measured: fp32 EOS puts G.u, G.S, w 1e-3 away from an fp64 run; fp64 EOS brings every field
-// within sqrt(eps32)).  fp64 VALU is half rate on gfx950 and this kernel is a small share of the step; the
-// depth dependence of the 55-term polynomial is folded per level on the host (28 fp64 FMAs per cell).
+// The state stays fp32, but the equation of state, the vertical integral AND the horizontal differences the
+// momentum tendencies need run in fp64: rho ~ 1e3 kg/m3 has an fp32 ulp of 1.2e-4 kg/m3 (after integration ~1e-3
+// of the pressure-gradient signal), and p' ~ 1e2..1e3 m2/s2 stored as fp32 still costs ~1e-4 of dp/dx on a
+// quarter-degree grid.  So the kernel emits, besides the fp32 pHY' field of the API, the two differences
+// dpx = p'(i)-p'(i-1) and dpy = p'(j)-p'(j-1) (small numbers, fp32 storage is then harmless).
+// Mapping: a wave is 64 consecutive columns of which lane 0 only feeds lane 1's west difference (tiles advance by
+// 63); a thread marches R = 4 adjacent rows plus the row south of them at once, which also gives the fp64 EOS
+// chains 5-way instruction-level parallelism.  fp64 VALU is half rate on gfx950; the depth dependence of the
+// 55-term polynomial is folded per level on the host (28 fp64 FMAs per evaluation).
+constexpr int PR = 4;   // rows per thread
 __global__ __launch_bounds__(256) void k_compute_p(Grid g, const float* __restrict__ T, const float* __restrict__ S,
-                                                   float* __restrict__ p) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x - g.H + 1;
-  int j = blockIdx.y * blockDim.y + threadIdx.y - g.H + 1;
-  if (i > g.Nx + g.H - 2 || j > g.Ny + g.H - 2) return;
+                                                   float* __restrict__ p, float* __restrict__ dpx,
+                                                   float* __restrict__ dpy) {
+  const int lane = threadIdx.x;
+  const int i = -g.H + blockIdx.x * 63 + lane;                               // lane 0: helper column
+  const int jb = -g.H + 1 + (blockIdx.y * blockDim.y + threadIdx.y) * PR;    // first of this thread's PR rows
+  const int imax = g.Nx + g.H - 2, jmax = g.Ny + g.H - 2;
+  if (jb > jmax) return;                                                    // whole wave leaves together
+  const int ic_ = min(i, g.Nx + g.H - 1);                                    // clamp: addresses stay in the parent
   const int Nz = g.Nz;
   const double gr = -(double)g.g / (double)g.rho0;
   const double sc = 0.875 / 35.16504;
-  int o = ic(g, i, j, Nz);
-  // b in the first halo cell above the surface: mirrored geopotential height (table row Nz)
-  double bup = gr * teos10_level(g.eos + 28 * Nz, sqrt(((double)S[o] + 32.0) * sc), (double)T[o] * 0.025);
-  double pk = 0.0;
-#pragma unroll 2
-  for (int k = Nz - 1; k >= 0; k--) {
-    o -= g.pl_c;
-    double bk = gr * teos10_level(g.eos + 28 * k, sqrt(((double)S[o] + 32.0) * sc), (double)T[o] * 0.025);
-    pk = pk - 0.5 * (bk + bup) * g.dzf_d[k + 1];
-    p[o] = (float)pk;
-    bup = bk;
+  int o[PR + 1];
+  double bup[PR + 1], pk[PR + 1];
+#pragma unroll
+  for (int r = 0; r <= PR; r++) {
+    const int j = min(jb - 1 + r, g.Ny + g.H - 1);    // r = 0 is the helper row south of the thread's rows
+    o[r] = ic(g, ic_, j, Nz);
+    // b in the first halo cell above the surface: mirrored geopotential height (table row Nz)
+    bup[r] = gr * teos10_level(g.eos + 28 * Nz, sqrt(((double)S[o[r]] + 32.0) * sc), (double)T[o[r]] * 0.025);
+    pk[r] = 0.0;
   }
+  for (int k = Nz - 1; k >= 0; k--) {
+    const double* c = g.eos + 28 * k;
+    const double dz = g.dzf_d[k + 1];
+#pragma unroll
+    for (int r = 0; r <= PR; r++) {
+      o[r] -= g.pl_c;
+      double bk = gr * teos10_level(c, sqrt(((double)S[o[r]] + 32.0) * sc), (double)T[o[r]] * 0.025);
+      pk[r] = pk[r] - 0.5 * (bk + bup[r]) * dz;
+      bup[r] = bk;
+    }
+#pragma unroll
+    for (int r = 1; r <= PR; r++) {
+      const double pw = __shfl_up(pk[r], 1);
+      const int j = jb - 1 + r;
+      if (lane >= 1 && i <= imax && j <= jmax) {
+        p[o[r]] = (float)pk[r];
+        dpx[o[r]] = (float)(pk[r] - pw);
+        dpy[o[r]] = (float)(pk[r] - pk[r - 1]);
+      }
+    }
+  }
+}
+// the same two differences from an fp32 pHY' uploaded by the host (set_field): keeps the arrays consistent
+__global__ void k_pressure_differences(Grid g, const float* __restrict__ p, float* __restrict__ dpx,
+                                       float* __restrict__ dpy, long n) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < g.sx || t >= n) return;
+  dpx[t] = p[t] - p[t - 1];
+  dpy[t] = p[t] - p[t - g.sx];
 }
 
 // =============================================================================================
@@ -222,7 +258,7 @@ __global__ __launch_bounds__(256) void k_tracer_tendencies(Grid g, const float* 
 // hydrostatic pressure gradient.  The barotropic pressure gradient lives in the sub-cycle.
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_gu(Grid g, const float* __restrict__ u, const float* __restrict__ v,
-                                            const float* __restrict__ w, const float* __restrict__ p,
+                                            const float* __restrict__ w, const float* __restrict__ dpx,
                                             float* __restrict__ Gu, int nbx, int nb) {
   TileIdx t = tile_index(g, nbx, nb);
   if (!t.ok) return;
@@ -299,12 +335,12 @@ __global__ __launch_bounds__(256) void k_gu(Grid g, const float* __restrict__ u,
   const float bern = (dKu + dKv) * rdxc_j;
 
   const float cor = -0.5f * (g.fcor[j] + g.fcor[j + 1]) * vhat;
-  const float dpdx = (p[o] - p[o - 1]) * rdxc_j;
+  const float dpdx = dpx[o] * rdxc_j;
   Gu[o] = -(hadv + vadv + bern) - cor - dpdx;
 }
 
 __global__ __launch_bounds__(256) void k_gv(Grid g, const float* __restrict__ u, const float* __restrict__ v,
-                                            const float* __restrict__ w, const float* __restrict__ p,
+                                            const float* __restrict__ w, const float* __restrict__ dpy,
                                             float* __restrict__ Gv, int nbx, int nb) {
   TileIdx t = tile_index(g, nbx, nb);
   if (!t.ok) return;
@@ -382,7 +418,7 @@ __global__ __launch_bounds__(256) void k_gv(Grid g, const float* __restrict__ u,
   const float bern = (dKv + dKu) * g.rdy;
 
   const float cor = g.fcor[j] * uhat;
-  const float dpdy = (p[o] - p[o - sx]) * g.rdy;
+  const float dpdy = dpy[o] * g.rdy;
   Gv[ov] = -(hadv + vadv + bern) - cor - dpdy;
 }
 

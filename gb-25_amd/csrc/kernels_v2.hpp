@@ -207,7 +207,8 @@ struct MomentumLds {
 template <int MINW, int V2_TY>
 __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
     Grid g, const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ w,
-    const float* __restrict__ p, float* __restrict__ Gu, float* __restrict__ Gv, int nbx, int kchunks, int nb) {
+    const float* __restrict__ dpx, const float* __restrict__ dpy, float* __restrict__ Gu, float* __restrict__ Gv,
+    int nbx, int kchunks, int nb) {
   __shared__ MomentumLds<V2_TY> lds;
   constexpr int MU_Y = V2_TY + 6, MW_Y = V2_TY + 3, MD_Y = V2_TY + 5;
   const int L = xcd_remap(blockIdx.x, nb);
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
     ew_off[q] = (e < MW_X * MW_Y) ? min(ex, g.Nx + H + 1 - i0) + sx * min(ey, g.Ny + H + 1 - j0) : -1;
     ew_lds[q] = e;
   }
-  float ru[NEU], rv[NEU], rw[NEW], rp = 0.f, rpw = 0.f, rps = 0.f;
+  float ru[NEU], rv[NEU], rw[NEW], rpw = 0.f, rps = 0.f;
   auto fetch = [&](int k, int oo) {
     const int bu = tile_u + pc * (k + H), bv = tile_u + pv * (k + H), bw = tile_w + pc * (k + 1 + H);
 #pragma unroll
@@ -281,9 +282,8 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
 #pragma unroll
     for (int q = 0; q < NEW; q++)
       if (ew_off[q] >= 0) rw[q] = w[bw + ew_off[q]];
-    rp = p[oo];
-    rpw = p[oo - 1];
-    rps = p[oo - sx];
+    rpw = dpx[oo];   // p'(i) - p'(i-1) and p'(j) - p'(j-1), differenced in fp64 by k_compute_p
+    rps = dpy[oo];
   };
   auto stash = [&](int par) {
     float* U0 = &lds.U[par][0][0];
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
   };
   fetch(k0, o);
   stash(k0 & 1);
-  float pc_ = rp, pw_ = rpw, ps_ = rps;   // pressure at (i,j), (i-1,j), (i,j-1) of the current level
+  float pw_ = rpw, ps_ = rps;   // p'(i,j) - p'(i-1,j) and p'(i,j) - p'(i,j-1) of the current level
   __syncthreads();
 
   for (int k = k0; k < k1; k++) {
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
       const float dKv = sym_interp(s4c_y, a4[0], a4[1], a4[2], a4[3]);
       const float bern = (dKu + dKv) * rdxc_j;
       const float cor = -fbar * vhat;
-      const float dpdx = (pc_ - pw_) * rdxc_j;
+      const float dpdx = pw_ * rdxc_j;
       gu = -(hadv + vadv + bern) - cor - dpdx;
     }
     {  // ---------------- G_v at (c,f,c)
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
       const float dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
       const float bern = (dKv + dKu) * g.rdy;
       const float cor = fcor_j * uhat;
-      const float dpdy = (pc_ - ps_) * g.rdy;
+      const float dpdy = ps_ * g.rdy;
       gv = -(hadv + vadv + bern) - cor - dpdy;
     }
 #undef UT
@@ -464,7 +464,6 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
     vz[6] = vnew;
     if (more) {
       stash(par ^ 1);
-      pc_ = rp;
       pw_ = rpw;
       ps_ = rps;
     }
@@ -592,7 +591,8 @@ struct MomentumLds4 {
 template <int MINW, int TY>
 __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
     Grid g, const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ w,
-    const float* __restrict__ p, float* __restrict__ Gu, float* __restrict__ Gv, int nbx, int kchunks, int nb) {
+    const float* __restrict__ dpx, const float* __restrict__ dpy, float* __restrict__ Gu, float* __restrict__ Gv,
+    int nbx, int kchunks, int nb) {
   __shared__ MomentumLds4<TY> lds;
   constexpr int MU_Y = TY + 6, MW_Y = TY + 3, MD_Y = TY + 5;
   const int L = xcd_remap(blockIdx.x, nb);
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
     fetch(k0 + 1);
     stash(b1);
   }
-  float pc_ = p[o], pw_ = p[o - 1], ps_ = p[o - sx];
+  float pw_ = dpx[o], ps_ = dpy[o];
   __syncthreads();
   derive(k0, b0, k0 & 1);
   __syncthreads();
@@ -717,11 +717,10 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
     const bool more1 = (k + 1 < k1), more2 = (k + 2 < k1);
     if (more2) fetch(k + 2);
     const float unew = u[o + 4 * pc], vnew = v[ov + 4 * pv];
-    float pcn = 0.f, pwn = 0.f, psn = 0.f;
+    float pwn = 0.f, psn = 0.f;
     if (more1) {
-      pcn = p[o + pc];
-      pwn = p[o + pc - 1];
-      psn = p[o + pc - sx];
+      pwn = dpx[o + pc];
+      psn = dpy[o + pc];
     }
 #define UT(di, dj) lds.U[b0][ty + 3 + (dj)][tx + 3 + (di)]
 #define VT(di, dj) lds.V[b0][ty + 3 + (dj)][tx + 3 + (di)]
@@ -780,7 +779,7 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
       const float dKv = sym_interp(s4c_y, a4[0], a4[1], a4[2], a4[3]);
       const float bern = (dKu + dKv) * rdxc_j;
       const float cor = -fbar * vhat;
-      const float dpdx = (pc_ - pw_) * rdxc_j;
+      const float dpdx = pw_ * rdxc_j;
       gu = -(hadv + vadv + bern) - cor - dpdx;
     }
     {  // ---------------- G_v at (c,f,c)
@@ -832,7 +831,7 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
       const float dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
       const float bern = (dKv + dKu) * g.rdy;
       const float cor = fcor_j * uhat;
-      const float dpdy = (pc_ - ps_) * g.rdy;
+      const float dpdy = ps_ * g.rdy;
       gv = -(hadv + vadv + bern) - cor - dpdy;
     }
 #undef UT
@@ -856,7 +855,6 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
     }
     uz[6] = unew;
     vz[6] = vnew;
-    pc_ = pcn;
     pw_ = pwn;
     ps_ = psn;
     const int t = b0;

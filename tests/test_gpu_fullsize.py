@@ -91,3 +91,25 @@ def test_zonal_symmetry_and_translation_invariance(model):
     m.backend.close()
     for n in results[0]:
         assert np.array_equal(np.roll(results[0][n], s, axis=0), results[1][n]), n
+
+
+def test_full_size_parity_against_oracle():
+    """BASELINE.json's full single-GPU size, 1440x720x48, against the fp64 oracle itself (about 3.5 s per oracle
+    step on 16 cores): first_time_step! + 2 steps from the deterministic baroclinic state with seeded velocity noise."""
+    from helpers import assert_states_close
+    from oracle_backend import CPU
+    r = fresh_model()
+    v = gb.baroclinic_instability_model(CPU("f64"), NX, NY, NZ, dt=240.0)
+    gb.set_baroclinic_instability(v)
+    v.set(u=1e-3 * counter_rng((NX, NY, NZ), 42, 1), v=1e-3 * counter_rng((NX, NY + 1, NZ), 42, 2))
+    for n in ("u", "v", "T", "S"):
+        a = v.backend.get_field(n, False).astype(np.float32)
+        r.backend.set_field(n, a, False)
+        v.backend.set_field(n, a.astype(np.float64), False)
+    for m in (r, v):
+        gb.first_time_step(m)
+        gb.loop(m, 2)
+    rep = assert_states_close(r, v, include_halos=False, label="1440x720x48 after 3 steps")
+    assert max(q["rel"] for q in rep) < 3.4527e-4
+    r.backend.close()
+    v.backend.close()
