@@ -15,6 +15,9 @@ from .model import (Field, HydrostaticFreeSurfaceModel, baroclinic_instability_m
                     fill_halo_regions_workload, ab2_step_workload,
                     correct_velocities_and_cache_previous_tendencies_workload)
 from .sharding import factors
+from .arg_parsing import (float_type_from_args, float_type_from_string, interior_size, multifloat_from_args,
+                          parse_baroclinic_instability_args)
+from .sharded_io import load_all_fields, load_global_field, save_model_state
 
 
 class GPU:

@@ -61,7 +61,9 @@ struct gb25_model {
   double time = 0, last_dt = 0;
   int64_t iteration = 0;
   // streams / timing
-  hipStream_t own_stream = nullptr, stream = nullptr;
+  hipStream_t own_stream = nullptr, stream = nullptr, side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool two_streams = true;          // GB25_TWO_STREAMS=0: strictly sequential phases on one stream
   bool profile = false;
   std::vector<EventPair> pending[GB25_K_COUNT];
   std::vector<EventPair> free_events;
@@ -322,9 +324,19 @@ gb25_status alloc_field(gb25_model* m, Field& F, int nx, int ny, int nz) {
 
 inline dim3 grid2(int nx, int ny, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y); }
 
-Halo3 halo3(gb25_model* m) {
-  Halo3 h;
-  h.p[0] = m->f[GB25_U].d; h.p[1] = m->f[GB25_V].d; h.p[2] = m->f[GB25_T].d; h.p[3] = m->f[GB25_S].d;
+// sel: 3 = u, v, T, S;  1 = u, v;  2 = T, S
+Halo3 halo3(gb25_model* m, int sel = 3) {
+  Halo3 h{};
+  int n = 0;
+  if (sel & 1) {
+    h.p[n] = m->f[GB25_U].d; h.is_v[n++] = 0;
+    h.p[n] = m->f[GB25_V].d; h.is_v[n++] = 1;
+  }
+  if (sel & 2) {
+    h.p[n] = m->f[GB25_T].d; h.is_v[n++] = 0;
+    h.p[n] = m->f[GB25_S].d; h.is_v[n++] = 0;
+  }
+  h.n = n;
   return h;
 }
 Halo2 halo2_prognostic(gb25_model* m) {
@@ -339,27 +351,30 @@ Halo2 halo2_prognostic(gb25_model* m) {
 // y/z boundary layers (always local) and, for a single slab, the periodic x copy.
 // extended: also treat the x-halo columns (slab mode, after the neighbours' columns were unpacked).
 // which: 3 = 3-D and 2-D fields, 1 = the 3-D bundle only, 2 = the 2-D fields only (slab pipeline).
-gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, int which = 3) {
+// sel3: which 3-D fields (halo3); st: stream (nullptr = the model's stream).
+gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, int which = 3, int sel3 = 3,
+                            hipStream_t st = nullptr, bool use_default_stream = true) {
   const Grid& g = m->g;
+  if (use_default_stream) st = m->stream;
   Timed t(m, GB25_K_FILL_HALOS);
-  Halo3 h3 = halo3(m);
+  Halo3 h3 = halo3(m, sel3);
   Halo2 h2 = halo2_prognostic(m);
   dim3 b(256);
   const int i0 = extended ? -g.H : 0, ni = extended ? g.Nx + 2 * g.H : g.Nx;
   if (which == 2) {
     Grid g2 = g;
     g2.Nz = 0;   // k_fill_y then runs its 2-D branch only
-    hipLaunchKernelGGL(k_fill_y, dim3((ni + 255) / 256, 1), b, 0, m->stream, g2, h3, h2, i0, ni);
+    hipLaunchKernelGGL(k_fill_y, dim3((ni + 255) / 256, 1), b, 0, st, g2, h3, h2, i0, ni);
     LAUNCHCHK();
     return GB25_OK;
   }
   if (which == 1) h2.n = 0;
-  hipLaunchKernelGGL(k_fill_y, dim3((ni + 255) / 256, g.Nz + 1), b, 0, m->stream, g, h3, h2, i0, ni);
-  hipLaunchKernelGGL(k_fill_z, dim3((ni + 255) / 256, g.Ny), b, 0, m->stream, g, h3, i0, ni);
+  hipLaunchKernelGGL(k_fill_y, dim3((ni + 255) / 256, g.Nz + 1), b, 0, st, g, h3, h2, i0, ni);
+  hipLaunchKernelGGL(k_fill_z, dim3((ni + 255) / 256, g.Ny), b, 0, st, g, h3, i0, ni);
   if (with_x && g.x_periodic) {
     int rows_c = g.sy_c * (g.Nz + 2 * g.H), rows_v = g.sy_v * (g.Nz + 2 * g.H);
     long threads = (long)rows_v * 2 * g.H;
-    hipLaunchKernelGGL(k_fill_x, dim3((unsigned)((threads + 255) / 256), 4 + h2.n), b, 0, m->stream, g, h3, h2, rows_c,
+    hipLaunchKernelGGL(k_fill_x, dim3((unsigned)((threads + 255) / 256), 4 + h2.n), b, 0, st, g, h3, h2, rows_c,
                        rows_v);
   }
   LAUNCHCHK();
@@ -485,39 +500,44 @@ gb25_status tracers_impl(gb25_model* m) {
   return GB25_OK;
 }
 
-gb25_status ab2_local_impl(gb25_model* m, float dt, float chi) {
+gb25_status ab2_velocities_impl(gb25_model* m, float dt, float chi) {
   const Grid& g = m->g;
   dim3 b(64, 4);
-  {
-    Timed t(m, GB25_K_AB2_VELOCITIES);
-    hipLaunchKernelGGL(k_ab2_velocities, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                       m->f[GB25_GN_U].d, m->f[GB25_GM_U].d, m->f[GB25_GN_V].d, m->f[GB25_GM_V].d,
-                       m->f[GB25_GN_BT_U].d, m->f[GB25_GN_BT_V].d, m->colsum[0].d, m->colsum[1].d, dt, chi);
-    m->colsum_valid = true;
-  }
-  {
-    Timed t(m, GB25_K_AB2_TRACERS);
-    const float C1 = 1.5f + chi, C2 = 0.5f + chi;
-    size_t off = (size_t)g.H * g.pl_c;
-    long n = (long)g.Nz * g.pl_c;
-    float *T = m->f[GB25_T].d + off, *S = m->f[GB25_S].d + off;
-    const float *a = m->f[GB25_GN_T].d + off, *bb = m->f[GB25_GM_T].d + off, *c = m->f[GB25_GN_S].d + off,
-                *d = m->f[GB25_GM_S].d + off;
-    bool aligned = (n % 4 == 0) && (((uintptr_t)T | (uintptr_t)S | (uintptr_t)a | (uintptr_t)bb | (uintptr_t)c |
-                                     (uintptr_t)d) % 16 == 0);
-    if (aligned) {
-      long n4 = n / 4;
-      int blocks = (int)std::min<long>((n4 + 255) / 256, 256 * 16);
-      auto kern = m->variant_c ? k_ab2_tracers4<true> : k_ab2_tracers4<false>;
-      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, m->stream, (float4*)T, (float4*)S,
-                         (const float4*)a, (const float4*)bb, (const float4*)c, (const float4*)d, n4, dt, C1, C2);
-    } else {
-      int blocks = (int)std::min<long>((n + 255) / 256, 256 * 16);
-      hipLaunchKernelGGL(k_ab2_tracers1, dim3(blocks), dim3(256), 0, m->stream, T, S, a, bb, c, d, n, dt, C1, C2);
-    }
+  Timed t(m, GB25_K_AB2_VELOCITIES);
+  hipLaunchKernelGGL(k_ab2_velocities, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                     m->f[GB25_GN_U].d, m->f[GB25_GM_U].d, m->f[GB25_GN_V].d, m->f[GB25_GM_V].d,
+                     m->f[GB25_GN_BT_U].d, m->f[GB25_GN_BT_V].d, m->colsum[0].d, m->colsum[1].d, dt, chi);
+  m->colsum_valid = true;
+  LAUNCHCHK();
+  return GB25_OK;
+}
+gb25_status ab2_tracers_impl(gb25_model* m, float dt, float chi) {
+  const Grid& g = m->g;
+  Timed t(m, GB25_K_AB2_TRACERS);
+  const float C1 = 1.5f + chi, C2 = 0.5f + chi;
+  size_t off = (size_t)g.H * g.pl_c;
+  long n = (long)g.Nz * g.pl_c;
+  float *T = m->f[GB25_T].d + off, *S = m->f[GB25_S].d + off;
+  const float *a = m->f[GB25_GN_T].d + off, *bb = m->f[GB25_GM_T].d + off, *c = m->f[GB25_GN_S].d + off,
+              *d = m->f[GB25_GM_S].d + off;
+  bool aligned = (n % 4 == 0) && (((uintptr_t)T | (uintptr_t)S | (uintptr_t)a | (uintptr_t)bb | (uintptr_t)c |
+                                   (uintptr_t)d) % 16 == 0);
+  if (aligned) {
+    long n4 = n / 4;
+    int blocks = (int)std::min<long>((n4 + 255) / 256, 256 * 16);
+    auto kern = m->variant_c ? k_ab2_tracers4<true> : k_ab2_tracers4<false>;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, m->stream, (float4*)T, (float4*)S, (const float4*)a,
+                       (const float4*)bb, (const float4*)c, (const float4*)d, n4, dt, C1, C2);
+  } else {
+    int blocks = (int)std::min<long>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_ab2_tracers1, dim3(blocks), dim3(256), 0, m->stream, T, S, a, bb, c, d, n, dt, C1, C2);
   }
   LAUNCHCHK();
   return GB25_OK;
+}
+gb25_status ab2_local_impl(gb25_model* m, float dt, float chi) {
+  gb25_status s = ab2_velocities_impl(m, dt, chi);
+  return s ? s : ab2_tracers_impl(m, dt, chi);
 }
 
 // step_free_surface!: Ns fused forward-backward substeps.  Single slab: canonical arrays, periodic x wrapped
@@ -631,18 +651,58 @@ gb25_status ab2_step_impl(gb25_model* m, double dt, int euler) {
   return barotropic_impl(m, (float)dt);
 }
 
+// One time step on a single slab.  Two HIP streams: the tracer branch (AB2 of T,S -> their halos -> hydrostatic
+// pressure: HBM- then fp64-bound) is independent of the velocity branch (AB2 of u,v -> split-explicit sub-cycle,
+// which is latency-bound -> halos -> corrector -> halos -> w) until the tendencies need both, so it runs on a
+// side stream and overlaps.  The phase order within each branch is the reference's (src/precompile.jl:31-42);
+// T and S are untouched between the two halo fills of the reference sequence, so they are filled once.
 gb25_status time_step_impl(gb25_model* m, int euler) {
   if (m->cfg.nranks != 1)
     return fail(m, GB25_ERR_STATE, "gb25_time_step on a slab of a %d-rank decomposition: drive gb25_time_step_stage",
                 m->cfg.nranks);
   gb25_status s;
   const double dt = m->last_dt;
-  if ((s = ab2_step_impl(m, dt, euler))) return s;
+  if (!m->two_streams) {
+    if ((s = ab2_step_impl(m, dt, euler))) return s;
+    m->time += dt;
+    m->iteration += 1;
+    if ((s = fill_halos_impl(m, true))) return s;
+    if ((s = corrector_impl(m, true))) return s;
+    return update_state_impl(m);
+  }
+  const float chi = euler ? -0.5f : (float)m->cfg.chi;
+  hipStream_t main = m->stream, side = m->side_stream;
+  HIPCHK(hipEventRecord(m->ev_fork, main));
+  HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
+  // ---- tracer branch (side stream)
+  m->stream = side;
+  s = ab2_tracers_impl(m, (float)dt, chi);
+  if (!s) s = fill_halos_impl(m, true, false, 1, 2);      // y/z/x halos of T, S
+  if (!s) s = compute_p_impl(m);
+  m->stream = main;
+  if (s) return s;
+  HIPCHK(hipEventRecord(m->ev_join, side));
+  // ---- velocity branch (main stream)
+  if ((s = ab2_velocities_impl(m, (float)dt, chi))) return s;
+  {
+    Halo2 hG;
+    hG.p[0] = m->f[GB25_GN_BT_U].d; hG.is_v[0] = 0;
+    hG.p[1] = m->f[GB25_GN_BT_V].d; hG.is_v[1] = 1;
+    hG.p[2] = nullptr; hG.is_v[2] = 0;
+    hG.n = 2;
+    if ((s = fill_halos_2d(m, hG))) return s;
+  }
+  if ((s = barotropic_impl(m, (float)dt))) return s;
   m->time += dt;
   m->iteration += 1;
-  if ((s = fill_halos_impl(m, true))) return s;
+  if ((s = fill_halos_impl(m, true, false, 3, 1))) return s;   // u, v and eta, U, V
   if ((s = corrector_impl(m, true))) return s;
-  return update_state_impl(m);
+  if ((s = fill_halos_impl(m, true, false, 3, 1))) return s;
+  if ((s = compute_w_impl(m))) return s;
+  // ---- join: the tendencies need w, u, v and the pressure differences, T, S
+  HIPCHK(hipStreamWaitEvent(main, m->ev_join, 0));
+  if ((s = momentum_impl(m))) return s;
+  return tracers_impl(m);
 }
 
 gb25_status initialize_impl(gb25_model* m) {
@@ -690,6 +750,10 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     return fail(m, GB25_ERR_INVALID_ARGUMENT, "device ordinal %d out of range (%d devices)", cfg->device, ndev);
   HIPCHK(hipSetDevice(cfg->device));
   HIPCHK(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+  if (const char* e = getenv("GB25_TWO_STREAMS")) m->two_streams = atoi(e) != 0;
   m->stream = m->own_stream;
   m->last_dt = cfg->dt;
   if (const char* e = getenv("GB25_KERNELS")) m->kernel_gen = (strcmp(e, "v1") == 0) ? 1 : 2;
@@ -768,6 +832,12 @@ void gb25_destroy(gb25_model* m) {
     hipEventDestroy(ev.a);
     hipEventDestroy(ev.b);
   }
+  if (m->side_stream) {
+    hipStreamSynchronize(m->side_stream);
+    hipStreamDestroy(m->side_stream);
+  }
+  if (m->ev_fork) hipEventDestroy(m->ev_fork);
+  if (m->ev_join) hipEventDestroy(m->ev_join);
   if (m->own_stream) hipStreamDestroy(m->own_stream);
   delete m;
 }

@@ -36,7 +36,9 @@ __device__ __forceinline__ TileIdx tile_index(const Grid& g, int nbx, int nb) {
 // columns over the whole parent (j,k) extent, filled last so corners are consistent.
 // =============================================================================================
 struct Halo3 {
-  float* p[4];  // u, v, T, S
+  float* p[4];   // up to four 3-D fields ...
+  int is_v[4];   // ... flagged when face-located in y (v-shaped parent, wall-normal velocity)
+  int n;
 };
 struct Halo2 {
   float* p[3];  // centre-y fields first, then the face-y field (is_v[])
@@ -52,10 +54,9 @@ __global__ void k_fill_y(Grid g, Halo3 f3, Halo2 f2, int i0, int ni) {
   i += i0;
   int k = blockIdx.y;
   if (k < g.Nz) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < f3.n; q++) {
       float* c = f3.p[q];
-      if (q == 1) {  // v: faces 0 and Ny are walls
+      if (f3.is_v[q]) {  // v: faces 0 and Ny are walls
         c[iv(g, i, 0, k)] = 0.f;
         c[iv(g, i, g.Ny, k)] = 0.f;
       } else {
@@ -82,10 +83,9 @@ __global__ void k_fill_z(Grid g, Halo3 f3, int i0, int ni) {
   if (i >= ni) return;
   i += i0;
   int j = blockIdx.y;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
+  for (int q = 0; q < f3.n; q++) {
     float* c = f3.p[q];
-    if (q == 1) {
+    if (f3.is_v[q]) {
       c[iv(g, i, j, -1)] = c[iv(g, i, j, 0)];
       c[iv(g, i, j, g.Nz)] = c[iv(g, i, j, g.Nz - 1)];
     } else {
@@ -107,8 +107,10 @@ __global__ void k_fill_x(Grid g, Halo3 f3, Halo2 f2, int rows_c, int rows_v) {
   long row = t / (2 * g.H);
   int f = blockIdx.y;
   if (f < 4) {
-    long rows = (f == 1) ? rows_v : rows_c;
-    if (row < rows) periodic_row(g, f3.p[f], row, q);
+    if (f < f3.n) {
+      long rows = f3.is_v[f] ? rows_v : rows_c;
+      if (row < rows) periodic_row(g, f3.p[f], row, q);
+    }
   } else {
     int s = f - 4;
     if (s < f2.n) {
