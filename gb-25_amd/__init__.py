@@ -24,11 +24,13 @@ class GPU:
     """Architecture object: `baroclinic_instability_model(GPU(), Nx, Ny, Nz; dt=...)`
     (the reference passes CPU() / GPU() / ReactantState(), correctness/..._run.jl:33-34)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, float_type="Float32"):
         self.device = device
+        self.float_type = float_type   # "Float32" | "Float64" (float_type_from_args)
 
     def __call__(self, Nx, Ny, Nz, **kw):
         kw.setdefault("device", self.device)
+        kw.setdefault("float_type", self.float_type)
         return HipBackend(Nx, Ny, Nz, **kw)
 
 

@@ -10,6 +10,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GB25_LIB") or os.path.join(_HERE, "libgb25hip.so")   # GB25_LIB: A/B builds while tuning
+# one library per Oceananigans float type (src/arg_parsing.jl:12-16): same source, same symbols
+LIB_PATHS = {"Float32": LIB_PATH, "Float64": os.path.join(_HERE, "libgb25hip_f64.so")}
+DTYPES = {"Float32": np.float32, "Float64": np.float64}
 
 FIELD_IDS = {
     "u": 0, "v": 1, "w": 2, "T": 3, "S": 4, "pHY": 5,
@@ -27,6 +30,7 @@ KERNEL_IDS = {"fill_halos": 0, "compute_w": 1, "compute_p": 2, "gu": 3, "gv": 4,
 # every symbol include/gb25.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "gb25_default_config", "gb25_create", "gb25_destroy", "gb25_last_error_string", "gb25_version",
+    "gb25_real_bytes",
     "gb25_set_stream", "gb25_use_own_stream", "gb25_synchronize", "gb25_field_dims", "gb25_set_field", "gb25_get_field",
     "gb25_field_device_ptr", "gb25_get_metric", "gb25_get_substepping", "gb25_set_baroclinic_instability",
     "gb25_get_clock", "gb25_set_dt", "gb25_initialize", "gb25_mask_immersed_fields",
@@ -56,19 +60,21 @@ class GB25Error(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """Load libgb25hip.so; raises if it has not been built (no fallback path exists)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load_library(float_type="Float32"):
+    """Load libgb25hip.so (or its Float64 build); raises if it has not been built (no fallback path exists)."""
+    if float_type not in LIB_PATHS:
+        raise GB25Error(f"float type must be one of {sorted(LIB_PATHS)}, got {float_type!r}")
+    if float_type in _libs:
+        return _libs[float_type]
+    path = LIB_PATHS[float_type]
+    if not os.path.exists(path):
         raise GB25Error(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  gb25_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     P = C.c_void_p
     lib.gb25_version.restype = C.c_char_p
     lib.gb25_last_error_string.restype = C.c_char_p
@@ -103,7 +109,10 @@ def load_library():
                  "gb25_compute_tendencies", "gb25_update_state", "gb25_first_time_step", "gb25_time_step",
                  "gb25_update_state_local", "gb25_fill_halo_regions_local", "gb25_profile_reset"]:
         getattr(lib, name).argtypes = [P]
-    _lib = lib
+    lib.gb25_real_bytes.restype = C.c_int32
+    if lib.gb25_real_bytes() != np.dtype(DTYPES[float_type]).itemsize:
+        raise GB25Error(f"{path} holds {lib.gb25_real_bytes()}-byte elements, expected {float_type}")
+    _libs[float_type] = lib
     return lib
 
 
@@ -111,10 +120,13 @@ class HipBackend:
     """One gb25_model handle.  Method names follow the phase list of
     GB-25 src/precompile.jl:31-42 and the entry points of src/timestepping_utils.jl:21-45."""
 
-    dtype = np.float32
-
-    def __init__(self, Nx, Ny, Nz, *, dt, halo=8, substeps=30, device=0, rank=0, nranks=1, **overrides):
-        self.lib = load_library()
+    def __init__(self, Nx, Ny, Nz, *, dt, halo=8, substeps=30, device=0, rank=0, nranks=1, float_type="Float32",
+                 **overrides):
+        float_type = getattr(float_type, "__name__", float_type)   # accepts "Float64", np.float64, ...
+        float_type = {"float32": "Float32", "float64": "Float64"}.get(float_type, float_type)
+        self.lib = load_library(float_type)
+        self.float_type = float_type
+        self.dtype = DTYPES[float_type]
         cfg = Config()
         self.lib.gb25_default_config(C.byref(cfg), Nx, Ny, Nz)
         cfg.halo, cfg.substeps, cfg.dt, cfg.device, cfg.rank, cfg.nranks = halo, substeps, dt, device, rank, nranks
@@ -159,13 +171,13 @@ class HipBackend:
     def get_field(self, name, include_halos=True):
         """numpy array shaped like parent(field) / interior(field), index order [i, j, k]."""
         d = self.field_dims(name, include_halos)
-        out = np.empty(d[::-1], dtype=np.float32)  # memory order is i fastest
+        out = np.empty(d[::-1], dtype=self.dtype)  # memory order is i fastest
         self._call("gb25_get_field", FIELD_IDS[name], out.ctypes.data_as(C.c_void_p), int(include_halos))
         return out.transpose(2, 1, 0)
 
     def set_field(self, name, array, include_halos=True):
         d = self.field_dims(name, include_halos)
-        a = np.asarray(array, dtype=np.float32)
+        a = np.asarray(array, dtype=self.dtype)
         if a.ndim == 2:
             a = a[:, :, None]
         if a.shape != d:

@@ -42,8 +42,8 @@ def compare_states(m1, m2, *, rtol=None, atol=0.0, include_halos=False, throw_er
     """compare_states(m1, m2; rtol=sqrt(eps(eltype(grid))), atol=0, include_halos, throw_error)
     -- src/correctness.jl:28-90.  Walks fields(model) = (u, v, w, eta, T, S), G^n and G^- of every name
     but w and eta, and the split-explicit filtered state (U, V, eta).  Returns (ok, report)."""
-    if rtol is None:
-        rtol = math.sqrt(np.finfo(np.float32).eps)
+    if rtol is None:   # sqrt(eps(eltype(grid)))
+        rtol = math.sqrt(np.finfo(getattr(m1.backend, "dtype", np.float32)).eps)
     get = (lambda f: f.parent) if include_halos else (lambda f: f.interior)
     report, ok = [], True
     f1, f2 = m1.fields(), m2.fields()

@@ -6,7 +6,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef GB25_REAL
+#define GB25_REAL float   // the model's float type; libgb25hip_f64.so is this same source built with double
+#endif
+
 namespace gb25 {
+
+using real = GB25_REAL;
+struct alignas(2 * sizeof(real)) real2 { real x, y; };
+struct alignas(4 * sizeof(real)) real4 { real x, y, z, w; };
+
+__device__ __forceinline__ float rabs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double rabs(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float rmin(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double rmin(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float rmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double rmax(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float rtanh(float x) { return tanhf(x); }
+__device__ __forceinline__ double rtanh(double x) { return tanh(x); }
 
 struct Grid {
   int Nx, Ny, Nz, H;      // LOCAL interior size and halo
@@ -14,12 +31,12 @@ struct Grid {
   int pl_c, pl_v;         // plane strides      = sx*(Ny+2H), sx*(Ny+2H+1)
   int sy_c, sy_v;         // parent y extents
   int x_periodic;         // 1: single slab, x halos are filled by local periodic copy
-  float dy, g, rho0, Lz;
+  real dy, g, rho0, Lz;
   // metric tables, pointers are pre-offset so that index 0 is the first interior cell/face
-  const float *dxc, *dxf, *azc, *azf, *fcor, *phic;  // by j   (valid j: -H-2 .. Ny+H+2)
-  const float *rdxc, *razc, *razf;                   // reciprocals (host-computed in fp64, rounded once)
-  const float *zc, *dzc, *dzf, *rdzc;                // by k   (valid k: -H-2 .. Nz+H+2)
-  float rdy, rLz;
+  const real *dxc, *dxf, *azc, *azf, *fcor, *phic;  // by j   (valid j: -H-2 .. Ny+H+2)
+  const real *rdxc, *razc, *razf;                   // reciprocals (host-computed in fp64, rounded once)
+  const real *zc, *dzc, *dzf, *rdzc;                // by k   (valid k: -H-2 .. Nz+H+2)
+  real rdy, rLz;
   // TEOS-10 folded per level: rho'(s,t) = sum_{i+j<=6} eos[k][idx(i,j)] s^i t^j, k = 0..Nz (Nz = mirrored halo level)
   const double* eos;
   const double* dzf_d;                               // dzf in fp64 for the hydrostatic integral, by k (0..Nz)
@@ -34,7 +51,9 @@ __device__ __forceinline__ int iv(const Grid& g, int i, int j, int k) {
 }
 __device__ __forceinline__ int i2(const Grid& g, int i, int j) { return (i + g.H) + g.sx * (j + g.H); }
 
+// reciprocal: the 1-ulp hardware approximation in fp32, a true division in fp64
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
 
 // ---------------------------------------------------------------------------------------------
 // WENO reconstruction, Oceananigans flavour: uniform coefficients, Z-weights
@@ -46,59 +65,59 @@ __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x);
 //  * the WENO5 indicators are carried as beta/0.75 = (13/3) d1^2 + d2^2 (3 instructions instead of 4); every
 //    indicator, tau and eps are scaled alike, so tau/(beta+eps) and hence the weights are unchanged;
 //  * the candidate polynomials are carried as 6 p_s (integer coefficients) and the 1/6 is applied once at the end.
-constexpr float kWenoEps = 1e-8f;
-constexpr float kWenoEps5 = 1e-8f / 0.75f;   // eps in the scaled WENO5 indicator units
+constexpr real kWenoEps = real(1e-8);
+constexpr real kWenoEps5 = real(1e-8) / real(0.75);   // eps in the scaled WENO5 indicator units
 
-__device__ __forceinline__ float beta5_0(float c, float d, float e) {
-  float d1 = c - 2.f * d + e, d2 = 3.f * c - 4.f * d + e;
-  return (d1 * (13.f / 3.f)) * d1 + d2 * d2;
+__device__ __forceinline__ real beta5_0(real c, real d, real e) {
+  real d1 = c - real(2.) * d + e, d2 = real(3.) * c - real(4.) * d + e;
+  return (d1 * (real(13.) / real(3.))) * d1 + d2 * d2;
 }
-__device__ __forceinline__ float beta5_1(float b, float c, float d) {
-  float d1 = b - 2.f * c + d, d2 = b - d;
-  return (d1 * (13.f / 3.f)) * d1 + d2 * d2;
+__device__ __forceinline__ real beta5_1(real b, real c, real d) {
+  real d1 = b - real(2.) * c + d, d2 = b - d;
+  return (d1 * (real(13.) / real(3.))) * d1 + d2 * d2;
 }
-__device__ __forceinline__ float beta5_2(float a, float b, float c) {
-  float d1 = a - 2.f * b + c, d2 = a - 4.f * b + 3.f * c;
-  return (d1 * (13.f / 3.f)) * d1 + d2 * d2;
+__device__ __forceinline__ real beta5_2(real a, real b, real c) {
+  real d1 = a - real(2.) * b + c, d2 = a - real(4.) * b + real(3.) * c;
+  return (d1 * (real(13.) / real(3.))) * d1 + d2 * d2;
 }
 // Z-weights alpha_s = C_s (1 + (tau/b_s)^2), b_s = beta_s + eps, evaluated as C_s (1 + (q rho_s)^2) with
 // q = min(tau/b_min, 1e9) and rho_s = b_min/b_s <= 1.  Identical in exact arithmetic; in fp32 the plain form
 // overflows (tau/b ~ 1e18 when one indicator cancels to zero next to area-weighted divergences ~1e8).
-constexpr float kZCap = 1e9f;
-__device__ __forceinline__ float weno5_combine(float a, float b, float c, float d, float e, float b0, float b1,
-                                               float b2) {
-  float p0 = 2.f * c + 5.f * d - e;            // 6 x the candidate polynomials
-  float p1 = 5.f * c + 2.f * d - b;
-  float p2 = 2.f * a - 7.f * b + 11.f * c;
-  float tau = fabsf(b0 - b2);
+constexpr real kZCap = real(1e9);
+__device__ __forceinline__ real weno5_combine(real a, real b, real c, real d, real e, real b0, real b1,
+                                               real b2) {
+  real p0 = real(2.) * c + real(5.) * d - e;            // 6 x the candidate polynomials
+  real p1 = real(5.) * c + real(2.) * d - b;
+  real p2 = real(2.) * a - real(7.) * b + real(11.) * c;
+  real tau = rabs(b0 - b2);
   b0 += kWenoEps5;
   b1 += kWenoEps5;
   b2 += kWenoEps5;
-  float bmin = fminf(b0, fminf(b1, b2));
-  float qb = fminf(tau * rcp(bmin), kZCap) * bmin;
-  float r0 = qb * rcp(b0), r1 = qb * rcp(b1), r2 = qb * rcp(b2);
-  float a0 = 0.3f * r0 * r0 + 0.3f, a1 = 0.6f * r1 * r1 + 0.6f, a2 = 0.1f * r2 * r2 + 0.1f;
-  return (a0 * p0 + a1 * p1 + a2 * p2) * (rcp(a0 + a1 + a2) * (1.f / 6.f));
+  real bmin = rmin(b0, rmin(b1, b2));
+  real qb = rmin(tau * rcp(bmin), kZCap) * bmin;
+  real r0 = qb * rcp(b0), r1 = qb * rcp(b1), r2 = qb * rcp(b2);
+  real a0 = real(0.3) * r0 * r0 + real(0.3), a1 = real(0.6) * r1 * r1 + real(0.6), a2 = real(0.1) * r2 * r2 + real(0.1);
+  return (a0 * p0 + a1 * p1 + a2 * p2) * (rcp(a0 + a1 + a2) * (real(1.) / real(6.)));
 }
-__device__ __forceinline__ float beta3(float x, float y) {
-  float d = x - y;
+__device__ __forceinline__ real beta3(real x, real y) {
+  real d = x - y;
   return d * d;
 }
-__device__ __forceinline__ float weno3_combine(float b, float c, float d, float b0, float b1) {
-  float p0 = c + d;                            // 2 x the candidate polynomials
-  float p1 = 3.f * c - b;
-  float tau = fabsf(b0 - b1);
+__device__ __forceinline__ real weno3_combine(real b, real c, real d, real b0, real b1) {
+  real p0 = c + d;                            // 2 x the candidate polynomials
+  real p1 = real(3.) * c - b;
+  real tau = rabs(b0 - b1);
   b0 += kWenoEps;
   b1 += kWenoEps;
-  float bmin = fminf(b0, b1);
-  float qb = fminf(tau * rcp(bmin), kZCap) * bmin;
-  float r0 = qb * rcp(b0), r1 = qb * rcp(b1);
-  float a0 = (2.f / 3.f) * r0 * r0 + (2.f / 3.f), a1 = (1.f / 3.f) * r1 * r1 + (1.f / 3.f);
-  return (a0 * p0 + a1 * p1) * (rcp(a0 + a1) * 0.5f);
+  real bmin = rmin(b0, b1);
+  real qb = rmin(tau * rcp(bmin), kZCap) * bmin;
+  real r0 = qb * rcp(b0), r1 = qb * rcp(b1);
+  real a0 = (real(2.) / real(3.)) * r0 * r0 + (real(2.) / real(3.)), a1 = (real(1.) / real(3.)) * r1 * r1 + (real(1.) / real(3.));
+  return (a0 * p0 + a1 * p1) * (rcp(a0 + a1) * real(0.5));
 }
 
 // Self-smoothness WENO5 of upwind-ordered values.
-__device__ __forceinline__ float weno5(float a, float b, float c, float d, float e) {
+__device__ __forceinline__ real weno5(real a, real b, real c, real d, real e) {
   return weno5_combine(a, b, c, d, e, beta5_0(c, d, e), beta5_1(b, c, d), beta5_2(a, b, c));
 }
 
@@ -108,33 +127,33 @@ __device__ __forceinline__ float weno5(float a, float b, float c, float d, float
 // s: smoothness inputs (FunctionStencil) or nullptr-equivalent (pass q); t: second smoothness
 // set (VelocityStencil) averaged with s when TWO is true.
 template <bool TWO>
-__device__ __forceinline__ float biased6(int order, bool left, const float* q, const float* s, const float* t) {
-  float c = left ? q[2] : q[3];
+__device__ __forceinline__ real biased6(int order, bool left, const real* q, const real* s, const real* t) {
+  real c = left ? q[2] : q[3];
   if (order == 1) return c;
-  float b = left ? q[1] : q[4], d = left ? q[3] : q[2];
-  float sb = left ? s[1] : s[4], sc = left ? s[2] : s[3], sd = left ? s[3] : s[2];
-  float tb = 0, tc = 0, td = 0;
+  real b = left ? q[1] : q[4], d = left ? q[3] : q[2];
+  real sb = left ? s[1] : s[4], sc = left ? s[2] : s[3], sd = left ? s[3] : s[2];
+  real tb = 0, tc = 0, td = 0;
   if (TWO) {
     tb = left ? t[1] : t[4];
     tc = left ? t[2] : t[3];
     td = left ? t[3] : t[2];
   }
   if (order == 3) {
-    float b0 = beta3(sc, sd), b1 = beta3(sb, sc);
+    real b0 = beta3(sc, sd), b1 = beta3(sb, sc);
     if (TWO) {
-      b0 = 0.5f * (b0 + beta3(tc, td));
-      b1 = 0.5f * (b1 + beta3(tb, tc));
+      b0 = real(0.5) * (b0 + beta3(tc, td));
+      b1 = real(0.5) * (b1 + beta3(tb, tc));
     }
     return weno3_combine(b, c, d, b0, b1);
   }
-  float a = left ? q[0] : q[5], e = left ? q[4] : q[1];
-  float sa = left ? s[0] : s[5], se = left ? s[4] : s[1];
-  float b0 = beta5_0(sc, sd, se), b1 = beta5_1(sb, sc, sd), b2 = beta5_2(sa, sb, sc);
+  real a = left ? q[0] : q[5], e = left ? q[4] : q[1];
+  real sa = left ? s[0] : s[5], se = left ? s[4] : s[1];
+  real b0 = beta5_0(sc, sd, se), b1 = beta5_1(sb, sc, sd), b2 = beta5_2(sa, sb, sc);
   if (TWO) {
-    float ta = left ? t[0] : t[5], te = left ? t[4] : t[1];
-    b0 = 0.5f * (b0 + beta5_0(tc, td, te));
-    b1 = 0.5f * (b1 + beta5_1(tb, tc, td));
-    b2 = 0.5f * (b2 + beta5_2(ta, tb, tc));
+    real ta = left ? t[0] : t[5], te = left ? t[4] : t[1];
+    b0 = real(0.5) * (b0 + beta5_0(tc, td, te));
+    b1 = real(0.5) * (b1 + beta5_1(tb, tc, td));
+    b2 = real(0.5) * (b2 + beta5_2(ta, tb, tc));
   }
   return weno5_combine(a, b, c, d, e, b0, b1, b2);
 }
@@ -149,8 +168,8 @@ __device__ __forceinline__ int biased_order_center(int c, int N) {
 __device__ __forceinline__ bool sym4_face(int f, int N) { return f >= 3 && f <= N - 3; }
 __device__ __forceinline__ bool sym4_center(int c, int N) { return c >= 2 && c <= N - 3; }
 // centred interpolation from four consecutive values (target sits between q1 and q2)
-__device__ __forceinline__ float sym_interp(bool fourth, float q0, float q1, float q2, float q3) {
-  return fourth ? (7.f * (q1 + q2) - (q0 + q3)) * (1.f / 12.f) : 0.5f * (q1 + q2);
+__device__ __forceinline__ real sym_interp(bool fourth, real q0, real q1, real q2, real q3) {
+  return fourth ? (real(7.) * (q1 + q2) - (q0 + q3)) * (real(1.) / real(12.)) : real(0.5) * (q1 + q2);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ namespace {
 constexpr int PAD = 2;  // metric tables extend 2 entries beyond the halo
 
 struct Field {
-  float* d = nullptr;
+  real* d = nullptr;
   int nx = 0, ny = 0, nz = 0;  // parent dims
   size_t elems() const { return (size_t)nx * ny * nz; }
 };
@@ -44,8 +44,8 @@ struct gb25_model {
   Field dpx, dpy;                // p'(i)-p'(i-1), p'(j)-p'(j-1), differenced in fp64 by k_compute_p, stored fp32
   Field colsum[2];               // column integrals of u, v after the AB2 update (consumed by the corrector)
   bool colsum_valid = false;
-  float* bars = nullptr;         // contiguous etabar | Ubar | Vbar
-  std::vector<float*> dev_tables;
+  real* bars = nullptr;         // contiguous etabar | Ubar | Vbar
+  std::vector<real*> dev_tables;
   std::vector<double> h_metric[11];
   int metric_off_j = 0, metric_off_k = 0;
   // substepping
@@ -150,12 +150,12 @@ void resolve_profile(gb25_model* m) {
 // --- grid ------------------------------------------------------------------------------------
 // simple_latitude_longitude_grid (GB-25 src/model_utils.jl:56-65): regular lat-lon spacing,
 // exponential_z_faces(Nz, depth, h) vertical faces, spherical-shell metrics.
-gb25_status upload_table(gb25_model* m, const std::vector<double>& h, int off, const float** out) {
-  std::vector<float> f(h.size());
-  for (size_t a = 0; a < h.size(); a++) f[a] = (float)h[a];
-  float* d = nullptr;
-  HIPCHK(hipMalloc(&d, f.size() * sizeof(float)));
-  HIPCHK(hipMemcpy(d, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+gb25_status upload_table(gb25_model* m, const std::vector<double>& h, int off, const real** out) {
+  std::vector<real> f(h.size());
+  for (size_t a = 0; a < h.size(); a++) f[a] = (real)h[a];
+  real* d = nullptr;
+  HIPCHK(hipMalloc(&d, f.size() * sizeof(real)));
+  HIPCHK(hipMemcpy(d, f.data(), f.size() * sizeof(real), hipMemcpyHostToDevice));
   m->dev_tables.push_back(d);
   *out = d + off;
   return GB25_OK;
@@ -211,8 +211,8 @@ gb25_status build_grid(gb25_model* m) {
   g.sy_c = Ny + 2 * H; g.sy_v = Ny + 2 * H + 1;
   g.pl_c = g.sx * g.sy_c; g.pl_v = g.sx * g.sy_v;
   g.x_periodic = (c.nranks == 1);
-  g.dy = (float)(R * dphi * d2r);
-  g.g = (float)c.g; g.rho0 = (float)c.rho0; g.Lz = (float)(zint[Nz] - zint[0]);
+  g.dy = (real)(R * dphi * d2r);
+  g.g = (real)c.g; g.rho0 = (real)c.rho0; g.Lz = (real)(zint[Nz] - zint[0]);
   gb25_status s;
   if ((s = upload_table(m, dxc, offj, &g.dxc))) return s;
   if ((s = upload_table(m, dxf, offj, &g.dxf))) return s;
@@ -230,8 +230,8 @@ gb25_status build_grid(gb25_model* m) {
     if ((s = upload_table(m, recip(azc), offj, &g.razc))) return s;
     if ((s = upload_table(m, recip(azf), offj, &g.razf))) return s;
     if ((s = upload_table(m, recip(dzc), offk, &g.rdzc))) return s;
-    g.rdy = (float)(1.0 / (R * dphi * d2r));
-    g.rLz = (float)(1.0 / (zint[Nz] - zint[0]));
+    g.rdy = (real)(1.0 / (R * dphi * d2r));
+    g.rLz = (real)(1.0 / (zint[Nz] - zint[0]));
   }
   if ((s = upload_table(m, zc, offk, &g.zc))) return s;
   if ((s = upload_table(m, dzc, offk, &g.dzc))) return s;
@@ -283,7 +283,7 @@ gb25_status build_eos_tables(gb25_model* m) {
   HIPCHK(hipMalloc(&d, (tab.size() + dz.size()) * sizeof(double)));
   HIPCHK(hipMemcpy(d, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d + tab.size(), dz.data(), dz.size() * sizeof(double), hipMemcpyHostToDevice));
-  m->dev_tables.push_back(reinterpret_cast<float*>(d));
+  m->dev_tables.push_back(reinterpret_cast<real*>(d));
   m->g.eos = d;
   m->g.dzf_d = d + tab.size();
   return GB25_OK;
@@ -314,11 +314,11 @@ void build_substeps(gb25_model* m) {
 
 gb25_status alloc_field(gb25_model* m, Field& F, int nx, int ny, int nz) {
   F.nx = nx; F.ny = ny; F.nz = nz;
-  hipError_t e = hipMalloc(&F.d, F.elems() * sizeof(float));
+  hipError_t e = hipMalloc(&F.d, F.elems() * sizeof(real));
   if (e != hipSuccess)
-    return fail(m, GB25_ERR_OUT_OF_MEMORY, "hipMalloc of %zu bytes failed: %s", F.elems() * sizeof(float),
+    return fail(m, GB25_ERR_OUT_OF_MEMORY, "hipMalloc of %zu bytes failed: %s", F.elems() * sizeof(real),
                 hipGetErrorString(e));
-  HIPCHK(hipMemset(F.d, 0, F.elems() * sizeof(float)));
+  HIPCHK(hipMemset(F.d, 0, F.elems() * sizeof(real)));
   return GB25_OK;
 }
 
@@ -438,9 +438,12 @@ gb25_status momentum_impl(gb25_model* m) {
     const int nby = (g.Ny + TY - 1) / TY;
     const int kchunks = std::max(1, g.Nz / 12);
     nb = nbx * nby * kchunks;
-    auto kern = TY == 4 ? (m->variant_b ? k_momentum_tendencies_v2<4, 4> : k_momentum_tendencies_v2<2, 4>)
-                        : (m->variant_b ? k_momentum_tendencies_v2<4, 8> : k_momentum_tendencies_v2<2, 8>);
-    if (m->momentum_v4) kern = k_momentum_tendencies_v4<4, 8>;
+    // waves/SIMD the register allocator is held to: 4 (128 VGPRs) in fp32; fp64 operands are register pairs,
+    // so the Float64 build asks for 2 (256 VGPRs) instead of spilling
+    constexpr int MW = sizeof(real) == 8 ? 2 : 4;
+    auto kern = TY == 4 ? (m->variant_b ? k_momentum_tendencies_v2<MW, 4> : k_momentum_tendencies_v2<2, 4>)
+                        : (m->variant_b ? k_momentum_tendencies_v2<MW, 8> : k_momentum_tendencies_v2<2, 8>);
+    if (m->momentum_v4) kern = k_momentum_tendencies_v4<MW, 8>;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(V2_TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                        m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, nbx, kchunks, nb);
     LAUNCHCHK();
@@ -470,7 +473,9 @@ gb25_status tracers_impl(gb25_model* m) {
     const int nby = (g.Ny + 3) / 4;
     const int kchunks = std::max(1, g.Nz / 12);
     nb = nbx * nby * kchunks;
-    auto kern = m->variant_a == 6 ? k_tracer_tendencies_v3<6> : (m->variant_a == 7 ? k_tracer_tendencies_v3<7> : k_tracer_tendencies_v3<5>);
+    constexpr int TW = sizeof(real) == 8 ? 3 : 5;   // see MW in momentum_impl
+    auto kern = m->variant_a == 6 ? k_tracer_tendencies_v3<6>
+                                  : (m->variant_a == 7 ? k_tracer_tendencies_v3<7> : k_tracer_tendencies_v3<TW>);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64, 4), 0, m->stream, g, m->f[GB25_U].d,
                        m->f[GB25_V].d, m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d,
                        m->f[GB25_GN_S].d, nbx, kchunks, nb);
@@ -500,7 +505,7 @@ gb25_status tracers_impl(gb25_model* m) {
   return GB25_OK;
 }
 
-gb25_status ab2_velocities_impl(gb25_model* m, float dt, float chi) {
+gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
   const Grid& g = m->g;
   dim3 b(64, 4);
   Timed t(m, GB25_K_AB2_VELOCITIES);
@@ -511,23 +516,23 @@ gb25_status ab2_velocities_impl(gb25_model* m, float dt, float chi) {
   LAUNCHCHK();
   return GB25_OK;
 }
-gb25_status ab2_tracers_impl(gb25_model* m, float dt, float chi) {
+gb25_status ab2_tracers_impl(gb25_model* m, real dt, real chi) {
   const Grid& g = m->g;
   Timed t(m, GB25_K_AB2_TRACERS);
-  const float C1 = 1.5f + chi, C2 = 0.5f + chi;
+  const real C1 = real(1.5) + chi, C2 = real(0.5) + chi;
   size_t off = (size_t)g.H * g.pl_c;
   long n = (long)g.Nz * g.pl_c;
-  float *T = m->f[GB25_T].d + off, *S = m->f[GB25_S].d + off;
-  const float *a = m->f[GB25_GN_T].d + off, *bb = m->f[GB25_GM_T].d + off, *c = m->f[GB25_GN_S].d + off,
+  real *T = m->f[GB25_T].d + off, *S = m->f[GB25_S].d + off;
+  const real *a = m->f[GB25_GN_T].d + off, *bb = m->f[GB25_GM_T].d + off, *c = m->f[GB25_GN_S].d + off,
               *d = m->f[GB25_GM_S].d + off;
   bool aligned = (n % 4 == 0) && (((uintptr_t)T | (uintptr_t)S | (uintptr_t)a | (uintptr_t)bb | (uintptr_t)c |
-                                   (uintptr_t)d) % 16 == 0);
+                                   (uintptr_t)d) % sizeof(real4) == 0);
   if (aligned) {
     long n4 = n / 4;
     int blocks = (int)std::min<long>((n4 + 255) / 256, 256 * 16);
     auto kern = m->variant_c ? k_ab2_tracers4<true> : k_ab2_tracers4<false>;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, m->stream, (float4*)T, (float4*)S, (const float4*)a,
-                       (const float4*)bb, (const float4*)c, (const float4*)d, n4, dt, C1, C2);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, m->stream, (real4*)T, (real4*)S, (const real4*)a,
+                       (const real4*)bb, (const real4*)c, (const real4*)d, n4, dt, C1, C2);
   } else {
     int blocks = (int)std::min<long>((n + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(k_ab2_tracers1, dim3(blocks), dim3(256), 0, m->stream, T, S, a, bb, c, d, n, dt, C1, C2);
@@ -535,7 +540,7 @@ gb25_status ab2_tracers_impl(gb25_model* m, float dt, float chi) {
   LAUNCHCHK();
   return GB25_OK;
 }
-gb25_status ab2_local_impl(gb25_model* m, float dt, float chi) {
+gb25_status ab2_local_impl(gb25_model* m, real dt, real chi) {
   gb25_status s = ab2_velocities_impl(m, dt, chi);
   return s ? s : ab2_tracers_impl(m, dt, chi);
 }
@@ -543,24 +548,24 @@ gb25_status ab2_local_impl(gb25_model* m, float dt, float chi) {
 // step_free_surface!: Ns fused forward-backward substeps.  Single slab: canonical arrays, periodic x wrapped
 // in-kernel.  Slab of a decomposition: wide-halo work arrays (halo W >= Ns filled once by the exchange of
 // group 1), every substep computes on [-W+1, Nx+W-1) and the invalid rim never reaches the interior.
-gb25_status barotropic_impl(gb25_model* m, float dt) {
+gb25_status barotropic_impl(gb25_model* m, real dt) {
   const Grid& g = m->g;
   Timed t(m, GB25_K_BAROTROPIC);
   const bool wide = m->cfg.nranks > 1;
-  const float dtau = (float)m->dtau_frac * dt;
+  const real dtau = (real)m->dtau_frac * dt;
   dim3 b(64, 4);
   Baro bb;
-  float *cur[3], *nxt[3];
+  real *cur[3], *nxt[3];
   if (!wide) {
     size_t nbar = m->f[GB25_ETA_BAR].elems() + m->f[GB25_U_BAR].elems() + m->f[GB25_V_BAR].elems();
-    HIPCHK(hipMemsetAsync(m->bars, 0, nbar * sizeof(float), m->stream));
+    HIPCHK(hipMemsetAsync(m->bars, 0, nbar * sizeof(real), m->stream));
     for (int q = 0; q < 3; q++) { cur[q] = m->f[GB25_ETA + q].d; nxt[q] = m->pp[q].d; }
     bb.etab = m->f[GB25_ETA_BAR].d; bb.Ub = m->f[GB25_U_BAR].d; bb.Vb = m->f[GB25_V_BAR].d;
     bb.GU = m->f[GB25_GN_BT_U].d; bb.GV = m->f[GB25_GN_BT_V].d;
     bb.sx = g.sx; bb.xo = g.H; bb.ilo = 0; bb.ihi = g.Nx; bb.wrap = 1;
   } else {
     for (int q = 0; q < 3; q++) {
-      HIPCHK(hipMemsetAsync(m->wideBar[q].d, 0, m->wideBar[q].elems() * sizeof(float), m->stream));
+      HIPCHK(hipMemsetAsync(m->wideBar[q].d, 0, m->wideBar[q].elems() * sizeof(real), m->stream));
       cur[q] = m->wide[0][q].d; nxt[q] = m->wide[1][q].d;
     }
     bb.etab = m->wideBar[0].d; bb.Ub = m->wideBar[1].d; bb.Vb = m->wideBar[2].d;
@@ -571,7 +576,7 @@ gb25_status barotropic_impl(gb25_model* m, float dt) {
     // temporally blocked: S substeps per launch on (64 x TY) tiles
     const int S = std::min(m->baro_block, (int)BT_SMAX), TYb = m->baro_rows;
     dim3 gm((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX, (g.Ny + TYb - 1) / TYb);
-    void (*kern)(Grid, BaroMulti, float) = nullptr;
+    void (*kern)(Grid, BaroMulti, real) = nullptr;
     if (TYb == 16) kern = S <= 3 ? k_barotropic_multi<3, 16> : (S <= 5 ? k_barotropic_multi<5, 16> : k_barotropic_multi<7, 16>);
     else kern = S <= 3 ? k_barotropic_multi<3, 32> : (S <= 5 ? k_barotropic_multi<5, 32> : k_barotropic_multi<7, 32>);
     const int Sk = S <= 3 ? 3 : (S <= 5 ? 5 : 7);
@@ -581,7 +586,7 @@ gb25_status barotropic_impl(gb25_model* m, float dt) {
       bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
       bm.b = bb;
       bm.ns = std::min(Sk, m->Ns - s);
-      for (int q = 0; q < BT_SMAX; q++) bm.w[q] = (s + q < m->Ns) ? (float)m->weights[s + q] : 0.f;
+      for (int q = 0; q < BT_SMAX; q++) bm.w[q] = (s + q < m->Ns) ? (real)m->weights[s + q] : real(0.);
       hipLaunchKernelGGL(kern, gm, dim3(BT_NT), 0, m->stream, g, bm, dtau);
       for (int q = 0; q < 3; q++) std::swap(cur[q], nxt[q]);
     }
@@ -590,7 +595,7 @@ gb25_status barotropic_impl(gb25_model* m, float dt) {
     for (int s = 0; s < m->Ns; s++) {
       bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
       bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
-      hipLaunchKernelGGL(k_barotropic_substep, gr, b, 0, m->stream, g, bb, dtau, (float)m->weights[s]);
+      hipLaunchKernelGGL(k_barotropic_substep, gr, b, 0, m->stream, g, bb, dtau, (real)m->weights[s]);
       for (int q = 0; q < 3; q++) std::swap(cur[q], nxt[q]);
     }
   }
@@ -640,15 +645,15 @@ gb25_status update_state_impl(gb25_model* m) {
 
 gb25_status ab2_step_impl(gb25_model* m, double dt, int euler) {
   gb25_status s;
-  const float chi = euler ? -0.5f : (float)m->cfg.chi;
-  if ((s = ab2_local_impl(m, (float)dt, chi))) return s;
+  const real chi = euler ? -real(0.5) : (real)m->cfg.chi;
+  if ((s = ab2_local_impl(m, (real)dt, chi))) return s;
   Halo2 hG;
   hG.p[0] = m->f[GB25_GN_BT_U].d; hG.is_v[0] = 0;
   hG.p[1] = m->f[GB25_GN_BT_V].d; hG.is_v[1] = 1;
   hG.p[2] = nullptr; hG.is_v[2] = 0;
   hG.n = 2;
   if ((s = fill_halos_2d(m, hG))) return s;
-  return barotropic_impl(m, (float)dt);
+  return barotropic_impl(m, (real)dt);
 }
 
 // One time step on a single slab.  Two HIP streams: the tracer branch (AB2 of T,S -> their halos -> hydrostatic
@@ -670,20 +675,20 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
     if ((s = corrector_impl(m, true))) return s;
     return update_state_impl(m);
   }
-  const float chi = euler ? -0.5f : (float)m->cfg.chi;
+  const real chi = euler ? -real(0.5) : (real)m->cfg.chi;
   hipStream_t main = m->stream, side = m->side_stream;
   HIPCHK(hipEventRecord(m->ev_fork, main));
   HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
   // ---- tracer branch (side stream)
   m->stream = side;
-  s = ab2_tracers_impl(m, (float)dt, chi);
+  s = ab2_tracers_impl(m, (real)dt, chi);
   if (!s) s = fill_halos_impl(m, true, false, 1, 2);      // y/z/x halos of T, S
   if (!s) s = compute_p_impl(m);
   m->stream = main;
   if (s) return s;
   HIPCHK(hipEventRecord(m->ev_join, side));
   // ---- velocity branch (main stream)
-  if ((s = ab2_velocities_impl(m, (float)dt, chi))) return s;
+  if ((s = ab2_velocities_impl(m, (real)dt, chi))) return s;
   {
     Halo2 hG;
     hG.p[0] = m->f[GB25_GN_BT_U].d; hG.is_v[0] = 0;
@@ -692,7 +697,7 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
     hG.n = 2;
     if ((s = fill_halos_2d(m, hG))) return s;
   }
-  if ((s = barotropic_impl(m, (float)dt))) return s;
+  if ((s = barotropic_impl(m, (real)dt))) return s;
   m->time += dt;
   m->iteration += 1;
   if ((s = fill_halos_impl(m, true, false, 3, 1))) return s;   // u, v and eta, U, V
@@ -719,7 +724,8 @@ gb25_status initialize_impl(gb25_model* m) {
 // =============================================================================================
 extern "C" {
 
-const char* gb25_version(void) { return "gb25hip 0.1 (gfx950)"; }
+const char* gb25_version(void) { return sizeof(real) == 8 ? "gb25hip 0.1 (gfx950, Float64)" : "gb25hip 0.1 (gfx950, Float32)"; }
+int32_t gb25_real_bytes(void) { return (int32_t)sizeof(real); }
 
 void gb25_default_config(gb25_config* c, int32_t Nx, int32_t Ny, int32_t Nz) {
   memset(c, 0, sizeof *c);
@@ -778,8 +784,8 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   }
   {
     size_t nc = (size_t)sx * (cfg->Ny + 2 * H), nv = (size_t)sx * (cfg->Ny + 2 * H + 1);
-    HIPCHK(hipMalloc(&m->bars, (2 * nc + nv) * sizeof(float)));
-    HIPCHK(hipMemset(m->bars, 0, (2 * nc + nv) * sizeof(float)));
+    HIPCHK(hipMalloc(&m->bars, (2 * nc + nv) * sizeof(real)));
+    HIPCHK(hipMemset(m->bars, 0, (2 * nc + nv) * sizeof(real)));
     Field& e = m->f[GB25_ETA_BAR]; e.d = m->bars; e.nx = sx; e.ny = cfg->Ny + 2 * H; e.nz = 1;
     Field& u = m->f[GB25_U_BAR]; u.d = m->bars + nc; u.nx = sx; u.ny = cfg->Ny + 2 * H; u.nz = 1;
     Field& v = m->f[GB25_V_BAR]; v.d = m->bars + 2 * nc; v.nx = sx; v.ny = cfg->Ny + 2 * H + 1; v.nz = 1;
@@ -826,7 +832,7 @@ void gb25_destroy(gb25_model* m) {
   }
   for (auto& w : m->wideBar)
     if (w.d) hipFree(w.d);
-  for (float* t : m->dev_tables) hipFree(t);
+  for (real* t : m->dev_tables) hipFree(t);
   resolve_profile(m);
   for (auto& ev : m->free_events) {
     hipEventDestroy(ev.a);
@@ -873,24 +879,24 @@ gb25_status gb25_field_dims(const gb25_model* m, gb25_field id, int include_halo
   return GB25_OK;
 }
 
-static gb25_status copy_field(gb25_model* m, gb25_field id, float* host, int include_halos, bool to_device) {
+static gb25_status copy_field(gb25_model* m, gb25_field id, real* host, int include_halos, bool to_device) {
   if (!m || id < 0 || id >= GB25_FIELD_COUNT || !host) return GB25_ERR_INVALID_ARGUMENT;
   if (to_device && (id == GB25_U || id == GB25_V)) m->colsum_valid = false;  // cached column integrals are stale
   Field& F = m->f[id];
   HIPCHK(hipStreamSynchronize(m->stream));
   if (include_halos) {
-    if (to_device) HIPCHK(hipMemcpy(F.d, host, F.elems() * sizeof(float), hipMemcpyHostToDevice));
-    else HIPCHK(hipMemcpy(host, F.d, F.elems() * sizeof(float), hipMemcpyDeviceToHost));
+    if (to_device) HIPCHK(hipMemcpy(F.d, host, F.elems() * sizeof(real), hipMemcpyHostToDevice));
+    else HIPCHK(hipMemcpy(host, F.d, F.elems() * sizeof(real), hipMemcpyDeviceToHost));
     return GB25_OK;
   }
   const int H = m->cfg.halo;
   int32_t d[3];
   gb25_field_dims(m, id, 0, d);
   hipMemcpy3DParms p = {};
-  hipPitchedPtr dev = make_hipPitchedPtr(F.d, (size_t)F.nx * sizeof(float), F.nx, F.ny);
-  hipPitchedPtr hst = make_hipPitchedPtr(host, (size_t)d[0] * sizeof(float), d[0], d[1]);
-  hipPos dpos = make_hipPos((size_t)H * sizeof(float), H, is_2d(id) ? 0 : H), zero = make_hipPos(0, 0, 0);
-  p.extent = make_hipExtent((size_t)d[0] * sizeof(float), d[1], d[2]);
+  hipPitchedPtr dev = make_hipPitchedPtr(F.d, (size_t)F.nx * sizeof(real), F.nx, F.ny);
+  hipPitchedPtr hst = make_hipPitchedPtr(host, (size_t)d[0] * sizeof(real), d[0], d[1]);
+  hipPos dpos = make_hipPos((size_t)H * sizeof(real), H, is_2d(id) ? 0 : H), zero = make_hipPos(0, 0, 0);
+  p.extent = make_hipExtent((size_t)d[0] * sizeof(real), d[1], d[2]);
   if (to_device) {
     p.srcPtr = hst; p.srcPos = zero; p.dstPtr = dev; p.dstPos = dpos; p.kind = hipMemcpyHostToDevice;
   } else {
@@ -906,12 +912,13 @@ static gb25_status widen_phy(gb25_model* m) {   // the host uploaded pHY': rebui
   LAUNCHCHK();
   return GB25_OK;
 }
-gb25_status gb25_set_field(gb25_model* m, gb25_field f, const float* host, int include_halos) {
-  gb25_status s = copy_field(m, f, const_cast<float*>(host), include_halos, true);
+gb25_status gb25_set_field(gb25_model* m, gb25_field f, const void* host, int include_halos) {
+  gb25_status s = copy_field(m, f, static_cast<real*>(const_cast<void*>(host)), include_halos, true);
   if (s == GB25_OK && f == GB25_PHY) s = widen_phy(m);
   return s;
 }
-gb25_status gb25_get_field(gb25_model* m, gb25_field f, float* host, int include_halos) {
+gb25_status gb25_get_field(gb25_model* m, gb25_field f, void* host_, int include_halos) {
+  real* host = static_cast<real*>(host_);
   return copy_field(m, f, host, include_halos, false);
 }
 gb25_status gb25_field_device_ptr(gb25_model* m, gb25_field id, void** dev) {
@@ -924,14 +931,14 @@ gb25_status gb25_get_metric(const gb25_model* m, gb25_metric id, int32_t logical
   int off = (id <= GB25_M_FCOR) ? m->metric_off_j : m->metric_off_k;
   long a = (long)logical_index - 1 + off;  // logical_index is 1-based like the Julia sources
   if (a < 0 || a >= (long)m->h_metric[id].size()) return GB25_ERR_INVALID_ARGUMENT;
-  *v = (double)(float)m->h_metric[id][a];
+  *v = (double)(real)m->h_metric[id][a];
   return GB25_OK;
 }
 gb25_status gb25_get_substepping(const gb25_model* m, int32_t* n, double* frac, double* w) {
   if (!m) return GB25_ERR_INVALID_ARGUMENT;
   if (n) *n = m->Ns;
   if (frac) *frac = m->dtau_frac;
-  if (w) for (int k = 0; k < m->Ns; k++) w[k] = (double)(float)m->weights[k];
+  if (w) for (int k = 0; k < m->Ns; k++) w[k] = (double)(real)m->weights[k];
   return GB25_OK;
 }
 
@@ -1020,8 +1027,8 @@ gb25_status gb25_loop(gb25_model* m, int32_t n) {
 // group 0: H columns of u, v, T, S (all parent rows) and of eta, U, V -> the neighbour's x halo.
 // group 1: W columns of eta, U, V, G.U, G.V -> the neighbour's wide barotropic halo.
 struct Piece {
-  float* src;      // array that is packed from (canonical layout)
-  float* dst;      // array that is unpacked into
+  real* src;      // array that is packed from (canonical layout)
+  real* dst;      // array that is unpacked into
   int src_sx, src_xo, dst_sx, dst_xo;
   long rows;
 };
@@ -1062,7 +1069,7 @@ gb25_status gb25_halo_buffer_elems(const gb25_model* m, int group, int64_t* n) {
   *n = t;
   return GB25_OK;
 }
-static gb25_status pack_unpack(gb25_model* m, int group, int side, float* buf, bool pack) {
+static gb25_status pack_unpack(gb25_model* m, int group, int side, real* buf, bool pack) {
   if (!m || !buf || group < 0 || group > 2 || side < 0 || side > 1) return GB25_ERR_INVALID_ARGUMENT;
   if (m->cfg.nranks == 1) return fail(m, GB25_ERR_STATE, "halo pack/unpack on a single-slab model");
   std::vector<Piece> ps;
@@ -1088,9 +1095,11 @@ static gb25_status pack_unpack(gb25_model* m, int group, int side, float* buf, b
   LAUNCHCHK();
   return GB25_OK;
 }
-gb25_status gb25_halo_pack(gb25_model* m, int group, int side, float* buf) { return pack_unpack(m, group, side, buf, true); }
-gb25_status gb25_halo_unpack(gb25_model* m, int group, int side, const float* buf) {
-  return pack_unpack(m, group, side, const_cast<float*>(buf), false);
+gb25_status gb25_halo_pack(gb25_model* m, int group, int side, void* buf) {
+  return pack_unpack(m, group, side, static_cast<real*>(buf), true);
+}
+gb25_status gb25_halo_unpack(gb25_model* m, int group, int side, const void* buf) {
+  return pack_unpack(m, group, side, static_cast<real*>(const_cast<void*>(buf)), false);
 }
 
 // The time step of one slab, cut at its two exchange points (see include/gb25.h).
@@ -1100,11 +1109,11 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
   const Grid& g = m->g;
   gb25_status s;
   const double dt = m->last_dt;
-  const float chi = euler ? -0.5f : (float)m->cfg.chi;
+  const real chi = euler ? -real(0.5) : (real)m->cfg.chi;
   if (stage == 0) {
     // AB2 update of u,v,T,S + barotropic forcing, then the y/z boundary layers of the 3-D bundle so that its packed
     // x columns (group 0) can travel WHILE the sub-cycle runs; the host also exchanges group 1 now
-    if ((s = ab2_local_impl(m, (float)dt, chi))) return s;
+    if ((s = ab2_local_impl(m, (real)dt, chi))) return s;
     return fill_halos_impl(m, false, false, 1);
   } else if (stage == 1) {
     // group 1 has been unpacked into the wide halos: copy the interiors, sub-cycle, publish
@@ -1115,7 +1124,7 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
       hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, (unsigned)p.rows), dim3(256), 0, m->stream,
                          p.dst, p.dst_sx, p.dst_xo, p.src, p.src_sx, p.src_xo, g.Nx, (int)p.rows);
     LAUNCHCHK();
-    if ((s = barotropic_impl(m, (float)dt))) return s;
+    if ((s = barotropic_impl(m, (real)dt))) return s;
     m->time += dt;
     m->iteration += 1;
     // y layer of the new eta, U, V; their x columns are group 2

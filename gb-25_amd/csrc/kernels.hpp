@@ -36,12 +36,12 @@ __device__ __forceinline__ TileIdx tile_index(const Grid& g, int nbx, int nb) {
 // columns over the whole parent (j,k) extent, filled last so corners are consistent.
 // =============================================================================================
 struct Halo3 {
-  float* p[4];   // up to four 3-D fields ...
+  real* p[4];   // up to four 3-D fields ...
   int is_v[4];   // ... flagged when face-located in y (v-shaped parent, wall-normal velocity)
   int n;
 };
 struct Halo2 {
-  float* p[3];  // centre-y fields first, then the face-y field (is_v[])
+  real* p[3];  // centre-y fields first, then the face-y field (is_v[])
   int is_v[3];
   int n;
 };
@@ -55,10 +55,10 @@ __global__ void k_fill_y(Grid g, Halo3 f3, Halo2 f2, int i0, int ni) {
   int k = blockIdx.y;
   if (k < g.Nz) {
     for (int q = 0; q < f3.n; q++) {
-      float* c = f3.p[q];
+      real* c = f3.p[q];
       if (f3.is_v[q]) {  // v: faces 0 and Ny are walls
-        c[iv(g, i, 0, k)] = 0.f;
-        c[iv(g, i, g.Ny, k)] = 0.f;
+        c[iv(g, i, 0, k)] = real(0.);
+        c[iv(g, i, g.Ny, k)] = real(0.);
       } else {
         c[ic(g, i, -1, k)] = c[ic(g, i, 0, k)];
         c[ic(g, i, g.Ny, k)] = c[ic(g, i, g.Ny - 1, k)];
@@ -66,10 +66,10 @@ __global__ void k_fill_y(Grid g, Halo3 f3, Halo2 f2, int i0, int ni) {
     }
   } else {
     for (int q = 0; q < f2.n; q++) {
-      float* c = f2.p[q];
+      real* c = f2.p[q];
       if (f2.is_v[q]) {
-        c[i2(g, i, 0)] = 0.f;
-        c[i2(g, i, g.Ny)] = 0.f;
+        c[i2(g, i, 0)] = real(0.);
+        c[i2(g, i, g.Ny)] = real(0.);
       } else {
         c[i2(g, i, -1)] = c[i2(g, i, 0)];
         c[i2(g, i, g.Ny)] = c[i2(g, i, g.Ny - 1)];
@@ -84,7 +84,7 @@ __global__ void k_fill_z(Grid g, Halo3 f3, int i0, int ni) {
   i += i0;
   int j = blockIdx.y;
   for (int q = 0; q < f3.n; q++) {
-    float* c = f3.p[q];
+    real* c = f3.p[q];
     if (f3.is_v[q]) {
       c[iv(g, i, j, -1)] = c[iv(g, i, j, 0)];
       c[iv(g, i, j, g.Nz)] = c[iv(g, i, j, g.Nz - 1)];
@@ -95,8 +95,8 @@ __global__ void k_fill_z(Grid g, Halo3 f3, int i0, int ni) {
   }
 }
 // periodic x for one array of `rows` parent rows: thread = (q in 0..2H-1, row)
-__device__ __forceinline__ void periodic_row(const Grid& g, float* c, long row, int q) {
-  float* r = c + row * g.sx;
+__device__ __forceinline__ void periodic_row(const Grid& g, real* c, long row, int q) {
+  real* r = c + row * g.sx;
   if (q < g.H) r[q] = r[g.Nx + q];                  // west halo <- east interior
   else r[g.Nx + q] = r[q];                          // east halo (index H+Nx+(q-H)) <- west interior
 }
@@ -125,20 +125,20 @@ __global__ void k_fill_x(Grid g, Halo3 f3, Halo2 f2, int rows_c, int rows_v) {
 // (GB-25 src/precompile.jl:113-115).  One thread per column on the extended range
 // [-H+1, N+H-2] so that w and p are valid in the halos without any exchange.
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_compute_w(Grid g, const float* __restrict__ u, const float* __restrict__ v,
-                                                   float* __restrict__ w) {
+__global__ __launch_bounds__(256) void k_compute_w(Grid g, const real* __restrict__ u, const real* __restrict__ v,
+                                                   real* __restrict__ w) {
   int i = blockIdx.x * blockDim.x + threadIdx.x - g.H + 1;
   int j = blockIdx.y * blockDim.y + threadIdx.y - g.H + 1;
   if (i > g.Nx + g.H - 2 || j > g.Ny + g.H - 2) return;
-  const float dxs = g.dxf[j], dxn = g.dxf[j + 1], raz = g.razc[j], dy = g.dy;
+  const real dxs = g.dxf[j], dxn = g.dxf[j + 1], raz = g.razc[j], dy = g.dy;
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
-  float wk = 0.f;
-  w[o] = 0.f;
+  real wk = real(0.);
+  w[o] = real(0.);
 #pragma unroll 4
   for (int k = 0; k < g.Nz; k++) {
-    float dz = g.dzc[k];
-    float Ax = dy * dz;
-    float div = (Ax * u[o + 1] - Ax * u[o]) + (dxn * dz * v[ov + g.sx] - dxs * dz * v[ov]);
+    real dz = g.dzc[k];
+    real Ax = dy * dz;
+    real div = (Ax * u[o + 1] - Ax * u[o]) + (dxn * dz * v[ov + g.sx] - dxs * dz * v[ov]);
     wk = wk - div * raz;
     o += g.pl_c;
     ov += g.pl_v;
@@ -157,9 +157,9 @@ __global__ __launch_bounds__(256) void k_compute_w(Grid g, const float* __restri
 // chains 5-way instruction-level parallelism.  fp64 VALU is half rate on gfx950; the depth dependence of the
 // 55-term polynomial is folded per level on the host (28 fp64 FMAs per evaluation).
 constexpr int PR = 4;   // rows per thread
-__global__ __launch_bounds__(256) void k_compute_p(Grid g, const float* __restrict__ T, const float* __restrict__ S,
-                                                   float* __restrict__ p, float* __restrict__ dpx,
-                                                   float* __restrict__ dpy) {
+__global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restrict__ T, const real* __restrict__ S,
+                                                   real* __restrict__ p, real* __restrict__ dpx,
+                                                   real* __restrict__ dpy) {
   const int lane = threadIdx.x;
   const int i = -g.H + blockIdx.x * 63 + lane;                               // lane 0: helper column
   const int jb = -g.H + 1 + (blockIdx.y * blockDim.y + threadIdx.y) * PR;    // first of this thread's PR rows
@@ -194,16 +194,16 @@ __global__ __launch_bounds__(256) void k_compute_p(Grid g, const float* __restri
       const double pw = __shfl_up(pk[r], 1);
       const int j = jb - 1 + r;
       if (lane >= 1 && i <= imax && j <= jmax) {
-        p[o[r]] = (float)pk[r];
-        dpx[o[r]] = (float)(pk[r] - pw);
-        dpy[o[r]] = (float)(pk[r] - pk[r - 1]);
+        p[o[r]] = (real)pk[r];
+        dpx[o[r]] = (real)(pk[r] - pw);
+        dpy[o[r]] = (real)(pk[r] - pk[r - 1]);
       }
     }
   }
 }
 // the same two differences from an fp32 pHY' uploaded by the host (set_field): keeps the arrays consistent
-__global__ void k_pressure_differences(Grid g, const float* __restrict__ p, float* __restrict__ dpx,
-                                       float* __restrict__ dpy, long n) {
+__global__ void k_pressure_differences(Grid g, const real* __restrict__ p, real* __restrict__ dpx,
+                                       real* __restrict__ dpy, long n) {
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < g.sx || t >= n) return;
   dpx[t] = p[t] - p[t - 1];
@@ -214,40 +214,40 @@ __global__ void k_pressure_differences(Grid g, const float* __restrict__ p, floa
 // Tracer tendencies: G_c = -div(U c), WENO(order=5) upwind-biased flux form
 // (compute_hydrostatic_free_surface_Gc!, GB-25 src/precompile.jl:75-111).  T and S in one pass.
 // =============================================================================================
-__device__ __forceinline__ float tracer_div(const Grid& g, const float* __restrict__ c, int o, float Ax, float uw,
-                                            float ue, float Ays, float Ayn, float vs, float vn, float Az, float wb,
-                                            float wt, int oys, int oyn, int ozb, int ozt) {
-  float q[7];
+__device__ __forceinline__ real tracer_div(const Grid& g, const real* __restrict__ c, int o, real Ax, real uw,
+                                            real ue, real Ays, real Ayn, real vs, real vn, real Az, real wb,
+                                            real wt, int oys, int oyn, int ozb, int ozt) {
+  real q[7];
 #pragma unroll
   for (int m = 0; m < 7; m++) q[m] = c[o + m - 3];
-  float fw = Ax * uw * biased6<false>(5, uw > 0.f, q, q, q);
-  float fe = Ax * ue * biased6<false>(5, ue > 0.f, q + 1, q + 1, q + 1);
+  real fw = Ax * uw * biased6<false>(5, uw > real(0.), q, q, q);
+  real fe = Ax * ue * biased6<false>(5, ue > real(0.), q + 1, q + 1, q + 1);
 #pragma unroll
   for (int m = 0; m < 7; m++) q[m] = c[o + (m - 3) * g.sx];
-  float fs = Ays * vs * biased6<false>(oys, vs > 0.f, q, q, q);
-  float fn = Ayn * vn * biased6<false>(oyn, vn > 0.f, q + 1, q + 1, q + 1);
+  real fs = Ays * vs * biased6<false>(oys, vs > real(0.), q, q, q);
+  real fn = Ayn * vn * biased6<false>(oyn, vn > real(0.), q + 1, q + 1, q + 1);
 #pragma unroll
   for (int m = 0; m < 7; m++) q[m] = c[o + (m - 3) * g.pl_c];
-  float fb = Az * wb * biased6<false>(ozb, wb > 0.f, q, q, q);
-  float ft = Az * wt * biased6<false>(ozt, wt > 0.f, q + 1, q + 1, q + 1);
+  real fb = Az * wb * biased6<false>(ozb, wb > real(0.), q, q, q);
+  real ft = Az * wt * biased6<false>(ozt, wt > real(0.), q + 1, q + 1, q + 1);
   return (fe - fw) + (fn - fs) + (ft - fb);
 }
 
-__global__ __launch_bounds__(256) void k_tracer_tendencies(Grid g, const float* __restrict__ u,
-                                                           const float* __restrict__ v, const float* __restrict__ w,
-                                                           const float* __restrict__ T, const float* __restrict__ S,
-                                                           float* __restrict__ GT, float* __restrict__ GS, int nbx,
+__global__ __launch_bounds__(256) void k_tracer_tendencies(Grid g, const real* __restrict__ u,
+                                                           const real* __restrict__ v, const real* __restrict__ w,
+                                                           const real* __restrict__ T, const real* __restrict__ S,
+                                                           real* __restrict__ GT, real* __restrict__ GS, int nbx,
                                                            int nb) {
   TileIdx t = tile_index(g, nbx, nb);
   if (!t.ok) return;
   const int i = t.i, j = t.j, k = t.k;
   const int o = ic(g, i, j, k), ov = iv(g, i, j, k);
-  const float dz = g.dzc[k];
-  const float Ax = g.dy * dz, Ays = g.dxf[j] * dz, Ayn = g.dxf[j + 1] * dz, Az = g.azc[j];
-  const float uw = u[o], ue = u[o + 1], vs = v[ov], vn = v[ov + g.sx], wb = w[o], wt = w[o + g.pl_c];
+  const real dz = g.dzc[k];
+  const real Ax = g.dy * dz, Ays = g.dxf[j] * dz, Ayn = g.dxf[j + 1] * dz, Az = g.azc[j];
+  const real uw = u[o], ue = u[o + 1], vs = v[ov], vn = v[ov + g.sx], wb = w[o], wt = w[o + g.pl_c];
   const int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny);
   const int ozb = biased_order_face(k, g.Nz), ozt = biased_order_face(k + 1, g.Nz);
-  const float rV = g.razc[j] * g.rdzc[k];
+  const real rV = g.razc[j] * g.rdzc[k];
   GT[o] = -(tracer_div(g, T, o, Ax, uw, ue, Ays, Ayn, vs, vn, Az, wb, wt, oys, oyn, ozb, ozt) * rV);
   GS[o] = -(tracer_div(g, S, o, Ax, uw, ue, Ays, Ayn, vs, vn, Az, wb, wt, oys, oyn, ozb, ozt) * rV);
 }
@@ -259,122 +259,122 @@ __global__ __launch_bounds__(256) void k_tracer_tendencies(Grid g, const float* 
 // centred 4th order), WENO5 vertical advection, enstrophy-conserving spherical Coriolis,
 // hydrostatic pressure gradient.  The barotropic pressure gradient lives in the sub-cycle.
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_gu(Grid g, const float* __restrict__ u, const float* __restrict__ v,
-                                            const float* __restrict__ w, const float* __restrict__ dpx,
-                                            float* __restrict__ Gu, int nbx, int nb) {
+__global__ __launch_bounds__(256) void k_gu(Grid g, const real* __restrict__ u, const real* __restrict__ v,
+                                            const real* __restrict__ w, const real* __restrict__ dpx,
+                                            real* __restrict__ Gu, int nbx, int nb) {
   TileIdx t = tile_index(g, nbx, nb);
   if (!t.ok) return;
   const int i = t.i, j = t.j, k = t.k;
   const int o = ic(g, i, j, k), ov = iv(g, i, j, k);
   const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
-  const float dy = g.dy, dz = g.dzc[k];
-  const float dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j];
+  const real dy = g.dy, dz = g.dzc[k];
+  const real dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j];
 
   // advecting v at (f,c,c)
-  const float vhat =
-      (0.5f * (dxf_s * v[ov - 1] + dxf_n * v[ov - 1 + sx]) + 0.5f * (dxf_s * v[ov] + dxf_n * v[ov + sx])) * 0.5f * rdxc_j;
+  const real vhat =
+      (real(0.5) * (dxf_s * v[ov - 1] + dxf_n * v[ov - 1 + sx]) + real(0.5) * (dxf_s * v[ov] + dxf_n * v[ov + sx])) * real(0.5) * rdxc_j;
 
   // vorticity at faces j-2 .. j+3 of column i, plus the VelocityStencil smoothness inputs
-  float zq[6], uq[6], vq[6];
+  real zq[6], uq[6], vq[6];
 #pragma unroll
   for (int m = 0; m < 6; m++) {
     int jf = j - 2 + m;
-    float vc = v[ov + (m - 2) * sx], vw = v[ov - 1 + (m - 2) * sx];
-    float uc = u[o + (m - 2) * sx], us = u[o + (m - 3) * sx];
+    real vc = v[ov + (m - 2) * sx], vw = v[ov - 1 + (m - 2) * sx];
+    real uc = u[o + (m - 2) * sx], us = u[o + (m - 3) * sx];
     zq[m] = ((dy * vc - dy * vw) - (g.dxc[jf] * uc - g.dxc[jf - 1] * us)) * g.razf[jf];
-    uq[m] = 0.5f * (us + uc);
-    vq[m] = 0.5f * (vw + vc);
+    uq[m] = real(0.5) * (us + uc);
+    vq[m] = real(0.5) * (vw + vc);
   }
-  const float zetaR = biased6<true>(biased_order_center(j, g.Ny), vhat > 0.f, zq, uq, vq);
-  const float hadv = -vhat * zetaR;
+  const real zetaR = biased6<true>(biased_order_center(j, g.Ny), vhat > real(0.), zq, uq, vq);
+  const real hadv = -vhat * zetaR;
 
   // self-upwinded divergence flux
-  const float uhat = u[o];
-  float u7[7];
+  const real uhat = u[o];
+  real u7[7];
 #pragma unroll
   for (int m = 0; m < 7; m++) u7[m] = u[o + m - 3];
-  const float Ax = dy * dz, Ays = dxf_s * dz, Ayn = dxf_n * dz;
-  float Du[6], Dv[6], Dd[6];
+  const real Ax = dy * dz, Ays = dxf_s * dz, Ayn = dxf_n * dz;
+  real Du[6], Dv[6], Dd[6];
 #pragma unroll
   for (int m = 0; m < 6; m++) {
     Du[m] = Ax * u7[m + 1] - Ax * u7[m];
     Dv[m] = Ayn * v[ov + (m - 3) + sx] - Ays * v[ov + (m - 3)];
     Dd[m] = Du[m] + Dv[m];
   }
-  const float dvs = sym_interp(true, Dv[1], Dv[2], Dv[3], Dv[4]);
-  const float duR = biased6<false>(5, uhat > 0.f, Du, Dd, Dd);
-  const float phi = uhat * (dvs + duR);
+  const real dvs = sym_interp(true, Dv[1], Dv[2], Dv[3], Dv[4]);
+  const real duR = biased6<false>(5, uhat > real(0.), Du, Dd, Dd);
+  const real phi = uhat * (dvs + duR);
 
   // vertical advection of u
-  const float Az = g.azc[j];
-  float fz[2];
+  const real Az = g.azc[j];
+  real fz[2];
 #pragma unroll
   for (int tt = 0; tt < 2; tt++) {
     int ow = o + tt * pc;
-    float wt = sym_interp(true, Az * w[ow - 2], Az * w[ow - 1], Az * w[ow], Az * w[ow + 1]);
-    float q[6];
+    real wt = sym_interp(true, Az * w[ow - 2], Az * w[ow - 1], Az * w[ow], Az * w[ow + 1]);
+    real q[6];
 #pragma unroll
     for (int m = 0; m < 6; m++) q[m] = u[o + (tt + m - 3) * pc];
-    fz[tt] = wt * biased6<false>(biased_order_face(k + tt, g.Nz), wt > 0.f, q, q, q);
+    fz[tt] = wt * biased6<false>(biased_order_face(k + tt, g.Nz), wt > real(0.), q, q, q);
   }
-  const float vadv = (phi + (fz[1] - fz[0])) * (g.razc[j] * g.rdzc[k]);
+  const real vadv = (phi + (fz[1] - fz[0])) * (g.razc[j] * g.rdzc[k]);
 
   // Bernoulli head
-  float Ku[6], su[6];
+  real Ku[6], su[6];
 #pragma unroll
   for (int m = 0; m < 6; m++) {
-    Ku[m] = 0.5f * u7[m + 1] * u7[m + 1] - 0.5f * u7[m] * u7[m];
-    su[m] = 0.5f * (u7[m] + u7[m + 1]);
+    Ku[m] = real(0.5) * u7[m + 1] * u7[m + 1] - real(0.5) * u7[m] * u7[m];
+    su[m] = real(0.5) * (u7[m] + u7[m + 1]);
   }
-  const float dKu = biased6<false>(5, uhat > 0.f, Ku, su, su);
-  float a4[4];
+  const real dKu = biased6<false>(5, uhat > real(0.), Ku, su, su);
+  real a4[4];
 #pragma unroll
   for (int m = 0; m < 4; m++) {
-    float vc = v[ov + (m - 1) * sx], vw = v[ov - 1 + (m - 1) * sx];
-    a4[m] = 0.5f * vc * vc - 0.5f * vw * vw;
+    real vc = v[ov + (m - 1) * sx], vw = v[ov - 1 + (m - 1) * sx];
+    a4[m] = real(0.5) * vc * vc - real(0.5) * vw * vw;
   }
-  const float dKv = sym_interp(sym4_center(j, g.Ny), a4[0], a4[1], a4[2], a4[3]);
-  const float bern = (dKu + dKv) * rdxc_j;
+  const real dKv = sym_interp(sym4_center(j, g.Ny), a4[0], a4[1], a4[2], a4[3]);
+  const real bern = (dKu + dKv) * rdxc_j;
 
-  const float cor = -0.5f * (g.fcor[j] + g.fcor[j + 1]) * vhat;
-  const float dpdx = dpx[o] * rdxc_j;
+  const real cor = -real(0.5) * (g.fcor[j] + g.fcor[j + 1]) * vhat;
+  const real dpdx = dpx[o] * rdxc_j;
   Gu[o] = -(hadv + vadv + bern) - cor - dpdx;
 }
 
-__global__ __launch_bounds__(256) void k_gv(Grid g, const float* __restrict__ u, const float* __restrict__ v,
-                                            const float* __restrict__ w, const float* __restrict__ dpy,
-                                            float* __restrict__ Gv, int nbx, int nb) {
+__global__ __launch_bounds__(256) void k_gv(Grid g, const real* __restrict__ u, const real* __restrict__ v,
+                                            const real* __restrict__ w, const real* __restrict__ dpy,
+                                            real* __restrict__ Gv, int nbx, int nb) {
   TileIdx t = tile_index(g, nbx, nb);
   if (!t.ok) return;
   const int i = t.i, j = t.j, k = t.k;
   const int o = ic(g, i, j, k), ov = iv(g, i, j, k);
   const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
-  const float dy = g.dy, dz = g.dzc[k];
+  const real dy = g.dy, dz = g.dzc[k];
 
   // advecting u at (c,f,c)
-  const float uhat = (0.5f * (dy * u[o - sx] + dy * u[o - sx + 1]) + 0.5f * (dy * u[o] + dy * u[o + 1])) * 0.5f * g.rdy;
+  const real uhat = (real(0.5) * (dy * u[o - sx] + dy * u[o - sx + 1]) + real(0.5) * (dy * u[o] + dy * u[o + 1])) * real(0.5) * g.rdy;
 
   // vorticity at faces i-2 .. i+3 of row j
-  const float dxc_j = g.dxc[j], dxc_s = g.dxc[j - 1], razf = g.razf[j];
-  float zq[6], uq[6], vq[6];
+  const real dxc_j = g.dxc[j], dxc_s = g.dxc[j - 1], razf = g.razf[j];
+  real zq[6], uq[6], vq[6];
 #pragma unroll
   for (int m = 0; m < 6; m++) {
-    float vc = v[ov + (m - 2)], vw = v[ov + (m - 3)];
-    float uc = u[o + (m - 2)], us = u[o + (m - 2) - sx];
+    real vc = v[ov + (m - 2)], vw = v[ov + (m - 3)];
+    real uc = u[o + (m - 2)], us = u[o + (m - 2) - sx];
     zq[m] = ((dy * vc - dy * vw) - (dxc_j * uc - dxc_s * us)) * razf;
-    uq[m] = 0.5f * (us + uc);
-    vq[m] = 0.5f * (vw + vc);
+    uq[m] = real(0.5) * (us + uc);
+    vq[m] = real(0.5) * (vw + vc);
   }
-  const float zetaR = biased6<true>(5, uhat > 0.f, zq, uq, vq);
-  const float hadv = uhat * zetaR;
+  const real zetaR = biased6<true>(5, uhat > real(0.), zq, uq, vq);
+  const real hadv = uhat * zetaR;
 
   // self-upwinded divergence flux
-  const float vhat = v[ov];
-  float v7[7];
+  const real vhat = v[ov];
+  real v7[7];
 #pragma unroll
   for (int m = 0; m < 7; m++) v7[m] = v[ov + (m - 3) * sx];
-  const float Ax = dy * dz;
-  float Du[6], Dv[6], Dd[6];
+  const real Ax = dy * dz;
+  real Du[6], Dv[6], Dd[6];
 #pragma unroll
   for (int m = 0; m < 6; m++) {
     int jc = j - 3 + m;
@@ -384,43 +384,43 @@ __global__ __launch_bounds__(256) void k_gv(Grid g, const float* __restrict__ u,
   }
   const int of = biased_order_face(j, g.Ny);
   const bool s4 = sym4_face(j, g.Ny);
-  const float dus = sym_interp(s4, Du[1], Du[2], Du[3], Du[4]);
-  const float dvR = biased6<false>(of, vhat > 0.f, Dv, Dd, Dd);
-  const float phi = vhat * (dus + dvR);
+  const real dus = sym_interp(s4, Du[1], Du[2], Du[3], Du[4]);
+  const real dvR = biased6<false>(of, vhat > real(0.), Dv, Dd, Dd);
+  const real phi = vhat * (dus + dvR);
 
   // vertical advection of v
-  float fz[2];
+  real fz[2];
 #pragma unroll
   for (int tt = 0; tt < 2; tt++) {
     int ow = o + tt * pc;
-    float wt = sym_interp(s4, g.azc[j - 2] * w[ow - 2 * sx], g.azc[j - 1] * w[ow - sx], g.azc[j] * w[ow],
+    real wt = sym_interp(s4, g.azc[j - 2] * w[ow - 2 * sx], g.azc[j - 1] * w[ow - sx], g.azc[j] * w[ow],
                           g.azc[j + 1] * w[ow + sx]);
-    float q[6];
+    real q[6];
 #pragma unroll
     for (int m = 0; m < 6; m++) q[m] = v[ov + (tt + m - 3) * pv];
-    fz[tt] = wt * biased6<false>(biased_order_face(k + tt, g.Nz), wt > 0.f, q, q, q);
+    fz[tt] = wt * biased6<false>(biased_order_face(k + tt, g.Nz), wt > real(0.), q, q, q);
   }
-  const float vadv = (phi + (fz[1] - fz[0])) * (razf * g.rdzc[k]);
+  const real vadv = (phi + (fz[1] - fz[0])) * (razf * g.rdzc[k]);
 
   // Bernoulli head
-  float Kv[6], sv[6];
+  real Kv[6], sv[6];
 #pragma unroll
   for (int m = 0; m < 6; m++) {
-    Kv[m] = 0.5f * v7[m + 1] * v7[m + 1] - 0.5f * v7[m] * v7[m];
-    sv[m] = 0.5f * (v7[m] + v7[m + 1]);
+    Kv[m] = real(0.5) * v7[m + 1] * v7[m + 1] - real(0.5) * v7[m] * v7[m];
+    sv[m] = real(0.5) * (v7[m] + v7[m + 1]);
   }
-  const float dKv = biased6<false>(of, vhat > 0.f, Kv, sv, sv);
-  float a4[4];
+  const real dKv = biased6<false>(of, vhat > real(0.), Kv, sv, sv);
+  real a4[4];
 #pragma unroll
   for (int m = 0; m < 4; m++) {
-    float un = u[o + (m - 1)], us = u[o + (m - 1) - sx];
-    a4[m] = 0.5f * un * un - 0.5f * us * us;
+    real un = u[o + (m - 1)], us = u[o + (m - 1) - sx];
+    a4[m] = real(0.5) * un * un - real(0.5) * us * us;
   }
-  const float dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
-  const float bern = (dKv + dKu) * g.rdy;
+  const real dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
+  const real bern = (dKv + dKu) * g.rdy;
 
-  const float cor = g.fcor[j] * uhat;
-  const float dpdy = dpy[o] * g.rdy;
+  const real cor = g.fcor[j] * uhat;
+  const real dpdy = dpy[o] * g.rdy;
   Gv[ov] = -(hadv + vadv + bern) - cor - dpdy;
 }
 
@@ -428,25 +428,25 @@ __global__ __launch_bounds__(256) void k_gv(Grid g, const float* __restrict__ u,
 // ab2_step!: velocities + vertically integrated AB2 tendencies (barotropic forcing), one thread
 // per column (fuses ab2_step_field! x2 with _compute_integrated_ab2_tendencies!).
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, float* __restrict__ u, float* __restrict__ v,
-                                                        const float* __restrict__ Gnu, const float* __restrict__ Gmu,
-                                                        const float* __restrict__ Gnv, const float* __restrict__ Gmv,
-                                                        float* __restrict__ GU, float* __restrict__ GV,
-                                                        float* __restrict__ Usum, float* __restrict__ Vsum, float dt,
-                                                        float chi) {
+__global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, real* __restrict__ u, real* __restrict__ v,
+                                                        const real* __restrict__ Gnu, const real* __restrict__ Gmu,
+                                                        const real* __restrict__ Gnv, const real* __restrict__ Gmv,
+                                                        real* __restrict__ GU, real* __restrict__ GV,
+                                                        real* __restrict__ Usum, real* __restrict__ Vsum, real dt,
+                                                        real chi) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= g.Nx || j >= g.Ny) return;
-  const float C1 = 1.5f + chi, C2 = 0.5f + chi;
-  const float ne = (chi != -0.5f) ? 1.f : 0.f;
+  const real C1 = real(1.5) + chi, C2 = real(0.5) + chi;
+  const real ne = (chi != -real(0.5)) ? real(1.) : real(0.);
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
-  float su = 0.f, sv = 0.f, iu = 0.f, iv_ = 0.f;
+  real su = real(0.), sv = real(0.), iu = real(0.), iv_ = real(0.);
 #pragma unroll 4
   for (int k = 0; k < g.Nz; k++) {
-    float dz = g.dzc[k];
-    float gu = C1 * Gnu[o] - C2 * Gmu[o] * ne;
-    float gv = C1 * Gnv[ov] - C2 * Gmv[ov] * ne;
-    float un = u[o] + dt * gu, vn = v[ov] + dt * gv;
+    real dz = g.dzc[k];
+    real gu = C1 * Gnu[o] - C2 * Gmu[o] * ne;
+    real gv = C1 * Gnv[ov] - C2 * Gmv[ov] * ne;
+    real un = u[o] + dt * gu, vn = v[ov] + dt * gv;
     u[o] = un;
     v[ov] = vn;
     su = (k == 0) ? dz * gu : su + dz * gu;
@@ -460,27 +460,27 @@ __global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, float* __restric
   }
   const int o2 = i2(g, i, j);
   GU[o2] = su;
-  GV[o2] = (j == 0) ? 0.f : sv;  // the wall face is a peripheral node
+  GV[o2] = (j == 0) ? real(0.) : sv;  // the wall face is a peripheral node
   Usum[o2] = iu;
-  Vsum[o2] = (j == 0) ? 0.f : iv_;  // v on the wall face is reset to zero by the halo fill before the corrector
+  Vsum[o2] = (j == 0) ? real(0.) : iv_;  // v on the wall face is reset to zero by the halo fill before the corrector
 }
 
 // tracers: flat AXPY over the interior planes of a parent array (G halos are identically zero)
-using f32x4 = __attribute__((ext_vector_type(4))) float;
+using realx4 = __attribute__((ext_vector_type(4))) real;
 template <bool NT>
-__global__ void k_ab2_tracers4(float4* __restrict__ T_, float4* __restrict__ S_, const float4* __restrict__ GnT_,
-                               const float4* __restrict__ GmT_, const float4* __restrict__ GnS_,
-                               const float4* __restrict__ GmS_, long n4, float dt, float C1, float C2) {
-  f32x4* T = reinterpret_cast<f32x4*>(T_);
-  f32x4* S = reinterpret_cast<f32x4*>(S_);
-  const f32x4 *GnT = reinterpret_cast<const f32x4*>(GnT_), *GmT = reinterpret_cast<const f32x4*>(GmT_);
-  const f32x4 *GnS = reinterpret_cast<const f32x4*>(GnS_), *GmS = reinterpret_cast<const f32x4*>(GmS_);
+__global__ void k_ab2_tracers4(real4* __restrict__ T_, real4* __restrict__ S_, const real4* __restrict__ GnT_,
+                               const real4* __restrict__ GmT_, const real4* __restrict__ GnS_,
+                               const real4* __restrict__ GmS_, long n4, real dt, real C1, real C2) {
+  realx4* T = reinterpret_cast<realx4*>(T_);
+  realx4* S = reinterpret_cast<realx4*>(S_);
+  const realx4 *GnT = reinterpret_cast<const realx4*>(GnT_), *GmT = reinterpret_cast<const realx4*>(GmT_);
+  const realx4 *GnS = reinterpret_cast<const realx4*>(GnS_), *GmS = reinterpret_cast<const realx4*>(GmS_);
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long stride = (long)gridDim.x * blockDim.x;
   // pure stream: every byte is touched once per step, so the tendency reads bypass the caches (nontemporal)
   for (; t < n4; t += stride) {
-    f32x4 a = T[t], b = S[t];
-    f32x4 gn, gm, hn, hm;
+    realx4 a = T[t], b = S[t];
+    realx4 gn, gm, hn, hm;
     if (NT) {
       gn = __builtin_nontemporal_load(&GnT[t]);
       gm = __builtin_nontemporal_load(&GmT[t]);
@@ -498,9 +498,9 @@ __global__ void k_ab2_tracers4(float4* __restrict__ T_, float4* __restrict__ S_,
     S[t] = b;
   }
 }
-__global__ void k_ab2_tracers1(float* __restrict__ T, float* __restrict__ S, const float* __restrict__ GnT,
-                               const float* __restrict__ GmT, const float* __restrict__ GnS,
-                               const float* __restrict__ GmS, long n, float dt, float C1, float C2) {
+__global__ void k_ab2_tracers1(real* __restrict__ T, real* __restrict__ S, const real* __restrict__ GnT,
+                               const real* __restrict__ GmT, const real* __restrict__ GnS,
+                               const real* __restrict__ GmS, long n, real dt, real C1, real C2) {
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long stride = (long)gridDim.x * blockDim.x;
   for (; t < n; t += stride) {
@@ -518,37 +518,37 @@ __global__ void k_ab2_tracers1(float* __restrict__ T, float* __restrict__ S, con
 // the sub-cycle.
 // =============================================================================================
 struct Baro {
-  const float *eta0, *U0, *V0;  // state at substep m
-  float *eta1, *U1, *V1;        // state at substep m+1
-  float *etab, *Ub, *Vb;        // running time averages
-  const float *GU, *GV;
+  const real *eta0, *U0, *V0;  // state at substep m
+  real *eta1, *U1, *V1;        // state at substep m+1
+  real *etab, *Ub, *Vb;        // running time averages
+  const real *GU, *GV;
   // geometry of these 2-D arrays: row pitch, array column of i = 0, computed range [ilo, ihi), and
   // whether i-1 / i+1 wrap around the periodic domain (single slab) or simply reach into the wide halo
   int sx, xo, ilo, ihi, wrap;
 };
 __device__ __forceinline__ int bi(const Grid& g, const Baro& b, int i, int j) { return (i + b.xo) + b.sx * (j + g.H); }
-__device__ __forceinline__ float eta_step(const Grid& g, const Baro& b, int i, int j, float dtau) {
+__device__ __forceinline__ real eta_step(const Grid& g, const Baro& b, int i, int j, real dtau) {
   int ip = (b.wrap && i == g.Nx - 1) ? 0 : i + 1;
-  float dxU = g.dy * b.U0[bi(g, b, ip, j)] - g.dy * b.U0[bi(g, b, i, j)];
-  float dyV;
+  real dxU = g.dy * b.U0[bi(g, b, ip, j)] - g.dy * b.U0[bi(g, b, i, j)];
+  real dyV;
   if (j == g.Ny - 1) dyV = -(g.dxf[j] * b.V0[bi(g, b, i, j)]);
   else if (j == 0) dyV = g.dxf[1] * b.V0[bi(g, b, i, 1)];
   else dyV = g.dxf[j + 1] * b.V0[bi(g, b, i, j + 1)] - g.dxf[j] * b.V0[bi(g, b, i, j)];
   return b.eta0[bi(g, b, i, j)] - dtau * (dxU + dyV) / g.azc[j];
 }
-__global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, float dtau, float wgt) {
+__global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, real dtau, real wgt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x + b.ilo;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= b.ihi || j >= g.Ny) return;
   int im = (b.wrap && i == 0) ? g.Nx - 1 : i - 1;
-  float e = eta_step(g, b, i, j, dtau);
-  float ew = eta_step(g, b, im, j, dtau);
-  float dxe = (e - ew) / g.dxc[j];
-  float dye = 0.f;
+  real e = eta_step(g, b, i, j, dtau);
+  real ew = eta_step(g, b, im, j, dtau);
+  real dxe = (e - ew) / g.dxc[j];
+  real dye = real(0.);
   if (j > 0) dye = (e - eta_step(g, b, i, j - 1, dtau)) / g.dy;
   int o = bi(g, b, i, j);
-  float Un = b.U0[o] + dtau * (-g.g * g.Lz * dxe + b.GU[o]);
-  float Vn = b.V0[o] + dtau * (-g.g * g.Lz * dye + b.GV[o]);
+  real Un = b.U0[o] + dtau * (-g.g * g.Lz * dxe + b.GU[o]);
+  real Vn = b.V0[o] + dtau * (-g.g * g.Lz * dye + b.GV[o]);
   b.eta1[o] = e;
   b.U1[o] = Un;
   b.V1[o] = Vn;
@@ -566,15 +566,15 @@ __global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, floa
 constexpr int BT_TX = 64, BT_NT = 256, BT_SMAX = 8;
 struct BaroMulti {
   Baro b;
-  float w[BT_SMAX];
+  real w[BT_SMAX];
   int ns;  // substeps in this launch (1..BT_S)
 };
 template <int BT_S, int BT_TY>
-__global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm, float dtau) {
+__global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm, real dtau) {
   constexpr int BT_RX = BT_TX + 2 * BT_S, BT_RY = BT_TY + 2 * BT_S, BT_NP = BT_RX * BT_RY;
   constexpr int BT_PPT = (BT_NP + BT_NT - 1) / BT_NT;
-  __shared__ float E[BT_RY][BT_RX], U[BT_RY][BT_RX], V[BT_RY][BT_RX], GUs[BT_RY][BT_RX], GVs[BT_RY][BT_RX];
-  __shared__ float Mdxf[BT_RY + 1], Mrazc[BT_RY], Mrdxc[BT_RY];   // row metrics: no global loads inside the sub-cycle
+  __shared__ real E[BT_RY][BT_RX], U[BT_RY][BT_RX], V[BT_RY][BT_RX], GUs[BT_RY][BT_RX], GVs[BT_RY][BT_RX];
+  __shared__ real Mdxf[BT_RY + 1], Mrazc[BT_RY], Mrdxc[BT_RY];   // row metrics: no global loads inside the sub-cycle
   const Baro& b = bm.b;
   const int tid = threadIdx.x;
   const int i0 = b.ilo + blockIdx.x * BT_TX, j0 = blockIdx.y * BT_TY;
@@ -586,11 +586,11 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
       Mrdxc[tid] = g.rdxc[jg];
     }
   }
-  const float gH = g.g * g.Lz, rdy = g.rdy, dyc = g.dy;
+  const real gH = g.g * g.Lz, rdy = g.rdy, dyc = g.dy;
   const int lo = -b.xo, hi = b.sx - b.xo - 1;   // valid array columns (slab mode: clamp; garbage stays in the rim)
   int pl[BT_PPT], pj[BT_PPT], po[BT_PPT];       // LDS index, global row, global element offset (-1: no such point)
   bool own[BT_PPT];
-  float ae[BT_PPT], au[BT_PPT], av[BT_PPT];
+  real ae[BT_PPT], au[BT_PPT], av[BT_PPT];
 #pragma unroll
   for (int q = 0; q < BT_PPT; q++) {
     const int p = tid + q * BT_NT;
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
     }
     po[q] = exists ? bi(g, b, ii, jg) : -1;
     own[q] = exists && lx >= BT_S && lx < BT_S + BT_TX && ly >= BT_S && ly < BT_S + BT_TY && ig < b.ihi;
-    float e = 0.f, u = 0.f, v = 0.f, gu = 0.f, gv = 0.f;
+    real e = real(0.), u = real(0.), v = real(0.), gu = real(0.), gv = real(0.);
     if (exists) {
       e = b.eta0[po[q]];
       u = b.U0[po[q]];
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
       (&GUs[0][0])[p] = gu;
       (&GVs[0][0])[p] = gv;
     }
-    ae[q] = au[q] = av[q] = 0.f;
+    ae[q] = au[q] = av[q] = real(0.);
     if (own[q]) {
       ae[q] = b.etab[po[q]];
       au[q] = b.Ub[po[q]];
@@ -632,19 +632,19 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
   }
   __syncthreads();
   for (int s = 0; s < bm.ns; s++) {
-    const float wgt = bm.w[s];
+    const real wgt = bm.w[s];
     // ---- eta with the old transports (needs U(i+1), V(j+1))
 #pragma unroll
     for (int q = 0; q < BT_PPT; q++) {
       const int p = pl[q], jg = pj[q];
       const int ly = p / BT_RX, lx = p - ly * BT_RX;
       if (po[q] >= 0 && lx < BT_RX - 1 && (ly < BT_RY - 1 || jg == g.Ny - 1)) {
-        float dxU = dyc * U[ly][lx + 1] - dyc * U[ly][lx];
-        float dyV;
+        real dxU = dyc * U[ly][lx + 1] - dyc * U[ly][lx];
+        real dyV;
         if (jg == g.Ny - 1) dyV = -(Mdxf[ly] * V[ly][lx]);
         else if (jg == 0) dyV = Mdxf[ly + 1] * V[ly + 1][lx];
         else dyV = Mdxf[ly + 1] * V[ly + 1][lx] - Mdxf[ly] * V[ly][lx];
-        float e = E[ly][lx] - dtau * (dxU + dyV) * Mrazc[ly];
+        real e = E[ly][lx] - dtau * (dxU + dyV) * Mrazc[ly];
         E[ly][lx] = e;
         if (own[q]) ae[q] += wgt * e;
       }
@@ -656,12 +656,12 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
       const int p = pl[q], jg = pj[q];
       const int ly = p / BT_RX, lx = p - ly * BT_RX;
       if (po[q] >= 0 && lx >= 1 && (ly >= 1 || jg == 0)) {
-        float e = E[ly][lx];
-        float dxe = (e - E[ly][lx - 1]) * Mrdxc[ly];
-        float dye = 0.f;
+        real e = E[ly][lx];
+        real dxe = (e - E[ly][lx - 1]) * Mrdxc[ly];
+        real dye = real(0.);
         if (jg > 0) dye = (e - E[ly - 1][lx]) * rdy;
-        float Un = U[ly][lx] + dtau * (GUs[ly][lx] - gH * dxe);
-        float Vn = V[ly][lx] + dtau * (GVs[ly][lx] - gH * dye);
+        real Un = U[ly][lx] + dtau * (GUs[ly][lx] - gH * dxe);
+        real Vn = V[ly][lx] + dtau * (GVs[ly][lx] - gH * dye);
         U[ly][lx] = Un;
         V[ly][lx] = Vn;
         if (own[q]) {
@@ -686,8 +686,8 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
 }
 
 // eta, U, V <- time averages on the interior (source arrays may be the wide work arrays)
-__global__ void k_barotropic_finalize(Grid g, float* eta, float* U, float* V, const float* etab, const float* Ub,
-                                      const float* Vb, int src_sx, int src_xo) {
+__global__ void k_barotropic_finalize(Grid g, real* eta, real* U, real* V, const real* etab, const real* Ub,
+                                      const real* Vb, int src_sx, int src_xo) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= g.Nx || j >= g.Ny) return;
@@ -697,7 +697,7 @@ __global__ void k_barotropic_finalize(Grid g, float* eta, float* U, float* V, co
   V[o] = Vb[q];
 }
 // copy columns [0, Nx) of whole rows between two 2-D arrays with different pitch / x-offset
-__global__ void k_copy_interior_columns(float* __restrict__ dst, int dsx, int dxo, const float* __restrict__ src,
+__global__ void k_copy_interior_columns(real* __restrict__ dst, int dsx, int dxo, const real* __restrict__ src,
                                         int ssx, int sxo, int Nx, int rows) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int r = blockIdx.y;
@@ -708,14 +708,14 @@ __global__ void k_copy_interior_columns(float* __restrict__ dst, int dsx, int dx
 // =============================================================================================
 // Barotropic mode and corrector (correct_velocities_and_cache_previous_tendencies!).
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const float* __restrict__ u,
-                                                         const float* __restrict__ v, float* __restrict__ U,
-                                                         float* __restrict__ V) {
+__global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const real* __restrict__ u,
+                                                         const real* __restrict__ v, real* __restrict__ U,
+                                                         real* __restrict__ V) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= g.Nx || j >= g.Ny) return;
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
-  float su = g.dzc[0] * u[o], sv = g.dzc[0] * v[ov];
+  real su = g.dzc[0] * u[o], sv = g.dzc[0] * v[ov];
   for (int k = 1; k < g.Nz; k++) {
     o += g.pl_c;
     ov += g.pl_v;
@@ -729,10 +729,10 @@ __global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const float* __
 // u += (U - Ubar)/H, v += (V - Vbar)/H.  The second sweep re-reads the column from L2.
 // Columns [i0, i0+ni): a slab of a multi-GPU run also corrects its x-halo columns (same arithmetic as the
 // owning neighbour, so no second halo exchange is needed); Ubar/Vbar are stored for interior columns only.
-__global__ __launch_bounds__(256) void k_corrector(Grid g, float* __restrict__ u, float* __restrict__ v,
-                                                   const float* __restrict__ U, const float* __restrict__ V,
-                                                   float* __restrict__ Ub, float* __restrict__ Vb,
-                                                   const float* __restrict__ Usum, const float* __restrict__ Vsum,
+__global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u, real* __restrict__ v,
+                                                   const real* __restrict__ U, const real* __restrict__ V,
+                                                   real* __restrict__ Ub, real* __restrict__ Vb,
+                                                   const real* __restrict__ Usum, const real* __restrict__ Vsum,
                                                    int i0, int ni) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, float* __restrict__ u
   const int o0 = ic(g, i, j, 0), ov0 = iv(g, i, j, 0);
   const int o2 = i2(g, i, j);
   int o = o0, ov = ov0;
-  float su, sv;
+  real su, sv;
   if (Usum != nullptr && i >= 0 && i < g.Nx) {
     // interior column: the integrals were accumulated by k_ab2_velocities (same summation order)
     su = Usum[o2];
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, float* __restrict__ u
     Ub[o2] = su;
     Vb[o2] = sv;
   }
-  const float du = (U[o2] - su) * g.rLz, dv = (V[o2] - sv) * g.rLz;
+  const real du = (U[o2] - su) * g.rLz, dv = (V[o2] - sv) * g.rLz;
   o = o0;
   ov = ov0;
 #pragma unroll 4
@@ -773,21 +773,21 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, float* __restrict__ u
 }
 
 // set_baroclinic_instability!(model) (GB-25 src/model_utils.jl:83-87,99-110)
-__global__ void k_set_baroclinic_instability(Grid g, float* __restrict__ T, float* __restrict__ S) {
+__global__ void k_set_baroclinic_instability(Grid g, real* __restrict__ T, real* __restrict__ S) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y;
   int k = blockIdx.z;
   if (i >= g.Nx) return;
-  float phi = g.phic[j], z = g.zc[k];
-  float step = (1.f - tanhf((fabsf(phi) - 40.f) / 5.f)) / 2.f;
+  real phi = g.phic[j], z = g.zc[k];
+  real step = (real(1.) - rtanh((rabs(phi) - real(40.)) / real(5.))) / real(2.);
   int o = ic(g, i, j, k);
-  T[o] = (30.f + 1e-3f * z) * step;
-  S[o] = -5e-3f * z;
+  T[o] = (real(30.) + real(1e-3) * z) * step;
+  S[o] = -real(5e-3) * z;
 }
 
 // x-slab halo exchange: pack H interior columns next to a slab edge / unpack into the halo.
 // buffer layout: [row][q] with q in 0..ncols-1, rows = all parent rows of the array.
-__global__ void k_pack_columns(const float* __restrict__ c, float* __restrict__ buf, int sx, int ncols, int i0,
+__global__ void k_pack_columns(const real* __restrict__ c, real* __restrict__ buf, int sx, int ncols, int i0,
                                long rows) {
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= rows * ncols) return;
@@ -795,7 +795,7 @@ __global__ void k_pack_columns(const float* __restrict__ c, float* __restrict__ 
   long row = t / ncols;
   buf[t] = c[row * sx + i0 + q];
 }
-__global__ void k_unpack_columns(float* __restrict__ c, const float* __restrict__ buf, int sx, int ncols, int i0,
+__global__ void k_unpack_columns(real* __restrict__ c, const real* __restrict__ buf, int sx, int ncols, int i0,
                                  long rows) {
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= rows * ncols) return;

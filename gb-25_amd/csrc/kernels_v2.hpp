@@ -19,19 +19,19 @@ constexpr int V2_TX = 64;   // tile width = one wavefront; tile height TY (rows 
 // =============================================================================================
 template <int TY>
 struct TracerLds {
-  float fx[2][2][TY][V2_TX + 1];   // [level parity][tracer][row][face i0..i0+64]
-  float fy[2][2][TY + 1][V2_TX];   // [level parity][tracer][face j0..j0+TY][column]
+  real fx[2][2][TY][V2_TX + 1];   // [level parity][tracer][row][face i0..i0+64]
+  real fy[2][2][TY + 1][V2_TX];   // [level parity][tracer][face j0..j0+TY][column]
 };
 
 // Stencil inputs of one level of one column, fetched one level AHEAD of their use: the marching loop is
 // latency-bound otherwise (one barrier per level; rocprof showed ~30 % VALU issue without the prefetch).
 struct TracerStencil {
-  float xT[6], yT[6], xS[6], yS[6];  // c[i-3..i+2, j, k] and c[i, j-3..j+2, k]
-  float u, v, w;                     // u[i,j,k], v[i,j,k], w[i,j,k+1]
+  real xT[6], yT[6], xS[6], yS[6];  // c[i-3..i+2, j, k] and c[i, j-3..j+2, k]
+  real u, v, w;                     // u[i,j,k], v[i,j,k], w[i,j,k+1]
 };
-__device__ __forceinline__ void load_stencil(TracerStencil& s, const Grid& g, const float* __restrict__ u,
-                                             const float* __restrict__ v, const float* __restrict__ w,
-                                             const float* __restrict__ T, const float* __restrict__ S, int o, int ov) {
+__device__ __forceinline__ void load_stencil(TracerStencil& s, const Grid& g, const real* __restrict__ u,
+                                             const real* __restrict__ v, const real* __restrict__ w,
+                                             const real* __restrict__ T, const real* __restrict__ S, int o, int ov) {
 #pragma unroll
   for (int m = 0; m < 6; m++) {
     s.xT[m] = T[o + m - 3];
@@ -43,23 +43,23 @@ __device__ __forceinline__ void load_stencil(TracerStencil& s, const Grid& g, co
   s.v = v[ov];
   s.w = w[o + g.pl_c];
 }
-__device__ __forceinline__ float x_face_flux(const Grid& g, const float* __restrict__ c, int o, float Axu) {
-  float q[6];
+__device__ __forceinline__ real x_face_flux(const Grid& g, const real* __restrict__ c, int o, real Axu) {
+  real q[6];
 #pragma unroll
   for (int m = 0; m < 6; m++) q[m] = c[o + m - 3];
-  return Axu * biased6<false>(5, Axu > 0.f, q, q, q);
+  return Axu * biased6<false>(5, Axu > real(0.), q, q, q);
 }
-__device__ __forceinline__ float y_face_flux(const Grid& g, const float* __restrict__ c, int o, float Ayv, int order) {
-  float q[6];
+__device__ __forceinline__ real y_face_flux(const Grid& g, const real* __restrict__ c, int o, real Ayv, int order) {
+  real q[6];
 #pragma unroll
   for (int m = 0; m < 6; m++) q[m] = c[o + (m - 3) * g.sx];
-  return Ayv * biased6<false>(order, Ayv > 0.f, q, q, q);
+  return Ayv * biased6<false>(order, Ayv > real(0.), q, q, q);
 }
 
 template <bool PREFETCH, int V2_TY>
 __global__ __launch_bounds__(V2_TX* V2_TY) void k_tracer_tendencies_v2(
-    Grid g, const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ w,
-    const float* __restrict__ T, const float* __restrict__ S, float* __restrict__ GT, float* __restrict__ GS, int nbx,
+    Grid g, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ w,
+    const real* __restrict__ T, const real* __restrict__ S, real* __restrict__ GT, real* __restrict__ GS, int nbx,
     int kchunks, int nb) {
   __shared__ TracerLds<V2_TY> lds;
   const int L = xcd_remap(blockIdx.x, nb);
@@ -73,70 +73,70 @@ __global__ __launch_bounds__(V2_TX* V2_TY) void k_tracer_tendencies_v2(
   const bool inside = (i < g.Nx) && (j < g.Ny);
   const int pc = g.pl_c, pv = g.pl_v;
 
-  const float dy = g.dy, Az = g.azc[j], dxf_s = g.dxf[j], razc_j = g.razc[j];
+  const real dy = g.dy, Az = g.azc[j], dxf_s = g.dxf[j], razc_j = g.razc[j];
   const int oys = biased_order_face(j, g.Ny);
   // the extra faces: wave 0 -> east faces (i0+64, j0+lane), lanes 0..TY-1; wave 1 -> north faces (i0+tx, j0+TY)
   const int jx = min(j0 + (tx < V2_TY ? tx : 0), g.Ny);
   const int ie = min(i0 + V2_TX, g.Nx), jn = min(j0 + V2_TY, g.Ny), icl = min(i, g.Nx);
   const int oyn = biased_order_face(jn, g.Ny);
-  const float dxf_n = g.dxf[jn];
+  const real dxf_n = g.dxf[jn];
 
   // Threads of a ragged edge tile beyond column Nx / row Ny work on a clamped (duplicate) column so that every
   // address stays in bounds; column Nx and row Ny themselves must stay exact: their west / south faces are the east /
   // north faces of the last interior cells.
   int o = ic(g, min(i, g.Nx), min(j, g.Ny), k0), ov = iv(g, min(i, g.Nx), min(j, g.Ny), k0);
   // vertical windows c[k-3 .. k+3] of the own column
-  float tz[7], sz[7];
+  real tz[7], sz[7];
 #pragma unroll
   for (int m = 0; m < 7; m++) {
     tz[m] = T[o + (m - 3) * pc];
     sz[m] = S[o + (m - 3) * pc];
   }
   // bottom face of the first level of this chunk
-  float fzT, fzS;
+  real fzT, fzS;
   {
-    float Azw = Az * w[o];
+    real Azw = Az * w[o];
     int ord = biased_order_face(k0, g.Nz);
-    fzT = Azw * biased6<false>(ord, Azw > 0.f, tz, tz, tz);
-    fzS = Azw * biased6<false>(ord, Azw > 0.f, sz, sz, sz);
+    fzT = Azw * biased6<false>(ord, Azw > real(0.), tz, tz, tz);
+    fzS = Azw * biased6<false>(ord, Azw > real(0.), sz, sz, sz);
   }
 
   // one level: fluxes of the own west / south / top faces from the prefetched stencil `st`
-  auto level = [&](int k, const TracerStencil& st, float tnew, float snew) {
+  auto level = [&](int k, const TracerStencil& st, real tnew, real snew) {
     const int par = k & 1;
-    const float dz = g.dzc[k];
+    const real dz = g.dzc[k];
     {
-      float Axu = dy * dz * st.u;
-      float Ayv = dxf_s * dz * st.v;
-      lds.fx[par][0][ty][tx] = Axu * biased6<false>(5, Axu > 0.f, st.xT, st.xT, st.xT);
-      lds.fx[par][1][ty][tx] = Axu * biased6<false>(5, Axu > 0.f, st.xS, st.xS, st.xS);
-      lds.fy[par][0][ty][tx] = Ayv * biased6<false>(oys, Ayv > 0.f, st.yT, st.yT, st.yT);
-      lds.fy[par][1][ty][tx] = Ayv * biased6<false>(oys, Ayv > 0.f, st.yS, st.yS, st.yS);
+      real Axu = dy * dz * st.u;
+      real Ayv = dxf_s * dz * st.v;
+      lds.fx[par][0][ty][tx] = Axu * biased6<false>(5, Axu > real(0.), st.xT, st.xT, st.xT);
+      lds.fx[par][1][ty][tx] = Axu * biased6<false>(5, Axu > real(0.), st.xS, st.xS, st.xS);
+      lds.fy[par][0][ty][tx] = Ayv * biased6<false>(oys, Ayv > real(0.), st.yT, st.yT, st.yT);
+      lds.fy[par][1][ty][tx] = Ayv * biased6<false>(oys, Ayv > real(0.), st.yS, st.yS, st.yS);
     }
     if (ty == 0) {  // wave-uniform: the column of east faces of the tile
       if (tx < V2_TY) {
         int oe = ic(g, ie, jx, k);
-        float Axu = dy * dz * u[oe];
+        real Axu = dy * dz * u[oe];
         lds.fx[par][0][tx][V2_TX] = x_face_flux(g, T, oe, Axu);
         lds.fx[par][1][tx][V2_TX] = x_face_flux(g, S, oe, Axu);
       }
     } else if (ty == 1) {  // wave-uniform: the row of north faces of the tile
       int on = ic(g, icl, jn, k);
-      float Ayv = dxf_n * dz * v[iv(g, icl, jn, k)];
+      real Ayv = dxf_n * dz * v[iv(g, icl, jn, k)];
       lds.fy[par][0][V2_TY][tx] = y_face_flux(g, T, on, Ayv, oyn);
       lds.fy[par][1][V2_TY][tx] = y_face_flux(g, S, on, Ayv, oyn);
     }
     // top face from the vertical window (values k-2 .. k+3)
-    const float Azw = Az * st.w;
+    const real Azw = Az * st.w;
     const int ozt = biased_order_face(k + 1, g.Nz);
-    const float ftT = Azw * biased6<false>(ozt, Azw > 0.f, tz + 1, tz + 1, tz + 1);
-    const float ftS = Azw * biased6<false>(ozt, Azw > 0.f, sz + 1, sz + 1, sz + 1);
+    const real ftT = Azw * biased6<false>(ozt, Azw > real(0.), tz + 1, tz + 1, tz + 1);
+    const real ftS = Azw * biased6<false>(ozt, Azw > real(0.), sz + 1, sz + 1, sz + 1);
     __syncthreads();
     if (inside) {
-      const float rV = razc_j * g.rdzc[k];
-      float dT = (lds.fx[par][0][ty][tx + 1] - lds.fx[par][0][ty][tx]) +
+      const real rV = razc_j * g.rdzc[k];
+      real dT = (lds.fx[par][0][ty][tx + 1] - lds.fx[par][0][ty][tx]) +
                  (lds.fy[par][0][ty + 1][tx] - lds.fy[par][0][ty][tx]) + (ftT - fzT);
-      float dS = (lds.fx[par][1][ty][tx + 1] - lds.fx[par][1][ty][tx]) +
+      real dS = (lds.fx[par][1][ty][tx + 1] - lds.fx[par][1][ty][tx]) +
                  (lds.fy[par][1][ty + 1][tx] - lds.fy[par][1][ty][tx]) + (ftS - fzS);
       GT[o] = -(dT * rV);
       GS[o] = -(dS * rV);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY) void k_tracer_tendencies_v2(
   load_stencil(A, g, u, v, w, T, S, o, ov);
   for (int k = k0; k < k1; k += 2) {
     const bool more1 = (k + 1 < k1);
-    float tn = T[o + 4 * pc], sn = S[o + 4 * pc];                     // enters the window after level k
+    real tn = T[o + 4 * pc], sn = S[o + 4 * pc];                     // enters the window after level k
     if (more1) load_stencil(B, g, u, v, w, T, S, o + pc, ov + pv);    // level k+1, in flight during level k
     level(k, A, tn, sn);
     if (more1) {
@@ -197,17 +197,17 @@ constexpr int MD_X = V2_TX + 5;   // derived tiles: ffc origin (i0-2, j0-2), ccc
 template <int V2_TY>
 struct MomentumLds {
   static constexpr int MU_Y = V2_TY + 6, MW_Y = V2_TY + 3, MD_Y = V2_TY + 5;
-  float U[2][MU_Y][MU_X];
-  float V[2][MU_Y][MU_X];
-  float W[2][MW_Y][MW_X];
-  float Z[MD_Y][MD_X], UQ[MD_Y][MD_X], VQ[MD_Y][MD_X];  // (f,f,c)
-  float DU[MD_Y][MD_X], DV[MD_Y][MD_X];                 // (c,c,c)
+  real U[2][MU_Y][MU_X];
+  real V[2][MU_Y][MU_X];
+  real W[2][MW_Y][MW_X];
+  real Z[MD_Y][MD_X], UQ[MD_Y][MD_X], VQ[MD_Y][MD_X];  // (f,f,c)
+  real DU[MD_Y][MD_X], DV[MD_Y][MD_X];                 // (c,c,c)
 };
 
 template <int MINW, int V2_TY>
 __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
-    Grid g, const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ w,
-    const float* __restrict__ dpx, const float* __restrict__ dpy, float* __restrict__ Gu, float* __restrict__ Gv,
+    Grid g, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ w,
+    const real* __restrict__ dpx, const real* __restrict__ dpy, real* __restrict__ Gu, real* __restrict__ Gv,
     int nbx, int kchunks, int nb) {
   __shared__ MomentumLds<V2_TY> lds;
   constexpr int MU_Y = V2_TY + 6, MW_Y = V2_TY + 3, MD_Y = V2_TY + 5;
@@ -221,31 +221,31 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
   const int i = i0 + tx, j = j0 + ty;
   const bool inside = (i < g.Nx) && (j < g.Ny);
   const int sx = g.sx, pc = g.pl_c, pv = g.pl_v, H = g.H;
-  const float dy = g.dy;
+  const real dy = g.dy;
 
   // j-dependent metrics of this thread's row
-  const float dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j], razc_j = g.razc[j], razf_j = g.razf[j];
-  const float Az = g.azc[j], fcor_j = g.fcor[j], fbar = 0.5f * (g.fcor[j] + g.fcor[j + 1]);
-  const float az_m2 = g.azc[j - 2], az_m1 = g.azc[j - 1], az_p1 = g.azc[j + 1];
+  const real dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j], razc_j = g.razc[j], razf_j = g.razf[j];
+  const real Az = g.azc[j], fcor_j = g.fcor[j], fbar = real(0.5) * (g.fcor[j] + g.fcor[j + 1]);
+  const real az_m2 = g.azc[j - 2], az_m1 = g.azc[j - 1], az_p1 = g.azc[j + 1];
   const int oc_y = biased_order_center(j, g.Ny), of_y = biased_order_face(j, g.Ny);
   const bool s4c_y = sym4_center(j, g.Ny), s4f_y = sym4_face(j, g.Ny);
 
   // threads of a ragged edge tile work on a clamped (duplicate) column so that every address stays in bounds
   int o = ic(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0), ov = iv(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0);
-  float uz[7], vz[7];
+  real uz[7], vz[7];
 #pragma unroll
   for (int m = 0; m < 7; m++) {
     uz[m] = u[o + (m - 3) * pc];
     vz[m] = v[ov + (m - 3) * pv];
   }
   // vertical momentum fluxes through the bottom face of the first level
-  float fzu, fzv;
+  real fzu, fzv;
   {
     const int ord = biased_order_face(k0, g.Nz);
-    float wu = sym_interp(true, Az * w[o - 2], Az * w[o - 1], Az * w[o], Az * w[o + 1]);
-    float wv = sym_interp(s4f_y, az_m2 * w[o - 2 * sx], az_m1 * w[o - sx], Az * w[o], az_p1 * w[o + sx]);
-    fzu = wu * biased6<false>(ord, wu > 0.f, uz, uz, uz);
-    fzv = wv * biased6<false>(ord, wv > 0.f, vz, vz, vz);
+    real wu = sym_interp(true, Az * w[o - 2], Az * w[o - 1], Az * w[o], Az * w[o + 1]);
+    real wv = sym_interp(s4f_y, az_m2 * w[o - 2 * sx], az_m1 * w[o - sx], Az * w[o], az_p1 * w[o + sx]);
+    fzu = wu * biased6<false>(ord, wu > real(0.), uz, uz, uz);
+    fzv = wv * biased6<false>(ord, wv > real(0.), vz, vz, vz);
   }
 
   // Tile staging is software-pipelined: the global loads of level k+1 are issued before the arithmetic of level
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
     ew_off[q] = (e < MW_X * MW_Y) ? min(ex, g.Nx + H + 1 - i0) + sx * min(ey, g.Ny + H + 1 - j0) : -1;
     ew_lds[q] = e;
   }
-  float ru[NEU], rv[NEU], rw[NEW], rpw = 0.f, rps = 0.f;
+  real ru[NEU], rv[NEU], rw[NEW], rpw = real(0.), rps = real(0.);
   auto fetch = [&](int k, int oo) {
     const int bu = tile_u + pc * (k + H), bv = tile_u + pv * (k + H), bw = tile_w + pc * (k + 1 + H);
 #pragma unroll
@@ -286,9 +286,9 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
     rps = dpy[oo];
   };
   auto stash = [&](int par) {
-    float* U0 = &lds.U[par][0][0];
-    float* V0 = &lds.V[par][0][0];
-    float* W0 = &lds.W[par][0][0];
+    real* U0 = &lds.U[par][0][0];
+    real* V0 = &lds.V[par][0][0];
+    real* W0 = &lds.W[par][0][0];
 #pragma unroll
     for (int q = 0; q < NEU; q++)
       if (eu_off[q] >= 0) {
@@ -301,32 +301,32 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
   };
   fetch(k0, o);
   stash(k0 & 1);
-  float pw_ = rpw, ps_ = rps;   // p'(i,j) - p'(i-1,j) and p'(i,j) - p'(i,j-1) of the current level
+  real pw_ = rpw, ps_ = rps;   // p'(i,j) - p'(i-1,j) and p'(i,j) - p'(i,j-1) of the current level
   __syncthreads();
 
   for (int k = k0; k < k1; k++) {
     const int par = k & 1;
-    const float dz = g.dzc[k];
+    const real dz = g.dzc[k];
     // ---- phase 0: issue the loads of the next level's tiles (consumed at the end of this iteration)
     const bool more = (k + 1 < k1);
     if (more) fetch(k + 1, o + pc);
-    const float unew = u[o + 4 * pc], vnew = v[ov + 4 * pv];
+    const real unew = u[o + 4 * pc], vnew = v[ov + 4 * pv];
     // ---- phase 1: derived quantities, once per point
     for (int e = tid; e < MD_X * MD_Y; e += NT) {
       int py = e / MD_X, px = e - py * MD_X;
       // (f,f,c) point (i0-2+px, j0-2+py)
       {
         const int J = j0 - 2 + py;
-        float uc = lds.U[par][py + 1][px + 1], us = lds.U[par][py][px + 1];
-        float vc = lds.V[par][py + 1][px + 1], vw = lds.V[par][py + 1][px];
+        real uc = lds.U[par][py + 1][px + 1], us = lds.U[par][py][px + 1];
+        real vc = lds.V[par][py + 1][px + 1], vw = lds.V[par][py + 1][px];
         lds.Z[py][px] = ((dy * vc - dy * vw) - (g.dxc[J] * uc - g.dxc[J - 1] * us)) * g.razf[J];
-        lds.UQ[py][px] = 0.5f * (us + uc);
-        lds.VQ[py][px] = 0.5f * (vw + vc);
+        lds.UQ[py][px] = real(0.5) * (us + uc);
+        lds.VQ[py][px] = real(0.5) * (vw + vc);
       }
       // (c,c,c) point (i0-3+px, j0-3+py)
       {
         const int J = j0 - 3 + py;
-        const float Ax = dy * dz;
+        const real Ax = dy * dz;
         lds.DU[py][px] = Ax * lds.U[par][py][px + 1] - Ax * lds.U[par][py][px];
         lds.DV[py][px] = g.dxf[J + 1] * dz * lds.V[par][py + 1][px] - g.dxf[J] * dz * lds.V[par][py][px];
       }
@@ -339,23 +339,23 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
 #define WT(di, dj) lds.W[par][ty + 2 + (dj)][tx + 2 + (di)]
 #define ZF(A, di, dj) lds.A[ty + 2 + (dj)][tx + 2 + (di)]
 #define DC(A, di, dj) lds.A[ty + 3 + (dj)][tx + 3 + (di)]
-    float gu, gv;
+    real gu, gv;
     const int ozt = biased_order_face(k + 1, g.Nz);
-    const float rdz = g.rdzc[k];
+    const real rdz = g.rdzc[k];
     {  // ---------------- G_u at (f,c,c)
-      const float vws = VT(-1, 0), vwn = VT(-1, 1), vcs = VT(0, 0), vcn = VT(0, 1);
-      const float vhat = (0.5f * (dxf_s * vws + dxf_n * vwn) + 0.5f * (dxf_s * vcs + dxf_n * vcn)) * 0.5f * rdxc_j;
-      float zq[6], uq[6], vq[6];
+      const real vws = VT(-1, 0), vwn = VT(-1, 1), vcs = VT(0, 0), vcn = VT(0, 1);
+      const real vhat = (real(0.5) * (dxf_s * vws + dxf_n * vwn) + real(0.5) * (dxf_s * vcs + dxf_n * vcn)) * real(0.5) * rdxc_j;
+      real zq[6], uq[6], vq[6];
 #pragma unroll
       for (int m = 0; m < 6; m++) {
         zq[m] = ZF(Z, 0, m - 2);
         uq[m] = ZF(UQ, 0, m - 2);
         vq[m] = ZF(VQ, 0, m - 2);
       }
-      const float hadv = -vhat * biased6<true>(oc_y, vhat > 0.f, zq, uq, vq);
+      const real hadv = -vhat * biased6<true>(oc_y, vhat > real(0.), zq, uq, vq);
 
-      const float uhat = uz[3];
-      float Du[6], Dd[6], Dv4[4];
+      const real uhat = uz[3];
+      real Du[6], Dd[6], Dv4[4];
 #pragma unroll
       for (int m = 0; m < 6; m++) {
         Du[m] = DC(DU, m - 3, 0);
@@ -363,50 +363,50 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
       }
 #pragma unroll
       for (int m = 0; m < 4; m++) Dv4[m] = DC(DV, m - 2, 0);
-      const float dvs = sym_interp(true, Dv4[0], Dv4[1], Dv4[2], Dv4[3]);
-      const float duR = biased6<false>(5, uhat > 0.f, Du, Dd, Dd);
-      const float phi = uhat * (dvs + duR);
+      const real dvs = sym_interp(true, Dv4[0], Dv4[1], Dv4[2], Dv4[3]);
+      const real duR = biased6<false>(5, uhat > real(0.), Du, Dd, Dd);
+      const real phi = uhat * (dvs + duR);
 
-      const float wt = sym_interp(true, Az * WT(-2, 0), Az * WT(-1, 0), Az * WT(0, 0), Az * WT(1, 0));
-      const float ft = wt * biased6<false>(ozt, wt > 0.f, uz + 1, uz + 1, uz + 1);
-      const float vadv = (phi + (ft - fzu)) * (razc_j * rdz);
+      const real wt = sym_interp(true, Az * WT(-2, 0), Az * WT(-1, 0), Az * WT(0, 0), Az * WT(1, 0));
+      const real ft = wt * biased6<false>(ozt, wt > real(0.), uz + 1, uz + 1, uz + 1);
+      const real vadv = (phi + (ft - fzu)) * (razc_j * rdz);
       fzu = ft;
 
-      float u7[7], Ku[6], su[6];
+      real u7[7], Ku[6], su[6];
 #pragma unroll
       for (int m = 0; m < 7; m++) u7[m] = UT(m - 3, 0);
 #pragma unroll
       for (int m = 0; m < 6; m++) {
-        Ku[m] = 0.5f * u7[m + 1] * u7[m + 1] - 0.5f * u7[m] * u7[m];
-        su[m] = 0.5f * (u7[m] + u7[m + 1]);
+        Ku[m] = real(0.5) * u7[m + 1] * u7[m + 1] - real(0.5) * u7[m] * u7[m];
+        su[m] = real(0.5) * (u7[m] + u7[m + 1]);
       }
-      const float dKu = biased6<false>(5, uhat > 0.f, Ku, su, su);
-      float a4[4];
+      const real dKu = biased6<false>(5, uhat > real(0.), Ku, su, su);
+      real a4[4];
 #pragma unroll
       for (int m = 0; m < 4; m++) {
-        float vc = VT(0, m - 1), vw = VT(-1, m - 1);
-        a4[m] = 0.5f * vc * vc - 0.5f * vw * vw;
+        real vc = VT(0, m - 1), vw = VT(-1, m - 1);
+        a4[m] = real(0.5) * vc * vc - real(0.5) * vw * vw;
       }
-      const float dKv = sym_interp(s4c_y, a4[0], a4[1], a4[2], a4[3]);
-      const float bern = (dKu + dKv) * rdxc_j;
-      const float cor = -fbar * vhat;
-      const float dpdx = pw_ * rdxc_j;
+      const real dKv = sym_interp(s4c_y, a4[0], a4[1], a4[2], a4[3]);
+      const real bern = (dKu + dKv) * rdxc_j;
+      const real cor = -fbar * vhat;
+      const real dpdx = pw_ * rdxc_j;
       gu = -(hadv + vadv + bern) - cor - dpdx;
     }
     {  // ---------------- G_v at (c,f,c)
-      const float uhat =
-          (0.5f * (dy * UT(0, -1) + dy * UT(1, -1)) + 0.5f * (dy * UT(0, 0) + dy * UT(1, 0))) * 0.5f * g.rdy;
-      float zq[6], uq[6], vq[6];
+      const real uhat =
+          (real(0.5) * (dy * UT(0, -1) + dy * UT(1, -1)) + real(0.5) * (dy * UT(0, 0) + dy * UT(1, 0))) * real(0.5) * g.rdy;
+      real zq[6], uq[6], vq[6];
 #pragma unroll
       for (int m = 0; m < 6; m++) {
         zq[m] = ZF(Z, m - 2, 0);
         uq[m] = ZF(UQ, m - 2, 0);
         vq[m] = ZF(VQ, m - 2, 0);
       }
-      const float hadv = uhat * biased6<true>(5, uhat > 0.f, zq, uq, vq);
+      const real hadv = uhat * biased6<true>(5, uhat > real(0.), zq, uq, vq);
 
-      const float vhat = vz[3];
-      float Dv[6], Dd[6], Du4[4];
+      const real vhat = vz[3];
+      real Dv[6], Dd[6], Du4[4];
 #pragma unroll
       for (int m = 0; m < 6; m++) {
         Dv[m] = DC(DV, 0, m - 3);
@@ -414,34 +414,34 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
       }
 #pragma unroll
       for (int m = 0; m < 4; m++) Du4[m] = DC(DU, 0, m - 2);
-      const float dus = sym_interp(s4f_y, Du4[0], Du4[1], Du4[2], Du4[3]);
-      const float dvR = biased6<false>(of_y, vhat > 0.f, Dv, Dd, Dd);
-      const float phi = vhat * (dus + dvR);
+      const real dus = sym_interp(s4f_y, Du4[0], Du4[1], Du4[2], Du4[3]);
+      const real dvR = biased6<false>(of_y, vhat > real(0.), Dv, Dd, Dd);
+      const real phi = vhat * (dus + dvR);
 
-      const float wt = sym_interp(s4f_y, az_m2 * WT(0, -2), az_m1 * WT(0, -1), Az * WT(0, 0), az_p1 * WT(0, 1));
-      const float ft = wt * biased6<false>(ozt, wt > 0.f, vz + 1, vz + 1, vz + 1);
-      const float vadv = (phi + (ft - fzv)) * (razf_j * rdz);
+      const real wt = sym_interp(s4f_y, az_m2 * WT(0, -2), az_m1 * WT(0, -1), Az * WT(0, 0), az_p1 * WT(0, 1));
+      const real ft = wt * biased6<false>(ozt, wt > real(0.), vz + 1, vz + 1, vz + 1);
+      const real vadv = (phi + (ft - fzv)) * (razf_j * rdz);
       fzv = ft;
 
-      float v7[7], Kv[6], sv[6];
+      real v7[7], Kv[6], sv[6];
 #pragma unroll
       for (int m = 0; m < 7; m++) v7[m] = VT(0, m - 3);
 #pragma unroll
       for (int m = 0; m < 6; m++) {
-        Kv[m] = 0.5f * v7[m + 1] * v7[m + 1] - 0.5f * v7[m] * v7[m];
-        sv[m] = 0.5f * (v7[m] + v7[m + 1]);
+        Kv[m] = real(0.5) * v7[m + 1] * v7[m + 1] - real(0.5) * v7[m] * v7[m];
+        sv[m] = real(0.5) * (v7[m] + v7[m + 1]);
       }
-      const float dKv = biased6<false>(of_y, vhat > 0.f, Kv, sv, sv);
-      float a4[4];
+      const real dKv = biased6<false>(of_y, vhat > real(0.), Kv, sv, sv);
+      real a4[4];
 #pragma unroll
       for (int m = 0; m < 4; m++) {
-        float un = UT(m - 1, 0), us = UT(m - 1, -1);
-        a4[m] = 0.5f * un * un - 0.5f * us * us;
+        real un = UT(m - 1, 0), us = UT(m - 1, -1);
+        a4[m] = real(0.5) * un * un - real(0.5) * us * us;
       }
-      const float dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
-      const float bern = (dKv + dKu) * g.rdy;
-      const float cor = fcor_j * uhat;
-      const float dpdy = ps_ * g.rdy;
+      const real dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
+      const real bern = (dKv + dKu) * g.rdy;
+      const real cor = fcor_j * uhat;
+      const real dpdy = ps_ * g.rdy;
       gv = -(hadv + vadv + bern) - cor - dpdy;
     }
 #undef UT
@@ -485,11 +485,11 @@ namespace gb25 {
 constexpr int V3_OUT = 63;   // outputs per wavefront
 
 template <int MINW>
-__global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v3(Grid g, const float* __restrict__ u,
-                                                              const float* __restrict__ v,
-                                                              const float* __restrict__ w,
-                                                              const float* __restrict__ T, const float* __restrict__ S,
-                                                              float* __restrict__ GT, float* __restrict__ GS, int nbx,
+__global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v3(Grid g, const real* __restrict__ u,
+                                                              const real* __restrict__ v,
+                                                              const real* __restrict__ w,
+                                                              const real* __restrict__ T, const real* __restrict__ S,
+                                                              real* __restrict__ GT, real* __restrict__ GS, int nbx,
                                                               int kchunks, int nb) {
   const int L = xcd_remap(blockIdx.x, nb);
   const int bx = L % nbx, r = L / nbx;
@@ -501,54 +501,54 @@ __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v3(Grid g, cons
   if (j >= g.Ny) return;                       // whole wave (one row) leaves together: no barriers in this kernel
   const bool writes = (lane < V3_OUT) && (i < g.Nx);
   const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
-  const float dy = g.dy, Az = g.azc[j], dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], razc_j = g.razc[j];
+  const real dy = g.dy, Az = g.azc[j], dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], razc_j = g.razc[j];
   const int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny);
 
   // lanes past the east edge work on a clamped (duplicate) column: every address stays inside the parent array
   int o = ic(g, min(i, g.Nx), j, k0), ov = iv(g, min(i, g.Nx), j, k0);
-  float tz[7], sz[7];
+  real tz[7], sz[7];
 #pragma unroll
   for (int m = 0; m < 7; m++) {
     tz[m] = T[o + (m - 3) * pc];
     sz[m] = S[o + (m - 3) * pc];
   }
-  float fzT, fzS;
+  real fzT, fzS;
   {
-    float Azw = Az * w[o];
+    real Azw = Az * w[o];
     int ord = biased_order_face(k0, g.Nz);
-    fzT = Azw * biased6<false>(ord, Azw > 0.f, tz, tz, tz);
-    fzS = Azw * biased6<false>(ord, Azw > 0.f, sz, sz, sz);
+    fzT = Azw * biased6<false>(ord, Azw > real(0.), tz, tz, tz);
+    fzS = Azw * biased6<false>(ord, Azw > real(0.), sz, sz, sz);
   }
   for (int k = k0; k < k1; k++) {
-    const float dz = g.dzc[k];
-    const float Axu = dy * dz * u[o];
-    const float Ays = dxf_s * dz * v[ov], Ayn = dxf_n * dz * v[ov + sx];
-    const float Azw = Az * w[o + pc];
-    float q[7];
+    const real dz = g.dzc[k];
+    const real Axu = dy * dz * u[o];
+    const real Ays = dxf_s * dz * v[ov], Ayn = dxf_n * dz * v[ov + sx];
+    const real Azw = Az * w[o + pc];
+    real q[7];
     // ---- T
 #pragma unroll
     for (int m = 0; m < 6; m++) q[m] = T[o + m - 3];
-    const float fxT = Axu * biased6<false>(5, Axu > 0.f, q, q, q);
+    const real fxT = Axu * biased6<false>(5, Axu > real(0.), q, q, q);
 #pragma unroll
     for (int m = 0; m < 7; m++) q[m] = T[o + (m - 3) * sx];
-    const float fsT = Ays * biased6<false>(oys, Ays > 0.f, q, q, q);
-    const float fnT = Ayn * biased6<false>(oyn, Ayn > 0.f, q + 1, q + 1, q + 1);
+    const real fsT = Ays * biased6<false>(oys, Ays > real(0.), q, q, q);
+    const real fnT = Ayn * biased6<false>(oyn, Ayn > real(0.), q + 1, q + 1, q + 1);
     // ---- S
 #pragma unroll
     for (int m = 0; m < 6; m++) q[m] = S[o + m - 3];
-    const float fxS = Axu * biased6<false>(5, Axu > 0.f, q, q, q);
+    const real fxS = Axu * biased6<false>(5, Axu > real(0.), q, q, q);
 #pragma unroll
     for (int m = 0; m < 7; m++) q[m] = S[o + (m - 3) * sx];
-    const float fsS = Ays * biased6<false>(oys, Ays > 0.f, q, q, q);
-    const float fnS = Ayn * biased6<false>(oyn, Ayn > 0.f, q + 1, q + 1, q + 1);
+    const real fsS = Ays * biased6<false>(oys, Ays > real(0.), q, q, q);
+    const real fnS = Ayn * biased6<false>(oyn, Ayn > real(0.), q + 1, q + 1, q + 1);
     // ---- top faces from the vertical windows
     const int ozt = biased_order_face(k + 1, g.Nz);
-    const float ftT = Azw * biased6<false>(ozt, Azw > 0.f, tz + 1, tz + 1, tz + 1);
-    const float ftS = Azw * biased6<false>(ozt, Azw > 0.f, sz + 1, sz + 1, sz + 1);
+    const real ftT = Azw * biased6<false>(ozt, Azw > real(0.), tz + 1, tz + 1, tz + 1);
+    const real ftS = Azw * biased6<false>(ozt, Azw > real(0.), sz + 1, sz + 1, sz + 1);
     // east faces = west faces of the next lane
-    const float feT = __shfl_down(fxT, 1), feS = __shfl_down(fxS, 1);
+    const real feT = __shfl_down(fxT, 1), feS = __shfl_down(fxS, 1);
     if (writes) {
-      const float rV = razc_j * g.rdzc[k];
+      const real rV = razc_j * g.rdzc[k];
       GT[o] = -(((feT - fxT) + (fnT - fsT) + (ftT - fzT)) * rV);
       GS[o] = -(((feS - fxS) + (fnS - fsS) + (ftS - fzS)) * rV);
     }
@@ -572,8 +572,8 @@ namespace gb25 {
 
 // =============================================================================================
 // Momentum tendencies, single-barrier pipeline ("v4").  Same arithmetic and the same LDS staging idea as
-// k_momentum_tendencies_v2, but (a) the derived (f,f,c) triple {zeta, uq, vq} is one float4 and the (c,c,c)
-// pair {DU, DV} one float2 per point, so a stencil point costs one ds_read_b128 / b64 instead of three / two
+// k_momentum_tendencies_v2, but (a) the derived (f,f,c) triple {zeta, uq, vq} is one real4 and the (c,c,c)
+// pair {DU, DV} one real2 per point, so a stencil point costs one ds_read_b128 / b64 instead of three / two
 // ds_read_b32, and (b) the level loop is software-pipelined two deep: iteration k evaluates the tendencies of
 // level k, derives the quantities of level k+1 and stages the tiles of level k+2, behind ONE barrier.
 // (v2 measured 50 % VALU issue with 34 % of wave time in s_waitcnt/barrier: profiles/r01_v2_pmc_sq3.csv.)
@@ -581,17 +581,17 @@ namespace gb25 {
 template <int TY>
 struct MomentumLds4 {
   static constexpr int MU_Y = TY + 6, MW_Y = TY + 3, MD_Y = TY + 5;
-  float U[3][MU_Y][MU_X];
-  float V[3][MU_Y][MU_X];
-  float W[3][MW_Y][MW_X];
-  float4 ZQ[2][MD_Y][MD_X];   // (f,f,c): x = zeta, y = uq, z = vq
-  float2 D2[2][MD_Y][MD_X];   // (c,c,c): x = DU, y = DV
+  real U[3][MU_Y][MU_X];
+  real V[3][MU_Y][MU_X];
+  real W[3][MW_Y][MW_X];
+  real4 ZQ[2][MD_Y][MD_X];   // (f,f,c): x = zeta, y = uq, z = vq
+  real2 D2[2][MD_Y][MD_X];   // (c,c,c): x = DU, y = DV
 };
 
 template <int MINW, int TY>
 __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
-    Grid g, const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ w,
-    const float* __restrict__ dpx, const float* __restrict__ dpy, float* __restrict__ Gu, float* __restrict__ Gv,
+    Grid g, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ w,
+    const real* __restrict__ dpx, const real* __restrict__ dpy, real* __restrict__ Gu, real* __restrict__ Gv,
     int nbx, int kchunks, int nb) {
   __shared__ MomentumLds4<TY> lds;
   constexpr int MU_Y = TY + 6, MW_Y = TY + 3, MD_Y = TY + 5;
@@ -605,29 +605,29 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
   const int i = i0 + tx, j = j0 + ty;
   const bool inside = (i < g.Nx) && (j < g.Ny);
   const int sx = g.sx, pc = g.pl_c, pv = g.pl_v, H = g.H;
-  const float dy = g.dy;
+  const real dy = g.dy;
 
-  const float dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j], razc_j = g.razc[j], razf_j = g.razf[j];
-  const float Az = g.azc[j], fcor_j = g.fcor[j], fbar = 0.5f * (g.fcor[j] + g.fcor[j + 1]);
-  const float az_m2 = g.azc[j - 2], az_m1 = g.azc[j - 1], az_p1 = g.azc[j + 1];
+  const real dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j], razc_j = g.razc[j], razf_j = g.razf[j];
+  const real Az = g.azc[j], fcor_j = g.fcor[j], fbar = real(0.5) * (g.fcor[j] + g.fcor[j + 1]);
+  const real az_m2 = g.azc[j - 2], az_m1 = g.azc[j - 1], az_p1 = g.azc[j + 1];
   const int oc_y = biased_order_center(j, g.Ny), of_y = biased_order_face(j, g.Ny);
   const bool s4c_y = sym4_center(j, g.Ny), s4f_y = sym4_face(j, g.Ny);
 
   // threads of a ragged edge tile work on a clamped (duplicate) column so that every address stays in bounds
   int o = ic(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0), ov = iv(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0);
-  float uz[7], vz[7];
+  real uz[7], vz[7];
 #pragma unroll
   for (int m = 0; m < 7; m++) {
     uz[m] = u[o + (m - 3) * pc];
     vz[m] = v[ov + (m - 3) * pv];
   }
-  float fzu, fzv;
+  real fzu, fzv;
   {
     const int ord = biased_order_face(k0, g.Nz);
-    float wu = sym_interp(true, Az * w[o - 2], Az * w[o - 1], Az * w[o], Az * w[o + 1]);
-    float wv = sym_interp(s4f_y, az_m2 * w[o - 2 * sx], az_m1 * w[o - sx], Az * w[o], az_p1 * w[o + sx]);
-    fzu = wu * biased6<false>(ord, wu > 0.f, uz, uz, uz);
-    fzv = wv * biased6<false>(ord, wv > 0.f, vz, vz, vz);
+    real wu = sym_interp(true, Az * w[o - 2], Az * w[o - 1], Az * w[o], Az * w[o + 1]);
+    real wv = sym_interp(s4f_y, az_m2 * w[o - 2 * sx], az_m1 * w[o - sx], Az * w[o], az_p1 * w[o + sx]);
+    fzu = wu * biased6<false>(ord, wu > real(0.), uz, uz, uz);
+    fzv = wv * biased6<false>(ord, wv > real(0.), vz, vz, vz);
   }
 
   // ---- tile staging: each thread owns NEU elements of the u / v tiles and NEW of the w tile
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
     int e = tid + q * NT, ey = e / MW_X, ex = e - ey * MW_X;
     ew_off[q] = (e < MW_X * MW_Y) ? min(ex, g.Nx + H + 1 - i0) + sx * min(ey, g.Ny + H + 1 - j0) : -1;
   }
-  float ru[NEU], rv[NEU], rw[NEW];
+  real ru[NEU], rv[NEU], rw[NEW];
   auto fetch = [&](int k) {
     const int bu = tile_u + pc * (k + H), bv = tile_u + pv * (k + H), bw = tile_w + pc * (k + 1 + H);
 #pragma unroll
@@ -659,9 +659,9 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
       if (ew_off[q] >= 0) rw[q] = w[bw + ew_off[q]];
   };
   auto stash = [&](int b) {
-    float* U0 = &lds.U[b][0][0];
-    float* V0 = &lds.V[b][0][0];
-    float* W0 = &lds.W[b][0][0];
+    real* U0 = &lds.U[b][0][0];
+    real* V0 = &lds.V[b][0][0];
+    real* W0 = &lds.W[b][0][0];
 #pragma unroll
     for (int q = 0; q < NEU; q++)
       if (eu_off[q] >= 0) {
@@ -674,24 +674,24 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
   };
   // derived quantities of one level, once per point: tiles[b] -> derived[par]
   auto derive = [&](int k, int b, int par) {
-    const float dz = g.dzc[k];
+    const real dz = g.dzc[k];
     for (int e = tid; e < MD_X * MD_Y; e += NT) {
       int py = e / MD_X, px = e - py * MD_X;
       {  // (f,f,c) point (i0-2+px, j0-2+py)
         const int J = j0 - 2 + py;
-        float uc = lds.U[b][py + 1][px + 1], us = lds.U[b][py][px + 1];
-        float vc = lds.V[b][py + 1][px + 1], vw = lds.V[b][py + 1][px];
-        float4 zq;
+        real uc = lds.U[b][py + 1][px + 1], us = lds.U[b][py][px + 1];
+        real vc = lds.V[b][py + 1][px + 1], vw = lds.V[b][py + 1][px];
+        real4 zq;
         zq.x = ((dy * vc - dy * vw) - (g.dxc[J] * uc - g.dxc[J - 1] * us)) * g.razf[J];
-        zq.y = 0.5f * (us + uc);
-        zq.z = 0.5f * (vw + vc);
-        zq.w = 0.f;
+        zq.y = real(0.5) * (us + uc);
+        zq.z = real(0.5) * (vw + vc);
+        zq.w = real(0.);
         lds.ZQ[par][py][px] = zq;
       }
       {  // (c,c,c) point (i0-3+px, j0-3+py)
         const int J = j0 - 3 + py;
-        const float Ax = dy * dz;
-        float2 d;
+        const real Ax = dy * dz;
+        real2 d;
         d.x = Ax * lds.U[b][py][px + 1] - Ax * lds.U[b][py][px];
         d.y = g.dxf[J + 1] * dz * lds.V[b][py + 1][px] - g.dxf[J] * dz * lds.V[b][py][px];
         lds.D2[par][py][px] = d;
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
     fetch(k0 + 1);
     stash(b1);
   }
-  float pw_ = dpx[o], ps_ = dpy[o];
+  real pw_ = dpx[o], ps_ = dpy[o];
   __syncthreads();
   derive(k0, b0, k0 & 1);
   __syncthreads();
@@ -716,8 +716,8 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
     const int par = k & 1;
     const bool more1 = (k + 1 < k1), more2 = (k + 2 < k1);
     if (more2) fetch(k + 2);
-    const float unew = u[o + 4 * pc], vnew = v[ov + 4 * pv];
-    float pwn = 0.f, psn = 0.f;
+    const real unew = u[o + 4 * pc], vnew = v[ov + 4 * pv];
+    real pwn = real(0.), psn = real(0.);
     if (more1) {
       pwn = dpx[o + pc];
       psn = dpy[o + pc];
@@ -727,111 +727,111 @@ __global__ __launch_bounds__(V2_TX* TY, MINW) void k_momentum_tendencies_v4(
 #define WT(di, dj) lds.W[b0][ty + 2 + (dj)][tx + 2 + (di)]
 #define ZQF(di, dj) lds.ZQ[par][ty + 2 + (dj)][tx + 2 + (di)]
 #define D2C(di, dj) lds.D2[par][ty + 3 + (dj)][tx + 3 + (di)]
-    float gu, gv;
+    real gu, gv;
     const int ozt = biased_order_face(k + 1, g.Nz);
-    const float rdz = g.rdzc[k];
+    const real rdz = g.rdzc[k];
     {  // ---------------- G_u at (f,c,c)
-      const float vws = VT(-1, 0), vwn = VT(-1, 1), vcs = VT(0, 0), vcn = VT(0, 1);
-      const float vhat = (0.5f * (dxf_s * vws + dxf_n * vwn) + 0.5f * (dxf_s * vcs + dxf_n * vcn)) * 0.5f * rdxc_j;
-      float zq[6], uq[6], vq[6];
+      const real vws = VT(-1, 0), vwn = VT(-1, 1), vcs = VT(0, 0), vcn = VT(0, 1);
+      const real vhat = (real(0.5) * (dxf_s * vws + dxf_n * vwn) + real(0.5) * (dxf_s * vcs + dxf_n * vcn)) * real(0.5) * rdxc_j;
+      real zq[6], uq[6], vq[6];
 #pragma unroll
       for (int m = 0; m < 6; m++) {
-        float4 t = ZQF(0, m - 2);
+        real4 t = ZQF(0, m - 2);
         zq[m] = t.x;
         uq[m] = t.y;
         vq[m] = t.z;
       }
-      const float hadv = -vhat * biased6<true>(oc_y, vhat > 0.f, zq, uq, vq);
+      const real hadv = -vhat * biased6<true>(oc_y, vhat > real(0.), zq, uq, vq);
 
-      const float uhat = uz[3];
-      float Du[6], Dd[6], Dv6[6];
+      const real uhat = uz[3];
+      real Du[6], Dd[6], Dv6[6];
 #pragma unroll
       for (int m = 0; m < 6; m++) {
-        float2 d = D2C(m - 3, 0);
+        real2 d = D2C(m - 3, 0);
         Du[m] = d.x;
         Dv6[m] = d.y;
         Dd[m] = d.x + d.y;
       }
-      const float dvs = sym_interp(true, Dv6[1], Dv6[2], Dv6[3], Dv6[4]);
-      const float duR = biased6<false>(5, uhat > 0.f, Du, Dd, Dd);
-      const float phi = uhat * (dvs + duR);
+      const real dvs = sym_interp(true, Dv6[1], Dv6[2], Dv6[3], Dv6[4]);
+      const real duR = biased6<false>(5, uhat > real(0.), Du, Dd, Dd);
+      const real phi = uhat * (dvs + duR);
 
-      const float wt = sym_interp(true, Az * WT(-2, 0), Az * WT(-1, 0), Az * WT(0, 0), Az * WT(1, 0));
-      const float ft = wt * biased6<false>(ozt, wt > 0.f, uz + 1, uz + 1, uz + 1);
-      const float vadv = (phi + (ft - fzu)) * (razc_j * rdz);
+      const real wt = sym_interp(true, Az * WT(-2, 0), Az * WT(-1, 0), Az * WT(0, 0), Az * WT(1, 0));
+      const real ft = wt * biased6<false>(ozt, wt > real(0.), uz + 1, uz + 1, uz + 1);
+      const real vadv = (phi + (ft - fzu)) * (razc_j * rdz);
       fzu = ft;
 
-      float u7[7], Ku[6], su[6];
+      real u7[7], Ku[6], su[6];
 #pragma unroll
       for (int m = 0; m < 7; m++) u7[m] = UT(m - 3, 0);
 #pragma unroll
       for (int m = 0; m < 6; m++) {
-        Ku[m] = 0.5f * u7[m + 1] * u7[m + 1] - 0.5f * u7[m] * u7[m];
-        su[m] = 0.5f * (u7[m] + u7[m + 1]);
+        Ku[m] = real(0.5) * u7[m + 1] * u7[m + 1] - real(0.5) * u7[m] * u7[m];
+        su[m] = real(0.5) * (u7[m] + u7[m + 1]);
       }
-      const float dKu = biased6<false>(5, uhat > 0.f, Ku, su, su);
-      float a4[4];
+      const real dKu = biased6<false>(5, uhat > real(0.), Ku, su, su);
+      real a4[4];
 #pragma unroll
       for (int m = 0; m < 4; m++) {
-        float vc = VT(0, m - 1), vw = VT(-1, m - 1);
-        a4[m] = 0.5f * vc * vc - 0.5f * vw * vw;
+        real vc = VT(0, m - 1), vw = VT(-1, m - 1);
+        a4[m] = real(0.5) * vc * vc - real(0.5) * vw * vw;
       }
-      const float dKv = sym_interp(s4c_y, a4[0], a4[1], a4[2], a4[3]);
-      const float bern = (dKu + dKv) * rdxc_j;
-      const float cor = -fbar * vhat;
-      const float dpdx = pw_ * rdxc_j;
+      const real dKv = sym_interp(s4c_y, a4[0], a4[1], a4[2], a4[3]);
+      const real bern = (dKu + dKv) * rdxc_j;
+      const real cor = -fbar * vhat;
+      const real dpdx = pw_ * rdxc_j;
       gu = -(hadv + vadv + bern) - cor - dpdx;
     }
     {  // ---------------- G_v at (c,f,c)
-      const float uhat =
-          (0.5f * (dy * UT(0, -1) + dy * UT(1, -1)) + 0.5f * (dy * UT(0, 0) + dy * UT(1, 0))) * 0.5f * g.rdy;
-      float zq[6], uq[6], vq[6];
+      const real uhat =
+          (real(0.5) * (dy * UT(0, -1) + dy * UT(1, -1)) + real(0.5) * (dy * UT(0, 0) + dy * UT(1, 0))) * real(0.5) * g.rdy;
+      real zq[6], uq[6], vq[6];
 #pragma unroll
       for (int m = 0; m < 6; m++) {
-        float4 t = ZQF(m - 2, 0);
+        real4 t = ZQF(m - 2, 0);
         zq[m] = t.x;
         uq[m] = t.y;
         vq[m] = t.z;
       }
-      const float hadv = uhat * biased6<true>(5, uhat > 0.f, zq, uq, vq);
+      const real hadv = uhat * biased6<true>(5, uhat > real(0.), zq, uq, vq);
 
-      const float vhat = vz[3];
-      float Dv[6], Dd[6], Du6[6];
+      const real vhat = vz[3];
+      real Dv[6], Dd[6], Du6[6];
 #pragma unroll
       for (int m = 0; m < 6; m++) {
-        float2 d = D2C(0, m - 3);
+        real2 d = D2C(0, m - 3);
         Du6[m] = d.x;
         Dv[m] = d.y;
         Dd[m] = d.x + d.y;
       }
-      const float dus = sym_interp(s4f_y, Du6[1], Du6[2], Du6[3], Du6[4]);
-      const float dvR = biased6<false>(of_y, vhat > 0.f, Dv, Dd, Dd);
-      const float phi = vhat * (dus + dvR);
+      const real dus = sym_interp(s4f_y, Du6[1], Du6[2], Du6[3], Du6[4]);
+      const real dvR = biased6<false>(of_y, vhat > real(0.), Dv, Dd, Dd);
+      const real phi = vhat * (dus + dvR);
 
-      const float wt = sym_interp(s4f_y, az_m2 * WT(0, -2), az_m1 * WT(0, -1), Az * WT(0, 0), az_p1 * WT(0, 1));
-      const float ft = wt * biased6<false>(ozt, wt > 0.f, vz + 1, vz + 1, vz + 1);
-      const float vadv = (phi + (ft - fzv)) * (razf_j * rdz);
+      const real wt = sym_interp(s4f_y, az_m2 * WT(0, -2), az_m1 * WT(0, -1), Az * WT(0, 0), az_p1 * WT(0, 1));
+      const real ft = wt * biased6<false>(ozt, wt > real(0.), vz + 1, vz + 1, vz + 1);
+      const real vadv = (phi + (ft - fzv)) * (razf_j * rdz);
       fzv = ft;
 
-      float v7[7], Kv[6], sv[6];
+      real v7[7], Kv[6], sv[6];
 #pragma unroll
       for (int m = 0; m < 7; m++) v7[m] = VT(0, m - 3);
 #pragma unroll
       for (int m = 0; m < 6; m++) {
-        Kv[m] = 0.5f * v7[m + 1] * v7[m + 1] - 0.5f * v7[m] * v7[m];
-        sv[m] = 0.5f * (v7[m] + v7[m + 1]);
+        Kv[m] = real(0.5) * v7[m + 1] * v7[m + 1] - real(0.5) * v7[m] * v7[m];
+        sv[m] = real(0.5) * (v7[m] + v7[m + 1]);
       }
-      const float dKv = biased6<false>(of_y, vhat > 0.f, Kv, sv, sv);
-      float a4[4];
+      const real dKv = biased6<false>(of_y, vhat > real(0.), Kv, sv, sv);
+      real a4[4];
 #pragma unroll
       for (int m = 0; m < 4; m++) {
-        float un = UT(m - 1, 0), us = UT(m - 1, -1);
-        a4[m] = 0.5f * un * un - 0.5f * us * us;
+        real un = UT(m - 1, 0), us = UT(m - 1, -1);
+        a4[m] = real(0.5) * un * un - real(0.5) * us * us;
       }
-      const float dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
-      const float bern = (dKv + dKu) * g.rdy;
-      const float cor = fcor_j * uhat;
-      const float dpdy = ps_ * g.rdy;
+      const real dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
+      const real bern = (dKv + dKu) * g.rdy;
+      const real cor = fcor_j * uhat;
+      const real dpdy = ps_ * g.rdy;
       gv = -(hadv + vadv + bern) - cor - dpdy;
     }
 #undef UT

@@ -83,8 +83,9 @@ class SlabStepper:
         self.send, self.recv = {}, {}
         for group in GROUPS:
             n = backend.halo_buffer_elems(group)
-            self.send[group] = [torch.empty(n, dtype=torch.float32, device=device) for _ in range(2)]
-            self.recv[group] = [torch.empty(n, dtype=torch.float32, device=device) for _ in range(2)]
+            dt = torch.float64 if np.dtype(getattr(backend, "dtype", np.float32)).itemsize == 8 else torch.float32
+            self.send[group] = [torch.empty(n, dtype=dt, device=device) for _ in range(2)]
+            self.recv[group] = [torch.empty(n, dtype=dt, device=device) for _ in range(2)]
         self.cuda = device.type == "cuda"
         if self.cuda:
             self.main = torch.cuda.current_stream(device)

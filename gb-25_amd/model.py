@@ -134,7 +134,8 @@ class HydrostaticFreeSurfaceModel:
 
     def __repr__(self):
         Nx, Ny, Nz = self.grid.size
-        return f"HydrostaticFreeSurfaceModel({Nx}x{Ny}x{Nz} LatitudeLongitudeGrid, halo {self.grid.halo}, fp32, MI355X)"
+        return (f"HydrostaticFreeSurfaceModel({Nx}x{Ny}x{Nz} LatitudeLongitudeGrid, halo {self.grid.halo}, "
+                f"{np.dtype(getattr(self.backend, 'dtype', np.float32)).name}, MI355X)")
 
 
 def resolution_to_points(resolution):

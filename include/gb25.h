@@ -19,7 +19,11 @@
  *     V, Vbar, G.V:                                            (Nx+2H, Ny+2H+1, 1)
  * (*) x is periodic, so u has Nx faces.  With an x-slab decomposition Nx is the
  * LOCAL slab width (Nx_global / nranks) and the x halos hold the neighbours' columns.
- * All data are fp32 (simulations/baroclinic_instability_simulation_run.jl:13).
+ * Element type: the library is built once per Oceananigans float type -- libgb25hip.so holds Float32
+ * (simulations/baroclinic_instability_simulation_run.jl:13, the headline runs) and libgb25hip_f64.so Float64
+ * (the default of --float-type, src/arg_parsing.jl:12-16, used by the correctness scripts).  Both export the
+ * same symbols; gb25_real_bytes() tells which one is loaded, and every `void *` data pointer below addresses
+ * elements of that size.
  */
 #ifndef GB25_H
 #define GB25_H
@@ -94,6 +98,7 @@ gb25_status gb25_create(const gb25_config *cfg, gb25_model **out);
 void gb25_destroy(gb25_model *m);
 const char *gb25_last_error_string(const gb25_model *m); /* valid until the next call on m */
 const char *gb25_version(void);
+int32_t gb25_real_bytes(void); /* sizeof one field element of THIS library: 4 (Float32) or 8 (Float64) */
 
 /* Run all kernels of this model on the caller's HIP stream (a hipStream_t passed as void*; NULL is HIP's
  * default stream, which is what torch.cuda.current_stream() is unless the host changed it).  Lets a host
@@ -107,8 +112,8 @@ gb25_status gb25_synchronize(gb25_model *m);
  *      (src/correctness.jl:92-103).  dims = parent dims (include_halos != 0) or interior dims.
  *      Host pointers are borrowed for the duration of the call. */
 gb25_status gb25_field_dims(const gb25_model *m, gb25_field f, int include_halos, int32_t dims[3]);
-gb25_status gb25_set_field(gb25_model *m, gb25_field f, const float *host, int include_halos);
-gb25_status gb25_get_field(gb25_model *m, gb25_field f, float *host, int include_halos);
+gb25_status gb25_set_field(gb25_model *m, gb25_field f, const void *host, int include_halos);
+gb25_status gb25_get_field(gb25_model *m, gb25_field f, void *host, int include_halos);
 /* Device pointer of parent(field) for zero-copy wrapping (e.g. unsafe_wrap(ROCArray, ...)).
  * G^n / G^- pointers are exchanged by correct_and_cache (a pointer swap replaces the copy). */
 gb25_status gb25_field_device_ptr(gb25_model *m, gb25_field f, void **dev);
@@ -152,9 +157,9 @@ gb25_status gb25_loop(gb25_model *m, int32_t n_inner);
  *      group 2: H columns of eta, U, V                                        -> x halos
  *      side: 0 = west, 1 = east.  For pack, `side` is the side of THIS slab whose interior columns are packed;
  *      for unpack it is the halo side that is filled. */
-gb25_status gb25_halo_buffer_elems(const gb25_model *m, int group, int64_t *n_floats);
-gb25_status gb25_halo_pack(gb25_model *m, int group, int side, float *dev_buffer);
-gb25_status gb25_halo_unpack(gb25_model *m, int group, int side, const float *dev_buffer);
+gb25_status gb25_halo_buffer_elems(const gb25_model *m, int group, int64_t *n_elements);
+gb25_status gb25_halo_pack(gb25_model *m, int group, int side, void *dev_buffer);
+gb25_status gb25_halo_unpack(gb25_model *m, int group, int side, const void *dev_buffer);
 /* The time step of one slab, cut at its exchange points (gb25_time_step does all of it when nranks == 1):
  *   stage 0: AB2 update of u,v,T,S, barotropic forcing, y/z layers of the 3-D bundle
  *            -> pack + exchange group 1 (critical path) and group 0 (overlaps with stage 1 on a second stream)

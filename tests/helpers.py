@@ -28,9 +28,9 @@ def set_noisy_velocities(model, amplitude=1e-3, seed=42):
     return ui, vi
 
 
-def make_pair(Nx, Ny, Nz, dt, precision="f64", **kw):
+def make_pair(Nx, Ny, Nz, dt, precision="f64", float_type="Float32", **kw):
     """(HIP model, oracle model) with the same configuration, like rmodel / vmodel of the reference."""
-    rmodel = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt, **kw)
+    rmodel = gb.baroclinic_instability_model(gb.GPU(float_type=float_type), Nx, Ny, Nz, dt=dt, **kw)
     vmodel = gb.baroclinic_instability_model(CPU(precision), Nx, Ny, Nz, dt=dt, **kw)
     return rmodel, vmodel
 
@@ -39,6 +39,7 @@ def make_oracle(Nx, Ny, Nz, dt, precision="f64", **kw):
     return gb.baroclinic_instability_model(CPU(precision), Nx, Ny, Nz, dt=dt, **kw)
 
 
+SQRT_EPS64 = float(np.sqrt(np.finfo(np.float64).eps))   # 1.4901e-8: the reference's rtol for Float64
 SQRT_EPS32 = float(np.sqrt(np.finfo(np.float32).eps))   # 3.4527e-4: the reference's rtol for Float32
 # One tolerance for every compared field (state AND tendencies), as in the reference.  It is attainable in fp32
 # because the hydrostatic pressure (equation of state + vertical integral) is evaluated in fp64 inside the GPU

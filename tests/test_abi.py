@@ -12,10 +12,10 @@ from gb25_amd import binding
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def lib():
+@pytest.fixture(scope="module", params=["Float32", "Float64"])
+def lib(request):
     gb.build_library()
-    return binding.load_library()
+    return binding.load_library(request.param)
 
 
 def declared_symbols():
@@ -50,6 +50,15 @@ def test_no_cpu_fallback_without_device(lib):
         gb.baroclinic_instability_model(gb.GPU(), 32, 16, 8, dt=1.0)
 
 
-def test_code_object_targets_gfx950(lib):
-    blob = open(binding.LIB_PATH, "rb").read()
+def test_element_size_matches_the_float_type(lib):
+    assert lib.gb25_real_bytes() == (8 if b"Float64" in lib.gb25_version() else 4)
+    assert binding.load_library("Float32").gb25_real_bytes() == 4
+    assert binding.load_library("Float64").gb25_real_bytes() == 8
+    with pytest.raises(binding.GB25Error):
+        binding.load_library("Float16")
+
+
+@pytest.mark.parametrize("float_type", ["Float32", "Float64"])
+def test_code_object_targets_gfx950(float_type):
+    blob = open(binding.LIB_PATHS[float_type], "rb").read()
     assert b"gfx950" in blob and b"k_gu" in blob
