@@ -51,6 +51,13 @@ __device__ __forceinline__ int iv(const Grid& g, int i, int j, int k) {
 }
 __device__ __forceinline__ int i2(const Grid& g, int i, int j) { return (i + g.H) + g.sx * (j + g.H); }
 
+__device__ __forceinline__ float rfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double rfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// ab2_step_field!: phi + dt (C1 G^n - C2 G^-).  Spelled with explicit FMAs so that every kernel that advances a
+// field (the stand-alone AXPY kernels and the tendency kernels that pre-advance the next step) rounds identically.
+__device__ __forceinline__ real ab2_advance(real phi, real gn, real gm, real dt, real C1, real C2) {
+  return rfma(dt, rfma(C1, gn, -(C2 * gm)), phi);
+}
 // reciprocal: the 1-ulp hardware approximation in fp32, a true division in fp64
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }

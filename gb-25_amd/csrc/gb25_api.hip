@@ -44,6 +44,12 @@ struct gb25_model {
   Field dpx, dpy;                // p'(i)-p'(i-1), p'(j)-p'(j-1), differenced in fp64 by k_compute_p, stored fp32
   Field colsum[2];               // column integrals of u, v after the AB2 update (consumed by the corrector)
   bool colsum_valid = false;
+  // AB2 look-ahead (kernels_v2.hpp, Ab2Ahead): the tracer tendency kernel also writes T, S of the next time level
+  // into `ahead`; ab2_step! adopts them by pointer exchange when dt, chi and every input are still the same.
+  Field ahead[2];
+  bool ahead_valid = false, ptr_exposed = false;
+  real ahead_dt = 0, ahead_chi = 0;
+  int ab2_ahead = 1;                 // GB25_AB2_AHEAD=0: always run the stand-alone tracer AXPY kernel
   real* bars = nullptr;         // contiguous etabar | Ubar | Vbar
   std::vector<real*> dev_tables;
   std::vector<double> h_metric[11];
@@ -474,14 +480,29 @@ gb25_status tracers_impl(gb25_model* m) {
     const int kchunks = std::max(1, g.Nz / 12);
     nb = nbx * nby * kchunks;
     constexpr int TW = sizeof(real) == 8 ? 3 : 5;   // see MW in momentum_impl
-    auto kern = m->variant_a == 6 ? k_tracer_tendencies_v3<6>
-                                  : (m->variant_a == 7 ? k_tracer_tendencies_v3<7> : k_tracer_tendencies_v3<TW>);
+    const bool ahead = m->ab2_ahead && !m->ptr_exposed;
+    Ab2Ahead nx{};
+    if (ahead) {   // predicted parameters of the next ab2_step!: the clock's dt and the model's chi
+      nx.GmT = m->f[GB25_GM_T].d; nx.GmS = m->f[GB25_GM_S].d;
+      nx.Tn = m->ahead[0].d; nx.Sn = m->ahead[1].d;
+      nx.dt = (real)m->last_dt;
+      nx.C1 = real(1.5) + (real)m->cfg.chi; nx.C2 = real(0.5) + (real)m->cfg.chi;
+    }
+    auto kern = m->variant_a == 6 ? k_tracer_tendencies_v3<6, false>
+                                  : (m->variant_a == 7 ? k_tracer_tendencies_v3<7, false>
+                                                       : (ahead ? k_tracer_tendencies_v3<TW, true>
+                                                                : k_tracer_tendencies_v3<TW, false>));
+    const bool ahead_run = ahead && m->variant_a != 6 && m->variant_a != 7;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64, 4), 0, m->stream, g, m->f[GB25_U].d,
                        m->f[GB25_V].d, m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d,
-                       m->f[GB25_GN_S].d, nbx, kchunks, nb);
+                       m->f[GB25_GN_S].d, nbx, kchunks, nb, nx);
     LAUNCHCHK();
+    m->ahead_valid = ahead_run;
+    m->ahead_dt = nx.dt;
+    m->ahead_chi = (real)m->cfg.chi;
     return GB25_OK;
   }
+  m->ahead_valid = false;   // only the v3 kernel looks ahead
   if (m->kernel_gen >= 2) {
     Timed t(m, GB25_K_TRACERS);
     nbx = (g.Nx + V2_TX - 1) / V2_TX;
@@ -518,6 +539,14 @@ gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
 }
 gb25_status ab2_tracers_impl(gb25_model* m, real dt, real chi) {
   const Grid& g = m->g;
+  if (m->ahead_valid && dt == m->ahead_dt && chi == m->ahead_chi) {
+    // the last tendency evaluation already advanced T and S with exactly these parameters
+    std::swap(m->f[GB25_T].d, m->ahead[0].d);
+    std::swap(m->f[GB25_S].d, m->ahead[1].d);
+    m->ahead_valid = false;
+    return GB25_OK;
+  }
+  m->ahead_valid = false;
   Timed t(m, GB25_K_AB2_TRACERS);
   const real C1 = real(1.5) + chi, C2 = real(0.5) + chi;
   size_t off = (size_t)g.H * g.pl_c;
@@ -631,6 +660,7 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false) {
   // cache_previous_tendencies!: G^- <- G^n is a pointer exchange; the next tendency evaluation
   // overwrites the (old G^-) buffers that now carry the G^n name.
   for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);
+  m->ahead_valid = false;   // the look-ahead used the tendency pair as it was before this exchange
   return GB25_OK;
 }
 
@@ -771,6 +801,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   if (const char* e = getenv("GB25_VARIANT_A")) m->variant_a = atoi(e);
   if (const char* e = getenv("GB25_VARIANT_B")) m->variant_b = atoi(e);
   if (const char* e = getenv("GB25_VARIANT_C")) m->variant_c = atoi(e);
+  if (const char* e = getenv("GB25_AB2_AHEAD")) m->ab2_ahead = atoi(e);
   gb25_status s;
   if ((s = build_grid(m))) return s;
   if ((s = build_eos_tables(m))) return s;
@@ -794,6 +825,8 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     if ((s = alloc_field(m, m->pp[q], sx, m->f[GB25_ETA + q].ny, 1))) return s;
   if ((s = alloc_field(m, m->dpx, m->f[GB25_PHY].nx, m->f[GB25_PHY].ny, m->f[GB25_PHY].nz))) return s;
   if ((s = alloc_field(m, m->dpy, m->f[GB25_PHY].nx, m->f[GB25_PHY].ny, m->f[GB25_PHY].nz))) return s;
+  for (int q = 0; q < 2; q++)
+    if ((s = alloc_field(m, m->ahead[q], m->f[GB25_T].nx, m->f[GB25_T].ny, m->f[GB25_T].nz))) return s;
   if ((s = alloc_field(m, m->colsum[0], sx, m->f[GB25_BT_U].ny, 1))) return s;
   if ((s = alloc_field(m, m->colsum[1], sx, m->f[GB25_BT_V].ny, 1))) return s;
   if (cfg->nranks > 1) {
@@ -824,6 +857,8 @@ void gb25_destroy(gb25_model* m) {
   for (auto& p : m->pp)
     if (p.d) hipFree(p.d);
   for (auto& p : m->colsum)
+    if (p.d) hipFree(p.d);
+  for (auto& p : m->ahead)
     if (p.d) hipFree(p.d);
   for (int a = 0; a < 2; a++) {
     for (auto& w : m->wide[a])
@@ -912,9 +947,22 @@ static gb25_status widen_phy(gb25_model* m) {   // the host uploaded pHY': rebui
   LAUNCHCHK();
   return GB25_OK;
 }
+// T and S alternate between two buffers (AB2 look-ahead).  Whatever the host writes into one, halos included, goes
+// into the partner too, so that the halo layers no kernel ever rewrites are the same in both.
+static gb25_status mirror_tracers(gb25_model* m) {
+  m->ahead_valid = false;
+  for (int q = 0; q < 2; q++)
+    HIPCHK(hipMemcpyAsync(m->ahead[q].d, m->f[GB25_T + q].d, m->f[GB25_T + q].elems() * sizeof(real),
+                          hipMemcpyDeviceToDevice, m->stream));
+  return GB25_OK;
+}
 gb25_status gb25_set_field(gb25_model* m, gb25_field f, const void* host, int include_halos) {
   gb25_status s = copy_field(m, f, static_cast<real*>(const_cast<void*>(host)), include_halos, true);
   if (s == GB25_OK && f == GB25_PHY) s = widen_phy(m);
+  if (s == GB25_OK) {
+    m->ahead_valid = false;   // any input of the look-ahead may have changed
+    if (f == GB25_T || f == GB25_S) s = mirror_tracers(m);
+  }
   return s;
 }
 gb25_status gb25_get_field(gb25_model* m, gb25_field f, void* host_, int include_halos) {
@@ -923,6 +971,12 @@ gb25_status gb25_get_field(gb25_model* m, gb25_field f, void* host_, int include
 }
 gb25_status gb25_field_device_ptr(gb25_model* m, gb25_field id, void** dev) {
   if (!m || id < 0 || id >= GB25_FIELD_COUNT || !dev) return GB25_ERR_INVALID_ARGUMENT;
+  if (id == GB25_T || id == GB25_S || id == GB25_GN_T || id == GB25_GN_S || id == GB25_GM_T || id == GB25_GM_S) {
+    // the host can now write T, S or their tendencies behind our back: no more look-ahead for this model,
+    // T and S stay in the buffers whose addresses are handed out
+    m->ptr_exposed = true;
+    m->ahead_valid = false;
+  }
   *dev = m->f[id].d;
   return GB25_OK;
 }
@@ -948,7 +1002,7 @@ gb25_status gb25_set_baroclinic_instability(gb25_model* m) {
   hipLaunchKernelGGL(k_set_baroclinic_instability, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, m->stream, g,
                      m->f[GB25_T].d, m->f[GB25_S].d);
   LAUNCHCHK();
-  return GB25_OK;
+  return mirror_tracers(m);
 }
 
 gb25_status gb25_get_clock(const gb25_model* m, double* time, int64_t* it, double* last_dt) {

@@ -492,8 +492,11 @@ __global__ void k_ab2_tracers4(real4* __restrict__ T_, real4* __restrict__ S_, c
       hn = GnS[t];
       hm = GmS[t];
     }
-    a += dt * (C1 * gn - C2 * gm);
-    b += dt * (C1 * hn - C2 * hm);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      a[e] = ab2_advance(a[e], gn[e], gm[e], dt, C1, C2);
+      b[e] = ab2_advance(b[e], hn[e], hm[e], dt, C1, C2);
+    }
     T[t] = a;
     S[t] = b;
   }
@@ -504,8 +507,8 @@ __global__ void k_ab2_tracers1(real* __restrict__ T, real* __restrict__ S, const
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long stride = (long)gridDim.x * blockDim.x;
   for (; t < n; t += stride) {
-    T[t] += dt * (C1 * GnT[t] - C2 * GmT[t]);
-    S[t] += dt * (C1 * GnS[t] - C2 * GmS[t]);
+    T[t] = ab2_advance(T[t], GnT[t], GmT[t], dt, C1, C2);
+    S[t] = ab2_advance(S[t], GnS[t], GmS[t], dt, C1, C2);
   }
 }
 

@@ -484,13 +484,22 @@ namespace gb25 {
 // =============================================================================================
 constexpr int V3_OUT = 63;   // outputs per wavefront
 
-template <int MINW>
+// AHEAD: the kernel also writes the tracers of the next time level, Tn = T + dt (C1 G^n - C2 G^-), into a second
+// pair of arrays: at this point T and the fresh G^n are in registers, so the next step's ab2_step_field! for T and S
+// costs one read (G^-) and one write per tracer here instead of a separate 3R + 1W sweep.  The host adopts Tn/Sn
+// (pointer exchange) at the next ab2_step! if dt, chi and the inputs are still the ones used here.
+struct Ab2Ahead {
+  const real *GmT, *GmS;
+  real *Tn, *Sn;
+  real dt, C1, C2;
+};
+template <int MINW, bool AHEAD>
 __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v3(Grid g, const real* __restrict__ u,
                                                               const real* __restrict__ v,
                                                               const real* __restrict__ w,
                                                               const real* __restrict__ T, const real* __restrict__ S,
                                                               real* __restrict__ GT, real* __restrict__ GS, int nbx,
-                                                              int kchunks, int nb) {
+                                                              int kchunks, int nb, Ab2Ahead next) {
   const int L = xcd_remap(blockIdx.x, nb);
   const int bx = L % nbx, r = L / nbx;
   const int kc = r % kchunks, by = r / kchunks;
@@ -549,8 +558,14 @@ __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v3(Grid g, cons
     const real feT = __shfl_down(fxT, 1), feS = __shfl_down(fxS, 1);
     if (writes) {
       const real rV = razc_j * g.rdzc[k];
-      GT[o] = -(((feT - fxT) + (fnT - fsT) + (ftT - fzT)) * rV);
-      GS[o] = -(((feS - fxS) + (fnS - fsS) + (ftS - fzS)) * rV);
+      const real gT = -(((feT - fxT) + (fnT - fsT) + (ftT - fzT)) * rV);
+      const real gS = -(((feS - fxS) + (fnS - fsS) + (ftS - fzS)) * rV);
+      GT[o] = gT;
+      GS[o] = gS;
+      if (AHEAD) {   // T, S of the NEXT step while T, S (tz[3], sz[3]) and the new tendency are in registers
+        next.Tn[o] = ab2_advance(tz[3], gT, __builtin_nontemporal_load(&next.GmT[o]), next.dt, next.C1, next.C2);
+        next.Sn[o] = ab2_advance(sz[3], gS, __builtin_nontemporal_load(&next.GmS[o]), next.dt, next.C1, next.C2);
+      }
     }
     fzT = ftT;
     fzS = ftS;

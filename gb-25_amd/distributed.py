@@ -6,8 +6,8 @@ XLA collective-permutes; here each time step has three explicit point-to-point e
 the large one hidden behind the barotropic sub-cycle on a second HIP stream:
 
     stage 0   AB2 update of u,v,T,S + barotropic forcing, y/z layers of the 3-D bundle            (compute stream)
+    group 1   W = Ns+1 columns of eta,U,V,G.U,G.V -> wide barotropic halos (posted first)         (compute stream)
     group 0   H columns of u,v,T,S          -> x halos        packed + sent on the COMM stream, in flight during stage 1
-    group 1   W = Ns+1 columns of eta,U,V,G.U,G.V -> wide barotropic halos                        (compute stream)
     stage 1   Ns split-explicit substeps on the widened slab (no exchange inside the sub-cycle)   (compute stream)
     group 2   H columns of eta,U,V          -> x halos                                            (compute stream)
     stage 2   [wait for group 0] corrector (also in the halo columns), w, p', tendencies          (compute stream)
@@ -106,15 +106,20 @@ class SlabStepper:
 
 
 class _OnComm:
-    """Context: torch's current stream = the comm stream of the steppers (no-op on CPU test doubles)."""
+    """Context: torch's current stream = the comm stream of the steppers (no-op on CPU test doubles).
+    `after` is an event recorded on the compute stream: the comm stream starts once it has completed."""
 
-    def __init__(self, steppers):
+    def __init__(self, steppers, after=None):
         self.s = steppers[0]
+        self.after = after
         self.ctx = None
 
     def __enter__(self):
         if self.s.cuda:
-            self.s.comm.wait_stream(self.s.main)      # everything stage 0 wrote is visible to the comm stream
+            if self.after is not None:
+                self.s.comm.wait_event(self.after)    # everything stage 0 wrote is visible to the comm stream
+            else:
+                self.s.comm.wait_stream(self.s.main)
             self.ctx = torch.cuda.stream(self.s.comm)
             self.ctx.__enter__()
 
@@ -130,11 +135,16 @@ def _run_stage(steppers, fn):
 
 def step_slabs(steppers, exchange, euler=False):
     """One time step of a list of slabs (a single one in the multi-process case)."""
-    _run_stage(steppers, lambda s: (s.b.time_step_stage(0, euler), s.pack(1)))
-    with _OnComm(steppers):                       # the 3-D bundle leaves on the second stream ...
+    _run_stage(steppers, lambda s: s.b.time_step_stage(0, euler))
+    stage0_done = steppers[0].main.record_event() if steppers[0].cuda else None
+    # The small barotropic exchange is on the critical path and is posted FIRST: a process group's point-to-point
+    # transfers share one RCCL stream and run in posting order, so the 6 MB bundle must not be queued ahead of it.
+    _run_stage(steppers, lambda s: s.pack(1))
+    exchange(1)
+    with _OnComm(steppers, stage0_done):          # the 3-D bundle leaves on the second stream ...
         _run_stage(steppers, lambda s: s.pack(0, on_comm=True))
         exchange(0)
-    exchange(1)                                   # ... while the barotropic halos and the sub-cycle run here
+    # ... and is in flight while the sub-cycle runs here
     _run_stage(steppers, lambda s: (s.unpack(1), s.b.time_step_stage(1, euler), s.pack(2)))
     exchange(2)
     if steppers[0].cuda:

@@ -97,13 +97,14 @@ def test_time_step_sequencing_and_local_ring():
                     ("unpack", 2, WEST), ("unpack", 2, EAST), ("unpack", 0, WEST), ("unpack", 0, EAST),
                     ("stage", 2, False)]
     # exchanges happen once per group, between the pack of every slab and the unpack of any slab;
-    # the 3-D bundle (group 0) is posted first so that it is in flight during the sub-cycle (stage 1)
+    # the small barotropic exchange (group 1, critical path) is posted first, then the 3-D bundle (group 0),
+    # which stays in flight during the sub-cycle (stage 1)
     ex = [i for i, e in enumerate(log) if e[0] == "exchange"]
-    assert [log[i][1] for i in ex] == [0, 1, 2]
+    assert [log[i][1] for i in ex] == [1, 0, 2]
     stage1 = min(i for i, e in enumerate(log) if e[0] != "exchange" and e[1:3] == ("stage", 1))
     unpack0 = min(i for i, e in enumerate(log) if e[0] != "exchange" and e[1:3] == ("unpack", 0))
-    assert ex[0] < stage1 < unpack0
-    for i, grp in zip(ex, (0, 1, 2)):
+    assert ex[1] < stage1 < unpack0
+    for i, grp in zip(ex, (1, 0, 2)):
         assert all(not (e[1] == "unpack" and e[2] == grp) for e in log[:i] if e[0] != "exchange")
         assert all(not (e[1] == "pack" and e[2] == grp) for e in log[i:] if e[0] != "exchange")
     # data: my west halo holds the west neighbour's EAST pack, my east halo the east neighbour's WEST pack

@@ -274,6 +274,63 @@ def test_v2_lds_kernels_match_v1_direct_kernels(monkeypatch):
         assert rel(a, b) < 2e-6, (n, rel(a, b))
 
 
+def test_ab2_lookahead_is_bitwise_neutral(monkeypatch):
+    """The tracer tendency kernel writes T, S of the next time level ahead of ab2_step! (Ab2Ahead); the step then
+    adopts them by pointer exchange.  Same bits as the stand-alone AXPY kernel (GB25_AB2_AHEAD=0), halos included,
+    across everything that must invalidate the look-ahead: a changed dt, host writes into T / G, an Euler restart,
+    phase-by-phase driving, and a handed-out device pointer."""
+    monkeypatch.setenv("GB25_AB2_AHEAD", "0")
+    a = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0)
+    monkeypatch.setenv("GB25_AB2_AHEAD", "1")
+    b = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0)
+    c = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0)   # will hand out its T pointer
+    names = ALL_FIELDS
+
+    def same(label):
+        for n in names:
+            x = a.backend.get_field(n, True)
+            assert np.array_equal(x, b.backend.get_field(n, True)), (label, n)
+            assert np.array_equal(x, c.backend.get_field(n, True)), (label, n, "exposed pointer")
+
+    for m in (a, b, c):
+        gb.set_baroclinic_instability(m)
+        set_noisy_velocities(m, 0.05)
+        # values in the halo layers that no kernel ever rewrites must survive the buffer alternation
+        T = m.backend.get_field("T", True)
+        T[:, :3, :] = 1.25
+        T[:, :, -3:] = -2.5
+        m.backend.set_field("T", T, True)
+        gb.first_time_step(m)
+        gb.loop(m, 3)
+    same("plain steps")
+    assert c.backend.field_device_ptr("T")
+    for m in (a, b, c):
+        m.backend.set_dt(450.0)                       # dt differs from the one the look-ahead assumed
+        gb.time_step(m)
+        gb.time_step(m)
+    same("after set_dt")
+    S = a.backend.get_field("S", False) + np.float32(0.125)
+    g = a.backend.get_field("Gn.T", True) * np.float32(1.5)
+    for m in (a, b, c):
+        m.backend.set_field("S", S, False)            # host writes into a tracer and into a tendency
+        m.backend.set_field("Gn.T", g, True)
+        gb.time_step(m)
+        gb.time_step(m)
+    same("after host writes")
+    for m in (a, b, c):
+        gb.first_time_step(m)                         # Euler step: chi differs from the look-ahead's
+        m.backend.ab2_step(450.0, False)              # phase by phase
+        m.backend.fill_halo_regions()
+        m.backend.correct_velocities_and_cache_previous_tendencies(450.0)
+        m.backend.update_state()
+        m.backend.compute_tracer_tendencies()         # a second evaluation must not advance twice
+        gb.time_step(m)
+    same("after Euler restart and phase-by-phase driving")
+    p0 = c.backend.field_device_ptr("T")
+    gb.time_step(c)
+    assert c.backend.field_device_ptr("T") == p0      # pinned once handed out
+
+
 @pytest.mark.parametrize("shape,halo", [((16, 9, 4), 4), ((24, 9, 5), 5), ((70, 13, 7), 8), ((8, 10, 4), 8)])
 def test_minimum_sizes_and_halos(shape, halo):
     """Smallest useful extents (Ny = 8 is excluded: with 20-degree rows the first latitude halo mirrors exactly
