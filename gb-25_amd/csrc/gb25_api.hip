@@ -33,6 +33,28 @@ struct EventPair {
   hipEvent_t a, b;
 };
 
+// Everything a time step changes on the HOST side (the device work is in the kernels): which buffer carries which
+// name after the pointer exchanges, and the validity flags of the cached by-products.
+struct HostState {
+  real* ptr[14];   // G^n/G^- of u,v,T,S (8), T, S and their look-ahead partners (4), column integrals (2)
+  bool ahead_valid, colsum_valid;
+  real ahead_dt, ahead_chi;
+  bool operator==(const HostState& o) const {
+    for (int q = 0; q < 14; q++)
+      if (ptr[q] != o.ptr[q]) return false;
+    return ahead_valid == o.ahead_valid && colsum_valid == o.colsum_valid &&
+           (!ahead_valid || (ahead_dt == o.ahead_dt && ahead_chi == o.ahead_chi));
+  }
+};
+// One captured time step: valid when the model is in state `pre` with the same dt and stream; leaves it in `post`.
+struct StepGraph {
+  HostState pre, post;
+  double dt;
+  hipStream_t stream;
+  hipGraphExec_t exec;
+  hipGraph_t graph;
+};
+
 }  // namespace
 
 struct gb25_model {
@@ -49,6 +71,9 @@ struct gb25_model {
   Field ahead[2];
   bool ahead_valid = false, ptr_exposed = false;
   real ahead_dt = 0, ahead_chi = 0;
+  int use_graphs = 0;                // GB25_GRAPH=1: replay a captured HIP graph of the step (see step_with_graph)
+  std::vector<StepGraph> graphs;
+  std::vector<HostState> seen;       // states met once: a state is captured when it comes round again
   int ab2_ahead = 1;                 // GB25_AB2_AHEAD=0: always run the stand-alone tracer AXPY kernel
   real* bars = nullptr;         // contiguous etabar | Ubar | Vbar
   std::vector<real*> dev_tables;
@@ -802,6 +827,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   if (const char* e = getenv("GB25_VARIANT_B")) m->variant_b = atoi(e);
   if (const char* e = getenv("GB25_VARIANT_C")) m->variant_c = atoi(e);
   if (const char* e = getenv("GB25_AB2_AHEAD")) m->ab2_ahead = atoi(e);
+  if (const char* e = getenv("GB25_GRAPH")) m->use_graphs = atoi(e);
   gb25_status s;
   if ((s = build_grid(m))) return s;
   if ((s = build_eos_tables(m))) return s;
@@ -849,6 +875,10 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
 void gb25_destroy(gb25_model* m) {
   if (!m) return;
   if (m->own_stream) hipStreamSynchronize(m->own_stream);
+  for (auto& e : m->graphs) {
+    hipGraphExecDestroy(e.exec);
+    hipGraphDestroy(e.graph);
+  }
   for (int id = 0; id < GB25_FIELD_COUNT; id++)
     if (!(id >= GB25_ETA_BAR && id <= GB25_V_BAR) && m->f[id].d) hipFree(m->f[id].d);
   if (m->bars) hipFree(m->bars);
@@ -1060,6 +1090,85 @@ gb25_status gb25_update_state_local(gb25_model* m) {
   return tracers_impl(m);
 }
 
+// ---- HIP-graph replay of the AB2 time step (opt-in: GB25_GRAPH=1) --------------------------------
+// A step is ~25 dependent launches; on the small configurations (128x64x8, 360x180x24) their dispatch latency, not
+// the kernels, sets the step time.  With GB25_GRAPH=1 the step is captured once per host state (the pointer
+// exchanges make the state alternate with period 2) and replayed with one hipGraphLaunch; the host-side transition
+// (pointer names, flags, clock) is re-applied from the recorded `post` state.  Bitwise identical to eager launches
+// (tests/test_gpu_parity.py).  It is OFF by default because it does not pay on this stack: measured on MI355X /
+// ROCm 7.2 (profiles/r01_tuning_log.md) 0.220 vs 0.201 ms/step at 128x64x8 with the two-stream step, 0.190 vs 0.191
+// single-stream, 0.320 vs 0.307 at 360x180x24 -- the ~8 us per dependent kernel are spent on the device side of the
+// dispatch, which a graph does not remove; only fewer kernels would.
+static HostState host_state(const gb25_model* m) {
+  HostState h;
+  for (int q = 0; q < 8; q++) h.ptr[q] = m->f[GB25_GN_U + q].d;
+  h.ptr[8] = m->f[GB25_T].d; h.ptr[9] = m->f[GB25_S].d;
+  h.ptr[10] = m->ahead[0].d; h.ptr[11] = m->ahead[1].d;
+  h.ptr[12] = m->colsum[0].d; h.ptr[13] = m->colsum[1].d;
+  h.ahead_valid = m->ahead_valid; h.colsum_valid = m->colsum_valid;
+  h.ahead_dt = m->ahead_dt; h.ahead_chi = m->ahead_chi;
+  return h;
+}
+static void set_host_state(gb25_model* m, const HostState& h) {
+  for (int q = 0; q < 8; q++) m->f[GB25_GN_U + q].d = h.ptr[q];
+  m->f[GB25_T].d = h.ptr[8]; m->f[GB25_S].d = h.ptr[9];
+  m->ahead[0].d = h.ptr[10]; m->ahead[1].d = h.ptr[11];
+  m->colsum[0].d = h.ptr[12]; m->colsum[1].d = h.ptr[13];
+  m->ahead_valid = h.ahead_valid; m->colsum_valid = h.colsum_valid;
+  m->ahead_dt = h.ahead_dt; m->ahead_chi = h.ahead_chi;
+}
+static void drop_graphs(gb25_model* m) {
+  for (auto& e : m->graphs) {
+    hipGraphExecDestroy(e.exec);
+    hipGraphDestroy(e.graph);
+  }
+  m->graphs.clear();
+}
+static gb25_status step_with_graph(gb25_model* m) {
+  if (!m->use_graphs || m->profile || m->cfg.nranks != 1 || m->stream == nullptr)
+    return time_step_impl(m, 0);
+  const HostState pre = host_state(m);
+  const double dt = m->last_dt;
+  StepGraph* hit = nullptr;
+  for (auto& e : m->graphs)
+    if (e.dt == dt && e.stream == m->stream && e.pre == pre) hit = &e;
+  if (!hit) {
+    bool again = false;
+    for (auto& h : m->seen) again |= (h == pre);
+    if (!again) {   // one-off states (after a host write, a changed dt, ...) are not worth a capture
+      if (m->seen.size() >= 8) m->seen.clear();
+      m->seen.push_back(pre);
+      return time_step_impl(m, 0);
+    }
+    const double time0 = m->time;
+    const int64_t it0 = m->iteration;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool ok = hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    gb25_status st = ok ? time_step_impl(m, 0) : GB25_ERR_HIP;
+    if (ok) ok = (hipStreamEndCapture(m->stream, &graph) == hipSuccess) && st == GB25_OK && graph != nullptr;
+    const HostState post = host_state(m);
+    set_host_state(m, pre);   // nothing has run yet: back to the state the graph starts from
+    m->time = time0;
+    m->iteration = it0;
+    if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (!ok) {   // capture is a convenience, never a requirement
+      if (graph) hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      m->use_graphs = 0;
+      return time_step_impl(m, 0);
+    }
+    if (m->graphs.size() >= 8) drop_graphs(m);   // states cycle with period 2; more than a few means churn
+    m->graphs.push_back({pre, post, dt, m->stream, exec, graph});
+    hit = &m->graphs.back();
+  }
+  HIPCHK(hipGraphLaunch(hit->exec, m->stream));
+  set_host_state(m, hit->post);
+  m->time += dt;
+  m->iteration += 1;
+  return GB25_OK;
+}
+
 gb25_status gb25_first_time_step(gb25_model* m) {
   CHECK_MODEL(m);
   gb25_status s;
@@ -1067,11 +1176,11 @@ gb25_status gb25_first_time_step(gb25_model* m) {
   if ((s = update_state_impl(m))) return s;
   return time_step_impl(m, 1);
 }
-gb25_status gb25_time_step(gb25_model* m) { CHECK_MODEL(m); return time_step_impl(m, 0); }
+gb25_status gb25_time_step(gb25_model* m) { CHECK_MODEL(m); return step_with_graph(m); }
 gb25_status gb25_loop(gb25_model* m, int32_t n) {
   CHECK_MODEL(m);
   for (int s = 0; s < n; s++) {
-    gb25_status st = time_step_impl(m, 0);
+    gb25_status st = step_with_graph(m);
     if (st) return st;
   }
   return GB25_OK;

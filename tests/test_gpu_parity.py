@@ -331,6 +331,46 @@ def test_ab2_lookahead_is_bitwise_neutral(monkeypatch):
     assert c.backend.field_device_ptr("T") == p0      # pinned once handed out
 
 
+def test_graph_replay_is_bitwise_neutral(monkeypatch):
+    """gb25_time_step / gb25_loop replay a captured HIP graph of the step once a host state recurs (the pointer
+    exchanges give period 2).  Same bits as eager launches (GB25_GRAPH=0), through host writes, a changed dt, an
+    Euler restart and phase-by-phase driving in between, and the clock advances alike."""
+    monkeypatch.setenv("GB25_GRAPH", "0")
+    a = gb.baroclinic_instability_model(gb.GPU(), 128, 64, 8, dt=1200.0)
+    monkeypatch.setenv("GB25_GRAPH", "1")
+    b = gb.baroclinic_instability_model(gb.GPU(), 128, 64, 8, dt=1200.0)
+
+    def same(label):
+        for n in ALL_FIELDS:
+            assert np.array_equal(a.backend.get_field(n, True), b.backend.get_field(n, True)), (label, n)
+        assert a.clock.iteration == b.clock.iteration and a.clock.time == b.clock.time, label
+
+    for m in (a, b):
+        gb.set_baroclinic_instability(m)
+        set_noisy_velocities(m, 0.05)
+        gb.first_time_step(m)
+        gb.loop(m, 9)                                  # eager, eager, capture A, capture B, replay ...
+    same("loop")
+    for m in (a, b):
+        gb.time_step(m)
+        m.backend.set_dt(900.0)
+        gb.loop(m, 6)
+    same("after set_dt")
+    S = a.backend.get_field("S", False) + np.float32(0.125)
+    for m in (a, b):
+        m.backend.set_field("S", S, False)
+        gb.loop(m, 5)
+        m.backend.ab2_step(900.0, False)
+        m.backend.fill_halo_regions()
+        m.backend.correct_velocities_and_cache_previous_tendencies(900.0)
+        m.backend.update_state()
+        gb.loop(m, 5)
+        gb.first_time_step(m)
+        gb.loop(m, 5)
+    same("after host writes, phases and an Euler restart")
+    assert np.isfinite(b.velocities.u.interior).all()
+
+
 @pytest.mark.parametrize("shape,halo", [((16, 9, 4), 4), ((24, 9, 5), 5), ((70, 13, 7), 8), ((8, 10, 4), 8)])
 def test_minimum_sizes_and_halos(shape, halo):
     """Smallest useful extents (Ny = 8 is excluded: with 20-degree rows the first latitude halo mirrors exactly
