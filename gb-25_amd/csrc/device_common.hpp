@@ -62,6 +62,23 @@ __device__ __forceinline__ real ab2_advance(real phi, real gn, real gm, real dt,
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
 
+// Two-wide values: a register PAIR per lane that carries the same quantity of two independent cells / tracers.
+// gfx950 issues one wave64 VALU instruction per 4 cycles per SIMD (tools/micro/valu_rate.hip: 2.0 ns per dependent
+// v_fma_f32 with 2-4 waves per SIMD, i.e. 65 TFLOP/s), and v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two lanes'
+// worth of fp32 work in one such slot (112-122 TFLOP/s measured).  Arithmetic on real2v compiles to those; rcp, min,
+// max, abs and selects have no packed form and cost one instruction per half.
+using real2v = real __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ real2v v2(real a, real b) {
+  real2v r;
+  r.x = a;
+  r.y = b;
+  return r;
+}
+__device__ __forceinline__ real2v rcp(real2v x) { return v2(rcp(x.x), rcp(x.y)); }
+__device__ __forceinline__ real2v rabs(real2v x) { return v2(rabs(x.x), rabs(x.y)); }
+__device__ __forceinline__ real2v rmin(real2v a, real2v b) { return v2(rmin(a.x, b.x), rmin(a.y, b.y)); }
+__device__ __forceinline__ real2v rmin(real2v a, real b) { return v2(rmin(a.x, b), rmin(a.y, b)); }
+
 // ---------------------------------------------------------------------------------------------
 // WENO reconstruction, Oceananigans flavour: uniform coefficients, Z-weights
 // alpha_s = C_s (1 + (tau/(beta_s+eps))^2), eps = 1e-8, integer-scaled smoothness indicators
@@ -75,56 +92,62 @@ __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
 constexpr real kWenoEps = real(1e-8);
 constexpr real kWenoEps5 = real(1e-8) / real(0.75);   // eps in the scaled WENO5 indicator units
 
-__device__ __forceinline__ real beta5_0(real c, real d, real e) {
-  real d1 = c - real(2.) * d + e, d2 = real(3.) * c - real(4.) * d + e;
+template <class T>
+__device__ __forceinline__ T beta5_0(T c, T d, T e) {
+  T d1 = c - real(2.) * d + e, d2 = real(3.) * c - real(4.) * d + e;
   return (d1 * (real(13.) / real(3.))) * d1 + d2 * d2;
 }
-__device__ __forceinline__ real beta5_1(real b, real c, real d) {
-  real d1 = b - real(2.) * c + d, d2 = b - d;
+template <class T>
+__device__ __forceinline__ T beta5_1(T b, T c, T d) {
+  T d1 = b - real(2.) * c + d, d2 = b - d;
   return (d1 * (real(13.) / real(3.))) * d1 + d2 * d2;
 }
-__device__ __forceinline__ real beta5_2(real a, real b, real c) {
-  real d1 = a - real(2.) * b + c, d2 = a - real(4.) * b + real(3.) * c;
+template <class T>
+__device__ __forceinline__ T beta5_2(T a, T b, T c) {
+  T d1 = a - real(2.) * b + c, d2 = a - real(4.) * b + real(3.) * c;
   return (d1 * (real(13.) / real(3.))) * d1 + d2 * d2;
 }
 // Z-weights alpha_s = C_s (1 + (tau/b_s)^2), b_s = beta_s + eps, evaluated as C_s (1 + (q rho_s)^2) with
 // q = min(tau/b_min, 1e9) and rho_s = b_min/b_s <= 1.  Identical in exact arithmetic; in fp32 the plain form
 // overflows (tau/b ~ 1e18 when one indicator cancels to zero next to area-weighted divergences ~1e8).
 constexpr real kZCap = real(1e9);
-__device__ __forceinline__ real weno5_combine(real a, real b, real c, real d, real e, real b0, real b1,
-                                               real b2) {
-  real p0 = real(2.) * c + real(5.) * d - e;            // 6 x the candidate polynomials
-  real p1 = real(5.) * c + real(2.) * d - b;
-  real p2 = real(2.) * a - real(7.) * b + real(11.) * c;
-  real tau = rabs(b0 - b2);
+template <class T>
+__device__ __forceinline__ T weno5_combine(T a, T b, T c, T d, T e, T b0, T b1, T b2) {
+  T p0 = real(2.) * c + real(5.) * d - e;            // 6 x the candidate polynomials
+  T p1 = real(5.) * c + real(2.) * d - b;
+  T p2 = real(2.) * a - real(7.) * b + real(11.) * c;
+  T tau = rabs(b0 - b2);
   b0 += kWenoEps5;
   b1 += kWenoEps5;
   b2 += kWenoEps5;
-  real bmin = rmin(b0, rmin(b1, b2));
-  real qb = rmin(tau * rcp(bmin), kZCap) * bmin;
-  real r0 = qb * rcp(b0), r1 = qb * rcp(b1), r2 = qb * rcp(b2);
-  real a0 = real(0.3) * r0 * r0 + real(0.3), a1 = real(0.6) * r1 * r1 + real(0.6), a2 = real(0.1) * r2 * r2 + real(0.1);
+  T bmin = rmin(b0, rmin(b1, b2));
+  T qb = rmin(tau * rcp(bmin), kZCap) * bmin;
+  T r0 = qb * rcp(b0), r1 = qb * rcp(b1), r2 = qb * rcp(b2);
+  T a0 = real(0.3) * r0 * r0 + real(0.3), a1 = real(0.6) * r1 * r1 + real(0.6), a2 = real(0.1) * r2 * r2 + real(0.1);
   return (a0 * p0 + a1 * p1 + a2 * p2) * (rcp(a0 + a1 + a2) * (real(1.) / real(6.)));
 }
-__device__ __forceinline__ real beta3(real x, real y) {
-  real d = x - y;
+template <class T>
+__device__ __forceinline__ T beta3(T x, T y) {
+  T d = x - y;
   return d * d;
 }
-__device__ __forceinline__ real weno3_combine(real b, real c, real d, real b0, real b1) {
-  real p0 = c + d;                            // 2 x the candidate polynomials
-  real p1 = real(3.) * c - b;
-  real tau = rabs(b0 - b1);
+template <class T>
+__device__ __forceinline__ T weno3_combine(T b, T c, T d, T b0, T b1) {
+  T p0 = c + d;                            // 2 x the candidate polynomials
+  T p1 = real(3.) * c - b;
+  T tau = rabs(b0 - b1);
   b0 += kWenoEps;
   b1 += kWenoEps;
-  real bmin = rmin(b0, b1);
-  real qb = rmin(tau * rcp(bmin), kZCap) * bmin;
-  real r0 = qb * rcp(b0), r1 = qb * rcp(b1);
-  real a0 = (real(2.) / real(3.)) * r0 * r0 + (real(2.) / real(3.)), a1 = (real(1.) / real(3.)) * r1 * r1 + (real(1.) / real(3.));
+  T bmin = rmin(b0, b1);
+  T qb = rmin(tau * rcp(bmin), kZCap) * bmin;
+  T r0 = qb * rcp(b0), r1 = qb * rcp(b1);
+  T a0 = (real(2.) / real(3.)) * r0 * r0 + (real(2.) / real(3.)), a1 = (real(1.) / real(3.)) * r1 * r1 + (real(1.) / real(3.));
   return (a0 * p0 + a1 * p1) * (rcp(a0 + a1) * real(0.5));
 }
 
 // Self-smoothness WENO5 of upwind-ordered values.
-__device__ __forceinline__ real weno5(real a, real b, real c, real d, real e) {
+template <class T>
+__device__ __forceinline__ T weno5(T a, T b, T c, T d, T e) {
   return weno5_combine(a, b, c, d, e, beta5_0(c, d, e), beta5_1(b, c, d), beta5_2(a, b, c));
 }
 
@@ -133,36 +156,103 @@ __device__ __forceinline__ real weno5(real a, real b, real c, real d, real e) {
 // left: use q[0..4]; right: use q[5..1] mirrored.  order in {5,3,1} (wall-adjacent reduction).
 // s: smoothness inputs (FunctionStencil) or nullptr-equivalent (pass q); t: second smoothness
 // set (VelocityStencil) averaged with s when TWO is true.
-template <bool TWO>
-__device__ __forceinline__ real biased6(int order, bool left, const real* q, const real* s, const real* t) {
-  real c = left ? q[2] : q[3];
+template <bool TWO, class T = real>
+__device__ __forceinline__ T biased6(int order, bool left, const T* q, const T* s, const T* t) {
+  T c = left ? q[2] : q[3];
   if (order == 1) return c;
-  real b = left ? q[1] : q[4], d = left ? q[3] : q[2];
-  real sb = left ? s[1] : s[4], sc = left ? s[2] : s[3], sd = left ? s[3] : s[2];
-  real tb = 0, tc = 0, td = 0;
+  T b = left ? q[1] : q[4], d = left ? q[3] : q[2];
+  T sb = left ? s[1] : s[4], sc = left ? s[2] : s[3], sd = left ? s[3] : s[2];
+  T tb = T(0), tc = T(0), td = T(0);
   if (TWO) {
     tb = left ? t[1] : t[4];
     tc = left ? t[2] : t[3];
     td = left ? t[3] : t[2];
   }
   if (order == 3) {
-    real b0 = beta3(sc, sd), b1 = beta3(sb, sc);
+    T b0 = beta3(sc, sd), b1 = beta3(sb, sc);
     if (TWO) {
       b0 = real(0.5) * (b0 + beta3(tc, td));
       b1 = real(0.5) * (b1 + beta3(tb, tc));
     }
     return weno3_combine(b, c, d, b0, b1);
   }
-  real a = left ? q[0] : q[5], e = left ? q[4] : q[1];
-  real sa = left ? s[0] : s[5], se = left ? s[4] : s[1];
-  real b0 = beta5_0(sc, sd, se), b1 = beta5_1(sb, sc, sd), b2 = beta5_2(sa, sb, sc);
+  T a = left ? q[0] : q[5], e = left ? q[4] : q[1];
+  T sa = left ? s[0] : s[5], se = left ? s[4] : s[1];
+  T b0 = beta5_0(sc, sd, se), b1 = beta5_1(sb, sc, sd), b2 = beta5_2(sa, sb, sc);
   if (TWO) {
-    real ta = left ? t[0] : t[5], te = left ? t[4] : t[1];
+    T ta = left ? t[0] : t[5], te = left ? t[4] : t[1];
     b0 = real(0.5) * (b0 + beta5_0(tc, td, te));
     b1 = real(0.5) * (b1 + beta5_1(tb, tc, td));
     b2 = real(0.5) * (b2 + beta5_2(ta, tb, tc));
   }
   return weno5_combine(a, b, c, d, e, b0, b1, b2);
+}
+
+// Two reconstructions of the same order at once, one per half of the pair, each with its own upwind direction
+// (l0 for .x, l1 for .y).  Used where two different quantities of one cell share stencil shape and order.
+__device__ __forceinline__ real2v pick(bool l0, bool l1, real2v a, real2v b) { return v2(l0 ? a.x : b.x, l1 ? a.y : b.y); }
+template <bool TWO>
+__device__ __forceinline__ real2v biased6p(int order, bool l0, bool l1, const real2v* q, const real2v* s,
+                                           const real2v* t) {
+  real2v c = pick(l0, l1, q[2], q[3]);
+  if (order == 1) return c;
+  real2v b = pick(l0, l1, q[1], q[4]), d = pick(l0, l1, q[3], q[2]);
+  real2v sb = pick(l0, l1, s[1], s[4]), sc = pick(l0, l1, s[2], s[3]), sd = pick(l0, l1, s[3], s[2]);
+  real2v tb = real2v(0), tc = real2v(0), td = real2v(0);
+  if (TWO) {
+    tb = pick(l0, l1, t[1], t[4]);
+    tc = pick(l0, l1, t[2], t[3]);
+    td = pick(l0, l1, t[3], t[2]);
+  }
+  if (order == 3) {
+    real2v b0 = beta3(sc, sd), b1 = beta3(sb, sc);
+    if (TWO) {
+      b0 = real(0.5) * (b0 + beta3(tc, td));
+      b1 = real(0.5) * (b1 + beta3(tb, tc));
+    }
+    return weno3_combine(b, c, d, b0, b1);
+  }
+  real2v a = pick(l0, l1, q[0], q[5]), e = pick(l0, l1, q[4], q[1]);
+  real2v sa = pick(l0, l1, s[0], s[5]), se = pick(l0, l1, s[4], s[1]);
+  real2v b0 = beta5_0(sc, sd, se), b1 = beta5_1(sb, sc, sd), b2 = beta5_2(sa, sb, sc);
+  if (TWO) {
+    real2v ta = pick(l0, l1, t[0], t[5]), te = pick(l0, l1, t[4], t[1]);
+    b0 = real(0.5) * (b0 + beta5_0(tc, td, te));
+    b1 = real(0.5) * (b1 + beta5_1(tb, tc, td));
+    b2 = real(0.5) * (b2 + beta5_2(ta, tb, tc));
+  }
+  return weno5_combine(a, b, c, d, e, b0, b1, b2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Buffer addressing.  A stencil kernel reads one array at many (i,j,k) offsets from the same cell.  With flat/global
+// loads every such access carries its own 64-bit per-lane address (one v_lshl_add_u64 and a VGPR pair each: 9 % of the
+// tracer kernel's VALU instructions and ~25 of its VGPRs).  A buffer access is  base(SGPR x4) + voffset(one VGPR,
+// shared by every access of the cell) + soffset(SGPR: the wave-uniform j/k displacement) + immediate(the i
+// displacement): no address arithmetic on the vector side at all.  Offsets are BYTES and must stay non-negative and
+// below 2^31: kernels bias voffset to the (-3,-3,-3) corner of the stencil.  Reads past `bytes` return zero.
+// ---------------------------------------------------------------------------------------------
+struct Buf {
+  __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ Buf make_buf(const real* p, long elems) {
+  Buf b;
+  b.r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(elems * (long)sizeof(real)), 0x00020000);
+  return b;
+}
+__device__ __forceinline__ float bload_(const Buf& b, int voff, int soff, float) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0));
+}
+__device__ __forceinline__ double bload_(const Buf& b, int voff, int soff, double) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 0));
+}
+__device__ __forceinline__ real bload(const Buf& b, int voff, int soff) { return bload_(b, voff, soff, real(0)); }
+__device__ __forceinline__ void bstore(const Buf& b, int voff, int soff, float x) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), b.r, voff, soff, 0);
+}
+__device__ __forceinline__ void bstore(const Buf& b, int voff, int soff, double x) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), b.r, voff, soff, 0);
 }
 
 // wall-adjacent order reduction in a bounded direction of extent N (0-based target index)

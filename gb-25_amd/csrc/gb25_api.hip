@@ -103,8 +103,9 @@ struct gb25_model {
   std::string err;
   int baro_rows = 16;                // tile height of the blocked barotropic kernel: 16 or 32 (GB25_BARO_ROWS)
   int baro_block = 7;             // substeps per barotropic launch (GB25_BARO_BLOCK=1: one launch per substep)
+  int momentum_v5 = 1;               // packed (G_u term, G_v term) reconstructions; GB25_MOMENTUM_V5=0: scalar v2 kernel
   int momentum_v4 = 0;               // GB25_MOMENTUM_V4=1: single-barrier pipelined momentum kernel
-  int tracer_v3 = 1;                 // wave-autonomous tracer kernel (no LDS); GB25_TRACER_V3=0 selects the LDS one
+  int tracer_v3 = 5;                 // 5: packed (T,S) wave-autonomous kernel, buffer addressing; 1: scalar v3; 0: LDS v2 (GB25_TRACER_V3)
   int tile_rows = 8;                 // rows (= waves) per block of the v2 tendency kernels: 8 or 4 (GB25_TILE_ROWS)
   int variant_c = 1;                 // nontemporal tendency reads in the tracer AB2 stream (GB25_VARIANT_C)
   int variant_a = 1, variant_b = 1;  // tuning switches (GB25_VARIANT_A / _B), see momentum_impl / tracers_impl
@@ -475,6 +476,8 @@ gb25_status momentum_impl(gb25_model* m) {
     auto kern = TY == 4 ? (m->variant_b ? k_momentum_tendencies_v2<MW, 4> : k_momentum_tendencies_v2<2, 4>)
                         : (m->variant_b ? k_momentum_tendencies_v2<MW, 8> : k_momentum_tendencies_v2<2, 8>);
     if (m->momentum_v4) kern = k_momentum_tendencies_v4<MW, 8>;
+    if (m->momentum_v5) kern = TY == 4 ? k_momentum_tendencies_v5<MW, 4> : k_momentum_tendencies_v5<MW, 8>;
+    if (m->momentum_v5 == 3) kern = k_momentum_tendencies_v5<3, 8>;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(V2_TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                        m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, nbx, kchunks, nb);
     LAUNCHCHK();
@@ -517,7 +520,11 @@ gb25_status tracers_impl(gb25_model* m) {
                                   : (m->variant_a == 7 ? k_tracer_tendencies_v3<7, false>
                                                        : (ahead ? k_tracer_tendencies_v3<TW, true>
                                                                 : k_tracer_tendencies_v3<TW, false>));
-    const bool ahead_run = ahead && m->variant_a != 6 && m->variant_a != 7;
+    if (m->tracer_v3 == 5) {   // packed (T, S) pairs
+      kern = ahead ? k_tracer_tendencies_v5<TW, true> : k_tracer_tendencies_v5<TW, false>;
+      if (m->variant_a == 4) kern = ahead ? k_tracer_tendencies_v5<4, true> : k_tracer_tendencies_v5<4, false>;
+    }
+    const bool ahead_run = ahead && ((m->variant_a != 6 && m->variant_a != 7) || m->tracer_v3 == 5);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64, 4), 0, m->stream, g, m->f[GB25_U].d,
                        m->f[GB25_V].d, m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d,
                        m->f[GB25_GN_S].d, nbx, kchunks, nb, nx);
@@ -820,6 +827,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   if (const char* e = getenv("GB25_KERNELS")) m->kernel_gen = (strcmp(e, "v1") == 0) ? 1 : 2;
   if (const char* e = getenv("GB25_TRACER_V3")) m->tracer_v3 = atoi(e);
   if (const char* e = getenv("GB25_MOMENTUM_V4")) m->momentum_v4 = atoi(e);
+  if (const char* e = getenv("GB25_MOMENTUM_V5")) m->momentum_v5 = atoi(e);
   if (const char* e = getenv("GB25_BARO_BLOCK")) m->baro_block = atoi(e);
   if (const char* e = getenv("GB25_BARO_ROWS")) m->baro_rows = (atoi(e) == 32) ? 32 : 16;
   if (const char* e = getenv("GB25_TILE_ROWS")) m->tile_rows = (atoi(e) == 4) ? 4 : 8;

@@ -471,6 +471,303 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
   }
 }
 
+// =============================================================================================
+// Momentum tendencies, packed variant ("v5"): staging, derived tiles and pipeline of k_momentum_tendencies_v2; the
+// eight WENO reconstructions of a cell are evaluated as four two-wide ones (a G_u term paired with the G_v term of
+// the same stencil shape and order), so their arithmetic issues as v_pk_fma/mul/add_f32.  Rows next to the walls,
+// where the vorticity reconstruction of G_u drops below order 5 but G_v's does not, take the scalar form for that
+// one pair.
+// =============================================================================================
+template <int MINW, int V2_TY>
+__global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
+    Grid g, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ w,
+    const real* __restrict__ dpx, const real* __restrict__ dpy, real* __restrict__ Gu, real* __restrict__ Gv,
+    int nbx, int kchunks, int nb) {
+  __shared__ MomentumLds<V2_TY> lds;
+  constexpr int MU_Y = V2_TY + 6, MW_Y = V2_TY + 3, MD_Y = V2_TY + 5;
+  const int L = xcd_remap(blockIdx.x, nb);
+  const int bx = L % nbx, r = L / nbx;
+  const int kc = r % kchunks, by = r / kchunks;
+  const int klen = (g.Nz + kchunks - 1) / kchunks;
+  const int k0 = kc * klen, k1 = min(g.Nz, k0 + klen);
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * V2_TX + tx;
+  const int i0 = bx * V2_TX, j0 = by * V2_TY;
+  const int i = i0 + tx, j = j0 + ty;
+  const bool inside = (i < g.Nx) && (j < g.Ny);
+  const int sx = g.sx, pc = g.pl_c, pv = g.pl_v, H = g.H;
+  const real dy = g.dy;
+
+  // j-dependent metrics of this thread's row
+  const real dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j], razc_j = g.razc[j], razf_j = g.razf[j];
+  const real Az = g.azc[j], fcor_j = g.fcor[j], fbar = real(0.5) * (g.fcor[j] + g.fcor[j + 1]);
+  const real az_m2 = g.azc[j - 2], az_m1 = g.azc[j - 1], az_p1 = g.azc[j + 1];
+  const int oc_y = biased_order_center(j, g.Ny), of_y = biased_order_face(j, g.Ny);
+  const bool s4c_y = sym4_center(j, g.Ny), s4f_y = sym4_face(j, g.Ny);
+
+  // threads of a ragged edge tile work on a clamped (duplicate) column so that every address stays in bounds
+  int o = ic(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0), ov = iv(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0);
+  real uz[7], vz[7];
+#pragma unroll
+  for (int m = 0; m < 7; m++) {
+    uz[m] = u[o + (m - 3) * pc];
+    vz[m] = v[ov + (m - 3) * pv];
+  }
+  // vertical momentum fluxes through the bottom face of the first level
+  real fzu, fzv;
+  {
+    const int ord = biased_order_face(k0, g.Nz);
+    real wu = sym_interp(true, Az * w[o - 2], Az * w[o - 1], Az * w[o], Az * w[o + 1]);
+    real wv = sym_interp(s4f_y, az_m2 * w[o - 2 * sx], az_m1 * w[o - sx], Az * w[o], az_p1 * w[o + sx]);
+    fzu = wu * biased6<false>(ord, wu > real(0.), uz, uz, uz);
+    fzv = wv * biased6<false>(ord, wv > real(0.), vz, vz, vz);
+  }
+
+  // Tile staging is software-pipelined: the global loads of level k+1 are issued before the arithmetic of level
+  // k and land in LDS (other parity) after it, so their latency hides behind phases 1-2 instead of in front of a
+  // barrier.  Each thread owns up to 2 elements of the u / v tiles and 2 of the w tile.
+  constexpr int NT = V2_TX * V2_TY;
+  constexpr int NEU = (MU_X * MU_Y + NT - 1) / NT, NEW = (MW_X * MW_Y + NT - 1) / NT;   // elements per thread
+  const int tile_u = (i0 - 3 + H) + sx * (j0 - 3 + H), tile_w = (i0 - 2 + H) + sx * (j0 - 2 + H);
+  int eu_off[NEU], eu_lds[NEU], ew_off[NEW], ew_lds[NEW];   // global offset within the tile plane / LDS index
+#pragma unroll
+  for (int q = 0; q < NEU; q++) {
+    int e = tid + q * NT;
+    int ey = e / MU_X, ex = e - ey * MU_X;
+    // clamp to the parent array (ragged tiles): columns <= Nx+H-1, rows <= Ny+H-1 relative to the tile origin
+    eu_off[q] = (e < MU_X * MU_Y) ? min(ex, g.Nx + H + 2 - i0) + sx * min(ey, g.Ny + H + 2 - j0) : -1;
+    eu_lds[q] = e;
+  }
+#pragma unroll
+  for (int q = 0; q < NEW; q++) {
+    int e = tid + q * NT;
+    int ey = e / MW_X, ex = e - ey * MW_X;
+    ew_off[q] = (e < MW_X * MW_Y) ? min(ex, g.Nx + H + 1 - i0) + sx * min(ey, g.Ny + H + 1 - j0) : -1;
+    ew_lds[q] = e;
+  }
+  real ru[NEU], rv[NEU], rw[NEW], rpw = real(0.), rps = real(0.);
+  auto fetch = [&](int k, int oo) {
+    const int bu = tile_u + pc * (k + H), bv = tile_u + pv * (k + H), bw = tile_w + pc * (k + 1 + H);
+#pragma unroll
+    for (int q = 0; q < NEU; q++)
+      if (eu_off[q] >= 0) {
+        ru[q] = u[bu + eu_off[q]];
+        rv[q] = v[bv + eu_off[q]];
+      }
+#pragma unroll
+    for (int q = 0; q < NEW; q++)
+      if (ew_off[q] >= 0) rw[q] = w[bw + ew_off[q]];
+    rpw = dpx[oo];   // p'(i) - p'(i-1) and p'(j) - p'(j-1), differenced in fp64 by k_compute_p
+    rps = dpy[oo];
+  };
+  auto stash = [&](int par) {
+    real* U0 = &lds.U[par][0][0];
+    real* V0 = &lds.V[par][0][0];
+    real* W0 = &lds.W[par][0][0];
+#pragma unroll
+    for (int q = 0; q < NEU; q++)
+      if (eu_off[q] >= 0) {
+        U0[eu_lds[q]] = ru[q];
+        V0[eu_lds[q]] = rv[q];
+      }
+#pragma unroll
+    for (int q = 0; q < NEW; q++)
+      if (ew_off[q] >= 0) W0[ew_lds[q]] = rw[q];
+  };
+  fetch(k0, o);
+  stash(k0 & 1);
+  real pw_ = rpw, ps_ = rps;   // p'(i,j) - p'(i-1,j) and p'(i,j) - p'(i,j-1) of the current level
+  __syncthreads();
+
+  for (int k = k0; k < k1; k++) {
+    const int par = k & 1;
+    const real dz = g.dzc[k];
+    // ---- phase 0: issue the loads of the next level's tiles (consumed at the end of this iteration)
+    const bool more = (k + 1 < k1);
+    if (more) fetch(k + 1, o + pc);
+    const real unew = u[o + 4 * pc], vnew = v[ov + 4 * pv];
+    // ---- phase 1: derived quantities, once per point
+    for (int e = tid; e < MD_X * MD_Y; e += NT) {
+      int py = e / MD_X, px = e - py * MD_X;
+      // (f,f,c) point (i0-2+px, j0-2+py)
+      {
+        const int J = j0 - 2 + py;
+        real uc = lds.U[par][py + 1][px + 1], us = lds.U[par][py][px + 1];
+        real vc = lds.V[par][py + 1][px + 1], vw = lds.V[par][py + 1][px];
+        lds.Z[py][px] = ((dy * vc - dy * vw) - (g.dxc[J] * uc - g.dxc[J - 1] * us)) * g.razf[J];
+        lds.UQ[py][px] = real(0.5) * (us + uc);
+        lds.VQ[py][px] = real(0.5) * (vw + vc);
+      }
+      // (c,c,c) point (i0-3+px, j0-3+py)
+      {
+        const int J = j0 - 3 + py;
+        const real Ax = dy * dz;
+        lds.DU[py][px] = Ax * lds.U[par][py][px + 1] - Ax * lds.U[par][py][px];
+        lds.DV[py][px] = g.dxf[J + 1] * dz * lds.V[par][py + 1][px] - g.dxf[J] * dz * lds.V[par][py][px];
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: the two tendencies of cell (i,j,k)
+    // tile accessors relative to (i,j)
+#define UT(di, dj) lds.U[par][ty + 3 + (dj)][tx + 3 + (di)]
+#define VT(di, dj) lds.V[par][ty + 3 + (dj)][tx + 3 + (di)]
+#define WT(di, dj) lds.W[par][ty + 2 + (dj)][tx + 2 + (di)]
+#define ZF(A, di, dj) lds.A[ty + 2 + (dj)][tx + 2 + (di)]
+#define DC(A, di, dj) lds.A[ty + 3 + (dj)][tx + 3 + (di)]
+    real gu, gv;
+    const int ozt = biased_order_face(k + 1, g.Nz);
+    const real rdz = g.rdzc[k];
+    {
+      // Packed evaluation: the eight reconstructions of the cell are done as four PAIRS that share stencil shape
+      // and order, (.x, .y) = (a term of G_u, a term of G_v); see real2v in device_common.hpp.
+      const real vws = VT(-1, 0), vwn = VT(-1, 1), vcs = VT(0, 0), vcn = VT(0, 1);
+      const real vhat_u = (real(0.5) * (dxf_s * vws + dxf_n * vwn) + real(0.5) * (dxf_s * vcs + dxf_n * vcn)) * real(0.5) * rdxc_j;
+      const real uhat_v =
+          (real(0.5) * (dy * UT(0, -1) + dy * UT(1, -1)) + real(0.5) * (dy * UT(0, 0) + dy * UT(1, 0))) * real(0.5) * g.rdy;
+      const real uhat_u = uz[3], vhat_v = vz[3];
+
+      // (1) vorticity flux: zeta reconstructed in y for G_u (centre order) and in x for G_v (order 5)
+      real hadv_u, hadv_v;
+      if (oc_y == 5) {
+        real2v zq[6], uq[6], vq[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          zq[m] = v2(ZF(Z, 0, m - 2), ZF(Z, m - 2, 0));
+          uq[m] = v2(ZF(UQ, 0, m - 2), ZF(UQ, m - 2, 0));
+          vq[m] = v2(ZF(VQ, 0, m - 2), ZF(VQ, m - 2, 0));
+        }
+        const real2v z = biased6p<true>(5, vhat_u > real(0.), uhat_v > real(0.), zq, uq, vq);
+        hadv_u = -vhat_u * z.x;
+        hadv_v = uhat_v * z.y;
+      } else {
+        real zq[6], uq[6], vq[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          zq[m] = ZF(Z, 0, m - 2);
+          uq[m] = ZF(UQ, 0, m - 2);
+          vq[m] = ZF(VQ, 0, m - 2);
+        }
+        hadv_u = -vhat_u * biased6<true>(oc_y, vhat_u > real(0.), zq, uq, vq);
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          zq[m] = ZF(Z, m - 2, 0);
+          uq[m] = ZF(UQ, m - 2, 0);
+          vq[m] = ZF(VQ, m - 2, 0);
+        }
+        hadv_v = uhat_v * biased6<true>(5, uhat_v > real(0.), zq, uq, vq);
+      }
+
+      // (2) G_u: divergence flux and Bernoulli head, both upwinded in x by u (order 5, one direction for the pair)
+      real duR, dKu_u;
+      {
+        real2v qq[6], ss[6];
+        real u7[7];
+#pragma unroll
+        for (int m = 0; m < 7; m++) u7[m] = UT(m - 3, 0);
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          const real Du = DC(DU, m - 3, 0);
+          qq[m] = v2(Du, real(0.5) * u7[m + 1] * u7[m + 1] - real(0.5) * u7[m] * u7[m]);
+          ss[m] = v2(Du + DC(DV, m - 3, 0), real(0.5) * (u7[m] + u7[m + 1]));
+        }
+        const bool l = uhat_u > real(0.);
+        const real2v rr = biased6p<false>(5, l, l, qq, ss, ss);
+        duR = rr.x;
+        dKu_u = rr.y;
+      }
+      // (3) G_v: the same two terms, upwinded in y by v (face order)
+      real dvR, dKv_v;
+      {
+        real2v qq[6], ss[6];
+        real v7[7];
+#pragma unroll
+        for (int m = 0; m < 7; m++) v7[m] = VT(0, m - 3);
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          const real Dv = DC(DV, 0, m - 3);
+          qq[m] = v2(Dv, real(0.5) * v7[m + 1] * v7[m + 1] - real(0.5) * v7[m] * v7[m]);
+          ss[m] = v2(DC(DU, 0, m - 3) + Dv, real(0.5) * (v7[m] + v7[m + 1]));
+        }
+        const bool l = vhat_v > real(0.);
+        const real2v rr = biased6p<false>(of_y, l, l, qq, ss, ss);
+        dvR = rr.x;
+        dKv_v = rr.y;
+      }
+      // (4) vertical advection of u and v: same order, own directions
+      const real wt_u = sym_interp(true, Az * WT(-2, 0), Az * WT(-1, 0), Az * WT(0, 0), Az * WT(1, 0));
+      const real wt_v = sym_interp(s4f_y, az_m2 * WT(0, -2), az_m1 * WT(0, -1), Az * WT(0, 0), az_p1 * WT(0, 1));
+      real2v zz[6];
+#pragma unroll
+      for (int m = 0; m < 6; m++) zz[m] = v2(uz[m + 1], vz[m + 1]);
+      const real2v ftp = v2(wt_u, wt_v) * biased6p<false>(ozt, wt_u > real(0.), wt_v > real(0.), zz, zz, zz);
+
+      {  // ---------------- assemble G_u at (f,c,c)
+        real Dv4[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) Dv4[m] = DC(DV, m - 2, 0);
+        const real dvs = sym_interp(true, Dv4[0], Dv4[1], Dv4[2], Dv4[3]);
+        const real phi = uhat_u * (dvs + duR);
+        const real vadv = (phi + (ftp.x - fzu)) * (razc_j * rdz);
+        fzu = ftp.x;
+        real a4[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          real vc = VT(0, m - 1), vw = VT(-1, m - 1);
+          a4[m] = real(0.5) * vc * vc - real(0.5) * vw * vw;
+        }
+        const real dKv = sym_interp(s4c_y, a4[0], a4[1], a4[2], a4[3]);
+        const real bern = (dKu_u + dKv) * rdxc_j;
+        const real cor = -fbar * vhat_u;
+        const real dpdx = pw_ * rdxc_j;
+        gu = -(hadv_u + vadv + bern) - cor - dpdx;
+      }
+      {  // ---------------- assemble G_v at (c,f,c)
+        real Du4[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) Du4[m] = DC(DU, 0, m - 2);
+        const real dus = sym_interp(s4f_y, Du4[0], Du4[1], Du4[2], Du4[3]);
+        const real phi = vhat_v * (dus + dvR);
+        const real vadv = (phi + (ftp.y - fzv)) * (razf_j * rdz);
+        fzv = ftp.y;
+        real a4[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          real un = UT(m - 1, 0), us = UT(m - 1, -1);
+          a4[m] = real(0.5) * un * un - real(0.5) * us * us;
+        }
+        const real dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
+        const real bern = (dKv_v + dKu) * g.rdy;
+        const real cor = fcor_j * uhat_v;
+        const real dpdy = ps_ * g.rdy;
+        gv = -(hadv_v + vadv + bern) - cor - dpdy;
+      }
+    }
+#undef UT
+#undef VT
+#undef WT
+#undef ZF
+#undef DC
+    if (inside) {
+      Gu[o] = gu;
+      Gv[ov] = gv;
+    }
+    o += pc;
+    ov += pv;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      uz[m] = uz[m + 1];
+      vz[m] = vz[m + 1];
+    }
+    uz[6] = unew;
+    vz[6] = vnew;
+    if (more) {
+      stash(par ^ 1);
+      pw_ = rpw;
+      ps_ = rps;
+    }
+    __syncthreads();   // next tiles visible; derived arrays free for the next phase 1
+  }
+}
+
 }  // namespace gb25
 
 namespace gb25 {
@@ -579,6 +876,103 @@ __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v3(Grid g, cons
     tz[6] = T[o + 3 * pc];
     sz[6] = S[o + 3 * pc];
   }
+}
+
+
+// =============================================================================================
+// Tracer tendencies, packed variant ("v5"): the v3 scheme (wave-autonomous, no LDS, no barriers, k-marching) with T
+// and S carried as ONE two-wide value per stencil point.  Both tracers see the same advecting velocity, the same
+// upwind direction and the same (wave-uniform) wall-adjacent order, so every reconstruction is evaluated once on
+// register pairs: the smoothness indicators, polynomials and weights become v_pk_fma/mul/add_f32, which do two lanes'
+// worth of fp32 work per issue slot (device_common.hpp, real2v).  Only rcp, min, abs and the upwind selects stay
+// per-half.  Same arithmetic as v3 up to FMA contraction.
+// =============================================================================================
+template <int MINW, bool AHEAD>
+__global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, const real* __restrict__ u,
+                                                              const real* __restrict__ v,
+                                                              const real* __restrict__ w,
+                                                              const real* __restrict__ T, const real* __restrict__ S,
+                                                              real* __restrict__ GT, real* __restrict__ GS, int nbx,
+                                                              int kchunks, int nb, Ab2Ahead next) {
+  const int L = xcd_remap(blockIdx.x, nb);
+  const int bx = L % nbx, r = L / nbx;
+  const int kc = r % kchunks, by = r / kchunks;
+  const int klen = (g.Nz + kchunks - 1) / kchunks;
+  const int k0 = kc * klen, k1 = min(g.Nz, k0 + klen);
+  const int lane = threadIdx.x;
+  const int i = bx * V3_OUT + lane, j = by * blockDim.y + threadIdx.y;
+  if (j >= g.Ny) return;                       // whole wave (one row) leaves together: no barriers in this kernel
+  const bool writes = (lane < V3_OUT) && (i < g.Nx);
+  const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
+  const real dy = g.dy, Az = g.azc[j], dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], razc_j = g.razc[j];
+  const int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny);
+
+  // buffer views (device_common.hpp): one per-lane byte offset for the centre-shaped arrays, one for v
+  constexpr int SZ = (int)sizeof(real);
+  const long nzp = g.Nz + 2 * g.H;
+  const Buf bT = make_buf(T, pc * nzp), bS = make_buf(S, pc * nzp), bu = make_buf(u, pc * nzp),
+            bw = make_buf(w, pc * (nzp + 1)), bv = make_buf(v, pv * nzp), bGT = make_buf(GT, pc * nzp),
+            bGS = make_buf(GS, pc * nzp);
+  Buf bGmT = bT, bGmS = bT, bTn = bT, bSn = bT;
+  if (AHEAD) {
+    bGmT = make_buf(next.GmT, pc * nzp); bGmS = make_buf(next.GmS, pc * nzp);
+    bTn = make_buf(next.Tn, pc * nzp);   bSn = make_buf(next.Sn, pc * nzp);
+  }
+  // lanes past the east edge work on a clamped (duplicate) column.  `vo` addresses the (-3,-3,-3) corner of the
+  // cell's stencil so that every displacement below is a non-negative byte count (needs H >= 3, as WENO5 does).
+  const int cc = (3 * pc + 3 * sx + 3) * SZ;                    // corner -> cell
+  int vo = (ic(g, min(i, g.Nx), j, k0)) * SZ - cc;
+  int vov = iv(g, min(i, g.Nx), j, k0) * SZ;
+#define CZ(m) (((m) * pc + 3 * sx + 3) * SZ)                     // (0, 0, m-3)
+#define CY(m) ((3 * pc + (m) * sx + 3) * SZ)                     // (0, m-3, 0)
+#define CX(m) ((3 * pc + 3 * sx) * SZ), ((m) * SZ)               // (m-3, 0, 0): uniform part, immediate part
+  real2v cz[7];                                // vertical window of (T, S)
+#pragma unroll
+  for (int m = 0; m < 7; m++) cz[m] = v2(bload(bT, vo, CZ(m)), bload(bS, vo, CZ(m)));
+  real2v fz;
+  {
+    real Azw = Az * bload(bw, vo, cc);
+    int ord = biased_order_face(k0, g.Nz);
+    fz = Azw * biased6<false, real2v>(ord, Azw > real(0.), cz, cz, cz);
+  }
+  for (int k = k0; k < k1; k++) {
+    const real dz = g.dzc[k];
+    const real Axu = dy * dz * bload(bu, vo, cc);
+    const real Ays = dxf_s * dz * bload(bv, vov, 0), Ayn = dxf_n * dz * bload(bv, vov, sx * SZ);
+    const real Azw = Az * bload(bw, vo, cc + pc * SZ);
+    real2v q[7];
+#pragma unroll
+    for (int m = 0; m < 6; m++) q[m] = v2(bload(bT, vo + m * SZ, (3 * pc + 3 * sx) * SZ), bload(bS, vo + m * SZ, (3 * pc + 3 * sx) * SZ));
+    const real2v fx = Axu * biased6<false, real2v>(5, Axu > real(0.), q, q, q);
+#pragma unroll
+    for (int m = 0; m < 7; m++) q[m] = v2(bload(bT, vo, CY(m)), bload(bS, vo, CY(m)));
+    const real2v fs = Ays * biased6<false, real2v>(oys, Ays > real(0.), q, q, q);
+    const real2v fn = Ayn * biased6<false, real2v>(oyn, Ayn > real(0.), q + 1, q + 1, q + 1);
+    // top face from the vertical window
+    const int ozt = biased_order_face(k + 1, g.Nz);
+    const real2v ft = Azw * biased6<false, real2v>(ozt, Azw > real(0.), cz + 1, cz + 1, cz + 1);
+    // east faces = west faces of the next lane
+    const real2v fe = v2(__shfl_down(fx.x, 1), __shfl_down(fx.y, 1));
+    if (writes) {
+      const real rV = razc_j * g.rdzc[k];
+      const real2v G = -(((fe - fx) + (fn - fs) + (ft - fz)) * rV);
+      bstore(bGT, vo, cc, G.x);
+      bstore(bGS, vo, cc, G.y);
+      if (AHEAD) {   // T, S of the NEXT step while T, S (cz[3]) and the new tendency are in registers
+        bstore(bTn, vo, cc, ab2_advance(cz[3].x, G.x, bload(bGmT, vo, cc), next.dt, next.C1, next.C2));
+        bstore(bSn, vo, cc, ab2_advance(cz[3].y, G.y, bload(bGmS, vo, cc), next.dt, next.C1, next.C2));
+      }
+    }
+    fz = ft;
+    vo += pc * SZ;
+    vov += pv * SZ;
+#pragma unroll
+    for (int m = 0; m < 6; m++) cz[m] = cz[m + 1];
+    cz[6] = v2(bload(bT, vo, CZ(6)), bload(bS, vo, CZ(6)));
+  }
+#undef CZ
+#undef CY
+#undef CX
 }
 
 }  // namespace gb25
