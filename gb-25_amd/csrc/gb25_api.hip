@@ -36,14 +36,17 @@ struct EventPair {
 // Everything a time step changes on the HOST side (the device work is in the kernels): which buffer carries which
 // name after the pointer exchanges, and the validity flags of the cached by-products.
 struct HostState {
-  real* ptr[14];   // G^n/G^- of u,v,T,S (8), T, S and their look-ahead partners (4), column integrals (2)
-  bool ahead_valid, colsum_valid;
-  real ahead_dt, ahead_chi;
+  // G^n/G^- of u,v,T,S (8); T, S and partners (4); column integrals and partners (4); u, v and partners (4);
+  // G.U, G.V and partners (4)
+  real* ptr[24];
+  bool ahead_valid, ahead_uv_valid, colsum_valid;
+  real ahead_dt, ahead_chi, ahead_uv_dt, ahead_uv_chi;
   bool operator==(const HostState& o) const {
-    for (int q = 0; q < 14; q++)
+    for (int q = 0; q < 24; q++)
       if (ptr[q] != o.ptr[q]) return false;
-    return ahead_valid == o.ahead_valid && colsum_valid == o.colsum_valid &&
-           (!ahead_valid || (ahead_dt == o.ahead_dt && ahead_chi == o.ahead_chi));
+    return ahead_valid == o.ahead_valid && ahead_uv_valid == o.ahead_uv_valid && colsum_valid == o.colsum_valid &&
+           (!ahead_valid || (ahead_dt == o.ahead_dt && ahead_chi == o.ahead_chi)) &&
+           (!ahead_uv_valid || (ahead_uv_dt == o.ahead_uv_dt && ahead_uv_chi == o.ahead_uv_chi));
   }
 };
 // One captured time step: valid when the model is in state `pre` with the same dt and stream; leaves it in `post`.
@@ -71,6 +74,12 @@ struct gb25_model {
   Field ahead[2];
   bool ahead_valid = false, ptr_exposed = false;
   real ahead_dt = 0, ahead_chi = 0;
+  // ... and the momentum kernel does the same for u, v (UvAhead): partner buffers of u, v, of G.U, G.V and of the
+  // corrector's column integrals, plus the per-chunk partial sums the kernel leaves for k_ab2_velocities_finish
+  Field ahead_uv[2], ahead_G[2], ahead_colsum[2];
+  real* uv_partials = nullptr;
+  bool ahead_uv_valid = false;
+  real ahead_uv_dt = 0, ahead_uv_chi = 0;
   int use_graphs = 0;                // GB25_GRAPH=1: replay a captured HIP graph of the step (see step_with_graph)
   std::vector<StepGraph> graphs;
   std::vector<HostState> seen;       // states met once: a state is captured when it comes round again
@@ -463,6 +472,7 @@ void tile_grid(const Grid& g, int* nbx, int* nb) {
 gb25_status momentum_impl(gb25_model* m) {
   const Grid& g = m->g;
   int nbx, nb;
+  m->ahead_uv_valid = false;   // a look-ahead made from the previous tendencies is void
   if (m->kernel_gen >= 2) {
     Timed t(m, GB25_K_GU);   // the fused G_u + G_v kernel is accounted under the "gu" timer
     nbx = (g.Nx + V2_TX - 1) / V2_TX;
@@ -476,8 +486,33 @@ gb25_status momentum_impl(gb25_model* m) {
     auto kern = TY == 4 ? (m->variant_b ? k_momentum_tendencies_v2<MW, 4> : k_momentum_tendencies_v2<2, 4>)
                         : (m->variant_b ? k_momentum_tendencies_v2<MW, 8> : k_momentum_tendencies_v2<2, 8>);
     if (m->momentum_v4) kern = k_momentum_tendencies_v4<MW, 8>;
-    if (m->momentum_v5) kern = TY == 4 ? k_momentum_tendencies_v5<MW, 4> : k_momentum_tendencies_v5<MW, 8>;
-    if (m->momentum_v5 == 3) kern = k_momentum_tendencies_v5<3, 8>;
+    if (m->momentum_v5) {
+      const bool ahead = m->ab2_ahead && !m->ptr_exposed && m->ab2_ahead != 2;   // GB25_AB2_AHEAD=2: tracers only
+      UvAhead nx{};
+      const real dt = (real)m->last_dt, chi = (real)m->cfg.chi;
+      if (ahead) {   // predicted parameters of the next ab2_step!: the clock's dt and the model's chi
+        nx.GmU = m->f[GB25_GM_U].d; nx.GmV = m->f[GB25_GM_V].d;
+        nx.un = m->ahead_uv[0].d; nx.vn = m->ahead_uv[1].d;
+        nx.P = m->uv_partials;
+        nx.dt = dt; nx.C1 = real(1.5) + chi; nx.C2 = real(0.5) + chi;
+        nx.plane2 = g.sx * g.sy_v;
+      }
+      auto k5 = TY == 4 ? (ahead ? k_momentum_tendencies_v5<MW, 4, true> : k_momentum_tendencies_v5<MW, 4, false>)
+                        : (ahead ? k_momentum_tendencies_v5<MW, 8, true> : k_momentum_tendencies_v5<MW, 8, false>);
+      hipLaunchKernelGGL(k5, dim3(nb), dim3(V2_TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                         m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, nbx, kchunks, nb,
+                         nx);
+      if (ahead) {
+        dim3 b(64, 4);
+        hipLaunchKernelGGL(k_ab2_velocities_finish, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->uv_partials, kchunks,
+                           nx.plane2, m->ahead_G[0].d, m->ahead_G[1].d, m->ahead_colsum[0].d, m->ahead_colsum[1].d);
+        m->ahead_uv_valid = true;
+        m->ahead_uv_dt = dt;
+        m->ahead_uv_chi = chi;
+      }
+      LAUNCHCHK();
+      return GB25_OK;
+    }
     hipLaunchKernelGGL(kern, dim3(nb), dim3(V2_TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                        m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, nbx, kchunks, nb);
     LAUNCHCHK();
@@ -560,11 +595,24 @@ gb25_status tracers_impl(gb25_model* m) {
 
 gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
   const Grid& g = m->g;
+  if (m->ahead_uv_valid && dt == m->ahead_uv_dt && chi == m->ahead_uv_chi) {
+    // the last momentum evaluation already advanced u and v with exactly these parameters: adopt its buffers
+    for (int q = 0; q < 2; q++) {
+      std::swap(m->f[GB25_U + q].d, m->ahead_uv[q].d);
+      std::swap(m->f[GB25_GN_BT_U + q].d, m->ahead_G[q].d);
+      std::swap(m->colsum[q].d, m->ahead_colsum[q].d);
+    }
+    m->colsum_valid = true;
+    m->ahead_uv_valid = false;
+    return GB25_OK;
+  }
+  m->ahead_uv_valid = false;
   dim3 b(64, 4);
   Timed t(m, GB25_K_AB2_VELOCITIES);
   hipLaunchKernelGGL(k_ab2_velocities, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                      m->f[GB25_GN_U].d, m->f[GB25_GM_U].d, m->f[GB25_GN_V].d, m->f[GB25_GM_V].d,
-                     m->f[GB25_GN_BT_U].d, m->f[GB25_GN_BT_V].d, m->colsum[0].d, m->colsum[1].d, dt, chi);
+                     m->f[GB25_GN_BT_U].d, m->f[GB25_GN_BT_V].d, m->colsum[0].d, m->colsum[1].d, dt, chi,
+                     std::max(1, g.Nz / 12));   // the momentum kernel's chunking (momentum_impl)
   m->colsum_valid = true;
   LAUNCHCHK();
   return GB25_OK;
@@ -692,7 +740,7 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false) {
   // cache_previous_tendencies!: G^- <- G^n is a pointer exchange; the next tendency evaluation
   // overwrites the (old G^-) buffers that now carry the G^n name.
   for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);
-  m->ahead_valid = false;   // the look-ahead used the tendency pair as it was before this exchange
+  m->ahead_valid = m->ahead_uv_valid = false;   // the look-aheads used the tendency pairs as they were before
   return GB25_OK;
 }
 
@@ -859,8 +907,18 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     if ((s = alloc_field(m, m->pp[q], sx, m->f[GB25_ETA + q].ny, 1))) return s;
   if ((s = alloc_field(m, m->dpx, m->f[GB25_PHY].nx, m->f[GB25_PHY].ny, m->f[GB25_PHY].nz))) return s;
   if ((s = alloc_field(m, m->dpy, m->f[GB25_PHY].nx, m->f[GB25_PHY].ny, m->f[GB25_PHY].nz))) return s;
-  for (int q = 0; q < 2; q++)
+  for (int q = 0; q < 2; q++) {
     if ((s = alloc_field(m, m->ahead[q], m->f[GB25_T].nx, m->f[GB25_T].ny, m->f[GB25_T].nz))) return s;
+    const Field &V3 = m->f[GB25_U + q], &V2 = m->f[GB25_GN_BT_U + q], &C2 = m->f[GB25_BT_U + q];
+    if ((s = alloc_field(m, m->ahead_uv[q], V3.nx, V3.ny, V3.nz))) return s;
+    if ((s = alloc_field(m, m->ahead_G[q], V2.nx, V2.ny, 1))) return s;
+    if ((s = alloc_field(m, m->ahead_colsum[q], C2.nx, C2.ny, 1))) return s;
+  }
+  {
+    const size_t np = (size_t)4 * std::max(1, m->g.Nz / 12) * m->g.sx * m->g.sy_v;
+    HIPCHK(hipMalloc(&m->uv_partials, np * sizeof(real)));
+    HIPCHK(hipMemset(m->uv_partials, 0, np * sizeof(real)));
+  }
   if ((s = alloc_field(m, m->colsum[0], sx, m->f[GB25_BT_U].ny, 1))) return s;
   if ((s = alloc_field(m, m->colsum[1], sx, m->f[GB25_BT_V].ny, 1))) return s;
   if (cfg->nranks > 1) {
@@ -896,8 +954,10 @@ void gb25_destroy(gb25_model* m) {
     if (p.d) hipFree(p.d);
   for (auto& p : m->colsum)
     if (p.d) hipFree(p.d);
-  for (auto& p : m->ahead)
-    if (p.d) hipFree(p.d);
+  for (int q = 0; q < 2; q++)
+    for (Field* p : {&m->ahead[q], &m->ahead_uv[q], &m->ahead_G[q], &m->ahead_colsum[q]})
+      if (p->d) hipFree(p->d);
+  if (m->uv_partials) hipFree(m->uv_partials);
   for (int a = 0; a < 2; a++) {
     for (auto& w : m->wide[a])
       if (w.d) hipFree(w.d);
@@ -994,12 +1054,20 @@ static gb25_status mirror_tracers(gb25_model* m) {
                           hipMemcpyDeviceToDevice, m->stream));
   return GB25_OK;
 }
+static gb25_status mirror_velocities(gb25_model* m) {   // u and v alternate between two buffers likewise
+  m->ahead_uv_valid = false;
+  for (int q = 0; q < 2; q++)
+    HIPCHK(hipMemcpyAsync(m->ahead_uv[q].d, m->f[GB25_U + q].d, m->f[GB25_U + q].elems() * sizeof(real),
+                          hipMemcpyDeviceToDevice, m->stream));
+  return GB25_OK;
+}
 gb25_status gb25_set_field(gb25_model* m, gb25_field f, const void* host, int include_halos) {
   gb25_status s = copy_field(m, f, static_cast<real*>(const_cast<void*>(host)), include_halos, true);
   if (s == GB25_OK && f == GB25_PHY) s = widen_phy(m);
   if (s == GB25_OK) {
-    m->ahead_valid = false;   // any input of the look-ahead may have changed
+    m->ahead_valid = m->ahead_uv_valid = false;   // any input of the look-aheads may have changed
     if (f == GB25_T || f == GB25_S) s = mirror_tracers(m);
+    if (f == GB25_U || f == GB25_V) s = mirror_velocities(m);
   }
   return s;
 }
@@ -1009,11 +1077,12 @@ gb25_status gb25_get_field(gb25_model* m, gb25_field f, void* host_, int include
 }
 gb25_status gb25_field_device_ptr(gb25_model* m, gb25_field id, void** dev) {
   if (!m || id < 0 || id >= GB25_FIELD_COUNT || !dev) return GB25_ERR_INVALID_ARGUMENT;
-  if (id == GB25_T || id == GB25_S || id == GB25_GN_T || id == GB25_GN_S || id == GB25_GM_T || id == GB25_GM_S) {
-    // the host can now write T, S or their tendencies behind our back: no more look-ahead for this model,
-    // T and S stay in the buffers whose addresses are handed out
+  if (id == GB25_U || id == GB25_V || id == GB25_T || id == GB25_S || (id >= GB25_GN_U && id <= GB25_GM_S) ||
+      id == GB25_GN_BT_U || id == GB25_GN_BT_V) {
+    // the host can now write prognostic fields or their tendencies behind our back: no more look-ahead for this
+    // model, u, v, T, S stay in the buffers whose addresses are handed out
     m->ptr_exposed = true;
-    m->ahead_valid = false;
+    m->ahead_valid = m->ahead_uv_valid = false;
   }
   *dev = m->f[id].d;
   return GB25_OK;
@@ -1112,18 +1181,28 @@ static HostState host_state(const gb25_model* m) {
   for (int q = 0; q < 8; q++) h.ptr[q] = m->f[GB25_GN_U + q].d;
   h.ptr[8] = m->f[GB25_T].d; h.ptr[9] = m->f[GB25_S].d;
   h.ptr[10] = m->ahead[0].d; h.ptr[11] = m->ahead[1].d;
-  h.ptr[12] = m->colsum[0].d; h.ptr[13] = m->colsum[1].d;
-  h.ahead_valid = m->ahead_valid; h.colsum_valid = m->colsum_valid;
+  for (int q = 0; q < 2; q++) {
+    h.ptr[12 + q] = m->colsum[q].d;    h.ptr[14 + q] = m->ahead_colsum[q].d;
+    h.ptr[16 + q] = m->f[GB25_U + q].d; h.ptr[18 + q] = m->ahead_uv[q].d;
+    h.ptr[20 + q] = m->f[GB25_GN_BT_U + q].d; h.ptr[22 + q] = m->ahead_G[q].d;
+  }
+  h.ahead_valid = m->ahead_valid; h.colsum_valid = m->colsum_valid; h.ahead_uv_valid = m->ahead_uv_valid;
   h.ahead_dt = m->ahead_dt; h.ahead_chi = m->ahead_chi;
+  h.ahead_uv_dt = m->ahead_uv_dt; h.ahead_uv_chi = m->ahead_uv_chi;
   return h;
 }
 static void set_host_state(gb25_model* m, const HostState& h) {
   for (int q = 0; q < 8; q++) m->f[GB25_GN_U + q].d = h.ptr[q];
   m->f[GB25_T].d = h.ptr[8]; m->f[GB25_S].d = h.ptr[9];
   m->ahead[0].d = h.ptr[10]; m->ahead[1].d = h.ptr[11];
-  m->colsum[0].d = h.ptr[12]; m->colsum[1].d = h.ptr[13];
-  m->ahead_valid = h.ahead_valid; m->colsum_valid = h.colsum_valid;
+  for (int q = 0; q < 2; q++) {
+    m->colsum[q].d = h.ptr[12 + q];    m->ahead_colsum[q].d = h.ptr[14 + q];
+    m->f[GB25_U + q].d = h.ptr[16 + q]; m->ahead_uv[q].d = h.ptr[18 + q];
+    m->f[GB25_GN_BT_U + q].d = h.ptr[20 + q]; m->ahead_G[q].d = h.ptr[22 + q];
+  }
+  m->ahead_valid = h.ahead_valid; m->colsum_valid = h.colsum_valid; m->ahead_uv_valid = h.ahead_uv_valid;
   m->ahead_dt = h.ahead_dt; m->ahead_chi = h.ahead_chi;
+  m->ahead_uv_dt = h.ahead_uv_dt; m->ahead_uv_chi = h.ahead_uv_chi;
 }
 static void drop_graphs(gb25_model* m) {
   for (auto& e : m->graphs) {

@@ -433,36 +433,71 @@ __global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, real* __restrict
                                                         const real* __restrict__ Gnv, const real* __restrict__ Gmv,
                                                         real* __restrict__ GU, real* __restrict__ GV,
                                                         real* __restrict__ Usum, real* __restrict__ Vsum, real dt,
-                                                        real chi) {
+                                                        real chi, int kchunks) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= g.Nx || j >= g.Ny) return;
   const real C1 = real(1.5) + chi, C2 = real(0.5) + chi;
   const real ne = (chi != -real(0.5)) ? real(1.) : real(0.);
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
-  real su = real(0.), sv = real(0.), iu = real(0.), iv_ = real(0.);
+  // The column integrals are summed per chunk of levels and the chunk sums added in order: the association of
+  // the momentum kernel's look-ahead (UvAhead, kernels_v2.hpp), whose blocks own one chunk of a column each, so
+  // that both routes give the same bits.  Explicit FMAs for the same reason.
+  const int klen = (g.Nz + kchunks - 1) / kchunks;
+  real SU = real(0.), SV = real(0.), IU = real(0.), IV = real(0.);
+  for (int k0 = 0; k0 < g.Nz; k0 += klen) {
+    const int k1 = min(g.Nz, k0 + klen);
+    real su = real(0.), sv = real(0.), iu = real(0.), iv_ = real(0.);
 #pragma unroll 4
-  for (int k = 0; k < g.Nz; k++) {
-    real dz = g.dzc[k];
-    real gu = C1 * Gnu[o] - C2 * Gmu[o] * ne;
-    real gv = C1 * Gnv[ov] - C2 * Gmv[ov] * ne;
-    real un = u[o] + dt * gu, vn = v[ov] + dt * gv;
-    u[o] = un;
-    v[ov] = vn;
-    su = (k == 0) ? dz * gu : su + dz * gu;
-    sv = (k == 0) ? dz * gv : sv + dz * gv;
-    // column integrals of the UPDATED velocities: the barotropic corrector needs them after the sub-cycle and
-    // they are in registers here (saves the corrector's first sweep over u and v)
-    iu = (k == 0) ? dz * un : iu + dz * un;
-    iv_ = (k == 0) ? dz * vn : iv_ + dz * vn;
-    o += g.pl_c;
-    ov += g.pl_v;
+    for (int k = k0; k < k1; k++) {
+      real dz = g.dzc[k];
+      real gu = rfma(C1, Gnu[o], -((C2 * Gmu[o]) * ne));
+      real gv = rfma(C1, Gnv[ov], -((C2 * Gmv[ov]) * ne));
+      real un = rfma(dt, gu, u[o]), vn = rfma(dt, gv, v[ov]);
+      u[o] = un;
+      v[ov] = vn;
+      su = (k == k0) ? dz * gu : rfma(dz, gu, su);
+      sv = (k == k0) ? dz * gv : rfma(dz, gv, sv);
+      // column integrals of the UPDATED velocities: the barotropic corrector needs them after the sub-cycle and
+      // they are in registers here (saves the corrector's first sweep over u and v)
+      iu = (k == k0) ? dz * un : rfma(dz, un, iu);
+      iv_ = (k == k0) ? dz * vn : rfma(dz, vn, iv_);
+      o += g.pl_c;
+      ov += g.pl_v;
+    }
+    SU = (k0 == 0) ? su : SU + su;
+    SV = (k0 == 0) ? sv : SV + sv;
+    IU = (k0 == 0) ? iu : IU + iu;
+    IV = (k0 == 0) ? iv_ : IV + iv_;
   }
   const int o2 = i2(g, i, j);
-  GU[o2] = su;
-  GV[o2] = (j == 0) ? real(0.) : sv;  // the wall face is a peripheral node
-  Usum[o2] = iu;
-  Vsum[o2] = (j == 0) ? real(0.) : iv_;  // v on the wall face is reset to zero by the halo fill before the corrector
+  GU[o2] = SU;
+  GV[o2] = (j == 0) ? real(0.) : SV;  // the wall face is a peripheral node
+  Usum[o2] = IU;
+  Vsum[o2] = (j == 0) ? real(0.) : IV;  // v on the wall face is reset to zero by the halo fill before the corrector
+}
+// Second half of the velocity look-ahead: adds up the per-chunk column sums the momentum kernel left in P
+// (layout [quantity 0..3][chunk][2-D parent]) in chunk order.
+__global__ __launch_bounds__(256) void k_ab2_velocities_finish(Grid g, const real* __restrict__ P, int kchunks,
+                                                               int plane2, real* __restrict__ GU,
+                                                               real* __restrict__ GV, real* __restrict__ Usum,
+                                                               real* __restrict__ Vsum) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const int o2 = i2(g, i, j);
+  real t[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const real* Pq = P + (long)q * kchunks * plane2 + o2;
+    real a = Pq[0];
+    for (int kc = 1; kc < kchunks; kc++) a = a + Pq[(long)kc * plane2];
+    t[q] = a;
+  }
+  GU[o2] = t[0];
+  GV[o2] = (j == 0) ? real(0.) : t[1];
+  Usum[o2] = t[2];
+  Vsum[o2] = (j == 0) ? real(0.) : t[3];
 }
 
 // tracers: flat AXPY over the interior planes of a parent array (G halos are identically zero)

@@ -478,11 +478,21 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v2(
 // where the vorticity reconstruction of G_u drops below order 5 but G_v's does not, take the scalar form for that
 // one pair.
 // =============================================================================================
-template <int MINW, int V2_TY>
+// AHEAD: the kernel also performs the NEXT step's ab2_step_field! of u and v into partner arrays (un, vn) and leaves
+// the per-chunk column sums of (C1 G^n - C2 G^-) dz and of un dz, vn dz in P; k_ab2_velocities_finish adds the chunks
+// up into G.U, G.V and the corrector's column integrals.  u, v and the fresh tendencies are in registers here, so the
+// separate 6R + 2W sweep of k_ab2_velocities shrinks to one read (G^-) and one write per component.
+struct UvAhead {
+  const real *GmU, *GmV;
+  real *un, *vn, *P;
+  real dt, C1, C2;
+  int plane2;
+};
+template <int MINW, int V2_TY, bool AHEAD>
 __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     Grid g, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ w,
     const real* __restrict__ dpx, const real* __restrict__ dpy, real* __restrict__ Gu, real* __restrict__ Gv,
-    int nbx, int kchunks, int nb) {
+    int nbx, int kchunks, int nb, UvAhead next) {
   __shared__ MomentumLds<V2_TY> lds;
   constexpr int MU_Y = V2_TY + 6, MW_Y = V2_TY + 3, MD_Y = V2_TY + 5;
   const int L = xcd_remap(blockIdx.x, nb);
@@ -573,6 +583,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     for (int q = 0; q < NEW; q++)
       if (ew_off[q] >= 0) W0[ew_lds[q]] = rw[q];
   };
+  real sAu = real(0.), sAv = real(0.), sIu = real(0.), sIv = real(0.);   // AHEAD: this chunk's column sums
   fetch(k0, o);
   stash(k0 & 1);
   real pw_ = rpw, ps_ = rps;   // p'(i,j) - p'(i-1,j) and p'(i,j) - p'(i,j-1) of the current level
@@ -749,6 +760,16 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     if (inside) {
       Gu[o] = gu;
       Gv[ov] = gv;
+      if (AHEAD) {
+        const real au = rfma(next.C1, gu, -(next.C2 * next.GmU[o])), av = rfma(next.C1, gv, -(next.C2 * next.GmV[ov]));
+        const real un = rfma(next.dt, au, uz[3]), vn = rfma(next.dt, av, vz[3]);
+        next.un[o] = un;
+        next.vn[ov] = vn;
+        sAu = (k == k0) ? dz * au : rfma(dz, au, sAu);
+        sAv = (k == k0) ? dz * av : rfma(dz, av, sAv);
+        sIu = (k == k0) ? dz * un : rfma(dz, un, sIu);
+        sIv = (k == k0) ? dz * vn : rfma(dz, vn, sIv);
+      }
     }
     o += pc;
     ov += pv;
@@ -765,6 +786,13 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
       ps_ = rps;
     }
     __syncthreads();   // next tiles visible; derived arrays free for the next phase 1
+  }
+  if (AHEAD && inside) {
+    const long o2 = i2(g, i, j), q = (long)kchunks * next.plane2, c = (long)kc * next.plane2;
+    next.P[c + o2] = sAu;
+    next.P[q + c + o2] = sAv;
+    next.P[2 * q + c + o2] = sIu;
+    next.P[3 * q + c + o2] = sIv;
   }
 }
 

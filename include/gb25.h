@@ -116,9 +116,10 @@ gb25_status gb25_set_field(gb25_model *m, gb25_field f, const void *host, int in
 gb25_status gb25_get_field(gb25_model *m, gb25_field f, void *host, int include_halos);
 /* Device pointer of parent(field) for zero-copy wrapping (e.g. unsafe_wrap(ROCArray, ...)).
  * G^n / G^- pointers are exchanged by correct_and_cache (a pointer swap replaces the copy): ask again after a step.
- * T and S normally alternate between two buffers as well (the tendency kernel writes the next time level ahead of
- * ab2_step!); asking for the pointer of T, S or one of their tendencies pins T and S to the buffers handed out and
- * turns that look-ahead off for this model, because writes through the pointer cannot be seen by the library. */
+ * u, v, T and S normally alternate between two buffers as well (the tendency kernels write the next time level
+ * ahead of ab2_step!); asking for the pointer of a prognostic 3-D field or of a tendency pins them to the buffers
+ * handed out and turns that look-ahead off for this model, because writes through the pointer cannot be seen by
+ * the library. */
 gb25_status gb25_field_device_ptr(gb25_model *m, gb25_field f, void **dev);
 gb25_status gb25_get_metric(const gb25_model *m, gb25_metric id, int32_t logical_index, double *value);
 gb25_status gb25_get_substepping(const gb25_model *m, int32_t *n_effective, double *dtau_fraction,
