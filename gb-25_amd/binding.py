@@ -38,7 +38,8 @@ ABI_SYMBOLS = [
     "gb25_compute_momentum_tendencies", "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
     "gb25_compute_tendencies", "gb25_ab2_step", "gb25_correct_velocities_and_cache_previous_tendencies",
     "gb25_update_state", "gb25_first_time_step", "gb25_time_step", "gb25_loop",
-    "gb25_halo_buffer_elems", "gb25_halo_pack", "gb25_halo_unpack", "gb25_time_step_stage",
+    "gb25_halo_buffer_elems", "gb25_halo_pack", "gb25_halo_unpack", "gb25_halo_pack_both", "gb25_halo_unpack_both",
+    "gb25_time_step_stage",
     "gb25_update_state_local", "gb25_fill_halo_regions_local",
     "gb25_profile_enable", "gb25_profile_reset", "gb25_profile_get",
 ]
@@ -99,6 +100,8 @@ def load_library(float_type="Float32"):
     lib.gb25_halo_buffer_elems.argtypes = [P, C.c_int, C.POINTER(C.c_int64)]
     lib.gb25_halo_pack.argtypes = [P, C.c_int, C.c_int, P]
     lib.gb25_halo_unpack.argtypes = [P, C.c_int, C.c_int, P]
+    lib.gb25_halo_pack_both.argtypes = [P, C.c_int, P, P]
+    lib.gb25_halo_unpack_both.argtypes = [P, C.c_int, P, P]
     lib.gb25_time_step_stage.argtypes = [P, C.c_int, C.c_int]
     lib.gb25_profile_enable.argtypes = [P, C.c_int]
     lib.gb25_profile_get.argtypes = [P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
@@ -247,6 +250,10 @@ class HipBackend:
 
     def halo_pack(self, group, side, dev_ptr): self._call("gb25_halo_pack", group, side, C.c_void_p(dev_ptr))
     def halo_unpack(self, group, side, dev_ptr): self._call("gb25_halo_unpack", group, side, C.c_void_p(dev_ptr))
+    def halo_pack_both(self, group, west_ptr, east_ptr):
+        self._call("gb25_halo_pack_both", group, C.c_void_p(west_ptr), C.c_void_p(east_ptr))
+    def halo_unpack_both(self, group, west_ptr, east_ptr):
+        self._call("gb25_halo_unpack_both", group, C.c_void_p(west_ptr), C.c_void_p(east_ptr))
 
     # ---- timers
     def profile_enable(self, on=True): self._call("gb25_profile_enable", int(on))

@@ -450,15 +450,30 @@ gb25_status compute_w_impl(gb25_model* m) {
   LAUNCHCHK();
   return GB25_OK;
 }
-gb25_status compute_p_impl(gb25_model* m) {
+// Hydrostatic pressure on columns [i_first, i_last] (default: the whole extended range -H+1 .. Nx+H-2; column
+// i_first - 1 is read as the west neighbour of the first x difference), optionally on a second range as well.
+gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = INT_MIN, int i_first_b = 0,
+                           int i_last_b = -1) {
   const Grid& g = m->g;
+  if (i_first == INT_MIN) {
+    i_first = -g.H + 1;
+    i_last = g.Nx + g.H - 2;
+  }
   Timed t(m, GB25_K_COMPUTE_P);
   dim3 b(64, 4);
-  const int ncol = g.Nx + 2 * g.H - 1;   // columns -H .. Nx+H-2 (the first one only as a west neighbour)
-  const int nrow = g.Ny + 2 * g.H - 2;   // rows -H+1 .. Ny+H-2
-  dim3 gr((ncol + 62) / 63, (nrow + PR * 4 - 1) / (PR * 4));
-  hipLaunchKernelGGL(k_compute_p, gr, b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_PHY].d, m->dpx.d,
-                     m->dpy.d);
+  const int ncol = i_last - i_first + 2;   // written columns + the helper column
+  const int ncol_b = i_last_b >= i_first_b ? i_last_b - i_first_b + 2 : 0;
+  const int nrow = g.Ny + 2 * g.H - 2;     // rows -H+1 .. Ny+H-2
+  const int tiles_a = (ncol + 62) / 63, tiles_b = (ncol_b + 62) / 63;
+  if (ncol <= 63) {   // strips: one row per thread (4x the waves, short chains)
+    dim3 gr(tiles_a + tiles_b, (nrow + 3) / 4);
+    hipLaunchKernelGGL(k_compute_p<1>, gr, b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_PHY].d,
+                       m->dpx.d, m->dpy.d, i_first, i_last, i_first_b, i_last_b, tiles_a);
+  } else {
+    dim3 gr(tiles_a + tiles_b, (nrow + PR * 4 - 1) / (PR * 4));
+    hipLaunchKernelGGL(k_compute_p<PR>, gr, b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_PHY].d,
+                       m->dpx.d, m->dpy.d, i_first, i_last, i_first_b, i_last_b, tiles_a);
+  }
   LAUNCHCHK();
   return GB25_OK;
 }
@@ -673,10 +688,10 @@ gb25_status barotropic_impl(gb25_model* m, real dt) {
     bb.GU = m->f[GB25_GN_BT_U].d; bb.GV = m->f[GB25_GN_BT_V].d;
     bb.sx = g.sx; bb.xo = g.H; bb.ilo = 0; bb.ihi = g.Nx; bb.wrap = 1;
   } else {
-    for (int q = 0; q < 3; q++) {
-      HIPCHK(hipMemsetAsync(m->wideBar[q].d, 0, m->wideBar[q].elems() * sizeof(real), m->stream));
-      cur[q] = m->wide[0][q].d; nxt[q] = m->wide[1][q].d;
-    }
+    HIPCHK(hipMemsetAsync(m->wideBar[0].d, 0,
+                          (m->wideBar[0].elems() + m->wideBar[1].elems() + m->wideBar[2].elems()) * sizeof(real),
+                          m->stream));
+    for (int q = 0; q < 3; q++) { cur[q] = m->wide[0][q].d; nxt[q] = m->wide[1][q].d; }
     bb.etab = m->wideBar[0].d; bb.Ub = m->wideBar[1].d; bb.Vb = m->wideBar[2].d;
     bb.GU = m->wideG[0].d; bb.GV = m->wideG[1].d;
     bb.sx = g.Nx + 2 * m->W; bb.xo = m->W; bb.ilo = -m->W + 1; bb.ihi = g.Nx + m->W - 1; bb.wrap = 0;
@@ -712,11 +727,16 @@ gb25_status barotropic_impl(gb25_model* m, real dt) {
   hipLaunchKernelGGL(k_barotropic_finalize, gi, b, 0, m->stream, g, m->f[GB25_ETA].d, m->f[GB25_BT_U].d,
                      m->f[GB25_BT_V].d, bb.etab, bb.Ub, bb.Vb, bb.sx, bb.xo);
   if (wide) {  // publish the averages in the canonical filtered-state arrays (compared by compare_states)
+    InteriorCopies C{};
+    int rmax = 0;
     for (int q = 0; q < 3; q++) {
       Field& dst = m->f[GB25_ETA_BAR + q];
-      hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, dst.ny), dim3(256), 0, m->stream, dst.d,
-                         dst.nx, g.H, m->wideBar[q].d, bb.sx, bb.xo, g.Nx, dst.ny);
+      C.dst[q] = dst.d; C.dsx[q] = dst.nx; C.dxo[q] = g.H;
+      C.src[q] = m->wideBar[q].d; C.ssx[q] = bb.sx; C.sxo[q] = bb.xo; C.rows[q] = dst.ny;
+      rmax = std::max(rmax, dst.ny);
     }
+    C.n = 3;
+    hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, rmax, C.n), dim3(256), 0, m->stream, C, g.Nx);
   }
   LAUNCHCHK();
   return GB25_OK;
@@ -929,8 +949,20 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     for (int a = 0; a < 2; a++)
       for (int q = 0; q < 3; q++)
         if ((s = alloc_field(m, m->wide[a][q], wsx, m->f[GB25_ETA + q].ny, 1))) return s;
-    for (int q = 0; q < 3; q++)
-      if ((s = alloc_field(m, m->wideBar[q], wsx, m->f[GB25_ETA + q].ny, 1))) return s;
+    {   // the three running averages are one allocation, zeroed by one memset per step
+      size_t tot = 0;
+      for (int q = 0; q < 3; q++) {
+        m->wideBar[q].nx = wsx; m->wideBar[q].ny = m->f[GB25_ETA + q].ny; m->wideBar[q].nz = 1;
+        tot += m->wideBar[q].elems();
+      }
+      real* base = nullptr;
+      HIPCHK(hipMalloc(&base, tot * sizeof(real)));
+      HIPCHK(hipMemset(base, 0, tot * sizeof(real)));
+      for (int q = 0; q < 3; q++) {
+        m->wideBar[q].d = base;
+        base += m->wideBar[q].elems();
+      }
+    }
     if ((s = alloc_field(m, m->wideG[0], wsx, m->f[GB25_GN_BT_U].ny, 1))) return s;
     if ((s = alloc_field(m, m->wideG[1], wsx, m->f[GB25_GN_BT_V].ny, 1))) return s;
   }
@@ -963,8 +995,7 @@ void gb25_destroy(gb25_model* m) {
       if (w.d) hipFree(w.d);
     if (m->wideG[a].d) hipFree(m->wideG[a].d);
   }
-  for (auto& w : m->wideBar)
-    if (w.d) hipFree(w.d);
+  if (m->wideBar[0].d) hipFree(m->wideBar[0].d);   // one allocation for all three
   for (real* t : m->dev_tables) hipFree(t);
   resolve_profile(m);
   for (auto& ev : m->free_events) {
@@ -1319,37 +1350,58 @@ gb25_status gb25_halo_buffer_elems(const gb25_model* m, int group, int64_t* n) {
   *n = t;
   return GB25_OK;
 }
-static gb25_status pack_unpack(gb25_model* m, int group, int side, real* buf, bool pack) {
-  if (!m || !buf || group < 0 || group > 2 || side < 0 || side > 1) return GB25_ERR_INVALID_ARGUMENT;
+// side_mask: bit 0 = west, bit 1 = east; buf[side] = that side's contiguous device buffer
+static gb25_status pack_unpack(gb25_model* m, int group, int side_mask, real* const buf[2], bool pack) {
+  if (!m || group < 0 || group > 2 || !(side_mask & 3)) return GB25_ERR_INVALID_ARGUMENT;
   if (m->cfg.nranks == 1) return fail(m, GB25_ERR_STATE, "halo pack/unpack on a single-slab model");
   std::vector<Piece> ps;
   int nc = 0;
   group_pieces(m, group, ps, &nc);
-  size_t off = 0;
-  for (auto& p : ps) {
-    long n = p.rows * nc;
-    unsigned blocks = (unsigned)((n + 255) / 256);
-    if (pack) {
-      // west side: interior columns [0, nc); east side: [Nx-nc, Nx)
-      int i0 = p.src_xo + (side == 0 ? 0 : m->Nx - nc);
-      hipLaunchKernelGGL(k_pack_columns, dim3(blocks), dim3(256), 0, m->stream, p.src, buf + off, p.src_sx, nc, i0,
-                         p.rows);
-    } else {
-      // west halo: columns [-nc, 0); east halo: [Nx, Nx+nc)
-      int i0 = p.dst_xo + (side == 0 ? -nc : m->Nx);
-      hipLaunchKernelGGL(k_unpack_columns, dim3(blocks), dim3(256), 0, m->stream, p.dst, buf + off, p.dst_sx, nc, i0,
-                         p.rows);
+  ColumnPieces P{};
+  P.ncols = nc;
+  long max_n = 0;
+  for (int side = 0; side < 2; side++) {
+    if (!(side_mask & (1 << side))) continue;
+    if (!buf[side]) return GB25_ERR_INVALID_ARGUMENT;
+    size_t off = 0;
+    for (auto& p : ps) {
+      const int f = P.n++;
+      P.rows[f] = p.rows;
+      P.buf[f] = buf[side] + off;
+      if (pack) {   // west side: interior columns [0, nc); east side: [Nx-nc, Nx)
+        P.arr[f] = p.src; P.sx[f] = p.src_sx; P.i0[f] = p.src_xo + (side == 0 ? 0 : m->Nx - nc);
+      } else {      // west halo: columns [-nc, 0); east halo: [Nx, Nx+nc)
+        P.arr[f] = p.dst; P.sx[f] = p.dst_sx; P.i0[f] = p.dst_xo + (side == 0 ? -nc : m->Nx);
+      }
+      off += (size_t)p.rows * nc;
+      max_n = std::max(max_n, p.rows * nc);
     }
-    off += n;
   }
+  dim3 gr((unsigned)((max_n + 255) / 256), (unsigned)P.n);
+  if (pack) hipLaunchKernelGGL(k_move_columns<true>, gr, dim3(256), 0, m->stream, P);
+  else hipLaunchKernelGGL(k_move_columns<false>, gr, dim3(256), 0, m->stream, P);
   LAUNCHCHK();
   return GB25_OK;
 }
 gb25_status gb25_halo_pack(gb25_model* m, int group, int side, void* buf) {
-  return pack_unpack(m, group, side, static_cast<real*>(buf), true);
+  if (side < 0 || side > 1) return GB25_ERR_INVALID_ARGUMENT;
+  real* b[2] = {nullptr, nullptr};
+  b[side] = static_cast<real*>(buf);
+  return pack_unpack(m, group, 1 << side, b, true);
 }
 gb25_status gb25_halo_unpack(gb25_model* m, int group, int side, const void* buf) {
-  return pack_unpack(m, group, side, static_cast<real*>(const_cast<void*>(buf)), false);
+  if (side < 0 || side > 1) return GB25_ERR_INVALID_ARGUMENT;
+  real* b[2] = {nullptr, nullptr};
+  b[side] = static_cast<real*>(const_cast<void*>(buf));
+  return pack_unpack(m, group, 1 << side, b, false);
+}
+gb25_status gb25_halo_pack_both(gb25_model* m, int group, void* west_buf, void* east_buf) {
+  real* b[2] = {static_cast<real*>(west_buf), static_cast<real*>(east_buf)};
+  return pack_unpack(m, group, 3, b, true);
+}
+gb25_status gb25_halo_unpack_both(gb25_model* m, int group, const void* west_buf, const void* east_buf) {
+  real* b[2] = {static_cast<real*>(const_cast<void*>(west_buf)), static_cast<real*>(const_cast<void*>(east_buf))};
+  return pack_unpack(m, group, 3, b, false);
 }
 
 // The time step of one slab, cut at its two exchange points (see include/gb25.h).
@@ -1364,15 +1416,38 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
     // AB2 update of u,v,T,S + barotropic forcing, then the y/z boundary layers of the 3-D bundle so that its packed
     // x columns (group 0) can travel WHILE the sub-cycle runs; the host also exchanges group 1 now
     if ((s = ab2_local_impl(m, (real)dt, chi))) return s;
-    return fill_halos_impl(m, false, false, 1);
+    if ((s = fill_halos_impl(m, false, false, 1))) return s;
+    if (m->two_streams) {
+      // T, S of the slab's own columns are final from here on: their pressure (fp64-bound) runs on the side stream
+      // beside the exchanges and the sub-cycle; the strips next to the x halos follow in stage 2.  The first x
+      // difference of this pass reads a stale halo column and is redone by the west strip.
+      HIPCHK(hipEventRecord(m->ev_fork, m->stream));
+      HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
+      hipStream_t main = m->stream;
+      m->stream = m->side_stream;
+      s = compute_p_impl(m, 0, g.Nx - 1);
+      m->stream = main;
+      if (s) return s;
+      HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
+    }
+    return GB25_OK;
   } else if (stage == 1) {
     // group 1 has been unpacked into the wide halos: copy the interiors, sub-cycle, publish
     std::vector<Piece> ps;
     int nc = 0;
     group_pieces(m, 1, ps, &nc);
-    for (auto& p : ps)
-      hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, (unsigned)p.rows), dim3(256), 0, m->stream,
-                         p.dst, p.dst_sx, p.dst_xo, p.src, p.src_sx, p.src_xo, g.Nx, (int)p.rows);
+    {
+      InteriorCopies C{};
+      int rmax = 0;
+      for (auto& p : ps) {
+        const int q = C.n++;
+        C.dst[q] = p.dst; C.dsx[q] = p.dst_sx; C.dxo[q] = p.dst_xo;
+        C.src[q] = p.src; C.ssx[q] = p.src_sx; C.sxo[q] = p.src_xo; C.rows[q] = (int)p.rows;
+        rmax = std::max(rmax, (int)p.rows);
+      }
+      hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, rmax, C.n), dim3(256), 0, m->stream, C,
+                         g.Nx);
+    }
     LAUNCHCHK();
     if ((s = barotropic_impl(m, (real)dt))) return s;
     m->time += dt;
@@ -1383,9 +1458,26 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
     // group 0 has been unpacked: corrector on interior + x-halo columns, then update_state without any
     // further exchange (y/z layers re-filled over the extended x range; w and p recomputed in the halos)
     if ((s = corrector_impl(m, true))) return s;
+    // the interior pressure pass of stage 0 must be over before the fills touch T, S and before the west strip
+    // rewrites column 0 (it has been for a while: the exchanges and the sub-cycle ran in between)
+    if (m->two_streams) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
     if ((s = fill_halos_impl(m, false, true))) return s;
+    if (m->two_streams) {   // the two pressure strips run beside w (side stream)
+      hipStream_t main = m->stream;
+      HIPCHK(hipEventRecord(m->ev_fork, main));
+      HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
+      m->stream = m->side_stream;
+      s = compute_p_impl(m, -g.H + 1, 0, g.Nx, g.Nx + g.H - 2);      // west strip (redoes column 0) + east strip
+      m->stream = main;
+      if (s) return s;
+      HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
+    }
     if ((s = compute_w_impl(m))) return s;
-    if ((s = compute_p_impl(m))) return s;
+    if (m->two_streams) {
+      HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+    } else {
+      if ((s = compute_p_impl(m))) return s;
+    }
     if ((s = momentum_impl(m))) return s;
     return tracers_impl(m);
   }

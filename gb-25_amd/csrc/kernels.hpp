@@ -156,23 +156,36 @@ __global__ __launch_bounds__(256) void k_compute_w(Grid g, const real* __restric
 // 63); a thread marches R = 4 adjacent rows plus the row south of them at once, which also gives the fp64 EOS
 // chains 5-way instruction-level parallelism.  fp64 VALU is half rate on gfx950; the depth dependence of the
 // 55-term polynomial is folded per level on the host (28 fp64 FMAs per evaluation).
-constexpr int PR = 4;   // rows per thread
+constexpr int PR = 4;   // rows per thread of the full-range launch
+// Columns [i_first, i_last] are written (whole extended range: -H+1 .. Nx+H-2; a slab of a decomposition does
+// its interior early and the strips next to the x halos once those have arrived).
+// PR_: rows per thread.  4 for the full range (five evaluations per level share one helper row); 1 for the narrow
+// strips of a slab, which have too few waves to hide latency behind each other and want short per-level chains.
+template <int PR_>
 __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restrict__ T, const real* __restrict__ S,
                                                    real* __restrict__ p, real* __restrict__ dpx,
-                                                   real* __restrict__ dpy) {
+                                                   real* __restrict__ dpy, int i_first, int i_last, int i_first_b,
+                                                   int i_last_b, int tiles_a) {
+  // an optional second column range [i_first_b, i_last_b] takes the tiles from tiles_a on (both strips of a slab in
+  // one launch)
   const int lane = threadIdx.x;
-  const int i = -g.H + blockIdx.x * 63 + lane;                               // lane 0: helper column
-  const int jb = -g.H + 1 + (blockIdx.y * blockDim.y + threadIdx.y) * PR;    // first of this thread's PR rows
-  const int imax = g.Nx + g.H - 2, jmax = g.Ny + g.H - 2;
+  const bool second = (int)blockIdx.x >= tiles_a;
+  if (second) {
+    i_first = i_first_b;
+    i_last = i_last_b;
+  }
+  const int i = i_first - 1 + ((int)blockIdx.x - (second ? tiles_a : 0)) * 63 + lane;   // lane 0: helper column
+  const int jb = -g.H + 1 + (blockIdx.y * blockDim.y + threadIdx.y) * PR_;    // first of this thread's PR rows
+  const int imax = i_last, jmax = g.Ny + g.H - 2;
   if (jb > jmax) return;                                                    // whole wave leaves together
   const int ic_ = min(i, g.Nx + g.H - 1);                                    // clamp: addresses stay in the parent
   const int Nz = g.Nz;
   const double gr = -(double)g.g / (double)g.rho0;
   const double sc = 0.875 / 35.16504;
-  int o[PR + 1];
-  double bup[PR + 1], pk[PR + 1];
+  int o[PR_ + 1];
+  double bup[PR_ + 1], pk[PR_ + 1];
 #pragma unroll
-  for (int r = 0; r <= PR; r++) {
+  for (int r = 0; r <= PR_; r++) {
     const int j = min(jb - 1 + r, g.Ny + g.H - 1);    // r = 0 is the helper row south of the thread's rows
     o[r] = ic(g, ic_, j, Nz);
     // b in the first halo cell above the surface: mirrored geopotential height (table row Nz)
@@ -183,14 +196,14 @@ __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restric
     const double* c = g.eos + 28 * k;
     const double dz = g.dzf_d[k + 1];
 #pragma unroll
-    for (int r = 0; r <= PR; r++) {
+    for (int r = 0; r <= PR_; r++) {
       o[r] -= g.pl_c;
       double bk = gr * teos10_level(c, sqrt(((double)S[o[r]] + 32.0) * sc), (double)T[o[r]] * 0.025);
       pk[r] = pk[r] - 0.5 * (bk + bup[r]) * dz;
       bup[r] = bk;
     }
 #pragma unroll
-    for (int r = 1; r <= PR; r++) {
+    for (int r = 1; r <= PR_; r++) {
       const double pw = __shfl_up(pk[r], 1);
       const int j = jb - 1 + r;
       if (lane >= 1 && i <= imax && j <= jmax) {
@@ -734,13 +747,20 @@ __global__ void k_barotropic_finalize(Grid g, real* eta, real* U, real* V, const
   U[o] = Ub[q];
   V[o] = Vb[q];
 }
-// copy columns [0, Nx) of whole rows between two 2-D arrays with different pitch / x-offset
-__global__ void k_copy_interior_columns(real* __restrict__ dst, int dsx, int dxo, const real* __restrict__ src,
-                                        int ssx, int sxo, int Nx, int rows) {
+// copy columns [0, Nx) of whole rows between 2-D arrays with different pitch / x-offset; up to five arrays per
+// launch (blockIdx.z = array)
+struct InteriorCopies {
+  real* dst[5];
+  const real* src[5];
+  int dsx[5], dxo[5], ssx[5], sxo[5], rows[5];
+  int n;
+};
+__global__ void k_copy_interior_columns(InteriorCopies C, int Nx) {
+  const int f = blockIdx.z;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int r = blockIdx.y;
-  if (i >= Nx || r >= rows) return;
-  dst[(i + dxo) + dsx * r] = src[(i + sxo) + ssx * r];
+  if (i >= Nx || r >= C.rows[f]) return;
+  C.dst[f][(i + C.dxo[f]) + C.dsx[f] * r] = C.src[f][(i + C.sxo[f]) + C.ssx[f] * r];
 }
 
 // =============================================================================================
@@ -823,23 +843,27 @@ __global__ void k_set_baroclinic_instability(Grid g, real* __restrict__ T, real*
   S[o] = -real(5e-3) * z;
 }
 
-// x-slab halo exchange: pack H interior columns next to a slab edge / unpack into the halo.
-// buffer layout: [row][q] with q in 0..ncols-1, rows = all parent rows of the array.
-__global__ void k_pack_columns(const real* __restrict__ c, real* __restrict__ buf, int sx, int ncols, int i0,
-                               long rows) {
-  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * ncols) return;
-  int q = t % ncols;
-  long row = t / ncols;
-  buf[t] = c[row * sx + i0 + q];
-}
-__global__ void k_unpack_columns(real* __restrict__ c, const real* __restrict__ buf, int sx, int ncols, int i0,
-                                 long rows) {
-  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * ncols) return;
-  int q = t % ncols;
-  long row = t / ncols;
-  c[row * sx + i0 + q] = buf[t];
+// x-slab halo exchange: pack the columns next to a slab edge / unpack into the halo.  ONE launch moves every field of
+// an exchange group on both sides (blockIdx.y = piece): a group used to be up to ten 5-10 us launches in a row on the
+// critical path of the staged step.  buffer layout per piece: [row][q], q in 0..ncols-1, rows = all parent rows.
+struct ColumnPieces {
+  real* arr[10];      // canonical (or wide) array of the piece
+  real* buf[10];      // its segment of the contiguous exchange buffer of that side
+  int sx[10], i0[10]; // row pitch of arr and first column (parent index) of the packed / unpacked strip
+  long rows[10];
+  int n, ncols;
+};
+template <bool PACK>
+__global__ void k_move_columns(ColumnPieces P) {
+  const int f = blockIdx.y;
+  if (f >= P.n) return;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P.rows[f] * P.ncols) return;
+  const int q = (int)(t % P.ncols);
+  const long row = t / P.ncols;
+  real* a = P.arr[f] + row * P.sx[f] + P.i0[f] + q;
+  if (PACK) P.buf[f][t] = *a;
+  else *a = P.buf[f][t];
 }
 
 }  // namespace gb25

@@ -95,14 +95,12 @@ class SlabStepper:
     def pack(self, group, on_comm=False):
         if on_comm and self.cuda:
             self.b.set_stream(self.comm.cuda_stream)
-        for side in (WEST, EAST):
-            self.b.halo_pack(group, side, self.send[group][side].data_ptr())
+        self.b.halo_pack_both(group, self.send[group][WEST].data_ptr(), self.send[group][EAST].data_ptr())
         if on_comm and self.cuda:
             self.b.set_stream(self.main.cuda_stream)
 
     def unpack(self, group):
-        for side in (WEST, EAST):
-            self.b.halo_unpack(group, side, self.recv[group][side].data_ptr())
+        self.b.halo_unpack_both(group, self.recv[group][WEST].data_ptr(), self.recv[group][EAST].data_ptr())
 
 
 class _OnComm:

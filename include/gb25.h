@@ -164,6 +164,9 @@ gb25_status gb25_loop(gb25_model *m, int32_t n_inner);
 gb25_status gb25_halo_buffer_elems(const gb25_model *m, int group, int64_t *n_elements);
 gb25_status gb25_halo_pack(gb25_model *m, int group, int side, void *dev_buffer);
 gb25_status gb25_halo_unpack(gb25_model *m, int group, int side, const void *dev_buffer);
+/* Both sides of a group in ONE kernel launch (what the staged step uses: a group is up to ten small strips). */
+gb25_status gb25_halo_pack_both(gb25_model *m, int group, void *west_buffer, void *east_buffer);
+gb25_status gb25_halo_unpack_both(gb25_model *m, int group, const void *west_buffer, const void *east_buffer);
 /* The time step of one slab, cut at its exchange points (gb25_time_step does all of it when nranks == 1):
  *   stage 0: AB2 update of u,v,T,S, barotropic forcing, y/z layers of the 3-D bundle
  *            -> pack + exchange group 1 (critical path) and group 0 (overlaps with stage 1 on a second stream)

@@ -76,6 +76,14 @@ class _RecordingBackend:
         self._rec("unpack", group, side)
         self.unpacked[(group, side)] = float(self.bufs_recv[group][side][0])
 
+    def halo_pack_both(self, group, west_ptr, east_ptr):        # one launch for both sides in the product
+        for side in (WEST, EAST):
+            self.halo_pack(group, side, None)
+
+    def halo_unpack_both(self, group, west_ptr, east_ptr):
+        for side in (WEST, EAST):
+            self.halo_unpack(group, side, None)
+
 
 def _make_local_ring(P):
     log = []
