@@ -166,11 +166,13 @@ struct Timed {
     }
     hipEventRecord(ev.a, m->stream);
   }
-  ~Timed() {
+  void stop() {
     if (!on) return;
     hipEventRecord(ev.b, m->stream);
     m->pending[k].push_back(ev);
+    on = false;
   }
+  ~Timed() { stop(); }
 };
 
 void resolve_profile(gb25_model* m) {
@@ -517,6 +519,7 @@ gb25_status momentum_impl(gb25_model* m) {
       hipLaunchKernelGGL(k5, dim3(nb), dim3(V2_TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                          m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, nbx, kchunks, nb,
                          nx);
+      t.stop();   // the timer covers the tendency kernel alone
       if (ahead) {
         dim3 b(64, 4);
         hipLaunchKernelGGL(k_ab2_velocities_finish, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->uv_partials, kchunks,
