@@ -115,7 +115,7 @@ struct gb25_model {
   int momentum_v5 = 1;               // packed (G_u term, G_v term) reconstructions; GB25_MOMENTUM_V5=0: scalar v2 kernel
   int momentum_v4 = 0;               // GB25_MOMENTUM_V4=1: single-barrier pipelined momentum kernel
   int tracer_v3 = 5;                 // 5: packed (T,S) wave-autonomous kernel, buffer addressing; 1: scalar v3; 0: LDS v2 (GB25_TRACER_V3)
-  int tile_rows = 8;                 // rows (= waves) per block of the v2 tendency kernels: 8 or 4 (GB25_TILE_ROWS)
+  int tile_rows = 4;                 // rows (= waves) per block of the LDS tendency kernels: 4 or 8 (GB25_TILE_ROWS); 4 wins with the packed kernel: more blocks per CU to cover the barriers
   int variant_c = 1;                 // nontemporal tendency reads in the tracer AB2 stream (GB25_VARIANT_C)
   int variant_a = 1, variant_b = 1;  // tuning switches (GB25_VARIANT_A / _B), see momentum_impl / tracers_impl
   int kernel_gen = 2;  // 2: LDS flux-sharing tendency kernels (kernels_v2.hpp); 1: direct-stencil kernels (GB25_KERNELS=v1)

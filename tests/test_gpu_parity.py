@@ -241,6 +241,41 @@ def test_ragged_sizes_not_multiples_of_the_tile():
     assert_states_close(r, v, label="52x22x6")
 
 
+@pytest.mark.parametrize("Nz", [13, 25, 37, 60, 100])
+def test_vertical_extents_with_ragged_level_chunks(Nz, monkeypatch):
+    """The tendency kernels split a column into max(1, Nz // 12) chunks of ceil(Nz / chunks) levels, the last one
+    shorter (Nz = 100, the 1/12-degree configuration, gives 8 chunks of 13, 13, ... 9; Nz = 60 gives 5 x 12).  Parity
+    with the oracle, and the look-ahead's chunked column sums against the stand-alone kernels bit for bit."""
+    r, v = make_pair(70, 22, Nz, dt=300.0)
+    baroclinic_state(r, v, amplitude=1e-2)
+    monkeypatch.setenv("GB25_AB2_AHEAD", "0")
+    plain = gb.baroclinic_instability_model(gb.GPU(), 70, 22, Nz, dt=300.0)
+    monkeypatch.delenv("GB25_AB2_AHEAD")
+    for n in ALL_FIELDS:
+        plain.backend.set_field(n, r.backend.get_field(n, True), True)
+    for m in (r, v, plain):
+        gb.first_time_step(m)
+        gb.loop(m, 4)
+    assert_states_close(r, v, label=f"Nz={Nz}")
+    for n in ALL_FIELDS:
+        assert np.array_equal(r.backend.get_field(n, True), plain.backend.get_field(n, True)), (Nz, n)
+
+
+@pytest.mark.parametrize("substeps", [8, 31, 60])
+def test_other_substep_counts(substeps):
+    """SplitExplicitFreeSurface(substeps=N): the averaging weights, their truncation and the blocked sub-cycle
+    (7 substeps per launch, remainder in the last launch) for counts other than GB-25's 30."""
+    r, v = make_pair(96, 36, 10, dt=600.0, substeps=substeps)   # (Ny = 40 would put a halo row centre exactly on the pole)
+    nr, fr, wr = r.backend.substepping()
+    nv, fv, wv = v.backend.substepping()
+    assert nr == nv and fr == fv
+    baroclinic_state(r, v, amplitude=1e-2)
+    for m in (r, v):
+        gb.first_time_step(m)
+        gb.loop(m, 5)
+    assert_states_close(r, v, label=f"substeps={substeps}")
+
+
 def test_error_paths():
     from gb25_amd.binding import GB25Error
     with pytest.raises(GB25Error):
