@@ -756,7 +756,8 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false) {
     hipLaunchKernelGGL(k_corrector, grid2(ni, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                        m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d,
                        (use_colsum && m->colsum_valid) ? m->colsum[0].d : nullptr,
-                       (use_colsum && m->colsum_valid) ? m->colsum[1].d : nullptr, i0, ni);
+                       (use_colsum && m->colsum_valid) ? m->colsum[1].d : nullptr, i0, ni,
+                       std::max(1, g.Nz / 12));
     m->colsum_valid = false;
     LAUNCHCHK();
   }

@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
                                                    const real* __restrict__ U, const real* __restrict__ V,
                                                    real* __restrict__ Ub, real* __restrict__ Vb,
                                                    const real* __restrict__ Usum, const real* __restrict__ Vsum,
-                                                   int i0, int ni) {
+                                                   int i0, int ni, int kchunks) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= ni || j >= g.Ny) return;
@@ -799,19 +799,26 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
   const int o0 = ic(g, i, j, 0), ov0 = iv(g, i, j, 0);
   const int o2 = i2(g, i, j);
   int o = o0, ov = ov0;
-  real su, sv;
+  real su = real(0.), sv = real(0.);
   if (Usum != nullptr && i >= 0 && i < g.Nx) {
-    // interior column: the integrals were accumulated by k_ab2_velocities (same summation order)
+    // interior column: the integrals were accumulated by the AB2 kernel / the momentum kernel's look-ahead
     su = Usum[o2];
     sv = Vsum[o2];
   } else {
-    su = g.dzc[0] * u[o];
-    sv = g.dzc[0] * v[ov];
-    for (int k = 1; k < g.Nz; k++) {
-      o += g.pl_c;
-      ov += g.pl_v;
-      su += g.dzc[k] * u[o];
-      sv += g.dzc[k] * v[ov];
+    // same association as theirs (per chunk of levels, chunks added in order, explicit FMAs): a halo column of a
+    // slab must get the bits its owner computes
+    const int klen = (g.Nz + kchunks - 1) / kchunks;
+    for (int k0 = 0; k0 < g.Nz; k0 += klen) {
+      const int k1 = min(g.Nz, k0 + klen);
+      real pu = real(0.), pv = real(0.);
+      for (int k = k0; k < k1; k++) {
+        pu = (k == k0) ? g.dzc[k] * u[o] : rfma(g.dzc[k], u[o], pu);
+        pv = (k == k0) ? g.dzc[k] * v[ov] : rfma(g.dzc[k], v[ov], pv);
+        o += g.pl_c;
+        ov += g.pl_v;
+      }
+      su = (k0 == 0) ? pu : su + pu;
+      sv = (k0 == 0) ? pv : sv + pv;
     }
   }
   if (i >= 0 && i < g.Nx) {

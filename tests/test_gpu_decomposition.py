@@ -23,9 +23,11 @@ def _initial(Nx, Ny, Nz, single):
     return {n: single.backend.get_field(n, False) for n in ("u", "v", "T", "S", "eta")}
 
 
-@pytest.mark.parametrize("P", [2, 4])
-def test_slabs_reproduce_single_domain_bitwise(P):
-    Nx, Ny, Nz, dt = 128, 48, 8, 600.0
+@pytest.mark.parametrize("P,Nz", [(2, 8), (4, 8), (2, 24), (4, 36)])
+def test_slabs_reproduce_single_domain_bitwise(P, Nz):
+    # Nz >= 24: the column integrals are summed in chunks of levels (the corrector of a halo column must use the
+    # owner's association)
+    Nx, Ny, dt = 128, 48, 600.0
     single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt)
     init = _initial(Nx, Ny, Nz, single)
     ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt)
