@@ -745,22 +745,33 @@ gb25_status barotropic_impl(gb25_model* m, real dt) {
   return GB25_OK;
 }
 
-// use_colsum: only inside a composite time step, where nothing can have touched u, v since the AB2 kernel
-gb25_status corrector_impl(gb25_model* m, bool use_colsum = false) {
+// use_colsum: only inside a composite time step, where nothing can have touched u, v since the AB2 kernel.
+// part: 0 = every column this model corrects (a slab of a decomposition includes its x-halo columns);
+//       1 = the slab's own columns only (needs no halo data: runs while the last exchanges are in flight);
+//       2 = the x-halo columns only.  The G^n/G^- exchange happens once, with part 0 or 1.
+gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0) {
   const Grid& g = m->g;
   {
     Timed t(m, GB25_K_CORRECTOR);
     dim3 b(64, 4);
     const bool ext = m->cfg.nranks > 1;
-    const int i0 = ext ? -g.H : 0, ni = ext ? g.Nx + 2 * g.H : g.Nx;
+    int i0 = ext ? -g.H : 0, ni = ext ? g.Nx + 2 * g.H : g.Nx, skip_from = INT_MAX, skip = 0;
+    if (part == 1) {
+      i0 = 0;
+      ni = g.Nx;
+    } else if (part == 2) {
+      if (!ext) return GB25_OK;
+      i0 = -g.H; ni = 2 * g.H; skip_from = 0; skip = g.Nx;
+    }
+    const bool cs = use_colsum && m->colsum_valid && part != 2;
     hipLaunchKernelGGL(k_corrector, grid2(ni, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                        m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d,
-                       (use_colsum && m->colsum_valid) ? m->colsum[0].d : nullptr,
-                       (use_colsum && m->colsum_valid) ? m->colsum[1].d : nullptr, i0, ni,
-                       std::max(1, g.Nz / 12));
-    m->colsum_valid = false;
+                       cs ? m->colsum[0].d : nullptr, cs ? m->colsum[1].d : nullptr, i0, ni, std::max(1, g.Nz / 12),
+                       skip_from, skip);
     LAUNCHCHK();
   }
+  if (part == 2) return GB25_OK;
+  m->colsum_valid = false;
   // cache_previous_tendencies!: G^- <- G^n is a pointer exchange; the next tendency evaluation
   // overwrites the (old G^-) buffers that now carry the G^n name.
   for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);
@@ -1459,9 +1470,13 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
     // y layer of the new eta, U, V; their x columns are group 2
     return fill_halos_impl(m, false, false, 2);
   } else if (stage == 2) {
-    // group 0 has been unpacked: corrector on interior + x-halo columns, then update_state without any
+    // the barotropic corrector on the slab's own columns: needs nothing from the neighbours, so it runs while
+    // groups 2 and 0 are still travelling
+    return corrector_impl(m, true, 1);
+  } else if (stage == 3) {
+    // groups 2 and 0 have been unpacked: corrector on the x-halo columns, then update_state without any
     // further exchange (y/z layers re-filled over the extended x range; w and p recomputed in the halos)
-    if ((s = corrector_impl(m, true))) return s;
+    if ((s = corrector_impl(m, true, 2))) return s;
     // the interior pressure pass of stage 0 must be over before the fills touch T, S and before the west strip
     // rewrites column 0 (it has been for a while: the exchanges and the sub-cycle ran in between)
     if (m->two_streams) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
@@ -1485,7 +1500,7 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
     if ((s = momentum_impl(m))) return s;
     return tracers_impl(m);
   }
-  return fail(m, GB25_ERR_INVALID_ARGUMENT, "stage must be 0, 1 or 2");
+  return fail(m, GB25_ERR_INVALID_ARGUMENT, "stage must be 0, 1, 2 or 3");
 }
 
 // ---- profiling ------------------------------------------------------------------------------

@@ -791,11 +791,12 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
                                                    const real* __restrict__ U, const real* __restrict__ V,
                                                    real* __restrict__ Ub, real* __restrict__ Vb,
                                                    const real* __restrict__ Usum, const real* __restrict__ Vsum,
-                                                   int i0, int ni, int kchunks) {
+                                                   int i0, int ni, int kchunks, int skip_from, int skip) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= ni || j >= g.Ny) return;
   i += i0;
+  if (i >= skip_from) i += skip;   // (the two x-halo strips of a slab in one launch: skip the interior)
   const int o0 = ic(g, i, j, 0), ov0 = iv(g, i, j, 0);
   const int o2 = i2(g, i, j);
   int o = o0, ov = ov0;

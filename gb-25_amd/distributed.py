@@ -9,8 +9,9 @@ the large one hidden behind the barotropic sub-cycle on a second HIP stream:
     group 1   W = Ns+1 columns of eta,U,V,G.U,G.V -> wide barotropic halos (posted first)         (compute stream)
     group 0   H columns of u,v,T,S          -> x halos        packed + sent on the COMM stream, in flight during stage 1
     stage 1   Ns split-explicit substeps on the widened slab (no exchange inside the sub-cycle)   (compute stream)
-    group 2   H columns of eta,U,V          -> x halos                                            (compute stream)
-    stage 2   [wait for group 0] corrector (also in the halo columns), w, p', tendencies          (compute stream)
+    group 2   H columns of eta,U,V          -> x halos        COMM stream, in flight during stage 2
+    stage 2   barotropic corrector on the slab's own columns                                      (compute stream)
+    stage 3   [wait for groups 0, 2] corrector in the halo columns, w, p' strips, tendencies      (compute stream)
 
 No collective is needed: every rank talks to its west and east neighbour only (send/recv over xGMI via
 torch.distributed, backend "nccl" = RCCL).  The transport is injected so that the same sequencing code runs
@@ -141,13 +142,19 @@ def step_slabs(steppers, exchange, euler=False):
     exchange(1)
     with _OnComm(steppers, stage0_done):          # the 3-D bundle leaves on the second stream ...
         _run_stage(steppers, lambda s: s.pack(0, on_comm=True))
+        packed0 = steppers[0].comm.record_event() if steppers[0].cuda else None
         exchange(0)
     # ... and is in flight while the sub-cycle runs here
     _run_stage(steppers, lambda s: (s.unpack(1), s.b.time_step_stage(1, euler), s.pack(2)))
-    exchange(2)
+    packed2 = steppers[0].main.record_event() if steppers[0].cuda else None
+    with _OnComm(steppers, packed2):              # eta, U, V columns leave behind the bundle on the second stream ...
+        exchange(2)
+    if packed0 is not None:
+        steppers[0].main.wait_event(packed0)      # the corrector rewrites the columns the bundle was packed from
+    _run_stage(steppers, lambda s: s.b.time_step_stage(2, euler))   # ... while the own columns are corrected
     if steppers[0].cuda:
         steppers[0].main.wait_stream(steppers[0].comm)
-    _run_stage(steppers, lambda s: (s.unpack(2), s.unpack(0), s.b.time_step_stage(2, euler)))
+    _run_stage(steppers, lambda s: (s.unpack(2), s.unpack(0), s.b.time_step_stage(3, euler)))
 
 
 def first_step_slabs(steppers, exchange):

@@ -168,11 +168,14 @@ gb25_status gb25_halo_unpack(gb25_model *m, int group, int side, const void *dev
 gb25_status gb25_halo_pack_both(gb25_model *m, int group, void *west_buffer, void *east_buffer);
 gb25_status gb25_halo_unpack_both(gb25_model *m, int group, const void *west_buffer, const void *east_buffer);
 /* The time step of one slab, cut at its exchange points (gb25_time_step does all of it when nranks == 1):
- *   stage 0: AB2 update of u,v,T,S, barotropic forcing, y/z layers of the 3-D bundle
- *            -> pack + exchange group 1 (critical path) and group 0 (overlaps with stage 1 on a second stream)
+ *   stage 0: AB2 update of u,v,T,S (adopting the look-ahead), y/z layers of the 3-D bundle; starts the pressure of
+ *            the slab's own columns on the side stream
+ *            -> pack + exchange group 1 (critical path) and group 0 (in flight during stages 1-2, second stream)
  *   stage 1: [group 1 unpacked] split-explicit substeps on the widened slab; y layer of eta, U, V
- *            -> pack + exchange group 2
- *   stage 2: [groups 0 and 2 unpacked] corrector (also in the halo columns), w, p', tendencies: no further exchange */
+ *            -> pack + exchange group 2 (in flight during stage 2)
+ *   stage 2: barotropic corrector on the slab's own columns (needs no halo data)
+ *   stage 3: [groups 2 and 0 unpacked] corrector on the x-halo columns, w, pressure strips, tendencies: no further
+ *            exchange */
 gb25_status gb25_time_step_stage(gb25_model *m, int stage, int euler);
 gb25_status gb25_update_state_local(gb25_model *m); /* update_state! without the x-halo fill */
 gb25_status gb25_fill_halo_regions_local(gb25_model *m); /* y/z boundary halos only */

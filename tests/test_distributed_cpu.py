@@ -102,8 +102,9 @@ def test_time_step_sequencing_and_local_ring():
     mine = [e[1:] for e in log if e[0] == 2]
     assert mine == [("stage", 0, False), ("pack", 1, WEST), ("pack", 1, EAST), ("pack", 0, WEST), ("pack", 0, EAST),
                     ("unpack", 1, WEST), ("unpack", 1, EAST), ("stage", 1, False), ("pack", 2, WEST), ("pack", 2, EAST),
+                    ("stage", 2, False),          # own-column corrector while group 2 (and 0) are in flight
                     ("unpack", 2, WEST), ("unpack", 2, EAST), ("unpack", 0, WEST), ("unpack", 0, EAST),
-                    ("stage", 2, False)]
+                    ("stage", 3, False)]
     # exchanges happen once per group, between the pack of every slab and the unpack of any slab;
     # the small barotropic exchange (group 1, critical path) is posted first, then the 3-D bundle (group 0),
     # which stays in flight during the sub-cycle (stage 1)
@@ -112,6 +113,9 @@ def test_time_step_sequencing_and_local_ring():
     stage1 = min(i for i, e in enumerate(log) if e[0] != "exchange" and e[1:3] == ("stage", 1))
     unpack0 = min(i for i, e in enumerate(log) if e[0] != "exchange" and e[1:3] == ("unpack", 0))
     assert ex[1] < stage1 < unpack0
+    stage2 = min(i for i, e in enumerate(log) if e[0] != "exchange" and e[1:3] == ("stage", 2))
+    unpack2 = min(i for i, e in enumerate(log) if e[0] != "exchange" and e[1:3] == ("unpack", 2))
+    assert ex[2] < stage2 < unpack2               # group 2 is posted before the own-column corrector starts
     for i, grp in zip(ex, (1, 0, 2)):
         assert all(not (e[1] == "unpack" and e[2] == grp) for e in log[:i] if e[0] != "exchange")
         assert all(not (e[1] == "pack" and e[2] == grp) for e in log[i:] if e[0] != "exchange")
@@ -131,4 +135,4 @@ def test_first_time_step_sequencing():
                          ("pack", 2, EAST), ("unpack", 0, WEST), ("unpack", 0, EAST), ("unpack", 2, WEST),
                          ("unpack", 2, EAST)]
     assert mine[10] == ("update_state_local",)
-    assert mine[11] == ("stage", 0, True) and mine[-1] == ("stage", 2, True)      # Euler first step
+    assert mine[11] == ("stage", 0, True) and mine[-1] == ("stage", 3, True)      # Euler first step
