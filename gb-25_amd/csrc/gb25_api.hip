@@ -845,9 +845,11 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   if ((s = barotropic_impl(m, (real)dt))) return s;
   m->time += dt;
   m->iteration += 1;
-  if ((s = fill_halos_impl(m, true, false, 3, 1))) return s;   // u, v and eta, U, V
+  // The reference fills the halos of u, v, eta, U, V here as well as after the corrector.  On a single slab the
+  // corrector reads and writes its own columns only, and the fill after it rewrites exactly the same halo cells from
+  // the corrected interior, so the first fill has no effect on any later value: it is left out (3 launches).
   if ((s = corrector_impl(m, true))) return s;
-  if ((s = fill_halos_impl(m, true, false, 3, 1))) return s;
+  if ((s = fill_halos_impl(m, true, false, 3, 1))) return s;   // u, v and eta, U, V
   if ((s = compute_w_impl(m))) return s;
   // ---- join: the tendencies need w, u, v and the pressure differences, T, S
   HIPCHK(hipStreamWaitEvent(main, m->ev_join, 0));
