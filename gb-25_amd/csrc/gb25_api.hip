@@ -822,6 +822,17 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   }
   const real chi = euler ? -real(0.5) : (real)m->cfg.chi;
   hipStream_t main = m->stream, side = m->side_stream;
+  // ---- AB2 of u, v: normally the adoption of the look-ahead (a pointer exchange on the host, no kernel)
+  const bool adopted = m->ahead_uv_valid && (real)dt == m->ahead_uv_dt && chi == m->ahead_uv_chi;
+  if ((s = ab2_velocities_impl(m, (real)dt, chi))) return s;
+  Halo2 hG;
+  hG.p[0] = m->f[GB25_GN_BT_U].d; hG.is_v[0] = 0;
+  hG.p[1] = m->f[GB25_GN_BT_V].d; hG.is_v[1] = 1;
+  hG.p[2] = nullptr; hG.is_v[2] = 0;
+  hG.n = 2;
+  // the sub-cycle reads G.U, G.V at interior points only (periodic wrap and walls are in the kernel): their halo
+  // fill is for the state's sake and leaves the critical path when no kernel on this stream produced them
+  if (!adopted && (s = fill_halos_2d(m, hG))) return s;
   HIPCHK(hipEventRecord(m->ev_fork, main));
   HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
   // ---- tracer branch (side stream)
@@ -829,19 +840,11 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   s = ab2_tracers_impl(m, (real)dt, chi);
   if (!s) s = fill_halos_impl(m, true, false, 1, 2);      // y/z/x halos of T, S
   if (!s) s = compute_p_impl(m);
+  if (!s && adopted) s = fill_halos_2d(m, hG);
   m->stream = main;
   if (s) return s;
   HIPCHK(hipEventRecord(m->ev_join, side));
   // ---- velocity branch (main stream)
-  if ((s = ab2_velocities_impl(m, (real)dt, chi))) return s;
-  {
-    Halo2 hG;
-    hG.p[0] = m->f[GB25_GN_BT_U].d; hG.is_v[0] = 0;
-    hG.p[1] = m->f[GB25_GN_BT_V].d; hG.is_v[1] = 1;
-    hG.p[2] = nullptr; hG.is_v[2] = 0;
-    hG.n = 2;
-    if ((s = fill_halos_2d(m, hG))) return s;
-  }
   if ((s = barotropic_impl(m, (real)dt))) return s;
   m->time += dt;
   m->iteration += 1;
