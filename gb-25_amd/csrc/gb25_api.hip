@@ -80,6 +80,15 @@ struct gb25_model {
   real* uv_partials = nullptr;
   bool ahead_uv_valid = false;
   real ahead_uv_dt = 0, ahead_uv_chi = 0;
+  // ... and once G.U, G.V of the next step exist (momentum look-ahead), so does everything its split-explicit
+  // sub-cycle needs: it runs on the side stream beside the tracer tendency kernel (latency-bound next to
+  // issue-bound) into partner buffers of eta, U, V and of the filtered state, adopted like the others.
+  Field pp2[3];                      // second scratch set: the sub-cycle never writes the arrays it starts from
+  Field ahead_eta[3], ahead_bar[3];  // partners of eta, U, V and of eta_bar, U_bar, V_bar
+  real* bars_ahead = nullptr;        // (the three partners of the averages are one allocation, like `bars`)
+  bool ahead_baro_valid = false;
+  int baro_ahead = 1;                // GB25_BARO_AHEAD=0: sub-cycle inside the step, on the critical path
+  hipEvent_t ev_baro = nullptr, ev_mom = nullptr;
   int use_graphs = 0;                // GB25_GRAPH=1: replay a captured HIP graph of the step (see step_with_graph)
   std::vector<StepGraph> graphs;
   std::vector<HostState> seen;       // states met once: a state is captured when it comes round again
@@ -489,7 +498,7 @@ void tile_grid(const Grid& g, int* nbx, int* nb) {
 gb25_status momentum_impl(gb25_model* m) {
   const Grid& g = m->g;
   int nbx, nb;
-  m->ahead_uv_valid = false;   // a look-ahead made from the previous tendencies is void
+  m->ahead_uv_valid = m->ahead_baro_valid = false;   // look-aheads made from the previous tendencies are void
   if (m->kernel_gen >= 2) {
     Timed t(m, GB25_K_GU);   // the fused G_u + G_v kernel is accounted under the "gu" timer
     nbx = (g.Nx + V2_TX - 1) / V2_TX;
@@ -675,26 +684,37 @@ gb25_status ab2_local_impl(gb25_model* m, real dt, real chi) {
 // step_free_surface!: Ns fused forward-backward substeps.  Single slab: canonical arrays, periodic x wrapped
 // in-kernel.  Slab of a decomposition: wide-halo work arrays (halo W >= Ns filled once by the exchange of
 // group 1), every substep computes on [-W+1, Nx+W-1) and the invalid rim never reaches the interior.
-gb25_status barotropic_impl(gb25_model* m, real dt) {
+// ahead (single slab only): read eta, U, V where they are and G.U, G.V from the momentum look-ahead, write the new
+// eta, U, V and the averages into the partner buffers.
+gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
   const Grid& g = m->g;
   Timed t(m, GB25_K_BAROTROPIC);
   const bool wide = m->cfg.nranks > 1;
   const real dtau = (real)m->dtau_frac * dt;
   dim3 b(64, 4);
   Baro bb;
-  real *cur[3], *nxt[3];
+  real *cur[3], *nxt[3], *other[3], *out[3];
   if (!wide) {
     size_t nbar = m->f[GB25_ETA_BAR].elems() + m->f[GB25_U_BAR].elems() + m->f[GB25_V_BAR].elems();
-    HIPCHK(hipMemsetAsync(m->bars, 0, nbar * sizeof(real), m->stream));
-    for (int q = 0; q < 3; q++) { cur[q] = m->f[GB25_ETA + q].d; nxt[q] = m->pp[q].d; }
-    bb.etab = m->f[GB25_ETA_BAR].d; bb.Ub = m->f[GB25_U_BAR].d; bb.Vb = m->f[GB25_V_BAR].d;
-    bb.GU = m->f[GB25_GN_BT_U].d; bb.GV = m->f[GB25_GN_BT_V].d;
+    HIPCHK(hipMemsetAsync(ahead ? m->bars_ahead : m->bars, 0, nbar * sizeof(real), m->stream));
+    // the state the sub-cycle starts from is only read; the substeps alternate between two scratch sets
+    for (int q = 0; q < 3; q++) {
+      cur[q] = m->f[GB25_ETA + q].d; nxt[q] = m->pp[q].d; other[q] = m->pp2[q].d;
+      out[q] = ahead ? m->ahead_eta[q].d : m->f[GB25_ETA + q].d;
+    }
+    const Field* bar = ahead ? m->ahead_bar : &m->f[GB25_ETA_BAR];
+    bb.etab = bar[0].d; bb.Ub = bar[1].d; bb.Vb = bar[2].d;
+    bb.GU = ahead ? m->ahead_G[0].d : m->f[GB25_GN_BT_U].d;
+    bb.GV = ahead ? m->ahead_G[1].d : m->f[GB25_GN_BT_V].d;
     bb.sx = g.sx; bb.xo = g.H; bb.ilo = 0; bb.ihi = g.Nx; bb.wrap = 1;
   } else {
     HIPCHK(hipMemsetAsync(m->wideBar[0].d, 0,
                           (m->wideBar[0].elems() + m->wideBar[1].elems() + m->wideBar[2].elems()) * sizeof(real),
                           m->stream));
-    for (int q = 0; q < 3; q++) { cur[q] = m->wide[0][q].d; nxt[q] = m->wide[1][q].d; }
+    for (int q = 0; q < 3; q++) {
+      cur[q] = m->wide[0][q].d; nxt[q] = m->wide[1][q].d; other[q] = m->wide[0][q].d;
+      out[q] = m->f[GB25_ETA + q].d;
+    }
     bb.etab = m->wideBar[0].d; bb.Ub = m->wideBar[1].d; bb.Vb = m->wideBar[2].d;
     bb.GU = m->wideG[0].d; bb.GV = m->wideG[1].d;
     bb.sx = g.Nx + 2 * m->W; bb.xo = m->W; bb.ilo = -m->W + 1; bb.ihi = g.Nx + m->W - 1; bb.wrap = 0;
@@ -715,7 +735,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt) {
       bm.ns = std::min(Sk, m->Ns - s);
       for (int q = 0; q < BT_SMAX; q++) bm.w[q] = (s + q < m->Ns) ? (real)m->weights[s + q] : real(0.);
       hipLaunchKernelGGL(kern, gm, dim3(BT_NT), 0, m->stream, g, bm, dtau);
-      for (int q = 0; q < 3; q++) std::swap(cur[q], nxt[q]);
+      for (int q = 0; q < 3; q++) { real* w_ = nxt[q]; nxt[q] = other[q]; other[q] = w_; cur[q] = w_; }
     }
   } else {
     dim3 gr = grid2(bb.ihi - bb.ilo, g.Ny, b);
@@ -723,12 +743,12 @@ gb25_status barotropic_impl(gb25_model* m, real dt) {
       bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
       bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
       hipLaunchKernelGGL(k_barotropic_substep, gr, b, 0, m->stream, g, bb, dtau, (real)m->weights[s]);
-      for (int q = 0; q < 3; q++) std::swap(cur[q], nxt[q]);
+      for (int q = 0; q < 3; q++) { real* w_ = nxt[q]; nxt[q] = other[q]; other[q] = w_; cur[q] = w_; }
     }
   }
   dim3 gi = grid2(g.Nx, g.Ny, b);
-  hipLaunchKernelGGL(k_barotropic_finalize, gi, b, 0, m->stream, g, m->f[GB25_ETA].d, m->f[GB25_BT_U].d,
-                     m->f[GB25_BT_V].d, bb.etab, bb.Ub, bb.Vb, bb.sx, bb.xo);
+  hipLaunchKernelGGL(k_barotropic_finalize, gi, b, 0, m->stream, g, out[0], out[1], out[2], bb.etab, bb.Ub, bb.Vb,
+                     bb.sx, bb.xo);
   if (wide) {  // publish the averages in the canonical filtered-state arrays (compared by compare_states)
     InteriorCopies C{};
     int rmax = 0;
@@ -775,7 +795,7 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
   // cache_previous_tendencies!: G^- <- G^n is a pointer exchange; the next tendency evaluation
   // overwrites the (old G^-) buffers that now carry the G^n name.
   for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);
-  m->ahead_valid = m->ahead_uv_valid = false;   // the look-aheads used the tendency pairs as they were before
+  m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;   // the look-aheads used the tendency pairs as they were before
   return GB25_OK;
 }
 
@@ -790,6 +810,7 @@ gb25_status update_state_impl(gb25_model* m) {
 
 gb25_status ab2_step_impl(gb25_model* m, double dt, int euler) {
   gb25_status s;
+  m->ahead_baro_valid = false;   // this route always runs the sub-cycle itself
   const real chi = euler ? -real(0.5) : (real)m->cfg.chi;
   if ((s = ab2_local_impl(m, (real)dt, chi))) return s;
   Halo2 hG;
@@ -824,6 +845,8 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   hipStream_t main = m->stream, side = m->side_stream;
   // ---- AB2 of u, v: normally the adoption of the look-ahead (a pointer exchange on the host, no kernel)
   const bool adopted = m->ahead_uv_valid && (real)dt == m->ahead_uv_dt && chi == m->ahead_uv_chi;
+  const bool baro_adopted = adopted && m->ahead_baro_valid;   // (made from that very look-ahead, same dt)
+  m->ahead_baro_valid = false;
   if ((s = ab2_velocities_impl(m, (real)dt, chi))) return s;
   Halo2 hG;
   hG.p[0] = m->f[GB25_GN_BT_U].d; hG.is_v[0] = 0;
@@ -845,7 +868,17 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   if (s) return s;
   HIPCHK(hipEventRecord(m->ev_join, side));
   // ---- velocity branch (main stream)
-  if ((s = barotropic_impl(m, (real)dt))) return s;
+  if (baro_adopted) {
+    // the sub-cycle of this step ran beside the last tracer kernel: adopt eta, U, V and the filtered state
+    HIPCHK(hipStreamWaitEvent(main, m->ev_baro, 0));
+    for (int q = 0; q < 3; q++) {
+      std::swap(m->f[GB25_ETA + q].d, m->ahead_eta[q].d);
+      std::swap(m->f[GB25_ETA_BAR + q].d, m->ahead_bar[q].d);
+    }
+    std::swap(m->bars, m->bars_ahead);
+  } else if ((s = barotropic_impl(m, (real)dt))) {
+    return s;
+  }
   m->time += dt;
   m->iteration += 1;
   // The reference fills the halos of u, v, eta, U, V here as well as after the corrector.  On a single slab the
@@ -857,6 +890,18 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   // ---- join: the tendencies need w, u, v and the pressure differences, T, S
   HIPCHK(hipStreamWaitEvent(main, m->ev_join, 0));
   if ((s = momentum_impl(m))) return s;
+  if (m->baro_ahead && m->ahead_uv_valid && !m->use_graphs && !m->ptr_exposed) {
+    // G.U, G.V of the next step exist now: its sub-cycle (latency-bound) runs on the side stream beside the tracer
+    // tendency kernel (issue-bound), into the partner buffers
+    HIPCHK(hipEventRecord(m->ev_mom, main));
+    HIPCHK(hipStreamWaitEvent(side, m->ev_mom, 0));
+    m->stream = side;
+    s = barotropic_impl(m, m->ahead_uv_dt, true);
+    m->stream = main;
+    if (s) return s;
+    HIPCHK(hipEventRecord(m->ev_baro, side));
+    m->ahead_baro_valid = true;
+  }
   return tracers_impl(m);
 }
 
@@ -909,6 +954,8 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   HIPCHK(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&m->ev_baro, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&m->ev_mom, hipEventDisableTiming));
   if (const char* e = getenv("GB25_TWO_STREAMS")) m->two_streams = atoi(e) != 0;
   m->stream = m->own_stream;
   m->last_dt = cfg->dt;
@@ -923,6 +970,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   if (const char* e = getenv("GB25_VARIANT_B")) m->variant_b = atoi(e);
   if (const char* e = getenv("GB25_VARIANT_C")) m->variant_c = atoi(e);
   if (const char* e = getenv("GB25_AB2_AHEAD")) m->ab2_ahead = atoi(e);
+  if (const char* e = getenv("GB25_BARO_AHEAD")) m->baro_ahead = atoi(e);
   if (const char* e = getenv("GB25_GRAPH")) m->use_graphs = atoi(e);
   gb25_status s;
   if ((s = build_grid(m))) return s;
@@ -943,8 +991,22 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     Field& u = m->f[GB25_U_BAR]; u.d = m->bars + nc; u.nx = sx; u.ny = cfg->Ny + 2 * H; u.nz = 1;
     Field& v = m->f[GB25_V_BAR]; v.d = m->bars + 2 * nc; v.nx = sx; v.ny = cfg->Ny + 2 * H + 1; v.nz = 1;
   }
-  for (int q = 0; q < 3; q++)
+  for (int q = 0; q < 3; q++) {
     if ((s = alloc_field(m, m->pp[q], sx, m->f[GB25_ETA + q].ny, 1))) return s;
+    if ((s = alloc_field(m, m->pp2[q], sx, m->f[GB25_ETA + q].ny, 1))) return s;
+    if ((s = alloc_field(m, m->ahead_eta[q], sx, m->f[GB25_ETA + q].ny, 1))) return s;
+  }
+  {   // partners of the filtered state, laid out like `bars`
+    size_t off = 0, tot = 0;
+    for (int q = 0; q < 3; q++) tot += m->f[GB25_ETA_BAR + q].elems();
+    HIPCHK(hipMalloc(&m->bars_ahead, tot * sizeof(real)));
+    HIPCHK(hipMemset(m->bars_ahead, 0, tot * sizeof(real)));
+    for (int q = 0; q < 3; q++) {
+      m->ahead_bar[q] = m->f[GB25_ETA_BAR + q];
+      m->ahead_bar[q].d = m->bars_ahead + off;
+      off += m->f[GB25_ETA_BAR + q].elems();
+    }
+  }
   if ((s = alloc_field(m, m->dpx, m->f[GB25_PHY].nx, m->f[GB25_PHY].ny, m->f[GB25_PHY].nz))) return s;
   if ((s = alloc_field(m, m->dpy, m->f[GB25_PHY].nx, m->f[GB25_PHY].ny, m->f[GB25_PHY].nz))) return s;
   for (int q = 0; q < 2; q++) {
@@ -1002,8 +1064,10 @@ void gb25_destroy(gb25_model* m) {
   if (m->bars) hipFree(m->bars);
   if (m->dpx.d) hipFree(m->dpx.d);
   if (m->dpy.d) hipFree(m->dpy.d);
-  for (auto& p : m->pp)
-    if (p.d) hipFree(p.d);
+  for (int q = 0; q < 3; q++)
+    for (Field* p : {&m->pp[q], &m->pp2[q], &m->ahead_eta[q]})
+      if (p->d) hipFree(p->d);
+  if (m->bars_ahead) hipFree(m->bars_ahead);
   for (auto& p : m->colsum)
     if (p.d) hipFree(p.d);
   for (int q = 0; q < 2; q++)
@@ -1028,6 +1092,8 @@ void gb25_destroy(gb25_model* m) {
   }
   if (m->ev_fork) hipEventDestroy(m->ev_fork);
   if (m->ev_join) hipEventDestroy(m->ev_join);
+  if (m->ev_baro) hipEventDestroy(m->ev_baro);
+  if (m->ev_mom) hipEventDestroy(m->ev_mom);
   if (m->own_stream) hipStreamDestroy(m->own_stream);
   delete m;
 }
@@ -1048,6 +1114,7 @@ gb25_status gb25_use_own_stream(gb25_model* m) {
 gb25_status gb25_synchronize(gb25_model* m) {
   CHECK_MODEL(m);
   HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(m->side_stream));   // the sub-cycle look-ahead may still be running there
   return GB25_OK;
 }
 
@@ -1068,6 +1135,7 @@ static gb25_status copy_field(gb25_model* m, gb25_field id, real* host, int incl
   if (to_device && (id == GB25_U || id == GB25_V)) m->colsum_valid = false;  // cached column integrals are stale
   Field& F = m->f[id];
   HIPCHK(hipStreamSynchronize(m->stream));
+  if (to_device) HIPCHK(hipStreamSynchronize(m->side_stream));   // a look-ahead may still be reading the old values
   if (include_halos) {
     if (to_device) HIPCHK(hipMemcpy(F.d, host, F.elems() * sizeof(real), hipMemcpyHostToDevice));
     else HIPCHK(hipMemcpy(host, F.d, F.elems() * sizeof(real), hipMemcpyDeviceToHost));
@@ -1116,9 +1184,13 @@ gb25_status gb25_set_field(gb25_model* m, gb25_field f, const void* host, int in
   gb25_status s = copy_field(m, f, static_cast<real*>(const_cast<void*>(host)), include_halos, true);
   if (s == GB25_OK && f == GB25_PHY) s = widen_phy(m);
   if (s == GB25_OK) {
-    m->ahead_valid = m->ahead_uv_valid = false;   // any input of the look-aheads may have changed
+    m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;   // any input of the look-aheads may have changed
     if (f == GB25_T || f == GB25_S) s = mirror_tracers(m);
     if (f == GB25_U || f == GB25_V) s = mirror_velocities(m);
+    if (s == GB25_OK && f >= GB25_ETA && f <= GB25_V_BAR) {   // eta, U, V and the filtered state alternate likewise
+      Field& P = (f <= GB25_BT_V) ? m->ahead_eta[f - GB25_ETA] : m->ahead_bar[f - GB25_ETA_BAR];
+      HIPCHK(hipMemcpyAsync(P.d, m->f[f].d, m->f[f].elems() * sizeof(real), hipMemcpyDeviceToDevice, m->stream));
+    }
   }
   return s;
 }
@@ -1129,11 +1201,11 @@ gb25_status gb25_get_field(gb25_model* m, gb25_field f, void* host_, int include
 gb25_status gb25_field_device_ptr(gb25_model* m, gb25_field id, void** dev) {
   if (!m || id < 0 || id >= GB25_FIELD_COUNT || !dev) return GB25_ERR_INVALID_ARGUMENT;
   if (id == GB25_U || id == GB25_V || id == GB25_T || id == GB25_S || (id >= GB25_GN_U && id <= GB25_GM_S) ||
-      id == GB25_GN_BT_U || id == GB25_GN_BT_V) {
+      (id >= GB25_ETA && id <= GB25_GN_BT_V)) {
     // the host can now write prognostic fields or their tendencies behind our back: no more look-ahead for this
     // model, u, v, T, S stay in the buffers whose addresses are handed out
     m->ptr_exposed = true;
-    m->ahead_valid = m->ahead_uv_valid = false;
+    m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
   }
   *dev = m->f[id].d;
   return GB25_OK;
