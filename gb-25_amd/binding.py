@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "gb25_compute_tendencies", "gb25_ab2_step", "gb25_correct_velocities_and_cache_previous_tendencies",
     "gb25_update_state", "gb25_first_time_step", "gb25_time_step", "gb25_loop",
     "gb25_halo_buffer_elems", "gb25_halo_pack", "gb25_halo_unpack", "gb25_halo_pack_both", "gb25_halo_unpack_both",
-    "gb25_time_step_stage",
+    "gb25_time_step_stage", "gb25_lookahead_state",
     "gb25_update_state_local", "gb25_fill_halo_regions_local",
     "gb25_profile_enable", "gb25_profile_reset", "gb25_profile_get",
 ]
@@ -103,6 +103,7 @@ def load_library(float_type="Float32"):
     lib.gb25_halo_pack_both.argtypes = [P, C.c_int, P, P]
     lib.gb25_halo_unpack_both.argtypes = [P, C.c_int, P, P]
     lib.gb25_time_step_stage.argtypes = [P, C.c_int, C.c_int]
+    lib.gb25_lookahead_state.argtypes = [P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.gb25_profile_enable.argtypes = [P, C.c_int]
     lib.gb25_profile_get.argtypes = [P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     for name in ["gb25_use_own_stream", "gb25_synchronize", "gb25_set_baroclinic_instability", "gb25_initialize",
@@ -241,6 +242,12 @@ class HipBackend:
     def time_step(self): self._call("gb25_time_step")
     def loop(self, n): self._call("gb25_loop", int(n))
     def time_step_stage(self, stage, euler=False): self._call("gb25_time_step_stage", int(stage), int(euler))
+
+    def lookahead_state(self):
+        """(velocity look-ahead of the next step exists, stage 0 of this step adopted the sub-cycle look-ahead)"""
+        a, b = C.c_int32(), C.c_int32()
+        self._call("gb25_lookahead_state", C.byref(a), C.byref(b))
+        return bool(a.value), bool(b.value)
 
     # ---- slab exchange
     def halo_buffer_elems(self, group):

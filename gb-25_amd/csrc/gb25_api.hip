@@ -87,6 +87,7 @@ struct gb25_model {
   Field ahead_eta[3], ahead_bar[3];  // partners of eta, U, V and of eta_bar, U_bar, V_bar
   real* bars_ahead = nullptr;        // (the three partners of the averages are one allocation, like `bars`)
   bool ahead_baro_valid = false;
+  bool baro_adopted = false;         // staged path: stage 0 of this step adopted the sub-cycle look-ahead
   int baro_ahead = 1;                // GB25_BARO_AHEAD=0: sub-cycle inside the step, on the critical path
   hipEvent_t ev_baro = nullptr, ev_mom = nullptr;
   int use_graphs = 0;                // GB25_GRAPH=1: replay a captured HIP graph of the step (see step_with_graph)
@@ -405,12 +406,12 @@ Halo2 halo2_prognostic(gb25_model* m) {
 // which: 3 = 3-D and 2-D fields, 1 = the 3-D bundle only, 2 = the 2-D fields only (slab pipeline).
 // sel3: which 3-D fields (halo3); st: stream (nullptr = the model's stream).
 gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, int which = 3, int sel3 = 3,
-                            hipStream_t st = nullptr, bool use_default_stream = true) {
+                            hipStream_t st = nullptr, bool use_default_stream = true, const Halo2* h2_other = nullptr) {
   const Grid& g = m->g;
   if (use_default_stream) st = m->stream;
   Timed t(m, GB25_K_FILL_HALOS);
   Halo3 h3 = halo3(m, sel3);
-  Halo2 h2 = halo2_prognostic(m);
+  Halo2 h2 = h2_other ? *h2_other : halo2_prognostic(m);
   dim3 b(256);
   const int i0 = extended ? -g.H : 0, ni = extended ? g.Nx + 2 * g.H : g.Nx;
   if (which == 2) {
@@ -713,7 +714,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
                           m->stream));
     for (int q = 0; q < 3; q++) {
       cur[q] = m->wide[0][q].d; nxt[q] = m->wide[1][q].d; other[q] = m->wide[0][q].d;
-      out[q] = m->f[GB25_ETA + q].d;
+      out[q] = ahead ? m->ahead_eta[q].d : m->f[GB25_ETA + q].d;
     }
     bb.etab = m->wideBar[0].d; bb.Ub = m->wideBar[1].d; bb.Vb = m->wideBar[2].d;
     bb.GU = m->wideG[0].d; bb.GV = m->wideG[1].d;
@@ -753,7 +754,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     InteriorCopies C{};
     int rmax = 0;
     for (int q = 0; q < 3; q++) {
-      Field& dst = m->f[GB25_ETA_BAR + q];
+      Field& dst = ahead ? m->ahead_bar[q] : m->f[GB25_ETA_BAR + q];
       C.dst[q] = dst.d; C.dsx[q] = dst.nx; C.dxo[q] = g.H;
       C.src[q] = m->wideBar[q].d; C.ssx[q] = bb.sx; C.sxo[q] = bb.xo; C.rows[q] = dst.ny;
       rmax = std::max(rmax, dst.ny);
@@ -1405,9 +1406,11 @@ struct Piece {
   int src_sx, src_xo, dst_sx, dst_xo;
   long rows;
 };
+// groups 3 and 4 are groups 1 and 2 of the sub-cycle LOOK-AHEAD: G.U, G.V come from the momentum look-ahead's partner
+// buffers, the new eta, U, V live in theirs
 static void group_pieces(gb25_model* m, int group, std::vector<Piece>& out, int* ncols) {
   const int H = m->cfg.halo, sx = m->Nx + 2 * H;
-  if (group == 0 || group == 2) {
+  if (group == 0 || group == 2 || group == 4) {
     *ncols = H;
     if (group == 0) {
       for (int id : {GB25_U, GB25_V, GB25_T, GB25_S}) {
@@ -1415,8 +1418,8 @@ static void group_pieces(gb25_model* m, int group, std::vector<Piece>& out, int*
         out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
       }
     } else {
-      for (int id : {GB25_ETA, GB25_BT_U, GB25_BT_V}) {
-        Field& F = m->f[id];
+      for (int q = 0; q < 3; q++) {
+        Field& F = group == 2 ? m->f[GB25_ETA + q] : m->ahead_eta[q];
         out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
       }
     }
@@ -1427,12 +1430,14 @@ static void group_pieces(gb25_model* m, int group, std::vector<Piece>& out, int*
       Field& F = m->f[GB25_ETA + q];
       out.push_back({F.d, m->wide[0][q].d, sx, H, wsx, m->W, (long)F.ny});
     }
-    out.push_back({m->f[GB25_GN_BT_U].d, m->wideG[0].d, sx, H, wsx, m->W, (long)m->f[GB25_GN_BT_U].ny});
-    out.push_back({m->f[GB25_GN_BT_V].d, m->wideG[1].d, sx, H, wsx, m->W, (long)m->f[GB25_GN_BT_V].ny});
+    for (int q = 0; q < 2; q++) {
+      Field& F = group == 1 ? m->f[GB25_GN_BT_U + q] : m->ahead_G[q];
+      out.push_back({F.d, m->wideG[q].d, sx, H, wsx, m->W, (long)F.ny});
+    }
   }
 }
 gb25_status gb25_halo_buffer_elems(const gb25_model* m, int group, int64_t* n) {
-  if (!m || !n || group < 0 || group > 2) return GB25_ERR_INVALID_ARGUMENT;
+  if (!m || !n || group < 0 || group > 4) return GB25_ERR_INVALID_ARGUMENT;
   if (m->cfg.nranks == 1) { *n = 0; return GB25_OK; }
   std::vector<Piece> ps;
   int nc = 0;
@@ -1444,7 +1449,7 @@ gb25_status gb25_halo_buffer_elems(const gb25_model* m, int group, int64_t* n) {
 }
 // side_mask: bit 0 = west, bit 1 = east; buf[side] = that side's contiguous device buffer
 static gb25_status pack_unpack(gb25_model* m, int group, int side_mask, real* const buf[2], bool pack) {
-  if (!m || group < 0 || group > 2 || !(side_mask & 3)) return GB25_ERR_INVALID_ARGUMENT;
+  if (!m || group < 0 || group > 4 || !(side_mask & 3)) return GB25_ERR_INVALID_ARGUMENT;
   if (m->cfg.nranks == 1) return fail(m, GB25_ERR_STATE, "halo pack/unpack on a single-slab model");
   std::vector<Piece> ps;
   int nc = 0;
@@ -1507,7 +1512,21 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
   if (stage == 0) {
     // AB2 update of u,v,T,S + barotropic forcing, then the y/z boundary layers of the 3-D bundle so that its packed
     // x columns (group 0) can travel WHILE the sub-cycle runs; the host also exchanges group 1 now
+    const bool uv_adopted = m->ahead_uv_valid && (real)dt == m->ahead_uv_dt && chi == m->ahead_uv_chi;
+    m->baro_adopted = uv_adopted && m->ahead_baro_valid;
+    m->ahead_baro_valid = false;
     if ((s = ab2_local_impl(m, (real)dt, chi))) return s;
+    if (m->baro_adopted) {
+      // the sub-cycle of this step, its wide-halo exchange and the exchange of the new eta, U, V columns all ran
+      // beside the last tracer kernel (stage 5): adopt the results, stages 1 and groups 1, 2 are skipped
+      for (int q = 0; q < 3; q++) {
+        std::swap(m->f[GB25_ETA + q].d, m->ahead_eta[q].d);
+        std::swap(m->f[GB25_ETA_BAR + q].d, m->ahead_bar[q].d);
+      }
+      std::swap(m->bars, m->bars_ahead);
+      m->time += dt;
+      m->iteration += 1;
+    }
     if ((s = fill_halos_impl(m, false, false, 1))) return s;
     if (m->two_streams) {
       // T, S of the slab's own columns are final from here on: their pressure (fp64-bound) runs on the side stream
@@ -1523,11 +1542,16 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
       HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
     }
     return GB25_OK;
-  } else if (stage == 1) {
-    // group 1 has been unpacked into the wide halos: copy the interiors, sub-cycle, publish
+  } else if (stage == 1 || stage == 5) {
+    // stage 1: group 1 has been unpacked into the wide halos: copy the interiors, sub-cycle, publish.
+    // stage 5: the same for the NEXT step (look-ahead): group 3 has been unpacked, G.U, G.V come from the momentum
+    //          look-ahead, the results go to the partner buffers of eta, U, V and of the filtered state.
+    const bool ahead = stage == 5;
+    if (ahead && !m->ahead_uv_valid) return fail(m, GB25_ERR_STATE, "stage 5 without a velocity look-ahead");
+    if (!ahead && m->baro_adopted) return fail(m, GB25_ERR_STATE, "stage 1 after stage 0 adopted the sub-cycle");
     std::vector<Piece> ps;
     int nc = 0;
-    group_pieces(m, 1, ps, &nc);
+    group_pieces(m, ahead ? 3 : 1, ps, &nc);
     {
       InteriorCopies C{};
       int rmax = 0;
@@ -1541,6 +1565,15 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
                          g.Nx);
     }
     LAUNCHCHK();
+    if (ahead) {
+      if ((s = barotropic_impl(m, m->ahead_uv_dt, true))) return s;
+      Halo2 h2;
+      for (int q = 0; q < 3; q++) { h2.p[q] = m->ahead_eta[q].d; h2.is_v[q] = q == 2; }
+      h2.n = 3;
+      if ((s = fill_halos_impl(m, false, false, 2, 3, nullptr, true, &h2))) return s;   // their x columns: group 4
+      m->ahead_baro_valid = true;
+      return GB25_OK;
+    }
     if ((s = barotropic_impl(m, (real)dt))) return s;
     m->time += dt;
     m->iteration += 1;
@@ -1574,10 +1607,19 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
     } else {
       if ((s = compute_p_impl(m))) return s;
     }
-    if ((s = momentum_impl(m))) return s;
+    return momentum_impl(m);
+  } else if (stage == 4) {
+    // the tracer tendencies; the host runs the look-ahead of the next sub-cycle (groups 3, 4 and stage 5) beside them
     return tracers_impl(m);
   }
-  return fail(m, GB25_ERR_INVALID_ARGUMENT, "stage must be 0, 1, 2 or 3");
+  return fail(m, GB25_ERR_INVALID_ARGUMENT, "stage must be 0 .. 5");
+}
+
+gb25_status gb25_lookahead_state(const gb25_model* m, int32_t* velocities_ready, int32_t* subcycle_adopted) {
+  if (!m) return GB25_ERR_INVALID_ARGUMENT;
+  if (velocities_ready) *velocities_ready = (m->ahead_uv_valid && m->baro_ahead && !m->ptr_exposed) ? 1 : 0;
+  if (subcycle_adopted) *subcycle_adopted = m->baro_adopted ? 1 : 0;
+  return GB25_OK;
 }
 
 // ---- profiling ------------------------------------------------------------------------------

@@ -5,13 +5,18 @@ partitioner (GB-25 sharding/sharded_baroclinic_instability_simulation_run.jl:65-
 XLA collective-permutes; here each time step has three explicit point-to-point exchanges,
 the large one hidden behind the barotropic sub-cycle on a second HIP stream:
 
-    stage 0   AB2 update of u,v,T,S + barotropic forcing, y/z layers of the 3-D bundle            (compute stream)
-    group 1   W = Ns+1 columns of eta,U,V,G.U,G.V -> wide barotropic halos (posted first)         (compute stream)
-    group 0   H columns of u,v,T,S          -> x halos        packed + sent on the COMM stream, in flight during stage 1
-    stage 1   Ns split-explicit substeps on the widened slab (no exchange inside the sub-cycle)   (compute stream)
-    group 2   H columns of eta,U,V          -> x halos        COMM stream, in flight during stage 2
+    stage 0   AB2 update of u,v,T,S (adoption of the look-aheads), y/z layers of the 3-D bundle; pressure of the own
+              columns starts on the model's side stream                                            (compute stream)
+    group 0   H columns of u,v,T,S          -> x halos        packed + sent on the COMM stream, in flight during stage 2
     stage 2   barotropic corrector on the slab's own columns                                      (compute stream)
-    stage 3   [wait for groups 0, 2] corrector in the halo columns, w, p' strips, tendencies      (compute stream)
+    stage 3   [wait for group 0] corrector in the halo columns, w, p' strips, momentum tendencies (compute stream)
+    stage 4   tracer tendencies                                                                   (compute stream)
+      beside stage 4, on the COMM stream, the sub-cycle of the NEXT step (its G.U, G.V exist since stage 3):
+    group 3   W = Ns+1 columns of eta,U,V and of the next G.U,G.V -> wide barotropic halos
+    stage 5   Ns split-explicit substeps on the widened slab into the partner buffers of eta,U,V, filtered state
+    group 4   H columns of the new eta,U,V  -> x halos of the partner buffers
+    The next stage 0 adopts them.  When a look-ahead is not valid (first step, changed dt, host writes) the same work
+    runs inside the step instead: group 1 (= 3), stage 1 (= 5), group 2 (= 4), on the critical path.
 
 No collective is needed: every rank talks to its west and east neighbour only (send/recv over xGMI via
 torch.distributed, backend "nccl" = RCCL).  The transport is injected so that the same sequencing code runs
@@ -87,11 +92,25 @@ class SlabStepper:
             dt = torch.float64 if np.dtype(getattr(backend, "dtype", np.float32)).itemsize == 8 else torch.float32
             self.send[group] = [torch.empty(n, dtype=dt, device=device) for _ in range(2)]
             self.recv[group] = [torch.empty(n, dtype=dt, device=device) for _ in range(2)]
+        # groups 3 and 4 (sub-cycle look-ahead) reuse the buffers of groups 1 and 2: never in use at the same time
+        self.send[3], self.recv[3] = self.send[1], self.recv[1]
+        self.send[4], self.recv[4] = self.send[2], self.recv[2]
+        self.lookahead_in_flight = False
         self.cuda = device.type == "cuda"
         if self.cuda:
             self.main = torch.cuda.current_stream(device)
             self.comm = comm_stream or torch.cuda.Stream(device)
             backend.set_stream(self.main.cuda_stream)
+
+    def on_comm(self, fn):
+        """Run model calls with the model's kernels on the comm stream."""
+        if self.cuda:
+            self.b.set_stream(self.comm.cuda_stream)
+        try:
+            fn()
+        finally:
+            if self.cuda:
+                self.b.set_stream(self.main.cuda_stream)
 
     def pack(self, group, on_comm=False):
         if on_comm and self.cuda:
@@ -134,27 +153,49 @@ def _run_stage(steppers, fn):
 
 def step_slabs(steppers, exchange, euler=False):
     """One time step of a list of slabs (a single one in the multi-process case)."""
+    s0 = steppers[0]
+    if s0.cuda and s0.lookahead_in_flight:
+        s0.main.wait_stream(s0.comm)              # stage 5 and groups 3, 4 of the previous step have finished
+    s0.lookahead_in_flight = False
     _run_stage(steppers, lambda s: s.b.time_step_stage(0, euler))
-    stage0_done = steppers[0].main.record_event() if steppers[0].cuda else None
-    # The small barotropic exchange is on the critical path and is posted FIRST: a process group's point-to-point
-    # transfers share one RCCL stream and run in posting order, so the 6 MB bundle must not be queued ahead of it.
-    _run_stage(steppers, lambda s: s.pack(1))
-    exchange(1)
+    adopted = all(s.b.lookahead_state()[1] for s in steppers)   # the sub-cycle of this step is already done
+    stage0_done = s0.main.record_event() if s0.cuda else None
+    if not adopted:
+        # The small barotropic exchange is on the critical path and is posted FIRST: a process group's
+        # point-to-point transfers share one RCCL stream and run in posting order, so the 6 MB bundle must not be
+        # queued ahead of it.
+        _run_stage(steppers, lambda s: s.pack(1))
+        exchange(1)
     with _OnComm(steppers, stage0_done):          # the 3-D bundle leaves on the second stream ...
         _run_stage(steppers, lambda s: s.pack(0, on_comm=True))
-        packed0 = steppers[0].comm.record_event() if steppers[0].cuda else None
+        packed0 = s0.comm.record_event() if s0.cuda else None
         exchange(0)
-    # ... and is in flight while the sub-cycle runs here
-    _run_stage(steppers, lambda s: (s.unpack(1), s.b.time_step_stage(1, euler), s.pack(2)))
-    packed2 = steppers[0].main.record_event() if steppers[0].cuda else None
-    with _OnComm(steppers, packed2):              # eta, U, V columns leave behind the bundle on the second stream ...
-        exchange(2)
+    if not adopted:
+        # ... and is in flight while the sub-cycle runs here
+        _run_stage(steppers, lambda s: (s.unpack(1), s.b.time_step_stage(1, euler), s.pack(2)))
+        packed2 = s0.main.record_event() if s0.cuda else None
+        with _OnComm(steppers, packed2):          # eta, U, V columns leave behind the bundle on the second stream
+            exchange(2)
     if packed0 is not None:
-        steppers[0].main.wait_event(packed0)      # the corrector rewrites the columns the bundle was packed from
-    _run_stage(steppers, lambda s: s.b.time_step_stage(2, euler))   # ... while the own columns are corrected
-    if steppers[0].cuda:
-        steppers[0].main.wait_stream(steppers[0].comm)
-    _run_stage(steppers, lambda s: (s.unpack(2), s.unpack(0), s.b.time_step_stage(3, euler)))
+        s0.main.wait_event(packed0)               # the corrector rewrites the columns the bundle was packed from
+    _run_stage(steppers, lambda s: s.b.time_step_stage(2, euler))   # own columns, while the exchanges are in flight
+    if s0.cuda:
+        s0.main.wait_stream(s0.comm)
+    if not adopted:
+        _run_stage(steppers, lambda s: s.unpack(2))
+    _run_stage(steppers, lambda s: (s.unpack(0), s.b.time_step_stage(3, euler)))
+    # the next step's G.U, G.V exist now: its wide-halo exchange, sub-cycle and eta,U,V exchange run on the second
+    # stream beside the tracer tendencies
+    if all(s.b.lookahead_state()[0] for s in steppers):
+        mom_done = s0.main.record_event() if s0.cuda else None
+        with _OnComm(steppers, mom_done):
+            _run_stage(steppers, lambda s: s.on_comm(lambda: s.pack(3)))
+            exchange(3)
+            _run_stage(steppers, lambda s: s.on_comm(lambda: (s.unpack(3), s.b.time_step_stage(5, euler), s.pack(4))))
+            exchange(4)
+            _run_stage(steppers, lambda s: s.on_comm(lambda: s.unpack(4)))
+        s0.lookahead_in_flight = True
+    _run_stage(steppers, lambda s: s.b.time_step_stage(4, euler))
 
 
 def first_step_slabs(steppers, exchange):

@@ -159,6 +159,7 @@ gb25_status gb25_loop(gb25_model *m, int32_t n_inner);
  *      group 0: H columns of the 3-D bundle u, v, T, S (all parent rows)      -> x halos
  *      group 1: W = Ns+1 columns of eta, U, V, G.U, G.V                       -> wide barotropic halos
  *      group 2: H columns of eta, U, V                                        -> x halos
+ *      groups 3, 4: groups 1, 2 of the sub-cycle look-ahead (next step's G.U, G.V; partner buffers of eta, U, V)
  *      side: 0 = west, 1 = east.  For pack, `side` is the side of THIS slab whose interior columns are packed;
  *      for unpack it is the halo side that is filled. */
 gb25_status gb25_halo_buffer_elems(const gb25_model *m, int group, int64_t *n_elements);
@@ -168,15 +169,22 @@ gb25_status gb25_halo_unpack(gb25_model *m, int group, int side, const void *dev
 gb25_status gb25_halo_pack_both(gb25_model *m, int group, void *west_buffer, void *east_buffer);
 gb25_status gb25_halo_unpack_both(gb25_model *m, int group, const void *west_buffer, const void *east_buffer);
 /* The time step of one slab, cut at its exchange points (gb25_time_step does all of it when nranks == 1):
- *   stage 0: AB2 update of u,v,T,S (adopting the look-ahead), y/z layers of the 3-D bundle; starts the pressure of
- *            the slab's own columns on the side stream
- *            -> pack + exchange group 1 (critical path) and group 0 (in flight during stages 1-2, second stream)
+ *   stage 0: AB2 update of u,v,T,S (adopting the look-aheads), y/z layers of the 3-D bundle; starts the pressure of
+ *            the slab's own columns on the side stream.  If the sub-cycle look-ahead of the previous step is valid it
+ *            is adopted here (gb25_lookahead_state says so) and stage 1 and groups 1, 2 are skipped
+ *            -> pack + exchange group 0 (second stream) [and group 1 first, on the compute stream, if not adopted]
  *   stage 1: [group 1 unpacked] split-explicit substeps on the widened slab; y layer of eta, U, V
  *            -> pack + exchange group 2 (in flight during stage 2)
  *   stage 2: barotropic corrector on the slab's own columns (needs no halo data)
- *   stage 3: [groups 2 and 0 unpacked] corrector on the x-halo columns, w, pressure strips, tendencies: no further
- *            exchange */
+ *   stage 3: [groups 2 and 0 unpacked] corrector on the x-halo columns, w, pressure strips, momentum tendencies
+ *   stage 4: tracer tendencies.  Beside them, on the second stream, the look-ahead of the NEXT sub-cycle:
+ *            pack + exchange group 3 (= group 1 with G.U, G.V of the next step) -> stage 5 -> pack + exchange group 4
+ *   stage 5: [group 3 unpacked] the next step's substeps into the partner buffers of eta, U, V and the filtered state
+ * Every rank of a run must take the same branch (they do when dt, chi and the host's writes are the same everywhere). */
 gb25_status gb25_time_step_stage(gb25_model *m, int stage, int euler);
+/* velocities_ready: the momentum look-ahead of the next step exists (stage 5 may run); subcycle_adopted: stage 0 of
+ * the current step adopted the sub-cycle look-ahead. */
+gb25_status gb25_lookahead_state(const gb25_model *m, int32_t *velocities_ready, int32_t *subcycle_adopted);
 gb25_status gb25_update_state_local(gb25_model *m); /* update_state! without the x-halo fill */
 gb25_status gb25_fill_halo_regions_local(gb25_model *m); /* y/z boundary halos only */
 

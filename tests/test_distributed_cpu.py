@@ -60,8 +60,12 @@ class _RecordingBackend:
         self.rank, self.log = rank, log
         self.unpacked = {}
 
+    ready = False        # velocity look-ahead of the next step exists (stage 5 may run)
+    adopted = False      # stage 0 adopted the sub-cycle look-ahead
+
     def halo_buffer_elems(self, group): return 4
     def set_stream(self, s): pass
+    def lookahead_state(self): return (self.ready, self.adopted)
     def _rec(self, *a): self.log.append((self.rank,) + a)
     def time_step_stage(self, stage, euler=False): self._rec("stage", stage, bool(euler))
     def initialize(self): self._rec("initialize")
@@ -104,7 +108,7 @@ def test_time_step_sequencing_and_local_ring():
                     ("unpack", 1, WEST), ("unpack", 1, EAST), ("stage", 1, False), ("pack", 2, WEST), ("pack", 2, EAST),
                     ("stage", 2, False),          # own-column corrector while group 2 (and 0) are in flight
                     ("unpack", 2, WEST), ("unpack", 2, EAST), ("unpack", 0, WEST), ("unpack", 0, EAST),
-                    ("stage", 3, False)]
+                    ("stage", 3, False), ("stage", 4, False)]
     # exchanges happen once per group, between the pack of every slab and the unpack of any slab;
     # the small barotropic exchange (group 1, critical path) is posted first, then the 3-D bundle (group 0),
     # which stays in flight during the sub-cycle (stage 1)
@@ -127,6 +131,30 @@ def test_time_step_sequencing_and_local_ring():
             assert b.unpacked[(grp, EAST)] == east * 100 + grp * 10 + WEST
 
 
+def test_time_step_sequencing_with_the_subcycle_lookahead():
+    """When the previous step left a valid look-ahead, stage 0 adopts the sub-cycle: groups 1, 2 and stage 1 vanish
+    from the step; after the momentum tendencies (stage 3) the NEXT sub-cycle is prepared beside the tracer
+    tendencies: group 3 -> stage 5 -> group 4."""
+    P = 3
+    backs, steppers, exchange, log = _make_local_ring(P)
+    for b in backs:
+        b.ready, b.adopted = True, True
+    step_slabs(steppers, exchange, euler=False)
+    mine = [e[1:] for e in log if e[0] == 1]
+    assert mine == [("stage", 0, False), ("pack", 0, WEST), ("pack", 0, EAST), ("stage", 2, False),
+                    ("unpack", 0, WEST), ("unpack", 0, EAST), ("stage", 3, False),
+                    ("pack", 3, WEST), ("pack", 3, EAST), ("unpack", 3, WEST), ("unpack", 3, EAST),
+                    ("stage", 5, False), ("pack", 4, WEST), ("pack", 4, EAST), ("unpack", 4, WEST), ("unpack", 4, EAST),
+                    ("stage", 4, False)]
+    assert [e[1] for e in log if e[0] == "exchange"] == [0, 3, 4]
+    assert steppers[0].lookahead_in_flight
+    for r, b in enumerate(backs):
+        west, east = slab_neighbours(r, P)
+        for grp in (0, 3, 4):
+            assert b.unpacked[(grp, WEST)] == west * 100 + grp * 10 + EAST
+            assert b.unpacked[(grp, EAST)] == east * 100 + grp * 10 + WEST
+
+
 def test_first_time_step_sequencing():
     backs, steppers, exchange, log = _make_local_ring(2)
     first_step_slabs(steppers, exchange)
@@ -135,4 +163,4 @@ def test_first_time_step_sequencing():
                          ("pack", 2, EAST), ("unpack", 0, WEST), ("unpack", 0, EAST), ("unpack", 2, WEST),
                          ("unpack", 2, EAST)]
     assert mine[10] == ("update_state_local",)
-    assert mine[11] == ("stage", 0, True) and mine[-1] == ("stage", 3, True)      # Euler first step
+    assert mine[11] == ("stage", 0, True) and mine[-2:] == [("stage", 3, True), ("stage", 4, True)]      # Euler first step

@@ -43,6 +43,9 @@ def test_slabs_reproduce_single_domain_bitwise(P, Nz):
         a, b = ens.gather(n), single.backend.get_field(n, False)
         assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
     assert np.abs(single.velocities.u.interior).max() > 1e-2      # a developed, non-trivial flow
+    # the staged path really took the look-ahead route: the last stage 0 adopted the sub-cycle prepared beside the
+    # previous tracer kernel, and the next one is already prepared
+    assert all(b.lookahead_state() == (True, True) for b in ens.backends)
     # halo columns of a slab equal the neighbour's interior columns (what the exchange + extended corrector produce)
     H = 8
     left, right = ens.backends[0], ens.backends[1]
