@@ -87,6 +87,9 @@ struct gb25_model {
   Field ahead_eta[3], ahead_bar[3];  // partners of eta, U, V and of eta_bar, U_bar, V_bar
   real* bars_ahead = nullptr;        // (the three partners of the averages are one allocation, like `bars`)
   bool ahead_baro_valid = false;
+  // pHY' is a diagnostic: inside a composite step only its differences are stored (4 of the kernel's 20 B/cell
+  // saved) and the field is recomputed when the host asks for it; pinned to "always stored" once its pointer is out
+  bool phy_stale = false, phy_pinned = false;
   bool baro_adopted = false;         // staged path: stage 0 of this step adopted the sub-cycle look-ahead
   int baro_ahead = 1;                // GB25_BARO_AHEAD=0: sub-cycle inside the step, on the critical path
   hipEvent_t ev_baro = nullptr, ev_mom = nullptr;
@@ -465,8 +468,10 @@ gb25_status compute_w_impl(gb25_model* m) {
 // Hydrostatic pressure on columns [i_first, i_last] (default: the whole extended range -H+1 .. Nx+H-2; column
 // i_first - 1 is read as the west neighbour of the first x difference), optionally on a second range as well.
 gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = INT_MIN, int i_first_b = 0,
-                           int i_last_b = -1) {
+                           int i_last_b = -1, bool may_skip_p = false) {
   const Grid& g = m->g;
+  const bool write_p = !may_skip_p || m->phy_pinned;
+  m->phy_stale = !write_p;
   if (i_first == INT_MIN) {
     i_first = -g.H + 1;
     i_last = g.Nx + g.H - 2;
@@ -479,12 +484,14 @@ gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = IN
   const int tiles_a = (ncol + 62) / 63, tiles_b = (ncol_b + 62) / 63;
   if (ncol <= 63) {   // strips: one row per thread (4x the waves, short chains)
     dim3 gr(tiles_a + tiles_b, (nrow + 3) / 4);
-    hipLaunchKernelGGL(k_compute_p<1>, gr, b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_PHY].d,
-                       m->dpx.d, m->dpy.d, i_first, i_last, i_first_b, i_last_b, tiles_a);
+    auto kern = write_p ? k_compute_p<1, true> : k_compute_p<1, false>;
+    hipLaunchKernelGGL(kern, gr, b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_PHY].d, m->dpx.d,
+                       m->dpy.d, i_first, i_last, i_first_b, i_last_b, tiles_a);
   } else {
     dim3 gr(tiles_a + tiles_b, (nrow + PR * 4 - 1) / (PR * 4));
-    hipLaunchKernelGGL(k_compute_p<PR>, gr, b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_PHY].d,
-                       m->dpx.d, m->dpy.d, i_first, i_last, i_first_b, i_last_b, tiles_a);
+    auto kern = write_p ? k_compute_p<PR, true> : k_compute_p<PR, false>;
+    hipLaunchKernelGGL(kern, gr, b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_PHY].d, m->dpx.d,
+                       m->dpy.d, i_first, i_last, i_first_b, i_last_b, tiles_a);
   }
   LAUNCHCHK();
   return GB25_OK;
@@ -863,7 +870,7 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   m->stream = side;
   s = ab2_tracers_impl(m, (real)dt, chi);
   if (!s) s = fill_halos_impl(m, true, false, 1, 2);      // y/z/x halos of T, S
-  if (!s) s = compute_p_impl(m);
+  if (!s) s = compute_p_impl(m, INT_MIN, INT_MIN, 0, -1, true);
   if (!s && adopted) s = fill_halos_2d(m, hG);
   m->stream = main;
   if (s) return s;
@@ -972,6 +979,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   if (const char* e = getenv("GB25_VARIANT_C")) m->variant_c = atoi(e);
   if (const char* e = getenv("GB25_AB2_AHEAD")) m->ab2_ahead = atoi(e);
   if (const char* e = getenv("GB25_BARO_AHEAD")) m->baro_ahead = atoi(e);
+  if (const char* e = getenv("GB25_LAZY_PHY")) m->phy_pinned = atoi(e) == 0;   // 0: store pHY' every step
   if (const char* e = getenv("GB25_GRAPH")) m->use_graphs = atoi(e);
   gb25_status s;
   if ((s = build_grid(m))) return s;
@@ -1183,7 +1191,10 @@ static gb25_status mirror_velocities(gb25_model* m) {   // u and v alternate bet
 }
 gb25_status gb25_set_field(gb25_model* m, gb25_field f, const void* host, int include_halos) {
   gb25_status s = copy_field(m, f, static_cast<real*>(const_cast<void*>(host)), include_halos, true);
-  if (s == GB25_OK && f == GB25_PHY) s = widen_phy(m);
+  if (s == GB25_OK && f == GB25_PHY) {
+    m->phy_stale = false;
+    s = widen_phy(m);
+  }
   if (s == GB25_OK) {
     m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;   // any input of the look-aheads may have changed
     if (f == GB25_T || f == GB25_S) s = mirror_tracers(m);
@@ -1197,6 +1208,10 @@ gb25_status gb25_set_field(gb25_model* m, gb25_field f, const void* host, int in
 }
 gb25_status gb25_get_field(gb25_model* m, gb25_field f, void* host_, int include_halos) {
   real* host = static_cast<real*>(host_);
+  if (m && f == GB25_PHY && m->phy_stale) {   // the step stored only the differences: T, S are those it was made from
+    gb25_status s = compute_p_impl(m);
+    if (s) return s;
+  }
   return copy_field(m, f, host, include_halos, false);
 }
 gb25_status gb25_field_device_ptr(gb25_model* m, gb25_field id, void** dev) {
@@ -1207,6 +1222,13 @@ gb25_status gb25_field_device_ptr(gb25_model* m, gb25_field id, void** dev) {
     // model, u, v, T, S stay in the buffers whose addresses are handed out
     m->ptr_exposed = true;
     m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+  }
+  if (id == GB25_PHY) {
+    m->phy_pinned = true;
+    if (m->phy_stale) {
+      gb25_status s = compute_p_impl(m);
+      if (s) return s;
+    }
   }
   *dev = m->f[id].d;
   return GB25_OK;
@@ -1536,7 +1558,7 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
       HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
       hipStream_t main = m->stream;
       m->stream = m->side_stream;
-      s = compute_p_impl(m, 0, g.Nx - 1);
+      s = compute_p_impl(m, 0, g.Nx - 1, 0, -1, true);
       m->stream = main;
       if (s) return s;
       HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
@@ -1596,7 +1618,7 @@ gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
       HIPCHK(hipEventRecord(m->ev_fork, main));
       HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
       m->stream = m->side_stream;
-      s = compute_p_impl(m, -g.H + 1, 0, g.Nx, g.Nx + g.H - 2);      // west strip (redoes column 0) + east strip
+      s = compute_p_impl(m, -g.H + 1, 0, g.Nx, g.Nx + g.H - 2, true);   // west strip (redoes column 0) + east strip
       m->stream = main;
       if (s) return s;
       HIPCHK(hipEventRecord(m->ev_join, m->side_stream));

@@ -161,7 +161,9 @@ constexpr int PR = 4;   // rows per thread of the full-range launch
 // its interior early and the strips next to the x halos once those have arrived).
 // PR_: rows per thread.  4 for the full range (five evaluations per level share one helper row); 1 for the narrow
 // strips of a slab, which have too few waves to hide latency behind each other and want short per-level chains.
-template <int PR_>
+// WRITE_P = false: only the two differences the momentum kernel consumes are stored; pHY' itself is a diagnostic
+// that the host side then materialises on demand (gb25_api.hip, phy_stale).
+template <int PR_, bool WRITE_P>
 __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restrict__ T, const real* __restrict__ S,
                                                    real* __restrict__ p, real* __restrict__ dpx,
                                                    real* __restrict__ dpy, int i_first, int i_last, int i_first_b,
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restric
       const double pw = __shfl_up(pk[r], 1);
       const int j = jb - 1 + r;
       if (lane >= 1 && i <= imax && j <= jmax) {
-        p[o[r]] = (real)pk[r];
+        if (WRITE_P) p[o[r]] = (real)pk[r];
         dpx[o[r]] = (real)(pk[r] - pw);
         dpy[o[r]] = (real)(pk[r] - pk[r - 1]);
       }

@@ -119,7 +119,10 @@ gb25_status gb25_get_field(gb25_model *m, gb25_field f, void *host, int include_
  * u, v, T and S normally alternate between two buffers as well (the tendency kernels write the next time level
  * ahead of ab2_step!); asking for the pointer of a prognostic 3-D field or of a tendency pins them to the buffers
  * handed out and turns that look-ahead off for this model, because writes through the pointer cannot be seen by
- * the library. */
+ * the library.
+ * GB25_PHY is a diagnostic: inside the composite steps only its horizontal differences (what the momentum tendencies
+ * use) are stored, and gb25_get_field(GB25_PHY) recomputes the field from T and S on demand; asking for its device
+ * pointer makes every later step store it (GB25_LAZY_PHY=0 in the environment does the same from the start). */
 gb25_status gb25_field_device_ptr(gb25_model *m, gb25_field f, void **dev);
 gb25_status gb25_get_metric(const gb25_model *m, gb25_metric id, int32_t logical_index, double *value);
 gb25_status gb25_get_substepping(const gb25_model *m, int32_t *n_effective, double *dtau_fraction,
