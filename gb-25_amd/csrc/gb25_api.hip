@@ -90,6 +90,7 @@ struct gb25_model {
   // pHY' is a diagnostic: inside a composite step only its differences are stored (4 of the kernel's 20 B/cell
   // saved) and the field is recomputed when the host asks for it; pinned to "always stored" once its pointer is out
   bool phy_stale = false, phy_pinned = false;
+  bool baro_inflight = false;        // a look-ahead sub-cycle is on the side stream and nobody has waited for it yet
   bool baro_adopted = false;         // staged path: stage 0 of this step adopted the sub-cycle look-ahead
   int baro_ahead = 1;                // GB25_BARO_AHEAD=0: sub-cycle inside the step, on the critical path
   hipEvent_t ev_baro = nullptr, ev_mom = nullptr;
@@ -696,6 +697,12 @@ gb25_status ab2_local_impl(gb25_model* m, real dt, real chi) {
 // eta, U, V and the averages into the partner buffers.
 gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
   const Grid& g = m->g;
+  if (m->baro_inflight && !ahead) {
+    // a look-ahead that is not being adopted (changed dt, ...) may still be running on the side stream, and it uses
+    // the same scratch sets
+    HIPCHK(hipStreamWaitEvent(m->stream, m->ev_baro, 0));
+    m->baro_inflight = false;
+  }
   Timed t(m, GB25_K_BAROTROPIC);
   const bool wide = m->cfg.nranks > 1;
   const real dtau = (real)m->dtau_frac * dt;
@@ -879,6 +886,7 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   if (baro_adopted) {
     // the sub-cycle of this step ran beside the last tracer kernel: adopt eta, U, V and the filtered state
     HIPCHK(hipStreamWaitEvent(main, m->ev_baro, 0));
+    m->baro_inflight = false;
     for (int q = 0; q < 3; q++) {
       std::swap(m->f[GB25_ETA + q].d, m->ahead_eta[q].d);
       std::swap(m->f[GB25_ETA_BAR + q].d, m->ahead_bar[q].d);
@@ -909,6 +917,7 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
     if (s) return s;
     HIPCHK(hipEventRecord(m->ev_baro, side));
     m->ahead_baro_valid = true;
+    m->baro_inflight = true;
   }
   return tracers_impl(m);
 }
