@@ -317,6 +317,7 @@ def test_ab2_lookahead_is_bitwise_neutral(monkeypatch):
     monkeypatch.setenv("GB25_AB2_AHEAD", "0")
     a = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0)
     monkeypatch.setenv("GB25_AB2_AHEAD", "1")
+    monkeypatch.setenv("GB25_BARO_AHEAD", "1")      # (off by default on grids this small)
     b = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0)
     c = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0)   # will hand out its T pointer
     names = ALL_FIELDS
@@ -373,6 +374,7 @@ def test_lookaheads_are_bitwise_neutral_over_a_longer_run(monkeypatch):
     monkeypatch.setenv("GB25_AB2_AHEAD", "0")
     a = gb.baroclinic_instability_model(gb.GPU(), 360, 180, 24, dt=600.0)
     monkeypatch.delenv("GB25_AB2_AHEAD")
+    monkeypatch.setenv("GB25_BARO_AHEAD", "1")      # (off by default on grids this small)
     b = gb.baroclinic_instability_model(gb.GPU(), 360, 180, 24, dt=600.0)
     for m in (a, b):
         gb.set_baroclinic_instability(m)
