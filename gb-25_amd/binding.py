@@ -263,7 +263,9 @@ class HipBackend:
         self._call("gb25_halo_unpack_both", group, C.c_void_p(west_ptr), C.c_void_p(east_ptr))
 
     # ---- timers
-    def profile_enable(self, on=True): self._call("gb25_profile_enable", int(on))
+    def profile_enable(self, on=True, only=None):
+        """on: time every kernel; only="momentum"|"gu"|...: time that kernel alone (least perturbation)."""
+        self._call("gb25_profile_enable", 2 + KERNEL_IDS[only] if only else int(on))
     def profile_reset(self): self._call("gb25_profile_reset")
 
     def profile_get(self, kernel):

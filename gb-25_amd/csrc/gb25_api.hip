@@ -119,6 +119,7 @@ struct gb25_model {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool two_streams = true;          // GB25_TWO_STREAMS=0: strictly sequential phases on one stream
   bool profile = false;
+  int profile_only = -1;             // >= 0: time this kernel id alone (keeps the event records out of the other launches)
   std::vector<EventPair> pending[GB25_K_COUNT];
   std::vector<EventPair> free_events;
   int64_t prof_count[GB25_K_COUNT] = {0};
@@ -169,7 +170,7 @@ struct Timed {
   int k;
   EventPair ev;
   bool on;
-  Timed(gb25_model* m_, int k_) : m(m_), k(k_), on(m_->profile) {
+  Timed(gb25_model* m_, int k_) : m(m_), k(k_), on(m_->profile && (m_->profile_only < 0 || m_->profile_only == k_)) {
     if (!on) return;
     if (!m->free_events.empty()) {
       ev = m->free_events.back();
@@ -1661,6 +1662,8 @@ gb25_status gb25_lookahead_state(const gb25_model* m, int32_t* velocities_ready,
 gb25_status gb25_profile_enable(gb25_model* m, int on) {
   CHECK_MODEL(m);
   m->profile = on != 0;
+  m->profile_only = on >= 2 ? on - 2 : -1;   // on = 2 + k: only kernel k
+  if (m->profile_only >= GB25_K_COUNT) return fail(m, GB25_ERR_INVALID_ARGUMENT, "no such kernel id %d", on - 2);
   return GB25_OK;
 }
 gb25_status gb25_profile_reset(gb25_model* m) {

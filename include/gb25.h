@@ -192,7 +192,7 @@ gb25_status gb25_update_state_local(gb25_model *m); /* update_state! without the
 gb25_status gb25_fill_halo_regions_local(gb25_model *m); /* y/z boundary halos only */
 
 /* ---- built-in per-kernel HIP-event timing (bench.py's roofline numbers) */
-gb25_status gb25_profile_enable(gb25_model *m, int on);
+gb25_status gb25_profile_enable(gb25_model *m, int on); /* 0: off, 1: every kernel, 2 + k: kernel k alone */
 gb25_status gb25_profile_reset(gb25_model *m);
 gb25_status gb25_profile_get(gb25_model *m, gb25_kernel k, int64_t *launches, double *total_ms);
 
