@@ -2,8 +2,14 @@
 // per (i,j,k) and shared through LDS (x, y) or carried in registers while marching up the column (z).
 //
 // The v1 kernels (kernels.hpp) evaluate every face reconstruction from both adjacent cells; rocprof (profiles/
-// r01_v1_*) shows they are VALU-bound (~50 % VALU issue, HBM traffic within 1.1-1.3x of compulsory), so the lever
-// is instruction count, not bytes.  Results are identical to v1 up to the order of the final flux differences.
+// r01_v1_*) shows them bound by VALU issue with HBM traffic within 1.1-1.3x of compulsory, so the lever is
+// instruction count, not bytes.  Results are identical to v1 up to the order of the final flux differences.
+//
+// Generations in this file, oldest first: tracer v2 (LDS flux sharing), momentum v2 (LDS tiles, scalar), tracer v3
+// (wave-autonomous, scalar), momentum v4 (single-barrier experiment), and the SHIPPED pair: tracer v5 and momentum v5
+// (two-wide fp32 values -> v_pk_* instructions, buffer addressing in the tracer kernel, AB2 look-ahead in both).  A wave64
+// VALU instruction costs ~4 cycles of a SIMD on gfx950 and the scalar kernels were issue-saturated (VALUBusy ~100 %):
+// see device_common.hpp (real2v), tools/micro/ and profiles/r01_tuning_log.md.
 #pragma once
 #include "device_common.hpp"
 
@@ -1013,7 +1019,7 @@ namespace gb25 {
 // pair {DU, DV} one real2 per point, so a stencil point costs one ds_read_b128 / b64 instead of three / two
 // ds_read_b32, and (b) the level loop is software-pipelined two deep: iteration k evaluates the tendencies of
 // level k, derives the quantities of level k+1 and stages the tiles of level k+2, behind ONE barrier.
-// (v2 measured 50 % VALU issue with 34 % of wave time in s_waitcnt/barrier: profiles/r01_v2_pmc_sq3.csv.)
+// (v2 spends 34 % of wave time in s_waitcnt/barrier: profiles/r01_v2_pmc_sq3.csv.)
 // =============================================================================================
 template <int TY>
 struct MomentumLds4 {
