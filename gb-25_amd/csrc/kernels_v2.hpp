@@ -590,6 +590,19 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
       if (ew_off[q] >= 0) W0[ew_lds[q]] = rw[q];
   };
   real sAu = real(0.), sAv = real(0.), sIu = real(0.), sIv = real(0.);   // AHEAD: this chunk's column sums
+  // per-block tables for phase 1: packed (row << 8 | column) of every derived point, and the metrics of the rows
+  // mdxc[py] = dxc(j0-3+py), mrazf[py] = razf(j0-2+py), mdxf[py] = dxf(j0-3+py)
+  __shared__ int ptab[MD_X * MD_Y];
+  __shared__ real mdxc[MD_Y + 1], mrazf[MD_Y], mdxf[MD_Y + 1];
+  for (int e = tid; e < MD_X * MD_Y; e += NT) {
+    const int py = e / MD_X;
+    ptab[e] = (py << 8) | (e - py * MD_X);
+  }
+  if (tid <= MD_Y) {
+    mdxc[tid] = g.dxc[j0 - 3 + tid];
+    mdxf[tid] = g.dxf[j0 - 3 + tid];
+    if (tid < MD_Y) mrazf[tid] = g.razf[j0 - 2 + tid];
+  }
   fetch(k0, o);
   stash(k0 & 1);
   real pw_ = rpw, ps_ = rps;   // p'(i,j) - p'(i-1,j) and p'(i,j) - p'(i,j-1) of the current level
@@ -602,24 +615,24 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     const bool more = (k + 1 < k1);
     if (more) fetch(k + 1, o + pc);
     const real unew = u[o + 4 * pc], vnew = v[ov + 4 * pv];
-    // ---- phase 1: derived quantities, once per point
+    // ---- phase 1: derived quantities, once per point.  (row, column) of a point and the row metrics come from the
+    // small LDS tables filled once per block: an integer division and five global loads per point and level otherwise
     for (int e = tid; e < MD_X * MD_Y; e += NT) {
-      int py = e / MD_X, px = e - py * MD_X;
+      const int pk = ptab[e];
+      const int py = pk >> 8, px = pk & 255;
       // (f,f,c) point (i0-2+px, j0-2+py)
       {
-        const int J = j0 - 2 + py;
         real uc = lds.U[par][py + 1][px + 1], us = lds.U[par][py][px + 1];
         real vc = lds.V[par][py + 1][px + 1], vw = lds.V[par][py + 1][px];
-        lds.Z[py][px] = ((dy * vc - dy * vw) - (g.dxc[J] * uc - g.dxc[J - 1] * us)) * g.razf[J];
+        lds.Z[py][px] = ((dy * vc - dy * vw) - (mdxc[py + 1] * uc - mdxc[py] * us)) * mrazf[py];
         lds.UQ[py][px] = real(0.5) * (us + uc);
         lds.VQ[py][px] = real(0.5) * (vw + vc);
       }
       // (c,c,c) point (i0-3+px, j0-3+py)
       {
-        const int J = j0 - 3 + py;
         const real Ax = dy * dz;
         lds.DU[py][px] = Ax * lds.U[par][py][px + 1] - Ax * lds.U[par][py][px];
-        lds.DV[py][px] = g.dxf[J + 1] * dz * lds.V[par][py + 1][px] - g.dxf[J] * dz * lds.V[par][py][px];
+        lds.DV[py][px] = mdxf[py + 1] * dz * lds.V[par][py + 1][px] - mdxf[py] * dz * lds.V[par][py][px];
       }
     }
     __syncthreads();
