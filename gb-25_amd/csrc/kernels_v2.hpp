@@ -550,28 +550,35 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     int e = tid + q * NT;
     int ey = e / MU_X, ex = e - ey * MU_X;
     // clamp to the parent array (ragged tiles): columns <= Nx+H-1, rows <= Ny+H-1 relative to the tile origin
-    eu_off[q] = (e < MU_X * MU_Y) ? min(ex, g.Nx + H + 2 - i0) + sx * min(ey, g.Ny + H + 2 - j0) : -1;
+    eu_off[q] = (e < MU_X * MU_Y) ? (min(ex, g.Nx + H + 2 - i0) + sx * min(ey, g.Ny + H + 2 - j0)) * (int)sizeof(real) : -1;
     eu_lds[q] = e;
   }
 #pragma unroll
   for (int q = 0; q < NEW; q++) {
     int e = tid + q * NT;
     int ey = e / MW_X, ex = e - ey * MW_X;
-    ew_off[q] = (e < MW_X * MW_Y) ? min(ex, g.Nx + H + 1 - i0) + sx * min(ey, g.Ny + H + 1 - j0) : -1;
+    ew_off[q] = (e < MW_X * MW_Y) ? (min(ex, g.Nx + H + 1 - i0) + sx * min(ey, g.Ny + H + 1 - j0)) * (int)sizeof(real) : -1;
     ew_lds[q] = e;
   }
   real ru[NEU], rv[NEU], rw[NEW], rpw = real(0.), rps = real(0.);
+  // (uniform base pointer + 32-bit per-lane byte offset: the loads take the scalar-base addressing form and need no
+  // 64-bit address arithmetic per lane)
+  auto at = [](const real* base, int byte_off) {
+    return *reinterpret_cast<const real*>(reinterpret_cast<const char*>(base) + (unsigned)byte_off);
+  };
   auto fetch = [&](int k, int oo) {
-    const int bu = tile_u + pc * (k + H), bv = tile_u + pv * (k + H), bw = tile_w + pc * (k + 1 + H);
+    const real* ub = u + (tile_u + pc * (k + H));
+    const real* vb = v + (tile_u + pv * (k + H));
+    const real* wb = w + (tile_w + pc * (k + 1 + H));
 #pragma unroll
     for (int q = 0; q < NEU; q++)
       if (eu_off[q] >= 0) {
-        ru[q] = u[bu + eu_off[q]];
-        rv[q] = v[bv + eu_off[q]];
+        ru[q] = at(ub, eu_off[q]);
+        rv[q] = at(vb, eu_off[q]);
       }
 #pragma unroll
     for (int q = 0; q < NEW; q++)
-      if (ew_off[q] >= 0) rw[q] = w[bw + ew_off[q]];
+      if (ew_off[q] >= 0) rw[q] = at(wb, ew_off[q]);
     rpw = dpx[oo];   // p'(i) - p'(i-1) and p'(j) - p'(j-1), differenced in fp64 by k_compute_p
     rps = dpy[oo];
   };
