@@ -522,6 +522,16 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
 
   // threads of a ragged edge tile work on a clamped (duplicate) column so that every address stays in bounds
   int o = ic(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0), ov = iv(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0);
+  // (uniform base pointer + 32-bit per-lane byte offset: the accesses take the scalar-base addressing form and need no
+  // 64-bit address arithmetic per lane; the own cell's byte offsets ob / obv serve every centre- / v-shaped array)
+  auto at = [](const real* base, unsigned byte_off) {
+    return *reinterpret_cast<const real*>(reinterpret_cast<const char*>(base) + byte_off);
+  };
+  auto put = [](real* base, unsigned byte_off, real x) {
+    *reinterpret_cast<real*>(reinterpret_cast<char*>(base) + byte_off) = x;
+  };
+  constexpr unsigned SZ = (unsigned)sizeof(real);
+  unsigned ob = (unsigned)o * SZ, obv = (unsigned)ov * SZ;
   real uz[7], vz[7];
 #pragma unroll
   for (int m = 0; m < 7; m++) {
@@ -563,24 +573,21 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   real ru[NEU], rv[NEU], rw[NEW], rpw = real(0.), rps = real(0.);
   // (uniform base pointer + 32-bit per-lane byte offset: the loads take the scalar-base addressing form and need no
   // 64-bit address arithmetic per lane)
-  auto at = [](const real* base, int byte_off) {
-    return *reinterpret_cast<const real*>(reinterpret_cast<const char*>(base) + (unsigned)byte_off);
-  };
-  auto fetch = [&](int k, int oo) {
+  auto fetch = [&](int k, unsigned oob) {   // oob: byte offset of the own cell at level k
     const real* ub = u + (tile_u + pc * (k + H));
     const real* vb = v + (tile_u + pv * (k + H));
     const real* wb = w + (tile_w + pc * (k + 1 + H));
 #pragma unroll
     for (int q = 0; q < NEU; q++)
       if (eu_off[q] >= 0) {
-        ru[q] = at(ub, eu_off[q]);
-        rv[q] = at(vb, eu_off[q]);
+        ru[q] = at(ub, (unsigned)eu_off[q]);
+        rv[q] = at(vb, (unsigned)eu_off[q]);
       }
 #pragma unroll
     for (int q = 0; q < NEW; q++)
-      if (ew_off[q] >= 0) rw[q] = at(wb, ew_off[q]);
-    rpw = dpx[oo];   // p'(i) - p'(i-1) and p'(j) - p'(j-1), differenced in fp64 by k_compute_p
-    rps = dpy[oo];
+      if (ew_off[q] >= 0) rw[q] = at(wb, (unsigned)ew_off[q]);
+    rpw = at(dpx, oob);   // p'(i) - p'(i-1) and p'(j) - p'(j-1), differenced in fp64 by k_compute_p
+    rps = at(dpy, oob);
   };
   auto stash = [&](int par) {
     real* U0 = &lds.U[par][0][0];
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     mdxf[tid] = g.dxf[j0 - 3 + tid];
     if (tid < MD_Y) mrazf[tid] = g.razf[j0 - 2 + tid];
   }
-  fetch(k0, o);
+  fetch(k0, ob);
   stash(k0 & 1);
   real pw_ = rpw, ps_ = rps;   // p'(i,j) - p'(i-1,j) and p'(i,j) - p'(i,j-1) of the current level
   __syncthreads();
@@ -620,8 +627,8 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     const real dz = g.dzc[k];
     // ---- phase 0: issue the loads of the next level's tiles (consumed at the end of this iteration)
     const bool more = (k + 1 < k1);
-    if (more) fetch(k + 1, o + pc);
-    const real unew = u[o + 4 * pc], vnew = v[ov + 4 * pv];
+    if (more) fetch(k + 1, ob + (unsigned)pc * SZ);
+    const real unew = at(u, ob + 4u * (unsigned)pc * SZ), vnew = at(v, obv + 4u * (unsigned)pv * SZ);
     // ---- phase 1: derived quantities, once per point.  (row, column) of a point and the row metrics come from the
     // small LDS tables filled once per block: an integer division and five global loads per point and level otherwise
     for (int e = tid; e < MD_X * MD_Y; e += NT) {
@@ -784,21 +791,21 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
 #undef ZF
 #undef DC
     if (inside) {
-      Gu[o] = gu;
-      Gv[ov] = gv;
+      put(Gu, ob, gu);
+      put(Gv, obv, gv);
       if (AHEAD) {
-        const real au = rfma(next.C1, gu, -(next.C2 * next.GmU[o])), av = rfma(next.C1, gv, -(next.C2 * next.GmV[ov]));
+        const real au = rfma(next.C1, gu, -(next.C2 * at(next.GmU, ob))), av = rfma(next.C1, gv, -(next.C2 * at(next.GmV, obv)));
         const real un = rfma(next.dt, au, uz[3]), vn = rfma(next.dt, av, vz[3]);
-        next.un[o] = un;
-        next.vn[ov] = vn;
+        put(next.un, ob, un);
+        put(next.vn, obv, vn);
         sAu = (k == k0) ? dz * au : rfma(dz, au, sAu);
         sAv = (k == k0) ? dz * av : rfma(dz, av, sAv);
         sIu = (k == k0) ? dz * un : rfma(dz, un, sIu);
         sIv = (k == k0) ? dz * vn : rfma(dz, vn, sIv);
       }
     }
-    o += pc;
-    ov += pv;
+    ob += (unsigned)pc * SZ;
+    obv += (unsigned)pv * SZ;
 #pragma unroll
     for (int m = 0; m < 6; m++) {
       uz[m] = uz[m + 1];
