@@ -712,7 +712,8 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
   real *cur[3], *nxt[3], *other[3], *out[3];
   if (!wide) {
     size_t nbar = m->f[GB25_ETA_BAR].elems() + m->f[GB25_U_BAR].elems() + m->f[GB25_V_BAR].elems();
-    HIPCHK(hipMemsetAsync(ahead ? m->bars_ahead : m->bars, 0, nbar * sizeof(real), m->stream));
+    if (m->baro_block <= 1)   // (the blocked kernel starts its averages from zero itself)
+      HIPCHK(hipMemsetAsync(ahead ? m->bars_ahead : m->bars, 0, nbar * sizeof(real), m->stream));
     // the state the sub-cycle starts from is only read; the substeps alternate between two scratch sets
     for (int q = 0; q < 3; q++) {
       cur[q] = m->f[GB25_ETA + q].d; nxt[q] = m->pp[q].d; other[q] = m->pp2[q].d;
@@ -724,9 +725,10 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     bb.GV = ahead ? m->ahead_G[1].d : m->f[GB25_GN_BT_V].d;
     bb.sx = g.sx; bb.xo = g.H; bb.ilo = 0; bb.ihi = g.Nx; bb.wrap = 1;
   } else {
-    HIPCHK(hipMemsetAsync(m->wideBar[0].d, 0,
-                          (m->wideBar[0].elems() + m->wideBar[1].elems() + m->wideBar[2].elems()) * sizeof(real),
-                          m->stream));
+    if (m->baro_block <= 1)
+      HIPCHK(hipMemsetAsync(m->wideBar[0].d, 0,
+                            (m->wideBar[0].elems() + m->wideBar[1].elems() + m->wideBar[2].elems()) * sizeof(real),
+                            m->stream));
     for (int q = 0; q < 3; q++) {
       cur[q] = m->wide[0][q].d; nxt[q] = m->wide[1][q].d; other[q] = m->wide[0][q].d;
       out[q] = ahead ? m->ahead_eta[q].d : m->f[GB25_ETA + q].d;
@@ -735,6 +737,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     bb.GU = m->wideG[0].d; bb.GV = m->wideG[1].d;
     bb.sx = g.Nx + 2 * m->W; bb.xo = m->W; bb.ilo = -m->W + 1; bb.ihi = g.Nx + m->W - 1; bb.wrap = 0;
   }
+  bool finalize_after = false;
   if (m->baro_block > 1) {
     // temporally blocked: S substeps per launch on (64 x TY) tiles
     const int S = std::min(m->baro_block, (int)BT_SMAX), TYb = m->baro_rows;
@@ -749,6 +752,19 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
       bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
       bm.b = bb;
       bm.ns = std::min(Sk, m->Ns - s);
+      bm.first = s == 0;
+      bm.last = s + Sk >= m->Ns;
+      if (bm.first && bm.last && !wide && !ahead) {
+        // a sub-cycle short enough for ONE launch would read and write the canonical eta, U, V in the same launch
+        bm.last = 0;
+        finalize_after = true;
+      }
+      bm.eta_out = out[0]; bm.U_out = out[1]; bm.V_out = out[2];
+      bm.eb_out = bm.ub_out = bm.vb_out = nullptr;
+      if (wide) {
+        const Field* fb = ahead ? m->ahead_bar : &m->f[GB25_ETA_BAR];
+        bm.eb_out = fb[0].d; bm.ub_out = fb[1].d; bm.vb_out = fb[2].d;
+      }
       for (int q = 0; q < BT_SMAX; q++) bm.w[q] = (s + q < m->Ns) ? (real)m->weights[s + q] : real(0.);
       hipLaunchKernelGGL(kern, gm, dim3(BT_NT), 0, m->stream, g, bm, dtau);
       for (int q = 0; q < 3; q++) { real* w_ = nxt[q]; nxt[q] = other[q]; other[q] = w_; cur[q] = w_; }
@@ -761,6 +777,10 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
       hipLaunchKernelGGL(k_barotropic_substep, gr, b, 0, m->stream, g, bb, dtau, (real)m->weights[s]);
       for (int q = 0; q < 3; q++) { real* w_ = nxt[q]; nxt[q] = other[q]; other[q] = w_; cur[q] = w_; }
     }
+  }
+  if (m->baro_block > 1 && !finalize_after) {   // the last blocked launch wrote eta, U, V and published the averages
+    LAUNCHCHK();
+    return GB25_OK;
   }
   dim3 gi = grid2(g.Nx, g.Ny, b);
   hipLaunchKernelGGL(k_barotropic_finalize, gi, b, 0, m->stream, g, out[0], out[1], out[2], bb.etab, bb.Ub, bb.Vb,

@@ -621,6 +621,11 @@ struct BaroMulti {
   Baro b;
   real w[BT_SMAX];
   int ns;  // substeps in this launch (1..BT_S)
+  // first launch of a sub-cycle: the running averages start from zero (no memset of the average arrays);
+  // last launch: eta, U, V <- averages are written here (no finalize launch), into arrays of the canonical layout,
+  // and so are the filtered-state arrays when the averages live in (wide) work arrays (no publish launch)
+  int first, last;
+  real *eta_out, *U_out, *V_out, *eb_out, *ub_out, *vb_out;
 };
 template <int BT_S, int BT_TY>
 __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm, real dtau) {
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
       (&GVs[0][0])[p] = gv;
     }
     ae[q] = au[q] = av[q] = real(0.);
-    if (own[q]) {
+    if (own[q] && !bm.first) {
       ae[q] = b.etab[po[q]];
       au[q] = b.Ub[po[q]];
       av[q] = b.Vb[po[q]];
@@ -735,6 +740,21 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
       b.etab[po[q]] = ae[q];
       b.Ub[po[q]] = au[q];
       b.Vb[po[q]] = av[q];
+      if (bm.last) {
+        const int ly = p / BT_RX, lx = p - ly * BT_RX;
+        const int ig = i0 - BT_S + lx;
+        if (ig >= 0 && ig < g.Nx) {   // (a widened slab also owns columns outside the canonical interior)
+          const int oc = i2(g, ig, pj[q]);
+          bm.eta_out[oc] = ae[q];
+          bm.U_out[oc] = au[q];
+          bm.V_out[oc] = av[q];
+          if (bm.eb_out) {
+            bm.eb_out[oc] = ae[q];
+            bm.ub_out[oc] = au[q];
+            bm.vb_out[oc] = av[q];
+          }
+        }
+      }
     }
 }
 
