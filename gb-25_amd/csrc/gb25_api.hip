@@ -427,8 +427,7 @@ gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, i
     return GB25_OK;
   }
   if (which == 1) h2.n = 0;
-  hipLaunchKernelGGL(k_fill_y, dim3((ni + 255) / 256, g.Nz + 1), b, 0, st, g, h3, h2, i0, ni);
-  hipLaunchKernelGGL(k_fill_z, dim3((ni + 255) / 256, g.Ny), b, 0, st, g, h3, i0, ni);
+  hipLaunchKernelGGL(k_fill_yz, dim3((ni + 255) / 256, g.Nz + 1 + g.Ny), b, 0, st, g, h3, h2, i0, ni);
   if (with_x && g.x_periodic) {
     int rows_c = g.sy_c * (g.Nz + 2 * g.H), rows_v = g.sy_v * (g.Nz + 2 * g.H);
     long threads = (long)rows_v * 2 * g.H;

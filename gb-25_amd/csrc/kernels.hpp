@@ -48,11 +48,10 @@ struct Halo2 {
 
 // south/north layer of the four 3-D fields + all 2-D fields over columns [i0, i0+ni).
 // grid: (ceil(ni/256), Nz + 1)
-__global__ void k_fill_y(Grid g, Halo3 f3, Halo2 f2, int i0, int ni) {
+__device__ __forceinline__ void fill_y_body(const Grid& g, const Halo3& f3, const Halo2& f2, int i0, int ni, int k) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ni) return;
   i += i0;
-  int k = blockIdx.y;
   if (k < g.Nz) {
     for (int q = 0; q < f3.n; q++) {
       real* c = f3.p[q];
@@ -77,22 +76,32 @@ __global__ void k_fill_y(Grid g, Halo3 f3, Halo2 f2, int i0, int ni) {
     }
   }
 }
+__global__ void k_fill_y(Grid g, Halo3 f3, Halo2 f2, int i0, int ni) { fill_y_body(g, f3, f2, i0, ni, blockIdx.y); }
 // bottom/top layer of the four 3-D fields over columns [i0, i0+ni).  grid: (ceil(ni/256), Ny)
-__global__ void k_fill_z(Grid g, Halo3 f3, int i0, int ni) {
+__device__ __forceinline__ void fill_z_body(const Grid& g, const Halo3& f3, int i0, int ni, int j) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ni) return;
   i += i0;
-  int j = blockIdx.y;
   for (int q = 0; q < f3.n; q++) {
     real* c = f3.p[q];
     if (f3.is_v[q]) {
-      c[iv(g, i, j, -1)] = c[iv(g, i, j, 0)];
-      c[iv(g, i, j, g.Nz)] = c[iv(g, i, j, g.Nz - 1)];
+      // (row 0 is the wall face: the y fill zeroes it at every level, and copying that zero is spelled out here so
+      // that this fill does not depend on the other one having run)
+      c[iv(g, i, j, -1)] = (j == 0) ? real(0.) : c[iv(g, i, j, 0)];
+      c[iv(g, i, j, g.Nz)] = (j == 0) ? real(0.) : c[iv(g, i, j, g.Nz - 1)];
     } else {
       c[ic(g, i, j, -1)] = c[ic(g, i, j, 0)];
       c[ic(g, i, j, g.Nz)] = c[ic(g, i, j, g.Nz - 1)];
     }
   }
+}
+__global__ void k_fill_z(Grid g, Halo3 f3, int i0, int ni) { fill_z_body(g, f3, i0, ni, blockIdx.y); }
+// both in one launch: they touch disjoint cells and neither reads what the other writes.
+// grid: (ceil(ni/256), Nz + 1 + Ny)
+__global__ void k_fill_yz(Grid g, Halo3 f3, Halo2 f2, int i0, int ni) {
+  const int b = blockIdx.y;
+  if (b <= g.Nz) fill_y_body(g, f3, f2, i0, ni, b);
+  else fill_z_body(g, f3, i0, ni, b - (g.Nz + 1));
 }
 // periodic x for one array of `rows` parent rows: thread = (q in 0..2H-1, row)
 __device__ __forceinline__ void periodic_row(const Grid& g, real* c, long row, int q) {
