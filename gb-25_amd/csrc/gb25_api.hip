@@ -97,6 +97,7 @@ struct gb25_model {
   int use_graphs = 0;                // GB25_GRAPH=1: replay a captured HIP graph of the step (see step_with_graph)
   std::vector<StepGraph> graphs;
   std::vector<HostState> seen;       // states met once: a state is captured when it comes round again
+  int fill_fused = 1;                // y, z and periodic-x fills of a single slab in one launch (GB25_FILL_FUSED=0: two)
   int ab2_ahead = 1;                 // GB25_AB2_AHEAD=0: always run the stand-alone tracer AXPY kernel
   real* bars = nullptr;         // contiguous etabar | Ubar | Vbar
   std::vector<real*> dev_tables;
@@ -427,6 +428,15 @@ gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, i
     return GB25_OK;
   }
   if (which == 1) h2.n = 0;
+  if (m->fill_fused && with_x && g.x_periodic && !extended) {   // single slab: y, z and periodic x in one launch
+    const int nbx = (g.Nx + 255) / 256, nb_yz = nbx * (g.Nz + 1 + g.Ny);
+    const int rows_c = g.sy_c * (g.Nz + 2 * g.H), rows_v = g.sy_v * (g.Nz + 2 * g.H);
+    const int nbr = (int)(((long)rows_v * 2 * g.H + 255) / 256);
+    hipLaunchKernelGGL(k_fill_fused, dim3(nb_yz + nbr * (4 + h2.n)), b, 0, st, g, h3, h2, nbx, nb_yz, nbr, rows_c,
+                       rows_v);
+    LAUNCHCHK();
+    return GB25_OK;
+  }
   hipLaunchKernelGGL(k_fill_yz, dim3((ni + 255) / 256, g.Nz + 1 + g.Ny), b, 0, st, g, h3, h2, i0, ni);
   if (with_x && g.x_periodic) {
     int rows_c = g.sy_c * (g.Nz + 2 * g.H), rows_v = g.sy_v * (g.Nz + 2 * g.H);
@@ -1012,6 +1022,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   // A slab of a decomposition always uses it: there it also takes two exchanges off the critical path.
   m->baro_ahead = (cfg->nranks > 1 || (long)cfg->Nx * cfg->Ny * cfg->Nz >= 8000000L) ? 1 : 0;
   if (const char* e = getenv("GB25_BARO_AHEAD")) m->baro_ahead = atoi(e);
+  if (const char* e = getenv("GB25_FILL_FUSED")) m->fill_fused = atoi(e);
   if (const char* e = getenv("GB25_LAZY_PHY")) m->phy_pinned = atoi(e) == 0;   // 0: store pHY' every step
   if (const char* e = getenv("GB25_GRAPH")) m->use_graphs = atoi(e);
   gb25_status s;

@@ -129,6 +129,116 @@ __global__ void k_fill_x(Grid g, Halo3 f3, Halo2 f2, int rows_c, int rows_v) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// All three fills in ONE launch.  The periodic x copy has to see the y / z layers of its source columns; instead of
+// waiting for them it reads what they are made FROM: a cell of a y layer is the neighbouring interior row (or zero on a
+// wall face of v), a cell of a z layer the neighbouring interior level, everything else is copied as it stands.  No
+// cell that one part reads is written by another, so the parts need no order.
+// 1-D grid: the first nb_yz blocks do the y and z layers (as k_fill_yz with nbx blocks per row of blocks), the rest
+// the x copy (nbr blocks per field).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ real x_source_3d(const Grid& g, const real* c, bool is_v, int isrc, int jj, int kk) {
+  // value at parent column isrc, parent row jj, parent level kk AFTER the y and z fills
+  const int sy = is_v ? g.sy_v : g.sy_c, pl = is_v ? g.pl_v : g.pl_c;
+  const int j = jj - g.H, k = kk - g.H;
+  int js = jj, ks = kk;
+  if (k >= 0 && k < g.Nz) {
+    if (is_v) {
+      if (j == 0 || j == g.Ny) return real(0.);
+    } else {
+      if (j == -1) js = g.H;
+      else if (j == g.Ny) js = g.H + g.Ny - 1;
+    }
+  } else if ((k == -1 || k == g.Nz) && j >= 0 && j < g.Ny) {
+    if (is_v && j == 0) return real(0.);
+    ks = (k == -1) ? g.H : g.H + g.Nz - 1;
+  }
+  (void)sy;
+  return c[isrc + g.sx * js + pl * ks];
+}
+__device__ __forceinline__ real x_source_2d(const Grid& g, const real* c, bool is_v, int isrc, int jj) {
+  const int j = jj - g.H;
+  int js = jj;
+  if (is_v) {
+    if (j == 0 || j == g.Ny) return real(0.);
+  } else {
+    if (j == -1) js = g.H;
+    else if (j == g.Ny) js = g.H + g.Ny - 1;
+  }
+  return c[isrc + g.sx * js];
+}
+__global__ void k_fill_fused(Grid g, Halo3 f3, Halo2 f2, int nbx, int nb_yz, int nbr, int rows_c, int rows_v) {
+  const int b = blockIdx.x;
+  if (b < nb_yz) {
+    const int by = b / nbx;
+    const int i = (b - by * nbx) * blockDim.x + threadIdx.x;
+    if (i >= g.Nx) return;
+    // (fill_y_body / fill_z_body take their column from blockIdx.x: do the same work inline)
+    if (by <= g.Nz) {
+      const int k = by;
+      if (k < g.Nz) {
+        for (int q = 0; q < f3.n; q++) {
+          real* c = f3.p[q];
+          if (f3.is_v[q]) {
+            c[iv(g, i, 0, k)] = real(0.);
+            c[iv(g, i, g.Ny, k)] = real(0.);
+          } else {
+            c[ic(g, i, -1, k)] = c[ic(g, i, 0, k)];
+            c[ic(g, i, g.Ny, k)] = c[ic(g, i, g.Ny - 1, k)];
+          }
+        }
+      } else {
+        for (int q = 0; q < f2.n; q++) {
+          real* c = f2.p[q];
+          if (f2.is_v[q]) {
+            c[i2(g, i, 0)] = real(0.);
+            c[i2(g, i, g.Ny)] = real(0.);
+          } else {
+            c[i2(g, i, -1)] = c[i2(g, i, 0)];
+            c[i2(g, i, g.Ny)] = c[i2(g, i, g.Ny - 1)];
+          }
+        }
+      }
+    } else {
+      const int j = by - (g.Nz + 1);
+      for (int q = 0; q < f3.n; q++) {
+        real* c = f3.p[q];
+        if (f3.is_v[q]) {
+          c[iv(g, i, j, -1)] = (j == 0) ? real(0.) : c[iv(g, i, j, 0)];
+          c[iv(g, i, j, g.Nz)] = (j == 0) ? real(0.) : c[iv(g, i, j, g.Nz - 1)];
+        } else {
+          c[ic(g, i, j, -1)] = c[ic(g, i, j, 0)];
+          c[ic(g, i, j, g.Nz)] = c[ic(g, i, j, g.Nz - 1)];
+        }
+      }
+    }
+    return;
+  }
+  // ---- periodic x copy, reading through the y / z fills
+  const int bb = b - nb_yz;
+  const int f = bb / nbr;
+  const long t = (long)(bb - f * nbr) * blockDim.x + threadIdx.x;
+  const int q = (int)(t % (2 * g.H));
+  const long row = t / (2 * g.H);
+  const int idst = (q < g.H) ? q : g.Nx + q;               // parent column written
+  const int isrc = (q < g.H) ? g.Nx + q : q;               // parent column it is the periodic image of
+  if (f < 4) {
+    if (f >= f3.n) return;
+    const bool is_v = f3.is_v[f] != 0;
+    const long rows = is_v ? rows_v : rows_c;
+    if (row >= rows) return;
+    const int sy = is_v ? g.sy_v : g.sy_c;
+    const int kk = (int)(row / sy), jj = (int)(row - (long)kk * sy);
+    f3.p[f][idst + row * g.sx] = x_source_3d(g, f3.p[f], is_v, isrc, jj, kk);
+  } else {
+    const int s2 = f - 4;
+    if (s2 >= f2.n) return;
+    const bool is_v = f2.is_v[s2] != 0;
+    if (row >= (is_v ? g.sy_v : g.sy_c)) return;
+    f2.p[s2][idst + row * g.sx] = x_source_2d(g, f2.p[s2], is_v, isrc, (int)row);
+  }
+}
+
 // =============================================================================================
 // compute_auxiliaries!: w from continuity and the hydrostatic pressure anomaly
 // (GB-25 src/precompile.jl:113-115).  One thread per column on the extended range

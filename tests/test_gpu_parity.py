@@ -389,6 +389,34 @@ def test_lookaheads_are_bitwise_neutral_over_a_longer_run(monkeypatch):
     assert np.abs(b.velocities.u.interior).max() > 0.05
 
 
+@pytest.mark.parametrize("shape,halo", [((150, 70, 12), 8), ((40, 21, 6), 4)])
+def test_fused_halo_fill_is_bitwise_neutral(monkeypatch, shape, halo):
+    """One launch for the y, z and periodic-x fills (the x copy reads through the other two) against the sequence
+    y+z, then x: every cell of every parent array, including halo values the host planted in layers that no fill
+    rewrites."""
+    Nx, Ny, Nz = shape
+    models = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("GB25_FILL_FUSED", fused)
+        m = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=300.0, halo=(halo,) * 3)
+        gb.set_baroclinic_instability(m)
+        set_noisy_velocities(m, 0.05)
+        for n, seed in (("T", 5), ("u", 6), ("v", 7), ("eta", 8), ("V", 9)):
+            a = m.backend.get_field(n, True)
+            a += (1e-3 * counter_rng(a.shape, seed, 1)).astype(np.float32)      # noise in EVERY halo layer
+            m.backend.set_field(n, a, True)
+        m.backend.fill_halo_regions()
+        models.append(m)
+    a, b = models
+    for n in ALL_FIELDS:
+        assert np.array_equal(a.backend.get_field(n, True), b.backend.get_field(n, True)), ("fill", n)
+    for m in (a, b):
+        gb.first_time_step(m)
+        gb.loop(m, 4)
+    for n in ALL_FIELDS:
+        assert np.array_equal(a.backend.get_field(n, True), b.backend.get_field(n, True)), ("steps", n)
+
+
 def test_graph_replay_is_bitwise_neutral(monkeypatch):
     """gb25_time_step / gb25_loop replay a captured HIP graph of the step once a host state recurs (the pointer
     exchanges give period 2).  Same bits as eager launches (GB25_GRAPH=0), through host writes, a changed dt, an
