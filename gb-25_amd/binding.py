@@ -71,10 +71,18 @@ def load_library(float_type="Float32"):
     if float_type in _libs:
         return _libs[float_type]
     path = LIB_PATHS[float_type]
+    if not os.path.exists(path) and not os.environ.get("GB25_LIB"):
+        # a fresh checkout: compile the library (hipcc cross-compiles gfx950 anywhere); there is no other code path
+        try:
+            from .build import build_library
+            print(f"gb25_amd: {os.path.basename(path)} not built yet, compiling it with hipcc ...", flush=True)
+            build_library(float_types=(float_type,))
+        except Exception as e:
+            raise GB25Error(
+                f"{path} not found and building it failed ({e}): run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950).  gb25_amd has no CPU fallback.") from e
     if not os.path.exists(path):
-        raise GB25Error(
-            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950).  gb25_amd has no CPU fallback.")
+        raise GB25Error(f"{path} not found.  gb25_amd has no CPU fallback.")
     lib = C.CDLL(path)
     P = C.c_void_p
     lib.gb25_version.restype = C.c_char_p
