@@ -991,6 +991,15 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
                 "invalid configuration: need Nx,Ny >= 8, Nz >= 4, halo >= 4, 1 <= substeps <= 4096, Nx %% nranks == 0");
   m->Nx = cfg->Nx / cfg->nranks;
   if (m->Nx < cfg->halo) return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab narrower than the halo");
+  {
+    // the kernels address a parent array with 32-bit element indices and 32-bit byte offsets (buffer addressing)
+    const double bytes = (double)(m->Nx + 2 * cfg->halo) * (cfg->Ny + 2 * cfg->halo + 1) * (cfg->Nz + 2 * cfg->halo + 1) *
+                         sizeof(real);
+    if (bytes >= 2147483648.0)
+      return fail(m, GB25_ERR_INVALID_ARGUMENT,
+                  "a %dx%dx%d slab needs %.1f GB per 3-D array; the kernels address at most 2 GB per array: decompose "
+                  "in x (nranks) so that the local slab is narrower", m->Nx, cfg->Ny, cfg->Nz, bytes / 1e9);
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(m, GB25_ERR_NO_DEVICE, "no HIP device visible; libgb25hip has no CPU fallback");
