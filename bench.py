@@ -16,6 +16,10 @@ import os
 import sys
 import time
 
+# RCCL / device-memory sharing across the ranks of a node needs dmabuf IPC on this driver stack; the variable is
+# exported on the build and GPU boxes already, this only covers a bare launch.  Must precede the first HIP call.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
