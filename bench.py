@@ -7,8 +7,10 @@ barrier + device synchronisation; the metric is K / wall (max over ranks).  A "s
 the whole grid.  Inputs are synthetic (deterministic baroclinic-instability IC + seeded velocity noise) and are
 resident in HBM before the timed region starts.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size Nx Ny Nz] [--no-cpu-baseline]
-N > 1 is launched by the driver with torch.distributed.run, one rank per GPU (x-slab decomposition).
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size Nx Ny Nz] [--weak] [--no-cpu-baseline]
+N > 1 is launched by the driver with torch.distributed.run, one rank per GPU: the SAME Nx x Ny x Nz grid (BASELINE.json:
+1440x720x48 at 1/2/4/8 GPUs) cut into N x-slabs, i.e. strong scaling; --weak gives every rank its own Nx x Ny x Nz slab of
+an (N Nx) x Ny x Nz grid instead (the reference's own scaling protocol, sharding/sharded_..._run.jl:82-88).
 """
 import argparse
 import json
@@ -64,7 +66,7 @@ def counter_rng(shape, seed, salt):
     return ((x >> np.uint64(11)).astype(np.float64) / float(1 << 53)).reshape(shape, order="F")
 
 
-def cpu_baseline(Nx, Ny, Nz, dt, budget_s=25.0):
+def cpu_baseline(Nx, Ny, Nz, dt, budget_s=25.0, max_steps=50):
     """The oracle (fp32 build, OpenMP) timed on this host on a bounded sample of the same workload.
     kind = "port": the reference's Julia CPU path cannot run here (no Julia)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -86,7 +88,7 @@ def cpu_baseline(Nx, Ny, Nz, dt, budget_s=25.0):
         gb.time_step(m)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 50 or el / n * (n + 1) > 1.6 * budget_s:
+        if el > budget_s or n >= max_steps or el / n * (n + 1) > 1.6 * budget_s:
             break
     m.backend.close()
     return {"value": n / el, "unit": "steps/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
@@ -100,6 +102,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, nargs=3, default=[1440, 720, 48], metavar=("Nx", "Ny", "Nz"))
     ap.add_argument("--dt", type=float, default=240.0)
+    ap.add_argument("--weak", action="store_true", help="N > 1: every rank a full --size slab of an N times wider grid")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="library option for A/B runs (gb25_set_option), e.g. --opt subcycle_lookahead=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timers")
     args = ap.parse_args()
@@ -119,32 +124,44 @@ def main():
     torch.cuda.set_device(local_rank)
     Nx, Ny, Nz = args.size
 
+    gNx = Nx * world if (args.weak and world > 1) else Nx          # global grid
     if world > 1:
         import torch.distributed as dist
         from gb25_amd.distributed import SlabModel
-        # "nccl" IS RCCL on ROCm.  GB25_DIST_BACKEND=gloo + GB25_ALL_ON_DEVICE0=1 rehearse the multi-process path
-        # with every rank on one GPU (RCCL refuses two ranks per device); used by tests on the 1-GPU box only.
+        # "nccl" IS RCCL on ROCm: torch.distributed only launches the ranks, shares the communicator's unique id and
+        # takes the max of the timings; the halo exchanges are the library's own ncclSend/ncclRecv.
+        # GB25_DIST_BACKEND=gloo + GB25_ALL_ON_DEVICE0=1 rehearse the multi-process path with every rank on one GPU
+        # (RCCL refuses two ranks per device; the exchanges then go through the host-callback transport): tests only.
         backend = os.environ.get("GB25_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-        # weak scaling: every rank owns one Nx x Ny x Nz slab of a (world*Nx) x Ny x Nz global grid.  The zonal
-        # spacing shrinks with the rank count, so the time step shrinks with it (constant barotropic Courant number,
-        # as the reference's resolution-dependent dt: simulations/ocean_climate_simulation.jl:50-51).
-        args.dt = args.dt / world
-        model = SlabModel(world * Nx, Ny, Nz, dt=args.dt, rank=rank, nranks=world, device=local_rank)
+        if gNx % world:
+            raise SystemExit(f"Nx = {gNx} is not divisible by {world} ranks")
+        if args.weak:
+            # the zonal spacing shrinks with the rank count, so the time step shrinks with it (constant barotropic
+            # Courant number, as the reference's resolution-dependent dt: simulations/ocean_climate_simulation.jl:50-51)
+            args.dt = args.dt / world
+        model = SlabModel(gNx, Ny, Nz, dt=args.dt, rank=rank, nranks=world, device=local_rank)
         barrier = dist.barrier
     else:
         model = gb.baroclinic_instability_model(gb.GPU(local_rank), Nx, Ny, Nz, dt=args.dt)
         barrier = lambda: None
+    locNx = gNx // world
     b = model.backend
+    for kv in args.opt:
+        name, val = kv.split("=")
+        b.set_option(name, int(val))
 
     # synthetic inputs, resident in HBM before timing
     gb.set_baroclinic_instability(model)
     ush, vsh = model.velocities.u.shape, model.velocities.v.shape
-    model.set(u=(1e-3 * counter_rng(ush, 42 + rank, 1)).astype(np.float32),
-              v=(1e-3 * counter_rng(vsh, 42 + rank, 2)).astype(np.float32))
+    # (the global noise field, cut into the rank's columns: the same initial state whatever the rank count)
+    u0 = (1e-3 * counter_rng((gNx,) + tuple(ush[1:]), 42, 1)).astype(np.float32)[rank * locNx:(rank + 1) * locNx]
+    v0 = (1e-3 * counter_rng((gNx,) + tuple(vsh[1:]), 42, 2)).astype(np.float32)[rank * locNx:(rank + 1) * locNx]
+    model.set(u=u0, v=v0)
+    del u0, v0
     gb.first_time_step(model)
     # Per-kernel times of every kernel are taken during the WARM-UP steps; in the timed region only the dominant kernel
     # carries event records (50 event records per step cost ~3 % of the step, and only that kernel's duration is needed
@@ -194,16 +211,19 @@ def main():
             kernels.setdefault(k, v)
 
     if rank == 0:
-        cells = Nx * Ny * Nz
+        cells = locNx * Ny * Nz                    # per GPU (= per launch of a kernel)
         steps_per_s = args.steps / elapsed
         out = {
             "metric": "model time-steps/sec", "value": steps_per_s, "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"baroclinic_instability_model {world * Nx}x{Ny}x{Nz} LatitudeLongitudeGrid, "
+            "higher_is_better": True, "scaling": "weak" if (args.weak and world > 1) else "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"baroclinic_instability_model {gNx}x{Ny}x{Nz} LatitudeLongitudeGrid, "
                                    f"halo 8, SplitExplicit(30), WENO5, TEOS10, dt={args.dt:g}s",
-                       "grid": [world * Nx, Ny, Nz], "cells_per_gpu": cells,
-                       "parallelism": f"x-slab x{world}" if world > 1 else "single GPU",
+                       "grid": [gNx, Ny, Nz], "cells_per_gpu": cells, "local_columns": locNx,
+                       "parallelism": (f"x-slab x{world}, RCCL send/recv inside the library"
+                                       if world > 1 else "single GPU"),
+                       "transport": getattr(model, "transport_kind", None),
                        "simulated_years_per_day": steps_per_s * args.dt / 365.0},
             "finite": finite,
         }
@@ -225,19 +245,29 @@ def main():
                 alg["tracers"] += 8 * 4
             bytes_per_launch = alg[dom] * cells
             achieved = bytes_per_launch / (timed[dom]["avg_ms"] * 1e-3) / 1e9
-            traffic, traffic_src = measured_traffic(dom, (Nx, Ny, Nz))
+            traffic, traffic_src = measured_traffic(dom, (locNx, Ny, Nz))
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "traffic_source": traffic_src,
+                               # what the kernel really pulls from HBM (PMC bytes / live launch time): the tendency
+                               # kernels are VALU-issue bound, the fused rows make `achieved` exceed this
+                               "traffic_GBps": (traffic / (timed[dom]["avg_ms"] * 1e-3) / 1e9) if traffic else None,
+                               "traffic_frac": (traffic / (timed[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                               if traffic else None,
                                "avg_launch_ms": timed[dom]["avg_ms"], "launches_per_step": launches_per_step,
                                "algorithmic_bytes_per_launch": bytes_per_launch,
                                "algorithmic_bytes_per_cell": alg[dom],
-                               "whole_step_achieved_GBps": 240.0 * cells * steps_per_s / 1e9}
+                               "whole_step_achieved_GBps": 240.0 * cells * steps_per_s / 1e9,
+                               "whole_step_frac": 240.0 * cells * steps_per_s / 1e9 / HBM_PEAK_GBS}
             out["kernels_ms_per_launch"] = {k: v["avg_ms"] for k, v in kernels.items()}
             out["kernel_times_from"] = (f"timed region: {dom}; others: warm-up steps" if warm_kernels
                                         else "timed region")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(Nx, Ny, Nz, args.dt)
+            # BASELINE.json configs[0] (the reference's own CPU-runnable case: 128x64x8, 100 AB2 steps) beside it
+            c1 = cpu_baseline(128, 64, 8, 1200.0, budget_s=10.0, max_steps=99)
+            c1["sample"] = c1["sample"].replace("the same ", "BASELINE configs[0] ")
+            out["cpu_baseline_config1"] = c1
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -38,11 +38,17 @@ ABI_SYMBOLS = [
     "gb25_compute_momentum_tendencies", "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
     "gb25_compute_tendencies", "gb25_ab2_step", "gb25_correct_velocities_and_cache_previous_tendencies",
     "gb25_update_state", "gb25_first_time_step", "gb25_time_step", "gb25_loop",
-    "gb25_halo_buffer_elems", "gb25_halo_pack", "gb25_halo_unpack", "gb25_halo_pack_both", "gb25_halo_unpack_both",
-    "gb25_time_step_stage", "gb25_lookahead_state",
-    "gb25_update_state_local", "gb25_fill_halo_regions_local",
+    "gb25_set_option", "gb25_get_option",
+    "gb25_comm_unique_id", "gb25_comm_init_rccl", "gb25_comm_init_local", "gb25_comm_init_callback", "gb25_comm_finalize",
+    "gb25_lookahead_state", "gb25_debug_sequence",
     "gb25_profile_enable", "gb25_profile_reset", "gb25_profile_get",
 ]
+# gb25_option (include/gb25.h)
+OPTION_IDS = {"kernels": 0, "ab2_lookahead": 1, "subcycle_lookahead": 2, "subcycle_block": 3, "fill_fused": 4,
+              "two_streams": 5, "store_pressure": 6, "split_tendencies": 7}
+UNIQUE_ID_BYTES = 128
+# int32 fn(void *user, int32 buffer_set, const void *send_w, const void *send_e, void *recv_w, void *recv_e, int64 nbytes)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
 
 
 class Config(C.Structure):
@@ -54,6 +60,7 @@ class Config(C.Structure):
         ("lat_south", C.c_double), ("lat_north", C.c_double), ("lon_west", C.c_double), ("lon_east", C.c_double),
         ("depth", C.c_double), ("zexp_h", C.c_double),
         ("g", C.c_double), ("Omega", C.c_double), ("radius", C.c_double), ("rho0", C.c_double),
+        ("slab_mode", C.c_int32), ("grid_type", C.c_int32),
     ]
 
 
@@ -71,16 +78,20 @@ def load_library(float_type="Float32"):
     if float_type in _libs:
         return _libs[float_type]
     path = LIB_PATHS[float_type]
-    if not os.path.exists(path) and not os.environ.get("GB25_LIB"):
-        # a fresh checkout: compile the library (hipcc cross-compiles gfx950 anywhere); there is no other code path
-        try:
-            from .build import build_library
-            print(f"gb25_amd: {os.path.basename(path)} not built yet, compiling it with hipcc ...", flush=True)
-            build_library(float_types=(float_type,))
-        except Exception as e:
-            raise GB25Error(
-                f"{path} not found and building it failed ({e}): run `python -c 'import __graft_entry__ as g; "
-                "g.build()'` (hipcc --offload-arch=gfx950).  gb25_amd has no CPU fallback.") from e
+    if not os.environ.get("GB25_LIB"):
+        # a fresh checkout, or sources newer than the binary: compile (hipcc cross-compiles gfx950 anywhere).  The build
+        # writes a temporary file and renames it under a lock, so concurrent ranks never load a half-written library.
+        from .build import build_library, _stale
+        if _stale(path):
+            try:
+                print(f"gb25_amd: building {os.path.basename(path)} with hipcc ...", flush=True)
+                build_library(float_types=(float_type,))
+            except Exception as e:
+                if not os.path.exists(path):
+                    raise GB25Error(
+                        f"{path} not found and building it failed ({e}): run `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` (hipcc --offload-arch=gfx950).  gb25_amd has no CPU fallback.") from e
+                raise GB25Error(f"{path} is older than its sources and rebuilding it failed: {e}") from e
     if not os.path.exists(path):
         raise GB25Error(f"{path} not found.  gb25_amd has no CPU fallback.")
     lib = C.CDLL(path)
@@ -105,12 +116,15 @@ def load_library(float_type="Float32"):
     lib.gb25_ab2_step.argtypes = [P, C.c_double, C.c_int]
     lib.gb25_correct_velocities_and_cache_previous_tendencies.argtypes = [P, C.c_double]
     lib.gb25_loop.argtypes = [P, C.c_int32]
-    lib.gb25_halo_buffer_elems.argtypes = [P, C.c_int, C.POINTER(C.c_int64)]
-    lib.gb25_halo_pack.argtypes = [P, C.c_int, C.c_int, P]
-    lib.gb25_halo_unpack.argtypes = [P, C.c_int, C.c_int, P]
-    lib.gb25_halo_pack_both.argtypes = [P, C.c_int, P, P]
-    lib.gb25_halo_unpack_both.argtypes = [P, C.c_int, P, P]
-    lib.gb25_time_step_stage.argtypes = [P, C.c_int, C.c_int]
+    lib.gb25_set_option.argtypes = [P, C.c_int, C.c_int32]
+    lib.gb25_get_option.argtypes = [P, C.c_int, C.POINTER(C.c_int32)]
+    lib.gb25_comm_unique_id.argtypes = [P]
+    lib.gb25_comm_init_rccl.argtypes = [P, P]
+    lib.gb25_comm_init_local.argtypes = [C.POINTER(P), C.c_int32]
+    lib.gb25_comm_init_callback.argtypes = [P, EXCHANGE_FN, P]
+    lib.gb25_comm_finalize.argtypes = [P]
+    lib.gb25_debug_sequence.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int64]
+    lib.gb25_debug_sequence.restype = C.c_int64
     lib.gb25_lookahead_state.argtypes = [P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.gb25_profile_enable.argtypes = [P, C.c_int]
     lib.gb25_profile_get.argtypes = [P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
@@ -119,7 +133,7 @@ def load_library(float_type="Float32"):
                  "gb25_fill_diffusivity_halos", "gb25_compute_momentum_tendencies",
                  "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
                  "gb25_compute_tendencies", "gb25_update_state", "gb25_first_time_step", "gb25_time_step",
-                 "gb25_update_state_local", "gb25_fill_halo_regions_local", "gb25_profile_reset"]:
+                 "gb25_profile_reset"]:
         getattr(lib, name).argtypes = [P]
     lib.gb25_real_bytes.restype = C.c_int32
     if lib.gb25_real_bytes() != np.dtype(DTYPES[float_type]).itemsize:
@@ -133,7 +147,7 @@ class HipBackend:
     GB-25 src/precompile.jl:31-42 and the entry points of src/timestepping_utils.jl:21-45."""
 
     def __init__(self, Nx, Ny, Nz, *, dt, halo=8, substeps=30, device=0, rank=0, nranks=1, float_type="Float32",
-                 **overrides):
+                 options=None, **overrides):
         float_type = getattr(float_type, "__name__", float_type)   # accepts "Float64", np.float64, ...
         float_type = {"float32": "Float32", "float64": "Float64"}.get(float_type, float_type)
         self.lib = load_library(float_type)
@@ -155,6 +169,9 @@ class HipBackend:
                 self.lib.gb25_destroy(self.h)
                 self.h = None
             raise GB25Error(f"gb25_create: status {st}: {msg}")
+        self._keep = []            # ctypes callbacks handed to the library
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
 
     def close(self):
         if getattr(self, "h", None):
@@ -234,7 +251,6 @@ class HipBackend:
     def initialize(self): self._call("gb25_initialize")
     def mask_immersed_fields(self): self._call("gb25_mask_immersed_fields")
     def fill_halo_regions(self): self._call("gb25_fill_halo_regions")
-    def fill_halo_regions_local(self): self._call("gb25_fill_halo_regions_local")
     def compute_auxiliaries(self): self._call("gb25_compute_auxiliaries")
     def fill_diffusivity_halos(self): self._call("gb25_fill_diffusivity_halos")
     def compute_momentum_tendencies(self): self._call("gb25_compute_momentum_tendencies")
@@ -245,11 +261,18 @@ class HipBackend:
     def correct_velocities_and_cache_previous_tendencies(self, dt=0.0):
         self._call("gb25_correct_velocities_and_cache_previous_tendencies", float(dt))
     def update_state(self): self._call("gb25_update_state")
-    def update_state_local(self): self._call("gb25_update_state_local")
     def first_time_step(self): self._call("gb25_first_time_step")
     def time_step(self): self._call("gb25_time_step")
     def loop(self, n): self._call("gb25_loop", int(n))
-    def time_step_stage(self, stage, euler=False): self._call("gb25_time_step_stage", int(stage), int(euler))
+
+    # ---- options (gb25_option)
+    def set_option(self, name, value):
+        self._call("gb25_set_option", OPTION_IDS[name], int(value))
+
+    def get_option(self, name):
+        v = C.c_int32()
+        self._call("gb25_get_option", OPTION_IDS[name], C.byref(v))
+        return v.value
 
     def lookahead_state(self):
         """(velocity look-ahead of the next step exists, stage 0 of this step adopted the sub-cycle look-ahead)"""
@@ -257,18 +280,42 @@ class HipBackend:
         self._call("gb25_lookahead_state", C.byref(a), C.byref(b))
         return bool(a.value), bool(b.value)
 
-    # ---- slab exchange
-    def halo_buffer_elems(self, group):
-        n = C.c_int64()
-        self._call("gb25_halo_buffer_elems", int(group), C.byref(n))
-        return n.value
+    # ---- exchange context of a slab (x decomposition)
+    def comm_unique_id(self):
+        """128 bytes from ncclGetUniqueId (rank 0 calls this and hands them to every rank)."""
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        st = self.lib.gb25_comm_unique_id(buf)
+        if st != 0:
+            raise GB25Error(f"gb25_comm_unique_id: status {st} (librccl could not be loaded?)")
+        return buf.raw
 
-    def halo_pack(self, group, side, dev_ptr): self._call("gb25_halo_pack", group, side, C.c_void_p(dev_ptr))
-    def halo_unpack(self, group, side, dev_ptr): self._call("gb25_halo_unpack", group, side, C.c_void_p(dev_ptr))
-    def halo_pack_both(self, group, west_ptr, east_ptr):
-        self._call("gb25_halo_pack_both", group, C.c_void_p(west_ptr), C.c_void_p(east_ptr))
-    def halo_unpack_both(self, group, west_ptr, east_ptr):
-        self._call("gb25_halo_unpack_both", group, C.c_void_p(west_ptr), C.c_void_p(east_ptr))
+    def comm_init_rccl(self, unique_id):
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        self._call("gb25_comm_init_rccl", C.c_char_p(bytes(unique_id)))
+
+    def comm_init_callback(self, fn):
+        """fn(buffer_set, send_west, send_east, recv_west, recv_east, nbytes) with device pointers as integers."""
+        def trampoline(user, b, sw, se, rw, re, nbytes):
+            try:
+                fn(b, sw, se, rw, re, nbytes)
+                return 0
+            except Exception as e:     # never let an exception cross the C frames
+                print(f"gb25_amd: exchange callback failed: {e!r}", flush=True)
+                return 1
+        cb = EXCHANGE_FN(trampoline)
+        self._keep.append(cb)
+        self._call("gb25_comm_init_callback", cb, None)
+
+    def comm_finalize(self):
+        self._call("gb25_comm_finalize")
+
+    @staticmethod
+    def comm_init_local(backends):
+        """All slabs of one decomposition in this process: ring of device copies; the composites of any member step all."""
+        b0 = backends[0]
+        arr = (C.c_void_p * len(backends))(*[b.h for b in backends])
+        b0._chk(b0.lib.gb25_comm_init_local(arr, len(backends)), "gb25_comm_init_local")
 
     # ---- timers
     def profile_enable(self, on=True, only=None):

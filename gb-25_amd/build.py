@@ -6,7 +6,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = [os.path.join(_HERE, "csrc", "gb25_api.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", n) for n in ("kernels.hpp", "kernels_v2.hpp", "device_common.hpp")] + \
+HEADERS = [os.path.join(_HERE, "csrc", n) for n in ("kernels.hpp", "tendency_kernels.hpp", "slab_step.hpp", "device_common.hpp")] + \
           [os.path.join(_HERE, "..", "include", "gb25.h")]
 OUTPUT = os.path.join(_HERE, "libgb25hip.so")
 OUTPUTS = {"Float32": (OUTPUT, "float"), "Float64": (os.path.join(_HERE, "libgb25hip_f64.so"), "double")}
@@ -20,22 +20,35 @@ def _stale(path):
 
 
 def build_library(force=False, verbose=False, float_types=("Float32", "Float64")):
-    """hipcc --offload-arch=gfx950 -shared: cross-compiles without a GPU.  Returns the Float32 library's path."""
+    """hipcc --offload-arch=gfx950 -shared: cross-compiles without a GPU.  Returns the Float32 library's path.
+    Each library is written to a temporary file and renamed into place while holding a lock file, so that several
+    ranks starting at once on a fresh checkout build it once and never dlopen a half-written file."""
+    import fcntl
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    procs = []
-    for ft in float_types:
-        out, ctype = OUTPUTS[ft]
-        if not force and not _stale(out):
-            continue
-        # -fno-slp-vectorize: hipcc otherwise packs neighbouring scalar f32 ops into v_pk_* pairs, which on these
-        # stencil kernels costs ~140 v_mov per kernel and 20-30 VGPRs (k_gu: 94 -> 70, tracers: 82 -> 61) for no
-        # throughput gain; measured 177 -> 217 steps/s at 1440x720x48 (profiles/r01_tuning_log.md).
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-               "-fno-slp-vectorize", f"-DGB25_REAL={ctype}", "-o", out] + SOURCES
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)          # other ranks wait here, then find the library up to date
+        procs = []
+        for ft in float_types:
+            out, ctype = OUTPUTS[ft]
+            if not force and not _stale(out):
+                continue
+            tmp = f"{out}.tmp{os.getpid()}"
+            # -fno-slp-vectorize: hipcc otherwise packs neighbouring scalar f32 ops into v_pk_* pairs, which on these
+            # stencil kernels costs ~140 v_mov per kernel and 20-30 VGPRs for no throughput gain; measured 177 -> 217
+            # steps/s at 1440x720x48 (profiles/r01_tuning_log.md).  Values that are born as pairs are packed by hand.
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+                   "-fno-slp-vectorize", f"-DGB25_REAL={ctype}", "-o", tmp] + SOURCES + ["-ldl"]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd), tmp, out))
+        err = None
+        for cmd, p, tmp, out in procs:
+            if p.wait() != 0:
+                err = subprocess.CalledProcessError(p.returncode, cmd)
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+            else:
+                os.replace(tmp, out)
+        if err:
+            raise err
     return OUTPUT

@@ -6,7 +6,7 @@
 // There is no CPU fallback: without a HIP device gb25_create fails with GB25_ERR_NO_DEVICE.
 #include "../../include/gb25.h"
 #include "kernels.hpp"
-#include "kernels_v2.hpp"
+#include "tendency_kernels.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -31,31 +31,6 @@ struct Field {
 
 struct EventPair {
   hipEvent_t a, b;
-};
-
-// Everything a time step changes on the HOST side (the device work is in the kernels): which buffer carries which
-// name after the pointer exchanges, and the validity flags of the cached by-products.
-struct HostState {
-  // G^n/G^- of u,v,T,S (8); T, S and partners (4); column integrals and partners (4); u, v and partners (4);
-  // G.U, G.V and partners (4)
-  real* ptr[24];
-  bool ahead_valid, ahead_uv_valid, colsum_valid;
-  real ahead_dt, ahead_chi, ahead_uv_dt, ahead_uv_chi;
-  bool operator==(const HostState& o) const {
-    for (int q = 0; q < 24; q++)
-      if (ptr[q] != o.ptr[q]) return false;
-    return ahead_valid == o.ahead_valid && ahead_uv_valid == o.ahead_uv_valid && colsum_valid == o.colsum_valid &&
-           (!ahead_valid || (ahead_dt == o.ahead_dt && ahead_chi == o.ahead_chi)) &&
-           (!ahead_uv_valid || (ahead_uv_dt == o.ahead_uv_dt && ahead_uv_chi == o.ahead_uv_chi));
-  }
-};
-// One captured time step: valid when the model is in state `pre` with the same dt and stream; leaves it in `post`.
-struct StepGraph {
-  HostState pre, post;
-  double dt;
-  hipStream_t stream;
-  hipGraphExec_t exec;
-  hipGraph_t graph;
 };
 
 }  // namespace
@@ -92,13 +67,10 @@ struct gb25_model {
   bool phy_stale = false, phy_pinned = false;
   bool baro_inflight = false;        // a look-ahead sub-cycle is on the side stream and nobody has waited for it yet
   bool baro_adopted = false;         // staged path: stage 0 of this step adopted the sub-cycle look-ahead
-  int baro_ahead = 1;                // GB25_BARO_AHEAD=0: sub-cycle inside the step, on the critical path
+  int baro_ahead = 1;                // option SUBCYCLE_LOOKAHEAD = 0: sub-cycle inside the step, on the critical path
   hipEvent_t ev_baro = nullptr, ev_mom = nullptr;
-  int use_graphs = 0;                // GB25_GRAPH=1: replay a captured HIP graph of the step (see step_with_graph)
-  std::vector<StepGraph> graphs;
-  std::vector<HostState> seen;       // states met once: a state is captured when it comes round again
-  int fill_fused = 1;                // y, z and periodic-x fills of a single slab in one launch (GB25_FILL_FUSED=0: two)
-  int ab2_ahead = 1;                 // GB25_AB2_AHEAD=0: always run the stand-alone tracer AXPY kernel
+  int fill_fused = 1;                // y, z and periodic-x fills of a single slab in one launch (option FILL_FUSED = 0: two)
+  int ab2_ahead = 1;                 // option AB2_LOOKAHEAD: 0 = stand-alone AB2 kernels, 1 = both look-aheads, 2 = tracers only
   real* bars = nullptr;         // contiguous etabar | Ubar | Vbar
   std::vector<real*> dev_tables;
   std::vector<double> h_metric[11];
@@ -118,7 +90,7 @@ struct gb25_model {
   // streams / timing
   hipStream_t own_stream = nullptr, stream = nullptr, side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool two_streams = true;          // GB25_TWO_STREAMS=0: strictly sequential phases on one stream
+  bool two_streams = true;          // option TWO_STREAMS = 0: strictly sequential phases on one stream
   bool profile = false;
   int profile_only = -1;             // >= 0: time this kernel id alone (keeps the event records out of the other launches)
   std::vector<EventPair> pending[GB25_K_COUNT];
@@ -126,15 +98,12 @@ struct gb25_model {
   int64_t prof_count[GB25_K_COUNT] = {0};
   double prof_ms[GB25_K_COUNT] = {0};
   std::string err;
-  int baro_rows = 16;                // tile height of the blocked barotropic kernel: 16 or 32 (GB25_BARO_ROWS)
-  int baro_block = 7;             // substeps per barotropic launch (GB25_BARO_BLOCK=1: one launch per substep)
-  int momentum_v5 = 1;               // packed (G_u term, G_v term) reconstructions; GB25_MOMENTUM_V5=0: scalar v2 kernel
-  int momentum_v4 = 0;               // GB25_MOMENTUM_V4=1: single-barrier pipelined momentum kernel
-  int tracer_v3 = 5;                 // 5: packed (T,S) wave-autonomous kernel, buffer addressing; 1: scalar v3; 0: LDS v2 (GB25_TRACER_V3)
-  int tile_rows = 4;                 // rows (= waves) per block of the LDS tendency kernels: 4 or 8 (GB25_TILE_ROWS); 4 wins with the packed kernel: more blocks per CU to cover the barriers
-  int variant_c = 1;                 // nontemporal tendency reads in the tracer AB2 stream (GB25_VARIANT_C)
-  int variant_a = 1, variant_b = 1;  // tuning switches (GB25_VARIANT_A / _B), see momentum_impl / tracers_impl
-  int kernel_gen = 2;  // 2: LDS flux-sharing tendency kernels (kernels_v2.hpp); 1: direct-stencil kernels (GB25_KERNELS=v1)
+  int baro_block = 7;                // substeps per barotropic launch (option SUBCYCLE_BLOCK = 1: one launch per substep)
+  int kernel_gen = 2;                // 2: LDS / flux-sharing tendency kernels (tendency_kernels.hpp); 1: direct-stencil kernels
+  int split_tendencies = 1;          // slab of a decomposition: interior tile columns before the x-halo bundle has arrived
+  bool slab = false;                 // x halos come from a neighbour (nranks > 1, or the self-ring of slab_mode = 1)
+  struct SlabGroup* group = nullptr; // exchange context (transport, buffers, comm stream) once gb25_comm_init_* was called
+  int group_index = 0;               // this slab's position in group->slabs
 };
 
 namespace {
@@ -269,7 +238,7 @@ gb25_status build_grid(gb25_model* m) {
   g.sx = m->Nx + 2 * H;
   g.sy_c = Ny + 2 * H; g.sy_v = Ny + 2 * H + 1;
   g.pl_c = g.sx * g.sy_c; g.pl_v = g.sx * g.sy_v;
-  g.x_periodic = (c.nranks == 1);
+  g.x_periodic = !m->slab;
   g.dy = (real)(R * dphi * d2r);
   g.g = (real)c.g; g.rho0 = (real)c.rho0; g.Lz = (real)(zint[Nz] - zint[0]);
   gb25_status s;
@@ -466,13 +435,22 @@ gb25_status fill_halos_2d(gb25_model* m, Halo2 h2) {
   return GB25_OK;
 }
 
-gb25_status compute_w_impl(gb25_model* m) {
+// part: 0 = the whole extended range -H+1 .. Nx+H-2; 1 = the slab's own columns 0 .. Nx-2 (they read own columns
+// only: runs while the x-halo bundle travels); 2 = the two edge strips that part 1 left out.
+gb25_status compute_w_impl(gb25_model* m, int part = 0) {
   const Grid& g = m->g;
   Timed t(m, GB25_K_COMPUTE_W);
-  dim3 b(64, 4);
-  int ex = g.Nx + 2 * g.H - 2, ey = g.Ny + 2 * g.H - 2;
-  hipLaunchKernelGGL(k_compute_w, grid2(ex, ey, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                     m->f[GB25_W].d);
+  int ia = -g.H + 1, na = g.Nx + 2 * g.H - 2, ib = 0, nbcols = 0;
+  if (part == 1) {
+    ia = 0; na = g.Nx - 1;
+  } else if (part == 2) {
+    ia = -g.H + 1; na = g.H - 1; ib = g.Nx - 1; nbcols = g.H;
+  }
+  const int ey = g.Ny + 2 * g.H - 2;
+  // narrow strips: 16 columns x 16 rows per block instead of 64 x 4 (a 64-wide block would be three-quarters empty)
+  dim3 b = (na + nbcols) >= 64 ? dim3(64, 4) : dim3(16, 16);
+  hipLaunchKernelGGL(k_compute_w, grid2(na + nbcols, ey, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                     m->f[GB25_W].d, ia, na, ib, nbcols);
   LAUNCHCHK();
   return GB25_OK;
 }
@@ -514,56 +492,65 @@ void tile_grid(const Grid& g, int* nbx, int* nb) {
   *nb = *nbx * nby * g.Nz;
 }
 
-gb25_status momentum_impl(gb25_model* m) {
+// Tile columns of the momentum kernel that read the slab's own columns only (u, v up to 3 columns, w up to 2 columns
+// away): [1, bx_hi).  Empty when the slab is too narrow.
+inline int interior_tile_columns_end(const Grid& g) {
+  const int nbx = (g.Nx + V2_TX - 1) / V2_TX;
+  return std::max(1, std::min(nbx - 1, (g.Nx - 3) / V2_TX));
+}
+inline bool tendencies_split(const gb25_model* m) {
+  return m->slab && m->split_tendencies && m->two_streams && m->kernel_gen >= 2 && interior_tile_columns_end(m->g) > 1;
+}
+
+// part: 0 = every tile column; 1 = the interior tile columns (a12: launched before the x-halo bundle has arrived);
+//       2 = the edge tile columns, then whatever follows the complete evaluation (the look-ahead's finish kernel).
+gb25_status momentum_impl(gb25_model* m, int part = 0) {
   const Grid& g = m->g;
   int nbx, nb;
-  m->ahead_uv_valid = m->ahead_baro_valid = false;   // look-aheads made from the previous tendencies are void
+  if (part != 2) m->ahead_uv_valid = m->ahead_baro_valid = false;   // look-aheads made from the previous tendencies are void
   if (m->kernel_gen >= 2) {
     Timed t(m, GB25_K_GU);   // the fused G_u + G_v kernel is accounted under the "gu" timer
     nbx = (g.Nx + V2_TX - 1) / V2_TX;
-    const int TY = m->tile_rows;
-    const int nby = (g.Ny + TY - 1) / TY;
+    constexpr int TYm = 4;   // rows (= waves) per block: 4 blocks per CU cover each other's barriers
+    const int nby = (g.Ny + TYm - 1) / TYm;
     const int kchunks = std::max(1, g.Nz / 12);
-    nb = nbx * nby * kchunks;
+    TileCols tc{nbx, nbx, 0, 0};
+    if (part) {
+      const int hi = interior_tile_columns_end(g);
+      if (part == 1) tc = TileCols{hi - 1, hi - 1, 1, 0};
+      else tc = TileCols{1 + nbx - hi, 1, 0, hi};
+    }
+    nb = tc.n * nby * kchunks;
     // waves/SIMD the register allocator is held to: 4 (128 VGPRs) in fp32; fp64 operands are register pairs,
     // so the Float64 build asks for 2 (256 VGPRs) instead of spilling
     constexpr int MW = sizeof(real) == 8 ? 2 : 4;
-    auto kern = TY == 4 ? (m->variant_b ? k_momentum_tendencies_v2<MW, 4> : k_momentum_tendencies_v2<2, 4>)
-                        : (m->variant_b ? k_momentum_tendencies_v2<MW, 8> : k_momentum_tendencies_v2<2, 8>);
-    if (m->momentum_v4) kern = k_momentum_tendencies_v4<MW, 8>;
-    if (m->momentum_v5) {
-      const bool ahead = m->ab2_ahead && !m->ptr_exposed && m->ab2_ahead != 2;   // GB25_AB2_AHEAD=2: tracers only
-      UvAhead nx{};
-      const real dt = (real)m->last_dt, chi = (real)m->cfg.chi;
-      if (ahead) {   // predicted parameters of the next ab2_step!: the clock's dt and the model's chi
-        nx.GmU = m->f[GB25_GM_U].d; nx.GmV = m->f[GB25_GM_V].d;
-        nx.un = m->ahead_uv[0].d; nx.vn = m->ahead_uv[1].d;
-        nx.P = m->uv_partials;
-        nx.dt = dt; nx.C1 = real(1.5) + chi; nx.C2 = real(0.5) + chi;
-        nx.plane2 = g.sx * g.sy_v;
-      }
-      auto k5 = TY == 4 ? (ahead ? k_momentum_tendencies_v5<MW, 4, true> : k_momentum_tendencies_v5<MW, 4, false>)
-                        : (ahead ? k_momentum_tendencies_v5<MW, 8, true> : k_momentum_tendencies_v5<MW, 8, false>);
-      hipLaunchKernelGGL(k5, dim3(nb), dim3(V2_TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                         m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, nbx, kchunks, nb,
-                         nx);
-      t.stop();   // the timer covers the tendency kernel alone
-      if (ahead) {
-        dim3 b(64, 4);
-        hipLaunchKernelGGL(k_ab2_velocities_finish, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->uv_partials, kchunks,
-                           nx.plane2, m->ahead_G[0].d, m->ahead_G[1].d, m->ahead_colsum[0].d, m->ahead_colsum[1].d);
-        m->ahead_uv_valid = true;
-        m->ahead_uv_dt = dt;
-        m->ahead_uv_chi = chi;
-      }
-      LAUNCHCHK();
-      return GB25_OK;
+    const bool ahead = m->ab2_ahead == 1 && !m->ptr_exposed;
+    UvAhead nx{};
+    const real dt = (real)m->last_dt, chi = (real)m->cfg.chi;
+    if (ahead) {   // predicted parameters of the next ab2_step!: the clock's dt and the model's chi
+      nx.GmU = m->f[GB25_GM_U].d; nx.GmV = m->f[GB25_GM_V].d;
+      nx.un = m->ahead_uv[0].d; nx.vn = m->ahead_uv[1].d;
+      nx.P = m->uv_partials;
+      nx.dt = dt; nx.C1 = real(1.5) + chi; nx.C2 = real(0.5) + chi;
+      nx.plane2 = g.sx * g.sy_v;
     }
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(V2_TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                       m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, nbx, kchunks, nb);
+    auto k5 = ahead ? k_momentum_tendencies_v5<MW, TYm, true> : k_momentum_tendencies_v5<MW, TYm, false>;
+    if (nb > 0)
+      hipLaunchKernelGGL(k5, dim3(nb), dim3(V2_TX, TYm), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                         m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, tc, kchunks, nb, nx);
+    t.stop();   // the timer covers the tendency kernel alone
+    if (ahead && part != 1) {
+      dim3 b(64, 4);
+      hipLaunchKernelGGL(k_ab2_velocities_finish, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->uv_partials, kchunks,
+                         nx.plane2, m->ahead_G[0].d, m->ahead_G[1].d, m->ahead_colsum[0].d, m->ahead_colsum[1].d);
+      m->ahead_uv_valid = true;
+      m->ahead_uv_dt = dt;
+      m->ahead_uv_chi = chi;
+    }
     LAUNCHCHK();
     return GB25_OK;
   }
+  if (part == 1) return GB25_OK;   // the direct-stencil kernels are not split: everything after the halos arrived
   tile_grid(g, &nbx, &nb);
   dim3 b(TX, TY);
   {
@@ -582,11 +569,11 @@ gb25_status momentum_impl(gb25_model* m) {
 gb25_status tracers_impl(gb25_model* m) {
   const Grid& g = m->g;
   int nbx, nb;
-  if (m->kernel_gen >= 2 && m->tracer_v3) {
+  if (m->kernel_gen >= 2) {
     Timed t(m, GB25_K_TRACERS);
     nbx = (g.Nx + V3_OUT - 1) / V3_OUT;
     const int nby = (g.Ny + 3) / 4;
-    const int kchunks = std::max(1, g.Nz / 12);
+    const int kchunks = std::max(1, g.Nz / 12);   // >= 12 levels per block: the z-carry start-up stays ~3 %
     nb = nbx * nby * kchunks;
     constexpr int TW = sizeof(real) == 8 ? 3 : 5;   // see MW in momentum_impl
     const bool ahead = m->ab2_ahead && !m->ptr_exposed;
@@ -597,40 +584,17 @@ gb25_status tracers_impl(gb25_model* m) {
       nx.dt = (real)m->last_dt;
       nx.C1 = real(1.5) + (real)m->cfg.chi; nx.C2 = real(0.5) + (real)m->cfg.chi;
     }
-    auto kern = m->variant_a == 6 ? k_tracer_tendencies_v3<6, false>
-                                  : (m->variant_a == 7 ? k_tracer_tendencies_v3<7, false>
-                                                       : (ahead ? k_tracer_tendencies_v3<TW, true>
-                                                                : k_tracer_tendencies_v3<TW, false>));
-    if (m->tracer_v3 == 5) {   // packed (T, S) pairs
-      kern = ahead ? k_tracer_tendencies_v5<TW, true> : k_tracer_tendencies_v5<TW, false>;
-      if (m->variant_a == 4) kern = ahead ? k_tracer_tendencies_v5<4, true> : k_tracer_tendencies_v5<4, false>;
-    }
-    const bool ahead_run = ahead && ((m->variant_a != 6 && m->variant_a != 7) || m->tracer_v3 == 5);
+    auto kern = ahead ? k_tracer_tendencies_v5<TW, true> : k_tracer_tendencies_v5<TW, false>;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64, 4), 0, m->stream, g, m->f[GB25_U].d,
                        m->f[GB25_V].d, m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d,
                        m->f[GB25_GN_S].d, nbx, kchunks, nb, nx);
     LAUNCHCHK();
-    m->ahead_valid = ahead_run;
+    m->ahead_valid = ahead;
     m->ahead_dt = nx.dt;
     m->ahead_chi = (real)m->cfg.chi;
     return GB25_OK;
   }
-  m->ahead_valid = false;   // only the v3 kernel looks ahead
-  if (m->kernel_gen >= 2) {
-    Timed t(m, GB25_K_TRACERS);
-    nbx = (g.Nx + V2_TX - 1) / V2_TX;
-    const int TY = m->tile_rows;
-    const int nby = (g.Ny + TY - 1) / TY;
-    const int kchunks = std::max(1, g.Nz / 12);   // >= 12 levels per block: the z-carry start-up stays ~3 %
-    nb = nbx * nby * kchunks;
-    auto kern = TY == 4 ? (m->variant_a ? k_tracer_tendencies_v2<true, 4> : k_tracer_tendencies_v2<false, 4>)
-                        : (m->variant_a ? k_tracer_tendencies_v2<true, 8> : k_tracer_tendencies_v2<false, 8>);
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(V2_TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                       m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d, m->f[GB25_GN_S].d, nbx,
-                       kchunks, nb);
-    LAUNCHCHK();
-    return GB25_OK;
-  }
+  m->ahead_valid = false;   // only the packed kernel looks ahead
   tile_grid(g, &nbx, &nb);
   Timed t(m, GB25_K_TRACERS);
   hipLaunchKernelGGL(k_tracer_tendencies, dim3(nb), dim3(TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
@@ -685,8 +649,8 @@ gb25_status ab2_tracers_impl(gb25_model* m, real dt, real chi) {
   if (aligned) {
     long n4 = n / 4;
     int blocks = (int)std::min<long>((n4 + 255) / 256, 256 * 16);
-    auto kern = m->variant_c ? k_ab2_tracers4<true> : k_ab2_tracers4<false>;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, m->stream, (real4*)T, (real4*)S, (const real4*)a,
+    // (nontemporal tendency reads: every byte of this stream is touched once per step)
+    hipLaunchKernelGGL(k_ab2_tracers4<true>, dim3(blocks), dim3(256), 0, m->stream, (real4*)T, (real4*)S, (const real4*)a,
                        (const real4*)bb, (const real4*)c, (const real4*)d, n4, dt, C1, C2);
   } else {
     int blocks = (int)std::min<long>((n + 255) / 256, 256 * 16);
@@ -714,7 +678,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     m->baro_inflight = false;
   }
   Timed t(m, GB25_K_BAROTROPIC);
-  const bool wide = m->cfg.nranks > 1;
+  const bool wide = m->slab;
   const real dtau = (real)m->dtau_frac * dt;
   dim3 b(64, 4);
   Baro bb;
@@ -749,11 +713,11 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
   bool finalize_after = false;
   if (m->baro_block > 1) {
     // temporally blocked: S substeps per launch on (64 x TY) tiles
-    const int S = std::min(m->baro_block, (int)BT_SMAX), TYb = m->baro_rows;
+    const int S = std::min(m->baro_block, (int)BT_SMAX);
+    constexpr int TYb = 16;
     dim3 gm((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX, (g.Ny + TYb - 1) / TYb);
-    void (*kern)(Grid, BaroMulti, real) = nullptr;
-    if (TYb == 16) kern = S <= 3 ? k_barotropic_multi<3, 16> : (S <= 5 ? k_barotropic_multi<5, 16> : k_barotropic_multi<7, 16>);
-    else kern = S <= 3 ? k_barotropic_multi<3, 32> : (S <= 5 ? k_barotropic_multi<5, 32> : k_barotropic_multi<7, 32>);
+    void (*kern)(Grid, BaroMulti, real) =
+        S <= 3 ? k_barotropic_multi<3, TYb> : (S <= 5 ? k_barotropic_multi<5, TYb> : k_barotropic_multi<7, TYb>);
     const int Sk = S <= 3 ? 3 : (S <= 5 ? 5 : 7);
     for (int s = 0; s < m->Ns; s += Sk) {
       BaroMulti bm;
@@ -819,7 +783,7 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
   {
     Timed t(m, GB25_K_CORRECTOR);
     dim3 b(64, 4);
-    const bool ext = m->cfg.nranks > 1;
+    const bool ext = m->slab;
     int i0 = ext ? -g.H : 0, ni = ext ? g.Nx + 2 * g.H : g.Nx, skip_from = INT_MAX, skip = 0;
     if (part == 1) {
       i0 = 0;
@@ -873,9 +837,6 @@ gb25_status ab2_step_impl(gb25_model* m, double dt, int euler) {
 // side stream and overlaps.  The phase order within each branch is the reference's (src/precompile.jl:31-42);
 // T and S are untouched between the two halo fills of the reference sequence, so they are filled once.
 gb25_status time_step_impl(gb25_model* m, int euler) {
-  if (m->cfg.nranks != 1)
-    return fail(m, GB25_ERR_STATE, "gb25_time_step on a slab of a %d-rank decomposition: drive gb25_time_step_stage",
-                m->cfg.nranks);
   gb25_status s;
   const double dt = m->last_dt;
   if (!m->two_streams) {
@@ -936,7 +897,7 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   // ---- join: the tendencies need w, u, v and the pressure differences, T, S
   HIPCHK(hipStreamWaitEvent(main, m->ev_join, 0));
   if ((s = momentum_impl(m))) return s;
-  if (m->baro_ahead && m->ahead_uv_valid && !m->use_graphs && !m->ptr_exposed) {
+  if (m->baro_ahead && m->ahead_uv_valid && !m->ptr_exposed) {
     // G.U, G.V of the next step exist now: its sub-cycle (latency-bound) runs on the side stream beside the tracer
     // tendency kernel (issue-bound), into the partner buffers
     HIPCHK(hipEventRecord(m->ev_mom, main));
@@ -963,10 +924,12 @@ gb25_status initialize_impl(gb25_model* m) {
 
 }  // namespace
 
+#include "slab_step.hpp"
+
 // =============================================================================================
 extern "C" {
 
-const char* gb25_version(void) { return sizeof(real) == 8 ? "gb25hip 0.1 (gfx950, Float64)" : "gb25hip 0.1 (gfx950, Float32)"; }
+const char* gb25_version(void) { return sizeof(real) == 8 ? "gb25hip 0.2 (gfx950, Float64)" : "gb25hip 0.2 (gfx950, Float32)"; }
 int32_t gb25_real_bytes(void) { return (int32_t)sizeof(real); }
 
 void gb25_default_config(gb25_config* c, int32_t Nx, int32_t Ny, int32_t Nz) {
@@ -977,6 +940,7 @@ void gb25_default_config(gb25_config* c, int32_t Nx, int32_t Ny, int32_t Nz) {
   c->lat_south = -80; c->lat_north = 80; c->lon_west = 0; c->lon_east = 360;
   c->depth = 4000; c->zexp_h = 30;
   c->g = 9.80665; c->Omega = 7.292115e-5; c->radius = 6371e3; c->rho0 = 1020.0;
+  c->slab_mode = 0; c->grid_type = GB25_GRID_LAT_LON;
 }
 
 gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
@@ -989,7 +953,10 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
       cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks || cfg->Nx % cfg->nranks != 0)
     return fail(m, GB25_ERR_INVALID_ARGUMENT,
                 "invalid configuration: need Nx,Ny >= 8, Nz >= 4, halo >= 4, 1 <= substeps <= 4096, Nx %% nranks == 0");
+  if (cfg->slab_mode < 0 || cfg->slab_mode > 1)
+    return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab_mode must be 0 (x halos by exchange iff nranks > 1) or 1 (always)");
   m->Nx = cfg->Nx / cfg->nranks;
+  m->slab = cfg->nranks > 1 || cfg->slab_mode == 1;
   if (m->Nx < cfg->halo) return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab narrower than the halo");
   {
     // the kernels address a parent array with 32-bit element indices and 32-bit byte offsets (buffer addressing)
@@ -1012,28 +979,13 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_baro, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_mom, hipEventDisableTiming));
-  if (const char* e = getenv("GB25_TWO_STREAMS")) m->two_streams = atoi(e) != 0;
   m->stream = m->own_stream;
   m->last_dt = cfg->dt;
-  if (const char* e = getenv("GB25_KERNELS")) m->kernel_gen = (strcmp(e, "v1") == 0) ? 1 : 2;
-  if (const char* e = getenv("GB25_TRACER_V3")) m->tracer_v3 = atoi(e);
-  if (const char* e = getenv("GB25_MOMENTUM_V4")) m->momentum_v4 = atoi(e);
-  if (const char* e = getenv("GB25_MOMENTUM_V5")) m->momentum_v5 = atoi(e);
-  if (const char* e = getenv("GB25_BARO_BLOCK")) m->baro_block = atoi(e);
-  if (const char* e = getenv("GB25_BARO_ROWS")) m->baro_rows = (atoi(e) == 32) ? 32 : 16;
-  if (const char* e = getenv("GB25_TILE_ROWS")) m->tile_rows = (atoi(e) == 4) ? 4 : 8;
-  if (const char* e = getenv("GB25_VARIANT_A")) m->variant_a = atoi(e);
-  if (const char* e = getenv("GB25_VARIANT_B")) m->variant_b = atoi(e);
-  if (const char* e = getenv("GB25_VARIANT_C")) m->variant_c = atoi(e);
-  if (const char* e = getenv("GB25_AB2_AHEAD")) m->ab2_ahead = atoi(e);
   // On launch-latency-bound grids the extra cross-stream hops of the sub-cycle look-ahead cost more than the
   // sub-cycle they hide (0.252 vs 0.262 ms/step at 360x180x24, 0.173 vs 0.185 at 128x64x8; +3.5 % at 1440x720x48).
   // A slab of a decomposition always uses it: there it also takes two exchanges off the critical path.
-  m->baro_ahead = (cfg->nranks > 1 || (long)cfg->Nx * cfg->Ny * cfg->Nz >= 8000000L) ? 1 : 0;
-  if (const char* e = getenv("GB25_BARO_AHEAD")) m->baro_ahead = atoi(e);
-  if (const char* e = getenv("GB25_FILL_FUSED")) m->fill_fused = atoi(e);
-  if (const char* e = getenv("GB25_LAZY_PHY")) m->phy_pinned = atoi(e) == 0;   // 0: store pHY' every step
-  if (const char* e = getenv("GB25_GRAPH")) m->use_graphs = atoi(e);
+  // (gb25_set_option changes any of these defaults; nothing is read from the environment.)
+  m->baro_ahead = (m->slab || (long)cfg->Nx * cfg->Ny * cfg->Nz >= 8000000L) ? 1 : 0;
   gb25_status s;
   if ((s = build_grid(m))) return s;
   if ((s = build_eos_tables(m))) return s;
@@ -1085,7 +1037,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   }
   if ((s = alloc_field(m, m->colsum[0], sx, m->f[GB25_BT_U].ny, 1))) return s;
   if ((s = alloc_field(m, m->colsum[1], sx, m->f[GB25_BT_V].ny, 1))) return s;
-  if (cfg->nranks > 1) {
+  if (m->slab) {
     m->W = m->Ns + 1;
     if (m->Nx < m->W)
       return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab width %d is narrower than the barotropic halo %d", m->Nx, m->W);
@@ -1116,11 +1068,8 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
 
 void gb25_destroy(gb25_model* m) {
   if (!m) return;
+  if (m->group) group_destroy(m->group);   // (the exchange context of every slab it holds)
   if (m->own_stream) hipStreamSynchronize(m->own_stream);
-  for (auto& e : m->graphs) {
-    hipGraphExecDestroy(e.exec);
-    hipGraphDestroy(e.graph);
-  }
   for (int id = 0; id < GB25_FIELD_COUNT; id++)
     if (!(id >= GB25_ETA_BAR && id <= GB25_V_BAR) && m->f[id].d) hipFree(m->f[id].d);
   if (m->bars) hipFree(m->bars);
@@ -1164,11 +1113,13 @@ const char* gb25_last_error_string(const gb25_model* m) { return m ? m->err.c_st
 
 gb25_status gb25_set_stream(gb25_model* m, void* s) {
   CHECK_MODEL(m);
+  if (m->group) return fail(m, GB25_ERR_STATE, "the slabs of an exchange context run on the context's own two streams");
   m->stream = (hipStream_t)s;  // NULL = HIP's default stream; ordering between streams is the caller's business
   return GB25_OK;
 }
 gb25_status gb25_use_own_stream(gb25_model* m) {
   CHECK_MODEL(m);
+  if (m->group) return GB25_OK;
   HIPCHK(hipStreamSynchronize(m->stream));
   m->stream = m->own_stream;
   return GB25_OK;
@@ -1177,6 +1128,7 @@ gb25_status gb25_synchronize(gb25_model* m) {
   CHECK_MODEL(m);
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(m->side_stream));   // the sub-cycle look-ahead may still be running there
+  if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));   // (a slab's runs on the second stream of its context)
   return GB25_OK;
 }
 
@@ -1197,7 +1149,10 @@ static gb25_status copy_field(gb25_model* m, gb25_field id, real* host, int incl
   if (to_device && (id == GB25_U || id == GB25_V)) m->colsum_valid = false;  // cached column integrals are stale
   Field& F = m->f[id];
   HIPCHK(hipStreamSynchronize(m->stream));
-  if (to_device) HIPCHK(hipStreamSynchronize(m->side_stream));   // a look-ahead may still be reading the old values
+  if (to_device) {   // a look-ahead may still be reading the old values
+    HIPCHK(hipStreamSynchronize(m->side_stream));
+    if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
+  }
   if (include_halos) {
     if (to_device) HIPCHK(hipMemcpy(F.d, host, F.elems() * sizeof(real), hipMemcpyHostToDevice));
     else HIPCHK(hipMemcpy(host, F.d, F.elems() * sizeof(real), hipMemcpyDeviceToHost));
@@ -1243,7 +1198,10 @@ static gb25_status mirror_velocities(gb25_model* m) {   // u and v alternate bet
   return GB25_OK;
 }
 gb25_status gb25_set_field(gb25_model* m, gb25_field f, const void* host, int include_halos) {
-  gb25_status s = copy_field(m, f, static_cast<real*>(const_cast<void*>(host)), include_halos, true);
+  CHECK_MODEL(m);
+  gb25_status s = collective_guard(m, 1, (unsigned)f, 0.0);
+  if (s) return s;
+  s = copy_field(m, f, static_cast<real*>(const_cast<void*>(host)), include_halos, true);
   if (s == GB25_OK && f == GB25_PHY) {
     m->phy_stale = false;
     s = widen_phy(m);
@@ -1269,6 +1227,7 @@ gb25_status gb25_get_field(gb25_model* m, gb25_field f, void* host_, int include
 }
 gb25_status gb25_field_device_ptr(gb25_model* m, gb25_field id, void** dev) {
   if (!m || id < 0 || id >= GB25_FIELD_COUNT || !dev) return GB25_ERR_INVALID_ARGUMENT;
+  if (gb25_status s = collective_guard(m, 2, (unsigned)id, 0.0)) return s;
   if (id == GB25_U || id == GB25_V || id == GB25_T || id == GB25_S || (id >= GB25_GN_U && id <= GB25_GM_S) ||
       (id >= GB25_ETA && id <= GB25_GN_BT_V)) {
     // the host can now write prognostic fields or their tendencies behind our back: no more look-ahead for this
@@ -1304,6 +1263,7 @@ gb25_status gb25_get_substepping(const gb25_model* m, int32_t* n, double* frac, 
 
 gb25_status gb25_set_baroclinic_instability(gb25_model* m) {
   CHECK_MODEL(m);
+  if (gb25_status s = collective_guard(m, 3, 0, 0.0)) return s;
   const Grid& g = m->g;
   hipLaunchKernelGGL(k_set_baroclinic_instability, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, m->stream, g,
                      m->f[GB25_T].d, m->f[GB25_S].d);
@@ -1320,14 +1280,18 @@ gb25_status gb25_get_clock(const gb25_model* m, double* time, int64_t* it, doubl
 }
 gb25_status gb25_set_dt(gb25_model* m, double dt) {
   CHECK_MODEL(m);
+  if (gb25_status s = collective_guard(m, 4, 0, dt)) return s;
   m->last_dt = dt;
   return GB25_OK;
 }
 
 gb25_status gb25_initialize(gb25_model* m) { CHECK_MODEL(m); return initialize_impl(m); }
 gb25_status gb25_mask_immersed_fields(gb25_model* m) { CHECK_MODEL(m); return GB25_OK; }
-gb25_status gb25_fill_halo_regions(gb25_model* m) { CHECK_MODEL(m); return fill_halos_impl(m, true); }
-gb25_status gb25_fill_halo_regions_local(gb25_model* m) { CHECK_MODEL(m); return fill_halos_impl(m, false); }
+gb25_status gb25_fill_halo_regions(gb25_model* m) {
+  CHECK_MODEL(m);
+  if (m->slab) return fail(m, GB25_ERR_STATE, "phase-by-phase driving is for single-domain models: a slab's x halos come from the exchange inside gb25_first_time_step / gb25_time_step / gb25_loop");
+  return fill_halos_impl(m, true);
+}
 gb25_status gb25_compute_auxiliaries(gb25_model* m) {
   CHECK_MODEL(m);
   gb25_status s = compute_w_impl(m);
@@ -1344,7 +1308,7 @@ gb25_status gb25_compute_tendencies(gb25_model* m) {
 }
 gb25_status gb25_ab2_step(gb25_model* m, double dt, int euler) {
   CHECK_MODEL(m);
-  if (m->cfg.nranks != 1) return fail(m, GB25_ERR_STATE, "gb25_ab2_step needs the staged path on a multi-rank slab");
+  if (m->slab) return fail(m, GB25_ERR_STATE, "gb25_ab2_step: phase-by-phase driving is for single-domain models");
   return ab2_step_impl(m, dt, euler);
 }
 gb25_status gb25_correct_velocities_and_cache_previous_tendencies(gb25_model* m, double) {
@@ -1353,341 +1317,150 @@ gb25_status gb25_correct_velocities_and_cache_previous_tendencies(gb25_model* m,
 }
 gb25_status gb25_update_state(gb25_model* m) {
   CHECK_MODEL(m);
-  if (m->cfg.nranks != 1) return fail(m, GB25_ERR_STATE, "gb25_update_state needs gb25_update_state_local + exchange");
+  if (m->slab) return fail(m, GB25_ERR_STATE, "gb25_update_state: phase-by-phase driving is for single-domain models");
   return update_state_impl(m);
 }
-gb25_status gb25_update_state_local(gb25_model* m) {
+// ---- options: every switch of the library is a per-model option; nothing is read from the environment
+gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
   CHECK_MODEL(m);
-  gb25_status s;
-  if ((s = fill_halos_impl(m, false, m->cfg.nranks > 1))) return s;
-  if ((s = compute_w_impl(m))) return s;
-  if ((s = compute_p_impl(m))) return s;
-  if ((s = momentum_impl(m))) return s;
-  return tracers_impl(m);
-}
-
-// ---- HIP-graph replay of the AB2 time step (opt-in: GB25_GRAPH=1) --------------------------------
-// A step is ~25 dependent launches; on the small configurations (128x64x8, 360x180x24) their dispatch latency, not
-// the kernels, sets the step time.  With GB25_GRAPH=1 the step is captured once per host state (the pointer
-// exchanges make the state alternate with period 2) and replayed with one hipGraphLaunch; the host-side transition
-// (pointer names, flags, clock) is re-applied from the recorded `post` state.  Bitwise identical to eager launches
-// (tests/test_gpu_parity.py).  It is OFF by default because it does not pay on this stack: measured on MI355X /
-// ROCm 7.2 (profiles/r01_tuning_log.md) 0.220 vs 0.201 ms/step at 128x64x8 with the two-stream step, 0.190 vs 0.191
-// single-stream, 0.320 vs 0.307 at 360x180x24 -- the ~8 us per dependent kernel are spent on the device side of the
-// dispatch, which a graph does not remove; only fewer kernels would.
-static HostState host_state(const gb25_model* m) {
-  HostState h;
-  for (int q = 0; q < 8; q++) h.ptr[q] = m->f[GB25_GN_U + q].d;
-  h.ptr[8] = m->f[GB25_T].d; h.ptr[9] = m->f[GB25_S].d;
-  h.ptr[10] = m->ahead[0].d; h.ptr[11] = m->ahead[1].d;
-  for (int q = 0; q < 2; q++) {
-    h.ptr[12 + q] = m->colsum[q].d;    h.ptr[14 + q] = m->ahead_colsum[q].d;
-    h.ptr[16 + q] = m->f[GB25_U + q].d; h.ptr[18 + q] = m->ahead_uv[q].d;
-    h.ptr[20 + q] = m->f[GB25_GN_BT_U + q].d; h.ptr[22 + q] = m->ahead_G[q].d;
+  if (gb25_status s = collective_guard(m, 5, (unsigned)opt, (double)v)) return s;
+  // a switch may change which buffers carry the next time level: whatever is in flight finishes, every look-ahead is void
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(m->side_stream));
+  if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
+  m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+  switch (opt) {
+    case GB25_OPT_KERNELS:
+      if (v != 1 && v != 2) return fail(m, GB25_ERR_INVALID_ARGUMENT, "GB25_OPT_KERNELS: 1 (direct stencil) or 2 (default)");
+      m->kernel_gen = v;
+      return GB25_OK;
+    case GB25_OPT_AB2_LOOKAHEAD:
+      if (v < 0 || v > 2) return fail(m, GB25_ERR_INVALID_ARGUMENT, "GB25_OPT_AB2_LOOKAHEAD: 0, 1 or 2 (tracers only)");
+      m->ab2_ahead = v;
+      return GB25_OK;
+    case GB25_OPT_SUBCYCLE_LOOKAHEAD: m->baro_ahead = v != 0; return GB25_OK;
+    case GB25_OPT_SUBCYCLE_BLOCK:
+      if (v != 1 && v != 3 && v != 5 && v != 7)
+        return fail(m, GB25_ERR_INVALID_ARGUMENT, "GB25_OPT_SUBCYCLE_BLOCK: 1, 3, 5 or 7 substeps per launch");
+      m->baro_block = v;
+      return GB25_OK;
+    case GB25_OPT_FILL_FUSED: m->fill_fused = v != 0; return GB25_OK;
+    case GB25_OPT_TWO_STREAMS: m->two_streams = v != 0; return GB25_OK;
+    case GB25_OPT_STORE_PRESSURE: m->phy_pinned = v != 0; return GB25_OK;
+    case GB25_OPT_SPLIT_TENDENCIES: m->split_tendencies = v != 0; return GB25_OK;
+    default: return fail(m, GB25_ERR_INVALID_ARGUMENT, "unknown option %d", (int)opt);
   }
-  h.ahead_valid = m->ahead_valid; h.colsum_valid = m->colsum_valid; h.ahead_uv_valid = m->ahead_uv_valid;
-  h.ahead_dt = m->ahead_dt; h.ahead_chi = m->ahead_chi;
-  h.ahead_uv_dt = m->ahead_uv_dt; h.ahead_uv_chi = m->ahead_uv_chi;
-  return h;
 }
-static void set_host_state(gb25_model* m, const HostState& h) {
-  for (int q = 0; q < 8; q++) m->f[GB25_GN_U + q].d = h.ptr[q];
-  m->f[GB25_T].d = h.ptr[8]; m->f[GB25_S].d = h.ptr[9];
-  m->ahead[0].d = h.ptr[10]; m->ahead[1].d = h.ptr[11];
-  for (int q = 0; q < 2; q++) {
-    m->colsum[q].d = h.ptr[12 + q];    m->ahead_colsum[q].d = h.ptr[14 + q];
-    m->f[GB25_U + q].d = h.ptr[16 + q]; m->ahead_uv[q].d = h.ptr[18 + q];
-    m->f[GB25_GN_BT_U + q].d = h.ptr[20 + q]; m->ahead_G[q].d = h.ptr[22 + q];
+gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
+  if (!m || !v) return GB25_ERR_INVALID_ARGUMENT;
+  switch (opt) {
+    case GB25_OPT_KERNELS: *v = m->kernel_gen; break;
+    case GB25_OPT_AB2_LOOKAHEAD: *v = m->ab2_ahead; break;
+    case GB25_OPT_SUBCYCLE_LOOKAHEAD: *v = m->baro_ahead; break;
+    case GB25_OPT_SUBCYCLE_BLOCK: *v = m->baro_block; break;
+    case GB25_OPT_FILL_FUSED: *v = m->fill_fused; break;
+    case GB25_OPT_TWO_STREAMS: *v = m->two_streams; break;
+    case GB25_OPT_STORE_PRESSURE: *v = m->phy_pinned; break;
+    case GB25_OPT_SPLIT_TENDENCIES: *v = m->split_tendencies; break;
+    default: return GB25_ERR_INVALID_ARGUMENT;
   }
-  m->ahead_valid = h.ahead_valid; m->colsum_valid = h.colsum_valid; m->ahead_uv_valid = h.ahead_uv_valid;
-  m->ahead_dt = h.ahead_dt; m->ahead_chi = h.ahead_chi;
-  m->ahead_uv_dt = h.ahead_uv_dt; m->ahead_uv_chi = h.ahead_uv_chi;
-}
-static void drop_graphs(gb25_model* m) {
-  for (auto& e : m->graphs) {
-    hipGraphExecDestroy(e.exec);
-    hipGraphDestroy(e.graph);
-  }
-  m->graphs.clear();
-}
-static gb25_status step_with_graph(gb25_model* m) {
-  if (!m->use_graphs || m->profile || m->cfg.nranks != 1 || m->stream == nullptr)
-    return time_step_impl(m, 0);
-  const HostState pre = host_state(m);
-  const double dt = m->last_dt;
-  StepGraph* hit = nullptr;
-  for (auto& e : m->graphs)
-    if (e.dt == dt && e.stream == m->stream && e.pre == pre) hit = &e;
-  if (!hit) {
-    bool again = false;
-    for (auto& h : m->seen) again |= (h == pre);
-    if (!again) {   // one-off states (after a host write, a changed dt, ...) are not worth a capture
-      if (m->seen.size() >= 8) m->seen.clear();
-      m->seen.push_back(pre);
-      return time_step_impl(m, 0);
-    }
-    const double time0 = m->time;
-    const int64_t it0 = m->iteration;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    bool ok = hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-    gb25_status st = ok ? time_step_impl(m, 0) : GB25_ERR_HIP;
-    if (ok) ok = (hipStreamEndCapture(m->stream, &graph) == hipSuccess) && st == GB25_OK && graph != nullptr;
-    const HostState post = host_state(m);
-    set_host_state(m, pre);   // nothing has run yet: back to the state the graph starts from
-    m->time = time0;
-    m->iteration = it0;
-    if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-    if (!ok) {   // capture is a convenience, never a requirement
-      if (graph) hipGraphDestroy(graph);
-      (void)hipGetLastError();
-      m->use_graphs = 0;
-      return time_step_impl(m, 0);
-    }
-    if (m->graphs.size() >= 8) drop_graphs(m);   // states cycle with period 2; more than a few means churn
-    m->graphs.push_back({pre, post, dt, m->stream, exec, graph});
-    hit = &m->graphs.back();
-  }
-  HIPCHK(hipGraphLaunch(hit->exec, m->stream));
-  set_host_state(m, hit->post);
-  m->time += dt;
-  m->iteration += 1;
   return GB25_OK;
 }
 
+// ---- exchange context of a decomposed model ----------------------------------------------------------------------
+gb25_status gb25_comm_unique_id(void* id_out) {
+  if (!id_out) return GB25_ERR_INVALID_ARGUMENT;
+  static_assert(sizeof(ncclUniqueId) == GB25_UNIQUE_ID_BYTES, "gb25.h: GB25_UNIQUE_ID_BYTES");
+  if (!rccl().load()) return GB25_ERR_COMM;
+  ncclUniqueId id;
+  if (rccl().GetUniqueId(&id) != ncclSuccess) return GB25_ERR_COMM;
+  memcpy(id_out, &id, sizeof id);
+  return GB25_OK;
+}
+gb25_status gb25_comm_init_rccl(gb25_model* m, const void* unique_id) {
+  CHECK_MODEL(m);
+  if (!unique_id) return GB25_ERR_INVALID_ARGUMENT;
+  if (!m->slab) return fail(m, GB25_ERR_STATE, "a single periodic domain (nranks = 1, slab_mode = 0) has nothing to exchange");
+  if (!rccl().load()) return fail(m, GB25_ERR_COMM, "%s", rccl().error.c_str());
+  HIPCHK(hipSetDevice(m->cfg.device));
+  RcclTransport* tr = new RcclTransport();
+  tr->rank = m->cfg.rank;
+  tr->nranks = m->cfg.nranks;
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof id);
+  ncclResult_t r = rccl().CommInitRank(&tr->comm, tr->nranks, id, tr->rank);
+  if (r != ncclSuccess) {
+    tr->comm = nullptr;
+    delete tr;
+    return fail(m, GB25_ERR_COMM, "ncclCommInitRank(rank %d of %d) failed: %s", m->cfg.rank, m->cfg.nranks,
+                rccl().GetErrorString(r));
+  }
+  gb25_model* one[1] = {m};
+  return group_create(one, 1, tr);
+}
+gb25_status gb25_comm_init_callback(gb25_model* m, gb25_exchange_fn fn, void* user) {
+  CHECK_MODEL(m);
+  if (!fn) return GB25_ERR_INVALID_ARGUMENT;
+  CallbackTransport* tr = new CallbackTransport();
+  tr->fn = fn;
+  tr->user = user;
+  gb25_model* one[1] = {m};
+  return group_create(one, 1, tr);
+}
+gb25_status gb25_comm_init_local(gb25_model* const* slabs, int32_t n) {
+  if (!slabs || n < 1 || !slabs[0]) return GB25_ERR_INVALID_ARGUMENT;
+  gb25_model* m = slabs[0];
+  for (int s = 0; s < n; s++) {
+    if (!slabs[s]) return GB25_ERR_INVALID_ARGUMENT;
+    const gb25_config &a = slabs[s]->cfg, &b = m->cfg;
+    if (a.nranks != n || a.rank != s || a.device != b.device || a.Nx != b.Nx || a.Ny != b.Ny || a.Nz != b.Nz ||
+        a.halo != b.halo || a.substeps != b.substeps)
+      return fail(m, GB25_ERR_INVALID_ARGUMENT,
+                  "gb25_comm_init_local wants the %d slabs of ONE decomposition in rank order on one device (slab %d does "
+                  "not fit)", n, s);
+  }
+  return group_create(slabs, n, new LocalRingTransport());
+}
+gb25_status gb25_comm_finalize(gb25_model* m) {
+  CHECK_MODEL(m);
+  if (m->group) group_destroy(m->group);
+  return GB25_OK;
+}
+
+static gb25_status need_group(gb25_model* m, const char* what) {
+  if (m->group) return GB25_OK;
+  return fail(m, GB25_ERR_STATE,
+              "%s on a slab of a decomposition needs an exchange context first: gb25_comm_init_rccl (one process per GPU), "
+              "gb25_comm_init_local (all slabs in this process) or gb25_comm_init_callback", what);
+}
+
+// ---- composites: GordonBell25.first_time_step!/time_step!/loop! (src/timestepping_utils.jl:21-45) ----------------------
+// On a slab these step every slab of the exchange context in lock-step (one slab per process with RCCL).
 gb25_status gb25_first_time_step(gb25_model* m) {
   CHECK_MODEL(m);
   gb25_status s;
+  if (m->slab) {
+    if ((s = need_group(m, "gb25_first_time_step"))) return s;
+    GroupOps ops(*m->group);
+    return sequence_first_time_step(ops, m->group->lookahead_in_flight);
+  }
   if ((s = initialize_impl(m))) return s;
   if ((s = update_state_impl(m))) return s;
   return time_step_impl(m, 1);
 }
-gb25_status gb25_time_step(gb25_model* m) { CHECK_MODEL(m); return step_with_graph(m); }
+gb25_status gb25_time_step(gb25_model* m) { return gb25_loop(m, 1); }
 gb25_status gb25_loop(gb25_model* m, int32_t n) {
   CHECK_MODEL(m);
-  for (int s = 0; s < n; s++) {
-    gb25_status st = step_with_graph(m);
-    if (st) return st;
-  }
-  return GB25_OK;
-}
-
-// ---- x-slab exchange -------------------------------------------------------------------------
-// group 0: H columns of u, v, T, S (all parent rows) and of eta, U, V -> the neighbour's x halo.
-// group 1: W columns of eta, U, V, G.U, G.V -> the neighbour's wide barotropic halo.
-struct Piece {
-  real* src;      // array that is packed from (canonical layout)
-  real* dst;      // array that is unpacked into
-  int src_sx, src_xo, dst_sx, dst_xo;
-  long rows;
-};
-// groups 3 and 4 are groups 1 and 2 of the sub-cycle LOOK-AHEAD: G.U, G.V come from the momentum look-ahead's partner
-// buffers, the new eta, U, V live in theirs
-static void group_pieces(gb25_model* m, int group, std::vector<Piece>& out, int* ncols) {
-  const int H = m->cfg.halo, sx = m->Nx + 2 * H;
-  if (group == 0 || group == 2 || group == 4) {
-    *ncols = H;
-    if (group == 0) {
-      for (int id : {GB25_U, GB25_V, GB25_T, GB25_S}) {
-        Field& F = m->f[id];
-        out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
-      }
-    } else {
-      for (int q = 0; q < 3; q++) {
-        Field& F = group == 2 ? m->f[GB25_ETA + q] : m->ahead_eta[q];
-        out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
-      }
-    }
-  } else {
-    *ncols = m->W;
-    const int wsx = m->Nx + 2 * m->W;
-    for (int q = 0; q < 3; q++) {
-      Field& F = m->f[GB25_ETA + q];
-      out.push_back({F.d, m->wide[0][q].d, sx, H, wsx, m->W, (long)F.ny});
-    }
-    for (int q = 0; q < 2; q++) {
-      Field& F = group == 1 ? m->f[GB25_GN_BT_U + q] : m->ahead_G[q];
-      out.push_back({F.d, m->wideG[q].d, sx, H, wsx, m->W, (long)F.ny});
-    }
-  }
-}
-gb25_status gb25_halo_buffer_elems(const gb25_model* m, int group, int64_t* n) {
-  if (!m || !n || group < 0 || group > 4) return GB25_ERR_INVALID_ARGUMENT;
-  if (m->cfg.nranks == 1) { *n = 0; return GB25_OK; }
-  std::vector<Piece> ps;
-  int nc = 0;
-  group_pieces(const_cast<gb25_model*>(m), group, ps, &nc);
-  int64_t t = 0;
-  for (auto& p : ps) t += p.rows * nc;
-  *n = t;
-  return GB25_OK;
-}
-// side_mask: bit 0 = west, bit 1 = east; buf[side] = that side's contiguous device buffer
-static gb25_status pack_unpack(gb25_model* m, int group, int side_mask, real* const buf[2], bool pack) {
-  if (!m || group < 0 || group > 4 || !(side_mask & 3)) return GB25_ERR_INVALID_ARGUMENT;
-  if (m->cfg.nranks == 1) return fail(m, GB25_ERR_STATE, "halo pack/unpack on a single-slab model");
-  std::vector<Piece> ps;
-  int nc = 0;
-  group_pieces(m, group, ps, &nc);
-  ColumnPieces P{};
-  P.ncols = nc;
-  long max_n = 0;
-  for (int side = 0; side < 2; side++) {
-    if (!(side_mask & (1 << side))) continue;
-    if (!buf[side]) return GB25_ERR_INVALID_ARGUMENT;
-    size_t off = 0;
-    for (auto& p : ps) {
-      const int f = P.n++;
-      P.rows[f] = p.rows;
-      P.buf[f] = buf[side] + off;
-      if (pack) {   // west side: interior columns [0, nc); east side: [Nx-nc, Nx)
-        P.arr[f] = p.src; P.sx[f] = p.src_sx; P.i0[f] = p.src_xo + (side == 0 ? 0 : m->Nx - nc);
-      } else {      // west halo: columns [-nc, 0); east halo: [Nx, Nx+nc)
-        P.arr[f] = p.dst; P.sx[f] = p.dst_sx; P.i0[f] = p.dst_xo + (side == 0 ? -nc : m->Nx);
-      }
-      off += (size_t)p.rows * nc;
-      max_n = std::max(max_n, p.rows * nc);
-    }
-  }
-  dim3 gr((unsigned)((max_n + 255) / 256), (unsigned)P.n);
-  if (pack) hipLaunchKernelGGL(k_move_columns<true>, gr, dim3(256), 0, m->stream, P);
-  else hipLaunchKernelGGL(k_move_columns<false>, gr, dim3(256), 0, m->stream, P);
-  LAUNCHCHK();
-  return GB25_OK;
-}
-gb25_status gb25_halo_pack(gb25_model* m, int group, int side, void* buf) {
-  if (side < 0 || side > 1) return GB25_ERR_INVALID_ARGUMENT;
-  real* b[2] = {nullptr, nullptr};
-  b[side] = static_cast<real*>(buf);
-  return pack_unpack(m, group, 1 << side, b, true);
-}
-gb25_status gb25_halo_unpack(gb25_model* m, int group, int side, const void* buf) {
-  if (side < 0 || side > 1) return GB25_ERR_INVALID_ARGUMENT;
-  real* b[2] = {nullptr, nullptr};
-  b[side] = static_cast<real*>(const_cast<void*>(buf));
-  return pack_unpack(m, group, 1 << side, b, false);
-}
-gb25_status gb25_halo_pack_both(gb25_model* m, int group, void* west_buf, void* east_buf) {
-  real* b[2] = {static_cast<real*>(west_buf), static_cast<real*>(east_buf)};
-  return pack_unpack(m, group, 3, b, true);
-}
-gb25_status gb25_halo_unpack_both(gb25_model* m, int group, const void* west_buf, const void* east_buf) {
-  real* b[2] = {static_cast<real*>(const_cast<void*>(west_buf)), static_cast<real*>(const_cast<void*>(east_buf))};
-  return pack_unpack(m, group, 3, b, false);
-}
-
-// The time step of one slab, cut at its two exchange points (see include/gb25.h).
-gb25_status gb25_time_step_stage(gb25_model* m, int stage, int euler) {
-  CHECK_MODEL(m);
-  if (m->cfg.nranks == 1) return fail(m, GB25_ERR_STATE, "gb25_time_step_stage on a single-slab model");
-  const Grid& g = m->g;
-  gb25_status s;
-  const double dt = m->last_dt;
-  const real chi = euler ? -real(0.5) : (real)m->cfg.chi;
-  if (stage == 0) {
-    // AB2 update of u,v,T,S + barotropic forcing, then the y/z boundary layers of the 3-D bundle so that its packed
-    // x columns (group 0) can travel WHILE the sub-cycle runs; the host also exchanges group 1 now
-    const bool uv_adopted = m->ahead_uv_valid && (real)dt == m->ahead_uv_dt && chi == m->ahead_uv_chi;
-    m->baro_adopted = uv_adopted && m->ahead_baro_valid;
-    m->ahead_baro_valid = false;
-    if ((s = ab2_local_impl(m, (real)dt, chi))) return s;
-    if (m->baro_adopted) {
-      // the sub-cycle of this step, its wide-halo exchange and the exchange of the new eta, U, V columns all ran
-      // beside the last tracer kernel (stage 5): adopt the results, stages 1 and groups 1, 2 are skipped
-      for (int q = 0; q < 3; q++) {
-        std::swap(m->f[GB25_ETA + q].d, m->ahead_eta[q].d);
-        std::swap(m->f[GB25_ETA_BAR + q].d, m->ahead_bar[q].d);
-      }
-      std::swap(m->bars, m->bars_ahead);
-      m->time += dt;
-      m->iteration += 1;
-    }
-    if ((s = fill_halos_impl(m, false, false, 1))) return s;
-    if (m->two_streams) {
-      // T, S of the slab's own columns are final from here on: their pressure (fp64-bound) runs on the side stream
-      // beside the exchanges and the sub-cycle; the strips next to the x halos follow in stage 2.  The first x
-      // difference of this pass reads a stale halo column and is redone by the west strip.
-      HIPCHK(hipEventRecord(m->ev_fork, m->stream));
-      HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
-      hipStream_t main = m->stream;
-      m->stream = m->side_stream;
-      s = compute_p_impl(m, 0, g.Nx - 1, 0, -1, true);
-      m->stream = main;
-      if (s) return s;
-      HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
-    }
+  if (m->slab) {
+    if (gb25_status s = need_group(m, "gb25_loop")) return s;
+    GroupOps ops(*m->group);
+    for (int it = 0; it < n; it++)
+      if (gb25_status s = sequence_time_step(ops, 0, m->group->lookahead_in_flight)) return s;
     return GB25_OK;
-  } else if (stage == 1 || stage == 5) {
-    // stage 1: group 1 has been unpacked into the wide halos: copy the interiors, sub-cycle, publish.
-    // stage 5: the same for the NEXT step (look-ahead): group 3 has been unpacked, G.U, G.V come from the momentum
-    //          look-ahead, the results go to the partner buffers of eta, U, V and of the filtered state.
-    const bool ahead = stage == 5;
-    if (ahead && !m->ahead_uv_valid) return fail(m, GB25_ERR_STATE, "stage 5 without a velocity look-ahead");
-    if (!ahead && m->baro_adopted) return fail(m, GB25_ERR_STATE, "stage 1 after stage 0 adopted the sub-cycle");
-    std::vector<Piece> ps;
-    int nc = 0;
-    group_pieces(m, ahead ? 3 : 1, ps, &nc);
-    {
-      InteriorCopies C{};
-      int rmax = 0;
-      for (auto& p : ps) {
-        const int q = C.n++;
-        C.dst[q] = p.dst; C.dsx[q] = p.dst_sx; C.dxo[q] = p.dst_xo;
-        C.src[q] = p.src; C.ssx[q] = p.src_sx; C.sxo[q] = p.src_xo; C.rows[q] = (int)p.rows;
-        rmax = std::max(rmax, (int)p.rows);
-      }
-      hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, rmax, C.n), dim3(256), 0, m->stream, C,
-                         g.Nx);
-    }
-    LAUNCHCHK();
-    if (ahead) {
-      if ((s = barotropic_impl(m, m->ahead_uv_dt, true))) return s;
-      Halo2 h2;
-      for (int q = 0; q < 3; q++) { h2.p[q] = m->ahead_eta[q].d; h2.is_v[q] = q == 2; }
-      h2.n = 3;
-      if ((s = fill_halos_impl(m, false, false, 2, 3, nullptr, true, &h2))) return s;   // their x columns: group 4
-      m->ahead_baro_valid = true;
-      return GB25_OK;
-    }
-    if ((s = barotropic_impl(m, (real)dt))) return s;
-    m->time += dt;
-    m->iteration += 1;
-    // y layer of the new eta, U, V; their x columns are group 2
-    return fill_halos_impl(m, false, false, 2);
-  } else if (stage == 2) {
-    // the barotropic corrector on the slab's own columns: needs nothing from the neighbours, so it runs while
-    // groups 2 and 0 are still travelling
-    return corrector_impl(m, true, 1);
-  } else if (stage == 3) {
-    // groups 2 and 0 have been unpacked: corrector on the x-halo columns, then update_state without any
-    // further exchange (y/z layers re-filled over the extended x range; w and p recomputed in the halos)
-    if ((s = corrector_impl(m, true, 2))) return s;
-    // the interior pressure pass of stage 0 must be over before the fills touch T, S and before the west strip
-    // rewrites column 0 (it has been for a while: the exchanges and the sub-cycle ran in between)
-    if (m->two_streams) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
-    if ((s = fill_halos_impl(m, false, true))) return s;
-    if (m->two_streams) {   // the two pressure strips run beside w (side stream)
-      hipStream_t main = m->stream;
-      HIPCHK(hipEventRecord(m->ev_fork, main));
-      HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
-      m->stream = m->side_stream;
-      s = compute_p_impl(m, -g.H + 1, 0, g.Nx, g.Nx + g.H - 2, true);   // west strip (redoes column 0) + east strip
-      m->stream = main;
-      if (s) return s;
-      HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
-    }
-    if ((s = compute_w_impl(m))) return s;
-    if (m->two_streams) {
-      HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
-    } else {
-      if ((s = compute_p_impl(m))) return s;
-    }
-    return momentum_impl(m);
-  } else if (stage == 4) {
-    // the tracer tendencies; the host runs the look-ahead of the next sub-cycle (groups 3, 4 and stage 5) beside them
-    return tracers_impl(m);
   }
-  return fail(m, GB25_ERR_INVALID_ARGUMENT, "stage must be 0 .. 5");
+  for (int it = 0; it < n; it++)
+    if (gb25_status s = time_step_impl(m, 0)) return s;
+  return GB25_OK;
 }
 
 gb25_status gb25_lookahead_state(const gb25_model* m, int32_t* velocities_ready, int32_t* subcycle_adopted) {
@@ -1695,6 +1468,26 @@ gb25_status gb25_lookahead_state(const gb25_model* m, int32_t* velocities_ready,
   if (velocities_ready) *velocities_ready = (m->ahead_uv_valid && m->baro_ahead && !m->ptr_exposed) ? 1 : 0;
   if (subcycle_adopted) *subcycle_adopted = m->baro_adopted ? 1 : 0;
   return GB25_OK;
+}
+
+// The order of operations of one (first) time step of `nslabs` slabs as text, one operation per line, without touching
+// a GPU: "stage <n> slab <s> euler <e> <stream>", "pack|unpack <group> slab <s> <stream>", "exchange <group> <stream>",
+// "record|wait <event> <stream>".  adopted / ready: what the slabs would report (sub-cycle look-ahead adopted by stage 0;
+// velocity look-ahead available after stage 3).  Returns the number of bytes needed (incl. the terminator).
+int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int32_t ready, char* out, int64_t cap) {
+  if (nslabs < 1) return -1;
+  TraceOps ops(nslabs, adopted != 0, ready != 0);
+  bool in_flight = false;
+  if (first) sequence_first_time_step(ops, in_flight);
+  else sequence_time_step(ops, 0, in_flight);
+  ops.add("lookahead_in_flight %d", in_flight ? 1 : 0);
+  const int64_t need = (int64_t)ops.log.size() + 1;
+  if (out && cap > 0) {
+    const int64_t ncopy = std::min<int64_t>(cap - 1, (int64_t)ops.log.size());
+    memcpy(out, ops.log.data(), (size_t)ncopy);
+    out[ncopy] = 0;
+  }
+  return need;
 }
 
 // ---- profiling ------------------------------------------------------------------------------

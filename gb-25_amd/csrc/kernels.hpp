@@ -244,11 +244,14 @@ __global__ void k_fill_fused(Grid g, Halo3 f3, Halo2 f2, int nbx, int nb_yz, int
 // (GB-25 src/precompile.jl:113-115).  One thread per column on the extended range
 // [-H+1, N+H-2] so that w and p are valid in the halos without any exchange.
 // =============================================================================================
+// Columns [i_first, i_first + n_a) and, after them, [i_first_b, i_first_b + n_b): the whole extended range in one piece,
+// or (slab of a decomposition) the own columns while the x-halo bundle travels and the two edge strips afterwards.
 __global__ __launch_bounds__(256) void k_compute_w(Grid g, const real* __restrict__ u, const real* __restrict__ v,
-                                                   real* __restrict__ w) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x - g.H + 1;
+                                                   real* __restrict__ w, int i_first, int n_a, int i_first_b, int n_b) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t < n_a ? i_first + t : i_first_b + (t - n_a);
   int j = blockIdx.y * blockDim.y + threadIdx.y - g.H + 1;
-  if (i > g.Nx + g.H - 2 || j > g.Ny + g.H - 2) return;
+  if (t >= n_a + n_b || j > g.Ny + g.H - 2) return;
   const real dxs = g.dxf[j], dxn = g.dxf[j + 1], raz = g.razc[j], dy = g.dy;
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
   real wk = real(0.);
@@ -756,7 +759,8 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
   const int tid = threadIdx.x;
   const int i0 = b.ilo + blockIdx.x * BT_TX, j0 = blockIdx.y * BT_TY;
   if (tid <= BT_RY) {
-    const int jg = j0 - BT_S + tid;
+    // rows beyond the metric tables (|jg| > Ny + H + 2) do not exist in the domain; their entries are never used
+    const int jg = max(-(g.H + 2), min(g.Ny + g.H + 2, j0 - BT_S + tid));
     Mdxf[tid] = g.dxf[jg];
     if (tid < BT_RY) {
       Mrazc[tid] = g.razc[jg];

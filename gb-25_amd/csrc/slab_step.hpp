@@ -1,0 +1,692 @@
+// slab_step.hpp -- the time step of an x-slab decomposition, inside the library.
+//
+// Replaces what the reference gets from `Oceananigans.Distributed(arch; partition=Partition(Rx, Ry, 1))` + XLA's SPMD
+// partitioner (GB-25 sharding/sharded_baroclinic_instability_simulation_run.jl:65-72,145-164): there `loop!(model,
+// Ninner)` is ONE executable whose halo copies XLA turned into collective-permutes (ncclSend/Recv kernels); here
+// gb25_loop on a slab is one call that sequences the stages of the step, the pack / unpack kernels and the
+// point-to-point exchanges on two HIP streams.  Three transports move the packed columns:
+//   * RCCL  (product, one process per GPU): ncclGroupStart; ncclSend/ncclRecv to west and east; ncclGroupEnd on the
+//            stream the exchange belongs to.  librccl is loaded at run time (dlopen), so the library itself has no
+//            link-time dependency and loads on a machine without RCCL (where only single-domain models are built).
+//   * local (several slabs of one decomposition in ONE process, same device): device-to-device copies.  This is what the
+//            decomposition-invariance tests run at full size on a one-GPU box.
+//   * host callback (rehearsal of the multi-process path where RCCL cannot run, e.g. two ranks on one device): the host
+//            moves the buffers; synchronous.
+// The sequencing itself (`sequence_time_step`) is written against an abstract StepOps so that a dry run can record the
+// order of operations without a GPU (gb25_debug_sequence; tests/test_distributed_cpu.py).
+//
+//   stage 0   AB2 update of u,v,T,S (adoption of the look-aheads), y/z layers of the 3-D bundle; pressure of the own
+//             columns starts on the slab's side stream                                            (main stream)
+//   group 0   H columns of u,v,T,S          -> x halos        packed + sent on the COMM stream, in flight during stage 2
+//   stage 2   barotropic corrector on the own columns, their y/z layers, w on the own columns, momentum tendencies of
+//             the INTERIOR tile columns                                              (main stream)
+//   stage 3   [wait for group 0] corrector in the halo columns, w and p' strips, momentum tendencies of the edge tile
+//             columns                                                                                (main stream)
+//   stage 4   tracer tendencies                                                                     (main stream)
+//     beside stage 4, on the COMM stream, the sub-cycle of the NEXT step (its G.U, G.V exist since stage 3):
+//   group 3   W = Ns+1 columns of eta,U,V and of the next G.U,G.V -> wide barotropic halos
+//   stage 5   Ns split-explicit substeps on the widened slab into the partner buffers of eta,U,V, filtered state
+//   group 4   H columns of the new eta,U,V  -> x halos of the partner buffers
+//   The next stage 0 adopts them.  When a look-ahead is not valid (first step, changed dt, host writes) the same work
+//   runs inside the step instead: group 1 (= 3), stage 1 (= 5), group 2 (= 4), on the critical path.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <array>
+#include <string>
+#include <vector>
+
+// (included by gb25_api.hip after the model and its phase implementations)
+
+namespace {
+
+// ---- x-slab exchange pieces --------------------------------------------------------------------------------------
+// group 0: H columns of u, v, T, S (all parent rows) -> the neighbour's x halo.
+// group 1: W columns of eta, U, V, G.U, G.V -> the neighbour's wide barotropic halo.
+// group 2: H columns of eta, U, V -> x halos.
+// groups 3 and 4 are groups 1 and 2 of the sub-cycle LOOK-AHEAD: G.U, G.V come from the momentum look-ahead's partner
+// buffers, the new eta, U, V live in theirs.
+struct Piece {
+  real* src;      // array that is packed from (canonical layout)
+  real* dst;      // array that is unpacked into
+  int src_sx, src_xo, dst_sx, dst_xo;
+  long rows;
+};
+void group_pieces(gb25_model* m, int group, std::vector<Piece>& out, int* ncols) {
+  const int H = m->cfg.halo, sx = m->Nx + 2 * H;
+  if (group == 0 || group == 2 || group == 4) {
+    *ncols = H;
+    if (group == 0) {
+      for (int id : {GB25_U, GB25_V, GB25_T, GB25_S}) {
+        Field& F = m->f[id];
+        out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
+      }
+    } else {
+      for (int q = 0; q < 3; q++) {
+        Field& F = group == 2 ? m->f[GB25_ETA + q] : m->ahead_eta[q];
+        out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
+      }
+    }
+  } else {
+    *ncols = m->W;
+    const int wsx = m->Nx + 2 * m->W;
+    for (int q = 0; q < 3; q++) {
+      Field& F = m->f[GB25_ETA + q];
+      out.push_back({F.d, m->wide[0][q].d, sx, H, wsx, m->W, (long)F.ny});
+    }
+    for (int q = 0; q < 2; q++) {
+      Field& F = group == 1 ? m->f[GB25_GN_BT_U + q] : m->ahead_G[q];
+      out.push_back({F.d, m->wideG[q].d, sx, H, wsx, m->W, (long)F.ny});
+    }
+  }
+}
+int64_t halo_buffer_elems(gb25_model* m, int group) {
+  std::vector<Piece> ps;
+  int nc = 0;
+  group_pieces(m, group, ps, &nc);
+  int64_t t = 0;
+  for (auto& p : ps) t += p.rows * nc;
+  return t;
+}
+// Both sides of a group in ONE launch (a group is up to ten small strips); buf[side] = that side's contiguous buffer.
+gb25_status pack_unpack(gb25_model* m, int group, real* const buf[2], bool pack) {
+  std::vector<Piece> ps;
+  int nc = 0;
+  group_pieces(m, group, ps, &nc);
+  ColumnPieces P{};
+  P.ncols = nc;
+  long max_n = 0;
+  for (int side = 0; side < 2; side++) {
+    size_t off = 0;
+    for (auto& p : ps) {
+      const int f = P.n++;
+      P.rows[f] = p.rows;
+      P.buf[f] = buf[side] + off;
+      if (pack) {   // west side: interior columns [0, nc); east side: [Nx-nc, Nx)
+        P.arr[f] = p.src; P.sx[f] = p.src_sx; P.i0[f] = p.src_xo + (side == 0 ? 0 : m->Nx - nc);
+      } else {      // west halo: columns [-nc, 0); east halo: [Nx, Nx+nc)
+        P.arr[f] = p.dst; P.sx[f] = p.dst_sx; P.i0[f] = p.dst_xo + (side == 0 ? -nc : m->Nx);
+      }
+      off += (size_t)p.rows * nc;
+      max_n = std::max(max_n, p.rows * nc);
+    }
+  }
+  dim3 gr((unsigned)((max_n + 255) / 256), (unsigned)P.n);
+  if (pack) hipLaunchKernelGGL(k_move_columns<true>, gr, dim3(256), 0, m->stream, P);
+  else hipLaunchKernelGGL(k_move_columns<false>, gr, dim3(256), 0, m->stream, P);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+
+// ---- the stages of one slab's time step (see the header of this file) -------------------------------------------------
+gb25_status slab_stage(gb25_model* m, int stage, int euler) {
+  const Grid& g = m->g;
+  gb25_status s;
+  const double dt = m->last_dt;
+  const real chi = euler ? -real(0.5) : (real)m->cfg.chi;
+  const bool split = tendencies_split(m);
+  if (stage == 0) {
+    // AB2 update of u,v,T,S + barotropic forcing, then the y/z boundary layers of the 3-D bundle so that its packed
+    // x columns (group 0) can travel WHILE the own columns are corrected
+    const bool uv_adopted = m->ahead_uv_valid && (real)dt == m->ahead_uv_dt && chi == m->ahead_uv_chi;
+    m->baro_adopted = uv_adopted && m->ahead_baro_valid;
+    m->ahead_baro_valid = false;
+    if ((s = ab2_local_impl(m, (real)dt, chi))) return s;
+    if (m->baro_adopted) {
+      // the sub-cycle of this step, its wide-halo exchange and the exchange of the new eta, U, V columns all ran
+      // beside the last tracer kernel (stage 5): adopt the results, stage 1 and groups 1, 2 are skipped
+      for (int q = 0; q < 3; q++) {
+        std::swap(m->f[GB25_ETA + q].d, m->ahead_eta[q].d);
+        std::swap(m->f[GB25_ETA_BAR + q].d, m->ahead_bar[q].d);
+      }
+      std::swap(m->bars, m->bars_ahead);
+      m->time += dt;
+      m->iteration += 1;
+    }
+    if ((s = fill_halos_impl(m, false, false, 1))) return s;
+    if (m->two_streams) {
+      // T, S of the slab's own columns are final from here on: their pressure (fp64-bound) runs on the side stream
+      // beside the exchanges and the sub-cycle; the strips next to the x halos follow in stage 3.  The first x
+      // difference of this pass reads a stale halo column and is redone by the west strip.
+      HIPCHK(hipEventRecord(m->ev_fork, m->stream));
+      HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
+      hipStream_t main = m->stream;
+      m->stream = m->side_stream;
+      s = compute_p_impl(m, 0, g.Nx - 1, 0, -1, true);
+      m->stream = main;
+      if (s) return s;
+      HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
+    }
+    return GB25_OK;
+  } else if (stage == 1 || stage == 5) {
+    // stage 1: group 1 has been unpacked into the wide halos: copy the interiors, sub-cycle, publish.
+    // stage 5: the same for the NEXT step (look-ahead): group 3 has been unpacked, G.U, G.V come from the momentum
+    //          look-ahead, the results go to the partner buffers of eta, U, V and of the filtered state.
+    const bool ahead = stage == 5;
+    if (ahead && !m->ahead_uv_valid) return fail(m, GB25_ERR_STATE, "stage 5 without a velocity look-ahead");
+    if (!ahead && m->baro_adopted) return fail(m, GB25_ERR_STATE, "stage 1 after stage 0 adopted the sub-cycle");
+    std::vector<Piece> ps;
+    int nc = 0;
+    group_pieces(m, ahead ? 3 : 1, ps, &nc);
+    {
+      InteriorCopies C{};
+      int rmax = 0;
+      for (auto& p : ps) {
+        const int q = C.n++;
+        C.dst[q] = p.dst; C.dsx[q] = p.dst_sx; C.dxo[q] = p.dst_xo;
+        C.src[q] = p.src; C.ssx[q] = p.src_sx; C.sxo[q] = p.src_xo; C.rows[q] = (int)p.rows;
+        rmax = std::max(rmax, (int)p.rows);
+      }
+      hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, rmax, C.n), dim3(256), 0, m->stream, C,
+                         g.Nx);
+    }
+    LAUNCHCHK();
+    if (ahead) {
+      if ((s = barotropic_impl(m, m->ahead_uv_dt, true))) return s;
+      Halo2 h2;
+      for (int q = 0; q < 3; q++) { h2.p[q] = m->ahead_eta[q].d; h2.is_v[q] = q == 2; }
+      h2.n = 3;
+      if ((s = fill_halos_impl(m, false, false, 2, 3, nullptr, true, &h2))) return s;   // their x columns: group 4
+      m->ahead_baro_valid = true;
+      return GB25_OK;
+    }
+    if ((s = barotropic_impl(m, (real)dt))) return s;
+    m->time += dt;
+    m->iteration += 1;
+    // y layer of the new eta, U, V; their x columns are group 2
+    return fill_halos_impl(m, false, false, 2);
+  } else if (stage == 2) {
+    // Everything that needs nothing from the neighbours runs while the exchanges are in flight: the barotropic
+    // corrector on the slab's own columns and, when the tendency kernels are split (a12), the y/z layers and w of the
+    // own columns and the momentum tendencies of the interior tile columns.
+    if ((s = corrector_impl(m, true, 1))) return s;
+    if (!split) return GB25_OK;
+    if ((s = fill_halos_impl(m, false, false, 1, 1))) return s;   // y/z layers of the corrected u, v, own columns
+    if ((s = compute_w_impl(m, 1))) return s;
+    HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));       // the own columns' pressure differences (side stream)
+    return momentum_impl(m, 1);
+  } else if (stage == 3) {
+    // groups 2 and 0 have been unpacked: corrector on the x-halo columns, then update_state without any
+    // further exchange (y/z layers re-filled over the extended x range; w and p recomputed in the halos)
+    if ((s = corrector_impl(m, true, 2))) return s;
+    // the interior pressure pass of stage 0 must be over before the fills touch T, S and before the west strip
+    // rewrites column 0 (it has been for a while: the exchanges and the sub-cycle ran in between)
+    if (m->two_streams) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+    if ((s = fill_halos_impl(m, false, true))) return s;
+    if (m->two_streams) {   // the two pressure strips run beside w (side stream)
+      hipStream_t main = m->stream;
+      HIPCHK(hipEventRecord(m->ev_fork, main));
+      HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
+      m->stream = m->side_stream;
+      s = compute_p_impl(m, -g.H + 1, 0, g.Nx, g.Nx + g.H - 2, true);   // west strip (redoes column 0) + east strip
+      m->stream = main;
+      if (s) return s;
+      HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
+    }
+    if ((s = compute_w_impl(m, split ? 2 : 0))) return s;
+    if (m->two_streams) {
+      HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+    } else {
+      if ((s = compute_p_impl(m))) return s;
+    }
+    return momentum_impl(m, split ? 2 : 0);
+  } else if (stage == 4) {
+    // the tracer tendencies; the look-ahead of the next sub-cycle (groups 3, 4 and stage 5) runs beside them
+    return tracers_impl(m);
+  }
+  return fail(m, GB25_ERR_INVALID_ARGUMENT, "stage must be 0 .. 5");
+}
+
+gb25_status update_state_local_impl(gb25_model* m) {   // update_state! without the x-halo fill
+  gb25_status s;
+  if ((s = fill_halos_impl(m, false, m->slab))) return s;
+  if ((s = compute_w_impl(m))) return s;
+  if ((s = compute_p_impl(m))) return s;
+  if ((s = momentum_impl(m))) return s;
+  return tracers_impl(m);
+}
+
+// ---- sequencing ------------------------------------------------------------------------------------------------------
+// Everything a step of the slabs driven by this process does, in issue order.  Streams: `main` (on_comm = false) and
+// `comm`; record(slot, on_comm) marks everything issued so far on a stream, wait(slot, comm_waits) makes the other (or
+// the same) stream wait for that mark.  No host synchronisation anywhere.
+struct StepOps {
+  virtual ~StepOps() {}
+  virtual int n() const = 0;
+  virtual gb25_status stage(int s, int stage, int euler, bool on_comm) = 0;
+  virtual gb25_status pack(int s, int group, bool on_comm) = 0;
+  virtual gb25_status unpack(int s, int group, bool on_comm) = 0;
+  virtual gb25_status exchange(int group, bool on_comm) = 0;   // every slab's packs -> its neighbours' receive buffers
+  virtual gb25_status local(int s, int what) = 0;              // 0: initialize!, 1: y/z halo layers, 2: update_state! (local)
+  virtual bool velocities_ready(int s) = 0;
+  virtual bool subcycle_adopted(int s) = 0;
+  virtual gb25_status record(int slot, bool on_comm) = 0;
+  virtual gb25_status wait(int slot, bool comm_waits) = 0;
+};
+#define SEQ(call)            \
+  do {                       \
+    gb25_status st_ = (call); \
+    if (st_) return st_;     \
+  } while (0)
+#define EACH(expr)                         \
+  for (int s = 0; s < n; s++) SEQ(expr)
+
+gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight) {
+  const int n = o.n();
+  if (lookahead_in_flight) {   // stage 5 and groups 3, 4 of the previous step have finished before stage 0 adopts them
+    SEQ(o.record(3, true));
+    SEQ(o.wait(3, false));
+  }
+  lookahead_in_flight = false;
+  EACH(o.stage(s, 0, euler, false));
+  bool adopted = true;         // the sub-cycle of this step is already done
+  for (int s = 0; s < n; s++) adopted = adopted && o.subcycle_adopted(s);
+  SEQ(o.record(0, false));     // everything stage 0 wrote
+  if (!adopted) {
+    // The small barotropic exchange is on the critical path and is posted FIRST: the point-to-point transfers of one
+    // communicator run in posting order, so the 6 MB bundle must not be queued ahead of it.
+    EACH(o.pack(s, 1, false));
+    SEQ(o.exchange(1, false));
+  }
+  SEQ(o.wait(0, true));        // the 3-D bundle leaves on the second stream ...
+  EACH(o.pack(s, 0, true));
+  SEQ(o.record(1, true));      // (packed)
+  SEQ(o.exchange(0, true));
+  if (!adopted) {              // ... and is in flight while the sub-cycle runs here
+    for (int s = 0; s < n; s++) {
+      SEQ(o.unpack(s, 1, false));
+      SEQ(o.stage(s, 1, euler, false));
+      SEQ(o.pack(s, 2, false));
+    }
+    SEQ(o.record(2, false));
+    SEQ(o.wait(2, true));      // eta, U, V columns leave behind the bundle on the second stream
+    SEQ(o.exchange(2, true));
+  }
+  SEQ(o.wait(1, false));       // the corrector rewrites the columns the bundle was packed from
+  EACH(o.stage(s, 2, euler, false));   // own columns + interior tendencies, while the exchanges are in flight
+  SEQ(o.record(3, true));
+  SEQ(o.wait(3, false));       // the halo columns have arrived
+  if (!adopted) EACH(o.unpack(s, 2, false));
+  for (int s = 0; s < n; s++) {
+    SEQ(o.unpack(s, 0, false));
+    SEQ(o.stage(s, 3, euler, false));
+  }
+  // the next step's G.U, G.V exist now: its wide-halo exchange, sub-cycle and eta,U,V exchange run on the second stream
+  // beside the tracer tendencies
+  bool ready = true;
+  for (int s = 0; s < n; s++) ready = ready && o.velocities_ready(s);
+  if (ready) {
+    SEQ(o.record(2, false));
+    SEQ(o.wait(2, true));
+    EACH(o.pack(s, 3, true));
+    SEQ(o.exchange(3, true));
+    for (int s = 0; s < n; s++) {
+      SEQ(o.unpack(s, 3, true));
+      SEQ(o.stage(s, 5, euler, true));
+      SEQ(o.pack(s, 4, true));
+    }
+    SEQ(o.exchange(4, true));
+    EACH(o.unpack(s, 4, true));
+    lookahead_in_flight = true;
+  }
+  EACH(o.stage(s, 4, euler, false));
+  return GB25_OK;
+}
+// first_time_step!: initialize!, update_state!, then an Euler step (GB-25 src/timestepping_utils.jl:21-27)
+gb25_status sequence_first_time_step(StepOps& o, bool& lookahead_in_flight) {
+  const int n = o.n();
+  if (lookahead_in_flight) {
+    SEQ(o.record(3, true));
+    SEQ(o.wait(3, false));
+    lookahead_in_flight = false;
+  }
+  for (int s = 0; s < n; s++) {
+    SEQ(o.local(s, 0));
+    SEQ(o.local(s, 1));
+    SEQ(o.pack(s, 0, false));
+    SEQ(o.pack(s, 2, false));
+  }
+  SEQ(o.exchange(0, false));
+  SEQ(o.exchange(2, false));
+  for (int s = 0; s < n; s++) {
+    SEQ(o.unpack(s, 0, false));
+    SEQ(o.unpack(s, 2, false));
+    SEQ(o.local(s, 2));
+  }
+  return sequence_time_step(o, 1, lookahead_in_flight);
+}
+#undef EACH
+#undef SEQ
+
+// Dry run: records the operations instead of launching anything (no HIP call) -- how the CPU-only tests see the order.
+struct TraceOps : StepOps {
+  int nslabs;
+  bool adopted, ready;
+  std::string log;
+  TraceOps(int n_, bool a, bool r) : nslabs(n_), adopted(a), ready(r) {}
+  void add(const char* fmt, ...) {
+    char buf[96];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    log += buf;
+    log += '\n';
+  }
+  static const char* st(bool on_comm) { return on_comm ? "comm" : "main"; }
+  int n() const override { return nslabs; }
+  gb25_status stage(int s, int stage, int euler, bool c) override { add("stage %d slab %d euler %d %s", stage, s, euler, st(c)); return GB25_OK; }
+  gb25_status pack(int s, int group, bool c) override { add("pack %d slab %d %s", group, s, st(c)); return GB25_OK; }
+  gb25_status unpack(int s, int group, bool c) override { add("unpack %d slab %d %s", group, s, st(c)); return GB25_OK; }
+  gb25_status exchange(int group, bool c) override { add("exchange %d %s", group, st(c)); return GB25_OK; }
+  gb25_status local(int s, int what) override {
+    static const char* names[] = {"initialize", "fill_local", "update_state_local"};
+    add("%s slab %d main", names[what], s);
+    return GB25_OK;
+  }
+  bool velocities_ready(int) override { return ready; }
+  bool subcycle_adopted(int) override { return adopted; }
+  gb25_status record(int slot, bool c) override { add("record %d %s", slot, st(c)); return GB25_OK; }
+  gb25_status wait(int slot, bool comm_waits) override { add("wait %d %s", slot, st(comm_waits)); return GB25_OK; }
+};
+
+// ---- transports ------------------------------------------------------------------------------------------------------
+struct Transport {
+  virtual ~Transport() {}
+  // buffer set b (0: group 0; 1: groups 1, 3; 2: groups 2, 4), nbytes per side, on stream st
+  virtual gb25_status exchange(SlabGroup& G, int b, size_t nbytes, hipStream_t st) = 0;
+  virtual const char* name() const = 0;
+};
+
+}  // namespace
+
+// The slabs this process drives, their exchange buffers, the second stream and the transport.
+struct SlabGroup {
+  std::vector<gb25_model*> slabs;
+  hipStream_t main = nullptr, comm = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  Transport* transport = nullptr;
+  std::vector<std::array<std::array<real*, 2>, 3>> send, recv;   // [slab][buffer set][side: 0 west, 1 east]
+  size_t elems[3] = {0, 0, 0};
+  bool lookahead_in_flight = false;
+  // neighbour handshake of the collective mutators (see collective_guard)
+  unsigned long long *tok_dev = nullptr, *tok_host = nullptr;
+};
+
+namespace {
+
+inline int buffer_set(int group) { return group == 0 ? 0 : ((group == 1 || group == 3) ? 1 : 2); }
+
+// several slabs of one decomposition in this process, all on one device: a ring of device-to-device copies
+struct LocalRingTransport : Transport {
+  const char* name() const override { return "local"; }
+  gb25_status exchange(SlabGroup& G, int b, size_t nbytes, hipStream_t st) override {
+    const int P = (int)G.slabs.size();
+    for (int r = 0; r < P; r++) {
+      gb25_model* m = G.slabs[r];
+      const int west = (r + P - 1) % P, east = (r + 1) % P;
+      // my west pack -> west neighbour's east halo; my east pack -> east neighbour's west halo
+      HIPCHK(hipMemcpyAsync(G.recv[west][b][1], G.send[r][b][0], nbytes, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(G.recv[east][b][0], G.send[r][b][1], nbytes, hipMemcpyDeviceToDevice, st));
+    }
+    return GB25_OK;
+  }
+};
+
+// librccl, resolved at run time.  When the host process has RCCL loaded already (PyTorch-ROCm ships one with the same
+// soname) dlopen hands back that copy, so there is exactly one RCCL in the process.
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+  bool load() {
+    if (lib) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) {
+      error = std::string("librccl.so.1 could not be loaded: ") + dlerror();
+      return false;
+    }
+    auto sym = [&](const char* n) {
+      void* p = dlsym(lib, n);
+      if (!p) error = std::string("librccl lacks ") + n;
+      return p;
+    };
+    GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+    CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    Send = (decltype(Send))sym("ncclSend");
+    Recv = (decltype(Recv))sym("ncclRecv");
+    GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+    GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !Send || !Recv || !GroupStart || !GroupEnd || !GetErrorString) {
+      lib = nullptr;
+      return false;
+    }
+    return true;
+  }
+};
+RcclApi& rccl() {
+  static RcclApi api;
+  return api;
+}
+#define NCCLCHK(call)                                                                                             \
+  do {                                                                                                            \
+    ncclResult_t r_ = (call);                                                                                     \
+    if (r_ != ncclSuccess)                                                                                        \
+      return fail(m, GB25_ERR_COMM, "%s:%d: %s failed: %s", __FILE__, __LINE__, #call, rccl().GetErrorString(r_)); \
+  } while (0)
+
+// one slab per process, one process per GPU: the ring neighbours are ranks rank-1 and rank+1 of the communicator.
+// Posting order is part of the protocol: sends [west pack, east pack], receives [east halo, west halo].  With two
+// ranks both neighbours are the same peer and the messages of one pair match in posting order, so the peer's FIRST send
+// (its west pack) must meet our FIRST receive (our east halo); with one rank (the self-ring) likewise.
+struct RcclTransport : Transport {
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+  const char* name() const override { return "rccl"; }
+  ~RcclTransport() override {
+    if (comm) rccl().CommDestroy(comm);
+  }
+  gb25_status send_recv(gb25_model* m, const void* sw, const void* se, void* rw, void* re, size_t nbytes, hipStream_t st) {
+    const int west = (rank + nranks - 1) % nranks, east = (rank + 1) % nranks;
+    RcclApi& R = rccl();
+    NCCLCHK(R.GroupStart());
+    NCCLCHK(R.Send(sw, nbytes, ncclInt8, west, comm, st));
+    NCCLCHK(R.Send(se, nbytes, ncclInt8, east, comm, st));
+    NCCLCHK(R.Recv(re, nbytes, ncclInt8, east, comm, st));
+    NCCLCHK(R.Recv(rw, nbytes, ncclInt8, west, comm, st));
+    NCCLCHK(R.GroupEnd());
+    return GB25_OK;
+  }
+  gb25_status exchange(SlabGroup& G, int b, size_t nbytes, hipStream_t st) override {
+    return send_recv(G.slabs[0], G.send[0][b][0], G.send[0][b][1], G.recv[0][b][0], G.recv[0][b][1], nbytes, st);
+  }
+};
+
+// the host moves the buffers (synchronous): rehearsal of the multi-process path where RCCL cannot run
+struct CallbackTransport : Transport {
+  gb25_exchange_fn fn = nullptr;
+  void* user = nullptr;
+  const char* name() const override { return "callback"; }
+  gb25_status exchange(SlabGroup& G, int b, size_t nbytes, hipStream_t st) override {
+    gb25_model* m = G.slabs[0];
+    HIPCHK(hipStreamSynchronize(st));   // the packs are complete
+    const int rc = fn(user, b, G.send[0][b][0], G.send[0][b][1], G.recv[0][b][0], G.recv[0][b][1], (int64_t)nbytes);
+    if (rc != 0) return fail(m, GB25_ERR_COMM, "the host's exchange callback failed with code %d (buffer set %d)", rc, b);
+    return GB25_OK;
+  }
+};
+
+// the real StepOps: the slabs of a SlabGroup
+struct GroupOps : StepOps {
+  SlabGroup& G;
+  explicit GroupOps(SlabGroup& g_) : G(g_) {}
+  int n() const override { return (int)G.slabs.size(); }
+  struct OnStream {   // run model calls with the model's kernels on the comm stream
+    gb25_model* m;
+    hipStream_t saved;
+    OnStream(gb25_model* m_, hipStream_t st) : m(m_), saved(m_->stream) { m->stream = st; }
+    ~OnStream() { m->stream = saved; }
+  };
+  hipStream_t st(bool on_comm) const { return on_comm ? G.comm : G.main; }
+  gb25_status stage(int s, int stage, int euler, bool c) override {
+    OnStream on(G.slabs[s], st(c));
+    return slab_stage(G.slabs[s], stage, euler);
+  }
+  gb25_status pack(int s, int group, bool c) override {
+    OnStream on(G.slabs[s], st(c));
+    const int b = buffer_set(group);
+    real* buf[2] = {G.send[s][b][0], G.send[s][b][1]};
+    return pack_unpack(G.slabs[s], group, buf, true);
+  }
+  gb25_status unpack(int s, int group, bool c) override {
+    OnStream on(G.slabs[s], st(c));
+    const int b = buffer_set(group);
+    real* buf[2] = {G.recv[s][b][0], G.recv[s][b][1]};
+    return pack_unpack(G.slabs[s], group, buf, false);
+  }
+  gb25_status exchange(int group, bool c) override {
+    const int b = buffer_set(group);
+    return G.transport->exchange(G, b, G.elems[b] * sizeof(real), st(c));
+  }
+  gb25_status local(int s, int what) override {
+    gb25_model* m = G.slabs[s];
+    if (what == 0) return initialize_impl(m);
+    if (what == 1) return fill_halos_impl(m, false);
+    return update_state_local_impl(m);
+  }
+  bool velocities_ready(int s) override {
+    gb25_model* m = G.slabs[s];
+    return m->ahead_uv_valid && m->baro_ahead && !m->ptr_exposed;
+  }
+  bool subcycle_adopted(int s) override { return G.slabs[s]->baro_adopted; }
+  gb25_status record(int slot, bool c) override {
+    gb25_model* m = G.slabs[0];
+    HIPCHK(hipEventRecord(G.ev[slot], st(c)));
+    return GB25_OK;
+  }
+  gb25_status wait(int slot, bool comm_waits) override {
+    gb25_model* m = G.slabs[0];
+    HIPCHK(hipStreamWaitEvent(st(comm_waits), G.ev[slot], 0));
+    return GB25_OK;
+  }
+};
+
+void group_destroy(SlabGroup* G) {
+  if (!G) return;
+  if (G->comm) hipStreamSynchronize(G->comm);
+  if (G->main) hipStreamSynchronize(G->main);
+  delete G->transport;
+  for (auto& s : G->send)
+    for (auto& b : s)
+      for (real* p : b)
+        if (p) hipFree(p);
+  for (auto& s : G->recv)
+    for (auto& b : s)
+      for (real* p : b)
+        if (p) hipFree(p);
+  for (hipEvent_t e : G->ev)
+    if (e) hipEventDestroy(e);
+  if (G->comm) hipStreamDestroy(G->comm);
+  if (G->tok_dev) hipFree(G->tok_dev);
+  if (G->tok_host) hipHostFree(G->tok_host);
+  for (gb25_model* m : G->slabs) {
+    m->group = nullptr;
+    m->stream = m->own_stream;
+  }
+  delete G;
+}
+
+// Builds the exchange context of `n` slabs (n > 1 only with the local transport).  Takes ownership of `tr`.
+gb25_status group_create(gb25_model* const* slabs, int n, Transport* tr) {
+  gb25_model* m = slabs[0];
+  for (int s = 0; s < n; s++) {
+    if (!slabs[s] || !slabs[s]->slab) {
+      delete tr;
+      return fail(m, GB25_ERR_STATE, "slab %d is not a slab of an x decomposition (nranks > 1 or slab_mode = 1)", s);
+    }
+    if (slabs[s]->group) group_destroy(slabs[s]->group);
+  }
+  SlabGroup* G = new SlabGroup();
+  G->transport = tr;
+  G->slabs.assign(slabs, slabs + n);
+  G->main = m->own_stream;
+  for (int s = 0; s < n; s++) {
+    slabs[s]->group = G;
+    slabs[s]->group_index = s;
+    slabs[s]->stream = G->main;
+  }
+  gb25_status st = GB25_OK;
+  do {
+    if (hipSetDevice(m->cfg.device) != hipSuccess ||
+        hipStreamCreateWithFlags(&G->comm, hipStreamNonBlocking) != hipSuccess) { st = GB25_ERR_HIP; break; }
+    for (auto& e : G->ev)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) st = GB25_ERR_HIP;
+    if (st) break;
+    for (int b = 0; b < 3; b++) G->elems[b] = (size_t)halo_buffer_elems(m, b);
+    G->send.resize(n);
+    G->recv.resize(n);
+    for (int s = 0; s < n && !st; s++)
+      for (int b = 0; b < 3 && !st; b++)
+        for (int side = 0; side < 2 && !st; side++) {
+          G->send[s][b][side] = G->recv[s][b][side] = nullptr;
+          if (hipMalloc(&G->send[s][b][side], G->elems[b] * sizeof(real)) != hipSuccess ||
+              hipMalloc(&G->recv[s][b][side], G->elems[b] * sizeof(real)) != hipSuccess)
+            st = GB25_ERR_OUT_OF_MEMORY;
+        }
+    if (st) break;
+    if (hipMalloc(&G->tok_dev, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc(&G->tok_host, 8 * sizeof(unsigned long long)) != hipSuccess) st = GB25_ERR_OUT_OF_MEMORY;
+  } while (0);
+  if (st) {
+    group_destroy(G);
+    return fail(m, st, "could not build the exchange context (%s)", hipGetErrorString(hipGetLastError()));
+  }
+  return GB25_OK;
+}
+
+// Calls that change what the look-aheads were made from (host writes, a new dt, an option, a handed-out pointer) void
+// the look-aheads of the calling slab -- and, through the halo columns the neighbours hold, theirs.  On a decomposed
+// model they are therefore COLLECTIVE: every rank must make the same call (as with set!(model, ...) on an Oceananigans
+// Distributed grid).  With the RCCL transport the call shakes hands with both ring neighbours (16 bytes each way): a
+// rank that made a different call gets GB25_ERR_STATE here instead of a mismatched exchange later, a rank that made no
+// call leaves the others waiting AT the call.  The branch every rank takes in the next step (adopt the look-aheads or
+// not) then depends on agreed values only.
+gb25_status collective_guard(gb25_model* m, unsigned op, unsigned arg, double payload) {
+  SlabGroup* G = m->group;
+  if (!G) return GB25_OK;
+  RcclTransport* R = dynamic_cast<RcclTransport*>(G->transport);
+  if (!R) return GB25_OK;   // local slabs share one host thread; the callback transport is a rehearsal
+  unsigned long long bits;
+  memcpy(&bits, &payload, sizeof bits);
+  unsigned long long* h = G->tok_host;
+  h[0] = h[2] = ((unsigned long long)op << 32) | arg;
+  h[1] = h[3] = bits;
+  HIPCHK(hipStreamSynchronize(G->comm));   // a look-ahead still in flight belongs to the state this call is about to void
+  HIPCHK(hipMemcpyAsync(G->tok_dev, h, 4 * sizeof *h, hipMemcpyHostToDevice, G->main));
+  gb25_status s = R->send_recv(m, G->tok_dev, G->tok_dev + 2, G->tok_dev + 4, G->tok_dev + 6, 2 * sizeof *h, G->main);
+  if (s) return s;
+  HIPCHK(hipMemcpyAsync(h + 4, G->tok_dev + 4, 4 * sizeof *h, hipMemcpyDeviceToHost, G->main));
+  HIPCHK(hipStreamSynchronize(G->main));
+  for (int q = 0; q < 2; q++)
+    if (h[4 + 2 * q] != h[0] || h[5 + 2 * q] != h[1])
+      return fail(m, GB25_ERR_STATE,
+                  "collective call mismatch on rank %d: this rank made call %u(%u, %g) but its %s neighbour made call "
+                  "%llu(%llu): setters of a decomposed model must be called alike on every rank",
+                  R->rank, op, arg, payload, q == 0 ? "west" : "east", h[4 + 2 * q] >> 32, h[4 + 2 * q] & 0xffffffffull);
+  return GB25_OK;
+}
+
+}  // namespace

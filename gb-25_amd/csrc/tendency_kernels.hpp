@@ -1,0 +1,509 @@
+// tendency_kernels.hpp -- the shipped tendency kernels (gfx950): momentum ("v5", LDS-staged tiles, packed fp32
+// reconstructions, AB2 look-ahead of u, v) and tracers ("v5", wave-autonomous, T and S as one two-wide value,
+// buffer addressing, AB2 look-ahead of T, S).  Each face flux / derived quantity is computed ONCE per (i,j,k) and
+// shared through LDS (x, y), a wave shuffle (x faces of the tracers) or carried in registers while marching up the
+// column (z).  The direct-stencil kernels of kernels.hpp (k_gu, k_gv, k_tracer_tendencies) evaluate the same
+// expressions cell by cell and are kept as the cross-check generation (option "kernels" = 1).
+//
+// A wave64 VALU instruction costs ~4 cycles of a SIMD on gfx950 and scalar forms of these kernels were
+// issue-saturated (VALUBusy ~100 %): see device_common.hpp (real2v), tools/micro/ and profiles/r01_tuning_log.md.
+#pragma once
+#include "device_common.hpp"
+
+namespace gb25 {
+
+constexpr int V2_TX = 64;   // tile width = one wavefront; tile height TY (rows = waves per block) is a template parameter
+
+// =============================================================================================
+// Momentum tendencies G_u and G_v fused: block = (64 x 8) columns marching in k.  Per level the block stages
+// the u, v (level k) and w (level k+1) tiles in LDS, derives vorticity zeta and its VelocityStencil inputs at the
+// (f,f,c) points and the area-weighted divergence pieces at the (c,c,c) points ONCE per point (v1 recomputed each
+// of them for 6-12 neighbouring cells), then every thread evaluates G_u and G_v of its cell from LDS.  The vertical
+// momentum fluxes are carried from level to level.  Arithmetic per term is that of k_gu / k_gv (kernels.hpp).
+// =============================================================================================
+constexpr int MU_X = V2_TX + 6;   // u, v tiles: origin (i0-3, j0-3), TY+6 rows
+constexpr int MW_X = V2_TX + 3;   // w tile:     origin (i0-2, j0-2), TY+3 rows
+constexpr int MD_X = V2_TX + 5;   // derived tiles: ffc origin (i0-2, j0-2), ccc origin (i0-3, j0-3), TY+5 rows
+
+template <int V2_TY>
+struct MomentumLds {
+  static constexpr int MU_Y = V2_TY + 6, MW_Y = V2_TY + 3, MD_Y = V2_TY + 5;
+  real U[2][MU_Y][MU_X];
+  real V[2][MU_Y][MU_X];
+  real W[2][MW_Y][MW_X];
+  real Z[MD_Y][MD_X], UQ[MD_Y][MD_X], VQ[MD_Y][MD_X];  // (f,f,c)
+  real DU[MD_Y][MD_X], DV[MD_Y][MD_X];                 // (c,c,c)
+};
+
+// =============================================================================================
+// Momentum tendencies, packed evaluation: the eight WENO reconstructions of a cell are evaluated as four two-wide ones (a G_u term paired with the G_v term of
+// the same stencil shape and order), so their arithmetic issues as v_pk_fma/mul/add_f32.  Rows next to the walls,
+// where the vorticity reconstruction of G_u drops below order 5 but G_v's does not, take the scalar form for that
+// one pair.
+// =============================================================================================
+// AHEAD: the kernel also performs the NEXT step's ab2_step_field! of u and v into partner arrays (un, vn) and leaves
+// the per-chunk column sums of (C1 G^n - C2 G^-) dz and of un dz, vn dz in P; k_ab2_velocities_finish adds the chunks
+// up into G.U, G.V and the corrector's column integrals.  u, v and the fresh tendencies are in registers here, so the
+// separate 6R + 2W sweep of k_ab2_velocities shrinks to one read (G^-) and one write per component.
+// Which tile columns a launch covers.  The x axis is cut into columns of tiles bx = 0 .. ceil(Nx/64)-1; a launch owns
+// `n` of them: the first `nlead` are bx0, bx0+1, ..., the rest bx1, bx1+1, ...  Whole domain: {n, n, 0, 0}.  A slab of
+// a decomposition launches its interior tile columns (which read own columns only) while the x-halo bundle is still
+// travelling, and the edge columns {0} + {last} afterwards (interior_tendency_kernel_parameters +
+// complete_communication_and_compute_buffer!, GB-25 src/precompile.jl:67,72): same tiles, same arithmetic, same bits.
+struct TileCols {
+  int n, nlead, bx0, bx1;
+};
+__device__ __forceinline__ int tile_column(const TileCols& tc, int q) { return q < tc.nlead ? tc.bx0 + q : tc.bx1 + (q - tc.nlead); }
+
+struct UvAhead {
+  const real *GmU, *GmV;
+  real *un, *vn, *P;
+  real dt, C1, C2;
+  int plane2;
+};
+template <int MINW, int V2_TY, bool AHEAD>
+__global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
+    Grid g, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ w,
+    const real* __restrict__ dpx, const real* __restrict__ dpy, real* __restrict__ Gu, real* __restrict__ Gv,
+    TileCols tc, int kchunks, int nb, UvAhead next) {
+  __shared__ MomentumLds<V2_TY> lds;
+  constexpr int MU_Y = V2_TY + 6, MW_Y = V2_TY + 3, MD_Y = V2_TY + 5;
+  const int L = xcd_remap(blockIdx.x, nb);
+  const int r = L / tc.n, bx = tile_column(tc, L - r * tc.n);
+  const int kc = r % kchunks, by = r / kchunks;
+  const int klen = (g.Nz + kchunks - 1) / kchunks;
+  const int k0 = kc * klen, k1 = min(g.Nz, k0 + klen);
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * V2_TX + tx;
+  const int i0 = bx * V2_TX, j0 = by * V2_TY;
+  const int i = i0 + tx, j = j0 + ty;
+  const bool inside = (i < g.Nx) && (j < g.Ny);
+  const int sx = g.sx, pc = g.pl_c, pv = g.pl_v, H = g.H;
+  const real dy = g.dy;
+
+  // j-dependent metrics of this thread's row
+  const real dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j], razc_j = g.razc[j], razf_j = g.razf[j];
+  const real Az = g.azc[j], fcor_j = g.fcor[j], fbar = real(0.5) * (g.fcor[j] + g.fcor[j + 1]);
+  const real az_m2 = g.azc[j - 2], az_m1 = g.azc[j - 1], az_p1 = g.azc[j + 1];
+  const int oc_y = biased_order_center(j, g.Ny), of_y = biased_order_face(j, g.Ny);
+  const bool s4c_y = sym4_center(j, g.Ny), s4f_y = sym4_face(j, g.Ny);
+
+  // threads of a ragged edge tile work on a clamped (duplicate) column so that every address stays in bounds
+  int o = ic(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0), ov = iv(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0);
+  // (uniform base pointer + 32-bit per-lane byte offset: the accesses take the scalar-base addressing form and need no
+  // 64-bit address arithmetic per lane; the own cell's byte offsets ob / obv serve every centre- / v-shaped array)
+  auto at = [](const real* base, unsigned byte_off) {
+    return *reinterpret_cast<const real*>(reinterpret_cast<const char*>(base) + byte_off);
+  };
+  auto put = [](real* base, unsigned byte_off, real x) {
+    *reinterpret_cast<real*>(reinterpret_cast<char*>(base) + byte_off) = x;
+  };
+  constexpr unsigned SZ = (unsigned)sizeof(real);
+  unsigned ob = (unsigned)o * SZ, obv = (unsigned)ov * SZ;
+  real uz[7], vz[7];
+#pragma unroll
+  for (int m = 0; m < 7; m++) {
+    uz[m] = u[o + (m - 3) * pc];
+    vz[m] = v[ov + (m - 3) * pv];
+  }
+  // vertical momentum fluxes through the bottom face of the first level
+  real fzu, fzv;
+  {
+    const int ord = biased_order_face(k0, g.Nz);
+    real wu = sym_interp(true, Az * w[o - 2], Az * w[o - 1], Az * w[o], Az * w[o + 1]);
+    real wv = sym_interp(s4f_y, az_m2 * w[o - 2 * sx], az_m1 * w[o - sx], Az * w[o], az_p1 * w[o + sx]);
+    fzu = wu * biased6<false>(ord, wu > real(0.), uz, uz, uz);
+    fzv = wv * biased6<false>(ord, wv > real(0.), vz, vz, vz);
+  }
+
+  // Tile staging is software-pipelined: the global loads of level k+1 are issued before the arithmetic of level
+  // k and land in LDS (other parity) after it, so their latency hides behind phases 1-2 instead of in front of a
+  // barrier.  Each thread owns up to 2 elements of the u / v tiles and 2 of the w tile.
+  constexpr int NT = V2_TX * V2_TY;
+  constexpr int NEU = (MU_X * MU_Y + NT - 1) / NT, NEW = (MW_X * MW_Y + NT - 1) / NT;   // elements per thread
+  const int tile_u = (i0 - 3 + H) + sx * (j0 - 3 + H), tile_w = (i0 - 2 + H) + sx * (j0 - 2 + H);
+  int eu_off[NEU], eu_lds[NEU], ew_off[NEW], ew_lds[NEW];   // global offset within the tile plane / LDS index
+#pragma unroll
+  for (int q = 0; q < NEU; q++) {
+    int e = tid + q * NT;
+    int ey = e / MU_X, ex = e - ey * MU_X;
+    // clamp to the parent array (ragged tiles): columns <= Nx+H-1, rows <= Ny+H-1 relative to the tile origin
+    eu_off[q] = (e < MU_X * MU_Y) ? (min(ex, g.Nx + H + 2 - i0) + sx * min(ey, g.Ny + H + 2 - j0)) * (int)sizeof(real) : -1;
+    eu_lds[q] = e;
+  }
+#pragma unroll
+  for (int q = 0; q < NEW; q++) {
+    int e = tid + q * NT;
+    int ey = e / MW_X, ex = e - ey * MW_X;
+    ew_off[q] = (e < MW_X * MW_Y) ? (min(ex, g.Nx + H + 1 - i0) + sx * min(ey, g.Ny + H + 1 - j0)) * (int)sizeof(real) : -1;
+    ew_lds[q] = e;
+  }
+  real ru[NEU], rv[NEU], rw[NEW], rpw = real(0.), rps = real(0.);
+  // (uniform base pointer + 32-bit per-lane byte offset: the loads take the scalar-base addressing form and need no
+  // 64-bit address arithmetic per lane)
+  auto fetch = [&](int k, unsigned oob) {   // oob: byte offset of the own cell at level k
+    const real* ub = u + (tile_u + pc * (k + H));
+    const real* vb = v + (tile_u + pv * (k + H));
+    const real* wb = w + (tile_w + pc * (k + 1 + H));
+#pragma unroll
+    for (int q = 0; q < NEU; q++)
+      if (eu_off[q] >= 0) {
+        ru[q] = at(ub, (unsigned)eu_off[q]);
+        rv[q] = at(vb, (unsigned)eu_off[q]);
+      }
+#pragma unroll
+    for (int q = 0; q < NEW; q++)
+      if (ew_off[q] >= 0) rw[q] = at(wb, (unsigned)ew_off[q]);
+    rpw = at(dpx, oob);   // p'(i) - p'(i-1) and p'(j) - p'(j-1), differenced in fp64 by k_compute_p
+    rps = at(dpy, oob);
+  };
+  auto stash = [&](int par) {
+    real* U0 = &lds.U[par][0][0];
+    real* V0 = &lds.V[par][0][0];
+    real* W0 = &lds.W[par][0][0];
+#pragma unroll
+    for (int q = 0; q < NEU; q++)
+      if (eu_off[q] >= 0) {
+        U0[eu_lds[q]] = ru[q];
+        V0[eu_lds[q]] = rv[q];
+      }
+#pragma unroll
+    for (int q = 0; q < NEW; q++)
+      if (ew_off[q] >= 0) W0[ew_lds[q]] = rw[q];
+  };
+  real sAu = real(0.), sAv = real(0.), sIu = real(0.), sIv = real(0.);   // AHEAD: this chunk's column sums
+  // per-block tables for phase 1: packed (row << 8 | column) of every derived point, and the metrics of the rows
+  // mdxc[py] = dxc(j0-3+py), mrazf[py] = razf(j0-2+py), mdxf[py] = dxf(j0-3+py)
+  __shared__ int ptab[MD_X * MD_Y];
+  __shared__ real mdxc[MD_Y + 1], mrazf[MD_Y], mdxf[MD_Y + 1];
+  for (int e = tid; e < MD_X * MD_Y; e += NT) {
+    const int py = e / MD_X;
+    ptab[e] = (py << 8) | (e - py * MD_X);
+  }
+  if (tid <= MD_Y) {
+    mdxc[tid] = g.dxc[j0 - 3 + tid];
+    mdxf[tid] = g.dxf[j0 - 3 + tid];
+    if (tid < MD_Y) mrazf[tid] = g.razf[j0 - 2 + tid];
+  }
+  fetch(k0, ob);
+  stash(k0 & 1);
+  real pw_ = rpw, ps_ = rps;   // p'(i,j) - p'(i-1,j) and p'(i,j) - p'(i,j-1) of the current level
+  __syncthreads();
+
+  for (int k = k0; k < k1; k++) {
+    const int par = k & 1;
+    const real dz = g.dzc[k];
+    // ---- phase 0: issue the loads of the next level's tiles (consumed at the end of this iteration)
+    const bool more = (k + 1 < k1);
+    if (more) fetch(k + 1, ob + (unsigned)pc * SZ);
+    const real unew = at(u, ob + 4u * (unsigned)pc * SZ), vnew = at(v, obv + 4u * (unsigned)pv * SZ);
+    // ---- phase 1: derived quantities, once per point.  (row, column) of a point and the row metrics come from the
+    // small LDS tables filled once per block: an integer division and five global loads per point and level otherwise
+    for (int e = tid; e < MD_X * MD_Y; e += NT) {
+      const int pk = ptab[e];
+      const int py = pk >> 8, px = pk & 255;
+      // (f,f,c) point (i0-2+px, j0-2+py)
+      {
+        real uc = lds.U[par][py + 1][px + 1], us = lds.U[par][py][px + 1];
+        real vc = lds.V[par][py + 1][px + 1], vw = lds.V[par][py + 1][px];
+        lds.Z[py][px] = ((dy * vc - dy * vw) - (mdxc[py + 1] * uc - mdxc[py] * us)) * mrazf[py];
+        lds.UQ[py][px] = real(0.5) * (us + uc);
+        lds.VQ[py][px] = real(0.5) * (vw + vc);
+      }
+      // (c,c,c) point (i0-3+px, j0-3+py)
+      {
+        const real Ax = dy * dz;
+        lds.DU[py][px] = Ax * lds.U[par][py][px + 1] - Ax * lds.U[par][py][px];
+        lds.DV[py][px] = mdxf[py + 1] * dz * lds.V[par][py + 1][px] - mdxf[py] * dz * lds.V[par][py][px];
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: the two tendencies of cell (i,j,k)
+    // tile accessors relative to (i,j)
+#define UT(di, dj) lds.U[par][ty + 3 + (dj)][tx + 3 + (di)]
+#define VT(di, dj) lds.V[par][ty + 3 + (dj)][tx + 3 + (di)]
+#define WT(di, dj) lds.W[par][ty + 2 + (dj)][tx + 2 + (di)]
+#define ZF(A, di, dj) lds.A[ty + 2 + (dj)][tx + 2 + (di)]
+#define DC(A, di, dj) lds.A[ty + 3 + (dj)][tx + 3 + (di)]
+    real gu, gv;
+    const int ozt = biased_order_face(k + 1, g.Nz);
+    const real rdz = g.rdzc[k];
+    {
+      // Packed evaluation: the eight reconstructions of the cell are done as four PAIRS that share stencil shape
+      // and order, (.x, .y) = (a term of G_u, a term of G_v); see real2v in device_common.hpp.
+      const real vws = VT(-1, 0), vwn = VT(-1, 1), vcs = VT(0, 0), vcn = VT(0, 1);
+      const real vhat_u = (real(0.5) * (dxf_s * vws + dxf_n * vwn) + real(0.5) * (dxf_s * vcs + dxf_n * vcn)) * real(0.5) * rdxc_j;
+      const real uhat_v =
+          (real(0.5) * (dy * UT(0, -1) + dy * UT(1, -1)) + real(0.5) * (dy * UT(0, 0) + dy * UT(1, 0))) * real(0.5) * g.rdy;
+      const real uhat_u = uz[3], vhat_v = vz[3];
+
+      // (1) vorticity flux: zeta reconstructed in y for G_u (centre order) and in x for G_v (order 5)
+      real hadv_u, hadv_v;
+      if (oc_y == 5) {
+        real2v zq[6], uq[6], vq[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          zq[m] = v2(ZF(Z, 0, m - 2), ZF(Z, m - 2, 0));
+          uq[m] = v2(ZF(UQ, 0, m - 2), ZF(UQ, m - 2, 0));
+          vq[m] = v2(ZF(VQ, 0, m - 2), ZF(VQ, m - 2, 0));
+        }
+        const real2v z = biased6p<true>(5, vhat_u > real(0.), uhat_v > real(0.), zq, uq, vq);
+        hadv_u = -vhat_u * z.x;
+        hadv_v = uhat_v * z.y;
+      } else {
+        real zq[6], uq[6], vq[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          zq[m] = ZF(Z, 0, m - 2);
+          uq[m] = ZF(UQ, 0, m - 2);
+          vq[m] = ZF(VQ, 0, m - 2);
+        }
+        hadv_u = -vhat_u * biased6<true>(oc_y, vhat_u > real(0.), zq, uq, vq);
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          zq[m] = ZF(Z, m - 2, 0);
+          uq[m] = ZF(UQ, m - 2, 0);
+          vq[m] = ZF(VQ, m - 2, 0);
+        }
+        hadv_v = uhat_v * biased6<true>(5, uhat_v > real(0.), zq, uq, vq);
+      }
+
+      // (2) G_u: divergence flux and Bernoulli head, both upwinded in x by u (order 5, one direction for the pair)
+      real duR, dKu_u;
+      {
+        real2v qq[6], ss[6];
+        real u7[7];
+#pragma unroll
+        for (int m = 0; m < 7; m++) u7[m] = UT(m - 3, 0);
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          const real Du = DC(DU, m - 3, 0);
+          qq[m] = v2(Du, real(0.5) * u7[m + 1] * u7[m + 1] - real(0.5) * u7[m] * u7[m]);
+          ss[m] = v2(Du + DC(DV, m - 3, 0), real(0.5) * (u7[m] + u7[m + 1]));
+        }
+        const bool l = uhat_u > real(0.);
+        const real2v rr = biased6p<false>(5, l, l, qq, ss, ss);
+        duR = rr.x;
+        dKu_u = rr.y;
+      }
+      // (3) G_v: the same two terms, upwinded in y by v (face order)
+      real dvR, dKv_v;
+      {
+        real2v qq[6], ss[6];
+        real v7[7];
+#pragma unroll
+        for (int m = 0; m < 7; m++) v7[m] = VT(0, m - 3);
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          const real Dv = DC(DV, 0, m - 3);
+          qq[m] = v2(Dv, real(0.5) * v7[m + 1] * v7[m + 1] - real(0.5) * v7[m] * v7[m]);
+          ss[m] = v2(DC(DU, 0, m - 3) + Dv, real(0.5) * (v7[m] + v7[m + 1]));
+        }
+        const bool l = vhat_v > real(0.);
+        const real2v rr = biased6p<false>(of_y, l, l, qq, ss, ss);
+        dvR = rr.x;
+        dKv_v = rr.y;
+      }
+      // (4) vertical advection of u and v: same order, own directions
+      const real wt_u = sym_interp(true, Az * WT(-2, 0), Az * WT(-1, 0), Az * WT(0, 0), Az * WT(1, 0));
+      const real wt_v = sym_interp(s4f_y, az_m2 * WT(0, -2), az_m1 * WT(0, -1), Az * WT(0, 0), az_p1 * WT(0, 1));
+      real2v zz[6];
+#pragma unroll
+      for (int m = 0; m < 6; m++) zz[m] = v2(uz[m + 1], vz[m + 1]);
+      const real2v ftp = v2(wt_u, wt_v) * biased6p<false>(ozt, wt_u > real(0.), wt_v > real(0.), zz, zz, zz);
+
+      {  // ---------------- assemble G_u at (f,c,c)
+        real Dv4[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) Dv4[m] = DC(DV, m - 2, 0);
+        const real dvs = sym_interp(true, Dv4[0], Dv4[1], Dv4[2], Dv4[3]);
+        const real phi = uhat_u * (dvs + duR);
+        const real vadv = (phi + (ftp.x - fzu)) * (razc_j * rdz);
+        fzu = ftp.x;
+        real a4[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          real vc = VT(0, m - 1), vw = VT(-1, m - 1);
+          a4[m] = real(0.5) * vc * vc - real(0.5) * vw * vw;
+        }
+        const real dKv = sym_interp(s4c_y, a4[0], a4[1], a4[2], a4[3]);
+        const real bern = (dKu_u + dKv) * rdxc_j;
+        const real cor = -fbar * vhat_u;
+        const real dpdx = pw_ * rdxc_j;
+        gu = -(hadv_u + vadv + bern) - cor - dpdx;
+      }
+      {  // ---------------- assemble G_v at (c,f,c)
+        real Du4[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) Du4[m] = DC(DU, 0, m - 2);
+        const real dus = sym_interp(s4f_y, Du4[0], Du4[1], Du4[2], Du4[3]);
+        const real phi = vhat_v * (dus + dvR);
+        const real vadv = (phi + (ftp.y - fzv)) * (razf_j * rdz);
+        fzv = ftp.y;
+        real a4[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          real un = UT(m - 1, 0), us = UT(m - 1, -1);
+          a4[m] = real(0.5) * un * un - real(0.5) * us * us;
+        }
+        const real dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
+        const real bern = (dKv_v + dKu) * g.rdy;
+        const real cor = fcor_j * uhat_v;
+        const real dpdy = ps_ * g.rdy;
+        gv = -(hadv_v + vadv + bern) - cor - dpdy;
+      }
+    }
+#undef UT
+#undef VT
+#undef WT
+#undef ZF
+#undef DC
+    if (inside) {
+      put(Gu, ob, gu);
+      put(Gv, obv, gv);
+      if (AHEAD) {
+        const real au = rfma(next.C1, gu, -(next.C2 * at(next.GmU, ob))), av = rfma(next.C1, gv, -(next.C2 * at(next.GmV, obv)));
+        const real un = rfma(next.dt, au, uz[3]), vn = rfma(next.dt, av, vz[3]);
+        put(next.un, ob, un);
+        put(next.vn, obv, vn);
+        sAu = (k == k0) ? dz * au : rfma(dz, au, sAu);
+        sAv = (k == k0) ? dz * av : rfma(dz, av, sAv);
+        sIu = (k == k0) ? dz * un : rfma(dz, un, sIu);
+        sIv = (k == k0) ? dz * vn : rfma(dz, vn, sIv);
+      }
+    }
+    ob += (unsigned)pc * SZ;
+    obv += (unsigned)pv * SZ;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      uz[m] = uz[m + 1];
+      vz[m] = vz[m + 1];
+    }
+    uz[6] = unew;
+    vz[6] = vnew;
+    if (more) {
+      stash(par ^ 1);
+      pw_ = rpw;
+      ps_ = rps;
+    }
+    __syncthreads();   // next tiles visible; derived arrays free for the next phase 1
+  }
+  if (AHEAD && inside) {
+    const long o2 = i2(g, i, j), q = (long)kchunks * next.plane2, c = (long)kc * next.plane2;
+    next.P[c + o2] = sAu;
+    next.P[q + c + o2] = sAv;
+    next.P[2 * q + c + o2] = sIu;
+    next.P[3 * q + c + o2] = sIv;
+  }
+}
+
+constexpr int V3_OUT = 63;   // outputs per wavefront
+
+// AHEAD: the kernel also writes the tracers of the next time level, Tn = T + dt (C1 G^n - C2 G^-), into a second
+// pair of arrays: at this point T and the fresh G^n are in registers, so the next step's ab2_step_field! for T and S
+// costs one read (G^-) and one write per tracer here instead of a separate 3R + 1W sweep.  The host adopts Tn/Sn
+// (pointer exchange) at the next ab2_step! if dt, chi and the inputs are still the ones used here.
+struct Ab2Ahead {
+  const real *GmT, *GmS;
+  real *Tn, *Sn;
+  real dt, C1, C2;
+};
+
+// =============================================================================================
+// Tracer tendencies: wave-autonomous (no LDS, no barriers).  A wavefront owns 63 consecutive cells of one row (lane
+// 63 only supplies the east face of lane 62), marches up the column, reconstructs the WEST face once (the east face
+// arrives from lane+1 by a wave shuffle), the TOP face once (bottom = carried) and both y faces: 8 reconstructions per
+// cell instead of 12.  T and S are carried as ONE two-wide value per stencil point.  Both tracers see the same advecting velocity, the same
+// upwind direction and the same (wave-uniform) wall-adjacent order, so every reconstruction is evaluated once on
+// register pairs: the smoothness indicators, polynomials and weights become v_pk_fma/mul/add_f32, which do two lanes'
+// worth of fp32 work per issue slot (device_common.hpp, real2v).  Only rcp, min, abs and the upwind selects stay
+// per-half.
+// =============================================================================================
+template <int MINW, bool AHEAD>
+__global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, const real* __restrict__ u,
+                                                              const real* __restrict__ v,
+                                                              const real* __restrict__ w,
+                                                              const real* __restrict__ T, const real* __restrict__ S,
+                                                              real* __restrict__ GT, real* __restrict__ GS, int nbx,
+                                                              int kchunks, int nb, Ab2Ahead next) {
+  const int L = xcd_remap(blockIdx.x, nb);
+  const int bx = L % nbx, r = L / nbx;
+  const int kc = r % kchunks, by = r / kchunks;
+  const int klen = (g.Nz + kchunks - 1) / kchunks;
+  const int k0 = kc * klen, k1 = min(g.Nz, k0 + klen);
+  const int lane = threadIdx.x;
+  const int i = bx * V3_OUT + lane, j = by * blockDim.y + threadIdx.y;
+  if (j >= g.Ny) return;                       // whole wave (one row) leaves together: no barriers in this kernel
+  const bool writes = (lane < V3_OUT) && (i < g.Nx);
+  const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
+  const real dy = g.dy, Az = g.azc[j], dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], razc_j = g.razc[j];
+  const int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny);
+
+  // buffer views (device_common.hpp): one per-lane byte offset for the centre-shaped arrays, one for v
+  constexpr int SZ = (int)sizeof(real);
+  const long nzp = g.Nz + 2 * g.H;
+  const Buf bT = make_buf(T, pc * nzp), bS = make_buf(S, pc * nzp), bu = make_buf(u, pc * nzp),
+            bw = make_buf(w, pc * (nzp + 1)), bv = make_buf(v, pv * nzp), bGT = make_buf(GT, pc * nzp),
+            bGS = make_buf(GS, pc * nzp);
+  Buf bGmT = bT, bGmS = bT, bTn = bT, bSn = bT;
+  if (AHEAD) {
+    bGmT = make_buf(next.GmT, pc * nzp); bGmS = make_buf(next.GmS, pc * nzp);
+    bTn = make_buf(next.Tn, pc * nzp);   bSn = make_buf(next.Sn, pc * nzp);
+  }
+  // lanes past the east edge work on a clamped (duplicate) column.  `vo` addresses the (-3,-3,-3) corner of the
+  // cell's stencil so that every displacement below is a non-negative byte count (needs H >= 3, as WENO5 does).
+  const int cc = (3 * pc + 3 * sx + 3) * SZ;                    // corner -> cell
+  int vo = (ic(g, min(i, g.Nx), j, k0)) * SZ - cc;
+  int vov = iv(g, min(i, g.Nx), j, k0) * SZ;
+#define CZ(m) (((m) * pc + 3 * sx + 3) * SZ)                     // (0, 0, m-3)
+#define CY(m) ((3 * pc + (m) * sx + 3) * SZ)                     // (0, m-3, 0)
+#define CX(m) ((3 * pc + 3 * sx) * SZ), ((m) * SZ)               // (m-3, 0, 0): uniform part, immediate part
+  real2v cz[7];                                // vertical window of (T, S)
+#pragma unroll
+  for (int m = 0; m < 7; m++) cz[m] = v2(bload(bT, vo, CZ(m)), bload(bS, vo, CZ(m)));
+  real2v fz;
+  {
+    real Azw = Az * bload(bw, vo, cc);
+    int ord = biased_order_face(k0, g.Nz);
+    fz = Azw * biased6<false, real2v>(ord, Azw > real(0.), cz, cz, cz);
+  }
+  for (int k = k0; k < k1; k++) {
+    const real dz = g.dzc[k];
+    const real Axu = dy * dz * bload(bu, vo, cc);
+    const real Ays = dxf_s * dz * bload(bv, vov, 0), Ayn = dxf_n * dz * bload(bv, vov, sx * SZ);
+    const real Azw = Az * bload(bw, vo, cc + pc * SZ);
+    real2v q[7];
+#pragma unroll
+    for (int m = 0; m < 6; m++) q[m] = v2(bload(bT, vo + m * SZ, (3 * pc + 3 * sx) * SZ), bload(bS, vo + m * SZ, (3 * pc + 3 * sx) * SZ));
+    const real2v fx = Axu * biased6<false, real2v>(5, Axu > real(0.), q, q, q);
+#pragma unroll
+    for (int m = 0; m < 7; m++) q[m] = v2(bload(bT, vo, CY(m)), bload(bS, vo, CY(m)));
+    const real2v fs = Ays * biased6<false, real2v>(oys, Ays > real(0.), q, q, q);
+    const real2v fn = Ayn * biased6<false, real2v>(oyn, Ayn > real(0.), q + 1, q + 1, q + 1);
+    // top face from the vertical window
+    const int ozt = biased_order_face(k + 1, g.Nz);
+    const real2v ft = Azw * biased6<false, real2v>(ozt, Azw > real(0.), cz + 1, cz + 1, cz + 1);
+    // east faces = west faces of the next lane
+    const real2v fe = v2(__shfl_down(fx.x, 1), __shfl_down(fx.y, 1));
+    if (writes) {
+      const real rV = razc_j * g.rdzc[k];
+      const real2v G = -(((fe - fx) + (fn - fs) + (ft - fz)) * rV);
+      bstore(bGT, vo, cc, G.x);
+      bstore(bGS, vo, cc, G.y);
+      if (AHEAD) {   // T, S of the NEXT step while T, S (cz[3]) and the new tendency are in registers
+        bstore(bTn, vo, cc, ab2_advance(cz[3].x, G.x, bload(bGmT, vo, cc), next.dt, next.C1, next.C2));
+        bstore(bSn, vo, cc, ab2_advance(cz[3].y, G.y, bload(bGmS, vo, cc), next.dt, next.C1, next.C2));
+      }
+    }
+    fz = ft;
+    vo += pc * SZ;
+    vov += pv * SZ;
+#pragma unroll
+    for (int m = 0; m < 6; m++) cz[m] = cz[m + 1];
+    cz[6] = v2(bload(bT, vo, CZ(6)), bload(bS, vo, CZ(6)));
+  }
+#undef CZ
+#undef CY
+#undef CX
+}
+
+}  // namespace gb25

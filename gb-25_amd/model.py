@@ -162,6 +162,7 @@ def baroclinic_instability_model(arch, Nx=None, Ny=None, Nz=None, *, dt, halo=(8
     H = halo[0] if isinstance(halo, (tuple, list)) else halo
     if isinstance(halo, (tuple, list)) and len(set(halo)) != 1:
         raise ValueError("halo must be the same in every direction")
+    # backend_kw: `options` (schedule switches, binding.OPTION_IDS) and overrides of gb25_config fields
     backend = arch(Nx, Ny, Nz, dt=dt, halo=H, substeps=substeps, **backend_kw)
     model = HydrostaticFreeSurfaceModel(backend, Nx, Ny, Nz, H)
     model.free_surface.substeps = substeps
@@ -196,6 +197,7 @@ def compute_interior_momentum_tendencies_workload(model): model.backend.compute_
 def compute_interior_tracer_tendencies_workload(model): model.backend.compute_tracer_tendencies()
 def compute_auxiliaries_workload(model): model.backend.compute_auxiliaries()
 def fill_halo_regions_workload(model): model.backend.fill_diffusivity_halos()
+def mask_immersed_model_fields_workload(model): model.backend.mask_immersed_fields()
 def ab2_step_workload(model, dt): model.backend.ab2_step(dt, False)
 def correct_velocities_and_cache_previous_tendencies_workload(model, dt):
     model.backend.correct_velocities_and_cache_previous_tendencies(dt)

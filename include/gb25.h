@@ -43,7 +43,8 @@ typedef enum {
   GB25_ERR_HIP = 2,          /* a HIP runtime call failed; see gb25_last_error_string */
   GB25_ERR_OUT_OF_MEMORY = 3,
   GB25_ERR_NO_DEVICE = 4,    /* no gfx950 device visible: there is NO CPU fallback */
-  GB25_ERR_STATE = 5
+  GB25_ERR_STATE = 5,
+  GB25_ERR_COMM = 6          /* RCCL could not be loaded / a communicator or exchange call failed */
 } gb25_status;
 
 /* Field identifiers: the set compared by compare_states (src/correctness.jl:28-90)
@@ -75,7 +76,30 @@ typedef struct {
   double lon_west, lon_east;   /* (0, 360) */
   double depth, zexp_h;        /* exponential_z_faces(Nz, depth=4000, h=30) */
   double g, Omega, radius, rho0; /* 9.80665, 7.292115e-5, 6371e3, 1020 (TEOS-10 reference) */
+  int32_t slab_mode;    /* 0: the x halos are a local periodic copy when nranks == 1 and come from the ring neighbours
+                              when nranks > 1;  1: always by exchange (nranks == 1: the slab is its own west and east
+                              neighbour -- the self-ring that runs the exchange code path on one GPU) */
+  int32_t grid_type;    /* gb25_grid_type: grid_type = :simple_lat_lon | :gaussian_islands
+                              (src/baroclinic_instability_model.jl:19,59-65) */
 } gb25_config;
+
+typedef enum {
+  GB25_GRID_LAT_LON = 0            /* simple_latitude_longitude_grid (src/model_utils.jl:56-65), flat bottom */
+} gb25_grid_type;
+
+/* Per-model switches (gb25_set_option).  Defaults in brackets.  None of them changes results beyond the last bits
+ * (KERNELS) or at all (the rest): they select schedules, and tests use them to prove exactly that. */
+typedef enum {
+  GB25_OPT_KERNELS = 0,          /* [2] 2: LDS-staged / flux-sharing tendency kernels; 1: direct-stencil kernels (cross-check) */
+  GB25_OPT_AB2_LOOKAHEAD,        /* [1] the tendency kernels also write the next time level: 0 off, 1 u,v,T,S, 2 T,S only */
+  GB25_OPT_SUBCYCLE_LOOKAHEAD,   /* [1 from 8 M cells and on slabs] next step's split-explicit sub-cycle beside the tracer kernel */
+  GB25_OPT_SUBCYCLE_BLOCK,       /* [7] substeps per barotropic launch: 1, 3, 5, 7 */
+  GB25_OPT_FILL_FUSED,           /* [1] y, z and periodic-x halo fills in one launch */
+  GB25_OPT_TWO_STREAMS,          /* [1] tracer branch (AB2, halos, pressure) on a second stream */
+  GB25_OPT_STORE_PRESSURE,       /* [0] store pHY' every step (1) or only its differences, pHY' on demand (0) */
+  GB25_OPT_SPLIT_TENDENCIES,     /* [1] slab: interior tile columns of the momentum tendencies before the halos arrive */
+  GB25_OPT_COUNT
+} gb25_option;
 
 /* Metric identifiers for gb25_get_metric (diagnostics / tests). */
 typedef enum {
@@ -104,6 +128,8 @@ int32_t gb25_real_bytes(void); /* sizeof one field element of THIS library: 4 (F
  * default stream, which is what torch.cuda.current_stream() is unless the host changed it).  Lets a host
  * framework order our kernels with its own work.  gb25_use_own_stream goes back to the model's private
  * non-blocking stream (the state after gb25_create). */
+gb25_status gb25_set_option(gb25_model *m, gb25_option opt, int32_t value);
+gb25_status gb25_get_option(const gb25_model *m, gb25_option opt, int32_t *value);
 gb25_status gb25_set_stream(gb25_model *m, void *hip_stream);
 gb25_status gb25_use_own_stream(gb25_model *m);
 gb25_status gb25_synchronize(gb25_model *m);
@@ -122,7 +148,7 @@ gb25_status gb25_get_field(gb25_model *m, gb25_field f, void *host, int include_
  * the library.
  * GB25_PHY is a diagnostic: inside the composite steps only its horizontal differences (what the momentum tendencies
  * use) are stored, and gb25_get_field(GB25_PHY) recomputes the field from T and S on demand; asking for its device
- * pointer makes every later step store it (GB25_LAZY_PHY=0 in the environment does the same from the start). */
+ * pointer makes every later step store it (GB25_OPT_STORE_PRESSURE = 1 does the same from the start). */
 gb25_status gb25_field_device_ptr(gb25_model *m, gb25_field f, void **dev);
 gb25_status gb25_get_metric(const gb25_model *m, gb25_metric id, int32_t logical_index, double *value);
 gb25_status gb25_get_substepping(const gb25_model *m, int32_t *n_effective, double *dtau_fraction,
@@ -149,6 +175,7 @@ gb25_status gb25_compute_tendencies(gb25_model *m);      /* src/precompile.jl:38
 gb25_status gb25_ab2_step(gb25_model *m, double dt, int euler); /* src/precompile.jl:39,121-123 ab2_step_workload! */
 gb25_status gb25_correct_velocities_and_cache_previous_tendencies(gb25_model *m, double dt); /* src/precompile.jl:41,125-127 */
 gb25_status gb25_update_state(gb25_model *m);            /* Oceananigans.TimeSteppers.update_state! (correctness/..._run.jl:53-54) */
+/* (the phase entry points are for single-domain models; on a slab of a decomposition only the composites are valid) */
 
 /* ---- composites: GordonBell25.first_time_step!/time_step!/loop! (src/timestepping_utils.jl:21-45).
  *      dt is read from the clock, the model is mutated in place, nothing is returned. */
@@ -156,40 +183,43 @@ gb25_status gb25_first_time_step(gb25_model *m);
 gb25_status gb25_time_step(gb25_model *m);
 gb25_status gb25_loop(gb25_model *m, int32_t n_inner);
 
-/* ---- x-slab halo exchange: pack the columns a neighbour needs into a contiguous device
- *      buffer / unpack received columns into the halo.  The host moves the buffers (RCCL send/recv through
- *      torch.distributed in this repository).  Kernels run on the stream given to gb25_set_stream.
- *      group 0: H columns of the 3-D bundle u, v, T, S (all parent rows)      -> x halos
- *      group 1: W = Ns+1 columns of eta, U, V, G.U, G.V                       -> wide barotropic halos
- *      group 2: H columns of eta, U, V                                        -> x halos
- *      groups 3, 4: groups 1, 2 of the sub-cycle look-ahead (next step's G.U, G.V; partner buffers of eta, U, V)
- *      side: 0 = west, 1 = east.  For pack, `side` is the side of THIS slab whose interior columns are packed;
- *      for unpack it is the halo side that is filled. */
-gb25_status gb25_halo_buffer_elems(const gb25_model *m, int group, int64_t *n_elements);
-gb25_status gb25_halo_pack(gb25_model *m, int group, int side, void *dev_buffer);
-gb25_status gb25_halo_unpack(gb25_model *m, int group, int side, const void *dev_buffer);
-/* Both sides of a group in ONE kernel launch (what the staged step uses: a group is up to ten small strips). */
-gb25_status gb25_halo_pack_both(gb25_model *m, int group, void *west_buffer, void *east_buffer);
-gb25_status gb25_halo_unpack_both(gb25_model *m, int group, const void *west_buffer, const void *east_buffer);
-/* The time step of one slab, cut at its exchange points (gb25_time_step does all of it when nranks == 1):
- *   stage 0: AB2 update of u,v,T,S (adopting the look-aheads), y/z layers of the 3-D bundle; starts the pressure of
- *            the slab's own columns on the side stream.  If the sub-cycle look-ahead of the previous step is valid it
- *            is adopted here (gb25_lookahead_state says so) and stage 1 and groups 1, 2 are skipped
- *            -> pack + exchange group 0 (second stream) [and group 1 first, on the compute stream, if not adopted]
- *   stage 1: [group 1 unpacked] split-explicit substeps on the widened slab; y layer of eta, U, V
- *            -> pack + exchange group 2 (in flight during stage 2)
- *   stage 2: barotropic corrector on the slab's own columns (needs no halo data)
- *   stage 3: [groups 2 and 0 unpacked] corrector on the x-halo columns, w, pressure strips, momentum tendencies
- *   stage 4: tracer tendencies.  Beside them, on the second stream, the look-ahead of the NEXT sub-cycle:
- *            pack + exchange group 3 (= group 1 with G.U, G.V of the next step) -> stage 5 -> pack + exchange group 4
- *   stage 5: [group 3 unpacked] the next step's substeps into the partner buffers of eta, U, V and the filtered state
- * Every rank of a run must take the same branch (they do when dt, chi and the host's writes are the same everywhere). */
-gb25_status gb25_time_step_stage(gb25_model *m, int stage, int euler);
-/* velocities_ready: the momentum look-ahead of the next step exists (stage 5 may run); subcycle_adopted: stage 0 of
- * the current step adopted the sub-cycle look-ahead. */
+/* ---- x-slab decomposition.  Replaces Oceananigans.Distributed(arch; partition=Partition(Rx,
+ *      Ry, 1)) + XLA's collective-permutes (sharding/sharded_baroclinic_instability_simulation_run.jl:65-72): each rank
+ *      creates ONE slab (cfg.rank, cfg.nranks; Nx is the global size) and gives it an exchange context; after that
+ *      gb25_first_time_step / gb25_time_step / gb25_loop are valid on the slab and `loop!(model, Ninner)` stays ONE
+ *      call, as in the reference (:147,162).  Inside a step: packed halo columns travel by ncclSend/ncclRecv (RCCL over
+ *      xGMI) on a second HIP stream, overlapped with the own-column work and the interior momentum tendencies; the 21
+ *      barotropic substeps need no exchange (wide halos, filled once).  No collective, no host synchronisation.
+ *
+ *      Setters of a decomposed model (gb25_set_field, gb25_set_dt, gb25_set_option, gb25_set_baroclinic_instability,
+ *      gb25_field_device_ptr) are COLLECTIVE: every rank makes the same call in the same order, like set!(model, ...)
+ *      on a Distributed grid.  With the RCCL transport they shake hands with both neighbours and return
+ *      GB25_ERR_STATE on a mismatch. */
+#define GB25_UNIQUE_ID_BYTES 128
+/* rank 0 calls this and hands the 128 bytes to every rank by whatever means the host has (MPI_Bcast, a torch.distributed
+ * store, a file): ncclGetUniqueId */
+gb25_status gb25_comm_unique_id(void *id_out);
+/* every rank, with the same id: ncclCommInitRank(nranks = cfg.nranks, rank = cfg.rank) on cfg.device.  nranks == 1 with
+ * slab_mode == 1 is the self-ring. */
+gb25_status gb25_comm_init_rccl(gb25_model *m, const void *unique_id);
+/* all `n` slabs of one decomposition live in THIS process on one device (tests of decomposition invariance; also a
+ * single-process multi-slab run): slabs[r] must have cfg.rank == r, cfg.nranks == n.  The composites called on ANY of
+ * them step all of them in lock-step; the exchange is a ring of device-to-device copies. */
+gb25_status gb25_comm_init_local(gb25_model *const *slabs, int32_t n);
+/* the host moves the buffers: fn is called once per exchange with device pointers of this slab's two packed sends and
+ * two receive buffers (nbytes each); it must return 0 after recv_west holds the west neighbour's send_east and
+ * recv_east the east neighbour's send_west.  The library synchronises the issuing stream before the call (no overlap):
+ * a rehearsal transport for setups where RCCL cannot run (two ranks on one device). */
+typedef int32_t (*gb25_exchange_fn)(void *user, int32_t buffer_set, const void *send_west, const void *send_east,
+                                    void *recv_west, void *recv_east, int64_t nbytes);
+gb25_status gb25_comm_init_callback(gb25_model *m, gb25_exchange_fn fn, void *user);
+gb25_status gb25_comm_finalize(gb25_model *m);
+/* velocities_ready: the momentum look-ahead of the next step exists (its sub-cycle can run beside the tracer kernel);
+ * subcycle_adopted: the last step adopted the sub-cycle look-ahead instead of sub-cycling inside the step. */
 gb25_status gb25_lookahead_state(const gb25_model *m, int32_t *velocities_ready, int32_t *subcycle_adopted);
-gb25_status gb25_update_state_local(gb25_model *m); /* update_state! without the x-halo fill */
-gb25_status gb25_fill_halo_regions_local(gb25_model *m); /* y/z boundary halos only */
+/* The order of operations of one time step (first != 0: of first_time_step!) of `nslabs` slabs as text, without
+ * touching a GPU (tests of the sequencing on CPU-only machines).  Returns the bytes needed, incl. the terminator. */
+int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int32_t ready, char *out, int64_t cap);
 
 /* ---- built-in per-kernel HIP-event timing (bench.py's roofline numbers) */
 gb25_status gb25_profile_enable(gb25_model *m, int on); /* 0: off, 1: every kernel, 2 + k: kernel k alone */

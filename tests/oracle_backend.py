@@ -214,4 +214,5 @@ class CPU:
 
     def __call__(self, Nx, Ny, Nz, **kw):
         kw.pop("device", None)
+        kw.pop("options", None)        # schedule switches of the HIP library: meaningless for the oracle
         return OracleBackend(Nx, Ny, Nz, precision=self.precision, **kw)

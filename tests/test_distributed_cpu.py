@@ -1,5 +1,7 @@
 """The N>1 path on CPU: the ring-exchange protocol under torch.distributed (gloo, world_size 2 and 3) and the
-order in which one slab's time step cuts into stages, packs, exchanges and unpacks."""
+order in which the LIBRARY sequences one time step of a decomposition into stages, packs, exchanges, unpacks and stream
+dependencies (a dry run of csrc/slab_step.hpp's sequencer through the C ABI: no GPU needed)."""
+import ctypes
 import os
 import socket
 
@@ -8,8 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gb25_amd.distributed import (EAST, WEST, LocalRingTransport, SlabStepper, TorchDistributedTransport,
-                                  first_step_slabs, step_slabs)
+from gb25_amd.binding import load_library
+from gb25_amd.distributed import TorchDistributedTransport
 from gb25_amd.sharding import slab_neighbours
 
 
@@ -53,114 +55,82 @@ def test_ring_exchange_gloo(world):
     assert all(results.get(r) for r in range(world))
 
 
-class _RecordingBackend:
-    """Stands in for HipBackend: records the call order and moves tagged 'columns' through the buffers."""
-
-    def __init__(self, rank, log):
-        self.rank, self.log = rank, log
-        self.unpacked = {}
-
-    ready = False        # velocity look-ahead of the next step exists (stage 5 may run)
-    adopted = False      # stage 0 adopted the sub-cycle look-ahead
-
-    def halo_buffer_elems(self, group): return 4
-    def set_stream(self, s): pass
-    def lookahead_state(self): return (self.ready, self.adopted)
-    def _rec(self, *a): self.log.append((self.rank,) + a)
-    def time_step_stage(self, stage, euler=False): self._rec("stage", stage, bool(euler))
-    def initialize(self): self._rec("initialize")
-    def fill_halo_regions_local(self): self._rec("fill_local")
-    def update_state_local(self): self._rec("update_state_local")
-
-    def halo_pack(self, group, side, ptr):
-        self._rec("pack", group, side)
-        self.bufs_send[group][side].fill_(self.rank * 100 + group * 10 + side)
-
-    def halo_unpack(self, group, side, ptr):
-        self._rec("unpack", group, side)
-        self.unpacked[(group, side)] = float(self.bufs_recv[group][side][0])
-
-    def halo_pack_both(self, group, west_ptr, east_ptr):        # one launch for both sides in the product
-        for side in (WEST, EAST):
-            self.halo_pack(group, side, None)
-
-    def halo_unpack_both(self, group, west_ptr, east_ptr):
-        for side in (WEST, EAST):
-            self.halo_unpack(group, side, None)
+def _sequence(nslabs, first=False, adopted=False, ready=False):
+    """The library's own sequencing of a time step as a dry run (gb25_debug_sequence: no GPU is touched)."""
+    lib = load_library("Float32")
+    need = lib.gb25_debug_sequence(nslabs, int(first), int(adopted), int(ready), None, 0)
+    buf = ctypes.create_string_buffer(need)
+    assert lib.gb25_debug_sequence(nslabs, int(first), int(adopted), int(ready), buf, need) == need
+    return [tuple(int(t) if t.lstrip("-").isdigit() else t for t in line.split()) for line in buf.value.decode().splitlines()]
 
 
-def _make_local_ring(P):
-    log = []
-    backs = [_RecordingBackend(r, log) for r in range(P)]
-    steppers = [SlabStepper(b, torch.device("cpu")) for b in backs]
-    for b, s in zip(backs, steppers):
-        b.bufs_send, b.bufs_recv = s.send, s.recv
-    exchange = lambda group: (log.append(("exchange", group)), LocalRingTransport.exchange_all(steppers, group))
-    return backs, steppers, exchange, log
+def _ops_of_slab(log, slab):
+    """(op, number, stream) of one slab, exchanges included (they involve every slab)."""
+    out = []
+    for e in log:
+        if e[0] in ("stage", "pack", "unpack") and e[3] == slab:
+            out.append((e[0], e[1], e[-1]))
+        elif e[0] == "exchange":
+            out.append(e)
+    return out
 
 
-def test_time_step_sequencing_and_local_ring():
-    P = 4
-    backs, steppers, exchange, log = _make_local_ring(P)
-    step_slabs(steppers, exchange, euler=False)
-    mine = [e[1:] for e in log if e[0] == 2]
-    assert mine == [("stage", 0, False), ("pack", 1, WEST), ("pack", 1, EAST), ("pack", 0, WEST), ("pack", 0, EAST),
-                    ("unpack", 1, WEST), ("unpack", 1, EAST), ("stage", 1, False), ("pack", 2, WEST), ("pack", 2, EAST),
-                    ("stage", 2, False),          # own-column corrector while group 2 (and 0) are in flight
-                    ("unpack", 2, WEST), ("unpack", 2, EAST), ("unpack", 0, WEST), ("unpack", 0, EAST),
-                    ("stage", 3, False), ("stage", 4, False)]
-    # exchanges happen once per group, between the pack of every slab and the unpack of any slab;
-    # the small barotropic exchange (group 1, critical path) is posted first, then the 3-D bundle (group 0),
-    # which stays in flight during the sub-cycle (stage 1)
-    ex = [i for i, e in enumerate(log) if e[0] == "exchange"]
-    assert [log[i][1] for i in ex] == [1, 0, 2]
-    stage1 = min(i for i, e in enumerate(log) if e[0] != "exchange" and e[1:3] == ("stage", 1))
-    unpack0 = min(i for i, e in enumerate(log) if e[0] != "exchange" and e[1:3] == ("unpack", 0))
-    assert ex[1] < stage1 < unpack0
-    stage2 = min(i for i, e in enumerate(log) if e[0] != "exchange" and e[1:3] == ("stage", 2))
-    unpack2 = min(i for i, e in enumerate(log) if e[0] != "exchange" and e[1:3] == ("unpack", 2))
-    assert ex[2] < stage2 < unpack2               # group 2 is posted before the own-column corrector starts
-    for i, grp in zip(ex, (1, 0, 2)):
-        assert all(not (e[1] == "unpack" and e[2] == grp) for e in log[:i] if e[0] != "exchange")
-        assert all(not (e[1] == "pack" and e[2] == grp) for e in log[i:] if e[0] != "exchange")
-    # data: my west halo holds the west neighbour's EAST pack, my east halo the east neighbour's WEST pack
-    for r, b in enumerate(backs):
-        west, east = slab_neighbours(r, P)
-        for grp in (0, 1, 2):
-            assert b.unpacked[(grp, WEST)] == west * 100 + grp * 10 + EAST
-            assert b.unpacked[(grp, EAST)] == east * 100 + grp * 10 + WEST
+def test_time_step_sequencing_in_step_subcycle():
+    """No look-ahead is valid (first steps, changed dt, host writes): the sub-cycle and its two exchanges run inside
+    the step."""
+    log = _sequence(4)
+    mine = _ops_of_slab(log, 2)
+    assert mine == [("stage", 0, "main"),
+                    ("pack", 1, "main"), ("exchange", 1, "main"),          # small barotropic exchange FIRST (critical path)
+                    ("pack", 0, "comm"), ("exchange", 0, "comm"),          # the 3-D bundle leaves on the second stream
+                    ("unpack", 1, "main"), ("stage", 1, "main"), ("pack", 2, "main"), ("exchange", 2, "comm"),
+                    ("stage", 2, "main"),                                   # own columns + interior tendencies meanwhile
+                    ("unpack", 2, "main"), ("unpack", 0, "main"), ("stage", 3, "main"), ("stage", 4, "main")]
+    idx = lambda *e: log.index(e)
+    # the comm stream starts packing the bundle only after stage 0 of every slab (event 0), the corrector of stage 2
+    # waits for the pack (event 1), the unpack of group 0 for the arrival (event 3 recorded on comm)
+    assert idx("record", 0, "main") > idx("stage", 0, "slab", 3, "euler", 0, "main")
+    assert idx("wait", 0, "comm") < idx("pack", 0, "slab", 0, "comm")
+    assert idx("record", 1, "comm") < idx("exchange", 0, "comm")
+    assert idx("wait", 1, "main") < idx("stage", 2, "slab", 0, "euler", 0, "main")
+    last_stage2 = idx("stage", 2, "slab", 3, "euler", 0, "main")
+    assert last_stage2 < idx("record", 3, "comm") < idx("wait", 3, "main") < idx("unpack", 2, "slab", 0, "main")
+    assert log[-1] == ("lookahead_in_flight", 0)
+    # every slab packs a group before its exchange and unpacks after
+    for grp in (0, 1, 2):
+        ex = [i for i, e in enumerate(log) if e[:2] == ("exchange", grp)]
+        assert len(ex) == 1
+        assert all(i < ex[0] for i, e in enumerate(log) if e[:2] == ("pack", grp))
+        assert all(i > ex[0] for i, e in enumerate(log) if e[:2] == ("unpack", grp))
 
 
 def test_time_step_sequencing_with_the_subcycle_lookahead():
     """When the previous step left a valid look-ahead, stage 0 adopts the sub-cycle: groups 1, 2 and stage 1 vanish
     from the step; after the momentum tendencies (stage 3) the NEXT sub-cycle is prepared beside the tracer
-    tendencies: group 3 -> stage 5 -> group 4."""
-    P = 3
-    backs, steppers, exchange, log = _make_local_ring(P)
-    for b in backs:
-        b.ready, b.adopted = True, True
-    step_slabs(steppers, exchange, euler=False)
-    mine = [e[1:] for e in log if e[0] == 1]
-    assert mine == [("stage", 0, False), ("pack", 0, WEST), ("pack", 0, EAST), ("stage", 2, False),
-                    ("unpack", 0, WEST), ("unpack", 0, EAST), ("stage", 3, False),
-                    ("pack", 3, WEST), ("pack", 3, EAST), ("unpack", 3, WEST), ("unpack", 3, EAST),
-                    ("stage", 5, False), ("pack", 4, WEST), ("pack", 4, EAST), ("unpack", 4, WEST), ("unpack", 4, EAST),
-                    ("stage", 4, False)]
+    tendencies on the second stream: group 3 -> stage 5 -> group 4."""
+    log = _sequence(3, adopted=True, ready=True)
+    mine = _ops_of_slab(log, 1)
+    assert mine == [("stage", 0, "main"), ("pack", 0, "comm"), ("exchange", 0, "comm"), ("stage", 2, "main"),
+                    ("unpack", 0, "main"), ("stage", 3, "main"),
+                    ("pack", 3, "comm"), ("exchange", 3, "comm"), ("unpack", 3, "comm"), ("stage", 5, "comm"),
+                    ("pack", 4, "comm"), ("exchange", 4, "comm"), ("unpack", 4, "comm"),
+                    ("stage", 4, "main")]
     assert [e[1] for e in log if e[0] == "exchange"] == [0, 3, 4]
-    assert steppers[0].lookahead_in_flight
-    for r, b in enumerate(backs):
-        west, east = slab_neighbours(r, P)
-        for grp in (0, 3, 4):
-            assert b.unpacked[(grp, WEST)] == west * 100 + grp * 10 + EAST
-            assert b.unpacked[(grp, EAST)] == east * 100 + grp * 10 + WEST
+    assert log[-1] == ("lookahead_in_flight", 1)
+    # the look-ahead starts after the momentum tendencies of every slab (event 2 recorded on main, awaited by comm)
+    i_mom = max(i for i, e in enumerate(log) if e[:2] == ("stage", 3))
+    i_rec = max(i for i, e in enumerate(log) if e == ("record", 2, "main"))
+    i_wait = max(i for i, e in enumerate(log) if e == ("wait", 2, "comm"))
+    i_pack3 = min(i for i, e in enumerate(log) if e[:2] == ("pack", 3))
+    assert i_mom < i_rec < i_wait < i_pack3
 
 
 def test_first_time_step_sequencing():
-    backs, steppers, exchange, log = _make_local_ring(2)
-    first_step_slabs(steppers, exchange)
-    mine = [e[1:] for e in log if e[0] == 0]
-    assert mine[:10] == [("initialize",), ("fill_local",), ("pack", 0, WEST), ("pack", 0, EAST), ("pack", 2, WEST),
-                         ("pack", 2, EAST), ("unpack", 0, WEST), ("unpack", 0, EAST), ("unpack", 2, WEST),
-                         ("unpack", 2, EAST)]
-    assert mine[10] == ("update_state_local",)
-    assert mine[11] == ("stage", 0, True) and mine[-2:] == [("stage", 3, True), ("stage", 4, True)]      # Euler first step
+    log = _sequence(2, first=True)
+    mine = [e for e in log if (len(e) > 3 and e[2] == "slab" and e[3] == 0) or e[0] == "exchange"
+            or (e[0] in ("initialize", "fill_local", "update_state_local") and e[2] == 0)]
+    assert [e[:2] for e in mine[:9]] == [("initialize", "slab"), ("fill_local", "slab"), ("pack", 0), ("pack", 2),
+                                          ("exchange", 0), ("exchange", 2), ("unpack", 0), ("unpack", 2),
+                                          ("update_state_local", "slab")]
+    stages = [e for e in log if e[0] == "stage" and e[3] == 0]
+    assert [e[1] for e in stages] == [0, 1, 2, 3, 4] and all(e[5] == 1 for e in stages)      # Euler first step

@@ -1,6 +1,7 @@
-"""Decomposition invariance: P x-slabs stepped in lock-step on ONE GPU, with the
-same pack / unpack kernels and the same staged time step the multi-process path uses (only the transport is
-a device-to-device copy instead of RCCL send/recv), must reproduce the single-slab run BIT FOR BIT."""
+"""Decomposition invariance: P x-slabs stepped in lock-step on ONE GPU by the library's
+own sequencer -- the same stages, pack / unpack kernels, two streams and interior/edge split of the momentum tendencies
+as the multi-process path; only the transport differs (device-to-device copies, or RCCL on the one-rank self-ring
+instead of RCCL between ranks) -- must reproduce the single-domain run BIT FOR BIT."""
 import numpy as np
 import pytest
 
@@ -88,3 +89,59 @@ def test_slabs_fall_back_when_a_lookahead_is_not_adopted(float_type):
     for n in FIELDS:
         a, b = ens.gather(n), single.backend.get_field(n, False)
         assert a.dtype == dtype and np.array_equal(a, b), (n, float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize("split", [1, 0])
+def test_rccl_self_ring_equals_periodic_domain(split):
+    """The RCCL transport on the one-GPU box: ONE rank whose west and east neighbour is itself (slab_mode = 1,
+    ncclCommInitRank with nranks = 1, ncclSend/ncclRecv to self inside a group on the library's two streams).  The slab
+    path with its exchanges must equal the periodic single domain bit for bit -- with and without the interior/edge
+    split of the momentum tendencies -- through the look-ahead route and the in-step fallback (changed dt)."""
+    from gb25_amd.distributed import SlabModel
+    Nx, Ny, Nz, dt = 256, 48, 24, 600.0
+    single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt)
+    init = _initial(Nx, Ny, Nz, single)
+    ring = SlabModel(Nx, Ny, Nz, dt=dt, rank=0, nranks=1, slab_mode=1, transport="rccl",
+                     options=dict(split_tendencies=split))
+    for n, a in init.items():
+        ring.backend.set_field(n, a, False)
+    for m in (single, ring):
+        gb.first_time_step(m)
+        gb.loop(m, 5)
+    assert ring.backend.lookahead_state() == (True, True)
+    for m in (single, ring):
+        m.backend.set_dt(450.0)
+        gb.loop(m, 3)
+    for n in FIELDS:
+        a, b = ring.backend.get_field(n, False), single.backend.get_field(n, False)
+        assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
+    # the x halos of the self-ring hold what the periodic copy of the single domain holds
+    for n in ("u", "v", "T", "S", "eta", "U", "V"):
+        a, b = ring.backend.get_field(n, True), single.backend.get_field(n, True)
+        assert np.array_equal(a[:, 8:-8], b[:, 8:-8]), n
+    assert np.abs(single.velocities.u.interior).max() > 1e-2
+    ring.backend.close()
+    single.backend.close()
+
+
+def test_split_tendencies_is_bitwise_neutral_on_ragged_slabs():
+    """Interior tile columns first, edge tile columns after the halos arrived against the unsplit kernels:
+    slabs of 160 columns (2.5 tiles), 129 (the interior shrinks to one tile) and 66 (no interior at all)."""
+    for Nx, P in ((480, 3), (258, 2), (132, 2)):
+        Ny, Nz, dt = 40, 12, 600.0
+        ens = [LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, options=dict(split_tendencies=sp)) for sp in (0, 1)]
+        single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt)
+        init = _initial(Nx, Ny, Nz, single)
+        for e in ens:
+            for n, a in init.items():
+                e.scatter(n, a)
+        for m in ens + [single]:
+            m.first_time_step() if m is not single else gb.first_time_step(single)
+            m.loop(4) if m is not single else gb.loop(single, 4)
+        for n in FIELDS:
+            ref = single.backend.get_field(n, False)
+            for e in ens:
+                assert np.array_equal(e.gather(n), ref), (Nx, P, n)
+        for e in ens:
+            e.close()
+        single.backend.close()

@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 NX, NY, NZ = 1440, 720, 48
 
 
-def fresh_model():
+def fresh_model(**options):
     """A new all-zero model (device allocation + memset: far cheaper than uploading 22 zero arrays)."""
-    return gb.baroclinic_instability_model(gb.GPU(), NX, NY, NZ, dt=240.0)
+    return gb.baroclinic_instability_model(gb.GPU(), NX, NY, NZ, dt=240.0, options=options)
 
 
 @pytest.fixture()
@@ -115,13 +115,11 @@ def test_full_size_parity_against_oracle():
     v.backend.close()
 
 
-def test_lookaheads_bitwise_at_full_size(monkeypatch):
+def test_lookaheads_bitwise_at_full_size():
     """The look-aheads (tracers, velocities, sub-cycle beside the tracer kernel) against the stand-alone kernels at the
     benchmark size, where the concurrent kernels really do overlap for milliseconds: 8 steps, every prognostic field and
     tendency bit for bit."""
-    monkeypatch.setenv("GB25_AB2_AHEAD", "0")
-    a = fresh_model()
-    monkeypatch.delenv("GB25_AB2_AHEAD")
+    a = fresh_model(ab2_lookahead=0)
     b = fresh_model()
     u0 = (1e-2 * counter_rng((NX, NY, NZ), 42, 1)).astype(np.float32)
     for m in (a, b):
@@ -136,3 +134,36 @@ def test_lookaheads_bitwise_at_full_size(monkeypatch):
         assert np.isfinite(x).all(), n
     a.backend.close()
     b.backend.close()
+
+
+def test_slabs_at_the_benchmark_size_bitwise():
+    """BASELINE config 3 as the multi-GPU run cuts it: 1440x720x48 as P = 2, 4, 8 x-slabs (720, 360, 180 columns; the
+    8-way slab has a ragged 52-column edge tile and a 22-column wide barotropic halo on 180 columns), stepped by the
+    library's sequencer with the local transport on this one GPU.  first_time_step! + 4 steps, every compared field bit
+    for bit against the single domain; the look-ahead route was taken."""
+    from gb25_amd.distributed import LocalSlabEnsemble
+    names = ("u", "v", "w", "T", "S", "eta", "U", "V", "eta_bar", "U_bar", "V_bar", "Gn.u", "Gn.v", "Gn.T", "Gn.S",
+             "Gm.u", "Gm.T", "Gn.U", "Gn.V")
+    single = fresh_model()
+    gb.set_baroclinic_instability(single)
+    u0 = (1e-2 * counter_rng((NX, NY, NZ), 42, 1)).astype(np.float32)
+    v0 = (1e-2 * counter_rng((NX, NY + 1, NZ), 42, 2)).astype(np.float32)
+    single.set(u=u0, v=v0)
+    T0, S0 = single.tracers.T.interior, single.tracers.S.interior
+    gb.first_time_step(single)
+    gb.loop(single, 4)
+    ref = {n: single.backend.get_field(n, False) for n in names}
+    single.backend.close()
+    assert np.abs(ref["u"]).max() > 1e-2 and np.isfinite(ref["Gn.u"]).all()
+    for P in (2, 4, 8):
+        ens = LocalSlabEnsemble(NX, NY, NZ, P, dt=240.0)
+        for n, a in (("u", u0), ("v", v0), ("T", T0), ("S", S0)):
+            ens.scatter(n, a)
+        ens.first_time_step()
+        ens.loop(4)
+        assert all(b.lookahead_state() == (True, True) for b in ens.backends), P
+        assert all(b.get_option("split_tendencies") == 1 for b in ens.backends)
+        for n in names:
+            got = ens.gather(n)
+            assert np.array_equal(got, ref[n]), (P, n, float(np.abs(got - ref[n]).max()))
+        ens.close()

@@ -1,6 +1,7 @@
-"""The real multi-process path (SlabModel + torch.distributed point-to-point ring) rehearsed on ONE GPU:
-two ranks launched by torch.distributed.run, both on device 0, gloo transport (RCCL refuses two ranks per
-device; on the 8-GPU node the backend is "nccl" = RCCL).  Result must equal the single-domain run bit for bit."""
+"""The multi-process path (one SlabModel per rank, the library's sequencer in every rank) rehearsed on ONE GPU: two
+ranks launched by torch.distributed.run, both on device 0.  RCCL refuses two ranks per device, so the exchanges go
+through the library's host-callback transport and torch.distributed's gloo ring here; on the 8-GPU node the same ranks
+use the library's RCCL communicator.  Result must equal the single-domain run bit for bit."""
 import json
 import os
 import subprocess
@@ -41,10 +42,10 @@ def test_two_rank_slab_run_matches_single_domain(tmp_path):
 
 
 def test_bench_two_ranks_prints_contract_line():
-    res = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "64", "48",
+    res = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "128", "48",
                    "8"], {})
     assert res.returncode == 0, res.stderr[-3000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["finite"]
-    assert out["config"]["grid"] == [128, 48, 8] and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "strong" and out["finite"]
+    assert out["config"]["grid"] == [128, 48, 8] and out["config"]["local_columns"] == 64 and out["value"] > 0

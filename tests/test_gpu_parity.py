@@ -242,15 +242,13 @@ def test_ragged_sizes_not_multiples_of_the_tile():
 
 
 @pytest.mark.parametrize("Nz", [13, 25, 37, 60, 100])
-def test_vertical_extents_with_ragged_level_chunks(Nz, monkeypatch):
+def test_vertical_extents_with_ragged_level_chunks(Nz):
     """The tendency kernels split a column into max(1, Nz // 12) chunks of ceil(Nz / chunks) levels, the last one
     shorter (Nz = 100, the 1/12-degree configuration, gives 8 chunks of 13, 13, ... 9; Nz = 60 gives 5 x 12).  Parity
     with the oracle, and the look-ahead's chunked column sums against the stand-alone kernels bit for bit."""
     r, v = make_pair(70, 22, Nz, dt=300.0)
     baroclinic_state(r, v, amplitude=1e-2)
-    monkeypatch.setenv("GB25_AB2_AHEAD", "0")
-    plain = gb.baroclinic_instability_model(gb.GPU(), 70, 22, Nz, dt=300.0)
-    monkeypatch.delenv("GB25_AB2_AHEAD")
+    plain = gb.baroclinic_instability_model(gb.GPU(), 70, 22, Nz, dt=300.0, options=dict(ab2_lookahead=0))
     for n in ALL_FIELDS:
         plain.backend.set_field(n, r.backend.get_field(n, True), True)
     for m in (r, v, plain):
@@ -289,15 +287,21 @@ def test_error_paths():
         m.velocities.u.set(np.zeros((3, 3, 3)))
     with pytest.raises(NotImplementedError):
         gb.baroclinic_instability_model(gb.GPU(), 32, 16, 8, dt=1.0, grid_type="gaussian_islands")
+    with pytest.raises(GB25Error, match="phase-by-phase"):                 # a slab is driven by the composites only
+        s = gb.baroclinic_instability_model(gb.GPU(), 64, 16, 8, dt=1.0, slab_mode=1)
+        s.backend.update_state()
+    with pytest.raises(GB25Error, match="exchange context"):
+        s.backend.time_step()
+    with pytest.raises(GB25Error, match="SUBCYCLE_BLOCK"):
+        m.backend.set_option("subcycle_block", 4)
 
 
-def test_v2_lds_kernels_match_v1_direct_kernels(monkeypatch):
-    """The flux-sharing / LDS-staged tendency kernels (kernels_v2.hpp, the default) evaluate the same expressions
-    as the direct-stencil kernels (kernels.hpp, GB25_KERNELS=v1): results agree to the last few bits."""
-    monkeypatch.setenv("GB25_KERNELS", "v1")
-    m1 = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 20, dt=600.0)     # ragged against the 64x8 tile
-    monkeypatch.setenv("GB25_KERNELS", "v2")
+def test_lds_kernels_match_direct_stencil_kernels():
+    """The flux-sharing / LDS-staged tendency kernels (tendency_kernels.hpp, the default) evaluate the same expressions
+    as the direct-stencil kernels (kernels.hpp, option kernels = 1): results agree to the last few bits."""
+    m1 = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 20, dt=600.0, options=dict(kernels=1))   # ragged tiles
     m2 = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 20, dt=600.0)
+    assert (m1.backend.get_option("kernels"), m2.backend.get_option("kernels")) == (1, 2)
     gb.set_baroclinic_instability(m1)
     set_noisy_velocities(m1, 0.05)
     m1.set(eta=(1e-2 * counter_rng((150, 70, 1), 3, 3)).astype(np.float32))
@@ -311,17 +315,15 @@ def test_v2_lds_kernels_match_v1_direct_kernels(monkeypatch):
         assert rel(a, b) < 2e-6, (n, rel(a, b))
 
 
-def test_ab2_lookahead_is_bitwise_neutral(monkeypatch):
+def test_ab2_lookahead_is_bitwise_neutral():
     """The tracer tendency kernel writes T, S of the next time level ahead of ab2_step! (Ab2Ahead); the step then
-    adopts them by pointer exchange.  Same bits as the stand-alone AXPY kernel (GB25_AB2_AHEAD=0), halos included,
+    adopts them by pointer exchange.  Same bits as the stand-alone AXPY kernel (option ab2_lookahead = 0), halos included,
     across everything that must invalidate the look-ahead: a changed dt, host writes into T / G, an Euler restart,
     phase-by-phase driving, and a handed-out device pointer."""
-    monkeypatch.setenv("GB25_AB2_AHEAD", "0")
-    a = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0)
-    monkeypatch.setenv("GB25_AB2_AHEAD", "1")
-    monkeypatch.setenv("GB25_BARO_AHEAD", "1")      # (off by default on grids this small)
-    b = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0)
-    c = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0)   # will hand out its T pointer
+    a = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0, options=dict(ab2_lookahead=0))
+    on = dict(ab2_lookahead=1, subcycle_lookahead=1)      # (the sub-cycle look-ahead is off by default on grids this small)
+    b = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0, options=on)
+    c = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0, options=on)   # will hand out its T pointer
     names = ALL_FIELDS
 
     def same(label):
@@ -369,15 +371,12 @@ def test_ab2_lookahead_is_bitwise_neutral(monkeypatch):
     assert c.backend.field_device_ptr("T") == p0      # pinned once handed out
 
 
-def test_lookaheads_are_bitwise_neutral_over_a_longer_run(monkeypatch):
+def test_lookaheads_are_bitwise_neutral_over_a_longer_run():
     """All look-aheads (tracers, velocities, sub-cycle) against none, 40 steps at BASELINE configs[1]'s size: the
     partner buffers, the pointer exchanges and the work that runs beside the tendency kernels on the side stream must
     not change a bit (a missing stream dependency shows up here as a difference that comes and goes)."""
-    monkeypatch.setenv("GB25_AB2_AHEAD", "0")
-    a = gb.baroclinic_instability_model(gb.GPU(), 360, 180, 24, dt=600.0)
-    monkeypatch.delenv("GB25_AB2_AHEAD")
-    monkeypatch.setenv("GB25_BARO_AHEAD", "1")      # (off by default on grids this small)
-    b = gb.baroclinic_instability_model(gb.GPU(), 360, 180, 24, dt=600.0)
+    a = gb.baroclinic_instability_model(gb.GPU(), 360, 180, 24, dt=600.0, options=dict(ab2_lookahead=0))
+    b = gb.baroclinic_instability_model(gb.GPU(), 360, 180, 24, dt=600.0, options=dict(subcycle_lookahead=1))
     for m in (a, b):
         gb.set_baroclinic_instability(m)
         set_noisy_velocities(m, 0.05)
@@ -392,15 +391,15 @@ def test_lookaheads_are_bitwise_neutral_over_a_longer_run(monkeypatch):
 
 
 @pytest.mark.parametrize("shape,halo", [((150, 70, 12), 8), ((40, 21, 6), 4)])
-def test_fused_halo_fill_is_bitwise_neutral(monkeypatch, shape, halo):
+def test_fused_halo_fill_is_bitwise_neutral(shape, halo):
     """One launch for the y, z and periodic-x fills (the x copy reads through the other two) against the sequence
     y+z, then x: every cell of every parent array, including halo values the host planted in layers that no fill
     rewrites."""
     Nx, Ny, Nz = shape
     models = []
-    for fused in ("0", "1"):
-        monkeypatch.setenv("GB25_FILL_FUSED", fused)
-        m = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=300.0, halo=(halo,) * 3)
+    for fused in (0, 1):
+        m = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=300.0, halo=(halo,) * 3,
+                                            options=dict(fill_fused=fused))
         gb.set_baroclinic_instability(m)
         set_noisy_velocities(m, 0.05)
         for n, seed in (("T", 5), ("u", 6), ("v", 7), ("eta", 8), ("V", 9)):
@@ -419,44 +418,28 @@ def test_fused_halo_fill_is_bitwise_neutral(monkeypatch, shape, halo):
         assert np.array_equal(a.backend.get_field(n, True), b.backend.get_field(n, True)), ("steps", n)
 
 
-def test_graph_replay_is_bitwise_neutral(monkeypatch):
-    """gb25_time_step / gb25_loop replay a captured HIP graph of the step once a host state recurs (the pointer
-    exchanges give period 2).  Same bits as eager launches (GB25_GRAPH=0), through host writes, a changed dt, an
-    Euler restart and phase-by-phase driving in between, and the clock advances alike."""
-    monkeypatch.setenv("GB25_GRAPH", "0")
-    a = gb.baroclinic_instability_model(gb.GPU(), 128, 64, 8, dt=1200.0)
-    monkeypatch.setenv("GB25_GRAPH", "1")
-    b = gb.baroclinic_instability_model(gb.GPU(), 128, 64, 8, dt=1200.0)
-
-    def same(label):
-        for n in ALL_FIELDS:
-            assert np.array_equal(a.backend.get_field(n, True), b.backend.get_field(n, True)), (label, n)
-        assert a.clock.iteration == b.clock.iteration and a.clock.time == b.clock.time, label
-
+@pytest.mark.parametrize("opts", [dict(two_streams=0), dict(subcycle_block=1), dict(subcycle_block=3),
+                                  dict(store_pressure=1), dict(ab2_lookahead=2, subcycle_lookahead=1)])
+def test_schedule_options_are_bitwise_neutral(opts):
+    """Every schedule switch of gb25_set_option (single stream, one launch per substep, pHY' stored every step, tracer
+    look-ahead only) gives the bits of the default schedule, through a changed dt and an option flipped mid-run."""
+    a = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0)
+    b = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0, options=opts)
+    for k, v in opts.items():
+        assert b.backend.get_option(k) == v
     for m in (a, b):
         gb.set_baroclinic_instability(m)
         set_noisy_velocities(m, 0.05)
         gb.first_time_step(m)
-        gb.loop(m, 9)                                  # eager, eager, capture A, capture B, replay ...
-    same("loop")
+        gb.loop(m, 4)
+        m.backend.set_dt(450.0)
+        gb.loop(m, 3)
+    b.backend.set_option("subcycle_lookahead", 1 - b.backend.get_option("subcycle_lookahead"))
     for m in (a, b):
-        gb.time_step(m)
-        m.backend.set_dt(900.0)
-        gb.loop(m, 6)
-    same("after set_dt")
-    S = a.backend.get_field("S", False) + np.float32(0.125)
-    for m in (a, b):
-        m.backend.set_field("S", S, False)
-        gb.loop(m, 5)
-        m.backend.ab2_step(900.0, False)
-        m.backend.fill_halo_regions()
-        m.backend.correct_velocities_and_cache_previous_tendencies(900.0)
-        m.backend.update_state()
-        gb.loop(m, 5)
-        gb.first_time_step(m)
-        gb.loop(m, 5)
-    same("after host writes, phases and an Euler restart")
-    assert np.isfinite(b.velocities.u.interior).all()
+        gb.loop(m, 3)
+    for n in ALL_FIELDS:
+        assert np.array_equal(a.backend.get_field(n, True), b.backend.get_field(n, True)), (opts, n)
+    assert a.clock.iteration == b.clock.iteration == 11
 
 
 @pytest.mark.parametrize("shape,halo", [((16, 9, 4), 4), ((24, 9, 5), 5), ((70, 13, 7), 8), ((8, 10, 4), 8)])
