@@ -100,6 +100,7 @@ struct gb25_model {
   std::string err;
   int baro_block = 7;                // substeps per barotropic launch (option SUBCYCLE_BLOCK = 1: one launch per substep)
   int kernel_gen = 2;                // 2: LDS / flux-sharing tendency kernels (tendency_kernels.hpp); 1: direct-stencil kernels
+  int pressure_bits = 64;            // option PRESSURE_PRECISION: 64 = fp64 EOS + integral (default); 32 = the float type's own
   int split_tendencies = 1;          // slab of a decomposition: interior tile columns before the x-halo bundle has arrived
   bool slab = false;                 // x halos come from a neighbour (nranks > 1, or the self-ring of slab_mode = 1)
   struct SlabGroup* group = nullptr; // exchange context (transport, buffers, comm stream) once gb25_comm_init_* was called
@@ -459,6 +460,20 @@ gb25_status compute_w_impl(gb25_model* m, int part = 0) {
 gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = INT_MIN, int i_first_b = 0,
                            int i_last_b = -1, bool may_skip_p = false) {
   const Grid& g = m->g;
+  if (m->pressure_bits == 32) {
+    // the model float type's own arithmetic, whole extended range, pHY' stored, differences from the stored values
+    Timed t(m, GB25_K_COMPUTE_P);
+    dim3 b(64, 4);
+    const int nx = g.Nx + 2 * g.H - 2, ny = g.Ny + 2 * g.H - 2;
+    hipLaunchKernelGGL(k_compute_p_literal, grid2(nx, ny, b), b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d,
+                       m->f[GB25_PHY].d, -g.H + 1, nx, 0, 0);
+    const long n = (long)m->f[GB25_PHY].elems();
+    hipLaunchKernelGGL(k_pressure_differences, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, g,
+                       m->f[GB25_PHY].d, m->dpx.d, m->dpy.d, n);
+    m->phy_stale = false;
+    LAUNCHCHK();
+    return GB25_OK;
+  }
   const bool write_p = !may_skip_p || m->phy_pinned;
   m->phy_stale = !write_p;
   if (i_first == INT_MIN) {
@@ -471,7 +486,9 @@ gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = IN
   const int ncol_b = i_last_b >= i_first_b ? i_last_b - i_first_b + 2 : 0;
   const int nrow = g.Ny + 2 * g.H - 2;     // rows -H+1 .. Ny+H-2
   const int tiles_a = (ncol + 62) / 63, tiles_b = (ncol_b + 62) / 63;
-  if (ncol <= 63) {   // strips: one row per thread (4x the waves, short chains)
+  // strips and narrow slabs: one row per thread (4x the waves, short chains) -- with four rows per thread a 180-column
+  // slab is 138 blocks on 256 CUs and the fp64 chains run at their latency (0.14 ms, against 0.31 ms for 1440 columns)
+  if ((tiles_a + tiles_b) * ((nrow + PR * 4 - 1) / (PR * 4)) < 1024) {
     dim3 gr(tiles_a + tiles_b, (nrow + 3) / 4);
     auto kern = write_p ? k_compute_p<1, true> : k_compute_p<1, false>;
     hipLaunchKernelGGL(kern, gr, b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_PHY].d, m->dpx.d,
@@ -499,7 +516,8 @@ inline int interior_tile_columns_end(const Grid& g) {
   return std::max(1, std::min(nbx - 1, (g.Nx - 3) / V2_TX));
 }
 inline bool tendencies_split(const gb25_model* m) {
-  return m->slab && m->split_tendencies && m->two_streams && m->kernel_gen >= 2 && interior_tile_columns_end(m->g) > 1;
+  return m->slab && m->split_tendencies && m->two_streams && m->pressure_bits == 64 && m->kernel_gen >= 2 &&
+         interior_tile_columns_end(m->g) > 1;
 }
 
 // part: 0 = every tile column; 1 = the interior tile columns (a12: launched before the x-halo bundle has arrived);
@@ -1348,6 +1366,10 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
     case GB25_OPT_TWO_STREAMS: m->two_streams = v != 0; return GB25_OK;
     case GB25_OPT_STORE_PRESSURE: m->phy_pinned = v != 0; return GB25_OK;
     case GB25_OPT_SPLIT_TENDENCIES: m->split_tendencies = v != 0; return GB25_OK;
+    case GB25_OPT_PRESSURE_PRECISION:
+      if (v != 32 && v != 64) return fail(m, GB25_ERR_INVALID_ARGUMENT, "GB25_OPT_PRESSURE_PRECISION: 64 or 32");
+      m->pressure_bits = (sizeof(real) == 8) ? 64 : v;   // (a Float64 model's own arithmetic IS fp64)
+      return GB25_OK;
     default: return fail(m, GB25_ERR_INVALID_ARGUMENT, "unknown option %d", (int)opt);
   }
 }
@@ -1362,6 +1384,7 @@ gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
     case GB25_OPT_TWO_STREAMS: *v = m->two_streams; break;
     case GB25_OPT_STORE_PRESSURE: *v = m->phy_pinned; break;
     case GB25_OPT_SPLIT_TENDENCIES: *v = m->split_tendencies; break;
+    case GB25_OPT_PRESSURE_PRECISION: *v = m->pressure_bits; break;
     default: return GB25_ERR_INVALID_ARGUMENT;
   }
   return GB25_OK;

@@ -338,6 +338,73 @@ __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restric
     }
   }
 }
+// GB25_OPT_PRESSURE_PRECISION = 32: the hydrostatic pressure exactly as a model whose float type is `real` evaluates
+// it -- the 55-term TEOS-10 polynomial at every cell in `real`, Horner in (t, s) then in zeta, no contraction into FMAs,
+// the integral and the stored pHY' in `real`, the differences taken from the stored values.  This is the arithmetic of
+// the all-Float32 restatement (oracle/gb25_oracle.c: teos10_rho, compute_p), operation for operation; it exists so
+// that the distance of the default (fp64-pressure) path from a Float32 reference run can be separated into "the
+// reference's own round-off" and "everything else" (tests/test_gpu_fp32_story.py).
+#pragma clang fp contract(off)
+__device__ __forceinline__ real teos10_rho_literal(real Theta, real Sa, real Z) {
+  const real t = Theta * real(0.025);
+  const real s = (real)sqrt((double)((Sa + real(32.0)) * real(0.875 / 35.16504)));
+  const real z = -Z * real(1e-4);
+  const real R000 = 8.0189615746e+02, R100 = 8.6672408165e+02, R200 = -1.7864682637e+03, R300 = 2.0375295546e+03,
+             R400 = -1.2849161071e+03, R500 = 4.3227585684e+02, R600 = -6.0579916612e+01, R010 = 2.6010145068e+01,
+             R110 = -6.5281885265e+01, R210 = 8.1770425108e+01, R310 = -5.6888046321e+01, R410 = 1.7681814114e+01,
+             R510 = -1.9193502195e+00, R020 = -3.7074170417e+01, R120 = 6.1548258127e+01, R220 = -6.0362551501e+01,
+             R320 = 2.9130021253e+01, R420 = -5.4723692739e+00, R030 = 2.1661789529e+01, R130 = -3.3449108469e+01,
+             R230 = 1.9717078466e+01, R330 = -3.1742946532e+00, R040 = -8.3627885467e+00, R140 = 1.1311538584e+01,
+             R240 = -5.3563304045e+00, R050 = 5.4048723791e-01, R150 = 4.8169980163e-01, R060 = -1.9083568888e-01,
+             R001 = 1.9681925209e+01, R101 = -4.2549998214e+01, R201 = 5.0774768218e+01, R301 = -3.0938076334e+01,
+             R401 = 6.6051753097e+00, R011 = -1.3336301113e+01, R111 = -4.4870114575e+00, R211 = 5.0042598061e+00,
+             R311 = -6.5399043664e-01, R021 = 6.7080479603e+00, R121 = 3.5063081279e+00, R221 = -1.8795372996e+00,
+             R031 = -2.4649669534e+00, R131 = -5.5077101279e-01, R041 = 5.5927935970e-01, R002 = 2.0660924175e+00,
+             R102 = -4.9527603989e+00, R202 = 2.5019633244e+00, R012 = 2.0564311499e+00, R112 = -2.1311365518e-01,
+             R022 = -1.2419983026e+00, R003 = -2.3342758797e-02, R103 = -1.8507636718e-02, R013 = 3.7969820455e-01;
+  const real R00 = 4.6494977072e+01, R01 = -5.2099962525e+00, R02 = 2.2601900708e-01, R03 = 6.4326772569e-02,
+             R04 = 1.5616995503e-02, R05 = -1.7243708991e-03;
+  real r3 = R013 * t + R103 * s + R003;
+  real r2 = (R022 * t + R112 * s + R012) * t + (R202 * s + R102) * s + R002;
+  real r1 = (((R041 * t + R131 * s + R031) * t + (R221 * s + R121) * s + R021) * t + ((R311 * s + R211) * s + R111) * s + R011) * t +
+            (((R401 * s + R301) * s + R201) * s + R101) * s + R001;
+  real r0 = (((((R060 * t + R150 * s + R050) * t + (R240 * s + R140) * s + R040) * t + ((R330 * s + R230) * s + R130) * s + R030) * t +
+              (((R420 * s + R320) * s + R220) * s + R120) * s + R020) * t +
+             ((((R510 * s + R410) * s + R310) * s + R210) * s + R110) * s + R010) * t +
+            (((((R600 * s + R500) * s + R400) * s + R300) * s + R200) * s + R100) * s + R000;
+  real rp = ((r3 * z + r2) * z + r1) * z + r0;
+  real rz = (((((R05 * z + R04) * z + R03) * z + R02) * z + R01) * z + R00) * z;
+  return rz + rp;
+}
+// one thread per column of the extended range; p is always stored (the differences are taken from the stored values)
+__global__ __launch_bounds__(256) void k_compute_p_literal(Grid g, const real* __restrict__ T, const real* __restrict__ S,
+                                                           real* __restrict__ p, int i_first, int n_a, int i_first_b,
+                                                           int n_b) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t < n_a ? i_first + t : i_first_b + (t - n_a);
+  const int j = blockIdx.y * blockDim.y + threadIdx.y - g.H + 1;
+  if (t >= n_a + n_b || j > g.Ny + g.H - 2) return;
+  const int Nz = g.Nz;
+  auto buoy = [&](int o, real Z) {
+    real rho = teos10_rho_literal(T[o], S[o], Z);
+    return -(g.g * (rho - g.rho0)) / g.rho0;
+  };
+  int o = ic(g, i, j, Nz);
+  real bup = buoy(o, g.zc[Nz - 1] - real(1.) * g.dzf[Nz - 1]);   // mirrored height of the first cell above the surface
+  o -= g.pl_c;
+  real bk = buoy(o, g.zc[Nz - 1]);
+  real pk = -((bk + bup) / real(2.)) * g.dzf[Nz];
+  p[o] = pk;
+  for (int k = Nz - 2; k >= 0; k--) {
+    o -= g.pl_c;
+    bup = bk;
+    bk = buoy(o, g.zc[k]);
+    pk = pk - ((bk + bup) / real(2.)) * g.dzf[k + 1];
+    p[o] = pk;
+  }
+}
+#pragma clang fp contract(fast)
+
 // the same two differences from an fp32 pHY' uploaded by the host (set_field): keeps the arrays consistent
 __global__ void k_pressure_differences(Grid g, const real* __restrict__ p, real* __restrict__ dpx,
                                        real* __restrict__ dpy, long n) {

@@ -126,6 +126,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
   const double dt = m->last_dt;
   const real chi = euler ? -real(0.5) : (real)m->cfg.chi;
   const bool split = tendencies_split(m);
+  const bool p_early = m->two_streams && m->pressure_bits == 64;   // own columns' pressure early, on the side stream
   if (stage == 0) {
     // AB2 update of u,v,T,S + barotropic forcing, then the y/z boundary layers of the 3-D bundle so that its packed
     // x columns (group 0) can travel WHILE the own columns are corrected
@@ -145,7 +146,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       m->iteration += 1;
     }
     if ((s = fill_halos_impl(m, false, false, 1))) return s;
-    if (m->two_streams) {
+    if (p_early) {
       // T, S of the slab's own columns are final from here on: their pressure (fp64-bound) runs on the side stream
       // beside the exchanges and the sub-cycle; the strips next to the x halos follow in stage 3.  The first x
       // difference of this pass reads a stale halo column and is redone by the west strip.
@@ -212,9 +213,9 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     if ((s = corrector_impl(m, true, 2))) return s;
     // the interior pressure pass of stage 0 must be over before the fills touch T, S and before the west strip
     // rewrites column 0 (it has been for a while: the exchanges and the sub-cycle ran in between)
-    if (m->two_streams) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+    if (p_early) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
     if ((s = fill_halos_impl(m, false, true))) return s;
-    if (m->two_streams) {   // the two pressure strips run beside w (side stream)
+    if (p_early) {   // the two pressure strips run beside w (side stream)
       hipStream_t main = m->stream;
       HIPCHK(hipEventRecord(m->ev_fork, main));
       HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
@@ -225,7 +226,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
     }
     if ((s = compute_w_impl(m, split ? 2 : 0))) return s;
-    if (m->two_streams) {
+    if (p_early) {
       HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
     } else {
       if ((s = compute_p_impl(m))) return s;

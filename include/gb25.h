@@ -98,6 +98,10 @@ typedef enum {
   GB25_OPT_TWO_STREAMS,          /* [1] tracer branch (AB2, halos, pressure) on a second stream */
   GB25_OPT_STORE_PRESSURE,       /* [0] store pHY' every step (1) or only its differences, pHY' on demand (0) */
   GB25_OPT_SPLIT_TENDENCIES,     /* [1] slab: interior tile columns of the momentum tendencies before the halos arrive */
+  GB25_OPT_PRESSURE_PRECISION,   /* [64] THE exception to "results unchanged": 64 = equation of state + hydrostatic integral
+                                    in fp64 whatever the model's float type (default; fp32 in, fp32 out); 32 = in the float
+                                    type's own arithmetic, operation for operation what an all-Float32 model computes
+                                    (the stated Float32 tolerance) */
   GB25_OPT_COUNT
 } gb25_option;
 

@@ -1,0 +1,211 @@
+# GB25HIP.jl -- Julia binding of libgb25hip.so (the C ABI of include/gb25.h).
+#
+# The host-language side of the drop-in boundary: GB-25 is a Julia package (src/GordonBell25.jl) and this module is
+# what its maintainers would `include` to run the HydrostaticFreeSurfaceModel time-step loop on MI355X through the
+# hand-written HIP library instead of through Reactant/XLA.  It keeps the GordonBell25 entry points
+# (first_time_step!, time_step!, loop! -- src/timestepping_utils.jl:21-45) and the per-phase workloads
+# (src/precompile.jl:31-127) as one `ccall` each.  No KernelAbstractions, no AMDGPU.jl code generation: the kernels are
+# prebuilt; AMDGPU.jl is only needed if zero-copy `ROCArray` views of the fields are wanted (see `device_view`).
+#
+# STATUS: written against include/gb25.h without a Julia installation at hand (none exists in the build image or on
+# the GPU box); it has not been executed.  The ctypes binding gb-25_amd/binding.py is the one the test-suite runs, and
+# this file mirrors it call for call.
+module GB25HIP
+
+export Config, Model, create, destroy!, first_time_step!, time_step!, loop!, initialize!, update_state!,
+       fill_halo_regions!, compute_auxiliaries!, compute_tendencies!, ab2_step!, mask_immersed_fields!,
+       correct_velocities_and_cache_previous_tendencies!, set_baroclinic_instability!, synchronize,
+       parent_array, interior_array, set_parent!, set_interior!, clock, set_dt!, set_option!, get_option,
+       comm_unique_id, comm_init_rccl!, comm_finalize!, FIELD, OPTION
+
+# One library per Oceananigans float type (src/arg_parsing.jl:12-16): Float32 -> libgb25hip.so, Float64 ->
+# libgb25hip_f64.so; same symbols, gb25_real_bytes() tells them apart.
+const LIBS = Dict(Float32 => get(ENV, "GB25HIP_LIB", "libgb25hip.so"),
+                  Float64 => get(ENV, "GB25HIP_LIB_F64", "libgb25hip_f64.so"))
+
+# gb25_field (include/gb25.h)
+const FIELD = (u = 0, v = 1, w = 2, T = 3, S = 4, pHY = 5,
+               Gn_u = 6, Gn_v = 7, Gn_T = 8, Gn_S = 9, Gm_u = 10, Gm_v = 11, Gm_T = 12, Gm_S = 13,
+               eta = 14, U = 15, V = 16, eta_bar = 17, U_bar = 18, V_bar = 19, Gn_U = 20, Gn_V = 21)
+# gb25_option
+const OPTION = (kernels = 0, ab2_lookahead = 1, subcycle_lookahead = 2, subcycle_block = 3, fill_fused = 4,
+                two_streams = 5, store_pressure = 6, split_tendencies = 7, pressure_precision = 8)
+
+# mirror of gb25_config; isbits, passed by reference
+Base.@kwdef mutable struct Config
+    Nx::Int32 = 0
+    Ny::Int32 = 0
+    Nz::Int32 = 0
+    halo::Int32 = 8                 # halo = (8, 8, 8) in every GB-25 script
+    substeps::Int32 = 30            # SplitExplicitFreeSurface(substeps=30), src/baroclinic_instability_model.jl:22
+    rank::Int32 = 0
+    nranks::Int32 = 1
+    device::Int32 = 0
+    dt::Float64 = 60.0              # model.clock.last_Δt, src/baroclinic_instability_model.jl:82
+    chi::Float64 = 0.1
+    lat_south::Float64 = -80.0
+    lat_north::Float64 = 80.0
+    lon_west::Float64 = 0.0
+    lon_east::Float64 = 360.0
+    depth::Float64 = 4000.0
+    zexp_h::Float64 = 30.0
+    g::Float64 = 9.80665
+    Omega::Float64 = 7.292115e-5
+    radius::Float64 = 6371e3
+    rho0::Float64 = 1020.0
+    slab_mode::Int32 = 0
+    grid_type::Int32 = 0            # 0 = :simple_lat_lon, 1 = :gaussian_islands on the lat-lon grid
+end
+
+mutable struct Model{FT}
+    ptr::Ptr{Cvoid}
+    lib::String
+    cfg::Config
+end
+
+struct GB25Error <: Exception
+    msg::String
+end
+Base.showerror(io::IO, e::GB25Error) = print(io, "GB25Error: ", e.msg)
+
+function check(m::Model, status::Integer, what::AbstractString)
+    status == 0 && return nothing
+    msg = unsafe_string(ccall((:gb25_last_error_string, m.lib), Cstring, (Ptr{Cvoid},), m.ptr))
+    throw(GB25Error("$what failed with status $status: $msg"))   # a Julia exception on the Julia side of the ABI only
+end
+
+"""
+    create(FT, cfg) -> Model{FT}
+
+`baroclinic_instability_model(arch, Nx, Ny, Nz; Δt, halo, free_surface=SplitExplicitFreeSurface(substeps=...))`
+(src/baroclinic_instability_model.jl:17-85): builds the grid metrics, allocates every field zeroed on the device.
+"""
+function create(::Type{FT}, cfg::Config) where {FT<:Union{Float32,Float64}}
+    lib = LIBS[FT]
+    nbytes = ccall((:gb25_real_bytes, lib), Int32, ())
+    nbytes == sizeof(FT) || throw(GB25Error("$lib holds $(nbytes)-byte elements, expected $FT"))
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    st = ccall((:gb25_create, lib), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, out)
+    m = Model{FT}(out[], lib, cfg)
+    if st != 0
+        msg = m.ptr == C_NULL ? "gb25_create failed" :
+              unsafe_string(ccall((:gb25_last_error_string, lib), Cstring, (Ptr{Cvoid},), m.ptr))
+        m.ptr == C_NULL || ccall((:gb25_destroy, lib), Cvoid, (Ptr{Cvoid},), m.ptr)
+        throw(GB25Error("gb25_create: status $st: $msg"))
+    end
+    finalizer(destroy!, m)
+    return m
+end
+
+"""
+    create(FT, Nx, Ny, Nz; Δt, halo=8, substeps=30, kw...)
+"""
+function create(::Type{FT}, Nx::Integer, Ny::Integer, Nz::Integer; Δt, halo = 8, substeps = 30, kw...) where {FT}
+    cfg = Config(; Nx = Nx, Ny = Ny, Nz = Nz, dt = Δt, halo = halo, substeps = substeps, kw...)
+    return create(FT, cfg)
+end
+
+function destroy!(m::Model)
+    if m.ptr != C_NULL
+        ccall((:gb25_destroy, m.lib), Cvoid, (Ptr{Cvoid},), m.ptr)
+        m.ptr = C_NULL
+    end
+    return nothing
+end
+
+# ---- the phases (src/precompile.jl:31-42) and the composites (src/timestepping_utils.jl:21-45): one ccall each
+for (jl, c) in ((:first_time_step!, :gb25_first_time_step),
+                (:time_step!, :gb25_time_step),
+                (:initialize!, :gb25_initialize),
+                (:update_state!, :gb25_update_state),
+                (:mask_immersed_fields!, :gb25_mask_immersed_fields),
+                (:fill_halo_regions!, :gb25_fill_halo_regions),
+                (:compute_auxiliaries!, :gb25_compute_auxiliaries),
+                (:fill_diffusivity_halos!, :gb25_fill_diffusivity_halos),
+                (:compute_momentum_tendencies!, :gb25_compute_momentum_tendencies),
+                (:compute_tracer_tendencies!, :gb25_compute_tracer_tendencies),
+                (:compute_boundary_tendencies!, :gb25_compute_boundary_tendencies),
+                (:compute_tendencies!, :gb25_compute_tendencies),
+                (:set_baroclinic_instability!, :gb25_set_baroclinic_instability),
+                (:synchronize, :gb25_synchronize),
+                (:comm_finalize!, :gb25_comm_finalize))
+    @eval $jl(m::Model) = check(m, ccall(($(QuoteNode(c)), m.lib), Cint, (Ptr{Cvoid},), m.ptr), $(string(c)))
+end
+
+loop!(m::Model, Ninner::Integer) =
+    check(m, ccall((:gb25_loop, m.lib), Cint, (Ptr{Cvoid}, Int32), m.ptr, Ninner), "gb25_loop")
+ab2_step!(m::Model, Δt::Real, euler::Bool = false) =
+    check(m, ccall((:gb25_ab2_step, m.lib), Cint, (Ptr{Cvoid}, Float64, Cint), m.ptr, Δt, euler), "gb25_ab2_step")
+correct_velocities_and_cache_previous_tendencies!(m::Model, Δt::Real = 0.0) =
+    check(m, ccall((:gb25_correct_velocities_and_cache_previous_tendencies, m.lib), Cint, (Ptr{Cvoid}, Float64),
+                   m.ptr, Δt), "gb25_correct_velocities_and_cache_previous_tendencies")
+
+set_option!(m::Model, opt::Integer, value::Integer) =
+    check(m, ccall((:gb25_set_option, m.lib), Cint, (Ptr{Cvoid}, Cint, Int32), m.ptr, opt, value), "gb25_set_option")
+function get_option(m::Model, opt::Integer)
+    v = Ref{Int32}(0)
+    check(m, ccall((:gb25_get_option, m.lib), Cint, (Ptr{Cvoid}, Cint, Ref{Int32}), m.ptr, opt, v), "gb25_get_option")
+    return v[]
+end
+
+# ---- clock: model.clock (src/model_utils.jl:150-155)
+function clock(m::Model)
+    t = Ref{Float64}(0); it = Ref{Int64}(0); dt = Ref{Float64}(0)
+    check(m, ccall((:gb25_get_clock, m.lib), Cint, (Ptr{Cvoid}, Ref{Float64}, Ref{Int64}, Ref{Float64}),
+                   m.ptr, t, it, dt), "gb25_get_clock")
+    return (time = t[], iteration = it[], last_Δt = dt[])
+end
+set_dt!(m::Model, Δt::Real) =
+    check(m, ccall((:gb25_set_dt, m.lib), Cint, (Ptr{Cvoid}, Float64), m.ptr, Δt), "gb25_set_dt")
+
+# ---- fields: parent(field) / interior(field) as host Arrays (copies), column-major [i, j, k] like Oceananigans
+function field_dims(m::Model, field::Integer, include_halos::Bool)
+    d = zeros(Int32, 3)
+    check(m, ccall((:gb25_field_dims, m.lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Int32}),
+                   m.ptr, field, include_halos, d), "gb25_field_dims")
+    return (Int(d[1]), Int(d[2]), Int(d[3]))
+end
+function _get(m::Model{FT}, field::Integer, include_halos::Bool) where {FT}
+    a = Array{FT}(undef, field_dims(m, field, include_halos)...)
+    check(m, ccall((:gb25_get_field, m.lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
+                   m.ptr, field, a, include_halos), "gb25_get_field")
+    return a
+end
+function _set!(m::Model{FT}, field::Integer, a::AbstractArray, include_halos::Bool) where {FT}
+    dims = field_dims(m, field, include_halos)
+    b = Array{FT}(reshape(a, dims))       # contiguous, converted to the library's element type
+    check(m, ccall((:gb25_set_field, m.lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
+                   m.ptr, field, b, include_halos), "gb25_set_field")
+    return nothing
+end
+parent_array(m::Model, field::Integer) = _get(m, field, true)
+interior_array(m::Model, field::Integer) = _get(m, field, false)
+set_parent!(m::Model, field::Integer, a::AbstractArray) = _set!(m, field, a, true)
+set_interior!(m::Model, field::Integer, a::AbstractArray) = _set!(m, field, a, false)
+
+"""
+    device_pointer(m, field) -> Ptr{FT}
+
+Device address of `parent(field)` (exactly the Oceananigans parent layout) for zero-copy wrapping, e.g. with AMDGPU.jl
+`unsafe_wrap(ROCArray, device_pointer(m, f), field_dims(m, f, true))`.  Handing out the pointer of u, v, T, S or of a
+tendency pins those fields to the buffers handed out and turns the AB2 look-ahead off for this model (gb25.h).
+"""
+function device_pointer(m::Model{FT}, field::Integer) where {FT}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(m, ccall((:gb25_field_device_ptr, m.lib), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), m.ptr, field, p),
+          "gb25_field_device_ptr")
+    return Ptr{FT}(p[])
+end
+
+# ---- x-slab decomposition: one Julia process per GPU (Config(rank=..., nranks=...)), halo exchange inside the library
+"128 bytes of ncclGetUniqueId; rank 0 calls this and MPI.Bcast's the buffer."
+function comm_unique_id(::Type{FT} = Float32) where {FT}
+    id = zeros(UInt8, 128)
+    st = ccall((:gb25_comm_unique_id, LIBS[FT]), Cint, (Ptr{UInt8},), id)
+    st == 0 || throw(GB25Error("gb25_comm_unique_id: status $st (librccl could not be loaded?)"))
+    return id
+end
+comm_init_rccl!(m::Model, id::Vector{UInt8}) =
+    check(m, ccall((:gb25_comm_init_rccl, m.lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}), m.ptr, id), "gb25_comm_init_rccl")
+
+end # module

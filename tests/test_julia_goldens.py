@@ -1,0 +1,125 @@
+"""Consumes golden vectors of the REFERENCE (a CPU() Oceananigans =0.96.26 run dumped by tools/dump_goldens.jl) when they
+are present under tests/golden/julia/ and skips otherwise.  This is the test that turns "parity unpinned" into "parity
+pinned": the same protocol as correctness/correctness_baroclinic_instability_simulation_run.jl:40-102, started from the
+stored first checkpoint, with the oracle (CPU, both float types) and with the HIP library (-m gpu) in place of the
+Reactant model, compared field by field at the six checkpoints at the reference's tolerance rtol = sqrt(eps(FT)),
+atol = 0, halos included.  DESIGN.md section 0 maps every restatement choice to the checkpoint / field that exposes it.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import gb25_amd as gb
+from oracle_backend import CPU
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "julia")
+CASES = sorted(d for d in glob.glob(os.path.join(GOLDEN, "*_Float*")) if os.path.isdir(d))
+CHECKPOINTS = ["1_beginning", "2_after_initialize_and_update_state", "3_after_first_time_step",
+               "4_after_2_plus_10_steps", "5_after_sync_and_update_state", "6_after_loop_100"]
+# golden file name -> field name of the backends
+FIELDS = {"u": "u", "v": "v", "w": "w", "η": "eta", "T": "T", "S": "S",
+          "Gn.u": "Gn.u", "Gn.v": "Gn.v", "Gn.T": "Gn.T", "Gn.S": "Gn.S",
+          "Gm.u": "Gm.u", "Gm.v": "Gm.v", "Gm.T": "Gm.T", "Gm.S": "Gm.S",
+          "filtered.U": "U_bar", "filtered.V": "V_bar", "filtered.η": "eta_bar", "U": "U", "V": "V"}
+PROGNOSTIC = ("u", "v", "T", "S", "η", "U", "V")
+
+
+def case_parameters(path):
+    name = os.path.basename(path)
+    ft = "Float64" if name.endswith("Float64") else "Float32"
+    size = name.split("_")[1]
+    Nx, Ny, Nz = (int(t) for t in size.split("x"))
+    dt = float(open(os.path.join(path, "1_beginning", "clock.txt")).read().split("last_dt")[1].split()[0])
+    return ft, Nx, Ny, Nz, dt
+
+
+def load(path, checkpoint, fname):
+    a = np.load(os.path.join(path, checkpoint, fname + ".npy"))
+    return a[:, :, None] if a.ndim == 2 else a
+
+
+def compare(model, path, checkpoint, rtol, names=FIELDS):
+    bad = []
+    for fname, bname in names.items():
+        f = os.path.join(path, checkpoint, fname + ".npy")
+        if not os.path.exists(f):
+            continue
+        ref = load(path, checkpoint, fname).astype(np.float64)
+        got = model.backend.get_field(bname, True).astype(np.float64)
+        got = got[:ref.shape[0], :ref.shape[1], :ref.shape[2]]
+        n = max(np.linalg.norm(ref.ravel()), np.linalg.norm(got.ravel()))
+        d = np.linalg.norm((ref - got).ravel())
+        if not d <= rtol * n:
+            idx = np.unravel_index(np.argmax(np.abs(ref - got)), ref.shape)
+            bad.append((fname, d / n if n else float("inf"), tuple(int(i) + 1 for i in idx)))
+    return bad
+
+
+def run_protocol(model, path, rtol):
+    """The reference's six checkpoints; returns {checkpoint: [(field, rel, 1-based index of the worst cell)]}."""
+    for fname in PROGNOSTIC:
+        model.backend.set_field(FIELDS[fname], load(path, "1_beginning", fname).astype(model.backend.dtype), True)
+    out = {CHECKPOINTS[0]: compare(model, path, CHECKPOINTS[0], rtol, {k: FIELDS[k] for k in PROGNOSTIC})}
+    gb.initialize(model)
+    gb.update_state(model)
+    out[CHECKPOINTS[1]] = compare(model, path, CHECKPOINTS[1], rtol)
+    gb.first_time_step(model)
+    out[CHECKPOINTS[2]] = compare(model, path, CHECKPOINTS[2], rtol)
+    for _ in range(12):
+        gb.time_step(model)
+    out[CHECKPOINTS[3]] = compare(model, path, CHECKPOINTS[3], rtol)
+    gb.update_state(model)
+    out[CHECKPOINTS[4]] = compare(model, path, CHECKPOINTS[4], rtol)
+    gb.loop(model, 100)
+    out[CHECKPOINTS[5]] = compare(model, path, CHECKPOINTS[5], rtol)
+    return out
+
+
+def _skip_if_none():
+    if not CASES:
+        pytest.skip("no reference goldens under tests/golden/julia (run tools/dump_goldens.jl on a Julia host): "
+                    "parity unpinned")
+
+
+def test_golden_directory_is_wired():
+    """Always runs: the loader finds the directory and the kit that fills it is in the tree."""
+    assert os.path.isdir(GOLDEN)
+    for f in ("tools/dump_goldens.jl", "bench/cpu_reference.jl", "julia/GB25HIP.jl"):
+        assert os.path.exists(os.path.join(ROOT, f)), f
+    src = open(os.path.join(ROOT, "tools", "dump_goldens.jl")).read()
+    for c in CHECKPOINTS:
+        assert c in src, c
+
+
+@pytest.mark.parametrize("path", CASES or [None])
+def test_oracle_reproduces_the_reference(path):
+    _skip_if_none()
+    ft, Nx, Ny, Nz, dt = case_parameters(path)
+    model = gb.baroclinic_instability_model(CPU("f64" if ft == "Float64" else "f32"), Nx, Ny, Nz, dt=dt)
+    # grid metrics first: they pin exponential_z_faces and the spherical metrics
+    for name in ("zf", "zc", "dzc", "dzf", "dxc", "dxf", "azc", "azf"):
+        f = os.path.join(path, "grid", name + ".npy")
+        if os.path.exists(f):
+            ref = np.load(f).ravel()
+            H = 8
+            n = Nz if name[0] in "zd" and name not in ("dxc", "dxf") else Ny
+            got = np.array([model.grid.metric(name, q) for q in range(1 - H, 1 - H + len(ref))])
+            core = slice(H, H + n)
+            assert np.allclose(got[core], ref[core], rtol=1e-6 if ft == "Float32" else 1e-12), name
+    rtol = float(np.sqrt(np.finfo(np.float64 if ft == "Float64" else np.float32).eps))
+    out = run_protocol(model, path, rtol)
+    assert not any(out.values()), out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", CASES or [None])
+def test_hip_library_reproduces_the_reference(path):
+    _skip_if_none()
+    ft, Nx, Ny, Nz, dt = case_parameters(path)
+    model = gb.baroclinic_instability_model(gb.GPU(float_type=ft), Nx, Ny, Nz, dt=dt)
+    rtol = float(np.sqrt(np.finfo(np.float64 if ft == "Float64" else np.float32).eps))
+    out = run_protocol(model, path, rtol)
+    assert not any(out.values()), out
