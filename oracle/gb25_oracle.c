@@ -48,6 +48,7 @@ typedef struct {
   double lat_south, lat_north, lon_west, lon_east;
   double depth, zexp_h;
   double g, Omega, radius, rho0;
+  int grid_type; /* 0: flat bottom; 1: GridFittedBottom(gaussian_islands) on this grid */
 } gb25o_config;
 
 typedef struct {
@@ -77,6 +78,12 @@ typedef struct {
   fld f[F_COUNT];
   double time;
   long iter;
+  /* ImmersedBoundaryGrid(grid, GridFittedBottom(bottom_height)) -- /root/reference/src/model_utils.jl:134-146.
+   * All 2-D, laid out like the parent of a (c,c) field (sx x sy): kbot = number of immersed cells of the column
+   * (0-based index of the first active level; Nz = land), static column depths at (c,c), (f,c), (c,f). */
+  int *kbot;
+  REAL *Hcc, *Hfc, *Hcf;
+  int immersed; /* any immersed cell at all */
 } model;
 
 /* ---------------------------------------------------------------- accessors */
@@ -102,6 +109,82 @@ static void alloc_field(model *m, int id, int extra_y, int extra_z, int twod) {
   F->sy = m->Ny + 2 * m->H + extra_y;
   F->sz = twod ? 1 : m->Nz + 2 * m->H + extra_z;
   F->p = (REAL *)calloc((size_t)F->sx * F->sy * F->sz, sizeof(REAL));
+}
+
+/* ---------------------------------------------------------------- immersed boundary
+ * Oceananigans.ImmersedBoundaries, restated [UPSTREAM-UNVERIFIED]:
+ *   immersed_cell(i,j,k)  = z_center(k) <= bottom_height(i,j)         (GridFittedBottom, CenterImmersedCondition)
+ *   inactive_cell         = immersed_cell | outside a Bounded direction (y, z here; x is periodic)
+ *   inactive_node at a face = BOTH adjacent cells inactive;  peripheral_node = EITHER adjacent cell inactive
+ *   immersed_peripheral_node = peripheral on the immersed grid but not on the underlying grid
+ * The materialised bottom height is the top face of the highest immersed cell, so immersed_cell(k) <=> k <= kbot
+ * (1-based k, kbot = number of immersed cells). */
+#define KB(i, j) (m->kbot[((long)(i)-1 + HH) + (long)(m->Nx + 2 * HH) * ((long)(j)-1 + HH)])
+#define H2(arr, i, j) (m->arr[((long)(i)-1 + HH) + (long)(m->Nx + 2 * HH) * ((long)(j)-1 + HH)])
+static inline int inactive_cell(const model *m, int i, int j, int k) {
+  if (j < 1 || j > m->Ny || k < 1 || k > m->Nz) return 1;
+  if (i < 1 - m->H) i = 1 - m->H;              /* (beyond the x halo: never reached by an interior stencil) */
+  if (i > m->Nx + m->H) i = m->Nx + m->H;
+  return k <= KB(i, j);
+}
+static inline int peripheral_u(const model *m, int i, int j, int k) { return inactive_cell(m, i - 1, j, k) || inactive_cell(m, i, j, k); }
+static inline int peripheral_v(const model *m, int i, int j, int k) { return inactive_cell(m, i, j - 1, k) || inactive_cell(m, i, j, k); }
+/* (the underlying lat-lon grid has peripheral nodes of its own only on the v faces j = 1 and j = Ny+1) */
+static inline int immersed_peripheral_u(const model *m, int i, int j, int k) { return peripheral_u(m, i, j, k); }
+static inline int immersed_peripheral_v(const model *m, int i, int j, int k) {
+  return j > 1 && j <= m->Ny && peripheral_v(m, i, j, k);
+}
+/* bottom heights at the cell centres of the interior columns -> kbot and the static column depths */
+static void set_bottom(model *m, const double *zb /* Nx*Ny, i fastest */) {
+  int Nx = m->Nx, Ny = m->Ny, Nz = m->Nz, H = m->H, sx = Nx + 2 * H;
+  long n2 = (long)sx * (Ny + 2 * H + 1);
+  for (long q = 0; q < n2; q++) { m->kbot[q] = 0; m->Hcc[q] = m->Hfc[q] = m->Hcf[q] = 0; }
+  m->immersed = 0;
+  for (int j = 1; j <= Ny; j++)
+    for (int i = 1; i <= Nx; i++) {
+      int kb = 0;
+      for (int k = 1; k <= Nz; k++)
+        if ((double)MK(zc, k) <= zb[(i - 1) + (long)Nx * (j - 1)]) kb = k;   /* z_center <= bottom: immersed */
+      KB(i, j) = kb;
+      if (kb > 0) m->immersed = 1;
+    }
+  /* fill_halo_regions!(bottom_height): periodic x; rows beyond the walls lie outside the domain anyway (the static
+   * depth there mirrors the wall row: zero-gradient) */
+  for (int j = 1; j <= Ny; j++)
+    for (int q = 0; q < H; q++) {
+      KB(1 - H + q, j) = KB(Nx - H + 1 + q, j);
+      KB(Nx + 1 + q, j) = KB(1 + q, j);
+    }
+  for (int i = 1 - H; i <= Nx + H; i++) {
+    KB(i, 0) = KB(i, 1);
+    KB(i, Ny + 1) = KB(i, Ny);
+  }
+  for (int j = 0; j <= Ny + 1; j++)
+    for (int i = 1 - H; i <= Nx + H; i++) {
+      /* static_column_depth = z of the top face - materialised bottom height (the bottom face of the first active cell) */
+      H2(Hcc, i, j) = (REAL)((double)MK(zf, Nz + 1) - (double)MK(zf, KB(i, j) + 1));
+    }
+  for (int j = 1; j <= Ny + 1; j++)
+    for (int i = 2 - H; i <= Nx + H; i++) {
+      REAL a = H2(Hcc, i, j), w = H2(Hcc, i - 1, j), sth = H2(Hcc, i, j - 1);
+      H2(Hfc, i, j) = a < w ? a : w;      /* static_column_depth at (f,c) = min of the two columns */
+      H2(Hcf, i, j) = a < sth ? a : sth;
+    }
+}
+static double mtn(double lam, double phi, double lam1, double phi1) {
+  const double dphi = 5;
+  return exp(-((lam - lam1) * (lam - lam1) + (phi - phi1) * (phi - phi1)) / (2 * dphi * dphi));
+}
+/* gaussian_islands(lambda, phi) = zb + h (mtn1 + mtn2), zb = z[1], h = -zb + 100
+ * (/root/reference/src/model_utils.jl:67-80,138-140) at the cell centres */
+static void gaussian_islands(model *m, const gb25o_config *c, double *zb) {
+  double z1 = -c->depth, h = -z1 + 100.0;
+  double dlam = (c->lon_east - c->lon_west) / m->Nx;
+  for (int j = 1; j <= m->Ny; j++)
+    for (int i = 1; i <= m->Nx; i++) {
+      double lam = c->lon_west + (i - 0.5) * dlam, phi = (double)MJ(phic, j);
+      zb[(i - 1) + (long)m->Nx * (j - 1)] = z1 + h * (mtn(lam, phi, 70, 55) + mtn(lam, phi, 70 + 180, 55));
+    }
 }
 
 /* ---------------------------------------------------------------- grid
@@ -218,6 +301,18 @@ void *FN(create)(const gb25o_config *c) {
   m->Omega = (REAL)c->Omega; m->R = (REAL)c->radius; m->rho0 = (REAL)c->rho0;
   build_grid(m, c);
   build_substeps(m, c->substeps);
+  {
+    long n2 = (long)(m->Nx + 2 * m->H) * (m->Ny + 2 * m->H + 1);
+    m->kbot = (int *)calloc(n2, sizeof(int));
+    m->Hcc = (REAL *)calloc(n2, sizeof(REAL));
+    m->Hfc = (REAL *)calloc(n2, sizeof(REAL));
+    m->Hcf = (REAL *)calloc(n2, sizeof(REAL));
+    double *zb = (double *)malloc(sizeof(double) * (size_t)m->Nx * m->Ny);
+    for (long q = 0; q < (long)m->Nx * m->Ny; q++) zb[q] = -1e30;   /* flat: nothing immersed */
+    if (c->grid_type == 1) gaussian_islands(m, c, zb);
+    set_bottom(m, zb);
+    free(zb);
+  }
   for (int id = 0; id < F_COUNT; id++) {
     int isv = (id == F_V || id == F_GNV || id == F_GMV || id == F_BV || id == F_VB || id == F_GBV);
     int isw = (id == F_W);
@@ -232,6 +327,7 @@ void FN(destroy)(void *h) {
   for (int id = 0; id < F_COUNT; id++) free(m->f[id].p);
   free(m->phif); free(m->phic); free(m->dxc); free(m->dxf); free(m->azc); free(m->azf);
   free(m->fcor); free(m->zf); free(m->zc); free(m->dzc); free(m->dzf);
+  free(m->kbot); free(m->Hcc); free(m->Hfc); free(m->Hcf);
   free(m);
 }
 REAL *FN(field_ptr)(void *h, int id) { return ((model *)h)->f[id].p; }
@@ -251,6 +347,13 @@ int FN(substep_info)(void *h, double *dtau_frac, double *w) {
   *dtau_frac = m->dtau_frac;
   for (int k = 0; k < m->Ns; k++) w[k] = m->wts[k];
   return m->Ns;
+}
+/* bottom height at the interior cell centres (Nx*Ny doubles, i fastest); GridFittedBottom(zb) */
+void FN(set_bottom_height)(void *h, const double *zb) { set_bottom((model *)h, zb); }
+/* which: 0 kbot, 1 Hcc, 2 Hfc, 3 Hcf at logical (i, j) */
+double FN(bottom_info)(void *h, int which, int i, int j) {
+  model *m = (model *)h;
+  return which == 0 ? (double)KB(i, j) : which == 1 ? (double)H2(Hcc, i, j) : which == 2 ? (double)H2(Hfc, i, j) : (double)H2(Hcf, i, j);
 }
 void FN(set_dt)(void *h, double dt) { ((model *)h)->dt = (REAL)dt; }
 double FN(get_time)(void *h) { return ((model *)h)->time; }
@@ -424,14 +527,34 @@ static inline REAL at_dir(const model *m, fn3 f, int dir, int i, int j, int k, i
  * s1/s2: optional smoothness functions (FunctionStencil: s1; VelocityStencil: s1,s2).
  * Bounded directions (y, z) drop to WENO3 and first-order upwind next to the walls
  * (topologically conditional interpolation, restated). */
+/* Is every node of the 2*buffer-point stencil around the target active?  Face target idx: the cells idx-buffer ..
+ * idx+buffer-1 (nodes at the centre location along dir); centre target idx: the faces idx-buffer+1 .. idx+buffer,
+ * a face node being inactive when BOTH cells it separates are inactive.  Along the other two directions the node sits
+ * at the centre location with the target's own indices (Oceananigans' near_*_immersed_boundary_* functions, restated).
+ * With nothing immersed this reduces to the topological rules for Bounded directions (outside_*_halo). */
+static int stencil_active(const model *m, int dir, int target, int i, int j, int k, int buffer) {
+  int idx = dir == DX ? i : dir == DY ? j : k;
+  /* a horizontal stencil of a quantity that lives on the z faces (the advecting Az w of the vertical momentum flux)
+   * sees the activity of the cell row above the face; the top face Nz+1 that of level Nz.  [restatement choice: keeps
+   * the flat-bottom immersed grid identical to the plain grid, where the rule looks at the horizontal index only] */
+  if (dir != DZ && k > m->Nz) k = m->Nz;
+  int p0 = target == TO_FACE ? idx - buffer : idx - buffer + 1, p1 = p0 + 2 * buffer - 1;
+  for (int p = p0; p <= p1; p++) {
+    int a = dir == DX ? inactive_cell(m, p, j, k) : dir == DY ? inactive_cell(m, i, p, k) : inactive_cell(m, i, j, p);
+    if (target == TO_FACE) {
+      if (a) return 0;
+    } else {
+      int b = dir == DX ? inactive_cell(m, p - 1, j, k) : dir == DY ? inactive_cell(m, i, p - 1, k) : inactive_cell(m, i, j, p - 1);
+      if (a && b) return 0;
+    }
+  }
+  return 1;
+}
 static REAL biased_interp(const model *m, int dir, int target, int i, int j, int k, int left, fn3 psi, fn3 s1, fn3 s2) {
   int idx = dir == DX ? i : dir == DY ? j : k;
-  int N = dir == DX ? m->Nx : dir == DY ? m->Ny : m->Nz;
-  int order = 5;
-  if (dir != DX) {
-    if (target == TO_FACE) order = (idx >= 4 && idx <= N - 2) ? 5 : (idx >= 3 && idx <= N - 1) ? 3 : 1;
-    else order = (idx >= 3 && idx <= N - 2) ? 5 : (idx >= 2 && idx <= N - 1) ? 3 : 1;
-  }
+  /* WENO5 -> WENO3 -> first-order upwind as the stencil meets a wall or the immersed boundary */
+  int order = (dir == DX && !m->immersed) ? 5
+            : stencil_active(m, dir, target, i, j, k, 3) ? 5 : stencil_active(m, dir, target, i, j, k, 2) ? 3 : 1;
   int c0 = target == TO_FACE ? (left ? idx - 1 : idx) : (left ? idx : idx + 1);
   int sg = left ? 1 : -1;
   if (order == 1) return at_dir(m, psi, dir, i, j, k, c0);
@@ -468,12 +591,7 @@ static REAL biased_interp(const model *m, int dir, int target, int i, int j, int
  * bounded directions it drops to second order. */
 static REAL sym_interp(const model *m, int dir, int target, int i, int j, int k, fn3 psi) {
   int idx = dir == DX ? i : dir == DY ? j : k;
-  int N = dir == DX ? m->Nx : dir == DY ? m->Ny : m->Nz;
-  int order = 4;
-  if (dir != DX) {
-    if (target == TO_FACE) order = (idx >= 4 && idx <= N - 2) ? 4 : 2;
-    else order = (idx >= 3 && idx <= N - 2) ? 4 : 2;
-  }
+  int order = (dir == DX && !m->immersed) ? 4 : stencil_active(m, dir, target, i, j, k, 3) ? 4 : 2;
   int b = target == TO_FACE ? idx - 1 : idx; /* the lower of the two central points */
   if (order == 2) return (at_dir(m, psi, dir, i, j, k, b) + at_dir(m, psi, dir, i, j, k, b + 1)) / (REAL)2;
   return (-at_dir(m, psi, dir, i, j, k, b - 1) + (REAL)7 * at_dir(m, psi, dir, i, j, k, b) +
@@ -642,8 +760,11 @@ void FN(compute_momentum_tendencies)(void *h) {
   for (int k = 1; k <= m->Nz; k++)
     for (int j = 1; j <= m->Ny; j++)
       for (int i = 1; i <= m->Nx; i++) {
-        A3(F_GNU, i, j, k) = Gu_at(m, i, j, k);
-        A3(F_GNV, i, j, k) = Gv_at(m, i, j, k);
+        /* zero at immersed peripheral nodes (faces that touch the solid): the velocity there is masked to zero and
+         * stays zero.  [restatement choice: upstream evaluates the kernel there too and discards the result through
+         * mask_immersed_field!; its integrated tendencies use exactly this mask] */
+        A3(F_GNU, i, j, k) = immersed_peripheral_u(m, i, j, k) ? (REAL)0 : Gu_at(m, i, j, k);
+        A3(F_GNV, i, j, k) = immersed_peripheral_v(m, i, j, k) ? (REAL)0 : Gv_at(m, i, j, k);
       }
 }
 static REAL tracer_flux(const model *m, int dir, int i, int j, int k, fn3 c) {
@@ -680,7 +801,27 @@ void FN(compute_tendencies)(void *h) {
 }
 /* update_state!(model; compute_tendencies=true): phases 1-5 of /root/reference/src/precompile.jl:34-38
  * (mask_immersed and diffusivity halos are no-ops for this configuration). */
+/* mask_immersed_model_fields!(model, grid) -- /root/reference/src/precompile.jl:21,34: prognostic fields are set to
+ * zero at peripheral nodes of their location (u, v: faces that touch an inactive cell; T, S: inactive cells); the
+ * barotropic transports where the column of their face has no depth. */
+void FN(mask_immersed_fields)(void *h) {
+  model *m = (model *)h;
+  for (int k = 1; k <= m->Nz; k++)
+    for (int j = 1; j <= m->Ny + 1; j++)
+      for (int i = 1; i <= m->Nx; i++) {
+        if (peripheral_v(m, i, j, k)) A3(F_V, i, j, k) = 0;
+        if (j > m->Ny) continue;
+        if (peripheral_u(m, i, j, k)) A3(F_U, i, j, k) = 0;
+        if (inactive_cell(m, i, j, k)) A3(F_T, i, j, k) = A3(F_S, i, j, k) = 0;
+      }
+  for (int j = 1; j <= m->Ny + 1; j++)
+    for (int i = 1; i <= m->Nx; i++) {
+      if (j <= m->Ny && H2(Hfc, i, j) == 0) A2(F_BU, i, j) = 0;
+      if (j == 1 || j > m->Ny || H2(Hcf, i, j) == 0) A2(F_BV, i, j) = 0;
+    }
+}
 void FN(update_state)(void *h) {
+  FN(mask_immersed_fields)(h);
   FN(fill_halos)(h);
   FN(compute_auxiliaries)(h);
   FN(compute_tendencies)(h);
@@ -741,7 +882,6 @@ static void ab2_field(model *m, int id, int gn, int gm, REAL dt, REAL chi, int v
 static void step_free_surface(model *m, REAL dt) {
   int Nx = m->Nx, Ny = m->Ny;
   REAL dtau = m->dtau_frac * dt;
-  REAL Hc = m->Lz;
   for (int id = F_ETAB; id <= F_VB; id++)
     memset(m->f[id].p, 0, sizeof(REAL) * (size_t)m->f[id].sx * m->f[id].sy);
   for (int s = 0; s < m->Ns; s++) {
@@ -762,8 +902,9 @@ static void step_free_surface(model *m, REAL dt) {
         int im = (i == 1) ? Nx : i - 1;
         REAL dxe = (A2(F_ETA, i, j) - A2(F_ETA, im, j)) / DXC(j);
         REAL dye = (j == 1) ? 0 : (A2(F_ETA, i, j) - A2(F_ETA, i, j - 1)) / m->dy;
-        REAL Un = A2(F_BU, i, j) + dtau * (-m->g * Hc * dxe + A2(F_GBU, i, j));
-        REAL Vn = A2(F_BV, i, j) + dtau * (-m->g * Hc * dye + A2(F_GBV, i, j));
+        /* static column depth at the face: min of the two columns (0 next to land: no pressure force, and G.U is 0) */
+        REAL Un = A2(F_BU, i, j) + dtau * (-m->g * H2(Hfc, i, j) * dxe + A2(F_GBU, i, j));
+        REAL Vn = A2(F_BV, i, j) + dtau * (-m->g * H2(Hcf, i, j) * dye + A2(F_GBV, i, j));
         A2(F_ETAB, i, j) += wgt * A2(F_ETA, i, j);
         A2(F_UB, i, j) += wgt * Un;
         A2(F_VB, i, j) += wgt * Vn;
@@ -794,13 +935,15 @@ void FN(ab2_step)(void *h, double dt_, int euler) {
 void FN(correct_and_cache)(void *h) {
   model *m = (model *)h;
   barotropic_mode(m, F_UB, F_VB);
-  REAL Hc = m->Lz;
 #pragma omp parallel for collapse(2) schedule(static)
   for (int k = 1; k <= m->Nz; k++)
     for (int j = 1; j <= m->Ny; j++)
       for (int i = 1; i <= m->Nx; i++) {
-        A3(F_U, i, j, k) = A3(F_U, i, j, k) + (A2(F_BU, i, j) - A2(F_UB, i, j)) / Hc;
-        A3(F_V, i, j, k) = A3(F_V, i, j, k) + (A2(F_BV, i, j) - A2(F_VB, i, j)) / Hc;
+        /* (peripheral faces keep their zero: what upstream gets from mask_immersed_model_fields! right after) */
+        if (!immersed_peripheral_u(m, i, j, k))
+          A3(F_U, i, j, k) = A3(F_U, i, j, k) + (A2(F_BU, i, j) - A2(F_UB, i, j)) / H2(Hfc, i, j);
+        if (!immersed_peripheral_v(m, i, j, k))
+          A3(F_V, i, j, k) = A3(F_V, i, j, k) + (A2(F_BV, i, j) - A2(F_VB, i, j)) / (j == 1 ? m->Lz : H2(Hcf, i, j));
       }
   for (int q = 0; q < 4; q++)
     for (int k = 1; k <= m->Nz; k++)

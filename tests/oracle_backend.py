@@ -38,7 +38,8 @@ class OConfig(C.Structure):
                 ("dt", C.c_double), ("chi", C.c_double),
                 ("lat_south", C.c_double), ("lat_north", C.c_double), ("lon_west", C.c_double),
                 ("lon_east", C.c_double), ("depth", C.c_double), ("zexp_h", C.c_double),
-                ("g", C.c_double), ("Omega", C.c_double), ("radius", C.c_double), ("rho0", C.c_double)]
+                ("g", C.c_double), ("Omega", C.c_double), ("radius", C.c_double), ("rho0", C.c_double),
+                ("grid_type", C.c_int)]
 
 
 def build_oracle():
@@ -68,7 +69,7 @@ class OracleBackend:
         self.dtype = np.float64 if precision == "f64" else np.float32
         self.ctype = C.c_double if precision == "f64" else C.c_float
         cfg = OConfig(Nx, Ny, Nz, halo, substeps, dt, 0.1, -80, 80, 0, 360, 4000, 30, 9.80665, 7.292115e-5, 6371e3,
-                      1020.0)
+                      1020.0, 0)
         for k, v in overrides.items():
             setattr(cfg, k, v)
         self.cfg = cfg
@@ -171,7 +172,20 @@ class OracleBackend:
     def synchronize(self): pass
     def set_baroclinic_instability(self): self._call("set_baroclinic_instability")
     def initialize(self): self._call("initialize")
-    def mask_immersed_fields(self): pass
+    def mask_immersed_fields(self): self._call("mask_immersed_fields")
+
+    def set_bottom_height(self, zb):
+        """GridFittedBottom(zb): bottom height at the interior cell centres, shape (Nx, Ny)."""
+        a = np.ascontiguousarray(np.asarray(zb, dtype=np.float64).T)      # i fastest
+        f = self._fn("set_bottom_height")
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        f(self.h, a.ctypes.data_as(C.c_void_p))
+
+    def bottom_info(self, which, i, j):
+        f = self._fn("bottom_info")
+        f.restype = C.c_double
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        return f(self.h, {"kbot": 0, "Hcc": 1, "Hfc": 2, "Hcf": 3}[which], i, j)
     def fill_halo_regions(self): self._call("fill_halos")
     def compute_auxiliaries(self): self._call("compute_auxiliaries")
     def fill_diffusivity_halos(self): pass
