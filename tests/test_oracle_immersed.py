@@ -140,7 +140,7 @@ def test_rest_state_over_topography_stays_at_rest():
 
 def test_barotropic_wave_feels_the_local_depth():
     """A zonal free-surface wave in a channel whose whole floor is raised to a shelf: phase speed sqrt(g H_shelf)."""
-    Nx, Ny, Nz, nsteps, mode = 64, 16, 8, 40, 2
+    Nx, Ny, Nz, nsteps, mode = 64, 16, 8, 120, 2
     m = make_oracle(Nx, Ny, Nz, 200.0, lat_south=-2.0, lat_north=2.0, Omega=0.0)
     zf = np.array([m.backend.metric("zf", k) for k in range(1, Nz + 2)])
     m.backend.set_bottom_height(np.full((Nx, Ny), zf[4] + 0.25 * (zf[5] - zf[4])))   # four levels immersed
