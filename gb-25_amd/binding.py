@@ -38,14 +38,14 @@ ABI_SYMBOLS = [
     "gb25_compute_momentum_tendencies", "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
     "gb25_compute_tendencies", "gb25_ab2_step", "gb25_correct_velocities_and_cache_previous_tendencies",
     "gb25_update_state", "gb25_first_time_step", "gb25_time_step", "gb25_loop",
-    "gb25_set_option", "gb25_get_option",
+    "gb25_set_option", "gb25_get_option", "gb25_set_bottom_height", "gb25_get_bottom_info",
     "gb25_comm_unique_id", "gb25_comm_init_rccl", "gb25_comm_init_local", "gb25_comm_init_callback", "gb25_comm_finalize",
     "gb25_lookahead_state", "gb25_debug_sequence",
     "gb25_profile_enable", "gb25_profile_reset", "gb25_profile_get",
 ]
 # gb25_option (include/gb25.h)
 OPTION_IDS = {"kernels": 0, "ab2_lookahead": 1, "subcycle_lookahead": 2, "subcycle_block": 3, "fill_fused": 4,
-              "two_streams": 5, "store_pressure": 6, "split_tendencies": 7, "pressure_precision": 8}
+              "two_streams": 5, "store_pressure": 6, "split_tendencies": 7, "pressure_precision": 8, "immersed_kernels": 9}
 UNIQUE_ID_BYTES = 128
 # int32 fn(void *user, int32 buffer_set, const void *send_w, const void *send_e, void *recv_w, void *recv_e, int64 nbytes)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
@@ -116,6 +116,8 @@ def load_library(float_type="Float32"):
     lib.gb25_ab2_step.argtypes = [P, C.c_double, C.c_int]
     lib.gb25_correct_velocities_and_cache_previous_tendencies.argtypes = [P, C.c_double]
     lib.gb25_loop.argtypes = [P, C.c_int32]
+    lib.gb25_set_bottom_height.argtypes = [P, P]
+    lib.gb25_get_bottom_info.argtypes = [P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     lib.gb25_set_option.argtypes = [P, C.c_int, C.c_int32]
     lib.gb25_get_option.argtypes = [P, C.c_int, C.POINTER(C.c_int32)]
     lib.gb25_comm_unique_id.argtypes = [P]
@@ -264,6 +266,20 @@ class HipBackend:
     def first_time_step(self): self._call("gb25_first_time_step")
     def time_step(self): self._call("gb25_time_step")
     def loop(self, n): self._call("gb25_loop", int(n))
+
+    # ---- immersed boundary
+    def set_bottom_height(self, zb):
+        """GridFittedBottom(zb): bottom height at the interior cell centres, shape (Nx, Ny)."""
+        a = np.ascontiguousarray(np.asarray(zb, dtype=np.float64).T)      # i fastest
+        if a.shape != (self.cfg.Ny, self.cfg.Nx // self.cfg.nranks):
+            raise ValueError(f"bottom height: expected shape ({self.cfg.Nx // self.cfg.nranks}, {self.cfg.Ny})")
+        self._call("gb25_set_bottom_height", a.ctypes.data_as(C.c_void_p))
+
+    def bottom_info(self, which, i, j):
+        """1-based (i, j) like the Julia sources; which: kbot | Hfc | Hcf."""
+        v = C.c_double()
+        self._call("gb25_get_bottom_info", {"kbot": 0, "Hfc": 1, "Hcf": 2}[which], i - 1, j - 1, C.byref(v))
+        return v.value
 
     # ---- options (gb25_option)
     def set_option(self, name, value):

@@ -25,6 +25,23 @@ __device__ __forceinline__ double rmax(double a, double b) { return __builtin_fm
 __device__ __forceinline__ float rtanh(float x) { return tanhf(x); }
 __device__ __forceinline__ double rtanh(double x) { return tanh(x); }
 
+// ImmersedBoundaryGrid(grid, GridFittedBottom(bottom_height); active_cells_map = false) -- GB-25 src/model_utils.jl:
+// 134-146.  A cell (i,j,k) is active from level kc(i,j) on (kc = number of immersed cells of the column).  Everything
+// the kernels need is folded per column on the host into small 2-D tables (laid out like the parent of a (c,f) field:
+// pitch sx, Ny+2H+1 rows), so that no kernel ever looks at a neighbour's bottom:
+//   first level from which a reconstruction stencil is fully active -- 255 = never; walls count as inactive, so the
+//   wall-adjacent order reduction of the plain grid is the special case kc = 0:
+//     ordA = kc | KX5 << 8 | KX3 << 16 | KY5 << 24      face target in x / y: cells i-3..i+2 (order 5), i-2..i+1 (order 3)
+//     ordB = KY3 | KXC5 << 8 | KXC3 << 16 | KYC5 << 24   centre target: face nodes i-2..i+3 / i-1..i+2, a face node being
+//     ordC = KYC3 | KPU << 8 | KPV << 16                  inactive when BOTH its cells are
+//   KPU / KPV: first level at which the u / v face is not an immersed peripheral node (max of the two columns' kc)
+//   static column depths at the faces (min of the two columns) and their reciprocals (0 where there is no depth)
+struct Immersed {
+  const unsigned *ordA, *ordB, *ordC;
+  const real *Hfc, *Hcf, *rHfc, *rHcf;
+};
+__device__ __forceinline__ int order_from(int k, int K5, int K3) { return k >= K5 ? 5 : (k >= K3 ? 3 : 1); }
+
 struct Grid {
   int Nx, Ny, Nz, H;      // LOCAL interior size and halo
   int sx;                 // row pitch          = Nx + 2H
@@ -40,6 +57,7 @@ struct Grid {
   // TEOS-10 folded per level: rho'(s,t) = sum_{i+j<=6} eos[k][idx(i,j)] s^i t^j, k = 0..Nz (Nz = mirrored halo level)
   const double* eos;
   const double* dzf_d;                               // dzf in fp64 for the hydrostatic integral, by k (0..Nz)
+  Immersed im;                                       // (null pointers on a grid without bathymetry)
 };
 
 // element offsets

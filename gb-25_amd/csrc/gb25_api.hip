@@ -102,6 +102,14 @@ struct gb25_model {
   int kernel_gen = 2;                // 2: LDS / flux-sharing tendency kernels (tendency_kernels.hpp); 1: direct-stencil kernels
   int pressure_bits = 64;            // option PRESSURE_PRECISION: 64 = fp64 EOS + integral (default); 32 = the float type's own
   int split_tendencies = 1;          // slab of a decomposition: interior tile columns before the x-halo bundle has arrived
+  // immersed boundary (GridFittedBottom): first active level per column on the columns [-kb_E, Nx + kb_E) x [0, Ny)
+  // (host), the folded tables of device_common.hpp (device), the depths of the wide barotropic arrays of a slab
+  bool immersed = false;             // some cell is immersed: the IMM kernel variants run
+  int kb_E = 0;
+  std::vector<int> kbot;
+  unsigned* d_ord[3] = {nullptr, nullptr, nullptr};
+  real* d_H[4] = {nullptr, nullptr, nullptr, nullptr};   // Hfc, Hcf, rHfc, rHcf (parent layout of a (c,f) field)
+  real* d_wideH[2] = {nullptr, nullptr};                 // Hfc, Hcf on the wide barotropic layout of a slab
   bool slab = false;                 // x halos come from a neighbour (nranks > 1, or the self-ring of slab_mode = 1)
   struct SlabGroup* group = nullptr; // exchange context (transport, buffers, comm stream) once gb25_comm_init_* was called
   int group_index = 0;               // this slab's position in group->slabs
@@ -341,6 +349,114 @@ void build_substeps(gb25_model* m) {
   for (int k = 1; k <= lo; k++) m->weights[k - 1] = w[k] / s;
 }
 
+// GridFittedBottom(bottom_height) -> first active level per column -> the folded tables (device_common.hpp, Immersed).
+// zb(i, j): bottom height at the centre of LOCAL column i (any i in [-E, Nx + E)), row j in [0, Ny).
+// Restated from Oceananigans.ImmersedBoundaries [UPSTREAM-UNVERIFIED]; oracle/gb25_oracle.c states the same rules cell
+// by cell (inactive_cell / stencil_active) and tests/test_gpu_immersed.py compares the two.
+template <class ZB>
+gb25_status build_bottom(gb25_model* m, ZB zb) {
+  const gb25_config& c = m->cfg;
+  const int Nx = m->Nx, Ny = c.Ny, Nz = c.Nz, H = c.halo, offk = m->metric_off_k;
+  const int E = std::max(H, m->W) + 4, ksx = Nx + 2 * E;
+  const std::vector<double>&zc = m->h_metric[GB25_M_ZC], &zf = m->h_metric[GB25_M_ZF];
+  m->kb_E = E;
+  m->kbot.assign((size_t)ksx * Ny, 0);
+  bool any = false;
+  for (int j = 0; j < Ny; j++)
+    for (int i = -E; i < Nx + E; i++) {
+      const double b = zb(i, j);
+      int kb = 0;
+      for (int k = 0; k < Nz; k++)
+        if ((double)(real)zc[offk + k] <= b) kb = k + 1;   // z_center <= bottom: immersed (CenterImmersedCondition)
+      m->kbot[(size_t)(i + E) + (size_t)ksx * j] = kb;
+      any = any || kb > 0;
+    }
+  m->immersed = any;
+  // level from which cell (i, j) is active; rows beyond the walls never are
+  auto thr = [&](int i, int j) -> int {
+    if (j < 0 || j >= Ny) return 255;
+    return m->kbot[(size_t)(std::min(std::max(i, -E), Nx + E - 1) + E) + (size_t)ksx * j];
+  };
+  auto node_x = [&](int q, int j) { return std::min(thr(q - 1, j), thr(q, j)); };   // face node: inactive when BOTH cells are
+  auto node_y = [&](int i, int q) { return std::min(thr(i, q - 1), thr(i, q)); };
+  auto depth = [&](int i, int j) -> double {   // static column depth: top face - materialised bottom
+    const int jj = std::min(std::max(j, 0), Ny - 1);
+    const int kb = thr(i, jj);
+    return (double)(real)zf[offk + Nz] - (double)(real)zf[offk + kb];
+  };
+  const int sx = Nx + 2 * H, sy = Ny + 2 * H + 1;
+  std::vector<unsigned> A((size_t)sx * sy, 0), B(A.size(), 0), C(A.size(), 0);
+  std::vector<real> Hf(A.size(), 0), Hc(A.size(), 0), rHf(A.size(), 0), rHc(A.size(), 0);
+  for (int j = 0; j <= Ny; j++)
+    for (int i = -H; i < Nx + H; i++) {
+      const size_t o = (size_t)(i + H) + (size_t)sx * (j + H);
+      int KX5 = 0, KX3 = 0, KY5 = 0, KY3 = 0, KXC5 = 0, KXC3 = 0, KYC5 = 0, KYC3 = 0;
+      for (int q = -3; q <= 2; q++) { KX5 = std::max(KX5, thr(i + q, j)); KY5 = std::max(KY5, thr(i, j + q)); }
+      for (int q = -2; q <= 1; q++) { KX3 = std::max(KX3, thr(i + q, j)); KY3 = std::max(KY3, thr(i, j + q)); }
+      for (int q = -2; q <= 3; q++) { KXC5 = std::max(KXC5, node_x(i + q, j)); KYC5 = std::max(KYC5, node_y(i, j + q)); }
+      for (int q = -1; q <= 2; q++) { KXC3 = std::max(KXC3, node_x(i + q, j)); KYC3 = std::max(KYC3, node_y(i, j + q)); }
+      const int kc = std::min(thr(i, j), Nz);   // (the extra face row j = Ny has no cells: its kc is never used)
+      const int KPU = std::max(thr(i - 1, j), thr(i, j));
+      const int KPV = (j == 0 || j >= Ny) ? 0 : std::max(thr(i, j - 1), thr(i, j));   // wall faces: the plain grid's business
+      A[o] = (unsigned)kc | (unsigned)KX5 << 8 | (unsigned)KX3 << 16 | (unsigned)KY5 << 24;
+      B[o] = (unsigned)KY3 | (unsigned)KXC5 << 8 | (unsigned)KXC3 << 16 | (unsigned)KYC5 << 24;
+      C[o] = (unsigned)KYC3 | (unsigned)std::min(KPU, 255) << 8 | (unsigned)KPV << 16;
+      const double hf = std::min(depth(i - 1, j), depth(i, j)), hc = std::min(depth(i, j - 1), depth(i, j));
+      Hf[o] = (real)hf;
+      Hc[o] = (real)hc;
+      rHf[o] = hf > 0 ? (real)(1.0 / hf) : real(0.);
+      // (the v face on the southern wall never moves; its correction divides by the full depth as on the plain grid)
+      rHc[o] = j == 0 ? (real)(1.0 / ((double)(real)zf[offk + Nz] - (double)(real)zf[offk])) : (hc > 0 ? (real)(1.0 / hc) : real(0.));
+    }
+  auto upload = [&](const void* h, size_t bytes, void** d) -> gb25_status {
+    if (!*d) HIPCHK(hipMalloc(d, bytes));
+    HIPCHK(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+    return GB25_OK;
+  };
+  gb25_status s;
+  if ((s = upload(A.data(), A.size() * sizeof(unsigned), (void**)&m->d_ord[0]))) return s;
+  if ((s = upload(B.data(), B.size() * sizeof(unsigned), (void**)&m->d_ord[1]))) return s;
+  if ((s = upload(C.data(), C.size() * sizeof(unsigned), (void**)&m->d_ord[2]))) return s;
+  if ((s = upload(Hf.data(), Hf.size() * sizeof(real), (void**)&m->d_H[0]))) return s;
+  if ((s = upload(Hc.data(), Hc.size() * sizeof(real), (void**)&m->d_H[1]))) return s;
+  if ((s = upload(rHf.data(), rHf.size() * sizeof(real), (void**)&m->d_H[2]))) return s;
+  if ((s = upload(rHc.data(), rHc.size() * sizeof(real), (void**)&m->d_H[3]))) return s;
+  m->g.im.ordA = m->d_ord[0]; m->g.im.ordB = m->d_ord[1]; m->g.im.ordC = m->d_ord[2];
+  m->g.im.Hfc = m->d_H[0]; m->g.im.Hcf = m->d_H[1]; m->g.im.rHfc = m->d_H[2]; m->g.im.rHcf = m->d_H[3];
+  if (m->slab) {   // the same depths on the widened barotropic slab: columns [-W, Nx + W)
+    const int W = m->W, wsx = Nx + 2 * W;
+    std::vector<real> wf((size_t)wsx * sy, 0), wc(wf.size(), 0);
+    for (int j = 0; j <= Ny; j++)
+      for (int i = -W; i < Nx + W; i++) {
+        const size_t o = (size_t)(i + W) + (size_t)wsx * (j + H);
+        wf[o] = (real)std::min(depth(i - 1, j), depth(i, j));
+        wc[o] = (real)std::min(depth(i, j - 1), depth(i, j));
+      }
+    if ((s = upload(wf.data(), wf.size() * sizeof(real), (void**)&m->d_wideH[0]))) return s;
+    if ((s = upload(wc.data(), wc.size() * sizeof(real), (void**)&m->d_wideH[1]))) return s;
+  }
+  m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+  return GB25_OK;
+}
+// gaussian_islands(lambda, phi) = zb + h (mtn1 + mtn2), zb = z[1], h = -zb + 100; mountains 5 degrees wide at (70 E,
+// 55 N) and (250 E, 55 N) (GB-25 src/model_utils.jl:67-80,138-140).  A function of the GLOBAL longitude: the halo
+// columns of a slab see the neighbour's bottom without any exchange.
+double gaussian_islands_bottom(const gb25_model* m, int i_local, int j) {
+  const gb25_config& c = m->cfg;
+  const double dlam = (c.lon_east - c.lon_west) / c.Nx, dphi = (c.lat_north - c.lat_south) / c.Ny;
+  int ig = (i_local + c.rank * m->Nx) % c.Nx;
+  if (ig < 0) ig += c.Nx;
+  const double lam = c.lon_west + (ig + 0.5) * dlam;
+  // (the centre latitude as the model's float type holds it: phi_c is a metric of the grid)
+  const double phi = (double)(real)(c.lat_south + (j + 0.5) * dphi);
+  auto mtn = [](double l, double p, double l1, double p1) {
+    const double d = 5;
+    return std::exp(-((l - l1) * (l - l1) + (p - p1) * (p - p1)) / (2 * d * d));
+  };
+  const double z1 = -c.depth, h = -z1 + 100.0;
+  return z1 + h * (mtn(lam, phi, 70, 55) + mtn(lam, phi, 70 + 180, 55));
+}
+
 gb25_status alloc_field(gb25_model* m, Field& F, int nx, int ny, int nz) {
   F.nx = nx; F.ny = ny; F.nz = nz;
   hipError_t e = hipMalloc(&F.d, F.elems() * sizeof(real));
@@ -552,7 +668,8 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
       nx.dt = dt; nx.C1 = real(1.5) + chi; nx.C2 = real(0.5) + chi;
       nx.plane2 = g.sx * g.sy_v;
     }
-    auto k5 = ahead ? k_momentum_tendencies_v5<MW, TYm, true> : k_momentum_tendencies_v5<MW, TYm, false>;
+    auto k5 = m->immersed ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true>)
+                          : (ahead ? k_momentum_tendencies_v5<MW, TYm, true, false> : k_momentum_tendencies_v5<MW, TYm, false, false>);
     if (nb > 0)
       hipLaunchKernelGGL(k5, dim3(nb), dim3(V2_TX, TYm), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                          m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, tc, kchunks, nb, nx);
@@ -569,6 +686,7 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
     return GB25_OK;
   }
   if (part == 1) return GB25_OK;   // the direct-stencil kernels are not split: everything after the halos arrived
+  if (m->immersed) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know no immersed boundary");
   tile_grid(g, &nbx, &nb);
   dim3 b(TX, TY);
   {
@@ -602,7 +720,8 @@ gb25_status tracers_impl(gb25_model* m) {
       nx.dt = (real)m->last_dt;
       nx.C1 = real(1.5) + (real)m->cfg.chi; nx.C2 = real(0.5) + (real)m->cfg.chi;
     }
-    auto kern = ahead ? k_tracer_tendencies_v5<TW, true> : k_tracer_tendencies_v5<TW, false>;
+    auto kern = m->immersed ? (ahead ? k_tracer_tendencies_v5<TW, true, true> : k_tracer_tendencies_v5<TW, false, true>)
+                            : (ahead ? k_tracer_tendencies_v5<TW, true, false> : k_tracer_tendencies_v5<TW, false, false>);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64, 4), 0, m->stream, g, m->f[GB25_U].d,
                        m->f[GB25_V].d, m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d,
                        m->f[GB25_GN_S].d, nbx, kchunks, nb, nx);
@@ -613,6 +732,7 @@ gb25_status tracers_impl(gb25_model* m) {
     return GB25_OK;
   }
   m->ahead_valid = false;   // only the packed kernel looks ahead
+  if (m->immersed) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know no immersed boundary");
   tile_grid(g, &nbx, &nb);
   Timed t(m, GB25_K_TRACERS);
   hipLaunchKernelGGL(k_tracer_tendencies, dim3(nb), dim3(TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
@@ -715,6 +835,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     bb.GU = ahead ? m->ahead_G[0].d : m->f[GB25_GN_BT_U].d;
     bb.GV = ahead ? m->ahead_G[1].d : m->f[GB25_GN_BT_V].d;
     bb.sx = g.sx; bb.xo = g.H; bb.ilo = 0; bb.ihi = g.Nx; bb.wrap = 1;
+    bb.Hfc = m->d_H[0]; bb.Hcf = m->d_H[1];
   } else {
     if (m->baro_block <= 1)
       HIPCHK(hipMemsetAsync(m->wideBar[0].d, 0,
@@ -727,7 +848,9 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     bb.etab = m->wideBar[0].d; bb.Ub = m->wideBar[1].d; bb.Vb = m->wideBar[2].d;
     bb.GU = m->wideG[0].d; bb.GV = m->wideG[1].d;
     bb.sx = g.Nx + 2 * m->W; bb.xo = m->W; bb.ilo = -m->W + 1; bb.ihi = g.Nx + m->W - 1; bb.wrap = 0;
+    bb.Hfc = m->d_wideH[0]; bb.Hcf = m->d_wideH[1];
   }
+  const bool imm = m->immersed;
   bool finalize_after = false;
   if (m->baro_block > 1) {
     // temporally blocked: S substeps per launch on (64 x TY) tiles
@@ -735,7 +858,8 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     constexpr int TYb = 16;
     dim3 gm((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX, (g.Ny + TYb - 1) / TYb);
     void (*kern)(Grid, BaroMulti, real) =
-        S <= 3 ? k_barotropic_multi<3, TYb> : (S <= 5 ? k_barotropic_multi<5, TYb> : k_barotropic_multi<7, TYb>);
+        imm ? (S <= 3 ? k_barotropic_multi<3, TYb, true> : (S <= 5 ? k_barotropic_multi<5, TYb, true> : k_barotropic_multi<7, TYb, true>))
+            : (S <= 3 ? k_barotropic_multi<3, TYb, false> : (S <= 5 ? k_barotropic_multi<5, TYb, false> : k_barotropic_multi<7, TYb, false>));
     const int Sk = S <= 3 ? 3 : (S <= 5 ? 5 : 7);
     for (int s = 0; s < m->Ns; s += Sk) {
       BaroMulti bm;
@@ -765,7 +889,8 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     for (int s = 0; s < m->Ns; s++) {
       bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
       bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
-      hipLaunchKernelGGL(k_barotropic_substep, gr, b, 0, m->stream, g, bb, dtau, (real)m->weights[s]);
+      hipLaunchKernelGGL(imm ? k_barotropic_substep<true> : k_barotropic_substep<false>, gr, b, 0, m->stream, g, bb, dtau,
+                         (real)m->weights[s]);
       for (int q = 0; q < 3; q++) { real* w_ = nxt[q]; nxt[q] = other[q]; other[q] = w_; cur[q] = w_; }
     }
   }
@@ -811,7 +936,7 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
       i0 = -g.H; ni = 2 * g.H; skip_from = 0; skip = g.Nx;
     }
     const bool cs = use_colsum && m->colsum_valid && part != 2;
-    hipLaunchKernelGGL(k_corrector, grid2(ni, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+    hipLaunchKernelGGL(m->immersed ? k_corrector<true> : k_corrector<false>, grid2(ni, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                        m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d,
                        cs ? m->colsum[0].d : nullptr, cs ? m->colsum[1].d : nullptr, i0, ni, std::max(1, g.Nz / 12),
                        skip_from, skip);
@@ -826,8 +951,22 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
   return GB25_OK;
 }
 
+// mask_immersed_model_fields! (src/precompile.jl:34): a sweep of its own only where the kernels of a composite step do
+// not already guarantee the zeros (update_state!, initialize!, after host writes)
+gb25_status mask_impl(gb25_model* m) {
+  if (!m->immersed) return GB25_OK;   // (the wall faces of v are the halo fill's business on the plain grid)
+  const Grid& g = m->g;
+  dim3 b(64, 4);
+  hipLaunchKernelGGL(k_mask_immersed, grid2(g.Nx, g.Ny + 1, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                     m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d);
+  LAUNCHCHK();
+  // the look-ahead partners of u, v, T, S hold the same zeros from the kernels' own masks; nothing else to do
+  return GB25_OK;
+}
+
 gb25_status update_state_impl(gb25_model* m) {
   gb25_status s;
+  if ((s = mask_impl(m))) return s;
   if ((s = fill_halos_impl(m, true))) return s;
   if ((s = compute_w_impl(m))) return s;
   if ((s = compute_p_impl(m))) return s;
@@ -1080,6 +1219,13 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     if ((s = alloc_field(m, m->wideG[0], wsx, m->f[GB25_GN_BT_U].ny, 1))) return s;
     if ((s = alloc_field(m, m->wideG[1], wsx, m->f[GB25_GN_BT_V].ny, 1))) return s;
   }
+  if (cfg->grid_type == GB25_GRID_LAT_LON_GAUSSIAN_ISLANDS) {
+    if (cfg->Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "an immersed boundary needs Nz <= 254 (8-bit level tables)");
+    if ((s = build_bottom(m, [&](int i, int j) { return gaussian_islands_bottom(m, i, j); }))) return s;
+  } else if (cfg->grid_type != GB25_GRID_LAT_LON) {
+    return fail(m, GB25_ERR_INVALID_ARGUMENT, "grid_type %d: 0 (lat-lon, flat bottom) or 1 (lat-lon, Gaussian islands)",
+                cfg->grid_type);
+  }
   HIPCHK(hipDeviceSynchronize());
   return GB25_OK;
 }
@@ -1103,6 +1249,12 @@ void gb25_destroy(gb25_model* m) {
     for (Field* p : {&m->ahead[q], &m->ahead_uv[q], &m->ahead_G[q], &m->ahead_colsum[q]})
       if (p->d) hipFree(p->d);
   if (m->uv_partials) hipFree(m->uv_partials);
+  for (auto p : m->d_ord)
+    if (p) hipFree(p);
+  for (auto p : m->d_H)
+    if (p) hipFree(p);
+  for (auto p : m->d_wideH)
+    if (p) hipFree(p);
   for (int a = 0; a < 2; a++) {
     for (auto& w : m->wide[a])
       if (w.d) hipFree(w.d);
@@ -1224,6 +1376,8 @@ gb25_status gb25_set_field(gb25_model* m, gb25_field f, const void* host, int in
     m->phy_stale = false;
     s = widen_phy(m);
   }
+  if (s == GB25_OK && m->immersed && (f == GB25_U || f == GB25_V || f == GB25_T || f == GB25_S || f == GB25_BT_U || f == GB25_BT_V))
+    s = mask_impl(m);   // set!(model, ...) masks what it has set (as Oceananigans' set! does on an immersed grid)
   if (s == GB25_OK) {
     m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;   // any input of the look-aheads may have changed
     if (f == GB25_T || f == GB25_S) s = mirror_tracers(m);
@@ -1286,6 +1440,7 @@ gb25_status gb25_set_baroclinic_instability(gb25_model* m) {
   hipLaunchKernelGGL(k_set_baroclinic_instability, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, m->stream, g,
                      m->f[GB25_T].d, m->f[GB25_S].d);
   LAUNCHCHK();
+  if (gb25_status s = mask_impl(m)) return s;
   return mirror_tracers(m);
 }
 
@@ -1304,7 +1459,43 @@ gb25_status gb25_set_dt(gb25_model* m, double dt) {
 }
 
 gb25_status gb25_initialize(gb25_model* m) { CHECK_MODEL(m); return initialize_impl(m); }
-gb25_status gb25_mask_immersed_fields(gb25_model* m) { CHECK_MODEL(m); return GB25_OK; }
+gb25_status gb25_mask_immersed_fields(gb25_model* m) {
+  CHECK_MODEL(m);
+  gb25_status s = mask_impl(m);
+  if (s == GB25_OK && m->immersed) {   // the partner buffers of the look-aheads follow
+    m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+    if ((s = mirror_tracers(m))) return s;
+    s = mirror_velocities(m);
+  }
+  return s;
+}
+// GridFittedBottom(bottom_height): bottom height (metres, negative down) at the centres of the interior columns,
+// Nx x Ny doubles, i fastest.  Single-domain models only (a slab would need its neighbours' columns: decomposed
+// models take an analytic grid_type).  Fields are masked at once.
+gb25_status gb25_set_bottom_height(gb25_model* m, const double* zb) {
+  CHECK_MODEL(m);
+  if (!zb) return GB25_ERR_INVALID_ARGUMENT;
+  if (m->slab) return fail(m, GB25_ERR_STATE, "gb25_set_bottom_height is for single-domain models; slabs use grid_type");
+  if (m->cfg.Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "an immersed boundary needs Nz <= 254 (8-bit level tables)");
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(m->side_stream));
+  const int Nx = m->Nx;
+  gb25_status s = build_bottom(m, [&](int i, int j) { return zb[(size_t)(((i % Nx) + Nx) % Nx) + (size_t)Nx * j]; });
+  if (s) return s;
+  if (m->kernel_gen == 1 && m->immersed) m->kernel_gen = 2;
+  return gb25_mask_immersed_fields(m);
+}
+// which: 0 = number of immersed cells of column (i, j) (0-based local indices), 1 = static depth at the U face,
+// 2 = at the V face
+gb25_status gb25_get_bottom_info(const gb25_model* m, int32_t which, int32_t i, int32_t j, double* value) {
+  if (!m || !value || j < 0 || j >= m->cfg.Ny || i < 0 || i >= m->Nx || which < 0 || which > 2) return GB25_ERR_INVALID_ARGUMENT;
+  if (m->kbot.empty()) { *value = which == 0 ? 0.0 : (double)m->g.Lz; return GB25_OK; }
+  const int E = m->kb_E, ksx = m->Nx + 2 * E, offk = m->metric_off_k, Nz = m->cfg.Nz;
+  auto kb = [&](int ii, int jj) { return m->kbot[(size_t)(ii + E) + (size_t)ksx * std::min(std::max(jj, 0), m->cfg.Ny - 1)]; };
+  auto depth = [&](int ii, int jj) { return (double)(real)m->h_metric[GB25_M_ZF][offk + Nz] - (double)(real)m->h_metric[GB25_M_ZF][offk + kb(ii, jj)]; };
+  *value = which == 0 ? (double)kb(i, j) : which == 1 ? std::min(depth(i - 1, j), depth(i, j)) : std::min(depth(i, j - 1), depth(i, j));
+  return GB25_OK;
+}
 gb25_status gb25_fill_halo_regions(gb25_model* m) {
   CHECK_MODEL(m);
   if (m->slab) return fail(m, GB25_ERR_STATE, "phase-by-phase driving is for single-domain models: a slab's x halos come from the exchange inside gb25_first_time_step / gb25_time_step / gb25_loop");
@@ -1350,6 +1541,7 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
   switch (opt) {
     case GB25_OPT_KERNELS:
       if (v != 1 && v != 2) return fail(m, GB25_ERR_INVALID_ARGUMENT, "GB25_OPT_KERNELS: 1 (direct stencil) or 2 (default)");
+      if (v == 1 && m->immersed) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels know no immersed boundary");
       m->kernel_gen = v;
       return GB25_OK;
     case GB25_OPT_AB2_LOOKAHEAD:
@@ -1370,6 +1562,20 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
       if (v != 32 && v != 64) return fail(m, GB25_ERR_INVALID_ARGUMENT, "GB25_OPT_PRESSURE_PRECISION: 64 or 32");
       m->pressure_bits = (sizeof(real) == 8) ? 64 : v;   // (a Float64 model's own arithmetic IS fp64)
       return GB25_OK;
+    case GB25_OPT_IMMERSED_KERNELS:
+      // 1: run the immersed-boundary kernel variants even where nothing is immersed (they must then give the bits of
+      // the plain ones: tests); 0: back to the choice the bottom makes
+      if (v != 0 && m->kernel_gen == 1) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels know no immersed boundary");
+      if (v != 0 && !m->d_ord[0]) {
+        if (m->cfg.Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "an immersed boundary needs Nz <= 254");
+        if (gb25_status s = build_bottom(m, [](int, int) { return -1e30; })) return s;
+      }
+      {
+        bool any = false;
+        for (int kb : m->kbot) any = any || kb > 0;
+        m->immersed = any || v != 0;
+      }
+      return GB25_OK;
     default: return fail(m, GB25_ERR_INVALID_ARGUMENT, "unknown option %d", (int)opt);
   }
 }
@@ -1385,6 +1591,7 @@ gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
     case GB25_OPT_STORE_PRESSURE: *v = m->phy_pinned; break;
     case GB25_OPT_SPLIT_TENDENCIES: *v = m->split_tendencies; break;
     case GB25_OPT_PRESSURE_PRECISION: *v = m->pressure_bits; break;
+    case GB25_OPT_IMMERSED_KERNELS: *v = m->immersed; break;
     default: return GB25_ERR_INVALID_ARGUMENT;
   }
   return GB25_OK;

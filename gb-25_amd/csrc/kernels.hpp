@@ -764,6 +764,7 @@ struct Baro {
   real *eta1, *U1, *V1;        // state at substep m+1
   real *etab, *Ub, *Vb;        // running time averages
   const real *GU, *GV;
+  const real *Hfc, *Hcf;       // static column depths at the U / V faces, same geometry (null: flat bottom, g.Lz)
   // geometry of these 2-D arrays: row pitch, array column of i = 0, computed range [ilo, ihi), and
   // whether i-1 / i+1 wrap around the periodic domain (single slab) or simply reach into the wide halo
   int sx, xo, ilo, ihi, wrap;
@@ -778,6 +779,7 @@ __device__ __forceinline__ real eta_step(const Grid& g, const Baro& b, int i, in
   else dyV = g.dxf[j + 1] * b.V0[bi(g, b, i, j + 1)] - g.dxf[j] * b.V0[bi(g, b, i, j)];
   return b.eta0[bi(g, b, i, j)] - dtau * (dxU + dyV) / g.azc[j];
 }
+template <bool IMM>
 __global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, real dtau, real wgt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x + b.ilo;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
@@ -789,8 +791,9 @@ __global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, real
   real dye = real(0.);
   if (j > 0) dye = (e - eta_step(g, b, i, j - 1, dtau)) / g.dy;
   int o = bi(g, b, i, j);
-  real Un = b.U0[o] + dtau * (-g.g * g.Lz * dxe + b.GU[o]);
-  real Vn = b.V0[o] + dtau * (-g.g * g.Lz * dye + b.GV[o]);
+  // (next to land the face has no depth: no pressure force, and G.U is zero there, so the transport stays zero)
+  real Un = b.U0[o] + dtau * (-g.g * (IMM ? b.Hfc[o] : g.Lz) * dxe + b.GU[o]);
+  real Vn = b.V0[o] + dtau * (-g.g * (IMM ? b.Hcf[o] : g.Lz) * dye + b.GV[o]);
   b.eta1[o] = e;
   b.U1[o] = Un;
   b.V1[o] = Vn;
@@ -816,7 +819,7 @@ struct BaroMulti {
   int first, last;
   real *eta_out, *U_out, *V_out, *eb_out, *ub_out, *vb_out;
 };
-template <int BT_S, int BT_TY>
+template <int BT_S, int BT_TY, bool IMM>
 __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm, real dtau) {
   constexpr int BT_RX = BT_TX + 2 * BT_S, BT_RY = BT_TY + 2 * BT_S, BT_NP = BT_RX * BT_RY;
   constexpr int BT_PPT = (BT_NP + BT_NT - 1) / BT_NT;
@@ -839,6 +842,7 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
   int pl[BT_PPT], pj[BT_PPT], po[BT_PPT];       // LDS index, global row, global element offset (-1: no such point)
   bool own[BT_PPT];
   real ae[BT_PPT], au[BT_PPT], av[BT_PPT];
+  real ghf[BT_PPT], ghc[BT_PPT];                // g x static column depth at the point's U / V face
 #pragma unroll
   for (int q = 0; q < BT_PPT; q++) {
     const int p = tid + q * BT_NT;
@@ -872,6 +876,11 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
       (&GVs[0][0])[p] = gv;
     }
     ae[q] = au[q] = av[q] = real(0.);
+    ghf[q] = ghc[q] = gH;
+    if (IMM && exists) {
+      ghf[q] = g.g * b.Hfc[po[q]];
+      ghc[q] = g.g * b.Hcf[po[q]];
+    }
     if (own[q] && !bm.first) {
       ae[q] = b.etab[po[q]];
       au[q] = b.Ub[po[q]];
@@ -908,8 +917,8 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
         real dxe = (e - E[ly][lx - 1]) * Mrdxc[ly];
         real dye = real(0.);
         if (jg > 0) dye = (e - E[ly - 1][lx]) * rdy;
-        real Un = U[ly][lx] + dtau * (GUs[ly][lx] - gH * dxe);
-        real Vn = V[ly][lx] + dtau * (GVs[ly][lx] - gH * dye);
+        real Un = U[ly][lx] + dtau * (GUs[ly][lx] - ghf[q] * dxe);
+        real Vn = V[ly][lx] + dtau * (GVs[ly][lx] - ghc[q] * dye);
         U[ly][lx] = Un;
         V[ly][lx] = Vn;
         if (own[q]) {
@@ -999,6 +1008,8 @@ __global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const real* __r
 // u += (U - Ubar)/H, v += (V - Vbar)/H.  The second sweep re-reads the column from L2.
 // Columns [i0, i0+ni): a slab of a multi-GPU run also corrects its x-halo columns (same arithmetic as the
 // owning neighbour, so no second halo exchange is needed); Ubar/Vbar are stored for interior columns only.
+// IMM: divide by the static column depth at the face and leave the faces that touch the solid at zero.
+template <bool IMM>
 __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u, real* __restrict__ v,
                                                    const real* __restrict__ U, const real* __restrict__ V,
                                                    real* __restrict__ Ub, real* __restrict__ Vb,
@@ -1038,13 +1049,19 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
     Ub[o2] = su;
     Vb[o2] = sv;
   }
-  const real du = (U[o2] - su) * g.rLz, dv = (V[o2] - sv) * g.rLz;
+  const real du = (U[o2] - su) * (IMM ? g.im.rHfc[o2] : g.rLz), dv = (V[o2] - sv) * (IMM ? g.im.rHcf[o2] : g.rLz);
+  int KPU = 0, KPV = 0;
+  if (IMM) {
+    const unsigned C = g.im.ordC[o2];
+    KPU = (C >> 8) & 255;
+    KPV = (C >> 16) & 255;
+  }
   o = o0;
   ov = ov0;
 #pragma unroll 4
   for (int k = 0; k < g.Nz; k++) {
-    u[o] = u[o] + du;
-    v[ov] = v[ov] + dv;
+    if (!IMM || k >= KPU) u[o] = u[o] + du;
+    if (!IMM || k >= KPV) v[ov] = v[ov] + dv;
     o += g.pl_c;
     ov += g.pl_v;
   }
@@ -1061,6 +1078,34 @@ __global__ void k_set_baroclinic_instability(Grid g, real* __restrict__ T, real*
   int o = ic(g, i, j, k);
   T[o] = (real(30.) + real(1e-3) * z) * step;
   S[o] = -real(5e-3) * z;
+}
+
+// mask_immersed_model_fields!(model, grid) (GB-25 src/precompile.jl:21,34): prognostic fields are zero at peripheral nodes
+// of their location -- u, v on faces that touch an inactive cell (the wall faces of v included), T, S in inactive cells;
+// the barotropic transports on faces without depth.  One thread per interior column.  Inside the composite steps the
+// kernels keep these zeros themselves (no tendency, no correction on such faces; no flux into such cells), so this
+// sweep runs in update_state! / initialize! and after host writes only.
+__global__ __launch_bounds__(256) void k_mask_immersed(Grid g, real* __restrict__ u, real* __restrict__ v,
+                                                       real* __restrict__ T, real* __restrict__ S,
+                                                       real* __restrict__ U, real* __restrict__ V) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j > g.Ny) return;
+  const int o2 = i2(g, i, j);
+  const unsigned A = g.im.ordA[o2], C = g.im.ordC[o2];
+  // v faces: j = 0 and j = Ny are walls (peripheral on the underlying grid); in between KPV levels touch the solid
+  const int kpv = (j == 0 || j == g.Ny) ? g.Nz : (int)((C >> 16) & 255);
+  int ov = iv(g, i, j, 0);
+  for (int k = 0; k < min(kpv, g.Nz); k++, ov += g.pl_v) v[ov] = real(0.);
+  if (j == 0 || j == g.Ny || g.im.Hcf[o2] == real(0.)) V[o2] = real(0.);
+  if (j == g.Ny) return;
+  const int kc = A & 255, kpu = (C >> 8) & 255;
+  int o = ic(g, i, j, 0);
+  for (int k = 0; k < min(max(kc, kpu), g.Nz); k++, o += g.pl_c) {
+    if (k < kpu) u[o] = real(0.);
+    if (k < kc) T[o] = S[o] = real(0.);
+  }
+  if (g.im.Hfc[o2] == real(0.)) U[o2] = real(0.);
 }
 
 // x-slab halo exchange: pack the columns next to a slab edge / unpack into the halo.  ONE launch moves every field of

@@ -241,6 +241,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
 
 gb25_status update_state_local_impl(gb25_model* m) {   // update_state! without the x-halo fill
   gb25_status s;
+  if ((s = mask_impl(m))) return s;   // (own columns; the halo columns arrived masked by their owners)
   if ((s = fill_halos_impl(m, false, m->slab))) return s;
   if ((s = compute_w_impl(m))) return s;
   if ((s = compute_p_impl(m))) return s;

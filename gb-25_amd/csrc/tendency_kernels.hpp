@@ -61,7 +61,11 @@ struct UvAhead {
   real dt, C1, C2;
   int plane2;
 };
-template <int MINW, int V2_TY, bool AHEAD>
+// IMM: immersed boundary.  Orders and the 4th/2nd-order switches of the centred interpolations come per lane and per
+// level from the folded tables; the tendencies of faces that touch the solid are zero (their velocities are masked and
+// stay so).  The pairs that share direction and target keep their packed evaluation; the vorticity pair (y for G_u, x
+// for G_v) is packed where both orders are 5 and evaluated one by one elsewhere, as next to the walls.
+template <int MINW, int V2_TY, bool AHEAD, bool IMM>
 __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     Grid g, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ w,
     const real* __restrict__ dpx, const real* __restrict__ dpy, real* __restrict__ Gu, real* __restrict__ Gv,
@@ -84,8 +88,30 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   const real dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j], razc_j = g.razc[j], razf_j = g.razf[j];
   const real Az = g.azc[j], fcor_j = g.fcor[j], fbar = real(0.5) * (g.fcor[j] + g.fcor[j + 1]);
   const real az_m2 = g.azc[j - 2], az_m1 = g.azc[j - 1], az_p1 = g.azc[j + 1];
-  const int oc_y = biased_order_center(j, g.Ny), of_y = biased_order_face(j, g.Ny);
-  const bool s4c_y = sym4_center(j, g.Ny), s4f_y = sym4_face(j, g.Ny);
+  int oc_y = biased_order_center(j, g.Ny), of_y = biased_order_face(j, g.Ny);
+  bool s4c_y = sym4_center(j, g.Ny), s4f_y = sym4_face(j, g.Ny);
+  // orders / switches that are constants of the plain grid (x is periodic) and per-level quantities with a bottom
+  int oc_x = 5, of_x = 5;
+  bool s4c_x = true, s4f_x = true, s4f_xw = true, s4f_yw = s4f_y;
+  int kbt = 0, KX5 = 0, KX3 = 0, KY5 = 0, KY3 = 0, KXC5 = 0, KXC3 = 0, KYC5 = 0, KYC3 = 0, KPU = 0, KPV = 0;
+  if (IMM) {
+    const int o2 = i2(g, min(i, g.Nx - 1), min(j, g.Ny - 1));
+    const unsigned A = g.im.ordA[o2], B = g.im.ordB[o2], C = g.im.ordC[o2];
+    kbt = A & 255; KX5 = (A >> 8) & 255; KX3 = (A >> 16) & 255; KY5 = A >> 24;
+    KY3 = B & 255; KXC5 = (B >> 8) & 255; KXC3 = (B >> 16) & 255; KYC5 = B >> 24;
+    KYC3 = C & 255; KPU = (C >> 8) & 255; KPV = (C >> 16) & 255;
+  }
+  const int Nzc = g.Nz - kbt;
+  // per-level orders: plain grid -> nothing to do; immersed -> from the thresholds.  `kw` is the level whose activity
+  // the horizontal stencil of Az w on the top face k+1 sees (the row above the face, the top face that of level Nz-1)
+  auto level_orders = [&](int k) {
+    if (!IMM) return;
+    oc_y = order_from(k, KYC5, KYC3); of_y = order_from(k, KY5, KY3);
+    oc_x = order_from(k, KXC5, KXC3); of_x = order_from(k, KX5, KX3);
+    s4c_y = k >= KYC5; s4f_y = k >= KY5; s4c_x = k >= KXC5; s4f_x = k >= KX5;
+    const int kw = min(k + 1, g.Nz - 1);
+    s4f_xw = kw >= KX5; s4f_yw = kw >= KY5;
+  };
 
   // threads of a ragged edge tile work on a clamped (duplicate) column so that every address stays in bounds
   int o = ic(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0), ov = iv(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0);
@@ -108,9 +134,11 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   // vertical momentum fluxes through the bottom face of the first level
   real fzu, fzv;
   {
-    const int ord = biased_order_face(k0, g.Nz);
-    real wu = sym_interp(true, Az * w[o - 2], Az * w[o - 1], Az * w[o], Az * w[o + 1]);
-    real wv = sym_interp(s4f_y, az_m2 * w[o - 2 * sx], az_m1 * w[o - sx], Az * w[o], az_p1 * w[o + sx]);
+    const int ord = biased_order_face(k0 - kbt, Nzc);
+    // (the bottom face k0 of the chunk is the top face of level k0-1; face 0 carries w = 0 whatever the order)
+    if (IMM) level_orders(max(k0 - 1, 0));
+    real wu = sym_interp(s4f_xw, Az * w[o - 2], Az * w[o - 1], Az * w[o], Az * w[o + 1]);
+    real wv = sym_interp(s4f_yw, az_m2 * w[o - 2 * sx], az_m1 * w[o - sx], Az * w[o], az_p1 * w[o + sx]);
     fzu = wu * biased6<false>(ord, wu > real(0.), uz, uz, uz);
     fzv = wv * biased6<false>(ord, wv > real(0.), vz, vz, vz);
   }
@@ -225,8 +253,9 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
 #define ZF(A, di, dj) lds.A[ty + 2 + (dj)][tx + 2 + (di)]
 #define DC(A, di, dj) lds.A[ty + 3 + (dj)][tx + 3 + (di)]
     real gu, gv;
-    const int ozt = biased_order_face(k + 1, g.Nz);
+    const int ozt = biased_order_face(k + 1 - kbt, Nzc);
     const real rdz = g.rdzc[k];
+    level_orders(k);
     {
       // Packed evaluation: the eight reconstructions of the cell are done as four PAIRS that share stencil shape
       // and order, (.x, .y) = (a term of G_u, a term of G_v); see real2v in device_common.hpp.
@@ -238,7 +267,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
 
       // (1) vorticity flux: zeta reconstructed in y for G_u (centre order) and in x for G_v (order 5)
       real hadv_u, hadv_v;
-      if (oc_y == 5) {
+      if (oc_y == 5 && oc_x == 5) {
         real2v zq[6], uq[6], vq[6];
 #pragma unroll
         for (int m = 0; m < 6; m++) {
@@ -264,7 +293,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
           uq[m] = ZF(UQ, m - 2, 0);
           vq[m] = ZF(VQ, m - 2, 0);
         }
-        hadv_v = uhat_v * biased6<true>(5, uhat_v > real(0.), zq, uq, vq);
+        hadv_v = uhat_v * biased6<true>(oc_x, uhat_v > real(0.), zq, uq, vq);
       }
 
       // (2) G_u: divergence flux and Bernoulli head, both upwinded in x by u (order 5, one direction for the pair)
@@ -281,7 +310,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
           ss[m] = v2(Du + DC(DV, m - 3, 0), real(0.5) * (u7[m] + u7[m + 1]));
         }
         const bool l = uhat_u > real(0.);
-        const real2v rr = biased6p<false>(5, l, l, qq, ss, ss);
+        const real2v rr = biased6p<false>(of_x, l, l, qq, ss, ss);
         duR = rr.x;
         dKu_u = rr.y;
       }
@@ -304,8 +333,8 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
         dKv_v = rr.y;
       }
       // (4) vertical advection of u and v: same order, own directions
-      const real wt_u = sym_interp(true, Az * WT(-2, 0), Az * WT(-1, 0), Az * WT(0, 0), Az * WT(1, 0));
-      const real wt_v = sym_interp(s4f_y, az_m2 * WT(0, -2), az_m1 * WT(0, -1), Az * WT(0, 0), az_p1 * WT(0, 1));
+      const real wt_u = sym_interp(s4f_xw, Az * WT(-2, 0), Az * WT(-1, 0), Az * WT(0, 0), Az * WT(1, 0));
+      const real wt_v = sym_interp(s4f_yw, az_m2 * WT(0, -2), az_m1 * WT(0, -1), Az * WT(0, 0), az_p1 * WT(0, 1));
       real2v zz[6];
 #pragma unroll
       for (int m = 0; m < 6; m++) zz[m] = v2(uz[m + 1], vz[m + 1]);
@@ -315,7 +344,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
         real Dv4[4];
 #pragma unroll
         for (int m = 0; m < 4; m++) Dv4[m] = DC(DV, m - 2, 0);
-        const real dvs = sym_interp(true, Dv4[0], Dv4[1], Dv4[2], Dv4[3]);
+        const real dvs = sym_interp(s4f_x, Dv4[0], Dv4[1], Dv4[2], Dv4[3]);
         const real phi = uhat_u * (dvs + duR);
         const real vadv = (phi + (ftp.x - fzu)) * (razc_j * rdz);
         fzu = ftp.x;
@@ -345,7 +374,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
           real un = UT(m - 1, 0), us = UT(m - 1, -1);
           a4[m] = real(0.5) * un * un - real(0.5) * us * us;
         }
-        const real dKu = sym_interp(true, a4[0], a4[1], a4[2], a4[3]);
+        const real dKu = sym_interp(s4c_x, a4[0], a4[1], a4[2], a4[3]);
         const real bern = (dKv_v + dKu) * g.rdy;
         const real cor = fcor_j * uhat_v;
         const real dpdy = ps_ * g.rdy;
@@ -357,6 +386,10 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
 #undef WT
 #undef ZF
 #undef DC
+    if (IMM) {   // faces that touch the solid: no tendency (their velocity is masked and stays zero)
+      if (k < KPU) gu = real(0.);
+      if (k < KPV) gv = real(0.);
+    }
     if (inside) {
       put(Gu, ob, gu);
       put(Gv, obv, gv);
@@ -418,7 +451,10 @@ struct Ab2Ahead {
 // worth of fp32 work per issue slot (device_common.hpp, real2v).  Only rcp, min, abs and the upwind selects stay
 // per-half.
 // =============================================================================================
-template <int MINW, bool AHEAD>
+// IMM: the grid has an immersed boundary.  The orders of the reconstructions then come per lane from the folded
+// per-column tables (device_common.hpp, Immersed) instead of per wave from the row index; everything else is unchanged:
+// the fluxes through faces that touch the solid vanish because the velocities there are masked to zero.
+template <int MINW, bool AHEAD, bool IMM>
 __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, const real* __restrict__ u,
                                                               const real* __restrict__ v,
                                                               const real* __restrict__ w,
@@ -436,7 +472,15 @@ __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, cons
   const bool writes = (lane < V3_OUT) && (i < g.Nx);
   const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
   const real dy = g.dy, Az = g.azc[j], dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], razc_j = g.razc[j];
-  const int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny);
+  int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny), ox = 5;
+  int kbt = 0, KX5 = 0, KX3 = 0, KY5 = 0, KY3 = 0, KY5n = 0, KY3n = 0;
+  if (IMM) {
+    const int o2 = i2(g, min(i, g.Nx), j);
+    const unsigned A = g.im.ordA[o2], B = g.im.ordB[o2], An = g.im.ordA[o2 + g.sx], Bn = g.im.ordB[o2 + g.sx];
+    kbt = A & 255; KX5 = (A >> 8) & 255; KX3 = (A >> 16) & 255; KY5 = A >> 24; KY3 = B & 255;
+    KY5n = An >> 24; KY3n = Bn & 255;
+  }
+  const int Nzc = g.Nz - kbt;   // (levels above the column's bottom: the bottom acts like the wall at k = 0, shifted)
 
   // buffer views (device_common.hpp): one per-lane byte offset for the centre-shaped arrays, one for v
   constexpr int SZ = (int)sizeof(real);
@@ -463,24 +507,29 @@ __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, cons
   real2v fz;
   {
     real Azw = Az * bload(bw, vo, cc);
-    int ord = biased_order_face(k0, g.Nz);
+    int ord = biased_order_face(k0 - kbt, Nzc);
     fz = Azw * biased6<false, real2v>(ord, Azw > real(0.), cz, cz, cz);
   }
   for (int k = k0; k < k1; k++) {
     const real dz = g.dzc[k];
+    if (IMM) {
+      ox = order_from(k, KX5, KX3);
+      oys = order_from(k, KY5, KY3);
+      oyn = order_from(k, KY5n, KY3n);
+    }
     const real Axu = dy * dz * bload(bu, vo, cc);
     const real Ays = dxf_s * dz * bload(bv, vov, 0), Ayn = dxf_n * dz * bload(bv, vov, sx * SZ);
     const real Azw = Az * bload(bw, vo, cc + pc * SZ);
     real2v q[7];
 #pragma unroll
     for (int m = 0; m < 6; m++) q[m] = v2(bload(bT, vo + m * SZ, (3 * pc + 3 * sx) * SZ), bload(bS, vo + m * SZ, (3 * pc + 3 * sx) * SZ));
-    const real2v fx = Axu * biased6<false, real2v>(5, Axu > real(0.), q, q, q);
+    const real2v fx = Axu * biased6<false, real2v>(IMM ? ox : 5, Axu > real(0.), q, q, q);
 #pragma unroll
     for (int m = 0; m < 7; m++) q[m] = v2(bload(bT, vo, CY(m)), bload(bS, vo, CY(m)));
     const real2v fs = Ays * biased6<false, real2v>(oys, Ays > real(0.), q, q, q);
     const real2v fn = Ayn * biased6<false, real2v>(oyn, Ayn > real(0.), q + 1, q + 1, q + 1);
     // top face from the vertical window
-    const int ozt = biased_order_face(k + 1, g.Nz);
+    const int ozt = biased_order_face(k + 1 - kbt, Nzc);
     const real2v ft = Azw * biased6<false, real2v>(ozt, Azw > real(0.), cz + 1, cz + 1, cz + 1);
     // east faces = west faces of the next lane
     const real2v fe = v2(__shfl_down(fx.x, 1), __shfl_down(fx.y, 1));

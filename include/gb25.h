@@ -84,7 +84,11 @@ typedef struct {
 } gb25_config;
 
 typedef enum {
-  GB25_GRID_LAT_LON = 0            /* simple_latitude_longitude_grid (src/model_utils.jl:56-65), flat bottom */
+  GB25_GRID_LAT_LON = 0,           /* simple_latitude_longitude_grid (src/model_utils.jl:56-65), flat bottom */
+  GB25_GRID_LAT_LON_GAUSSIAN_ISLANDS = 1 /* ImmersedBoundaryGrid(that grid, GridFittedBottom(gaussian_islands); active_cells_map
+                                            = false): the two Gaussian mountains of src/model_utils.jl:67-80,138-146.  (The
+                                            reference's :gaussian_islands puts them on a TripolarGrid; the tripolar
+                                            underlying grid does not exist here yet.) */
 } gb25_grid_type;
 
 /* Per-model switches (gb25_set_option).  Defaults in brackets.  None of them changes results beyond the last bits
@@ -102,6 +106,7 @@ typedef enum {
                                     in fp64 whatever the model's float type (default; fp32 in, fp32 out); 32 = in the float
                                     type's own arithmetic, operation for operation what an all-Float32 model computes
                                     (the stated Float32 tolerance) */
+  GB25_OPT_IMMERSED_KERNELS,     /* [1 iff some cell is immersed] 1: run the immersed-boundary kernel variants anyway */
   GB25_OPT_COUNT
 } gb25_option;
 
@@ -158,6 +163,14 @@ gb25_status gb25_get_metric(const gb25_model *m, gb25_metric id, int32_t logical
 gb25_status gb25_get_substepping(const gb25_model *m, int32_t *n_effective, double *dtau_fraction,
                                  double *weights /* >= substeps entries */);
 
+/* ---- immersed boundary: ImmersedBoundaryGrid(grid, GridFittedBottom(bottom_height)) (src/model_utils.jl:134-146).
+ *      gb25_set_bottom_height replaces the bottom of a single-domain model by an arbitrary one (Nx x Ny doubles at the
+ *      cell centres, i fastest; metres, negative down) and masks the fields; decomposed models take an analytic
+ *      grid_type, evaluated for halo columns too.  gb25_get_bottom_info (diagnostic; 0-based local i, j): which = 0 the
+ *      number of immersed cells of the column, 1 / 2 the static column depth at its U / V face. */
+gb25_status gb25_set_bottom_height(gb25_model *m, const double *bottom_height);
+gb25_status gb25_get_bottom_info(const gb25_model *m, int32_t which, int32_t i, int32_t j, double *value);
+
 /* ---- initial conditions: set_baroclinic_instability!(model) (src/model_utils.jl:99-127) */
 gb25_status gb25_set_baroclinic_instability(gb25_model *m);
 
@@ -168,7 +181,7 @@ gb25_status gb25_set_dt(gb25_model *m, double dt);
 /* ---- the phases of one time step, in the reference's order (src/precompile.jl:31-42).
  *      Each replaces the *_workload! wrapper cited. */
 gb25_status gb25_initialize(gb25_model *m);              /* Oceananigans.initialize!(model) (correctness/..._run.jl:50-51) */
-gb25_status gb25_mask_immersed_fields(gb25_model *m);    /* src/precompile.jl:34   (no-op on this grid) */
+gb25_status gb25_mask_immersed_fields(gb25_model *m);    /* src/precompile.jl:21,34 mask_immersed_model_fields! (nothing to do on a flat bottom) */
 gb25_status gb25_fill_halo_regions(gb25_model *m);       /* src/precompile.jl:35,40,44-46 tupled_fill_halo_regions_workload! */
 gb25_status gb25_compute_auxiliaries(gb25_model *m);     /* src/precompile.jl:36,113-115  compute_auxiliaries_workload! */
 gb25_status gb25_fill_diffusivity_halos(gb25_model *m);  /* src/precompile.jl:37,117-119  (closure=nothing: no-op) */

@@ -29,7 +29,8 @@ const FIELD = (u = 0, v = 1, w = 2, T = 3, S = 4, pHY = 5,
                eta = 14, U = 15, V = 16, eta_bar = 17, U_bar = 18, V_bar = 19, Gn_U = 20, Gn_V = 21)
 # gb25_option
 const OPTION = (kernels = 0, ab2_lookahead = 1, subcycle_lookahead = 2, subcycle_block = 3, fill_fused = 4,
-                two_streams = 5, store_pressure = 6, split_tendencies = 7, pressure_precision = 8)
+                two_streams = 5, store_pressure = 6, split_tendencies = 7, pressure_precision = 8,
+                immersed_kernels = 9)
 
 # mirror of gb25_config; isbits, passed by reference
 Base.@kwdef mutable struct Config

@@ -355,6 +355,7 @@ double FN(bottom_info)(void *h, int which, int i, int j) {
   model *m = (model *)h;
   return which == 0 ? (double)KB(i, j) : which == 1 ? (double)H2(Hcc, i, j) : which == 2 ? (double)H2(Hfc, i, j) : (double)H2(Hcf, i, j);
 }
+int FN(is_immersed)(void *h) { return ((model *)h)->immersed; }
 void FN(set_dt)(void *h, double dt) { ((model *)h)->dt = (REAL)dt; }
 double FN(get_time)(void *h) { return ((model *)h)->time; }
 long FN(get_iteration)(void *h) { return ((model *)h)->iter; }
@@ -991,6 +992,8 @@ void FN(set_baroclinic_instability)(void *h) {
         A3(F_T, i, j, k) = (REAL)((30.0 + 1e-3 * z) * step);
         A3(F_S, i, j, k) = (REAL)(-5e-3 * z);
       }
+  /* set!(model, ...) on an immersed grid masks what it has set */
+  if (m->immersed) FN(mask_immersed_fields)(h);
 }
 
 /* diagnostics for tests: the individual terms of G_u at (i,j,k) (1-based) */

@@ -149,6 +149,9 @@ class OracleBackend:
         if a.shape != tgt.shape:
             raise ValueError(f"{name}: expected {tgt.shape}, got {a.shape}")
         tgt[...] = a
+        # set!(model, ...) on an immersed grid masks what it has set (flat bottom: nothing to do, as in the product)
+        if name in ("u", "v", "T", "S", "U", "V") and self._fn("is_immersed")(C.c_void_p(self.h)):
+            self._call("mask_immersed_fields")
 
     def metric(self, name, index):
         return self._fn("metric")(self.h, METRIC_IDS[name], index)
@@ -180,6 +183,8 @@ class OracleBackend:
         f = self._fn("set_bottom_height")
         f.argtypes = [C.c_void_p, C.c_void_p]
         f(self.h, a.ctypes.data_as(C.c_void_p))
+        if self._fn("is_immersed")(C.c_void_p(self.h)):
+            self._call("mask_immersed_fields")
 
     def bottom_info(self, which, i, j):
         f = self._fn("bottom_info")
