@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "gb25_update_state", "gb25_first_time_step", "gb25_time_step", "gb25_loop",
     "gb25_set_option", "gb25_get_option", "gb25_set_bottom_height", "gb25_get_bottom_info",
     "gb25_comm_unique_id", "gb25_comm_init_rccl", "gb25_comm_init_local", "gb25_comm_init_callback", "gb25_comm_finalize",
-    "gb25_lookahead_state", "gb25_debug_sequence",
+    "gb25_lookahead_state", "gb25_debug_sequence", "gb25_save_state",
     "gb25_profile_enable", "gb25_profile_reset", "gb25_profile_get",
 ]
 # gb25_option (include/gb25.h)
@@ -116,6 +116,7 @@ def load_library(float_type="Float32"):
     lib.gb25_ab2_step.argtypes = [P, C.c_double, C.c_int]
     lib.gb25_correct_velocities_and_cache_previous_tendencies.argtypes = [P, C.c_double]
     lib.gb25_loop.argtypes = [P, C.c_int32]
+    lib.gb25_save_state.argtypes = [P, C.c_char_p, C.c_char_p]
     lib.gb25_set_bottom_height.argtypes = [P, P]
     lib.gb25_get_bottom_info.argtypes = [P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     lib.gb25_set_option.argtypes = [P, C.c_int, C.c_int32]
@@ -266,6 +267,11 @@ class HipBackend:
     def first_time_step(self): self._call("gb25_first_time_step")
     def time_step(self): self._call("gb25_time_step")
     def loop(self, n): self._call("gb25_loop", int(n))
+
+    def save_state(self, directory, label="checkpoint"):
+        """save_model_state: this rank's slab -> <directory>/<label>/fields_rank<R>.npz; returns the path."""
+        self._call("gb25_save_state", str(directory).encode(), str(label).encode())
+        return os.path.join(str(directory), label, f"fields_rank{self.cfg.rank}.npz")
 
     # ---- immersed boundary
     def set_bottom_height(self, zb):

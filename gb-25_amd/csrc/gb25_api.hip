@@ -1082,6 +1082,7 @@ gb25_status initialize_impl(gb25_model* m) {
 }  // namespace
 
 #include "slab_step.hpp"
+#include "state_io.hpp"
 
 // =============================================================================================
 extern "C" {
@@ -1718,6 +1719,45 @@ int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int3
     out[ncopy] = 0;
   }
   return need;
+}
+
+// ---- state dump: save_model_state(dir, model, arch; label) (src/sharded_io.jl:122-138) -- see state_io.hpp
+gb25_status gb25_save_state(gb25_model* m, const char* directory, const char* label) {
+  CHECK_MODEL(m);
+  if (!directory || !*directory) return GB25_ERR_INVALID_ARGUMENT;
+  const std::string dir = std::string(directory) + "/" + (label && *label ? label : "checkpoint");
+  for (size_t q = 1; q <= dir.size(); q++)   // mkpath
+    if (q == dir.size() || dir[q] == '/') mkdir(dir.substr(0, q).c_str(), 0777);
+  const std::string path = dir + "/fields_rank" + std::to_string(m->cfg.rank) + ".npz";
+  NpzWriter z;
+  if (!z.open(path)) return fail(m, GB25_ERR_STATE, "cannot write %s", path.c_str());
+  const int64_t meta[4] = {m->iteration, (int64_t)m->cfg.rank, (int64_t)m->cfg.nranks, (int64_t)sizeof(real)};
+  z.add_array("iteration", "<i8", {}, &meta[0]);
+  z.add_array("time", "<f8", {}, &m->time);
+  z.add_array("rank", "<i8", {}, &meta[1]);
+  z.add_array("nranks", "<i8", {}, &meta[2]);
+  static const struct { const char* name; gb25_field id; } fs[] = {
+      {"u", GB25_U}, {"v", GB25_V}, {"w", GB25_W}, {"eta", GB25_ETA}, {"T", GB25_T}, {"S", GB25_S}};
+  std::string names;
+  std::vector<real> host;
+  for (auto& fld : fs) {
+    int32_t d[3];
+    gb25_field_dims(m, fld.id, 0, d);
+    host.resize((size_t)d[0] * d[1] * d[2]);
+    if (gb25_status s = gb25_get_field(m, fld.id, host.data(), 0)) {
+      z.close();
+      return s;
+    }
+    const int64_t i0 = (int64_t)m->cfg.rank * m->Nx;
+    const int64_t slice[6] = {i0, i0 + d[0], 0, d[1], 0, d[2]}, gshape[3] = {m->cfg.Nx, d[1], d[2]};
+    z.add_array(std::string(fld.name) + ".data", sizeof(real) == 8 ? "<f8" : "<f4", {d[0], d[1], d[2]}, host.data());
+    z.add_array(std::string(fld.name) + ".slice", "<i8", {6}, slice);
+    z.add_array(std::string(fld.name) + ".global_shape", "<i8", {3}, gshape);
+    names += std::string(fld.name) + "\n";
+  }
+  z.add("field_names", names, nullptr, 0);
+  if (!z.close()) return fail(m, GB25_ERR_STATE, "writing %s failed (disk full, or a member beyond the 4 GB of zip32)", path.c_str());
+  return GB25_OK;
 }
 
 // ---- profiling ------------------------------------------------------------------------------

@@ -10,7 +10,12 @@ import numpy as np
 
 
 def save_model_state(directory, model, rank=0, nranks=1, label="checkpoint"):
-    """save_model_state(dir, model, arch; label) -- src/sharded_io.jl:122-138.  Returns the file path."""
+    """save_model_state(dir, model, arch; label) -- src/sharded_io.jl:122-138.  Returns the file path.
+    The HIP library writes the file itself (gb25_save_state, one ABI call, no Python in the data path); a backend
+    without that entry point (the test-side oracle) is dumped from here in the same format."""
+    b = model.backend
+    if hasattr(b, "save_state"):
+        return b.save_state(directory, label)
     outdir = os.path.join(directory, label)
     os.makedirs(outdir, exist_ok=True)
     payload = {"iteration": np.int64(model.clock.iteration), "time": np.float64(model.clock.time),
@@ -27,6 +32,13 @@ def save_model_state(directory, model, rank=0, nranks=1, label="checkpoint"):
     path = os.path.join(outdir, f"fields_rank{rank}.npz")
     np.savez(path, **payload)
     return path
+
+
+def _field_names(z):
+    names = z["field_names"]
+    if isinstance(names, (bytes, bytearray)):          # written by the library: a text member, one name per line
+        return names.decode().split()
+    return [str(n) for n in names]
 
 
 def load_global_field(directory, name):
@@ -48,6 +60,6 @@ def load_global_field(directory, name):
 def load_all_fields(directory):
     """load_all_fields(dir) -- src/sharded_io.jl:198-213: dict name -> global array, plus iteration and time."""
     first = np.load(sorted(glob.glob(os.path.join(directory, "fields_rank*.npz")))[0])
-    out = {str(n): load_global_field(directory, str(n)) for n in first["field_names"]}
+    out = {n: load_global_field(directory, n) for n in _field_names(first)}
     out["iteration"], out["time"] = int(first["iteration"]), float(first["time"])
     return out

@@ -238,6 +238,14 @@ gb25_status gb25_lookahead_state(const gb25_model *m, int32_t *velocities_ready,
  * touching a GPU (tests of the sequencing on CPU-only machines).  Returns the bytes needed, incl. the terminator. */
 int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int32_t ready, char *out, int64_t cap);
 
+/* ---- state dump: save_model_state(dir, model, arch; label) (src/sharded_io.jl:70-96,122-138; called after each loop
+ *      of the benchmark script, sharding/sharded_..._run.jl:151-155,167-171).  Every rank writes only its own slab --
+ *      no communication -- to <directory>/<label>/fields_rank<rank>.npz (uncompressed NumPy .npz): per field of
+ *      Oceananigans.fields(model) the local interior (<name>.data), its slice of the global array (<name>.slice: i0, i1,
+ *      j0, j1, k0, k1) and the global shape, plus iteration, time, rank, nranks.  Offline gather (load_all_fields,
+ *      src/sharded_io.jl:198-213): gb-25_amd/sharded_io.py. */
+gb25_status gb25_save_state(gb25_model *m, const char *directory, const char *label);
+
 /* ---- built-in per-kernel HIP-event timing (bench.py's roofline numbers) */
 gb25_status gb25_profile_enable(gb25_model *m, int on); /* 0: off, 1: every kernel, 2 + k: kernel k alone */
 gb25_status gb25_profile_reset(gb25_model *m);

@@ -145,3 +145,30 @@ def test_split_tendencies_is_bitwise_neutral_on_ragged_slabs():
         for e in ens:
             e.close()
         single.backend.close()
+
+
+def test_state_dump_through_the_abi_and_offline_gather(tmp_path):
+    """save_model_state / load_all_fields (src/sharded_io.jl:122-138,198-213): every slab writes its own
+    fields_rank<R>.npz through gb25_save_state (no communication); the offline gather reproduces the single domain."""
+    Nx, Ny, Nz, P, dt = 128, 48, 8, 4, 600.0
+    single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt)
+    init = _initial(Nx, Ny, Nz, single)
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt)
+    for n, a in init.items():
+        ens.scatter(n, a)
+    gb.first_time_step(single)
+    ens.first_time_step()
+    gb.loop(single, 3)
+    ens.loop(3)
+    for b in ens.backends:
+        path = b.save_state(str(tmp_path), "after_loop")
+        assert path.endswith(f"fields_rank{b.cfg.rank}.npz")
+    got = gb.load_all_fields(str(tmp_path / "after_loop"))
+    assert got["iteration"] == 4 and got["time"] == 4 * dt
+    for n in ("u", "v", "w", "eta", "T", "S"):
+        assert np.array_equal(got[n], single.backend.get_field(n, False)), n
+    # the single domain through the same entry point
+    gb.save_model_state(str(tmp_path), single, label="single")
+    one = gb.load_all_fields(str(tmp_path / "single"))
+    assert np.array_equal(one["T"], got["T"]) and one["iteration"] == 4
+    ens.close()

@@ -85,3 +85,39 @@ def test_state_dump_roundtrip(tmp_path):
     got = gb.load_all_fields(str(tmp_path / "after_loop"))
     assert np.array_equal(got["u"], whole.velocities.u.interior) and np.array_equal(got["v"], whole.velocities.v.interior)
     assert got["iteration"] == 0 and set(got) >= {"u", "v", "w", "eta", "T", "S"}
+
+
+def test_library_npz_writer_roundtrip(tmp_path):
+    """The state dump of the library (csrc/state_io.hpp: an uncompressed .npz written by hand, CRC-32 and all) as a
+    host-only harness: np.load and zipfile must accept it, arrays come back in [i, j, k] order."""
+    import os
+    import subprocess
+    import zipfile
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.cpp"
+    out = tmp_path / "t.npz"
+    src.write_text('#include "%s"\n' % os.path.join(ROOT, "gb-25_amd", "csrc", "state_io.hpp") + r'''
+int main() {
+  NpzWriter z;
+  if (!z.open("%s")) return 2;
+  long long it = 42; double t = 3.5;
+  z.add_array("iteration", "<i8", {}, &it);
+  z.add_array("time", "<f8", {}, &t);
+  std::vector<float> a(5 * 3 * 4);
+  for (size_t q = 0; q < a.size(); q++) a[q] = (float)q;
+  z.add_array("u.data", "<f4", {5, 3, 4}, a.data());
+  std::vector<double> b(7, 1.25);
+  z.add_array("w.data", "<f8", {7}, b.data());
+  z.add("field_names", "u\nw\n", nullptr, 0);
+  return z.close() ? 0 : 1;
+}''' % out)
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-o", str(exe), str(src)], check=True)
+    subprocess.run([str(exe)], check=True)
+    assert zipfile.ZipFile(out).testzip() is None                      # every CRC-32 checks out
+    z = np.load(out)
+    assert int(z["iteration"]) == 42 and float(z["time"]) == 3.5
+    u = z["u.data"]
+    assert u.shape == (5, 3, 4) and u.dtype == np.float32
+    assert u[2, 1, 3] == 2 + 5 * 1 + 15 * 3                             # i fastest
+    assert np.array_equal(z["w.data"], np.full(7, 1.25)) and z["field_names"] == b"u\nw\n"
