@@ -89,6 +89,8 @@ struct gb25_model {
   int64_t iteration = 0;
   // streams / timing
   hipStream_t own_stream = nullptr, stream = nullptr, side_stream = nullptr;
+  hipStream_t baro_stream = nullptr;   // the look-ahead sub-cycle of a single domain: a stream of its own, so that the
+                                       // pressure of the next step (side stream) need not queue behind its tail
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool two_streams = true;          // option TWO_STREAMS = 0: strictly sequential phases on one stream
   bool profile = false;
@@ -101,6 +103,16 @@ struct gb25_model {
   int baro_block = 7;                // substeps per barotropic launch (option SUBCYCLE_BLOCK = 1: one launch per substep)
   int kernel_gen = 2;                // 2: LDS / flux-sharing tendency kernels (tendency_kernels.hpp); 1: direct-stencil kernels
   int pressure_bits = 64;            // option PRESSURE_PRECISION: 64 = fp64 EOS + integral (default); 32 = the float type's own
+  // single periodic domain: the last writers of u, v (corrector), T, S (tracer look-ahead) and eta, U, V (last barotropic
+  // launch) also write the halo cells the fills derive from them, and the fill launches leave the step.  Halo cells
+  // deeper than one layer in y / z are static while stepping, so their x images only need the complete fills of the two
+  // steps (one per buffer of each alternating pair) that follow a host write.
+  int n_cu = 256;                    // compute units of the device
+  int fold_fills = 1;
+  bool composite = false;            // inside gb25_time_step / gb25_loop (the phase entry points leave halos alone, as the
+                                     // reference's phases do: there the producers do not fold)
+  int complete_fills_needed = 2;
+  bool ahead_ts_folded = false, ahead_eta_folded = false, last_baro_folded = false;
   int split_tendencies = 1;          // slab of a decomposition: interior tile columns before the x-halo bundle has arrived
   // immersed boundary (GridFittedBottom): first active level per column on the columns [-kb_E, Nx + kb_E) x [0, Ny)
   // (host), the folded tables of device_common.hpp (device), the depths of the wide barotropic arrays of a slab
@@ -497,6 +509,7 @@ Halo2 halo2_prognostic(gb25_model* m) {
 // extended: also treat the x-halo columns (slab mode, after the neighbours' columns were unpacked).
 // which: 3 = 3-D and 2-D fields, 1 = the 3-D bundle only, 2 = the 2-D fields only (slab pipeline).
 // sel3: which 3-D fields (halo3); st: stream (nullptr = the model's stream).
+gb25_status fill_halos_2d(gb25_model* m, Halo2 h2);
 gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, int which = 3, int sel3 = 3,
                             hipStream_t st = nullptr, bool use_default_stream = true, const Halo2* h2_other = nullptr) {
   const Grid& g = m->g;
@@ -506,6 +519,7 @@ gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, i
   Halo2 h2 = h2_other ? *h2_other : halo2_prognostic(m);
   dim3 b(256);
   const int i0 = extended ? -g.H : 0, ni = extended ? g.Nx + 2 * g.H : g.Nx;
+  if (which == 2 && with_x && g.x_periodic && !extended && !h2_other) return fill_halos_2d(m, halo2_prognostic(m));
   if (which == 2) {
     Grid g2 = g;
     g2.Nz = 0;   // k_fill_y then runs its 2-D branch only
@@ -576,6 +590,8 @@ gb25_status compute_w_impl(gb25_model* m, int part = 0) {
 gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = INT_MIN, int i_first_b = 0,
                            int i_last_b = -1, bool may_skip_p = false) {
   const Grid& g = m->g;
+  const real *Tsrc = m->f[GB25_T].d, *Ssrc = m->f[GB25_S].d;
+  real *dpx_out = m->dpx.d, *dpy_out = m->dpy.d;
   if (m->pressure_bits == 32) {
     // the model float type's own arithmetic, whole extended range, pHY' stored, differences from the stored values
     Timed t(m, GB25_K_COMPUTE_P);
@@ -607,13 +623,13 @@ gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = IN
   if ((tiles_a + tiles_b) * ((nrow + PR * 4 - 1) / (PR * 4)) < 1024) {
     dim3 gr(tiles_a + tiles_b, (nrow + 3) / 4);
     auto kern = write_p ? k_compute_p<1, true> : k_compute_p<1, false>;
-    hipLaunchKernelGGL(kern, gr, b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_PHY].d, m->dpx.d,
-                       m->dpy.d, i_first, i_last, i_first_b, i_last_b, tiles_a);
+    hipLaunchKernelGGL(kern, gr, b, 0, m->stream, g, Tsrc, Ssrc, m->f[GB25_PHY].d, dpx_out, dpy_out, i_first, i_last,
+                       i_first_b, i_last_b, tiles_a);
   } else {
     dim3 gr(tiles_a + tiles_b, (nrow + PR * 4 - 1) / (PR * 4));
     auto kern = write_p ? k_compute_p<PR, true> : k_compute_p<PR, false>;
-    hipLaunchKernelGGL(kern, gr, b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_PHY].d, m->dpx.d,
-                       m->dpy.d, i_first, i_last, i_first_b, i_last_b, tiles_a);
+    hipLaunchKernelGGL(kern, gr, b, 0, m->stream, g, Tsrc, Ssrc, m->f[GB25_PHY].d, dpx_out, dpy_out, i_first, i_last,
+                       i_first_b, i_last_b, tiles_a);
   }
   LAUNCHCHK();
   return GB25_OK;
@@ -720,8 +736,12 @@ gb25_status tracers_impl(gb25_model* m) {
       nx.dt = (real)m->last_dt;
       nx.C1 = real(1.5) + (real)m->cfg.chi; nx.C2 = real(0.5) + (real)m->cfg.chi;
     }
-    auto kern = m->immersed ? (ahead ? k_tracer_tendencies_v5<TW, true, true> : k_tracer_tendencies_v5<TW, false, true>)
-                            : (ahead ? k_tracer_tendencies_v5<TW, true, false> : k_tracer_tendencies_v5<TW, false, false>);
+    const bool fold = ahead && !m->slab && m->fold_fills;
+    auto kern = m->immersed ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false>)
+                                     : k_tracer_tendencies_v5<TW, false, true, false>)
+                            : (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, false, true> : k_tracer_tendencies_v5<TW, true, false, false>)
+                                     : k_tracer_tendencies_v5<TW, false, false, false>);
+    m->ahead_ts_folded = fold;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64, 4), 0, m->stream, g, m->f[GB25_U].d,
                        m->f[GB25_V].d, m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d,
                        m->f[GB25_GN_S].d, nbx, kchunks, nb, nx);
@@ -816,6 +836,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     m->baro_inflight = false;
   }
   Timed t(m, GB25_K_BAROTROPIC);
+  m->last_baro_folded = false;
   const bool wide = m->slab;
   const real dtau = (real)m->dtau_frac * dt;
   dim3 b(64, 4);
@@ -876,6 +897,8 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
       }
       bm.eta_out = out[0]; bm.U_out = out[1]; bm.V_out = out[2];
       bm.eb_out = bm.ub_out = bm.vb_out = nullptr;
+      bm.fold = (!wide && m->fold_fills && m->composite && bm.last) ? 1 : 0;
+      if (bm.last) m->last_baro_folded = bm.fold != 0;
       if (wide) {
         const Field* fb = ahead ? m->ahead_bar : &m->f[GB25_ETA_BAR];
         bm.eb_out = fb[0].d; bm.ub_out = fb[1].d; bm.vb_out = fb[2].d;
@@ -936,7 +959,10 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
       i0 = -g.H; ni = 2 * g.H; skip_from = 0; skip = g.Nx;
     }
     const bool cs = use_colsum && m->colsum_valid && part != 2;
-    hipLaunchKernelGGL(m->immersed ? k_corrector<true> : k_corrector<false>, grid2(ni, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+    const bool fold = !m->slab && m->fold_fills && m->composite;
+    auto kern = m->immersed ? (fold ? k_corrector<true, true> : k_corrector<true, false>)
+                            : (fold ? k_corrector<false, true> : k_corrector<false, false>);
+    hipLaunchKernelGGL(kern, grid2(ni, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                        m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d,
                        cs ? m->colsum[0].d : nullptr, cs ? m->colsum[1].d : nullptr, i0, ni, std::max(1, g.Nz / 12),
                        skip_from, skip);
@@ -996,6 +1022,11 @@ gb25_status ab2_step_impl(gb25_model* m, double dt, int euler) {
 gb25_status time_step_impl(gb25_model* m, int euler) {
   gb25_status s;
   const double dt = m->last_dt;
+  struct Composite {
+    gb25_model* m;
+    explicit Composite(gb25_model* m_) : m(m_) { m->composite = true; }
+    ~Composite() { m->composite = false; }
+  } composite_scope(m);
   if (!m->two_streams) {
     if ((s = ab2_step_impl(m, dt, euler))) return s;
     m->time += dt;
@@ -1023,8 +1054,13 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
   // ---- tracer branch (side stream)
   m->stream = side;
+  // (complete fills for the two steps after a host write, one per buffer of each alternating pair: see fold_fills)
+  const bool complete = m->complete_fills_needed > 0;
+  if (complete) m->complete_fills_needed -= 1;
+  const bool ts_adopted = m->ahead_valid && (real)dt == m->ahead_dt && chi == m->ahead_chi;
   s = ab2_tracers_impl(m, (real)dt, chi);
-  if (!s) s = fill_halos_impl(m, true, false, 1, 2);      // y/z/x halos of T, S
+  // y/z/x halos of T, S -- unless the look-ahead that was just adopted wrote them itself
+  if (!s && (complete || !(ts_adopted && m->ahead_ts_folded))) s = fill_halos_impl(m, true, false, 1, 2);
   if (!s) s = compute_p_impl(m, INT_MIN, INT_MIN, 0, -1, true);
   if (!s && adopted) s = fill_halos_2d(m, hG);
   m->stream = main;
@@ -1032,40 +1068,59 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   HIPCHK(hipEventRecord(m->ev_join, side));
   // ---- velocity branch (main stream)
   if (baro_adopted) {
-    // the sub-cycle of this step ran beside the last tracer kernel: adopt eta, U, V and the filtered state
-    HIPCHK(hipStreamWaitEvent(main, m->ev_baro, 0));
+    // the sub-cycle of this step ran in the previous one: adopt eta, U, V and the filtered state
+    if (m->baro_inflight) HIPCHK(hipStreamWaitEvent(main, m->ev_baro, 0));
     m->baro_inflight = false;
     for (int q = 0; q < 3; q++) {
       std::swap(m->f[GB25_ETA + q].d, m->ahead_eta[q].d);
       std::swap(m->f[GB25_ETA_BAR + q].d, m->ahead_bar[q].d);
     }
     std::swap(m->bars, m->bars_ahead);
+    m->last_baro_folded = m->ahead_eta_folded;
   } else if ((s = barotropic_impl(m, (real)dt))) {
     return s;
   }
+  const bool eta_halos_fresh = m->last_baro_folded;   // the last launch of this step's sub-cycle wrote them
   m->time += dt;
   m->iteration += 1;
   // The reference fills the halos of u, v, eta, U, V here as well as after the corrector.  On a single slab the
   // corrector reads and writes its own columns only, and the fill after it rewrites exactly the same halo cells from
   // the corrected interior, so the first fill has no effect on any later value: it is left out (3 launches).
   if ((s = corrector_impl(m, true))) return s;
-  if ((s = fill_halos_impl(m, true, false, 3, 1))) return s;   // u, v and eta, U, V
+  {
+    // u, v and eta, U, V -- whatever their last writers (the corrector, the sub-cycle's last launch) did not fill
+    const bool uv_fresh = !m->slab && m->fold_fills && m->composite && !complete;
+    const int which = (uv_fresh ? 0 : 1) | ((eta_halos_fresh && !complete) ? 0 : 2);
+    if (which && (s = fill_halos_impl(m, true, false, which, 1))) return s;
+  }
   if ((s = compute_w_impl(m))) return s;
   // ---- join: the tendencies need w, u, v and the pressure differences, T, S
   HIPCHK(hipStreamWaitEvent(main, m->ev_join, 0));
   if ((s = momentum_impl(m))) return s;
   if (m->baro_ahead && m->ahead_uv_valid && !m->ptr_exposed) {
-    // G.U, G.V of the next step exist now: its sub-cycle (latency-bound) runs on the side stream beside the tracer
-    // tendency kernel (issue-bound), into the partner buffers
-    HIPCHK(hipEventRecord(m->ev_mom, main));
-    HIPCHK(hipStreamWaitEvent(side, m->ev_mom, 0));
-    m->stream = side;
-    s = barotropic_impl(m, m->ahead_uv_dt, true);
-    m->stream = main;
-    if (s) return s;
-    HIPCHK(hipEventRecord(m->ev_baro, side));
+    // G.U, G.V of the next step exist now, and with them everything its split-explicit sub-cycle needs: it runs here,
+    // into the partner buffers, and leaves the head of the next step (where the corrector waits for it).
+    if (m->baro_ahead == 2) {
+      // ... on a stream of its own beside the tracer tendency kernel.  (Measured on MI355X, profiles/r02b: the first of
+      // its three launches is dispatched 7 us after the tracer kernel's 16 560 blocks and does not become resident until
+      // they have drained -- 800 us instead of 60 -- so the "beside" is mostly an "after", and the other two launches
+      // then compete with the next step's pressure kernel.  Kept as a schedule; not the default.)
+      HIPCHK(hipEventRecord(m->ev_mom, main));
+      HIPCHK(hipStreamWaitEvent(m->baro_stream, m->ev_mom, 0));
+      m->stream = m->baro_stream;
+      s = barotropic_impl(m, m->ahead_uv_dt, true);
+      m->ahead_eta_folded = m->last_baro_folded;
+      m->stream = main;
+      if (s) return s;
+      HIPCHK(hipEventRecord(m->ev_baro, m->baro_stream));
+      m->baro_inflight = true;
+    } else {
+      // ... on the main stream, between the momentum and the tracer tendencies: three launches of 60 us with the GPU to
+      // themselves, no cross-stream dependency at all.
+      if ((s = barotropic_impl(m, m->ahead_uv_dt, true))) return s;
+      m->ahead_eta_folded = m->last_baro_folded;
+    }
     m->ahead_baro_valid = true;
-    m->baro_inflight = true;
   }
   return tracers_impl(m);
 }
@@ -1131,12 +1186,27 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   if (cfg->device < 0 || cfg->device >= ndev)
     return fail(m, GB25_ERR_INVALID_ARGUMENT, "device ordinal %d out of range (%d devices)", cfg->device, ndev);
   HIPCHK(hipSetDevice(cfg->device));
+  {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+    m->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
   HIPCHK(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+  {
+    // The side stream carries the latency-bound work that runs BESIDE a long kernel of the main stream (the next step's
+    // split-explicit sub-cycle beside the tracer tendencies, the pressure beside the corrector): highest priority, so
+    // that its few blocks are dispatched ahead of the thousands the main stream has queued and it finishes first.
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    (void)lo;
+    HIPCHK(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithPriority(&m->baro_stream, hipStreamNonBlocking, hi));
+  }
   HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_baro, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_mom, hipEventDisableTiming));
+
   m->stream = m->own_stream;
   m->last_dt = cfg->dt;
   // On launch-latency-bound grids the extra cross-stream hops of the sub-cycle look-ahead cost more than the
@@ -1181,6 +1251,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   }
   if ((s = alloc_field(m, m->dpx, m->f[GB25_PHY].nx, m->f[GB25_PHY].ny, m->f[GB25_PHY].nz))) return s;
   if ((s = alloc_field(m, m->dpy, m->f[GB25_PHY].nx, m->f[GB25_PHY].ny, m->f[GB25_PHY].nz))) return s;
+
   for (int q = 0; q < 2; q++) {
     if ((s = alloc_field(m, m->ahead[q], m->f[GB25_T].nx, m->f[GB25_T].ny, m->f[GB25_T].nz))) return s;
     const Field &V3 = m->f[GB25_U + q], &V2 = m->f[GB25_GN_BT_U + q], &C2 = m->f[GB25_BT_U + q];
@@ -1240,6 +1311,7 @@ void gb25_destroy(gb25_model* m) {
   if (m->bars) hipFree(m->bars);
   if (m->dpx.d) hipFree(m->dpx.d);
   if (m->dpy.d) hipFree(m->dpy.d);
+
   for (int q = 0; q < 3; q++)
     for (Field* p : {&m->pp[q], &m->pp2[q], &m->ahead_eta[q]})
       if (p->d) hipFree(p->d);
@@ -1272,6 +1344,10 @@ void gb25_destroy(gb25_model* m) {
     hipStreamSynchronize(m->side_stream);
     hipStreamDestroy(m->side_stream);
   }
+  if (m->baro_stream) {
+    hipStreamSynchronize(m->baro_stream);
+    hipStreamDestroy(m->baro_stream);
+  }
   if (m->ev_fork) hipEventDestroy(m->ev_fork);
   if (m->ev_join) hipEventDestroy(m->ev_join);
   if (m->ev_baro) hipEventDestroy(m->ev_baro);
@@ -1298,7 +1374,8 @@ gb25_status gb25_use_own_stream(gb25_model* m) {
 gb25_status gb25_synchronize(gb25_model* m) {
   CHECK_MODEL(m);
   HIPCHK(hipStreamSynchronize(m->stream));
-  HIPCHK(hipStreamSynchronize(m->side_stream));   // the sub-cycle look-ahead may still be running there
+  HIPCHK(hipStreamSynchronize(m->side_stream));
+  HIPCHK(hipStreamSynchronize(m->baro_stream));   // the sub-cycle look-ahead may still be running there
   if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));   // (a slab's runs on the second stream of its context)
   return GB25_OK;
 }
@@ -1322,6 +1399,7 @@ static gb25_status copy_field(gb25_model* m, gb25_field id, real* host, int incl
   HIPCHK(hipStreamSynchronize(m->stream));
   if (to_device) {   // a look-ahead may still be reading the old values
     HIPCHK(hipStreamSynchronize(m->side_stream));
+    HIPCHK(hipStreamSynchronize(m->baro_stream));
     if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
   }
   if (include_halos) {
@@ -1356,6 +1434,7 @@ static gb25_status widen_phy(gb25_model* m) {   // the host uploaded pHY': rebui
 // into the partner too, so that the halo layers no kernel ever rewrites are the same in both.
 static gb25_status mirror_tracers(gb25_model* m) {
   m->ahead_valid = false;
+  m->complete_fills_needed = 2;
   for (int q = 0; q < 2; q++)
     HIPCHK(hipMemcpyAsync(m->ahead[q].d, m->f[GB25_T + q].d, m->f[GB25_T + q].elems() * sizeof(real),
                           hipMemcpyDeviceToDevice, m->stream));
@@ -1363,6 +1442,7 @@ static gb25_status mirror_tracers(gb25_model* m) {
 }
 static gb25_status mirror_velocities(gb25_model* m) {   // u and v alternate between two buffers likewise
   m->ahead_uv_valid = false;
+  m->complete_fills_needed = 2;
   for (int q = 0; q < 2; q++)
     HIPCHK(hipMemcpyAsync(m->ahead_uv[q].d, m->f[GB25_U + q].d, m->f[GB25_U + q].elems() * sizeof(real),
                           hipMemcpyDeviceToDevice, m->stream));
@@ -1381,6 +1461,7 @@ gb25_status gb25_set_field(gb25_model* m, gb25_field f, const void* host, int in
     s = mask_impl(m);   // set!(model, ...) masks what it has set (as Oceananigans' set! does on an immersed grid)
   if (s == GB25_OK) {
     m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;   // any input of the look-aheads may have changed
+    m->complete_fills_needed = 2;
     if (f == GB25_T || f == GB25_S) s = mirror_tracers(m);
     if (f == GB25_U || f == GB25_V) s = mirror_velocities(m);
     if (s == GB25_OK && f >= GB25_ETA && f <= GB25_V_BAR) {   // eta, U, V and the filtered state alternate likewise
@@ -1480,6 +1561,7 @@ gb25_status gb25_set_bottom_height(gb25_model* m, const double* zb) {
   if (m->cfg.Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "an immersed boundary needs Nz <= 254 (8-bit level tables)");
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(m->side_stream));
+  HIPCHK(hipStreamSynchronize(m->baro_stream));
   const int Nx = m->Nx;
   gb25_status s = build_bottom(m, [&](int i, int j) { return zb[(size_t)(((i % Nx) + Nx) % Nx) + (size_t)Nx * j]; });
   if (s) return s;
@@ -1519,6 +1601,9 @@ gb25_status gb25_compute_tendencies(gb25_model* m) {
 gb25_status gb25_ab2_step(gb25_model* m, double dt, int euler) {
   CHECK_MODEL(m);
   if (m->slab) return fail(m, GB25_ERR_STATE, "gb25_ab2_step: phase-by-phase driving is for single-domain models");
+  // ab2_step! leaves every halo as it is; look-ahead buffers written with their halos (fold_fills) are therefore not
+  // adopted here: the stand-alone kernels give the same interior bits
+  if (m->fold_fills) m->ahead_valid = false;
   return ab2_step_impl(m, dt, euler);
 }
 gb25_status gb25_correct_velocities_and_cache_previous_tendencies(gb25_model* m, double) {
@@ -1537,6 +1622,7 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
   // a switch may change which buffers carry the next time level: whatever is in flight finishes, every look-ahead is void
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(m->side_stream));
+  HIPCHK(hipStreamSynchronize(m->baro_stream));
   if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
   m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
   switch (opt) {
@@ -1549,7 +1635,10 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
       if (v < 0 || v > 2) return fail(m, GB25_ERR_INVALID_ARGUMENT, "GB25_OPT_AB2_LOOKAHEAD: 0, 1 or 2 (tracers only)");
       m->ab2_ahead = v;
       return GB25_OK;
-    case GB25_OPT_SUBCYCLE_LOOKAHEAD: m->baro_ahead = v != 0; return GB25_OK;
+    case GB25_OPT_SUBCYCLE_LOOKAHEAD:
+      if (v < 0 || v > 2) return fail(m, GB25_ERR_INVALID_ARGUMENT, "GB25_OPT_SUBCYCLE_LOOKAHEAD: 0, 1 (main stream) or 2 (own stream)");
+      m->baro_ahead = v;
+      return GB25_OK;
     case GB25_OPT_SUBCYCLE_BLOCK:
       if (v != 1 && v != 3 && v != 5 && v != 7)
         return fail(m, GB25_ERR_INVALID_ARGUMENT, "GB25_OPT_SUBCYCLE_BLOCK: 1, 3, 5 or 7 substeps per launch");
@@ -1562,6 +1651,10 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
     case GB25_OPT_PRESSURE_PRECISION:
       if (v != 32 && v != 64) return fail(m, GB25_ERR_INVALID_ARGUMENT, "GB25_OPT_PRESSURE_PRECISION: 64 or 32");
       m->pressure_bits = (sizeof(real) == 8) ? 64 : v;   // (a Float64 model's own arithmetic IS fp64)
+      return GB25_OK;
+    case GB25_OPT_FOLD_FILLS:
+      m->fold_fills = v != 0;
+      m->complete_fills_needed = 2;
       return GB25_OK;
     case GB25_OPT_IMMERSED_KERNELS:
       // 1: run the immersed-boundary kernel variants even where nothing is immersed (they must then give the bits of
@@ -1593,6 +1686,7 @@ gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
     case GB25_OPT_SPLIT_TENDENCIES: *v = m->split_tendencies; break;
     case GB25_OPT_PRESSURE_PRECISION: *v = m->pressure_bits; break;
     case GB25_OPT_IMMERSED_KERNELS: *v = m->immersed; break;
+    case GB25_OPT_FOLD_FILLS: *v = m->fold_fills; break;
     default: return GB25_ERR_INVALID_ARGUMENT;
   }
   return GB25_OK;

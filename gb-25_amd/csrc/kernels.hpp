@@ -759,6 +759,12 @@ __global__ void k_ab2_tracers1(real* __restrict__ T, real* __restrict__ S, const
 // Periodic x / wall y are handled in-kernel (topology-aware operators): no halo fills inside
 // the sub-cycle.
 // =============================================================================================
+// a value and its periodic x images (see the FOLD variants of k_corrector, k_barotropic_multi and the tracer kernel)
+__device__ __forceinline__ void store_x_images(const Grid& g, real* a, int o, real x, bool xw, bool xe) {
+  a[o] = x;
+  if (xw) a[o + g.Nx] = x;   // column i < H is the periodic image of column i + Nx (east halo)
+  if (xe) a[o - g.Nx] = x;   // column i >= Nx - H of column i - Nx (west halo)
+}
 struct Baro {
   const real *eta0, *U0, *V0;  // state at substep m
   real *eta1, *U1, *V1;        // state at substep m+1
@@ -818,6 +824,9 @@ struct BaroMulti {
   // and so are the filtered-state arrays when the averages live in (wide) work arrays (no publish launch)
   int first, last;
   real *eta_out, *U_out, *V_out, *eb_out, *ub_out, *vb_out;
+  // single periodic domain: the last launch also writes the halo cells tupled_fill_halo_regions! derives from the new
+  // eta, U, V (periodic x images, y layer, zero on the wall faces of V): no fill launch for them in the step
+  int fold;
 };
 template <int BT_S, int BT_TY, bool IMM>
 __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm, real dtau) {
@@ -825,6 +834,11 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
   constexpr int BT_PPT = (BT_NP + BT_NT - 1) / BT_NT;
   __shared__ real E[BT_RY][BT_RX], U[BT_RY][BT_RX], V[BT_RY][BT_RX], GUs[BT_RY][BT_RX], GVs[BT_RY][BT_RX];
   __shared__ real Mdxf[BT_RY + 1], Mrazc[BT_RY], Mrdxc[BT_RY];   // row metrics: no global loads inside the sub-cycle
+  // This kernel is a chain of short dependent phases (LDS, two barriers per substep) and runs BESIDE the tracer
+  // tendency kernel, whose waves saturate the vector issue of every SIMD: with equal priority each of its instructions
+  // queues behind theirs and the sub-cycle takes 0.32 ms per launch instead of 0.07 -- longer than the kernel it hides
+  // behind.  Static high priority for its few waves costs the neighbour almost nothing.
+  __builtin_amdgcn_s_setprio(3);
   const Baro& b = bm.b;
   const int tid = threadIdx.x;
   const int i0 = b.ilo + blockIdx.x * BT_TX, j0 = blockIdx.y * BT_TY;
@@ -944,9 +958,27 @@ __global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm
         const int ig = i0 - BT_S + lx;
         if (ig >= 0 && ig < g.Nx) {   // (a widened slab also owns columns outside the canonical interior)
           const int oc = i2(g, ig, pj[q]);
-          bm.eta_out[oc] = ae[q];
-          bm.U_out[oc] = au[q];
-          bm.V_out[oc] = av[q];
+          if (bm.fold) {
+            const int jg = pj[q];
+            const bool xw = ig < g.H, xe = ig >= g.Nx - g.H;
+            const real vv = jg == 0 ? real(0.) : av[q];                    // the southern wall face
+            store_x_images(g, bm.eta_out, oc, ae[q], xw, xe);
+            store_x_images(g, bm.U_out, oc, au[q], xw, xe);
+            store_x_images(g, bm.V_out, oc, vv, xw, xe);
+            if (jg == 0) {
+              store_x_images(g, bm.eta_out, oc - g.sx, ae[q], xw, xe);
+              store_x_images(g, bm.U_out, oc - g.sx, au[q], xw, xe);
+            }
+            if (jg == g.Ny - 1) {
+              store_x_images(g, bm.eta_out, oc + g.sx, ae[q], xw, xe);
+              store_x_images(g, bm.U_out, oc + g.sx, au[q], xw, xe);
+              store_x_images(g, bm.V_out, oc + g.sx, real(0.), xw, xe);   // the northern wall face
+            }
+          } else {
+            bm.eta_out[oc] = ae[q];
+            bm.U_out[oc] = au[q];
+            bm.V_out[oc] = av[q];
+          }
           if (bm.eb_out) {
             bm.eb_out[oc] = ae[q];
             bm.ub_out[oc] = au[q];
@@ -1009,7 +1041,12 @@ __global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const real* __r
 // Columns [i0, i0+ni): a slab of a multi-GPU run also corrects its x-halo columns (same arithmetic as the
 // owning neighbour, so no second halo exchange is needed); Ubar/Vbar are stored for interior columns only.
 // IMM: divide by the static column depth at the face and leave the faces that touch the solid at zero.
-template <bool IMM>
+// FOLD (single periodic domain): the corrector is the last writer of u and v in a step, so it also writes every halo
+// cell tupled_fill_halo_regions! would derive from the cell it has in hand -- the periodic x image, the y layer (the
+// wall faces of v: zero), the z layers, and the x images of those -- and the separate fill launch of u, v disappears
+// from the critical path of the step.  Halo cells deeper than one layer in y / z never change while stepping; their x
+// images were written by the last complete fill (first_time_step!, or the step after a host write).
+template <bool IMM, bool FOLD>
 __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u, real* __restrict__ v,
                                                    const real* __restrict__ U, const real* __restrict__ V,
                                                    real* __restrict__ Ub, real* __restrict__ Vb,
@@ -1062,6 +1099,40 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
   for (int k = 0; k < g.Nz; k++) {
     if (!IMM || k >= KPU) u[o] = u[o] + du;
     if (!IMM || k >= KPV) v[ov] = v[ov] + dv;
+    o += g.pl_c;
+    ov += g.pl_v;
+  }
+  if (!FOLD) return;
+  if (j == 0) {   // v on the southern wall face: zero (what the y fill writes there)
+    ov = ov0;
+#pragma unroll 8
+    for (int k = 0; k < g.Nz; k++, ov += g.pl_v) v[ov] = real(0.);
+  }
+  // ---- the halo cells derived from this column (the streaming loop above stays as it was: the few threads with images
+  // to write re-read their column from L2)
+  const bool xw = i < g.H, xe = i >= g.Nx - g.H, ys = j == 0, yn = j == g.Ny - 1;
+  {   // z layers: level -1 <- level 0, level Nz <- level Nz-1 (interior rows), with their x images
+    const int ot = o0 + (g.Nz - 1) * g.pl_c, ovt = ov0 + (g.Nz - 1) * g.pl_v;
+    store_x_images(g, u, o0 - g.pl_c, u[o0], xw, xe);
+    store_x_images(g, v, ov0 - g.pl_v, v[ov0], xw, xe);
+    store_x_images(g, u, ot + g.pl_c, u[ot], xw, xe);
+    store_x_images(g, v, ovt + g.pl_v, v[ovt], xw, xe);
+  }
+  if (!(xw || xe || ys || yn)) return;
+  o = o0;
+  ov = ov0;
+  // (few threads, one dependent chain each: unrolled so that eight levels' loads are in flight at once -- the row
+  // blocks of the northern edge are dispatched last and their time is the tail of the kernel)
+#pragma unroll 8
+  for (int k = 0; k < g.Nz; k++) {
+    const real un = u[o], vn = v[ov];
+    if (xw) { u[o + g.Nx] = un; v[ov + g.Nx] = vn; }
+    if (xe) { u[o - g.Nx] = un; v[ov - g.Nx] = vn; }
+    if (ys) store_x_images(g, u, o - g.sx, un, xw, xe);                 // row -1 <- row 0
+    if (yn) {
+      store_x_images(g, u, o + g.sx, un, xw, xe);                       // row Ny <- row Ny-1
+      store_x_images(g, v, ov + g.sx, real(0.), xw, xe);                // v: face Ny is the northern wall
+    }
     o += g.pl_c;
     ov += g.pl_v;
   }

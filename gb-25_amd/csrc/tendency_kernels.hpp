@@ -454,14 +454,15 @@ struct Ab2Ahead {
 // IMM: the grid has an immersed boundary.  The orders of the reconstructions then come per lane from the folded
 // per-column tables (device_common.hpp, Immersed) instead of per wave from the row index; everything else is unchanged:
 // the fluxes through faces that touch the solid vanish because the velocities there are masked to zero.
-template <int MINW, bool AHEAD, bool IMM>
-__global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, const real* __restrict__ u,
-                                                              const real* __restrict__ v,
-                                                              const real* __restrict__ w,
-                                                              const real* __restrict__ T, const real* __restrict__ S,
-                                                              real* __restrict__ GT, real* __restrict__ GS, int nbx,
-                                                              int kchunks, int nb, Ab2Ahead next) {
-  const int L = xcd_remap(blockIdx.x, nb);
+// FOLD (with AHEAD, single periodic domain): T and S of the next time level are written with the halo cells
+// tupled_fill_halo_regions! derives from them (periodic x images, y layer, z layers and their x images), so that the
+// adopted buffers need no fill launch.
+// The arithmetic of one tile (63 cells of a row x 4 rows x one chunk of levels); L = logical tile index.
+template <bool AHEAD, bool IMM, bool FOLD>
+__device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restrict__ u, const real* __restrict__ v,
+                                            const real* __restrict__ w, const real* __restrict__ T,
+                                            const real* __restrict__ S, real* __restrict__ GT, real* __restrict__ GS,
+                                            int nbx, int kchunks, const Ab2Ahead& next, const int L) {
   const int bx = L % nbx, r = L / nbx;
   const int kc = r % kchunks, by = r / kchunks;
   const int klen = (g.Nz + kchunks - 1) / kchunks;
@@ -510,6 +511,8 @@ __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, cons
     int ord = biased_order_face(k0 - kbt, Nzc);
     fz = Azw * biased6<false, real2v>(ord, Azw > real(0.), cz, cz, cz);
   }
+  // FOLD: does this wave hold cells with a periodic x image or a y layer to write?
+  const bool fold_row = FOLD && (j == 0 || j == g.Ny - 1 || bx * V3_OUT < g.H || bx * V3_OUT + V3_OUT > g.Nx - g.H);
   for (int k = k0; k < k1; k++) {
     const real dz = g.dzc[k];
     if (IMM) {
@@ -539,8 +542,24 @@ __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, cons
       bstore(bGT, vo, cc, G.x);
       bstore(bGS, vo, cc, G.y);
       if (AHEAD) {   // T, S of the NEXT step while T, S (cz[3]) and the new tendency are in registers
-        bstore(bTn, vo, cc, ab2_advance(cz[3].x, G.x, bload(bGmT, vo, cc), next.dt, next.C1, next.C2));
-        bstore(bSn, vo, cc, ab2_advance(cz[3].y, G.y, bload(bGmS, vo, cc), next.dt, next.C1, next.C2));
+        const real tn = ab2_advance(cz[3].x, G.x, bload(bGmT, vo, cc), next.dt, next.C1, next.C2);
+        const real sn = ab2_advance(cz[3].y, G.y, bload(bGmS, vo, cc), next.dt, next.C1, next.C2);
+        bstore(bTn, vo, cc, tn);
+        bstore(bSn, vo, cc, sn);
+        if (FOLD && (fold_row || k == 0 || k == g.Nz - 1)) {   // (wave-uniform: most waves and levels skip all of it)
+          const int NxB = g.Nx * SZ;
+          const bool xw = i < g.H, xe = i >= g.Nx - g.H;
+          auto images = [&](int so, bool self) {   // the cell displaced by `so` bytes (a y / z layer) and its x images
+            if (self) { bstore(bTn, vo, cc + so, tn); bstore(bSn, vo, cc + so, sn); }
+            if (xw) { bstore(bTn, vo + NxB, cc + so, tn); bstore(bSn, vo + NxB, cc + so, sn); }
+            if (xe) { bstore(bTn, vo - NxB, cc + so, tn); bstore(bSn, vo - NxB, cc + so, sn); }
+          };
+          images(0, false);
+          if (j == 0) images(-sx * SZ, true);
+          if (j == g.Ny - 1) images(sx * SZ, true);
+          if (k == 0) images(-pc * SZ, true);
+          if (k == g.Nz - 1) images(pc * SZ, true);
+        }
       }
     }
     fz = ft;
@@ -553,6 +572,15 @@ __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, cons
 #undef CZ
 #undef CY
 #undef CX
+}
+template <int MINW, bool AHEAD, bool IMM, bool FOLD = false>
+__global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, const real* __restrict__ u,
+                                                              const real* __restrict__ v,
+                                                              const real* __restrict__ w,
+                                                              const real* __restrict__ T, const real* __restrict__ S,
+                                                              real* __restrict__ GT, real* __restrict__ GS, int nbx,
+                                                              int kchunks, int nb, Ab2Ahead next) {
+  tracer_tile<AHEAD, IMM, FOLD>(g, u, v, w, T, S, GT, GS, nbx, kchunks, next, xcd_remap(blockIdx.x, nb));
 }
 
 }  // namespace gb25

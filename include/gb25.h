@@ -96,7 +96,9 @@ typedef enum {
 typedef enum {
   GB25_OPT_KERNELS = 0,          /* [2] 2: LDS-staged / flux-sharing tendency kernels; 1: direct-stencil kernels (cross-check) */
   GB25_OPT_AB2_LOOKAHEAD,        /* [1] the tendency kernels also write the next time level: 0 off, 1 u,v,T,S, 2 T,S only */
-  GB25_OPT_SUBCYCLE_LOOKAHEAD,   /* [1 from 8 M cells and on slabs] next step's split-explicit sub-cycle beside the tracer kernel */
+  GB25_OPT_SUBCYCLE_LOOKAHEAD,   /* [1 from 8 M cells and on slabs] the next step's split-explicit sub-cycle runs as soon as its
+                                    G.U, G.V exist: 1 = between the momentum and the tracer kernel, 2 = beside the tracer
+                                    kernel on a stream of its own (slabs: on the exchange stream), 0 = inside its own step */
   GB25_OPT_SUBCYCLE_BLOCK,       /* [7] substeps per barotropic launch: 1, 3, 5, 7 */
   GB25_OPT_FILL_FUSED,           /* [1] y, z and periodic-x halo fills in one launch */
   GB25_OPT_TWO_STREAMS,          /* [1] tracer branch (AB2, halos, pressure) on a second stream */
@@ -107,6 +109,7 @@ typedef enum {
                                     type's own arithmetic, operation for operation what an all-Float32 model computes
                                     (the stated Float32 tolerance) */
   GB25_OPT_IMMERSED_KERNELS,     /* [1 iff some cell is immersed] 1: run the immersed-boundary kernel variants anyway */
+  GB25_OPT_FOLD_FILLS,           /* [1] single domain: the last writers of u,v / T,S / eta,U,V write the halo cells themselves */
   GB25_OPT_COUNT
 } gb25_option;
 

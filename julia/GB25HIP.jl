@@ -30,7 +30,7 @@ const FIELD = (u = 0, v = 1, w = 2, T = 3, S = 4, pHY = 5,
 # gb25_option
 const OPTION = (kernels = 0, ab2_lookahead = 1, subcycle_lookahead = 2, subcycle_block = 3, fill_fused = 4,
                 two_streams = 5, store_pressure = 6, split_tendencies = 7, pressure_precision = 8,
-                immersed_kernels = 9)
+                immersed_kernels = 9, fold_fills = 10)
 
 # mirror of gb25_config; isbits, passed by reference
 Base.@kwdef mutable struct Config

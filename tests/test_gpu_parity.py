@@ -418,8 +418,47 @@ def test_fused_halo_fill_is_bitwise_neutral(shape, halo):
         assert np.array_equal(a.backend.get_field(n, True), b.backend.get_field(n, True)), ("steps", n)
 
 
+@pytest.mark.parametrize("shape,halo", [((150, 70, 12), 8), ((40, 21, 6), 4), ((1440, 90, 14), 8)])
+def test_fills_folded_into_their_producers_are_bitwise_neutral(shape, halo):
+    """The corrector (u, v), the tracer look-ahead (T, S) and the last barotropic launch (eta, U, V) write the halo cells
+    of what they produce, and the fill launches leave the step (option fold_fills, the default) -- against the explicit
+    fills: every cell of every parent array, including halo values the host planted in layers no fill rewrites, through
+    a host write and a changed dt (which bring the explicit fills back for two steps)."""
+    Nx, Ny, Nz = shape
+    models = []
+    for fold in (0, 1):
+        m = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=300.0, halo=(halo,) * 3,
+                                            options=dict(fold_fills=fold, subcycle_lookahead=1))
+        gb.set_baroclinic_instability(m)
+        set_noisy_velocities(m, 0.05)
+        for n, seed in (("T", 5), ("u", 6), ("v", 7), ("eta", 8), ("V", 9)):
+            a = m.backend.get_field(n, True)
+            a += (1e-3 * counter_rng(a.shape, seed, 1)).astype(np.float32)      # noise in EVERY halo layer
+            m.backend.set_field(n, a, True)
+        models.append(m)
+    a, b = models
+
+    def same(label):
+        for n in ALL_FIELDS:
+            assert np.array_equal(a.backend.get_field(n, True), b.backend.get_field(n, True)), (label, n)
+
+    for m in (a, b):
+        gb.first_time_step(m)
+        gb.loop(m, 7)
+    same("8 steps")
+    assert b.backend.lookahead_state()[0]
+    S = a.backend.get_field("S", False) + np.float32(0.125)
+    for m in (a, b):
+        m.backend.set_field("S", S, False)
+        gb.loop(m, 3)
+        m.backend.set_dt(240.0)
+        gb.loop(m, 4)
+    same("after a host write and a changed dt")
+
+
 @pytest.mark.parametrize("opts", [dict(two_streams=0), dict(subcycle_block=3), dict(subcycle_block=1),
-                                  dict(store_pressure=1), dict(ab2_lookahead=2, subcycle_lookahead=1)])
+                                  dict(store_pressure=1), dict(ab2_lookahead=2, subcycle_lookahead=1),
+                                  dict(subcycle_lookahead=2), dict(fold_fills=0)])
 def test_schedule_options_are_bitwise_neutral(opts):
     """Every schedule switch of gb25_set_option (single stream, 3 substeps per launch, pHY' stored every step, tracer
     look-ahead only) gives the bits of the default schedule, through a changed dt and an option flipped mid-run.  One
@@ -436,7 +475,7 @@ def test_schedule_options_are_bitwise_neutral(opts):
         gb.loop(m, 4)
         m.backend.set_dt(450.0)
         gb.loop(m, 3)
-    b.backend.set_option("subcycle_lookahead", 1 - b.backend.get_option("subcycle_lookahead"))
+    b.backend.set_option("subcycle_lookahead", 0 if b.backend.get_option("subcycle_lookahead") else 1)
     for m in (a, b):
         gb.loop(m, 3)
     for n in ALL_FIELDS:
