@@ -1105,6 +1105,7 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
       // its three launches is dispatched 7 us after the tracer kernel's 16 560 blocks and does not become resident until
       // they have drained -- 800 us instead of 60 -- so the "beside" is mostly an "after", and the other two launches
       // then compete with the next step's pressure kernel.  Kept as a schedule; not the default.)
+      if (!m->baro_stream) HIPCHK(hipStreamCreateWithFlags(&m->baro_stream, hipStreamNonBlocking));
       HIPCHK(hipEventRecord(m->ev_mom, main));
       HIPCHK(hipStreamWaitEvent(m->baro_stream, m->ev_mom, 0));
       m->stream = m->baro_stream;
@@ -1192,16 +1193,11 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     m->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   HIPCHK(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
-  {
-    // The side stream carries the latency-bound work that runs BESIDE a long kernel of the main stream (the next step's
-    // split-explicit sub-cycle beside the tracer tendencies, the pressure beside the corrector): highest priority, so
-    // that its few blocks are dispatched ahead of the thousands the main stream has queued and it finishes first.
-    int lo = 0, hi = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    (void)lo;
-    HIPCHK(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithPriority(&m->baro_stream, hipStreamNonBlocking, hi));
-  }
+  // (few streams on purpose: HIP multiplexes streams onto a handful of hardware queues, and two streams that share one
+  // run in order -- a rocprof trace of eight slabs in one process, 25 streams, shows the exchange stream and the main
+  // stream taking turns.  A slab has three: own, side, and the exchange stream of its context; the stream of
+  // SUBCYCLE_LOOKAHEAD = 2 is created on demand.)
+  HIPCHK(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_baro, hipEventDisableTiming));
@@ -1375,7 +1371,7 @@ gb25_status gb25_synchronize(gb25_model* m) {
   CHECK_MODEL(m);
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(m->side_stream));
-  HIPCHK(hipStreamSynchronize(m->baro_stream));   // the sub-cycle look-ahead may still be running there
+  if (m->baro_stream) HIPCHK(hipStreamSynchronize(m->baro_stream));   // the sub-cycle look-ahead may still be running there
   if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));   // (a slab's runs on the second stream of its context)
   return GB25_OK;
 }
@@ -1399,7 +1395,7 @@ static gb25_status copy_field(gb25_model* m, gb25_field id, real* host, int incl
   HIPCHK(hipStreamSynchronize(m->stream));
   if (to_device) {   // a look-ahead may still be reading the old values
     HIPCHK(hipStreamSynchronize(m->side_stream));
-    HIPCHK(hipStreamSynchronize(m->baro_stream));
+    if (m->baro_stream) HIPCHK(hipStreamSynchronize(m->baro_stream));
     if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
   }
   if (include_halos) {
@@ -1561,7 +1557,7 @@ gb25_status gb25_set_bottom_height(gb25_model* m, const double* zb) {
   if (m->cfg.Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "an immersed boundary needs Nz <= 254 (8-bit level tables)");
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(m->side_stream));
-  HIPCHK(hipStreamSynchronize(m->baro_stream));
+  if (m->baro_stream) HIPCHK(hipStreamSynchronize(m->baro_stream));
   const int Nx = m->Nx;
   gb25_status s = build_bottom(m, [&](int i, int j) { return zb[(size_t)(((i % Nx) + Nx) % Nx) + (size_t)Nx * j]; });
   if (s) return s;
@@ -1622,7 +1618,7 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
   // a switch may change which buffers carry the next time level: whatever is in flight finishes, every look-ahead is void
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(m->side_stream));
-  HIPCHK(hipStreamSynchronize(m->baro_stream));
+  if (m->baro_stream) HIPCHK(hipStreamSynchronize(m->baro_stream));
   if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
   m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
   switch (opt) {
