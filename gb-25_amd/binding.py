@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "gb25_compute_momentum_tendencies", "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
     "gb25_compute_tendencies", "gb25_ab2_step", "gb25_correct_velocities_and_cache_previous_tendencies",
     "gb25_update_state", "gb25_first_time_step", "gb25_time_step", "gb25_loop",
-    "gb25_set_option", "gb25_get_option", "gb25_set_bottom_height", "gb25_get_bottom_info",
+    "gb25_set_option", "gb25_get_option", "gb25_set_bottom_height", "gb25_get_bottom_info", "gb25_set_top_flux",
     "gb25_comm_unique_id", "gb25_comm_init_rccl", "gb25_comm_init_local", "gb25_comm_init_callback", "gb25_comm_finalize",
     "gb25_lookahead_state", "gb25_debug_sequence", "gb25_save_state",
     "gb25_profile_enable", "gb25_profile_reset", "gb25_profile_get",
@@ -117,6 +117,7 @@ def load_library(float_type="Float32"):
     lib.gb25_correct_velocities_and_cache_previous_tendencies.argtypes = [P, C.c_double]
     lib.gb25_loop.argtypes = [P, C.c_int32]
     lib.gb25_save_state.argtypes = [P, C.c_char_p, C.c_char_p]
+    lib.gb25_set_top_flux.argtypes = [P, C.c_int, P]
     lib.gb25_set_bottom_height.argtypes = [P, P]
     lib.gb25_get_bottom_info.argtypes = [P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     lib.gb25_set_option.argtypes = [P, C.c_int, C.c_int32]
@@ -272,6 +273,15 @@ class HipBackend:
         """save_model_state: this rank's slab -> <directory>/<label>/fields_rank<R>.npz; returns the path."""
         self._call("gb25_save_state", str(directory).encode(), str(label).encode())
         return os.path.join(str(directory), label, f"fields_rank{self.cfg.rank}.npz")
+
+    def set_top_flux(self, name, J):
+        """FluxBoundaryCondition at the top of u | v | T | S: interior-shaped array (None: back to no-flux)."""
+        if J is None:
+            self._call("gb25_set_top_flux", FIELD_IDS[name], None)
+            return
+        d = self.field_dims(name, False)
+        a = np.ascontiguousarray(np.asarray(J, dtype=self.dtype).reshape(d[0], d[1]).T)
+        self._call("gb25_set_top_flux", FIELD_IDS[name], a.ctypes.data_as(C.c_void_p))
 
     # ---- immersed boundary
     def set_bottom_height(self, zb):

@@ -58,6 +58,9 @@ struct Grid {
   const double* eos;
   const double* dzf_d;                               // dzf in fp64 for the hydrostatic integral, by k (0..Nz)
   Immersed im;                                       // (null pointers on a grid without bathymetry)
+  // FluxBoundaryCondition at the top of u, v, T, S (null: the default no-flux): 2-D arrays with the parent layout of a
+  // 2-D field of the same location; enter the tendency of the top cell as -J / dz (apply_z_top_bc!)
+  const real* top_flux[4];
 };
 
 // element offsets

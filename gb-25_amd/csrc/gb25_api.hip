@@ -122,6 +122,7 @@ struct gb25_model {
   unsigned* d_ord[3] = {nullptr, nullptr, nullptr};
   real* d_H[4] = {nullptr, nullptr, nullptr, nullptr};   // Hfc, Hcf, rHfc, rHcf (parent layout of a (c,f) field)
   real* d_wideH[2] = {nullptr, nullptr};                 // Hfc, Hcf on the wide barotropic layout of a slab
+  real* d_top_flux[4] = {nullptr, nullptr, nullptr, nullptr};   // FluxBoundaryCondition at the top of u, v, T, S
   bool slab = false;                 // x halos come from a neighbour (nranks > 1, or the self-ring of slab_mode = 1)
   struct SlabGroup* group = nullptr; // exchange context (transport, buffers, comm stream) once gb25_comm_init_* was called
   int group_index = 0;               // this slab's position in group->slabs
@@ -703,6 +704,7 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
   }
   if (part == 1) return GB25_OK;   // the direct-stencil kernels are not split: everything after the halos arrived
   if (m->immersed) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know no immersed boundary");
+  if (g.top_flux[0] || g.top_flux[1]) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know no flux boundary conditions");
   tile_grid(g, &nbx, &nb);
   dim3 b(TX, TY);
   {
@@ -753,6 +755,7 @@ gb25_status tracers_impl(gb25_model* m) {
   }
   m->ahead_valid = false;   // only the packed kernel looks ahead
   if (m->immersed) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know no immersed boundary");
+  if (g.top_flux[2] || g.top_flux[3]) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know no flux boundary conditions");
   tile_grid(g, &nbx, &nb);
   Timed t(m, GB25_K_TRACERS);
   hipLaunchKernelGGL(k_tracer_tendencies, dim3(nb), dim3(TX, TY), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
@@ -1324,6 +1327,8 @@ void gb25_destroy(gb25_model* m) {
     if (p) hipFree(p);
   for (auto p : m->d_wideH)
     if (p) hipFree(p);
+  for (auto p : m->d_top_flux)
+    if (p) hipFree(p);
   for (int a = 0; a < 2; a++) {
     for (auto& w : m->wide[a])
       if (w.d) hipFree(w.d);
@@ -1588,7 +1593,38 @@ gb25_status gb25_compute_auxiliaries(gb25_model* m) {
 gb25_status gb25_fill_diffusivity_halos(gb25_model* m) { CHECK_MODEL(m); return GB25_OK; }
 gb25_status gb25_compute_momentum_tendencies(gb25_model* m) { CHECK_MODEL(m); return momentum_impl(m); }
 gb25_status gb25_compute_tracer_tendencies(gb25_model* m) { CHECK_MODEL(m); return tracers_impl(m); }
+// compute_hydrostatic_boundary_tendency_contributions! (src/precompile.jl:25,52-61): the flux boundary conditions are
+// applied INSIDE the tendency kernels (the top cell's tendency gets -J/dz where it is computed, so that the AB2
+// look-aheads see the complete tendency); as a phase of its own there is nothing left to do.
 gb25_status gb25_compute_boundary_tendencies(gb25_model* m) { CHECK_MODEL(m); return GB25_OK; }
+// FluxBoundaryCondition at the top of u, v, T or S (f = GB25_U, GB25_V, GB25_T, GB25_S): J at the interior points of the
+// field's horizontal location (dims = gb25_field_dims(f, 0)[0..1], i fastest), positive upward (out of the ocean), in
+// the units of the field times m/s.  NULL restores the default no-flux condition.  With ClimaOcean's ocean_simulation
+// these are the arrays the coupled model fills every step (wind stress, heat and fresh-water flux).
+gb25_status gb25_set_top_flux(gb25_model* m, gb25_field f, const void* host) {
+  CHECK_MODEL(m);
+  const int q = f == GB25_U ? 0 : f == GB25_V ? 1 : f == GB25_T ? 2 : f == GB25_S ? 3 : -1;
+  if (q < 0) return fail(m, GB25_ERR_INVALID_ARGUMENT, "top flux boundary conditions exist for u, v, T, S");
+  if (gb25_status s = collective_guard(m, 6, (unsigned)f, host ? 1.0 : 0.0)) return s;
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(m->side_stream));
+  m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+  const Field& F = m->f[f];
+  const size_t n2 = (size_t)F.nx * F.ny;
+  if (!host) {
+    m->g.top_flux[q] = nullptr;   // (the array stays allocated for the next use)
+    return GB25_OK;
+  }
+  if (!m->d_top_flux[q]) {
+    HIPCHK(hipMalloc(&m->d_top_flux[q], n2 * sizeof(real)));
+    HIPCHK(hipMemset(m->d_top_flux[q], 0, n2 * sizeof(real)));
+  }
+  const int H = m->cfg.halo, nxi = F.nx - 2 * H, nyi = F.ny - 2 * H;
+  HIPCHK(hipMemcpy2D(m->d_top_flux[q] + (size_t)H * F.nx + H, (size_t)F.nx * sizeof(real), host, (size_t)nxi * sizeof(real),
+                     (size_t)nxi * sizeof(real), nyi, hipMemcpyHostToDevice));
+  m->g.top_flux[q] = m->d_top_flux[q];
+  return GB25_OK;
+}
 gb25_status gb25_compute_tendencies(gb25_model* m) {
   CHECK_MODEL(m);
   gb25_status s = momentum_impl(m);

@@ -386,6 +386,12 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
 #undef WT
 #undef ZF
 #undef DC
+    if (k == g.Nz - 1 && (g.top_flux[0] || g.top_flux[1])) {
+      // compute_hydrostatic_boundary_tendency_contributions!: top flux boundary conditions (wind stress)
+      const int o2 = i2(g, min(i, g.Nx - 1), min(j, g.Ny - 1));
+      if (g.top_flux[0]) gu = gu - g.top_flux[0][o2] * rdz;
+      if (g.top_flux[1] && j > 0) gv = gv - g.top_flux[1][o2] * rdz;
+    }
     if (IMM) {   // faces that touch the solid: no tendency (their velocity is masked and stays zero)
       if (k < KPU) gu = real(0.);
       if (k < KPV) gv = real(0.);
@@ -538,7 +544,13 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
     const real2v fe = v2(__shfl_down(fx.x, 1), __shfl_down(fx.y, 1));
     if (writes) {
       const real rV = razc_j * g.rdzc[k];
-      const real2v G = -(((fe - fx) + (fn - fs) + (ft - fz)) * rV);
+      real2v G = -(((fe - fx) + (fn - fs) + (ft - fz)) * rV);
+      if (k == g.Nz - 1 && (g.top_flux[2] || g.top_flux[3]) && (!IMM || kbt < g.Nz)) {
+        // compute_hydrostatic_boundary_tendency_contributions!: top flux boundary conditions (heat, fresh water)
+        const int o2 = i2(g, i, j);
+        if (g.top_flux[2]) G.x = G.x - g.top_flux[2][o2] * g.rdzc[k];
+        if (g.top_flux[3]) G.y = G.y - g.top_flux[3][o2] * g.rdzc[k];
+      }
       bstore(bGT, vo, cc, G.x);
       bstore(bGS, vo, cc, G.y);
       if (AHEAD) {   // T, S of the NEXT step while T, S (cz[3]) and the new tendency are in registers

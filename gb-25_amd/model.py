@@ -176,6 +176,17 @@ def baroclinic_instability_model(arch, Nx=None, Ny=None, Nz=None, *, dt, halo=(8
     return model
 
 
+def set_top_flux(model, **fluxes):
+    """FluxBoundaryCondition at the top of u, v, T, S (what ClimaOcean's ocean_simulation gives the ocean model and the
+    coupled model fills every step: wind stress, heat and fresh-water flux; src/data_free_ocean_climate_model.jl:26,
+    src/precompile.jl:52-61).  `set_top_flux(model, T=J_T, u=tau_x)`; arrays at the interior points of the field's
+    horizontal location, positive upward; None restores the default no-flux condition."""
+    for name, J in fluxes.items():
+        if name not in ("u", "v", "T", "S"):
+            raise ValueError(f"top flux boundary conditions exist for u, v, T, S, not {name!r}")
+        model.backend.set_top_flux(name, J)
+
+
 def set_baroclinic_instability(model):
     """set_baroclinic_instability!(model) -- src/model_utils.jl:120-127."""
     model.backend.set_baroclinic_instability()

@@ -174,6 +174,12 @@ gb25_status gb25_get_substepping(const gb25_model *m, int32_t *n_effective, doub
 gb25_status gb25_set_bottom_height(gb25_model *m, const double *bottom_height);
 gb25_status gb25_get_bottom_info(const gb25_model *m, int32_t which, int32_t i, int32_t j, double *value);
 
+/* ---- flux boundary conditions: what compute_hydrostatic_boundary_tendency_contributions! (src/precompile.jl:25,52-61)
+ *      adds to the tendencies.  f = GB25_U | GB25_V | GB25_T | GB25_S; `flux` holds J at the interior points of the field's
+ *      horizontal location (gb25_field_dims(f, 0): dims[0] x dims[1] values, i fastest), positive upward; NULL restores
+ *      the default no-flux condition.  The top cell's tendency gets -J/dz inside the tendency kernels. */
+gb25_status gb25_set_top_flux(gb25_model *m, gb25_field f, const void *flux);
+
 /* ---- initial conditions: set_baroclinic_instability!(model) (src/model_utils.jl:99-127) */
 gb25_status gb25_set_baroclinic_instability(gb25_model *m);
 
@@ -190,7 +196,7 @@ gb25_status gb25_compute_auxiliaries(gb25_model *m);     /* src/precompile.jl:36
 gb25_status gb25_fill_diffusivity_halos(gb25_model *m);  /* src/precompile.jl:37,117-119  (closure=nothing: no-op) */
 gb25_status gb25_compute_momentum_tendencies(gb25_model *m); /* src/precompile.jl:63-73  */
 gb25_status gb25_compute_tracer_tendencies(gb25_model *m);   /* src/precompile.jl:75-111 */
-gb25_status gb25_compute_boundary_tendencies(gb25_model *m); /* src/precompile.jl:52-61 (default no-flux: no-op) */
+gb25_status gb25_compute_boundary_tendencies(gb25_model *m); /* src/precompile.jl:52-61: applied inside the tendency kernels (gb25_set_top_flux) */
 gb25_status gb25_compute_tendencies(gb25_model *m);      /* src/precompile.jl:38,48-50 compute_tendencies_workload! */
 gb25_status gb25_ab2_step(gb25_model *m, double dt, int euler); /* src/precompile.jl:39,121-123 ab2_step_workload! */
 gb25_status gb25_correct_velocities_and_cache_previous_tendencies(gb25_model *m, double dt); /* src/precompile.jl:41,125-127 */

@@ -84,6 +84,10 @@ typedef struct {
   int *kbot;
   REAL *Hcc, *Hfc, *Hcf;
   int immersed; /* any immersed cell at all */
+  /* FluxBoundaryCondition at the top of u, v, T, S (NULL: the default no-flux): 2-D, laid out like the parent of a 2-D
+   * field of the same horizontal location; J > 0 is a flux OUT of the domain through the surface (Oceananigans'
+   * convention: top flux positive upward) */
+  REAL *top_flux[4];
 } model;
 
 /* ---------------------------------------------------------------- accessors */
@@ -328,6 +332,7 @@ void FN(destroy)(void *h) {
   free(m->phif); free(m->phic); free(m->dxc); free(m->dxf); free(m->azc); free(m->azf);
   free(m->fcor); free(m->zf); free(m->zc); free(m->dzc); free(m->dzf);
   free(m->kbot); free(m->Hcc); free(m->Hfc); free(m->Hcf);
+  for (int q = 0; q < 4; q++) free(m->top_flux[q]);
   free(m);
 }
 REAL *FN(field_ptr)(void *h, int id) { return ((model *)h)->f[id].p; }
@@ -796,9 +801,43 @@ void FN(compute_tracer_tendencies)(void *h) {
   tracer_tendency(m, F_GNT, f_T);
   tracer_tendency(m, F_GNS, f_S);
 }
+/* compute_hydrostatic_boundary_tendency_contributions!(Gn, arch, velocities, tracers, clock, fields, closure, buoyancy)
+ * -- /root/reference/src/precompile.jl:25,52-61: flux boundary conditions enter the tendencies of the cells next to
+ * the boundary; here the top ones (apply_z_top_bc!, restated): G[i,j,Nz] -= J Az / V. */
+void FN(compute_boundary_tendencies)(void *h) {
+  model *m = (model *)h;
+  const int gid[4] = {F_GNU, F_GNV, F_GNT, F_GNS};
+  for (int q = 0; q < 4; q++) {
+    if (!m->top_flux[q]) continue;
+    const fld *F = &m->f[gid[q]];
+    for (int j = 1; j <= m->Ny; j++)
+      for (int i = 1; i <= m->Nx; i++) {
+        if (q == 0 && immersed_peripheral_u(m, i, j, m->Nz)) continue;
+        if (q == 1 && (j == 1 || immersed_peripheral_v(m, i, j, m->Nz))) continue;
+        if (q >= 2 && inactive_cell(m, i, j, m->Nz)) continue;
+        REAL J = m->top_flux[q][((long)i - 1 + HH) + (long)F->sx * ((long)j - 1 + HH)];
+        A3(gid[q], i, j, m->Nz) = A3(gid[q], i, j, m->Nz) - J / DZC(m->Nz);
+      }
+  }
+}
+/* q: 0 u, 1 v, 2 T, 3 S; J: interior values (Nx x Ny (+1 for v), i fastest) or NULL for the default no-flux */
+void FN(set_top_flux)(void *h, int q, const double *J) {
+  model *m = (model *)h;
+  const int gid[4] = {F_GNU, F_GNV, F_GNT, F_GNS};
+  free(m->top_flux[q]);
+  m->top_flux[q] = NULL;
+  if (!J) return;
+  const fld *F = &m->f[gid[q]];
+  m->top_flux[q] = (REAL *)calloc((size_t)F->sx * F->sy, sizeof(REAL));
+  int ny = m->Ny + (q == 1 ? 1 : 0);
+  for (int j = 1; j <= ny; j++)
+    for (int i = 1; i <= m->Nx; i++)
+      m->top_flux[q][((long)i - 1 + HH) + (long)F->sx * ((long)j - 1 + HH)] = (REAL)J[(i - 1) + (long)m->Nx * (j - 1)];
+}
 void FN(compute_tendencies)(void *h) {
   FN(compute_momentum_tendencies)(h);
   FN(compute_tracer_tendencies)(h);
+  FN(compute_boundary_tendencies)(h);
 }
 /* update_state!(model; compute_tendencies=true): phases 1-5 of /root/reference/src/precompile.jl:34-38
  * (mask_immersed and diffusivity halos are no-ops for this configuration). */

@@ -196,7 +196,18 @@ class OracleBackend:
     def fill_diffusivity_halos(self): pass
     def compute_momentum_tendencies(self): self._call("compute_momentum_tendencies")
     def compute_tracer_tendencies(self): self._call("compute_tracer_tendencies")
-    def compute_boundary_tendencies(self): pass
+    def compute_boundary_tendencies(self): self._call("compute_boundary_tendencies")
+
+    def set_top_flux(self, name, J):
+        """FluxBoundaryCondition at the top of u | v | T | S: interior-shaped array (None: back to no-flux)."""
+        f = self._fn("set_top_flux")
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        q = {"u": 0, "v": 1, "T": 2, "S": 3}[name]
+        if J is None:
+            f(self.h, q, None)
+            return
+        a = np.ascontiguousarray(np.asarray(J, dtype=np.float64).reshape(self.field_dims(name, False)[:2]).T)
+        f(self.h, q, a.ctypes.data_as(C.c_void_p))
     def compute_tendencies(self): self._call("compute_tendencies")
     def ab2_step(self, dt, euler=False): self._fn("ab2_step")(self.h, float(dt), int(euler))
     def correct_velocities_and_cache_previous_tendencies(self, dt=0.0): self._call("correct_and_cache")

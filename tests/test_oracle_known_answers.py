@@ -273,3 +273,26 @@ def test_fp32_state_with_fp64_pressure_tracks_fp64_oracle():
     #  ~4e-4 on G.S; the GPU kernels use the factored form and are held to sqrt(eps) on every field)
     assert_states_close(models["f32p64"], models["f64"], tendency_rtol=1e-3,
                         label="fp32 state + fp64 pressure vs fp64, 11 steps")
+
+
+def test_top_flux_boundary_conditions():
+    """compute_hydrostatic_boundary_tendency_contributions! (src/precompile.jl:52-61) with FluxBoundaryConditions at the
+    top: a uniform upward heat flux J cools the top cell at J/dz and nothing else; a wind stress accelerates the top
+    layer; the default (no flux) leaves the tendencies untouched."""
+    m = make_oracle(32, 24, 6, 60.0)
+    Nx, Ny, Nz = m.grid.size
+    dz_top = m.backend.metric("dzc", Nz)
+    gb.update_state(m)
+    assert np.abs(m.timestepper.Gn.T.interior).max() == 0.0
+    JT, taux = 2.5e-4, -1.0e-4                      # K m/s upward (cooling); m2/s2, negative upward = eastward push
+    gb.set_top_flux(m, T=np.full((Nx, Ny), JT), u=np.full((Nx, Ny), taux))
+    gb.update_state(m)
+    GT, Gu = m.timestepper.Gn.T.interior, m.timestepper.Gn.u.interior
+    assert np.allclose(GT[:, :, -1], -JT / dz_top, rtol=1e-14) and np.abs(GT[:, :, :-1]).max() == 0.0
+    assert np.allclose(Gu[:, :, -1], -taux / dz_top, rtol=1e-14) and np.abs(Gu[:, :, :-1]).max() == 0.0
+    assert np.abs(m.timestepper.Gn.S.interior).max() == 0.0
+    gb.first_time_step(m)
+    assert np.allclose(m.tracers.T.interior[:, :, -1], -60.0 * JT / dz_top, rtol=1e-12)      # Euler step from T = 0
+    gb.set_top_flux(m, T=None, u=None)
+    gb.update_state(m)
+    assert np.abs(m.timestepper.Gn.T.interior[:, :, -1] - 0.0).max() < 1e-12    # only advection of the tiny state left
