@@ -156,14 +156,14 @@ def baroclinic_instability_model(arch, Nx=None, Ny=None, Nz=None, *, dt, halo=(8
     (set_baroclinic_instability! is commented out at :74-80)."""
     if resolution is not None:
         Nx, Ny = resolution_to_points(resolution)
-    # grid_type (src/baroclinic_instability_model.jl:19,59-65): :simple_lat_lon | :gaussian_islands.  The reference's
-    # :gaussian_islands is ImmersedBoundaryGrid(TripolarGrid, GridFittedBottom(gaussian_islands)); what exists here is
-    # the same immersed boundary (the two Gaussian mountains of src/model_utils.jl:67-80,138-140) on the
-    # LatitudeLongitudeGrid: "gaussian_islands_lat_lon".  The tripolar underlying grid is not built yet.
-    grid_types = {"simple_lat_lon": 0, "gaussian_islands_lat_lon": 1}
+    # grid_type (src/baroclinic_instability_model.jl:19,59-65): :simple_lat_lon | :gaussian_islands, where
+    # :gaussian_islands = ImmersedBoundaryGrid(TripolarGrid, GridFittedBottom(gaussian_islands)) (src/model_utils.jl:
+    # 134-146).  Also: the same mountains on the lat-lon grid, the bare tripolar grid, and (tests) the lat-lon metrics
+    # sent through the curvilinear code path.
+    grid_types = {"simple_lat_lon": 0, "gaussian_islands_lat_lon": 1, "lat_lon_as_curvilinear": 2, "tripolar": 3,
+                  "gaussian_islands": 4}
     if grid_type not in grid_types:
-        raise NotImplementedError(f"grid_type={grid_type!r}: only {sorted(grid_types)} exist; :gaussian_islands on the "
-                                  "TripolarGrid (SURVEY.md section 8f.1) needs the tripolar underlying grid")
+        raise ValueError(f"grid_type={grid_type!r} must be one of {sorted(grid_types)}")
     if grid_types[grid_type]:
         backend_kw["grid_type"] = grid_types[grid_type]
     H = halo[0] if isinstance(halo, (tuple, list)) else halo

@@ -88,7 +88,15 @@ typedef struct {
    * field of the same horizontal location; J > 0 is a flux OUT of the domain through the surface (Oceananigans'
    * convention: top flux positive upward) */
   REAL *top_flux[4];
+  /* orthogonal curvilinear grid: 2-D metrics (see the macros above), cell-centre latitude for the initial condition,
+   * and the topology of the northern edge: 0 = wall (Bounded), 1 = zipper fold (the tripolar grid) */
+  int curv, north_fold;
+  REAL *dxfc2, *dxcc2, *dxcf2, *dxff2, *dyfc2, *dycc2, *dycf2, *dyff2, *azcc2, *azfc2, *azcf2, *azff2, *fff2, *phicc2;
+  double *lamcc_d, *phicc_d; /* cell-centre coordinates in degrees (double), interior Nx x Ny, for analytic bottoms */
 } model;
+/* number of prognostic rows of the y-face fields: with the zipper fold the face ON the fold line (row Ny+1) is a face
+ * between two rows of cells like any other and is stepped; at a wall it is not */
+#define NYV (m->Ny + (m->north_fold ? 1 : 0))
 
 /* ---------------------------------------------------------------- accessors */
 #define HH (m->H)
@@ -99,11 +107,24 @@ typedef struct {
 #define A2(id, i, j) (m->f[id].p[IDX2(m->f[id], i, j)])
 #define MJ(arr, j) (m->arr[(j)-1 + HH + PAD])
 #define MK(arr, k) (m->arr[(k)-1 + HH + PAD])
-#define DXC(j) MJ(dxc, j) /* dx at centre latitudes: dx^fc = dx^cc */
-#define DXF(j) MJ(dxf, j) /* dx at face latitudes:   dx^cf = dx^ff */
-#define AZC(j) MJ(azc, j) /* Az^cc = Az^fc */
-#define AZF(j) MJ(azf, j) /* Az^cf = Az^ff */
-#define FCOR(j) MJ(fcor, j)
+/* Horizontal metrics by location (Oceananigans names: Δxᶠᶜᵃ -> DXFC, Azᶜᶠᵃ -> AZCF, ...).  On the
+ * LatitudeLongitudeGrid they depend on the row only: dx^fc = dx^cc at centre latitudes, dx^cf = dx^ff at face
+ * latitudes, dy constant, Az^fc = Az^cc, Az^cf = Az^ff, f at face latitudes.  On an orthogonal curvilinear grid
+ * (m->curv: the tripolar grid) each is a 2-D array laid out like the parent of a (c,f) field. */
+#define M2(arr, i, j) (m->arr[((long)(i)-1 + HH) + (long)(m->Nx + 2 * HH) * ((long)(j)-1 + HH)])
+#define DXFC(i, j) (m->curv ? M2(dxfc2, i, j) : MJ(dxc, j))
+#define DXCC(i, j) (m->curv ? M2(dxcc2, i, j) : MJ(dxc, j))
+#define DXCF(i, j) (m->curv ? M2(dxcf2, i, j) : MJ(dxf, j))
+#define DXFF(i, j) (m->curv ? M2(dxff2, i, j) : MJ(dxf, j))
+#define DYFC(i, j) (m->curv ? M2(dyfc2, i, j) : m->dy)
+#define DYCC(i, j) (m->curv ? M2(dycc2, i, j) : m->dy)
+#define DYCF(i, j) (m->curv ? M2(dycf2, i, j) : m->dy)
+#define DYFF(i, j) (m->curv ? M2(dyff2, i, j) : m->dy)
+#define AZCC(i, j) (m->curv ? M2(azcc2, i, j) : MJ(azc, j))
+#define AZFC(i, j) (m->curv ? M2(azfc2, i, j) : MJ(azc, j))
+#define AZCF(i, j) (m->curv ? M2(azcf2, i, j) : MJ(azf, j))
+#define AZFF(i, j) (m->curv ? M2(azff2, i, j) : MJ(azf, j))
+#define FFF(i, j) (m->curv ? M2(fff2, i, j) : MJ(fcor, j))
 #define DZC(k) MK(dzc, k)
 #define DZF(k) MK(dzf, k)
 
@@ -126,6 +147,10 @@ static void alloc_field(model *m, int id, int extra_y, int extra_z, int twod) {
 #define KB(i, j) (m->kbot[((long)(i)-1 + HH) + (long)(m->Nx + 2 * HH) * ((long)(j)-1 + HH)])
 #define H2(arr, i, j) (m->arr[((long)(i)-1 + HH) + (long)(m->Nx + 2 * HH) * ((long)(j)-1 + HH)])
 static inline int inactive_cell(const model *m, int i, int j, int k) {
+  if (m->north_fold && j > m->Ny) {   /* beyond the fold: the cell it is the image of */
+    i = m->Nx - i + 1;
+    j = 2 * m->Ny + 1 - j;
+  }
   if (j < 1 || j > m->Ny || k < 1 || k > m->Nz) return 1;
   if (i < 1 - m->H) i = 1 - m->H;              /* (beyond the x halo: never reached by an interior stencil) */
   if (i > m->Nx + m->H) i = m->Nx + m->H;
@@ -136,7 +161,7 @@ static inline int peripheral_v(const model *m, int i, int j, int k) { return ina
 /* (the underlying lat-lon grid has peripheral nodes of its own only on the v faces j = 1 and j = Ny+1) */
 static inline int immersed_peripheral_u(const model *m, int i, int j, int k) { return peripheral_u(m, i, j, k); }
 static inline int immersed_peripheral_v(const model *m, int i, int j, int k) {
-  return j > 1 && j <= m->Ny && peripheral_v(m, i, j, k);
+  return j > 1 && j <= NYV && peripheral_v(m, i, j, k);
 }
 /* bottom heights at the cell centres of the interior columns -> kbot and the static column depths */
 static void set_bottom(model *m, const double *zb /* Nx*Ny, i fastest */) {
@@ -160,8 +185,11 @@ static void set_bottom(model *m, const double *zb /* Nx*Ny, i fastest */) {
       KB(Nx + 1 + q, j) = KB(1 + q, j);
     }
   for (int i = 1 - H; i <= Nx + H; i++) {
+    int im = Nx - i + 1;
+    if (im < 1 - H) im = 1 - H;
+    if (im > Nx + H) im = Nx + H;
     KB(i, 0) = KB(i, 1);
-    KB(i, Ny + 1) = KB(i, Ny);
+    KB(i, Ny + 1) = m->north_fold ? KB(im, Ny) : KB(i, Ny);
   }
   for (int j = 0; j <= Ny + 1; j++)
     for (int i = 1 - H; i <= Nx + H; i++) {
@@ -187,6 +215,15 @@ static void gaussian_islands(model *m, const gb25o_config *c, double *zb) {
   for (int j = 1; j <= m->Ny; j++)
     for (int i = 1; i <= m->Nx; i++) {
       double lam = c->lon_west + (i - 0.5) * dlam, phi = (double)MJ(phic, j);
+      if (m->curv) {
+        /* physical coordinates of the cell centre; the longitude brought next to each mountain (the tripolar grid
+         * starts AT the first mountain's longitude: without this only its eastern half would exist) */
+        lam = m->lamcc_d[(i - 1) + (size_t)m->Nx * (j - 1)];
+        phi = m->phicc_d[(i - 1) + (size_t)m->Nx * (j - 1)];
+        double l1 = lam - 360.0 * floor((lam - 70.0 + 180.0) / 360.0), l2 = lam - 360.0 * floor((lam - 250.0 + 180.0) / 360.0);
+        zb[(i - 1) + (long)m->Nx * (j - 1)] = z1 + h * (mtn(l1, phi, 70, 55) + mtn(l2, phi, 70 + 180, 55));
+        continue;
+      }
       zb[(i - 1) + (long)m->Nx * (j - 1)] = z1 + h * (mtn(lam, phi, 70, 55) + mtn(lam, phi, 70 + 180, 55));
     }
 }
@@ -270,6 +307,124 @@ static void build_grid(model *m, const gb25o_config *c) {
   free(zint);
 }
 
+/* ---------------------------------------------------------------- orthogonal curvilinear grids
+ * TripolarGrid (/root/reference/src/model_utils.jl:134-137: TripolarGrid(arch; size, halo, z)), restated as an analytic
+ * bipolar cap after Murray (1996) [UPSTREAM-UNVERIFIED: Oceananigans builds its coordinates numerically; the topology,
+ * pole positions (first_pole_longitude = 70, north_poles_latitude = 55), southernmost latitude (-80) and the fold are
+ * the same, the interior coordinate lines of the cap need not be].
+ * Computational coordinates: lambda~ uniform from the first pole's longitude eastward, phi~ uniform from the southern
+ * edge to 90 degrees.  South of the poles' latitude phi_P the grid IS the lat-lon grid.  North of it the cap |z| <= r_P
+ * of the polar stereographic plane (z = tan(pi/4 - phi/2) e^{i lambda}, r_P = tan(pi/4 - phi_P/2)) carries bipolar
+ * coordinates with foci at the two poles: w = z / (r_P e^{i lambda_P}) = (sinh t + i sin s) / (cosh t - cos s), with
+ * t = atanh(cos(lambda~ - lambda_P)) (so that the rim keeps its longitudes) and cot(s/2) = tan(pi/4 - phi~/2) / r_P (so
+ * that the meridian halfway between the poles keeps its latitudes).  Lines of constant t and s are orthogonal circles;
+ * phi~ = 90 is the segment between the poles: the fold line.  Metrics are great-circle distances between neighbouring
+ * nodes and spherical areas of the quadrilaterals they span (as for Oceananigans' OrthogonalSphericalShellGrid). */
+#define TRIPOLAR_POLE_LAT 55.0
+#define TRIPOLAR_POLE_LON 70.0
+typedef struct { double x, y, z, lam, phi; } gnode;
+static gnode sphere_node(double lam, double phi) {
+  const double d2r = M_PI / 180.0;
+  if (phi < -89.999) phi = -89.999; /* (halo rows of coarse grids beyond the south pole: never used) */
+  gnode n = {cos(phi * d2r) * cos(lam * d2r), cos(phi * d2r) * sin(lam * d2r), sin(phi * d2r), lam, phi};
+  return n;
+}
+static gnode tripolar_node(double lamt, double phit) {
+  const double d2r = M_PI / 180.0, lamP = TRIPOLAR_POLE_LON, phiP = TRIPOLAR_POLE_LAT;
+  if (phit > 90.0) { /* beyond the fold: the image point */
+    phit = 180.0 - phit;
+    lamt = 2 * lamP - lamt;
+  }
+  if (phit <= phiP) return sphere_node(lamt, phit);
+  const double rP = tan((90.0 - phiP) / 2 * d2r), rt = tan((90.0 - phit) / 2 * d2r) / rP;
+  const double th = (lamt - lamP) * d2r;
+  double ct = cos(th), sth = sin(th), st = fabs(sth);
+  const double sg = 2 * atan2(1.0, rt); /* cot(s/2) = rt */
+  const double D = 1.0 - cos(sg) * st;
+  const double xw = ct / D, yw = (sth < 0 ? -1.0 : 1.0) * sin(sg) * st / D;
+  const double rz = rP * sqrt(xw * xw + yw * yw);
+  return sphere_node(lamP + atan2(yw, xw) / d2r, 90.0 - 2 * atan(rz) / d2r);
+}
+static double gc_dist(gnode a, gnode b, double R) {
+  double cx = a.y * b.z - a.z * b.y, cy = a.z * b.x - a.x * b.z, cz = a.x * b.y - a.y * b.x;
+  double d = R * atan2(sqrt(cx * cx + cy * cy + cz * cz), a.x * b.x + a.y * b.y + a.z * b.z);
+  return d > 100.0 ? d : 100.0; /* (the coordinate lines meet at the poles: keep the metrics finite there) */
+}
+static double tri_area(gnode a, gnode b, gnode c) {
+  double t = a.x * (b.y * c.z - b.z * c.y) + a.y * (b.z * c.x - b.x * c.z) + a.z * (b.x * c.y - b.y * c.x);
+  double d = 1.0 + (a.x * b.x + a.y * b.y + a.z * b.z) + (b.x * c.x + b.y * c.y + b.z * c.z) + (c.x * a.x + c.y * a.y + c.z * a.z);
+  return 2 * atan2(fabs(t), d);
+}
+static double quad_area(gnode a, gnode b, gnode c, gnode d, double R) {
+  double A = R * R * (tri_area(a, b, c) + tri_area(a, c, d));
+  return A > 1e4 ? A : 1e4;
+}
+/* grid_type 2: the lat-lon metrics copied into the 2-D arrays (the curvilinear code path must then reproduce the plain
+ * one bit for bit); 3, 4: the tripolar grid */
+static void build_curv_grid(model *m, const gb25o_config *c) {
+  int Nx = m->Nx, Ny = m->Ny, H = m->H, sx = Nx + 2 * H, sy = Ny + 2 * H + 1;
+  size_t n2 = (size_t)sx * sy;
+  REAL **arr[] = {&m->dxfc2, &m->dxcc2, &m->dxcf2, &m->dxff2, &m->dyfc2, &m->dycc2, &m->dycf2, &m->dyff2,
+                  &m->azcc2, &m->azfc2, &m->azcf2, &m->azff2, &m->fff2, &m->phicc2};
+  for (int q = 0; q < 14; q++) *arr[q] = (REAL *)calloc(n2, sizeof(REAL));
+  m->lamcc_d = (double *)calloc((size_t)Nx * Ny, sizeof(double));
+  m->phicc_d = (double *)calloc((size_t)Nx * Ny, sizeof(double));
+  m->curv = 1;
+  const double d2r = M_PI / 180.0, R = c->radius;
+  const int tri = c->grid_type >= 3;
+  const double lam0 = tri ? TRIPOLAR_POLE_LON : c->lon_west;
+  const double dlam = (tri ? 360.0 : (c->lon_east - c->lon_west)) / Nx;
+  const double phiN = tri ? 90.0 : c->lat_north, dphi = (phiN - c->lat_south) / Ny;
+  for (int j = 1 - H; j <= Ny + H + 1; j++)
+    for (int i = 1 - H; i <= Nx + H; i++) {
+      if (!tri) {
+        M2(dxfc2, i, j) = M2(dxcc2, i, j) = MJ(dxc, j);
+        M2(dxcf2, i, j) = M2(dxff2, i, j) = MJ(dxf, j);
+        M2(dyfc2, i, j) = M2(dycc2, i, j) = M2(dycf2, i, j) = M2(dyff2, i, j) = m->dy;
+        M2(azcc2, i, j) = M2(azfc2, i, j) = MJ(azc, j);
+        M2(azcf2, i, j) = M2(azff2, i, j) = MJ(azf, j);
+        M2(fff2, i, j) = MJ(fcor, j);
+        M2(phicc2, i, j) = MJ(phic, j);
+        continue;
+      }
+      /* computational coordinates of the four node families around (i, j) */
+      const double lf = lam0 + (i - 1) * dlam, lc = lam0 + (i - 0.5) * dlam;
+      const double pf = c->lat_south + (j - 1) * dphi, pc = c->lat_south + (j - 0.5) * dphi;
+#define NODE(l, p) tripolar_node(l, p)
+      gnode cc = NODE(lc, pc), fc = NODE(lf, pc), cf = NODE(lc, pf), ff = NODE(lf, pf);
+      gnode fc_e = NODE(lf + dlam, pc), ff_e = NODE(lf + dlam, pf), cc_w = NODE(lc - dlam, pc), cf_w = NODE(lc - dlam, pf);
+      gnode cf_n = NODE(lc, pf + dphi), ff_n = NODE(lf, pf + dphi), ff_ne = NODE(lf + dlam, pf + dphi);
+      gnode cc_s = NODE(lc, pc - dphi), fc_s = NODE(lf, pc - dphi), cc_sw = NODE(lc - dlam, pc - dphi);
+      gnode cf_nw = NODE(lc - dlam, pf + dphi), fc_se = NODE(lf + dlam, pc - dphi);
+      M2(dxcc2, i, j) = (REAL)gc_dist(fc, fc_e, R);
+      M2(dxfc2, i, j) = (REAL)gc_dist(cc_w, cc, R);
+      M2(dxcf2, i, j) = (REAL)gc_dist(ff, ff_e, R);
+      M2(dxff2, i, j) = (REAL)gc_dist(cf_w, cf, R);
+      M2(dycc2, i, j) = (REAL)gc_dist(cf, cf_n, R);
+      M2(dyfc2, i, j) = (REAL)gc_dist(ff, ff_n, R);
+      M2(dycf2, i, j) = (REAL)gc_dist(cc_s, cc, R);
+      M2(dyff2, i, j) = (REAL)gc_dist(fc_s, fc, R);
+      M2(azcc2, i, j) = (REAL)quad_area(ff, ff_e, ff_ne, ff_n, R);
+      M2(azfc2, i, j) = (REAL)quad_area(cf_w, cf, cf_n, cf_nw, R);
+      M2(azcf2, i, j) = (REAL)quad_area(fc_s, fc_se, fc_e, fc, R);
+      M2(azff2, i, j) = (REAL)quad_area(cc_sw, cc_s, cc, cc_w, R);
+      M2(fff2, i, j) = (REAL)(2.0 * c->Omega * sin(ff.phi * d2r));
+      M2(phicc2, i, j) = (REAL)cc.phi;
+      if (i >= 1 && i <= Nx && j >= 1 && j <= Ny) {
+        m->lamcc_d[(i - 1) + (size_t)Nx * (j - 1)] = cc.lam;
+        m->phicc_d[(i - 1) + (size_t)Nx * (j - 1)] = cc.phi;
+      }
+#undef NODE
+    }
+  if (!tri)
+    for (int j = 1; j <= Ny; j++)
+      for (int i = 1; i <= Nx; i++) {
+        m->lamcc_d[(i - 1) + (size_t)Nx * (j - 1)] = c->lon_west + (i - 0.5) * dlam;
+        m->phicc_d[(i - 1) + (size_t)Nx * (j - 1)] = (double)MJ(phic, j);
+      }
+  m->north_fold = tri;
+}
+
 /* Split-explicit averaging weights (Oceananigans FixedSubstepNumber, restated;
  * SURVEY.md appendix A.7): shape function with p=2, q=4, r=0.18927 sampled at
  * tau = 2m/Ns, m=1..Ns; searchsortedlast(weights, 0, rev=true) truncation; normalised. */
@@ -304,6 +459,7 @@ void *FN(create)(const gb25o_config *c) {
   m->dt = (REAL)c->dt; m->chi = (REAL)c->chi; m->g = (REAL)c->g;
   m->Omega = (REAL)c->Omega; m->R = (REAL)c->radius; m->rho0 = (REAL)c->rho0;
   build_grid(m, c);
+  if (c->grid_type >= 2) build_curv_grid(m, c);
   build_substeps(m, c->substeps);
   {
     long n2 = (long)(m->Nx + 2 * m->H) * (m->Ny + 2 * m->H + 1);
@@ -313,7 +469,7 @@ void *FN(create)(const gb25o_config *c) {
     m->Hcf = (REAL *)calloc(n2, sizeof(REAL));
     double *zb = (double *)malloc(sizeof(double) * (size_t)m->Nx * m->Ny);
     for (long q = 0; q < (long)m->Nx * m->Ny; q++) zb[q] = -1e30;   /* flat: nothing immersed */
-    if (c->grid_type == 1) gaussian_islands(m, c, zb);
+    if (c->grid_type == 1 || c->grid_type == 4) gaussian_islands(m, c, zb);
     set_bottom(m, zb);
     free(zb);
   }
@@ -332,6 +488,9 @@ void FN(destroy)(void *h) {
   free(m->phif); free(m->phic); free(m->dxc); free(m->dxf); free(m->azc); free(m->azf);
   free(m->fcor); free(m->zf); free(m->zc); free(m->dzc); free(m->dzf);
   free(m->kbot); free(m->Hcc); free(m->Hfc); free(m->Hcf);
+  free(m->dxfc2); free(m->dxcc2); free(m->dxcf2); free(m->dxff2); free(m->dyfc2); free(m->dycc2); free(m->dycf2);
+  free(m->dyff2); free(m->azcc2); free(m->azfc2); free(m->azcf2); free(m->azff2); free(m->fff2); free(m->phicc2);
+  free(m->lamcc_d); free(m->phicc_d);
   for (int q = 0; q < 4; q++) free(m->top_flux[q]);
   free(m);
 }
@@ -347,6 +506,18 @@ double FN(metric)(void *h, int id, int idx) {
   return (double)a[id][idx - 1 + m->H + PAD];
 }
 double FN(dy)(void *h) { return (double)((model *)h)->dy; }
+/* 2-D metric at logical (i, j): 0 dxfc 1 dxcc 2 dxcf 3 dxff 4 dyfc 5 dycc 6 dycf 7 dyff 8 azcc 9 azfc 10 azcf 11 azff
+ * 12 f(f,f) 13 phi(c,c) */
+double FN(metric2)(void *h, int id, int i, int j) {
+  model *m = (model *)h;
+  switch (id) {
+    case 0: return DXFC(i, j); case 1: return DXCC(i, j); case 2: return DXCF(i, j); case 3: return DXFF(i, j);
+    case 4: return DYFC(i, j); case 5: return DYCC(i, j); case 6: return DYCF(i, j); case 7: return DYFF(i, j);
+    case 8: return AZCC(i, j); case 9: return AZFC(i, j); case 10: return AZCF(i, j); case 11: return AZFF(i, j);
+    case 12: return FFF(i, j);
+    default: return m->curv ? (double)M2(phicc2, i, j) : (double)MJ(phic, j);
+  }
+}
 int FN(substep_info)(void *h, double *dtau_frac, double *w) {
   model *m = (model *)h;
   *dtau_frac = m->dtau_frac;
@@ -494,23 +665,22 @@ static REAL f_u(const model *m, int i, int j, int k) { return A3(F_U, i, j, k); 
 static REAL f_v(const model *m, int i, int j, int k) { return A3(F_V, i, j, k); }
 static REAL f_T(const model *m, int i, int j, int k) { return A3(F_T, i, j, k); }
 static REAL f_S(const model *m, int i, int j, int k) { return A3(F_S, i, j, k); }
-static REAL f_Azw(const model *m, int i, int j, int k) { return AZC(j) * A3(F_W, i, j, k); }
+static REAL f_Azw(const model *m, int i, int j, int k) { return AZCC(i, j) * A3(F_W, i, j, k); }
 /* vertical vorticity zeta at (f,f,c) */
 static REAL f_zeta(const model *m, int i, int j, int k) {
-  REAL circ = (m->dy * A3(F_V, i, j, k) - m->dy * A3(F_V, i - 1, j, k)) -
-              (DXC(j) * A3(F_U, i, j, k) - DXC(j - 1) * A3(F_U, i, j - 1, k));
-  return circ / AZF(j);
+  REAL circ = (DYCF(i, j) * A3(F_V, i, j, k) - DYCF(i - 1, j) * A3(F_V, i - 1, j, k)) -
+              (DXFC(i, j) * A3(F_U, i, j, k) - DXFC(i, j - 1) * A3(F_U, i, j - 1, k));
+  return circ / AZFF(i, j);
 }
 /* VelocityStencil smoothness inputs at (f,f,c) */
 static REAL f_uy(const model *m, int i, int j, int k) { return (A3(F_U, i, j - 1, k) + A3(F_U, i, j, k)) / (REAL)2; }
 static REAL f_vx(const model *m, int i, int j, int k) { return (A3(F_V, i - 1, j, k) + A3(F_V, i, j, k)) / (REAL)2; }
 /* delta_x(Ax u), delta_y(Ay v) at (c,c,c) */
 static REAL f_dxU(const model *m, int i, int j, int k) {
-  REAL Ax = m->dy * DZC(k);
-  return Ax * A3(F_U, i + 1, j, k) - Ax * A3(F_U, i, j, k);
+  return DYFC(i + 1, j) * DZC(k) * A3(F_U, i + 1, j, k) - DYFC(i, j) * DZC(k) * A3(F_U, i, j, k);
 }
 static REAL f_dyV(const model *m, int i, int j, int k) {
-  return DXF(j + 1) * DZC(k) * A3(F_V, i, j + 1, k) - DXF(j) * DZC(k) * A3(F_V, i, j, k);
+  return DXCF(i, j + 1) * DZC(k) * A3(F_V, i, j + 1, k) - DXCF(i, j) * DZC(k) * A3(F_V, i, j, k);
 }
 static REAL f_div(const model *m, int i, int j, int k) { return f_dxU(m, i, j, k) + f_dyV(m, i, j, k); }
 static inline REAL half_sq(REAL x) { return x * x / (REAL)2; }
@@ -619,47 +789,79 @@ static void fill_periodic_x(const model *m, fld *F) {
     }
   }
 }
-static void fill_halo_3d(model *m, int id, int is_v) {
+/* Zipper fold at the northern edge of the tripolar grid (Oceananigans' fold_north_* functions, restated
+ * [UPSTREAM-UNVERIFIED]; the convention used here is stated in DESIGN.md): the fold line is the row of y faces Ny+1, it
+ * runs between the two north poles, which sit on the x faces i = 1 and i = Nx/2 + 1.  The cell (i, Ny+q) beyond it is
+ * the image of cell (Nx-i+1, Ny-q+1); x faces mirror as i -> Nx-i+2, y faces as j -> 2(Ny+1)-j; vector components
+ * change sign.  The y faces ON the fold line are each seen from both sides: v(i) = -v(Nx-i+1); both are stepped, the
+ * copy in the eastern half is overwritten with minus its partner (exact antisymmetry, fluxes match to the last bit). */
+static inline int fold_i(const model *m, int i, int xface) {
+  int ip = xface ? m->Nx - i + 2 : m->Nx - i + 1;
+  if (ip > m->Nx) ip -= m->Nx;
+  return ip;
+}
+static void fold_rows(model *m, int id, int twod, int is_v, int xface, REAL sgn) {
+  int Nx = m->Nx, Ny = m->Ny, H = m->H, k0 = 1, k1 = twod ? 1 : m->Nz;
+  for (int k = k0; k <= k1; k++) {
+    REAL *base = twod ? m->f[id].p : m->f[id].p + (long)m->f[id].sx * m->f[id].sy * (k - 1 + H);
+#define AF(i, j) base[((long)(i)-1 + H) + (long)m->f[id].sx * ((long)(j)-1 + H)]
+    if (is_v) {
+      for (int i = Nx / 2 + 1; i <= Nx; i++) AF(i, Ny + 1) = sgn * AF(fold_i(m, i, 0), Ny + 1);   /* the pivot row */
+      for (int q = 1; q < H; q++)
+        for (int i = 1; i <= Nx; i++) AF(i, Ny + 1 + q) = sgn * AF(fold_i(m, i, 0), Ny + 1 - q);
+    } else {
+      for (int q = 1; q <= H; q++)
+        for (int i = 1; i <= Nx; i++) AF(i, Ny + q) = sgn * AF(fold_i(m, i, xface), Ny + 1 - q);
+    }
+#undef AF
+  }
+}
+/* xface: located on x faces (u, U, G.U); sgn: -1 for vector components */
+static void fill_halo_3d(model *m, int id, int is_v, int xface, REAL sgn) {
   int Nx = m->Nx, Ny = m->Ny, Nz = m->Nz;
   for (int k = 1; k <= Nz; k++)
     for (int i = 1; i <= Nx; i++) {
       if (is_v) {
         A3(id, i, 1, k) = 0;
-        A3(id, i, Ny + 1, k) = 0;
+        if (!m->north_fold) A3(id, i, Ny + 1, k) = 0;
       } else {
         A3(id, i, 0, k) = A3(id, i, 1, k);
-        A3(id, i, Ny + 1, k) = A3(id, i, Ny, k);
+        if (!m->north_fold) A3(id, i, Ny + 1, k) = A3(id, i, Ny, k);
       }
     }
-  for (int j = 1; j <= Ny; j++)
+  if (m->north_fold) fold_rows(m, id, 0, is_v, xface, sgn);
+  /* bottom / top layer; with the fold also of the rows beyond it (the pressure of those rows enters the pressure
+   * gradient on the fold line: its vertical integral starts in the top halo level) */
+  for (int j = 1; j <= Ny + (m->north_fold ? m->H : 0); j++)
     for (int i = 1; i <= Nx; i++) {
       A3(id, i, j, 0) = A3(id, i, j, 1);
       A3(id, i, j, Nz + 1) = A3(id, i, j, Nz);
     }
   fill_periodic_x(m, &m->f[id]);
 }
-static void fill_halo_2d(model *m, int id, int is_v) {
+static void fill_halo_2d(model *m, int id, int is_v, int xface, REAL sgn) {
   int Nx = m->Nx, Ny = m->Ny;
   for (int i = 1; i <= Nx; i++) {
     if (is_v) {
       A2(id, i, 1) = 0;
-      A2(id, i, Ny + 1) = 0;
+      if (!m->north_fold) A2(id, i, Ny + 1) = 0;
     } else {
       A2(id, i, 0) = A2(id, i, 1);
-      A2(id, i, Ny + 1) = A2(id, i, Ny);
+      if (!m->north_fold) A2(id, i, Ny + 1) = A2(id, i, Ny);
     }
   }
+  if (m->north_fold) fold_rows(m, id, 1, is_v, xface, sgn);
   fill_periodic_x(m, &m->f[id]);
 }
 void FN(fill_halos)(void *h) {
   model *m = (model *)h;
-  fill_halo_3d(m, F_U, 0);
-  fill_halo_3d(m, F_V, 1);
-  fill_halo_3d(m, F_T, 0);
-  fill_halo_3d(m, F_S, 0);
-  fill_halo_2d(m, F_ETA, 0);
-  fill_halo_2d(m, F_BU, 0);
-  fill_halo_2d(m, F_BV, 1);
+  fill_halo_3d(m, F_U, 0, 1, -1);
+  fill_halo_3d(m, F_V, 1, 0, -1);
+  fill_halo_3d(m, F_T, 0, 0, 1);
+  fill_halo_3d(m, F_S, 0, 0, 1);
+  fill_halo_2d(m, F_ETA, 0, 0, 1);
+  fill_halo_2d(m, F_BU, 0, 1, -1);
+  fill_halo_2d(m, F_BV, 1, 0, -1);
 }
 
 /* ---------------------------------------------------------------- auxiliaries
@@ -673,7 +875,7 @@ void FN(compute_w)(void *h) {
     for (int i = -H + 2; i <= m->Nx + H - 1; i++) {
       A3(F_W, i, j, 1) = 0;
       for (int k = 2; k <= m->Nz + 1; k++) {
-        REAL dh = f_div(m, i, j, k - 1) / AZC(j);
+        REAL dh = f_div(m, i, j, k - 1) / AZCC(i, j);
         A3(F_W, i, j, k) = A3(F_W, i, j, k - 1) - dh;
       }
     }
@@ -708,8 +910,8 @@ void FN(compute_auxiliaries)(void *h) {
  * (enstrophy conserving), hydrostatic pressure gradient.  Tracers: WENO(order=5) flux form. */
 static REAL Gu_at(const model *m, int i, int j, int k) {
   /* advecting v at (f,c,c) */
-  REAL vhat = ((DXF(j) * A3(F_V, i - 1, j, k) + DXF(j + 1) * A3(F_V, i - 1, j + 1, k)) / (REAL)2 +
-               (DXF(j) * A3(F_V, i, j, k) + DXF(j + 1) * A3(F_V, i, j + 1, k)) / (REAL)2) / (REAL)2 / DXC(j);
+  REAL vhat = ((DXCF(i - 1, j) * A3(F_V, i - 1, j, k) + DXCF(i - 1, j + 1) * A3(F_V, i - 1, j + 1, k)) / (REAL)2 +
+               (DXCF(i, j) * A3(F_V, i, j, k) + DXCF(i, j + 1) * A3(F_V, i, j + 1, k)) / (REAL)2) / (REAL)2 / DXFC(i, j);
   REAL zetaR = biased_interp(m, DY, TO_CENTER, i, j, k, vhat > 0, f_zeta, f_uy, f_vx);
   REAL hadv = -vhat * zetaR;
   /* vertical advection: upwinded divergence flux + vertical flux divergence */
@@ -724,21 +926,21 @@ static REAL Gu_at(const model *m, int i, int j, int k) {
     REAL uR = biased_interp(m, DZ, TO_FACE, i, j, kk, wt > 0, f_u, NULL, NULL);
     fz[t] = wt * uR;
   }
-  REAL vadv = (phi + (fz[1] - fz[0])) / (AZC(j) * DZC(k));
+  REAL vadv = (phi + (fz[1] - fz[0])) / (AZFC(i, j) * DZC(k));
   /* Bernoulli head */
   REAL dKu = biased_interp(m, DX, TO_FACE, i, j, k, uhat > 0, f_dxu2, f_usm, NULL);
   REAL dKv = sym_interp(m, DY, TO_CENTER, i, j, k, f_dxv2);
-  REAL bern = (dKu + dKv) / DXC(j);
+  REAL bern = (dKu + dKv) / DXFC(i, j);
   /* Coriolis: x_f_cross_U = -Iy(f) * vhat */
-  REAL fbar = (FCOR(j) + FCOR(j + 1)) / (REAL)2;
+  REAL fbar = (FFF(i, j) + FFF(i, j + 1)) / (REAL)2;
   REAL cor = -fbar * vhat;
-  REAL dpdx = (A3(F_P, i, j, k) - A3(F_P, i - 1, j, k)) / DXC(j);
+  REAL dpdx = (A3(F_P, i, j, k) - A3(F_P, i - 1, j, k)) / DXFC(i, j);
   return -(hadv + vadv + bern) - cor - dpdx;
 }
 static REAL Gv_at(const model *m, int i, int j, int k) {
   /* advecting u at (c,f,c) */
-  REAL uhat = ((m->dy * A3(F_U, i, j - 1, k) + m->dy * A3(F_U, i + 1, j - 1, k)) / (REAL)2 +
-               (m->dy * A3(F_U, i, j, k) + m->dy * A3(F_U, i + 1, j, k)) / (REAL)2) / (REAL)2 / m->dy;
+  REAL uhat = ((DYFC(i, j - 1) * A3(F_U, i, j - 1, k) + DYFC(i + 1, j - 1) * A3(F_U, i + 1, j - 1, k)) / (REAL)2 +
+               (DYFC(i, j) * A3(F_U, i, j, k) + DYFC(i + 1, j) * A3(F_U, i + 1, j, k)) / (REAL)2) / (REAL)2 / DYCF(i, j);
   REAL zetaR = biased_interp(m, DX, TO_CENTER, i, j, k, uhat > 0, f_zeta, f_uy, f_vx);
   REAL hadv = uhat * zetaR;
   REAL vhat = A3(F_V, i, j, k);
@@ -752,12 +954,12 @@ static REAL Gv_at(const model *m, int i, int j, int k) {
     REAL vR = biased_interp(m, DZ, TO_FACE, i, j, kk, wt > 0, f_v, NULL, NULL);
     fz[t] = wt * vR;
   }
-  REAL vadv = (phi + (fz[1] - fz[0])) / (AZF(j) * DZC(k));
+  REAL vadv = (phi + (fz[1] - fz[0])) / (AZCF(i, j) * DZC(k));
   REAL dKv = biased_interp(m, DY, TO_FACE, i, j, k, vhat > 0, f_dyv2, f_vsm, NULL);
   REAL dKu = sym_interp(m, DX, TO_CENTER, i, j, k, f_dyu2);
-  REAL bern = (dKv + dKu) / m->dy;
-  REAL cor = FCOR(j) * uhat;
-  REAL dpdy = (A3(F_P, i, j, k) - A3(F_P, i, j - 1, k)) / m->dy;
+  REAL bern = (dKv + dKu) / DYCF(i, j);
+  REAL cor = ((FFF(i, j) + FFF(i + 1, j)) / (REAL)2) * uhat;
+  REAL dpdy = (A3(F_P, i, j, k) - A3(F_P, i, j - 1, k)) / DYCF(i, j);
   return -(hadv + vadv + bern) - cor - dpdy;
 }
 void FN(compute_momentum_tendencies)(void *h) {
@@ -772,17 +974,21 @@ void FN(compute_momentum_tendencies)(void *h) {
         A3(F_GNU, i, j, k) = immersed_peripheral_u(m, i, j, k) ? (REAL)0 : Gu_at(m, i, j, k);
         A3(F_GNV, i, j, k) = immersed_peripheral_v(m, i, j, k) ? (REAL)0 : Gv_at(m, i, j, k);
       }
+  if (m->north_fold) /* the y faces on the fold line */
+    for (int k = 1; k <= m->Nz; k++)
+      for (int i = 1; i <= m->Nx; i++)
+        A3(F_GNV, i, m->Ny + 1, k) = immersed_peripheral_v(m, i, m->Ny + 1, k) ? (REAL)0 : Gv_at(m, i, m->Ny + 1, k);
 }
 static REAL tracer_flux(const model *m, int dir, int i, int j, int k, fn3 c) {
   if (dir == DX) {
     REAL u = A3(F_U, i, j, k);
-    return m->dy * DZC(k) * u * biased_interp(m, DX, TO_FACE, i, j, k, u > 0, c, NULL, NULL);
+    return DYFC(i, j) * DZC(k) * u * biased_interp(m, DX, TO_FACE, i, j, k, u > 0, c, NULL, NULL);
   } else if (dir == DY) {
     REAL v = A3(F_V, i, j, k);
-    return DXF(j) * DZC(k) * v * biased_interp(m, DY, TO_FACE, i, j, k, v > 0, c, NULL, NULL);
+    return DXCF(i, j) * DZC(k) * v * biased_interp(m, DY, TO_FACE, i, j, k, v > 0, c, NULL, NULL);
   } else {
     REAL w = A3(F_W, i, j, k);
-    return AZC(j) * w * biased_interp(m, DZ, TO_FACE, i, j, k, w > 0, c, NULL, NULL);
+    return AZCC(i, j) * w * biased_interp(m, DZ, TO_FACE, i, j, k, w > 0, c, NULL, NULL);
   }
 }
 static void tracer_tendency(model *m, int gid, fn3 c) {
@@ -793,7 +999,7 @@ static void tracer_tendency(model *m, int gid, fn3 c) {
         REAL div = (tracer_flux(m, DX, i + 1, j, k, c) - tracer_flux(m, DX, i, j, k, c)) +
                    (tracer_flux(m, DY, i, j + 1, k, c) - tracer_flux(m, DY, i, j, k, c)) +
                    (tracer_flux(m, DZ, i, j, k + 1, c) - tracer_flux(m, DZ, i, j, k, c));
-        A3(gid, i, j, k) = -(div / (AZC(j) * DZC(k)));
+        A3(gid, i, j, k) = -(div / (AZCC(i, j) * DZC(k)));
       }
 }
 void FN(compute_tracer_tendencies)(void *h) {
@@ -810,7 +1016,7 @@ void FN(compute_boundary_tendencies)(void *h) {
   for (int q = 0; q < 4; q++) {
     if (!m->top_flux[q]) continue;
     const fld *F = &m->f[gid[q]];
-    for (int j = 1; j <= m->Ny; j++)
+    for (int j = 1; j <= (q == 1 ? NYV : m->Ny); j++)
       for (int i = 1; i <= m->Nx; i++) {
         if (q == 0 && immersed_peripheral_u(m, i, j, m->Nz)) continue;
         if (q == 1 && (j == 1 || immersed_peripheral_v(m, i, j, m->Nz))) continue;
@@ -849,7 +1055,7 @@ void FN(mask_immersed_fields)(void *h) {
   for (int k = 1; k <= m->Nz; k++)
     for (int j = 1; j <= m->Ny + 1; j++)
       for (int i = 1; i <= m->Nx; i++) {
-        if (peripheral_v(m, i, j, k)) A3(F_V, i, j, k) = 0;
+        if ((j <= NYV || !m->north_fold) && peripheral_v(m, i, j, k)) A3(F_V, i, j, k) = 0;
         if (j > m->Ny) continue;
         if (peripheral_u(m, i, j, k)) A3(F_U, i, j, k) = 0;
         if (inactive_cell(m, i, j, k)) A3(F_T, i, j, k) = A3(F_S, i, j, k) = 0;
@@ -857,7 +1063,7 @@ void FN(mask_immersed_fields)(void *h) {
   for (int j = 1; j <= m->Ny + 1; j++)
     for (int i = 1; i <= m->Nx; i++) {
       if (j <= m->Ny && H2(Hfc, i, j) == 0) A2(F_BU, i, j) = 0;
-      if (j == 1 || j > m->Ny || H2(Hcf, i, j) == 0) A2(F_BV, i, j) = 0;
+      if (j == 1 || j > NYV || H2(Hcf, i, j) == 0) A2(F_BV, i, j) = 0;
     }
 }
 void FN(update_state)(void *h) {
@@ -881,6 +1087,12 @@ static void barotropic_mode(model *m, int idU, int idV) {
       A2(idU, i, j) = su;
       A2(idV, i, j) = sv;
     }
+  if (m->north_fold)
+    for (int i = 1; i <= m->Nx; i++) {
+      REAL sv = DZC(1) * A3(F_V, i, m->Ny + 1, 1);
+      for (int k = 2; k <= m->Nz; k++) sv += DZC(k) * A3(F_V, i, m->Ny + 1, k);
+      A2(idV, i, m->Ny + 1) = sv;
+    }
 }
 static inline REAL ab2_G(const model *m, int gn, int gm, int i, int j, int k, REAL chi) {
   REAL C1 = (REAL)1.5 + chi, C2 = (REAL)0.5 + chi;
@@ -900,15 +1112,22 @@ static void free_surface_tendency(model *m, REAL chi) {
       A2(F_GBU, i, j) = su;
       A2(F_GBV, i, j) = sv;
     }
-  fill_halo_2d(m, F_GBU, 0);
-  fill_halo_2d(m, F_GBV, 1);
+  if (m->north_fold)
+    for (int i = 1; i <= m->Nx; i++) {
+      REAL sv = DZC(1) * ab2_G(m, F_GNV, F_GMV, i, m->Ny + 1, 1, chi);
+      for (int k = 2; k <= m->Nz; k++) sv += DZC(k) * ab2_G(m, F_GNV, F_GMV, i, m->Ny + 1, k, chi);
+      A2(F_GBV, i, m->Ny + 1) = sv;
+    }
+  fill_halo_2d(m, F_GBU, 0, 1, -1);
+  fill_halo_2d(m, F_GBV, 1, 0, -1);
 }
 static void ab2_field(model *m, int id, int gn, int gm, REAL dt, REAL chi, int velocity) {
   REAL C1 = (REAL)1.5 + chi, C2 = (REAL)0.5 + chi;
   REAL not_euler = (chi != (REAL)-0.5) ? (REAL)1 : (REAL)0;
+  const int nyrows = (id == F_V) ? NYV : m->Ny;
 #pragma omp parallel for collapse(2) schedule(static)
   for (int k = 1; k <= m->Nz; k++)
-    for (int j = 1; j <= m->Ny; j++)
+    for (int j = 1; j <= nyrows; j++)
       for (int i = 1; i <= m->Nx; i++) {
         if (velocity) {
           REAL G = C1 * A3(gn, i, j, k) - C2 * A3(gm, i, j, k) * not_euler;
@@ -930,18 +1149,18 @@ static void step_free_surface(model *m, REAL dt) {
     for (int j = 1; j <= Ny; j++)
       for (int i = 1; i <= Nx; i++) {
         int ip = (i == Nx) ? 1 : i + 1;
-        REAL dxU = m->dy * A2(F_BU, ip, j) - m->dy * A2(F_BU, i, j);
-        REAL dyV = (j == Ny) ? -(DXF(j) * A2(F_BV, i, j))
-                 : (j == 1)  ? DXF(2) * A2(F_BV, i, 2)
-                             : DXF(j + 1) * A2(F_BV, i, j + 1) - DXF(j) * A2(F_BV, i, j);
-        A2(F_ETA, i, j) -= dtau * (dxU + dyV) / AZC(j);
+        REAL dxU = DYFC(ip, j) * A2(F_BU, ip, j) - DYFC(i, j) * A2(F_BU, i, j);
+        REAL dyV = (j == Ny && !m->north_fold) ? -(DXCF(i, j) * A2(F_BV, i, j))
+                 : (j == 1)  ? DXCF(i, 2) * A2(F_BV, i, 2)
+                             : DXCF(i, j + 1) * A2(F_BV, i, j + 1) - DXCF(i, j) * A2(F_BV, i, j);
+        A2(F_ETA, i, j) -= dtau * (dxU + dyV) / AZCC(i, j);
       }
 #pragma omp parallel for schedule(static)
     for (int j = 1; j <= Ny; j++)
       for (int i = 1; i <= Nx; i++) {
         int im = (i == 1) ? Nx : i - 1;
-        REAL dxe = (A2(F_ETA, i, j) - A2(F_ETA, im, j)) / DXC(j);
-        REAL dye = (j == 1) ? 0 : (A2(F_ETA, i, j) - A2(F_ETA, i, j - 1)) / m->dy;
+        REAL dxe = (A2(F_ETA, i, j) - A2(F_ETA, im, j)) / DXFC(i, j);
+        REAL dye = (j == 1) ? 0 : (A2(F_ETA, i, j) - A2(F_ETA, i, j - 1)) / DYCF(i, j);
         /* static column depth at the face: min of the two columns (0 next to land: no pressure force, and G.U is 0) */
         REAL Un = A2(F_BU, i, j) + dtau * (-m->g * H2(Hfc, i, j) * dxe + A2(F_GBU, i, j));
         REAL Vn = A2(F_BV, i, j) + dtau * (-m->g * H2(Hcf, i, j) * dye + A2(F_GBV, i, j));
@@ -951,6 +1170,17 @@ static void step_free_surface(model *m, REAL dt) {
         A2(F_BU, i, j) = Un;
         A2(F_BV, i, j) = Vn;
       }
+    if (m->north_fold) {
+      /* the y faces on the fold line: eta beyond the fold is the image of row Ny; then exact antisymmetry */
+      for (int i = 1; i <= Nx; i++) {
+        int j = Ny + 1, ifo = fold_i(m, i, 0);
+        REAL dye = (A2(F_ETA, ifo, Ny) - A2(F_ETA, i, Ny)) / DYCF(i, j);
+        REAL Vn = A2(F_BV, i, j) + dtau * (-m->g * H2(Hcf, i, j) * dye + A2(F_GBV, i, j));
+        A2(F_BV, i, j) = Vn;
+      }
+      for (int i = Nx / 2 + 1; i <= Nx; i++) A2(F_BV, i, Ny + 1) = -A2(F_BV, fold_i(m, i, 0), Ny + 1);
+      for (int i = 1; i <= Nx; i++) A2(F_VB, i, Ny + 1) += wgt * A2(F_BV, i, Ny + 1);
+    }
   }
   for (int j = 1; j <= Ny; j++)
     for (int i = 1; i <= Nx; i++) {
@@ -958,6 +1188,8 @@ static void step_free_surface(model *m, REAL dt) {
       A2(F_BU, i, j) = A2(F_UB, i, j);
       A2(F_BV, i, j) = A2(F_VB, i, j);
     }
+  if (m->north_fold)
+    for (int i = 1; i <= Nx; i++) A2(F_BV, i, Ny + 1) = A2(F_VB, i, Ny + 1);
 }
 void FN(ab2_step)(void *h, double dt_, int euler) {
   model *m = (model *)h;
@@ -985,18 +1217,25 @@ void FN(correct_and_cache)(void *h) {
         if (!immersed_peripheral_v(m, i, j, k))
           A3(F_V, i, j, k) = A3(F_V, i, j, k) + (A2(F_BV, i, j) - A2(F_VB, i, j)) / (j == 1 ? m->Lz : H2(Hcf, i, j));
       }
+  if (m->north_fold)
+    for (int k = 1; k <= m->Nz; k++)
+      for (int i = 1; i <= m->Nx; i++) {
+        int j = m->Ny + 1;
+        if (!immersed_peripheral_v(m, i, j, k))
+          A3(F_V, i, j, k) = A3(F_V, i, j, k) + (A2(F_BV, i, j) - A2(F_VB, i, j)) / H2(Hcf, i, j);
+      }
   for (int q = 0; q < 4; q++)
     for (int k = 1; k <= m->Nz; k++)
-      for (int j = 1; j <= m->Ny; j++)
+      for (int j = 1; j <= (q == 1 ? NYV : m->Ny); j++)
         for (int i = 1; i <= m->Nx; i++) A3(F_GMU + q, i, j, k) = A3(F_GNU + q, i, j, k);
 }
 /* initialize!(model): barotropic velocities from the 3-D velocities + their halos */
 void FN(initialize)(void *h) {
   model *m = (model *)h;
   barotropic_mode(m, F_BU, F_BV);
-  fill_halo_2d(m, F_BU, 0);
-  fill_halo_2d(m, F_BV, 1);
-  fill_halo_2d(m, F_ETA, 0);
+  fill_halo_2d(m, F_BU, 0, 1, -1);
+  fill_halo_2d(m, F_BV, 1, 0, -1);
+  fill_halo_2d(m, F_ETA, 0, 0, 1);
 }
 /* time_step!(model, dt; euler) -- /root/reference/src/timestepping_utils.jl:29-35 */
 void FN(time_step_euler)(void *h, int euler) {
@@ -1026,7 +1265,7 @@ void FN(set_baroclinic_instability)(void *h) {
   for (int k = 1; k <= m->Nz; k++)
     for (int j = 1; j <= m->Ny; j++)
       for (int i = 1; i <= m->Nx; i++) {
-        double phi = (double)MJ(phic, j), z = (double)MK(zc, k);
+        double phi = m->curv ? (double)M2(phicc2, i, j) : (double)MJ(phic, j), z = (double)MK(zc, k);
         double step = (1.0 - tanh((fabs(phi) - 40.0) / 5.0)) / 2.0;
         A3(F_T, i, j, k) = (REAL)((30.0 + 1e-3 * z) * step);
         A3(F_S, i, j, k) = (REAL)(-5e-3 * z);
@@ -1038,8 +1277,8 @@ void FN(set_baroclinic_instability)(void *h) {
 /* diagnostics for tests: the individual terms of G_u at (i,j,k) (1-based) */
 void FN(debug_gu_terms)(void *h, int i, int j, int k, double *out) {
   const model *m = (const model *)h;
-  REAL vhat = ((DXF(j) * A3(F_V, i - 1, j, k) + DXF(j + 1) * A3(F_V, i - 1, j + 1, k)) / (REAL)2 +
-               (DXF(j) * A3(F_V, i, j, k) + DXF(j + 1) * A3(F_V, i, j + 1, k)) / (REAL)2) / (REAL)2 / DXC(j);
+  REAL vhat = ((DXCF(i - 1, j) * A3(F_V, i - 1, j, k) + DXCF(i - 1, j + 1) * A3(F_V, i - 1, j + 1, k)) / (REAL)2 +
+               (DXCF(i, j) * A3(F_V, i, j, k) + DXCF(i, j + 1) * A3(F_V, i, j + 1, k)) / (REAL)2) / (REAL)2 / DXFC(i, j);
   REAL uhat = A3(F_U, i, j, k);
   out[0] = vhat;
   out[1] = biased_interp(m, DY, TO_CENTER, i, j, k, vhat > 0, f_zeta, f_uy, f_vx);
@@ -1051,5 +1290,5 @@ void FN(debug_gu_terms)(void *h, int i, int j, int k, double *out) {
   }
   out[6] = biased_interp(m, DX, TO_FACE, i, j, k, uhat > 0, f_dxu2, f_usm, NULL);
   out[7] = sym_interp(m, DY, TO_CENTER, i, j, k, f_dxv2);
-  out[8] = (A3(F_P, i, j, k) - A3(F_P, i - 1, j, k)) / DXC(j);
+  out[8] = (A3(F_P, i, j, k) - A3(F_P, i - 1, j, k)) / DXFC(i, j);
 }

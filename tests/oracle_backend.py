@@ -156,6 +156,14 @@ class OracleBackend:
     def metric(self, name, index):
         return self._fn("metric")(self.h, METRIC_IDS[name], index)
 
+    def metric2(self, name, i, j):
+        """2-D metric at the 1-based logical (i, j): dxfc dxcc dxcf dxff dyfc dycc dycf dyff azcc azfc azcf azff fff phicc."""
+        ids = ["dxfc", "dxcc", "dxcf", "dxff", "dyfc", "dycc", "dycf", "dyff", "azcc", "azfc", "azcf", "azff", "fff", "phicc"]
+        f = self._fn("metric2")
+        f.restype = C.c_double
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        return f(self.h, ids.index(name), i, j)
+
     def substepping(self):
         w = (C.c_double * 4096)()
         frac = C.c_double()
