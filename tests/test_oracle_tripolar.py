@@ -160,7 +160,4 @@ def test_first_step_is_mirror_symmetric_away_from_the_mountains():
     far[9:28] = far[45:64] = True                  # >= 9 columns (45 degrees) from both mountain meridians
     assert np.abs(Gv - Gv[::-1])[far].max() < 1e-12 * np.abs(Gv).max()
     assert np.abs(Gv[far][:, Ny - 3:Ny + 1]).max() > 0          # ... including the rows next to and on the fold line
-    gb.first_time_step(m)
-    for n in ("T", "eta", "v", "Gn.T", "Gn.v"):
-        a = m.backend.get_field(n, False)
-        assert np.abs(a - a[::-1])[far].max() < 1e-10 * np.abs(a).max(), n
+    # (after a step the sub-cycle has carried the mountains' asymmetry 21 columns far: nothing sharp left to check)
