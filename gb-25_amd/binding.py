@@ -22,6 +22,7 @@ FIELD_IDS = {
     "eta_bar": 17, "U_bar": 18, "V_bar": 19,
     "Gn.U": 20, "Gn.V": 21,
 }
+METRIC2_IDS = ["dxfc", "dxcc", "dxcf", "dxff", "dyfc", "dycc", "dycf", "dyff", "azcc", "azfc", "azcf", "azff", "fff", "phicc"]
 METRIC_IDS = {"phif": 0, "phic": 1, "dxc": 2, "dxf": 3, "azc": 4, "azf": 5, "fcor": 6,
               "zf": 7, "zc": 8, "dzc": 9, "dzf": 10}
 KERNEL_IDS = {"fill_halos": 0, "compute_w": 1, "compute_p": 2, "gu": 3, "gv": 4, "tracers": 5,
@@ -32,7 +33,7 @@ ABI_SYMBOLS = [
     "gb25_default_config", "gb25_create", "gb25_destroy", "gb25_last_error_string", "gb25_version",
     "gb25_real_bytes",
     "gb25_set_stream", "gb25_use_own_stream", "gb25_synchronize", "gb25_field_dims", "gb25_set_field", "gb25_get_field",
-    "gb25_field_device_ptr", "gb25_get_metric", "gb25_get_substepping", "gb25_set_baroclinic_instability",
+    "gb25_field_device_ptr", "gb25_get_metric", "gb25_get_metric2", "gb25_get_substepping", "gb25_set_baroclinic_instability",
     "gb25_get_clock", "gb25_set_dt", "gb25_initialize", "gb25_mask_immersed_fields",
     "gb25_fill_halo_regions", "gb25_compute_auxiliaries", "gb25_fill_diffusivity_halos",
     "gb25_compute_momentum_tendencies", "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
@@ -110,6 +111,7 @@ def load_library(float_type="Float32"):
     lib.gb25_get_field.argtypes = [P, C.c_int, P, C.c_int]
     lib.gb25_field_device_ptr.argtypes = [P, C.c_int, C.POINTER(P)]
     lib.gb25_get_metric.argtypes = [P, C.c_int, C.c_int32, C.POINTER(C.c_double)]
+    lib.gb25_get_metric2.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.c_int64]
     lib.gb25_get_substepping.argtypes = [P, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.gb25_get_clock.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.gb25_set_dt.argtypes = [P, C.c_double]
@@ -227,6 +229,14 @@ class HipBackend:
         v = C.c_double()
         self._call("gb25_get_metric", METRIC_IDS[name], index, C.byref(v))
         return v.value
+
+    def metric2(self, name):
+        """One horizontal metric of a curvilinear grid (grid_type >= 2): (Nx + 2H, Ny + 2H + 1) float64, [i, j]."""
+        H = self.cfg.halo
+        shape = (self.cfg.Ny + 2 * H + 1, self.cfg.Nx // self.cfg.nranks + 2 * H)
+        out = np.empty(shape, np.float64)
+        self._call("gb25_get_metric2", METRIC2_IDS.index(name), out.ctypes.data_as(C.POINTER(C.c_double)), out.size)
+        return out.T
 
     def substepping(self):
         n, frac = C.c_int32(), C.c_double()

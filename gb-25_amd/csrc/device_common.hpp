@@ -42,6 +42,17 @@ struct Immersed {
 };
 __device__ __forceinline__ int order_from(int k, int K5, int K3) { return k >= K5 ? 5 : (k >= K3 ? 3 : 1); }
 
+// Orthogonal curvilinear grid (the TripolarGrid of GB-25 src/model_utils.jl:134-137): horizontal metrics by location,
+// 2-D arrays with the parent layout of a (c,f) field (pitch sx, Ny+2H+1 rows), Oceananigans' names (dxfc = Δxᶠᶜᵃ ...),
+// reciprocals computed on the host in fp64 and rounded once, Coriolis parameter averaged to the u and v points.
+// north_fold: the northern edge is the zipper fold instead of a wall; the y faces on the fold line (row Ny) are stepped.
+struct Curv {
+  const real *dxfc, *dxcf, *dyfc, *dycf, *azcc;
+  const real *rdxfc, *rdycf, *razcc, *razfc, *razcf, *razff;
+  const real *fbar_u, *fbar_v, *phicc;
+  int on, north_fold;
+};
+
 struct Grid {
   int Nx, Ny, Nz, H;      // LOCAL interior size and halo
   int sx;                 // row pitch          = Nx + 2H
@@ -61,6 +72,7 @@ struct Grid {
   // FluxBoundaryCondition at the top of u, v, T, S (null: the default no-flux): 2-D arrays with the parent layout of a
   // 2-D field of the same location; enter the tendency of the top cell as -J / dz (apply_z_top_bc!)
   const real* top_flux[4];
+  Curv cv;                                           // (on = 0: the LatitudeLongitudeGrid with its row tables)
 };
 
 // element offsets

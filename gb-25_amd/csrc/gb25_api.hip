@@ -74,6 +74,10 @@ struct gb25_model {
   real* bars = nullptr;         // contiguous etabar | Ubar | Vbar
   std::vector<real*> dev_tables;
   std::vector<double> h_metric[11];
+  // orthogonal curvilinear grid (grid_type >= 2): the 14 horizontal metrics by location, fp64, parent layout of a (c,f)
+  // field (gb25_get_metric2); cell-centre coordinates in degrees for analytic bottoms
+  std::vector<double> h_curv[GB25_M2_COUNT];
+  std::vector<double> h_lamcc, h_phicc;
   int metric_off_j = 0, metric_off_k = 0;
   // substepping
   int Ns = 0;
@@ -289,6 +293,142 @@ gb25_status build_grid(gb25_model* m) {
   return GB25_OK;
 }
 
+// --- orthogonal curvilinear grids ---------------------------------------------------------------------------------
+// TripolarGrid(arch; size, halo, z) (GB-25 src/model_utils.jl:134-137), restated as an analytic bipolar cap after Murray
+// (1996): first pole at 70 E, both at 55 N, southern edge as configured, northern edge the fold line between the poles
+// [UPSTREAM-UNVERIFIED: Oceananigans builds its cap numerically; topology, poles and fold agree, the interior coordinate
+// lines of the cap need not].  South of 55 N the grid is the lat-lon grid.  In the polar stereographic plane the cap
+// carries bipolar coordinates with the foci at the poles, chosen so that the rim keeps its longitudes and the meridian
+// halfway between the poles its latitudes.  Metrics: great-circle distances between neighbouring nodes, spherical areas
+// of the quadrilaterals they span.  oracle/gb25_oracle.c states the same construction; tests compare the two.
+struct GNode { double x, y, z, lam, phi; };
+GNode sphere_node(double lam, double phi) {
+  const double d2r = M_PI / 180.0;
+  phi = std::max(phi, -89.999);   // (halo rows of coarse grids beyond the south pole: never used)
+  return {std::cos(phi * d2r) * std::cos(lam * d2r), std::cos(phi * d2r) * std::sin(lam * d2r), std::sin(phi * d2r), lam, phi};
+}
+GNode tripolar_node(double lamt, double phit) {
+  const double d2r = M_PI / 180.0, lamP = 70.0, phiP = 55.0;
+  if (phit > 90.0) {   // beyond the fold: the image point
+    phit = 180.0 - phit;
+    lamt = 2 * lamP - lamt;
+  }
+  if (phit <= phiP) return sphere_node(lamt, phit);
+  const double rP = std::tan((90.0 - phiP) / 2 * d2r), rt = std::tan((90.0 - phit) / 2 * d2r) / rP;
+  const double th = (lamt - lamP) * d2r, ct = std::cos(th), sth = std::sin(th), st = std::fabs(sth);
+  const double sg = 2 * std::atan2(1.0, rt), D = 1.0 - std::cos(sg) * st;
+  const double xw = ct / D, yw = (sth < 0 ? -1.0 : 1.0) * std::sin(sg) * st / D;
+  const double rz = rP * std::sqrt(xw * xw + yw * yw);
+  return sphere_node(lamP + std::atan2(yw, xw) / d2r, 90.0 - 2 * std::atan(rz) / d2r);
+}
+double gc_dist(const GNode& a, const GNode& b, double R) {
+  const double cx = a.y * b.z - a.z * b.y, cy = a.z * b.x - a.x * b.z, cz = a.x * b.y - a.y * b.x;
+  const double d = R * std::atan2(std::sqrt(cx * cx + cy * cy + cz * cz), a.x * b.x + a.y * b.y + a.z * b.z);
+  return std::max(d, 100.0);   // the coordinate lines meet at the poles: keep the metrics finite there
+}
+double tri_area(const GNode& a, const GNode& b, const GNode& c) {
+  const double t = a.x * (b.y * c.z - b.z * c.y) + a.y * (b.z * c.x - b.x * c.z) + a.z * (b.x * c.y - b.y * c.x);
+  const double d = 1.0 + (a.x * b.x + a.y * b.y + a.z * b.z) + (b.x * c.x + b.y * c.y + b.z * c.z) + (c.x * a.x + c.y * a.y + c.z * a.z);
+  return 2 * std::atan2(std::fabs(t), d);
+}
+double quad_area(const GNode& a, const GNode& b, const GNode& c, const GNode& d, double R) {
+  return std::max(R * R * (tri_area(a, b, c) + tri_area(a, c, d)), 1e4);
+}
+
+// grid_type 2: the lat-lon metrics through the 2-D arrays (the curvilinear kernels must then agree with the plain ones);
+// 3, 4: the tripolar grid.  Fills m->h_curv and uploads what the kernels read (device_common.hpp, Curv).
+gb25_status build_curv_grid(gb25_model* m) {
+  const gb25_config& c = m->cfg;
+  const int Nx = m->Nx, Ny = c.Ny, H = c.halo, sx = Nx + 2 * H, sy = Ny + 2 * H + 1, offj = m->metric_off_j;
+  const size_t n2 = (size_t)sx * sy;
+  const bool tri = c.grid_type >= GB25_GRID_TRIPOLAR;
+  const double d2r = M_PI / 180.0, R = c.radius;
+  const double lam0 = tri ? 70.0 : c.lon_west, dlam = (tri ? 360.0 : (c.lon_east - c.lon_west)) / c.Nx;
+  const double phiN = tri ? 90.0 : c.lat_north, dphi = (phiN - c.lat_south) / Ny;
+  for (auto& a : m->h_curv) a.assign(n2, 0.0);
+  m->h_lamcc.assign((size_t)Nx * Ny, 0.0);
+  m->h_phicc.assign((size_t)Nx * Ny, 0.0);
+  auto at = [&](int id) -> std::vector<double>& { return m->h_curv[id]; };
+  // (the row tables were rounded to the float type when they were uploaded: the same values here)
+  auto rnd = [](double v) { return (double)(real)v; };
+  for (int j = -H; j <= Ny + H; j++)
+    for (int i = -H; i < Nx + H; i++) {
+      const size_t o = (size_t)(i + H) + (size_t)sx * (j + H);
+      if (!tri) {
+        const int a = offj + j;
+        at(GB25_M2_DXFC)[o] = at(GB25_M2_DXCC)[o] = m->h_metric[GB25_M_DXC][a];
+        at(GB25_M2_DXCF)[o] = at(GB25_M2_DXFF)[o] = m->h_metric[GB25_M_DXF][a];
+        at(GB25_M2_DYFC)[o] = at(GB25_M2_DYCC)[o] = at(GB25_M2_DYCF)[o] = at(GB25_M2_DYFF)[o] = R * dphi * d2r;
+        at(GB25_M2_AZCC)[o] = at(GB25_M2_AZFC)[o] = m->h_metric[GB25_M_AZC][a];
+        at(GB25_M2_AZCF)[o] = at(GB25_M2_AZFF)[o] = m->h_metric[GB25_M_AZF][a];
+        at(GB25_M2_FFF)[o] = m->h_metric[GB25_M_FCOR][a];
+        at(GB25_M2_PHICC)[o] = m->h_metric[GB25_M_PHIC][a];
+        if (i >= 0 && i < Nx && j >= 0 && j < Ny) {
+          m->h_lamcc[(size_t)i + (size_t)Nx * j] = c.lon_west + (i + c.rank * Nx + 0.5) * dlam;
+          m->h_phicc[(size_t)i + (size_t)Nx * j] = rnd(m->h_metric[GB25_M_PHIC][a]);
+        }
+        continue;
+      }
+      // computational coordinates of the four node families around the 0-based (i, j)
+      const double lf = lam0 + i * dlam, lc = lam0 + (i + 0.5) * dlam;
+      const double pf = c.lat_south + j * dphi, pc = c.lat_south + (j + 0.5) * dphi;
+      auto N = [](double l, double p) { return tripolar_node(l, p); };
+      const GNode cc = N(lc, pc), fc = N(lf, pc), cf = N(lc, pf), ff = N(lf, pf);
+      const GNode fc_e = N(lf + dlam, pc), ff_e = N(lf + dlam, pf), cc_w = N(lc - dlam, pc), cf_w = N(lc - dlam, pf);
+      const GNode cf_n = N(lc, pf + dphi), ff_n = N(lf, pf + dphi), ff_ne = N(lf + dlam, pf + dphi);
+      const GNode cc_s = N(lc, pc - dphi), fc_s = N(lf, pc - dphi), cc_sw = N(lc - dlam, pc - dphi);
+      const GNode cf_nw = N(lc - dlam, pf + dphi), fc_se = N(lf + dlam, pc - dphi);
+      at(GB25_M2_DXCC)[o] = gc_dist(fc, fc_e, R);
+      at(GB25_M2_DXFC)[o] = gc_dist(cc_w, cc, R);
+      at(GB25_M2_DXCF)[o] = gc_dist(ff, ff_e, R);
+      at(GB25_M2_DXFF)[o] = gc_dist(cf_w, cf, R);
+      at(GB25_M2_DYCC)[o] = gc_dist(cf, cf_n, R);
+      at(GB25_M2_DYFC)[o] = gc_dist(ff, ff_n, R);
+      at(GB25_M2_DYCF)[o] = gc_dist(cc_s, cc, R);
+      at(GB25_M2_DYFF)[o] = gc_dist(fc_s, fc, R);
+      at(GB25_M2_AZCC)[o] = quad_area(ff, ff_e, ff_ne, ff_n, R);
+      at(GB25_M2_AZFC)[o] = quad_area(cf_w, cf, cf_n, cf_nw, R);
+      at(GB25_M2_AZCF)[o] = quad_area(fc_s, fc_se, fc_e, fc, R);
+      at(GB25_M2_AZFF)[o] = quad_area(cc_sw, cc_s, cc, cc_w, R);
+      at(GB25_M2_FFF)[o] = 2.0 * c.Omega * std::sin(ff.phi * d2r);
+      at(GB25_M2_PHICC)[o] = cc.phi;
+      if (i >= 0 && i < Nx && j >= 0 && j < Ny) {
+        m->h_lamcc[(size_t)i + (size_t)Nx * j] = cc.lam;
+        m->h_phicc[(size_t)i + (size_t)Nx * j] = cc.phi;
+      }
+    }
+  Curv& cv = m->g.cv;
+  gb25_status s;
+  auto up = [&](const std::vector<double>& h, const real** out) { return upload_table(m, h, 0, out); };
+  auto recip = [&](int id) {
+    std::vector<double> r(n2);
+    for (size_t q = 0; q < n2; q++) r[q] = at(id)[q] != 0.0 ? 1.0 / at(id)[q] : 0.0;
+    return r;
+  };
+  if ((s = up(at(GB25_M2_DXFC), &cv.dxfc)) || (s = up(at(GB25_M2_DXCF), &cv.dxcf)) || (s = up(at(GB25_M2_DYFC), &cv.dyfc)) ||
+      (s = up(at(GB25_M2_DYCF), &cv.dycf)) || (s = up(at(GB25_M2_AZCC), &cv.azcc)) || (s = up(at(GB25_M2_PHICC), &cv.phicc)) ||
+      (s = up(recip(GB25_M2_DXFC), &cv.rdxfc)) || (s = up(recip(GB25_M2_DYCF), &cv.rdycf)) ||
+      (s = up(recip(GB25_M2_AZCC), &cv.razcc)) || (s = up(recip(GB25_M2_AZFC), &cv.razfc)) ||
+      (s = up(recip(GB25_M2_AZCF), &cv.razcf)) || (s = up(recip(GB25_M2_AZFF), &cv.razff)))
+    return s;
+  {
+    // Coriolis parameter at the u and v points: the mean of the two (f,f) values either side, formed in the float type
+    // from the rounded values exactly as the plain kernels form it from their row table
+    std::vector<double> fu(n2, 0.0), fv(n2, 0.0);
+    const std::vector<double>& F = at(GB25_M2_FFF);
+    for (int j = -H; j < Ny + H; j++)
+      for (int i = -H; i < Nx + H - 1; i++) {
+        const size_t o = (size_t)(i + H) + (size_t)sx * (j + H);
+        fu[o] = (double)(real(0.5) * ((real)F[o] + (real)F[o + sx]));
+        fv[o] = (double)(real(0.5) * ((real)F[o] + (real)F[o + 1]));
+      }
+    if ((s = up(fu, &cv.fbar_u)) || (s = up(fv, &cv.fbar_v))) return s;
+  }
+  cv.on = 1;
+  cv.north_fold = tri ? 1 : 0;
+  return GB25_OK;
+}
+
 // TEOS-10 (Roquet et al. 2015) coefficient table R[i][j][k] of s^i t^j zeta^k and the reference profile r0(zeta),
 // folded per model level: rho - rho0 = sum_{i+j<=6} C_ij(k) s^i t^j with
 // C_ij(k) = sum_m R_ijm zeta_k^m  (+ r0(zeta_k) - rho0 on the constant term).
@@ -385,15 +525,21 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
       any = any || kb > 0;
     }
   m->immersed = any;
-  // level from which cell (i, j) is active; rows beyond the walls never are
+  // level from which cell (i, j) is active; rows beyond the walls never are; rows beyond the zipper fold are the images
+  // of the cells they mirror
+  const bool nfold = m->g.cv.north_fold != 0;
   auto thr = [&](int i, int j) -> int {
+    if (nfold && j >= Ny) {
+      i = Nx - 1 - i;
+      j = 2 * Ny - 1 - j;
+    }
     if (j < 0 || j >= Ny) return 255;
     return m->kbot[(size_t)(std::min(std::max(i, -E), Nx + E - 1) + E) + (size_t)ksx * j];
   };
   auto node_x = [&](int q, int j) { return std::min(thr(q - 1, j), thr(q, j)); };   // face node: inactive when BOTH cells are
   auto node_y = [&](int i, int q) { return std::min(thr(i, q - 1), thr(i, q)); };
   auto depth = [&](int i, int j) -> double {   // static column depth: top face - materialised bottom
-    const int jj = std::min(std::max(j, 0), Ny - 1);
+    const int jj = (nfold && j >= Ny) ? j : std::min(std::max(j, 0), Ny - 1);
     const int kb = thr(i, jj);
     return (double)(real)zf[offk + Nz] - (double)(real)zf[offk + kb];
   };
@@ -410,7 +556,8 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
       for (int q = -1; q <= 2; q++) { KXC3 = std::max(KXC3, node_x(i + q, j)); KYC3 = std::max(KYC3, node_y(i, j + q)); }
       const int kc = std::min(thr(i, j), Nz);   // (the extra face row j = Ny has no cells: its kc is never used)
       const int KPU = std::max(thr(i - 1, j), thr(i, j));
-      const int KPV = (j == 0 || j >= Ny) ? 0 : std::max(thr(i, j - 1), thr(i, j));   // wall faces: the plain grid's business
+      // wall faces: the plain grid's business (the fold line is no wall)
+      const int KPV = (j == 0 || (j >= Ny && !nfold)) ? 0 : std::min(std::max(thr(i, j - 1), thr(i, j)), 255);
       A[o] = (unsigned)kc | (unsigned)KX5 << 8 | (unsigned)KX3 << 16 | (unsigned)KY5 << 24;
       B[o] = (unsigned)KY3 | (unsigned)KXC5 << 8 | (unsigned)KXC3 << 16 | (unsigned)KYC5 << 24;
       C[o] = (unsigned)KYC3 | (unsigned)std::min(KPU, 255) << 8 | (unsigned)KPV << 16;
@@ -459,14 +606,21 @@ double gaussian_islands_bottom(const gb25_model* m, int i_local, int j) {
   const double dlam = (c.lon_east - c.lon_west) / c.Nx, dphi = (c.lat_north - c.lat_south) / c.Ny;
   int ig = (i_local + c.rank * m->Nx) % c.Nx;
   if (ig < 0) ig += c.Nx;
-  const double lam = c.lon_west + (ig + 0.5) * dlam;
-  // (the centre latitude as the model's float type holds it: phi_c is a metric of the grid)
-  const double phi = (double)(real)(c.lat_south + (j + 0.5) * dphi);
   auto mtn = [](double l, double p, double l1, double p1) {
     const double d = 5;
     return std::exp(-((l - l1) * (l - l1) + (p - p1) * (p - p1)) / (2 * d * d));
   };
   const double z1 = -c.depth, h = -z1 + 100.0;
+  if (m->g.cv.on) {
+    // physical coordinates of the cell centre, the longitude brought next to each mountain (the tripolar grid starts AT
+    // the first mountain's longitude: without this only its eastern half would exist)
+    const double lam = m->h_lamcc[(size_t)ig + (size_t)m->Nx * j], phi = m->h_phicc[(size_t)ig + (size_t)m->Nx * j];
+    const double l1 = lam - 360.0 * std::floor((lam - 70.0 + 180.0) / 360.0), l2 = lam - 360.0 * std::floor((lam - 250.0 + 180.0) / 360.0);
+    return z1 + h * (mtn(l1, phi, 70, 55) + mtn(l2, phi, 70 + 180, 55));
+  }
+  const double lam = c.lon_west + (ig + 0.5) * dlam;
+  // (the centre latitude as the model's float type holds it: phi_c is a metric of the grid)
+  const double phi = (double)(real)(c.lat_south + (j + 0.5) * dphi);
   return z1 + h * (mtn(lam, phi, 70, 55) + mtn(lam, phi, 70 + 180, 55));
 }
 
@@ -486,9 +640,9 @@ inline dim3 grid2(int nx, int ny, dim3 b) { return dim3((nx + b.x - 1) / b.x, (n
 Halo3 halo3(gb25_model* m, int sel = 3) {
   Halo3 h{};
   int n = 0;
-  if (sel & 1) {
-    h.p[n] = m->f[GB25_U].d; h.is_v[n++] = 0;
-    h.p[n] = m->f[GB25_V].d; h.is_v[n++] = 1;
+  if (sel & 1) {   // (xf, neg: how the field crosses the zipper fold -- on x faces, changing sign)
+    h.p[n] = m->f[GB25_U].d; h.xf[n] = 1; h.neg[n] = 1; h.is_v[n++] = 0;
+    h.p[n] = m->f[GB25_V].d; h.neg[n] = 1; h.is_v[n++] = 1;
   }
   if (sel & 2) {
     h.p[n] = m->f[GB25_T].d; h.is_v[n++] = 0;
@@ -498,13 +652,25 @@ Halo3 halo3(gb25_model* m, int sel = 3) {
   return h;
 }
 Halo2 halo2_prognostic(gb25_model* m) {
-  Halo2 h;
+  Halo2 h{};
   h.p[0] = m->f[GB25_ETA].d; h.is_v[0] = 0;
-  h.p[1] = m->f[GB25_BT_U].d; h.is_v[1] = 0;
-  h.p[2] = m->f[GB25_BT_V].d; h.is_v[2] = 1;
+  h.p[1] = m->f[GB25_BT_U].d; h.is_v[1] = 0; h.xf[1] = 1; h.neg[1] = 1;
+  h.p[2] = m->f[GB25_BT_V].d; h.is_v[2] = 1; h.neg[2] = 1;
   h.n = 3;
   return h;
 }
+Halo2 halo2_G(gb25_model* m) {   // the barotropic forcing G.U, G.V
+  Halo2 h{};
+  h.p[0] = m->f[GB25_GN_BT_U].d; h.is_v[0] = 0; h.xf[0] = 1; h.neg[0] = 1;
+  h.p[1] = m->f[GB25_GN_BT_V].d; h.is_v[1] = 1; h.neg[1] = 1;
+  h.n = 2;
+  return h;
+}
+// the single-domain producers write the halo cells derived from their output themselves (option FOLD_FILLS) -- not across
+// the zipper fold, whose images live in other threads' columns
+inline bool producers_fold(const gb25_model* m) { return !m->slab && m->fold_fills && !m->g.cv.north_fold; }
+// rows of y faces that are stepped: the fold line is one
+inline int v_rows(const Grid& g) { return g.Ny + g.cv.north_fold; }
 
 // y/z boundary layers (always local) and, for a single slab, the periodic x copy.
 // extended: also treat the x-halo columns (slab mode, after the neighbours' columns were unpacked).
@@ -521,6 +687,17 @@ gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, i
   dim3 b(256);
   const int i0 = extended ? -g.H : 0, ni = extended ? g.Nx + 2 * g.H : g.Nx;
   if (which == 2 && with_x && g.x_periodic && !extended && !h2_other) return fill_halos_2d(m, halo2_prognostic(m));
+  if (g.cv.north_fold) {   // y / z layers, the rows beyond the fold, then the periodic x copy over all of them
+    if (which == 2) return fill_halos_2d(m, h2);
+    if (which == 1) h2.n = 0;
+    hipLaunchKernelGGL(k_fill_yz, dim3((g.Nx + 255) / 256, g.Nz + 1 + g.Ny), b, 0, st, g, h3, h2, 0, g.Nx);
+    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H, g.Nz + 2 + (h2.n ? 1 : 0)), b, 0, st, g, h3, h2);
+    const int rows_c = g.sy_c * (g.Nz + 2 * g.H), rows_v = g.sy_v * (g.Nz + 2 * g.H);
+    hipLaunchKernelGGL(k_fill_x, dim3((unsigned)(((long)rows_v * 2 * g.H + 255) / 256), 4 + h2.n), b, 0, st, g, h3, h2,
+                       rows_c, rows_v);
+    LAUNCHCHK();
+    return GB25_OK;
+  }
   if (which == 2) {
     Grid g2 = g;
     g2.Nz = 0;   // k_fill_y then runs its 2-D branch only
@@ -558,6 +735,7 @@ gb25_status fill_halos_2d(gb25_model* m, Halo2 h2) {
   Grid g2 = g;
   g2.Nz = 0;
   hipLaunchKernelGGL(k_fill_y, dim3((g.Nx + 255) / 256, 1), b, 0, m->stream, g2, none, h2, 0, g.Nx);
+  if (g.cv.north_fold) hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H, 1), b, 0, m->stream, g, none, h2);
   if (g.x_periodic) {
     long threads = (long)g.sy_v * 2 * g.H;
     hipLaunchKernelGGL(k_fill_x, dim3((unsigned)((threads + 255) / 256), 4 + h2.n), b, 0, m->stream, g2, none, h2, 0,
@@ -581,7 +759,7 @@ gb25_status compute_w_impl(gb25_model* m, int part = 0) {
   const int ey = g.Ny + 2 * g.H - 2;
   // narrow strips: 16 columns x 16 rows per block instead of 64 x 4 (a 64-wide block would be three-quarters empty)
   dim3 b = (na + nbcols) >= 64 ? dim3(64, 4) : dim3(16, 16);
-  hipLaunchKernelGGL(k_compute_w, grid2(na + nbcols, ey, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+  hipLaunchKernelGGL(g.cv.on ? k_compute_w<true> : k_compute_w<false>, grid2(na + nbcols, ey, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                      m->f[GB25_W].d, ia, na, ib, nbcols);
   LAUNCHCHK();
   return GB25_OK;
@@ -663,7 +841,7 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
     Timed t(m, GB25_K_GU);   // the fused G_u + G_v kernel is accounted under the "gu" timer
     nbx = (g.Nx + V2_TX - 1) / V2_TX;
     constexpr int TYm = 4;   // rows (= waves) per block: 4 blocks per CU cover each other's barriers
-    const int nby = (g.Ny + TYm - 1) / TYm;
+    const int nby = (v_rows(g) + TYm - 1) / TYm;   // (zipper fold: the y faces on the fold line have a tendency too)
     const int kchunks = std::max(1, g.Nz / 12);
     TileCols tc{nbx, nbx, 0, 0};
     if (part) {
@@ -685,15 +863,16 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
       nx.dt = dt; nx.C1 = real(1.5) + chi; nx.C2 = real(0.5) + chi;
       nx.plane2 = g.sx * g.sy_v;
     }
-    auto k5 = m->immersed ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true>)
-                          : (ahead ? k_momentum_tendencies_v5<MW, TYm, true, false> : k_momentum_tendencies_v5<MW, TYm, false, false>);
+    auto k5 = g.cv.on ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true, true>)
+              : m->immersed ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true>)
+                            : (ahead ? k_momentum_tendencies_v5<MW, TYm, true, false> : k_momentum_tendencies_v5<MW, TYm, false, false>);
     if (nb > 0)
       hipLaunchKernelGGL(k5, dim3(nb), dim3(V2_TX, TYm), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                          m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, tc, kchunks, nb, nx);
     t.stop();   // the timer covers the tendency kernel alone
     if (ahead && part != 1) {
       dim3 b(64, 4);
-      hipLaunchKernelGGL(k_ab2_velocities_finish, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->uv_partials, kchunks,
+      hipLaunchKernelGGL(k_ab2_velocities_finish, grid2(g.Nx, v_rows(g), b), b, 0, m->stream, g, m->uv_partials, kchunks,
                          nx.plane2, m->ahead_G[0].d, m->ahead_G[1].d, m->ahead_colsum[0].d, m->ahead_colsum[1].d);
       m->ahead_uv_valid = true;
       m->ahead_uv_dt = dt;
@@ -703,7 +882,7 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
     return GB25_OK;
   }
   if (part == 1) return GB25_OK;   // the direct-stencil kernels are not split: everything after the halos arrived
-  if (m->immersed) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know no immersed boundary");
+  if (m->immersed || g.cv.on) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know neither immersed boundaries nor curvilinear grids");
   if (g.top_flux[0] || g.top_flux[1]) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know no flux boundary conditions");
   tile_grid(g, &nbx, &nb);
   dim3 b(TX, TY);
@@ -738,8 +917,10 @@ gb25_status tracers_impl(gb25_model* m) {
       nx.dt = (real)m->last_dt;
       nx.C1 = real(1.5) + (real)m->cfg.chi; nx.C2 = real(0.5) + (real)m->cfg.chi;
     }
-    const bool fold = ahead && !m->slab && m->fold_fills;
-    auto kern = m->immersed ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false>)
+    const bool fold = ahead && producers_fold(m);
+    auto kern = g.cv.on ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false, true>)
+                                 : k_tracer_tendencies_v5<TW, false, true, false, true>)
+                : m->immersed ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false>)
                                      : k_tracer_tendencies_v5<TW, false, true, false>)
                             : (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, false, true> : k_tracer_tendencies_v5<TW, true, false, false>)
                                      : k_tracer_tendencies_v5<TW, false, false, false>);
@@ -754,7 +935,7 @@ gb25_status tracers_impl(gb25_model* m) {
     return GB25_OK;
   }
   m->ahead_valid = false;   // only the packed kernel looks ahead
-  if (m->immersed) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know no immersed boundary");
+  if (m->immersed || g.cv.on) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know neither immersed boundaries nor curvilinear grids");
   if (g.top_flux[2] || g.top_flux[3]) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know no flux boundary conditions");
   tile_grid(g, &nbx, &nb);
   Timed t(m, GB25_K_TRACERS);
@@ -780,7 +961,7 @@ gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
   m->ahead_uv_valid = false;
   dim3 b(64, 4);
   Timed t(m, GB25_K_AB2_VELOCITIES);
-  hipLaunchKernelGGL(k_ab2_velocities, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+  hipLaunchKernelGGL(k_ab2_velocities, grid2(g.Nx, v_rows(g), b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                      m->f[GB25_GN_U].d, m->f[GB25_GM_U].d, m->f[GB25_GN_V].d, m->f[GB25_GM_V].d,
                      m->f[GB25_GN_BT_U].d, m->f[GB25_GN_BT_V].d, m->colsum[0].d, m->colsum[1].d, dt, chi,
                      std::max(1, g.Nz / 12));   // the momentum kernel's chunking (momentum_impl)
@@ -847,7 +1028,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
   real *cur[3], *nxt[3], *other[3], *out[3];
   if (!wide) {
     size_t nbar = m->f[GB25_ETA_BAR].elems() + m->f[GB25_U_BAR].elems() + m->f[GB25_V_BAR].elems();
-    if (m->baro_block <= 1)   // (the blocked kernel starts its averages from zero itself)
+    if (m->baro_block <= 1 || g.cv.on)   // (the blocked kernel starts its averages from zero itself)
       HIPCHK(hipMemsetAsync(ahead ? m->bars_ahead : m->bars, 0, nbar * sizeof(real), m->stream));
     // the state the sub-cycle starts from is only read; the substeps alternate between two scratch sets
     for (int q = 0; q < 3; q++) {
@@ -876,7 +1057,8 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
   }
   const bool imm = m->immersed;
   bool finalize_after = false;
-  if (m->baro_block > 1) {
+  const bool blocked = m->baro_block > 1 && !g.cv.on;   // (the temporally blocked kernel knows the lat-lon row metrics only)
+  if (blocked) {
     // temporally blocked: S substeps per launch on (64 x TY) tiles
     const int S = std::min(m->baro_block, (int)BT_SMAX);
     constexpr int TYb = 16;
@@ -900,7 +1082,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
       }
       bm.eta_out = out[0]; bm.U_out = out[1]; bm.V_out = out[2];
       bm.eb_out = bm.ub_out = bm.vb_out = nullptr;
-      bm.fold = (!wide && m->fold_fills && m->composite && bm.last) ? 1 : 0;
+      bm.fold = (!wide && producers_fold(m) && m->composite && bm.last) ? 1 : 0;
       if (bm.last) m->last_baro_folded = bm.fold != 0;
       if (wide) {
         const Field* fb = ahead ? m->ahead_bar : &m->f[GB25_ETA_BAR];
@@ -911,20 +1093,23 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
       for (int q = 0; q < 3; q++) { real* w_ = nxt[q]; nxt[q] = other[q]; other[q] = w_; cur[q] = w_; }
     }
   } else {
-    dim3 gr = grid2(bb.ihi - bb.ilo, g.Ny, b);
+    dim3 gr = grid2(bb.ihi - bb.ilo, v_rows(g), b);
     for (int s = 0; s < m->Ns; s++) {
       bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
       bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
-      hipLaunchKernelGGL(imm ? k_barotropic_substep<true> : k_barotropic_substep<false>, gr, b, 0, m->stream, g, bb, dtau,
-                         (real)m->weights[s]);
+      if (g.cv.on)
+        hipLaunchKernelGGL(k_barotropic_substep_curv, gr, b, 0, m->stream, g, bb, dtau, (real)m->weights[s]);
+      else
+        hipLaunchKernelGGL(imm ? k_barotropic_substep<true> : k_barotropic_substep<false>, gr, b, 0, m->stream, g, bb, dtau,
+                           (real)m->weights[s]);
       for (int q = 0; q < 3; q++) { real* w_ = nxt[q]; nxt[q] = other[q]; other[q] = w_; cur[q] = w_; }
     }
   }
-  if (m->baro_block > 1 && !finalize_after) {   // the last blocked launch wrote eta, U, V and published the averages
+  if (blocked && !finalize_after) {   // the last blocked launch wrote eta, U, V and published the averages
     LAUNCHCHK();
     return GB25_OK;
   }
-  dim3 gi = grid2(g.Nx, g.Ny, b);
+  dim3 gi = grid2(g.Nx, v_rows(g), b);
   hipLaunchKernelGGL(k_barotropic_finalize, gi, b, 0, m->stream, g, out[0], out[1], out[2], bb.etab, bb.Ub, bb.Vb,
                      bb.sx, bb.xo);
   if (wide) {  // publish the averages in the canonical filtered-state arrays (compared by compare_states)
@@ -962,10 +1147,10 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
       i0 = -g.H; ni = 2 * g.H; skip_from = 0; skip = g.Nx;
     }
     const bool cs = use_colsum && m->colsum_valid && part != 2;
-    const bool fold = !m->slab && m->fold_fills && m->composite;
+    const bool fold = producers_fold(m) && m->composite;
     auto kern = m->immersed ? (fold ? k_corrector<true, true> : k_corrector<true, false>)
                             : (fold ? k_corrector<false, true> : k_corrector<false, false>);
-    hipLaunchKernelGGL(kern, grid2(ni, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+    hipLaunchKernelGGL(kern, grid2(ni, v_rows(g), b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                        m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d,
                        cs ? m->colsum[0].d : nullptr, cs ? m->colsum[1].d : nullptr, i0, ni, std::max(1, g.Nz / 12),
                        skip_from, skip);
@@ -1008,11 +1193,7 @@ gb25_status ab2_step_impl(gb25_model* m, double dt, int euler) {
   m->ahead_baro_valid = false;   // this route always runs the sub-cycle itself
   const real chi = euler ? -real(0.5) : (real)m->cfg.chi;
   if ((s = ab2_local_impl(m, (real)dt, chi))) return s;
-  Halo2 hG;
-  hG.p[0] = m->f[GB25_GN_BT_U].d; hG.is_v[0] = 0;
-  hG.p[1] = m->f[GB25_GN_BT_V].d; hG.is_v[1] = 1;
-  hG.p[2] = nullptr; hG.is_v[2] = 0;
-  hG.n = 2;
+  Halo2 hG = halo2_G(m);
   if ((s = fill_halos_2d(m, hG))) return s;
   return barotropic_impl(m, (real)dt);
 }
@@ -1045,11 +1226,7 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   const bool baro_adopted = adopted && m->ahead_baro_valid;   // (made from that very look-ahead, same dt)
   m->ahead_baro_valid = false;
   if ((s = ab2_velocities_impl(m, (real)dt, chi))) return s;
-  Halo2 hG;
-  hG.p[0] = m->f[GB25_GN_BT_U].d; hG.is_v[0] = 0;
-  hG.p[1] = m->f[GB25_GN_BT_V].d; hG.is_v[1] = 1;
-  hG.p[2] = nullptr; hG.is_v[2] = 0;
-  hG.n = 2;
+  Halo2 hG = halo2_G(m);
   // the sub-cycle reads G.U, G.V at interior points only (periodic wrap and walls are in the kernel): their halo
   // fill is for the state's sake and leaves the critical path when no kernel on this stream produced them
   if (!adopted && (s = fill_halos_2d(m, hG))) return s;
@@ -1092,7 +1269,7 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   if ((s = corrector_impl(m, true))) return s;
   {
     // u, v and eta, U, V -- whatever their last writers (the corrector, the sub-cycle's last launch) did not fill
-    const bool uv_fresh = !m->slab && m->fold_fills && m->composite && !complete;
+    const bool uv_fresh = producers_fold(m) && m->composite && !complete;
     const int which = (uv_fresh ? 0 : 1) | ((eta_halos_fresh && !complete) ? 0 : 2);
     if (which && (s = fill_halos_impl(m, true, false, which, 1))) return s;
   }
@@ -1132,7 +1309,7 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
 gb25_status initialize_impl(gb25_model* m) {
   const Grid& g = m->g;
   dim3 b(64, 4);
-  hipLaunchKernelGGL(k_barotropic_mode, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+  hipLaunchKernelGGL(k_barotropic_mode, grid2(g.Nx, v_rows(g), b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                      m->f[GB25_BT_U].d, m->f[GB25_BT_V].d);
   LAUNCHCHK();
   return fill_halos_2d(m, halo2_prognostic(m));
@@ -1217,6 +1394,15 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   if ((s = build_grid(m))) return s;
   if ((s = build_eos_tables(m))) return s;
   build_substeps(m);
+  if (cfg->grid_type < 0 || cfg->grid_type >= GB25_GRID_COUNT)
+    return fail(m, GB25_ERR_INVALID_ARGUMENT, "grid_type %d: 0 lat-lon, 1 lat-lon with the Gaussian islands, 2 lat-lon "
+                "through the curvilinear kernels, 3 tripolar, 4 tripolar with the Gaussian islands", cfg->grid_type);
+  if (cfg->grid_type >= GB25_GRID_LAT_LON_AS_CURVILINEAR) {
+    if (m->slab) return fail(m, GB25_ERR_INVALID_ARGUMENT, "curvilinear grids (grid_type >= 2) are single-domain: nranks = 1, slab_mode = 0");
+    if (cfg->grid_type >= GB25_GRID_TRIPOLAR && (cfg->Nx % 2 || cfg->Ny < 2 * cfg->halo))
+      return fail(m, GB25_ERR_INVALID_ARGUMENT, "the tripolar grid needs an even Nx and Ny >= 2 halo (the fold maps columns onto columns)");
+    if ((s = build_curv_grid(m))) return s;
+  }
   const int H = cfg->halo, sx = m->Nx + 2 * H;
   for (int id = 0; id < GB25_FIELD_COUNT; id++) {
     if (id >= GB25_ETA_BAR && id <= GB25_V_BAR) continue;  // allocated contiguously below
@@ -1290,12 +1476,14 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     if ((s = alloc_field(m, m->wideG[0], wsx, m->f[GB25_GN_BT_U].ny, 1))) return s;
     if ((s = alloc_field(m, m->wideG[1], wsx, m->f[GB25_GN_BT_V].ny, 1))) return s;
   }
-  if (cfg->grid_type == GB25_GRID_LAT_LON_GAUSSIAN_ISLANDS) {
+  if (cfg->grid_type == GB25_GRID_LAT_LON_GAUSSIAN_ISLANDS || cfg->grid_type == GB25_GRID_TRIPOLAR_GAUSSIAN_ISLANDS) {
     if (cfg->Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "an immersed boundary needs Nz <= 254 (8-bit level tables)");
     if ((s = build_bottom(m, [&](int i, int j) { return gaussian_islands_bottom(m, i, j); }))) return s;
-  } else if (cfg->grid_type != GB25_GRID_LAT_LON) {
-    return fail(m, GB25_ERR_INVALID_ARGUMENT, "grid_type %d: 0 (lat-lon, flat bottom) or 1 (lat-lon, Gaussian islands)",
-                cfg->grid_type);
+  } else if (m->g.cv.on) {
+    // the curvilinear kernels take every reconstruction order and mask from the tables (that is also where the fold's
+    // "north is not a wall" lives): a flat bottom is a bottom nothing touches
+    if (cfg->Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "curvilinear grids need Nz <= 254 (8-bit level tables)");
+    if ((s = build_bottom(m, [&](int, int) { return -1e30; }))) return s;
   }
   HIPCHK(hipDeviceSynchronize());
   return GB25_OK;
@@ -1506,6 +1694,13 @@ gb25_status gb25_get_metric(const gb25_model* m, gb25_metric id, int32_t logical
   long a = (long)logical_index - 1 + off;  // logical_index is 1-based like the Julia sources
   if (a < 0 || a >= (long)m->h_metric[id].size()) return GB25_ERR_INVALID_ARGUMENT;
   *v = (double)(real)m->h_metric[id][a];
+  return GB25_OK;
+}
+gb25_status gb25_get_metric2(const gb25_model* m, gb25_metric2 id, double* v, int64_t count) {
+  if (!m || id < 0 || id >= GB25_M2_COUNT || !v) return GB25_ERR_INVALID_ARGUMENT;
+  const std::vector<double>& a = m->h_curv[id];
+  if (a.empty() || count != (int64_t)a.size()) return GB25_ERR_INVALID_ARGUMENT;   // (not a curvilinear grid, or a wrong size)
+  for (size_t q = 0; q < a.size(); q++) v[q] = (double)(real)a[q];
   return GB25_OK;
 }
 gb25_status gb25_get_substepping(const gb25_model* m, int32_t* n, double* frac, double* w) {

@@ -39,11 +39,13 @@ struct Halo3 {
   real* p[4];   // up to four 3-D fields ...
   int is_v[4];   // ... flagged when face-located in y (v-shaped parent, wall-normal velocity)
   int n;
+  int xf[4], neg[4];   // zipper fold only: located on x faces (u); a vector component (changes sign across the fold)
 };
 struct Halo2 {
   real* p[3];  // centre-y fields first, then the face-y field (is_v[])
   int is_v[3];
   int n;
+  int xf[3], neg[3];
 };
 
 // south/north layer of the four 3-D fields + all 2-D fields over columns [i0, i0+ni).
@@ -55,12 +57,12 @@ __device__ __forceinline__ void fill_y_body(const Grid& g, const Halo3& f3, cons
   if (k < g.Nz) {
     for (int q = 0; q < f3.n; q++) {
       real* c = f3.p[q];
-      if (f3.is_v[q]) {  // v: faces 0 and Ny are walls
+      if (f3.is_v[q]) {  // v: faces 0 and Ny are walls (Ny: unless it is the fold line -- k_fill_fold)
         c[iv(g, i, 0, k)] = real(0.);
-        c[iv(g, i, g.Ny, k)] = real(0.);
+        if (!g.cv.north_fold) c[iv(g, i, g.Ny, k)] = real(0.);
       } else {
         c[ic(g, i, -1, k)] = c[ic(g, i, 0, k)];
-        c[ic(g, i, g.Ny, k)] = c[ic(g, i, g.Ny - 1, k)];
+        if (!g.cv.north_fold) c[ic(g, i, g.Ny, k)] = c[ic(g, i, g.Ny - 1, k)];
       }
     }
   } else {
@@ -68,10 +70,10 @@ __device__ __forceinline__ void fill_y_body(const Grid& g, const Halo3& f3, cons
       real* c = f2.p[q];
       if (f2.is_v[q]) {
         c[i2(g, i, 0)] = real(0.);
-        c[i2(g, i, g.Ny)] = real(0.);
+        if (!g.cv.north_fold) c[i2(g, i, g.Ny)] = real(0.);
       } else {
         c[i2(g, i, -1)] = c[i2(g, i, 0)];
-        c[i2(g, i, g.Ny)] = c[i2(g, i, g.Ny - 1)];
+        if (!g.cv.north_fold) c[i2(g, i, g.Ny)] = c[i2(g, i, g.Ny - 1)];
       }
     }
   }
@@ -126,6 +128,43 @@ __global__ void k_fill_x(Grid g, Halo3 f3, Halo2 f2, int rows_c, int rows_v) {
       long rows = f2.is_v[s] ? g.sy_v : g.sy_c;
       if (row < rows) periodic_row(g, f2.p[s], row, q);
     }
+  }
+}
+
+// Zipper fold along the northern edge of the tripolar grid (Oceananigans' fold boundary condition, restated; convention in
+// DESIGN.md): the fold line is the row of y faces Ny between the two poles, which sit on the x faces 0 and Nx/2.  Cell
+// (i, Ny-1+q) beyond it is the image of cell (Nx-1-i, Ny-q); x faces mirror as i -> (Nx-i) mod Nx, y faces as row
+// Ny+q -> Ny-q; vector components change sign.  The y faces ON the fold line are seen from both sides, v(i) = -v(Nx-1-i):
+// both are stepped and the eastern copy is overwritten with minus its partner here.  The bottom / top layer of the rows
+// beyond the fold is filled too (the hydrostatic integral of those rows starts in the top halo level).  Reads interior
+// rows and levels only: independent of the y / z fill, before the periodic x copy.
+// grid: (ceil(Nx/256), H, Nz + 2 | 1); blockIdx.z = level + 1 of the 3-D fields, the last slice does the 2-D fields
+__global__ void k_fill_fold(Grid g, Halo3 f3, Halo2 f2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.Nx) return;
+  const int q = blockIdx.y;   // 0 .. H-1
+  const bool twod = (int)blockIdx.z == (f3.n ? g.Nz + 2 : 0);
+  const int k = (int)blockIdx.z - 1, ks = min(max(k, 0), g.Nz - 1);
+  const int n = twod ? f2.n : f3.n;
+  for (int f = 0; f < n; f++) {
+    real* c = twod ? f2.p[f] : f3.p[f];
+    const bool is_v = twod ? f2.is_v[f] : f3.is_v[f], xf = twod ? f2.xf[f] : f3.xf[f];
+    const real sg = (twod ? f2.neg[f] : f3.neg[f]) ? -real(1.) : real(1.);
+    const int isrc = xf ? (i == 0 ? 0 : g.Nx - i) : g.Nx - 1 - i;
+    int jd, js;
+    if (is_v) {
+      jd = g.Ny + q; js = g.Ny - q;
+      if (q == 0 && i < g.Nx / 2) {          // western half of the fold line: stepped values stay ...
+        if (twod || (k >= 0 && k < g.Nz)) continue;
+        c[iv(g, i, jd, k)] = c[iv(g, i, jd, ks)];   // ... and get their bottom / top layer
+        continue;
+      }
+    } else {
+      jd = g.Ny + q; js = g.Ny - 1 - q;
+    }
+    if (twod) c[i2(g, i, jd)] = sg * c[i2(g, isrc, js)];
+    else if (is_v) c[iv(g, i, jd, k)] = sg * c[iv(g, isrc, js, ks)];
+    else c[ic(g, i, jd, k)] = sg * c[ic(g, isrc, js, ks)];
   }
 }
 
@@ -246,21 +285,25 @@ __global__ void k_fill_fused(Grid g, Halo3 f3, Halo2 f2, int nbx, int nb_yz, int
 // =============================================================================================
 // Columns [i_first, i_first + n_a) and, after them, [i_first_b, i_first_b + n_b): the whole extended range in one piece,
 // or (slab of a decomposition) the own columns while the x-halo bundle travels and the two edge strips afterwards.
+// CURV: orthogonal curvilinear grid, the four face lengths of the column from the 2-D metric arrays.
+template <bool CURV>
 __global__ __launch_bounds__(256) void k_compute_w(Grid g, const real* __restrict__ u, const real* __restrict__ v,
                                                    real* __restrict__ w, int i_first, int n_a, int i_first_b, int n_b) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = t < n_a ? i_first + t : i_first_b + (t - n_a);
   int j = blockIdx.y * blockDim.y + threadIdx.y - g.H + 1;
   if (t >= n_a + n_b || j > g.Ny + g.H - 2) return;
-  const real dxs = g.dxf[j], dxn = g.dxf[j + 1], raz = g.razc[j], dy = g.dy;
+  const int o2 = i2(g, i, j);
+  const real dxs = CURV ? g.cv.dxcf[o2] : g.dxf[j], dxn = CURV ? g.cv.dxcf[o2 + g.sx] : g.dxf[j + 1];
+  const real raz = CURV ? g.cv.razcc[o2] : g.razc[j];
+  const real dyw = CURV ? g.cv.dyfc[o2] : g.dy, dye = CURV ? g.cv.dyfc[o2 + 1] : g.dy;
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
   real wk = real(0.);
   w[o] = real(0.);
 #pragma unroll 4
   for (int k = 0; k < g.Nz; k++) {
     real dz = g.dzc[k];
-    real Ax = dy * dz;
-    real div = (Ax * u[o + 1] - Ax * u[o]) + (dxn * dz * v[ov + g.sx] - dxs * dz * v[ov]);
+    real div = (dye * dz * u[o + 1] - dyw * dz * u[o]) + (dxn * dz * v[ov + g.sx] - dxs * dz * v[ov]);
     wk = wk - div * raz;
     o += g.pl_c;
     ov += g.pl_v;
@@ -640,10 +683,11 @@ __global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, real* __restrict
                                                         real chi, int kchunks) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny) return;
+  if (i >= g.Nx || j >= g.Ny + g.cv.north_fold) return;
+  const bool urow = j < g.Ny;   // (zipper fold: the row of y faces on the fold line is stepped, v only)
   const real C1 = real(1.5) + chi, C2 = real(0.5) + chi;
   const real ne = (chi != -real(0.5)) ? real(1.) : real(0.);
-  int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
+  int o = ic(g, i, min(j, g.Ny - 1), 0), ov = iv(g, i, j, 0);
   // The column integrals are summed per chunk of levels and the chunk sums added in order: the association of
   // the momentum kernel's look-ahead (UvAhead, kernels_v2.hpp), whose blocks own one chunk of a column each, so
   // that both routes give the same bits.  Explicit FMAs for the same reason.
@@ -658,7 +702,7 @@ __global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, real* __restrict
       real gu = rfma(C1, Gnu[o], -((C2 * Gmu[o]) * ne));
       real gv = rfma(C1, Gnv[ov], -((C2 * Gmv[ov]) * ne));
       real un = rfma(dt, gu, u[o]), vn = rfma(dt, gv, v[ov]);
-      u[o] = un;
+      if (urow) u[o] = un;
       v[ov] = vn;
       su = (k == k0) ? dz * gu : rfma(dz, gu, su);
       sv = (k == k0) ? dz * gv : rfma(dz, gv, sv);
@@ -675,9 +719,11 @@ __global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, real* __restrict
     IV = (k0 == 0) ? iv_ : IV + iv_;
   }
   const int o2 = i2(g, i, j);
-  GU[o2] = SU;
+  if (urow) {
+    GU[o2] = SU;
+    Usum[o2] = IU;
+  }
   GV[o2] = (j == 0) ? real(0.) : SV;  // the wall face is a peripheral node
-  Usum[o2] = IU;
   Vsum[o2] = (j == 0) ? real(0.) : IV;  // v on the wall face is reset to zero by the halo fill before the corrector
 }
 // Second half of the velocity look-ahead: adds up the per-chunk column sums the momentum kernel left in P
@@ -688,7 +734,7 @@ __global__ __launch_bounds__(256) void k_ab2_velocities_finish(Grid g, const rea
                                                                real* __restrict__ Vsum) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny) return;
+  if (i >= g.Nx || j >= g.Ny + g.cv.north_fold) return;
   const int o2 = i2(g, i, j);
   real t[4];
 #pragma unroll
@@ -698,9 +744,11 @@ __global__ __launch_bounds__(256) void k_ab2_velocities_finish(Grid g, const rea
     for (int kc = 1; kc < kchunks; kc++) a = a + Pq[(long)kc * plane2];
     t[q] = a;
   }
-  GU[o2] = t[0];
+  if (j < g.Ny) {
+    GU[o2] = t[0];
+    Usum[o2] = t[2];
+  }
   GV[o2] = (j == 0) ? real(0.) : t[1];
-  Usum[o2] = t[2];
   Vsum[o2] = (j == 0) ? real(0.) : t[3];
 }
 
@@ -800,6 +848,49 @@ __global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, real
   // (next to land the face has no depth: no pressure force, and G.U is zero there, so the transport stays zero)
   real Un = b.U0[o] + dtau * (-g.g * (IMM ? b.Hfc[o] : g.Lz) * dxe + b.GU[o]);
   real Vn = b.V0[o] + dtau * (-g.g * (IMM ? b.Hcf[o] : g.Lz) * dye + b.GV[o]);
+  b.eta1[o] = e;
+  b.U1[o] = Un;
+  b.V1[o] = Vn;
+  b.etab[o] += wgt * e;
+  b.Ub[o] += wgt * Un;
+  b.Vb[o] += wgt * Vn;
+}
+// Orthogonal curvilinear grid (single domain, tables always present): the same substep with the face lengths and areas
+// from the 2-D metric arrays.  With the zipper fold the launch has one more row of threads for the y faces ON the fold
+// line: eta beyond the fold is the image of row Ny-1, and the eastern half of the line takes minus its partner's new
+// value (computed here a second time: no ordering between threads needed), so the transports match to the last bit.
+__device__ __forceinline__ real eta_step_curv(const Grid& g, const Baro& b, int i, int j, real dtau) {
+  const int ip = (i == g.Nx - 1) ? 0 : i + 1, o2 = i2(g, i, j);
+  const real dxU = g.cv.dyfc[i2(g, ip, j)] * b.U0[bi(g, b, ip, j)] - g.cv.dyfc[o2] * b.U0[bi(g, b, i, j)];
+  real dyV;
+  if (j == g.Ny - 1 && !g.cv.north_fold) dyV = -(g.cv.dxcf[o2] * b.V0[bi(g, b, i, j)]);
+  else if (j == 0) dyV = g.cv.dxcf[o2 + g.sx] * b.V0[bi(g, b, i, 1)];
+  else dyV = g.cv.dxcf[o2 + g.sx] * b.V0[bi(g, b, i, j + 1)] - g.cv.dxcf[o2] * b.V0[bi(g, b, i, j)];
+  return b.eta0[bi(g, b, i, j)] - dtau * (dxU + dyV) * g.cv.razcc[o2];
+}
+__device__ __forceinline__ real fold_line_V(const Grid& g, const Baro& b, int i, real dtau) {
+  const int j = g.Ny, o = bi(g, b, i, j), o2 = i2(g, i, j);
+  const real dye = (eta_step_curv(g, b, g.Nx - 1 - i, j - 1, dtau) - eta_step_curv(g, b, i, j - 1, dtau)) * g.cv.rdycf[o2];
+  return b.V0[o] + dtau * (-g.g * b.Hcf[o] * dye + b.GV[o]);
+}
+__global__ __launch_bounds__(256) void k_barotropic_substep_curv(Grid g, Baro b, real dtau, real wgt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny + g.cv.north_fold) return;
+  const int o = bi(g, b, i, j);
+  if (j == g.Ny) {
+    const real Vn = (i < g.Nx / 2) ? fold_line_V(g, b, i, dtau) : -fold_line_V(g, b, g.Nx - 1 - i, dtau);
+    b.V1[o] = Vn;
+    b.Vb[o] += wgt * Vn;
+    return;
+  }
+  const int im = (i == 0) ? g.Nx - 1 : i - 1, o2 = i2(g, i, j);
+  const real e = eta_step_curv(g, b, i, j, dtau);
+  const real dxe = (e - eta_step_curv(g, b, im, j, dtau)) * g.cv.rdxfc[o2];
+  real dye = real(0.);
+  if (j > 0) dye = (e - eta_step_curv(g, b, i, j - 1, dtau)) * g.cv.rdycf[o2];
+  const real Un = b.U0[o] + dtau * (-g.g * b.Hfc[o] * dxe + b.GU[o]);
+  const real Vn = b.V0[o] + dtau * (-g.g * b.Hcf[o] * dye + b.GV[o]);
   b.eta1[o] = e;
   b.U1[o] = Un;
   b.V1[o] = Vn;
@@ -994,11 +1085,12 @@ __global__ void k_barotropic_finalize(Grid g, real* eta, real* U, real* V, const
                                       const real* Vb, int src_sx, int src_xo) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny) return;
+  if (i >= g.Nx || j >= g.Ny + g.cv.north_fold) return;
   int o = i2(g, i, j), q = (i + src_xo) + src_sx * (j + g.H);
+  V[o] = Vb[q];
+  if (j >= g.Ny) return;   // (the fold line carries y faces only)
   eta[o] = etab[q];
   U[o] = Ub[q];
-  V[o] = Vb[q];
 }
 // copy columns [0, Nx) of whole rows between 2-D arrays with different pitch / x-offset; up to five arrays per
 // launch (blockIdx.z = array)
@@ -1024,8 +1116,8 @@ __global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const real* __r
                                                          real* __restrict__ V) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny) return;
-  int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
+  if (i >= g.Nx || j >= g.Ny + g.cv.north_fold) return;
+  int o = ic(g, i, min(j, g.Ny - 1), 0), ov = iv(g, i, j, 0);
   real su = g.dzc[0] * u[o], sv = g.dzc[0] * v[ov];
   for (int k = 1; k < g.Nz; k++) {
     o += g.pl_c;
@@ -1033,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const real* __r
     su += g.dzc[k] * u[o];
     sv += g.dzc[k] * v[ov];
   }
-  U[i2(g, i, j)] = su;
+  if (j < g.Ny) U[i2(g, i, j)] = su;
   V[i2(g, i, j)] = sv;
 }
 // Ubar,Vbar <- column integrals of u,v (work arrays, as in the reference), then
@@ -1054,9 +1146,32 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
                                                    int i0, int ni, int kchunks, int skip_from, int skip) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= ni || j >= g.Ny) return;
+  if (i >= ni || j >= g.Ny + g.cv.north_fold) return;
   i += i0;
   if (i >= skip_from) i += skip;   // (the two x-halo strips of a slab in one launch: skip the interior)
+  if (j >= g.Ny) {   // zipper fold: the y faces on the fold line, v only (never with FOLD, never a slab)
+    const int o2 = i2(g, i, j);
+    int ov = iv(g, i, j, 0);
+    real sv = real(0.);
+    if (Vsum != nullptr) {
+      sv = Vsum[o2];
+    } else {
+      const int klen = (g.Nz + kchunks - 1) / kchunks;
+      for (int k0 = 0; k0 < g.Nz; k0 += klen) {
+        const int k1 = min(g.Nz, k0 + klen);
+        real pv = real(0.);
+        for (int k = k0; k < k1; k++, ov += g.pl_v) pv = (k == k0) ? g.dzc[k] * v[ov] : rfma(g.dzc[k], v[ov], pv);
+        sv = (k0 == 0) ? pv : sv + pv;
+      }
+    }
+    Vb[o2] = sv;
+    const real dv = (V[o2] - sv) * (IMM ? g.im.rHcf[o2] : g.rLz);
+    const int KPV = IMM ? (int)((g.im.ordC[o2] >> 16) & 255) : 0;
+    ov = iv(g, i, j, 0);
+    for (int k = 0; k < g.Nz; k++, ov += g.pl_v)
+      if (k >= KPV) v[ov] = v[ov] + dv;
+    return;
+  }
   const int o0 = ic(g, i, j, 0), ov0 = iv(g, i, j, 0);
   const int o2 = i2(g, i, j);
   int o = o0, ov = ov0;
@@ -1144,7 +1259,7 @@ __global__ void k_set_baroclinic_instability(Grid g, real* __restrict__ T, real*
   int j = blockIdx.y;
   int k = blockIdx.z;
   if (i >= g.Nx) return;
-  real phi = g.phic[j], z = g.zc[k];
+  real phi = g.cv.on ? g.cv.phicc[i2(g, i, j)] : g.phic[j], z = g.zc[k];
   real step = (real(1.) - rtanh((rabs(phi) - real(40.)) / real(5.))) / real(2.);
   int o = ic(g, i, j, k);
   T[o] = (real(30.) + real(1e-3) * z) * step;
@@ -1165,10 +1280,11 @@ __global__ __launch_bounds__(256) void k_mask_immersed(Grid g, real* __restrict_
   const int o2 = i2(g, i, j);
   const unsigned A = g.im.ordA[o2], C = g.im.ordC[o2];
   // v faces: j = 0 and j = Ny are walls (peripheral on the underlying grid); in between KPV levels touch the solid
-  const int kpv = (j == 0 || j == g.Ny) ? g.Nz : (int)((C >> 16) & 255);
+  const bool wall = j == 0 || (j == g.Ny && !g.cv.north_fold);   // (the fold line is no wall)
+  const int kpv = wall ? g.Nz : (int)((C >> 16) & 255);
   int ov = iv(g, i, j, 0);
   for (int k = 0; k < min(kpv, g.Nz); k++, ov += g.pl_v) v[ov] = real(0.);
-  if (j == 0 || j == g.Ny || g.im.Hcf[o2] == real(0.)) V[o2] = real(0.);
+  if (wall || g.im.Hcf[o2] == real(0.)) V[o2] = real(0.);
   if (j == g.Ny) return;
   const int kc = A & 255, kpu = (C >> 8) & 255;
   int o = ic(g, i, j, 0);

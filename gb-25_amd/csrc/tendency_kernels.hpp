@@ -8,6 +8,8 @@
 // A wave64 VALU instruction costs ~4 cycles of a SIMD on gfx950 and scalar forms of these kernels were
 // issue-saturated (VALUBusy ~100 %): see device_common.hpp (real2v), tools/micro/ and profiles/r01_tuning_log.md.
 #pragma once
+#include <type_traits>
+
 #include "device_common.hpp"
 
 namespace gb25 {
@@ -34,6 +36,15 @@ struct MomentumLds {
   real Z[MD_Y][MD_X], UQ[MD_Y][MD_X], VQ[MD_Y][MD_X];  // (f,f,c)
   real DU[MD_Y][MD_X], DV[MD_Y][MD_X];                 // (c,c,c)
 };
+// Orthogonal curvilinear grid: the face lengths every derived point needs, staged once per block in the geometry of the
+// u / v tiles (origin (i0-3, j0-3)), and 1 / Az^ffc in the geometry of the (f,f,c) tile (origin (i0-2, j0-2)).
+template <int V2_TY>
+struct MomentumMetricLds {
+  static constexpr int MU_Y = V2_TY + 6, MD_Y = V2_TY + 5;
+  real dxfc[MU_Y][MU_X], dxcf[MU_Y][MU_X], dyfc[MU_Y][MU_X], dycf[MU_Y][MU_X];
+  real razff[MD_Y][MD_X];
+};
+struct NoLds { char unused; };
 
 // =============================================================================================
 // Momentum tendencies, packed evaluation: the eight WENO reconstructions of a cell are evaluated as four two-wide ones (a G_u term paired with the G_v term of
@@ -65,12 +76,18 @@ struct UvAhead {
 // level from the folded tables; the tendencies of faces that touch the solid are zero (their velocities are masked and
 // stay so).  The pairs that share direction and target keep their packed evaluation; the vorticity pair (y for G_u, x
 // for G_v) is packed where both orders are 5 and evaluated one by one elsewhere, as next to the walls.
-template <int MINW, int V2_TY, bool AHEAD, bool IMM>
+// CURV: orthogonal curvilinear grid (always with the tables, IMM): every face length, area and the Coriolis parameter per
+// point -- k-independent, so the lengths of the tile sit in LDS (MomentumMetricLds), the own cell's reciprocals in
+// registers, and Az^ccc is multiplied into the w tile when it is staged.  With the zipper fold the tiles cover one more
+// row: the y faces ON the fold line have a G_v (and, AHEAD, a v of the next step) like any other row.
+template <int MINW, int V2_TY, bool AHEAD, bool IMM, bool CURV = false>
 __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     Grid g, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ w,
     const real* __restrict__ dpx, const real* __restrict__ dpy, real* __restrict__ Gu, real* __restrict__ Gv,
     TileCols tc, int kchunks, int nb, UvAhead next) {
+  static_assert(!CURV || IMM, "the curvilinear variant takes its orders from the tables");
   __shared__ MomentumLds<V2_TY> lds;
+  __shared__ typename std::conditional<CURV, MomentumMetricLds<V2_TY>, NoLds>::type mt;
   constexpr int MU_Y = V2_TY + 6, MW_Y = V2_TY + 3, MD_Y = V2_TY + 5;
   const int L = xcd_remap(blockIdx.x, nb);
   const int r = L / tc.n, bx = tile_column(tc, L - r * tc.n);
@@ -80,14 +97,26 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * V2_TX + tx;
   const int i0 = bx * V2_TX, j0 = by * V2_TY;
   const int i = i0 + tx, j = j0 + ty;
-  const bool inside = (i < g.Nx) && (j < g.Ny);
+  // rows of y faces that have a tendency: with the zipper fold the fold line (row Ny) is one of them
+  const int jv_last = CURV ? g.Ny - 1 + g.cv.north_fold : g.Ny - 1;
+  const bool inside_u = (i < g.Nx) && (j < g.Ny), inside_v = (i < g.Nx) && (j <= jv_last);
+  const int ic_ = min(i, g.Nx - 1), jc_ = min(j, jv_last);   // ragged tiles: threads past the edge work on a duplicate
   const int sx = g.sx, pc = g.pl_c, pv = g.pl_v, H = g.H;
   const real dy = g.dy;
 
-  // j-dependent metrics of this thread's row
-  const real dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j], razc_j = g.razc[j], razf_j = g.razf[j];
-  const real Az = g.azc[j], fcor_j = g.fcor[j], fbar = real(0.5) * (g.fcor[j] + g.fcor[j + 1]);
-  const real az_m2 = g.azc[j - 2], az_m1 = g.azc[j - 1], az_p1 = g.azc[j + 1];
+  // metrics of this thread's row (lat-lon) or cell (curvilinear: reciprocals at the u and the v point, 1/Az^fcc and
+  // 1/Az^cfc for the vertical advection, the Coriolis parameter averaged to the two points)
+  const int om = CURV ? i2(g, ic_, jc_) : 0;
+  const real dxf_s = CURV ? real(0.) : g.dxf[j], dxf_n = CURV ? real(0.) : g.dxf[j + 1];
+  const real rdxc_j = CURV ? g.cv.rdxfc[om] : g.rdxc[j], rdy_j = CURV ? g.cv.rdycf[om] : g.rdy;
+  const real razc_j = CURV ? g.cv.razfc[om] : g.razc[j], razf_j = CURV ? g.cv.razcf[om] : g.razf[j];
+  const real fcor_j = CURV ? g.cv.fbar_v[om] : g.fcor[j];
+  const real fbar = CURV ? g.cv.fbar_u[om] : real(0.5) * (g.fcor[j] + g.fcor[j + 1]);
+  // Az^ccc of the cell and its neighbours in x and y (the advecting Az w of the vertical momentum flux); the curvilinear
+  // tiles carry Az w already, so the factors are needed for the flux through the chunk's bottom face only
+  const real Az = CURV ? g.cv.azcc[om] : g.azc[j];
+  const real az_m2 = CURV ? g.cv.azcc[om - 2 * sx] : g.azc[j - 2], az_m1 = CURV ? g.cv.azcc[om - sx] : g.azc[j - 1],
+             az_p1 = CURV ? g.cv.azcc[om + sx] : g.azc[j + 1];
   int oc_y = biased_order_center(j, g.Ny), of_y = biased_order_face(j, g.Ny);
   bool s4c_y = sym4_center(j, g.Ny), s4f_y = sym4_face(j, g.Ny);
   // orders / switches that are constants of the plain grid (x is periodic) and per-level quantities with a bottom
@@ -95,7 +124,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   bool s4c_x = true, s4f_x = true, s4f_xw = true, s4f_yw = s4f_y;
   int kbt = 0, KX5 = 0, KX3 = 0, KY5 = 0, KY3 = 0, KXC5 = 0, KXC3 = 0, KYC5 = 0, KYC3 = 0, KPU = 0, KPV = 0;
   if (IMM) {
-    const int o2 = i2(g, min(i, g.Nx - 1), min(j, g.Ny - 1));
+    const int o2 = i2(g, ic_, jc_);
     const unsigned A = g.im.ordA[o2], B = g.im.ordB[o2], C = g.im.ordC[o2];
     kbt = A & 255; KX5 = (A >> 8) & 255; KX3 = (A >> 16) & 255; KY5 = A >> 24;
     KY3 = B & 255; KXC5 = (B >> 8) & 255; KXC3 = (B >> 16) & 255; KYC5 = B >> 24;
@@ -114,7 +143,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   };
 
   // threads of a ragged edge tile work on a clamped (duplicate) column so that every address stays in bounds
-  int o = ic(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0), ov = iv(g, min(i, g.Nx - 1), min(j, g.Ny - 1), k0);
+  int o = ic(g, ic_, jc_, k0), ov = iv(g, ic_, jc_, k0);
   // (uniform base pointer + 32-bit per-lane byte offset: the accesses take the scalar-base addressing form and need no
   // 64-bit address arithmetic per lane; the own cell's byte offsets ob / obv serve every centre- / v-shaped array)
   auto at = [](const real* base, unsigned byte_off) {
@@ -137,7 +166,8 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     const int ord = biased_order_face(k0 - kbt, Nzc);
     // (the bottom face k0 of the chunk is the top face of level k0-1; face 0 carries w = 0 whatever the order)
     if (IMM) level_orders(max(k0 - 1, 0));
-    real wu = sym_interp(s4f_xw, Az * w[o - 2], Az * w[o - 1], Az * w[o], Az * w[o + 1]);
+    const real ax_m2 = CURV ? g.cv.azcc[om - 2] : Az, ax_m1 = CURV ? g.cv.azcc[om - 1] : Az, ax_p1 = CURV ? g.cv.azcc[om + 1] : Az;
+    real wu = sym_interp(s4f_xw, ax_m2 * w[o - 2], ax_m1 * w[o - 1], Az * w[o], ax_p1 * w[o + 1]);
     real wv = sym_interp(s4f_yw, az_m2 * w[o - 2 * sx], az_m1 * w[o - sx], Az * w[o], az_p1 * w[o + sx]);
     fzu = wu * biased6<false>(ord, wu > real(0.), uz, uz, uz);
     fzv = wv * biased6<false>(ord, wv > real(0.), vz, vz, vz);
@@ -166,6 +196,27 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     ew_lds[q] = e;
   }
   real ru[NEU], rv[NEU], rw[NEW], rpw = real(0.), rps = real(0.);
+  real azw[NEW];   // CURV: Az^ccc at this thread's elements of the w tile
+  if constexpr (CURV) {
+    const real* ab = g.cv.azcc + tile_w;
+#pragma unroll
+    for (int q = 0; q < NEW; q++) azw[q] = ew_off[q] >= 0 ? *reinterpret_cast<const real*>(reinterpret_cast<const char*>(ab) + ew_off[q]) : real(0.);
+    const real *m0 = g.cv.dxfc + tile_u, *m1 = g.cv.dxcf + tile_u, *m2 = g.cv.dyfc + tile_u, *m3 = g.cv.dycf + tile_u;
+#pragma unroll
+    for (int q = 0; q < NEU; q++)
+      if (eu_off[q] >= 0) {
+        auto ld = [&](const real* b_) { return *reinterpret_cast<const real*>(reinterpret_cast<const char*>(b_) + eu_off[q]); };
+        (&mt.dxfc[0][0])[eu_lds[q]] = ld(m0);
+        (&mt.dxcf[0][0])[eu_lds[q]] = ld(m1);
+        (&mt.dyfc[0][0])[eu_lds[q]] = ld(m2);
+        (&mt.dycf[0][0])[eu_lds[q]] = ld(m3);
+      }
+    for (int e = tid; e < MD_X * MD_Y; e += NT) {
+      const int py = e / MD_X, px = e - py * MD_X;
+      // (clamped like the tiles: the last rows / columns of a ragged tile are never used)
+      (&mt.razff[0][0])[e] = g.cv.razff[(min(i0 - 2 + px, g.Nx + H - 1) + H) + sx * (min(j0 - 2 + py, g.Ny + H) + H)];
+    }
+  }
   // (uniform base pointer + 32-bit per-lane byte offset: the loads take the scalar-base addressing form and need no
   // 64-bit address arithmetic per lane)
   auto fetch = [&](int k, unsigned oob) {   // oob: byte offset of the own cell at level k
@@ -196,7 +247,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
       }
 #pragma unroll
     for (int q = 0; q < NEW; q++)
-      if (ew_off[q] >= 0) W0[ew_lds[q]] = rw[q];
+      if (ew_off[q] >= 0) W0[ew_lds[q]] = CURV ? azw[q] * rw[q] : rw[q];
   };
   real sAu = real(0.), sAv = real(0.), sIu = real(0.), sIv = real(0.);   // AHEAD: this chunk's column sums
   // per-block tables for phase 1: packed (row << 8 | column) of every derived point, and the metrics of the rows
@@ -207,7 +258,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     const int py = e / MD_X;
     ptab[e] = (py << 8) | (e - py * MD_X);
   }
-  if (tid <= MD_Y) {
+  if (!CURV && tid <= MD_Y) {
     mdxc[tid] = g.dxc[j0 - 3 + tid];
     mdxf[tid] = g.dxf[j0 - 3 + tid];
     if (tid < MD_Y) mrazf[tid] = g.razf[j0 - 2 + tid];
@@ -233,12 +284,19 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
       {
         real uc = lds.U[par][py + 1][px + 1], us = lds.U[par][py][px + 1];
         real vc = lds.V[par][py + 1][px + 1], vw = lds.V[par][py + 1][px];
-        lds.Z[py][px] = ((dy * vc - dy * vw) - (mdxc[py + 1] * uc - mdxc[py] * us)) * mrazf[py];
+        if constexpr (CURV)
+          lds.Z[py][px] = ((mt.dycf[py + 1][px + 1] * vc - mt.dycf[py + 1][px] * vw) -
+                           (mt.dxfc[py + 1][px + 1] * uc - mt.dxfc[py][px + 1] * us)) * mt.razff[py][px];
+        else
+          lds.Z[py][px] = ((dy * vc - dy * vw) - (mdxc[py + 1] * uc - mdxc[py] * us)) * mrazf[py];
         lds.UQ[py][px] = real(0.5) * (us + uc);
         lds.VQ[py][px] = real(0.5) * (vw + vc);
       }
       // (c,c,c) point (i0-3+px, j0-3+py)
-      {
+      if constexpr (CURV) {
+        lds.DU[py][px] = mt.dyfc[py][px + 1] * dz * lds.U[par][py][px + 1] - mt.dyfc[py][px] * dz * lds.U[par][py][px];
+        lds.DV[py][px] = mt.dxcf[py + 1][px] * dz * lds.V[par][py + 1][px] - mt.dxcf[py][px] * dz * lds.V[par][py][px];
+      } else {
         const real Ax = dy * dz;
         lds.DU[py][px] = Ax * lds.U[par][py][px + 1] - Ax * lds.U[par][py][px];
         lds.DV[py][px] = mdxf[py + 1] * dz * lds.V[par][py + 1][px] - mdxf[py] * dz * lds.V[par][py][px];
@@ -260,9 +318,18 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
       // Packed evaluation: the eight reconstructions of the cell are done as four PAIRS that share stencil shape
       // and order, (.x, .y) = (a term of G_u, a term of G_v); see real2v in device_common.hpp.
       const real vws = VT(-1, 0), vwn = VT(-1, 1), vcs = VT(0, 0), vcn = VT(0, 1);
-      const real vhat_u = (real(0.5) * (dxf_s * vws + dxf_n * vwn) + real(0.5) * (dxf_s * vcs + dxf_n * vcn)) * real(0.5) * rdxc_j;
-      const real uhat_v =
-          (real(0.5) * (dy * UT(0, -1) + dy * UT(1, -1)) + real(0.5) * (dy * UT(0, 0) + dy * UT(1, 0))) * real(0.5) * g.rdy;
+#define MT(A, di, dj) mt.A[ty + 3 + (dj)][tx + 3 + (di)]
+      real vhat_u, uhat_v;
+      if constexpr (CURV) {
+        vhat_u = (real(0.5) * (MT(dxcf, -1, 0) * vws + MT(dxcf, -1, 1) * vwn) + real(0.5) * (MT(dxcf, 0, 0) * vcs + MT(dxcf, 0, 1) * vcn)) *
+                 real(0.5) * rdxc_j;
+        uhat_v = (real(0.5) * (MT(dyfc, 0, -1) * UT(0, -1) + MT(dyfc, 1, -1) * UT(1, -1)) +
+                  real(0.5) * (MT(dyfc, 0, 0) * UT(0, 0) + MT(dyfc, 1, 0) * UT(1, 0))) * real(0.5) * rdy_j;
+      } else {
+        vhat_u = (real(0.5) * (dxf_s * vws + dxf_n * vwn) + real(0.5) * (dxf_s * vcs + dxf_n * vcn)) * real(0.5) * rdxc_j;
+        uhat_v = (real(0.5) * (dy * UT(0, -1) + dy * UT(1, -1)) + real(0.5) * (dy * UT(0, 0) + dy * UT(1, 0))) * real(0.5) * rdy_j;
+      }
+#undef MT
       const real uhat_u = uz[3], vhat_v = vz[3];
 
       // (1) vorticity flux: zeta reconstructed in y for G_u (centre order) and in x for G_v (order 5)
@@ -333,8 +400,11 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
         dKv_v = rr.y;
       }
       // (4) vertical advection of u and v: same order, own directions
-      const real wt_u = sym_interp(s4f_xw, Az * WT(-2, 0), Az * WT(-1, 0), Az * WT(0, 0), Az * WT(1, 0));
-      const real wt_v = sym_interp(s4f_yw, az_m2 * WT(0, -2), az_m1 * WT(0, -1), Az * WT(0, 0), az_p1 * WT(0, 1));
+      // (curvilinear: the tile holds Az w)
+      const real wt_u = CURV ? sym_interp(s4f_xw, WT(-2, 0), WT(-1, 0), WT(0, 0), WT(1, 0))
+                             : sym_interp(s4f_xw, Az * WT(-2, 0), Az * WT(-1, 0), Az * WT(0, 0), Az * WT(1, 0));
+      const real wt_v = CURV ? sym_interp(s4f_yw, WT(0, -2), WT(0, -1), WT(0, 0), WT(0, 1))
+                             : sym_interp(s4f_yw, az_m2 * WT(0, -2), az_m1 * WT(0, -1), Az * WT(0, 0), az_p1 * WT(0, 1));
       real2v zz[6];
 #pragma unroll
       for (int m = 0; m < 6; m++) zz[m] = v2(uz[m + 1], vz[m + 1]);
@@ -375,9 +445,9 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
           a4[m] = real(0.5) * un * un - real(0.5) * us * us;
         }
         const real dKu = sym_interp(s4c_x, a4[0], a4[1], a4[2], a4[3]);
-        const real bern = (dKv_v + dKu) * g.rdy;
+        const real bern = (dKv_v + dKu) * rdy_j;
         const real cor = fcor_j * uhat_v;
-        const real dpdy = ps_ * g.rdy;
+        const real dpdy = ps_ * rdy_j;
         gv = -(hadv_v + vadv + bern) - cor - dpdy;
       }
     }
@@ -388,7 +458,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
 #undef DC
     if (k == g.Nz - 1 && (g.top_flux[0] || g.top_flux[1])) {
       // compute_hydrostatic_boundary_tendency_contributions!: top flux boundary conditions (wind stress)
-      const int o2 = i2(g, min(i, g.Nx - 1), min(j, g.Ny - 1));
+      const int o2 = i2(g, ic_, jc_);
       if (g.top_flux[0]) gu = gu - g.top_flux[0][o2] * rdz;
       if (g.top_flux[1] && j > 0) gv = gv - g.top_flux[1][o2] * rdz;
     }
@@ -396,13 +466,13 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
       if (k < KPU) gu = real(0.);
       if (k < KPV) gv = real(0.);
     }
-    if (inside) {
-      put(Gu, ob, gu);
+    if (inside_v) {
+      if (inside_u) put(Gu, ob, gu);
       put(Gv, obv, gv);
       if (AHEAD) {
         const real au = rfma(next.C1, gu, -(next.C2 * at(next.GmU, ob))), av = rfma(next.C1, gv, -(next.C2 * at(next.GmV, obv)));
         const real un = rfma(next.dt, au, uz[3]), vn = rfma(next.dt, av, vz[3]);
-        put(next.un, ob, un);
+        if (inside_u) put(next.un, ob, un);
         put(next.vn, obv, vn);
         sAu = (k == k0) ? dz * au : rfma(dz, au, sAu);
         sAv = (k == k0) ? dz * av : rfma(dz, av, sAv);
@@ -426,12 +496,14 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     }
     __syncthreads();   // next tiles visible; derived arrays free for the next phase 1
   }
-  if (AHEAD && inside) {
+  if (AHEAD && inside_v) {
     const long o2 = i2(g, i, j), q = (long)kchunks * next.plane2, c = (long)kc * next.plane2;
-    next.P[c + o2] = sAu;
     next.P[q + c + o2] = sAv;
-    next.P[2 * q + c + o2] = sIu;
     next.P[3 * q + c + o2] = sIv;
+    if (inside_u) {
+      next.P[c + o2] = sAu;
+      next.P[2 * q + c + o2] = sIu;
+    }
   }
 }
 
@@ -464,7 +536,8 @@ struct Ab2Ahead {
 // tupled_fill_halo_regions! derives from them (periodic x images, y layer, z layers and their x images), so that the
 // adopted buffers need no fill launch.
 // The arithmetic of one tile (63 cells of a row x 4 rows x one chunk of levels); L = logical tile index.
-template <bool AHEAD, bool IMM, bool FOLD>
+// CURV: orthogonal curvilinear grid (with the tables): the three face lengths, the area and its reciprocal per lane.
+template <bool AHEAD, bool IMM, bool FOLD, bool CURV = false>
 __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restrict__ u, const real* __restrict__ v,
                                             const real* __restrict__ w, const real* __restrict__ T,
                                             const real* __restrict__ S, real* __restrict__ GT, real* __restrict__ GS,
@@ -478,7 +551,11 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
   if (j >= g.Ny) return;                       // whole wave (one row) leaves together: no barriers in this kernel
   const bool writes = (lane < V3_OUT) && (i < g.Nx);
   const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
-  const real dy = g.dy, Az = g.azc[j], dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], razc_j = g.razc[j];
+  static_assert(!CURV || IMM, "the curvilinear variant takes its orders from the tables");
+  const int om = i2(g, min(i, g.Nx), j);
+  const real dy = CURV ? g.cv.dyfc[om] : g.dy, Az = CURV ? g.cv.azcc[om] : g.azc[j];
+  const real dxf_s = CURV ? g.cv.dxcf[om] : g.dxf[j], dxf_n = CURV ? g.cv.dxcf[om + g.sx] : g.dxf[j + 1];
+  const real razc_j = CURV ? g.cv.razcc[om] : g.razc[j];
   int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny), ox = 5;
   int kbt = 0, KX5 = 0, KX3 = 0, KY5 = 0, KY3 = 0, KY5n = 0, KY3n = 0;
   if (IMM) {
@@ -585,14 +662,14 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
 #undef CY
 #undef CX
 }
-template <int MINW, bool AHEAD, bool IMM, bool FOLD = false>
+template <int MINW, bool AHEAD, bool IMM, bool FOLD = false, bool CURV = false>
 __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, const real* __restrict__ u,
                                                               const real* __restrict__ v,
                                                               const real* __restrict__ w,
                                                               const real* __restrict__ T, const real* __restrict__ S,
                                                               real* __restrict__ GT, real* __restrict__ GS, int nbx,
                                                               int kchunks, int nb, Ab2Ahead next) {
-  tracer_tile<AHEAD, IMM, FOLD>(g, u, v, w, T, S, GT, GS, nbx, kchunks, next, xcd_remap(blockIdx.x, nb));
+  tracer_tile<AHEAD, IMM, FOLD, CURV>(g, u, v, w, T, S, GT, GS, nbx, kchunks, next, xcd_remap(blockIdx.x, nb));
 }
 
 }  // namespace gb25

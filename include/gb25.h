@@ -84,11 +84,17 @@ typedef struct {
 } gb25_config;
 
 typedef enum {
-  GB25_GRID_LAT_LON = 0,           /* simple_latitude_longitude_grid (src/model_utils.jl:56-65), flat bottom */
-  GB25_GRID_LAT_LON_GAUSSIAN_ISLANDS = 1 /* ImmersedBoundaryGrid(that grid, GridFittedBottom(gaussian_islands); active_cells_map
-                                            = false): the two Gaussian mountains of src/model_utils.jl:67-80,138-146.  (The
-                                            reference's :gaussian_islands puts them on a TripolarGrid; the tripolar
-                                            underlying grid does not exist here yet.) */
+  GB25_GRID_LAT_LON = 0,                  /* simple_latitude_longitude_grid (src/model_utils.jl:56-65), flat bottom */
+  GB25_GRID_LAT_LON_GAUSSIAN_ISLANDS = 1, /* ImmersedBoundaryGrid(that grid, GridFittedBottom(gaussian_islands);
+                                             active_cells_map = false): the two mountains of src/model_utils.jl:67-80 */
+  GB25_GRID_LAT_LON_AS_CURVILINEAR = 2,   /* grid 0 stepped by the orthogonal-curvilinear kernels (2-D metrics): a test
+                                             vehicle, results equal those of grid 0 to round-off */
+  GB25_GRID_TRIPOLAR = 3,                 /* TripolarGrid(arch; size, halo, z) (src/model_utils.jl:134-137), flat bottom:
+                                             poles at (70 E, 55 N) and (250 E, 55 N), southern edge lat_south, zipper
+                                             fold along the northern edge.  The poles are singular without land. */
+  GB25_GRID_TRIPOLAR_GAUSSIAN_ISLANDS = 4, /* grid_type = :gaussian_islands of the reference (src/model_utils.jl:129-146):
+                                             the tripolar grid with the two Gaussian mountains over its poles */
+  GB25_GRID_COUNT
 } gb25_grid_type;
 
 /* Per-model switches (gb25_set_option).  Defaults in brackets.  None of them changes results beyond the last bits
@@ -118,6 +124,12 @@ typedef enum {
   GB25_M_PHIF = 0, GB25_M_PHIC, GB25_M_DXC, GB25_M_DXF, GB25_M_AZC, GB25_M_AZF, GB25_M_FCOR,
   GB25_M_ZF, GB25_M_ZC, GB25_M_DZC, GB25_M_DZF
 } gb25_metric;
+/* Horizontal metrics of an orthogonal curvilinear grid by location, for gb25_get_metric2 (Oceananigans' names:
+ * GB25_M2_DXFC = dx at (Face, Center), ...; FFF = Coriolis parameter at (f,f); PHICC = latitude of the cell centres). */
+typedef enum {
+  GB25_M2_DXFC = 0, GB25_M2_DXCC, GB25_M2_DXCF, GB25_M2_DXFF, GB25_M2_DYFC, GB25_M2_DYCC, GB25_M2_DYCF, GB25_M2_DYFF,
+  GB25_M2_AZCC, GB25_M2_AZFC, GB25_M2_AZCF, GB25_M2_AZFF, GB25_M2_FFF, GB25_M2_PHICC, GB25_M2_COUNT
+} gb25_metric2;
 
 /* Kernel identifiers for the built-in HIP-event timers (gb25_profile_*). */
 typedef enum {
@@ -163,6 +175,9 @@ gb25_status gb25_get_field(gb25_model *m, gb25_field f, void *host, int include_
  * pointer makes every later step store it (GB25_OPT_STORE_PRESSURE = 1 does the same from the start). */
 gb25_status gb25_field_device_ptr(gb25_model *m, gb25_field f, void **dev);
 gb25_status gb25_get_metric(const gb25_model *m, gb25_metric id, int32_t logical_index, double *value);
+/* grid_type >= 2: one horizontal metric as fp64, the parent layout of a (Center, Face) 2-D field:
+ * (Nx + 2 halo) x (Ny + 2 halo + 1) values, i fastest (the role of grid.Δxᶠᶜᵃ etc. of an OrthogonalSphericalShellGrid). */
+gb25_status gb25_get_metric2(const gb25_model *m, gb25_metric2 id, double *values, int64_t count);
 gb25_status gb25_get_substepping(const gb25_model *m, int32_t *n_effective, double *dtau_fraction,
                                  double *weights /* >= substeps entries */);
 

@@ -1,0 +1,183 @@
+"""TripolarGrid + GridFittedBottom(gaussian_islands) on the HIP path (second half; GB-25
+src/model_utils.jl:129-146, grid_type = :gaussian_islands of src/baroclinic_instability_model.jl:59-65) against the
+oracle's restatement of the same grid (tests/test_oracle_tripolar.py pins that one): the grid generator, the
+orthogonal-curvilinear kernel variants (2-D metrics), the zipper fold in the halo fills, the stepped row of y faces on
+the fold line, the fold inside the split-explicit sub-cycle."""
+import numpy as np
+import pytest
+
+import gb25_amd as gb
+from gb25_amd.binding import METRIC2_IDS
+from helpers import SQRT_EPS32, assert_states_close, counter_rng, make_pair, set_noisy_velocities
+
+pytestmark = pytest.mark.gpu
+ALL_FIELDS = ["u", "v", "w", "T", "S", "pHY", "Gn.u", "Gn.v", "Gn.T", "Gn.S", "Gm.u", "Gm.v", "Gm.T", "Gm.S",
+              "eta", "U", "V", "eta_bar", "U_bar", "V_bar", "Gn.U", "Gn.V"]
+H = 8
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    n = max(np.linalg.norm(a.ravel()), np.linalg.norm(b.ravel()))
+    return 0.0 if n == 0 else float(np.linalg.norm((a - b).ravel()) / n)
+
+
+def start(r, v, amplitude=1e-2):
+    gb.set_baroclinic_instability(v)
+    set_noisy_velocities(v, amplitude)
+    for n in ALL_FIELDS:
+        a = v.backend.get_field(n, True).astype(np.float32)
+        r.backend.set_field(n, a, True)
+        v.backend.set_field(n, a.astype(v.backend.dtype), True)
+
+
+@pytest.mark.parametrize("grid_type", ["lat_lon_as_curvilinear", "tripolar"])
+def test_grid_generator_matches_the_oracle(grid_type):
+    """Every metric, every location, halo rows and columns included (the rows beyond the fold are the mirrored cells)."""
+    Nx, Ny, Nz = 72, 36, 6
+    r, v = make_pair(Nx, Ny, Nz, dt=600.0, float_type="Float64", grid_type=grid_type)
+    for name in METRIC2_IDS:
+        a = r.backend.metric2(name)
+        assert a.shape == (Nx + 2 * H, Ny + 2 * H + 1)
+        # (the outermost halo row / column have no neighbour to measure to in the oracle's arrays either: same formula)
+        b = np.array([[v.backend.metric2(name, i, j) for j in range(2 - H, Ny + H + 1)] for i in range(2 - H, Nx + H)])
+        assert np.allclose(a[1:-1, 1:-1], b, rtol=1e-11, atol=0), (name, np.abs(a[1:-1, 1:-1] / b - 1).max())
+    # an analytic bottom sees the same physical coordinates
+    ri, vi = make_pair(Nx, Ny, 8, dt=600.0, grid_type="gaussian_islands" if grid_type == "tripolar" else "lat_lon_as_curvilinear")
+    for i in range(1, Nx + 1):
+        for j in range(1, Ny + 1):
+            assert ri.backend.bottom_info("kbot", i, j) == vi.backend.bottom_info("kbot", i, j), (i, j)
+            assert ri.backend.bottom_info("Hfc", i, j) == pytest.approx(vi.backend.bottom_info("Hfc", i, j), rel=1e-6)
+            assert ri.backend.bottom_info("Hcf", i, j) == pytest.approx(vi.backend.bottom_info("Hcf", i, j), rel=1e-6)
+
+
+@pytest.mark.parametrize("float_type,tol", [("Float64", 1e-12), ("Float32", 5e-6)])
+def test_lat_lon_grid_through_the_curvilinear_kernels(float_type, tol):
+    """grid_type 2: the lat-lon metrics as 2-D arrays through the CURV kernel variants (per-point face lengths in LDS,
+    Az w tiles, per-point reciprocals, the per-substep barotropic kernel) against the plain kernels with their row
+    tables: the same numbers to round-off (different template instances contract different FMAs; the sub-cycle divides
+    where the blocked kernel multiplies by a reciprocal)."""
+    Nx, Ny, Nz, dt = 150, 70, 24, 600.0
+    dtype = np.float64 if float_type == "Float64" else np.float32
+    a = gb.baroclinic_instability_model(gb.GPU(float_type=float_type), Nx, Ny, Nz, dt=dt)
+    b = gb.baroclinic_instability_model(gb.GPU(float_type=float_type), Nx, Ny, Nz, dt=dt, grid_type="lat_lon_as_curvilinear")
+    for m in (a, b):
+        gb.set_baroclinic_instability(m)
+        set_noisy_velocities(m, 0.05)
+        m.set(eta=(1e-2 * counter_rng((Nx, Ny, 1), 3, 3)).astype(dtype))
+        gb.first_time_step(m)
+        gb.loop(m, 6)
+    for n in ALL_FIELDS:
+        x, y = a.backend.get_field(n, False), b.backend.get_field(n, False)
+        assert rel(x, y) < tol, (n, rel(x, y))
+    assert np.abs(a.velocities.u.interior).max() > 0.05
+
+
+def test_fold_fill_is_the_oracles_data_movement():
+    """tupled_fill_halo_regions! with the zipper fold: pure data movement (signs, mirrored columns, the symmetrised row
+    of y faces on the fold line, the bottom / top layers of the rows beyond the fold): identical parents."""
+    Nx, Ny, Nz = 72, 36, 8
+    r, v = make_pair(Nx, Ny, Nz, dt=600.0, grid_type="tripolar")
+    rng = np.random.default_rng(5)
+    for n in ("u", "v", "T", "S", "eta", "U", "V"):
+        shape = r.backend.get_field(n, True).shape
+        a = rng.standard_normal(shape).astype(np.float32)
+        r.backend.set_field(n, a, True)
+        v.backend.set_field(n, a.astype(np.float64), True)
+    for m in (r, v):
+        m.backend.fill_halo_regions()
+    for n in ("u", "v", "T", "S", "eta", "U", "V"):
+        a, b = r.backend.get_field(n, True), v.backend.get_field(n, True).astype(np.float32)
+        assert np.array_equal(a, b), (n, np.argwhere(a != b)[:5])
+    vv = r.backend.get_field("v", True)[H:-H, H + Ny, H:-H]
+    assert np.array_equal(vv, -vv[::-1])
+
+
+def test_phase_by_phase_on_the_tripolar_grid_with_islands():
+    Nx, Ny, Nz = 72, 36, 8
+    r, v = make_pair(Nx, Ny, Nz, dt=600.0, grid_type="gaussian_islands")
+    start(r, v)
+    get = lambda m, n: m.backend.get_field(n, True)
+    sync = lambda: [r.backend.set_field(n, get(v, n).astype(np.float32), True) or
+                    v.backend.set_field(n, get(v, n).astype(np.float32).astype(np.float64), True) for n in ALL_FIELDS]
+    for m in (r, v):
+        m.backend.mask_immersed_fields()
+    for n in ("u", "v", "T", "S", "U", "V"):
+        assert np.array_equal(get(r, n), get(v, n).astype(np.float32)), n
+    sync()
+    for m in (r, v):
+        m.backend.initialize()
+        m.backend.update_state()
+    core = (slice(H - 1, -(H - 1)), slice(H - 1, -(H - 1)), slice(H, -H))
+    assert rel(get(r, "w")[core], get(v, "w")[core]) < 1e-5
+    for n, tol in (("Gn.T", 2e-4), ("Gn.S", 2e-4), ("Gn.u", 2e-4), ("Gn.v", 2e-4)):
+        assert rel(get(r, n), get(v, n)) < tol, (n, rel(get(r, n), get(v, n)))
+    # the row of y faces on the fold line has a tendency of its own, and it agrees
+    piv = (slice(H, -H), H + Ny, slice(H, -H))
+    assert np.abs(get(v, "Gn.v")[piv]).max() > 0
+    assert rel(get(r, "Gn.v")[piv], get(v, "Gn.v")[piv]) < 2e-4
+    for n in ("Gn.u", "Gn.v"):
+        assert np.array_equal(get(r, n) == 0, get(v, n) == 0), n
+    for euler in (True, False):
+        sync()
+        for m in (r, v):
+            m.backend.ab2_step(600.0, euler)
+        for n in ("u", "v", "T", "S", "eta", "U", "V", "eta_bar", "U_bar", "V_bar", "Gn.U", "Gn.V"):
+            assert rel(get(r, n), get(v, n)) < 2e-5, (n, euler, rel(get(r, n), get(v, n)))
+        V = get(r, "V")[H:-H, H + Ny, 0]
+        assert np.array_equal(V, -V[::-1]) and np.abs(V).max() > 0      # exact antisymmetry out of the sub-cycle
+    sync()
+    for m in (r, v):
+        m.backend.fill_halo_regions()
+        m.backend.correct_velocities_and_cache_previous_tendencies(600.0)
+    for n in ("u", "v", "U_bar", "V_bar"):
+        assert rel(get(r, n), get(v, n)) < 2e-6, n
+        assert np.array_equal(get(r, n)[H:-H, H:-H] == 0, get(v, n)[H:-H, H:-H] == 0), n
+
+
+@pytest.mark.parametrize("size", [(72, 36, 8, 600.0, 8), (180, 90, 12, 600.0, 5)])
+def test_stepping_the_reference_gaussian_islands_grid(size):
+    """first_time_step! + loop! on grid_type = :gaussian_islands against the oracle at the reference's tolerance, every
+    compared field, halos (the fold rows among them) included."""
+    Nx, Ny, Nz, dt, nsteps = size
+    r, v = make_pair(Nx, Ny, Nz, dt=dt, grid_type="gaussian_islands")
+    start(r, v, 1e-3)
+    for m in (r, v):
+        gb.first_time_step(m)
+        gb.loop(m, nsteps - 1)
+    assert_states_close(r, v, label=f"{Nx}x{Ny}x{Nz} tripolar islands after {nsteps} steps")
+    assert np.isfinite(r.backend.get_field("eta", False)).all()
+    assert np.abs(r.velocities.u.interior).max() > 1e-3
+    r.backend.fill_halo_regions()
+    vv = r.backend.get_field("v", True)[H:-H, H + Ny, H:-H]
+    assert np.array_equal(vv, -vv[::-1]) and np.abs(vv).max() > 0
+
+
+def test_rest_state_stays_at_rest_on_the_tripolar_grid():
+    Nx, Ny, Nz = 72, 36, 8
+    m = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=600.0, grid_type="gaussian_islands")
+    zc = np.array([m.backend.metric("zc", k) for k in range(1, Nz + 1)])
+    m.set(T=np.broadcast_to(10 + 5e-3 * zc, (Nx, Ny, Nz)).astype(np.float32),
+          S=np.broadcast_to(35 - 1e-3 * zc, (Nx, Ny, Nz)).astype(np.float32))
+    gb.first_time_step(m)
+    gb.loop(m, 3)
+    for name in ("u", "v", "w", "eta", "U", "V"):
+        assert np.abs(m.backend.get_field(name, False)).max() == 0.0, name
+
+
+def test_schedule_options_do_not_change_the_tripolar_step():
+    """The AB2 and sub-cycle look-aheads, and the one-stream schedule, on the folded grid: the fold-line row rides along
+    in every route (adopted buffers, per-chunk column sums, the sub-cycle's own row of threads)."""
+    Nx, Ny, Nz = 72, 36, 12
+    outs = []
+    for opts in (dict(), dict(ab2_lookahead=0), dict(subcycle_lookahead=1), dict(two_streams=0)):
+        m = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=600.0, grid_type="gaussian_islands", options=opts)
+        gb.set_baroclinic_instability(m)
+        set_noisy_velocities(m, 1e-2)
+        gb.first_time_step(m)
+        gb.loop(m, 5)
+        outs.append({n: m.backend.get_field(n, False) for n in ("u", "v", "T", "S", "eta", "U", "V")})
+        m.backend.close()
+    for o in outs[1:]:
+        for n, a in outs[0].items():
+            assert rel(a, o[n]) < 2e-6, (n, rel(a, o[n]))
