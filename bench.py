@@ -66,7 +66,12 @@ def counter_rng(shape, seed, salt):
     return ((x >> np.uint64(11)).astype(np.float64) / float(1 << 53)).reshape(shape, order="F")
 
 
-def cpu_baseline(Nx, Ny, Nz, dt, budget_s=25.0, max_steps=50):
+GRID_NAMES = {"simple_lat_lon": "LatitudeLongitudeGrid", "gaussian_islands_lat_lon": "LatitudeLongitudeGrid + GridFittedBottom(gaussian_islands)",
+              "lat_lon_as_curvilinear": "LatitudeLongitudeGrid (curvilinear kernels)", "tripolar": "TripolarGrid",
+              "gaussian_islands": "TripolarGrid + GridFittedBottom(gaussian_islands)"}
+
+
+def cpu_baseline(Nx, Ny, Nz, dt, budget_s=25.0, max_steps=50, grid_type="simple_lat_lon"):
     """The oracle (fp32 build, OpenMP) timed on this host on a bounded sample of the same workload.
     kind = "port": the reference's Julia CPU path cannot run here (no Julia)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -78,7 +83,7 @@ def cpu_baseline(Nx, Ny, Nz, dt, budget_s=25.0, max_steps=50):
         cores = os.cpu_count() or 1
     cores = min(cores, int(os.environ.get("GB25_CPU_BASELINE_CORES", "16")))
     os.environ["OMP_NUM_THREADS"] = str(cores)
-    m = gb.baroclinic_instability_model(CPU("f32"), Nx, Ny, Nz, dt=dt)
+    m = gb.baroclinic_instability_model(CPU("f32"), Nx, Ny, Nz, dt=dt, grid_type=grid_type)
     gb.set_baroclinic_instability(m)
     m.set(u=(1e-3 * counter_rng(m.velocities.u.shape, 42, 1)).astype(np.float32),
           v=(1e-3 * counter_rng(m.velocities.v.shape, 42, 2)).astype(np.float32))
@@ -105,6 +110,9 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N > 1: every rank a full --size slab of an N times wider grid")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="library option for A/B runs (gb25_set_option), e.g. --opt subcycle_lookahead=0")
+    ap.add_argument("--grid-type", default="simple_lat_lon",
+                    help="single GPU: gaussian_islands_lat_lon | tripolar | gaussian_islands (the reference's TripolarGrid + "
+                         "GridFittedBottom); the headline line is the default, simple_lat_lon")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timers")
     args = ap.parse_args()
@@ -146,7 +154,7 @@ def main():
         model = SlabModel(gNx, Ny, Nz, dt=args.dt, rank=rank, nranks=world, device=local_rank)
         barrier = dist.barrier
     else:
-        model = gb.baroclinic_instability_model(gb.GPU(local_rank), Nx, Ny, Nz, dt=args.dt)
+        model = gb.baroclinic_instability_model(gb.GPU(local_rank), Nx, Ny, Nz, dt=args.dt, grid_type=args.grid_type)
         barrier = lambda: None
     locNx = gNx // world
     b = model.backend
@@ -218,7 +226,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak" if (args.weak and world > 1) else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"baroclinic_instability_model {gNx}x{Ny}x{Nz} LatitudeLongitudeGrid, "
+            "config": {"workload": f"baroclinic_instability_model {gNx}x{Ny}x{Nz} {GRID_NAMES[args.grid_type]}, "
                                    f"halo 8, SplitExplicit(30), WENO5, TEOS10, dt={args.dt:g}s",
                        "grid": [gNx, Ny, Nz], "cells_per_gpu": cells, "local_columns": locNx,
                        "parallelism": (f"x-slab x{world}, RCCL send/recv inside the library"
@@ -263,7 +271,7 @@ def main():
             out["kernel_times_from"] = (f"timed region: {dom}; others: warm-up steps" if warm_kernels
                                         else "timed region")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(Nx, Ny, Nz, args.dt)
+            out["cpu_baseline"] = cpu_baseline(Nx, Ny, Nz, args.dt, grid_type=args.grid_type)
             # BASELINE.json configs[0] (the reference's own CPU-runnable case: 128x64x8, 100 AB2 steps) beside it
             c1 = cpu_baseline(128, 64, 8, 1200.0, budget_s=10.0, max_steps=99)
             c1["sample"] = c1["sample"].replace("the same ", "BASELINE configs[0] ")

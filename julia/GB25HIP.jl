@@ -16,7 +16,7 @@ export Config, Model, create, destroy!, first_time_step!, time_step!, loop!, ini
        fill_halo_regions!, compute_auxiliaries!, compute_tendencies!, ab2_step!, mask_immersed_fields!,
        correct_velocities_and_cache_previous_tendencies!, set_baroclinic_instability!, synchronize,
        parent_array, interior_array, set_parent!, set_interior!, clock, set_dt!, set_option!, get_option,
-       comm_unique_id, comm_init_rccl!, comm_finalize!, FIELD, OPTION
+       comm_unique_id, comm_init_rccl!, comm_finalize!, set_top_flux!, set_bottom_height!, metric2, FIELD, OPTION, METRIC2
 
 # One library per Oceananigans float type (src/arg_parsing.jl:12-16): Float32 -> libgb25hip.so, Float64 ->
 # libgb25hip_f64.so; same symbols, gb25_real_bytes() tells them apart.
@@ -55,7 +55,8 @@ Base.@kwdef mutable struct Config
     radius::Float64 = 6371e3
     rho0::Float64 = 1020.0
     slab_mode::Int32 = 0
-    grid_type::Int32 = 0            # 0 = :simple_lat_lon, 1 = :gaussian_islands on the lat-lon grid
+    grid_type::Int32 = 0            # gb25_grid_type: 0 = :simple_lat_lon, 1 = the Gaussian islands on the lat-lon grid,
+                                    # 3 = TripolarGrid, 4 = :gaussian_islands (TripolarGrid + GridFittedBottom)
 end
 
 mutable struct Model{FT}
@@ -140,6 +141,28 @@ ab2_step!(m::Model, Δt::Real, euler::Bool = false) =
 correct_velocities_and_cache_previous_tendencies!(m::Model, Δt::Real = 0.0) =
     check(m, ccall((:gb25_correct_velocities_and_cache_previous_tendencies, m.lib), Cint, (Ptr{Cvoid}, Float64),
                    m.ptr, Δt), "gb25_correct_velocities_and_cache_previous_tendencies")
+
+# ---- FluxBoundaryCondition at the top of u, v, T, S (what ocean_simulation's coupled fluxes fill every step;
+# src/data_free_ocean_climate_model.jl:26, src/precompile.jl:52-61): J at the interior points, positive upward
+function set_top_flux!(m::Model{FT}, field::Integer, J::Union{Nothing, AbstractMatrix}) where FT
+    a = J === nothing ? nothing : convert(Matrix{FT}, J)          # values in the model's float type
+    p = a === nothing ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(a))
+    GC.@preserve a check(m, ccall((:gb25_set_top_flux, m.lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), m.ptr, field, p),
+                         "gb25_set_top_flux")
+end
+# GridFittedBottom(bottom_height): heights at the cell centres of the interior columns, (Nx, Ny)
+set_bottom_height!(m::Model, zb::AbstractMatrix) =
+    check(m, ccall((:gb25_set_bottom_height, m.lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), m.ptr, convert(Matrix{Float64}, zb)),
+          "gb25_set_bottom_height")
+# gb25_metric2: horizontal metrics of an orthogonal curvilinear grid (grid_type >= 2) by location
+const METRIC2 = (dxfc = 0, dxcc = 1, dxcf = 2, dxff = 3, dyfc = 4, dycc = 5, dycf = 6, dyff = 7,
+                 azcc = 8, azfc = 9, azcf = 10, azff = 11, fff = 12, phicc = 13)
+function metric2(m::Model, id::Integer, Nx::Integer, Ny::Integer, H::Integer)
+    a = Matrix{Float64}(undef, Nx + 2H, Ny + 2H + 1)        # parent layout of a (Center, Face) field
+    check(m, ccall((:gb25_get_metric2, m.lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Int64), m.ptr, id, a, length(a)),
+          "gb25_get_metric2")
+    return a
+end
 
 set_option!(m::Model, opt::Integer, value::Integer) =
     check(m, ccall((:gb25_set_option, m.lib), Cint, (Ptr{Cvoid}, Cint, Int32), m.ptr, opt, value), "gb25_set_option")
