@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--grid-type", default="simple_lat_lon",
                     help="single GPU: gaussian_islands_lat_lon | tripolar | gaussian_islands (the reference's TripolarGrid + "
                          "GridFittedBottom); the headline line is the default, simple_lat_lon")
+    ap.add_argument("--closure", default=None, metavar="NU,KAPPA",
+                    help="VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu), e.g. 1e-4,1e-5 "
+                         "(src/baroclinic_instability_model.jl:31); the headline line is closure = nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timers")
     args = ap.parse_args()
@@ -154,7 +157,9 @@ def main():
         model = SlabModel(gNx, Ny, Nz, dt=args.dt, rank=rank, nranks=world, device=local_rank)
         barrier = dist.barrier
     else:
-        model = gb.baroclinic_instability_model(gb.GPU(local_rank), Nx, Ny, Nz, dt=args.dt, grid_type=args.grid_type)
+        closure = gb.VerticalScalarDiffusivity(*map(float, args.closure.split(","))) if args.closure else None
+        model = gb.baroclinic_instability_model(gb.GPU(local_rank), Nx, Ny, Nz, dt=args.dt, grid_type=args.grid_type,
+                                                closure=closure)
         barrier = lambda: None
     locNx = gNx // world
     b = model.backend

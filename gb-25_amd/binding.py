@@ -33,7 +33,8 @@ ABI_SYMBOLS = [
     "gb25_default_config", "gb25_create", "gb25_destroy", "gb25_last_error_string", "gb25_version",
     "gb25_real_bytes",
     "gb25_set_stream", "gb25_use_own_stream", "gb25_synchronize", "gb25_field_dims", "gb25_set_field", "gb25_get_field",
-    "gb25_field_device_ptr", "gb25_get_metric", "gb25_get_metric2", "gb25_get_substepping", "gb25_set_baroclinic_instability",
+    "gb25_field_device_ptr", "gb25_get_metric", "gb25_get_metric2", "gb25_get_substepping", "gb25_set_vertical_diffusivity",
+    "gb25_get_vertical_diffusivity", "gb25_set_baroclinic_instability",
     "gb25_get_clock", "gb25_set_dt", "gb25_initialize", "gb25_mask_immersed_fields",
     "gb25_fill_halo_regions", "gb25_compute_auxiliaries", "gb25_fill_diffusivity_halos",
     "gb25_compute_momentum_tendencies", "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
@@ -112,6 +113,8 @@ def load_library(float_type="Float32"):
     lib.gb25_field_device_ptr.argtypes = [P, C.c_int, C.POINTER(P)]
     lib.gb25_get_metric.argtypes = [P, C.c_int, C.c_int32, C.POINTER(C.c_double)]
     lib.gb25_get_metric2.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.c_int64]
+    lib.gb25_set_vertical_diffusivity.argtypes = [P, C.c_double, C.c_double]
+    lib.gb25_get_vertical_diffusivity.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.gb25_get_substepping.argtypes = [P, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.gb25_get_clock.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.gb25_set_dt.argtypes = [P, C.c_double]
@@ -229,6 +232,14 @@ class HipBackend:
         v = C.c_double()
         self._call("gb25_get_metric", METRIC_IDS[name], index, C.byref(v))
         return v.value
+
+    def set_vertical_diffusivity(self, nu, kappa):
+        self._call("gb25_set_vertical_diffusivity", float(nu), float(kappa))
+
+    def vertical_diffusivity(self):
+        nu, kappa = C.c_double(), C.c_double()
+        self._call("gb25_get_vertical_diffusivity", C.byref(nu), C.byref(kappa))
+        return nu.value, kappa.value
 
     def metric2(self, name):
         """One horizontal metric of a curvilinear grid (grid_type >= 2): (Nx + 2H, Ny + 2H + 1) float64, [i, j]."""

@@ -127,6 +127,10 @@ struct gb25_model {
   real* d_H[4] = {nullptr, nullptr, nullptr, nullptr};   // Hfc, Hcf, rHfc, rHcf (parent layout of a (c,f) field)
   real* d_wideH[2] = {nullptr, nullptr};                 // Hfc, Hcf on the wide barotropic layout of a slab
   real* d_top_flux[4] = {nullptr, nullptr, nullptr, nullptr};   // FluxBoundaryCondition at the top of u, v, T, S
+  // closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu); both zero: closure = nothing
+  double nu = 0, kappa = 0;
+  real* d_implicit[2] = {nullptr, nullptr};   // elimination tables of the implicit solve for (u, v) and (T, S): lo | 1/beta | gamma
+  double implicit_key[2][2] = {{0, 0}, {0, 0}};   // the (dt, K) they were built for
   bool slab = false;                 // x halos come from a neighbour (nranks > 1, or the self-ring of slab_mode = 1)
   struct SlabGroup* group = nullptr; // exchange context (transport, buffers, comm stream) once gb25_comm_init_* was called
   int group_index = 0;               // this slab's position in group->slabs
@@ -667,8 +671,11 @@ Halo2 halo2_G(gb25_model* m) {   // the barotropic forcing G.U, G.V
   return h;
 }
 // the single-domain producers write the halo cells derived from their output themselves (option FOLD_FILLS) -- not across
-// the zipper fold, whose images live in other threads' columns
-inline bool producers_fold(const gb25_model* m) { return !m->slab && m->fold_fills && !m->g.cv.north_fold; }
+// the zipper fold, whose images live in other threads' columns, and not with a closure (the implicit solve comes after
+// the look-aheads' writes)
+inline bool producers_fold(const gb25_model* m) {
+  return !m->slab && m->fold_fills && !m->g.cv.north_fold && m->nu == 0 && m->kappa == 0;
+}
 // rows of y faces that are stepped: the fold line is one
 inline int v_rows(const Grid& g) { return g.Ny + g.cv.north_fold; }
 
@@ -945,6 +952,86 @@ gb25_status tracers_impl(gb25_model* m) {
   return GB25_OK;
 }
 
+// implicit_step! of a pair of fields (kind 0: u, v with nu, the corrector's column integrals rewritten; 1: T, S with kappa)
+gb25_status implicit_tables(gb25_model* m, int kind, double dt, double K) {
+  if (m->d_implicit[kind] && m->implicit_key[kind][0] == dt && m->implicit_key[kind][1] == K) return GB25_OK;
+  const int Nz = m->cfg.Nz, offk = m->metric_off_k;
+  const std::vector<double>&dzc = m->h_metric[GB25_M_DZC], &dzf = m->h_metric[GB25_M_DZF];
+  // (the spacings as the float type holds them; the chains in fp64, rounded once)
+  auto Dc = [&](int k) { return (double)(real)dzc[offk + k]; };
+  auto Df = [&](int k) { return (double)(real)dzf[offk + k]; };
+  const double dK = (double)(real)dt * (double)(real)K;
+  std::vector<real> tab((size_t)Nz + 2 * (size_t)Nz * Nz, real(0.));
+  real *lo = tab.data(), *rb = lo + Nz, *gm = rb + (size_t)Nz * Nz;
+  for (int k = 1; k < Nz; k++) lo[k] = (real)(-dK / (Dc(k) * Df(k)));
+  for (int kf = 0; kf < Nz; kf++) {
+    double bet = 1.0;
+    for (int k = kf; k < Nz; k++) {
+      const double l = k == kf ? 0.0 : -dK / (Dc(k) * Df(k)), u = k == Nz - 1 ? 0.0 : -dK / (Dc(k) * Df(k + 1));
+      double gk = 0.0;
+      if (k > kf) gk = (-dK / (Dc(k - 1) * Df(k))) / bet;
+      bet = (1.0 - l - u) - l * gk;
+      rb[(size_t)kf * Nz + k] = (real)(1.0 / bet);
+      gm[(size_t)kf * Nz + k] = (real)gk;
+    }
+  }
+  HIPCHK(hipStreamSynchronize(m->stream));   // (a solve with the old tables may still be running)
+  if (!m->d_implicit[kind]) HIPCHK(hipMalloc(&m->d_implicit[kind], tab.size() * sizeof(real)));
+  HIPCHK(hipMemcpy(m->d_implicit[kind], tab.data(), tab.size() * sizeof(real), hipMemcpyHostToDevice));
+  m->implicit_key[kind][0] = dt;
+  m->implicit_key[kind][1] = K;
+  return GB25_OK;
+}
+gb25_status implicit_vertical_impl(gb25_model* m, int kind, real dt) {
+  const Grid& g = m->g;
+  const real K = (real)(kind == 0 ? m->nu : m->kappa);
+  if (K == real(0.)) return GB25_OK;
+  real *a = m->f[kind == 0 ? GB25_U : GB25_T].d, *b = m->f[kind == 0 ? GB25_V : GB25_S].d;
+  real *sa = kind == 0 ? m->colsum[0].d : nullptr, *sb = kind == 0 ? m->colsum[1].d : nullptr;
+  const int kchunks = std::max(1, g.Nz / 12);
+  if (g.Nz <= 128) {   // the column in registers, the elimination factors from tables
+    if (gb25_status s = implicit_tables(m, kind, (double)dt, (double)K)) return s;
+    ImplicitFields A{};
+    const real* t = m->d_implicit[kind];
+    for (int f = 0; f < 2; f++) {
+      A.f[f] = f ? b : a;
+      A.vshape[f] = kind == 0 && f == 1;
+      A.first[f] = kind == 0 ? f : 2;
+      A.lo[f] = t; A.rb[f] = t + g.Nz; A.gm[f] = t + g.Nz + (size_t)g.Nz * g.Nz;
+      A.sum[f] = f ? sb : sa;
+    }
+    const bool imm = m->immersed;
+    void (*kern)(Grid, ImplicitFields, int) =
+        g.Nz <= 32 ? (imm ? k_implicit_vertical_reg<32, true> : k_implicit_vertical_reg<32, false>)
+        : g.Nz <= 48 ? (imm ? k_implicit_vertical_reg<48, true> : k_implicit_vertical_reg<48, false>)
+        : g.Nz <= 64 ? (imm ? k_implicit_vertical_reg<64, true> : k_implicit_vertical_reg<64, false>)
+                     : (imm ? k_implicit_vertical_reg<128, true> : k_implicit_vertical_reg<128, false>);
+    Timed tm(m, kind == 0 ? GB25_K_AB2_VELOCITIES : GB25_K_AB2_TRACERS);   // (accounted with the update it completes)
+    dim3 b(64, 4);
+    hipLaunchKernelGGL(kern, dim3((g.Nx + 63) / 64, ((kind == 0 ? v_rows(g) : g.Ny) + 3) / 4, 2), b, 0, m->stream, g, A, kchunks);
+    LAUNCHCHK();
+    if (kind == 0) m->colsum_valid = true;
+    return GB25_OK;
+  }
+  // deeper columns: the column and the per-thread elimination factors in LDS
+  int T = 256;
+  while (T > 64 && (size_t)(2 * T + 2) * g.Nz * sizeof(real) > 64 * 1024) T /= 2;
+  const size_t lds = (size_t)(2 * T + 2) * g.Nz * sizeof(real);
+  if (lds > 160 * 1024) return fail(m, GB25_ERR_INVALID_ARGUMENT, "the implicit vertical solve keeps a column in LDS: Nz = %d is too deep", g.Nz);
+  auto kern = m->immersed ? k_implicit_vertical<true> : k_implicit_vertical<false>;
+  static bool raised[2] = {false, false};
+  if (lds > 64 * 1024 && !raised[m->immersed ? 1 : 0]) {
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised[m->immersed ? 1 : 0] = true;
+  }
+  Timed tm(m, kind == 0 ? GB25_K_AB2_VELOCITIES : GB25_K_AB2_TRACERS);
+  hipLaunchKernelGGL(kern, dim3((g.Nx + T - 1) / T, kind == 0 ? v_rows(g) : g.Ny, 2), dim3(T), lds, m->stream, g, a, b, kind, K, K,
+                     dt, sa, sb, kchunks);
+  LAUNCHCHK();
+  if (kind == 0) m->colsum_valid = true;
+  return GB25_OK;
+}
+
 gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
   const Grid& g = m->g;
   if (m->ahead_uv_valid && dt == m->ahead_uv_dt && chi == m->ahead_uv_chi) {
@@ -956,7 +1043,7 @@ gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
     }
     m->colsum_valid = true;
     m->ahead_uv_valid = false;
-    return GB25_OK;
+    return implicit_vertical_impl(m, 0, dt);
   }
   m->ahead_uv_valid = false;
   dim3 b(64, 4);
@@ -967,7 +1054,7 @@ gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
                      std::max(1, g.Nz / 12));   // the momentum kernel's chunking (momentum_impl)
   m->colsum_valid = true;
   LAUNCHCHK();
-  return GB25_OK;
+  return implicit_vertical_impl(m, 0, dt);
 }
 gb25_status ab2_tracers_impl(gb25_model* m, real dt, real chi) {
   const Grid& g = m->g;
@@ -976,7 +1063,7 @@ gb25_status ab2_tracers_impl(gb25_model* m, real dt, real chi) {
     std::swap(m->f[GB25_T].d, m->ahead[0].d);
     std::swap(m->f[GB25_S].d, m->ahead[1].d);
     m->ahead_valid = false;
-    return GB25_OK;
+    return implicit_vertical_impl(m, 1, dt);
   }
   m->ahead_valid = false;
   Timed t(m, GB25_K_AB2_TRACERS);
@@ -999,7 +1086,7 @@ gb25_status ab2_tracers_impl(gb25_model* m, real dt, real chi) {
     hipLaunchKernelGGL(k_ab2_tracers1, dim3(blocks), dim3(256), 0, m->stream, T, S, a, bb, c, d, n, dt, C1, C2);
   }
   LAUNCHCHK();
-  return GB25_OK;
+  return implicit_vertical_impl(m, 1, dt);
 }
 gb25_status ab2_local_impl(gb25_model* m, real dt, real chi) {
   gb25_status s = ab2_velocities_impl(m, dt, chi);
@@ -1517,6 +1604,8 @@ void gb25_destroy(gb25_model* m) {
     if (p) hipFree(p);
   for (auto p : m->d_top_flux)
     if (p) hipFree(p);
+  for (auto p : m->d_implicit)
+    if (p) hipFree(p);
   for (int a = 0; a < 2; a++) {
     for (auto& w : m->wide[a])
       if (w.d) hipFree(w.d);
@@ -1733,6 +1822,26 @@ gb25_status gb25_set_dt(gb25_model* m, double dt) {
   CHECK_MODEL(m);
   if (gb25_status s = collective_guard(m, 4, 0, dt)) return s;
   m->last_dt = dt;
+  return GB25_OK;
+}
+
+// closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu) (src/baroclinic_instability_model.jl:
+// 31); nu = kappa = 0 is closure = nothing.  Collective on a decomposed model.
+gb25_status gb25_set_vertical_diffusivity(gb25_model* m, double nu, double kappa) {
+  CHECK_MODEL(m);
+  if (!(nu >= 0) || !(kappa >= 0)) return fail(m, GB25_ERR_INVALID_ARGUMENT, "viscosity and diffusivity must be >= 0");
+  if (gb25_status s = collective_guard(m, 7, 0, nu)) return s;
+  if (gb25_status s = collective_guard(m, 7, 1, kappa)) return s;
+  m->nu = nu;
+  m->kappa = kappa;
+  m->ahead_valid = false;   // (a look-ahead of T, S written with its halos predates the solve)
+  if (!m->slab) m->complete_fills_needed = 2;
+  return GB25_OK;
+}
+gb25_status gb25_get_vertical_diffusivity(const gb25_model* m, double* nu, double* kappa) {
+  if (!m || !nu || !kappa) return GB25_ERR_INVALID_ARGUMENT;
+  *nu = m->nu;
+  *kappa = m->kappa;
   return GB25_OK;
 }
 

@@ -752,6 +752,152 @@ __global__ __launch_bounds__(256) void k_ab2_velocities_finish(Grid g, const rea
   Vsum[o2] = (j == 0) ? real(0.) : t[3];
 }
 
+// =============================================================================================
+// implicit_step!: vertically implicit diffusion after the explicit AB2 update (closure =
+// VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu), GB-25 src/baroclinic_instability_model.jl:31;
+// "batched tridiagonal per column").  (1 - dt d/dz K d/dz) phi = phi*, no flux through the bottom
+// face of the column's first free level and through the top face:
+//   lower_k = -dt K / (dz^c_k dz^f_k),  upper_k = -dt K / (dz^c_k dz^f_{k+1}),  diag_k = 1 - lower_k - upper_k.
+// One thread per column and field, a PAIR of fields per launch (u with v, T with S; blockIdx.z).  Thomas algorithm; every
+// global element is read once and written once -- 2 accesses per cell and field, the compulsory traffic.  The velocity
+// launch also leaves the column integrals of the new u, v for the barotropic corrector, with the chunked association
+// every other producer of those sums uses.  kind 0: (u, v); 1: (T, S).
+// Two kernels: columns of up to 128 levels live in registers (k_implicit_vertical_reg, below: the one that runs at the
+// sizes of BASELINE.json); deeper ones in LDS with per-thread elimination factors ([level][thread], conflict-free;
+// dynamic LDS (2 blockDim.x + 2) Nz reals) -- this kernel.
+// =============================================================================================
+template <bool IMM>
+__global__ __launch_bounds__(256) void k_implicit_vertical(Grid g, real* __restrict__ fa, real* __restrict__ fb, int kind,
+                                                           real Ka, real Kb, real dt, real* __restrict__ sum_a,
+                                                           real* __restrict__ sum_b, int kchunks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int T = blockDim.x, tid = threadIdx.x, Nz = g.Nz, f = blockIdx.z;
+  // LDS: the column [Nz][T], its elimination factors [Nz][T], the per-level coupling tables [2][Nz]
+  real* col = reinterpret_cast<real*>(lds_raw);
+  real* gam = col + (size_t)Nz * T;
+  real* cdn = gam + (size_t)Nz * T;    // cdn[k] = 1 / (dz^c_k dz^f_k): coupling of level k to the level below
+  real* cup = cdn + Nz;                // cup[k] = 1 / (dz^c_k dz^f_{k+1}): to the level above
+  for (int k = tid; k < Nz; k += T) {
+    cdn[k] = real(1.) / (g.dzc[k] * g.dzf[k]);
+    cup[k] = real(1.) / (g.dzc[k] * g.dzf[k + 1]);
+  }
+  __syncthreads();
+  const int i = blockIdx.x * T + tid, j = blockIdx.y;
+  const bool vsh = kind == 0 && f == 1;
+  // rows: cells 0 .. Ny-1; y faces 1 .. Ny-1 and, with the zipper fold, the fold line Ny (the wall faces stay zero)
+  if (i >= g.Nx || (vsh ? (j > g.Ny - 1 + g.cv.north_fold) : (j >= g.Ny))) return;
+  const int o2 = i2(g, i, j);
+  int kf = 0;
+  if (IMM) {
+    const unsigned w = kind == 1 ? g.im.ordA[o2] : g.im.ordC[o2] >> (f == 0 ? 8 : 16);
+    kf = min((int)(w & 255), Nz);
+  }
+  real* F = f ? fb : fa;
+  real* S = f ? sum_b : sum_a;
+  const real dK = dt * (f ? Kb : Ka);
+  const bool solve = dK != real(0.) && kf < Nz && !(vsh && j == 0);
+  if (!solve && S == nullptr) return;
+  const int pl = vsh ? g.pl_v : g.pl_c, o0 = vsh ? iv(g, i, j, 0) : ic(g, i, j, 0);
+#pragma unroll 8
+  for (int k = 0; k < Nz; k++) col[k * T + tid] = F[o0 + k * pl];
+  if (solve) {
+    real rb = real(1.), p = real(0.);   // 1 / beta and the last eliminated value
+    for (int k = kf; k < Nz; k++) {
+      const real up = (k == Nz - 1) ? real(0.) : cup[k];
+      const real lo = (k == kf) ? real(0.) : -(dK * cdn[k]);
+      const real gk = (k == kf) ? real(0.) : -(dK * cup[k - 1]) * rb;       // gamma_k = upper_{k-1} / beta_{k-1}
+      rb = rcp((real(1.) - lo + dK * up) - lo * gk);
+      gam[k * T + tid] = gk;
+      p = (col[k * T + tid] - lo * p) * rb;
+      col[k * T + tid] = p;
+    }
+    // back substitution, the results leave for HBM as they are formed
+    real nxt = col[(Nz - 1) * T + tid];
+    F[o0 + (Nz - 1) * pl] = nxt;
+    for (int k = Nz - 2; k >= kf; k--) {
+      nxt = col[k * T + tid] - gam[(k + 1) * T + tid] * nxt;
+      col[k * T + tid] = nxt;
+      F[o0 + k * pl] = nxt;
+    }
+  }
+  if (S != nullptr) {   // column integral of the new velocity (the corrector's), chunked like every other producer of it
+    const int klen = (Nz + kchunks - 1) / kchunks;
+    real tot = real(0.);
+    for (int k0 = 0; k0 < Nz; k0 += klen) {
+      const int k1 = min(Nz, k0 + klen);
+      real q = real(0.);
+      for (int k = k0; k < k1; k++) q = (k == k0) ? g.dzc[k] * col[k * T + tid] : rfma(g.dzc[k], col[k * T + tid], q);
+      tot = (k0 == 0) ? q : tot + q;
+    }
+    S[o2] = (vsh && j == 0) ? real(0.) : tot;
+  }
+}
+
+// The same solve with the column in REGISTERS (Nz <= NZT, loops fully unrolled: all of a column's loads are in flight at
+// once, 8+ waves per SIMD hide the rest) and the elimination factors from tables: with a constant K they depend on the
+// level and on the column's first free level only, so the host tabulates 1/beta and gamma for every (kfirst, k) once per
+// (dt, K) -- flat bottom: every lane reads the same 2 Nz numbers.  One thread per column AND field (blockIdx.z).
+struct ImplicitFields {
+  real* f[2];
+  int vshape[2];        // v-shaped parent (y faces)
+  int first[2];         // first free level from: 0 = the u-face table, 1 = the v-face table, 2 = the cell table
+  const real* lo[2];    // [Nz]: -dt K / (dz^c_k dz^f_k)
+  const real* rb[2];    // [Nz][Nz]: 1 / beta_k of the chain that starts at level kfirst
+  const real* gm[2];    // [Nz][Nz]: gamma_k of that chain
+  real* sum[2];         // column integral of the result (null: not wanted)
+};
+template <int NZT, bool IMM>
+__global__ __launch_bounds__(256) void k_implicit_vertical_reg(Grid g, ImplicitFields A, int kchunks) {
+  const int f = blockIdx.z, Nz = g.Nz;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  const bool vsh = A.vshape[f] != 0;
+  if (i >= g.Nx || (vsh ? (j > g.Ny - 1 + g.cv.north_fold) : (j >= g.Ny))) return;
+  const int o2 = i2(g, i, j);
+  int kf = 0;
+  if (IMM) {
+    const unsigned w = A.first[f] == 2 ? g.im.ordA[o2] : g.im.ordC[o2] >> (A.first[f] == 0 ? 8 : 16);
+    kf = min((int)(w & 255), Nz);
+  }
+  real* F = A.f[f];
+  const int pl = vsh ? g.pl_v : g.pl_c, o0 = vsh ? iv(g, i, j, 0) : ic(g, i, j, 0);
+  real x[NZT];
+#pragma unroll
+  for (int k = 0; k < NZT; k++) x[k] = (k < Nz) ? F[o0 + k * pl] : real(0.);
+  if (kf < Nz && !(vsh && j == 0)) {
+    const real* rb = A.rb[f] + kf * Nz;
+    const real* gm = A.gm[f] + kf * Nz;
+    const real* lo = A.lo[f];
+    real p = real(0.);
+#pragma unroll
+    for (int k = 0; k < NZT; k++)
+      if (k < Nz && k >= kf) {
+        p = (k == kf ? x[k] : x[k] - lo[k] * p) * rb[k];
+        x[k] = p;
+      }
+#pragma unroll
+    for (int k = NZT - 2; k >= 0; k--)
+      if (k < Nz - 1 && k >= kf) x[k] = x[k] - gm[k + 1] * x[k + 1];
+#pragma unroll
+    for (int k = 0; k < NZT; k++)
+      if (k < Nz && k >= kf) F[o0 + k * pl] = x[k];
+  }
+  if (A.sum[f] != nullptr) {
+    const int klen = (Nz + kchunks - 1) / kchunks;
+    real tot = real(0.), p = real(0.);
+    int kk = 0;   // position inside the chunk
+#pragma unroll
+    for (int k = 0; k < NZT; k++)
+      if (k < Nz) {
+        p = (kk == 0) ? g.dzc[k] * x[k] : rfma(g.dzc[k], x[k], p);
+        if (++kk == klen || k == Nz - 1) {
+          tot = (k < klen) ? p : tot + p;
+          kk = 0;
+        }
+      }
+    A.sum[f][o2] = (vsh && j == 0) ? real(0.) : tot;
+  }
+}
+
 // tracers: flat AXPY over the interior planes of a parent array (G halos are identically zero)
 using realx4 = __attribute__((ext_vector_type(4))) real;
 template <bool NT>

@@ -146,8 +146,17 @@ def resolution_to_points(resolution):
     return int(Nx), int(Ny)
 
 
+class VerticalScalarDiffusivity:
+    """closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), κ=1e-5, ν=1e-4), the alternative the
+    reference keeps next to `closure = nothing` (src/baroclinic_instability_model.jl:29-31): constant vertical viscosity
+    ν and diffusivity κ, stepped implicitly (one tridiagonal solve per column and field after the AB2 update)."""
+
+    def __init__(self, nu=1e-4, kappa=1e-5):
+        self.nu, self.kappa = float(nu), float(kappa)
+
+
 def baroclinic_instability_model(arch, Nx=None, Ny=None, Nz=None, *, dt, halo=(8, 8, 8), grid_type="simple_lat_lon",
-                                 substeps=30, resolution=None, **backend_kw):
+                                 substeps=30, resolution=None, closure=None, **backend_kw):
     """baroclinic_instability_model(arch, Nx, Ny, Nz; dt, halo, grid_type, free_surface=SplitExplicit(substeps))
     -- src/baroclinic_instability_model.jl:12-85.  `arch` is a backend factory: GPU() from this package
     (or, in tests only, an oracle-backed factory).  Physics is fixed to the reference defaults:
@@ -173,6 +182,11 @@ def baroclinic_instability_model(arch, Nx=None, Ny=None, Nz=None, *, dt, halo=(8
     backend = arch(Nx, Ny, Nz, dt=dt, halo=H, substeps=substeps, **backend_kw)
     model = HydrostaticFreeSurfaceModel(backend, Nx, Ny, Nz, H)
     model.free_surface.substeps = substeps
+    model.closure = closure
+    if closure is not None:
+        if not isinstance(closure, VerticalScalarDiffusivity):
+            raise NotImplementedError("closures: None or VerticalScalarDiffusivity(nu, kappa) (CATKE is SURVEY section 8f.2)")
+        backend.set_vertical_diffusivity(closure.nu, closure.kappa)
     return model
 
 

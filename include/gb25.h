@@ -195,6 +195,13 @@ gb25_status gb25_get_bottom_info(const gb25_model *m, int32_t which, int32_t i, 
  *      the default no-flux condition.  The top cell's tendency gets -J/dz inside the tendency kernels. */
 gb25_status gb25_set_top_flux(gb25_model *m, gb25_field f, const void *flux);
 
+/* ---- closure: `closure = nothing` (the default, src/baroclinic_instability_model.jl:29) or
+ *      VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), κ = kappa, ν = nu) (:31): after the explicit AB2
+ *      update of u, v (nu) and T, S (kappa), ab2_step! solves (1 - Δt ∂z K ∂z) φ = φ* per column (implicit_step!, batched
+ *      tridiagonal solver).  nu = kappa = 0 restores closure = nothing.  [m²/s] */
+gb25_status gb25_set_vertical_diffusivity(gb25_model *m, double nu, double kappa);
+gb25_status gb25_get_vertical_diffusivity(const gb25_model *m, double *nu, double *kappa);
+
 /* ---- initial conditions: set_baroclinic_instability!(model) (src/model_utils.jl:99-127) */
 gb25_status gb25_set_baroclinic_instability(gb25_model *m);
 

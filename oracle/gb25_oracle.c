@@ -90,6 +90,9 @@ typedef struct {
   REAL *top_flux[4];
   /* orthogonal curvilinear grid: 2-D metrics (see the macros above), cell-centre latitude for the initial condition,
    * and the topology of the northern edge: 0 = wall (Bounded), 1 = zipper fold (the tripolar grid) */
+  /* closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu)
+   * (/root/reference/src/baroclinic_instability_model.jl:31); both zero: closure = nothing */
+  REAL nu, kappa;
   int curv, north_fold;
   REAL *dxfc2, *dxcc2, *dxcf2, *dxff2, *dyfc2, *dycc2, *dycf2, *dyff2, *azcc2, *azfc2, *azcf2, *azff2, *fff2, *phicc2;
   double *lamcc_d, *phicc_d; /* cell-centre coordinates in degrees (double), interior Nx x Ny, for analytic bottoms */
@@ -453,7 +456,7 @@ static void build_substeps(model *m, int substeps) {
 
 /* ---------------------------------------------------------------- lifecycle */
 void *FN(create)(const gb25o_config *c) {
-  if (c->substeps > MAX_SUBSTEPS || c->Nx < 8 || c->Ny < 8 || c->Nz < 4 || c->H < 4) return NULL;
+  if (c->substeps > MAX_SUBSTEPS || c->Nx < 8 || c->Ny < 8 || c->Nz < 4 || c->Nz > 500 || c->H < 4) return NULL;
   model *m = (model *)calloc(1, sizeof(model));
   m->Nx = c->Nx; m->Ny = c->Ny; m->Nz = c->Nz; m->H = c->H;
   m->dt = (REAL)c->dt; m->chi = (REAL)c->chi; m->g = (REAL)c->g;
@@ -1073,6 +1076,59 @@ void FN(update_state)(void *h) {
   FN(compute_tendencies)(h);
 }
 
+/* ---------------------------------------------------------------- vertically implicit diffusion
+ * implicit_step!(field, implicit_solver, closure, ...) after the explicit AB2 update of each prognostic field
+ * (Oceananigans TimeSteppers / TurbulenceClosures.vertically_implicit_diffusion_solver, restated [UPSTREAM-UNVERIFIED]):
+ * solve (1 - dt d/dz K d/dz) phi_new = phi_star per column with the batched tridiagonal (Thomas) solver,
+ *   lower_k = -dt K^f_k     / (dz^c_k dz^f_k)      (face k: between cells k-1 and k)
+ *   upper_k = -dt K^f_{k+1} / (dz^c_k dz^f_{k+1})
+ *   diag_k  = 1 - lower_k - upper_k,
+ * no flux through the bottom face of the first free level and through the top face (flux boundary conditions enter the
+ * explicit tendency, compute_boundary_tendencies).  kfirst (1-based): first level of the column that is solved; levels
+ * below it (immersed cells, faces that touch the solid) are left alone. */
+static void implicit_column(const model *m, REAL *col, long stride, int kfirst, REAL K, REAL dt) {
+  int Nz = m->Nz;
+  if (kfirst > Nz || K == 0) return;
+  REAL gam[512], bet = 1, prev = 0;
+  for (int k = kfirst; k <= Nz; k++) {
+    REAL lo = (k == kfirst) ? 0 : -dt * K / (DZC(k) * DZF(k));
+    REAL up = (k == Nz) ? 0 : -dt * K / (DZC(k) * DZF(k + 1));
+    REAL dg = (REAL)1 - lo - up;
+    if (k == kfirst) {
+      bet = dg;
+      prev = col[(k - 1) * stride] / bet;
+    } else {
+      REAL up_below = -dt * K / (DZC(k - 1) * DZF(k));   /* upper coefficient of the level below */
+      gam[k] = up_below / bet;
+      bet = dg - lo * gam[k];
+      prev = (col[(k - 1) * stride] - lo * prev) / bet;
+    }
+    col[(k - 1) * stride] = prev;
+  }
+  for (int k = Nz - 1; k >= kfirst; k--) col[(k - 1) * stride] -= gam[k + 1] * col[k * stride];
+}
+/* first level (1-based) from which the column of field `which` (0 u, 1 v, 2 tracers) at (i, j) is free */
+static int first_free_level(const model *m, int which, int i, int j) {
+  int k = 1;
+  while (k <= m->Nz && (which == 0 ? peripheral_u(m, i, j, k) : which == 1 ? peripheral_v(m, i, j, k) : inactive_cell(m, i, j, k))) k++;
+  return k;
+}
+static void implicit_step_field(model *m, int id, int which, REAL K, REAL dt) {
+  if (K == 0) return;
+  const fld *F = &m->f[id];
+  long stride = (long)F->sx * F->sy;
+  int nyrows = (which == 1) ? NYV : m->Ny;
+#pragma omp parallel for schedule(static)
+  for (int j = (which == 1 ? 2 : 1); j <= nyrows; j++)   /* (v on the southern wall face stays zero) */
+    for (int i = 1; i <= m->Nx; i++)
+      implicit_column(m, &A3(id, i, j, 1), stride, first_free_level(m, which, i, j), K, dt);
+}
+void FN(set_vertical_diffusivity)(void *h, double nu, double kappa) {
+  model *m = (model *)h;
+  m->nu = (REAL)nu;
+  m->kappa = (REAL)kappa;
+}
+
 /* ---------------------------------------------------------------- AB2 + free surface
  * ab2_step!(model, dt) -- /root/reference/src/precompile.jl:39,121-123 (appendix A.4, A.7). */
 static void barotropic_mode(model *m, int idU, int idV) {
@@ -1198,8 +1254,12 @@ void FN(ab2_step)(void *h, double dt_, int euler) {
   free_surface_tendency(m, chi);
   ab2_field(m, F_U, F_GNU, F_GMU, dt, chi, 1);
   ab2_field(m, F_V, F_GNV, F_GMV, dt, chi, 1);
+  implicit_step_field(m, F_U, 0, m->nu, dt);      /* ab2_step_velocities!: explicit update, then implicit_step! */
+  implicit_step_field(m, F_V, 1, m->nu, dt);
   ab2_field(m, F_T, F_GNT, F_GMT, dt, chi, 0);
   ab2_field(m, F_S, F_GNS, F_GMS, dt, chi, 0);
+  implicit_step_field(m, F_T, 2, m->kappa, dt);
+  implicit_step_field(m, F_S, 2, m->kappa, dt);
   step_free_surface(m, dt);
 }
 /* correct_velocities_and_cache_previous_tendencies!(model, dt) --

@@ -156,6 +156,12 @@ class OracleBackend:
     def metric(self, name, index):
         return self._fn("metric")(self.h, METRIC_IDS[name], index)
 
+    def set_vertical_diffusivity(self, nu, kappa):
+        f = self._fn("set_vertical_diffusivity")
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        f(self.h, float(nu), float(kappa))
+
     def metric2(self, name, i, j):
         """2-D metric at the 1-based logical (i, j): dxfc dxcc dxcf dxff dyfc dycc dycf dyff azcc azfc azcf azff fff phicc."""
         ids = ["dxfc", "dxcc", "dxcf", "dxff", "dyfc", "dycc", "dycf", "dyff", "azcc", "azfc", "azcf", "azff", "fff", "phicc"]
