@@ -16,7 +16,7 @@ export Config, Model, create, destroy!, first_time_step!, time_step!, loop!, ini
        fill_halo_regions!, compute_auxiliaries!, compute_tendencies!, ab2_step!, mask_immersed_fields!,
        correct_velocities_and_cache_previous_tendencies!, set_baroclinic_instability!, synchronize,
        parent_array, interior_array, set_parent!, set_interior!, clock, set_dt!, set_option!, get_option,
-       comm_unique_id, comm_init_rccl!, comm_finalize!, set_top_flux!, set_bottom_height!, metric2, FIELD, OPTION, METRIC2
+       comm_unique_id, comm_init_rccl!, comm_finalize!, set_top_flux!, set_bottom_height!, set_vertical_diffusivity!, metric2, FIELD, OPTION, METRIC2
 
 # One library per Oceananigans float type (src/arg_parsing.jl:12-16): Float32 -> libgb25hip.so, Float64 ->
 # libgb25hip_f64.so; same symbols, gb25_real_bytes() tells them apart.
@@ -150,6 +150,11 @@ function set_top_flux!(m::Model{FT}, field::Integer, J::Union{Nothing, AbstractM
     GC.@preserve a check(m, ccall((:gb25_set_top_flux, m.lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), m.ptr, field, p),
                          "gb25_set_top_flux")
 end
+# closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), κ, ν) (src/baroclinic_instability_model.jl:31);
+# ν = κ = 0: closure = nothing
+set_vertical_diffusivity!(m::Model; ν::Real = 0, κ::Real = 0) =
+    check(m, ccall((:gb25_set_vertical_diffusivity, m.lib), Cint, (Ptr{Cvoid}, Float64, Float64), m.ptr, ν, κ),
+          "gb25_set_vertical_diffusivity")
 # GridFittedBottom(bottom_height): heights at the cell centres of the interior columns, (Nx, Ny)
 set_bottom_height!(m::Model, zb::AbstractMatrix) =
     check(m, ccall((:gb25_set_bottom_height, m.lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), m.ptr, convert(Matrix{Float64}, zb)),
