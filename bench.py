@@ -103,8 +103,8 @@ def cpu_baseline(Nx, Ny, Nz, dt, budget_s=25.0, max_steps=50, grid_type="simple_
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, nargs=3, default=[1440, 720, 48], metavar=("Nx", "Ny", "Nz"))
     ap.add_argument("--dt", type=float, default=240.0)
     ap.add_argument("--weak", action="store_true", help="N > 1: every rank a full --size slab of an N times wider grid")

@@ -53,6 +53,13 @@ struct Curv {
   int on, north_fold;
 };
 
+// The barotropic correction of the current step when it is applied inside the kernels that read u and v instead of by a
+// sweep over them (k_corrector_2d, kernels.hpp): 2-D, parent layout of a (c,f) field; u = u_mem + du, v = v_mem + dv on
+// the levels the fills write.
+struct LazyCorr {
+  const real *du, *dv;
+};
+
 struct Grid {
   int Nx, Ny, Nz, H;      // LOCAL interior size and halo
   int sx;                 // row pitch          = Nx + 2H

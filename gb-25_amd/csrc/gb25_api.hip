@@ -127,6 +127,11 @@ struct gb25_model {
   real* d_H[4] = {nullptr, nullptr, nullptr, nullptr};   // Hfc, Hcf, rHfc, rHcf (parent layout of a (c,f) field)
   real* d_wideH[2] = {nullptr, nullptr};                 // Hfc, Hcf on the wide barotropic layout of a slab
   real* d_top_flux[4] = {nullptr, nullptr, nullptr, nullptr};   // FluxBoundaryCondition at the top of u, v, T, S
+  // the corrector applied inside its consumers (k_corrector_2d): du, dv of the current step; while uv_lazy is set, u and
+  // v in memory lack them (only between the steps of one composite call: gb25_loop applies them before it returns)
+  Field corr[2];
+  bool uv_lazy = false;
+  int lazy_corrector = 1;            // option LAZY_CORRECTOR
   // closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu); both zero: closure = nothing
   double nu = 0, kappa = 0;
   real* d_implicit[2] = {nullptr, nullptr};   // elimination tables of the implicit solve for (u, v) and (T, S): lo | 1/beta | gamma
@@ -766,8 +771,12 @@ gb25_status compute_w_impl(gb25_model* m, int part = 0) {
   const int ey = g.Ny + 2 * g.H - 2;
   // narrow strips: 16 columns x 16 rows per block instead of 64 x 4 (a 64-wide block would be three-quarters empty)
   dim3 b = (na + nbcols) >= 64 ? dim3(64, 4) : dim3(16, 16);
-  hipLaunchKernelGGL(g.cv.on ? k_compute_w<true> : k_compute_w<false>, grid2(na + nbcols, ey, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                     m->f[GB25_W].d, ia, na, ib, nbcols);
+  const LazyCorr lz{m->corr[0].d, m->corr[1].d};
+  auto kw = k_compute_w<false, false>;
+  if (m->uv_lazy) kw = k_compute_w<false, true>;
+  else if (g.cv.on) kw = k_compute_w<true, false>;
+  hipLaunchKernelGGL(kw, grid2(na + nbcols, ey, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_W].d, ia,
+                     na, ib, nbcols, lz);
   LAUNCHCHK();
   return GB25_OK;
 }
@@ -869,13 +878,18 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
       nx.P = m->uv_partials;
       nx.dt = dt; nx.C1 = real(1.5) + chi; nx.C2 = real(0.5) + chi;
       nx.plane2 = g.sx * g.sy_v;
+      nx.fold = (producers_fold(m) && !m->immersed) ? 1 : 0;   // (with a bottom the corrector's own halo writes do it)
     }
-    auto k5 = g.cv.on ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true, true>)
+    const LazyCorr lz{m->corr[0].d, m->corr[1].d};
+    if (m->uv_lazy && !(ahead && nx.fold && part == 0))
+      return fail(m, GB25_ERR_STATE, "internal: uncorrected velocities in a step whose momentum kernel cannot correct them");
+    auto k5 = (m->uv_lazy && ahead) ? k_momentum_tendencies_v5<MW, TYm, true, false, false, true>
+              : g.cv.on ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true, true>)
               : m->immersed ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true>)
                             : (ahead ? k_momentum_tendencies_v5<MW, TYm, true, false> : k_momentum_tendencies_v5<MW, TYm, false, false>);
     if (nb > 0)
       hipLaunchKernelGGL(k5, dim3(nb), dim3(V2_TX, TYm), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                         m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, tc, kchunks, nb, nx);
+                         m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, tc, kchunks, nb, nx, lz);
     t.stop();   // the timer covers the tendency kernel alone
     if (ahead && part != 1) {
       dim3 b(64, 4);
@@ -925,7 +939,11 @@ gb25_status tracers_impl(gb25_model* m) {
       nx.C1 = real(1.5) + (real)m->cfg.chi; nx.C2 = real(0.5) + (real)m->cfg.chi;
     }
     const bool fold = ahead && producers_fold(m);
-    auto kern = g.cv.on ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false, true>)
+    const LazyCorr lz{m->corr[0].d, m->corr[1].d};
+    if (m->uv_lazy && !(ahead && fold))
+      return fail(m, GB25_ERR_STATE, "internal: uncorrected velocities in a step whose tracer kernel cannot correct them");
+    auto kern = (m->uv_lazy && ahead && fold) ? k_tracer_tendencies_v5<TW, true, false, true, false, true>
+                : g.cv.on ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false, true>)
                                  : k_tracer_tendencies_v5<TW, false, true, false, true>)
                 : m->immersed ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false>)
                                      : k_tracer_tendencies_v5<TW, false, true, false>)
@@ -934,7 +952,7 @@ gb25_status tracers_impl(gb25_model* m) {
     m->ahead_ts_folded = fold;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64, 4), 0, m->stream, g, m->f[GB25_U].d,
                        m->f[GB25_V].d, m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d,
-                       m->f[GB25_GN_S].d, nbx, kchunks, nb, nx);
+                       m->f[GB25_GN_S].d, nbx, kchunks, nb, nx, lz);
     LAUNCHCHK();
     m->ahead_valid = ahead;
     m->ahead_dt = nx.dt;
@@ -1285,12 +1303,30 @@ gb25_status ab2_step_impl(gb25_model* m, double dt, int euler) {
   return barotropic_impl(m, (real)dt);
 }
 
+// u, v <- u + du, v + dv: ends the state in which the corrector lives inside its consumers (before a composite call returns)
+gb25_status materialize_uv(gb25_model* m) {
+  if (!m->uv_lazy) return GB25_OK;
+  const Grid& g = m->g;
+  dim3 b(64, 4);
+  hipLaunchKernelGGL(k_apply_correction, grid2(g.sx, g.sy_v, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                     LazyCorr{m->corr[0].d, m->corr[1].d});
+  LAUNCHCHK();
+  m->uv_lazy = false;
+  return GB25_OK;
+}
+// may this step leave u, v uncorrected in memory?  Flat lat-lon single domain, both look-aheads on and able to write
+// their halos, the default kernels; `more`: another step of the same composite call follows
+inline bool lazy_corrector_ok(const gb25_model* m) {
+  return m->lazy_corrector && m->two_streams && producers_fold(m) && !m->immersed && !m->g.cv.on && m->kernel_gen >= 2 &&
+         m->ab2_ahead == 1 && !m->ptr_exposed && m->pressure_bits == 64;
+}
+
 // One time step on a single slab.  Two HIP streams: the tracer branch (AB2 of T,S -> their halos -> hydrostatic
 // pressure: HBM- then fp64-bound) is independent of the velocity branch (AB2 of u,v -> split-explicit sub-cycle,
 // which is latency-bound -> halos -> corrector -> halos -> w) until the tendencies need both, so it runs on a
 // side stream and overlaps.  The phase order within each branch is the reference's (src/precompile.jl:31-42);
 // T and S are untouched between the two halo fills of the reference sequence, so they are filled once.
-gb25_status time_step_impl(gb25_model* m, int euler) {
+gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
   gb25_status s;
   const double dt = m->last_dt;
   struct Composite {
@@ -1299,6 +1335,7 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
     ~Composite() { m->composite = false; }
   } composite_scope(m);
   if (!m->two_streams) {
+    if ((s = materialize_uv(m))) return s;
     if ((s = ab2_step_impl(m, dt, euler))) return s;
     m->time += dt;
     m->iteration += 1;
@@ -1312,6 +1349,10 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   const bool adopted = m->ahead_uv_valid && (real)dt == m->ahead_uv_dt && chi == m->ahead_uv_chi;
   const bool baro_adopted = adopted && m->ahead_baro_valid;   // (made from that very look-ahead, same dt)
   m->ahead_baro_valid = false;
+  // The corrector inside its consumers: when everything this step needs was made ahead of time (u, v, the sub-cycle) and
+  // another step follows, no sweep over u and v at all -- a 2-D kernel leaves du, dv and w, the tendency kernels add them.
+  const bool lazy = more && adopted && baro_adopted && m->complete_fills_needed == 0 && lazy_corrector_ok(m);
+  if (!lazy && (s = materialize_uv(m))) return s;   // (the stand-alone kernels below expect corrected velocities)
   if ((s = ab2_velocities_impl(m, (real)dt, chi))) return s;
   Halo2 hG = halo2_G(m);
   // the sub-cycle reads G.U, G.V at interior points only (periodic wrap and walls are in the kernel): their halo
@@ -1353,10 +1394,23 @@ gb25_status time_step_impl(gb25_model* m, int euler) {
   // The reference fills the halos of u, v, eta, U, V here as well as after the corrector.  On a single slab the
   // corrector reads and writes its own columns only, and the fill after it rewrites exactly the same halo cells from
   // the corrected interior, so the first fill has no effect on any later value: it is left out (3 launches).
-  if ((s = corrector_impl(m, true))) return s;
+  if (lazy) {
+    const Grid& g = m->g;
+    dim3 b(64, 4);
+    Timed t(m, GB25_K_CORRECTOR);
+    hipLaunchKernelGGL(k_corrector_2d, grid2(g.Nx, g.Ny + 1, b), b, 0, main, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
+                       m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d);
+    LAUNCHCHK();
+    m->uv_lazy = true;
+    m->colsum_valid = false;
+    for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);   // cache_previous_tendencies!
+    m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+  } else if ((s = corrector_impl(m, true))) {
+    return s;
+  }
   {
     // u, v and eta, U, V -- whatever their last writers (the corrector, the sub-cycle's last launch) did not fill
-    const bool uv_fresh = producers_fold(m) && m->composite && !complete;
+    const bool uv_fresh = lazy || (producers_fold(m) && m->composite && !complete);
     const int which = (uv_fresh ? 0 : 1) | ((eta_halos_fresh && !complete) ? 0 : 2);
     if (which && (s = fill_halos_impl(m, true, false, which, 1))) return s;
   }
@@ -1536,6 +1590,8 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     HIPCHK(hipMalloc(&m->uv_partials, np * sizeof(real)));
     HIPCHK(hipMemset(m->uv_partials, 0, np * sizeof(real)));
   }
+  if ((s = alloc_field(m, m->corr[0], sx, m->f[GB25_BT_V].ny, 1))) return s;
+  if ((s = alloc_field(m, m->corr[1], sx, m->f[GB25_BT_V].ny, 1))) return s;
   if ((s = alloc_field(m, m->colsum[0], sx, m->f[GB25_BT_U].ny, 1))) return s;
   if ((s = alloc_field(m, m->colsum[1], sx, m->f[GB25_BT_V].ny, 1))) return s;
   if (m->slab) {
@@ -1591,6 +1647,8 @@ void gb25_destroy(gb25_model* m) {
       if (p->d) hipFree(p->d);
   if (m->bars_ahead) hipFree(m->bars_ahead);
   for (auto& p : m->colsum)
+    if (p.d) hipFree(p.d);
+  for (auto& p : m->corr)
     if (p.d) hipFree(p.d);
   for (int q = 0; q < 2; q++)
     for (Field* p : {&m->ahead[q], &m->ahead_uv[q], &m->ahead_G[q], &m->ahead_colsum[q]})
@@ -1992,6 +2050,7 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
       m->fold_fills = v != 0;
       m->complete_fills_needed = 2;
       return GB25_OK;
+    case GB25_OPT_LAZY_CORRECTOR: m->lazy_corrector = v != 0; return GB25_OK;
     case GB25_OPT_IMMERSED_KERNELS:
       // 1: run the immersed-boundary kernel variants even where nothing is immersed (they must then give the bits of
       // the plain ones: tests); 0: back to the choice the bottom makes
@@ -2023,6 +2082,7 @@ gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
     case GB25_OPT_PRESSURE_PRECISION: *v = m->pressure_bits; break;
     case GB25_OPT_IMMERSED_KERNELS: *v = m->immersed; break;
     case GB25_OPT_FOLD_FILLS: *v = m->fold_fills; break;
+    case GB25_OPT_LAZY_CORRECTOR: *v = m->lazy_corrector; break;
     default: return GB25_ERR_INVALID_ARGUMENT;
   }
   return GB25_OK;
@@ -2120,8 +2180,8 @@ gb25_status gb25_loop(gb25_model* m, int32_t n) {
     return GB25_OK;
   }
   for (int it = 0; it < n; it++)
-    if (gb25_status s = time_step_impl(m, 0)) return s;
-  return GB25_OK;
+    if (gb25_status s = time_step_impl(m, 0, it + 1 < n)) return s;
+  return materialize_uv(m);   // (no-op unless the last steps kept the corrector inside its consumers)
 }
 
 gb25_status gb25_lookahead_state(const gb25_model* m, int32_t* velocities_ready, int32_t* subcycle_adopted) {

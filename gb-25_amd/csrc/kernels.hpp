@@ -286,9 +286,11 @@ __global__ void k_fill_fused(Grid g, Halo3 f3, Halo2 f2, int nbx, int nb_yz, int
 // Columns [i_first, i_first + n_a) and, after them, [i_first_b, i_first_b + n_b): the whole extended range in one piece,
 // or (slab of a decomposition) the own columns while the x-halo bundle travels and the two edge strips afterwards.
 // CURV: orthogonal curvilinear grid, the four face lengths of the column from the 2-D metric arrays.
-template <bool CURV>
+// LAZY: u, v in memory lack the barotropic correction of this step; it is added on the fly (LazyCorr, below).
+template <bool CURV, bool LAZY = false>
 __global__ __launch_bounds__(256) void k_compute_w(Grid g, const real* __restrict__ u, const real* __restrict__ v,
-                                                   real* __restrict__ w, int i_first, int n_a, int i_first_b, int n_b) {
+                                                   real* __restrict__ w, int i_first, int n_a, int i_first_b, int n_b,
+                                                   LazyCorr lz) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = t < n_a ? i_first + t : i_first_b + (t - n_a);
   int j = blockIdx.y * blockDim.y + threadIdx.y - g.H + 1;
@@ -300,10 +302,16 @@ __global__ __launch_bounds__(256) void k_compute_w(Grid g, const real* __restric
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
   real wk = real(0.);
   w[o] = real(0.);
+  real due = real(0.), duw = real(0.), dvn = real(0.), dvs = real(0.);
+  if (LAZY) {
+    due = lz.du[o2 + 1]; duw = lz.du[o2];
+    dvn = lz.dv[o2 + g.sx]; dvs = lz.dv[o2];
+  }
 #pragma unroll 4
   for (int k = 0; k < g.Nz; k++) {
     real dz = g.dzc[k];
-    real div = (dye * dz * u[o + 1] - dyw * dz * u[o]) + (dxn * dz * v[ov + g.sx] - dxs * dz * v[ov]);
+    real div = LAZY ? (dye * dz * (u[o + 1] + due) - dyw * dz * (u[o] + duw)) + (dxn * dz * (v[ov + g.sx] + dvn) - dxs * dz * (v[ov] + dvs))
+                    : (dye * dz * u[o + 1] - dyw * dz * u[o]) + (dxn * dz * v[ov + g.sx] - dxs * dz * v[ov]);
     wk = wk - div * raz;
     o += g.pl_c;
     ov += g.pl_v;
@@ -1065,8 +1073,10 @@ struct BaroMulti {
   // eta, U, V (periodic x images, y layer, zero on the wall faces of V): no fill launch for them in the step
   int fold;
 };
+// (3 waves per SIMD: at 1440x720 the launch has 540 blocks; with the 173 VGPRs the 7-substep variant took when left alone
+// only two blocks fit a CU, 512 on the chip, and the last 28 blocks were a second round that doubled the launch time)
 template <int BT_S, int BT_TY, bool IMM>
-__global__ __launch_bounds__(BT_NT) void k_barotropic_multi(Grid g, BaroMulti bm, real dtau) {
+__global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi(Grid g, BaroMulti bm, real dtau) {
   constexpr int BT_RX = BT_TX + 2 * BT_S, BT_RY = BT_TY + 2 * BT_S, BT_NP = BT_RX * BT_RY;
   constexpr int BT_PPT = (BT_NP + BT_NT - 1) / BT_NT;
   __shared__ real E[BT_RY][BT_RX], U[BT_RY][BT_RX], V[BT_RY][BT_RX], GUs[BT_RY][BT_RX], GVs[BT_RY][BT_RX];
@@ -1274,6 +1284,53 @@ __global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const real* __r
   if (j < g.Ny) U[i2(g, i, j)] = su;
   V[i2(g, i, j)] = sv;
 }
+// The corrector applied INSIDE its consumers (single periodic domain, flat lat-lon grid, composite steps): the
+// correction u += (U - Ubar) / H is the same number for every level of a column, so instead of a sweep over u and v
+// (2R + 2W per cell: 0.8 GB at 1440x720x48) this 2-D kernel leaves du = (U - Ubar) / H and dv (with the halo cells the
+// fills would derive: periodic x images, the y layer of du, zero on the wall faces of dv), and the three kernels that read
+// u, v in a step -- w, the momentum tendencies (which also produce the next u, v), the tracer tendencies -- add it as they
+// load.  Memory then holds the uncorrected velocities until the composite call returns (k_apply_correction).
+// Same operands, same additions: the same bits as the sweep.
+__global__ __launch_bounds__(256) void k_corrector_2d(Grid g, const real* __restrict__ U, const real* __restrict__ V,
+                                                      const real* __restrict__ Usum, const real* __restrict__ Vsum,
+                                                      real* __restrict__ Ub, real* __restrict__ Vb, real* __restrict__ du,
+                                                      real* __restrict__ dv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j > g.Ny) return;
+  const int o2 = i2(g, i, j);
+  const bool xw = i < g.H, xe = i >= g.Nx - g.H;
+  if (j == g.Ny) {   // the northern wall face of v
+    store_x_images(g, dv, o2, real(0.), xw, xe);
+    return;
+  }
+  const real su = Usum[o2], sv = Vsum[o2];
+  Ub[o2] = su;
+  Vb[o2] = sv;
+  const real a = (U[o2] - su) * g.rLz, b = j == 0 ? real(0.) : (V[o2] - sv) * g.rLz;
+  store_x_images(g, du, o2, a, xw, xe);
+  store_x_images(g, dv, o2, b, xw, xe);
+  if (j == 0) store_x_images(g, du, o2 - g.sx, a, xw, xe);
+  if (j == g.Ny - 1) store_x_images(g, du, o2 + g.sx, a, xw, xe);
+}
+// u += du, v += dv over the whole parent extent in x and y, levels -1 .. Nz: what the consumers saw becomes what memory holds
+__global__ __launch_bounds__(256) void k_apply_correction(Grid g, real* __restrict__ u, real* __restrict__ v, LazyCorr lz) {
+  const int ip = blockIdx.x * blockDim.x + threadIdx.x, jp = blockIdx.y * blockDim.y + threadIdx.y;   // parent indices
+  if (ip >= g.sx || jp >= g.sy_v) return;
+  const int o2 = ip + g.sx * jp;
+  const real a = lz.du[o2], b = lz.dv[o2];
+  // (the y layer has no bottom / top layer of its own: the fills never write those corner cells)
+  const bool ylayer = jp < g.H || jp >= g.H + g.Ny;
+  const int klo = ylayer ? 0 : -1, khi = ylayer ? g.Nz - 1 : g.Nz;
+  if (a != real(0.) && jp < g.sy_c) {
+    int o = ip + g.sx * jp + g.pl_c * (g.H + klo);
+    for (int k = klo; k <= khi; k++, o += g.pl_c) u[o] = u[o] + a;
+  }
+  if (b != real(0.)) {
+    int o = ip + g.sx * jp + g.pl_v * (g.H + klo);
+    for (int k = klo; k <= khi; k++, o += g.pl_v) v[o] = v[o] + b;
+  }
+}
+
 // Ubar,Vbar <- column integrals of u,v (work arrays, as in the reference), then
 // u += (U - Ubar)/H, v += (V - Vbar)/H.  The second sweep re-reads the column from L2.
 // Columns [i0, i0+ni): a slab of a multi-GPU run also corrects its x-halo columns (same arithmetic as the

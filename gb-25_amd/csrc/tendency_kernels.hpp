@@ -45,6 +45,11 @@ struct MomentumMetricLds {
   real razff[MD_Y][MD_X];
 };
 struct NoLds { char unused; };
+// LAZY: the barotropic corrections of the u / v tile (k-independent), staged once per block
+template <int V2_TY>
+struct MomentumCorrLds {
+  real du[V2_TY + 6][MU_X], dv[V2_TY + 6][MU_X];
+};
 
 // =============================================================================================
 // Momentum tendencies, packed evaluation: the eight WENO reconstructions of a cell are evaluated as four two-wide ones (a G_u term paired with the G_v term of
@@ -71,7 +76,12 @@ struct UvAhead {
   real *un, *vn, *P;
   real dt, C1, C2;
   int plane2;
+  // single periodic domain: un, vn are written with the halo cells tupled_fill_halo_regions! derives from them (periodic
+  // x images, the y layer of u, zero on the wall faces of v, the bottom / top layers and their x images), so that the
+  // adopted buffers need no fill launch whatever the corrector does afterwards
+  int fold;
 };
+
 // IMM: immersed boundary.  Orders and the 4th/2nd-order switches of the centred interpolations come per lane and per
 // level from the folded tables; the tendencies of faces that touch the solid are zero (their velocities are masked and
 // stay so).  The pairs that share direction and target keep their packed evaluation; the vorticity pair (y for G_u, x
@@ -80,14 +90,18 @@ struct UvAhead {
 // point -- k-independent, so the lengths of the tile sit in LDS (MomentumMetricLds), the own cell's reciprocals in
 // registers, and Az^ccc is multiplied into the w tile when it is staged.  With the zipper fold the tiles cover one more
 // row: the y faces ON the fold line have a G_v (and, AHEAD, a v of the next step) like any other row.
-template <int MINW, int V2_TY, bool AHEAD, bool IMM, bool CURV = false>
+// LAZY: u, v in memory lack this step's barotropic correction (k_corrector_2d, kernels.hpp): it is added to every value
+// as it is loaded -- tile elements (their du, dv are k-independent: registers) and the own column's vertical window.
+template <int MINW, int V2_TY, bool AHEAD, bool IMM, bool CURV = false, bool LAZY = false>
 __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     Grid g, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ w,
     const real* __restrict__ dpx, const real* __restrict__ dpy, real* __restrict__ Gu, real* __restrict__ Gv,
-    TileCols tc, int kchunks, int nb, UvAhead next) {
+    TileCols tc, int kchunks, int nb, UvAhead next, LazyCorr lz) {
   static_assert(!CURV || IMM, "the curvilinear variant takes its orders from the tables");
+  static_assert(!LAZY || (!IMM && !CURV), "the corrector is applied inside its consumers on the flat lat-lon grid only");
   __shared__ MomentumLds<V2_TY> lds;
   __shared__ typename std::conditional<CURV, MomentumMetricLds<V2_TY>, NoLds>::type mt;
+  __shared__ typename std::conditional<LAZY, MomentumCorrLds<V2_TY>, NoLds>::type cr;
   constexpr int MU_Y = V2_TY + 6, MW_Y = V2_TY + 3, MD_Y = V2_TY + 5;
   const int L = xcd_remap(blockIdx.x, nb);
   const int r = L / tc.n, bx = tile_column(tc, L - r * tc.n);
@@ -160,6 +174,16 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     uz[m] = u[o + (m - 3) * pc];
     vz[m] = v[ov + (m - 3) * pv];
   }
+  if constexpr (LAZY) {   // the own column's correction (levels the fills write: deeper ones are never used)
+    const int o2 = i2(g, ic_, jc_);
+    const real du_o = lz.du[o2], dv_o = lz.dv[o2];
+#pragma unroll
+    for (int m = 0; m < 7; m++)
+      if (k0 + m - 3 >= -1 && k0 + m - 3 <= g.Nz) {
+        uz[m] = uz[m] + du_o;
+        vz[m] = vz[m] + dv_o;
+      }
+  }
   // vertical momentum fluxes through the bottom face of the first level
   real fzu, fzv;
   {
@@ -196,6 +220,14 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     ew_lds[q] = e;
   }
   real ru[NEU], rv[NEU], rw[NEW], rpw = real(0.), rps = real(0.);
+  if constexpr (LAZY) {   // the corrections of the tile, in LDS (registers are what this kernel is short of)
+#pragma unroll
+    for (int q = 0; q < NEU; q++)
+      if (eu_off[q] >= 0) {
+        (&cr.du[0][0])[eu_lds[q]] = *reinterpret_cast<const real*>(reinterpret_cast<const char*>(lz.du + tile_u) + eu_off[q]);
+        (&cr.dv[0][0])[eu_lds[q]] = *reinterpret_cast<const real*>(reinterpret_cast<const char*>(lz.dv + tile_u) + eu_off[q]);
+      }
+  }
   real azw[NEW];   // CURV: Az^ccc at this thread's elements of the w tile
   if constexpr (CURV) {
     const real* ab = g.cv.azcc + tile_w;
@@ -242,14 +274,21 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
 #pragma unroll
     for (int q = 0; q < NEU; q++)
       if (eu_off[q] >= 0) {
-        U0[eu_lds[q]] = ru[q];
-        V0[eu_lds[q]] = rv[q];
+        if constexpr (LAZY) {
+          U0[eu_lds[q]] = ru[q] + (&cr.du[0][0])[eu_lds[q]];
+          V0[eu_lds[q]] = rv[q] + (&cr.dv[0][0])[eu_lds[q]];
+        } else {
+          U0[eu_lds[q]] = ru[q];
+          V0[eu_lds[q]] = rv[q];
+        }
       }
 #pragma unroll
     for (int q = 0; q < NEW; q++)
       if (ew_off[q] >= 0) W0[ew_lds[q]] = CURV ? azw[q] * rw[q] : rw[q];
   };
   real sAu = real(0.), sAv = real(0.), sIu = real(0.), sIv = real(0.);   // AHEAD: this chunk's column sums
+  // AHEAD with next.fold: does this tile hold cells with a periodic x image or a y layer to write?
+  const bool fold_tile = AHEAD && (j0 == 0 || j0 + V2_TY >= g.Ny || i0 < H || i0 + V2_TX > g.Nx - H);
   // per-block tables for phase 1: packed (row << 8 | column) of every derived point, and the metrics of the rows
   // mdxc[py] = dxc(j0-3+py), mrazf[py] = razf(j0-2+py), mdxf[py] = dxf(j0-3+py)
   __shared__ int ptab[MD_X * MD_Y];
@@ -274,7 +313,13 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     // ---- phase 0: issue the loads of the next level's tiles (consumed at the end of this iteration)
     const bool more = (k + 1 < k1);
     if (more) fetch(k + 1, ob + (unsigned)pc * SZ);
-    const real unew = at(u, ob + 4u * (unsigned)pc * SZ), vnew = at(v, obv + 4u * (unsigned)pv * SZ);
+    real unew = at(u, ob + 4u * (unsigned)pc * SZ), vnew = at(v, obv + 4u * (unsigned)pv * SZ);
+    if constexpr (LAZY) {
+      if (k + 4 <= g.Nz) {
+        unew = unew + cr.du[ty + 3][tx + 3];
+        vnew = vnew + cr.dv[ty + 3][tx + 3];
+      }
+    }
     // ---- phase 1: derived quantities, once per point.  (row, column) of a point and the row metrics come from the
     // small LDS tables filled once per block: an integer division and five global loads per point and level otherwise
     for (int e = tid; e < MD_X * MD_Y; e += NT) {
@@ -471,9 +516,34 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
       put(Gv, obv, gv);
       if (AHEAD) {
         const real au = rfma(next.C1, gu, -(next.C2 * at(next.GmU, ob))), av = rfma(next.C1, gv, -(next.C2 * at(next.GmV, obv)));
-        const real un = rfma(next.dt, au, uz[3]), vn = rfma(next.dt, av, vz[3]);
+        const real un = rfma(next.dt, au, uz[3]);
+        const real vn = (next.fold && j == 0) ? real(0.) : rfma(next.dt, av, vz[3]);   // (the southern wall face)
         if (inside_u) put(next.un, ob, un);
         put(next.vn, obv, vn);
+        if (next.fold && (fold_tile || k == 0 || k == g.Nz - 1)) {   // (wave-uniform: most tiles and levels skip all of it)
+          const unsigned NxB = (unsigned)g.Nx * SZ, sxB = (unsigned)sx * SZ;
+          const bool xw = i < H, xe = i >= g.Nx - H;
+          auto images = [&](real* base, unsigned off, real x, bool self) {
+            if (self) put(base, off, x);
+            if (xw) put(base, off + NxB, x);
+            if (xe) put(base, off - NxB, x);
+          };
+          images(next.un, ob, un, false);
+          images(next.vn, obv, vn, false);
+          if (j == 0) images(next.un, ob - sxB, un, true);                    // row -1 <- row 0
+          if (j == g.Ny - 1) {
+            images(next.un, ob + sxB, un, true);                             // row Ny <- row Ny-1
+            images(next.vn, obv + sxB, real(0.), true);                      // v: face Ny is the northern wall
+          }
+          if (k == 0) {
+            images(next.un, ob - (unsigned)pc * SZ, un, true);
+            images(next.vn, obv - (unsigned)pv * SZ, vn, true);
+          }
+          if (k == g.Nz - 1) {
+            images(next.un, ob + (unsigned)pc * SZ, un, true);
+            images(next.vn, obv + (unsigned)pv * SZ, vn, true);
+          }
+        }
         sAu = (k == k0) ? dz * au : rfma(dz, au, sAu);
         sAv = (k == k0) ? dz * av : rfma(dz, av, sAv);
         sIu = (k == k0) ? dz * un : rfma(dz, un, sIu);
@@ -537,11 +607,12 @@ struct Ab2Ahead {
 // adopted buffers need no fill launch.
 // The arithmetic of one tile (63 cells of a row x 4 rows x one chunk of levels); L = logical tile index.
 // CURV: orthogonal curvilinear grid (with the tables): the three face lengths, the area and its reciprocal per lane.
-template <bool AHEAD, bool IMM, bool FOLD, bool CURV = false>
+// LAZY: the barotropic correction of this step is added to u and v as they are loaded (see k_momentum_tendencies_v5).
+template <bool AHEAD, bool IMM, bool FOLD, bool CURV = false, bool LAZY = false>
 __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restrict__ u, const real* __restrict__ v,
                                             const real* __restrict__ w, const real* __restrict__ T,
                                             const real* __restrict__ S, real* __restrict__ GT, real* __restrict__ GS,
-                                            int nbx, int kchunks, const Ab2Ahead& next, const int L) {
+                                            int nbx, int kchunks, const Ab2Ahead& next, const int L, const LazyCorr& lz) {
   const int bx = L % nbx, r = L / nbx;
   const int kc = r % kchunks, by = r / kchunks;
   const int klen = (g.Nz + kchunks - 1) / kchunks;
@@ -556,6 +627,12 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
   const real dy = CURV ? g.cv.dyfc[om] : g.dy, Az = CURV ? g.cv.azcc[om] : g.azc[j];
   const real dxf_s = CURV ? g.cv.dxcf[om] : g.dxf[j], dxf_n = CURV ? g.cv.dxcf[om + g.sx] : g.dxf[j + 1];
   const real razc_j = CURV ? g.cv.razcc[om] : g.razc[j];
+  real du_l = real(0.), dv_s = real(0.), dv_n = real(0.);
+  if (LAZY) {
+    du_l = lz.du[om];
+    dv_s = lz.dv[om];
+    dv_n = lz.dv[om + g.sx];
+  }
   int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny), ox = 5;
   int kbt = 0, KX5 = 0, KX3 = 0, KY5 = 0, KY3 = 0, KY5n = 0, KY3n = 0;
   if (IMM) {
@@ -603,8 +680,9 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
       oys = order_from(k, KY5, KY3);
       oyn = order_from(k, KY5n, KY3n);
     }
-    const real Axu = dy * dz * bload(bu, vo, cc);
-    const real Ays = dxf_s * dz * bload(bv, vov, 0), Ayn = dxf_n * dz * bload(bv, vov, sx * SZ);
+    const real Axu = dy * dz * (LAZY ? bload(bu, vo, cc) + du_l : bload(bu, vo, cc));
+    const real Ays = dxf_s * dz * (LAZY ? bload(bv, vov, 0) + dv_s : bload(bv, vov, 0));
+    const real Ayn = dxf_n * dz * (LAZY ? bload(bv, vov, sx * SZ) + dv_n : bload(bv, vov, sx * SZ));
     const real Azw = Az * bload(bw, vo, cc + pc * SZ);
     real2v q[7];
 #pragma unroll
@@ -662,14 +740,14 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
 #undef CY
 #undef CX
 }
-template <int MINW, bool AHEAD, bool IMM, bool FOLD = false, bool CURV = false>
+template <int MINW, bool AHEAD, bool IMM, bool FOLD = false, bool CURV = false, bool LAZY = false>
 __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, const real* __restrict__ u,
                                                               const real* __restrict__ v,
                                                               const real* __restrict__ w,
                                                               const real* __restrict__ T, const real* __restrict__ S,
                                                               real* __restrict__ GT, real* __restrict__ GS, int nbx,
-                                                              int kchunks, int nb, Ab2Ahead next) {
-  tracer_tile<AHEAD, IMM, FOLD, CURV>(g, u, v, w, T, S, GT, GS, nbx, kchunks, next, xcd_remap(blockIdx.x, nb));
+                                                              int kchunks, int nb, Ab2Ahead next, LazyCorr lz) {
+  tracer_tile<AHEAD, IMM, FOLD, CURV, LAZY>(g, u, v, w, T, S, GT, GS, nbx, kchunks, next, xcd_remap(blockIdx.x, nb), lz);
 }
 
 }  // namespace gb25

@@ -116,6 +116,9 @@ typedef enum {
                                     (the stated Float32 tolerance) */
   GB25_OPT_IMMERSED_KERNELS,     /* [1 iff some cell is immersed] 1: run the immersed-boundary kernel variants anyway */
   GB25_OPT_FOLD_FILLS,           /* [1] single domain: the last writers of u,v / T,S / eta,U,V write the halo cells themselves */
+  GB25_OPT_LAZY_CORRECTOR,       /* [1] single flat lat-lon domain, between the steps of one gb25_loop call: the barotropic
+                                    correction of u, v is added by the kernels that read them instead of by a sweep over
+                                    u and v (same bits; memory holds the corrected velocities when the call returns) */
   GB25_OPT_COUNT
 } gb25_option;
 

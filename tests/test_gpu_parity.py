@@ -491,6 +491,50 @@ def test_schedule_options_are_bitwise_neutral(opts):
     assert a.clock.iteration == b.clock.iteration == 11
 
 
+@pytest.mark.parametrize("float_type", ["Float32", "Float64"])
+@pytest.mark.parametrize("shape,halo", [((150, 70, 12), 8), ((40, 21, 6), 4), ((1440, 90, 14), 8)])
+def test_the_corrector_inside_its_consumers_is_bitwise_neutral(shape, halo, float_type):
+    """Between the steps of one loop! call the barotropic correction of u, v is not swept over the fields: a 2-D kernel
+    leaves du, dv and the w, momentum and tracer kernels add them as they load (option lazy_corrector, the default where
+    both look-aheads run) -- against the sweep: every cell of every parent array when the call returns, loops of
+    different lengths (the last step of a call always sweeps), single steps in between, a changed dt."""
+    Nx, Ny, Nz = shape
+    dtype = np.float32 if float_type == "Float32" else np.float64
+    models = []
+    for lazy in (0, 1):
+        m = gb.baroclinic_instability_model(gb.GPU(float_type=float_type), Nx, Ny, Nz, dt=300.0, halo=(halo,) * 3,
+                                            options=dict(lazy_corrector=lazy, subcycle_lookahead=1))
+        assert m.backend.get_option("lazy_corrector") == lazy
+        gb.set_baroclinic_instability(m)
+        set_noisy_velocities(m, 0.05)
+        for n, seed in (("T", 5), ("u", 6), ("v", 7), ("eta", 8), ("V", 9)):
+            a = m.backend.get_field(n, True)
+            a += (1e-3 * counter_rng(a.shape, seed, 1)).astype(dtype)          # noise in EVERY halo layer
+            m.backend.set_field(n, a, True)
+        models.append(m)
+    a, b = models
+
+    def same(label):
+        for n in ALL_FIELDS:
+            x, y = a.backend.get_field(n, True), b.backend.get_field(n, True)
+            assert np.array_equal(x, y), (label, n, float(np.abs(x - y).max()))
+
+    for m in (a, b):
+        gb.first_time_step(m)
+        gb.loop(m, 7)
+    same("loop of 7")
+    for m in (a, b):
+        gb.loop(m, 2)
+        gb.time_step(m)
+        gb.loop(m, 5)
+    same("loops of 2, 1, 5")
+    for m in (a, b):
+        m.backend.set_dt(240.0)
+        gb.loop(m, 6)
+    same("after a changed dt")
+    assert np.abs(a.velocities.u.interior).max() > 0.01
+
+
 @pytest.mark.parametrize("shape,halo", [((16, 9, 4), 4), ((24, 9, 5), 5), ((70, 13, 7), 8), ((8, 10, 4), 8)])
 def test_minimum_sizes_and_halos(shape, halo):
     """Smallest useful extents (Ny = 8 is excluded: with 20-degree rows the first latitude halo mirrors exactly
