@@ -154,7 +154,12 @@ def main():
             # the zonal spacing shrinks with the rank count, so the time step shrinks with it (constant barotropic
             # Courant number, as the reference's resolution-dependent dt: simulations/ocean_climate_simulation.jl:50-51)
             args.dt = args.dt / world
-        model = SlabModel(gNx, Ny, Nz, dt=args.dt, rank=rank, nranks=world, device=local_rank)
+        gt = {"simple_lat_lon": 0, "gaussian_islands_lat_lon": 1, "lat_lon_as_curvilinear": 2, "tripolar": 3,
+              "gaussian_islands": 4}[args.grid_type]
+        model = SlabModel(gNx, Ny, Nz, dt=args.dt, rank=rank, nranks=world, device=local_rank,
+                          **(dict(grid_type=gt) if gt else {}))
+        if args.closure:
+            model.backend.set_vertical_diffusivity(*map(float, args.closure.split(",")))
         barrier = dist.barrier
     else:
         closure = gb.VerticalScalarDiffusivity(*map(float, args.closure.split(","))) if args.closure else None

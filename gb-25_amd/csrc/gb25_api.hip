@@ -77,7 +77,6 @@ struct gb25_model {
   // orthogonal curvilinear grid (grid_type >= 2): the 14 horizontal metrics by location, fp64, parent layout of a (c,f)
   // field (gb25_get_metric2); cell-centre coordinates in degrees for analytic bottoms
   std::vector<double> h_curv[GB25_M2_COUNT];
-  std::vector<double> h_lamcc, h_phicc;
   int metric_off_j = 0, metric_off_k = 0;
   // substepping
   int Ns = 0;
@@ -126,6 +125,9 @@ struct gb25_model {
   unsigned* d_ord[3] = {nullptr, nullptr, nullptr};
   real* d_H[4] = {nullptr, nullptr, nullptr, nullptr};   // Hfc, Hcf, rHfc, rHcf (parent layout of a (c,f) field)
   real* d_wideH[2] = {nullptr, nullptr};                 // Hfc, Hcf on the wide barotropic layout of a slab
+  // curvilinear slab: dyfc, dxcf, 1/azcc, 1/dxfc, 1/dycf on the wide barotropic layout, and (zipper fold) the metrics of
+  // the cells row Ny-1 mirrors onto, by own wide column (CurvBaro::mir, kernels.hpp)
+  real* d_wideM[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   real* d_top_flux[4] = {nullptr, nullptr, nullptr, nullptr};   // FluxBoundaryCondition at the top of u, v, T, S
   // the corrector applied inside its consumers (k_corrector_2d): du, dv of the current step; while uv_lazy is set, u and
   // v in memory lack them (only between the steps of one composite call: gb25_loop applies them before it returns)
@@ -139,6 +141,7 @@ struct gb25_model {
   bool slab = false;                 // x halos come from a neighbour (nranks > 1, or the self-ring of slab_mode = 1)
   struct SlabGroup* group = nullptr; // exchange context (transport, buffers, comm stream) once gb25_comm_init_* was called
   int group_index = 0;               // this slab's position in group->slabs
+  int fold_flip = 0;                 // folded slab: which of the two widened state sets the next substep reads
 };
 
 namespace {
@@ -344,67 +347,71 @@ double quad_area(const GNode& a, const GNode& b, const GNode& c, const GNode& d,
   return std::max(R * R * (tri_area(a, b, c) + tri_area(a, c, d)), 1e4);
 }
 
-// grid_type 2: the lat-lon metrics through the 2-D arrays (the curvilinear kernels must then agree with the plain ones);
-// 3, 4: the tripolar grid.  Fills m->h_curv and uploads what the kernels read (device_common.hpp, Curv).
-gb25_status build_curv_grid(gb25_model* m) {
+// The 14 horizontal metrics (gb25_metric2 order) and the physical coordinates of the cell centre at GLOBAL column ig,
+// row j (any integers: halo rows and columns are generated like interior ones; rows beyond the fold are the mirrored
+// cells).  grid_type 2: the lat-lon metrics; 3, 4: the tripolar grid.
+void curv_metrics_at(const gb25_model* m, int ig, int j, double out[GB25_M2_COUNT], double* lam_c, double* phi_c) {
   const gb25_config& c = m->cfg;
-  const int Nx = m->Nx, Ny = c.Ny, H = c.halo, sx = Nx + 2 * H, sy = Ny + 2 * H + 1, offj = m->metric_off_j;
-  const size_t n2 = (size_t)sx * sy;
   const bool tri = c.grid_type >= GB25_GRID_TRIPOLAR;
   const double d2r = M_PI / 180.0, R = c.radius;
   const double lam0 = tri ? 70.0 : c.lon_west, dlam = (tri ? 360.0 : (c.lon_east - c.lon_west)) / c.Nx;
-  const double phiN = tri ? 90.0 : c.lat_north, dphi = (phiN - c.lat_south) / Ny;
+  const double phiN = tri ? 90.0 : c.lat_north, dphi = (phiN - c.lat_south) / c.Ny;
+  if (!tri) {
+    const int a = m->metric_off_j + j;
+    out[GB25_M2_DXFC] = out[GB25_M2_DXCC] = m->h_metric[GB25_M_DXC][a];
+    out[GB25_M2_DXCF] = out[GB25_M2_DXFF] = m->h_metric[GB25_M_DXF][a];
+    out[GB25_M2_DYFC] = out[GB25_M2_DYCC] = out[GB25_M2_DYCF] = out[GB25_M2_DYFF] = R * dphi * d2r;
+    out[GB25_M2_AZCC] = out[GB25_M2_AZFC] = m->h_metric[GB25_M_AZC][a];
+    out[GB25_M2_AZCF] = out[GB25_M2_AZFF] = m->h_metric[GB25_M_AZF][a];
+    out[GB25_M2_FFF] = m->h_metric[GB25_M_FCOR][a];
+    out[GB25_M2_PHICC] = m->h_metric[GB25_M_PHIC][a];
+    if (lam_c) *lam_c = c.lon_west + (ig + 0.5) * dlam;
+    // (the row tables were rounded to the float type when they were uploaded: the same value here)
+    if (phi_c) *phi_c = (double)(real)m->h_metric[GB25_M_PHIC][a];
+    return;
+  }
+  // computational coordinates of the four node families around the 0-based (ig, j)
+  const double lf = lam0 + ig * dlam, lc = lam0 + (ig + 0.5) * dlam;
+  const double pf = c.lat_south + j * dphi, pc = c.lat_south + (j + 0.5) * dphi;
+  auto N = [](double l, double p) { return tripolar_node(l, p); };
+  const GNode cc = N(lc, pc), fc = N(lf, pc), cf = N(lc, pf), ff = N(lf, pf);
+  const GNode fc_e = N(lf + dlam, pc), ff_e = N(lf + dlam, pf), cc_w = N(lc - dlam, pc), cf_w = N(lc - dlam, pf);
+  const GNode cf_n = N(lc, pf + dphi), ff_n = N(lf, pf + dphi), ff_ne = N(lf + dlam, pf + dphi);
+  const GNode cc_s = N(lc, pc - dphi), fc_s = N(lf, pc - dphi), cc_sw = N(lc - dlam, pc - dphi);
+  const GNode cf_nw = N(lc - dlam, pf + dphi), fc_se = N(lf + dlam, pc - dphi);
+  out[GB25_M2_DXCC] = gc_dist(fc, fc_e, R);
+  out[GB25_M2_DXFC] = gc_dist(cc_w, cc, R);
+  out[GB25_M2_DXCF] = gc_dist(ff, ff_e, R);
+  out[GB25_M2_DXFF] = gc_dist(cf_w, cf, R);
+  out[GB25_M2_DYCC] = gc_dist(cf, cf_n, R);
+  out[GB25_M2_DYFC] = gc_dist(ff, ff_n, R);
+  out[GB25_M2_DYCF] = gc_dist(cc_s, cc, R);
+  out[GB25_M2_DYFF] = gc_dist(fc_s, fc, R);
+  out[GB25_M2_AZCC] = quad_area(ff, ff_e, ff_ne, ff_n, R);
+  out[GB25_M2_AZFC] = quad_area(cf_w, cf, cf_n, cf_nw, R);
+  out[GB25_M2_AZCF] = quad_area(fc_s, fc_se, fc_e, fc, R);
+  out[GB25_M2_AZFF] = quad_area(cc_sw, cc_s, cc, cc_w, R);
+  out[GB25_M2_FFF] = 2.0 * c.Omega * std::sin(ff.phi * d2r);
+  out[GB25_M2_PHICC] = cc.phi;
+  if (lam_c) *lam_c = cc.lam;
+  if (phi_c) *phi_c = cc.phi;
+}
+
+// Fills m->h_curv (the local slab's columns, halo columns by their own global index) and uploads what the kernels read
+// (device_common.hpp, Curv).
+gb25_status build_curv_grid(gb25_model* m) {
+  const gb25_config& c = m->cfg;
+  const int Nx = m->Nx, Ny = c.Ny, H = c.halo, sx = Nx + 2 * H, sy = Ny + 2 * H + 1;
+  const size_t n2 = (size_t)sx * sy;
+  const bool tri = c.grid_type >= GB25_GRID_TRIPOLAR;
   for (auto& a : m->h_curv) a.assign(n2, 0.0);
-  m->h_lamcc.assign((size_t)Nx * Ny, 0.0);
-  m->h_phicc.assign((size_t)Nx * Ny, 0.0);
   auto at = [&](int id) -> std::vector<double>& { return m->h_curv[id]; };
-  // (the row tables were rounded to the float type when they were uploaded: the same values here)
-  auto rnd = [](double v) { return (double)(real)v; };
   for (int j = -H; j <= Ny + H; j++)
     for (int i = -H; i < Nx + H; i++) {
       const size_t o = (size_t)(i + H) + (size_t)sx * (j + H);
-      if (!tri) {
-        const int a = offj + j;
-        at(GB25_M2_DXFC)[o] = at(GB25_M2_DXCC)[o] = m->h_metric[GB25_M_DXC][a];
-        at(GB25_M2_DXCF)[o] = at(GB25_M2_DXFF)[o] = m->h_metric[GB25_M_DXF][a];
-        at(GB25_M2_DYFC)[o] = at(GB25_M2_DYCC)[o] = at(GB25_M2_DYCF)[o] = at(GB25_M2_DYFF)[o] = R * dphi * d2r;
-        at(GB25_M2_AZCC)[o] = at(GB25_M2_AZFC)[o] = m->h_metric[GB25_M_AZC][a];
-        at(GB25_M2_AZCF)[o] = at(GB25_M2_AZFF)[o] = m->h_metric[GB25_M_AZF][a];
-        at(GB25_M2_FFF)[o] = m->h_metric[GB25_M_FCOR][a];
-        at(GB25_M2_PHICC)[o] = m->h_metric[GB25_M_PHIC][a];
-        if (i >= 0 && i < Nx && j >= 0 && j < Ny) {
-          m->h_lamcc[(size_t)i + (size_t)Nx * j] = c.lon_west + (i + c.rank * Nx + 0.5) * dlam;
-          m->h_phicc[(size_t)i + (size_t)Nx * j] = rnd(m->h_metric[GB25_M_PHIC][a]);
-        }
-        continue;
-      }
-      // computational coordinates of the four node families around the 0-based (i, j)
-      const double lf = lam0 + i * dlam, lc = lam0 + (i + 0.5) * dlam;
-      const double pf = c.lat_south + j * dphi, pc = c.lat_south + (j + 0.5) * dphi;
-      auto N = [](double l, double p) { return tripolar_node(l, p); };
-      const GNode cc = N(lc, pc), fc = N(lf, pc), cf = N(lc, pf), ff = N(lf, pf);
-      const GNode fc_e = N(lf + dlam, pc), ff_e = N(lf + dlam, pf), cc_w = N(lc - dlam, pc), cf_w = N(lc - dlam, pf);
-      const GNode cf_n = N(lc, pf + dphi), ff_n = N(lf, pf + dphi), ff_ne = N(lf + dlam, pf + dphi);
-      const GNode cc_s = N(lc, pc - dphi), fc_s = N(lf, pc - dphi), cc_sw = N(lc - dlam, pc - dphi);
-      const GNode cf_nw = N(lc - dlam, pf + dphi), fc_se = N(lf + dlam, pc - dphi);
-      at(GB25_M2_DXCC)[o] = gc_dist(fc, fc_e, R);
-      at(GB25_M2_DXFC)[o] = gc_dist(cc_w, cc, R);
-      at(GB25_M2_DXCF)[o] = gc_dist(ff, ff_e, R);
-      at(GB25_M2_DXFF)[o] = gc_dist(cf_w, cf, R);
-      at(GB25_M2_DYCC)[o] = gc_dist(cf, cf_n, R);
-      at(GB25_M2_DYFC)[o] = gc_dist(ff, ff_n, R);
-      at(GB25_M2_DYCF)[o] = gc_dist(cc_s, cc, R);
-      at(GB25_M2_DYFF)[o] = gc_dist(fc_s, fc, R);
-      at(GB25_M2_AZCC)[o] = quad_area(ff, ff_e, ff_ne, ff_n, R);
-      at(GB25_M2_AZFC)[o] = quad_area(cf_w, cf, cf_n, cf_nw, R);
-      at(GB25_M2_AZCF)[o] = quad_area(fc_s, fc_se, fc_e, fc, R);
-      at(GB25_M2_AZFF)[o] = quad_area(cc_sw, cc_s, cc, cc_w, R);
-      at(GB25_M2_FFF)[o] = 2.0 * c.Omega * std::sin(ff.phi * d2r);
-      at(GB25_M2_PHICC)[o] = cc.phi;
-      if (i >= 0 && i < Nx && j >= 0 && j < Ny) {
-        m->h_lamcc[(size_t)i + (size_t)Nx * j] = cc.lam;
-        m->h_phicc[(size_t)i + (size_t)Nx * j] = cc.phi;
-      }
+      double v[GB25_M2_COUNT];
+      curv_metrics_at(m, i + c.rank * Nx, j, v, nullptr, nullptr);
+      for (int q = 0; q < GB25_M2_COUNT; q++) at(q)[o] = v[q];
     }
   Curv& cv = m->g.cv;
   gb25_status s;
@@ -435,6 +442,51 @@ gb25_status build_curv_grid(gb25_model* m) {
   }
   cv.on = 1;
   cv.north_fold = tri ? 1 : 0;
+  return GB25_OK;
+}
+// The metrics of the split-explicit sub-cycle on the WIDENED slab (columns [-W, Nx + W), pitch Nx + 2W, rows like a
+// (c,f) field).  Global columns are wrapped into [0, Nx_global): the sub-cycle of a single domain wraps its indices the
+// same way, so that a decomposition reads the very numbers the single domain reads.
+gb25_status build_curv_wide(gb25_model* m) {
+  const gb25_config& c = m->cfg;
+  const int Nx = m->Nx, Ny = c.Ny, H = c.halo, W = m->W, wsx = Nx + 2 * W, sy = Ny + 2 * H + 1;
+  auto wrap = [&](int ig) { return ((ig % c.Nx) + c.Nx) % c.Nx; };
+  std::vector<real> t[5];
+  for (auto& a : t) a.assign((size_t)wsx * sy, real(0.));
+  for (int j = -H; j <= Ny + H; j++)
+    for (int i = -W; i < Nx + W; i++) {
+      const size_t o = (size_t)(i + W) + (size_t)wsx * (j + H);
+      double v[GB25_M2_COUNT];
+      curv_metrics_at(m, wrap(i + c.rank * Nx), j, v, nullptr, nullptr);
+      t[0][o] = (real)v[GB25_M2_DYFC];
+      t[1][o] = (real)v[GB25_M2_DXCF];
+      t[2][o] = (real)(1.0 / v[GB25_M2_AZCC]);
+      t[3][o] = (real)(1.0 / v[GB25_M2_DXFC]);
+      t[4][o] = (real)(1.0 / v[GB25_M2_DYCF]);
+    }
+  for (int q = 0; q < 5; q++) {
+    HIPCHK(hipMalloc(&m->d_wideM[q], t[q].size() * sizeof(real)));
+    HIPCHK(hipMemcpy(m->d_wideM[q], t[q].data(), t[q].size() * sizeof(real), hipMemcpyHostToDevice));
+  }
+  if (m->g.cv.north_fold) {
+    // the cell that (own wide column a, row Ny-1) mirrors onto: global column Nx_global - 1 - ig, row Ny-1
+    std::vector<real> mir((size_t)6 * wsx, real(0.));
+    for (int i = -W; i < Nx + W; i++) {
+      const int igm = wrap(c.Nx - 1 - (i + c.rank * Nx)), a = i + W;
+      double v[GB25_M2_COUNT], ve[GB25_M2_COUNT], vn[GB25_M2_COUNT];
+      curv_metrics_at(m, igm, Ny - 1, v, nullptr, nullptr);
+      curv_metrics_at(m, wrap(igm + 1), Ny - 1, ve, nullptr, nullptr);
+      curv_metrics_at(m, igm, Ny, vn, nullptr, nullptr);
+      mir[a] = (real)v[GB25_M2_DYFC];
+      mir[(size_t)wsx + a] = (real)ve[GB25_M2_DYFC];
+      mir[(size_t)2 * wsx + a] = (real)v[GB25_M2_DXCF];
+      mir[(size_t)3 * wsx + a] = (real)vn[GB25_M2_DXCF];
+      mir[(size_t)4 * wsx + a] = (real)(1.0 / v[GB25_M2_AZCC]);
+      mir[(size_t)5 * wsx + a] = (real)(1.0 / vn[GB25_M2_DYCF]);
+    }
+    HIPCHK(hipMalloc(&m->d_wideM[5], mir.size() * sizeof(real)));
+    HIPCHK(hipMemcpy(m->d_wideM[5], mir.data(), mir.size() * sizeof(real), hipMemcpyHostToDevice));
+  }
   return GB25_OK;
 }
 
@@ -524,12 +576,15 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
   m->kb_E = E;
   m->kbot.assign((size_t)ksx * Ny, 0);
   bool any = false;
+  auto level = [&](double b) {   // number of immersed cells of a column whose bottom is at height b
+    int kb = 0;
+    for (int k = 0; k < Nz; k++)
+      if ((double)(real)zc[offk + k] <= b) kb = k + 1;   // z_center <= bottom: immersed (CenterImmersedCondition)
+    return kb;
+  };
   for (int j = 0; j < Ny; j++)
     for (int i = -E; i < Nx + E; i++) {
-      const double b = zb(i, j);
-      int kb = 0;
-      for (int k = 0; k < Nz; k++)
-        if ((double)(real)zc[offk + k] <= b) kb = k + 1;   // z_center <= bottom: immersed (CenterImmersedCondition)
+      const int kb = level(zb(i, j));
       m->kbot[(size_t)(i + E) + (size_t)ksx * j] = kb;
       any = any || kb > 0;
     }
@@ -539,8 +594,10 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
   const bool nfold = m->g.cv.north_fold != 0;
   auto thr = [&](int i, int j) -> int {
     if (nfold && j >= Ny) {
-      i = Nx - 1 - i;
-      j = 2 * Ny - 1 - j;
+      // the mirrored cell: GLOBAL column Nx_global - 1 - ig, usually another rank's -- the bottom is a function of the
+      // global position, evaluated here (a slab sees its partner's bottom without any exchange)
+      const int il = c.Nx - 1 - (i + c.rank * Nx) - c.rank * Nx, jm = 2 * Ny - 1 - j;
+      return jm < 0 ? 255 : level(zb(il, jm));
     }
     if (j < 0 || j >= Ny) return 255;
     return m->kbot[(size_t)(std::min(std::max(i, -E), Nx + E - 1) + E) + (size_t)ksx * j];
@@ -623,7 +680,8 @@ double gaussian_islands_bottom(const gb25_model* m, int i_local, int j) {
   if (m->g.cv.on) {
     // physical coordinates of the cell centre, the longitude brought next to each mountain (the tripolar grid starts AT
     // the first mountain's longitude: without this only its eastern half would exist)
-    const double lam = m->h_lamcc[(size_t)ig + (size_t)m->Nx * j], phi = m->h_phicc[(size_t)ig + (size_t)m->Nx * j];
+    double v[GB25_M2_COUNT], lam, phi;
+    curv_metrics_at(m, ig, j, v, &lam, &phi);
     const double l1 = lam - 360.0 * std::floor((lam - 70.0 + 180.0) / 360.0), l2 = lam - 360.0 * std::floor((lam - 250.0 + 180.0) / 360.0);
     return z1 + h * (mtn(l1, phi, 70, 55) + mtn(l2, phi, 70 + 180, 55));
   }
@@ -699,7 +757,7 @@ gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, i
   dim3 b(256);
   const int i0 = extended ? -g.H : 0, ni = extended ? g.Nx + 2 * g.H : g.Nx;
   if (which == 2 && with_x && g.x_periodic && !extended && !h2_other) return fill_halos_2d(m, halo2_prognostic(m));
-  if (g.cv.north_fold) {   // y / z layers, the rows beyond the fold, then the periodic x copy over all of them
+  if (g.cv.north_fold && !m->slab) {   // y / z layers, the rows beyond the fold, then the periodic x copy over all of them
     if (which == 2) return fill_halos_2d(m, h2);
     if (which == 1) h2.n = 0;
     hipLaunchKernelGGL(k_fill_yz, dim3((g.Nx + 255) / 256, g.Nz + 1 + g.Ny), b, 0, st, g, h3, h2, 0, g.Nx);
@@ -747,7 +805,8 @@ gb25_status fill_halos_2d(gb25_model* m, Halo2 h2) {
   Grid g2 = g;
   g2.Nz = 0;
   hipLaunchKernelGGL(k_fill_y, dim3((g.Nx + 255) / 256, 1), b, 0, m->stream, g2, none, h2, 0, g.Nx);
-  if (g.cv.north_fold) hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H, 1), b, 0, m->stream, g, none, h2);
+  if (g.cv.north_fold && !m->slab)   // (a slab's rows beyond the fold come from its partner rank: slab_step.hpp)
+    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H, 1), b, 0, m->stream, g, none, h2);
   if (g.x_periodic) {
     long threads = (long)g.sy_v * 2 * g.H;
     hipLaunchKernelGGL(k_fill_x, dim3((unsigned)((threads + 255) / 256), 4 + h2.n), b, 0, m->stream, g2, none, h2, 0,
@@ -844,7 +903,7 @@ inline int interior_tile_columns_end(const Grid& g) {
 }
 inline bool tendencies_split(const gb25_model* m) {
   return m->slab && m->split_tendencies && m->two_streams && m->pressure_bits == 64 && m->kernel_gen >= 2 &&
-         interior_tile_columns_end(m->g) > 1;
+         interior_tile_columns_end(m->g) > 1 && !m->g.cv.north_fold;   // (the rows beyond a fold arrive last)
 }
 
 // part: 0 = every tile column; 1 = the interior tile columns (a12: launched before the x-halo bundle has arrived);
@@ -1124,6 +1183,8 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     HIPCHK(hipStreamWaitEvent(m->stream, m->ev_baro, 0));
     m->baro_inflight = false;
   }
+  if (m->slab && g.cv.north_fold)
+    return fail(m, GB25_ERR_STATE, "internal: the sub-cycle of a slab of a folded grid runs substep by substep (slab_step.hpp)");
   Timed t(m, GB25_K_BAROTROPIC);
   m->last_baro_folded = false;
   const bool wide = m->slab;
@@ -1147,7 +1208,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     bb.sx = g.sx; bb.xo = g.H; bb.ilo = 0; bb.ihi = g.Nx; bb.wrap = 1;
     bb.Hfc = m->d_H[0]; bb.Hcf = m->d_H[1];
   } else {
-    if (m->baro_block <= 1)
+    if (m->baro_block <= 1 || g.cv.on)
       HIPCHK(hipMemsetAsync(m->wideBar[0].d, 0,
                             (m->wideBar[0].elems() + m->wideBar[1].elems() + m->wideBar[2].elems()) * sizeof(real),
                             m->stream));
@@ -1199,11 +1260,14 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     }
   } else {
     dim3 gr = grid2(bb.ihi - bb.ilo, v_rows(g), b);
+    const CurvBaro cb = wide ? CurvBaro{m->d_wideM[0], m->d_wideM[1], m->d_wideM[2], m->d_wideM[3], m->d_wideM[4], nullptr,
+                                        nullptr, m->cfg.rank * g.Nx, m->cfg.Nx}
+                             : CurvBaro{g.cv.dyfc, g.cv.dxcf, g.cv.razcc, g.cv.rdxfc, g.cv.rdycf, nullptr, nullptr, 0, g.Nx};
     for (int s = 0; s < m->Ns; s++) {
       bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
       bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
       if (g.cv.on)
-        hipLaunchKernelGGL(k_barotropic_substep_curv, gr, b, 0, m->stream, g, bb, dtau, (real)m->weights[s]);
+        hipLaunchKernelGGL(k_barotropic_substep_curv<false>, gr, b, 0, m->stream, g, bb, cb, dtau, (real)m->weights[s]);
       else
         hipLaunchKernelGGL(imm ? k_barotropic_substep<true> : k_barotropic_substep<false>, gr, b, 0, m->stream, g, bb, dtau,
                            (real)m->weights[s]);
@@ -1539,7 +1603,6 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     return fail(m, GB25_ERR_INVALID_ARGUMENT, "grid_type %d: 0 lat-lon, 1 lat-lon with the Gaussian islands, 2 lat-lon "
                 "through the curvilinear kernels, 3 tripolar, 4 tripolar with the Gaussian islands", cfg->grid_type);
   if (cfg->grid_type >= GB25_GRID_LAT_LON_AS_CURVILINEAR) {
-    if (m->slab) return fail(m, GB25_ERR_INVALID_ARGUMENT, "curvilinear grids (grid_type >= 2) are single-domain: nranks = 1, slab_mode = 0");
     if (cfg->grid_type >= GB25_GRID_TRIPOLAR && (cfg->Nx % 2 || cfg->Ny < 2 * cfg->halo))
       return fail(m, GB25_ERR_INVALID_ARGUMENT, "the tripolar grid needs an even Nx and Ny >= 2 halo (the fold maps columns onto columns)");
     if ((s = build_curv_grid(m))) return s;
@@ -1618,10 +1681,12 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     }
     if ((s = alloc_field(m, m->wideG[0], wsx, m->f[GB25_GN_BT_U].ny, 1))) return s;
     if ((s = alloc_field(m, m->wideG[1], wsx, m->f[GB25_GN_BT_V].ny, 1))) return s;
+    if (m->g.cv.on && (s = build_curv_wide(m))) return s;
   }
   if (cfg->grid_type == GB25_GRID_LAT_LON_GAUSSIAN_ISLANDS || cfg->grid_type == GB25_GRID_TRIPOLAR_GAUSSIAN_ISLANDS) {
     if (cfg->Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "an immersed boundary needs Nz <= 254 (8-bit level tables)");
     if ((s = build_bottom(m, [&](int i, int j) { return gaussian_islands_bottom(m, i, j); }))) return s;
+    m->immersed = true;   // (every slab of a decomposition runs the kernel variants the single domain runs, mountains or not)
   } else if (m->g.cv.on) {
     // the curvilinear kernels take every reconstruction order and mask from the tables (that is also where the fold's
     // "north is not a wall" lives): a flat bottom is a bottom nothing touches
@@ -1659,6 +1724,8 @@ void gb25_destroy(gb25_model* m) {
   for (auto p : m->d_H)
     if (p) hipFree(p);
   for (auto p : m->d_wideH)
+    if (p) hipFree(p);
+  for (auto p : m->d_wideM)
     if (p) hipFree(p);
   for (auto p : m->d_top_flux)
     if (p) hipFree(p);
@@ -2198,6 +2265,12 @@ gb25_status gb25_lookahead_state(const gb25_model* m, int32_t* velocities_ready,
 int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int32_t ready, char* out, int64_t cap) {
   if (nslabs < 1) return -1;
   TraceOps ops(nslabs, adopted != 0, ready != 0);
+  if (first & 2) {          // (bit 1 of `first`: a folded grid with the default three-substep trace)
+    ops.fold = true;
+    ops.nsub = 3;
+    ops.adopted = ops.ready = false;
+  }
+  first &= 1;
   bool in_flight = false;
   if (first) sequence_first_time_step(ops, in_flight);
   else sequence_time_step(ops, 0, in_flight);

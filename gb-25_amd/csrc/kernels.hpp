@@ -168,6 +168,78 @@ __global__ void k_fill_fold(Grid g, Halo3 f3, Halo2 f2) {
   }
 }
 
+// The same fold on a slab of a decomposition: the cells beyond the fold are the images of cells of the PARTNER rank
+// P-1-r (mirrored in x), which sends the H rows next to its fold line -- all its parent columns, every interior level --
+// and receives ours.  Buffer layout per field: [level][q][parent column], q = 0 .. H-1 counting rows away from the fold
+// line (cell rows Ny-1-q; y-face rows Ny-q, q = 0 being the fold line itself); 3-D fields first, then the 2-D ones.
+struct FoldFields {
+  real* p[7];
+  int is_v[7], xf[7], neg[7], nz[7];   // nz: interior levels (1: a 2-D field)
+  long off[7];                          // element offset of the field in the exchange buffer
+  int n;
+};
+// grid: (ceil(sx/256), H, sum of nz)
+__global__ void k_fold_pack(Grid g, FoldFields F, real* __restrict__ buf) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (a >= g.sx) return;
+  int f = 0, k = blockIdx.z;
+  while (k >= F.nz[f]) k -= F.nz[f++];
+  const bool twod = F.nz[f] == 1;
+  const int row = (F.is_v[f] ? g.Ny - q : g.Ny - 1 - q) + g.H;
+  const long pl = F.is_v[f] ? g.pl_v : g.pl_c;
+  buf[F.off[f] + ((long)k * g.H + q) * g.sx + a] = F.p[f][a + (long)g.sx * row + (twod ? 0 : pl * (k + g.H))];
+}
+// grid: (ceil(sx/256), H, sum of (nz + 2 | 1)): the 3-D fields also get the bottom / top layer of the rows beyond the fold.
+// ig0: global column of local column 0; Nxg: global Nx (the fold line's eastern half takes minus its partner).
+__global__ void k_fold_unpack(Grid g, FoldFields F, const real* __restrict__ buf, int ig0, int Nxg) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (a >= g.sx) return;
+  int f = 0, kk = blockIdx.z;
+  while (kk >= (F.nz[f] == 1 ? 1 : F.nz[f] + 2)) kk -= (F.nz[f] == 1 ? 1 : F.nz[f] + 2), f++;
+  const bool twod = F.nz[f] == 1, is_v = F.is_v[f] != 0;
+  const int k = twod ? 0 : kk - 1, ks = twod ? 0 : min(max(k, 0), g.Nz - 1);
+  const int am = F.xf[f] ? g.sx - a : g.sx - 1 - a;      // the partner's parent column of the mirrored cell / face
+  if (am >= g.sx) return;                                   // (the westernmost x face of the halo: never read)
+  const real sg = F.neg[f] ? -real(1.) : real(1.);
+  const long pl = is_v ? g.pl_v : g.pl_c;
+  real* c = F.p[f];
+  const int jd = g.Ny + q + g.H;                            // destination parent row
+  const long od = a + (long)g.sx * jd + (twod ? 0 : pl * (k + g.H));
+  if (is_v && q == 0) {
+    // the fold line itself: the western half keeps what it stepped (and gets its bottom / top layer), the eastern
+    // half is minus its partner
+    int ig = ig0 + a - g.H;
+    ig = ((ig % Nxg) + Nxg) % Nxg;
+    if (2 * ig < Nxg) {
+      if (!twod && (k < 0 || k >= g.Nz)) c[od] = c[a + (long)g.sx * jd + pl * (ks + g.H)];
+      return;
+    }
+  }
+  c[od] = sg * buf[F.off[f] + ((long)ks * g.H + q) * g.sx + am];
+}
+// the five rows of the widened barotropic arrays that the partner's fold-line faces need in a substep (CurvBaro::img)
+__global__ void k_fold_rows_pack(Grid g, const real* __restrict__ eta, const real* __restrict__ U, const real* __restrict__ V,
+                                 const real* __restrict__ GV, int wsx, real* __restrict__ buf) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= wsx) return;
+  const long r1 = (long)wsx * (g.Ny - 1 + g.H), r0 = (long)wsx * (g.Ny + g.H);
+  buf[a] = eta[r1 + a];
+  buf[wsx + a] = U[r1 + a];
+  buf[2 * wsx + a] = V[r1 + a];
+  buf[3 * wsx + a] = V[r0 + a];
+  buf[4 * wsx + a] = GV[r0 + a];
+}
+
+// G.V on the eastern half of the fold line <- minus the partner's (what the fold fill of G.U, G.V does on a single domain);
+// img: the partner's rows as it sent them for the sub-cycle (row 4 = its fold-line G.V on the widened layout, halo W)
+__global__ void k_fold_line_GV(Grid g, real* __restrict__ GV, const real* __restrict__ img, int wsx, int W, int ig0, int Nxg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.Nx) return;
+  int ig = ((ig0 + i) % Nxg + Nxg) % Nxg;
+  if (2 * ig < Nxg) return;
+  GV[i2(g, i, g.Ny)] = -img[4 * wsx + (wsx - 1 - (i + W))];
+}
+
 // ---------------------------------------------------------------------------------------------
 // All three fills in ONE launch.  The periodic x copy has to see the y / z layers of its source columns; instead of
 // waiting for them it reads what they are made FROM: a cell of a y layer is the neighbouring interior row (or zero on a
@@ -1009,40 +1081,92 @@ __global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, real
   b.Ub[o] += wgt * Un;
   b.Vb[o] += wgt * Vn;
 }
-// Orthogonal curvilinear grid (single domain, tables always present): the same substep with the face lengths and areas
-// from the 2-D metric arrays.  With the zipper fold the launch has one more row of threads for the y faces ON the fold
-// line: eta beyond the fold is the image of row Ny-1, and the eastern half of the line takes minus its partner's new
-// value (computed here a second time: no ordering between threads needed), so the transports match to the last bit.
-__device__ __forceinline__ real eta_step_curv(const Grid& g, const Baro& b, int i, int j, real dtau) {
-  const int ip = (i == g.Nx - 1) ? 0 : i + 1, o2 = i2(g, i, j);
-  const real dxU = g.cv.dyfc[i2(g, ip, j)] * b.U0[bi(g, b, ip, j)] - g.cv.dyfc[o2] * b.U0[bi(g, b, i, j)];
+// Orthogonal curvilinear grid (tables always present): the same substep with the face lengths and areas from 2-D metric
+// arrays laid out like the Baro arrays (canonical on a single domain, widened on a slab).  With the zipper fold the
+// launch has one more row of threads for the y faces ON the fold line.  eta beyond the fold is the image of row Ny-1 of
+// the MIRRORED columns: on a single domain those are read in place (REMOTE = false); on a slab they belong to the partner
+// rank P-1-r, which sends its rows Ny-1 of eta, U, V and its fold-line rows of V and G.V once per substep (REMOTE = true:
+// `img`, five rows of the partner's widened arrays as it holds them -- the mirror of array column a is sx-1-a) while the
+// metrics of the mirrored cells come from the grid generator (`mir`).  West of the half-way meridian a fold-line face
+// takes its own new value, east of it minus its partner's (computed here a second time: no ordering between threads or
+// ranks needed), so the transports match to the last bit and a decomposition gives the bits of the single domain.
+// (No contraction into FMAs in this kernel: the mirrored cell's new eta is formed by two different code paths -- in place
+// on a single domain, from the partner's rows on a slab -- and must come out the same to the last bit.)
+#pragma clang fp contract(off)
+struct CurvBaro {
+  const real *dyfc, *dxcf, *razcc, *rdxfc, *rdycf;   // geometry of the Baro arrays (pitch b.sx, column offset b.xo)
+  const real* img;       // REMOTE: [5][b.sx] = eta, U, V of row Ny-1, V and G.V of the fold line, partner's layout
+  const real* mir;       // REMOTE: [6][b.sx] by OWN array column: dyfc_w, dyfc_e, dxcf_s, dxcf_n, razcc of the mirrored cell
+                         //         of row Ny-1, rdycf of the mirrored fold-line face
+  int ig0, Nxg;          // global column of local column 0, global Nx (which half of the fold line a face is on)
+};
+__device__ __forceinline__ real eta_step_curv(const Grid& g, const Baro& b, const CurvBaro& c, int i, int j, real dtau) {
+  const int ip = (b.wrap && i == g.Nx - 1) ? 0 : i + 1, o = bi(g, b, i, j), oe = bi(g, b, ip, j);
+  const real dxU = c.dyfc[oe] * b.U0[oe] - c.dyfc[o] * b.U0[o];
   real dyV;
-  if (j == g.Ny - 1 && !g.cv.north_fold) dyV = -(g.cv.dxcf[o2] * b.V0[bi(g, b, i, j)]);
-  else if (j == 0) dyV = g.cv.dxcf[o2 + g.sx] * b.V0[bi(g, b, i, 1)];
-  else dyV = g.cv.dxcf[o2 + g.sx] * b.V0[bi(g, b, i, j + 1)] - g.cv.dxcf[o2] * b.V0[bi(g, b, i, j)];
-  return b.eta0[bi(g, b, i, j)] - dtau * (dxU + dyV) * g.cv.razcc[o2];
+  if (j == g.Ny - 1 && !g.cv.north_fold) dyV = -(c.dxcf[o] * b.V0[o]);
+  else if (j == 0) dyV = c.dxcf[o + b.sx] * b.V0[o + b.sx];
+  else dyV = c.dxcf[o + b.sx] * b.V0[o + b.sx] - c.dxcf[o] * b.V0[o];
+  return b.eta0[o] - dtau * (dxU + dyV) * c.razcc[o];
 }
-__device__ __forceinline__ real fold_line_V(const Grid& g, const Baro& b, int i, real dtau) {
-  const int j = g.Ny, o = bi(g, b, i, j), o2 = i2(g, i, j);
-  const real dye = (eta_step_curv(g, b, g.Nx - 1 - i, j - 1, dtau) - eta_step_curv(g, b, i, j - 1, dtau)) * g.cv.rdycf[o2];
-  return b.V0[o] + dtau * (-g.g * b.Hcf[o] * dye + b.GV[o]);
+// new eta of the cell that local column i of row Ny-1 mirrors onto.  vn: V on the fold line above THAT cell (old value)
+template <bool REMOTE>
+__device__ __forceinline__ real eta_step_mirror(const Grid& g, const Baro& b, const CurvBaro& c, int i, real vn, real dtau) {
+  if (!REMOTE) return eta_step_curv(g, b, c, g.Nx - 1 - i, g.Ny - 1, dtau);
+  const int a = i + b.xo, am = b.sx - 1 - a;   // own array column, the partner's array column of the mirrored cell
+  const real* M = c.mir + a;
+  const real e0 = c.img[am], uw = c.img[b.sx + am], ue = c.img[b.sx + am + 1], vs = c.img[2 * b.sx + am];
+  const real dxU = M[b.sx] * ue - M[0] * uw;
+  const real dyV = M[3 * b.sx] * vn - M[2 * b.sx] * vs;
+  return e0 - dtau * (dxU + dyV) * M[4 * b.sx];
 }
-__global__ __launch_bounds__(256) void k_barotropic_substep_curv(Grid g, Baro b, real dtau, real wgt) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// new V of the fold-line face of local column i (own = true) or of the face it mirrors onto (own = false)
+template <bool REMOTE>
+__device__ __forceinline__ real fold_line_V(const Grid& g, const Baro& b, const CurvBaro& c, int i, bool own, real dtau) {
+  const int j = g.Ny, o = bi(g, b, i, j);
+  const real e_here = eta_step_curv(g, b, c, i, j - 1, dtau);          // cell (i, Ny-1)
+  if (own) {
+    // (V on the fold line above the mirrored cell is minus the own one: antisymmetric since the last fill / substep)
+    const real e_mir = eta_step_mirror<REMOTE>(g, b, c, i, REMOTE ? c.img[3 * b.sx + (b.sx - 1 - (i + b.xo))] : real(0.), dtau);
+    const real dye = (e_mir - e_here) * c.rdycf[o];
+    return b.V0[o] + dtau * (-g.g * b.Hcf[o] * dye + b.GV[o]);
+  }
+  // the partner's face: its own cell is the mirrored one, its image cell is (i, Ny-1)
+  real V0p, GVp, rdy;
+  if (REMOTE) {
+    const int am = b.sx - 1 - (i + b.xo);
+    V0p = c.img[3 * b.sx + am];
+    GVp = c.img[4 * b.sx + am];
+    rdy = c.mir[5 * b.sx + i + b.xo];
+  } else {
+    const int om = bi(g, b, g.Nx - 1 - i, j);
+    V0p = b.V0[om];
+    GVp = b.GV[om];
+    rdy = c.rdycf[om];
+  }
+  const real e_mir = eta_step_mirror<REMOTE>(g, b, c, i, V0p, dtau);
+  const real dye = (e_here - e_mir) * rdy;
+  return V0p + dtau * (-g.g * b.Hcf[o] * dye + GVp);   // (the static depth of a fold-line face is the same from both sides)
+}
+template <bool REMOTE>
+__global__ __launch_bounds__(256) void k_barotropic_substep_curv(Grid g, Baro b, CurvBaro c, real dtau, real wgt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x + b.ilo;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny + g.cv.north_fold) return;
+  if (i >= b.ihi || j >= g.Ny + g.cv.north_fold) return;
   const int o = bi(g, b, i, j);
   if (j == g.Ny) {
-    const real Vn = (i < g.Nx / 2) ? fold_line_V(g, b, i, dtau) : -fold_line_V(g, b, g.Nx - 1 - i, dtau);
+    int ig = c.ig0 + i;                     // (a widened slab reaches beyond [0, Nxg))
+    ig = ((ig % c.Nxg) + c.Nxg) % c.Nxg;
+    const real Vn = (2 * ig < c.Nxg) ? fold_line_V<REMOTE>(g, b, c, i, true, dtau) : -fold_line_V<REMOTE>(g, b, c, i, false, dtau);
     b.V1[o] = Vn;
     b.Vb[o] += wgt * Vn;
     return;
   }
-  const int im = (i == 0) ? g.Nx - 1 : i - 1, o2 = i2(g, i, j);
-  const real e = eta_step_curv(g, b, i, j, dtau);
-  const real dxe = (e - eta_step_curv(g, b, im, j, dtau)) * g.cv.rdxfc[o2];
+  const int im = (b.wrap && i == 0) ? g.Nx - 1 : i - 1;
+  const real e = eta_step_curv(g, b, c, i, j, dtau);
+  const real dxe = (e - eta_step_curv(g, b, c, im, j, dtau)) * c.rdxfc[o];
   real dye = real(0.);
-  if (j > 0) dye = (e - eta_step_curv(g, b, i, j - 1, dtau)) * g.cv.rdycf[o2];
+  if (j > 0) dye = (e - eta_step_curv(g, b, c, i, j - 1, dtau)) * c.rdycf[o];
   const real Un = b.U0[o] + dtau * (-g.g * b.Hfc[o] * dxe + b.GU[o]);
   const real Vn = b.V0[o] + dtau * (-g.g * b.Hcf[o] * dye + b.GV[o]);
   b.eta1[o] = e;
@@ -1052,6 +1176,7 @@ __global__ __launch_bounds__(256) void k_barotropic_substep_curv(Grid g, Baro b,
   b.Ub[o] += wgt * Un;
   b.Vb[o] += wgt * Vn;
 }
+#pragma clang fp contract(fast)
 // ---------------------------------------------------------------------------------------------
 // Temporally blocked sub-cycle: BT_S substeps per launch.  The one-substep kernel above moves ~60 MB per substep
 // through L2/Infinity Cache (14 array sweeps of 4.3 MB at 1440x720) and is bound by that; here a block loads its
@@ -1352,11 +1477,11 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
   if (i >= ni || j >= g.Ny + g.cv.north_fold) return;
   i += i0;
   if (i >= skip_from) i += skip;   // (the two x-halo strips of a slab in one launch: skip the interior)
-  if (j >= g.Ny) {   // zipper fold: the y faces on the fold line, v only (never with FOLD, never a slab)
+  if (j >= g.Ny) {   // zipper fold: the y faces on the fold line, v only (never with FOLD)
     const int o2 = i2(g, i, j);
     int ov = iv(g, i, j, 0);
     real sv = real(0.);
-    if (Vsum != nullptr) {
+    if (Vsum != nullptr && i >= 0 && i < g.Nx) {
       sv = Vsum[o2];
     } else {
       const int klen = (g.Nz + kchunks - 1) / kchunks;
@@ -1367,7 +1492,7 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
         sv = (k0 == 0) ? pv : sv + pv;
       }
     }
-    Vb[o2] = sv;
+    if (i >= 0 && i < g.Nx) Vb[o2] = sv;
     const real dv = (V[o2] - sv) * (IMM ? g.im.rHcf[o2] : g.rLz);
     const int KPV = IMM ? (int)((g.im.ordC[o2] >> 16) & 255) : 0;
     ov = iv(g, i, j, 0);

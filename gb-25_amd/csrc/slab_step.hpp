@@ -119,6 +119,54 @@ gb25_status pack_unpack(gb25_model* m, int group, real* const buf[2], bool pack)
   return GB25_OK;
 }
 
+// ---- zipper fold of a decomposed tripolar grid: the partner rank P-1-r holds the cells beyond this slab's fold line -----
+// buffer set 3: the H rows next to the fold line of u, v, T, S and eta, U, V (all parent columns, interior levels);
+// buffer set 4: five rows of the widened barotropic arrays, once per substep (CurvBaro::img, kernels.hpp)
+FoldFields fold_fields(gb25_model* m) {
+  FoldFields F{};
+  const Grid& g = m->g;
+  long off = 0;
+  auto add = [&](real* p, int is_v, int xf, int neg, int nz) {
+    const int f = F.n++;
+    F.p[f] = p; F.is_v[f] = is_v; F.xf[f] = xf; F.neg[f] = neg; F.nz[f] = nz; F.off[f] = off;
+    off += (long)nz * g.H * g.sx;
+  };
+  add(m->f[GB25_U].d, 0, 1, 1, g.Nz);
+  add(m->f[GB25_V].d, 1, 0, 1, g.Nz);
+  add(m->f[GB25_T].d, 0, 0, 0, g.Nz);
+  add(m->f[GB25_S].d, 0, 0, 0, g.Nz);
+  add(m->f[GB25_ETA].d, 0, 0, 0, 1);
+  add(m->f[GB25_BT_U].d, 0, 1, 1, 1);
+  add(m->f[GB25_BT_V].d, 1, 0, 1, 1);
+  return F;
+}
+int64_t fold_buffer_elems(gb25_model* m, int b) {
+  const Grid& g = m->g;
+  if (!g.cv.north_fold) return 1;
+  return b == 3 ? (int64_t)g.H * g.sx * (4 * g.Nz + 3) : (int64_t)5 * (g.Nx + 2 * m->W);
+}
+gb25_status fold_pack(gb25_model* m, real* buf) {
+  const Grid& g = m->g;
+  FoldFields F = fold_fields(m);
+  hipLaunchKernelGGL(k_fold_pack, dim3((g.sx + 255) / 256, g.H, 4 * g.Nz + 3), dim3(256), 0, m->stream, g, F, buf);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+gb25_status fold_unpack(gb25_model* m, const real* buf) {
+  const Grid& g = m->g;
+  FoldFields F = fold_fields(m);
+  hipLaunchKernelGGL(k_fold_unpack, dim3((g.sx + 255) / 256, g.H, 4 * (g.Nz + 2) + 3), dim3(256), 0, m->stream, g, F, buf,
+                     m->cfg.rank * m->Nx, m->cfg.Nx);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+
+// the sub-cycle of a slab of a folded grid, one substep per call (defined after SlabGroup: they use its buffers)
+gb25_status barotropic_fold_begin(gb25_model* m);
+gb25_status barotropic_fold_rows(gb25_model* m, int sub);
+gb25_status barotropic_fold_substep(gb25_model* m, int sub, real dt);
+gb25_status barotropic_fold_end(gb25_model* m, real dt);
+
 // ---- the stages of one slab's time step (see the header of this file) -------------------------------------------------
 gb25_status slab_stage(gb25_model* m, int stage, int euler) {
   const Grid& g = m->g;
@@ -126,7 +174,8 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
   const double dt = m->last_dt;
   const real chi = euler ? -real(0.5) : (real)m->cfg.chi;
   const bool split = tendencies_split(m);
-  const bool p_early = m->two_streams && m->pressure_bits == 64;   // own columns' pressure early, on the side stream
+  // own columns' pressure early, on the side stream (not on a folded grid: the rows beyond the fold arrive last)
+  const bool p_early = m->two_streams && m->pressure_bits == 64 && !g.cv.north_fold;
   if (stage == 0) {
     // AB2 update of u,v,T,S + barotropic forcing, then the y/z boundary layers of the 3-D bundle so that its packed
     // x columns (group 0) can travel WHILE the own columns are corrected
@@ -207,14 +256,18 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     if ((s = compute_w_impl(m, 1))) return s;
     HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));       // the own columns' pressure differences (side stream)
     return momentum_impl(m, 1);
-  } else if (stage == 3) {
+  } else if (stage == 3 || stage == 30 || stage == 31) {
     // groups 2 and 0 have been unpacked: corrector on the x-halo columns, then update_state without any
-    // further exchange (y/z layers re-filled over the extended x range; w and p recomputed in the halos)
-    if ((s = corrector_impl(m, true, 2))) return s;
-    // the interior pressure pass of stage 0 must be over before the fills touch T, S and before the west strip
-    // rewrites column 0 (it has been for a while: the exchanges and the sub-cycle ran in between)
-    if (p_early) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
-    if ((s = fill_halos_impl(m, false, true))) return s;
+    // further exchange (y/z layers re-filled over the extended x range; w and p recomputed in the halos).
+    // Folded grid: stage 30 = up to the y/z layers, then the rows beyond the fold arrive from the partner, stage 31 = the rest.
+    if (stage != 31) {
+      if ((s = corrector_impl(m, true, 2))) return s;
+      // the interior pressure pass of stage 0 must be over before the fills touch T, S and before the west strip
+      // rewrites column 0 (it has been for a while: the exchanges and the sub-cycle ran in between)
+      if (p_early) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+      if ((s = fill_halos_impl(m, false, true))) return s;
+      if (stage == 30) return GB25_OK;
+    }
     if (p_early) {   // the two pressure strips run beside w (side stream)
       hipStream_t main = m->stream;
       HIPCHK(hipEventRecord(m->ev_fork, main));
@@ -235,8 +288,31 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
   } else if (stage == 4) {
     // the tracer tendencies; the look-ahead of the next sub-cycle (groups 3, 4 and stage 5) runs beside them
     return tracers_impl(m);
+  } else if (stage == 10) {
+    // folded grid, sub-cycle inside the step: group 1 has been unpacked into the wide halos: copy the interiors, zero the
+    // running averages
+    std::vector<Piece> ps;
+    int nc = 0;
+    group_pieces(m, 1, ps, &nc);
+    InteriorCopies C{};
+    int rmax = 0;
+    for (auto& p : ps) {
+      const int q = C.n++;
+      C.dst[q] = p.dst; C.dsx[q] = p.dst_sx; C.dxo[q] = p.dst_xo;
+      C.src[q] = p.src; C.ssx[q] = p.src_sx; C.sxo[q] = p.src_xo; C.rows[q] = (int)p.rows;
+      rmax = std::max(rmax, (int)p.rows);
+    }
+    hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, rmax, C.n), dim3(256), 0, m->stream, C, g.Nx);
+    LAUNCHCHK();
+    return barotropic_fold_begin(m);
+  } else if (stage == 11) {
+    return barotropic_fold_end(m, (real)dt);
+  } else if (stage >= 100 && stage < 100 + 4096) {
+    return barotropic_fold_rows(m, stage - 100);            // pack the rows the partner's fold-line faces need in this substep
+  } else if (stage >= 5000 && stage < 5000 + 4096) {
+    return barotropic_fold_substep(m, stage - 5000, (real)dt);
   }
-  return fail(m, GB25_ERR_INVALID_ARGUMENT, "stage must be 0 .. 5");
+  return fail(m, GB25_ERR_INVALID_ARGUMENT, "unknown stage %d", stage);
 }
 
 gb25_status update_state_local_impl(gb25_model* m) {   // update_state! without the x-halo fill
@@ -263,6 +339,8 @@ struct StepOps {
   virtual gb25_status local(int s, int what) = 0;              // 0: initialize!, 1: y/z halo layers, 2: update_state! (local)
   virtual bool velocities_ready(int s) = 0;
   virtual bool subcycle_adopted(int s) = 0;
+  virtual bool folded() = 0;          // zipper fold: exchanges with the partner rank (buffer sets 3 and 4; groups 6 and 7)
+  virtual int substeps() = 0;
   virtual gb25_status record(int slot, bool on_comm) = 0;
   virtual gb25_status wait(int slot, bool comm_waits) = 0;
 };
@@ -295,12 +373,26 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
   EACH(o.pack(s, 0, true));
   SEQ(o.record(1, true));      // (packed)
   SEQ(o.exchange(0, true));
-  if (!adopted) {              // ... and is in flight while the sub-cycle runs here
+  if (!adopted && o.folded()) {
+    // zipper fold: the fold-line faces of a slab need rows of the partner rank P-1-r in every substep, so the slabs advance
+    // substep by substep: pack five rows, exchange with the partner (buffer set 4), one substep on the widened slab
+    EACH(o.unpack(s, 1, false));
+    EACH(o.stage(s, 10, euler, false));
+    for (int sub = 0; sub < o.substeps(); sub++) {
+      EACH(o.stage(s, 100 + sub, euler, false));
+      SEQ(o.exchange(7, false));
+      EACH(o.stage(s, 5000 + sub, euler, false));
+    }
+    EACH(o.stage(s, 11, euler, false));
+    EACH(o.pack(s, 2, false));
+  } else if (!adopted) {       // ... and is in flight while the sub-cycle runs here
     for (int s = 0; s < n; s++) {
       SEQ(o.unpack(s, 1, false));
       SEQ(o.stage(s, 1, euler, false));
       SEQ(o.pack(s, 2, false));
     }
+  }
+  if (!adopted) {
     SEQ(o.record(2, false));
     SEQ(o.wait(2, true));      // eta, U, V columns leave behind the bundle on the second stream
     SEQ(o.exchange(2, true));
@@ -310,9 +402,24 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
   SEQ(o.record(3, true));
   SEQ(o.wait(3, false));       // the halo columns have arrived
   if (!adopted) EACH(o.unpack(s, 2, false));
-  for (int s = 0; s < n; s++) {
-    SEQ(o.unpack(s, 0, false));
-    SEQ(o.stage(s, 3, euler, false));
+  if (o.folded()) {
+    // the rows beyond the fold come from the partner once every slab has its x halos and y/z layers (the partner sends
+    // its halo columns too: the corners), then the rest of update_state!
+    for (int s = 0; s < n; s++) {
+      SEQ(o.unpack(s, 0, false));
+      SEQ(o.stage(s, 30, euler, false));
+      SEQ(o.pack(s, 6, false));
+    }
+    SEQ(o.exchange(6, false));
+    for (int s = 0; s < n; s++) {
+      SEQ(o.unpack(s, 6, false));
+      SEQ(o.stage(s, 31, euler, false));
+    }
+  } else {
+    for (int s = 0; s < n; s++) {
+      SEQ(o.unpack(s, 0, false));
+      SEQ(o.stage(s, 3, euler, false));
+    }
   }
   // the next step's G.U, G.V exist now: its wide-halo exchange, sub-cycle and eta,U,V exchange run on the second stream
   // beside the tracer tendencies
@@ -351,6 +458,20 @@ gb25_status sequence_first_time_step(StepOps& o, bool& lookahead_in_flight) {
   }
   SEQ(o.exchange(0, false));
   SEQ(o.exchange(2, false));
+  if (o.folded()) {
+    for (int s = 0; s < n; s++) {
+      SEQ(o.unpack(s, 0, false));
+      SEQ(o.unpack(s, 2, false));
+      SEQ(o.local(s, 3));          // mask, y/z layers over the extended columns
+      SEQ(o.pack(s, 6, false));
+    }
+    SEQ(o.exchange(6, false));
+    for (int s = 0; s < n; s++) {
+      SEQ(o.unpack(s, 6, false));
+      SEQ(o.local(s, 4));          // w, pressure, tendencies
+    }
+    return sequence_time_step(o, 1, lookahead_in_flight);
+  }
   for (int s = 0; s < n; s++) {
     SEQ(o.unpack(s, 0, false));
     SEQ(o.unpack(s, 2, false));
@@ -366,7 +487,11 @@ struct TraceOps : StepOps {
   int nslabs;
   bool adopted, ready;
   std::string log;
+  bool fold = false;
+  int nsub = 21;
   TraceOps(int n_, bool a, bool r) : nslabs(n_), adopted(a), ready(r) {}
+  bool folded() override { return fold; }
+  int substeps() override { return nsub; }
   void add(const char* fmt, ...) {
     char buf[96];
     va_list ap;
@@ -383,7 +508,7 @@ struct TraceOps : StepOps {
   gb25_status unpack(int s, int group, bool c) override { add("unpack %d slab %d %s", group, s, st(c)); return GB25_OK; }
   gb25_status exchange(int group, bool c) override { add("exchange %d %s", group, st(c)); return GB25_OK; }
   gb25_status local(int s, int what) override {
-    static const char* names[] = {"initialize", "fill_local", "update_state_local"};
+    static const char* names[] = {"initialize", "fill_local", "update_state_local", "mask_fill_local", "auxiliaries_tendencies_local"};
     add("%s slab %d main", names[what], s);
     return GB25_OK;
   }
@@ -409,8 +534,9 @@ struct SlabGroup {
   hipStream_t main = nullptr, comm = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   Transport* transport = nullptr;
-  std::vector<std::array<std::array<real*, 2>, 3>> send, recv;   // [slab][buffer set][side: 0 west, 1 east]
-  size_t elems[3] = {0, 0, 0};
+  // [slab][buffer set][side: 0 west, 1 east]; sets 3, 4 go to the fold partner (side 0 only)
+  std::vector<std::array<std::array<real*, 2>, 5>> send, recv;
+  size_t elems[5] = {0, 0, 0, 0, 0};
   bool lookahead_in_flight = false;
   // neighbour handshake of the collective mutators (see collective_guard)
   unsigned long long *tok_dev = nullptr, *tok_host = nullptr;
@@ -418,13 +544,21 @@ struct SlabGroup {
 
 namespace {
 
-inline int buffer_set(int group) { return group == 0 ? 0 : ((group == 1 || group == 3) ? 1 : 2); }
+// (groups 6, 7: the partner exchanges of a folded grid -- the rows next to the fold line; the sub-cycle's rows)
+inline int buffer_set(int group) { return group == 6 ? 3 : group == 7 ? 4 : group == 0 ? 0 : ((group == 1 || group == 3) ? 1 : 2); }
 
 // several slabs of one decomposition in this process, all on one device: a ring of device-to-device copies
 struct LocalRingTransport : Transport {
   const char* name() const override { return "local"; }
   gb25_status exchange(SlabGroup& G, int b, size_t nbytes, hipStream_t st) override {
     const int P = (int)G.slabs.size();
+    if (b >= 3) {   // zipper fold: slab r <-> slab P-1-r (the middle slab of an odd count is its own partner)
+      for (int r = 0; r < P; r++) {
+        gb25_model* m = G.slabs[r];
+        HIPCHK(hipMemcpyAsync(G.recv[P - 1 - r][b][0], G.send[r][b][0], nbytes, hipMemcpyDeviceToDevice, st));
+      }
+      return GB25_OK;
+    }
     for (int r = 0; r < P; r++) {
       gb25_model* m = G.slabs[r];
       const int west = (r + P - 1) % P, east = (r + 1) % P;
@@ -513,6 +647,20 @@ struct RcclTransport : Transport {
     return GB25_OK;
   }
   gb25_status exchange(SlabGroup& G, int b, size_t nbytes, hipStream_t st) override {
+    if (b >= 3) {   // zipper fold: the partner is rank P-1-r
+      gb25_model* m = G.slabs[0];
+      const int partner = nranks - 1 - rank;
+      if (partner == rank) {
+        HIPCHK(hipMemcpyAsync(G.recv[0][b][0], G.send[0][b][0], nbytes, hipMemcpyDeviceToDevice, st));
+        return GB25_OK;
+      }
+      RcclApi& R = rccl();
+      NCCLCHK(R.GroupStart());
+      NCCLCHK(R.Send(G.send[0][b][0], nbytes, ncclInt8, partner, comm, st));
+      NCCLCHK(R.Recv(G.recv[0][b][0], nbytes, ncclInt8, partner, comm, st));
+      NCCLCHK(R.GroupEnd());
+      return GB25_OK;
+    }
     return send_recv(G.slabs[0], G.send[0][b][0], G.send[0][b][1], G.recv[0][b][0], G.recv[0][b][1], nbytes, st);
   }
 };
@@ -525,11 +673,77 @@ struct CallbackTransport : Transport {
   gb25_status exchange(SlabGroup& G, int b, size_t nbytes, hipStream_t st) override {
     gb25_model* m = G.slabs[0];
     HIPCHK(hipStreamSynchronize(st));   // the packs are complete
-    const int rc = fn(user, b, G.send[0][b][0], G.send[0][b][1], G.recv[0][b][0], G.recv[0][b][1], (int64_t)nbytes);
+    // (buffer sets 3, 4: to and from the fold partner rank P-1-r; the east pointers are null)
+    const int rc = b >= 3 ? fn(user, b, G.send[0][b][0], nullptr, G.recv[0][b][0], nullptr, (int64_t)nbytes)
+                          : fn(user, b, G.send[0][b][0], G.send[0][b][1], G.recv[0][b][0], G.recv[0][b][1], (int64_t)nbytes);
     if (rc != 0) return fail(m, GB25_ERR_COMM, "the host's exchange callback failed with code %d (buffer set %d)", rc, b);
     return GB25_OK;
   }
 };
+
+// ---- the sub-cycle of a slab of a folded grid (stages 10, 100 + sub, 5000 + sub, 11) ---------------------------------
+// Widened arrays as on the lat-lon grid (one wide-halo exchange per step, no x exchange inside), one launch per substep
+// (k_barotropic_substep_curv<true>), and before each of them the five rows the partner's fold-line faces need.
+gb25_status barotropic_fold_begin(gb25_model* m) {
+  HIPCHK(hipMemsetAsync(m->wideBar[0].d, 0,
+                        (m->wideBar[0].elems() + m->wideBar[1].elems() + m->wideBar[2].elems()) * sizeof(real), m->stream));
+  m->fold_flip = 0;
+  return GB25_OK;
+}
+gb25_status barotropic_fold_rows(gb25_model* m, int) {
+  const Grid& g = m->g;
+  SlabGroup* G = m->group;
+  const int wsx = g.Nx + 2 * m->W, a = m->fold_flip;
+  hipLaunchKernelGGL(k_fold_rows_pack, dim3((wsx + 255) / 256), dim3(256), 0, m->stream, g, m->wide[a][0].d, m->wide[a][1].d,
+                     m->wide[a][2].d, m->wideG[1].d, wsx, G->send[m->group_index][4][0]);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+gb25_status barotropic_fold_substep(gb25_model* m, int sub, real dt) {
+  const Grid& g = m->g;
+  SlabGroup* G = m->group;
+  const int a = m->fold_flip;
+  Baro bb;
+  bb.eta0 = m->wide[a][0].d; bb.U0 = m->wide[a][1].d; bb.V0 = m->wide[a][2].d;
+  bb.eta1 = m->wide[a ^ 1][0].d; bb.U1 = m->wide[a ^ 1][1].d; bb.V1 = m->wide[a ^ 1][2].d;
+  bb.etab = m->wideBar[0].d; bb.Ub = m->wideBar[1].d; bb.Vb = m->wideBar[2].d;
+  bb.GU = m->wideG[0].d; bb.GV = m->wideG[1].d;
+  bb.sx = g.Nx + 2 * m->W; bb.xo = m->W; bb.ilo = -m->W + 1; bb.ihi = g.Nx + m->W - 1; bb.wrap = 0;
+  bb.Hfc = m->d_wideH[0]; bb.Hcf = m->d_wideH[1];
+  const CurvBaro cb{m->d_wideM[0], m->d_wideM[1], m->d_wideM[2], m->d_wideM[3], m->d_wideM[4],
+                    G->recv[m->group_index][4][0], m->d_wideM[5], m->cfg.rank * g.Nx, m->cfg.Nx};
+  dim3 b(64, 4);
+  Timed t(m, GB25_K_BAROTROPIC);
+  hipLaunchKernelGGL(k_barotropic_substep_curv<true>, grid2(bb.ihi - bb.ilo, v_rows(g), b), b, 0, m->stream, g, bb, cb,
+                     (real)m->dtau_frac * dt, (real)m->weights[sub]);
+  LAUNCHCHK();
+  m->fold_flip ^= 1;
+  return GB25_OK;
+}
+gb25_status barotropic_fold_end(gb25_model* m, real dt) {
+  const Grid& g = m->g;
+  dim3 b(64, 4);
+  const int wsx = g.Nx + 2 * m->W;
+  hipLaunchKernelGGL(k_barotropic_finalize, grid2(g.Nx, v_rows(g), b), b, 0, m->stream, g, m->f[GB25_ETA].d, m->f[GB25_BT_U].d,
+                     m->f[GB25_BT_V].d, m->wideBar[0].d, m->wideBar[1].d, m->wideBar[2].d, wsx, m->W);
+  InteriorCopies C{};
+  int rmax = 0;
+  for (int q = 0; q < 3; q++) {   // publish the averages in the canonical filtered-state arrays
+    Field& dst = m->f[GB25_ETA_BAR + q];
+    C.dst[q] = dst.d; C.dsx[q] = dst.nx; C.dxo[q] = g.H;
+    C.src[q] = m->wideBar[q].d; C.ssx[q] = wsx; C.sxo[q] = m->W; C.rows[q] = dst.ny;
+    rmax = std::max(rmax, dst.ny);
+  }
+  C.n = 3;
+  hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, rmax, C.n), dim3(256), 0, m->stream, C, g.Nx);
+  // the state's G.V on the fold line: antisymmetric, as the fold fill of G.U, G.V leaves it on a single domain
+  hipLaunchKernelGGL(k_fold_line_GV, dim3((g.Nx + 255) / 256), dim3(256), 0, m->stream, g, m->f[GB25_GN_BT_V].d,
+                     m->group->recv[m->group_index][4][0], wsx, m->W, m->cfg.rank * g.Nx, m->cfg.Nx);
+  LAUNCHCHK();
+  m->time += (double)dt;
+  m->iteration += 1;
+  return fill_halos_impl(m, false, false, 2);   // y layer of the new eta, U, V; their x columns are group 2
+}
 
 // the real StepOps: the slabs of a SlabGroup
 struct GroupOps : StepOps {
@@ -547,15 +761,19 @@ struct GroupOps : StepOps {
     OnStream on(G.slabs[s], st(c));
     return slab_stage(G.slabs[s], stage, euler);
   }
+  bool folded() override { return G.slabs[0]->g.cv.north_fold != 0; }
+  int substeps() override { return G.slabs[0]->Ns; }
   gb25_status pack(int s, int group, bool c) override {
     OnStream on(G.slabs[s], st(c));
     const int b = buffer_set(group);
+    if (group == 6) return fold_pack(G.slabs[s], G.send[s][b][0]);
     real* buf[2] = {G.send[s][b][0], G.send[s][b][1]};
     return pack_unpack(G.slabs[s], group, buf, true);
   }
   gb25_status unpack(int s, int group, bool c) override {
     OnStream on(G.slabs[s], st(c));
     const int b = buffer_set(group);
+    if (group == 6) return fold_unpack(G.slabs[s], G.recv[s][b][0]);
     real* buf[2] = {G.recv[s][b][0], G.recv[s][b][1]};
     return pack_unpack(G.slabs[s], group, buf, false);
   }
@@ -567,11 +785,22 @@ struct GroupOps : StepOps {
     gb25_model* m = G.slabs[s];
     if (what == 0) return initialize_impl(m);
     if (what == 1) return fill_halos_impl(m, false);
+    if (what == 3) {
+      if (gb25_status s_ = mask_impl(m)) return s_;
+      return fill_halos_impl(m, false, true);
+    }
+    if (what == 4) {
+      gb25_status s_;
+      if ((s_ = compute_w_impl(m))) return s_;
+      if ((s_ = compute_p_impl(m))) return s_;
+      if ((s_ = momentum_impl(m))) return s_;
+      return tracers_impl(m);
+    }
     return update_state_local_impl(m);
   }
   bool velocities_ready(int s) override {
     gb25_model* m = G.slabs[s];
-    return m->ahead_uv_valid && m->baro_ahead && !m->ptr_exposed;
+    return m->ahead_uv_valid && m->baro_ahead && !m->ptr_exposed && !m->g.cv.north_fold;
   }
   bool subcycle_adopted(int s) override { return G.slabs[s]->baro_adopted; }
   gb25_status record(int slot, bool c) override {
@@ -638,11 +867,12 @@ gb25_status group_create(gb25_model* const* slabs, int n, Transport* tr) {
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) st = GB25_ERR_HIP;
     if (st) break;
     for (int b = 0; b < 3; b++) G->elems[b] = (size_t)halo_buffer_elems(m, b);
+    for (int b = 3; b < 5; b++) G->elems[b] = (size_t)fold_buffer_elems(m, b);
     G->send.resize(n);
     G->recv.resize(n);
     for (int s = 0; s < n && !st; s++)
-      for (int b = 0; b < 3 && !st; b++)
-        for (int side = 0; side < 2 && !st; side++) {
+      for (int b = 0; b < 5 && !st; b++)
+        for (int side = 0; side < (b < 3 ? 2 : 1) && !st; side++) {
           G->send[s][b][side] = G->recv[s][b][side] = nullptr;
           if (hipMalloc(&G->send[s][b][side], G->elems[b] * sizeof(real)) != hipSuccess ||
               hipMalloc(&G->recv[s][b][side], G->elems[b] * sizeof(real)) != hipSuccess)

@@ -55,6 +55,24 @@ class TorchDistributedTransport:
             torch.cuda.current_stream().synchronize()     # the library's streams know nothing of torch's
 
 
+    def exchange_partner(self, send, recv):
+        """Zipper fold of a decomposed tripolar grid: slab r <-> slab P-1-r (buffer sets 3 and 4 of the library)."""
+        d = self.dist
+        partner = self.nranks - 1 - self.rank
+        if partner == self.rank:
+            recv.copy_(send)
+            return
+        stage = send.is_cuda and d.get_backend() != "nccl"
+        dev = recv
+        if stage:
+            send, recv = send.cpu(), torch.empty_like(send, device="cpu")
+        for req in d.batch_isend_irecv([d.P2POp(d.isend, send, partner), d.P2POp(d.irecv, recv, partner)]):
+            req.wait()
+        if stage:
+            dev.copy_(recv)
+            torch.cuda.current_stream().synchronize()
+
+
 class _DevicePointer:
     """A device buffer of the library seen by torch (zero-copy) through __cuda_array_interface__."""
 
@@ -101,6 +119,11 @@ class SlabModel(HydrostaticFreeSurfaceModel):
             dev = torch.device("cuda", device)
 
             def exchange(buffer_set, sw, se, rw, re, nbytes):
+                if buffer_set >= 3:      # to and from the fold partner (the east pointers are null)
+                    self._ring.exchange_partner(_as_tensor(sw, nbytes, dev), _as_tensor(rw, nbytes, dev))
+                    if torch.cuda.is_available():
+                        torch.cuda.current_stream().synchronize()
+                    return
                 self._ring.exchange(_as_tensor(sw, nbytes, dev), _as_tensor(se, nbytes, dev),
                                     _as_tensor(rw, nbytes, dev), _as_tensor(re, nbytes, dev))
             backend.comm_init_callback(exchange)

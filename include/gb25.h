@@ -91,7 +91,9 @@ typedef enum {
                                              vehicle, results equal those of grid 0 to round-off */
   GB25_GRID_TRIPOLAR = 3,                 /* TripolarGrid(arch; size, halo, z) (src/model_utils.jl:134-137), flat bottom:
                                              poles at (70 E, 55 N) and (250 E, 55 N), southern edge lat_south, zipper
-                                             fold along the northern edge.  The poles are singular without land. */
+                                             fold along the northern edge.  The poles are singular without land.
+                                             Decomposed in x like the other grids: the cells beyond a slab's fold line
+                                             belong to the mirrored rank nranks-1-rank, an extra point-to-point partner */
   GB25_GRID_TRIPOLAR_GAUSSIAN_ISLANDS = 4, /* grid_type = :gaussian_islands of the reference (src/model_utils.jl:129-146):
                                              the tripolar grid with the two Gaussian mountains over its poles */
   GB25_GRID_COUNT
@@ -260,7 +262,9 @@ gb25_status gb25_comm_init_local(gb25_model *const *slabs, int32_t n);
 /* the host moves the buffers: fn is called once per exchange with device pointers of this slab's two packed sends and
  * two receive buffers (nbytes each); it must return 0 after recv_west holds the west neighbour's send_east and
  * recv_east the east neighbour's send_west.  The library synchronises the issuing stream before the call (no overlap):
- * a rehearsal transport for setups where RCCL cannot run (two ranks on one device). */
+ * a rehearsal transport for setups where RCCL cannot run (two ranks on one device).  buffer_set 3 and 4 (tripolar grid
+ * only) are exchanges with the FOLD PARTNER, rank nranks-1-rank: send_west goes to it, recv_west must hold what it sent,
+ * the east pointers are NULL. */
 typedef int32_t (*gb25_exchange_fn)(void *user, int32_t buffer_set, const void *send_west, const void *send_east,
                                     void *recv_west, void *recv_east, int64_t nbytes);
 gb25_status gb25_comm_init_callback(gb25_model *m, gb25_exchange_fn fn, void *user);

@@ -18,7 +18,9 @@ if __name__ == "__main__":
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group(os.environ.get("GB25_DIST_BACKEND", "gloo"))
-    m = SlabModel(Nx, Ny, Nz, dt=600.0, rank=rank, nranks=world, device=0)   # gloo => the host-callback transport
+    grid_type = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    kw = dict(grid_type=grid_type) if grid_type else {}
+    m = SlabModel(Nx, Ny, Nz, dt=600.0, rank=rank, nranks=world, device=0, **kw)   # gloo => the host-callback transport
     nloc = Nx // world
     gb.set_baroclinic_instability(m)
     u0 = (1e-2 * counter_rng((Nx, Ny, Nz), 42, 1)).astype(np.float32)

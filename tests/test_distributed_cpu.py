@@ -104,6 +104,43 @@ def test_time_step_sequencing_in_step_subcycle():
         assert all(i > ex[0] for i, e in enumerate(log) if e[:2] == ("unpack", grp))
 
 
+def test_time_step_sequencing_on_a_folded_grid():
+    """Tripolar grid in slabs: the rows beyond a slab's fold line belong to the mirrored rank.  The sub-cycle advances
+    substep by substep (five rows from the partner before each: buffer set 4, "exchange 7"), the rows next to the fold line
+    of u, v, T, S, eta, U, V travel once per step ("exchange 6") after the x halos and y/z layers of EVERY slab are in
+    place (the partner sends its halo columns too) and before w, pressure and the tendencies."""
+    lib = load_library("Float32")
+    need = lib.gb25_debug_sequence(3, 2, 0, 0, None, 0)
+    buf = ctypes.create_string_buffer(need)
+    lib.gb25_debug_sequence(3, 2, 0, 0, buf, need)
+    log = [tuple(int(t) if t.lstrip("-").isdigit() else t for t in line.split()) for line in buf.value.decode().splitlines()]
+    mine = _ops_of_slab(log, 1)
+    assert mine == [("stage", 0, "main"), ("pack", 1, "main"), ("exchange", 1, "main"),
+                    ("pack", 0, "comm"), ("exchange", 0, "comm"),
+                    ("unpack", 1, "main"), ("stage", 10, "main"),
+                    ("stage", 100, "main"), ("exchange", 7, "main"), ("stage", 5000, "main"),
+                    ("stage", 101, "main"), ("exchange", 7, "main"), ("stage", 5001, "main"),
+                    ("stage", 102, "main"), ("exchange", 7, "main"), ("stage", 5002, "main"),
+                    ("stage", 11, "main"), ("pack", 2, "main"), ("exchange", 2, "comm"),
+                    ("stage", 2, "main"),
+                    ("unpack", 2, "main"), ("unpack", 0, "main"), ("stage", 30, "main"), ("pack", 6, "main"),
+                    ("exchange", 6, "main"), ("unpack", 6, "main"), ("stage", 31, "main"), ("stage", 4, "main")]
+    # every slab has packed its rows before the partner exchange and no slab unpacks before it
+    ex = [i for i, e in enumerate(log) if e[:2] == ("exchange", 6)]
+    assert len(ex) == 1
+    assert all(i < ex[0] for i, e in enumerate(log) if e[:2] == ("pack", 6))
+    assert all(i > ex[0] for i, e in enumerate(log) if e[:2] == ("unpack", 6))
+    assert not any(e[:2] == ("stage", 5) for e in log) and log[-1] == ("lookahead_in_flight", 0)
+    # first_time_step!: mask + y/z layers of every slab, the fold exchange, then auxiliaries and tendencies
+    need = lib.gb25_debug_sequence(2, 3, 0, 0, None, 0)
+    buf = ctypes.create_string_buffer(need)
+    lib.gb25_debug_sequence(2, 3, 0, 0, buf, need)
+    names = [line.split()[0] for line in buf.value.decode().splitlines()]
+    first = names[:names.index("stage")]
+    assert first.index("mask_fill_local") < first.index("auxiliaries_tendencies_local")
+    assert "update_state_local" not in first
+
+
 def test_time_step_sequencing_with_the_subcycle_lookahead():
     """When the previous step left a valid look-ahead, stage 0 adopts the sub-cycle: groups 1, 2 and stage 1 vanish
     from the step; after the momentum tendencies (stage 3) the NEXT sub-cycle is prepared beside the tracer

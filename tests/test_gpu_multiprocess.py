@@ -41,6 +41,25 @@ def test_two_rank_slab_run_matches_single_domain(tmp_path):
         assert np.array_equal(got, single.backend.get_field(n, False)), n
 
 
+def test_two_rank_run_on_the_folded_grid_matches_single_domain(tmp_path):
+    """grid_type = :gaussian_islands (tripolar grid + mountains) on two ranks: each is the other's fold partner; the partner
+    exchanges (rows next to the fold line once per step, five rows per substep) go through the same host callback."""
+    Nx, Ny, Nz, nsteps = 96, 40, 8, 4
+    res = _launch([os.path.join(ROOT, "tests", "mp_slab_worker.py"), str(tmp_path), str(Nx), str(Ny), str(Nz),
+                   str(nsteps), "4"], {})
+    assert res.returncode == 0, res.stderr[-3000:]
+    single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=600.0, grid_type="gaussian_islands")
+    gb.set_baroclinic_instability(single)
+    single.set(u=(1e-2 * counter_rng((Nx, Ny, Nz), 42, 1)).astype(np.float32),
+               v=(1e-2 * counter_rng((Nx, Ny + 1, Nz), 42, 2)).astype(np.float32))
+    gb.first_time_step(single)
+    gb.loop(single, nsteps - 1)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    for n in parts[0].files:
+        got = np.concatenate([p[n] for p in parts], axis=0)
+        assert np.array_equal(got, single.backend.get_field(n, False)), n
+
+
 def test_bench_two_ranks_prints_contract_line():
     res = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "128", "48",
                    "8"], {})

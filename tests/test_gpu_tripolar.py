@@ -181,3 +181,71 @@ def test_schedule_options_do_not_change_the_tripolar_step():
     for o in outs[1:]:
         for n, a in outs[0].items():
             assert rel(a, o[n]) < 2e-6, (n, rel(a, o[n]))
+
+
+@pytest.mark.parametrize("grid_type,P", [("lat_lon_as_curvilinear", 3), ("gaussian_islands", 2), ("gaussian_islands", 3),
+                                         ("gaussian_islands", 4), ("tripolar", 1)])
+def test_slabs_of_a_curvilinear_grid_reproduce_the_single_domain_bitwise(grid_type, P):
+    """x-slab decomposition of the curvilinear grids: the 2-D metrics of a slab
+    come from the same generator at its global columns; on the tripolar grid the cells beyond a slab's fold line belong
+    to the mirrored slab P-1-r (an odd count makes the middle slab its own partner; P = 1 is the self-ring: slab_mode 1)
+    -- the rows next to the fold line travel once per step, five rows of the widened barotropic arrays once per
+    substep.  Every compared field bit for bit against the single domain."""
+    from gb25_amd.distributed import LocalSlabEnsemble
+    Nx, Ny, Nz, dt = 96 * max(P, 2) // 2, 40, 10, 600.0       # slabs of >= 48 columns (> the 22-column barotropic halo)
+    single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt, grid_type=grid_type)
+    gb.set_baroclinic_instability(single)
+    single.set(u=(1e-2 * counter_rng((Nx, Ny, Nz), 42, 1)).astype(np.float32),
+               v=(1e-2 * counter_rng((Nx, Ny + 1, Nz), 42, 2)).astype(np.float32),
+               eta=(1e-2 * counter_rng((Nx, Ny, 1), 42, 3)).astype(np.float32))
+    init = {n: single.backend.get_field(n, False) for n in ("u", "v", "T", "S", "eta")}
+    gtypes = {"lat_lon_as_curvilinear": 2, "tripolar": 3, "gaussian_islands": 4}
+    kw = dict(slab_mode=1) if P == 1 else {}
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, grid_type=gtypes[grid_type], **kw)
+    for n, a in init.items():
+        ens.scatter(n, a)
+    gb.first_time_step(single)
+    ens.first_time_step()
+    steps = 2 if grid_type == "tripolar" else 5          # (the bare tripolar grid does not live long: the poles)
+    gb.loop(single, steps)
+    ens.loop(steps)
+    for n in ALL_FIELDS:
+        a, b = ens.gather(n), single.backend.get_field(n, False)
+        if grid_type == "tripolar":
+            # without land the two poles are singular points of the coordinates (metrics clamped there): the handful of
+            # cells around them amplify the last bit; everywhere else, and everywhere on the grids one can run, bit for bit
+            assert rel(a, b) < 1e-6, (grid_type, P, n, rel(a, b))
+            far = np.ones(Nx, bool)
+            far[:4] = far[-4:] = far[Nx // 2 - 4: Nx // 2 + 4] = False
+            if n not in ("Gn.u", "Gn.v", "Gn.T", "Gn.S", "w"):
+                assert np.array_equal(a[far], b[far]), (grid_type, P, n)
+        else:
+            assert np.array_equal(a, b), (grid_type, P, n, float(np.abs(a - b).max()), np.argwhere(a != b)[:3].tolist())
+    assert np.abs(single.velocities.u.interior).max() > 1e-3
+    ens.close()
+
+
+def test_rccl_self_ring_on_the_folded_grid():
+    """The RCCL transport with the fold: ONE rank that is its own west / east neighbour AND its own fold partner
+    (slab_mode = 1): the x exchanges are ncclSend/ncclRecv to self, the partner exchanges device copies; bit for bit the
+    single domain, through a changed dt."""
+    from gb25_amd.distributed import SlabModel
+    Nx, Ny, Nz, dt = 128, 40, 10, 600.0
+    single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt, grid_type="gaussian_islands")
+    gb.set_baroclinic_instability(single)
+    single.set(u=(1e-2 * counter_rng((Nx, Ny, Nz), 42, 1)).astype(np.float32),
+               v=(1e-2 * counter_rng((Nx, Ny + 1, Nz), 42, 2)).astype(np.float32))
+    init = {n: single.backend.get_field(n, False) for n in ("u", "v", "T", "S", "eta")}
+    ring = SlabModel(Nx, Ny, Nz, dt=dt, rank=0, nranks=1, slab_mode=1, transport="rccl", grid_type=4)
+    for n, a in init.items():
+        ring.backend.set_field(n, a, False)
+    for m in (single, ring):
+        gb.first_time_step(m)
+        gb.loop(m, 4)
+        m.backend.set_dt(450.0)
+        gb.loop(m, 3)
+    for n in ALL_FIELDS:
+        a, b = ring.backend.get_field(n, False), single.backend.get_field(n, False)
+        assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
+    ring.backend.close()
+    single.backend.close()
