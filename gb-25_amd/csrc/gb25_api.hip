@@ -680,8 +680,15 @@ double gaussian_islands_bottom(const gb25_model* m, int i_local, int j) {
   if (m->g.cv.on) {
     // physical coordinates of the cell centre, the longitude brought next to each mountain (the tripolar grid starts AT
     // the first mountain's longitude: without this only its eastern half would exist)
-    double v[GB25_M2_COUNT], lam, phi;
-    curv_metrics_at(m, ig, j, v, &lam, &phi);
+    double lam, phi;
+    if (c.grid_type >= GB25_GRID_TRIPOLAR) {   // (the centre node alone: this runs for every column of the bottom tables)
+      const GNode cc = tripolar_node(70.0 + (ig + 0.5) * (360.0 / c.Nx), c.lat_south + (j + 0.5) * ((90.0 - c.lat_south) / c.Ny));
+      lam = cc.lam;
+      phi = cc.phi;
+    } else {
+      double v[GB25_M2_COUNT];
+      curv_metrics_at(m, ig, j, v, &lam, &phi);
+    }
     const double l1 = lam - 360.0 * std::floor((lam - 70.0 + 180.0) / 360.0), l2 = lam - 360.0 * std::floor((lam - 250.0 + 180.0) / 360.0);
     return z1 + h * (mtn(l1, phi, 70, 55) + mtn(l2, phi, 70 + 180, 55));
   }
