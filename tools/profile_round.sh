@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
 echo "[1/4] kernel stats"; date
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python3 $REPO/bench.py --steps 20 --warmup 5 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python3 $REPO/bench.py > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "[2/4] FETCH_SIZE"; date
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python3 $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_fetch.json 2> $OUT/fetch.err
 echo "[3/4] WRITE_SIZE"; date
