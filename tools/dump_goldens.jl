@@ -77,11 +77,35 @@ function dump_grid(dir, grid)
     end
 end
 
-function run_case(outdir, casename, FT, Nx, Ny, Nz, Δt, baroclinic_state::Bool)
+# the 2-D metrics of an orthogonal curvilinear underlying grid (TripolarGrid), the coordinates of the cell centres and
+# the bottom height: what pins this repository's analytic tripolar restatement (DESIGN.md section 0) -- or shows how far
+# its cap is from Oceananigans' numerically generated one
+function dump_curvilinear_grid(dir, ibg)
+    mkpath(dir)
+    grid = ibg.underlying_grid
+    FT = eltype(grid)
+    for name in (:Δxᶠᶜᵃ, :Δxᶜᶜᵃ, :Δxᶜᶠᵃ, :Δxᶠᶠᵃ, :Δyᶠᶜᵃ, :Δyᶜᶜᵃ, :Δyᶜᶠᵃ, :Δyᶠᶠᵃ, :Azᶜᶜᵃ, :Azᶠᶜᵃ, :Azᶜᶠᵃ, :Azᶠᶠᵃ,
+                 :λᶜᶜᵃ, :φᶜᶜᵃ, :λᶠᶠᵃ, :φᶠᶠᵃ)
+        write_npy(joinpath(dir, "$(name).npy"), FT.(collect(parent(getproperty(grid, name)))))
+    end
+    for (name, a) in (("zf", grid.z.cᵃᵃᶠ), ("zc", grid.z.cᵃᵃᶜ), ("dzc", grid.z.Δᵃᵃᶜ), ("dzf", grid.z.Δᵃᵃᶠ))
+        write_npy(joinpath(dir, "$(name).npy"), FT.(collect(parent(a))))
+    end
+    write_npy(joinpath(dir, "bottom_height.npy"), FT.(collect(parent(ibg.immersed_boundary.bottom_height))))
+end
+
+# kw: what the case passes on to baroclinic_instability_model (grid_type = :gaussian_islands;
+# closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), κ = ..., ν = ...): both are keyword arguments
+# of the reference's own constructor, src/baroclinic_instability_model.jl:17-31)
+function run_case(outdir, casename, FT, Nx, Ny, Nz, Δt, baroclinic_state::Bool; kw...)
     Oceananigans.defaults.FloatType = FT
-    model = GordonBell25.baroclinic_instability_model(CPU(), Nx, Ny, Nz; Δt, halo = (8, 8, 8))
+    model = GordonBell25.baroclinic_instability_model(CPU(), Nx, Ny, Nz; Δt, halo = (8, 8, 8), kw...)
     dir = joinpath(outdir, "$(casename)_$(FT)")
-    dump_grid(joinpath(dir, "grid"), model.grid)
+    if model.grid isa Oceananigans.ImmersedBoundaries.ImmersedBoundaryGrid
+        dump_curvilinear_grid(joinpath(dir, "grid"), model.grid)
+    else
+        dump_grid(joinpath(dir, "grid"), model.grid)
+    end
     # split-explicit substepping as materialised by the model (weights, effective substep count, fractional step)
     ss = model.free_surface.substepping
     write_npy(joinpath(dir, "grid", "substep_weights.npy"), Float64.(collect(ss.averaging_weights)))
@@ -120,6 +144,11 @@ function main(args)
     for FT in (Float32, Float64)
         run_case(outdir, "protocol_112x112x16", FT, 112, 112, 16, 1e-9, false)
         run_case(outdir, "config1_128x64x8", FT, 128, 64, 8, 1200.0, true)
+        # grid_type = :gaussian_islands: TripolarGrid + GridFittedBottom (src/model_utils.jl:129-146)
+        run_case(outdir, "islands_72x36x8", FT, 72, 36, 8, 600.0, true; grid_type = :gaussian_islands)
+        # the closure the reference keeps next to `nothing` (src/baroclinic_instability_model.jl:31); ν, κ large enough to matter
+        run_case(outdir, "closure_128x64x8", FT, 128, 64, 8, 1200.0, true;
+                 closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), κ = 1e-3, ν = 1e-2))
     end
 end
 
