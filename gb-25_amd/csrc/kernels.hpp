@@ -1201,7 +1201,7 @@ struct BaroMulti {
 // (3 waves per SIMD: at 1440x720 the launch has 540 blocks; with the 173 VGPRs the 7-substep variant took when left alone
 // only two blocks fit a CU, 512 on the chip, and the last 28 blocks were a second round that doubled the launch time)
 template <int BT_S, int BT_TY, bool IMM>
-__global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi(Grid g, BaroMulti bm, real dtau) {
+__global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi(Grid g, BaroMulti bm, real dtau) {
   constexpr int BT_RX = BT_TX + 2 * BT_S, BT_RY = BT_TY + 2 * BT_S, BT_NP = BT_RX * BT_RY;
   constexpr int BT_PPT = (BT_NP + BT_NT - 1) / BT_NT;
   __shared__ real E[BT_RY][BT_RX], U[BT_RY][BT_RX], V[BT_RY][BT_RX], GUs[BT_RY][BT_RX], GVs[BT_RY][BT_RX];

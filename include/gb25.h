@@ -107,7 +107,7 @@ typedef enum {
   GB25_OPT_SUBCYCLE_LOOKAHEAD,   /* [1 from 8 M cells and on slabs] the next step's split-explicit sub-cycle runs as soon as its
                                     G.U, G.V exist: 1 = between the momentum and the tracer kernel, 2 = beside the tracer
                                     kernel on a stream of its own (slabs: on the exchange stream), 0 = inside its own step */
-  GB25_OPT_SUBCYCLE_BLOCK,       /* [7] substeps per barotropic launch: 1, 3, 5, 7 */
+  GB25_OPT_SUBCYCLE_BLOCK,       /* [5] substeps per barotropic launch: 1, 3, 5, 7 */
   GB25_OPT_FILL_FUSED,           /* [1] y, z and periodic-x halo fills in one launch */
   GB25_OPT_TWO_STREAMS,          /* [1] tracer branch (AB2, halos, pressure) on a second stream */
   GB25_OPT_STORE_PRESSURE,       /* [0] store pHY' every step (1) or only its differences, pHY' on demand (0) */
