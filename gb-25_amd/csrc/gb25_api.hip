@@ -135,6 +135,10 @@ struct gb25_model {
   Field corr[2];
   bool uv_lazy = false;
   int lazy_corrector = 1;            // option LAZY_CORRECTOR
+  // levels a block of the momentum / tracer tendency kernel marches through (options MOMENTUM_CHUNK_LEVELS,
+  // TRACER_CHUNK_LEVELS): fewer, longer chunks amortise the start-up of the vertical windows, more chunks fill the chip.
+  // The momentum chunking is also the association of every column integral of u, v (all their producers share it).
+  int mom_chunk_levels = 12, trc_chunk_levels = 12;
   // closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu); both zero: closure = nothing
   double nu = 0, kappa = 0;
   real* d_implicit[2] = {nullptr, nullptr};   // elimination tables of the implicit solve for (u, v) and (T, S): lo | 1/beta | gamma
@@ -709,6 +713,7 @@ gb25_status alloc_field(gb25_model* m, Field& F, int nx, int ny, int nz) {
   return GB25_OK;
 }
 
+inline int mom_kchunks(const gb25_model* m) { return std::max(1, m->g.Nz / m->mom_chunk_levels); }
 inline dim3 grid2(int nx, int ny, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y); }
 
 // sel: 3 = u, v, T, S;  1 = u, v;  2 = T, S
@@ -925,7 +930,7 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
     nbx = (g.Nx + V2_TX - 1) / V2_TX;
     constexpr int TYm = 4;   // rows (= waves) per block: 4 blocks per CU cover each other's barriers
     const int nby = (v_rows(g) + TYm - 1) / TYm;   // (zipper fold: the y faces on the fold line have a tendency too)
-    const int kchunks = std::max(1, g.Nz / 12);
+    const int kchunks = mom_kchunks(m);
     TileCols tc{nbx, nbx, 0, 0};
     if (part) {
       const int hi = interior_tile_columns_end(g);
@@ -994,7 +999,7 @@ gb25_status tracers_impl(gb25_model* m) {
     Timed t(m, GB25_K_TRACERS);
     nbx = (g.Nx + V3_OUT - 1) / V3_OUT;
     const int nby = (g.Ny + 3) / 4;
-    const int kchunks = std::max(1, g.Nz / 12);   // >= 12 levels per block: the z-carry start-up stays ~3 %
+    const int kchunks = std::max(1, g.Nz / m->trc_chunk_levels);   // >= 12 levels per block: the z-carry start-up stays ~3 %
     nb = nbx * nby * kchunks;
     constexpr int TW = sizeof(real) == 8 ? 3 : 5;   // see MW in momentum_impl
     const bool ahead = m->ab2_ahead && !m->ptr_exposed;
@@ -1060,7 +1065,9 @@ gb25_status implicit_tables(gb25_model* m, int kind, double dt, double K) {
       gm[(size_t)kf * Nz + k] = (real)gk;
     }
   }
-  HIPCHK(hipStreamSynchronize(m->stream));   // (a solve with the old tables may still be running)
+  HIPCHK(hipStreamSynchronize(m->stream));   // (a solve with the old tables may still be running, on either stream)
+  HIPCHK(hipStreamSynchronize(m->own_stream));
+  HIPCHK(hipStreamSynchronize(m->side_stream));
   if (!m->d_implicit[kind]) HIPCHK(hipMalloc(&m->d_implicit[kind], tab.size() * sizeof(real)));
   HIPCHK(hipMemcpy(m->d_implicit[kind], tab.data(), tab.size() * sizeof(real), hipMemcpyHostToDevice));
   m->implicit_key[kind][0] = dt;
@@ -1073,7 +1080,7 @@ gb25_status implicit_vertical_impl(gb25_model* m, int kind, real dt) {
   if (K == real(0.)) return GB25_OK;
   real *a = m->f[kind == 0 ? GB25_U : GB25_T].d, *b = m->f[kind == 0 ? GB25_V : GB25_S].d;
   real *sa = kind == 0 ? m->colsum[0].d : nullptr, *sb = kind == 0 ? m->colsum[1].d : nullptr;
-  const int kchunks = std::max(1, g.Nz / 12);
+  const int kchunks = mom_kchunks(m);
   if (g.Nz <= 128) {   // the column in registers, the elimination factors from tables
     if (gb25_status s = implicit_tables(m, kind, (double)dt, (double)K)) return s;
     ImplicitFields A{};
@@ -1136,7 +1143,7 @@ gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
   hipLaunchKernelGGL(k_ab2_velocities, grid2(g.Nx, v_rows(g), b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                      m->f[GB25_GN_U].d, m->f[GB25_GM_U].d, m->f[GB25_GN_V].d, m->f[GB25_GM_V].d,
                      m->f[GB25_GN_BT_U].d, m->f[GB25_GN_BT_V].d, m->colsum[0].d, m->colsum[1].d, dt, chi,
-                     std::max(1, g.Nz / 12));   // the momentum kernel's chunking (momentum_impl)
+                     mom_kchunks(m));   // the momentum kernel's chunking (momentum_impl)
   m->colsum_valid = true;
   LAUNCHCHK();
   return implicit_vertical_impl(m, 0, dt);
@@ -1330,7 +1337,7 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
                             : (fold ? k_corrector<false, true> : k_corrector<false, false>);
     hipLaunchKernelGGL(kern, grid2(ni, v_rows(g), b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                        m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d,
-                       cs ? m->colsum[0].d : nullptr, cs ? m->colsum[1].d : nullptr, i0, ni, std::max(1, g.Nz / 12),
+                       cs ? m->colsum[0].d : nullptr, cs ? m->colsum[1].d : nullptr, i0, ni, mom_kchunks(m),
                        skip_from, skip);
     LAUNCHCHK();
   }
@@ -1658,7 +1665,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     if ((s = alloc_field(m, m->ahead_colsum[q], C2.nx, C2.ny, 1))) return s;
   }
   {
-    const size_t np = (size_t)4 * std::max(1, m->g.Nz / 12) * m->g.sx * m->g.sy_v;
+    const size_t np = (size_t)4 * std::max(1, m->g.Nz / 6) * m->g.sx * m->g.sy_v;   // (room for chunks of 6 levels)
     HIPCHK(hipMalloc(&m->uv_partials, np * sizeof(real)));
     HIPCHK(hipMemset(m->uv_partials, 0, np * sizeof(real)));
   }
@@ -1807,6 +1814,8 @@ gb25_status gb25_field_dims(const gb25_model* m, gb25_field id, int include_halo
 static gb25_status copy_field(gb25_model* m, gb25_field id, real* host, int include_halos, bool to_device) {
   if (!m || id < 0 || id >= GB25_FIELD_COUNT || !host) return GB25_ERR_INVALID_ARGUMENT;
   if (to_device && (id == GB25_U || id == GB25_V)) m->colsum_valid = false;  // cached column integrals are stale
+  if (m->uv_lazy)   // (only after a composite call that failed half-way: memory must hold the corrected velocities)
+    if (gb25_status s = materialize_uv(m)) return s;
   Field& F = m->f[id];
   HIPCHK(hipStreamSynchronize(m->stream));
   if (to_device) {   // a look-ahead may still be reading the old values
@@ -1894,6 +1903,8 @@ gb25_status gb25_get_field(gb25_model* m, gb25_field f, void* host_, int include
 gb25_status gb25_field_device_ptr(gb25_model* m, gb25_field id, void** dev) {
   if (!m || id < 0 || id >= GB25_FIELD_COUNT || !dev) return GB25_ERR_INVALID_ARGUMENT;
   if (gb25_status s = collective_guard(m, 2, (unsigned)id, 0.0)) return s;
+  if (m->uv_lazy)
+    if (gb25_status s = materialize_uv(m)) return s;
   if (id == GB25_U || id == GB25_V || id == GB25_T || id == GB25_S || (id >= GB25_GN_U && id <= GB25_GM_S) ||
       (id >= GB25_ETA && id <= GB25_GN_BT_V)) {
     // the host can now write prognostic fields or their tendencies behind our back: no more look-ahead for this
@@ -2127,6 +2138,12 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
       m->complete_fills_needed = 2;
       return GB25_OK;
     case GB25_OPT_LAZY_CORRECTOR: m->lazy_corrector = v != 0; return GB25_OK;
+    case GB25_OPT_MOMENTUM_CHUNK_LEVELS:
+    case GB25_OPT_TRACER_CHUNK_LEVELS:
+      if (v < 6 || v > 4096) return fail(m, GB25_ERR_INVALID_ARGUMENT, "chunk levels: 6 or more");
+      (opt == GB25_OPT_MOMENTUM_CHUNK_LEVELS ? m->mom_chunk_levels : m->trc_chunk_levels) = v;
+      m->colsum_valid = false;
+      return GB25_OK;
     case GB25_OPT_IMMERSED_KERNELS:
       // 1: run the immersed-boundary kernel variants even where nothing is immersed (they must then give the bits of
       // the plain ones: tests); 0: back to the choice the bottom makes
@@ -2159,6 +2176,8 @@ gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
     case GB25_OPT_IMMERSED_KERNELS: *v = m->immersed; break;
     case GB25_OPT_FOLD_FILLS: *v = m->fold_fills; break;
     case GB25_OPT_LAZY_CORRECTOR: *v = m->lazy_corrector; break;
+    case GB25_OPT_MOMENTUM_CHUNK_LEVELS: *v = m->mom_chunk_levels; break;
+    case GB25_OPT_TRACER_CHUNK_LEVELS: *v = m->trc_chunk_levels; break;
     default: return GB25_ERR_INVALID_ARGUMENT;
   }
   return GB25_OK;

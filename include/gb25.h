@@ -121,6 +121,9 @@ typedef enum {
   GB25_OPT_LAZY_CORRECTOR,       /* [1] single flat lat-lon domain, between the steps of one gb25_loop call: the barotropic
                                     correction of u, v is added by the kernels that read them instead of by a sweep over
                                     u and v (same bits; memory holds the corrected velocities when the call returns) */
+  GB25_OPT_MOMENTUM_CHUNK_LEVELS, /* [12] levels a block of the momentum tendency kernel marches through (>= 6); also the
+                                    association of the column integrals of u, v: results change in the last bits */
+  GB25_OPT_TRACER_CHUNK_LEVELS,  /* [12] the same for the tracer tendency kernel (bitwise neutral) */
   GB25_OPT_COUNT
 } gb25_option;
 
