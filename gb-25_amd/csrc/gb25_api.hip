@@ -101,6 +101,7 @@ struct gb25_model {
   std::vector<EventPair> pending[GB25_K_COUNT];
   std::vector<EventPair> free_events;
   int64_t prof_count[GB25_K_COUNT] = {0};
+  int64_t prof_seen[GB25_K_COUNT] = {0};
   double prof_ms[GB25_K_COUNT] = {0};
   std::string err;
   int baro_block = 5;                // substeps per barotropic launch (option SUBCYCLE_BLOCK = 1: one launch per substep; 5: 64 x 17 tiles,
@@ -184,6 +185,8 @@ struct Timed {
   EventPair ev;
   bool on;
   Timed(gb25_model* m_, int k_) : m(m_), k(k_), on(m_->profile && (m_->profile_only < 0 || m_->profile_only == k_)) {
+    // one kernel alone: every fourth launch is timed (the event records cost the step ~1.6 % when every launch carries them)
+    if (on && m->profile_only == k_ && (m->prof_seen[k_]++ & 3) != 0) on = false;
     if (!on) return;
     if (!m->free_events.empty()) {
       ev = m->free_events.back();

@@ -249,3 +249,38 @@ def test_rccl_self_ring_on_the_folded_grid():
         assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
     ring.backend.close()
     single.backend.close()
+
+
+@pytest.mark.parametrize("float_type", ["Float32", "Float64"])
+def test_folded_slabs_with_closure_and_fluxes(float_type):
+    """Everything at once on the reference's :gaussian_islands grid in three slabs (the middle one its own fold partner):
+    the vertically implicit closure, a wind stress and a heat flux, both float types -- bit for bit the single domain."""
+    from gb25_amd.distributed import LocalSlabEnsemble
+    Nx, Ny, Nz, dt, P = 144, 40, 10, 600.0, 3
+    dtype = np.float32 if float_type == "Float32" else np.float64
+    closure = gb.VerticalScalarDiffusivity(nu=1e-2, kappa=1e-3)
+    single = gb.baroclinic_instability_model(gb.GPU(float_type=float_type), Nx, Ny, Nz, dt=dt, grid_type="gaussian_islands",
+                                             closure=closure)
+    gb.set_baroclinic_instability(single)
+    single.set(u=(1e-2 * counter_rng((Nx, Ny, Nz), 42, 1)).astype(dtype),
+               v=(1e-2 * counter_rng((Nx, Ny + 1, Nz), 42, 2)).astype(dtype))
+    tau = (1e-4 * np.cos(np.linspace(-1.4, 1.4, Ny))[None, :] * np.ones((Nx, 1))).astype(dtype)
+    heat = (1e-5 * (counter_rng((Nx, Ny), 7, 1) - 0.5)).astype(dtype)
+    gb.set_top_flux(single, u=tau, T=heat)
+    init = {n: single.backend.get_field(n, False) for n in ("u", "v", "T", "S", "eta")}
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, grid_type=4, float_type=float_type)
+    n = Nx // P
+    for r, b in enumerate(ens.backends):
+        b.set_vertical_diffusivity(closure.nu, closure.kappa)
+        b.set_top_flux("u", tau[r * n:(r + 1) * n])
+        b.set_top_flux("T", heat[r * n:(r + 1) * n])
+    for name, a in init.items():
+        ens.scatter(name, a)
+    gb.first_time_step(single)
+    ens.first_time_step()
+    gb.loop(single, 4)
+    ens.loop(4)
+    for name in ALL_FIELDS:
+        a, b = ens.gather(name), single.backend.get_field(name, False)
+        assert np.array_equal(a, b), (float_type, name, float(np.abs(a - b).max()))
+    ens.close()
