@@ -2207,7 +2207,13 @@ gb25_status gb25_comm_init_rccl(gb25_model* m, const void* unique_id) {
   tr->nranks = m->cfg.nranks;
   ncclUniqueId id;
   memcpy(&id, unique_id, sizeof id);
+  (void)hipGetLastError();   // (RCCL reports a stale, already-handled HIP error of this process as "unhandled cuda error")
   ncclResult_t r = rccl().CommInitRank(&tr->comm, tr->nranks, id, tr->rank);
+  if (r != ncclSuccess && tr->nranks == 1) {
+    // a one-rank communicator (the self-ring) needs nobody's agreement: once more with a fresh id
+    (void)hipGetLastError();
+    if (rccl().GetUniqueId(&id) == ncclSuccess) r = rccl().CommInitRank(&tr->comm, 1, id, 0);
+  }
   if (r != ncclSuccess) {
     tr->comm = nullptr;
     delete tr;

@@ -41,7 +41,7 @@ struct MomentumLds {
 template <int V2_TY>
 struct MomentumMetricLds {
   static constexpr int MU_Y = V2_TY + 6, MD_Y = V2_TY + 5;
-  real dxfc[MU_Y][MU_X], dxcf[MU_Y][MU_X], dyfc[MU_Y][MU_X], dycf[MU_Y][MU_X];
+  real dxfc[MU_Y][MU_X], dxcf[MU_Y][MU_X], dyfc[MU_Y - 1][MU_X], dycf[MU_Y][MU_X];   // (the last row of dyfc is never read)
   real razff[MD_Y][MD_X];
 };
 struct NoLds { char unused; };
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
         auto ld = [&](const real* b_) { return *reinterpret_cast<const real*>(reinterpret_cast<const char*>(b_) + eu_off[q]); };
         (&mt.dxfc[0][0])[eu_lds[q]] = ld(m0);
         (&mt.dxcf[0][0])[eu_lds[q]] = ld(m1);
-        (&mt.dyfc[0][0])[eu_lds[q]] = ld(m2);
+        if (eu_lds[q] < (MU_Y - 1) * MU_X) (&mt.dyfc[0][0])[eu_lds[q]] = ld(m2);
         (&mt.dycf[0][0])[eu_lds[q]] = ld(m3);
       }
     for (int e = tid; e < MD_X * MD_Y; e += NT) {
@@ -291,12 +291,15 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   const bool fold_tile = AHEAD && (j0 == 0 || j0 + V2_TY >= g.Ny || i0 < H || i0 + V2_TX > g.Nx - H);
   // per-block tables for phase 1: packed (row << 8 | column) of every derived point, and the metrics of the rows
   // mdxc[py] = dxc(j0-3+py), mrazf[py] = razf(j0-2+py), mdxf[py] = dxf(j0-3+py)
-  __shared__ int ptab[MD_X * MD_Y];
-  __shared__ real mdxc[MD_Y + 1], mrazf[MD_Y], mdxf[MD_Y + 1];
-  for (int e = tid; e < MD_X * MD_Y; e += NT) {
-    const int py = e / MD_X;
-    ptab[e] = (py << 8) | (e - py * MD_X);
-  }
+  // (the curvilinear variant does without them: its metric tiles need the LDS, and with 40 KB per block a fourth block
+  // fits a CU; the point's row and column then cost a multiply-high per level)
+  __shared__ int ptab[CURV ? 1 : MD_X * MD_Y];
+  __shared__ real mdxc[CURV ? 1 : MD_Y + 1], mrazf[CURV ? 1 : MD_Y], mdxf[CURV ? 1 : MD_Y + 1];
+  if (!CURV)
+    for (int e = tid; e < MD_X * MD_Y; e += NT) {
+      const int py = e / MD_X;
+      ptab[e] = (py << 8) | (e - py * MD_X);
+    }
   if (!CURV && tid <= MD_Y) {
     mdxc[tid] = g.dxc[j0 - 3 + tid];
     mdxf[tid] = g.dxf[j0 - 3 + tid];
@@ -323,8 +326,15 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     // ---- phase 1: derived quantities, once per point.  (row, column) of a point and the row metrics come from the
     // small LDS tables filled once per block: an integer division and five global loads per point and level otherwise
     for (int e = tid; e < MD_X * MD_Y; e += NT) {
-      const int pk = ptab[e];
-      const int py = pk >> 8, px = pk & 255;
+      int py, px;
+      if constexpr (CURV) {
+        py = e / MD_X;
+        px = e - py * MD_X;
+      } else {
+        const int pk = ptab[e];
+        py = pk >> 8;
+        px = pk & 255;
+      }
       // (f,f,c) point (i0-2+px, j0-2+py)
       {
         real uc = lds.U[par][py + 1][px + 1], us = lds.U[par][py][px + 1];
