@@ -1336,12 +1336,19 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
     }
     const bool cs = use_colsum && m->colsum_valid && part != 2;
     const bool fold = producers_fold(m) && m->composite;
-    auto kern = m->immersed ? (fold ? k_corrector<true, true> : k_corrector<true, false>)
-                            : (fold ? k_corrector<false, true> : k_corrector<false, false>);
-    hipLaunchKernelGGL(kern, grid2(ni, v_rows(g), b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                       m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d,
-                       cs ? m->colsum[0].d : nullptr, cs ? m->colsum[1].d : nullptr, i0, ni, mom_kchunks(m),
-                       skip_from, skip);
+    if (m->slab && part == 1 && cs) {   // own columns of a slab, integrals at hand: one thread per cell
+      hipLaunchKernelGGL(m->immersed ? k_corrector_cells<true> : k_corrector_cells<false>,
+                         dim3((g.Nx + 63) / 64, (v_rows(g) + 3) / 4, g.Nz), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                         m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->colsum[0].d,
+                         m->colsum[1].d);
+    } else {
+      auto kern = m->immersed ? (fold ? k_corrector<true, true> : k_corrector<true, false>)
+                              : (fold ? k_corrector<false, true> : k_corrector<false, false>);
+      hipLaunchKernelGGL(kern, grid2(ni, v_rows(g), b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                         m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d,
+                         cs ? m->colsum[0].d : nullptr, cs ? m->colsum[1].d : nullptr, i0, ni, mom_kchunks(m),
+                         skip_from, skip);
+    }
     LAUNCHCHK();
   }
   if (part == 2) return GB25_OK;

@@ -1409,6 +1409,45 @@ __global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const real* __r
   if (j < g.Ny) U[i2(g, i, j)] = su;
   V[i2(g, i, j)] = sv;
 }
+// The corrector of a slab's OWN columns when their column integrals are at hand (AB2 kernel / momentum look-ahead): no
+// marching at all -- one thread per cell.  A 180-column slab has 2000 waves' worth of columns: the column-marching form
+// runs at the latency of its 48 dependent steps (44 us for 25 MB), this one at the bandwidth of its 100 MB.
+// Same operands, same additions as k_corrector -- where the correction is a rounded number before it is added, so no
+// contraction of the product into the sum here: the same bits.
+#pragma clang fp contract(off)
+template <bool IMM>
+__global__ __launch_bounds__(256) void k_corrector_cells(Grid g, real* __restrict__ u, real* __restrict__ v,
+                                                         const real* __restrict__ U, const real* __restrict__ V,
+                                                         real* __restrict__ Ub, real* __restrict__ Vb,
+                                                         const real* __restrict__ Usum, const real* __restrict__ Vsum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
+  if (i >= g.Nx || j >= g.Ny + g.cv.north_fold) return;
+  const int o2 = i2(g, i, j);
+  const bool urow = j < g.Ny;   // (zipper fold: the fold line carries y faces only)
+  const real su = Usum[o2], sv = Vsum[o2];
+  if (k == 0) {
+    if (urow) Ub[o2] = su;
+    Vb[o2] = sv;
+  }
+  int KPU = 0, KPV = 0;
+  if (IMM) {
+    const unsigned C = g.im.ordC[o2];
+    KPU = (C >> 8) & 255;
+    KPV = (C >> 16) & 255;
+  }
+  if (urow && (!IMM || k >= KPU)) {
+    const real du = (U[o2] - su) * (IMM ? g.im.rHfc[o2] : g.rLz);
+    const int o = ic(g, i, j, k);
+    u[o] = u[o] + du;
+  }
+  if (!IMM || k >= KPV) {
+    const real dv = (V[o2] - sv) * (IMM ? g.im.rHcf[o2] : g.rLz);
+    const int o = iv(g, i, j, k);
+    v[o] = v[o] + dv;
+  }
+}
+#pragma clang fp contract(fast)
+
 // The corrector applied INSIDE its consumers (single periodic domain, flat lat-lon grid, composite steps): the
 // correction u += (U - Ubar) / H is the same number for every level of a column, so instead of a sweep over u and v
 // (2R + 2W per cell: 0.8 GB at 1440x720x48) this 2-D kernel leaves du = (U - Ubar) / H and dv (with the halo cells the
