@@ -7,7 +7,8 @@ C ABI of include/gb25.h; this package only sequences calls and moves host arrays
 from .binding import GB25Error, HipBackend, LIB_PATH, load_library
 from .build import build_library
 from .correctness import approx_equal, compare_states, sync_states
-from .model import (Field, HydrostaticFreeSurfaceModel, VerticalScalarDiffusivity, baroclinic_instability_model, first_time_step, initialize,
+from .model import (CATKEVerticalDiffusivity, Field, HydrostaticFreeSurfaceModel, VerticalScalarDiffusivity,
+                    baroclinic_instability_model, first_time_step, initialize,
                     loop, resolution_to_points, set_baroclinic_instability, set_top_flux, time_step, update_state,
                     tupled_fill_halo_regions_workload, compute_tendencies_workload,
                     compute_boundary_tendencies_workload, compute_interior_momentum_tendencies_workload,

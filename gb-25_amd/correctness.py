@@ -57,6 +57,11 @@ def compare_states(m1, m2, *, rtol=None, atol=0.0, include_halos=False, throw_er
     for name in ("U", "V", "eta"):
         ok &= _compare(f"filtered.{name}", get(getattr(m1.free_surface.filtered_state, name)),
                        get(getattr(m2.free_surface.filtered_state, name)), rtol, atol, report)
+    # if m1.closure isa CATKEVerticalDiffusivity: the diffusivity fields (src/correctness.jl:60-67)
+    if getattr(m1, "diffusivity_fields", None) is not None and getattr(m2, "diffusivity_fields", None) is not None:
+        for name in ("kappa_u", "kappa_c", "kappa_e", "Le", "Jb"):
+            ok &= _compare(name, get(getattr(m1.diffusivity_fields, name)), get(getattr(m2.diffusivity_fields, name)),
+                           rtol, atol, report)
     if verbose:
         for r in report:
             print("(%10s) psi1 ~ psi2: %-5s, max|psi1|, max|psi2|: %.9e, %.9e, max|d|: %.9e at %d %d %d"

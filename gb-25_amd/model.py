@@ -112,10 +112,26 @@ class HydrostaticFreeSurfaceModel:
         Gn.U, Gn.V = F("Gn.U", "fc"), F("Gn.V", "cf")
         self.timestepper = SimpleNamespace(Gn=Gn, Gm=G("Gm"), chi=0.1)
 
+        self.closure = None
+        self.diffusivity_fields = None
+
+    def enable_catke_fields(self):
+        """closure = CATKEVerticalDiffusivity(): tracers = (:T, :S, :e) and model.diffusivity_fields
+        (src/baroclinic_instability_model.jl:50-51, src/correctness.jl:60-67)."""
+        b = self.backend
+        F = lambda n, loc: Field(b, n, loc)
+        self.tracers.e = F("e", "ccc")
+        self.timestepper.Gn.e, self.timestepper.Gm.e = F("Gn.e", "ccc"), F("Gm.e", "ccc")
+        self.diffusivity_fields = SimpleNamespace(kappa_u=F("kappa_u", "ccf"), kappa_c=F("kappa_c", "ccf"),
+                                                  kappa_e=F("kappa_e", "ccf"), Le=F("Le", "ccc"), Jb=F("Jb", "cc"))
+
     # Oceananigans.fields(model): the set compare_states walks (src/correctness.jl:34-35)
     def fields(self):
-        return {"u": self.velocities.u, "v": self.velocities.v, "w": self.velocities.w,
-                "eta": self.free_surface.eta, "T": self.tracers.T, "S": self.tracers.S}
+        out = {"u": self.velocities.u, "v": self.velocities.v, "w": self.velocities.w,
+               "eta": self.free_surface.eta, "T": self.tracers.T, "S": self.tracers.S}
+        if hasattr(self.tracers, "e"):
+            out["e"] = self.tracers.e
+        return out
 
     def prognostic_fields(self):
         fs = self.free_surface
@@ -155,6 +171,12 @@ class VerticalScalarDiffusivity:
         self.nu, self.kappa = float(nu), float(kappa)
 
 
+class CATKEVerticalDiffusivity:
+    """closure = Oceananigans.TurbulenceClosures.CATKEVerticalDiffusivity() (src/baroclinic_instability_model.jl:30,
+    sharding/less_simple_sharding_problem.jl:84-93): a third tracer e (turbulent kinetic energy), diffusivity fields
+    κu, κc, κe, Lᵉ, Jᵇ (compared by src/correctness.jl:60-67), vertically implicit mixing of u, v, T, S, e."""
+
+
 def baroclinic_instability_model(arch, Nx=None, Ny=None, Nz=None, *, dt, halo=(8, 8, 8), grid_type="simple_lat_lon",
                                  substeps=30, resolution=None, closure=None, **backend_kw):
     """baroclinic_instability_model(arch, Nx, Ny, Nz; dt, halo, grid_type, free_surface=SplitExplicit(substeps))
@@ -183,9 +205,12 @@ def baroclinic_instability_model(arch, Nx=None, Ny=None, Nz=None, *, dt, halo=(8
     model = HydrostaticFreeSurfaceModel(backend, Nx, Ny, Nz, H)
     model.free_surface.substeps = substeps
     model.closure = closure
-    if closure is not None:
+    if isinstance(closure, CATKEVerticalDiffusivity):
+        backend.set_catke(True)
+        model.enable_catke_fields()
+    elif closure is not None:
         if not isinstance(closure, VerticalScalarDiffusivity):
-            raise NotImplementedError("closures: None or VerticalScalarDiffusivity(nu, kappa) (CATKE is SURVEY section 8f.2)")
+            raise NotImplementedError("closures: None, VerticalScalarDiffusivity(nu, kappa) or CATKEVerticalDiffusivity()")
         backend.set_vertical_diffusivity(closure.nu, closure.kappa)
     return model
 

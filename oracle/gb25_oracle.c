@@ -61,6 +61,9 @@ enum {
   F_GNU, F_GNV, F_GNT, F_GNS,
   F_GMU, F_GMV, F_GMT, F_GMS,
   F_ETA, F_BU, F_BV, F_ETAB, F_UB, F_VB, F_GBU, F_GBV,
+  /* closure = CATKEVerticalDiffusivity(): the TKE tracer e with its tendencies, the diffusivity fields the reference
+   * compares (kappa_u, kappa_c, kappa_e at (c,c,f); L^e at (c,c,c); J^b 2-D: /root/reference/src/correctness.jl:60-67) */
+  F_E, F_GNE, F_GME, F_KU, F_KC, F_KE, F_LE, F_JB,
   F_COUNT
 };
 
@@ -93,6 +96,7 @@ typedef struct {
   /* closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu)
    * (/root/reference/src/baroclinic_instability_model.jl:31); both zero: closure = nothing */
   REAL nu, kappa;
+  int catke; /* closure = CATKEVerticalDiffusivity() */
   int curv, north_fold;
   REAL *dxfc2, *dxcc2, *dxcf2, *dxff2, *dyfc2, *dycc2, *dycf2, *dyff2, *azcc2, *azfc2, *azcf2, *azff2, *fff2, *phicc2;
   double *lamcc_d, *phicc_d; /* cell-centre coordinates in degrees (double), interior Nx x Ny, for analytic bottoms */
@@ -478,8 +482,8 @@ void *FN(create)(const gb25o_config *c) {
   }
   for (int id = 0; id < F_COUNT; id++) {
     int isv = (id == F_V || id == F_GNV || id == F_GMV || id == F_BV || id == F_VB || id == F_GBV);
-    int isw = (id == F_W);
-    int twod = id >= F_ETA;
+    int isw = (id == F_W || id == F_KU || id == F_KC || id == F_KE);
+    int twod = (id >= F_ETA && id <= F_GBV) || id == F_JB;
     alloc_field(m, id, isv, isw, twod);
   }
   return m;
@@ -668,6 +672,7 @@ static REAL f_u(const model *m, int i, int j, int k) { return A3(F_U, i, j, k); 
 static REAL f_v(const model *m, int i, int j, int k) { return A3(F_V, i, j, k); }
 static REAL f_T(const model *m, int i, int j, int k) { return A3(F_T, i, j, k); }
 static REAL f_S(const model *m, int i, int j, int k) { return A3(F_S, i, j, k); }
+static REAL f_E(const model *m, int i, int j, int k) { return A3(F_E, i, j, k); }
 static REAL f_Azw(const model *m, int i, int j, int k) { return AZCC(i, j) * A3(F_W, i, j, k); }
 /* vertical vorticity zeta at (f,f,c) */
 static REAL f_zeta(const model *m, int i, int j, int k) {
@@ -865,6 +870,7 @@ void FN(fill_halos)(void *h) {
   fill_halo_2d(m, F_ETA, 0, 0, 1);
   fill_halo_2d(m, F_BU, 0, 1, -1);
   fill_halo_2d(m, F_BV, 1, 0, -1);
+  if (m->catke) fill_halo_3d(m, F_E, 0, 0, 1);
 }
 
 /* ---------------------------------------------------------------- auxiliaries
@@ -1043,10 +1049,12 @@ void FN(set_top_flux)(void *h, int q, const double *J) {
     for (int i = 1; i <= m->Nx; i++)
       m->top_flux[q][((long)i - 1 + HH) + (long)F->sx * ((long)j - 1 + HH)] = (REAL)J[(i - 1) + (long)m->Nx * (j - 1)];
 }
+static void catke_tke_tendency(model *m);
 void FN(compute_tendencies)(void *h) {
   FN(compute_momentum_tendencies)(h);
   FN(compute_tracer_tendencies)(h);
   FN(compute_boundary_tendencies)(h);
+  if (((model *)h)->catke) catke_tke_tendency((model *)h);
 }
 /* update_state!(model; compute_tendencies=true): phases 1-5 of /root/reference/src/precompile.jl:34-38
  * (mask_immersed and diffusivity halos are no-ops for this configuration). */
@@ -1069,10 +1077,12 @@ void FN(mask_immersed_fields)(void *h) {
       if (j == 1 || j > NYV || H2(Hcf, i, j) == 0) A2(F_BV, i, j) = 0;
     }
 }
+static void catke_compute_diffusivities(model *m);
 void FN(update_state)(void *h) {
   FN(mask_immersed_fields)(h);
   FN(fill_halos)(h);
   FN(compute_auxiliaries)(h);
+  if (((model *)h)->catke) catke_compute_diffusivities((model *)h);   /* compute_diffusivities! + their halos (a14) */
   FN(compute_tendencies)(h);
 }
 
@@ -1123,11 +1133,223 @@ static void implicit_step_field(model *m, int id, int which, REAL K, REAL dt) {
     for (int i = 1; i <= m->Nx; i++)
       implicit_column(m, &A3(id, i, j, 1), stride, first_free_level(m, which, i, j), K, dt);
 }
+/* the same solve with CATKE's diffusivity fields: kappa at the faces of the column -- kappa_u averaged to the u / v
+ * column (which = 0 / 1), kappa_c (2), kappa_e with the implicit linear term L^e on the diagonal (3) */
+static inline REAL catke_kface(const model *m, int which, int i, int j, int k) {
+  if (which == 0) return (A3(F_KU, i - 1, j, k) + A3(F_KU, i, j, k)) / (REAL)2;
+  if (which == 1) return (A3(F_KU, i, j - 1, k) + A3(F_KU, i, j, k)) / (REAL)2;
+  return which == 2 ? A3(F_KC, i, j, k) : A3(F_KE, i, j, k);
+}
+static void implicit_column_catke(const model *m, REAL *col, long stride, int kfirst, int which, int i, int j, REAL dt) {
+  int Nz = m->Nz;
+  if (kfirst > Nz) return;
+  REAL gam[512], bet = 1, prev = 0;
+  for (int k = kfirst; k <= Nz; k++) {
+    REAL lo = (k == kfirst) ? 0 : -dt * catke_kface(m, which, i, j, k) / (DZC(k) * DZF(k));
+    REAL up = (k == Nz) ? 0 : -dt * catke_kface(m, which, i, j, k + 1) / (DZC(k) * DZF(k + 1));
+    REAL dg = (REAL)1 - lo - up - (which == 3 ? dt * A3(F_LE, i, j, k) : 0);
+    if (k == kfirst) {
+      bet = dg;
+      prev = col[(k - 1) * stride] / bet;
+    } else {
+      REAL up_below = -dt * catke_kface(m, which, i, j, k) / (DZC(k - 1) * DZF(k));
+      gam[k] = up_below / bet;
+      bet = dg - lo * gam[k];
+      prev = (col[(k - 1) * stride] - lo * prev) / bet;
+    }
+    col[(k - 1) * stride] = prev;
+  }
+  for (int k = Nz - 1; k >= kfirst; k--) col[(k - 1) * stride] -= gam[k + 1] * col[k * stride];
+}
+static void implicit_step_field_catke(model *m, int id, int which, REAL dt) {
+  const fld *F = &m->f[id];
+  long stride = (long)F->sx * F->sy;
+  int nyrows = (which == 1) ? NYV : m->Ny;
+#pragma omp parallel for schedule(static)
+  for (int j = (which == 1 ? 2 : 1); j <= nyrows; j++)
+    for (int i = 1; i <= m->Nx; i++)
+      implicit_column_catke(m, &A3(id, i, j, 1), stride, first_free_level(m, which > 2 ? 2 : which, i, j), which, i, j, dt);
+}
 void FN(set_vertical_diffusivity)(void *h, double nu, double kappa) {
   model *m = (model *)h;
   m->nu = (REAL)nu;
   m->kappa = (REAL)kappa;
 }
+
+/* ---------------------------------------------------------------- CATKE
+ * closure = CATKEVerticalDiffusivity() (/root/reference/sharding/less_simple_sharding_problem.jl:84-93,
+ * /root/reference/src/baroclinic_instability_model.jl:30,50-51; compared fields /root/reference/src/correctness.jl:60-67),
+ * Oceananigans.TurbulenceClosures.TKEBasedVerticalDiffusivities restated [UPSTREAM-UNVERIFIED] after Wagner et al.
+ * (2025), "Formulation and calibration of CATKE, a one-equation parameterization for microscale ocean mixing".
+ *
+ *   de/dt = -div(u e) + d/dz(kappa_e de/dz) + kappa_u S^2 - kappa_c N^2 - e^(3/2)/l_D,   kappa_psi = l_psi sqrt(e)
+ *
+ * At (c,c,f) faces, with e, N^2 = db/dz, S^2 = Ix((du/dz)^2) + Iy((dv/dz)^2), Ri = N^2/S^2 there, w* = sqrt(max(e,0)):
+ *   stable length     l* = min(C^s d_surface, C^b d_bottom, wstar / N)                                  (N^2 > 0, else no N limit)
+ *   stability fn      sigma_psi(Ri) = C^un_psi (Ri < 0);  C^lo_psi + (C^hi_psi - C^lo_psi) step((Ri - CRi0)/CRid) (Ri >= 0)
+ *   convective length l^h = C^c_psi w*^3 / J^b+ * max(0, 1 - C^sp sqrt(S^2) w*^2 / J^b+)  where J^b > J^b_min and N^2 < 0;
+ *                     l^e = C^e_psi J^b+ / (w* N^2 + J^b_min) just below such a layer (N^2 >= 0 here, < 0 above)
+ *   l_psi = max(l_conv, sigma_psi l*);   dissipation: l_D = max(l_conv(C^c_D, C^e_D), l* / sigma_D(Ri))
+ * TKE equation per cell: P = Iz(kappa_u S^2); wb = Iz(-kappa_c N^2); omega = sqrt|e| / Iz(l_D);
+ *   explicit: P + max(wb, 0) (+ the surface flux -(C^W_u* u*^3 + C^W_wD w_D^3) in the top cell);
+ *   implicit linear term L^e = -omega + min(wb, 0)/e [e > e_min] - [e < 0]/tau_neg.
+ * Restatement choices of this file: the surface buoyancy flux J^b is the instantaneous one (no time filter); with the
+ * default no-flux boundary conditions J^b = 0 and u* = 0; N^2 and S^2 vanish on the bottom and top faces; e steps like the
+ * other tracers (AB2 of advection + explicit TKE terms, then the implicit solve with kappa_e and L^e), T, S with kappa_c,
+ * u, v with kappa_u averaged to their columns. */
+typedef struct {
+  REAL Cs, Cb, Csp, CRid, CRi0;
+  REAL Chi[4], Clo[4], Cun[4], Cc[4], Ce[4]; /* psi = u, c, e, D */
+  REAL CWu, CWw, emin, Jbmin, tau_neg;
+} catke_par;
+static const catke_par CATKE = {
+  (REAL)1.131, (REAL)0.28, (REAL)0.505, (REAL)1.02, (REAL)0.254,
+  {(REAL)0.242, (REAL)0.098, (REAL)0.548, (REAL)0.579},
+  {(REAL)0.361, (REAL)0.198, (REAL)7.863, (REAL)1.604},
+  {(REAL)0.370, (REAL)0.369, (REAL)1.447, (REAL)0.923},
+  {(REAL)3.705, (REAL)4.793, (REAL)3.642, (REAL)3.254},
+  {(REAL)0.0, (REAL)0.112, (REAL)0.0, (REAL)0.0},
+  (REAL)3.179, (REAL)0.383, (REAL)1e-9, (REAL)1e-11, (REAL)60.0};
+
+static inline REAL catke_step(REAL x, REAL c, REAL w) {
+  REAL t = (x - c) / w;
+  return t < 0 ? 0 : (t > 1 ? 1 : t);
+}
+static inline REAL catke_sigma(int psi, REAL Ri) {
+  if (Ri < 0) return CATKE.Cun[psi];
+  return CATKE.Clo[psi] + (CATKE.Chi[psi] - CATKE.Clo[psi]) * catke_step(Ri, CATKE.CRi0, CATKE.CRid);
+}
+/* N^2 at face k (between cells k-1 and k; 1-based), zero on the boundary faces and next to the solid */
+static inline REAL catke_N2(const model *m, int i, int j, int k) {
+  if (k <= 1 || k > m->Nz || inactive_cell(m, i, j, k - 1) || inactive_cell(m, i, j, k)) return 0;
+  return (REAL)((buoyancy(m, i, j, k) - buoyancy(m, i, j, k - 1)) / (PREAL)DZF(k));
+}
+static inline REAL catke_S2(const model *m, int i, int j, int k) {
+  if (k <= 1 || k > m->Nz) return 0;
+  REAL uw = (A3(F_U, i, j, k) - A3(F_U, i, j, k - 1)) / DZF(k), ue = (A3(F_U, i + 1, j, k) - A3(F_U, i + 1, j, k - 1)) / DZF(k);
+  REAL vs = (A3(F_V, i, j, k) - A3(F_V, i, j, k - 1)) / DZF(k), vn = (A3(F_V, i, j + 1, k) - A3(F_V, i, j + 1, k - 1)) / DZF(k);
+  return (uw * uw + ue * ue) / (REAL)2 + (vs * vs + vn * vn) / (REAL)2;
+}
+typedef struct { REAL ku, kc, ke, lD, P, wb; } catke_face;
+static catke_face catke_at_face(const model *m, int i, int j, int k) {
+  catke_face f = {0, 0, 0, 0, 0, 0};
+  int Nz = m->Nz;
+  if (k <= 1 || k > Nz || inactive_cell(m, i, j, k - 1) || inactive_cell(m, i, j, k)) return f;
+  REAL ef = (A3(F_E, i, j, k - 1) + A3(F_E, i, j, k)) / (REAL)2;
+  REAL ep = ef > 0 ? ef : 0, ws = (REAL)sqrt((double)ep);
+  REAL N2 = catke_N2(m, i, j, k), S2 = catke_S2(m, i, j, k);
+  REAL Ri = (N2 == 0) ? 0 : N2 / S2;
+  REAL d_up = CATKE.Cs * (MK(zf, Nz + 1) - MK(zf, k)), d_dn = CATKE.Cb * (MK(zf, k) - MK(zf, KB(i, j) + 1));
+  REAL ls = d_up < d_dn ? d_up : d_dn;
+  if (N2 > 0) {
+    REAL lN = ws / (REAL)sqrt((double)N2);
+    if (lN < ls) ls = lN;
+  }
+  REAL Jb = A2(F_JB, i, j), Jbp = Jb > CATKE.Jbmin ? Jb : CATKE.Jbmin;
+  REAL N2above = catke_N2(m, i, j, k + 1);
+  int convecting = (Jb > CATKE.Jbmin) && (N2 < 0), entraining = (Jb > CATKE.Jbmin) && (N2 >= 0) && (N2above < 0);
+  REAL lconv[4];
+  for (int p = 0; p < 4; p++) {
+    REAL lh = CATKE.Cc[p] * ws * ws * ws / Jbp;
+    REAL esp = (REAL)1 - CATKE.Csp * (REAL)sqrt((double)S2) * ws * ws / Jbp;
+    lh *= esp > 0 ? esp : 0;
+    REAL le = CATKE.Ce[p] * Jbp / (ws * N2 + CATKE.Jbmin);
+    lconv[p] = convecting ? lh : (entraining ? le : 0);
+  }
+  REAL lpsi[3];
+  for (int p = 0; p < 3; p++) {
+    REAL l = catke_sigma(p, Ri) * ls;
+    lpsi[p] = lconv[p] > l ? lconv[p] : l;
+  }
+  f.ku = lpsi[0] * ws; f.kc = lpsi[1] * ws; f.ke = lpsi[2] * ws;
+  REAL lD = ls / catke_sigma(3, Ri);
+  f.lD = lconv[3] > lD ? lconv[3] : lD;
+  f.P = f.ku * S2;
+  f.wb = -f.kc * N2;
+  return f;
+}
+/* J^b = g (alpha J^T - beta J^S) at the surface from the top flux boundary conditions of T and S (zero without them);
+ * alpha, beta by centred differences of the equation of state in fp64 */
+static void catke_surface_buoyancy_flux(model *m) {
+  for (int j = 1; j <= m->Ny; j++)
+    for (int i = 1; i <= m->Nx; i++) {
+      double Jb = 0;
+      if (m->top_flux[2] || m->top_flux[3]) {
+        long o = ((long)i - 1 + HH) + (long)m->f[F_T].sx * ((long)j - 1 + HH);
+        double T = A3(F_T, i, j, m->Nz), S = A3(F_S, i, j, m->Nz), Z = MK(zc, m->Nz), d = 1e-2;
+        double drdT = ((double)teos10_rho((PREAL)(T + d), (PREAL)S, (PREAL)Z) - (double)teos10_rho((PREAL)(T - d), (PREAL)S, (PREAL)Z)) / (2 * d);
+        double drdS = ((double)teos10_rho((PREAL)T, (PREAL)(S + d), (PREAL)Z) - (double)teos10_rho((PREAL)T, (PREAL)(S - d), (PREAL)Z)) / (2 * d);
+        double JT = m->top_flux[2] ? m->top_flux[2][o] : 0, JS = m->top_flux[3] ? m->top_flux[3][o] : 0;
+        Jb = (double)m->g * (-drdT * JT - drdS * JS) / (double)m->rho0;   /* alpha = -rho_T/rho0, beta = rho_S/rho0 */
+      }
+      A2(F_JB, i, j) = (REAL)Jb;
+    }
+  fill_halo_2d(m, F_JB, 0, 0, 1);
+}
+/* compute_diffusivities!: kappa_u, kappa_c, kappa_e on the faces, L^e in the cells, then their halos
+ * (fill_halo_regions!(model.diffusivity_fields; only_local_halos = true), /root/reference/src/precompile.jl:37,117-119) */
+static void catke_compute_diffusivities(model *m) {
+  int Nz = m->Nz;
+  catke_surface_buoyancy_flux(m);
+#pragma omp parallel for schedule(static)
+  for (int j = 1; j <= m->Ny; j++)
+    for (int i = 1; i <= m->Nx; i++) {
+      catke_face lo = catke_at_face(m, i, j, 1);
+      A3(F_KU, i, j, 1) = A3(F_KC, i, j, 1) = A3(F_KE, i, j, 1) = 0;
+      for (int k = 1; k <= Nz; k++) {
+        catke_face hi = catke_at_face(m, i, j, k + 1);
+        A3(F_KU, i, j, k + 1) = hi.ku; A3(F_KC, i, j, k + 1) = hi.kc; A3(F_KE, i, j, k + 1) = hi.ke;
+        REAL e = A3(F_E, i, j, k), L = 0;
+        if (!inactive_cell(m, i, j, k)) {
+          REAL lD = (lo.lD + hi.lD) / (REAL)2, wb = (lo.wb + hi.wb) / (REAL)2;
+          REAL omega = lD > 0 ? (REAL)sqrt(fabs((double)e)) / lD : 0;
+          REAL wbm = wb < 0 ? wb : 0;
+          L = -omega + (e > CATKE.emin ? wbm / e : 0) - (e < 0 ? (REAL)1 / CATKE.tau_neg : 0);
+        }
+        A3(F_LE, i, j, k) = L;
+        lo = hi;
+      }
+    }
+  /* a14: zero-gradient y layer and periodic x of the face-located diffusivities (no z layer: the boundary faces carry
+   * zero), the usual fill for L^e */
+  for (int id = F_KU; id <= F_KE; id++) {
+    for (int k = 1; k <= Nz + 1; k++)
+      for (int i = 1; i <= m->Nx; i++) {
+        A3(id, i, 0, k) = A3(id, i, 1, k);
+        A3(id, i, m->Ny + 1, k) = A3(id, i, m->Ny, k);
+      }
+    fill_periodic_x(m, &m->f[id]);
+  }
+  fill_halo_3d(m, F_LE, 0, 0, 1);
+}
+/* G^n.e = -div(u e) + shear production + the positive part of the buoyancy flux + the surface TKE flux */
+static void catke_tke_tendency(model *m) {
+  int Nz = m->Nz;
+  tracer_tendency(m, F_GNE, f_E);
+#pragma omp parallel for schedule(static)
+  for (int j = 1; j <= m->Ny; j++)
+    for (int i = 1; i <= m->Nx; i++) {
+      catke_face lo = catke_at_face(m, i, j, 1);
+      for (int k = 1; k <= Nz; k++) {
+        catke_face hi = catke_at_face(m, i, j, k + 1);
+        if (!inactive_cell(m, i, j, k)) {
+          REAL wb = (lo.wb + hi.wb) / (REAL)2;
+          A3(F_GNE, i, j, k) += (lo.P + hi.P) / (REAL)2 + (wb > 0 ? wb : 0);
+        }
+        lo = hi;
+      }
+      if (!inactive_cell(m, i, j, Nz)) {
+        long o = ((long)i - 1 + HH) + (long)m->f[F_U].sx * ((long)j - 1 + HH), ov = ((long)i - 1 + HH) + (long)m->f[F_V].sx * ((long)j - 1 + HH);
+        REAL Ju = m->top_flux[0] ? (m->top_flux[0][o] + m->top_flux[0][o + 1]) / (REAL)2 : 0;
+        REAL Jv = m->top_flux[1] ? (m->top_flux[1][ov] + m->top_flux[1][ov + m->f[F_V].sx]) / (REAL)2 : 0;
+        REAL us2 = (REAL)sqrt((double)(Ju * Ju + Jv * Jv)), us3 = us2 * (REAL)sqrt((double)us2);   /* u*^2, u*^3 */
+        REAL Jb = A2(F_JB, i, j), wD3 = (Jb > 0 ? Jb : 0) * DZC(Nz);
+        REAL Qe = -(CATKE.CWu * us3 + CATKE.CWw * wD3);
+        A3(F_GNE, i, j, Nz) -= Qe / DZC(Nz);
+      }
+    }
+}
+void FN(set_catke)(void *h, int on) { ((model *)h)->catke = on != 0; }
 
 /* ---------------------------------------------------------------- AB2 + free surface
  * ab2_step!(model, dt) -- /root/reference/src/precompile.jl:39,121-123 (appendix A.4, A.7). */
@@ -1260,6 +1482,14 @@ void FN(ab2_step)(void *h, double dt_, int euler) {
   ab2_field(m, F_S, F_GNS, F_GMS, dt, chi, 0);
   implicit_step_field(m, F_T, 2, m->kappa, dt);
   implicit_step_field(m, F_S, 2, m->kappa, dt);
+  if (m->catke) {   /* (the diffusivity fields are those of the last update_state!) */
+    implicit_step_field_catke(m, F_U, 0, dt);
+    implicit_step_field_catke(m, F_V, 1, dt);
+    implicit_step_field_catke(m, F_T, 2, dt);
+    implicit_step_field_catke(m, F_S, 2, dt);
+    ab2_field(m, F_E, F_GNE, F_GME, dt, chi, 0);
+    implicit_step_field_catke(m, F_E, 3, dt);
+  }
   step_free_surface(m, dt);
 }
 /* correct_velocities_and_cache_previous_tendencies!(model, dt) --
@@ -1288,6 +1518,10 @@ void FN(correct_and_cache)(void *h) {
     for (int k = 1; k <= m->Nz; k++)
       for (int j = 1; j <= (q == 1 ? NYV : m->Ny); j++)
         for (int i = 1; i <= m->Nx; i++) A3(F_GMU + q, i, j, k) = A3(F_GNU + q, i, j, k);
+  if (m->catke)
+    for (int k = 1; k <= m->Nz; k++)
+      for (int j = 1; j <= m->Ny; j++)
+        for (int i = 1; i <= m->Nx; i++) A3(F_GME, i, j, k) = A3(F_GNE, i, j, k);
 }
 /* initialize!(model): barotropic velocities from the 3-D velocities + their halos */
 void FN(initialize)(void *h) {

@@ -28,6 +28,8 @@ FIELD_IDS = {
     "Gn.u": 6, "Gn.v": 7, "Gn.T": 8, "Gn.S": 9,
     "Gm.u": 10, "Gm.v": 11, "Gm.T": 12, "Gm.S": 13,
     "eta": 14, "U": 15, "V": 16, "eta_bar": 17, "U_bar": 18, "V_bar": 19, "Gn.U": 20, "Gn.V": 21,
+    # closure = CATKEVerticalDiffusivity(): the TKE tracer and the diffusivity fields (src/correctness.jl:60-67)
+    "e": 22, "Gn.e": 23, "Gm.e": 24, "kappa_u": 25, "kappa_c": 26, "kappa_e": 27, "Le": 28, "Jb": 29,
 }
 METRIC_IDS = {"phif": 0, "phic": 1, "dxc": 2, "dxf": 3, "azc": 4, "azf": 5, "fcor": 6,
               "zf": 7, "zc": 8, "dzc": 9, "dzf": 10}
@@ -155,6 +157,12 @@ class OracleBackend:
 
     def metric(self, name, index):
         return self._fn("metric")(self.h, METRIC_IDS[name], index)
+
+    def set_catke(self, on=True):
+        f = self._fn("set_catke")
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int]
+        f(self.h, int(on))
 
     def set_vertical_diffusivity(self, nu, kappa):
         f = self._fn("set_vertical_diffusivity")
