@@ -21,6 +21,8 @@ FIELD_IDS = {
     "eta": 14, "U": 15, "V": 16,
     "eta_bar": 17, "U_bar": 18, "V_bar": 19,
     "Gn.U": 20, "Gn.V": 21,
+    # closure = CATKEVerticalDiffusivity() only
+    "e": 22, "Gn.e": 23, "Gm.e": 24, "kappa_u": 25, "kappa_c": 26, "kappa_e": 27, "Le": 28, "Jb": 29,
 }
 METRIC2_IDS = ["dxfc", "dxcc", "dxcf", "dxff", "dyfc", "dycc", "dycf", "dyff", "azcc", "azfc", "azcf", "azff", "fff", "phicc"]
 METRIC_IDS = {"phif": 0, "phic": 1, "dxc": 2, "dxf": 3, "azc": 4, "azf": 5, "fcor": 6,
@@ -34,7 +36,7 @@ ABI_SYMBOLS = [
     "gb25_real_bytes",
     "gb25_set_stream", "gb25_use_own_stream", "gb25_synchronize", "gb25_field_dims", "gb25_set_field", "gb25_get_field",
     "gb25_field_device_ptr", "gb25_get_metric", "gb25_get_metric2", "gb25_get_substepping", "gb25_set_vertical_diffusivity",
-    "gb25_get_vertical_diffusivity", "gb25_set_baroclinic_instability",
+    "gb25_get_vertical_diffusivity", "gb25_set_closure_catke", "gb25_set_baroclinic_instability",
     "gb25_get_clock", "gb25_set_dt", "gb25_initialize", "gb25_mask_immersed_fields",
     "gb25_fill_halo_regions", "gb25_compute_auxiliaries", "gb25_fill_diffusivity_halos",
     "gb25_compute_momentum_tendencies", "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
@@ -115,6 +117,7 @@ def load_library(float_type="Float32"):
     lib.gb25_get_metric.argtypes = [P, C.c_int, C.c_int32, C.POINTER(C.c_double)]
     lib.gb25_get_metric2.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.c_int64]
     lib.gb25_set_vertical_diffusivity.argtypes = [P, C.c_double, C.c_double]
+    lib.gb25_set_closure_catke.argtypes = [P, C.c_int32]
     lib.gb25_get_vertical_diffusivity.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.gb25_get_substepping.argtypes = [P, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.gb25_get_clock.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
@@ -234,12 +237,15 @@ class HipBackend:
         self._call("gb25_get_metric", METRIC_IDS[name], index, C.byref(v))
         return v.value
 
+    def set_catke(self, on=True):
+        self._call("gb25_set_closure_catke", int(on))
+
     def set_vertical_diffusivity(self, nu, kappa):
         self._call("gb25_set_vertical_diffusivity", float(nu), float(kappa))
 
     def vertical_diffusivity(self):
         nu, kappa = C.c_double(), C.c_double()
-        self._call("gb25_get_vertical_diffusivity", C.byref(nu), C.byref(kappa))
+        self._call("gb25_get_vertical_diffusivity", "gb25_set_closure_catke", C.byref(nu), C.byref(kappa))
         return nu.value, kappa.value
 
     def metric2(self, name):

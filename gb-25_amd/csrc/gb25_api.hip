@@ -142,6 +142,8 @@ struct gb25_model {
   int mom_chunk_levels = 12, trc_chunk_levels = 12;
   // closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu); both zero: closure = nothing
   double nu = 0, kappa = 0;
+  bool catke = false;                // closure = CATKEVerticalDiffusivity(): the fields GB25_E .. GB25_JB exist
+  Field catke_b, catke_scratch;      // N^2 on the faces; the unused half of the two-wide tracer kernel's output
   real* d_implicit[2] = {nullptr, nullptr};   // elimination tables of the implicit solve for (u, v) and (T, S): lo | 1/beta | gamma
   double implicit_key[2][2] = {{0, 0}, {0, 0}};   // the (dt, K) they were built for
   bool slab = false;                 // x halos come from a neighbour (nranks > 1, or the self-ring of slab_mode = 1)
@@ -176,7 +178,8 @@ bool is_v_shaped(int id) {
   return id == GB25_V || id == GB25_GN_V || id == GB25_GM_V || id == GB25_BT_V || id == GB25_V_BAR ||
          id == GB25_GN_BT_V;
 }
-bool is_2d(int id) { return id >= GB25_ETA; }
+bool is_2d(int id) { return (id >= GB25_ETA && id <= GB25_GN_BT_V) || id == GB25_JB; }
+bool is_catke_field(int id) { return id >= GB25_E && id <= GB25_JB; }
 
 // --- profiling helpers -----------------------------------------------------------------------
 struct Timed {
@@ -731,6 +734,7 @@ Halo3 halo3(gb25_model* m, int sel = 3) {
     h.p[n] = m->f[GB25_T].d; h.is_v[n++] = 0;
     h.p[n] = m->f[GB25_S].d; h.is_v[n++] = 0;
   }
+  if (sel & 4) h.p[n] = m->f[GB25_E].d, h.is_v[n++] = 0;   // (the TKE tracer of CATKE: a launch of its own, sel = 4)
   h.n = n;
   return h;
 }
@@ -753,7 +757,7 @@ Halo2 halo2_G(gb25_model* m) {   // the barotropic forcing G.U, G.V
 // the zipper fold, whose images live in other threads' columns, and not with a closure (the implicit solve comes after
 // the look-aheads' writes)
 inline bool producers_fold(const gb25_model* m) {
-  return !m->slab && m->fold_fills && !m->g.cv.north_fold && m->nu == 0 && m->kappa == 0;
+  return !m->slab && m->fold_fills && !m->g.cv.north_fold && m->nu == 0 && m->kappa == 0 && !m->catke;
 }
 // rows of y faces that are stepped: the fold line is one
 inline int v_rows(const Grid& g) { return g.Ny + g.cv.north_fold; }
@@ -1045,6 +1049,7 @@ gb25_status tracers_impl(gb25_model* m) {
   return GB25_OK;
 }
 
+gb25_status catke_implicit_impl(gb25_model* m, int f0, int n, real dt);   // (with CATKE's diffusivity fields: below)
 // implicit_step! of a pair of fields (kind 0: u, v with nu, the corrector's column integrals rewritten; 1: T, S with kappa)
 gb25_status implicit_tables(gb25_model* m, int kind, double dt, double K) {
   if (m->d_implicit[kind] && m->implicit_key[kind][0] == dt && m->implicit_key[kind][1] == K) return GB25_OK;
@@ -1138,6 +1143,7 @@ gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
     }
     m->colsum_valid = true;
     m->ahead_uv_valid = false;
+    if (m->catke) return catke_implicit_impl(m, 0, 2, dt);
     return implicit_vertical_impl(m, 0, dt);
   }
   m->ahead_uv_valid = false;
@@ -1149,7 +1155,19 @@ gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
                      mom_kchunks(m));   // the momentum kernel's chunking (momentum_impl)
   m->colsum_valid = true;
   LAUNCHCHK();
+  if (m->catke) return catke_implicit_impl(m, 0, 2, dt);
   return implicit_vertical_impl(m, 0, dt);
+}
+// e <- e + dt (C1 G^n.e - C2 G^-.e), then the implicit solves of T, S, e with CATKE's diffusivity fields
+gb25_status catke_tracers_impl(gb25_model* m, real dt, real chi) {
+  const Grid& g = m->g;
+  const real C1 = real(1.5) + chi, C2 = real(0.5) + chi;
+  const size_t off = (size_t)g.H * g.pl_c;
+  const long n = (long)g.Nz * g.pl_c;
+  hipLaunchKernelGGL(k_ab2_single, dim3((unsigned)std::min<long>((n + 255) / 256, 256 * 16)), dim3(256), 0, m->stream,
+                     m->f[GB25_E].d + off, m->f[GB25_GN_E].d + off, m->f[GB25_GM_E].d + off, n, dt, C1, C2);
+  LAUNCHCHK();
+  return catke_implicit_impl(m, 2, 3, dt);
 }
 gb25_status ab2_tracers_impl(gb25_model* m, real dt, real chi) {
   const Grid& g = m->g;
@@ -1158,6 +1176,7 @@ gb25_status ab2_tracers_impl(gb25_model* m, real dt, real chi) {
     std::swap(m->f[GB25_T].d, m->ahead[0].d);
     std::swap(m->f[GB25_S].d, m->ahead[1].d);
     m->ahead_valid = false;
+    if (m->catke) return catke_tracers_impl(m, dt, chi);
     return implicit_vertical_impl(m, 1, dt);
   }
   m->ahead_valid = false;
@@ -1181,6 +1200,7 @@ gb25_status ab2_tracers_impl(gb25_model* m, real dt, real chi) {
     hipLaunchKernelGGL(k_ab2_tracers1, dim3(blocks), dim3(256), 0, m->stream, T, S, a, bb, c, d, n, dt, C1, C2);
   }
   LAUNCHCHK();
+  if (m->catke) return catke_tracers_impl(m, dt, chi);
   return implicit_vertical_impl(m, 1, dt);
 }
 gb25_status ab2_local_impl(gb25_model* m, real dt, real chi) {
@@ -1356,6 +1376,7 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
   // cache_previous_tendencies!: G^- <- G^n is a pointer exchange; the next tendency evaluation
   // overwrites the (old G^-) buffers that now carry the G^n name.
   for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);
+  if (m->catke) std::swap(m->f[GB25_GN_E].d, m->f[GB25_GM_E].d);
   m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;   // the look-aheads used the tendency pairs as they were before
   return GB25_OK;
 }
@@ -1373,14 +1394,79 @@ gb25_status mask_impl(gb25_model* m) {
   return GB25_OK;
 }
 
+// closure = CATKEVerticalDiffusivity(): what update_state! adds -- the advection of e (the two-wide tracer kernel with e in
+// both halves: a first version, the second half is thrown away), the buoyancy field, J^b, then the diffusivity fields with
+// their halo cells and the explicit TKE terms added to G^n.e.  After the tendencies of T, S (same stream).
+CatkePar catke_parameters() {
+  CatkePar c;
+  c.Cs = real(1.131); c.Cb = real(0.28); c.Csp = real(0.505); c.CRid = real(1.02); c.CRi0 = real(0.254);
+  const double hi[4] = {0.242, 0.098, 0.548, 0.579}, lo[4] = {0.361, 0.198, 7.863, 1.604}, un[4] = {0.370, 0.369, 1.447, 0.923};
+  const double cc[4] = {3.705, 4.793, 3.642, 3.254}, ce[4] = {0.0, 0.112, 0.0, 0.0};
+  for (int p = 0; p < 4; p++) {
+    c.Chi[p] = (real)hi[p]; c.Clo[p] = (real)lo[p]; c.Cun[p] = (real)un[p]; c.Cc[p] = (real)cc[p]; c.Ce[p] = (real)ce[p];
+  }
+  c.CWu = real(3.179); c.CWw = real(0.383); c.emin = real(1e-9); c.Jbmin = real(1e-11); c.tau_neg = real(60.);
+  return c;
+}
+gb25_status catke_update_impl(gb25_model* m) {
+  if (!m->catke) return GB25_OK;
+  const Grid& g = m->g;
+  int nbx = (g.Nx + V3_OUT - 1) / V3_OUT;
+  const int nby = (g.Ny + 3) / 4, kchunks = std::max(1, g.Nz / m->trc_chunk_levels);
+  const int nb = nbx * nby * kchunks;
+  constexpr int TW = sizeof(real) == 8 ? 3 : 5;
+  Ab2Ahead none{};
+  const LazyCorr lz{nullptr, nullptr};
+  auto kt = m->immersed ? k_tracer_tendencies_v5<TW, false, true, false> : k_tracer_tendencies_v5<TW, false, false, false>;
+  Grid ge = g;                                   // (the top fluxes of T, S are not e's: its surface flux comes below)
+  ge.top_flux[2] = ge.top_flux[3] = nullptr;
+  hipLaunchKernelGGL(kt, dim3(nb), dim3(64, 4), 0, m->stream, ge, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_W].d,
+                     m->f[GB25_E].d, m->f[GB25_E].d, m->f[GB25_GN_E].d, m->catke_scratch.d, nbx, kchunks, nb, none, lz);
+  dim3 b(64, 4);
+  hipLaunchKernelGGL(k_catke_buoyancy, dim3((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz - 1), b, 0, m->stream, g, m->f[GB25_T].d,
+                     m->f[GB25_S].d, m->catke_b.d);   // (N^2 on the interior faces 1 .. Nz-1)
+  hipLaunchKernelGGL(k_catke_surface_flux, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d,
+                     m->f[GB25_JB].d);
+  hipLaunchKernelGGL(m->immersed ? k_catke_diffusivities<true> : k_catke_diffusivities<false>, grid2(g.Nx, g.Ny, b), b, 0,
+                     m->stream, g, catke_parameters(), m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_E].d, m->catke_b.d,
+                     m->f[GB25_JB].d, m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d,
+                     m->f[GB25_GN_E].d);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+// implicit_step! with CATKE's diffusivity fields: fields [f0, f0 + n) of (u, v, T, S, e)
+gb25_status catke_implicit_impl(gb25_model* m, int f0, int n, real dt) {
+  const Grid& g = m->g;
+  if (g.Nz > 64) return fail(m, GB25_ERR_INVALID_ARGUMENT, "CATKE's implicit solve keeps a column and its factors in registers: Nz <= 64");
+  ImplicitVarFields A{};
+  A.f[0] = m->f[GB25_U].d; A.f[1] = m->f[GB25_V].d; A.f[2] = m->f[GB25_T].d; A.f[3] = m->f[GB25_S].d; A.f[4] = m->f[GB25_E].d;
+  A.KU = m->f[GB25_KAPPA_U].d; A.KC = m->f[GB25_KAPPA_C].d; A.KE = m->f[GB25_KAPPA_E].d; A.Le = m->f[GB25_LE].d;
+  A.dt = dt; A.f0 = f0;
+  A.sum[0] = f0 == 0 ? m->colsum[0].d : nullptr;
+  A.sum[1] = f0 == 0 ? m->colsum[1].d : nullptr;
+  A.kchunks = mom_kchunks(m);
+  const bool imm = m->immersed;
+  void (*kern)(Grid, ImplicitVarFields) =
+      g.Nz <= 32 ? (imm ? k_implicit_vertical_var<32, true> : k_implicit_vertical_var<32, false>)
+      : g.Nz <= 48 ? (imm ? k_implicit_vertical_var<48, true> : k_implicit_vertical_var<48, false>)
+                   : (imm ? k_implicit_vertical_var<64, true> : k_implicit_vertical_var<64, false>);
+  dim3 b(64, 4);
+  hipLaunchKernelGGL(kern, dim3((g.Nx + 63) / 64, (g.Ny + 3) / 4, n), b, 0, m->stream, g, A);
+  LAUNCHCHK();
+  if (f0 == 0) m->colsum_valid = true;
+  return GB25_OK;
+}
+
 gb25_status update_state_impl(gb25_model* m) {
   gb25_status s;
   if ((s = mask_impl(m))) return s;
   if ((s = fill_halos_impl(m, true))) return s;
+  if (m->catke && (s = fill_halos_impl(m, true, false, 1, 4))) return s;   // the TKE tracer
   if ((s = compute_w_impl(m))) return s;
   if ((s = compute_p_impl(m))) return s;
   if ((s = momentum_impl(m))) return s;
-  return tracers_impl(m);
+  if ((s = tracers_impl(m))) return s;
+  return catke_update_impl(m);
 }
 
 gb25_status ab2_step_impl(gb25_model* m, double dt, int euler) {
@@ -1459,6 +1545,7 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
   s = ab2_tracers_impl(m, (real)dt, chi);
   // y/z/x halos of T, S -- unless the look-ahead that was just adopted wrote them itself
   if (!s && (complete || !(ts_adopted && m->ahead_ts_folded))) s = fill_halos_impl(m, true, false, 1, 2);
+  if (!s && m->catke) s = fill_halos_impl(m, true, false, 1, 4);   // the TKE tracer
   if (!s) s = compute_p_impl(m, INT_MIN, INT_MIN, 0, -1, true);
   if (!s && adopted) s = fill_halos_2d(m, hG);
   m->stream = main;
@@ -1534,7 +1621,8 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     }
     m->ahead_baro_valid = true;
   }
-  return tracers_impl(m);
+  if ((s = tracers_impl(m))) return s;
+  return catke_update_impl(m);
 }
 
 gb25_status initialize_impl(gb25_model* m) {
@@ -1636,6 +1724,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   const int H = cfg->halo, sx = m->Nx + 2 * H;
   for (int id = 0; id < GB25_FIELD_COUNT; id++) {
     if (id >= GB25_ETA_BAR && id <= GB25_V_BAR) continue;  // allocated contiguously below
+    if (is_catke_field(id)) continue;   // (allocated when the closure is switched on)
     int ny = cfg->Ny + 2 * H + (is_v_shaped(id) ? 1 : 0);
     int nz = is_2d(id) ? 1 : cfg->Nz + 2 * H + (id == GB25_W ? 1 : 0);
     if ((s = alloc_field(m, m->f[id], sx, ny, nz))) return s;
@@ -1757,6 +1846,8 @@ void gb25_destroy(gb25_model* m) {
     if (p) hipFree(p);
   for (auto p : m->d_implicit)
     if (p) hipFree(p);
+  if (m->catke_b.d) hipFree(m->catke_b.d);
+  if (m->catke_scratch.d) hipFree(m->catke_scratch.d);
   for (int a = 0; a < 2; a++) {
     for (auto& w : m->wide[a])
       if (w.d) hipFree(w.d);
@@ -1812,6 +1903,7 @@ gb25_status gb25_synchronize(gb25_model* m) {
 gb25_status gb25_field_dims(const gb25_model* m, gb25_field id, int include_halos, int32_t d[3]) {
   if (!m || id < 0 || id >= GB25_FIELD_COUNT || !d) return GB25_ERR_INVALID_ARGUMENT;
   const Field& F = m->f[id];
+  if (!F.d) return GB25_ERR_INVALID_ARGUMENT;   // (a field of CATKE on a model whose closure is not CATKE)
   const int H = m->cfg.halo;
   if (include_halos) {
     d[0] = F.nx; d[1] = F.ny; d[2] = F.nz;
@@ -1823,6 +1915,7 @@ gb25_status gb25_field_dims(const gb25_model* m, gb25_field id, int include_halo
 
 static gb25_status copy_field(gb25_model* m, gb25_field id, real* host, int include_halos, bool to_device) {
   if (!m || id < 0 || id >= GB25_FIELD_COUNT || !host) return GB25_ERR_INVALID_ARGUMENT;
+  if (!m->f[id].d) return fail(m, GB25_ERR_INVALID_ARGUMENT, "this model has no such field (closure = CATKEVerticalDiffusivity() only)");
   if (to_device && (id == GB25_U || id == GB25_V)) m->colsum_valid = false;  // cached column integrals are stale
   if (m->uv_lazy)   // (only after a composite call that failed half-way: memory must hold the corrected velocities)
     if (gb25_status s = materialize_uv(m)) return s;
@@ -1912,6 +2005,7 @@ gb25_status gb25_get_field(gb25_model* m, gb25_field f, void* host_, int include
 }
 gb25_status gb25_field_device_ptr(gb25_model* m, gb25_field id, void** dev) {
   if (!m || id < 0 || id >= GB25_FIELD_COUNT || !dev) return GB25_ERR_INVALID_ARGUMENT;
+  if (!m->f[id].d) return fail(m, GB25_ERR_INVALID_ARGUMENT, "this model has no such field (closure = CATKEVerticalDiffusivity() only)");
   if (gb25_status s = collective_guard(m, 2, (unsigned)id, 0.0)) return s;
   if (m->uv_lazy)
     if (gb25_status s = materialize_uv(m)) return s;
@@ -1991,6 +2085,29 @@ gb25_status gb25_set_vertical_diffusivity(gb25_model* m, double nu, double kappa
   m->kappa = kappa;
   m->ahead_valid = false;   // (a look-ahead of T, S written with its halos predates the solve)
   if (!m->slab) m->complete_fills_needed = 2;
+  return GB25_OK;
+}
+gb25_status gb25_set_closure_catke(gb25_model* m, int32_t on) {
+  CHECK_MODEL(m);
+  if (on && (m->slab || m->g.cv.on))
+    return fail(m, GB25_ERR_INVALID_ARGUMENT, "CATKE runs on a single lat-lon domain (flat bottom or GridFittedBottom) for now");
+  if (on && m->cfg.Nz > 64) return fail(m, GB25_ERR_INVALID_ARGUMENT, "CATKE: Nz <= 64 (its implicit solve is register-resident)");
+  if (on && (m->nu != 0 || m->kappa != 0)) return fail(m, GB25_ERR_STATE, "one closure at a time: the vertical diffusivity is set");
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(m->side_stream));
+  if (on && !m->f[GB25_E].d) {
+    const int H = m->cfg.halo, sx = m->Nx + 2 * H, sy = m->cfg.Ny + 2 * H, nz = m->cfg.Nz + 2 * H;
+    gb25_status s;
+    for (int id = GB25_E; id <= GB25_JB; id++) {
+      const bool faces = id >= GB25_KAPPA_U && id <= GB25_KAPPA_E;
+      if ((s = alloc_field(m, m->f[id], sx, sy, id == GB25_JB ? 1 : nz + (faces ? 1 : 0)))) return s;
+    }
+    if ((s = alloc_field(m, m->catke_b, sx, sy, nz))) return s;
+    if ((s = alloc_field(m, m->catke_scratch, sx, sy, nz))) return s;
+  }
+  m->catke = on != 0;
+  m->ahead_valid = false;
+  m->complete_fills_needed = 2;
   return GB25_OK;
 }
 gb25_status gb25_get_vertical_diffusivity(const gb25_model* m, double* nu, double* kappa) {

@@ -12,6 +12,13 @@
 
 namespace gb25 {
 
+// a value and its periodic x images (see the FOLD variants of k_corrector, k_barotropic_multi and the tracer kernel)
+__device__ __forceinline__ void store_x_images(const Grid& g, real* a, int o, real x, bool xw, bool xe) {
+  a[o] = x;
+  if (xw) a[o + g.Nx] = x;   // column i < H is the periodic image of column i + Nx (east halo)
+  if (xe) a[o - g.Nx] = x;   // column i >= Nx - H of column i - Nx (west halo)
+}
+
 constexpr int TX = 64, TY = 4;
 
 struct TileIdx {
@@ -978,6 +985,247 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_reg(Grid g, ImplicitF
   }
 }
 
+// =============================================================================================
+// closure = CATKEVerticalDiffusivity() (GB-25 src/baroclinic_instability_model.jl:30,50-51; sharding/
+// less_simple_sharding_problem.jl:84-93; compared fields src/correctness.jl:60-67).  The formulas are those of
+// oracle/gb25_oracle.c (catke_at_face: Oceananigans' TKE-based closure restated [UPSTREAM-UNVERIFIED] after Wagner et al.
+// 2025); single domain, lat-lon grid (flat or with a GridFittedBottom).
+//   k_catke_buoyancy        b = -g rho'(T, S, z) / rho0 per cell (the equation of state in fp64, as the pressure kernel)
+//   k_catke_surface_flux    J^b = g (alpha J^T - beta J^S) from the top flux boundary conditions (zero without them)
+//   k_catke_diffusivities   one thread per column, marching up the faces: kappa_u, kappa_c, kappa_e, L^e with the halo cells
+//                           their fill derives (a14), and the explicit TKE terms added to G^n.e (shear production, positive
+//                           buoyancy flux, surface TKE flux)
+//   k_implicit_vertical_var the tridiagonal solve with these diffusivity fields (u, v, T, S, e in one launch)
+// =============================================================================================
+struct CatkePar {
+  real Cs, Cb, Csp, CRid, CRi0;
+  real Chi[4], Clo[4], Cun[4], Cc[4], Ce[4];   // psi = u, c, e, D
+  real CWu, CWw, emin, Jbmin, tau_neg;
+};
+// N^2 at face k (between cells k-1 and k; k = blockIdx.z + 1), stored at the index of cell k.  Both buoyancies and their
+// difference in fp64 (as the pressure kernel differences its pressure): in a mixed layer the difference of two Float32
+// buoyancies is a handful of ulps, and the stratification-limited mixing length goes with N^-1.
+__global__ void k_catke_buoyancy(Grid g, const real* __restrict__ T, const real* __restrict__ S, real* __restrict__ n2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z + 1;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const int o = ic(g, i, j, k), ob = o - g.pl_c;
+  const double gr = -(double)g.g / (double)g.rho0, sc = 0.875 / 35.16504;
+  const double bk = gr * teos10_level(g.eos + 28 * k, sqrt(((double)S[o] + 32.0) * sc), (double)T[o] * 0.025);
+  const double bb = gr * teos10_level(g.eos + 28 * (k - 1), sqrt(((double)S[ob] + 32.0) * sc), (double)T[ob] * 0.025);
+  n2[o] = (real)((bk - bb) / g.dzf_d[k]);
+}
+__global__ void k_catke_surface_flux(Grid g, const real* __restrict__ T, const real* __restrict__ S, real* __restrict__ Jb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const int o2 = i2(g, i, j);
+  double J = 0.0;
+  if (g.top_flux[2] || g.top_flux[3]) {
+    const int o = ic(g, i, j, g.Nz - 1);
+    const double sc = 0.875 / 35.16504, d = 1e-2, Tc = (double)T[o], Sc = (double)S[o];
+    const double* c = g.eos + 28 * (g.Nz - 1);
+    auto rho = [&](double t, double s) { return teos10_level(c, sqrt((s + 32.0) * sc), t * 0.025); };
+    const double drdT = (rho(Tc + d, Sc) - rho(Tc - d, Sc)) / (2 * d), drdS = (rho(Tc, Sc + d) - rho(Tc, Sc - d)) / (2 * d);
+    const double JT = g.top_flux[2] ? (double)g.top_flux[2][o2] : 0.0, JS = g.top_flux[3] ? (double)g.top_flux[3][o2] : 0.0;
+    J = (double)g.g * (-drdT * JT - drdS * JS) / (double)g.rho0;
+  }
+  const bool xw = i < g.H, xe = i >= g.Nx - g.H;
+  store_x_images(g, Jb, o2, (real)J, xw, xe);
+  if (j == 0) store_x_images(g, Jb, o2 - g.sx, (real)J, xw, xe);
+  if (j == g.Ny - 1) store_x_images(g, Jb, o2 + g.sx, (real)J, xw, xe);
+}
+struct CatkeFace {
+  real ku, kc, ke, lD, P, wb;
+};
+__device__ __forceinline__ real catke_sigma(const CatkePar& c, int p, real Ri) {
+  if (Ri < real(0.)) return c.Cun[p];
+  real t = (Ri - c.CRi0) / c.CRid;
+  t = t < real(0.) ? real(0.) : (t > real(1.) ? real(1.) : t);
+  return c.Clo[p] + (c.Chi[p] - c.Clo[p]) * t;
+}
+template <bool IMM>
+__global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c, const real* __restrict__ u,
+                                                             const real* __restrict__ v, const real* __restrict__ e,
+                                                             const real* __restrict__ b, const real* __restrict__ Jb,
+                                                             real* __restrict__ KU, real* __restrict__ KC,
+                                                             real* __restrict__ KE, real* __restrict__ Le,
+                                                             real* __restrict__ Ge) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const int Nz = g.Nz, o2 = i2(g, i, j), pc = g.pl_c, pv = g.pl_v;
+  const int kc0 = IMM ? min((int)(g.im.ordA[o2] & 255), Nz) : 0;   // first active level of the column
+  const bool xw = i < g.H, xe = i >= g.Nx - g.H, ys = j == 0, yn = j == g.Ny - 1;
+  auto put = [&](real* a, int o, real x) {   // the cell and the halo cells its fill derives from it (a14)
+    store_x_images(g, a, o, x, xw, xe);
+    if (ys) store_x_images(g, a, o - g.sx, x, xw, xe);
+    if (yn) store_x_images(g, a, o + g.sx, x, xw, xe);
+  };
+  const real zt = g.zc[Nz - 1] + real(0.5) * g.dzc[Nz - 1];          // surface
+  const real jb = Jb[o2], jbp = jb > c.Jbmin ? jb : c.Jbmin;
+  // N^2 at face k (between cells k-1 and k), zero on the boundary faces and next to the solid
+  auto N2at = [&](int k) -> real {
+    if (k <= kc0 || k >= Nz) return real(0.);
+    return b[ic(g, i, j, k)];
+  };
+  int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
+  CatkeFace lo = {real(0.), real(0.), real(0.), real(0.), real(0.), real(0.)};
+  put(KU, o, real(0.)); put(KC, o, real(0.)); put(KE, o, real(0.));
+  real zf_k = g.zc[0] - real(0.5) * g.dzc[0], zbot = zf_k;            // z of face 0; bottom of the column
+  for (int q = 0; q < kc0; q++) zbot += g.dzc[q];
+  real N2here = real(0.), N2above = N2at(1);
+  for (int k = 0; k < Nz; k++) {
+    // ---- face k+1 (top of cell k)
+    zf_k += g.dzc[k];
+    N2here = N2above;
+    N2above = N2at(k + 2);
+    CatkeFace hi = {real(0.), real(0.), real(0.), real(0.), real(0.), real(0.)};
+    const int kf = k + 1;
+    if (kf > kc0 && kf < Nz) {
+      const int of = o + pc, ovf = ov + pv;   // cell kf
+      const real rdz = real(1.) / g.dzf[kf];
+      const real ef = (e[o] + e[of]) / real(2.), ep = ef > real(0.) ? ef : real(0.), ws = sqrt(ep);
+      const real uw = (u[of] - u[o]) * rdz, ue = (u[of + 1] - u[o + 1]) * rdz;
+      const real vs = (v[ovf] - v[ov]) * rdz, vn = (v[ovf + g.sx] - v[ov + g.sx]) * rdz;
+      const real S2 = (uw * uw + ue * ue) / real(2.) + (vs * vs + vn * vn) / real(2.);
+      const real N2 = N2here;
+      const real Ri = (N2 == real(0.)) ? real(0.) : N2 / S2;
+      const real dup = c.Cs * (zt - zf_k), ddn = c.Cb * (zf_k - zbot);
+      real ls = dup < ddn ? dup : ddn;
+      if (N2 > real(0.)) {
+        const real lN = ws / sqrt(N2);
+        ls = lN < ls ? lN : ls;
+      }
+      const bool convecting = jb > c.Jbmin && N2 < real(0.), entraining = jb > c.Jbmin && N2 >= real(0.) && N2above < real(0.);
+      real lpsi[4];
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        real lh = c.Cc[p] * ws * ws * ws / jbp;
+        const real esp = real(1.) - c.Csp * sqrt(S2) * ws * ws / jbp;
+        lh *= esp > real(0.) ? esp : real(0.);
+        const real le = c.Ce[p] * jbp / (ws * N2 + c.Jbmin);
+        const real lconv = convecting ? lh : (entraining ? le : real(0.));
+        const real sg = catke_sigma(c, p, Ri);
+        const real lst = p < 3 ? sg * ls : ls / sg;
+        lpsi[p] = lconv > lst ? lconv : lst;
+      }
+      hi.ku = lpsi[0] * ws; hi.kc = lpsi[1] * ws; hi.ke = lpsi[2] * ws; hi.lD = lpsi[3];
+      hi.P = hi.ku * S2;
+      hi.wb = -hi.kc * N2;
+    }
+    put(KU, o + pc, hi.ku); put(KC, o + pc, hi.kc); put(KE, o + pc, hi.ke);
+    // ---- cell k
+    real L = real(0.);
+    if (k >= kc0) {
+      const real ek = e[o], lD = (lo.lD + hi.lD) / real(2.), wb = (lo.wb + hi.wb) / real(2.);
+      const real omega = lD > real(0.) ? sqrt(rabs(ek)) / lD : real(0.);
+      const real wbm = wb < real(0.) ? wb : real(0.);
+      L = -omega + (ek > c.emin ? wbm / ek : real(0.)) - (ek < real(0.) ? real(1.) / c.tau_neg : real(0.));
+      real src = (lo.P + hi.P) / real(2.) + (wb > real(0.) ? wb : real(0.));
+      if (k == Nz - 1) {   // the surface TKE flux: -(C^W_u* u*^3 + C^W_wD w_D^3), into the top cell
+        const real Ju = g.top_flux[0] ? (g.top_flux[0][o2] + g.top_flux[0][o2 + 1]) / real(2.) : real(0.);
+        const real Jv = g.top_flux[1] ? (g.top_flux[1][o2] + g.top_flux[1][o2 + g.sx]) / real(2.) : real(0.);
+        const real us2 = sqrt(Ju * Ju + Jv * Jv), us3 = us2 * sqrt(us2);
+        const real wD3 = (jb > real(0.) ? jb : real(0.)) * g.dzc[k];
+        src += (c.CWu * us3 + c.CWw * wD3) / g.dzc[k];
+      }
+      Ge[o] = Ge[o] + src;
+    }
+    put(Le, o, L);
+    if (k == 0) store_x_images(g, Le, o - pc, L, xw, xe);        // bottom / top layer (interior rows only, like the fill)
+    if (k == Nz - 1) store_x_images(g, Le, o + pc, L, xw, xe);
+    lo = hi;
+    o += pc;
+    ov += pv;
+  }
+}
+// e <- e + dt (C1 G^n - C2 G^-): ab2_step_field! of the one tracer the packed kernels do not carry
+__global__ void k_ab2_single(real* __restrict__ e, const real* __restrict__ Gn, const real* __restrict__ Gm, long n, real dt,
+                             real C1, real C2) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; t < n; t += stride) e[t] = ab2_advance(e[t], Gn[t], Gm[t], dt, C1, C2);
+}
+// The tridiagonal solve with diffusivity FIELDS: per-thread elimination (the factors depend on the column), the column and
+// its factors in registers (Nz <= NZT).  blockIdx.z = field: 0 u (kappa_u averaged in x), 1 v (in y), 2 T, 3 S (kappa_c),
+// 4 e (kappa_e, with the implicit linear term L^e on the diagonal).
+struct ImplicitVarFields {
+  real* f[5];
+  const real *KU, *KC, *KE, *Le;
+  real dt;
+  int f0;            // first field of this launch (u, v on the main stream; T, S, e on the side stream)
+  real* sum[2];      // column integrals of the new u, v (the corrector's; the look-ahead's predate the solve)
+  int kchunks;
+};
+template <int NZT, bool IMM>
+__global__ __launch_bounds__(256) void k_implicit_vertical_var(Grid g, ImplicitVarFields A) {
+  const int f = blockIdx.z + A.f0, Nz = g.Nz;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  const bool vsh = f == 1;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const int o2 = i2(g, i, j);
+  int kf = 0;
+  if (IMM) {
+    const unsigned w = f >= 2 ? g.im.ordA[o2] : g.im.ordC[o2] >> (f == 0 ? 8 : 16);
+    kf = min((int)(w & 255), Nz);
+  }
+  if (vsh && j == 0) kf = Nz;   // (the wall face: nothing to solve, its column integral is zero)
+  real* F = A.f[f];
+  const int pl = vsh ? g.pl_v : g.pl_c, o0 = vsh ? iv(g, i, j, 0) : ic(g, i, j, 0), oc = ic(g, i, j, 0), pc = g.pl_c;
+  const real* K = f < 2 ? A.KU : (f < 4 ? A.KC : A.KE);
+  const int nb = f == 0 ? -1 : (f == 1 ? -g.sx : 0);     // the second column kappa_u is averaged with
+  real x[NZT], gam[NZT];
+#pragma unroll
+  for (int k = 0; k < NZT; k++) x[k] = (k < Nz) ? F[o0 + k * pl] : real(0.);
+  real bet = real(1.), p = real(0.), kup = real(0.);     // kup: dt kappa at the top face of the level below
+#pragma unroll
+  for (int k = 0; k < NZT; k++)
+    if (k < Nz && k >= kf) {
+      // faces k (bottom) and k+1 (top) of this level
+      real ktop = real(0.);
+      if (k < Nz - 1) {
+        const int of = oc + (k + 1) * pc;
+        ktop = A.dt * (f < 2 ? (K[of + nb] + K[of]) / real(2.) : K[of]);
+      }
+      const real rc = real(1.) / g.dzc[k];
+      const real lo = (k == kf) ? real(0.) : -(kup * rc) / g.dzf[k];
+      const real up = (k == Nz - 1) ? real(0.) : -(ktop * rc) / g.dzf[k + 1];
+      real dg = real(1.) - lo - up;
+      if (f == 4) dg -= A.dt * A.Le[oc + k * pc];
+      if (k == kf) {
+        bet = dg;
+        p = x[k] / bet;
+        gam[k] = real(0.);
+      } else {
+        const real upb = -(kup / g.dzc[k - 1]) / g.dzf[k];   // upper coefficient of the level below
+        gam[k] = upb / bet;
+        bet = dg - lo * gam[k];
+        p = (x[k] - lo * p) / bet;
+      }
+      x[k] = p;
+      kup = ktop;
+    }
+#pragma unroll
+  for (int k = NZT - 2; k >= 0; k--)
+    if (k < Nz - 1 && k >= kf) x[k] = x[k] - gam[k + 1] * x[k + 1];
+#pragma unroll
+  for (int k = 0; k < NZT; k++)
+    if (k < Nz && k >= kf) F[o0 + k * pl] = x[k];
+  if (f < 2 && A.sum[f] != nullptr) {   // chunked like every other producer of these sums
+    const int klen = (Nz + A.kchunks - 1) / A.kchunks;
+    real tot = real(0.), q = real(0.);
+    int kk = 0;
+#pragma unroll
+    for (int k = 0; k < NZT; k++)
+      if (k < Nz) {
+        q = (kk == 0) ? g.dzc[k] * x[k] : rfma(g.dzc[k], x[k], q);
+        if (++kk == klen || k == Nz - 1) {
+          tot = (k < klen) ? q : tot + q;
+          kk = 0;
+        }
+      }
+    A.sum[f][o2] = (vsh && j == 0) ? real(0.) : tot;
+  }
+}
+
 // tracers: flat AXPY over the interior planes of a parent array (G halos are identically zero)
 using realx4 = __attribute__((ext_vector_type(4))) real;
 template <bool NT>
@@ -1033,12 +1281,6 @@ __global__ void k_ab2_tracers1(real* __restrict__ T, real* __restrict__ S, const
 // Periodic x / wall y are handled in-kernel (topology-aware operators): no halo fills inside
 // the sub-cycle.
 // =============================================================================================
-// a value and its periodic x images (see the FOLD variants of k_corrector, k_barotropic_multi and the tracer kernel)
-__device__ __forceinline__ void store_x_images(const Grid& g, real* a, int o, real x, bool xw, bool xe) {
-  a[o] = x;
-  if (xw) a[o + g.Nx] = x;   // column i < H is the periodic image of column i + Nx (east halo)
-  if (xe) a[o - g.Nx] = x;   // column i >= Nx - H of column i - Nx (west halo)
-}
 struct Baro {
   const real *eta0, *U0, *V0;  // state at substep m
   real *eta1, *U1, *V1;        // state at substep m+1

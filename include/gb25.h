@@ -56,6 +56,10 @@ typedef enum {
   GB25_ETA, GB25_BT_U, GB25_BT_V,             /* free_surface.eta, barotropic_velocities */
   GB25_ETA_BAR, GB25_U_BAR, GB25_V_BAR,       /* free_surface.filtered_state */
   GB25_GN_BT_U, GB25_GN_BT_V,                 /* timestepper.G^n.U, .V */
+  /* closure = CATKEVerticalDiffusivity() only (gb25_set_closure_catke): the TKE tracer, its tendencies, and
+   * model.diffusivity_fields as src/correctness.jl:60-67 compares them: kappa_u, kappa_c, kappa_e at (Center, Center,
+   * Face) [Nz + 1 levels], L^e at cell centres, the surface buoyancy flux J^b (2-D) */
+  GB25_E, GB25_GN_E, GB25_GM_E, GB25_KAPPA_U, GB25_KAPPA_C, GB25_KAPPA_E, GB25_LE, GB25_JB,
   GB25_FIELD_COUNT
 } gb25_field;
 
@@ -208,6 +212,11 @@ gb25_status gb25_set_top_flux(gb25_model *m, gb25_field f, const void *flux);
  *      update of u, v (nu) and T, S (kappa), ab2_step! solves (1 - Δt ∂z K ∂z) φ = φ* per column (implicit_step!, batched
  *      tridiagonal solver).  nu = kappa = 0 restores closure = nothing.  [m²/s] */
 gb25_status gb25_set_vertical_diffusivity(gb25_model *m, double nu, double kappa);
+/*      closure = Oceananigans.TurbulenceClosures.CATKEVerticalDiffusivity() (src/baroclinic_instability_model.jl:30,
+ *      sharding/less_simple_sharding_problem.jl:84-93): tracers become (T, S, e); update_state! computes the diffusivity
+ *      fields (and fills their halos, src/precompile.jl:37); ab2_step! mixes u, v, T, S, e implicitly with them.  Single
+ *      domain, lat-lon grid (flat bottom or GridFittedBottom).  on = 0: back to closure = nothing. */
+gb25_status gb25_set_closure_catke(gb25_model *m, int32_t on);
 gb25_status gb25_get_vertical_diffusivity(const gb25_model *m, double *nu, double *kappa);
 
 /* ---- initial conditions: set_baroclinic_instability!(model) (src/model_utils.jl:99-127) */

@@ -1,0 +1,114 @@
+"""closure = CATKEVerticalDiffusivity() on the HIP path (GB-25 src/baroclinic_instability_model.jl:
+30,50-51, sharding/less_simple_sharding_problem.jl:84-93) against the oracle's restatement (tests/test_oracle_catke.py
+pins that one): the diffusivity fields the reference compares (src/correctness.jl:60-67), the TKE tracer, the implicit
+solves with diffusivity fields, wind- and cooling-driven mixing."""
+import numpy as np
+import pytest
+
+import gb25_amd as gb
+from gb25_amd.binding import GB25Error
+from helpers import SQRT_EPS32, counter_rng, make_pair
+
+pytestmark = pytest.mark.gpu
+CATKE = gb.CATKEVerticalDiffusivity
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    n = max(np.linalg.norm(a.ravel()), np.linalg.norm(b.ravel()))
+    return 0.0 if n == 0 else float(np.linalg.norm((a - b).ravel()) / n)
+
+
+def start(r, v, N2=1e-5, wind=None, heat=None):
+    Nx, Ny, Nz = v.grid.size
+    zc = np.array([v.backend.metric("zc", k) for k in range(1, Nz + 1)])
+    T = np.broadcast_to(20.0 + (N2 / (9.80665 * 2e-4)) * zc, (Nx, Ny, Nz))
+    rng = np.random.default_rng(3)
+    e = 1e-5 * rng.random((Nx, Ny, Nz)) + 1e-7
+    u = 0.02 * rng.standard_normal((Nx, Ny, Nz))
+    for m in (r, v):
+        dt = m.backend.dtype
+        S = np.broadcast_to(35.0 - 1e-3 * zc, (Nx, Ny, Nz))
+        m.set(T=T.astype(np.float32).astype(dt), S=S.astype(np.float32).astype(dt), e=e.astype(np.float32).astype(dt),
+              u=u.astype(np.float32).astype(dt))
+        if wind is not None:
+            gb.set_top_flux(m, u=np.full((Nx, Ny), wind, dt))
+        if heat is not None:
+            gb.set_top_flux(m, T=np.full((Nx, Ny), heat, dt))
+
+
+@pytest.mark.parametrize("float_type,tol", [("Float64", 1e-10), ("Float32", 2e-5)])
+def test_diffusivity_fields_match_the_oracle(float_type, tol):
+    """compute_diffusivities! alone (update_state!): kappa_u, kappa_c, kappa_e, L^e, J^b and the TKE tendency, halos
+    included (a14: the fill of the diffusivity fields)."""
+    r, v = make_pair(40, 44, 16, dt=120.0, float_type=float_type, depth=200.0, closure=CATKE())
+    start(r, v, wind=-1e-4, heat=5e-5)
+    for m in (r, v):
+        gb.update_state(m)
+    for n in ("kappa_u", "kappa_c", "kappa_e", "Le", "Jb", "Gn.e", "Gn.T", "Gn.u"):
+        a, b = r.backend.get_field(n, True), v.backend.get_field(n, True)
+        assert rel(a, b) < tol, (n, rel(a, b))
+    assert r.diffusivity_fields.kappa_u.interior.max() > 1e-5 and r.diffusivity_fields.Jb.interior.min() > 1e-8
+
+
+@pytest.mark.parametrize("float_type", ["Float64", "Float32"])
+@pytest.mark.parametrize("case", ["wind", "cooling", "islands"])
+def test_stepping_with_catke_matches_the_oracle(case, float_type):
+    """first_time_step! + 30 steps.  The Float64 build is the logic check (every compared field, halos included, to
+    1e-7: the switches of the mixing lengths -- min / max / step of Ri -- amplify round-off a little).  Float32 against
+    the Float64 oracle: sqrt(eps) where a Float32 run can reach it; the diffusivity fields, e and what they feed are
+    products of square roots, clipped ratios and switches on quantities near zero (L^e = -sqrt|e|/l_D + wb-/e [e > e_min])
+    -- there the yardstick is the Float32 ORACLE's own distance from the Float64 one (as close to a
+    Float32 reference run as that run is to the truth)."""
+    kw = dict(grid_type="gaussian_islands_lat_lon") if case == "islands" else {}
+    size = (90, 44, 16) if case == "islands" else (40, 44, 24)
+    r, v = make_pair(*size, dt=120.0, float_type=float_type, depth=200.0 if case != "islands" else 4000.0, closure=CATKE(), **kw)
+    start(r, v, wind=-1e-4 if case != "cooling" else None, heat=1e-4 if case == "cooling" else None)
+    for m in (r, v):
+        gb.first_time_step(m)
+        gb.loop(m, 30)
+    ok, report = gb.compare_states(r, v, rtol=SQRT_EPS32, include_halos=True, verbose=False)
+    if float_type == "Float64":
+        bad = [(q["name"], q["rel"]) for q in report if not q["rel"] <= 1e-7]
+        assert not bad, bad
+    else:
+        # what a Float32 run of the reference itself is away from the Float64 truth: the oracle in Float32
+        from oracle_backend import CPU
+        w = gb.baroclinic_instability_model(CPU("f32"), *size, dt=120.0, depth=200.0 if case != "islands" else 4000.0,
+                                            closure=CATKE(), **kw)
+        start(w, w, wind=-1e-4 if case != "cooling" else None, heat=1e-4 if case == "cooling" else None)
+        gb.first_time_step(w)
+        gb.loop(w, 30)
+        _, own = gb.compare_states(w, v, rtol=SQRT_EPS32, include_halos=True, verbose=False)
+        own = {q["name"]: q["rel"] for q in own}
+        bad = [(q["name"], q["rel"], own[q["name"]]) for q in report if not q["rel"] <= max(SQRT_EPS32, 2.0 * own[q["name"]])]
+        print({q["name"]: (round(q["rel"], 6), round(own[q["name"]], 6)) for q in report if q["rel"] > SQRT_EPS32})
+        assert not bad, bad
+    names = [q["name"] for q in report]
+    for n in ("e", "Gn.e", "kappa_u", "kappa_c", "kappa_e", "Le", "Jb"):
+        assert n in names
+    e = r.tracers.e.interior
+    assert e[:, :, -1].max() > 1e-6 and np.isfinite(e).all()
+
+
+def test_catke_is_refused_where_it_is_not_built():
+    with pytest.raises(GB25Error, match="single lat-lon domain"):
+        gb.baroclinic_instability_model(gb.GPU(), 72, 36, 8, dt=60.0, grid_type="gaussian_islands", closure=CATKE())
+    m = gb.baroclinic_instability_model(gb.GPU(), 32, 16, 8, dt=60.0)
+    with pytest.raises(GB25Error):                                # closure = nothing: no TKE tracer
+        m.backend.get_field("e", False)
+
+
+def test_catke_schedules_agree():
+    outs = []
+    for opts in (dict(), dict(two_streams=0), dict(ab2_lookahead=0)):
+        m = gb.baroclinic_instability_model(gb.GPU(), 40, 44, 24, dt=120.0, depth=200.0, closure=CATKE(), options=opts)
+        v = m
+        start(m, v, wind=-1e-4)
+        gb.first_time_step(m)
+        gb.loop(m, 10)
+        outs.append({n: m.backend.get_field(n, False) for n in ("u", "T", "e", "kappa_c", "eta")})
+        m.backend.close()
+    for o in outs[1:]:
+        for n, a in outs[0].items():
+            assert rel(a, o[n]) < 2e-6, (n, rel(a, o[n]))
