@@ -115,9 +115,10 @@ def main():
     ap.add_argument("--grid-type", default="simple_lat_lon",
                     help="single GPU: gaussian_islands_lat_lon | tripolar | gaussian_islands (the reference's TripolarGrid + "
                          "GridFittedBottom); the headline line is the default, simple_lat_lon")
-    ap.add_argument("--closure", default=None, metavar="NU,KAPPA",
+    ap.add_argument("--closure", default=None, metavar="NU,KAPPA|catke",
                     help="VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu), e.g. 1e-4,1e-5 "
-                         "(src/baroclinic_instability_model.jl:31); the headline line is closure = nothing")
+                         "(src/baroclinic_instability_model.jl:31), or catke = CATKEVerticalDiffusivity() (:30, single GPU); "
+                         "the headline line is closure = nothing")
     ap.add_argument("--burn", type=int, default=0,
                     help="single GPU: run this many steps of a throw-away model first (GPU clocks at load before the timed model starts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,11 +163,14 @@ def main():
               "gaussian_islands": 4}[args.grid_type]
         model = SlabModel(gNx, Ny, Nz, dt=args.dt, rank=rank, nranks=world, device=local_rank,
                           **(dict(grid_type=gt) if gt else {}))
+        if args.closure == "catke":
+            raise SystemExit("--closure catke: single GPU")
         if args.closure:
             model.backend.set_vertical_diffusivity(*map(float, args.closure.split(",")))
         barrier = dist.barrier
     else:
-        closure = gb.VerticalScalarDiffusivity(*map(float, args.closure.split(","))) if args.closure else None
+        closure = (gb.CATKEVerticalDiffusivity() if args.closure == "catke" else
+                   gb.VerticalScalarDiffusivity(*map(float, args.closure.split(","))) if args.closure else None)
         model = gb.baroclinic_instability_model(gb.GPU(local_rank), Nx, Ny, Nz, dt=args.dt, grid_type=args.grid_type,
                                                 closure=closure)
         barrier = lambda: None
@@ -250,7 +254,8 @@ def main():
             "higher_is_better": True, "scaling": "weak" if (args.weak and world > 1) else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"baroclinic_instability_model {gNx}x{Ny}x{Nz} {GRID_NAMES[args.grid_type]}, "
-                                   f"halo 8, SplitExplicit(30), WENO5, TEOS10, dt={args.dt:g}s",
+                                   f"halo 8, SplitExplicit(30), WENO5, TEOS10, dt={args.dt:g}s"
+                                   + (f", closure {args.closure}" if args.closure else ""),
                        "grid": [gNx, Ny, Nz], "cells_per_gpu": cells, "local_columns": locNx,
                        "parallelism": (f"x-slab x{world}, RCCL send/recv inside the library"
                                        if world > 1 else "single GPU"),

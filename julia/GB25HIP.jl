@@ -16,7 +16,7 @@ export Config, Model, create, destroy!, first_time_step!, time_step!, loop!, ini
        fill_halo_regions!, compute_auxiliaries!, compute_tendencies!, ab2_step!, mask_immersed_fields!,
        correct_velocities_and_cache_previous_tendencies!, set_baroclinic_instability!, synchronize,
        parent_array, interior_array, set_parent!, set_interior!, clock, set_dt!, set_option!, get_option,
-       comm_unique_id, comm_init_rccl!, comm_finalize!, set_top_flux!, set_bottom_height!, set_vertical_diffusivity!, metric2, FIELD, OPTION, METRIC2
+       comm_unique_id, comm_init_rccl!, comm_finalize!, set_top_flux!, set_bottom_height!, set_vertical_diffusivity!, set_closure_catke!, metric2, FIELD, OPTION, METRIC2
 
 # One library per Oceananigans float type (src/arg_parsing.jl:12-16): Float32 -> libgb25hip.so, Float64 ->
 # libgb25hip_f64.so; same symbols, gb25_real_bytes() tells them apart.
@@ -26,11 +26,13 @@ const LIBS = Dict(Float32 => get(ENV, "GB25HIP_LIB", "libgb25hip.so"),
 # gb25_field (include/gb25.h)
 const FIELD = (u = 0, v = 1, w = 2, T = 3, S = 4, pHY = 5,
                Gn_u = 6, Gn_v = 7, Gn_T = 8, Gn_S = 9, Gm_u = 10, Gm_v = 11, Gm_T = 12, Gm_S = 13,
-               eta = 14, U = 15, V = 16, eta_bar = 17, U_bar = 18, V_bar = 19, Gn_U = 20, Gn_V = 21)
+               eta = 14, U = 15, V = 16, eta_bar = 17, U_bar = 18, V_bar = 19, Gn_U = 20, Gn_V = 21,
+               # closure = CATKEVerticalDiffusivity() (exist after set_closure_catke!)
+               e = 22, Gn_e = 23, Gm_e = 24, κu = 25, κc = 26, κe = 27, Le = 28, Jb = 29)
 # gb25_option
 const OPTION = (kernels = 0, ab2_lookahead = 1, subcycle_lookahead = 2, subcycle_block = 3, fill_fused = 4,
                 two_streams = 5, store_pressure = 6, split_tendencies = 7, pressure_precision = 8,
-                immersed_kernels = 9, fold_fills = 10)
+                immersed_kernels = 9, fold_fills = 10, lazy_corrector = 11, momentum_chunk_levels = 12, tracer_chunk_levels = 13)
 
 # mirror of gb25_config; isbits, passed by reference
 Base.@kwdef mutable struct Config
@@ -155,6 +157,10 @@ end
 set_vertical_diffusivity!(m::Model; ν::Real = 0, κ::Real = 0) =
     check(m, ccall((:gb25_set_vertical_diffusivity, m.lib), Cint, (Ptr{Cvoid}, Float64, Float64), m.ptr, ν, κ),
           "gb25_set_vertical_diffusivity")
+# closure = CATKEVerticalDiffusivity() (src/baroclinic_instability_model.jl:30): tracers = (:T, :S, :e), diffusivity fields
+# κu, κc, κe, Le, Jb; once after creation, before the initial state is set
+set_closure_catke!(m::Model, on::Bool = true) =
+    check(m, ccall((:gb25_set_closure_catke, m.lib), Cint, (Ptr{Cvoid}, Int32), m.ptr, on), "gb25_set_closure_catke")
 # GridFittedBottom(bottom_height): heights at the cell centres of the interior columns, (Nx, Ny)
 set_bottom_height!(m::Model, zb::AbstractMatrix) =
     check(m, ccall((:gb25_set_bottom_height, m.lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), m.ptr, convert(Matrix{Float64}, zb)),

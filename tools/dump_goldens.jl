@@ -62,6 +62,13 @@ function dump_checkpoint(dir, model)
     write_npy(joinpath(dir, "U.npy"), parent(fs.barotropic_velocities.U))
     write_npy(joinpath(dir, "V.npy"), parent(fs.barotropic_velocities.V))
     write_npy(joinpath(dir, "pHY.npy"), parent(model.pressure.pHY′))
+    # closure = CATKEVerticalDiffusivity(): the fields src/correctness.jl:60-67 compares (e, Gn.e, Gm.e are in fields(model))
+    κ = model.diffusivity_fields
+    if κ isa NamedTuple && haskey(κ, :κu)
+        for name in (:κu, :κc, :κe, :Le, :Jᵇ)
+            write_npy(joinpath(dir, "$(name).npy"), parent(getproperty(κ, name)))
+        end
+    end
     open(joinpath(dir, "clock.txt"), "w") do io
         @printf(io, "time %.17g\niteration %d\nlast_dt %.17g\n", model.clock.time, model.clock.iteration, model.clock.last_Δt)
     end
@@ -114,6 +121,9 @@ function run_case(outdir, casename, FT, Nx, Ny, Nz, Δt, baroclinic_state::Bool;
     end
 
     baroclinic_state && GordonBell25.set_baroclinic_instability!(model)
+    if haskey(Oceananigans.fields(model), :e)            # a CATKE case: some TKE to start from, seeded like u, v
+        set!(model, e = 1e-4 .* counter_rng(size(model.tracers.e), 42, 3))
+    end
     ui = 1e-3 .* counter_rng(size(model.velocities.u), 42, 1)
     vi = 1e-3 .* counter_rng(size(model.velocities.v), 42, 2)
     set!(model, u = ui, v = vi)
@@ -149,6 +159,9 @@ function main(args)
         # the closure the reference keeps next to `nothing` (src/baroclinic_instability_model.jl:31); ν, κ large enough to matter
         run_case(outdir, "closure_128x64x8", FT, 128, 64, 8, 1200.0, true;
                  closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), κ = 1e-3, ν = 1e-2))
+        # src/baroclinic_instability_model.jl:30, sharding/less_simple_sharding_problem.jl:84-93
+        run_case(outdir, "catke_128x64x8", FT, 128, 64, 8, 1200.0, true;
+                 closure = Oceananigans.TurbulenceClosures.CATKEVerticalDiffusivity())
     end
 end
 
