@@ -70,7 +70,7 @@ struct Grid {
   // metric tables, pointers are pre-offset so that index 0 is the first interior cell/face
   const real *dxc, *dxf, *azc, *azf, *fcor, *phic;  // by j   (valid j: -H-2 .. Ny+H+2)
   const real *rdxc, *razc, *razf;                   // reciprocals (host-computed in fp64, rounded once)
-  const real *zc, *dzc, *dzf, *rdzc;                // by k   (valid k: -H-2 .. Nz+H+2)
+  const real *zc, *dzc, *dzf, *rdzc, *rdzf;         // by k   (valid k: -H-2 .. Nz+H+2)
   real rdy, rLz;
   // TEOS-10 folded per level: rho'(s,t) = sum_{i+j<=6} eos[k][idx(i,j)] s^i t^j, k = 0..Nz (Nz = mirrored halo level)
   const double* eos;

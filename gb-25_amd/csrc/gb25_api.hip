@@ -144,6 +144,8 @@ struct gb25_model {
   double nu = 0, kappa = 0;
   bool catke = false;                // closure = CATKEVerticalDiffusivity(): the fields GB25_E .. GB25_JB exist
   Field catke_b, catke_scratch;      // N^2 on the faces; the unused half of the two-wide tracer kernel's output
+  bool n2_fresh = false;             // catke_b holds N^2 of the current T, S (written by the pressure kernel)
+  Field catke_gam[2];                // Nz > 64: the elimination factors of the streamed implicit solve
   real* d_implicit[2] = {nullptr, nullptr};   // elimination tables of the implicit solve for (u, v) and (T, S): lo | 1/beta | gamma
   double implicit_key[2][2] = {{0, 0}, {0, 0}};   // the (dt, K) they were built for
   bool slab = false;                 // x halos come from a neighbour (nranks > 1, or the self-ring of slab_mode = 1)
@@ -307,6 +309,7 @@ gb25_status build_grid(gb25_model* m) {
     if ((s = upload_table(m, recip(azc), offj, &g.razc))) return s;
     if ((s = upload_table(m, recip(azf), offj, &g.razf))) return s;
     if ((s = upload_table(m, recip(dzc), offk, &g.rdzc))) return s;
+    if ((s = upload_table(m, recip(dzf), offk, &g.rdzf))) return s;
     g.rdy = (real)(1.0 / (R * dphi * d2r));
     g.rLz = (real)(1.0 / (zint[Nz] - zint[0]));
   }
@@ -877,9 +880,12 @@ gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = IN
     hipLaunchKernelGGL(k_pressure_differences, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, g,
                        m->f[GB25_PHY].d, m->dpx.d, m->dpy.d, n);
     m->phy_stale = false;
+    m->n2_fresh = false;
     LAUNCHCHK();
     return GB25_OK;
   }
+  real* n2 = m->catke ? m->catke_b.d : nullptr;   // CATKE's N^2 comes out of the same buoyancies
+  m->n2_fresh = n2 != nullptr;
   const bool write_p = !may_skip_p || m->phy_pinned;
   m->phy_stale = !write_p;
   if (i_first == INT_MIN) {
@@ -898,12 +904,12 @@ gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = IN
     dim3 gr(tiles_a + tiles_b, (nrow + 3) / 4);
     auto kern = write_p ? k_compute_p<1, true> : k_compute_p<1, false>;
     hipLaunchKernelGGL(kern, gr, b, 0, m->stream, g, Tsrc, Ssrc, m->f[GB25_PHY].d, dpx_out, dpy_out, i_first, i_last,
-                       i_first_b, i_last_b, tiles_a);
+                       i_first_b, i_last_b, tiles_a, n2);
   } else {
     dim3 gr(tiles_a + tiles_b, (nrow + PR * 4 - 1) / (PR * 4));
     auto kern = write_p ? k_compute_p<PR, true> : k_compute_p<PR, false>;
     hipLaunchKernelGGL(kern, gr, b, 0, m->stream, g, Tsrc, Ssrc, m->f[GB25_PHY].d, dpx_out, dpy_out, i_first, i_last,
-                       i_first_b, i_last_b, tiles_a);
+                       i_first_b, i_last_b, tiles_a, n2);
   }
   LAUNCHCHK();
   return GB25_OK;
@@ -1049,7 +1055,7 @@ gb25_status tracers_impl(gb25_model* m) {
   return GB25_OK;
 }
 
-gb25_status catke_implicit_impl(gb25_model* m, int f0, int n, real dt);   // (with CATKE's diffusivity fields: below)
+gb25_status catke_implicit_impl(gb25_model* m, int mode, real dt, real chi = real(0.));   // (with CATKE's diffusivity fields: below)
 // implicit_step! of a pair of fields (kind 0: u, v with nu, the corrector's column integrals rewritten; 1: T, S with kappa)
 gb25_status implicit_tables(gb25_model* m, int kind, double dt, double K) {
   if (m->d_implicit[kind] && m->implicit_key[kind][0] == dt && m->implicit_key[kind][1] == K) return GB25_OK;
@@ -1143,7 +1149,7 @@ gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
     }
     m->colsum_valid = true;
     m->ahead_uv_valid = false;
-    if (m->catke) return catke_implicit_impl(m, 0, 2, dt);
+    if (m->catke) return catke_implicit_impl(m, 0, dt);
     return implicit_vertical_impl(m, 0, dt);
   }
   m->ahead_uv_valid = false;
@@ -1155,20 +1161,12 @@ gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
                      mom_kchunks(m));   // the momentum kernel's chunking (momentum_impl)
   m->colsum_valid = true;
   LAUNCHCHK();
-  if (m->catke) return catke_implicit_impl(m, 0, 2, dt);
+  if (m->catke) return catke_implicit_impl(m, 0, dt);
   return implicit_vertical_impl(m, 0, dt);
 }
-// e <- e + dt (C1 G^n.e - C2 G^-.e), then the implicit solves of T, S, e with CATKE's diffusivity fields
-gb25_status catke_tracers_impl(gb25_model* m, real dt, real chi) {
-  const Grid& g = m->g;
-  const real C1 = real(1.5) + chi, C2 = real(0.5) + chi;
-  const size_t off = (size_t)g.H * g.pl_c;
-  const long n = (long)g.Nz * g.pl_c;
-  hipLaunchKernelGGL(k_ab2_single, dim3((unsigned)std::min<long>((n + 255) / 256, 256 * 16)), dim3(256), 0, m->stream,
-                     m->f[GB25_E].d + off, m->f[GB25_GN_E].d + off, m->f[GB25_GM_E].d + off, n, dt, C1, C2);
-  LAUNCHCHK();
-  return catke_implicit_impl(m, 2, 3, dt);
-}
+// the implicit solves of T, S (one elimination) and e with CATKE's diffusivity fields; e <- e + dt (C1 G^n.e - C2 G^-.e)
+// happens as its column is loaded
+gb25_status catke_tracers_impl(gb25_model* m, real dt, real chi) { return catke_implicit_impl(m, 1, dt, chi); }
 gb25_status ab2_tracers_impl(gb25_model* m, real dt, real chi) {
   const Grid& g = m->g;
   if (m->ahead_valid && dt == m->ahead_dt && chi == m->ahead_chi) {
@@ -1423,8 +1421,9 @@ gb25_status catke_update_impl(gb25_model* m) {
   hipLaunchKernelGGL(kt, dim3(nb), dim3(64, 4), 0, m->stream, ge, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_W].d,
                      m->f[GB25_E].d, m->f[GB25_E].d, m->f[GB25_GN_E].d, m->catke_scratch.d, nbx, kchunks, nb, none, lz);
   dim3 b(64, 4);
-  hipLaunchKernelGGL(k_catke_buoyancy, dim3((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz - 1), b, 0, m->stream, g, m->f[GB25_T].d,
-                     m->f[GB25_S].d, m->catke_b.d);   // (N^2 on the interior faces 1 .. Nz-1)
+  if (!m->n2_fresh)   // (normally the pressure kernel of this state left N^2 behind: compute_p_impl)
+    hipLaunchKernelGGL(k_catke_buoyancy, dim3((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz - 1), b, 0, m->stream, g,
+                       m->f[GB25_T].d, m->f[GB25_S].d, m->catke_b.d);   // (N^2 on the interior faces 1 .. Nz-1)
   hipLaunchKernelGGL(k_catke_surface_flux, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d,
                      m->f[GB25_JB].d);
   hipLaunchKernelGGL(m->immersed ? k_catke_diffusivities<true> : k_catke_diffusivities<false>, grid2(g.Nx, g.Ny, b), b, 0,
@@ -1434,26 +1433,44 @@ gb25_status catke_update_impl(gb25_model* m) {
   LAUNCHCHK();
   return GB25_OK;
 }
-// implicit_step! with CATKE's diffusivity fields: fields [f0, f0 + n) of (u, v, T, S, e)
-gb25_status catke_implicit_impl(gb25_model* m, int f0, int n, real dt) {
+// implicit_step! with CATKE's diffusivity fields.  mode 0: u, v (and the corrector's column integrals); 1: T with S, and
+// e with its AB2 update
+gb25_status catke_implicit_impl(gb25_model* m, int mode, real dt, real chi) {
   const Grid& g = m->g;
-  if (g.Nz > 64) return fail(m, GB25_ERR_INVALID_ARGUMENT, "CATKE's implicit solve keeps a column and its factors in registers: Nz <= 64");
   ImplicitVarFields A{};
   A.f[0] = m->f[GB25_U].d; A.f[1] = m->f[GB25_V].d; A.f[2] = m->f[GB25_T].d; A.f[3] = m->f[GB25_S].d; A.f[4] = m->f[GB25_E].d;
   A.KU = m->f[GB25_KAPPA_U].d; A.KC = m->f[GB25_KAPPA_C].d; A.KE = m->f[GB25_KAPPA_E].d; A.Le = m->f[GB25_LE].d;
-  A.dt = dt; A.f0 = f0;
-  A.sum[0] = f0 == 0 ? m->colsum[0].d : nullptr;
-  A.sum[1] = f0 == 0 ? m->colsum[1].d : nullptr;
+  A.dt = dt;
+  if (mode == 1) {
+    A.GnE = m->f[GB25_GN_E].d; A.GmE = m->f[GB25_GM_E].d;
+    A.C1 = real(1.5) + chi; A.C2 = real(0.5) + chi;
+  }
+  A.sum[0] = mode == 0 ? m->colsum[0].d : nullptr;
+  A.sum[1] = mode == 0 ? m->colsum[1].d : nullptr;
   A.kchunks = mom_kchunks(m);
   const bool imm = m->immersed;
-  void (*kern)(Grid, ImplicitVarFields) =
-      g.Nz <= 32 ? (imm ? k_implicit_vertical_var<32, true> : k_implicit_vertical_var<32, false>)
-      : g.Nz <= 48 ? (imm ? k_implicit_vertical_var<48, true> : k_implicit_vertical_var<48, false>)
-                   : (imm ? k_implicit_vertical_var<64, true> : k_implicit_vertical_var<64, false>);
+  void (*kern)(Grid, ImplicitVarFields);
+#define VARK(NZT) (mode == 0 ? (imm ? k_implicit_vertical_var<NZT, true, 0> : k_implicit_vertical_var<NZT, false, 0>) \
+                             : (imm ? k_implicit_vertical_var<NZT, true, 1> : k_implicit_vertical_var<NZT, false, 1>))
+  constexpr int REG_LEVELS = sizeof(real) == 8 ? 32 : 64;   // three per-thread arrays of that many values fit the VGPRs
+  if (g.Nz <= 32) kern = VARK(32);
+  else if (g.Nz <= 48 && REG_LEVELS >= 48) kern = VARK(48);
+  else if (g.Nz <= 64 && REG_LEVELS >= 64) kern = VARK(64);
+  else {   // deeper columns stream through HBM with the factors in two scratch arrays
+    gb25_status s;
+    for (int q = 0; q < 2; q++) {
+      if (!m->catke_gam[q].d && (s = alloc_field(m, m->catke_gam[q], g.sx, g.sy_v, g.Nz + 2 * g.H))) return s;
+      A.gam[q] = m->catke_gam[q].d;
+    }
+    kern = mode == 0 ? (imm ? k_implicit_vertical_var_stream<true, 0> : k_implicit_vertical_var_stream<false, 0>)
+                     : (imm ? k_implicit_vertical_var_stream<true, 1> : k_implicit_vertical_var_stream<false, 1>);
+  }
+#undef VARK
   dim3 b(64, 4);
-  hipLaunchKernelGGL(kern, dim3((g.Nx + 63) / 64, (g.Ny + 3) / 4, n), b, 0, m->stream, g, A);
+  const int rows = mode == 0 ? v_rows(g) : g.Ny;   // (with the zipper fold v has the fold line too)
+  hipLaunchKernelGGL(kern, dim3((g.Nx + 63) / 64, (rows + 3) / 4, 2), b, 0, m->stream, g, A);
   LAUNCHCHK();
-  if (f0 == 0) m->colsum_valid = true;
+  if (mode == 0) m->colsum_valid = true;
   return GB25_OK;
 }
 
@@ -1848,6 +1865,7 @@ void gb25_destroy(gb25_model* m) {
     if (p) hipFree(p);
   if (m->catke_b.d) hipFree(m->catke_b.d);
   if (m->catke_scratch.d) hipFree(m->catke_scratch.d);
+  for (auto& F : m->catke_gam) if (F.d) hipFree(F.d);
   for (int a = 0; a < 2; a++) {
     for (auto& w : m->wide[a])
       if (w.d) hipFree(w.d);
@@ -1986,7 +2004,10 @@ gb25_status gb25_set_field(gb25_model* m, gb25_field f, const void* host, int in
   if (s == GB25_OK) {
     m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;   // any input of the look-aheads may have changed
     m->complete_fills_needed = 2;
-    if (f == GB25_T || f == GB25_S) s = mirror_tracers(m);
+    if (f == GB25_T || f == GB25_S) {
+      s = mirror_tracers(m);
+      m->n2_fresh = false;
+    }
     if (f == GB25_U || f == GB25_V) s = mirror_velocities(m);
     if (s == GB25_OK && f >= GB25_ETA && f <= GB25_V_BAR) {   // eta, U, V and the filtered state alternate likewise
       Field& P = (f <= GB25_BT_V) ? m->ahead_eta[f - GB25_ETA] : m->ahead_bar[f - GB25_ETA_BAR];
@@ -2091,7 +2112,6 @@ gb25_status gb25_set_closure_catke(gb25_model* m, int32_t on) {
   CHECK_MODEL(m);
   if (on && (m->slab || m->g.cv.on))
     return fail(m, GB25_ERR_INVALID_ARGUMENT, "CATKE runs on a single lat-lon domain (flat bottom or GridFittedBottom) for now");
-  if (on && m->cfg.Nz > 64) return fail(m, GB25_ERR_INVALID_ARGUMENT, "CATKE: Nz <= 64 (its implicit solve is register-resident)");
   if (on && (m->nu != 0 || m->kappa != 0)) return fail(m, GB25_ERR_STATE, "one closure at a time: the vertical diffusivity is set");
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(m->side_stream));
@@ -2106,6 +2126,7 @@ gb25_status gb25_set_closure_catke(gb25_model* m, int32_t on) {
     if ((s = alloc_field(m, m->catke_scratch, sx, sy, nz))) return s;
   }
   m->catke = on != 0;
+  m->n2_fresh = false;
   m->ahead_valid = false;
   m->complete_fills_needed = 2;
   return GB25_OK;

@@ -419,7 +419,9 @@ template <int PR_, bool WRITE_P>
 __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restrict__ T, const real* __restrict__ S,
                                                    real* __restrict__ p, real* __restrict__ dpx,
                                                    real* __restrict__ dpy, int i_first, int i_last, int i_first_b,
-                                                   int i_last_b, int tiles_a) {
+                                                   int i_last_b, int tiles_a, real* __restrict__ n2) {
+  // n2 (CATKE, else null): N^2 = db/dz on the faces between the cells, from the very buoyancies of the integral and
+  // differenced in fp64 like the pressure, stored at the index of the cell above the face (k_catke_buoyancy's layout).
   // an optional second column range [i_first_b, i_last_b] takes the tiles from tiles_a on (both strips of a slab in
   // one launch)
   const int lane = threadIdx.x;
@@ -449,11 +451,13 @@ __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restric
   for (int k = Nz - 1; k >= 0; k--) {
     const double* c = g.eos + 28 * k;
     const double dz = g.dzf_d[k + 1];
+    double dbz[PR_ + 1];
 #pragma unroll
     for (int r = 0; r <= PR_; r++) {
       o[r] -= g.pl_c;
       double bk = gr * teos10_level(c, sqrt(((double)S[o[r]] + 32.0) * sc), (double)T[o[r]] * 0.025);
       pk[r] = pk[r] - 0.5 * (bk + bup[r]) * dz;
+      dbz[r] = (bup[r] - bk) / dz;
       bup[r] = bk;
     }
 #pragma unroll
@@ -464,6 +468,7 @@ __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restric
         if (WRITE_P) p[o[r]] = (real)pk[r];
         dpx[o[r]] = (real)(pk[r] - pw);
         dpy[o[r]] = (real)(pk[r] - pk[r - 1]);
+        if (n2 != nullptr && k < Nz - 1) n2[o[r] + g.pl_c] = (real)dbz[r];
       }
     }
   }
@@ -1036,12 +1041,6 @@ __global__ void k_catke_surface_flux(Grid g, const real* __restrict__ T, const r
 struct CatkeFace {
   real ku, kc, ke, lD, P, wb;
 };
-__device__ __forceinline__ real catke_sigma(const CatkePar& c, int p, real Ri) {
-  if (Ri < real(0.)) return c.Cun[p];
-  real t = (Ri - c.CRi0) / c.CRid;
-  t = t < real(0.) ? real(0.) : (t > real(1.) ? real(1.) : t);
-  return c.Clo[p] + (c.Chi[p] - c.Clo[p]) * t;
-}
 template <bool IMM>
 __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c, const real* __restrict__ u,
                                                              const real* __restrict__ v, const real* __restrict__ e,
@@ -1060,33 +1059,41 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
     if (yn) store_x_images(g, a, o + g.sx, x, xw, xe);
   };
   const real zt = g.zc[Nz - 1] + real(0.5) * g.dzc[Nz - 1];          // surface
-  const real jb = Jb[o2], jbp = jb > c.Jbmin ? jb : c.Jbmin;
-  // N^2 at face k (between cells k-1 and k), zero on the boundary faces and next to the solid
-  auto N2at = [&](int k) -> real {
-    if (k <= kc0 || k >= Nz) return real(0.);
-    return b[ic(g, i, j, k)];
+  const real jb = Jb[o2], jbp = jb > c.Jbmin ? jb : c.Jbmin, rjbp = real(1.) / jbp, rCRid = real(1.) / c.CRid;
+  const bool cooled = jb > c.Jbmin;
+  // A window of three levels travels up the column: what a cell level contributes -- e, u on its two x faces, v on its two
+  // y faces, N^2 on the face below it (zero on the boundary faces and next to the solid) -- is loaded two levels AHEAD of
+  // its use, so the loads of a level are in flight during the arithmetic of the level below (a first version loaded and
+  // used level by level and ran at the latency of 48 dependent round trips).
+  struct Level { real e, uw, ue, vs, vn, n2; };
+  auto load_level = [&](int k, int oc_, int ov_) -> Level {
+    Level L = {real(0.), real(0.), real(0.), real(0.), real(0.), real(0.)};
+    if (k < Nz) {
+      L.e = e[oc_]; L.uw = u[oc_]; L.ue = u[oc_ + 1]; L.vs = v[ov_]; L.vn = v[ov_ + g.sx];
+      if (k > kc0) L.n2 = b[oc_];
+    }
+    return L;
   };
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
   CatkeFace lo = {real(0.), real(0.), real(0.), real(0.), real(0.), real(0.)};
   put(KU, o, real(0.)); put(KC, o, real(0.)); put(KE, o, real(0.));
   real zf_k = g.zc[0] - real(0.5) * g.dzc[0], zbot = zf_k;            // z of face 0; bottom of the column
   for (int q = 0; q < kc0; q++) zbot += g.dzc[q];
-  real N2here = real(0.), N2above = N2at(1);
+  Level cur = load_level(0, o, ov), nxt = load_level(1, o + pc, ov + pv);
   for (int k = 0; k < Nz; k++) {
+    const Level pre = load_level(k + 2, o + 2 * pc, ov + 2 * pv);
+    const real ge = Ge[o];
     // ---- face k+1 (top of cell k)
     zf_k += g.dzc[k];
-    N2here = N2above;
-    N2above = N2at(k + 2);
     CatkeFace hi = {real(0.), real(0.), real(0.), real(0.), real(0.), real(0.)};
     const int kf = k + 1;
     if (kf > kc0 && kf < Nz) {
-      const int of = o + pc, ovf = ov + pv;   // cell kf
-      const real rdz = real(1.) / g.dzf[kf];
-      const real ef = (e[o] + e[of]) / real(2.), ep = ef > real(0.) ? ef : real(0.), ws = sqrt(ep);
-      const real uw = (u[of] - u[o]) * rdz, ue = (u[of + 1] - u[o + 1]) * rdz;
-      const real vs = (v[ovf] - v[ov]) * rdz, vn = (v[ovf + g.sx] - v[ov + g.sx]) * rdz;
+      const real rdz = g.rdzf[kf];
+      const real ef = (cur.e + nxt.e) / real(2.), ep = ef > real(0.) ? ef : real(0.), ws = sqrt(ep);
+      const real uw = (nxt.uw - cur.uw) * rdz, ue = (nxt.ue - cur.ue) * rdz;
+      const real vs = (nxt.vs - cur.vs) * rdz, vn = (nxt.vn - cur.vn) * rdz;
       const real S2 = (uw * uw + ue * ue) / real(2.) + (vs * vs + vn * vn) / real(2.);
-      const real N2 = N2here;
+      const real N2 = nxt.n2, N2above = pre.n2;
       const real Ri = (N2 == real(0.)) ? real(0.) : N2 / S2;
       const real dup = c.Cs * (zt - zf_k), ddn = c.Cb * (zf_k - zbot);
       real ls = dup < ddn ? dup : ddn;
@@ -1094,16 +1101,28 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
         const real lN = ws / sqrt(N2);
         ls = lN < ls ? lN : ls;
       }
-      const bool convecting = jb > c.Jbmin && N2 < real(0.), entraining = jb > c.Jbmin && N2 >= real(0.) && N2above < real(0.);
+      // convective lengths: l^h_psi = C^c_psi w*^3 / J^b+ * max(0, 1 - C^sp sqrt(S^2) w*^2 / J^b+) where the column loses
+      // buoyancy and N^2 < 0; l^e_psi = C^e_psi J^b+ / (w* N^2 + J^b_min) in the stable level just below such a layer.
+      // The factor common to the four psi is formed once (and only in columns with J^b > J^b_min at all).
+      real conv_scale = real(0.);
+      bool entraining = false;
+      if (cooled) {
+        if (N2 < real(0.)) {
+          const real esp = real(1.) - c.Csp * sqrt(S2) * ws * ws * rjbp;
+          conv_scale = ws * ws * ws * rjbp * (esp > real(0.) ? esp : real(0.));
+        } else if (N2above < real(0.)) {
+          entraining = true;
+          conv_scale = jbp / (ws * N2 + c.Jbmin);
+        }
+      }
+      // stability functions: one step function of Ri for the four psi
+      real tstep = (Ri - c.CRi0) * rCRid;
+      tstep = tstep < real(0.) ? real(0.) : (tstep > real(1.) ? real(1.) : tstep);
       real lpsi[4];
 #pragma unroll
       for (int p = 0; p < 4; p++) {
-        real lh = c.Cc[p] * ws * ws * ws / jbp;
-        const real esp = real(1.) - c.Csp * sqrt(S2) * ws * ws / jbp;
-        lh *= esp > real(0.) ? esp : real(0.);
-        const real le = c.Ce[p] * jbp / (ws * N2 + c.Jbmin);
-        const real lconv = convecting ? lh : (entraining ? le : real(0.));
-        const real sg = catke_sigma(c, p, Ri);
+        const real lconv = (entraining ? c.Ce[p] : c.Cc[p]) * conv_scale;
+        const real sg = Ri < real(0.) ? c.Cun[p] : c.Clo[p] + (c.Chi[p] - c.Clo[p]) * tstep;
         const real lst = p < 3 ? sg * ls : ls / sg;
         lpsi[p] = lconv > lst ? lconv : lst;
       }
@@ -1115,7 +1134,7 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
     // ---- cell k
     real L = real(0.);
     if (k >= kc0) {
-      const real ek = e[o], lD = (lo.lD + hi.lD) / real(2.), wb = (lo.wb + hi.wb) / real(2.);
+      const real ek = cur.e, lD = (lo.lD + hi.lD) / real(2.), wb = (lo.wb + hi.wb) / real(2.);
       const real omega = lD > real(0.) ? sqrt(rabs(ek)) / lD : real(0.);
       const real wbm = wb < real(0.) ? wb : real(0.);
       L = -omega + (ek > c.emin ? wbm / ek : real(0.)) - (ek < real(0.) ? real(1.) / c.tau_neg : real(0.));
@@ -1127,102 +1146,210 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
         const real wD3 = (jb > real(0.) ? jb : real(0.)) * g.dzc[k];
         src += (c.CWu * us3 + c.CWw * wD3) / g.dzc[k];
       }
-      Ge[o] = Ge[o] + src;
+      Ge[o] = ge + src;
     }
     put(Le, o, L);
     if (k == 0) store_x_images(g, Le, o - pc, L, xw, xe);        // bottom / top layer (interior rows only, like the fill)
     if (k == Nz - 1) store_x_images(g, Le, o + pc, L, xw, xe);
     lo = hi;
+    cur = nxt;
+    nxt = pre;
     o += pc;
     ov += pv;
   }
 }
-// e <- e + dt (C1 G^n - C2 G^-): ab2_step_field! of the one tracer the packed kernels do not carry
-__global__ void k_ab2_single(real* __restrict__ e, const real* __restrict__ Gn, const real* __restrict__ Gm, long n, real dt,
-                             real C1, real C2) {
-  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (; t < n; t += stride) e[t] = ab2_advance(e[t], Gn[t], Gm[t], dt, C1, C2);
-}
-// The tridiagonal solve with diffusivity FIELDS: per-thread elimination (the factors depend on the column), the column and
-// its factors in registers (Nz <= NZT).  blockIdx.z = field: 0 u (kappa_u averaged in x), 1 v (in y), 2 T, 3 S (kappa_c),
-// 4 e (kappa_e, with the implicit linear term L^e on the diagonal).
+// The tridiagonal solve with diffusivity FIELDS (implicit_step! with CATKE's kappa_u, kappa_c, kappa_e, L^e).  The
+// elimination factors depend on the column, so each thread eliminates its own.  Two launches per step:
+//   MODE 0 (after the AB2 update of u, v): blockIdx.z = 0 u (kappa_u averaged in x), 1 v (averaged in y; with the zipper
+//          fold also the fold line); the column integrals of the new u, v are rewritten for the barotropic corrector;
+//   MODE 1 (after that of T, S):           blockIdx.z = 0 T AND S in one thread -- they share kappa_c, hence the factors:
+//          one elimination, two right-hand sides; 1 e with kappa_e and -dt L^e on the diagonal, its AB2 update
+//          e* = e + dt (C1 G^n.e - C2 G^-.e) formed as the column is loaded (no separate sweep over e).
+// Register kernel (Nz <= NZT <= 64): three per-thread arrays -- a column, a second column (S, or dt L^e), and the
+// diffusivities dt kappa(face k+1), ALL loaded before the elimination starts (the loads of a wave are in flight together;
+// a first version fetched kappa inside the dependent chain and ran at a quarter of the bandwidth) and overwritten by the
+// factors gamma_k as the chain passes.  Per level one reciprocal of the pivot (the 1-ulp v_rcp_f32 in Float32, as the
+// constant-coefficient kernels) and a dozen multiply-adds: with true divisions the kernel was bound by VALU issue.
 struct ImplicitVarFields {
-  real* f[5];
+  real* f[5];                  // u, v, T, S, e
   const real *KU, *KC, *KE, *Le;
-  real dt;
-  int f0;            // first field of this launch (u, v on the main stream; T, S, e on the side stream)
-  real* sum[2];      // column integrals of the new u, v (the corrector's; the look-ahead's predate the solve)
+  const real *GnE, *GmE;       // null: e already holds e*
+  real dt, C1, C2;
+  real* sum[2];                // column integrals of the new u, v (the look-ahead's predate the solve)
   int kchunks;
+  real* gam[2];                // streaming kernel only: the factors of the two blockIdx.z slices ((c,f,c)-shaped scratch)
 };
-template <int NZT, bool IMM>
-__global__ __launch_bounds__(256) void k_implicit_vertical_var(Grid g, ImplicitVarFields A) {
-  const int f = blockIdx.z + A.f0, Nz = g.Nz;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
-  const bool vsh = f == 1;
-  if (i >= g.Nx || j >= g.Ny) return;
-  const int o2 = i2(g, i, j);
+template <bool IMM, int MODE>
+__device__ __forceinline__ int implicit_var_first_level(const Grid& g, int z, int o2, int j) {
   int kf = 0;
   if (IMM) {
-    const unsigned w = f >= 2 ? g.im.ordA[o2] : g.im.ordC[o2] >> (f == 0 ? 8 : 16);
-    kf = min((int)(w & 255), Nz);
+    const unsigned w = MODE == 1 ? g.im.ordA[o2] : g.im.ordC[o2] >> (z == 0 ? 8 : 16);
+    kf = min((int)(w & 255), g.Nz);
   }
-  if (vsh && j == 0) kf = Nz;   // (the wall face: nothing to solve, its column integral is zero)
-  real* F = A.f[f];
+  if (MODE == 0 && z == 1 && j == 0) kf = g.Nz;   // (the wall face: nothing to solve, its column integral is zero)
+  return kf;
+}
+// column integral of u / v with the chunked association every other producer of these sums uses
+template <class Get>
+__device__ __forceinline__ real implicit_var_colsum(const Grid& g, int kchunks, Get x) {
+  const int Nz = g.Nz, klen = (Nz + kchunks - 1) / kchunks;
+  real tot = real(0.), q = real(0.);
+  int kk = 0;
+  for (int k = 0; k < Nz; k++) {
+    q = (kk == 0) ? g.dzc[k] * x(k) : rfma(g.dzc[k], x(k), q);
+    if (++kk == klen || k == Nz - 1) {
+      tot = (k < klen) ? q : tot + q;
+      kk = 0;
+    }
+  }
+  return tot;
+}
+template <int NZT, bool IMM, int MODE>
+__global__ __launch_bounds__(256) void k_implicit_vertical_var(Grid g, ImplicitVarFields A) {
+  const int z = blockIdx.z, Nz = g.Nz;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  const bool vsh = MODE == 0 && z == 1, pair = MODE == 1 && z == 0, tke = MODE == 1 && z == 1;
+  if (i >= g.Nx || j >= (vsh ? g.Ny + g.cv.north_fold : g.Ny)) return;
+  const int o2 = i2(g, i, j), kf = implicit_var_first_level<IMM, MODE>(g, z, o2, j);
+  real* Fa = MODE == 0 ? A.f[z] : (pair ? A.f[2] : A.f[4]);
+  real* Fb = A.f[3];
+  const real* K = MODE == 0 ? A.KU : (pair ? A.KC : A.KE);
   const int pl = vsh ? g.pl_v : g.pl_c, o0 = vsh ? iv(g, i, j, 0) : ic(g, i, j, 0), oc = ic(g, i, j, 0), pc = g.pl_c;
-  const real* K = f < 2 ? A.KU : (f < 4 ? A.KC : A.KE);
-  const int nb = f == 0 ? -1 : (f == 1 ? -g.sx : 0);     // the second column kappa_u is averaged with
-  real x[NZT], gam[NZT];
+  const int nb = MODE == 0 ? (z == 0 ? -1 : -g.sx) : 0;   // the second column kappa_u is averaged with
+  real a[NZT], b[NZT], gm[NZT];
+  const bool ab2 = tke && A.GnE != nullptr;
+  // ---- loads only, no arithmetic between them: every load of the column is in flight before the first wait
+  if (MODE == 1 && ab2) {   // e* = e + dt (C1 G^n.e - C2 G^-.e) first (three arrays in, one out), then L^e and kappa_e
 #pragma unroll
-  for (int k = 0; k < NZT; k++) x[k] = (k < Nz) ? F[o0 + k * pl] : real(0.);
-  real bet = real(1.), p = real(0.), kup = real(0.);     // kup: dt kappa at the top face of the level below
+    for (int k = 0; k < NZT; k++)
+      if (k < Nz) {
+        a[k] = Fa[o0 + k * pl];
+        b[k] = A.GnE[o0 + k * pl];
+        gm[k] = A.GmE[o0 + k * pl];
+      }
+#pragma unroll
+    for (int k = 0; k < NZT; k++)
+      if (k < Nz) a[k] = ab2_advance(a[k], b[k], gm[k], A.dt, A.C1, A.C2);
+  }
+#pragma unroll
+  for (int k = 0; k < NZT; k++) {
+    if (!(MODE == 1 && ab2)) a[k] = (k < Nz) ? Fa[o0 + k * pl] : real(0.);
+    const int of = oc + (k + 1) * pc;                      // the top face of level k
+    gm[k] = (k < Nz - 1) ? K[of] : real(0.);
+    if (MODE == 0) b[k] = (k < Nz - 1) ? K[of + nb] : real(0.);
+    else b[k] = (k < Nz) ? (pair ? Fb[o0 + k * pl] : A.Le[o0 + k * pl]) : real(0.);
+  }
+  real rbet = real(1.), pa = real(0.), pb = real(0.), kup = real(0.);   // rbet: reciprocal of the last pivot
 #pragma unroll
   for (int k = 0; k < NZT; k++)
     if (k < Nz && k >= kf) {
-      // faces k (bottom) and k+1 (top) of this level
-      real ktop = real(0.);
-      if (k < Nz - 1) {
-        const int of = oc + (k + 1) * pc;
-        ktop = A.dt * (f < 2 ? (K[of + nb] + K[of]) / real(2.) : K[of]);
-      }
-      const real rc = real(1.) / g.dzc[k];
-      const real lo = (k == kf) ? real(0.) : -(kup * rc) / g.dzf[k];
-      const real up = (k == Nz - 1) ? real(0.) : -(ktop * rc) / g.dzf[k + 1];
+      const real ktop = A.dt * (MODE == 0 ? (b[k] + gm[k]) / real(2.) : gm[k]);   // dt kappa at the top face of level k
+      const real t = (k == kf) ? real(0.) : -(kup * g.rdzf[k]);    // coupling through face k, without the cell height
+      const real lo = t * g.rdzc[k];
+      const real up = -(ktop * g.rdzc[k]) * g.rdzf[k + 1];         // (ktop = 0 at the top level)
       real dg = real(1.) - lo - up;
-      if (f == 4) dg -= A.dt * A.Le[oc + k * pc];
-      if (k == kf) {
-        bet = dg;
-        p = x[k] / bet;
-        gam[k] = real(0.);
-      } else {
-        const real upb = -(kup / g.dzc[k - 1]) / g.dzf[k];   // upper coefficient of the level below
-        gam[k] = upb / bet;
-        bet = dg - lo * gam[k];
-        p = (x[k] - lo * p) / bet;
+      if (MODE == 1 && tke) dg -= A.dt * b[k];
+      const real gk = (t * g.rdzc[k - 1]) * rbet;                   // upper coefficient of the level below / its pivot
+      rbet = rcp(dg - lo * gk);                                     // (k = kf: t = lo = gk = 0)
+      pa = (a[k] - lo * pa) * rbet;
+      a[k] = pa;
+      if (MODE == 1 && pair) {
+        pb = (b[k] - lo * pb) * rbet;
+        b[k] = pb;
       }
-      x[k] = p;
+      gm[k] = gk;
       kup = ktop;
     }
 #pragma unroll
   for (int k = NZT - 2; k >= 0; k--)
-    if (k < Nz - 1 && k >= kf) x[k] = x[k] - gam[k + 1] * x[k + 1];
-#pragma unroll
-  for (int k = 0; k < NZT; k++)
-    if (k < Nz && k >= kf) F[o0 + k * pl] = x[k];
-  if (f < 2 && A.sum[f] != nullptr) {   // chunked like every other producer of these sums
+    if (k < Nz - 1 && k >= kf) {
+      a[k] = a[k] - gm[k + 1] * a[k + 1];
+      if (MODE == 1 && pair) b[k] = b[k] - gm[k + 1] * b[k + 1];
+    }
+  real tot = real(0.);
+  if (MODE == 0 && A.sum[z] != nullptr) {   // (before the stores: the table loads below must not wait behind them)
     const int klen = (Nz + A.kchunks - 1) / A.kchunks;
-    real tot = real(0.), q = real(0.);
+    real q = real(0.);
     int kk = 0;
 #pragma unroll
     for (int k = 0; k < NZT; k++)
       if (k < Nz) {
-        q = (kk == 0) ? g.dzc[k] * x[k] : rfma(g.dzc[k], x[k], q);
+        q = (kk == 0) ? g.dzc[k] * a[k] : rfma(g.dzc[k], a[k], q);
         if (++kk == klen || k == Nz - 1) {
           tot = (k < klen) ? q : tot + q;
           kk = 0;
         }
       }
-    A.sum[f][o2] = (vsh && j == 0) ? real(0.) : tot;
+  }
+#pragma unroll
+  for (int k = 0; k < NZT; k++)
+    if (k < Nz && (k >= kf || ab2)) {
+      Fa[o0 + k * pl] = a[k];
+      if (MODE == 1 && pair) Fb[o0 + k * pl] = b[k];
+    }
+  if (MODE == 0 && A.sum[z] != nullptr) A.sum[z][o2] = (vsh && j == 0) ? real(0.) : tot;
+}
+// Any Nz (the register kernel stops at 64 levels): the same elimination streamed through HBM.  Forward sweep: the
+// eliminated right-hand side goes back into the field, the factors into a scratch array; backward sweep reads both.
+// 7 instead of 3 accesses per cell and field, ~30 registers, loads independent of the chain (unrolled by 4).
+template <bool IMM, int MODE>
+__global__ __launch_bounds__(256) void k_implicit_vertical_var_stream(Grid g, ImplicitVarFields A) {
+  const int z = blockIdx.z, Nz = g.Nz;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  const bool vsh = MODE == 0 && z == 1, pair = MODE == 1 && z == 0, tke = MODE == 1 && z == 1;
+  if (i >= g.Nx || j >= (vsh ? g.Ny + g.cv.north_fold : g.Ny)) return;
+  const int o2 = i2(g, i, j), kf = implicit_var_first_level<IMM, MODE>(g, z, o2, j);
+  real* Fa = MODE == 0 ? A.f[z] : (pair ? A.f[2] : A.f[4]);
+  real* Fb = A.f[3];
+  real* G = A.gam[z];
+  const real* K = MODE == 0 ? A.KU : (pair ? A.KC : A.KE);
+  const int pl = vsh ? g.pl_v : g.pl_c, o0 = vsh ? iv(g, i, j, 0) : ic(g, i, j, 0), oc = ic(g, i, j, 0), pc = g.pl_c;
+  const int og = iv(g, i, j, 0), pg = g.pl_v;              // the scratch array has the larger of the two shapes
+  const int nb = MODE == 0 ? (z == 0 ? -1 : -g.sx) : 0;
+  const bool ab2 = tke && A.GnE != nullptr;
+  if (ab2)
+    for (int k = 0; k < kf; k++)
+      Fa[o0 + k * pl] = ab2_advance(Fa[o0 + k * pl], A.GnE[o0 + k * pl], A.GmE[o0 + k * pl], A.dt, A.C1, A.C2);
+  real rbet = real(1.), pa = real(0.), pb = real(0.), kup = real(0.);
+#pragma unroll 4
+  for (int k = kf; k < Nz; k++) {
+    real xa = Fa[o0 + k * pl], xb = real(0.), le = real(0.);
+    if (MODE == 1 && pair) xb = Fb[o0 + k * pl];
+    if (MODE == 1 && tke) le = A.dt * A.Le[o0 + k * pl];
+    if (MODE == 1 && ab2) xa = ab2_advance(xa, A.GnE[o0 + k * pl], A.GmE[o0 + k * pl], A.dt, A.C1, A.C2);
+    real ktop = real(0.);
+    if (k < Nz - 1) {
+      const int of = oc + (k + 1) * pc;
+      ktop = A.dt * (MODE == 0 ? (K[of + nb] + K[of]) / real(2.) : K[of]);
+    }
+    const real t = (k == kf) ? real(0.) : -(kup * g.rdzf[k]);
+    const real lo = t * g.rdzc[k];
+    const real up = -(ktop * g.rdzc[k]) * g.rdzf[k + 1];
+    const real dg = real(1.) - lo - up - le;
+    const real gk = (t * g.rdzc[k - 1]) * rbet;
+    rbet = rcp(dg - lo * gk);
+    pa = (xa - lo * pa) * rbet;
+    Fa[o0 + k * pl] = pa;
+    if (MODE == 1 && pair) {
+      pb = (xb - lo * pb) * rbet;
+      Fb[o0 + k * pl] = pb;
+    }
+    G[og + k * pg] = gk;
+    kup = ktop;
+  }
+#pragma unroll 4
+  for (int k = Nz - 2; k >= kf; k--) {
+    const real gk = G[og + (k + 1) * pg];
+    pa = Fa[o0 + k * pl] - gk * pa;
+    Fa[o0 + k * pl] = pa;
+    if (MODE == 1 && pair) {
+      pb = Fb[o0 + k * pl] - gk * pb;
+      Fb[o0 + k * pl] = pb;
+    }
+  }
+  if (MODE == 0 && A.sum[z] != nullptr) {
+    const real tot = implicit_var_colsum(g, A.kchunks, [&](int k) { return Fa[o0 + k * pl]; });
+    A.sum[z][o2] = (vsh && j == 0) ? real(0.) : tot;
   }
 }
 

@@ -52,7 +52,7 @@ def test_diffusivity_fields_match_the_oracle(float_type, tol):
 
 
 @pytest.mark.parametrize("float_type", ["Float64", "Float32"])
-@pytest.mark.parametrize("case", ["wind", "cooling", "islands"])
+@pytest.mark.parametrize("case", ["wind", "cooling", "islands", "deep"])
 def test_stepping_with_catke_matches_the_oracle(case, float_type):
     """first_time_step! + 30 steps.  The Float64 build is the logic check (every compared field, halos included, to
     1e-7: the switches of the mixing lengths -- min / max / step of Ri -- amplify round-off a little).  Float32 against
@@ -61,7 +61,8 @@ def test_stepping_with_catke_matches_the_oracle(case, float_type):
     -- there the yardstick is the Float32 ORACLE's own distance from the Float64 one (as close to a
     Float32 reference run as that run is to the truth)."""
     kw = dict(grid_type="gaussian_islands_lat_lon") if case == "islands" else {}
-    size = (90, 44, 16) if case == "islands" else (40, 44, 24)
+    # deep: 72 levels -- past the register-resident implicit solve (64 levels in Float32, 32 in Float64): the streamed one
+    size = (90, 44, 16) if case == "islands" else (40, 44, 72) if case == "deep" else (40, 44, 24)
     r, v = make_pair(*size, dt=120.0, float_type=float_type, depth=200.0 if case != "islands" else 4000.0, closure=CATKE(), **kw)
     start(r, v, wind=-1e-4 if case != "cooling" else None, heat=1e-4 if case == "cooling" else None)
     for m in (r, v):
@@ -69,7 +70,8 @@ def test_stepping_with_catke_matches_the_oracle(case, float_type):
         gb.loop(m, 30)
     ok, report = gb.compare_states(r, v, rtol=SQRT_EPS32, include_halos=True, verbose=False)
     if float_type == "Float64":
-        bad = [(q["name"], q["rel"]) for q in report if not q["rel"] <= 1e-7]
+        # (deep: 72 levels over 200 m -- the differences of S across a cell are 4e-5 of S, its tendency loses those digits)
+        bad = [(q["name"], q["rel"]) for q in report if not q["rel"] <= (5e-7 if case == "deep" else 1e-7)]
         assert not bad, bad
     else:
         # what a Float32 run of the reference itself is away from the Float64 truth: the oracle in Float32
