@@ -1415,7 +1415,9 @@ gb25_status catke_update_impl(gb25_model* m) {
   constexpr int TW = sizeof(real) == 8 ? 3 : 5;
   Ab2Ahead none{};
   const LazyCorr lz{nullptr, nullptr};
-  auto kt = m->immersed ? k_tracer_tendencies_v5<TW, false, true, false> : k_tracer_tendencies_v5<TW, false, false, false>;
+  auto kt = g.cv.on       ? k_tracer_tendencies_v5<TW, false, true, false, true>
+            : m->immersed ? k_tracer_tendencies_v5<TW, false, true, false>
+                          : k_tracer_tendencies_v5<TW, false, false, false>;
   Grid ge = g;                                   // (the top fluxes of T, S are not e's: its surface flux comes below)
   ge.top_flux[2] = ge.top_flux[3] = nullptr;
   hipLaunchKernelGGL(kt, dim3(nb), dim3(64, 4), 0, m->stream, ge, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_W].d,
@@ -1430,6 +1432,9 @@ gb25_status catke_update_impl(gb25_model* m) {
                      m->stream, g, catke_parameters(), m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_E].d, m->catke_b.d,
                      m->f[GB25_JB].d, m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d,
                      m->f[GB25_GN_E].d);
+  if (g.cv.north_fold && !m->slab)   // the rows beyond the zipper (a slab's come from its fold partner: slab_step.hpp)
+    hipLaunchKernelGGL(k_catke_fold, dim3((g.sx + 255) / 256, g.H, g.Nz + 3), dim3(256), 0, m->stream, g,
+                       m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_JB].d);
   LAUNCHCHK();
   return GB25_OK;
 }
@@ -2110,8 +2115,8 @@ gb25_status gb25_set_vertical_diffusivity(gb25_model* m, double nu, double kappa
 }
 gb25_status gb25_set_closure_catke(gb25_model* m, int32_t on) {
   CHECK_MODEL(m);
-  if (on && (m->slab || m->g.cv.on))
-    return fail(m, GB25_ERR_INVALID_ARGUMENT, "CATKE runs on a single lat-lon domain (flat bottom or GridFittedBottom) for now");
+  if (on && m->slab)
+    return fail(m, GB25_ERR_INVALID_ARGUMENT, "CATKE runs on a single domain (any grid type) for now, not on a slab of a decomposition");
   if (on && (m->nu != 0 || m->kappa != 0)) return fail(m, GB25_ERR_STATE, "one closure at a time: the vertical diffusivity is set");
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(m->side_stream));

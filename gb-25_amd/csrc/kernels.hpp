@@ -1158,6 +1158,26 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
     ov += pv;
   }
 }
+// TripolarGrid: the rows beyond the zipper fold of the diffusivity fields and of J^b (cell-centred in x and y, no sign
+// change): (i, Ny-1+q) <- (Nx-1-i, Ny-q), q = 1 .. H, over every parent column (source column wrapped periodically), which
+// replaces the zero-gradient northern layer k_catke_diffusivities wrote.  blockIdx.z: face levels 0 .. Nz of the three
+// kappa, levels -1 .. Nz of L^e (its bottom / top layer on those rows), then J^b.
+__global__ void k_catke_fold(Grid g, real* __restrict__ KU, real* __restrict__ KC, real* __restrict__ KE,
+                             real* __restrict__ Le, real* __restrict__ Jb) {
+  const int ip = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ip >= g.sx) return;
+  const int i = ip - g.H, q = blockIdx.y + 1, z = blockIdx.z, Nz = g.Nz;
+  const int isrc = (((g.Nx - 1 - i) % g.Nx) + g.Nx) % g.Nx;
+  const int jd = g.Ny - 1 + q, js = g.Ny - q;
+  if (z <= Nz) {
+    const int od = ic(g, i, jd, z), os = ic(g, isrc, js, z);
+    KU[od] = KU[os];
+    KC[od] = KC[os];
+    KE[od] = KE[os];
+  }
+  if (z <= Nz + 1) Le[ic(g, i, jd, z - 1)] = Le[ic(g, isrc, js, min(max(z - 1, 0), Nz - 1))];
+  if (z == Nz + 2) Jb[i2(g, i, jd)] = Jb[i2(g, isrc, js)];
+}
 // The tridiagonal solve with diffusivity FIELDS (implicit_step! with CATKE's kappa_u, kappa_c, kappa_e, L^e).  The
 // elimination factors depend on the column, so each thread eliminates its own.  Two launches per step:
 //   MODE 0 (after the AB2 update of u, v): blockIdx.z = 0 u (kappa_u averaged in x), 1 v (averaged in y; with the zipper

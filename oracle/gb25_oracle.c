@@ -808,8 +808,8 @@ static inline int fold_i(const model *m, int i, int xface) {
   if (ip > m->Nx) ip -= m->Nx;
   return ip;
 }
-static void fold_rows(model *m, int id, int twod, int is_v, int xface, REAL sgn) {
-  int Nx = m->Nx, Ny = m->Ny, H = m->H, k0 = 1, k1 = twod ? 1 : m->Nz;
+static void fold_rows_levels(model *m, int id, int twod, int is_v, int xface, REAL sgn, int nlev) {
+  int Nx = m->Nx, Ny = m->Ny, H = m->H, k0 = 1, k1 = twod ? 1 : nlev;
   for (int k = k0; k <= k1; k++) {
     REAL *base = twod ? m->f[id].p : m->f[id].p + (long)m->f[id].sx * m->f[id].sy * (k - 1 + H);
 #define AF(i, j) base[((long)(i)-1 + H) + (long)m->f[id].sx * ((long)(j)-1 + H)]
@@ -825,6 +825,9 @@ static void fold_rows(model *m, int id, int twod, int is_v, int xface, REAL sgn)
   }
 }
 /* xface: located on x faces (u, U, G.U); sgn: -1 for vector components */
+static void fold_rows(model *m, int id, int twod, int is_v, int xface, REAL sgn) {
+  fold_rows_levels(m, id, twod, is_v, xface, sgn, m->Nz);
+}
 static void fill_halo_3d(model *m, int id, int is_v, int xface, REAL sgn) {
   int Nx = m->Nx, Ny = m->Ny, Nz = m->Nz;
   for (int k = 1; k <= Nz; k++)
@@ -1316,8 +1319,9 @@ static void catke_compute_diffusivities(model *m) {
     for (int k = 1; k <= Nz + 1; k++)
       for (int i = 1; i <= m->Nx; i++) {
         A3(id, i, 0, k) = A3(id, i, 1, k);
-        A3(id, i, m->Ny + 1, k) = A3(id, i, m->Ny, k);
+        if (!m->north_fold) A3(id, i, m->Ny + 1, k) = A3(id, i, m->Ny, k);
       }
+    if (m->north_fold) fold_rows_levels(m, id, 0, 0, 0, (REAL)1, Nz + 1);   /* the rows beyond the zipper, all Nz+1 faces */
     fill_periodic_x(m, &m->f[id]);
   }
   fill_halo_3d(m, F_LE, 0, 0, 1);

@@ -52,7 +52,7 @@ def test_diffusivity_fields_match_the_oracle(float_type, tol):
 
 
 @pytest.mark.parametrize("float_type", ["Float64", "Float32"])
-@pytest.mark.parametrize("case", ["wind", "cooling", "islands", "deep"])
+@pytest.mark.parametrize("case", ["wind", "cooling", "islands", "deep", "tripolar"])
 def test_stepping_with_catke_matches_the_oracle(case, float_type):
     """first_time_step! + 30 steps.  The Float64 build is the logic check (every compared field, halos included, to
     1e-7: the switches of the mixing lengths -- min / max / step of Ri -- amplify round-off a little).  Float32 against
@@ -60,10 +60,13 @@ def test_stepping_with_catke_matches_the_oracle(case, float_type):
     products of square roots, clipped ratios and switches on quantities near zero (L^e = -sqrt|e|/l_D + wb-/e [e > e_min])
     -- there the yardstick is the Float32 ORACLE's own distance from the Float64 one (as close to a
     Float32 reference run as that run is to the truth)."""
-    kw = dict(grid_type="gaussian_islands_lat_lon") if case == "islands" else {}
+    # tripolar: the reference's grid_type = :gaussian_islands (TripolarGrid + mountains) -- the diffusivity fields cross the
+    # zipper fold (kappa_u is averaged onto the v faces of the fold line)
+    kw = dict(grid_type="gaussian_islands_lat_lon") if case == "islands" else dict(grid_type="gaussian_islands") if case == "tripolar" else {}
+    big = case in ("islands", "tripolar")
     # deep: 72 levels -- past the register-resident implicit solve (64 levels in Float32, 32 in Float64): the streamed one
-    size = (90, 44, 16) if case == "islands" else (40, 44, 72) if case == "deep" else (40, 44, 24)
-    r, v = make_pair(*size, dt=120.0, float_type=float_type, depth=200.0 if case != "islands" else 4000.0, closure=CATKE(), **kw)
+    size = (90, 44, 16) if case == "islands" else (72, 44, 16) if case == "tripolar" else (40, 44, 72) if case == "deep" else (40, 44, 24)
+    r, v = make_pair(*size, dt=120.0, float_type=float_type, depth=4000.0 if big else 200.0, closure=CATKE(), **kw)
     start(r, v, wind=-1e-4 if case != "cooling" else None, heat=1e-4 if case == "cooling" else None)
     for m in (r, v):
         gb.first_time_step(m)
@@ -76,7 +79,7 @@ def test_stepping_with_catke_matches_the_oracle(case, float_type):
     else:
         # what a Float32 run of the reference itself is away from the Float64 truth: the oracle in Float32
         from oracle_backend import CPU
-        w = gb.baroclinic_instability_model(CPU("f32"), *size, dt=120.0, depth=200.0 if case != "islands" else 4000.0,
+        w = gb.baroclinic_instability_model(CPU("f32"), *size, dt=120.0, depth=4000.0 if big else 200.0,
                                             closure=CATKE(), **kw)
         start(w, w, wind=-1e-4 if case != "cooling" else None, heat=1e-4 if case == "cooling" else None)
         gb.first_time_step(w)
@@ -94,8 +97,11 @@ def test_stepping_with_catke_matches_the_oracle(case, float_type):
 
 
 def test_catke_is_refused_where_it_is_not_built():
-    with pytest.raises(GB25Error, match="single lat-lon domain"):
-        gb.baroclinic_instability_model(gb.GPU(), 72, 36, 8, dt=60.0, grid_type="gaussian_islands", closure=CATKE())
+    from gb25_amd.distributed import LocalSlabEnsemble
+    ens = LocalSlabEnsemble(96, 44, 8, 2, dt=60.0)
+    with pytest.raises(GB25Error, match="single domain"):
+        ens.backends[0].set_catke(True)
+    ens.close()
     m = gb.baroclinic_instability_model(gb.GPU(), 32, 16, 8, dt=60.0)
     with pytest.raises(GB25Error):                                # closure = nothing: no TKE tracer
         m.backend.get_field("e", False)
