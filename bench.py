@@ -117,7 +117,7 @@ def main():
                          "GridFittedBottom); the headline line is the default, simple_lat_lon")
     ap.add_argument("--closure", default=None, metavar="NU,KAPPA|catke",
                     help="VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu), e.g. 1e-4,1e-5 "
-                         "(src/baroclinic_instability_model.jl:31), or catke = CATKEVerticalDiffusivity() (:30, single GPU); "
+                         "(src/baroclinic_instability_model.jl:31), or catke = CATKEVerticalDiffusivity() (:30); "
                          "the headline line is closure = nothing")
     ap.add_argument("--burn", type=int, default=0,
                     help="single GPU: run this many steps of a throw-away model first (GPU clocks at load before the timed model starts)")
@@ -164,8 +164,9 @@ def main():
         model = SlabModel(gNx, Ny, Nz, dt=args.dt, rank=rank, nranks=world, device=local_rank,
                           **(dict(grid_type=gt) if gt else {}))
         if args.closure == "catke":
-            raise SystemExit("--closure catke: single GPU")
-        if args.closure:
+            model.backend.set_catke(True)
+            model.enable_catke_fields()
+        elif args.closure:
             model.backend.set_vertical_diffusivity(*map(float, args.closure.split(",")))
         barrier = dist.barrier
     else:

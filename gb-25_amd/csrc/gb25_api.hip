@@ -1406,6 +1406,13 @@ CatkePar catke_parameters() {
   c.CWu = real(3.179); c.CWw = real(0.383); c.emin = real(1e-9); c.Jbmin = real(1e-11); c.tau_neg = real(60.);
   return c;
 }
+// J^b = g (alpha J^T - beta J^S) of the model's own columns from the top fluxes and the surface T, S
+void catke_surface_flux_impl(gb25_model* m) {
+  const Grid& g = m->g;
+  dim3 b(64, 4);
+  hipLaunchKernelGGL(k_catke_surface_flux, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d,
+                     m->f[GB25_JB].d);
+}
 gb25_status catke_update_impl(gb25_model* m) {
   if (!m->catke) return GB25_OK;
   const Grid& g = m->g;
@@ -1426,13 +1433,15 @@ gb25_status catke_update_impl(gb25_model* m) {
   if (!m->n2_fresh)   // (normally the pressure kernel of this state left N^2 behind: compute_p_impl)
     hipLaunchKernelGGL(k_catke_buoyancy, dim3((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz - 1), b, 0, m->stream, g,
                        m->f[GB25_T].d, m->f[GB25_S].d, m->catke_b.d);   // (N^2 on the interior faces 1 .. Nz-1)
-  hipLaunchKernelGGL(k_catke_surface_flux, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d,
-                     m->f[GB25_JB].d);
-  hipLaunchKernelGGL(m->immersed ? k_catke_diffusivities<true> : k_catke_diffusivities<false>, grid2(g.Nx, g.Ny, b), b, 0,
-                     m->stream, g, catke_parameters(), m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_E].d, m->catke_b.d,
-                     m->f[GB25_JB].d, m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d,
-                     m->f[GB25_GN_E].d);
-  if (g.cv.north_fold && !m->slab)   // the rows beyond the zipper (a slab's come from its fold partner: slab_step.hpp)
+  // J^b: on a slab it was made right after the AB2 update of T, S and travelled with the 3-D bundle (slab_step.hpp)
+  if (!m->slab) catke_surface_flux_impl(m);
+  // a slab computes kappa in the one halo column / fold row the implicit solves of u / v read (k_catke_diffusivities)
+  const int i_lo = m->slab ? -1 : 0, j_hi = g.Ny + ((m->slab && g.cv.north_fold) ? 1 : 0);
+  hipLaunchKernelGGL(m->immersed ? k_catke_diffusivities<true> : k_catke_diffusivities<false>,
+                     grid2(g.Nx - i_lo, j_hi, b), b, 0, m->stream, g, catke_parameters(), m->f[GB25_U].d, m->f[GB25_V].d,
+                     m->f[GB25_E].d, m->catke_b.d, m->f[GB25_JB].d, m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d,
+                     m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_GN_E].d, i_lo, j_hi);
+  if (g.cv.north_fold && !m->slab)   // the rows beyond the zipper
     hipLaunchKernelGGL(k_catke_fold, dim3((g.sx + 255) / 256, g.H, g.Nz + 3), dim3(256), 0, m->stream, g,
                        m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_JB].d);
   LAUNCHCHK();
@@ -2115,8 +2124,7 @@ gb25_status gb25_set_vertical_diffusivity(gb25_model* m, double nu, double kappa
 }
 gb25_status gb25_set_closure_catke(gb25_model* m, int32_t on) {
   CHECK_MODEL(m);
-  if (on && m->slab)
-    return fail(m, GB25_ERR_INVALID_ARGUMENT, "CATKE runs on a single domain (any grid type) for now, not on a slab of a decomposition");
+  if (gb25_status s = collective_guard(m, 8, (unsigned)(on != 0), 0.0)) return s;
   if (on && (m->nu != 0 || m->kappa != 0)) return fail(m, GB25_ERR_STATE, "one closure at a time: the vertical diffusivity is set");
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(m->side_stream));
@@ -2403,7 +2411,7 @@ gb25_status gb25_comm_finalize(gb25_model* m) {
 }
 
 static gb25_status need_group(gb25_model* m, const char* what) {
-  if (m->group) return GB25_OK;
+  if (m->group) return group_refresh(m->group);   // (the bundles grow when a closure adds fields)
   return fail(m, GB25_ERR_STATE,
               "%s on a slab of a decomposition needs an exchange context first: gb25_comm_init_rccl (one process per GPU), "
               "gb25_comm_init_local (all slabs in this process) or gb25_comm_init_callback", what);

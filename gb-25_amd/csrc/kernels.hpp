@@ -180,9 +180,9 @@ __global__ void k_fill_fold(Grid g, Halo3 f3, Halo2 f2) {
 // and receives ours.  Buffer layout per field: [level][q][parent column], q = 0 .. H-1 counting rows away from the fold
 // line (cell rows Ny-1-q; y-face rows Ny-q, q = 0 being the fold line itself); 3-D fields first, then the 2-D ones.
 struct FoldFields {
-  real* p[7];
-  int is_v[7], xf[7], neg[7], nz[7];   // nz: interior levels (1: a 2-D field)
-  long off[7];                          // element offset of the field in the exchange buffer
+  real* p[9];
+  int is_v[9], xf[9], neg[9], nz[9];   // nz: interior levels (1: a 2-D field)
+  long off[9];                          // element offset of the field in the exchange buffer
   int n;
 };
 // grid: (ceil(sx/256), H, sum of nz)
@@ -1033,10 +1033,11 @@ __global__ void k_catke_surface_flux(Grid g, const real* __restrict__ T, const r
     const double JT = g.top_flux[2] ? (double)g.top_flux[2][o2] : 0.0, JS = g.top_flux[3] ? (double)g.top_flux[3][o2] : 0.0;
     J = (double)g.g * (-drdT * JT - drdS * JS) / (double)g.rho0;
   }
-  const bool xw = i < g.H, xe = i >= g.Nx - g.H;
+  // (a slab of a decomposition: the x halo columns and the rows beyond a zipper fold arrive with the 3-D bundle)
+  const bool xw = g.x_periodic && i < g.H, xe = g.x_periodic && i >= g.Nx - g.H;
   store_x_images(g, Jb, o2, (real)J, xw, xe);
   if (j == 0) store_x_images(g, Jb, o2 - g.sx, (real)J, xw, xe);
-  if (j == g.Ny - 1) store_x_images(g, Jb, o2 + g.sx, (real)J, xw, xe);
+  if (j == g.Ny - 1 && !(g.cv.north_fold && !g.x_periodic)) store_x_images(g, Jb, o2 + g.sx, (real)J, xw, xe);
 }
 struct CatkeFace {
   real ku, kc, ke, lD, P, wb;
@@ -1047,12 +1048,18 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
                                                              const real* __restrict__ b, const real* __restrict__ Jb,
                                                              real* __restrict__ KU, real* __restrict__ KC,
                                                              real* __restrict__ KE, real* __restrict__ Le,
-                                                             real* __restrict__ Ge) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny) return;
+                                                             real* __restrict__ Ge, int i_lo, int j_hi) {
+  // Columns i_lo .. Nx-1, rows 0 .. j_hi-1.  Single domain: the interior (0, Ny), the halo cells written as images.  A slab
+  // of a decomposition: i_lo = -1 and, with the zipper fold, j_hi = Ny + 1 -- the one halo column / row whose kappa_u the
+  // implicit solves of u (averaged in x) and of v (in y, on the fold line) read is COMPUTED here from the halo columns of
+  // e, u, v, N^2 and J^b (all of them exchanged already), bit for bit what its owner computes, instead of exchanged.
+  const int i = i_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= j_hi) return;
+  const bool own = i >= 0 && j < g.Ny;
   const int Nz = g.Nz, o2 = i2(g, i, j), pc = g.pl_c, pv = g.pl_v;
   const int kc0 = IMM ? min((int)(g.im.ordA[o2] & 255), Nz) : 0;   // first active level of the column
-  const bool xw = i < g.H, xe = i >= g.Nx - g.H, ys = j == 0, yn = j == g.Ny - 1;
+  const bool xw = g.x_periodic && i < g.H, xe = g.x_periodic && i >= g.Nx - g.H;
+  const bool ys = own && j == 0, yn = own && j == g.Ny - 1 && j_hi == g.Ny;
   auto put = [&](real* a, int o, real x) {   // the cell and the halo cells its fill derives from it (a14)
     store_x_images(g, a, o, x, xw, xe);
     if (ys) store_x_images(g, a, o - g.sx, x, xw, xe);
@@ -1082,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
   Level cur = load_level(0, o, ov), nxt = load_level(1, o + pc, ov + pv);
   for (int k = 0; k < Nz; k++) {
     const Level pre = load_level(k + 2, o + 2 * pc, ov + 2 * pv);
-    const real ge = Ge[o];
+    const real ge = own ? Ge[o] : real(0.);
     // ---- face k+1 (top of cell k)
     zf_k += g.dzc[k];
     CatkeFace hi = {real(0.), real(0.), real(0.), real(0.), real(0.), real(0.)};
@@ -1131,26 +1138,29 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
       hi.wb = -hi.kc * N2;
     }
     put(KU, o + pc, hi.ku); put(KC, o + pc, hi.kc); put(KE, o + pc, hi.ke);
-    // ---- cell k
+    // ---- cell k (own columns: the halo ones are there for their kappa only)
     real L = real(0.);
-    if (k >= kc0) {
+    if (own && k >= kc0) {
       const real ek = cur.e, lD = (lo.lD + hi.lD) / real(2.), wb = (lo.wb + hi.wb) / real(2.);
       const real omega = lD > real(0.) ? sqrt(rabs(ek)) / lD : real(0.);
       const real wbm = wb < real(0.) ? wb : real(0.);
       L = -omega + (ek > c.emin ? wbm / ek : real(0.)) - (ek < real(0.) ? real(1.) / c.tau_neg : real(0.));
       real src = (lo.P + hi.P) / real(2.) + (wb > real(0.) ? wb : real(0.));
       if (k == Nz - 1) {   // the surface TKE flux: -(C^W_u* u*^3 + C^W_wD w_D^3), into the top cell
-        const real Ju = g.top_flux[0] ? (g.top_flux[0][o2] + g.top_flux[0][o2 + 1]) / real(2.) : real(0.);
-        const real Jv = g.top_flux[1] ? (g.top_flux[1][o2] + g.top_flux[1][o2 + g.sx]) / real(2.) : real(0.);
+        // (friction velocity from the boundary-condition values AT (i, j), as Oceananigans' friction_velocity takes them)
+        const real Ju = g.top_flux[0] ? g.top_flux[0][o2] : real(0.);
+        const real Jv = g.top_flux[1] ? g.top_flux[1][o2] : real(0.);
         const real us2 = sqrt(Ju * Ju + Jv * Jv), us3 = us2 * sqrt(us2);
         const real wD3 = (jb > real(0.) ? jb : real(0.)) * g.dzc[k];
         src += (c.CWu * us3 + c.CWw * wD3) / g.dzc[k];
       }
       Ge[o] = ge + src;
     }
-    put(Le, o, L);
-    if (k == 0) store_x_images(g, Le, o - pc, L, xw, xe);        // bottom / top layer (interior rows only, like the fill)
-    if (k == Nz - 1) store_x_images(g, Le, o + pc, L, xw, xe);
+    if (own) {
+      put(Le, o, L);
+      if (k == 0) store_x_images(g, Le, o - pc, L, xw, xe);        // bottom / top layer (interior rows only, like the fill)
+      if (k == Nz - 1) store_x_images(g, Le, o + pc, L, xw, xe);
+    }
     lo = hi;
     cur = nxt;
     nxt = pre;
@@ -2055,10 +2065,10 @@ __global__ __launch_bounds__(256) void k_mask_immersed(Grid g, real* __restrict_
 // an exchange group on both sides (blockIdx.y = piece): a group used to be up to ten 5-10 us launches in a row on the
 // critical path of the staged step.  buffer layout per piece: [row][q], q in 0..ncols-1, rows = all parent rows.
 struct ColumnPieces {
-  real* arr[10];      // canonical (or wide) array of the piece
-  real* buf[10];      // its segment of the contiguous exchange buffer of that side
-  int sx[10], i0[10]; // row pitch of arr and first column (parent index) of the packed / unpacked strip
-  long rows[10];
+  real* arr[16];      // canonical (or wide) array of the piece
+  real* buf[16];      // its segment of the contiguous exchange buffer of that side
+  int sx[16], i0[16]; // row pitch of arr and first column (parent index) of the packed / unpacked strip
+  long rows[16];
   int n, ncols;
 };
 template <bool PACK>

@@ -58,7 +58,8 @@ void group_pieces(gb25_model* m, int group, std::vector<Piece>& out, int* ncols)
   if (group == 0 || group == 2 || group == 4) {
     *ncols = H;
     if (group == 0) {
-      for (int id : {GB25_U, GB25_V, GB25_T, GB25_S}) {
+      for (int id : {GB25_U, GB25_V, GB25_T, GB25_S, GB25_E, GB25_JB}) {
+        if (id >= GB25_E && !m->catke) continue;   // CATKE: the TKE tracer, and J^b for kappa in the first halo column
         Field& F = m->f[id];
         out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
       }
@@ -120,7 +121,8 @@ gb25_status pack_unpack(gb25_model* m, int group, real* const buf[2], bool pack)
 }
 
 // ---- zipper fold of a decomposed tripolar grid: the partner rank P-1-r holds the cells beyond this slab's fold line -----
-// buffer set 3: the H rows next to the fold line of u, v, T, S and eta, U, V (all parent columns, interior levels);
+// buffer set 3: the H rows next to the fold line of u, v, T, S (CATKE: e, J^b too) and eta, U, V (all parent columns,
+// interior levels);
 // buffer set 4: five rows of the widened barotropic arrays, once per substep (CurvBaro::img, kernels.hpp)
 FoldFields fold_fields(gb25_model* m) {
   FoldFields F{};
@@ -138,24 +140,33 @@ FoldFields fold_fields(gb25_model* m) {
   add(m->f[GB25_ETA].d, 0, 0, 0, 1);
   add(m->f[GB25_BT_U].d, 0, 1, 1, 1);
   add(m->f[GB25_BT_V].d, 1, 0, 1, 1);
+  if (m->catke) {
+    add(m->f[GB25_E].d, 0, 0, 0, g.Nz);
+    add(m->f[GB25_JB].d, 0, 0, 0, 1);
+  }
   return F;
+}
+int fold_levels(const FoldFields& F, bool with_layers) {   // blockIdx.z extent of k_fold_pack / k_fold_unpack
+  int t = 0;
+  for (int f = 0; f < F.n; f++) t += F.nz[f] == 1 ? 1 : F.nz[f] + (with_layers ? 2 : 0);
+  return t;
 }
 int64_t fold_buffer_elems(gb25_model* m, int b) {
   const Grid& g = m->g;
   if (!g.cv.north_fold) return 1;
-  return b == 3 ? (int64_t)g.H * g.sx * (4 * g.Nz + 3) : (int64_t)5 * (g.Nx + 2 * m->W);
+  return b == 3 ? (int64_t)g.H * g.sx * fold_levels(fold_fields(m), false) : (int64_t)5 * (g.Nx + 2 * m->W);
 }
 gb25_status fold_pack(gb25_model* m, real* buf) {
   const Grid& g = m->g;
   FoldFields F = fold_fields(m);
-  hipLaunchKernelGGL(k_fold_pack, dim3((g.sx + 255) / 256, g.H, 4 * g.Nz + 3), dim3(256), 0, m->stream, g, F, buf);
+  hipLaunchKernelGGL(k_fold_pack, dim3((g.sx + 255) / 256, g.H, fold_levels(F, false)), dim3(256), 0, m->stream, g, F, buf);
   LAUNCHCHK();
   return GB25_OK;
 }
 gb25_status fold_unpack(gb25_model* m, const real* buf) {
   const Grid& g = m->g;
   FoldFields F = fold_fields(m);
-  hipLaunchKernelGGL(k_fold_unpack, dim3((g.sx + 255) / 256, g.H, 4 * (g.Nz + 2) + 3), dim3(256), 0, m->stream, g, F, buf,
+  hipLaunchKernelGGL(k_fold_unpack, dim3((g.sx + 255) / 256, g.H, fold_levels(F, true)), dim3(256), 0, m->stream, g, F, buf,
                      m->cfg.rank * m->Nx, m->cfg.Nx);
   LAUNCHCHK();
   return GB25_OK;
@@ -183,6 +194,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     m->baro_adopted = uv_adopted && m->ahead_baro_valid;
     m->ahead_baro_valid = false;
     if ((s = ab2_local_impl(m, (real)dt, chi))) return s;
+    if (m->catke) catke_surface_flux_impl(m);   // J^b of the new T, S: its halo columns travel with group 0
     if (m->baro_adopted) {
       // the sub-cycle of this step, its wide-halo exchange and the exchange of the new eta, U, V columns all ran
       // beside the last tracer kernel (stage 5): adopt the results, stage 1 and groups 1, 2 are skipped
@@ -195,6 +207,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       m->iteration += 1;
     }
     if ((s = fill_halos_impl(m, false, false, 1))) return s;
+    if (m->catke && (s = fill_halos_impl(m, false, false, 1, 4))) return s;   // (the TKE tracer's y/z layers)
     if (p_early) {
       // T, S of the slab's own columns are final from here on: their pressure (fp64-bound) runs on the side stream
       // beside the exchanges and the sub-cycle; the strips next to the x halos follow in stage 3.  The first x
@@ -266,6 +279,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       // rewrites column 0 (it has been for a while: the exchanges and the sub-cycle ran in between)
       if (p_early) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
       if ((s = fill_halos_impl(m, false, true))) return s;
+      if (m->catke && (s = fill_halos_impl(m, false, true, 1, 4))) return s;
       if (stage == 30) return GB25_OK;
     }
     if (p_early) {   // the two pressure strips run beside w (side stream)
@@ -287,7 +301,8 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     return momentum_impl(m, split ? 2 : 0);
   } else if (stage == 4) {
     // the tracer tendencies; the look-ahead of the next sub-cycle (groups 3, 4 and stage 5) runs beside them
-    return tracers_impl(m);
+    if ((s = tracers_impl(m))) return s;
+    return catke_update_impl(m);
   } else if (stage == 10) {
     // folded grid, sub-cycle inside the step: group 1 has been unpacked into the wide halos: copy the interiors, zero the
     // running averages
@@ -319,10 +334,12 @@ gb25_status update_state_local_impl(gb25_model* m) {   // update_state! without 
   gb25_status s;
   if ((s = mask_impl(m))) return s;   // (own columns; the halo columns arrived masked by their owners)
   if ((s = fill_halos_impl(m, false, m->slab))) return s;
+  if (m->catke && (s = fill_halos_impl(m, false, m->slab, 1, 4))) return s;
   if ((s = compute_w_impl(m))) return s;
   if ((s = compute_p_impl(m))) return s;
   if ((s = momentum_impl(m))) return s;
-  return tracers_impl(m);
+  if ((s = tracers_impl(m))) return s;
+  return catke_update_impl(m);
 }
 
 // ---- sequencing ------------------------------------------------------------------------------------------------------
@@ -536,7 +553,8 @@ struct SlabGroup {
   Transport* transport = nullptr;
   // [slab][buffer set][side: 0 west, 1 east]; sets 3, 4 go to the fold partner (side 0 only)
   std::vector<std::array<std::array<real*, 2>, 5>> send, recv;
-  size_t elems[5] = {0, 0, 0, 0, 0};
+  size_t elems[5] = {0, 0, 0, 0, 0};      // elements per side of buffer set b in an exchange
+  size_t capacity[5] = {0, 0, 0, 0, 0};   // ... and allocated
   bool lookahead_in_flight = false;
   // neighbour handshake of the collective mutators (see collective_guard)
   unsigned long long *tok_dev = nullptr, *tok_host = nullptr;
@@ -784,17 +802,25 @@ struct GroupOps : StepOps {
   gb25_status local(int s, int what) override {
     gb25_model* m = G.slabs[s];
     if (what == 0) return initialize_impl(m);
-    if (what == 1) return fill_halos_impl(m, false);
+    if (what == 1) {
+      if (gb25_status s_ = fill_halos_impl(m, false)) return s_;
+      if (!m->catke) return GB25_OK;
+      catke_surface_flux_impl(m);   // (J^b travels with group 0)
+      return fill_halos_impl(m, false, false, 1, 4);
+    }
     if (what == 3) {
-      if (gb25_status s_ = mask_impl(m)) return s_;
-      return fill_halos_impl(m, false, true);
+      gb25_status s_;
+      if ((s_ = mask_impl(m))) return s_;
+      if ((s_ = fill_halos_impl(m, false, true))) return s_;
+      return m->catke ? fill_halos_impl(m, false, true, 1, 4) : GB25_OK;
     }
     if (what == 4) {
       gb25_status s_;
       if ((s_ = compute_w_impl(m))) return s_;
       if ((s_ = compute_p_impl(m))) return s_;
       if ((s_ = momentum_impl(m))) return s_;
-      return tracers_impl(m);
+      if ((s_ = tracers_impl(m))) return s_;
+      return catke_update_impl(m);
     }
     return update_state_local_impl(m);
   }
@@ -840,6 +866,34 @@ void group_destroy(SlabGroup* G) {
   delete G;
 }
 
+// The bundles of group 0 and of the fold rows carry more fields once a closure adds them (CATKE: e, J^b): sizes again, larger
+// buffers if needed.  Called at the head of the composites; every rank made the same (collective) setter calls.
+gb25_status group_refresh(SlabGroup* G) {
+  gb25_model* m = G->slabs[0];
+  const int n = (int)G->slabs.size();
+  for (int b : {0, 3}) {
+    size_t need = 0;
+    for (gb25_model* q : G->slabs) need = std::max(need, (size_t)(b == 0 ? halo_buffer_elems(q, 0) : fold_buffer_elems(q, 3)));
+    if (need == G->elems[b]) continue;
+    HIPCHK(hipStreamSynchronize(G->comm));
+    HIPCHK(hipStreamSynchronize(G->main));
+    if (need > G->capacity[b]) {
+      for (int s = 0; s < n; s++)
+        for (int side = 0; side < (b < 3 ? 2 : 1); side++) {
+          if (G->send[s][b][side]) hipFree(G->send[s][b][side]);
+          if (G->recv[s][b][side]) hipFree(G->recv[s][b][side]);
+          G->send[s][b][side] = G->recv[s][b][side] = nullptr;
+          if (hipMalloc(&G->send[s][b][side], need * sizeof(real)) != hipSuccess ||
+              hipMalloc(&G->recv[s][b][side], need * sizeof(real)) != hipSuccess)
+            return fail(m, GB25_ERR_OUT_OF_MEMORY, "exchange buffers of %zu elements", need);
+        }
+      G->capacity[b] = need;
+    }
+    G->elems[b] = need;
+  }
+  return GB25_OK;
+}
+
 // Builds the exchange context of `n` slabs (n > 1 only with the local transport).  Takes ownership of `tr`.
 gb25_status group_create(gb25_model* const* slabs, int n, Transport* tr) {
   gb25_model* m = slabs[0];
@@ -868,6 +922,7 @@ gb25_status group_create(gb25_model* const* slabs, int n, Transport* tr) {
     if (st) break;
     for (int b = 0; b < 3; b++) G->elems[b] = (size_t)halo_buffer_elems(m, b);
     for (int b = 3; b < 5; b++) G->elems[b] = (size_t)fold_buffer_elems(m, b);
+    for (int b = 0; b < 5; b++) G->capacity[b] = G->elems[b];
     G->send.resize(n);
     G->recv.resize(n);
     for (int s = 0; s < n && !st; s++)

@@ -1344,8 +1344,10 @@ static void catke_tke_tendency(model *m) {
       }
       if (!inactive_cell(m, i, j, Nz)) {
         long o = ((long)i - 1 + HH) + (long)m->f[F_U].sx * ((long)j - 1 + HH), ov = ((long)i - 1 + HH) + (long)m->f[F_V].sx * ((long)j - 1 + HH);
-        REAL Ju = m->top_flux[0] ? (m->top_flux[0][o] + m->top_flux[0][o + 1]) / (REAL)2 : 0;
-        REAL Jv = m->top_flux[1] ? (m->top_flux[1][ov] + m->top_flux[1][ov + m->f[F_V].sx]) / (REAL)2 : 0;
+        /* u* from the boundary-condition values at (i, j), not interpolated to the cell centre: Oceananigans'
+         * friction_velocity reads getbc(velocity_bcs.u, i, j, ...) and getbc(velocity_bcs.v, i, j, ...) */
+        REAL Ju = m->top_flux[0] ? m->top_flux[0][o] : 0;
+        REAL Jv = m->top_flux[1] ? m->top_flux[1][ov] : 0;
         REAL us2 = (REAL)sqrt((double)(Ju * Ju + Jv * Jv)), us3 = us2 * (REAL)sqrt((double)us2);   /* u*^2, u*^3 */
         REAL Jb = A2(F_JB, i, j), wD3 = (Jb > 0 ? Jb : 0) * DZC(Nz);
         REAL Qe = -(CATKE.CWu * us3 + CATKE.CWw * wD3);

@@ -96,15 +96,48 @@ def test_stepping_with_catke_matches_the_oracle(case, float_type):
     assert e[:, :, -1].max() > 1e-6 and np.isfinite(e).all()
 
 
-def test_catke_is_refused_where_it_is_not_built():
-    from gb25_amd.distributed import LocalSlabEnsemble
-    ens = LocalSlabEnsemble(96, 44, 8, 2, dt=60.0)
-    with pytest.raises(GB25Error, match="single domain"):
-        ens.backends[0].set_catke(True)
-    ens.close()
+def test_catke_fields_exist_only_with_the_closure():
     m = gb.baroclinic_instability_model(gb.GPU(), 32, 16, 8, dt=60.0)
     with pytest.raises(GB25Error):                                # closure = nothing: no TKE tracer
         m.backend.get_field("e", False)
+
+
+@pytest.mark.parametrize("grid_type,P", [("simple_lat_lon", 3), ("gaussian_islands_lat_lon", 2), ("gaussian_islands", 2),
+                                         ("gaussian_islands", 4)])
+def test_catke_on_slabs_is_the_single_domain_bit_for_bit(grid_type, P):
+    """x slabs with CATKE: e and J^b ride in the 3-D bundle (and in the fold rows of a tripolar grid), kappa in the one halo
+    column / fold row the implicit solves read is computed locally from exchanged halos -- no further exchange."""
+    from gb25_amd.distributed import LocalSlabEnsemble
+    Nx, Ny, Nz, dt = 192, 44, 12, 300.0
+    depth = 4000.0 if "islands" in grid_type else 200.0
+    m = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt, depth=depth, grid_type=grid_type, closure=CATKE())
+    start(m, m, wind=-1e-4, heat=5e-5)
+    rng = np.random.default_rng(11)
+    Ju = (-1e-4 * (1.0 + 0.3 * rng.random((Nx, Ny)))).astype(np.float32)     # (fluxes that differ from column to column)
+    JT = (5e-5 * (1.0 + 0.3 * rng.random((Nx, Ny)))).astype(np.float32)
+    gb.set_top_flux(m, u=Ju, T=JT)
+    names = ("u", "v", "T", "S", "e", "eta")
+    init = {n: m.backend.get_field(n, False) for n in names}
+    gb.first_time_step(m)
+    gb.loop(m, 6)
+    out = ("u", "v", "T", "S", "e", "eta", "U", "V", "kappa_u", "kappa_c", "kappa_e", "Le", "Jb", "Gn.e")
+    ref = {n: m.backend.get_field(n, False) for n in out}
+    assert np.isfinite(ref["e"]).all() and ref["kappa_u"].max() > 1e-6
+    m.backend.close()
+    gt = {"simple_lat_lon": 0, "gaussian_islands_lat_lon": 1, "gaussian_islands": 4}[grid_type]
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, depth=depth, **(dict(grid_type=gt) if gt else {}))
+    w = Nx // P
+    for r, b in enumerate(ens.backends):
+        b.set_catke(True)
+        b.set_top_flux("u", np.ascontiguousarray(Ju[r * w:(r + 1) * w]))
+        b.set_top_flux("T", np.ascontiguousarray(JT[r * w:(r + 1) * w]))
+    for n, a in init.items():
+        ens.scatter(n, a)
+    ens.first_time_step()
+    ens.loop(6)
+    bad = [n for n, a in ref.items() if not np.array_equal(ens.gather(n), a)]
+    assert not bad, [(n, rel(ens.gather(n), ref[n])) for n in bad]
+    ens.close()
 
 
 def test_catke_schedules_agree():
