@@ -245,7 +245,7 @@ class HipBackend:
 
     def vertical_diffusivity(self):
         nu, kappa = C.c_double(), C.c_double()
-        self._call("gb25_get_vertical_diffusivity", "gb25_set_closure_catke", C.byref(nu), C.byref(kappa))
+        self._call("gb25_get_vertical_diffusivity", C.byref(nu), C.byref(kappa))
         return nu.value, kappa.value
 
     def metric2(self, name):
