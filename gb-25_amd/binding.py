@@ -27,6 +27,7 @@ FIELD_IDS = {
 METRIC2_IDS = ["dxfc", "dxcc", "dxcf", "dxff", "dyfc", "dycc", "dycf", "dyff", "azcc", "azfc", "azcf", "azff", "fff", "phicc"]
 METRIC_IDS = {"phif": 0, "phic": 1, "dxc": 2, "dxf": 3, "azc": 4, "azf": 5, "fcor": 6,
               "zf": 7, "zc": 8, "dzc": 9, "dzf": 10}
+ATMOSPHERE_IDS = {"u": 0, "v": 1, "T": 2, "q": 3, "p": 4, "shortwave": 5, "longwave": 6}
 KERNEL_IDS = {"fill_halos": 0, "compute_w": 1, "compute_p": 2, "gu": 3, "gv": 4, "tracers": 5,
               "ab2_velocities": 6, "ab2_tracers": 7, "barotropic": 8, "corrector": 9}
 
@@ -36,7 +37,8 @@ ABI_SYMBOLS = [
     "gb25_real_bytes",
     "gb25_set_stream", "gb25_use_own_stream", "gb25_synchronize", "gb25_field_dims", "gb25_set_field", "gb25_get_field",
     "gb25_field_device_ptr", "gb25_get_metric", "gb25_get_metric2", "gb25_get_substepping", "gb25_set_vertical_diffusivity",
-    "gb25_get_vertical_diffusivity", "gb25_set_closure_catke", "gb25_set_baroclinic_instability",
+    "gb25_get_vertical_diffusivity", "gb25_set_closure_catke", "gb25_set_prescribed_atmosphere",
+    "gb25_compute_atmosphere_ocean_fluxes", "gb25_get_top_flux", "gb25_set_baroclinic_instability",
     "gb25_get_clock", "gb25_set_dt", "gb25_initialize", "gb25_mask_immersed_fields",
     "gb25_fill_halo_regions", "gb25_compute_auxiliaries", "gb25_fill_diffusivity_halos",
     "gb25_compute_momentum_tendencies", "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
@@ -118,6 +120,7 @@ def load_library(float_type="Float32"):
     lib.gb25_get_metric2.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.c_int64]
     lib.gb25_set_vertical_diffusivity.argtypes = [P, C.c_double, C.c_double]
     lib.gb25_set_closure_catke.argtypes = [P, C.c_int32]
+    lib.gb25_set_prescribed_atmosphere.argtypes = [P, C.c_int, C.c_void_p]
     lib.gb25_get_vertical_diffusivity.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.gb25_get_substepping.argtypes = [P, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.gb25_get_clock.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
@@ -242,6 +245,27 @@ class HipBackend:
 
     def set_vertical_diffusivity(self, nu, kappa):
         self._call("gb25_set_vertical_diffusivity", float(nu), float(kappa))
+
+    def set_prescribed_atmosphere(self, name, values):
+        """One field of the PrescribedAtmosphere at the cell centres, halo cells included: (Nx + 2H, Ny + 2H) [i, j]; None
+        clears it.  name: u | v | T | q | p | shortwave | longwave."""
+        f = ATMOSPHERE_IDS[name]
+        if values is None:
+            self._call("gb25_set_prescribed_atmosphere", f, None)
+            return
+        H = self.cfg.halo
+        a = np.ascontiguousarray(np.asarray(values, np.float64).reshape(self.cfg.Nx // self.cfg.nranks + 2 * H, self.cfg.Ny + 2 * H).T)
+        self._call("gb25_set_prescribed_atmosphere", f, a.ctypes.data_as(C.c_void_p))
+
+    def compute_atmosphere_ocean_fluxes(self):
+        self._call("gb25_compute_atmosphere_ocean_fluxes")
+
+    def top_flux(self, name):
+        """The top flux boundary condition of u | v | T | S as the device holds it (interior points of the field)."""
+        d = self.field_dims(name, False)
+        a = np.empty((d[1], d[0]), self.dtype)
+        self._call("gb25_get_top_flux", FIELD_IDS[name], a.ctypes.data_as(C.c_void_p))
+        return a.T
 
     def vertical_diffusivity(self):
         nu, kappa = C.c_double(), C.c_double()

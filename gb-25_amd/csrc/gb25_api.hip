@@ -131,6 +131,11 @@ struct gb25_model {
   // the cells row Ny-1 mirrors onto, by own wide column (CurvBaro::mir, kernels.hpp)
   real* d_wideM[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   real* d_top_flux[4] = {nullptr, nullptr, nullptr, nullptr};   // FluxBoundaryCondition at the top of u, v, T, S
+  // PrescribedAtmosphere at the cell centres (data-free forcing); all seven set: the composites compute the
+  // atmosphere-ocean fluxes after every step.  d_tau: the stress components at the centres.
+  double* d_atm[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double* d_tau[2] = {nullptr, nullptr};
+  bool coupled = false;
   // the corrector applied inside its consumers (k_corrector_2d): du, dv of the current step; while uv_lazy is set, u and
   // v in memory lack them (only between the steps of one composite call: gb25_loop applies them before it returns)
   Field corr[2];
@@ -1488,6 +1493,37 @@ gb25_status catke_implicit_impl(gb25_model* m, int mode, real dt, real chi) {
   return GB25_OK;
 }
 
+// compute_atmosphere_ocean_fluxes! + the net ocean fluxes of ClimaOcean's OceanSeaIceModel (data-free forcing): similarity
+// theory per surface cell, then the top flux boundary conditions of u, v, T, S (allocated here if the host set none)
+gb25_status atmosphere_ocean_fluxes_impl(gb25_model* m) {
+  if (!m->coupled) return GB25_OK;
+  const Grid& g = m->g;
+  const size_t n2 = (size_t)g.sx * g.sy_v;
+  for (int q = 0; q < 4; q++) {
+    if (!m->d_top_flux[q]) {
+      HIPCHK(hipMalloc(&m->d_top_flux[q], n2 * sizeof(real)));
+      HIPCHK(hipMemsetAsync(m->d_top_flux[q], 0, n2 * sizeof(real), m->stream));
+    }
+    m->g.top_flux[q] = m->d_top_flux[q];
+  }
+  for (int q = 0; q < 2; q++)
+    if (!m->d_tau[q]) {
+      HIPCHK(hipMalloc(&m->d_tau[q], n2 * sizeof(double)));
+      HIPCHK(hipMemsetAsync(m->d_tau[q], 0, n2 * sizeof(double), m->stream));
+    }
+  Atmosphere A;
+  for (int q = 0; q < 7; q++) A.a[q] = m->d_atm[q];
+  const int j_hi = g.Ny + g.cv.north_fold;
+  dim3 b(64, 4);
+  hipLaunchKernelGGL(m->immersed ? k_similarity_fluxes<true> : k_similarity_fluxes<false>, grid2(g.Nx + 1, j_hi + 1, b), b, 0,
+                     m->stream, m->g, A, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_T].d, m->f[GB25_S].d, m->d_tau[0],
+                     m->d_tau[1], m->d_top_flux[2], m->d_top_flux[3], j_hi, 5);
+  hipLaunchKernelGGL(k_stress_to_faces, grid2(g.Nx, j_hi, b), b, 0, m->stream, m->g, m->d_tau[0], m->d_tau[1],
+                     m->d_top_flux[0], m->d_top_flux[1], j_hi);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+
 gb25_status update_state_impl(gb25_model* m) {
   gb25_status s;
   if ((s = mask_impl(m))) return s;
@@ -1524,7 +1560,7 @@ gb25_status materialize_uv(gb25_model* m) {
 // may this step leave u, v uncorrected in memory?  Flat lat-lon single domain, both look-aheads on and able to write
 // their halos, the default kernels; `more`: another step of the same composite call follows
 inline bool lazy_corrector_ok(const gb25_model* m) {
-  return m->lazy_corrector && m->two_streams && producers_fold(m) && !m->immersed && !m->g.cv.on && m->kernel_gen >= 2 &&
+  return m->lazy_corrector && !m->coupled && m->two_streams && producers_fold(m) && !m->immersed && !m->g.cv.on && m->kernel_gen >= 2 &&
          m->ab2_ahead == 1 && !m->ptr_exposed && m->pressure_bits == 64;
 }
 
@@ -1548,7 +1584,8 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     m->iteration += 1;
     if ((s = fill_halos_impl(m, true))) return s;
     if ((s = corrector_impl(m, true))) return s;
-    return update_state_impl(m);
+    if ((s = update_state_impl(m))) return s;
+    return atmosphere_ocean_fluxes_impl(m);
   }
   const real chi = euler ? -real(0.5) : (real)m->cfg.chi;
   hipStream_t main = m->stream, side = m->side_stream;
@@ -1652,6 +1689,16 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     }
     m->ahead_baro_valid = true;
   }
+  if ((s = tracers_impl(m))) return s;
+  if ((s = catke_update_impl(m))) return s;
+  return atmosphere_ocean_fluxes_impl(m);   // (a coupled model: the fluxes the NEXT evaluation of the tendencies sees)
+}
+// a coupled model at iteration 0: the fluxes of the initial state, then the tendencies again, which now see them
+gb25_status first_fluxes_impl(gb25_model* m) {
+  if (!m->coupled) return GB25_OK;
+  gb25_status s;
+  if ((s = atmosphere_ocean_fluxes_impl(m))) return s;
+  if ((s = momentum_impl(m))) return s;
   if ((s = tracers_impl(m))) return s;
   return catke_update_impl(m);
 }
@@ -1872,6 +1919,10 @@ void gb25_destroy(gb25_model* m) {
   for (auto p : m->d_wideH)
     if (p) hipFree(p);
   for (auto p : m->d_wideM)
+    if (p) hipFree(p);
+  for (auto p : m->d_atm)
+    if (p) hipFree(p);
+  for (auto p : m->d_tau)
     if (p) hipFree(p);
   for (auto p : m->d_top_flux)
     if (p) hipFree(p);
@@ -2235,6 +2286,44 @@ gb25_status gb25_set_top_flux(gb25_model* m, gb25_field f, const void* host) {
   m->g.top_flux[q] = m->d_top_flux[q];
   return GB25_OK;
 }
+gb25_status gb25_get_top_flux(gb25_model* m, gb25_field f, void* host) {
+  CHECK_MODEL(m);
+  const int q = f == GB25_U ? 0 : f == GB25_V ? 1 : f == GB25_T ? 2 : f == GB25_S ? 3 : -1;
+  if (q < 0 || !host) return fail(m, GB25_ERR_INVALID_ARGUMENT, "top flux boundary conditions exist for u, v, T, S");
+  if (!m->g.top_flux[q]) return fail(m, GB25_ERR_STATE, "no top flux boundary condition is set for this field");
+  HIPCHK(hipStreamSynchronize(m->stream));
+  const Field& F = m->f[f];
+  const int H = m->cfg.halo, nxi = F.nx - 2 * H, nyi = F.ny - 2 * H;
+  HIPCHK(hipMemcpy2D(host, (size_t)nxi * sizeof(real), m->g.top_flux[q] + (size_t)H * F.nx + H, (size_t)F.nx * sizeof(real),
+                     (size_t)nxi * sizeof(real), nyi, hipMemcpyDeviceToHost));
+  return GB25_OK;
+}
+gb25_status gb25_set_prescribed_atmosphere(gb25_model* m, gb25_atmosphere_field f, const double* host) {
+  CHECK_MODEL(m);
+  if ((int)f < 0 || (int)f >= GB25_ATM_COUNT) return fail(m, GB25_ERR_INVALID_ARGUMENT, "atmosphere field %d", (int)f);
+  if (gb25_status s = collective_guard(m, 9, (unsigned)f, host ? 1.0 : 0.0)) return s;
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(m->side_stream));
+  const size_t n2 = (size_t)m->g.sx * m->g.sy_c;
+  if (!host) {
+    if (m->d_atm[f]) hipFree(m->d_atm[f]);
+    m->d_atm[f] = nullptr;
+  } else {
+    if (!m->d_atm[f]) HIPCHK(hipMalloc(&m->d_atm[f], n2 * sizeof(double)));
+    HIPCHK(hipMemcpy(m->d_atm[f], host, n2 * sizeof(double), hipMemcpyHostToDevice));
+  }
+  m->coupled = true;
+  for (auto p : m->d_atm) m->coupled = m->coupled && p != nullptr;
+  m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+  return GB25_OK;
+}
+gb25_status gb25_compute_atmosphere_ocean_fluxes(gb25_model* m) {
+  CHECK_MODEL(m);
+  if (!m->coupled) return fail(m, GB25_ERR_STATE, "no prescribed atmosphere: set all of its fields first (gb25_set_prescribed_atmosphere)");
+  if (gb25_status s = materialize_uv(m)) return s;
+  m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;   // (made from tendencies with the old fluxes)
+  return atmosphere_ocean_fluxes_impl(m);
+}
 gb25_status gb25_compute_tendencies(gb25_model* m) {
   CHECK_MODEL(m);
   gb25_status s = momentum_impl(m);
@@ -2429,6 +2518,7 @@ gb25_status gb25_first_time_step(gb25_model* m) {
   }
   if ((s = initialize_impl(m))) return s;
   if ((s = update_state_impl(m))) return s;
+  if ((s = first_fluxes_impl(m))) return s;
   return time_step_impl(m, 1);
 }
 gb25_status gb25_time_step(gb25_model* m) { return gb25_loop(m, 1); }

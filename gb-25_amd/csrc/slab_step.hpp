@@ -302,7 +302,8 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
   } else if (stage == 4) {
     // the tracer tendencies; the look-ahead of the next sub-cycle (groups 3, 4 and stage 5) runs beside them
     if ((s = tracers_impl(m))) return s;
-    return catke_update_impl(m);
+    if ((s = catke_update_impl(m))) return s;
+    return atmosphere_ocean_fluxes_impl(m);
   } else if (stage == 10) {
     // folded grid, sub-cycle inside the step: group 1 has been unpacked into the wide halos: copy the interiors, zero the
     // running averages
@@ -356,6 +357,7 @@ struct StepOps {
   virtual gb25_status local(int s, int what) = 0;              // 0: initialize!, 1: y/z halo layers, 2: update_state! (local)
   virtual bool velocities_ready(int s) = 0;
   virtual bool subcycle_adopted(int s) = 0;
+  virtual bool coupled() { return false; }   // a prescribed atmosphere is set (data-free forcing)
   virtual bool folded() = 0;          // zipper fold: exchanges with the partner rank (buffer sets 3 and 4; groups 6 and 7)
   virtual int substeps() = 0;
   virtual gb25_status record(int slot, bool on_comm) = 0;
@@ -487,12 +489,29 @@ gb25_status sequence_first_time_step(StepOps& o, bool& lookahead_in_flight) {
       SEQ(o.unpack(s, 6, false));
       SEQ(o.local(s, 4));          // w, pressure, tendencies
     }
-    return sequence_time_step(o, 1, lookahead_in_flight);
+  } else {
+    for (int s = 0; s < n; s++) {
+      SEQ(o.unpack(s, 0, false));
+      SEQ(o.unpack(s, 2, false));
+      SEQ(o.local(s, 2));
+    }
   }
-  for (int s = 0; s < n; s++) {
-    SEQ(o.unpack(s, 0, false));
-    SEQ(o.unpack(s, 2, false));
-    SEQ(o.local(s, 2));
+  if (o.coupled()) {
+    // a coupled model (data-free forcing) updates its state at iteration 0: the atmosphere-ocean fluxes of the initial state,
+    // J^b from them, once more through the bundles (J^b of the halo column / the fold rows), then the diffusivities and
+    // tendencies that see them
+    for (int s = 0; s < n; s++) {
+      SEQ(o.local(s, 5));
+      SEQ(o.pack(s, 0, false));
+    }
+    SEQ(o.exchange(0, false));
+    EACH(o.unpack(s, 0, false));
+    if (o.folded()) {
+      EACH(o.pack(s, 6, false));
+      SEQ(o.exchange(6, false));
+      EACH(o.unpack(s, 6, false));
+    }
+    EACH(o.local(s, 6));
   }
   return sequence_time_step(o, 1, lookahead_in_flight);
 }
@@ -525,7 +544,8 @@ struct TraceOps : StepOps {
   gb25_status unpack(int s, int group, bool c) override { add("unpack %d slab %d %s", group, s, st(c)); return GB25_OK; }
   gb25_status exchange(int group, bool c) override { add("exchange %d %s", group, st(c)); return GB25_OK; }
   gb25_status local(int s, int what) override {
-    static const char* names[] = {"initialize", "fill_local", "update_state_local", "mask_fill_local", "auxiliaries_tendencies_local"};
+    static const char* names[] = {"initialize", "fill_local", "update_state_local", "mask_fill_local", "auxiliaries_tendencies_local",
+                                  "first_fluxes_local", "tendencies_local"};
     add("%s slab %d main", names[what], s);
     return GB25_OK;
   }
@@ -780,6 +800,7 @@ struct GroupOps : StepOps {
     return slab_stage(G.slabs[s], stage, euler);
   }
   bool folded() override { return G.slabs[0]->g.cv.north_fold != 0; }
+  bool coupled() override { return G.slabs[0]->coupled; }
   int substeps() override { return G.slabs[0]->Ns; }
   gb25_status pack(int s, int group, bool c) override {
     OnStream on(G.slabs[s], st(c));
@@ -818,6 +839,17 @@ struct GroupOps : StepOps {
       gb25_status s_;
       if ((s_ = compute_w_impl(m))) return s_;
       if ((s_ = compute_p_impl(m))) return s_;
+      if ((s_ = momentum_impl(m))) return s_;
+      if ((s_ = tracers_impl(m))) return s_;
+      return catke_update_impl(m);
+    }
+    if (what == 5) {   // coupled model, iteration 0: fluxes of the initial state and J^b of the own columns
+      if (gb25_status s_ = atmosphere_ocean_fluxes_impl(m)) return s_;
+      if (m->catke) catke_surface_flux_impl(m);
+      return GB25_OK;
+    }
+    if (what == 6) {
+      gb25_status s_;
       if ((s_ = momentum_impl(m))) return s_;
       if ((s_ = tracers_impl(m))) return s_;
       return catke_update_impl(m);

@@ -204,6 +204,7 @@ def baroclinic_instability_model(arch, Nx=None, Ny=None, Nz=None, *, dt, halo=(8
     backend = arch(Nx, Ny, Nz, dt=dt, halo=H, substeps=substeps, **backend_kw)
     model = HydrostaticFreeSurfaceModel(backend, Nx, Ny, Nz, H)
     model.free_surface.substeps = substeps
+    model.grid_type = grid_type
     model.closure = closure
     if isinstance(closure, CATKEVerticalDiffusivity):
         backend.set_catke(True)

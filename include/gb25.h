@@ -206,6 +206,31 @@ gb25_status gb25_get_bottom_info(const gb25_model *m, int32_t which, int32_t i, 
  *      horizontal location (gb25_field_dims(f, 0): dims[0] x dims[1] values, i fastest), positive upward; NULL restores
  *      the default no-flux condition.  The top cell's tendency gets -J/dz inside the tendency kernels. */
 gb25_status gb25_set_top_flux(gb25_model *m, gb25_field f, const void *flux);
+/* the flux as the device holds it (same shape; what the coupled model last computed, or what the host set) */
+gb25_status gb25_get_top_flux(gb25_model *m, gb25_field f, void *flux);
+
+/* ---- data-free forcing (src/data_free_ocean_climate_model.jl:12-70): a PrescribedAtmosphere + Radiation +
+ *      SimilarityTheoryFluxes(solver_stop_criteria = FixedIterations(5)) coupled to the ocean as ClimaOcean's OceanSeaIceModel
+ *      does.  The host evaluates the atmosphere at the ocean's cell centres (the reference: analytic fields on a 360 x 180
+ *      grid, interpolated) and hands each field over as DOUBLES in the parent layout of a 2-D (c,c) field, halo cells
+ *      included ((Nx_local + 2 halo) x (Ny + 2 halo), i fastest): the fluxes of the first halo column / row are computed
+ *      from them, not exchanged.  Once all seven fields are set the model is coupled: gb25_first_time_step computes the
+ *      fluxes of the initial state, every step ends with the flux computation (similarity theory per surface cell, fp64)
+ *      and the results are the top flux boundary conditions of u, v, T, S.  NULL clears a field (uncoupled).
+ *      Collective on a decomposed model. */
+typedef enum {
+  GB25_ATM_U = 0,      /* zonal wind at 10 m [m/s]                      (zonal_wind, :1)        */
+  GB25_ATM_V,          /* meridional wind [m/s]                                                 */
+  GB25_ATM_T,          /* air temperature [K]                           (Tatm + 273.15, :3,6)   */
+  GB25_ATM_Q,          /* specific humidity [kg/kg]                     (0, :57)                */
+  GB25_ATM_P,          /* surface pressure [Pa]                                                 */
+  GB25_ATM_SHORTWAVE,  /* downwelling shortwave radiation [W/m2]        (sunlight, :2)          */
+  GB25_ATM_LONGWAVE,   /* downwelling longwave radiation [W/m2]                                 */
+  GB25_ATM_COUNT
+} gb25_atmosphere_field;
+gb25_status gb25_set_prescribed_atmosphere(gb25_model *m, gb25_atmosphere_field f, const double *values);
+/* compute_atmosphere_ocean_fluxes! + the net fluxes, on demand (the composites call it themselves) */
+gb25_status gb25_compute_atmosphere_ocean_fluxes(gb25_model *m);
 
 /* ---- closure: `closure = nothing` (the default, src/baroclinic_instability_model.jl:29) or
  *      VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), κ = kappa, ν = nu) (:31): after the explicit AB2

@@ -91,6 +91,10 @@ typedef struct {
    * field of the same horizontal location; J > 0 is a flux OUT of the domain through the surface (Oceananigans'
    * convention: top flux positive upward) */
   REAL *top_flux[4];
+  /* PrescribedAtmosphere at the ocean's cell centres (data-free forcing, /root/reference/src/data_free_ocean_climate_model.jl):
+   * u_a, v_a [m/s], T_a [K], q_a [kg/kg], p_a [Pa], downwelling shortwave and longwave [W/m2]; 2-D with the parent layout of a
+   * (c,c) field, halo cells included (the host evaluates the analytic fields there too).  All seven set: coupled. */
+  double *atm[7];
   /* orthogonal curvilinear grid: 2-D metrics (see the macros above), cell-centre latitude for the initial condition,
    * and the topology of the northern edge: 0 = wall (Bounded), 1 = zipper fold (the tripolar grid) */
   /* closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu)
@@ -499,6 +503,7 @@ void FN(destroy)(void *h) {
   free(m->dyff2); free(m->azcc2); free(m->azfc2); free(m->azcf2); free(m->azff2); free(m->fff2); free(m->phicc2);
   free(m->lamcc_d); free(m->phicc_d);
   for (int q = 0; q < 4; q++) free(m->top_flux[q]);
+  for (int q = 0; q < 7; q++) free(m->atm[q]);
   free(m);
 }
 REAL *FN(field_ptr)(void *h, int id) { return ((model *)h)->f[id].p; }
@@ -1052,6 +1057,15 @@ void FN(set_top_flux)(void *h, int q, const double *J) {
     for (int i = 1; i <= m->Nx; i++)
       m->top_flux[q][((long)i - 1 + HH) + (long)F->sx * ((long)j - 1 + HH)] = (REAL)J[(i - 1) + (long)m->Nx * (j - 1)];
 }
+void FN(get_top_flux)(void *h, int q, double *J) {
+  model *m = (model *)h;
+  const int gid[4] = {F_GNU, F_GNV, F_GNT, F_GNS};
+  const fld *F = &m->f[gid[q]];
+  int ny = m->Ny + (q == 1 ? 1 : 0);
+  for (int j = 1; j <= ny; j++)
+    for (int i = 1; i <= m->Nx; i++)
+      J[(i - 1) + (long)m->Nx * (j - 1)] = m->top_flux[q] ? (double)m->top_flux[q][((long)i - 1 + HH) + (long)F->sx * ((long)j - 1 + HH)] : 0.0;
+}
 static void catke_tke_tendency(model *m);
 void FN(compute_tendencies)(void *h) {
   FN(compute_momentum_tendencies)(h);
@@ -1537,6 +1551,142 @@ void FN(initialize)(void *h) {
   fill_halo_2d(m, F_BV, 1, 0, -1);
   fill_halo_2d(m, F_ETA, 0, 0, 1);
 }
+/* ---------------------------------------------------------------- data-free forcing
+ * /root/reference/src/data_free_ocean_climate_model.jl:12-70: an analytic PrescribedAtmosphere, Radiation and
+ * SimilarityTheoryFluxes(solver_stop_criteria = FixedIterations(5)) inside ClimaOcean's OceanSeaIceModel.  ClimaOcean is not
+ * in /root/reference; restated [UPSTREAM-UNVERIFIED] as Monin-Obukhov similarity theory with the published COARE 3.5
+ * ingredients (Edson et al. 2013, "On the exchange of momentum over the open ocean"; Fairall et al. 2003), in the structure
+ * of ClimaOcean's solver: characteristic scales (u*, theta*, q*) iterated a fixed number of times from the differences
+ * between the atmospheric state at h = 10 m and the ocean surface.
+ *   surface humidity   q_s = 0.98 q_sat(T_s, p_a), Clausius-Clapeyron with constant heat capacities (CliMA Thermodynamics form)
+ *   buoyancy scale     b* = g / T_v (theta* (1 + 0.608 q_a) + 0.608 T_a q*),   zeta = kappa h b* / u*^2  (clipped to +-50)
+ *   gustiness          U_g = max(0.2, beta (max(-u* b*, 0) z_i)^(1/3)), beta = 1.2, z_i = 600 m;  dU = sqrt(du^2 + dv^2 + U_g^2)
+ *   roughness          l_u = 0.011 u*^2 / g + 0.11 nu / u*;  l_q = l_theta = min(1.6e-4, 5.8e-5 / (l_u u* / nu)^0.72)
+ *   transfer           u* = kappa dU / (ln(h / l_u) - psi_u(zeta) + psi_u(zeta l_u / h)), theta*, q* alike with psi_q, l_q
+ *   stability          psi_u, psi_q of COARE 3.5 (Kansas / convective blend for zeta < 0, Beljaars-Holtslag for zeta >= 0)
+ * Fluxes, positive UPWARD (Oceananigans' top flux convention), at the cell centres:
+ *   tau = rho_a u*^2 (du, dv) / dU into the ocean;  Q_c = -rho_a c_p u* theta*;  Q_v = -rho_a L_v u* q*;  E = -rho_a u* q*
+ *   Q = Q_c + Q_v + eps (sigma T_s^4 - Q_lw) - (1 - albedo) Q_sw,  eps = 0.97, albedo = 0.05
+ *   J^T = Q / (rho0 c_p^ocean), J^S = -S E / rho_fw at (c,c);  J^u = -Ix(tau_x) / rho0 at (f,c), J^v = -Iy(tau_y) / rho0 at (c,f)
+ * Everything in double, whatever the float type of the model (a 2-D computation); land columns carry no flux.
+ * compute_atmosphere_ocean_fluxes runs after every time step of a coupled model (OceanSeaIceModel's time_step!: ocean step,
+ * then update_state! of the coupled model), so the tendencies of a step see the fluxes of the state before it. */
+typedef struct { double taux, tauy, JT, JS; } ao_flux;
+static double ao_psi_u(double z) {
+  if (z < 0) {
+    double x = sqrt(sqrt(1 - 15 * z)), pk = 2 * log((1 + x) / 2) + log((1 + x * x) / 2) - 2 * atan(x) + 2 * atan(1.0);
+    double y = cbrt(1 - 10.15 * z), pc = 1.5 * log((1 + y + y * y) / 3) - sqrt(3.0) * atan((1 + 2 * y) / sqrt(3.0)) + 4 * atan(1.0) / sqrt(3.0);
+    double f = z * z / (1 + z * z);
+    return (1 - f) * pk + f * pc;
+  }
+  double dz = 0.35 * z < 50 ? 0.35 * z : 50;
+  return -(0.7 * z + 0.75 * (z - 5 / 0.35) * exp(-dz) + 0.75 * 5 / 0.35);
+}
+static double ao_psi_q(double z) {
+  if (z < 0) {
+    double x = sqrt(1 - 15 * z), pk = 2 * log((1 + x) / 2);
+    double y = cbrt(1 - 34.15 * z), pc = 1.5 * log((1 + y + y * y) / 3) - sqrt(3.0) * atan((1 + 2 * y) / sqrt(3.0)) + 4 * atan(1.0) / sqrt(3.0);
+    double f = z * z / (1 + z * z);
+    return (1 - f) * pk + f * pc;
+  }
+  double dz = 0.35 * z < 50 ? 0.35 * z : 50;
+  return -(pow(1 + 2.0 / 3.0 * z, 1.5) + 2.0 / 3.0 * (z - 14.28) * exp(-dz) + 8.525);
+}
+static ao_flux ao_similarity_fluxes(double ua, double va, double Ta, double qa, double pa, double Qsw, double Qlw, double uo,
+                                    double vo, double To, double So, double grav, double rho0, int iterations) {
+  const double kap = 0.4, Rd = 287.0, Rv = 461.5, cpd = 1005.0, cpv = 1859.0, cpl = 4181.0, Lv0 = 2.5008e6, T0 = 273.16,
+               ptr = 611.657, h = 10.0, zi = 600.0, beta = 1.2, charnock = 0.011, nu = 1.5e-5, emis = 0.97, albedo = 0.05,
+               sigma = 5.670374419e-8, cpo = 3991.86795711963, rho_fw = 1000.0;
+  const double Ts = To + 273.15, eps = Rd / Rv;
+  const double psat = ptr * pow(Ts / T0, (cpv - cpl) / Rv) * exp((Lv0 - (cpv - cpl) * T0) / Rv * (1 / T0 - 1 / Ts));
+  const double qs = 0.98 * eps * psat / (pa - (1 - eps) * psat);
+  const double rho_a = pa / ((Rd * (1 - qa) + Rv * qa) * Ta), cpm = cpd * (1 - qa) + cpv * qa, Lv = Lv0 + (cpv - cpl) * (Ts - T0);
+  const double du = ua - uo, dv = va - vo, dth = Ta + grav / cpm * h - Ts, dq = qa - qs, Tv = Ta * (1 + 0.608 * qa);
+  double U = sqrt(du * du + dv * dv + 0.2 * 0.2), chi0 = log(h / 1e-4);
+  double us = kap * U / chi0, ths = kap * dth / chi0, qst = kap * dq / chi0;
+  for (int it = 0; it < iterations; it++) {
+    const double bs = grav / Tv * (ths * (1 + 0.608 * qa) + 0.608 * Ta * qst), Jb = -us * bs;
+    const double Ug = fmax(0.2, beta * cbrt(fmax(Jb, 0.0) * zi));
+    U = sqrt(du * du + dv * dv + Ug * Ug);
+    const double lu = charnock * us * us / grav + 0.11 * nu / us, lq = fmin(1.6e-4, 5.8e-5 / pow(lu * us / nu, 0.72));
+    double zeta = kap * h * bs / (us * us);
+    zeta = zeta > 50 ? 50 : (zeta < -50 ? -50 : zeta);
+    const double chiu = log(h / lu) - ao_psi_u(zeta) + ao_psi_u(zeta * lu / h);
+    const double chiq = log(h / lq) - ao_psi_q(zeta) + ao_psi_q(zeta * lq / h);
+    us = kap * U / chiu;
+    ths = kap * dth / chiq;
+    qst = kap * dq / chiq;
+  }
+  ao_flux f;
+  f.taux = rho_a * us * us * du / U;
+  f.tauy = rho_a * us * us * dv / U;
+  const double Qc = -rho_a * cpm * us * ths, Qv = -rho_a * Lv * us * qst, E = -rho_a * us * qst;
+  const double Q = Qc + Qv + emis * (sigma * Ts * Ts * Ts * Ts - Qlw) - (1 - albedo) * Qsw;
+  f.JT = Q / (rho0 * cpo);
+  f.JS = -So * E / rho_fw;
+  return f;
+}
+/* the flux solve at one point (tests): in = {u_a, v_a, T_a, q_a, p_a, Q_sw, Q_lw, u_o, v_o, T_o, S_o, g, rho0}; out = {tau_x, tau_y, J^T, J^S} */
+void FN(similarity_fluxes_point)(const double *in, int iterations, double *out) {
+  ao_flux f = ao_similarity_fluxes(in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], in[8], in[9], in[10], in[11], in[12], iterations);
+  out[0] = f.taux; out[1] = f.tauy; out[2] = f.JT; out[3] = f.JS;
+}
+/* one field of the prescribed atmosphere: q = 0 u, 1 v, 2 T, 3 q, 4 p, 5 shortwave, 6 longwave; parent-shaped (sx x sy of a
+ * (c,c) field), i fastest; NULL clears it (uncoupled) */
+void FN(set_prescribed_atmosphere)(void *h, int q, const double *a) {
+  model *m = (model *)h;
+  free(m->atm[q]);
+  m->atm[q] = NULL;
+  if (!a) return;
+  size_t n = (size_t)m->f[F_T].sx * m->f[F_T].sy;
+  m->atm[q] = (double *)malloc(n * sizeof(double));
+  memcpy(m->atm[q], a, n * sizeof(double));
+}
+static int ao_coupled(const model *m) {
+  for (int q = 0; q < 7; q++)
+    if (!m->atm[q]) return 0;
+  return 1;
+}
+void FN(compute_atmosphere_ocean_fluxes)(void *h) {
+  model *m = (model *)h;
+  if (!ao_coupled(m)) return;
+  int Nx = m->Nx, Ny = m->Ny, Nz = m->Nz, jtop = Ny + (m->north_fold ? 1 : 0);
+  const fld *Fc = &m->f[F_T];
+  long n2 = (long)Fc->sx * Fc->sy;
+  double *tx = (double *)calloc(n2, sizeof(double)), *ty = (double *)calloc(n2, sizeof(double));
+  const int gid[4] = {F_GNU, F_GNV, F_GNT, F_GNS};
+  for (int q = 0; q < 4; q++)
+    if (!m->top_flux[q]) m->top_flux[q] = (REAL *)calloc((size_t)m->f[gid[q]].sx * m->f[gid[q]].sy, sizeof(REAL));
+#define C2(i, j) (((long)(i)-1 + HH) + (long)Fc->sx * ((long)(j)-1 + HH))
+  /* centres, one halo column to the west and one row to the south (and the row beyond a zipper fold): the x / y averages
+   * onto the faces of the interior read them */
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j <= jtop; j++)
+    for (int i = 0; i <= Nx; i++) {
+      long o = C2(i, j);
+      if (inactive_cell(m, i, j, Nz)) continue;
+      double uo = ((double)A3(F_U, i, j, Nz) + (double)A3(F_U, i + 1, j, Nz)) / 2, vo = ((double)A3(F_V, i, j, Nz) + (double)A3(F_V, i, j + 1, Nz)) / 2;
+      ao_flux f = ao_similarity_fluxes(m->atm[0][o], m->atm[1][o], m->atm[2][o], m->atm[3][o], m->atm[4][o], m->atm[5][o],
+                                       m->atm[6][o], uo, vo, (double)A3(F_T, i, j, Nz), (double)A3(F_S, i, j, Nz), (double)m->g,
+                                       (double)m->rho0, 5);
+      tx[o] = f.taux;
+      ty[o] = f.tauy;
+      if (i >= 1 && j >= 1 && j <= Ny) {
+        m->top_flux[2][o] = (REAL)f.JT;
+        m->top_flux[3][o] = (REAL)f.JS;
+      }
+    }
+  long sxv = m->f[F_V].sx;
+  for (int j = 1; j <= jtop; j++)
+    for (int i = 1; i <= Nx; i++) {
+      if (j <= Ny) m->top_flux[0][C2(i, j)] = (REAL)(-(tx[C2(i - 1, j)] + tx[C2(i, j)]) / 2 / (double)m->rho0);
+      m->top_flux[1][((long)i - 1 + HH) + sxv * ((long)j - 1 + HH)] = (REAL)(-(ty[C2(i, j - 1)] + ty[C2(i, j)]) / 2 / (double)m->rho0);
+    }
+#undef C2
+  free(tx);
+  free(ty);
+}
+
 /* time_step!(model, dt; euler) -- /root/reference/src/timestepping_utils.jl:29-35 */
 void FN(time_step_euler)(void *h, int euler) {
   model *m = (model *)h;
@@ -1546,12 +1696,18 @@ void FN(time_step_euler)(void *h, int euler) {
   FN(fill_halos)(h);
   FN(correct_and_cache)(h);
   FN(update_state)(h);
+  FN(compute_atmosphere_ocean_fluxes)(h);   /* (a coupled model only) */
 }
 void FN(time_step)(void *h) { FN(time_step_euler)(h, 0); }
 /* first_time_step!(model) -- /root/reference/src/timestepping_utils.jl:21-27 */
 void FN(first_time_step)(void *h) {
   FN(initialize)(h);
   FN(update_state)(h);
+  if (ao_coupled((model *)h)) {   /* a coupled model updates its state at iteration 0 ("be paranoid"): the fluxes of the
+                                   * initial state, then the ocean's update_state! (diffusivities, tendencies) sees them */
+    FN(compute_atmosphere_ocean_fluxes)(h);
+    FN(update_state)(h);
+  }
   FN(time_step_euler)(h, 1);
 }
 /* loop!(model, Ninner) -- /root/reference/src/timestepping_utils.jl:37-45 */

@@ -230,6 +230,27 @@ class OracleBackend:
             return
         a = np.ascontiguousarray(np.asarray(J, dtype=np.float64).reshape(self.field_dims(name, False)[:2]).T)
         f(self.h, q, a.ctypes.data_as(C.c_void_p))
+    def set_prescribed_atmosphere(self, name, values):
+        f = self._fn("set_prescribed_atmosphere")
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        q = {"u": 0, "v": 1, "T": 2, "q": 3, "p": 4, "shortwave": 5, "longwave": 6}[name]
+        if values is None:
+            f(self.h, q, None)
+            return
+        H = self.H
+        a = np.ascontiguousarray(np.asarray(values, np.float64).reshape(self.cfg.Nx + 2 * H, self.cfg.Ny + 2 * H).T)
+        f(self.h, q, a.ctypes.data_as(C.c_void_p))
+
+    def compute_atmosphere_ocean_fluxes(self): self._call("compute_atmosphere_ocean_fluxes")
+
+    def top_flux(self, name):
+        f = self._fn("get_top_flux")
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        d = self.field_dims(name, False)
+        a = np.empty((d[1], d[0]), np.float64)
+        f(self.h, {"u": 0, "v": 1, "T": 2, "S": 3}[name], a.ctypes.data_as(C.c_void_p))
+        return a.T.astype(self.dtype)
+
     def compute_tendencies(self): self._call("compute_tendencies")
     def ab2_step(self, dt, euler=False): self._fn("ab2_step")(self.h, float(dt), int(euler))
     def correct_velocities_and_cache_previous_tendencies(self, dt=0.0): self._call("correct_and_cache")
