@@ -119,11 +119,17 @@ def main():
                     help="VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu), e.g. 1e-4,1e-5 "
                          "(src/baroclinic_instability_model.jl:31), or catke = CATKEVerticalDiffusivity() (:30); "
                          "the headline line is closure = nothing")
+    ap.add_argument("--data-free", action="store_true",
+                    help="BASELINE.json configs[3]: the data-free climate model -- TripolarGrid with the Gaussian islands, "
+                         "CATKE, analytic atmosphere + similarity-theory fluxes every step, dt = 30 s (use --size 1440 720 60); "
+                         "x slabs where the reference decomposes in 2-D.  Not the headline line")
     ap.add_argument("--burn", type=int, default=0,
                     help="single GPU: run this many steps of a throw-away model first (GPU clocks at load before the timed model starts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timers")
     args = ap.parse_args()
+    if args.data_free:
+        args.grid_type, args.closure, args.dt = "gaussian_islands", "catke", 30.0
 
     import torch
     import gb25_amd as gb
@@ -190,7 +196,11 @@ def main():
         scratch.backend.close()
 
     # synthetic inputs, resident in HBM before timing
-    gb.set_baroclinic_instability(model)
+    if args.data_free:
+        model.grid_type = "gaussian_islands"
+        gb.set_data_free_state(model)        # T = Ti, S = Si and the analytic atmosphere: coupled
+    else:
+        gb.set_baroclinic_instability(model)
     ush, vsh = model.velocities.u.shape, model.velocities.v.shape
     # (the global noise field, cut into the rank's columns: the same initial state whatever the rank count)
     u0 = (1e-3 * counter_rng((gNx,) + tuple(ush[1:]), 42, 1)).astype(np.float32)[rank * locNx:(rank + 1) * locNx]
@@ -256,7 +266,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"baroclinic_instability_model {gNx}x{Ny}x{Nz} {GRID_NAMES[args.grid_type]}, "
                                    f"halo 8, SplitExplicit(30), WENO5, TEOS10, dt={args.dt:g}s"
-                                   + (f", closure {args.closure}" if args.closure else ""),
+                                   + (f", closure {args.closure}" if args.closure else "")
+                                   + (", data-free forcing (similarity-theory fluxes every step)" if args.data_free else ""),
                        "grid": [gNx, Ny, Nz], "cells_per_gpu": cells, "local_columns": locNx,
                        "parallelism": (f"x-slab x{world}, RCCL send/recv inside the library"
                                        if world > 1 else "single GPU"),

@@ -16,7 +16,7 @@ from .model import (CATKEVerticalDiffusivity, Field, HydrostaticFreeSurfaceModel
                     fill_halo_regions_workload, ab2_step_workload,
                     correct_velocities_and_cache_previous_tendencies_workload)
 from .data_free import (PrescribedAtmosphere, analytic_atmosphere, data_free_ocean_climate_model_init,
-                        set_prescribed_atmosphere, zonal_wind, sunlight, Tatm)
+                        set_prescribed_atmosphere, set_data_free_state, zonal_wind, sunlight, Tatm)
 from .sharding import factors
 from .arg_parsing import (float_type_from_args, float_type_from_string, interior_size, multifloat_from_args,
                           parse_baroclinic_instability_args)

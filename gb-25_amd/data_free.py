@@ -98,14 +98,11 @@ def smooth_step(phi):
     return (1 - np.tanh((np.abs(phi) - 40.0) / 5.0)) / 2      # src/model_utils.jl:83-87
 
 
-def data_free_ocean_climate_model_init(arch, resolution=2, Nz=20, *, dt=30.0, noise=None, **backend_kw):
-    """data_free_ocean_climate_model_init(arch; resolution = 2, Nz = 20) -- src/data_free_ocean_climate_model.jl:12-70:
-    gaussian_islands_tripolar_grid(arch, resolution, Nz), SplitExplicitFreeSurface(substeps = 30), dt = 30 s, the closure of
-    ClimaOcean's ocean_simulation (CATKE), T = Ti, S = Si (src/model_utils.jl:89-97; their rand() term is `noise`, an
-    (Nx, Ny, Nz) array or None), the analytic atmosphere, coupled."""
-    Nx, Ny = resolution_to_points(resolution)
-    model = baroclinic_instability_model(arch, Nx, Ny, Nz, dt=dt, grid_type="gaussian_islands",
-                                         closure=CATKEVerticalDiffusivity(), **backend_kw)
+def set_data_free_state(model, noise=None):
+    """set!(ocean.model, T = Ti, S = Si) (src/data_free_ocean_climate_model.jl:27, src/model_utils.jl:89-97; their rand()
+    term is `noise`, an (Nx, Ny, Nz) array or None) and the analytic atmosphere: coupled from here on.  Works on a slab too
+    (the latitudes are the slab's own)."""
+    Nx, Ny, Nz = model.grid.size
     H = model.grid.halo[0]
     phi = cell_centre_latitudes(model)[H:H + Nx, H:H + Ny]
     zc = np.array([model.backend.metric("zc", k) for k in range(1, Nz + 1)])
@@ -114,3 +111,14 @@ def data_free_ocean_climate_model_init(arch, resolution=2, Nz=20, *, dt=30.0, no
               S=np.broadcast_to(-5e-3 * zc, (Nx, Ny, Nz)) + r)
     set_prescribed_atmosphere(model, analytic_atmosphere())
     return model
+
+
+def data_free_ocean_climate_model_init(arch, resolution=2, Nz=20, *, dt=30.0, noise=None, size=None, **backend_kw):
+    """data_free_ocean_climate_model_init(arch; resolution = 2, Nz = 20) -- src/data_free_ocean_climate_model.jl:12-70:
+    gaussian_islands_tripolar_grid(arch, resolution, Nz), SplitExplicitFreeSurface(substeps = 30), dt = 30 s, the closure of
+    ClimaOcean's ocean_simulation (CATKE), T = Ti, S = Si, the analytic atmosphere, coupled.  size = (Nx, Ny): a grid that is
+    not one of resolution_to_points (BASELINE.json configs[3]: 1440 x 720)."""
+    Nx, Ny = size if size is not None else resolution_to_points(resolution)
+    model = baroclinic_instability_model(arch, Nx, Ny, Nz, dt=dt, grid_type="gaussian_islands",
+                                         closure=CATKEVerticalDiffusivity(), **backend_kw)
+    return set_data_free_state(model, noise)

@@ -16,7 +16,7 @@ export Config, Model, create, destroy!, first_time_step!, time_step!, loop!, ini
        fill_halo_regions!, compute_auxiliaries!, compute_tendencies!, ab2_step!, mask_immersed_fields!,
        correct_velocities_and_cache_previous_tendencies!, set_baroclinic_instability!, synchronize,
        parent_array, interior_array, set_parent!, set_interior!, clock, set_dt!, set_option!, get_option,
-       comm_unique_id, comm_init_rccl!, comm_finalize!, set_top_flux!, set_bottom_height!, set_vertical_diffusivity!, set_closure_catke!, metric2, FIELD, OPTION, METRIC2
+       comm_unique_id, comm_init_rccl!, comm_finalize!, set_top_flux!, set_bottom_height!, set_vertical_diffusivity!, set_closure_catke!, set_prescribed_atmosphere!, compute_atmosphere_ocean_fluxes!, metric2, FIELD, OPTION, METRIC2
 
 # One library per Oceananigans float type (src/arg_parsing.jl:12-16): Float32 -> libgb25hip.so, Float64 ->
 # libgb25hip_f64.so; same symbols, gb25_real_bytes() tells them apart.
@@ -161,6 +161,15 @@ set_vertical_diffusivity!(m::Model; ν::Real = 0, κ::Real = 0) =
 # κu, κc, κe, Le, Jb; once after creation, before the initial state is set
 set_closure_catke!(m::Model, on::Bool = true) =
     check(m, ccall((:gb25_set_closure_catke, m.lib), Cint, (Ptr{Cvoid}, Int32), m.ptr, on), "gb25_set_closure_catke")
+# data-free forcing (src/data_free_ocean_climate_model.jl:12-70): one field of the PrescribedAtmosphere at the ocean's cell
+# centres, halo cells included ((Nx + 2H) x (Ny + 2H) Float64); all seven set => coupled: first_time_step! / loop! compute the
+# similarity-theory fluxes after every step and keep them in the top flux boundary conditions
+const ATMOSPHERE = (u = 0, v = 1, T = 2, q = 3, p = 4, shortwave = 5, longwave = 6)
+set_prescribed_atmosphere!(m::Model, field::Symbol, values::AbstractMatrix) =
+    check(m, ccall((:gb25_set_prescribed_atmosphere, m.lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), m.ptr,
+                   getproperty(ATMOSPHERE, field), convert(Matrix{Float64}, values)), "gb25_set_prescribed_atmosphere")
+compute_atmosphere_ocean_fluxes!(m::Model) =
+    check(m, ccall((:gb25_compute_atmosphere_ocean_fluxes, m.lib), Cint, (Ptr{Cvoid},), m.ptr), "gb25_compute_atmosphere_ocean_fluxes")
 # GridFittedBottom(bottom_height): heights at the cell centres of the interior columns, (Nx, Ny)
 set_bottom_height!(m::Model, zb::AbstractMatrix) =
     check(m, ccall((:gb25_set_bottom_height, m.lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), m.ptr, convert(Matrix{Float64}, zb)),
