@@ -101,6 +101,16 @@ def load_library(float_type="Float32"):
                 raise GB25Error(f"{path} is older than its sources and rebuilding it failed: {e}") from e
     if not os.path.exists(path):
         raise GB25Error(f"{path} not found.  gb25_amd has no CPU fallback.")
+    # One HIP runtime per process.  PyTorch ships its own copies of libamdhip64 / libhsa-runtime64 / librccl; were this
+    # library loaded first it would bind /opt/rocm's copies, a later `import torch` (gb25_amd.distributed, bench.py) would
+    # bring a second runtime into the process, and the RCCL the exchanges find by soname -- torch's -- would sit on the
+    # runtime that does not own the device (ncclCommInitRank: "no ROCm-capable device is detected").  With torch imported
+    # first every HIP user of the process shares torch's copies.  (A host without PyTorch -- the Julia binding -- gets
+    # /opt/rocm's throughout.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     P = C.c_void_p
     lib.gb25_version.restype = C.c_char_p

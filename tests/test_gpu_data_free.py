@@ -108,3 +108,31 @@ def test_coupled_slabs_are_the_single_domain_bit_for_bit():
         got = np.concatenate([b.top_flux(n) for b in ens.backends], axis=0)
         assert np.array_equal(got, a), n
     ens.close()
+
+
+def test_rccl_self_ring_with_the_coupled_model():
+    """The RCCL transport with the larger bundles of a coupled CATKE model (e and J^b in group 0 and in the fold rows, buffers
+    re-sized after the closure was switched on): ONE rank that is its own neighbour and fold partner; bit for bit the single
+    domain."""
+    from gb25_amd.distributed import SlabModel
+    Nx, Ny, Nz, dt = 96, 48, 8, 30.0
+    single = gb.data_free_ocean_climate_model_init(gb.GPU(), resolution=4, Nz=Nz, dt=dt)
+    stir(single, 4)
+    init = {n: single.backend.get_field(n, False) for n in ("u", "v", "T", "S", "eta")}
+    ring = SlabModel(Nx, Ny, Nz, dt=dt, rank=0, nranks=1, slab_mode=1, transport="rccl", grid_type=4)
+    ring.grid_type = "gaussian_islands"
+    ring.backend.set_catke(True)
+    ring.enable_catke_fields()
+    gb.set_prescribed_atmosphere(ring, gb.analytic_atmosphere())
+    for n, a in init.items():
+        ring.backend.set_field(n, a, False)
+    for m in (single, ring):
+        gb.first_time_step(m)
+        gb.loop(m, 4)
+    for n in ("u", "v", "T", "S", "e", "eta", "U", "V", "kappa_u", "Gn.e", "Gn.u"):
+        a, b = ring.backend.get_field(n, False), single.backend.get_field(n, False)
+        assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
+    for n in ("u", "v", "T", "S"):
+        assert np.array_equal(ring.backend.top_flux(n), single.backend.top_flux(n)), n
+    ring.backend.close()
+    single.backend.close()
