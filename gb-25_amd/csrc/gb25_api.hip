@@ -414,6 +414,19 @@ void curv_metrics_at(const gb25_model* m, int ig, int j, double out[GB25_M2_COUN
   out[GB25_M2_PHICC] = cc.phi;
   if (lam_c) *lam_c = cc.lam;
   if (phi_c) *phi_c = cc.phi;
+  if (j == c.Ny) {
+    // The y faces on the fold line are shared by the two halves of the row: face ig IS face Nx-1-ig.  The generator reaches
+    // it along two different index paths; both halves get the western half's numbers, to the last bit (the blocked
+    // sub-cycle advances images of the cells beyond the fold and relies on it).
+    const int iw = ((ig % c.Nx) + c.Nx) % c.Nx;
+    if (2 * iw >= c.Nx) {
+      double w[GB25_M2_COUNT];
+      curv_metrics_at(m, c.Nx - 1 - iw, j, w, nullptr, nullptr);
+      out[GB25_M2_DXCF] = w[GB25_M2_DXCF];
+      out[GB25_M2_DYCF] = w[GB25_M2_DYCF];
+      out[GB25_M2_AZCF] = w[GB25_M2_AZCF];
+    }
+  }
 }
 
 // Fills m->h_curv (the local slab's columns, halo columns by their own global index) and uploads what the kernels read
@@ -1235,7 +1248,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
   real *cur[3], *nxt[3], *other[3], *out[3];
   if (!wide) {
     size_t nbar = m->f[GB25_ETA_BAR].elems() + m->f[GB25_U_BAR].elems() + m->f[GB25_V_BAR].elems();
-    if (m->baro_block <= 1 || g.cv.on)   // (the blocked kernel starts its averages from zero itself)
+    if (m->baro_block <= 1)   // (the blocked kernels start their averages from zero themselves)
       HIPCHK(hipMemsetAsync(ahead ? m->bars_ahead : m->bars, 0, nbar * sizeof(real), m->stream));
     // the state the sub-cycle starts from is only read; the substeps alternate between two scratch sets
     for (int q = 0; q < 3; q++) {
@@ -1264,8 +1277,34 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
   }
   const bool imm = m->immersed;
   bool finalize_after = false;
-  const bool blocked = m->baro_block > 1 && !g.cv.on;   // (the temporally blocked kernel knows the lat-lon row metrics only)
-  if (blocked) {
+  // temporally blocked: the lat-lon kernel (row metrics; single domain and widened slabs), or its curvilinear sibling
+  // (single domain; a widened curvilinear slab advances substep by substep)
+  const bool blocked_curv = m->baro_block > 1 && g.cv.on && !wide;
+  const bool blocked = (m->baro_block > 1 && !g.cv.on) || blocked_curv;
+  if (blocked_curv) {
+    constexpr int Sk = 5, TYc = 17;
+    dim3 gm((g.Nx + BT_TX - 1) / BT_TX, (v_rows(g) + TYc - 1) / TYc);
+    const CurvBaro cb{g.cv.dyfc, g.cv.dxcf, g.cv.razcc, g.cv.rdxfc, g.cv.rdycf, nullptr, nullptr, 0, g.Nx};
+    for (int s = 0; s < m->Ns; s += Sk) {
+      BaroMulti bm;
+      bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
+      bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
+      bm.b = bb;
+      bm.ns = std::min(Sk, m->Ns - s);
+      bm.first = s == 0;
+      bm.last = s + Sk >= m->Ns;
+      if (bm.first && bm.last && !ahead) {   // (one launch would read and write the canonical eta, U, V)
+        bm.last = 0;
+        finalize_after = true;
+      }
+      bm.eta_out = out[0]; bm.U_out = out[1]; bm.V_out = out[2];
+      bm.eb_out = bm.ub_out = bm.vb_out = nullptr;
+      bm.fold = 0;
+      for (int q = 0; q < BT_SMAX; q++) bm.w[q] = (s + q < m->Ns) ? (real)m->weights[s + q] : real(0.);
+      hipLaunchKernelGGL((k_barotropic_multi_curv<Sk, TYc>), gm, dim3(BT_NT), 0, m->stream, g, bm, cb, dtau);
+      for (int q = 0; q < 3; q++) { real* w_ = nxt[q]; nxt[q] = other[q]; other[q] = w_; cur[q] = w_; }
+    }
+  } else if (blocked) {
     // temporally blocked: S substeps per launch on (64 x TY) tiles
     const int S = std::min(m->baro_block, (int)BT_SMAX);
     constexpr int TYb = 16, TY5 = 17;   // (5 substeps per launch: 64 x 17 tiles keep LDS under 40 KB -- four blocks per CU)

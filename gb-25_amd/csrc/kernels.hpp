@@ -1856,6 +1856,150 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
     }
 }
 
+// The temporally blocked sub-cycle on an orthogonal curvilinear grid (single domain, periodic in x), zipper fold included.
+// Arithmetic per point is that of k_barotropic_substep_curv, operation for operation (no FMA contraction either), so the two
+// are interchangeable bit for bit -- the slabs of a folded grid advance substep by substep with that kernel.  Differences
+// from the lat-lon version above: the five metrics and the two depths a point needs are per-point registers; the products
+// dyfc U and dxcf V that the eta update differences live in LDS (FU, FV) in place of G.U, G.V (registers here).
+// The fold: rows Ny .. Ny+S of a tile are IMAGES of the cells beyond the fold line -- cell (i, Ny+q) is cell
+// (Nx-1-i, Ny-1-q), x faces Nx-i, y faces rows Ny-q, transports with the sign flipped -- loaded (values, metrics, depths)
+// from those interior cells and advanced by the same formulas: with every operand the exact negative / equal of its
+// source's, an image evolves into the exact image of the evolved source.  The fold line itself: the western half is
+// stepped, the eastern half starts from minus its partner (as k_barotropic_substep_curv forms it) and evolves likewise.
+// (curv_metrics_at makes the fold-line metrics of the two halves the same numbers.)
+#pragma clang fp contract(off)
+template <int BT_S, int BT_TY>
+__global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, BaroMulti bm, CurvBaro c, real dtau) {
+  constexpr int BT_RX = BT_TX + 2 * BT_S, BT_RY = BT_TY + 2 * BT_S, BT_NP = BT_RX * BT_RY;
+  constexpr int BT_PPT = (BT_NP + BT_NT - 1) / BT_NT;
+  __shared__ real E[BT_RY][BT_RX], U[BT_RY][BT_RX], V[BT_RY][BT_RX], FU[BT_RY][BT_RX], FV[BT_RY][BT_RX];
+  __builtin_amdgcn_s_setprio(3);
+  const Baro& b = bm.b;
+  const int tid = threadIdx.x, Nx = g.Nx, Ny = g.Ny;
+  const int i0 = blockIdx.x * BT_TX, j0 = blockIdx.y * BT_TY;
+  const bool fold = g.cv.north_fold != 0;
+  const int jtop = fold ? Ny + BT_S + 1 : Ny;   // rows [0, jtop) exist (beyond the fold line: as far as a ring reaches)
+  int po[BT_PPT];                               // element offset of the point in the scratch / average arrays (-1: none)
+  unsigned char own[BT_PPT];                    // bit 0: eta, U are this block's to write; bit 1: V
+  real ae[BT_PPT], au[BT_PPT], av[BT_PPT], gu[BT_PPT], gv[BT_PPT];
+  real mrazcc[BT_PPT], mdyfc[BT_PPT], mdxcf[BT_PPT], mrdxfc[BT_PPT], mrdycf[BT_PPT], nghf[BT_PPT], nghc[BT_PPT];
+#pragma unroll
+  for (int q = 0; q < BT_PPT; q++) {
+    const int p = tid + q * BT_NT;
+    const int ly = p / BT_RX, lx = p - ly * BT_RX;
+    const int ig = i0 - BT_S + lx, jg = j0 - BT_S + ly;
+    const bool exists = (p < BT_NP) && jg >= 0 && jg < jtop;
+    int ii = ig % Nx;
+    if (ii < 0) ii += Nx;
+    // where the point's cell-, x-face- and y-face-located quantities live (an image: its source beyond the fold)
+    int ci = ii, cj = jg, ui = ii, uj = jg, vi = ii, vj = jg;
+    real su = real(1.), sv = real(1.);
+    if (jg >= Ny) {
+      ci = Nx - 1 - ii; cj = 2 * Ny - 1 - jg;
+      ui = ii == 0 ? 0 : Nx - ii; uj = cj; su = -real(1.);
+    }
+    if (jg > Ny) {
+      vi = Nx - 1 - ii; vj = 2 * Ny - jg; sv = -real(1.);
+    } else if (jg == Ny && 2 * ii >= Nx) {
+      vi = Nx - 1 - ii; sv = -real(1.);
+    }
+    const bool in_tile = exists && lx >= BT_S && lx < BT_S + BT_TX && ly >= BT_S && ly < BT_S + BT_TY && ig < Nx;
+    own[q] = (unsigned char)((in_tile && jg < Ny ? 1 : 0) | (in_tile && jg < Ny + (fold ? 1 : 0) ? 2 : 0));
+    po[q] = exists ? bi(g, b, ii, min(jg, Ny)) : -1;
+    real e = real(0.), u = real(0.), v = real(0.);
+    gu[q] = gv[q] = real(0.);
+    mrazcc[q] = mdyfc[q] = mdxcf[q] = mrdxfc[q] = mrdycf[q] = nghf[q] = nghc[q] = real(0.);
+    if (exists) {
+      const int oc = bi(g, b, ci, cj), ou = bi(g, b, ui, uj), ov = bi(g, b, vi, vj);
+      e = b.eta0[oc];
+      u = su * b.U0[ou];
+      v = sv * b.V0[ov];
+      gu[q] = su * b.GU[ou];
+      gv[q] = sv * b.GV[ov];
+      mrazcc[q] = c.razcc[oc];
+      mdyfc[q] = c.dyfc[ou];
+      mrdxfc[q] = c.rdxfc[ou];
+      nghf[q] = -g.g * b.Hfc[ou];
+      mdxcf[q] = c.dxcf[ov];
+      mrdycf[q] = c.rdycf[ov];
+      nghc[q] = -g.g * b.Hcf[jg == Ny ? bi(g, b, ii, Ny) : ov];   // (the fold line: the face's own depth, as the one-substep kernel)
+    }
+    if (p < BT_NP) {
+      (&E[0][0])[p] = e;
+      (&U[0][0])[p] = u;
+      (&V[0][0])[p] = v;
+      (&FU[0][0])[p] = mdyfc[q] * u;
+      (&FV[0][0])[p] = mdxcf[q] * v;
+    }
+    ae[q] = au[q] = av[q] = real(0.);
+    if (!bm.first && po[q] >= 0) {
+      if (own[q] & 1) { ae[q] = b.etab[po[q]]; au[q] = b.Ub[po[q]]; }
+      if (own[q] & 2) av[q] = b.Vb[po[q]];
+    }
+  }
+  __syncthreads();
+  for (int s = 0; s < bm.ns; s++) {
+    const real wgt = bm.w[s];
+    // ---- eta with the old transports
+#pragma unroll
+    for (int q = 0; q < BT_PPT; q++) {
+      const int p = tid + q * BT_NT;
+      const int ly = p / BT_RX, lx = p - ly * BT_RX, jg = j0 - BT_S + ly;
+      const bool wall = !fold && jg == Ny - 1;
+      if (po[q] >= 0 && lx < BT_RX - 1 && (ly < BT_RY - 1 || wall)) {
+        const real dxU = FU[ly][lx + 1] - FU[ly][lx];
+        real dyV;
+        if (wall) dyV = -FV[ly][lx];
+        else if (jg == 0) dyV = FV[ly + 1][lx];
+        else dyV = FV[ly + 1][lx] - FV[ly][lx];
+        const real e = E[ly][lx] - dtau * (dxU + dyV) * mrazcc[q];
+        E[ly][lx] = e;
+        if (own[q] & 1) ae[q] += wgt * e;
+      }
+    }
+    __syncthreads();
+    // ---- U, V with the new eta
+#pragma unroll
+    for (int q = 0; q < BT_PPT; q++) {
+      const int p = tid + q * BT_NT;
+      const int ly = p / BT_RX, lx = p - ly * BT_RX, jg = j0 - BT_S + ly;
+      if (po[q] >= 0 && lx >= 1 && (ly >= 1 || jg == 0)) {
+        const real e = E[ly][lx];
+        const real dxe = (e - E[ly][lx - 1]) * mrdxfc[q];
+        real dye = real(0.);
+        if (jg > 0) dye = (e - E[ly - 1][lx]) * mrdycf[q];
+        const real Un = U[ly][lx] + dtau * (nghf[q] * dxe + gu[q]);
+        const real Vn = V[ly][lx] + dtau * (nghc[q] * dye + gv[q]);
+        U[ly][lx] = Un;
+        V[ly][lx] = Vn;
+        FU[ly][lx] = mdyfc[q] * Un;
+        FV[ly][lx] = mdxcf[q] * Vn;
+        if (own[q] & 1) au[q] += wgt * Un;
+        if (own[q] & 2) av[q] += wgt * Vn;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < BT_PPT; q++)
+    if (own[q]) {
+      const int p = tid + q * BT_NT, o = po[q];
+      if (own[q] & 1) {
+        b.eta1[o] = (&E[0][0])[p];
+        b.U1[o] = (&U[0][0])[p];
+        b.etab[o] = ae[q];
+        b.Ub[o] = au[q];
+      }
+      b.V1[o] = (&V[0][0])[p];
+      b.Vb[o] = av[q];
+      if (bm.last) {   // eta, U, V <- the averages, in the canonical arrays (the same geometry on a single domain)
+        if (own[q] & 1) { bm.eta_out[o] = ae[q]; bm.U_out[o] = au[q]; }
+        bm.V_out[o] = av[q];
+      }
+    }
+}
+#pragma clang fp contract(fast)
+
 // eta, U, V <- time averages on the interior (source arrays may be the wide work arrays)
 __global__ void k_barotropic_finalize(Grid g, real* eta, real* U, real* V, const real* etab, const real* Ub,
                                       const real* Vb, int src_sx, int src_xo) {
