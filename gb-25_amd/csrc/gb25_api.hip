@@ -1300,6 +1300,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
       bm.eta_out = out[0]; bm.U_out = out[1]; bm.V_out = out[2];
       bm.eb_out = bm.ub_out = bm.vb_out = nullptr;
       bm.fold = 0;
+      bm.out_halo = 0;
       for (int q = 0; q < BT_SMAX; q++) bm.w[q] = (s + q < m->Ns) ? (real)m->weights[s + q] : real(0.);
       hipLaunchKernelGGL((k_barotropic_multi_curv<Sk, TYc>), gm, dim3(BT_NT), 0, m->stream, g, bm, cb, dtau);
       for (int q = 0; q < 3; q++) { real* w_ = nxt[q]; nxt[q] = other[q]; other[q] = w_; cur[q] = w_; }
@@ -1330,6 +1331,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
       bm.eta_out = out[0]; bm.U_out = out[1]; bm.V_out = out[2];
       bm.eb_out = bm.ub_out = bm.vb_out = nullptr;
       bm.fold = (!wide && producers_fold(m) && m->composite && bm.last) ? 1 : 0;
+      bm.out_halo = wide ? g.H : 0;   // (a widened slab also writes the x halo columns of the new eta, U, V)
       if (bm.last) m->last_baro_folded = bm.fold != 0;
       if (wide) {
         const Field* fb = ahead ? m->ahead_bar : &m->f[GB25_ETA_BAR];
@@ -1360,8 +1362,9 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     return GB25_OK;
   }
   dim3 gi = grid2(g.Nx, v_rows(g), b);
+  if (wide) gi = grid2(g.Nx + 2 * g.H, v_rows(g), b);   // (with the x halo columns: nothing is exchanged after the sub-cycle)
   hipLaunchKernelGGL(k_barotropic_finalize, gi, b, 0, m->stream, g, out[0], out[1], out[2], bb.etab, bb.Ub, bb.Vb,
-                     bb.sx, bb.xo);
+                     bb.sx, bb.xo, wide ? g.H : 0);
   if (wide) {  // publish the averages in the canonical filtered-state arrays (compared by compare_states)
     InteriorCopies C{};
     int rmax = 0;
@@ -1890,7 +1893,9 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   if ((s = alloc_field(m, m->colsum[0], sx, m->f[GB25_BT_U].ny, 1))) return s;
   if ((s = alloc_field(m, m->colsum[1], sx, m->f[GB25_BT_V].ny, 1))) return s;
   if (m->slab) {
-    m->W = m->Ns + 1;
+    // wide enough that after the Ns substeps the valid region still covers the slab's x HALO columns of eta, U, V: they are
+    // computed here like the neighbour computes them (same inputs, same arithmetic) and no exchange follows the sub-cycle
+    m->W = m->Ns + 1 + m->cfg.halo;
     if (m->Nx < m->W)
       return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab width %d is narrower than the barotropic halo %d", m->Nx, m->W);
     const int wsx = m->Nx + 2 * m->W;

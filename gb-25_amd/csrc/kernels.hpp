@@ -1692,6 +1692,7 @@ struct BaroMulti {
   // single periodic domain: the last launch also writes the halo cells tupled_fill_halo_regions! derives from the new
   // eta, U, V (periodic x images, y layer, zero on the wall faces of V): no fill launch for them in the step
   int fold;
+  int out_halo;   // widened slab: the last launch writes eta, U, V of this many x halo columns too (nothing is exchanged after it)
 };
 // (3 waves per SIMD: at 1440x720 the launch has 540 blocks; with the 173 VGPRs the 7-substep variant took when left alone
 // only two blocks fit a CU, 512 on the chip, and the last 28 blocks were a second round that doubled the launch time)
@@ -1823,7 +1824,7 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
       if (bm.last) {
         const int ly = p / BT_RX, lx = p - ly * BT_RX;
         const int ig = i0 - BT_S + lx;
-        if (ig >= 0 && ig < g.Nx) {   // (a widened slab also owns columns outside the canonical interior)
+        if (ig >= -bm.out_halo && ig < g.Nx + bm.out_halo) {   // (a widened slab also owns columns outside the canonical array)
           const int oc = i2(g, ig, pj[q]);
           if (bm.fold) {
             const int jg = pj[q];
@@ -2002,10 +2003,10 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
 
 // eta, U, V <- time averages on the interior (source arrays may be the wide work arrays)
 __global__ void k_barotropic_finalize(Grid g, real* eta, real* U, real* V, const real* etab, const real* Ub,
-                                      const real* Vb, int src_sx, int src_xo) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+                                      const real* Vb, int src_sx, int src_xo, int halo) {
+  int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - halo;   // (halo > 0: a widened slab, its x halo columns included)
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny + g.cv.north_fold) return;
+  if (i >= g.Nx + halo || j >= g.Ny + g.cv.north_fold) return;
   int o = i2(g, i, j), q = (i + src_xo) + src_sx * (j + g.H);
   V[o] = Vb[q];
   if (j >= g.Ny) return;   // (the fold line carries y faces only)

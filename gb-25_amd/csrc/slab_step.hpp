@@ -250,15 +250,16 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       Halo2 h2;
       for (int q = 0; q < 3; q++) { h2.p[q] = m->ahead_eta[q].d; h2.is_v[q] = q == 2; }
       h2.n = 3;
-      if ((s = fill_halos_impl(m, false, false, 2, 3, nullptr, true, &h2))) return s;   // their x columns: group 4
+      // y layer, x halo columns included: the widened sub-cycle computed those like the neighbour did (no group 4)
+      if ((s = fill_halos_impl(m, false, true, 2, 3, nullptr, true, &h2))) return s;
       m->ahead_baro_valid = true;
       return GB25_OK;
     }
     if ((s = barotropic_impl(m, (real)dt))) return s;
     m->time += dt;
     m->iteration += 1;
-    // y layer of the new eta, U, V; their x columns are group 2
-    return fill_halos_impl(m, false, false, 2);
+    // y layer of the new eta, U, V, x halo columns included (computed by the widened sub-cycle: no group 2)
+    return fill_halos_impl(m, false, true, 2);
   } else if (stage == 2) {
     // Everything that needs nothing from the neighbours runs while the exchanges are in flight: the barotropic
     // corrector on the slab's own columns and, when the tendency kernels are split (a12), the y/z layers and w of the
@@ -404,14 +405,13 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
     }
     EACH(o.stage(s, 11, euler, false));
     EACH(o.pack(s, 2, false));
-  } else if (!adopted) {       // ... and is in flight while the sub-cycle runs here
-    for (int s = 0; s < n; s++) {
+  } else if (!adopted) {       // ... and is in flight while the sub-cycle runs here (it leaves the x halo columns of the
+    for (int s = 0; s < n; s++) {   // new eta, U, V behind as well: the slab is widened by Ns + 1 + H columns, no group 2)
       SEQ(o.unpack(s, 1, false));
       SEQ(o.stage(s, 1, euler, false));
-      SEQ(o.pack(s, 2, false));
     }
   }
-  if (!adopted) {
+  if (!adopted && o.folded()) {
     SEQ(o.record(2, false));
     SEQ(o.wait(2, true));      // eta, U, V columns leave behind the bundle on the second stream
     SEQ(o.exchange(2, true));
@@ -420,7 +420,7 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
   EACH(o.stage(s, 2, euler, false));   // own columns + interior tendencies, while the exchanges are in flight
   SEQ(o.record(3, true));
   SEQ(o.wait(3, false));       // the halo columns have arrived
-  if (!adopted) EACH(o.unpack(s, 2, false));
+  if (!adopted && o.folded()) EACH(o.unpack(s, 2, false));
   if (o.folded()) {
     // the rows beyond the fold come from the partner once every slab has its x halos and y/z layers (the partner sends
     // its halo columns too: the corners), then the rest of update_state!
@@ -451,11 +451,8 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
     SEQ(o.exchange(3, true));
     for (int s = 0; s < n; s++) {
       SEQ(o.unpack(s, 3, true));
-      SEQ(o.stage(s, 5, euler, true));
-      SEQ(o.pack(s, 4, true));
+      SEQ(o.stage(s, 5, euler, true));   // (x halo columns of the new eta, U, V included: nothing to exchange after it)
     }
-    SEQ(o.exchange(4, true));
-    EACH(o.unpack(s, 4, true));
     lookahead_in_flight = true;
   }
   EACH(o.stage(s, 4, euler, false));
@@ -763,7 +760,7 @@ gb25_status barotropic_fold_end(gb25_model* m, real dt) {
   dim3 b(64, 4);
   const int wsx = g.Nx + 2 * m->W;
   hipLaunchKernelGGL(k_barotropic_finalize, grid2(g.Nx, v_rows(g), b), b, 0, m->stream, g, m->f[GB25_ETA].d, m->f[GB25_BT_U].d,
-                     m->f[GB25_BT_V].d, m->wideBar[0].d, m->wideBar[1].d, m->wideBar[2].d, wsx, m->W);
+                     m->f[GB25_BT_V].d, m->wideBar[0].d, m->wideBar[1].d, m->wideBar[2].d, wsx, m->W, 0);
   InteriorCopies C{};
   int rmax = 0;
   for (int q = 0; q < 3; q++) {   // publish the averages in the canonical filtered-state arrays
@@ -926,6 +923,9 @@ gb25_status group_refresh(SlabGroup* G) {
   return GB25_OK;
 }
 
+// (The comm stream is an ordinary stream.  A high-priority one -- tried so that it would not share a hardware queue with
+// the slab's side stream -- made the 180-column step 2.3x slower beside RCCL's kernel.  What helps is more hardware queues
+// for the process: GPU_MAX_HW_QUEUES=8, which bench.py and gb25_amd set by default before the runtime starts.)
 // Builds the exchange context of `n` slabs (n > 1 only with the local transport).  Takes ownership of `tr`.
 gb25_status group_create(gb25_model* const* slabs, int n, Transport* tr) {
   gb25_model* m = slabs[0];

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""One rank's share of an x-slab decomposition as a proxy on a one-GPU box: a slab of --columns columns whose west / east
+neighbour is itself (slab_mode = 1, the RCCL transport: ncclSend / ncclRecv to self on the comm stream).  The staged step,
+the pack / unpack kernels, the widened sub-cycle and the exchanges are those of a rank of the 8-GPU run; only the wire is
+missing.  Prints the wall time per step; under `rocprofv3 --kernel-trace` the trace is one rank's timeline.
+usage: slab_selfring.py [--columns 180] [--steps 200]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("--columns", type=int, default=180)
+ap.add_argument("--size", type=int, nargs=2, default=[720, 48], metavar=("Ny", "Nz"))
+ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--dt", type=float, default=240.0)
+ap.add_argument("--opt", action="append", default=[])
+a = ap.parse_args()
+import numpy as np
+import gb25_amd as gb
+from gb25_amd.distributed import SlabModel
+m = SlabModel(a.columns, a.size[0], a.size[1], dt=a.dt, rank=0, nranks=1, slab_mode=1, transport="rccl")
+for kv in a.opt:
+    k, v = kv.split("=")
+    m.backend.set_option(k, int(v))
+gb.set_baroclinic_instability(m)
+gb.first_time_step(m)
+gb.loop(m, 20)
+m.backend.synchronize()
+t0 = time.perf_counter()
+gb.loop(m, a.steps)
+m.backend.synchronize()
+t = (time.perf_counter() - t0) / a.steps
+print(f"{a.columns} columns x {a.size[0]} x {a.size[1]}: {1e3 * t:.3f} ms per step ({1 / t:.0f} steps/s per rank)", flush=True)
