@@ -374,14 +374,17 @@ struct StepOps {
 
 gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight) {
   const int n = o.n();
-  if (lookahead_in_flight) {   // stage 5 and groups 3, 4 of the previous step have finished before stage 0 adopts them
-    SEQ(o.record(3, true));
-    SEQ(o.wait(3, false));
-  }
+  // The previous step may have left the look-ahead chain (group 3, stage 5) running on the second stream.  Stage 0 touches
+  // nothing of it on the device (the adoption of eta, U, V is a pointer exchange on the host; its kernels update and fill
+  // u, v, T, S and start the pressure), so it does not wait: on a narrow slab the chain (an exchange + the sub-cycle,
+  // ~230 us) outlasts the tracer kernel it runs beside (~120 us), and stage 0 fills part of the difference.
+  const bool in_flight = lookahead_in_flight;
   lookahead_in_flight = false;
   EACH(o.stage(s, 0, euler, false));
   bool adopted = true;         // the sub-cycle of this step is already done
   for (int s = 0; s < n; s++) adopted = adopted && o.subcycle_adopted(s);
+  if (in_flight && !adopted)   // not adopted after all: it must be over before its buffers and work arrays are reused
+    SEQ(o.wait(4, false));    // (event 4: recorded behind the chain when it was issued)
   SEQ(o.record(0, false));     // everything stage 0 wrote
   if (!adopted) {
     // The small barotropic exchange is on the critical path and is posted FIRST: the point-to-point transfers of one
@@ -417,6 +420,8 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
     SEQ(o.exchange(2, true));
   }
   SEQ(o.wait(1, false));       // the corrector rewrites the columns the bundle was packed from
+  if (in_flight && adopted)    // ... and reads the adopted sub-cycle: the look-ahead chain has finished (event 4 sits
+    SEQ(o.wait(4, false));     // behind the chain, ahead of this step's bundle on the same stream)
   EACH(o.stage(s, 2, euler, false));   // own columns + interior tendencies, while the exchanges are in flight
   SEQ(o.record(3, true));
   SEQ(o.wait(3, false));       // the halo columns have arrived
@@ -453,6 +458,7 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
       SEQ(o.unpack(s, 3, true));
       SEQ(o.stage(s, 5, euler, true));   // (x halo columns of the new eta, U, V included: nothing to exchange after it)
     }
+    SEQ(o.record(4, true));
     lookahead_in_flight = true;
   }
   EACH(o.stage(s, 4, euler, false));
@@ -566,7 +572,7 @@ struct Transport {
 struct SlabGroup {
   std::vector<gb25_model*> slabs;
   hipStream_t main = nullptr, comm = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   Transport* transport = nullptr;
   // [slab][buffer set][side: 0 west, 1 east]; sets 3, 4 go to the fold partner (side 0 only)
   std::vector<std::array<std::array<real*, 2>, 5>> send, recv;
