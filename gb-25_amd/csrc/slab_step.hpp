@@ -24,11 +24,12 @@
 //             columns                                                                                (main stream)
 //   stage 4   tracer tendencies                                                                     (main stream)
 //     beside stage 4, on the COMM stream, the sub-cycle of the NEXT step (its G.U, G.V exist since stage 3):
-//   group 3   W = Ns+1 columns of eta,U,V and of the next G.U,G.V -> wide barotropic halos
-//   stage 5   Ns split-explicit substeps on the widened slab into the partner buffers of eta,U,V, filtered state
-//   group 4   H columns of the new eta,U,V  -> x halos of the partner buffers
+//   group 3   W = Ns+1+H columns of eta,U,V and of the next G.U,G.V -> wide barotropic halos
+//   stage 5   Ns split-explicit substeps on the widened slab into the partner buffers of eta,U,V, filtered state; the slab
+//             is wide enough that the x HALO columns of the new eta,U,V come out valid too: nothing is exchanged after it
 //   The next stage 0 adopts them.  When a look-ahead is not valid (first step, changed dt, host writes) the same work
-//   runs inside the step instead: group 1 (= 3), stage 1 (= 5), group 2 (= 4), on the critical path.
+//   runs inside the step instead: group 1 (= 3), stage 1 (= 5), on the critical path.  (Groups 2 and 4 -- H columns of the
+//   new eta,U,V -- remain for the initial state and on a folded grid, whose sub-cycle advances substep by substep.)
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
