@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void k_compute_w(Grid g, const real* __restric
     due = lz.du[o2 + 1]; duw = lz.du[o2];
     dvn = lz.dv[o2 + g.sx]; dvs = lz.dv[o2];
   }
-#pragma unroll 4
+#pragma unroll 8
   for (int k = 0; k < g.Nz; k++) {
     real dz = g.dzc[k];
     real div = LAZY ? (dye * dz * (u[o + 1] + due) - dyw * dz * (u[o] + duw)) + (dxn * dz * (v[ov + g.sx] + dvn) - dxs * dz * (v[ov] + dvs))
