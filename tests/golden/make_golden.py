@@ -35,6 +35,23 @@ def run_case():
     return out
 
 
+COUPLED = dict(resolution=8, Nz=6, dt=30.0)     # 48 x 24 x 6: TripolarGrid + mountains + CATKE + the analytic atmosphere
+COUPLED_FIELDS = ["u", "v", "T", "S", "e", "eta", "U", "V", "kappa_u", "kappa_c", "kappa_e", "Le", "Jb", "Gn.e", "Gn.u", "Gn.T"]
+
+
+def run_coupled():
+    """The whole section-8f stack in one small case: data_free_ocean_climate_model_init (tripolar grid with the Gaussian
+    islands, CATKE, similarity-theory fluxes after every step), first_time_step! + 4 steps."""
+    from oracle_backend import CPU
+    m = gb.data_free_ocean_climate_model_init(CPU("f64"), **COUPLED)
+    out = {"in." + n: m.backend.get_field(n, False) for n in ("T", "S")}
+    gb.first_time_step(m)
+    gb.loop(m, 4)
+    out.update({"step5." + n: m.backend.get_field(n, False) for n in COUPLED_FIELDS})
+    out.update({"flux5." + n: m.backend.top_flux(n).astype(np.float64) for n in ("u", "v", "T", "S")})
+    return out
+
+
 def unit_vectors():
     ob = OracleBackend(16, 16, 4, dt=1.0)
     rng = np.random.default_rng(2025)
@@ -49,4 +66,5 @@ def unit_vectors():
 if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "oracle_f64_16x12x6.npz"), **run_case())
     np.savez_compressed(os.path.join(HERE, "oracle_f64_units.npz"), **unit_vectors())
+    np.savez_compressed(os.path.join(HERE, "oracle_f64_coupled_48x24x6.npz"), **run_coupled())
     print("wrote", os.listdir(HERE))
