@@ -176,12 +176,14 @@ def main():
                           **(dict(grid_type=gt) if gt else {}))
         if args.closure == "catke":
             model.backend.set_catke(True)
+            if args.data_free:
+                model.backend.set_catke_parameters(**gb.default_ocean_closure().parameters)
             model.enable_catke_fields()
         elif args.closure:
             model.backend.set_vertical_diffusivity(*map(float, args.closure.split(",")))
         barrier = dist.barrier
     else:
-        closure = (gb.CATKEVerticalDiffusivity() if args.closure == "catke" else
+        closure = (gb.default_ocean_closure() if args.data_free else gb.CATKEVerticalDiffusivity() if args.closure == "catke" else
                    gb.VerticalScalarDiffusivity(*map(float, args.closure.split(","))) if args.closure else None)
         model = gb.baroclinic_instability_model(gb.GPU(local_rank), Nx, Ny, Nz, dt=args.dt, grid_type=args.grid_type,
                                                 closure=closure)

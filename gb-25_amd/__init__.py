@@ -13,7 +13,7 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from .binding import GB25Error, HipBackend, LIB_PATH, load_library
 from .build import build_library
 from .correctness import approx_equal, compare_states, sync_states
-from .model import (CATKEVerticalDiffusivity, Field, HydrostaticFreeSurfaceModel, VerticalScalarDiffusivity,
+from .model import (CATKEVerticalDiffusivity, default_ocean_closure, Field, HydrostaticFreeSurfaceModel, VerticalScalarDiffusivity,
                     baroclinic_instability_model, first_time_step, initialize,
                     loop, resolution_to_points, set_baroclinic_instability, set_top_flux, time_step, update_state,
                     tupled_fill_halo_regions_workload, compute_tendencies_workload,

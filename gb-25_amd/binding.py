@@ -38,7 +38,8 @@ ABI_SYMBOLS = [
     "gb25_set_stream", "gb25_use_own_stream", "gb25_synchronize", "gb25_field_dims", "gb25_set_field", "gb25_get_field",
     "gb25_field_device_ptr", "gb25_get_metric", "gb25_get_metric2", "gb25_get_substepping", "gb25_set_vertical_diffusivity",
     "gb25_get_vertical_diffusivity", "gb25_set_closure_catke", "gb25_set_prescribed_atmosphere",
-    "gb25_compute_atmosphere_ocean_fluxes", "gb25_get_top_flux", "gb25_set_baroclinic_instability",
+    "gb25_compute_atmosphere_ocean_fluxes", "gb25_get_top_flux", "gb25_default_catke_parameters",
+    "gb25_set_catke_parameters", "gb25_get_catke_parameters", "gb25_set_baroclinic_instability",
     "gb25_get_clock", "gb25_set_dt", "gb25_initialize", "gb25_mask_immersed_fields",
     "gb25_fill_halo_regions", "gb25_compute_auxiliaries", "gb25_fill_diffusivity_halos",
     "gb25_compute_momentum_tendencies", "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
@@ -56,6 +57,20 @@ OPTION_IDS = {"kernels": 0, "ab2_lookahead": 1, "subcycle_lookahead": 2, "subcyc
 UNIQUE_ID_BYTES = 128
 # int32 fn(void *user, int32 buffer_set, const void *send_w, const void *send_e, void *recv_w, void *recv_e, int64 nbytes)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+
+
+class CatkeParameters(C.Structure):
+    """gb25_catke_parameters (include/gb25.h); the arrays are psi = u, c, e, D."""
+    _fields_ = [("Cs", C.c_double), ("Cb", C.c_double), ("Csp", C.c_double), ("CRid", C.c_double), ("CRi0", C.c_double),
+                ("Chi", C.c_double * 4), ("Clo", C.c_double * 4), ("Cun", C.c_double * 4), ("Cc", C.c_double * 4),
+                ("Ce", C.c_double * 4), ("CWu", C.c_double), ("CWw", C.c_double), ("minimum_tke", C.c_double),
+                ("minimum_convective_buoyancy_flux", C.c_double), ("negative_tke_damping_time_scale", C.c_double)]
+
+    def as_list(self):
+        out = [self.Cs, self.Cb, self.Csp, self.CRid, self.CRi0]
+        for a in (self.Chi, self.Clo, self.Cun, self.Cc, self.Ce):
+            out += list(a)
+        return out + [self.CWu, self.CWw, self.minimum_tke, self.minimum_convective_buoyancy_flux, self.negative_tke_damping_time_scale]
 
 
 class Config(C.Structure):
@@ -130,6 +145,10 @@ def load_library(float_type="Float32"):
     lib.gb25_get_metric2.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.c_int64]
     lib.gb25_set_vertical_diffusivity.argtypes = [P, C.c_double, C.c_double]
     lib.gb25_set_closure_catke.argtypes = [P, C.c_int32]
+    lib.gb25_default_catke_parameters.argtypes = [C.POINTER(CatkeParameters)]
+    lib.gb25_default_catke_parameters.restype = None
+    lib.gb25_set_catke_parameters.argtypes = [P, C.POINTER(CatkeParameters)]
+    lib.gb25_get_catke_parameters.argtypes = [P, C.POINTER(CatkeParameters)]
     lib.gb25_set_prescribed_atmosphere.argtypes = [P, C.c_int, C.c_void_p]
     lib.gb25_get_vertical_diffusivity.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.gb25_get_substepping.argtypes = [P, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -252,6 +271,24 @@ class HipBackend:
 
     def set_catke(self, on=True):
         self._call("gb25_set_closure_catke", int(on))
+
+    def catke_parameters(self):
+        p = CatkeParameters()
+        self._call("gb25_get_catke_parameters", C.byref(p))
+        return p
+
+    def set_catke_parameters(self, **changes):
+        """Changes some of CATKE's parameters (names of gb25_catke_parameters; arrays as 4-sequences psi = u, c, e, D)."""
+        p = self.catke_parameters()
+        for k, v in changes.items():
+            if not hasattr(p, k):
+                raise TypeError(f"unknown CATKE parameter {k!r}")
+            if isinstance(getattr(p, k), float):
+                setattr(p, k, float(v))
+            else:
+                for q in range(4):
+                    getattr(p, k)[q] = float(v[q])
+        self._call("gb25_set_catke_parameters", C.byref(p))
 
     def set_vertical_diffusivity(self, nu, kappa):
         self._call("gb25_set_vertical_diffusivity", float(nu), float(kappa))

@@ -149,6 +149,7 @@ struct gb25_model {
   double nu = 0, kappa = 0;
   bool catke = false;                // closure = CATKEVerticalDiffusivity(): the fields GB25_E .. GB25_JB exist
   Field catke_b, catke_scratch;      // N^2 on the faces; the unused half of the two-wide tracer kernel's output
+  gb25_catke_parameters catke_par;   // (gb25_default_catke_parameters at creation)
   bool n2_fresh = false;             // catke_b holds N^2 of the current T, S (written by the pressure kernel)
   Field catke_gam[2];                // Nz > 64: the elimination factors of the streamed implicit solve
   real* d_implicit[2] = {nullptr, nullptr};   // elimination tables of the implicit solve for (u, v) and (T, S): lo | 1/beta | gamma
@@ -1442,15 +1443,15 @@ gb25_status mask_impl(gb25_model* m) {
 // closure = CATKEVerticalDiffusivity(): what update_state! adds -- the advection of e (the two-wide tracer kernel with e in
 // both halves: a first version, the second half is thrown away), the buoyancy field, J^b, then the diffusivity fields with
 // their halo cells and the explicit TKE terms added to G^n.e.  After the tendencies of T, S (same stream).
-CatkePar catke_parameters() {
+CatkePar catke_parameters(const gb25_model* m) {
+  const gb25_catke_parameters& p = m->catke_par;
   CatkePar c;
-  c.Cs = real(1.131); c.Cb = real(0.28); c.Csp = real(0.505); c.CRid = real(1.02); c.CRi0 = real(0.254);
-  const double hi[4] = {0.242, 0.098, 0.548, 0.579}, lo[4] = {0.361, 0.198, 7.863, 1.604}, un[4] = {0.370, 0.369, 1.447, 0.923};
-  const double cc[4] = {3.705, 4.793, 3.642, 3.254}, ce[4] = {0.0, 0.112, 0.0, 0.0};
-  for (int p = 0; p < 4; p++) {
-    c.Chi[p] = (real)hi[p]; c.Clo[p] = (real)lo[p]; c.Cun[p] = (real)un[p]; c.Cc[p] = (real)cc[p]; c.Ce[p] = (real)ce[p];
+  c.Cs = (real)p.Cs; c.Cb = (real)p.Cb; c.Csp = (real)p.Csp; c.CRid = (real)p.CRid; c.CRi0 = (real)p.CRi0;
+  for (int q = 0; q < 4; q++) {
+    c.Chi[q] = (real)p.Chi[q]; c.Clo[q] = (real)p.Clo[q]; c.Cun[q] = (real)p.Cun[q]; c.Cc[q] = (real)p.Cc[q]; c.Ce[q] = (real)p.Ce[q];
   }
-  c.CWu = real(3.179); c.CWw = real(0.383); c.emin = real(1e-9); c.Jbmin = real(1e-11); c.tau_neg = real(60.);
+  c.CWu = (real)p.CWu; c.CWw = (real)p.CWw; c.emin = (real)p.minimum_tke; c.Jbmin = (real)p.minimum_convective_buoyancy_flux;
+  c.tau_neg = (real)p.negative_tke_damping_time_scale;
   return c;
 }
 // J^b = g (alpha J^T - beta J^S) of the model's own columns from the top fluxes and the surface T, S
@@ -1485,7 +1486,7 @@ gb25_status catke_update_impl(gb25_model* m) {
   // a slab computes kappa in the one halo column / fold row the implicit solves of u / v read (k_catke_diffusivities)
   const int i_lo = m->slab ? -1 : 0, j_hi = g.Ny + ((m->slab && g.cv.north_fold) ? 1 : 0);
   hipLaunchKernelGGL(m->immersed ? k_catke_diffusivities<true> : k_catke_diffusivities<false>,
-                     grid2(g.Nx - i_lo, j_hi, b), b, 0, m->stream, g, catke_parameters(), m->f[GB25_U].d, m->f[GB25_V].d,
+                     grid2(g.Nx - i_lo, j_hi, b), b, 0, m->stream, g, catke_parameters(m), m->f[GB25_U].d, m->f[GB25_V].d,
                      m->f[GB25_E].d, m->catke_b.d, m->f[GB25_JB].d, m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d,
                      m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_GN_E].d, i_lo, j_hi);
   if (g.cv.north_fold && !m->slab)   // the rows beyond the zipper
@@ -1780,6 +1781,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   if (!cfg || !out) return GB25_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   gb25_model* m = new gb25_model();
+  gb25_default_catke_parameters(&m->catke_par);
   *out = m;  // returned even on failure so the caller can read the error string, then destroy
   m->cfg = *cfg;
   if (cfg->Nx < 8 || cfg->Ny < 8 || cfg->Nz < 4 || cfg->halo < 4 || cfg->substeps < 1 || cfg->substeps > 4096 ||
@@ -2237,6 +2239,30 @@ gb25_status gb25_set_closure_catke(gb25_model* m, int32_t on) {
   m->n2_fresh = false;
   m->ahead_valid = false;
   m->complete_fills_needed = 2;
+  return GB25_OK;
+}
+void gb25_default_catke_parameters(gb25_catke_parameters* p) {
+  if (!p) return;
+  const double hi[4] = {0.242, 0.098, 0.548, 0.579}, lo[4] = {0.361, 0.198, 7.863, 1.604}, un[4] = {0.370, 0.369, 1.447, 0.923};
+  const double cc[4] = {3.705, 4.793, 3.642, 3.254}, ce[4] = {0.0, 0.112, 0.0, 0.0};
+  p->Cs = 1.131; p->Cb = 0.28; p->Csp = 0.505; p->CRid = 1.02; p->CRi0 = 0.254;
+  for (int q = 0; q < 4; q++) { p->Chi[q] = hi[q]; p->Clo[q] = lo[q]; p->Cun[q] = un[q]; p->Cc[q] = cc[q]; p->Ce[q] = ce[q]; }
+  p->CWu = 3.179; p->CWw = 0.383;
+  p->minimum_tke = 1e-9; p->minimum_convective_buoyancy_flux = 1e-11; p->negative_tke_damping_time_scale = 60.0;
+}
+gb25_status gb25_set_catke_parameters(gb25_model* m, const gb25_catke_parameters* p) {
+  CHECK_MODEL(m);
+  if (!p) return GB25_ERR_INVALID_ARGUMENT;
+  if (!(p->CRid > 0) || !(p->negative_tke_damping_time_scale > 0) || !(p->minimum_convective_buoyancy_flux > 0))
+    return fail(m, GB25_ERR_INVALID_ARGUMENT, "CATKE parameters: CRid, the damping time scale and the minimum convective buoyancy flux must be positive");
+  if (gb25_status s = collective_guard(m, 10, 0, p->Cb)) return s;
+  m->catke_par = *p;
+  m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+  return GB25_OK;
+}
+gb25_status gb25_get_catke_parameters(const gb25_model* m, gb25_catke_parameters* p) {
+  if (!m || !p) return GB25_ERR_INVALID_ARGUMENT;
+  *p = m->catke_par;
   return GB25_OK;
 }
 gb25_status gb25_get_vertical_diffusivity(const gb25_model* m, double* nu, double* kappa) {

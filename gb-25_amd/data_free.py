@@ -10,7 +10,7 @@ advection, quadratic bottom drag) is not built; DESIGN.md says so.
 """
 import numpy as np
 
-from .model import CATKEVerticalDiffusivity, baroclinic_instability_model, resolution_to_points
+from .model import baroclinic_instability_model, default_ocean_closure, resolution_to_points
 
 ATMOSPHERE_FIELDS = ("u", "v", "T", "q", "p", "shortwave", "longwave")
 
@@ -116,9 +116,9 @@ def set_data_free_state(model, noise=None):
 def data_free_ocean_climate_model_init(arch, resolution=2, Nz=20, *, dt=30.0, noise=None, size=None, **backend_kw):
     """data_free_ocean_climate_model_init(arch; resolution = 2, Nz = 20) -- src/data_free_ocean_climate_model.jl:12-70:
     gaussian_islands_tripolar_grid(arch, resolution, Nz), SplitExplicitFreeSurface(substeps = 30), dt = 30 s, the closure of
-    ClimaOcean's ocean_simulation (CATKE), T = Ti, S = Si, the analytic atmosphere, coupled.  size = (Nx, Ny): a grid that is
+    ClimaOcean's ocean_simulation (default_ocean_closure: CATKE with Cᵇ = 0.01), T = Ti, S = Si, the analytic atmosphere, coupled.  size = (Nx, Ny): a grid that is
     not one of resolution_to_points (BASELINE.json configs[3]: 1440 x 720)."""
     Nx, Ny = size if size is not None else resolution_to_points(resolution)
     model = baroclinic_instability_model(arch, Nx, Ny, Nz, dt=dt, grid_type="gaussian_islands",
-                                         closure=CATKEVerticalDiffusivity(), **backend_kw)
+                                         closure=default_ocean_closure(), **backend_kw)
     return set_data_free_state(model, noise)

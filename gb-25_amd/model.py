@@ -174,7 +174,18 @@ class VerticalScalarDiffusivity:
 class CATKEVerticalDiffusivity:
     """closure = Oceananigans.TurbulenceClosures.CATKEVerticalDiffusivity() (src/baroclinic_instability_model.jl:30,
     sharding/less_simple_sharding_problem.jl:84-93): a third tracer e (turbulent kinetic energy), diffusivity fields
-    κu, κc, κe, Lᵉ, Jᵇ (compared by src/correctness.jl:60-67), vertically implicit mixing of u, v, T, S, e."""
+    κu, κc, κe, Lᵉ, Jᵇ (compared by src/correctness.jl:60-67), vertically implicit mixing of u, v, T, S, e.
+    Keyword arguments change parameters (names of gb25_catke_parameters in include/gb25.h), e.g. Cb=0.01."""
+
+    def __init__(self, **parameters):
+        self.parameters = parameters
+
+
+def default_ocean_closure():
+    """ClimaOcean.OceanSimulations.default_ocean_closure() -- what ocean_simulation(grid; ...) uses when no closure is given
+    (src/data_free_ocean_climate_model.jl:26): CATKEVerticalDiffusivity with CATKEMixingLength(Cᵇ = 0.01)
+    [UPSTREAM-UNVERIFIED: recalled from ClimaOcean, which is not in /root/reference]."""
+    return CATKEVerticalDiffusivity(Cb=0.01)
 
 
 def baroclinic_instability_model(arch, Nx=None, Ny=None, Nz=None, *, dt, halo=(8, 8, 8), grid_type="simple_lat_lon",
@@ -208,6 +219,8 @@ def baroclinic_instability_model(arch, Nx=None, Ny=None, Nz=None, *, dt, halo=(8
     model.closure = closure
     if isinstance(closure, CATKEVerticalDiffusivity):
         backend.set_catke(True)
+        if closure.parameters:
+            backend.set_catke_parameters(**closure.parameters)
         model.enable_catke_fields()
     elif closure is not None:
         if not isinstance(closure, VerticalScalarDiffusivity):

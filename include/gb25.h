@@ -239,9 +239,23 @@ gb25_status gb25_compute_atmosphere_ocean_fluxes(gb25_model *m);
 gb25_status gb25_set_vertical_diffusivity(gb25_model *m, double nu, double kappa);
 /*      closure = Oceananigans.TurbulenceClosures.CATKEVerticalDiffusivity() (src/baroclinic_instability_model.jl:30,
  *      sharding/less_simple_sharding_problem.jl:84-93): tracers become (T, S, e); update_state! computes the diffusivity
- *      fields (and fills their halos, src/precompile.jl:37); ab2_step! mixes u, v, T, S, e implicitly with them.  Single
- *      domain, lat-lon grid (flat bottom or GridFittedBottom).  on = 0: back to closure = nothing. */
+ *      fields (and fills their halos, src/precompile.jl:37); ab2_step! mixes u, v, T, S, e implicitly with them.  Every grid
+ *      type, single domain and slabs (collective there).  on = 0: back to closure = nothing. */
 gb25_status gb25_set_closure_catke(gb25_model *m, int32_t on);
+/*      The closure's parameters (psi = u, c, e, D in the arrays): the defaults are those of CATKEVerticalDiffusivity();
+ *      ClimaOcean's ocean_simulation (src/data_free_ocean_climate_model.jl:26) uses its default_ocean_closure(), which differs
+ *      in C^b.  Collective on a decomposed model. */
+typedef struct {
+  double Cs, Cb, Csp;              /* mixing length: distance to the surface / to the bottom, shear-plume parameter */
+  double CRid, CRi0;               /* stability function: width and centre of the step in Ri */
+  double Chi[4], Clo[4], Cun[4];   /* stability function: strongly stable, weakly stable, unstable */
+  double Cc[4], Ce[4];             /* convective and entrainment lengths */
+  double CWu, CWw;                 /* surface TKE flux: friction velocity and convective velocity terms */
+  double minimum_tke, minimum_convective_buoyancy_flux, negative_tke_damping_time_scale;
+} gb25_catke_parameters;
+void gb25_default_catke_parameters(gb25_catke_parameters *p);
+gb25_status gb25_set_catke_parameters(gb25_model *m, const gb25_catke_parameters *p);
+gb25_status gb25_get_catke_parameters(const gb25_model *m, gb25_catke_parameters *p);
 gb25_status gb25_get_vertical_diffusivity(const gb25_model *m, double *nu, double *kappa);
 
 /* ---- initial conditions: set_baroclinic_instability!(model) (src/model_utils.jl:99-127) */

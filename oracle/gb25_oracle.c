@@ -101,6 +101,7 @@ typedef struct {
    * (/root/reference/src/baroclinic_instability_model.jl:31); both zero: closure = nothing */
   REAL nu, kappa;
   int catke; /* closure = CATKEVerticalDiffusivity() */
+  void *catke_params; /* its parameters when they are not the defaults (catke_par, below) */
   int curv, north_fold;
   REAL *dxfc2, *dxcc2, *dxcf2, *dxff2, *dyfc2, *dycc2, *dycf2, *dyff2, *azcc2, *azfc2, *azcf2, *azff2, *fff2, *phicc2;
   double *lamcc_d, *phicc_d; /* cell-centre coordinates in degrees (double), interior Nx x Ny, for analytic bottoms */
@@ -504,6 +505,7 @@ void FN(destroy)(void *h) {
   free(m->lamcc_d); free(m->phicc_d);
   for (int q = 0; q < 4; q++) free(m->top_flux[q]);
   for (int q = 0; q < 7; q++) free(m->atm[q]);
+  free(m->catke_params);
   free(m);
 }
 REAL *FN(field_ptr)(void *h, int id) { return ((model *)h)->f[id].p; }
@@ -1219,7 +1221,7 @@ typedef struct {
   REAL Chi[4], Clo[4], Cun[4], Cc[4], Ce[4]; /* psi = u, c, e, D */
   REAL CWu, CWw, emin, Jbmin, tau_neg;
 } catke_par;
-static const catke_par CATKE = {
+static const catke_par CATKE_DEFAULT = {
   (REAL)1.131, (REAL)0.28, (REAL)0.505, (REAL)1.02, (REAL)0.254,
   {(REAL)0.242, (REAL)0.098, (REAL)0.548, (REAL)0.579},
   {(REAL)0.361, (REAL)0.198, (REAL)7.863, (REAL)1.604},
@@ -1228,11 +1230,27 @@ static const catke_par CATKE = {
   {(REAL)0.0, (REAL)0.112, (REAL)0.0, (REAL)0.0},
   (REAL)3.179, (REAL)0.383, (REAL)1e-9, (REAL)1e-11, (REAL)60.0};
 
+static inline const catke_par *catke_parameters_of(const model *m) {
+  return m->catke_params ? (const catke_par *)m->catke_params : &CATKE_DEFAULT;
+}
+#define CATKE (*catke_parameters_of(m))
+/* the parameters as 31 doubles in the order of gb25_catke_parameters (include/gb25.h): Cs, Cb, Csp, CRid, CRi0, Chi[4], Clo[4],
+ * Cun[4], Cc[4], Ce[4], CWu, CWw, minimum TKE, minimum convective buoyancy flux, damping time scale of negative TKE */
+void FN(set_catke_parameters)(void *h, const double *p) {
+  model *m = (model *)h;
+  if (!m->catke_params) m->catke_params = malloc(sizeof(catke_par));
+  catke_par *c = (catke_par *)m->catke_params;
+  c->Cs = (REAL)p[0]; c->Cb = (REAL)p[1]; c->Csp = (REAL)p[2]; c->CRid = (REAL)p[3]; c->CRi0 = (REAL)p[4];
+  for (int q = 0; q < 4; q++) {
+    c->Chi[q] = (REAL)p[5 + q]; c->Clo[q] = (REAL)p[9 + q]; c->Cun[q] = (REAL)p[13 + q]; c->Cc[q] = (REAL)p[17 + q]; c->Ce[q] = (REAL)p[21 + q];
+  }
+  c->CWu = (REAL)p[25]; c->CWw = (REAL)p[26]; c->emin = (REAL)p[27]; c->Jbmin = (REAL)p[28]; c->tau_neg = (REAL)p[29];
+}
 static inline REAL catke_step(REAL x, REAL c, REAL w) {
   REAL t = (x - c) / w;
   return t < 0 ? 0 : (t > 1 ? 1 : t);
 }
-static inline REAL catke_sigma(int psi, REAL Ri) {
+static inline REAL catke_sigma(const model *m, int psi, REAL Ri) {
   if (Ri < 0) return CATKE.Cun[psi];
   return CATKE.Clo[psi] + (CATKE.Chi[psi] - CATKE.Clo[psi]) * catke_step(Ri, CATKE.CRi0, CATKE.CRid);
 }
@@ -1275,11 +1293,11 @@ static catke_face catke_at_face(const model *m, int i, int j, int k) {
   }
   REAL lpsi[3];
   for (int p = 0; p < 3; p++) {
-    REAL l = catke_sigma(p, Ri) * ls;
+    REAL l = catke_sigma(m, p, Ri) * ls;
     lpsi[p] = lconv[p] > l ? lconv[p] : l;
   }
   f.ku = lpsi[0] * ws; f.kc = lpsi[1] * ws; f.ke = lpsi[2] * ws;
-  REAL lD = ls / catke_sigma(3, Ri);
+  REAL lD = ls / catke_sigma(m, 3, Ri);
   f.lD = lconv[3] > lD ? lconv[3] : lD;
   f.P = f.ku * S2;
   f.wb = -f.kc * N2;

@@ -164,6 +164,26 @@ class OracleBackend:
         f.argtypes = [C.c_void_p, C.c_int]
         f(self.h, int(on))
 
+    def set_catke_parameters(self, **changes):
+        """Same call as HipBackend.set_catke_parameters: the defaults of the library with `changes` applied."""
+        from gb25_amd.binding import CatkeParameters, load_library
+        p = getattr(self, "_catke_par", None)
+        if p is None:
+            p = CatkeParameters()
+            load_library("Float32").gb25_default_catke_parameters(C.byref(p))
+        for k, v in changes.items():
+            if isinstance(getattr(p, k), float):
+                setattr(p, k, float(v))
+            else:
+                for q in range(4):
+                    getattr(p, k)[q] = float(v[q])
+        self._catke_par = p
+        a = (C.c_double * 31)(*p.as_list())
+        f = self._fn("set_catke_parameters")
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        f(self.h, a)
+
     def set_vertical_diffusivity(self, nu, kappa):
         f = self._fn("set_vertical_diffusivity")
         f.restype = None

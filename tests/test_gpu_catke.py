@@ -153,3 +153,23 @@ def test_catke_schedules_agree():
     for o in outs[1:]:
         for n, a in outs[0].items():
             assert rel(a, o[n]) < 2e-6, (n, rel(a, o[n]))
+
+
+@pytest.mark.parametrize("float_type,tol", [("Float64", 1e-10), ("Float32", 2e-5)])
+def test_catke_parameters_reach_the_kernels(float_type, tol):
+    """gb25_set_catke_parameters (ClimaOcean's default_ocean_closure changes C^b; any other parameter likewise): the
+    diffusivity fields follow, HIP and oracle alike."""
+    fields = {}
+    for par in (dict(), dict(Cb=0.01, Cs=0.8, Cun=(0.5, 0.4, 1.0, 0.9), CWu=2.0)):
+        r, v = make_pair(40, 44, 16, dt=120.0, float_type=float_type, depth=200.0, closure=CATKE(**par))
+        start(r, v, wind=-1e-4, heat=5e-5)
+        for m in (r, v):
+            gb.update_state(m)
+        for n in ("kappa_u", "kappa_c", "kappa_e", "Le", "Gn.e"):
+            a, b = r.backend.get_field(n, True), v.backend.get_field(n, True)
+            assert rel(a, b) < tol, (par, n, rel(a, b))
+        fields[bool(par)] = r.backend.get_field("kappa_c", False)
+        p = r.backend.catke_parameters()
+        assert p.Cb == par.get("Cb", 0.28) and tuple(p.Cun) == tuple(par.get("Cun", (0.370, 0.369, 1.447, 0.923)))
+        r.backend.close()
+    assert rel(fields[True], fields[False]) > 1e-2          # (they do change the answer)

@@ -95,6 +95,7 @@ def test_coupled_slabs_are_the_single_domain_bit_for_bit():
     w = Nx // P
     for r, b in enumerate(ens.backends):
         b.set_catke(True)
+        b.set_catke_parameters(**gb.default_ocean_closure().parameters)
         lp = np.asarray(b.metric2("phicc"))[:, : Ny + 2 * H]
         for n in ATMOSPHERE_FIELDS:
             b.set_prescribed_atmosphere(n, atm.interpolate(n, np.zeros_like(lp), lp))
@@ -122,6 +123,7 @@ def test_rccl_self_ring_with_the_coupled_model():
     ring = SlabModel(Nx, Ny, Nz, dt=dt, rank=0, nranks=1, slab_mode=1, transport="rccl", grid_type=4)
     ring.grid_type = "gaussian_islands"
     ring.backend.set_catke(True)
+    ring.backend.set_catke_parameters(**gb.default_ocean_closure().parameters)
     ring.enable_catke_fields()
     gb.set_prescribed_atmosphere(ring, gb.analytic_atmosphere())
     for n, a in init.items():
