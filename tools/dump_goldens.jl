@@ -149,6 +149,31 @@ function run_case(outdir, casename, FT, Nx, Ny, Nz, Δt, baroclinic_state::Bool;
     @info "wrote $dir"
 end
 
+# The data-free climate model (src/data_free_ocean_climate_model.jl:12-70): the ocean's state and the four top flux
+# boundary conditions the coupled model fills (ocean_simulation gives u, v, T, S a FluxBoundaryCondition over a Field), at
+# iteration 0 (after update_state! of the coupled model) and after a few coupled steps.  What pins -- or refutes -- the
+# similarity-theory restatement of this repository (DESIGN.md section 4, "Data-free forcing").
+function dump_coupled(dir, coupled)
+    ocean = coupled.ocean.model
+    dump_checkpoint(dir, ocean)
+    for (name, f) in (("Ju", ocean.velocities.u), ("Jv", ocean.velocities.v), ("JT", ocean.tracers.T), ("JS", ocean.tracers.S))
+        write_npy(joinpath(dir, "$(name).npy"), parent(f.boundary_conditions.top.condition))
+    end
+end
+function run_data_free(outdir, FT, resolution, Nz)
+    Oceananigans.defaults.FloatType = FT
+    coupled = GordonBell25.data_free_ocean_climate_model_init(CPU(); resolution, Nz)
+    dir = joinpath(outdir, "datafree_r$(resolution)x$(Nz)_$(FT)")
+    dump_curvilinear_grid(joinpath(dir, "grid"), coupled.ocean.model.grid)
+    Oceananigans.TimeSteppers.update_state!(coupled)
+    dump_coupled(joinpath(dir, "1_beginning"), coupled)
+    for _ in 1:5
+        Oceananigans.TimeSteppers.time_step!(coupled, 30)
+    end
+    dump_coupled(joinpath(dir, "2_after_5_coupled_steps"), coupled)
+    @info "wrote $dir"
+end
+
 function main(args)
     outdir = length(args) >= 1 ? args[1] : joinpath(@__DIR__, "..", "tests", "golden", "julia")
     for FT in (Float32, Float64)
@@ -162,6 +187,7 @@ function main(args)
         # src/baroclinic_instability_model.jl:30, sharding/less_simple_sharding_problem.jl:84-93
         run_case(outdir, "catke_128x64x8", FT, 128, 64, 8, 1200.0, true;
                  closure = Oceananigans.TurbulenceClosures.CATKEVerticalDiffusivity())
+        run_data_free(outdir, FT, 8, 6)      # 48 x 24 x 6: the size of tests/golden/oracle_f64_coupled_48x24x6.npz
     end
 end
 
