@@ -16,7 +16,8 @@ from oracle_backend import CPU
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden", "julia")
-CASES = sorted(d for d in glob.glob(os.path.join(GOLDEN, "*_Float*")) if os.path.isdir(d))
+CASES = sorted(d for d in glob.glob(os.path.join(GOLDEN, "*_Float*")) if os.path.isdir(d) and not os.path.basename(d).startswith("datafree_"))
+COUPLED_CASES = sorted(d for d in glob.glob(os.path.join(GOLDEN, "datafree_*_Float*")) if os.path.isdir(d))
 CHECKPOINTS = ["1_beginning", "2_after_initialize_and_update_state", "3_after_first_time_step",
                "4_after_2_plus_10_steps", "5_after_sync_and_update_state", "6_after_loop_100"]
 # golden file name -> field name of the backends
@@ -152,3 +153,42 @@ def test_hip_library_reproduces_the_reference(path):
     rtol = float(np.sqrt(np.finfo(np.float64 if ft == "Float64" else np.float32).eps))
     out = run_protocol(model, path, rtol)
     assert not any(out.values()), out
+
+
+def _fluxes_from_the_dumped_state(arch, path):
+    """datafree_* cases (tools/dump_goldens.jl, run_data_free): T, S, u, v of checkpoint 1 go into a coupled model of the
+    same size; its atmosphere-ocean fluxes are compared with the dumped top flux fields (the reference's own T, S carry
+    rand(), so the state is loaded, not regenerated)."""
+    name = os.path.basename(path)                        # datafree_r8x6_Float32
+    res, Nz = name.split("_")[1][1:].split("x")
+    m = gb.data_free_ocean_climate_model_init(arch, resolution=int(res), Nz=int(Nz))
+    for fname in ("u", "v", "T", "S"):
+        m.backend.set_field(FIELDS[fname], load(path, "1_beginning", fname).astype(m.backend.dtype), True)
+    gb.update_state(m)
+    m.backend.compute_atmosphere_ocean_fluxes()
+    H, bad = m.grid.halo[0], []
+    for fname, n in (("Ju", "u"), ("Jv", "v"), ("JT", "T"), ("JS", "S")):
+        ref = load(path, "1_beginning", fname)[H:-H, H:-H, 0]
+        got = m.backend.top_flux(n)
+        ref = ref[: got.shape[0], : got.shape[1]]
+        d = np.linalg.norm((ref - got).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-300)
+        if not d <= 1e-3:                                # (bulk formulae: agreement to 1e-3 would already pin the restatement)
+            bad.append((fname, d))
+    return bad
+
+
+@pytest.mark.parametrize("path", COUPLED_CASES or [None])
+def test_oracle_reproduces_the_reference_fluxes(path):
+    if path is None:
+        pytest.skip("no datafree_* goldens under tests/golden/julia (tools/dump_goldens.jl writes them)")
+    ft = "Float64" if path.endswith("Float64") else "Float32"
+    assert not _fluxes_from_the_dumped_state(CPU("f64" if ft == "Float64" else "f32"), path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", COUPLED_CASES or [None])
+def test_hip_library_reproduces_the_reference_fluxes(path):
+    if path is None:
+        pytest.skip("no datafree_* goldens under tests/golden/julia (tools/dump_goldens.jl writes them)")
+    ft = "Float64" if path.endswith("Float64") else "Float32"
+    assert not _fluxes_from_the_dumped_state(gb.GPU(float_type=ft), path)
