@@ -136,6 +136,7 @@ struct gb25_model {
   double* d_atm[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double* d_tau[2] = {nullptr, nullptr};
   bool coupled = false;
+  bool halo_colsum_valid = false;    // slab: the x-halo columns of colsum hold their owner's integrals (packed with group 0)
   // the corrector applied inside its consumers (k_corrector_2d): du, dv of the current step; while uv_lazy is set, u and
   // v in memory lack them (only between the steps of one composite call: gb25_loop applies them before it returns)
   Field corr[2];
@@ -1402,11 +1403,15 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
     }
     const bool cs = use_colsum && m->colsum_valid && part != 2;
     const bool fold = producers_fold(m) && m->composite;
-    if (m->slab && part == 1 && cs) {   // own columns of a slab, integrals at hand: one thread per cell
+    // one thread per cell where the column integrals are at hand: the own columns of a slab, and its x-halo columns when
+    // the integrals came with the 3-D bundle (group 0 carries the owner's; marching 16 columns x Ny threads up 48 levels
+    // for them was 36 us of latency on the critical path of a 180-column rank)
+    const bool cells_halo = m->slab && part == 2 && use_colsum && m->halo_colsum_valid;
+    if ((m->slab && part == 1 && cs) || cells_halo) {
       hipLaunchKernelGGL(m->immersed ? k_corrector_cells<true> : k_corrector_cells<false>,
-                         dim3((g.Nx + 63) / 64, (v_rows(g) + 3) / 4, g.Nz), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                         dim3((ni + 63) / 64, (v_rows(g) + 3) / 4, g.Nz), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                          m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->colsum[0].d,
-                         m->colsum[1].d);
+                         m->colsum[1].d, i0, ni, skip_from, skip);
     } else {
       auto kern = m->immersed ? (fold ? k_corrector<true, true> : k_corrector<true, false>)
                               : (fold ? k_corrector<false, true> : k_corrector<false, false>);

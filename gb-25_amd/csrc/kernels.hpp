@@ -2059,9 +2059,14 @@ template <bool IMM>
 __global__ __launch_bounds__(256) void k_corrector_cells(Grid g, real* __restrict__ u, real* __restrict__ v,
                                                          const real* __restrict__ U, const real* __restrict__ V,
                                                          real* __restrict__ Ub, real* __restrict__ Vb,
-                                                         const real* __restrict__ Usum, const real* __restrict__ Vsum) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
-  if (i >= g.Nx || j >= g.Ny + g.cv.north_fold) return;
+                                                         const real* __restrict__ Usum, const real* __restrict__ Vsum,
+                                                         int i0, int ni, int skip_from, int skip) {
+  // columns i0 .. i0+ni-1 with a gap of `skip` columns from index skip_from on (the two x-halo strips of a slab in one
+  // launch: their column integrals arrived with the 3-D bundle, computed by the columns' owner)
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
+  if (idx >= ni || j >= g.Ny + g.cv.north_fold) return;
+  int i = i0 + idx;
+  if (i >= skip_from) i += skip;
   const int o2 = i2(g, i, j);
   const bool urow = j < g.Ny;   // (zipper fold: the fold line carries y faces only)
   const real su = Usum[o2], sv = Vsum[o2];

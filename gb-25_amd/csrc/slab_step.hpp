@@ -64,6 +64,8 @@ void group_pieces(gb25_model* m, int group, std::vector<Piece>& out, int* ncols)
         Field& F = m->f[id];
         out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
       }
+      // the column integrals of u, v (the corrector's): the receiver corrects its halo columns cell by cell with them
+      for (int q = 0; q < 2; q++) out.push_back({m->colsum[q].d, m->colsum[q].d, sx, H, sx, H, (long)m->colsum[q].ny});
     } else {
       for (int q = 0; q < 3; q++) {
         Field& F = group == 2 ? m->f[GB25_ETA + q] : m->ahead_eta[q];
@@ -810,6 +812,7 @@ struct GroupOps : StepOps {
     OnStream on(G.slabs[s], st(c));
     const int b = buffer_set(group);
     if (group == 6) return fold_pack(G.slabs[s], G.send[s][b][0]);
+    if (group == 0) G.slabs[s]->halo_colsum_valid = G.slabs[s]->colsum_valid;   // (every slab alike: same calls, same state)
     real* buf[2] = {G.send[s][b][0], G.send[s][b][1]};
     return pack_unpack(G.slabs[s], group, buf, true);
   }
