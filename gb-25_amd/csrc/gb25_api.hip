@@ -2228,6 +2228,7 @@ gb25_status gb25_set_closure_catke(gb25_model* m, int32_t on) {
   CHECK_MODEL(m);
   if (gb25_status s = collective_guard(m, 8, (unsigned)(on != 0), 0.0)) return s;
   if (on && (m->nu != 0 || m->kappa != 0)) return fail(m, GB25_ERR_STATE, "one closure at a time: the vertical diffusivity is set");
+  if (on && m->cfg.Nz < 2) return fail(m, GB25_ERR_INVALID_ARGUMENT, "CATKE needs at least two levels (it lives on the faces between them)");
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(m->side_stream));
   if (on && !m->f[GB25_E].d) {
