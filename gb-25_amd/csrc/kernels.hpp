@@ -1725,6 +1725,7 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
   bool own[BT_PPT];
   real ae[BT_PPT], au[BT_PPT], av[BT_PPT];
   real ghf[BT_PPT], ghc[BT_PPT];                // g x static column depth at the point's U / V face
+  real le[BT_PPT], lu[BT_PPT], lv[BT_PPT], lgu[BT_PPT], lgv[BT_PPT];   // (the loaded tile on its way to LDS)
 #pragma unroll
   for (int q = 0; q < BT_PPT; q++) {
     const int p = tid + q * BT_NT;
@@ -1742,20 +1743,15 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
     }
     po[q] = exists ? bi(g, b, ii, jg) : -1;
     own[q] = exists && lx >= BT_S && lx < BT_S + BT_TX && ly >= BT_S && ly < BT_S + BT_TY && ig < b.ihi;
-    real e = real(0.), u = real(0.), v = real(0.), gu = real(0.), gv = real(0.);
+    // loads only: the values wait in registers until every load of the thread's points is in flight (stored to LDS
+    // point by point, each point's five loads were waited for before the next point's were issued: eight round trips)
+    le[q] = lu[q] = lv[q] = lgu[q] = lgv[q] = real(0.);
     if (exists) {
-      e = b.eta0[po[q]];
-      u = b.U0[po[q]];
-      v = b.V0[po[q]];
-      gu = b.GU[po[q]];
-      gv = b.GV[po[q]];
-    }
-    if (p < BT_NP) {
-      (&E[0][0])[p] = e;
-      (&U[0][0])[p] = u;
-      (&V[0][0])[p] = v;
-      (&GUs[0][0])[p] = gu;
-      (&GVs[0][0])[p] = gv;
+      le[q] = b.eta0[po[q]];
+      lu[q] = b.U0[po[q]];
+      lv[q] = b.V0[po[q]];
+      lgu[q] = b.GU[po[q]];
+      lgv[q] = b.GV[po[q]];
     }
     ae[q] = au[q] = av[q] = real(0.);
     ghf[q] = ghc[q] = gH;
@@ -1767,6 +1763,17 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
       ae[q] = b.etab[po[q]];
       au[q] = b.Ub[po[q]];
       av[q] = b.Vb[po[q]];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < BT_PPT; q++) {
+    const int p = tid + q * BT_NT;
+    if (p < BT_NP) {
+      (&E[0][0])[p] = le[q];
+      (&U[0][0])[p] = lu[q];
+      (&V[0][0])[p] = lv[q];
+      (&GUs[0][0])[p] = lgu[q];
+      (&GVs[0][0])[p] = lgv[q];
     }
   }
   __syncthreads();
@@ -1884,6 +1891,7 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
   unsigned char own[BT_PPT];                    // bit 0: eta, U are this block's to write; bit 1: V
   real ae[BT_PPT], au[BT_PPT], av[BT_PPT], gu[BT_PPT], gv[BT_PPT];
   real mrazcc[BT_PPT], mdyfc[BT_PPT], mdxcf[BT_PPT], mrdxfc[BT_PPT], mrdycf[BT_PPT], nghf[BT_PPT], nghc[BT_PPT];
+  real le[BT_PPT], lu[BT_PPT], lv[BT_PPT];   // (the loaded tile on its way to LDS)
 #pragma unroll
   for (int q = 0; q < BT_PPT; q++) {
     const int p = tid + q * BT_NT;
@@ -1907,14 +1915,15 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
     const bool in_tile = exists && lx >= BT_S && lx < BT_S + BT_TX && ly >= BT_S && ly < BT_S + BT_TY && ig < Nx;
     own[q] = (unsigned char)((in_tile && jg < Ny ? 1 : 0) | (in_tile && jg < Ny + (fold ? 1 : 0) ? 2 : 0));
     po[q] = exists ? bi(g, b, ii, min(jg, Ny)) : -1;
-    real e = real(0.), u = real(0.), v = real(0.);
+    // (loads only in this loop: the tile goes to LDS once every load of the thread's points is in flight)
+    le[q] = lu[q] = lv[q] = real(0.);
     gu[q] = gv[q] = real(0.);
     mrazcc[q] = mdyfc[q] = mdxcf[q] = mrdxfc[q] = mrdycf[q] = nghf[q] = nghc[q] = real(0.);
     if (exists) {
       const int oc = bi(g, b, ci, cj), ou = bi(g, b, ui, uj), ov = bi(g, b, vi, vj);
-      e = b.eta0[oc];
-      u = su * b.U0[ou];
-      v = sv * b.V0[ov];
+      le[q] = b.eta0[oc];
+      lu[q] = su * b.U0[ou];
+      lv[q] = sv * b.V0[ov];
       gu[q] = su * b.GU[ou];
       gv[q] = sv * b.GV[ov];
       mrazcc[q] = c.razcc[oc];
@@ -1925,17 +1934,21 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
       mrdycf[q] = c.rdycf[ov];
       nghc[q] = -g.g * b.Hcf[jg == Ny ? bi(g, b, ii, Ny) : ov];   // (the fold line: the face's own depth, as the one-substep kernel)
     }
-    if (p < BT_NP) {
-      (&E[0][0])[p] = e;
-      (&U[0][0])[p] = u;
-      (&V[0][0])[p] = v;
-      (&FU[0][0])[p] = mdyfc[q] * u;
-      (&FV[0][0])[p] = mdxcf[q] * v;
-    }
     ae[q] = au[q] = av[q] = real(0.);
     if (!bm.first && po[q] >= 0) {
       if (own[q] & 1) { ae[q] = b.etab[po[q]]; au[q] = b.Ub[po[q]]; }
       if (own[q] & 2) av[q] = b.Vb[po[q]];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < BT_PPT; q++) {
+    const int p = tid + q * BT_NT;
+    if (p < BT_NP) {
+      (&E[0][0])[p] = le[q];
+      (&U[0][0])[p] = lu[q];
+      (&V[0][0])[p] = lv[q];
+      (&FU[0][0])[p] = mdyfc[q] * lu[q];
+      (&FV[0][0])[p] = mdxcf[q] * lv[q];
     }
   }
   __syncthreads();
