@@ -6,7 +6,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = [os.path.join(_HERE, "csrc", "gb25_api.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", n) for n in ("kernels.hpp", "tendency_kernels.hpp", "slab_step.hpp", "device_common.hpp")] + \
+HEADERS = sorted(os.path.join(_HERE, "csrc", n) for n in os.listdir(os.path.join(_HERE, "csrc")) if n.endswith(".hpp")) + \
           [os.path.join(_HERE, "..", "include", "gb25.h")]
 OUTPUT = os.path.join(_HERE, "libgb25hip.so")
 OUTPUTS = {"Float32": (OUTPUT, "float"), "Float64": (os.path.join(_HERE, "libgb25hip_f64.so"), "double")}

@@ -1,0 +1,99 @@
+// forcing_kernels.hpp -- the data-free forcing: similarity-theory atmosphere-ocean fluxes per surface cell and their
+// interpolation onto the velocity faces.  Included by kernels.hpp, inside namespace gb25.
+#pragma once
+// =============================================================================================
+// Data-free forcing (GB-25 src/data_free_ocean_climate_model.jl:12-70): the atmosphere-ocean fluxes of
+// ClimaOcean's OceanSeaIceModel -- SimilarityTheoryFluxes(FixedIterations(5)) + Radiation -- from a PrescribedAtmosphere held
+// at the ocean's cell centres, written into the top flux boundary conditions of u, v, T, S (a13).  The algorithm is the
+// oracle's (oracle/gb25_oracle.c, "data-free forcing": Monin-Obukhov similarity theory with the COARE 3.5 roughness lengths
+// and stability functions, restated [UPSTREAM-UNVERIFIED]); a 2-D computation, all of it in fp64.
+//   k_similarity_fluxes   one thread per surface cell, one halo column to the west and one row to the south (and the row
+//                         beyond a zipper fold) included -- computed there from the halo cells of u, v, T, S, never exchanged:
+//                         J^T, J^S at the centres, the stress components into two scratch arrays
+//   k_stress_to_faces     J^u = -Ix(tau_x) / rho0 on the x faces, J^v = -Iy(tau_y) / rho0 on the y faces
+// =============================================================================================
+struct Atmosphere {
+  const double* a[7];   // u_a, v_a, T_a [K], q_a, p_a, shortwave, longwave: parent layout of a 2-D (c,c) field
+};
+__device__ __forceinline__ double ao_psi_c(double y) {
+  return 1.5 * log((1 + y + y * y) / 3) - sqrt(3.0) * atan((1 + 2 * y) / sqrt(3.0)) + 4 * atan(1.0) / sqrt(3.0);
+}
+__device__ __forceinline__ double ao_psi_u(double z) {
+  if (z < 0) {
+    const double x = sqrt(sqrt(1 - 15 * z)), pk = 2 * log((1 + x) / 2) + log((1 + x * x) / 2) - 2 * atan(x) + 2 * atan(1.0);
+    const double f = z * z / (1 + z * z);
+    return (1 - f) * pk + f * ao_psi_c(cbrt(1 - 10.15 * z));
+  }
+  const double dz = 0.35 * z < 50 ? 0.35 * z : 50;
+  return -(0.7 * z + 0.75 * (z - 5 / 0.35) * exp(-dz) + 0.75 * 5 / 0.35);
+}
+__device__ __forceinline__ double ao_psi_q(double z) {
+  if (z < 0) {
+    const double x = sqrt(1 - 15 * z), pk = 2 * log((1 + x) / 2);
+    const double f = z * z / (1 + z * z);
+    return (1 - f) * pk + f * ao_psi_c(cbrt(1 - 34.15 * z));
+  }
+  const double dz = 0.35 * z < 50 ? 0.35 * z : 50;
+  return -(pow(1 + 2.0 / 3.0 * z, 1.5) + 2.0 / 3.0 * (z - 14.28) * exp(-dz) + 8.525);
+}
+template <bool IMM>
+__global__ void k_similarity_fluxes(Grid g, Atmosphere A, const real* __restrict__ u, const real* __restrict__ v,
+                                    const real* __restrict__ T, const real* __restrict__ S, double* __restrict__ tx,
+                                    double* __restrict__ ty, real* __restrict__ JT, real* __restrict__ JS, int j_hi,
+                                    int iterations) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1, j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+  if (i >= g.Nx || j >= j_hi) return;
+  const int o2 = i2(g, i, j), k = g.Nz - 1, o = ic(g, i, j, k), ov = iv(g, i, j, k);
+  const bool own = i >= 0 && j >= 0 && j < g.Ny;
+  if (IMM && (int)(g.im.ordA[o2] & 255) >= g.Nz) {   // land
+    tx[o2] = 0.0;
+    ty[o2] = 0.0;
+    if (own) { JT[o2] = real(0.); JS[o2] = real(0.); }
+    return;
+  }
+  const double kap = 0.4, Rd = 287.0, Rv = 461.5, cpd = 1005.0, cpv = 1859.0, cpl = 4181.0, Lv0 = 2.5008e6, T0 = 273.16,
+               ptr = 611.657, h = 10.0, zi = 600.0, beta = 1.2, charnock = 0.011, nu = 1.5e-5, emis = 0.97, albedo = 0.05,
+               sigma = 5.670374419e-8, cpo = 3991.86795711963, rho_fw = 1000.0;
+  const double grav = (double)g.g, rho0 = (double)g.rho0;
+  const double ua = A.a[0][o2], va = A.a[1][o2], Ta = A.a[2][o2], qa = A.a[3][o2], pa = A.a[4][o2], Qsw = A.a[5][o2], Qlw = A.a[6][o2];
+  const double uo = ((double)u[o] + (double)u[o + 1]) / 2, vo = ((double)v[ov] + (double)v[ov + g.sx]) / 2;
+  const double To = (double)T[o], So = (double)S[o];
+  const double Ts = To + 273.15, eps = Rd / Rv;
+  const double psat = ptr * pow(Ts / T0, (cpv - cpl) / Rv) * exp((Lv0 - (cpv - cpl) * T0) / Rv * (1 / T0 - 1 / Ts));
+  const double qs = 0.98 * eps * psat / (pa - (1 - eps) * psat);
+  const double rho_a = pa / ((Rd * (1 - qa) + Rv * qa) * Ta), cpm = cpd * (1 - qa) + cpv * qa, Lv = Lv0 + (cpv - cpl) * (Ts - T0);
+  const double du = ua - uo, dv = va - vo, dth = Ta + grav / cpm * h - Ts, dq = qa - qs, Tv = Ta * (1 + 0.608 * qa);
+  double U = sqrt(du * du + dv * dv + 0.2 * 0.2);
+  const double chi0 = log(h / 1e-4);
+  double us = kap * U / chi0, ths = kap * dth / chi0, qst = kap * dq / chi0;
+  for (int it = 0; it < iterations; it++) {
+    const double bs = grav / Tv * (ths * (1 + 0.608 * qa) + 0.608 * Ta * qst), Jb = -us * bs;
+    const double Ug = fmax(0.2, beta * cbrt(fmax(Jb, 0.0) * zi));
+    U = sqrt(du * du + dv * dv + Ug * Ug);
+    const double lu = charnock * us * us / grav + 0.11 * nu / us, lq = fmin(1.6e-4, 5.8e-5 / pow(lu * us / nu, 0.72));
+    double zeta = kap * h * bs / (us * us);
+    zeta = zeta > 50 ? 50 : (zeta < -50 ? -50 : zeta);
+    const double chiu = log(h / lu) - ao_psi_u(zeta) + ao_psi_u(zeta * lu / h);
+    const double chiq = log(h / lq) - ao_psi_q(zeta) + ao_psi_q(zeta * lq / h);
+    us = kap * U / chiu;
+    ths = kap * dth / chiq;
+    qst = kap * dq / chiq;
+  }
+  tx[o2] = rho_a * us * us * du / U;
+  ty[o2] = rho_a * us * us * dv / U;
+  if (own) {
+    const double Qc = -rho_a * cpm * us * ths, Qv = -rho_a * Lv * us * qst, E = -rho_a * us * qst;
+    const double Q = Qc + Qv + emis * (sigma * Ts * Ts * Ts * Ts - Qlw) - (1 - albedo) * Qsw;
+    JT[o2] = (real)(Q / (rho0 * cpo));
+    JS[o2] = (real)(-So * E / rho_fw);
+  }
+}
+__global__ void k_stress_to_faces(Grid g, const double* __restrict__ tx, const double* __restrict__ ty, real* __restrict__ Ju,
+                                  real* __restrict__ Jv, int j_hi) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= j_hi) return;
+  const int o2 = i2(g, i, j);
+  if (j < g.Ny) Ju[o2] = (real)(-(tx[o2 - 1] + tx[o2]) / 2 / (double)g.rho0);
+  Jv[o2] = (real)(-(ty[o2 - g.sx] + ty[o2]) / 2 / (double)g.rho0);
+}
+
