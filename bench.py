@@ -178,6 +178,7 @@ def main():
             model.backend.set_catke(True)
             if args.data_free:
                 model.backend.set_catke_parameters(**gb.default_ocean_closure().parameters)
+                model.backend.set_bottom_drag(0.003)
             model.enable_catke_fields()
         elif args.closure:
             model.backend.set_vertical_diffusivity(*map(float, args.closure.split(",")))
@@ -205,6 +206,8 @@ def main():
     # synthetic inputs, resident in HBM before timing
     if args.data_free:
         model.grid_type = "gaussian_islands"
+        if world == 1:
+            model.backend.set_bottom_drag(0.003)   # ocean_simulation's default
         gb.set_data_free_state(model)        # T = Ti, S = Si and the analytic atmosphere: coupled
     else:
         gb.set_baroclinic_instability(model)

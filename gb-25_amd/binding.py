@@ -39,7 +39,8 @@ ABI_SYMBOLS = [
     "gb25_field_device_ptr", "gb25_get_metric", "gb25_get_metric2", "gb25_get_substepping", "gb25_set_vertical_diffusivity",
     "gb25_get_vertical_diffusivity", "gb25_set_closure_catke", "gb25_set_prescribed_atmosphere",
     "gb25_compute_atmosphere_ocean_fluxes", "gb25_get_top_flux", "gb25_default_catke_parameters",
-    "gb25_set_catke_parameters", "gb25_get_catke_parameters", "gb25_set_baroclinic_instability",
+    "gb25_set_catke_parameters", "gb25_get_catke_parameters", "gb25_set_bottom_drag", "gb25_get_bottom_drag",
+    "gb25_set_baroclinic_instability",
     "gb25_get_clock", "gb25_set_dt", "gb25_initialize", "gb25_mask_immersed_fields",
     "gb25_fill_halo_regions", "gb25_compute_auxiliaries", "gb25_fill_diffusivity_halos",
     "gb25_compute_momentum_tendencies", "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
@@ -145,6 +146,8 @@ def load_library(float_type="Float32"):
     lib.gb25_get_metric2.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.c_int64]
     lib.gb25_set_vertical_diffusivity.argtypes = [P, C.c_double, C.c_double]
     lib.gb25_set_closure_catke.argtypes = [P, C.c_int32]
+    lib.gb25_set_bottom_drag.argtypes = [P, C.c_double]
+    lib.gb25_get_bottom_drag.argtypes = [P, C.POINTER(C.c_double)]
     lib.gb25_default_catke_parameters.argtypes = [C.POINTER(CatkeParameters)]
     lib.gb25_default_catke_parameters.restype = None
     lib.gb25_set_catke_parameters.argtypes = [P, C.POINTER(CatkeParameters)]
@@ -292,6 +295,15 @@ class HipBackend:
 
     def set_vertical_diffusivity(self, nu, kappa):
         self._call("gb25_set_vertical_diffusivity", float(nu), float(kappa))
+
+    def set_bottom_drag(self, Cd):
+        """Quadratic bottom drag coefficient (ClimaOcean's ocean_simulation: 0.003); 0: none."""
+        self._call("gb25_set_bottom_drag", float(Cd))
+
+    def bottom_drag(self):
+        v = C.c_double()
+        self._call("gb25_get_bottom_drag", C.byref(v))
+        return v.value
 
     def set_prescribed_atmosphere(self, name, values):
         """One field of the PrescribedAtmosphere at the cell centres, halo cells included: (Nx + 2H, Ny + 2H) [i, j]; None

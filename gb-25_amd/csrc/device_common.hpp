@@ -79,6 +79,9 @@ struct Grid {
   // FluxBoundaryCondition at the top of u, v, T, S (null: the default no-flux): 2-D arrays with the parent layout of a
   // 2-D field of the same location; enter the tendency of the top cell as -J / dz (apply_z_top_bc!)
   const real* top_flux[4];
+  // quadratic bottom drag (gb25_set_bottom_drag): the bottom flux boundary condition of u and v, 2-D like top_flux, added to
+  // the tendency of the face's first free level as +J / dz (null: no drag)
+  const real* bottom_flux[2];
   Curv cv;                                           // (on = 0: the LatitudeLongitudeGrid with its row tables)
 };
 

@@ -97,3 +97,39 @@ __global__ void k_stress_to_faces(Grid g, const double* __restrict__ tx, const d
   Jv[o2] = (real)(-(ty[o2 - g.sx] + ty[o2]) / 2 / (double)g.rho0);
 }
 
+
+// Quadratic bottom drag: the bottom boundary condition ClimaOcean's ocean_simulation gives u and v (and their immersed bottoms),
+// FluxBoundaryCondition(-Cd u sqrt(u^2 + Ixy(v)^2)) at the first free level of the face's column (oracle:
+// compute_bottom_drag_fluxes).  One thread per column; x faces [i_first, i_first + n) (a slab computes its face 0 -- the one
+// that reads a halo column of v -- after the halos arrived).  The tendency kernels add J / dz at that level.
+template <bool IMM>
+__global__ void k_bottom_drag_flux(Grid g, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ Ju,
+                                   real* __restrict__ Jv, real Cd, int i_first, int n) {
+  const int i = i_first + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= i_first + n || j >= g.Ny + g.cv.north_fold) return;
+  const int o2 = i2(g, i, j);
+  int ku = 0, kv = 0;
+  if (IMM) {
+    const unsigned C = g.im.ordC[o2];
+    ku = (C >> 8) & 255;
+    kv = (C >> 16) & 255;
+  }
+  if (j < g.Ny) {
+    real J = real(0.);
+    if (ku < g.Nz) {
+      const int o = ic(g, i, j, ku), ov = iv(g, i, j, ku);
+      const real uu = u[o], vb = (v[ov - 1] + v[ov] + v[ov - 1 + g.sx] + v[ov + g.sx]) / real(4.);
+      J = -Cd * uu * sqrt(uu * uu + vb * vb);
+    }
+    Ju[o2] = J;
+  }
+  {
+    real J = real(0.);
+    if (j >= 1 && kv < g.Nz) {
+      const int o = ic(g, i, j, kv), ov = iv(g, i, j, kv);
+      const real vv = v[ov], ub = (u[o - g.sx] + u[o - g.sx + 1] + u[o] + u[o + 1]) / real(4.);
+      J = -Cd * vv * sqrt(vv * vv + ub * ub);
+    }
+    Jv[o2] = J;
+  }
+}

@@ -136,6 +136,8 @@ struct gb25_model {
   double* d_atm[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double* d_tau[2] = {nullptr, nullptr};
   bool coupled = false;
+  double bottom_drag = 0.0;          // quadratic bottom drag coefficient (0: none); the two flux arrays behind Grid.bottom_flux
+  real* d_bottom_flux[2] = {nullptr, nullptr};
   bool halo_colsum_valid = false;    // slab: the x-halo columns of colsum hold their owner's integrals (packed with group 0)
   // the corrector applied inside its consumers (k_corrector_2d): du, dv of the current step; while uv_lazy is set, u and
   // v in memory lack them (only between the steps of one composite call: gb25_loop applies them before it returns)
@@ -985,10 +987,23 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
       nx.plane2 = g.sx * g.sy_v;
       nx.fold = (producers_fold(m) && !m->immersed) ? 1 : 0;   // (with a bottom the corrector's own halo writes do it)
     }
+    if (m->bottom_drag != 0) {
+      // the bottom flux boundary condition of u, v from the (corrected) velocities this evaluation sees.  A slab's
+      // interior pass runs before the x halos arrive: face 0, the one that reads v of the west halo column, waits for part 2
+      const int i_first = part == 1 ? 1 : 0, n = part == 2 ? 1 : g.Nx - i_first;
+      dim3 b(64, 4);
+      hipLaunchKernelGGL(m->immersed ? k_bottom_drag_flux<true> : k_bottom_drag_flux<false>, grid2(n, v_rows(g), b), b, 0,
+                         m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d, m->d_bottom_flux[0], m->d_bottom_flux[1],
+                         (real)m->bottom_drag, i_first, n);
+    }
     const LazyCorr lz{m->corr[0].d, m->corr[1].d};
     if (m->uv_lazy && !(ahead && nx.fold && part == 0))
       return fail(m, GB25_ERR_STATE, "internal: uncorrected velocities in a step whose momentum kernel cannot correct them");
-    auto k5 = (m->uv_lazy && ahead) ? k_momentum_tendencies_v5<MW, TYm, true, false, false, true>
+    const bool drag = m->bottom_drag != 0;
+    auto k5 = drag ? (g.cv.on ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, true, false, true> : k_momentum_tendencies_v5<MW, TYm, false, true, true, false, true>)
+                      : m->immersed ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, false, false, true> : k_momentum_tendencies_v5<MW, TYm, false, true, false, false, true>)
+                                    : (ahead ? k_momentum_tendencies_v5<MW, TYm, true, false, false, false, true> : k_momentum_tendencies_v5<MW, TYm, false, false, false, false, true>))
+              : (m->uv_lazy && ahead) ? k_momentum_tendencies_v5<MW, TYm, true, false, false, true>
               : g.cv.on ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true, true>)
               : m->immersed ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true>)
                             : (ahead ? k_momentum_tendencies_v5<MW, TYm, true, false> : k_momentum_tendencies_v5<MW, TYm, false, false>);
@@ -1009,7 +1024,7 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
   }
   if (part == 1) return GB25_OK;   // the direct-stencil kernels are not split: everything after the halos arrived
   if (m->immersed || g.cv.on) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know neither immersed boundaries nor curvilinear grids");
-  if (g.top_flux[0] || g.top_flux[1]) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know no flux boundary conditions");
+  if (g.top_flux[0] || g.top_flux[1] || g.bottom_flux[0]) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know no flux boundary conditions");
   tile_grid(g, &nbx, &nb);
   dim3 b(TX, TY);
   {
@@ -1608,7 +1623,7 @@ gb25_status materialize_uv(gb25_model* m) {
 // may this step leave u, v uncorrected in memory?  Flat lat-lon single domain, both look-aheads on and able to write
 // their halos, the default kernels; `more`: another step of the same composite call follows
 inline bool lazy_corrector_ok(const gb25_model* m) {
-  return m->lazy_corrector && !m->coupled && m->two_streams && producers_fold(m) && !m->immersed && !m->g.cv.on && m->kernel_gen >= 2 &&
+  return m->lazy_corrector && !m->coupled && m->bottom_drag == 0 && m->two_streams && producers_fold(m) && !m->immersed && !m->g.cv.on && m->kernel_gen >= 2 &&
          m->ab2_ahead == 1 && !m->ptr_exposed && m->pressure_bits == 64;
 }
 
@@ -1970,6 +1985,8 @@ void gb25_destroy(gb25_model* m) {
   for (auto p : m->d_wideH)
     if (p) hipFree(p);
   for (auto p : m->d_wideM)
+    if (p) hipFree(p);
+  for (auto p : m->d_bottom_flux)
     if (p) hipFree(p);
   for (auto p : m->d_atm)
     if (p) hipFree(p);
@@ -2360,6 +2377,29 @@ gb25_status gb25_set_top_flux(gb25_model* m, gb25_field f, const void* host) {
   HIPCHK(hipMemcpy2D(m->d_top_flux[q] + (size_t)H * F.nx + H, (size_t)F.nx * sizeof(real), host, (size_t)nxi * sizeof(real),
                      (size_t)nxi * sizeof(real), nyi, hipMemcpyHostToDevice));
   m->g.top_flux[q] = m->d_top_flux[q];
+  return GB25_OK;
+}
+gb25_status gb25_set_bottom_drag(gb25_model* m, double Cd) {
+  CHECK_MODEL(m);
+  if (!(Cd >= 0)) return fail(m, GB25_ERR_INVALID_ARGUMENT, "the bottom drag coefficient must be >= 0");
+  if (gb25_status s = collective_guard(m, 11, 0, Cd)) return s;
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(m->side_stream));
+  const size_t n2 = (size_t)m->g.sx * m->g.sy_v;
+  for (int q = 0; q < 2; q++) {
+    if (Cd != 0 && !m->d_bottom_flux[q]) {
+      HIPCHK(hipMalloc(&m->d_bottom_flux[q], n2 * sizeof(real)));
+      HIPCHK(hipMemset(m->d_bottom_flux[q], 0, n2 * sizeof(real)));
+    }
+    m->g.bottom_flux[q] = Cd != 0 ? m->d_bottom_flux[q] : nullptr;
+  }
+  m->bottom_drag = Cd;
+  m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+  return GB25_OK;
+}
+gb25_status gb25_get_bottom_drag(const gb25_model* m, double* Cd) {
+  if (!m || !Cd) return GB25_ERR_INVALID_ARGUMENT;
+  *Cd = m->bottom_drag;
   return GB25_OK;
 }
 gb25_status gb25_get_top_flux(gb25_model* m, gb25_field f, void* host) {

@@ -92,7 +92,9 @@ struct UvAhead {
 // row: the y faces ON the fold line have a G_v (and, AHEAD, a v of the next step) like any other row.
 // LAZY: u, v in memory lack this step's barotropic correction (k_corrector_2d, kernels.hpp): it is added to every value
 // as it is loaded -- tile elements (their du, dv are k-independent: registers) and the own column's vertical window.
-template <int MINW, int V2_TY, bool AHEAD, bool IMM, bool CURV = false, bool LAZY = false>
+// DRAG: the quadratic bottom drag's flux boundary condition (Grid.bottom_flux) enters the first free level (an instance of its
+// own: the hook cost the default instances a few spilled registers)
+template <int MINW, int V2_TY, bool AHEAD, bool IMM, bool CURV = false, bool LAZY = false, bool DRAG = false>
 __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     Grid g, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ w,
     const real* __restrict__ dpx, const real* __restrict__ dpy, real* __restrict__ Gu, real* __restrict__ Gv,
@@ -516,6 +518,12 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
       const int o2 = i2(g, ic_, jc_);
       if (g.top_flux[0]) gu = gu - g.top_flux[0][o2] * rdz;
       if (g.top_flux[1] && j > 0) gv = gv - g.top_flux[1][o2] * rdz;
+    }
+    if (DRAG && g.bottom_flux[0] != nullptr) {
+      // quadratic bottom drag: the bottom flux boundary condition enters the first free level of the face's column
+      const int o2 = i2(g, ic_, jc_);
+      if (k == (IMM ? KPU : 0)) gu = gu + g.bottom_flux[0][o2] * rdz;
+      if (k == (IMM ? KPV : 0) && j > 0) gv = gv + g.bottom_flux[1][o2] * rdz;
     }
     if (IMM) {   // faces that touch the solid: no tendency (their velocity is masked and stays zero)
       if (k < KPU) gu = real(0.);

@@ -209,6 +209,13 @@ gb25_status gb25_set_top_flux(gb25_model *m, gb25_field f, const void *flux);
 /* the flux as the device holds it (same shape; what the coupled model last computed, or what the host set) */
 gb25_status gb25_get_top_flux(gb25_model *m, gb25_field f, void *flux);
 
+/* ---- quadratic bottom drag: what ClimaOcean's ocean_simulation (src/data_free_ocean_climate_model.jl:26) puts at the bottom
+ *      of u and v -- also the immersed bottom -- with bottom_drag_coefficient = 0.003: the flux boundary condition
+ *      J = -Cd u sqrt(u^2 + Ixy(v)^2) (likewise for v), evaluated before every tendency evaluation and added to the tendency of
+ *      the face's first free level.  Cd = 0 (the default; baroclinic_instability_model has none): no drag.  Collective. */
+gb25_status gb25_set_bottom_drag(gb25_model *m, double Cd);
+gb25_status gb25_get_bottom_drag(const gb25_model *m, double *Cd);
+
 /* ---- data-free forcing (src/data_free_ocean_climate_model.jl:12-70): a PrescribedAtmosphere + Radiation +
  *      SimilarityTheoryFluxes(solver_stop_criteria = FixedIterations(5)) coupled to the ocean as ClimaOcean's OceanSeaIceModel
  *      does.  The host evaluates the atmosphere at the ocean's cell centres (the reference: analytic fields on a 360 x 180

@@ -91,6 +91,10 @@ typedef struct {
    * field of the same horizontal location; J > 0 is a flux OUT of the domain through the surface (Oceananigans'
    * convention: top flux positive upward) */
   REAL *top_flux[4];
+  /* quadratic bottom drag (ClimaOcean's ocean_simulation: bottom_drag_coefficient = 0.003): the bottom flux boundary condition
+   * of u and v, J = -Cd |u| u at the first free level of the face's column, recomputed before every tendency evaluation */
+  REAL bottom_drag;
+  REAL *bottom_flux[2];
   /* PrescribedAtmosphere at the ocean's cell centres (data-free forcing, /root/reference/src/data_free_ocean_climate_model.jl):
    * u_a, v_a [m/s], T_a [K], q_a [kg/kg], p_a [Pa], downwelling shortwave and longwave [W/m2]; 2-D with the parent layout of a
    * (c,c) field, halo cells included (the host evaluates the analytic fields there too).  All seven set: coupled. */
@@ -504,6 +508,7 @@ void FN(destroy)(void *h) {
   free(m->dyff2); free(m->azcc2); free(m->azfc2); free(m->azcf2); free(m->azff2); free(m->fff2); free(m->phicc2);
   free(m->lamcc_d); free(m->phicc_d);
   for (int q = 0; q < 4; q++) free(m->top_flux[q]);
+  for (int q = 0; q < 2; q++) free(m->bottom_flux[q]);
   for (int q = 0; q < 7; q++) free(m->atm[q]);
   free(m->catke_params);
   free(m);
@@ -1029,9 +1034,54 @@ void FN(compute_tracer_tendencies)(void *h) {
 /* compute_hydrostatic_boundary_tendency_contributions!(Gn, arch, velocities, tracers, clock, fields, closure, buoyancy)
  * -- /root/reference/src/precompile.jl:25,52-61: flux boundary conditions enter the tendencies of the cells next to
  * the boundary; here the top ones (apply_z_top_bc!, restated): G[i,j,Nz] -= J Az / V. */
+static int first_free_level(const model *m, int which, int i, int j);
+/* Quadratic bottom drag, the bottom boundary condition ClimaOcean's ocean_simulation gives u and v (and their immersed
+ * bottoms): FluxBoundaryCondition(-Cd u sqrt(u^2 + Ixy(v)^2)) at (f,c,c), likewise for v at (c,f,c) [UPSTREAM-UNVERIFIED].
+ * The flux is positive upward, i.e. INTO the column through its bottom face: G[kbottom] += J / dz (apply_z_bottom_bc!). */
+static void compute_bottom_drag_fluxes(model *m) {
+  const REAL Cd = m->bottom_drag;
+  for (int q = 0; q < 2; q++)
+    if (!m->bottom_flux[q]) m->bottom_flux[q] = (REAL *)calloc((size_t)m->f[q ? F_GNV : F_GNU].sx * m->f[q ? F_GNV : F_GNU].sy, sizeof(REAL));
+  long sxu = m->f[F_GNU].sx, sxv = m->f[F_GNV].sx;
+#pragma omp parallel for schedule(static)
+  for (int j = 1; j <= NYV; j++)
+    for (int i = 1; i <= m->Nx; i++) {
+      if (j <= m->Ny) {
+        int k = first_free_level(m, 0, i, j);
+        REAL J = 0;
+        if (k <= m->Nz) {
+          REAL u = A3(F_U, i, j, k);
+          REAL vb = (A3(F_V, i - 1, j, k) + A3(F_V, i, j, k) + A3(F_V, i - 1, j + 1, k) + A3(F_V, i, j + 1, k)) / (REAL)4;
+          J = -Cd * u * (REAL)sqrt((double)(u * u + vb * vb));
+        }
+        m->bottom_flux[0][((long)i - 1 + HH) + sxu * ((long)j - 1 + HH)] = J;
+      }
+      {
+        int k = j >= 2 ? first_free_level(m, 1, i, j) : m->Nz + 1;
+        REAL J = 0;
+        if (k <= m->Nz) {
+          REAL v = A3(F_V, i, j, k);
+          REAL ub = (A3(F_U, i, j - 1, k) + A3(F_U, i + 1, j - 1, k) + A3(F_U, i, j, k) + A3(F_U, i + 1, j, k)) / (REAL)4;
+          J = -Cd * v * (REAL)sqrt((double)(v * v + ub * ub));
+        }
+        m->bottom_flux[1][((long)i - 1 + HH) + sxv * ((long)j - 1 + HH)] = J;
+      }
+    }
+}
+void FN(set_bottom_drag)(void *h, double Cd) { ((model *)h)->bottom_drag = (REAL)Cd; }
 void FN(compute_boundary_tendencies)(void *h) {
   model *m = (model *)h;
   const int gid[4] = {F_GNU, F_GNV, F_GNT, F_GNS};
+  if (m->bottom_drag != 0) {
+    compute_bottom_drag_fluxes(m);
+    long sxu = m->f[F_GNU].sx, sxv = m->f[F_GNV].sx;
+    for (int j = 1; j <= NYV; j++)
+      for (int i = 1; i <= m->Nx; i++) {
+        int ku = j <= m->Ny ? first_free_level(m, 0, i, j) : m->Nz + 1, kv = j >= 2 ? first_free_level(m, 1, i, j) : m->Nz + 1;
+        if (ku <= m->Nz) A3(F_GNU, i, j, ku) = A3(F_GNU, i, j, ku) + m->bottom_flux[0][((long)i - 1 + HH) + sxu * ((long)j - 1 + HH)] / DZC(ku);
+        if (kv <= m->Nz) A3(F_GNV, i, j, kv) = A3(F_GNV, i, j, kv) + m->bottom_flux[1][((long)i - 1 + HH) + sxv * ((long)j - 1 + HH)] / DZC(kv);
+      }
+  }
   for (int q = 0; q < 4; q++) {
     if (!m->top_flux[q]) continue;
     const fld *F = &m->f[gid[q]];

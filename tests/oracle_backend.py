@@ -250,6 +250,12 @@ class OracleBackend:
             return
         a = np.ascontiguousarray(np.asarray(J, dtype=np.float64).reshape(self.field_dims(name, False)[:2]).T)
         f(self.h, q, a.ctypes.data_as(C.c_void_p))
+    def set_bottom_drag(self, Cd):
+        f = self._fn("set_bottom_drag")
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_double]
+        f(self.h, float(Cd))
+
     def set_prescribed_atmosphere(self, name, values):
         f = self._fn("set_prescribed_atmosphere")
         f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

@@ -1,0 +1,68 @@
+"""Quadratic bottom drag on the HIP path against the oracle (tests/test_oracle_bottom_drag.py pins that one): tendencies,
+stepping on the three kinds of grid, slabs."""
+import numpy as np
+import pytest
+
+import gb25_amd as gb
+from helpers import SQRT_EPS32, make_pair, set_noisy_velocities
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    n = max(np.linalg.norm(a.ravel()), np.linalg.norm(b.ravel()))
+    return 0.0 if n == 0 else float(np.linalg.norm((a - b).ravel()) / n)
+
+
+@pytest.mark.parametrize("float_type", ["Float64", "Float32"])
+@pytest.mark.parametrize("grid_type", ["simple_lat_lon", "gaussian_islands_lat_lon", "gaussian_islands"])
+def test_stepping_with_bottom_drag_matches_the_oracle(grid_type, float_type):
+    r, v = make_pair(96, 44, 10, dt=300.0, float_type=float_type, grid_type=grid_type)
+    for m in (r, v):
+        gb.set_baroclinic_instability(m)
+        set_noisy_velocities(m, 0.2)
+        m.backend.set_bottom_drag(0.003)
+        gb.update_state(m)
+    # the drag is there: the bottom-level tendency differs from a drag-free evaluation
+    w = gb.baroclinic_instability_model(gb.GPU(float_type=float_type), 96, 44, 10, dt=300.0, grid_type=grid_type)
+    gb.set_baroclinic_instability(w)
+    set_noisy_velocities(w, 0.2)
+    gb.update_state(w)
+    assert rel(w.backend.get_field("Gn.u", False), r.backend.get_field("Gn.u", False)) > 1e-4
+    w.backend.close()
+    tol = 1e-9 if float_type == "Float64" else SQRT_EPS32
+    for n in ("Gn.u", "Gn.v"):
+        assert rel(r.backend.get_field(n, False), v.backend.get_field(n, False)) < tol, n
+    for m in (r, v):
+        gb.first_time_step(m)
+        gb.loop(m, 6)
+    _, report = gb.compare_states(r, v, rtol=SQRT_EPS32, include_halos=True, verbose=False)
+    bad = [(q["name"], q["rel"]) for q in report if not q["rel"] <= (1e-8 if float_type == "Float64" else SQRT_EPS32)]
+    assert not bad, bad
+    assert r.backend.bottom_drag() == 0.003
+
+
+@pytest.mark.parametrize("grid_type,gt", [("simple_lat_lon", 0), ("gaussian_islands", 4)])
+def test_bottom_drag_on_slabs_bit_for_bit(grid_type, gt):
+    from gb25_amd.distributed import LocalSlabEnsemble
+    Nx, Ny, Nz, dt, P = 192, 44, 10, 300.0, 3
+    m = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt, grid_type=grid_type)
+    gb.set_baroclinic_instability(m)
+    set_noisy_velocities(m, 0.2)
+    m.backend.set_bottom_drag(0.003)
+    init = {n: m.backend.get_field(n, False) for n in ("u", "v", "T", "S", "eta")}
+    gb.first_time_step(m)
+    gb.loop(m, 5)
+    ref = {n: m.backend.get_field(n, False) for n in ("u", "v", "T", "S", "eta", "U", "V", "Gn.u", "Gn.v")}
+    m.backend.close()
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, **(dict(grid_type=gt) if gt else {}))
+    for b in ens.backends:
+        b.set_bottom_drag(0.003)
+    for n, a in init.items():
+        ens.scatter(n, a)
+    ens.first_time_step()
+    ens.loop(5)
+    bad = [n for n, a in ref.items() if not np.array_equal(ens.gather(n), a)]
+    assert not bad, [(n, rel(ens.gather(n), ref[n])) for n in bad]
+    ens.close()

@@ -96,6 +96,7 @@ def test_coupled_slabs_are_the_single_domain_bit_for_bit():
     for r, b in enumerate(ens.backends):
         b.set_catke(True)
         b.set_catke_parameters(**gb.default_ocean_closure().parameters)
+        b.set_bottom_drag(0.003)
         lp = np.asarray(b.metric2("phicc"))[:, : Ny + 2 * H]
         for n in ATMOSPHERE_FIELDS:
             b.set_prescribed_atmosphere(n, atm.interpolate(n, np.zeros_like(lp), lp))
@@ -124,6 +125,7 @@ def test_rccl_self_ring_with_the_coupled_model():
     ring.grid_type = "gaussian_islands"
     ring.backend.set_catke(True)
     ring.backend.set_catke_parameters(**gb.default_ocean_closure().parameters)
+    ring.backend.set_bottom_drag(0.003)
     ring.enable_catke_fields()
     gb.set_prescribed_atmosphere(ring, gb.analytic_atmosphere())
     for n, a in init.items():
