@@ -2671,8 +2671,9 @@ int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int3
     ops.nsub = 3;
     ops.adopted = ops.ready = false;
   }
+  if (first & 4) ops.is_coupled = true;   // (bit 2: a coupled model -- data-free forcing)
+  bool in_flight = (first & 8) != 0;      // (bit 3: the previous step left the look-ahead chain in flight)
   first &= 1;
-  bool in_flight = false;
   if (first) sequence_first_time_step(ops, in_flight);
   else sequence_time_step(ops, 0, in_flight);
   ops.add("lookahead_in_flight %d", in_flight ? 1 : 0);

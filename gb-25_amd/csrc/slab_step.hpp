@@ -529,10 +529,11 @@ struct TraceOps : StepOps {
   int nslabs;
   bool adopted, ready;
   std::string log;
-  bool fold = false;
+  bool fold = false, is_coupled = false;
   int nsub = 21;
   TraceOps(int n_, bool a, bool r) : nslabs(n_), adopted(a), ready(r) {}
   bool folded() override { return fold; }
+  bool coupled() override { return is_coupled; }
   int substeps() override { return nsub; }
   void add(const char* fmt, ...) {
     char buf[96];

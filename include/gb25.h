@@ -330,7 +330,8 @@ gb25_status gb25_comm_finalize(gb25_model *m);
 /* velocities_ready: the momentum look-ahead of the next step exists (its sub-cycle can run beside the tracer kernel);
  * subcycle_adopted: the last step adopted the sub-cycle look-ahead instead of sub-cycling inside the step. */
 gb25_status gb25_lookahead_state(const gb25_model *m, int32_t *velocities_ready, int32_t *subcycle_adopted);
-/* The order of operations of one time step (first != 0: of first_time_step!) of `nslabs` slabs as text, without
+/* The order of operations of one time step (bit 0 of `first`: of first_time_step!; bit 1: on a folded grid; bit 2: of a
+ * coupled model; bit 3: with the previous step's look-ahead chain still in flight) of `nslabs` slabs as text, without
  * touching a GPU (tests of the sequencing on CPU-only machines).  Returns the bytes needed, incl. the terminator. */
 int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int32_t ready, char *out, int64_t cap);
 

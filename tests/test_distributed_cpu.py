@@ -172,3 +172,42 @@ def test_first_time_step_sequencing():
                                           ("update_state_local", "slab")]
     stages = [e for e in log if e[0] == "stage" and e[3] == 0]
     assert [e[1] for e in stages] == [0, 1, 2, 3, 4] and all(e[5] == 1 for e in stages)      # Euler first step
+
+
+def _raw_sequence(nslabs, first, adopted=0, ready=0):
+    lib = load_library("Float32")
+    need = lib.gb25_debug_sequence(nslabs, first, adopted, ready, None, 0)
+    buf = ctypes.create_string_buffer(need)
+    lib.gb25_debug_sequence(nslabs, first, adopted, ready, buf, need)
+    return [tuple(int(t) if t.lstrip("-").isdigit() else t for t in line.split()) for line in buf.value.decode().splitlines()]
+
+
+def test_first_time_step_of_a_coupled_model():
+    """Data-free forcing on slabs: after the ordinary update_state! every slab computes the atmosphere-ocean fluxes of the
+    initial state and its J^b, the 3-D bundle travels once more (J^b of the halo column), then the diffusivities and
+    tendencies that see the fluxes; only then the Euler step."""
+    log = _raw_sequence(2, 1 | 4)
+    names = [e[0] for e in log]
+    i_state = names.index("update_state_local")
+    i_flux = names.index("first_fluxes_local")
+    i_tend = names.index("tendencies_local")
+    ex0 = [i for i, e in enumerate(log) if e[:2] == ("exchange", 0)]
+    assert i_state < i_flux < i_tend and len(ex0) == 3                    # initial halos, J^b, the Euler step's bundle
+    assert i_flux < ex0[1] < i_tend < ex0[2]
+    plain = _raw_sequence(2, 1)
+    assert "first_fluxes_local" not in [e[0] for e in plain]
+
+
+def test_a_step_behind_a_look_ahead_chain_in_flight():
+    """The previous step left its look-ahead chain (group 3, stage 5) on the second stream: stage 0 does not wait for it;
+    the corrector (stage 2) does, through the event recorded behind the chain -- or, when the look-ahead is not adopted after
+    all, everything that reuses its buffers does."""
+    log = _raw_sequence(3, 8, adopted=1, ready=1)
+    idx = lambda *e: log.index(e)
+    w = idx("wait", 4, "main")
+    assert idx("stage", 0, "slab", 2, "euler", 0, "main") < w < idx("stage", 2, "slab", 0, "euler", 0, "main")
+    assert idx("exchange", 0, "comm") < w                                  # the bundle is on its way by then
+    assert ("record", 4, "comm") in log and log[-1] == ("lookahead_in_flight", 1)
+    log = _raw_sequence(3, 8, adopted=0, ready=0)
+    idx = lambda *e: log.index(e)
+    assert idx("stage", 0, "slab", 2, "euler", 0, "main") < idx("wait", 4, "main") < idx("pack", 1, "slab", 0, "main")
