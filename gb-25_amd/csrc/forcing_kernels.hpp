@@ -15,26 +15,31 @@
 struct Atmosphere {
   const double* a[7];   // u_a, v_a, T_a [K], q_a, p_a, shortwave, longwave: parent layout of a 2-D (c,c) field
 };
-__device__ __forceinline__ double ao_psi_c(double y) {
-  return 1.5 * log((1 + y + y * y) / 3) - sqrt(3.0) * atan((1 + 2 * y) / sqrt(3.0)) + 4 * atan(1.0) / sqrt(3.0);
+template <class F>
+__device__ __forceinline__ F ao_psi_c(F y) {
+  const F r3 = F(1.7320508075688772);
+  return F(1.5) * log((1 + y + y * y) / 3) - r3 * atan((1 + 2 * y) / r3) + F(3.141592653589793) / r3;
 }
-__device__ __forceinline__ double ao_psi_u(double z) {
+template <class F>
+__device__ __forceinline__ F ao_psi_u(F z) {
   if (z < 0) {
-    const double x = sqrt(sqrt(1 - 15 * z)), pk = 2 * log((1 + x) / 2) + log((1 + x * x) / 2) - 2 * atan(x) + 2 * atan(1.0);
-    const double f = z * z / (1 + z * z);
-    return (1 - f) * pk + f * ao_psi_c(cbrt(1 - 10.15 * z));
+    const F x = sqrt(sqrt(1 - 15 * z)), pk = 2 * log((1 + x) / 2) + log((1 + x * x) / 2) - 2 * atan(x) + F(1.5707963267948966);
+    const F f = z * z / (1 + z * z);
+    return (1 - f) * pk + f * ao_psi_c<F>(cbrt(1 - F(10.15) * z));
   }
-  const double dz = 0.35 * z < 50 ? 0.35 * z : 50;
-  return -(0.7 * z + 0.75 * (z - 5 / 0.35) * exp(-dz) + 0.75 * 5 / 0.35);
+  const F dz = F(0.35) * z < 50 ? F(0.35) * z : F(50);
+  return -(F(0.7) * z + F(0.75) * (z - F(5 / 0.35)) * exp(-dz) + F(0.75 * 5 / 0.35));
 }
-__device__ __forceinline__ double ao_psi_q(double z) {
+template <class F>
+__device__ __forceinline__ F ao_psi_q(F z) {
   if (z < 0) {
-    const double x = sqrt(1 - 15 * z), pk = 2 * log((1 + x) / 2);
-    const double f = z * z / (1 + z * z);
-    return (1 - f) * pk + f * ao_psi_c(cbrt(1 - 34.15 * z));
+    const F x = sqrt(1 - 15 * z), pk = 2 * log((1 + x) / 2);
+    const F f = z * z / (1 + z * z);
+    return (1 - f) * pk + f * ao_psi_c<F>(cbrt(1 - F(34.15) * z));
   }
-  const double dz = 0.35 * z < 50 ? 0.35 * z : 50;
-  return -(pow(1 + 2.0 / 3.0 * z, 1.5) + 2.0 / 3.0 * (z - 14.28) * exp(-dz) + 8.525);
+  const F dz = F(0.35) * z < 50 ? F(0.35) * z : F(50);
+  const F t = 1 + F(2.0 / 3.0) * z;
+  return -(t * sqrt(t) + F(2.0 / 3.0) * (z - F(14.28)) * exp(-dz) + F(8.525));
 }
 template <bool IMM>
 __global__ void k_similarity_fluxes(Grid g, Atmosphere A, const real* __restrict__ u, const real* __restrict__ v,
@@ -66,18 +71,29 @@ __global__ void k_similarity_fluxes(Grid g, Atmosphere A, const real* __restrict
   double U = sqrt(du * du + dv * dv + 0.2 * 0.2);
   const double chi0 = log(h / 1e-4);
   double us = kap * U / chi0, ths = kap * dth / chi0, qst = kap * dq / chi0;
-  for (int it = 0; it < iterations; it++) {
-    const double bs = grav / Tv * (ths * (1 + 0.608 * qa) + 0.608 * Ta * qst), Jb = -us * bs;
-    const double Ug = fmax(0.2, beta * cbrt(fmax(Jb, 0.0) * zi));
-    U = sqrt(du * du + dv * dv + Ug * Ug);
-    const double lu = charnock * us * us / grav + 0.11 * nu / us, lq = fmin(1.6e-4, 5.8e-5 / pow(lu * us / nu, 0.72));
-    double zeta = kap * h * bs / (us * us);
-    zeta = zeta > 50 ? 50 : (zeta < -50 ? -50 : zeta);
-    const double chiu = log(h / lu) - ao_psi_u(zeta) + ao_psi_u(zeta * lu / h);
-    const double chiq = log(h / lq) - ao_psi_q(zeta) + ao_psi_q(zeta * lq / h);
-    us = kap * U / chiu;
-    ths = kap * dth / chiq;
-    qst = kap * dq / chiq;
+  // The five iterations in the float type of the model (ClimaOcean iterates in it too): in Float32 the transcendental
+  // functions of the loop are single-precision ones, several times cheaper than their fp64 siblings (the kernel was
+  // 0.35 ms at 1440 x 720, all of it fp64 log / pow / atan / cbrt); thermodynamics and the fluxes themselves stay in fp64.
+  using F = real;
+  {
+    const F kapF = (F)kap, hF = (F)h, gravF = (F)grav, rTv = (F)(1 / Tv), qaF = (F)qa, TaF = (F)Ta;
+    const F duF = (F)du, dvF = (F)dv, dthF = (F)dth, dqF = (F)dq, nuF = (F)nu;
+    F usF = (F)us, thsF = (F)ths, qstF = (F)qst, UF = (F)U;
+    for (int it = 0; it < iterations; it++) {
+      const F bs = gravF * rTv * (thsF * (1 + F(0.608) * qaF) + F(0.608) * TaF * qstF), Jb = -usF * bs;
+      const F Ug = fmax(F(0.2), (F)beta * cbrt(fmax(Jb, F(0.)) * (F)zi));
+      UF = sqrt(duF * duF + dvF * dvF + Ug * Ug);
+      const F lu = (F)charnock * usF * usF / gravF + F(0.11) * nuF / usF;
+      const F lq = fmin(F(1.6e-4), F(5.8e-5) / pow(lu * usF / nuF, F(0.72)));
+      F zeta = kapF * hF * bs / (usF * usF);
+      zeta = zeta > 50 ? F(50) : (zeta < -50 ? F(-50) : zeta);
+      const F chiu = log(hF / lu) - ao_psi_u<F>(zeta) + ao_psi_u<F>(zeta * lu / hF);
+      const F chiq = log(hF / lq) - ao_psi_q<F>(zeta) + ao_psi_q<F>(zeta * lq / hF);
+      usF = kapF * UF / chiu;
+      thsF = kapF * dthF / chiq;
+      qstF = kapF * dqF / chiq;
+    }
+    us = (double)usF; ths = (double)thsF; qst = (double)qstF; U = (double)UF;
   }
   tx[o2] = rho_a * us * us * du / U;
   ty[o2] = rho_a * us * us * dv / U;
