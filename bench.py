@@ -24,7 +24,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # The step runs on three streams (main, side, comm) beside RCCL's own; with the runtime's default of four hardware queues
 # per process two of them end up sharing one (rocprofv3 timeline of tools/slab_selfring.py: the 10 us pack kernel of the
 # 3-D bundle queued behind the 60 us pressure kernel).  Eight queues: 0.77 -> 0.73 ms per step of a 180-column rank; no
-# measurable difference on the single GPU.  Read when the runtime starts; an exported value wins.
+# measurable difference on the single GPU.  (One model per process, as here.  P slabs stepped in ONE process -- the
+# LocalSlabEnsemble of the tests, 2 P + 2 streams -- run up to 1.6x slower with eight queues than with four: the Python
+# package itself leaves the runtime's default alone.)  Read when the runtime starts; an exported value wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np

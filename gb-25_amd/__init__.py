@@ -4,12 +4,6 @@ Public names mirror `GordonBell25` (GB-25 src/GordonBell25.jl:3-4 and the un-exp
 its scripts call); Julia's trailing `!` is dropped.  Kernels live in libgb25hip.so behind the
 C ABI of include/gb25.h; this package only sequences calls and moves host arrays.
 """
-import os as _os
-
-# (eight hardware queues instead of the runtime's four: the library's three streams and RCCL's then do not share one; see
-# bench.py.  Only effective if the HIP runtime has not started yet; an exported value wins.)
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 from .binding import GB25Error, HipBackend, LIB_PATH, load_library
 from .build import build_library
 from .correctness import approx_equal, compare_states, sync_states

@@ -5,6 +5,7 @@ the pack / unpack kernels, the widened sub-cycle and the exchanges are those of 
 missing.  Prints the wall time per step; under `rocprofv3 --kernel-trace` the trace is one rank's timeline.
 usage: slab_selfring.py [--columns 180] [--steps 200]"""
 import argparse, os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # as bench.py: one rank per process
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--columns", type=int, default=180)
