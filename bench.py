@@ -225,7 +225,7 @@ def main():
     # carries event records (50 event records per step cost ~3 % of the step, and only that kernel's duration is needed
     # live for the roofline).  Without warm-up steps everything is timed inside the timed region.
     names = ("fill_halos", "compute_w", "compute_p", "gu", "gv", "tracers", "ab2_velocities", "ab2_tracers",
-             "barotropic", "corrector")
+             "barotropic", "corrector", "implicit", "closure", "fluxes")
 
     def collect():
         out = {}

@@ -29,7 +29,8 @@ METRIC_IDS = {"phif": 0, "phic": 1, "dxc": 2, "dxf": 3, "azc": 4, "azf": 5, "fco
               "zf": 7, "zc": 8, "dzc": 9, "dzf": 10}
 ATMOSPHERE_IDS = {"u": 0, "v": 1, "T": 2, "q": 3, "p": 4, "shortwave": 5, "longwave": 6}
 KERNEL_IDS = {"fill_halos": 0, "compute_w": 1, "compute_p": 2, "gu": 3, "gv": 4, "tracers": 5,
-              "ab2_velocities": 6, "ab2_tracers": 7, "barotropic": 8, "corrector": 9}
+              "ab2_velocities": 6, "ab2_tracers": 7, "barotropic": 8, "corrector": 9, "implicit": 10, "closure": 11,
+              "fluxes": 12}
 
 # every symbol include/gb25.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [

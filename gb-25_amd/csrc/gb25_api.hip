@@ -1127,6 +1127,7 @@ gb25_status implicit_vertical_impl(gb25_model* m, int kind, real dt) {
   const Grid& g = m->g;
   const real K = (real)(kind == 0 ? m->nu : m->kappa);
   if (K == real(0.)) return GB25_OK;
+  Timed t_implicit(m, GB25_K_IMPLICIT);
   real *a = m->f[kind == 0 ? GB25_U : GB25_T].d, *b = m->f[kind == 0 ? GB25_V : GB25_S].d;
   real *sa = kind == 0 ? m->colsum[0].d : nullptr, *sb = kind == 0 ? m->colsum[1].d : nullptr;
   const int kchunks = mom_kchunks(m);
@@ -1483,6 +1484,7 @@ void catke_surface_flux_impl(gb25_model* m) {
 }
 gb25_status catke_update_impl(gb25_model* m) {
   if (!m->catke) return GB25_OK;
+  Timed t_closure(m, GB25_K_CLOSURE);
   const Grid& g = m->g;
   int nbx = (g.Nx + V3_OUT - 1) / V3_OUT;
   const int nby = (g.Ny + 3) / 4, kchunks = std::max(1, g.Nz / m->trc_chunk_levels);
@@ -1519,6 +1521,7 @@ gb25_status catke_update_impl(gb25_model* m) {
 // e with its AB2 update
 gb25_status catke_implicit_impl(gb25_model* m, int mode, real dt, real chi) {
   const Grid& g = m->g;
+  Timed t_implicit(m, GB25_K_IMPLICIT);
   ImplicitVarFields A{};
   A.f[0] = m->f[GB25_U].d; A.f[1] = m->f[GB25_V].d; A.f[2] = m->f[GB25_T].d; A.f[3] = m->f[GB25_S].d; A.f[4] = m->f[GB25_E].d;
   A.KU = m->f[GB25_KAPPA_U].d; A.KC = m->f[GB25_KAPPA_C].d; A.KE = m->f[GB25_KAPPA_E].d; A.Le = m->f[GB25_LE].d;
@@ -1560,6 +1563,7 @@ gb25_status catke_implicit_impl(gb25_model* m, int mode, real dt, real chi) {
 // theory per surface cell, then the top flux boundary conditions of u, v, T, S (allocated here if the host set none)
 gb25_status atmosphere_ocean_fluxes_impl(gb25_model* m) {
   if (!m->coupled) return GB25_OK;
+  Timed t_fluxes(m, GB25_K_FLUXES);
   const Grid& g = m->g;
   const size_t n2 = (size_t)g.sx * g.sy_v;
   for (int q = 0; q < 4; q++) {

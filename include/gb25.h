@@ -146,7 +146,11 @@ typedef enum {
 /* Kernel identifiers for the built-in HIP-event timers (gb25_profile_*). */
 typedef enum {
   GB25_K_FILL_HALOS = 0, GB25_K_COMPUTE_W, GB25_K_COMPUTE_P, GB25_K_GU, GB25_K_GV, GB25_K_TRACERS,
-  GB25_K_AB2_VELOCITIES, GB25_K_AB2_TRACERS, GB25_K_BAROTROPIC, GB25_K_CORRECTOR, GB25_K_COUNT
+  GB25_K_AB2_VELOCITIES, GB25_K_AB2_TRACERS, GB25_K_BAROTROPIC, GB25_K_CORRECTOR,
+  GB25_K_IMPLICIT,     /* implicit_step!: the vertical solves of a closure (all of a step's launches together)        */
+  GB25_K_CLOSURE,      /* CATKE: advection of e, surface flux, diffusivities                                          */
+  GB25_K_FLUXES,       /* data-free forcing: similarity-theory fluxes; the bottom drag's flux kernel                   */
+  GB25_K_COUNT
 } gb25_kernel;
 
 void gb25_default_config(gb25_config *cfg, int32_t Nx, int32_t Ny, int32_t Nz);
