@@ -95,6 +95,7 @@ typedef struct {
    * of u and v, J = -Cd |u| u at the first free level of the face's column, recomputed before every tendency evaluation */
   REAL bottom_drag;
   REAL *bottom_flux[2];
+  int tracer_order; /* tracer_advection = WENO(order = 5) (0 or 5: baroclinic_instability_model) | 7 (ClimaOcean's ocean_simulation) */
   /* PrescribedAtmosphere at the ocean's cell centres (data-free forcing, /root/reference/src/data_free_ocean_climate_model.jl):
    * u_a, v_a [m/s], T_a [K], q_a [kg/kg], p_a [Pa], downwelling shortwave and longwave [W/m2]; 2-D with the parent layout of a
    * (c,c) field, halo cells included (the host evaluates the analytic fields there too).  All seven set: coupled. */
@@ -678,6 +679,41 @@ double FN(weno3)(double b, double c, double d) {
   return (double)weno3_combine(v, beta3(v[2], v[3]), beta3(v[1], v[2]));
 }
 
+/* WENO(order = 7) (ClimaOcean's ocean_simulation: tracer_advection = WENO(order = 7)) [UPSTREAM-UNVERIFIED: the
+ * reconstruction polynomials, linear weights and smoothness indicators are those of Balsara & Shu (2000) for uniform
+ * spacing, with Z-weights tau_7 = |beta_0 + 3 beta_1 - 3 beta_2 - beta_3| as Oceananigans' global smoothness indicator of
+ * buffer 4].  v[0..6]: upwind-most .. downwind-most, the face between v[3] and v[4]; stencil r uses v[3-r .. 6-r]. */
+static inline REAL weno7_combine(const REAL *v) {
+  const REAL a = v[0], b = v[1], c = v[2], d = v[3], e = v[4], f = v[5], g = v[6];
+  REAL p0 = ((REAL)3 * d + (REAL)13 * e - (REAL)5 * f + g) / (REAL)12;
+  REAL p1 = (-c + (REAL)7 * d + (REAL)7 * e - f) / (REAL)12;
+  REAL p2 = (b - (REAL)5 * c + (REAL)13 * d + (REAL)3 * e) / (REAL)12;
+  REAL p3 = ((REAL)-3 * a + (REAL)13 * b - (REAL)23 * c + (REAL)25 * d) / (REAL)12;
+  REAL b0 = d * ((REAL)2107 * d - (REAL)9402 * e + (REAL)7042 * f - (REAL)1854 * g) + e * ((REAL)11003 * e - (REAL)17246 * f + (REAL)4642 * g) +
+            f * ((REAL)7043 * f - (REAL)3882 * g) + (REAL)547 * g * g;
+  REAL b1 = c * ((REAL)547 * c - (REAL)2522 * d + (REAL)1922 * e - (REAL)494 * f) + d * ((REAL)3443 * d - (REAL)5966 * e + (REAL)1602 * f) +
+            e * ((REAL)2843 * e - (REAL)1642 * f) + (REAL)267 * f * f;
+  REAL b2 = b * ((REAL)267 * b - (REAL)1642 * c + (REAL)1602 * d - (REAL)494 * e) + c * ((REAL)2843 * c - (REAL)5966 * d + (REAL)1922 * e) +
+            d * ((REAL)3443 * d - (REAL)2522 * e) + (REAL)547 * e * e;
+  REAL b3 = a * ((REAL)547 * a - (REAL)3882 * b + (REAL)4642 * c - (REAL)1854 * d) + b * ((REAL)7043 * b - (REAL)17246 * c + (REAL)7042 * d) +
+            c * ((REAL)11003 * c - (REAL)9402 * d) + (REAL)2107 * d * d;
+  REAL tau = (REAL)fabs((double)(b0 + (REAL)3 * b1 - (REAL)3 * b2 - b3));
+  b0 = (b0 > 0 ? b0 : 0) + WENO_EPS; b1 = (b1 > 0 ? b1 : 0) + WENO_EPS; b2 = (b2 > 0 ? b2 : 0) + WENO_EPS; b3 = (b3 > 0 ? b3 : 0) + WENO_EPS;
+  REAL bmin = b0 < b1 ? b0 : b1;
+  bmin = bmin < b2 ? bmin : b2;
+  bmin = bmin < b3 ? bmin : b3;
+  REAL q = zq(tau, bmin);
+  REAL r0 = q * (bmin / b0), r1 = q * (bmin / b1), r2 = q * (bmin / b2), r3 = q * (bmin / b3);
+  REAL a0 = (REAL)(4.0 / 35.0) * ((REAL)1 + r0 * r0), a1 = (REAL)(18.0 / 35.0) * ((REAL)1 + r1 * r1),
+       a2 = (REAL)(12.0 / 35.0) * ((REAL)1 + r2 * r2), a3 = (REAL)(1.0 / 35.0) * ((REAL)1 + r3 * r3);
+  return (a0 * p0 + a1 * p1 + a2 * p2 + a3 * p3) / (a0 + a1 + a2 + a3);
+}
+double FN(weno7)(const double *u) {
+  REAL v[7];
+  for (int q = 0; q < 7; q++) v[q] = (REAL)u[q];
+  return (double)weno7_combine(v);
+}
+
 /* ---------------------------------------------------------------- stencil functions */
 typedef REAL (*fn3)(const model *, int, int, int);
 static REAL f_u(const model *m, int i, int j, int k) { return A3(F_U, i, j, k); }
@@ -745,6 +781,20 @@ static int stencil_active(const model *m, int dir, int target, int i, int j, int
     }
   }
   return 1;
+}
+static int stencil_active(const model *m, int dir, int target, int i, int j, int k, int buffer);
+/* WENO(order = 7) to a face, self-smoothness (the tracer fluxes of an ocean_simulation); falls back to the order-5 path
+ * below where the eight-point stencil meets a wall or the immersed boundary */
+static int weno7_applies(const model *m, int dir, int i, int j, int k) {
+  return m->tracer_order == 7 && ((dir == DX && !m->immersed) || stencil_active(m, dir, TO_FACE, i, j, k, 4));
+}
+static REAL biased_interp(const model *m, int dir, int target, int i, int j, int k, int left, fn3 psi, fn3 s1, fn3 s2);
+static REAL tracer_interp(const model *m, int dir, int i, int j, int k, int left, fn3 c) {
+  if (!weno7_applies(m, dir, i, j, k)) return biased_interp(m, dir, TO_FACE, i, j, k, left, c, NULL, NULL);
+  int idx = dir == DX ? i : dir == DY ? j : k, c0 = left ? idx - 1 : idx, sg = left ? 1 : -1;
+  REAL v[7];
+  for (int q = -3; q <= 3; q++) v[q + 3] = at_dir(m, c, dir, i, j, k, c0 + sg * q);
+  return weno7_combine(v);
 }
 static REAL biased_interp(const model *m, int dir, int target, int i, int j, int k, int left, fn3 psi, fn3 s1, fn3 s2) {
   int idx = dir == DX ? i : dir == DY ? j : k;
@@ -1006,13 +1056,13 @@ void FN(compute_momentum_tendencies)(void *h) {
 static REAL tracer_flux(const model *m, int dir, int i, int j, int k, fn3 c) {
   if (dir == DX) {
     REAL u = A3(F_U, i, j, k);
-    return DYFC(i, j) * DZC(k) * u * biased_interp(m, DX, TO_FACE, i, j, k, u > 0, c, NULL, NULL);
+    return DYFC(i, j) * DZC(k) * u * tracer_interp(m, DX, i, j, k, u > 0, c);
   } else if (dir == DY) {
     REAL v = A3(F_V, i, j, k);
-    return DXCF(i, j) * DZC(k) * v * biased_interp(m, DY, TO_FACE, i, j, k, v > 0, c, NULL, NULL);
+    return DXCF(i, j) * DZC(k) * v * tracer_interp(m, DY, i, j, k, v > 0, c);
   } else {
     REAL w = A3(F_W, i, j, k);
-    return AZCC(i, j) * w * biased_interp(m, DZ, TO_FACE, i, j, k, w > 0, c, NULL, NULL);
+    return AZCC(i, j) * w * tracer_interp(m, DZ, i, j, k, w > 0, c);
   }
 }
 static void tracer_tendency(model *m, int gid, fn3 c) {
@@ -1069,6 +1119,7 @@ static void compute_bottom_drag_fluxes(model *m) {
     }
 }
 void FN(set_bottom_drag)(void *h, double Cd) { ((model *)h)->bottom_drag = (REAL)Cd; }
+void FN(set_tracer_advection_order)(void *h, int order) { ((model *)h)->tracer_order = order; }
 void FN(compute_boundary_tendencies)(void *h) {
   model *m = (model *)h;
   const int gid[4] = {F_GNU, F_GNV, F_GNT, F_GNS};
