@@ -181,6 +181,7 @@ def main():
             if args.data_free:
                 model.backend.set_catke_parameters(**gb.default_ocean_closure().parameters)
                 model.backend.set_bottom_drag(0.003)
+                model.backend.set_tracer_advection_order(7)
             model.enable_catke_fields()
         elif args.closure:
             model.backend.set_vertical_diffusivity(*map(float, args.closure.split(",")))
@@ -209,7 +210,8 @@ def main():
     if args.data_free:
         model.grid_type = "gaussian_islands"
         if world == 1:
-            model.backend.set_bottom_drag(0.003)   # ocean_simulation's default
+            model.backend.set_bottom_drag(0.003)   # ocean_simulation's defaults
+            model.backend.set_tracer_advection_order(7)
         gb.set_data_free_state(model)        # T = Ti, S = Si and the analytic atmosphere: coupled
     else:
         gb.set_baroclinic_instability(model)
@@ -277,7 +279,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if (args.weak and world > 1) else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"baroclinic_instability_model {gNx}x{Ny}x{Nz} {GRID_NAMES[args.grid_type]}, "
-                                   f"halo 8, SplitExplicit(30), WENO5, TEOS10, dt={args.dt:g}s"
+                                   f"halo 8, SplitExplicit(30), {'WENO5 momentum / WENO7 tracers' if args.data_free else 'WENO5'}, TEOS10, dt={args.dt:g}s"
                                    + (f", closure {args.closure}" if args.closure else "")
                                    + (", data-free forcing (similarity-theory fluxes every step)" if args.data_free else ""),
                        "grid": [gNx, Ny, Nz], "cells_per_gpu": cells, "local_columns": locNx,

@@ -40,7 +40,8 @@ ABI_SYMBOLS = [
     "gb25_field_device_ptr", "gb25_get_metric", "gb25_get_metric2", "gb25_get_substepping", "gb25_set_vertical_diffusivity",
     "gb25_get_vertical_diffusivity", "gb25_set_closure_catke", "gb25_set_prescribed_atmosphere",
     "gb25_compute_atmosphere_ocean_fluxes", "gb25_get_top_flux", "gb25_default_catke_parameters",
-    "gb25_set_catke_parameters", "gb25_get_catke_parameters", "gb25_set_bottom_drag", "gb25_get_bottom_drag",
+    "gb25_set_catke_parameters", "gb25_get_catke_parameters", "gb25_set_bottom_drag", "gb25_get_bottom_drag", "gb25_set_tracer_advection_order",
+    "gb25_get_tracer_advection_order",
     "gb25_set_baroclinic_instability",
     "gb25_get_clock", "gb25_set_dt", "gb25_initialize", "gb25_mask_immersed_fields",
     "gb25_fill_halo_regions", "gb25_compute_auxiliaries", "gb25_fill_diffusivity_halos",
@@ -147,6 +148,8 @@ def load_library(float_type="Float32"):
     lib.gb25_get_metric2.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.c_int64]
     lib.gb25_set_vertical_diffusivity.argtypes = [P, C.c_double, C.c_double]
     lib.gb25_set_closure_catke.argtypes = [P, C.c_int32]
+    lib.gb25_set_tracer_advection_order.argtypes = [P, C.c_int32]
+    lib.gb25_get_tracer_advection_order.argtypes = [P, C.POINTER(C.c_int32)]
     lib.gb25_set_bottom_drag.argtypes = [P, C.c_double]
     lib.gb25_get_bottom_drag.argtypes = [P, C.POINTER(C.c_double)]
     lib.gb25_default_catke_parameters.argtypes = [C.POINTER(CatkeParameters)]
@@ -296,6 +299,15 @@ class HipBackend:
 
     def set_vertical_diffusivity(self, nu, kappa):
         self._call("gb25_set_vertical_diffusivity", float(nu), float(kappa))
+
+    def set_tracer_advection_order(self, order):
+        """tracer_advection = WENO(order = 5) (the default) or WENO(order = 7) (ClimaOcean's ocean_simulation)."""
+        self._call("gb25_set_tracer_advection_order", int(order))
+
+    def tracer_advection_order(self):
+        v = C.c_int32()
+        self._call("gb25_get_tracer_advection_order", C.byref(v))
+        return v.value
 
     def set_bottom_drag(self, Cd):
         """Quadratic bottom drag coefficient (ClimaOcean's ocean_simulation: 0.003); 0: none."""

@@ -38,9 +38,12 @@ __device__ __forceinline__ double rtanh(double x) { return tanh(x); }
 //   static column depths at the faces (min of the two columns) and their reciprocals (0 where there is no depth)
 struct Immersed {
   const unsigned *ordA, *ordB, *ordC;
+  const unsigned* ordD;   // WENO(order = 7) tracer advection: first level from which the eight-cell stencil of the x face /
+                          // the y face is fully active (bits 0-7 / 8-15)
   const real *Hfc, *Hcf, *rHfc, *rHcf;
 };
 __device__ __forceinline__ int order_from(int k, int K5, int K3) { return k >= K5 ? 5 : (k >= K3 ? 3 : 1); }
+__device__ __forceinline__ int order_from7(int k, int K7, int K5, int K3) { return k >= K7 ? 7 : order_from(k, K5, K3); }
 
 // Orthogonal curvilinear grid (the TripolarGrid of GB-25 src/model_utils.jl:134-137): horizontal metrics by location,
 // 2-D arrays with the parent layout of a (c,f) field (pitch sx, Ny+2H+1 rows), Oceananigans' names (dxfc = Δxᶠᶜᵃ ...),
@@ -236,6 +239,41 @@ __device__ __forceinline__ T biased6(int order, bool left, const T* q, const T* 
   return weno5_combine(a, b, c, d, e, b0, b1, b2);
 }
 
+// WENO(order = 7), self-smoothness (tracer fluxes of ClimaOcean's ocean_simulation): candidate polynomials, linear weights and
+// smoothness indicators of Balsara & Shu (2000), Z-weights with tau_7 = |b0 + 3 b1 - 3 b2 - b3| (oracle: weno7_combine).
+// a..g: upwind-most .. downwind-most, the face between d and e.  The indicators are translation invariant and are
+// evaluated on the values minus d: in Float32 the expanded quadratic forms (coefficients up to 17246) would otherwise
+// cancel eight digits of T^2 ~ 1e3.
+template <class T>
+__device__ __forceinline__ T weno7(T a, T b, T c, T d, T e, T f, T g) {
+  const T p0 = real(3.) * d + real(13.) * e - real(5.) * f + g;          // 12 x the candidate polynomials
+  const T p1 = real(7.) * (d + e) - (c + f);
+  const T p2 = b - real(5.) * c + real(13.) * d + real(3.) * e;
+  const T p3 = real(25.) * d - real(23.) * c + real(13.) * b - real(3.) * a;
+  const T A = a - d, B = b - d, C = c - d, E = e - d, F = f - d, G = g - d;   // (D = 0)
+  T b0 = E * (real(11003.) * E - real(17246.) * F + real(4642.) * G) + F * (real(7043.) * F - real(3882.) * G) + real(547.) * G * G;
+  T b1 = C * (real(547.) * C + real(1922.) * E - real(494.) * F) + E * (real(2843.) * E - real(1642.) * F) + real(267.) * F * F;
+  T b2 = B * (real(267.) * B - real(1642.) * C - real(494.) * E) + C * (real(2843.) * C + real(1922.) * E) + real(547.) * E * E;
+  T b3 = A * (real(547.) * A - real(3882.) * B + real(4642.) * C) + B * (real(7043.) * B - real(17246.) * C) + real(11003.) * C * C;
+  const T tau = rabs(b0 + real(3.) * b1 - real(3.) * b2 - b3);
+  b0 = rmax(b0, T(real(0.))) + kWenoEps; b1 = rmax(b1, T(real(0.))) + kWenoEps;
+  b2 = rmax(b2, T(real(0.))) + kWenoEps; b3 = rmax(b3, T(real(0.))) + kWenoEps;
+  const T bmin = rmin(rmin(b0, b1), rmin(b2, b3));
+  const T i0 = rcp(b0), i1 = rcp(b1), i2 = rcp(b2), i3 = rcp(b3);
+  const T qb = rmin(tau * rmax(rmax(i0, i1), rmax(i2, i3)), kZCap) * bmin;
+  const T r0 = qb * i0, r1 = qb * i1, r2 = qb * i2, r3 = qb * i3;
+  const T a0 = real(4. / 35.) * r0 * r0 + real(4. / 35.), a1 = real(18. / 35.) * r1 * r1 + real(18. / 35.);
+  const T a2 = real(12. / 35.) * r2 * r2 + real(12. / 35.), a3 = real(1. / 35.) * r3 * r3 + real(1. / 35.);
+  return (a0 * p0 + a1 * p1 + a2 * p2 + a3 * p3) * (rcp(a0 + a1 + a2 + a3) * (real(1.) / real(12.)));
+}
+// Upwind-biased reconstruction to a face from eight consecutive values w[0..7] (cells f-4 .. f+3); order in {7, 5, 3, 1}: the
+// lower orders are those of biased6 on the inner six.
+template <class T = real>
+__device__ __forceinline__ T biased8(int order, bool left, const T* w) {
+  if (order != 7) return biased6<false, T>(order, left, w + 1, w + 1, w + 1);
+  return left ? weno7(w[0], w[1], w[2], w[3], w[4], w[5], w[6]) : weno7(w[7], w[6], w[5], w[4], w[3], w[2], w[1]);
+}
+
 // Two reconstructions of the same order at once, one per half of the pair, each with its own upwind direction
 // (l0 for .x, l1 for .y).  Used where two different quantities of one cell share stencil shape and order.
 __device__ __forceinline__ real2v pick(bool l0, bool l1, real2v a, real2v b) { return v2(l0 ? a.x : b.x, l1 ? a.y : b.y); }
@@ -307,6 +345,7 @@ __device__ __forceinline__ void bstore(const Buf& b, int voff, int soff, double 
 __device__ __forceinline__ int biased_order_face(int f, int N) {
   return (f >= 3 && f <= N - 3) ? 5 : ((f >= 2 && f <= N - 2) ? 3 : 1);
 }
+__device__ __forceinline__ int biased_order_face7(int f, int N) { return (f >= 4 && f <= N - 4) ? 7 : biased_order_face(f, N); }
 __device__ __forceinline__ int biased_order_center(int c, int N) {
   return (c >= 2 && c <= N - 3) ? 5 : ((c >= 1 && c <= N - 2) ? 3 : 1);
 }

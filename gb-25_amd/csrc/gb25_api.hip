@@ -124,7 +124,7 @@ struct gb25_model {
   bool immersed = false;             // some cell is immersed: the IMM kernel variants run
   int kb_E = 0;
   std::vector<int> kbot;
-  unsigned* d_ord[3] = {nullptr, nullptr, nullptr};
+  unsigned* d_ord[4] = {nullptr, nullptr, nullptr, nullptr};
   real* d_H[4] = {nullptr, nullptr, nullptr, nullptr};   // Hfc, Hcf, rHfc, rHcf (parent layout of a (c,f) field)
   real* d_wideH[2] = {nullptr, nullptr};                 // Hfc, Hcf on the wide barotropic layout of a slab
   // curvilinear slab: dyfc, dxcf, 1/azcc, 1/dxfc, 1/dycf on the wide barotropic layout, and (zipper fold) the metrics of
@@ -136,6 +136,7 @@ struct gb25_model {
   double* d_atm[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double* d_tau[2] = {nullptr, nullptr};
   bool coupled = false;
+  int tracer_order = 5;              // tracer_advection = WENO(order = 5 | 7)
   double bottom_drag = 0.0;          // quadratic bottom drag coefficient (0: none); the two flux arrays behind Grid.bottom_flux
   real* d_bottom_flux[2] = {nullptr, nullptr};
   bool halo_colsum_valid = false;    // slab: the x-halo columns of colsum hold their owner's integrals (packed with group 0)
@@ -646,7 +647,7 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
     return (double)(real)zf[offk + Nz] - (double)(real)zf[offk + kb];
   };
   const int sx = Nx + 2 * H, sy = Ny + 2 * H + 1;
-  std::vector<unsigned> A((size_t)sx * sy, 0), B(A.size(), 0), C(A.size(), 0);
+  std::vector<unsigned> A((size_t)sx * sy, 0), B(A.size(), 0), C(A.size(), 0), D(A.size(), 0);
   std::vector<real> Hf(A.size(), 0), Hc(A.size(), 0), rHf(A.size(), 0), rHc(A.size(), 0);
   for (int j = 0; j <= Ny; j++)
     for (int i = -H; i < Nx + H; i++) {
@@ -663,6 +664,9 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
       A[o] = (unsigned)kc | (unsigned)KX5 << 8 | (unsigned)KX3 << 16 | (unsigned)KY5 << 24;
       B[o] = (unsigned)KY3 | (unsigned)KXC5 << 8 | (unsigned)KXC3 << 16 | (unsigned)KYC5 << 24;
       C[o] = (unsigned)KYC3 | (unsigned)std::min(KPU, 255) << 8 | (unsigned)KPV << 16;
+      int KX7 = 0, KY7 = 0;   // WENO(order = 7) tracer advection: the eight cells around the x face / the y face
+      for (int q = -4; q <= 3; q++) { KX7 = std::max(KX7, thr(i + q, j)); KY7 = std::max(KY7, thr(i, j + q)); }
+      D[o] = (unsigned)std::min(KX7, 255) | (unsigned)std::min(KY7, 255) << 8;
       const double hf = std::min(depth(i - 1, j), depth(i, j)), hc = std::min(depth(i, j - 1), depth(i, j));
       Hf[o] = (real)hf;
       Hc[o] = (real)hc;
@@ -679,11 +683,12 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
   if ((s = upload(A.data(), A.size() * sizeof(unsigned), (void**)&m->d_ord[0]))) return s;
   if ((s = upload(B.data(), B.size() * sizeof(unsigned), (void**)&m->d_ord[1]))) return s;
   if ((s = upload(C.data(), C.size() * sizeof(unsigned), (void**)&m->d_ord[2]))) return s;
+  if ((s = upload(D.data(), D.size() * sizeof(unsigned), (void**)&m->d_ord[3]))) return s;
   if ((s = upload(Hf.data(), Hf.size() * sizeof(real), (void**)&m->d_H[0]))) return s;
   if ((s = upload(Hc.data(), Hc.size() * sizeof(real), (void**)&m->d_H[1]))) return s;
   if ((s = upload(rHf.data(), rHf.size() * sizeof(real), (void**)&m->d_H[2]))) return s;
   if ((s = upload(rHc.data(), rHc.size() * sizeof(real), (void**)&m->d_H[3]))) return s;
-  m->g.im.ordA = m->d_ord[0]; m->g.im.ordB = m->d_ord[1]; m->g.im.ordC = m->d_ord[2];
+  m->g.im.ordA = m->d_ord[0]; m->g.im.ordB = m->d_ord[1]; m->g.im.ordC = m->d_ord[2]; m->g.im.ordD = m->d_ord[3];
   m->g.im.Hfc = m->d_H[0]; m->g.im.Hcf = m->d_H[1]; m->g.im.rHfc = m->d_H[2]; m->g.im.rHcf = m->d_H[3];
   if (m->slab) {   // the same depths on the widened barotropic slab: columns [-W, Nx + W)
     const int W = m->W, wsx = Nx + 2 * W;
@@ -782,7 +787,7 @@ Halo2 halo2_G(gb25_model* m) {   // the barotropic forcing G.U, G.V
 // the zipper fold, whose images live in other threads' columns, and not with a closure (the implicit solve comes after
 // the look-aheads' writes)
 inline bool producers_fold(const gb25_model* m) {
-  return !m->slab && m->fold_fills && !m->g.cv.north_fold && m->nu == 0 && m->kappa == 0 && !m->catke;
+  return !m->slab && m->fold_fills && !m->g.cv.north_fold && m->nu == 0 && m->kappa == 0 && !m->catke && m->tracer_order == 5;
 }
 // rows of y faces that are stepped: the fold line is one
 inline int v_rows(const Grid& g) { return g.Ny + g.cv.north_fold; }
@@ -1062,7 +1067,12 @@ gb25_status tracers_impl(gb25_model* m) {
     const LazyCorr lz{m->corr[0].d, m->corr[1].d};
     if (m->uv_lazy && !(ahead && fold))
       return fail(m, GB25_ERR_STATE, "internal: uncorrected velocities in a step whose tracer kernel cannot correct them");
-    auto kern = (m->uv_lazy && ahead && fold) ? k_tracer_tendencies_v5<TW, true, false, true, false, true>
+    constexpr int TW7 = sizeof(real) == 8 ? 2 : 3;   // (the order-7 windows: 9 register pairs per direction)
+    auto kern = m->tracer_order == 7
+                    ? (g.cv.on ? (ahead ? k_tracer_tendencies_v5<TW7, true, true, false, true, false, 7> : k_tracer_tendencies_v5<TW7, false, true, false, true, false, 7>)
+                       : m->immersed ? (ahead ? k_tracer_tendencies_v5<TW7, true, true, false, false, false, 7> : k_tracer_tendencies_v5<TW7, false, true, false, false, false, 7>)
+                                     : (ahead ? k_tracer_tendencies_v5<TW7, true, false, false, false, false, 7> : k_tracer_tendencies_v5<TW7, false, false, false, false, false, 7>))
+                : (m->uv_lazy && ahead && fold) ? k_tracer_tendencies_v5<TW, true, false, true, false, true>
                 : g.cv.on ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false, true>)
                                  : k_tracer_tendencies_v5<TW, false, true, false, true>)
                 : m->immersed ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false>)
@@ -1492,7 +1502,12 @@ gb25_status catke_update_impl(gb25_model* m) {
   constexpr int TW = sizeof(real) == 8 ? 3 : 5;
   Ab2Ahead none{};
   const LazyCorr lz{nullptr, nullptr};
-  auto kt = g.cv.on       ? k_tracer_tendencies_v5<TW, false, true, false, true>
+  constexpr int TW7 = sizeof(real) == 8 ? 2 : 3;
+  auto kt = m->tracer_order == 7
+                ? (g.cv.on       ? k_tracer_tendencies_v5<TW7, false, true, false, true, false, 7>
+                   : m->immersed ? k_tracer_tendencies_v5<TW7, false, true, false, false, false, 7>
+                                 : k_tracer_tendencies_v5<TW7, false, false, false, false, false, 7>)
+            : g.cv.on       ? k_tracer_tendencies_v5<TW, false, true, false, true>
             : m->immersed ? k_tracer_tendencies_v5<TW, false, true, false>
                           : k_tracer_tendencies_v5<TW, false, false, false>;
   Grid ge = g;                                   // (the top fluxes of T, S are not e's: its surface flux comes below)
@@ -1627,7 +1642,7 @@ gb25_status materialize_uv(gb25_model* m) {
 // may this step leave u, v uncorrected in memory?  Flat lat-lon single domain, both look-aheads on and able to write
 // their halos, the default kernels; `more`: another step of the same composite call follows
 inline bool lazy_corrector_ok(const gb25_model* m) {
-  return m->lazy_corrector && !m->coupled && m->bottom_drag == 0 && m->two_streams && producers_fold(m) && !m->immersed && !m->g.cv.on && m->kernel_gen >= 2 &&
+  return m->lazy_corrector && !m->coupled && m->bottom_drag == 0 && m->tracer_order == 5 && m->two_streams && producers_fold(m) && !m->immersed && !m->g.cv.on && m->kernel_gen >= 2 &&
          m->ab2_ahead == 1 && !m->ptr_exposed && m->pressure_bits == 64;
 }
 
@@ -2399,6 +2414,22 @@ gb25_status gb25_set_bottom_drag(gb25_model* m, double Cd) {
   }
   m->bottom_drag = Cd;
   m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+  return GB25_OK;
+}
+gb25_status gb25_set_tracer_advection_order(gb25_model* m, int32_t order) {
+  CHECK_MODEL(m);
+  if (order != 5 && order != 7) return fail(m, GB25_ERR_INVALID_ARGUMENT, "tracer_advection = WENO(order = 5) or WENO(order = 7), not %d", order);
+  if (order == 7 && m->cfg.halo < 4) return fail(m, GB25_ERR_INVALID_ARGUMENT, "WENO(order = 7) needs a halo of at least 4");
+  if (order == 7 && m->kernel_gen < 2) return fail(m, GB25_ERR_STATE, "the direct-stencil kernels (GB25_OPT_KERNELS = 1) know WENO(order = 5) only");
+  if (gb25_status s = collective_guard(m, 12, (unsigned)order, 0.0)) return s;
+  m->tracer_order = order;
+  m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+  m->complete_fills_needed = 2;
+  return GB25_OK;
+}
+gb25_status gb25_get_tracer_advection_order(const gb25_model* m, int32_t* order) {
+  if (!m || !order) return GB25_ERR_INVALID_ARGUMENT;
+  *order = m->tracer_order;
   return GB25_OK;
 }
 gb25_status gb25_get_bottom_drag(const gb25_model* m, double* Cd) {

@@ -626,7 +626,9 @@ struct Ab2Ahead {
 // The arithmetic of one tile (63 cells of a row x 4 rows x one chunk of levels); L = logical tile index.
 // CURV: orthogonal curvilinear grid (with the tables): the three face lengths, the area and its reciprocal per lane.
 // LAZY: the barotropic correction of this step is added to u and v as they are loaded (see k_momentum_tendencies_v5).
-template <bool AHEAD, bool IMM, bool FOLD, bool CURV = false, bool LAZY = false>
+// ORD: 5 = WENO(order = 5) (baroclinic_instability_model); 7 = WENO(order = 7) (ClimaOcean's ocean_simulation): windows of
+// 2R = 8 values per face (R = 4), the order-5 path next to walls and the immersed boundary (biased8, device_common.hpp).
+template <bool AHEAD, bool IMM, bool FOLD, bool CURV = false, bool LAZY = false, int ORD = 5>
 __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restrict__ u, const real* __restrict__ v,
                                             const real* __restrict__ w, const real* __restrict__ T,
                                             const real* __restrict__ S, real* __restrict__ GT, real* __restrict__ GS,
@@ -651,13 +653,20 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
     dv_s = lz.dv[om];
     dv_n = lz.dv[om + g.sx];
   }
-  int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny), ox = 5;
-  int kbt = 0, KX5 = 0, KX3 = 0, KY5 = 0, KY3 = 0, KY5n = 0, KY3n = 0;
+  constexpr int R = ORD == 7 ? 4 : 3;   // reach of the reconstruction stencils
+  static_assert(ORD == 5 || ORD == 7, "WENO(order = 5) or WENO(order = 7)");
+  int oys = ORD == 7 ? biased_order_face7(j, g.Ny) : biased_order_face(j, g.Ny);
+  int oyn = ORD == 7 ? biased_order_face7(j + 1, g.Ny) : biased_order_face(j + 1, g.Ny), ox = ORD;
+  int kbt = 0, KX5 = 0, KX3 = 0, KY5 = 0, KY3 = 0, KY5n = 0, KY3n = 0, KX7 = 0, KY7 = 0, KY7n = 0;
   if (IMM) {
     const int o2 = i2(g, min(i, g.Nx), j);
     const unsigned A = g.im.ordA[o2], B = g.im.ordB[o2], An = g.im.ordA[o2 + g.sx], Bn = g.im.ordB[o2 + g.sx];
     kbt = A & 255; KX5 = (A >> 8) & 255; KX3 = (A >> 16) & 255; KY5 = A >> 24; KY3 = B & 255;
     KY5n = An >> 24; KY3n = Bn & 255;
+    if (ORD == 7) {
+      const unsigned D = g.im.ordD[o2], Dn = g.im.ordD[o2 + g.sx];
+      KX7 = D & 255; KY7 = (D >> 8) & 255; KY7n = (Dn >> 8) & 255;
+    }
   }
   const int Nzc = g.Nz - kbt;   // (levels above the column's bottom: the bottom acts like the wall at k = 0, shifted)
 
@@ -674,45 +683,50 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
   }
   // lanes past the east edge work on a clamped (duplicate) column.  `vo` addresses the (-3,-3,-3) corner of the
   // cell's stencil so that every displacement below is a non-negative byte count (needs H >= 3, as WENO5 does).
-  const int cc = (3 * pc + 3 * sx + 3) * SZ;                    // corner -> cell
+  const int cc = (R * pc + R * sx + R) * SZ;                    // corner -> cell
   int vo = (ic(g, min(i, g.Nx), j, k0)) * SZ - cc;
   int vov = iv(g, min(i, g.Nx), j, k0) * SZ;
-#define CZ(m) (((m) * pc + 3 * sx + 3) * SZ)                     // (0, 0, m-3)
-#define CY(m) ((3 * pc + (m) * sx + 3) * SZ)                     // (0, m-3, 0)
-#define CX(m) ((3 * pc + 3 * sx) * SZ), ((m) * SZ)               // (m-3, 0, 0): uniform part, immediate part
-  real2v cz[7];                                // vertical window of (T, S)
+#define CZ(m) (((m) * pc + R * sx + R) * SZ)                     // (0, 0, m-R)
+#define CY(m) ((R * pc + (m) * sx + R) * SZ)                     // (0, m-R, 0)
+#define CX(m) ((R * pc + R * sx) * SZ), ((m) * SZ)               // (m-R, 0, 0): uniform part, immediate part
+  auto recon = [](int order, bool left, const real2v* w) {      // reconstruction to the face between w[R-1] and w[R]
+    if constexpr (ORD == 7) return biased8<real2v>(order, left, w);
+    else return biased6<false, real2v>(order, left, w, w, w);
+  };
+  auto zorder = [](int f, int N) { return ORD == 7 ? biased_order_face7(f, N) : biased_order_face(f, N); };
+  real2v cz[2 * R + 1];                        // vertical window of (T, S)
 #pragma unroll
-  for (int m = 0; m < 7; m++) cz[m] = v2(bload(bT, vo, CZ(m)), bload(bS, vo, CZ(m)));
+  for (int m = 0; m < 2 * R + 1; m++) cz[m] = v2(bload(bT, vo, CZ(m)), bload(bS, vo, CZ(m)));
   real2v fz;
   {
     real Azw = Az * bload(bw, vo, cc);
-    int ord = biased_order_face(k0 - kbt, Nzc);
-    fz = Azw * biased6<false, real2v>(ord, Azw > real(0.), cz, cz, cz);
+    int ord = zorder(k0 - kbt, Nzc);
+    fz = Azw * recon(ord, Azw > real(0.), cz);
   }
   // FOLD: does this wave hold cells with a periodic x image or a y layer to write?
   const bool fold_row = FOLD && (j == 0 || j == g.Ny - 1 || bx * V3_OUT < g.H || bx * V3_OUT + V3_OUT > g.Nx - g.H);
   for (int k = k0; k < k1; k++) {
     const real dz = g.dzc[k];
     if (IMM) {
-      ox = order_from(k, KX5, KX3);
-      oys = order_from(k, KY5, KY3);
-      oyn = order_from(k, KY5n, KY3n);
+      ox = ORD == 7 ? order_from7(k, KX7, KX5, KX3) : order_from(k, KX5, KX3);
+      oys = ORD == 7 ? order_from7(k, KY7, KY5, KY3) : order_from(k, KY5, KY3);
+      oyn = ORD == 7 ? order_from7(k, KY7n, KY5n, KY3n) : order_from(k, KY5n, KY3n);
     }
     const real Axu = dy * dz * (LAZY ? bload(bu, vo, cc) + du_l : bload(bu, vo, cc));
     const real Ays = dxf_s * dz * (LAZY ? bload(bv, vov, 0) + dv_s : bload(bv, vov, 0));
     const real Ayn = dxf_n * dz * (LAZY ? bload(bv, vov, sx * SZ) + dv_n : bload(bv, vov, sx * SZ));
     const real Azw = Az * bload(bw, vo, cc + pc * SZ);
-    real2v q[7];
+    real2v q[2 * R + 1];
 #pragma unroll
-    for (int m = 0; m < 6; m++) q[m] = v2(bload(bT, vo + m * SZ, (3 * pc + 3 * sx) * SZ), bload(bS, vo + m * SZ, (3 * pc + 3 * sx) * SZ));
-    const real2v fx = Axu * biased6<false, real2v>(IMM ? ox : 5, Axu > real(0.), q, q, q);
+    for (int m = 0; m < 2 * R; m++) q[m] = v2(bload(bT, vo + m * SZ, (R * pc + R * sx) * SZ), bload(bS, vo + m * SZ, (R * pc + R * sx) * SZ));
+    const real2v fx = Axu * recon(IMM ? ox : ORD, Axu > real(0.), q);
 #pragma unroll
-    for (int m = 0; m < 7; m++) q[m] = v2(bload(bT, vo, CY(m)), bload(bS, vo, CY(m)));
-    const real2v fs = Ays * biased6<false, real2v>(oys, Ays > real(0.), q, q, q);
-    const real2v fn = Ayn * biased6<false, real2v>(oyn, Ayn > real(0.), q + 1, q + 1, q + 1);
+    for (int m = 0; m < 2 * R + 1; m++) q[m] = v2(bload(bT, vo, CY(m)), bload(bS, vo, CY(m)));
+    const real2v fs = Ays * recon(oys, Ays > real(0.), q);
+    const real2v fn = Ayn * recon(oyn, Ayn > real(0.), q + 1);
     // top face from the vertical window
-    const int ozt = biased_order_face(k + 1 - kbt, Nzc);
-    const real2v ft = Azw * biased6<false, real2v>(ozt, Azw > real(0.), cz + 1, cz + 1, cz + 1);
+    const int ozt = zorder(k + 1 - kbt, Nzc);
+    const real2v ft = Azw * recon(ozt, Azw > real(0.), cz + 1);
     // east faces = west faces of the next lane
     const real2v fe = v2(__shfl_down(fx.x, 1), __shfl_down(fx.y, 1));
     if (writes) {
@@ -727,8 +741,8 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
       bstore(bGT, vo, cc, G.x);
       bstore(bGS, vo, cc, G.y);
       if (AHEAD) {   // T, S of the NEXT step while T, S (cz[3]) and the new tendency are in registers
-        const real tn = ab2_advance(cz[3].x, G.x, bload(bGmT, vo, cc), next.dt, next.C1, next.C2);
-        const real sn = ab2_advance(cz[3].y, G.y, bload(bGmS, vo, cc), next.dt, next.C1, next.C2);
+        const real tn = ab2_advance(cz[R].x, G.x, bload(bGmT, vo, cc), next.dt, next.C1, next.C2);
+        const real sn = ab2_advance(cz[R].y, G.y, bload(bGmS, vo, cc), next.dt, next.C1, next.C2);
         bstore(bTn, vo, cc, tn);
         bstore(bSn, vo, cc, sn);
         if (FOLD && (fold_row || k == 0 || k == g.Nz - 1)) {   // (wave-uniform: most waves and levels skip all of it)
@@ -751,21 +765,21 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
     vo += pc * SZ;
     vov += pv * SZ;
 #pragma unroll
-    for (int m = 0; m < 6; m++) cz[m] = cz[m + 1];
-    cz[6] = v2(bload(bT, vo, CZ(6)), bload(bS, vo, CZ(6)));
+    for (int m = 0; m < 2 * R; m++) cz[m] = cz[m + 1];
+    cz[2 * R] = v2(bload(bT, vo, CZ(2 * R)), bload(bS, vo, CZ(2 * R)));
   }
 #undef CZ
 #undef CY
 #undef CX
 }
-template <int MINW, bool AHEAD, bool IMM, bool FOLD = false, bool CURV = false, bool LAZY = false>
+template <int MINW, bool AHEAD, bool IMM, bool FOLD = false, bool CURV = false, bool LAZY = false, int ORD = 5>
 __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, const real* __restrict__ u,
                                                               const real* __restrict__ v,
                                                               const real* __restrict__ w,
                                                               const real* __restrict__ T, const real* __restrict__ S,
                                                               real* __restrict__ GT, real* __restrict__ GS, int nbx,
                                                               int kchunks, int nb, Ab2Ahead next, LazyCorr lz) {
-  tracer_tile<AHEAD, IMM, FOLD, CURV, LAZY>(g, u, v, w, T, S, GT, GS, nbx, kchunks, next, xcd_remap(blockIdx.x, nb), lz);
+  tracer_tile<AHEAD, IMM, FOLD, CURV, LAZY, ORD>(g, u, v, w, T, S, GT, GS, nbx, kchunks, next, xcd_remap(blockIdx.x, nb), lz);
 }
 
 }  // namespace gb25

@@ -114,7 +114,7 @@ def set_data_free_state(model, noise=None):
 
 
 def data_free_ocean_climate_model_init(arch, resolution=2, Nz=20, *, dt=30.0, noise=None, size=None,
-                                       bottom_drag_coefficient=0.003, **backend_kw):
+                                       bottom_drag_coefficient=0.003, tracer_advection_order=7, **backend_kw):
     """data_free_ocean_climate_model_init(arch; resolution = 2, Nz = 20) -- src/data_free_ocean_climate_model.jl:12-70:
     gaussian_islands_tripolar_grid(arch, resolution, Nz), SplitExplicitFreeSurface(substeps = 30), dt = 30 s, the closure of
     ClimaOcean's ocean_simulation (default_ocean_closure: CATKE with Cᵇ = 0.01), T = Ti, S = Si, the analytic atmosphere, coupled.  size = (Nx, Ny): a grid that is
@@ -124,4 +124,6 @@ def data_free_ocean_climate_model_init(arch, resolution=2, Nz=20, *, dt=30.0, no
                                          closure=default_ocean_closure(), **backend_kw)
     # ocean_simulation(grid; ...): bottom_drag_coefficient = Default(0.003) [UPSTREAM-UNVERIFIED: recalled from ClimaOcean]
     model.backend.set_bottom_drag(bottom_drag_coefficient)
+    # ... and tracer_advection = WENO(order = 7) [UPSTREAM-UNVERIFIED likewise]
+    model.backend.set_tracer_advection_order(tracer_advection_order)
     return set_data_free_state(model, noise)

@@ -218,6 +218,11 @@ gb25_status gb25_get_top_flux(gb25_model *m, gb25_field f, void *flux);
  *      J = -Cd u sqrt(u^2 + Ixy(v)^2) (likewise for v), evaluated before every tendency evaluation and added to the tendency of
  *      the face's first free level.  Cd = 0 (the default; baroclinic_instability_model has none): no drag.  Collective. */
 gb25_status gb25_set_bottom_drag(gb25_model *m, double Cd);
+/*      tracer_advection of the same ocean_simulation: WENO(order = 7) (baroclinic_instability_model: WENO(order = 5), the
+ *      default here).  T, S and CATKE's e; the order-5 path where the eight-point stencil meets a wall or the immersed
+ *      boundary.  Collective. */
+gb25_status gb25_set_tracer_advection_order(gb25_model *m, int32_t order);
+gb25_status gb25_get_tracer_advection_order(const gb25_model *m, int32_t *order);
 gb25_status gb25_get_bottom_drag(const gb25_model *m, double *Cd);
 
 /* ---- data-free forcing (src/data_free_ocean_climate_model.jl:12-70): a PrescribedAtmosphere + Radiation +

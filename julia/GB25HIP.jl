@@ -16,7 +16,7 @@ export Config, Model, create, destroy!, first_time_step!, time_step!, loop!, ini
        fill_halo_regions!, compute_auxiliaries!, compute_tendencies!, ab2_step!, mask_immersed_fields!,
        correct_velocities_and_cache_previous_tendencies!, set_baroclinic_instability!, synchronize,
        parent_array, interior_array, set_parent!, set_interior!, clock, set_dt!, set_option!, get_option,
-       comm_unique_id, comm_init_rccl!, comm_finalize!, set_top_flux!, set_bottom_height!, set_vertical_diffusivity!, set_closure_catke!, CatkeParameters, default_catke_parameters, set_catke_parameters!, set_bottom_drag!, set_prescribed_atmosphere!, compute_atmosphere_ocean_fluxes!, metric2, FIELD, OPTION, METRIC2
+       comm_unique_id, comm_init_rccl!, comm_finalize!, set_top_flux!, set_bottom_height!, set_vertical_diffusivity!, set_closure_catke!, CatkeParameters, default_catke_parameters, set_catke_parameters!, set_bottom_drag!, set_tracer_advection_order!, set_prescribed_atmosphere!, compute_atmosphere_ocean_fluxes!, metric2, FIELD, OPTION, METRIC2
 
 # One library per Oceananigans float type (src/arg_parsing.jl:12-16): Float32 -> libgb25hip.so, Float64 ->
 # libgb25hip_f64.so; same symbols, gb25_real_bytes() tells them apart.
@@ -170,6 +170,9 @@ set_prescribed_atmosphere!(m::Model, field::Symbol, values::AbstractMatrix) =
                    getproperty(ATMOSPHERE, field), convert(Matrix{Float64}, values)), "gb25_set_prescribed_atmosphere")
 compute_atmosphere_ocean_fluxes!(m::Model) =
     check(m, ccall((:gb25_compute_atmosphere_ocean_fluxes, m.lib), Cint, (Ptr{Cvoid},), m.ptr), "gb25_compute_atmosphere_ocean_fluxes")
+# tracer_advection = WENO(order = 5) (default) | WENO(order = 7) (ClimaOcean's ocean_simulation)
+set_tracer_advection_order!(m::Model, order::Integer) =
+    check(m, ccall((:gb25_set_tracer_advection_order, m.lib), Cint, (Ptr{Cvoid}, Int32), m.ptr, order), "gb25_set_tracer_advection_order")
 # quadratic bottom drag (ClimaOcean's ocean_simulation: bottom_drag_coefficient = 0.003); 0: none
 set_bottom_drag!(m::Model, Cd::Real) =
     check(m, ccall((:gb25_set_bottom_drag, m.lib), Cint, (Ptr{Cvoid}, Float64), m.ptr, Cd), "gb25_set_bottom_drag")

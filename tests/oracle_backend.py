@@ -250,6 +250,12 @@ class OracleBackend:
             return
         a = np.ascontiguousarray(np.asarray(J, dtype=np.float64).reshape(self.field_dims(name, False)[:2]).T)
         f(self.h, q, a.ctypes.data_as(C.c_void_p))
+    def set_tracer_advection_order(self, order):
+        f = self._fn("set_tracer_advection_order")
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int]
+        f(self.h, int(order))
+
     def set_bottom_drag(self, Cd):
         f = self._fn("set_bottom_drag")
         f.restype = None

@@ -34,6 +34,7 @@ def test_config4_grid_single_domain_and_eight_slabs():
         b.set_catke(True)
         b.set_catke_parameters(**gb.default_ocean_closure().parameters)
         b.set_bottom_drag(0.003)
+        b.set_tracer_advection_order(7)
         phi = np.asarray(b.metric2("phicc"))[:, : NY + 2 * H]
         for n in ATMOSPHERE_FIELDS:
             b.set_prescribed_atmosphere(n, atm.interpolate(n, np.zeros_like(phi), phi))
