@@ -341,6 +341,35 @@ __device__ __forceinline__ void bstore(const Buf& b, int voff, int soff, double 
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), b.r, voff, soff, 0);
 }
 
+// Two reconstructions to a face at once, one per half of the pair, each with its own upwind direction AND its own order
+// (two different columns of one field: k_tracer_tendencies_single): the same order in both halves -- the usual case -- is one
+// packed evaluation; different orders (next to bathymetry) evaluate both and keep a half of each.
+template <int ORD>
+__device__ __forceinline__ real2v biased_pair_same(int order, bool l0, bool l1, const real2v* w) {
+  if (ORD == 7) {
+    if (order == 7)
+      return weno7(pick(l0, l1, w[0], w[7]), pick(l0, l1, w[1], w[6]), pick(l0, l1, w[2], w[5]), pick(l0, l1, w[3], w[4]),
+                   pick(l0, l1, w[4], w[3]), pick(l0, l1, w[5], w[2]), pick(l0, l1, w[6], w[1]));
+    return biased6p<false>(order, l0, l1, w + 1, w + 1, w + 1);
+  }
+  return biased6p<false>(order, l0, l1, w, w, w);
+}
+template <int ORD>
+__device__ __forceinline__ real2v biased_pair(int o0, int o1, bool l0, bool l1, const real2v* w) {
+  // ONE instance of the evaluation, run once or twice: a second inlined copy of which only one half is used gets
+  // scalarised by the compiler, with its own choice of fused multiply-adds -- and a column's result then depended, in
+  // the last bit, on which column it happened to be paired with (slabs against the single domain).
+  real2v out = real2v(real(0.));
+  const int n = o0 == o1 ? 1 : 2;
+#pragma nounroll
+  for (int h = 0; h < n; h++) {
+    const real2v r = biased_pair_same<ORD>(h ? o1 : o0, l0, l1, w);
+    if (h == 0) out = r;
+    else out.y = r.y;
+  }
+  return out;
+}
+
 // wall-adjacent order reduction in a bounded direction of extent N (0-based target index)
 __device__ __forceinline__ int biased_order_face(int f, int N) {
   return (f >= 3 && f <= N - 3) ? 5 : ((f >= 2 && f <= N - 2) ? 3 : 1);

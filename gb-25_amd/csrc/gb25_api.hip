@@ -1496,24 +1496,22 @@ gb25_status catke_update_impl(gb25_model* m) {
   if (!m->catke) return GB25_OK;
   Timed t_closure(m, GB25_K_CLOSURE);
   const Grid& g = m->g;
-  int nbx = (g.Nx + V3_OUT - 1) / V3_OUT;
-  const int nby = (g.Ny + 3) / 4, kchunks = std::max(1, g.Nz / m->trc_chunk_levels);
-  const int nb = nbx * nby * kchunks;
-  constexpr int TW = sizeof(real) == 8 ? 3 : 5;
-  Ab2Ahead none{};
-  const LazyCorr lz{nullptr, nullptr};
-  constexpr int TW7 = sizeof(real) == 8 ? 2 : 3;
-  auto kt = m->tracer_order == 7
-                ? (g.cv.on       ? k_tracer_tendencies_v5<TW7, false, true, false, true, false, 7>
-                   : m->immersed ? k_tracer_tendencies_v5<TW7, false, true, false, false, false, 7>
-                                 : k_tracer_tendencies_v5<TW7, false, false, false, false, false, 7>)
-            : g.cv.on       ? k_tracer_tendencies_v5<TW, false, true, false, true>
-            : m->immersed ? k_tracer_tendencies_v5<TW, false, true, false>
-                          : k_tracer_tendencies_v5<TW, false, false, false>;
-  Grid ge = g;                                   // (the top fluxes of T, S are not e's: its surface flux comes below)
-  ge.top_flux[2] = ge.top_flux[3] = nullptr;
-  hipLaunchKernelGGL(kt, dim3(nb), dim3(64, 4), 0, m->stream, ge, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_W].d,
-                     m->f[GB25_E].d, m->f[GB25_E].d, m->f[GB25_GN_E].d, m->catke_scratch.d, nbx, kchunks, nb, none, lz);
+  // -div(u e) into G^n.e: one tracer, the two halves of the packed arithmetic on two columns of it (k_tracer_tendencies_single)
+  {
+    const int nbx = (g.Nx + V3_PAIR - 1) / V3_PAIR, nby = (g.Ny + 3) / 4, kchunks = std::max(1, g.Nz / m->trc_chunk_levels);
+    const int nb = nbx * nby * kchunks;
+    constexpr int TW = sizeof(real) == 8 ? 2 : 4;
+    void (*kt)(Grid, const real*, const real*, const real*, const real*, real*, int, int, int) =
+        m->tracer_order == 7
+            ? (g.cv.on       ? k_tracer_tendencies_single<TW, true, true, 7>
+               : m->immersed ? k_tracer_tendencies_single<TW, true, false, 7>
+                             : k_tracer_tendencies_single<TW, false, false, 7>)
+        : g.cv.on       ? k_tracer_tendencies_single<TW, true, true, 5>
+        : m->immersed ? k_tracer_tendencies_single<TW, true, false, 5>
+                      : k_tracer_tendencies_single<TW, false, false, 5>;
+    hipLaunchKernelGGL(kt, dim3(nb), dim3(64, 4), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_W].d, m->f[GB25_E].d,
+                       m->f[GB25_GN_E].d, nbx, kchunks, nb);
+  }
   dim3 b(64, 4);
   if (!m->n2_fresh)   // (normally the pressure kernel of this state left N^2 behind: compute_p_impl)
     hipLaunchKernelGGL(k_catke_buoyancy, dim3((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz - 1), b, 0, m->stream, g,

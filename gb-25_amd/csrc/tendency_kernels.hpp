@@ -782,4 +782,119 @@ __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, cons
   tracer_tile<AHEAD, IMM, FOLD, CURV, LAZY, ORD>(g, u, v, w, T, S, GT, GS, nbx, kchunks, next, xcd_remap(blockIdx.x, nb), lz);
 }
 
+// =============================================================================================
+// Advection of ONE tracer (CATKE's e): the wave-autonomous scheme of tracer_tile with the two halves of every register pair
+// holding the same field at two COLUMNS 63 apart instead of two tracers at one -- a wave owns 2 x 63 consecutive cells of a
+// row.  Velocities, upwind directions, metrics and (with bathymetry) reconstruction orders are then per half; the arithmetic
+// per half is that of tracer_tile.  (Sending e through the two-tracer kernel with T = S = e left half of every packed
+// instruction idle: 1.73 ms for the third tracer against 1.95 ms for the first two at 1440 x 720 x 60 with WENO(order = 7).)
+// No look-ahead, no halo writes, no flux boundary condition: e has none of them.
+// =============================================================================================
+constexpr int V3_PAIR = 2 * V3_OUT;   // outputs per wavefront
+template <bool IMM, bool CURV, int ORD>
+__device__ __forceinline__ void tracer_tile_single(const Grid& g, const real* __restrict__ u, const real* __restrict__ v,
+                                                   const real* __restrict__ w, const real* __restrict__ E,
+                                                   real* __restrict__ GE, int nbx, int kchunks, const int L) {
+  constexpr int R = ORD == 7 ? 4 : 3;
+  const int bx = L % nbx, r = L / nbx;
+  const int kc = r % kchunks, by = r / kchunks;
+  const int klen = (g.Nz + kchunks - 1) / kchunks;
+  const int k0 = kc * klen, k1 = min(g.Nz, k0 + klen);
+  const int lane = threadIdx.x;
+  const int j = by * blockDim.y + threadIdx.y;
+  if (j >= g.Ny) return;
+  const int i0 = bx * V3_PAIR + lane, i1 = i0 + V3_OUT;          // the two columns of this lane
+  const bool wr0 = (lane < V3_OUT) && (i0 < g.Nx), wr1 = (lane < V3_OUT) && (i1 < g.Nx);
+  const int c0 = min(i0, g.Nx), c1 = min(i1, g.Nx);              // (lanes past the east edge work on a clamped column)
+  const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
+  static_assert(!CURV || IMM, "the curvilinear variant takes its orders from the tables");
+  const int om0 = i2(g, c0, j), om1 = i2(g, c1, j);
+  auto m2 = [&](const real* tab, int d) { return v2(tab[om0 + d], tab[om1 + d]); };
+  const real2v dy = CURV ? m2(g.cv.dyfc, 0) : real2v(g.dy), Az = CURV ? m2(g.cv.azcc, 0) : real2v(g.azc[j]);
+  const real2v dxf_s = CURV ? m2(g.cv.dxcf, 0) : real2v(g.dxf[j]), dxf_n = CURV ? m2(g.cv.dxcf, g.sx) : real2v(g.dxf[j + 1]);
+  const real2v razc_j = CURV ? m2(g.cv.razcc, 0) : real2v(g.razc[j]);
+  const int oys_w = ORD == 7 ? biased_order_face7(j, g.Ny) : biased_order_face(j, g.Ny);
+  const int oyn_w = ORD == 7 ? biased_order_face7(j + 1, g.Ny) : biased_order_face(j + 1, g.Ny);
+  int kbt[2] = {0, 0}, KX5[2] = {0, 0}, KX3[2] = {0, 0}, KY5[2] = {0, 0}, KY3[2] = {0, 0}, KY5n[2] = {0, 0}, KY3n[2] = {0, 0};
+  int KX7[2] = {0, 0}, KY7[2] = {0, 0}, KY7n[2] = {0, 0};
+  if (IMM) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int o2 = h ? om1 : om0;
+      const unsigned A = g.im.ordA[o2], B = g.im.ordB[o2], An = g.im.ordA[o2 + g.sx], Bn = g.im.ordB[o2 + g.sx];
+      kbt[h] = A & 255; KX5[h] = (A >> 8) & 255; KX3[h] = (A >> 16) & 255; KY5[h] = A >> 24; KY3[h] = B & 255;
+      KY5n[h] = An >> 24; KY3n[h] = Bn & 255;
+      if (ORD == 7) {
+        const unsigned D = g.im.ordD[o2], Dn = g.im.ordD[o2 + g.sx];
+        KX7[h] = D & 255; KY7[h] = (D >> 8) & 255; KY7n[h] = (Dn >> 8) & 255;
+      }
+    }
+  }
+  const int Nzc0 = g.Nz - kbt[0], Nzc1 = g.Nz - kbt[1];
+  constexpr int SZ = (int)sizeof(real);
+  const long nzp = g.Nz + 2 * g.H;
+  const Buf bE = make_buf(E, pc * nzp), bu = make_buf(u, pc * nzp), bw = make_buf(w, pc * (nzp + 1)), bv = make_buf(v, pv * nzp),
+            bG = make_buf(GE, pc * nzp);
+  const int cc = (R * pc + R * sx + R) * SZ;
+  int vo0 = ic(g, c0, j, k0) * SZ - cc, vo1 = ic(g, c1, j, k0) * SZ - cc;
+  int vv0 = iv(g, c0, j, k0) * SZ, vv1 = iv(g, c1, j, k0) * SZ;
+  auto ld2 = [&](const Buf& b, int a0, int a1, int so) { return v2(bload(b, a0, so), bload(b, a1, so)); };
+  auto zorder = [](int f, int N) { return ORD == 7 ? biased_order_face7(f, N) : biased_order_face(f, N); };
+  auto ord3 = [](int k, int K7_, int K5_, int K3_) { return ORD == 7 ? order_from7(k, K7_, K5_, K3_) : order_from(k, K5_, K3_); };
+#define CZ(m) (((m) * pc + R * sx + R) * SZ)
+#define CY(m) ((R * pc + (m) * sx + R) * SZ)
+  real2v cz[2 * R + 1];
+#pragma unroll
+  for (int m = 0; m < 2 * R + 1; m++) cz[m] = ld2(bE, vo0, vo1, CZ(m));
+  real2v fz;
+  {
+    const real2v Azw = Az * ld2(bw, vo0, vo1, cc);
+    fz = Azw * biased_pair<ORD>(zorder(k0 - kbt[0], Nzc0), zorder(k0 - kbt[1], Nzc1), Azw.x > real(0.), Azw.y > real(0.), cz);
+  }
+  for (int k = k0; k < k1; k++) {
+    const real dz = g.dzc[k];
+    int ox0 = ORD, ox1 = ORD, os0 = oys_w, os1 = oys_w, on0 = oyn_w, on1 = oyn_w;
+    if (IMM) {
+      ox0 = ord3(k, KX7[0], KX5[0], KX3[0]); ox1 = ord3(k, KX7[1], KX5[1], KX3[1]);
+      os0 = ord3(k, KY7[0], KY5[0], KY3[0]); os1 = ord3(k, KY7[1], KY5[1], KY3[1]);
+      on0 = ord3(k, KY7n[0], KY5n[0], KY3n[0]); on1 = ord3(k, KY7n[1], KY5n[1], KY3n[1]);
+    }
+    const real2v Axu = dy * dz * ld2(bu, vo0, vo1, cc);
+    const real2v Ays = dxf_s * dz * ld2(bv, vv0, vv1, 0);
+    const real2v Ayn = dxf_n * dz * ld2(bv, vv0, vv1, sx * SZ);
+    const real2v Azw = Az * ld2(bw, vo0, vo1, cc + pc * SZ);
+    real2v q[2 * R + 1];
+#pragma unroll
+    for (int m = 0; m < 2 * R; m++) q[m] = ld2(bE, vo0 + m * SZ, vo1 + m * SZ, (R * pc + R * sx) * SZ);
+    const real2v fx = Axu * biased_pair<ORD>(ox0, ox1, Axu.x > real(0.), Axu.y > real(0.), q);
+#pragma unroll
+    for (int m = 0; m < 2 * R + 1; m++) q[m] = ld2(bE, vo0, vo1, CY(m));
+    const real2v fs = Ays * biased_pair<ORD>(os0, os1, Ays.x > real(0.), Ays.y > real(0.), q);
+    const real2v fn = Ayn * biased_pair<ORD>(on0, on1, Ayn.x > real(0.), Ayn.y > real(0.), q + 1);
+    const real2v ft = Azw * biased_pair<ORD>(zorder(k + 1 - kbt[0], Nzc0), zorder(k + 1 - kbt[1], Nzc1), Azw.x > real(0.),
+                                             Azw.y > real(0.), cz + 1);
+    // east faces = west faces of the next lane; lane 62's second column borders the NEXT wave's first, supplied by lane 63
+    const real2v fe = v2(__shfl_down(fx.x, 1), __shfl_down(fx.y, 1));
+    const real2v G = -(((fe - fx) + (fn - fs) + (ft - fz)) * (razc_j * g.rdzc[k]));
+    if (wr0) bstore(bG, vo0, cc, G.x);
+    if (wr1) bstore(bG, vo1, cc, G.y);
+    fz = ft;
+    vo0 += pc * SZ; vo1 += pc * SZ;
+    vv0 += pv * SZ; vv1 += pv * SZ;
+#pragma unroll
+    for (int m = 0; m < 2 * R; m++) cz[m] = cz[m + 1];
+    cz[2 * R] = ld2(bE, vo0, vo1, CZ(2 * R));
+  }
+#undef CZ
+#undef CY
+}
+template <int MINW, bool IMM, bool CURV, int ORD>
+__global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_single(Grid g, const real* __restrict__ u,
+                                                                       const real* __restrict__ v,
+                                                                       const real* __restrict__ w,
+                                                                       const real* __restrict__ E, real* __restrict__ GE,
+                                                                       int nbx, int kchunks, int nb) {
+  tracer_tile_single<IMM, CURV, ORD>(g, u, v, w, E, GE, nbx, kchunks, xcd_remap(blockIdx.x, nb));
+}
+
 }  // namespace gb25
