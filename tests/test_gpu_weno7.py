@@ -67,3 +67,21 @@ def test_order_seven_with_catke_and_on_slabs():
     bad = [n for n, a in ref.items() if not np.array_equal(ens.gather(n), a)]
     assert not bad, [(n, rel(ens.gather(n), ref[n])) for n in bad]
     ens.close()
+
+
+def test_order_seven_on_a_shallow_grid_and_its_refusals():
+    """Five levels: every vertical stencil is cut by the bottom or the surface (orders 1, 3, 5 only in z); Float64 so that the
+    comparison is about logic."""
+    from gb25_amd.binding import GB25Error
+    r, v = make_pair(64, 44, 5, dt=300.0, float_type="Float64", grid_type="gaussian_islands_lat_lon")
+    for m in (r, v):
+        gb.set_baroclinic_instability(m)
+        set_noisy_velocities(m, 0.1)
+        m.backend.set_tracer_advection_order(7)
+        gb.first_time_step(m)
+        gb.loop(m, 3)
+    for n in ("T", "S", "Gn.T", "Gn.S"):
+        assert rel(r.backend.get_field(n, True), v.backend.get_field(n, True)) < 1e-9, n
+    with pytest.raises(GB25Error):
+        r.backend.set_tracer_advection_order(6)
+    # (a halo of 3 could not carry the eight-point stencil: gb25_create asks for at least 4 anyway)
