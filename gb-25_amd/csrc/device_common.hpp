@@ -155,8 +155,9 @@ __device__ __forceinline__ T beta5_2(T a, T b, T c) {
   return (d1 * (real(13.) / real(3.))) * d1 + d2 * d2;
 }
 // Z-weights alpha_s = C_s (1 + (tau/b_s)^2), b_s = beta_s + eps, evaluated as C_s (1 + (q rho_s)^2) with
-// q = min(tau/b_min, 1e9) and rho_s = b_min/b_s <= 1.  Identical in exact arithmetic; in fp32 the plain form
-// overflows (tau/b ~ 1e18 when one indicator cancels to zero next to area-weighted divergences ~1e8).
+// q = min(tau/b_min, 1e9) and rho_s = b_min/b_s <= 1, i.e. q rho_s = min(tau, 1e9 b_min) / b_s.  Identical in exact
+// arithmetic; in fp32 the plain form overflows (tau/b ~ 1e18 when one indicator cancels to zero next to area-weighted
+// divergences ~1e8).
 constexpr real kZCap = real(1e9);
 template <class T>
 __device__ __forceinline__ T weno5_combine(T a, T b, T c, T d, T e, T b0, T b1, T b2) {
@@ -168,10 +169,10 @@ __device__ __forceinline__ T weno5_combine(T a, T b, T c, T d, T e, T b0, T b1, 
   b1 += kWenoEps5;
   b2 += kWenoEps5;
   T bmin = rmin(b0, rmin(b1, b2));
-  // 1 / b_min is the largest of the three reciprocals that are needed anyway (v_rcp_f32 issues at half rate and has no
-  // packed form: four instead of five per reconstruction is 5 % of the tracer kernel's issue time)
+  // q b_min = min(tau / b_min, 1e9) b_min = min(tau, 1e9 b_min): no reciprocal of b_min and no search for the largest
+  // of the three that are needed anyway (v_rcp_f32, min and max have no packed form: one instruction per half each)
   T i0 = rcp(b0), i1 = rcp(b1), i2 = rcp(b2);
-  T qb = rmin(tau * rmax(i0, rmax(i1, i2)), kZCap) * bmin;
+  T qb = rmin(tau, kZCap * bmin);
   T r0 = qb * i0, r1 = qb * i1, r2 = qb * i2;
   T a0 = real(0.3) * r0 * r0 + real(0.3), a1 = real(0.6) * r1 * r1 + real(0.6), a2 = real(0.1) * r2 * r2 + real(0.1);
   return (a0 * p0 + a1 * p1 + a2 * p2) * (rcp(a0 + a1 + a2) * (real(1.) / real(6.)));
@@ -190,7 +191,7 @@ __device__ __forceinline__ T weno3_combine(T b, T c, T d, T b0, T b1) {
   b1 += kWenoEps;
   T bmin = rmin(b0, b1);
   T i0 = rcp(b0), i1 = rcp(b1);
-  T qb = rmin(tau * rmax(i0, i1), kZCap) * bmin;
+  T qb = rmin(tau, kZCap * bmin);
   T r0 = qb * i0, r1 = qb * i1;
   T a0 = (real(2.) / real(3.)) * r0 * r0 + (real(2.) / real(3.)), a1 = (real(1.) / real(3.)) * r1 * r1 + (real(1.) / real(3.));
   return (a0 * p0 + a1 * p1) * (rcp(a0 + a1) * real(0.5));
@@ -260,7 +261,7 @@ __device__ __forceinline__ T weno7(T a, T b, T c, T d, T e, T f, T g) {
   b2 = rmax(b2, T(real(0.))) + kWenoEps; b3 = rmax(b3, T(real(0.))) + kWenoEps;
   const T bmin = rmin(rmin(b0, b1), rmin(b2, b3));
   const T i0 = rcp(b0), i1 = rcp(b1), i2 = rcp(b2), i3 = rcp(b3);
-  const T qb = rmin(tau * rmax(rmax(i0, i1), rmax(i2, i3)), kZCap) * bmin;
+  const T qb = rmin(tau, kZCap * bmin);
   const T r0 = qb * i0, r1 = qb * i1, r2 = qb * i2, r3 = qb * i3;
   const T a0 = real(4. / 35.) * r0 * r0 + real(4. / 35.), a1 = real(18. / 35.) * r1 * r1 + real(18. / 35.);
   const T a2 = real(12. / 35.) * r2 * r2 + real(12. / 35.), a3 = real(1. / 35.) * r3 * r3 + real(1. / 35.);
