@@ -56,7 +56,7 @@ def measured_traffic(kernel, size, prefer=None):
             prefix = KERNEL_SYMBOL.get(kernel, kernel)
             hits = [(name, k) for name, k in json.load(open(f))["kernels"].items() if name.startswith(prefix)]
             if prefer:       # several template instances of one kernel in the trace: the one the timed loop runs
-                hits = [h for h in hits if h[0].endswith(prefer)] or hits
+                hits = [h for h in hits if h[0].endswith(tuple(prefer))] or hits
             if hits:
                 return hits[0][1]["hbm_bytes"], os.path.basename(f)
         except Exception:
@@ -315,7 +315,7 @@ def main():
                 alg["momentum"] += 4 * 4
             bytes_per_launch = alg[dom] * cells
             achieved = bytes_per_launch / (timed[dom]["avg_ms"] * 1e-3) / 1e9
-            traffic, traffic_src = measured_traffic(dom, (locNx, Ny, Nz), prefer=", true>" if (lazy and dom == "momentum") else None)
+            traffic, traffic_src = measured_traffic(dom, (locNx, Ny, Nz), prefer=(", true, false>", ", true>") if (lazy and dom == "momentum") else None)
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "traffic_source": traffic_src,
