@@ -139,20 +139,25 @@ __device__ __forceinline__ real2v rmax(real2v a, real2v b) { return v2(rmax(a.x,
 constexpr real kWenoEps = real(1e-8);
 constexpr real kWenoEps5 = real(1e-8) / real(0.75);   // eps in the scaled WENO5 indicator units
 
+//  * the indicators are formed from the differences of neighbours (ten instructions for the three instead of twelve, and
+//    no cancellation of the values' common part), and the eps of b_s = beta_s + eps rides in their first FMA (`seed`).
 template <class T>
-__device__ __forceinline__ T beta5_0(T c, T d, T e) {
-  T d1 = c - real(2.) * d + e, d2 = real(3.) * c - real(4.) * d + e;
-  return (d1 * (real(13.) / real(3.))) * d1 + d2 * d2;
+__device__ __forceinline__ T beta5_0(T c, T d, T e, real seed) {
+  T D1 = d - c, D2 = e - d;
+  T d1 = D2 - D1, d2 = D2 - real(3.) * D1;
+  return ((d1 * (real(13.) / real(3.))) * d1 + T(seed)) + d2 * d2;
 }
 template <class T>
-__device__ __forceinline__ T beta5_1(T b, T c, T d) {
-  T d1 = b - real(2.) * c + d, d2 = b - d;
-  return (d1 * (real(13.) / real(3.))) * d1 + d2 * d2;
+__device__ __forceinline__ T beta5_1(T b, T c, T d, real seed) {
+  T D0 = c - b, D1 = d - c;
+  T d1 = D1 - D0, d2 = D0 + D1;
+  return ((d1 * (real(13.) / real(3.))) * d1 + T(seed)) + d2 * d2;
 }
 template <class T>
-__device__ __forceinline__ T beta5_2(T a, T b, T c) {
-  T d1 = a - real(2.) * b + c, d2 = a - real(4.) * b + real(3.) * c;
-  return (d1 * (real(13.) / real(3.))) * d1 + d2 * d2;
+__device__ __forceinline__ T beta5_2(T a, T b, T c, real seed) {
+  T Dm = b - a, D0 = c - b;
+  T d1 = D0 - Dm, d2 = real(3.) * D0 - Dm;
+  return ((d1 * (real(13.) / real(3.))) * d1 + T(seed)) + d2 * d2;
 }
 // Z-weights alpha_s = C_s (1 + (tau/b_s)^2), b_s = beta_s + eps, evaluated as C_s (1 + (q rho_s)^2) with
 // q = min(tau/b_min, 1e9) and rho_s = b_min/b_s <= 1, i.e. q rho_s = min(tau, 1e9 b_min) / b_s.  Identical in exact
@@ -164,10 +169,7 @@ __device__ __forceinline__ T weno5_combine(T a, T b, T c, T d, T e, T b0, T b1, 
   T p0 = real(2.) * c + real(5.) * d - e;            // 6 x the candidate polynomials
   T p1 = real(5.) * c + real(2.) * d - b;
   T p2 = real(2.) * a - real(7.) * b + real(11.) * c;
-  T tau = rabs(b0 - b2);
-  b0 += kWenoEps5;
-  b1 += kWenoEps5;
-  b2 += kWenoEps5;
+  T tau = rabs(b0 - b2);                             // (b_s = beta_s + eps already: the eps cancels here)
   T bmin = rmin(b0, rmin(b1, b2));
   // q b_min = min(tau / b_min, 1e9) b_min = min(tau, 1e9 b_min): no reciprocal of b_min and no search for the largest
   // of the three that are needed anyway (v_rcp_f32, min and max have no packed form: one instruction per half each)
@@ -200,7 +202,7 @@ __device__ __forceinline__ T weno3_combine(T b, T c, T d, T b0, T b1) {
 // Self-smoothness WENO5 of upwind-ordered values.
 template <class T>
 __device__ __forceinline__ T weno5(T a, T b, T c, T d, T e) {
-  return weno5_combine(a, b, c, d, e, beta5_0(c, d, e), beta5_1(b, c, d), beta5_2(a, b, c));
+  return weno5_combine(a, b, c, d, e, beta5_0(c, d, e, kWenoEps5), beta5_1(b, c, d, kWenoEps5), beta5_2(a, b, c, kWenoEps5));
 }
 
 // Upwind-biased reconstruction from six consecutive values q[0..5] (positions p..p+5).
@@ -230,12 +232,13 @@ __device__ __forceinline__ T biased6(int order, bool left, const T* q, const T* 
   }
   T a = left ? q[0] : q[5], e = left ? q[4] : q[1];
   T sa = left ? s[0] : s[5], se = left ? s[4] : s[1];
-  T b0 = beta5_0(sc, sd, se), b1 = beta5_1(sb, sc, sd), b2 = beta5_2(sa, sb, sc);
+  const real seed = TWO ? real(2.) * kWenoEps5 : kWenoEps5;      // (averaged below when TWO: 0.5 (2 eps) = eps)
+  T b0 = beta5_0(sc, sd, se, seed), b1 = beta5_1(sb, sc, sd, seed), b2 = beta5_2(sa, sb, sc, seed);
   if (TWO) {
     T ta = left ? t[0] : t[5], te = left ? t[4] : t[1];
-    b0 = real(0.5) * (b0 + beta5_0(tc, td, te));
-    b1 = real(0.5) * (b1 + beta5_1(tb, tc, td));
-    b2 = real(0.5) * (b2 + beta5_2(ta, tb, tc));
+    b0 = real(0.5) * (b0 + beta5_0(tc, td, te, real(0.)));
+    b1 = real(0.5) * (b1 + beta5_1(tb, tc, td, real(0.)));
+    b2 = real(0.5) * (b2 + beta5_2(ta, tb, tc, real(0.)));
   }
   return weno5_combine(a, b, c, d, e, b0, b1, b2);
 }
@@ -301,12 +304,13 @@ __device__ __forceinline__ real2v biased6p(int order, bool l0, bool l1, const re
   }
   real2v a = pick(l0, l1, q[0], q[5]), e = pick(l0, l1, q[4], q[1]);
   real2v sa = pick(l0, l1, s[0], s[5]), se = pick(l0, l1, s[4], s[1]);
-  real2v b0 = beta5_0(sc, sd, se), b1 = beta5_1(sb, sc, sd), b2 = beta5_2(sa, sb, sc);
+  const real seed = TWO ? real(2.) * kWenoEps5 : kWenoEps5;      // (averaged below when TWO: 0.5 (2 eps) = eps)
+  real2v b0 = beta5_0(sc, sd, se, seed), b1 = beta5_1(sb, sc, sd, seed), b2 = beta5_2(sa, sb, sc, seed);
   if (TWO) {
     real2v ta = pick(l0, l1, t[0], t[5]), te = pick(l0, l1, t[4], t[1]);
-    b0 = real(0.5) * (b0 + beta5_0(tc, td, te));
-    b1 = real(0.5) * (b1 + beta5_1(tb, tc, td));
-    b2 = real(0.5) * (b2 + beta5_2(ta, tb, tc));
+    b0 = real(0.5) * (b0 + beta5_0(tc, td, te, real(0.)));
+    b1 = real(0.5) * (b1 + beta5_1(tb, tc, td, real(0.)));
+    b2 = real(0.5) * (b2 + beta5_2(ta, tb, tc, real(0.)));
   }
   return weno5_combine(a, b, c, d, e, b0, b1, b2);
 }

@@ -17,4 +17,4 @@ for t in sys.argv[1:] or ["float", "double"]:
     print(t)
     for n, v, s, l, o in zip(names, vg, sp, lds, occ):
         n = subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip().split("(")[0]
-        print(f"  {n[:58]:58s} vgpr {v:>4} spill {s:>4} lds {l:>7} occ {o}")
+        print(f"  {n[:86]:86s} vgpr {v:>4} spill {s:>4} lds {l:>7} occ {o}")
