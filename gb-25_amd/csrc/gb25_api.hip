@@ -1054,7 +1054,7 @@ gb25_status tracers_impl(gb25_model* m) {
     const int nby = (g.Ny + 3) / 4;
     const int kchunks = std::max(1, g.Nz / m->trc_chunk_levels);   // >= 12 levels per block: the z-carry start-up stays ~3 %
     nb = nbx * nby * kchunks;
-    constexpr int TW = sizeof(real) == 8 ? 3 : 5;   // see MW in momentum_impl
+    constexpr int TW = sizeof(real) == 8 ? 3 : 6;   // see MW in momentum_impl (Float32: held to 80 VGPRs, six waves per SIMD)
     const bool ahead = m->ab2_ahead && !m->ptr_exposed;
     Ab2Ahead nx{};
     if (ahead) {   // predicted parameters of the next ab2_step!: the clock's dt and the model's chi
