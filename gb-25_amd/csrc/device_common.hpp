@@ -164,11 +164,11 @@ __device__ __forceinline__ T beta5_2(T a, T b, T c, real seed) {
 // arithmetic; in fp32 the plain form overflows (tau/b ~ 1e18 when one indicator cancels to zero next to area-weighted
 // divergences ~1e8).
 constexpr real kZCap = real(1e9);
+// `self`: the indicators were formed from a..e themselves (a compile-time fact after inlining).  Then the result is taken
+// as c + sum_s w_s (p_s - c) with 6 (p_s - c) from the neighbour differences the indicators already hold: two
+// instructions fewer, and c's digits are not carried through the weighted sum.
 template <class T>
-__device__ __forceinline__ T weno5_combine(T a, T b, T c, T d, T e, T b0, T b1, T b2) {
-  T p0 = real(2.) * c + real(5.) * d - e;            // 6 x the candidate polynomials
-  T p1 = real(5.) * c + real(2.) * d - b;
-  T p2 = real(2.) * a - real(7.) * b + real(11.) * c;
+__device__ __forceinline__ T weno5_combine(T a, T b, T c, T d, T e, T b0, T b1, T b2, bool self = false) {
   T tau = rabs(b0 - b2);                             // (b_s = beta_s + eps already: the eps cancels here)
   T bmin = rmin(b0, rmin(b1, b2));
   // q b_min = min(tau / b_min, 1e9) b_min = min(tau, 1e9 b_min): no reciprocal of b_min and no search for the largest
@@ -177,7 +177,18 @@ __device__ __forceinline__ T weno5_combine(T a, T b, T c, T d, T e, T b0, T b1, 
   T qb = rmin(tau, kZCap * bmin);
   T r0 = qb * i0, r1 = qb * i1, r2 = qb * i2;
   T a0 = real(0.3) * r0 * r0 + real(0.3), a1 = real(0.6) * r1 * r1 + real(0.6), a2 = real(0.1) * r2 * r2 + real(0.1);
-  return (a0 * p0 + a1 * p1 + a2 * p2) * (rcp(a0 + a1 + a2) * (real(1.) / real(6.)));
+  T w = rcp(a0 + a1 + a2) * (real(1.) / real(6.));
+  if (self) {
+    T Dm = b - a, D0 = c - b, D1 = d - c, D2 = e - d;
+    T q0 = real(4.) * D1 - D2;                       // 6 (p_s - c)
+    T q1 = real(2.) * D1 + D0;
+    T q2 = real(5.) * D0 - real(2.) * Dm;
+    return c + (a0 * q0 + a1 * q1 + a2 * q2) * w;
+  }
+  T p0 = real(2.) * c + real(5.) * d - e;            // 6 x the candidate polynomials
+  T p1 = real(5.) * c + real(2.) * d - b;
+  T p2 = real(2.) * a - real(7.) * b + real(11.) * c;
+  return (a0 * p0 + a1 * p1 + a2 * p2) * w;
 }
 template <class T>
 __device__ __forceinline__ T beta3(T x, T y) {
@@ -202,7 +213,7 @@ __device__ __forceinline__ T weno3_combine(T b, T c, T d, T b0, T b1) {
 // Self-smoothness WENO5 of upwind-ordered values.
 template <class T>
 __device__ __forceinline__ T weno5(T a, T b, T c, T d, T e) {
-  return weno5_combine(a, b, c, d, e, beta5_0(c, d, e, kWenoEps5), beta5_1(b, c, d, kWenoEps5), beta5_2(a, b, c, kWenoEps5));
+  return weno5_combine(a, b, c, d, e, beta5_0(c, d, e, kWenoEps5), beta5_1(b, c, d, kWenoEps5), beta5_2(a, b, c, kWenoEps5), true);
 }
 
 // Upwind-biased reconstruction from six consecutive values q[0..5] (positions p..p+5).
@@ -240,7 +251,7 @@ __device__ __forceinline__ T biased6(int order, bool left, const T* q, const T* 
     b1 = real(0.5) * (b1 + beta5_1(tb, tc, td, real(0.)));
     b2 = real(0.5) * (b2 + beta5_2(ta, tb, tc, real(0.)));
   }
-  return weno5_combine(a, b, c, d, e, b0, b1, b2);
+  return weno5_combine(a, b, c, d, e, b0, b1, b2, !TWO && q == s);
 }
 
 // WENO(order = 7), self-smoothness (tracer fluxes of ClimaOcean's ocean_simulation): candidate polynomials, linear weights and
@@ -312,7 +323,7 @@ __device__ __forceinline__ real2v biased6p(int order, bool l0, bool l1, const re
     b1 = real(0.5) * (b1 + beta5_1(tb, tc, td, real(0.)));
     b2 = real(0.5) * (b2 + beta5_2(ta, tb, tc, real(0.)));
   }
-  return weno5_combine(a, b, c, d, e, b0, b1, b2);
+  return weno5_combine(a, b, c, d, e, b0, b1, b2, !TWO && q == s);
 }
 
 // ---------------------------------------------------------------------------------------------
