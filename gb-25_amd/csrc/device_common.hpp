@@ -142,22 +142,22 @@ constexpr real kWenoEps5 = real(1e-8) / real(0.75);   // eps in the scaled WENO5
 //  * the indicators are formed from the differences of neighbours (ten instructions for the three instead of twelve, and
 //    no cancellation of the values' common part), and the eps of b_s = beta_s + eps rides in their first FMA (`seed`).
 template <class T>
-__device__ __forceinline__ T beta5_0(T c, T d, T e, real seed) {
+__device__ __forceinline__ T beta5_0(T c, T d, T e, T seed) {
   T D1 = d - c, D2 = e - d;
   T d1 = D2 - D1, d2 = D2 - real(3.) * D1;
-  return ((d1 * (real(13.) / real(3.))) * d1 + T(seed)) + d2 * d2;
+  return ((d1 * (real(13.) / real(3.))) * d1 + seed) + d2 * d2;
 }
 template <class T>
-__device__ __forceinline__ T beta5_1(T b, T c, T d, real seed) {
+__device__ __forceinline__ T beta5_1(T b, T c, T d, T seed) {
   T D0 = c - b, D1 = d - c;
   T d1 = D1 - D0, d2 = D0 + D1;
-  return ((d1 * (real(13.) / real(3.))) * d1 + T(seed)) + d2 * d2;
+  return ((d1 * (real(13.) / real(3.))) * d1 + seed) + d2 * d2;
 }
 template <class T>
-__device__ __forceinline__ T beta5_2(T a, T b, T c, real seed) {
+__device__ __forceinline__ T beta5_2(T a, T b, T c, T seed) {
   T Dm = b - a, D0 = c - b;
   T d1 = D0 - Dm, d2 = real(3.) * D0 - Dm;
-  return ((d1 * (real(13.) / real(3.))) * d1 + T(seed)) + d2 * d2;
+  return ((d1 * (real(13.) / real(3.))) * d1 + seed) + d2 * d2;
 }
 // Z-weights alpha_s = C_s (1 + (tau/b_s)^2), b_s = beta_s + eps, evaluated as C_s (1 + (q rho_s)^2) with
 // q = min(tau/b_min, 1e9) and rho_s = b_min/b_s <= 1, i.e. q rho_s = min(tau, 1e9 b_min) / b_s.  Identical in exact
@@ -213,7 +213,7 @@ __device__ __forceinline__ T weno3_combine(T b, T c, T d, T b0, T b1) {
 // Self-smoothness WENO5 of upwind-ordered values.
 template <class T>
 __device__ __forceinline__ T weno5(T a, T b, T c, T d, T e) {
-  return weno5_combine(a, b, c, d, e, beta5_0(c, d, e, kWenoEps5), beta5_1(b, c, d, kWenoEps5), beta5_2(a, b, c, kWenoEps5), true);
+  return weno5_combine(a, b, c, d, e, beta5_0(c, d, e, T(kWenoEps5)), beta5_1(b, c, d, T(kWenoEps5)), beta5_2(a, b, c, T(kWenoEps5)), true);
 }
 
 // Upwind-biased reconstruction from six consecutive values q[0..5] (positions p..p+5).
@@ -243,13 +243,15 @@ __device__ __forceinline__ T biased6(int order, bool left, const T* q, const T* 
   }
   T a = left ? q[0] : q[5], e = left ? q[4] : q[1];
   T sa = left ? s[0] : s[5], se = left ? s[4] : s[1];
-  const real seed = TWO ? real(2.) * kWenoEps5 : kWenoEps5;      // (averaged below when TWO: 0.5 (2 eps) = eps)
+  // TWO: the SUM of the two indicator sets with 2 eps (every b_s, tau and the cap scale alike: the weights are those of
+  // the average with eps), the second set accumulated onto the first inside its FMAs
+  const T seed = T(TWO ? real(2.) * kWenoEps5 : kWenoEps5);
   T b0 = beta5_0(sc, sd, se, seed), b1 = beta5_1(sb, sc, sd, seed), b2 = beta5_2(sa, sb, sc, seed);
   if (TWO) {
     T ta = left ? t[0] : t[5], te = left ? t[4] : t[1];
-    b0 = real(0.5) * (b0 + beta5_0(tc, td, te, real(0.)));
-    b1 = real(0.5) * (b1 + beta5_1(tb, tc, td, real(0.)));
-    b2 = real(0.5) * (b2 + beta5_2(ta, tb, tc, real(0.)));
+    b0 = beta5_0(tc, td, te, b0);
+    b1 = beta5_1(tb, tc, td, b1);
+    b2 = beta5_2(ta, tb, tc, b2);
   }
   return weno5_combine(a, b, c, d, e, b0, b1, b2, !TWO && q == s);
 }
@@ -315,13 +317,15 @@ __device__ __forceinline__ real2v biased6p(int order, bool l0, bool l1, const re
   }
   real2v a = pick(l0, l1, q[0], q[5]), e = pick(l0, l1, q[4], q[1]);
   real2v sa = pick(l0, l1, s[0], s[5]), se = pick(l0, l1, s[4], s[1]);
-  const real seed = TWO ? real(2.) * kWenoEps5 : kWenoEps5;      // (averaged below when TWO: 0.5 (2 eps) = eps)
+  // TWO: the SUM of the two indicator sets with 2 eps (every b_s, tau and the cap scale alike: the weights are those of
+  // the average with eps), the second set accumulated onto the first inside its FMAs
+  const real2v seed = real2v(TWO ? real(2.) * kWenoEps5 : kWenoEps5);
   real2v b0 = beta5_0(sc, sd, se, seed), b1 = beta5_1(sb, sc, sd, seed), b2 = beta5_2(sa, sb, sc, seed);
   if (TWO) {
     real2v ta = pick(l0, l1, t[0], t[5]), te = pick(l0, l1, t[4], t[1]);
-    b0 = real(0.5) * (b0 + beta5_0(tc, td, te, real(0.)));
-    b1 = real(0.5) * (b1 + beta5_1(tb, tc, td, real(0.)));
-    b2 = real(0.5) * (b2 + beta5_2(ta, tb, tc, real(0.)));
+    b0 = beta5_0(tc, td, te, b0);
+    b1 = beta5_1(tb, tc, td, b1);
+    b2 = beta5_2(ta, tb, tc, b2);
   }
   return weno5_combine(a, b, c, d, e, b0, b1, b2, !TWO && q == s);
 }
