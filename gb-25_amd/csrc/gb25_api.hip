@@ -1068,7 +1068,7 @@ gb25_status tracers_impl(gb25_model* m) {
     if (m->uv_lazy && !(ahead && fold))
       return fail(m, GB25_ERR_STATE, "internal: uncorrected velocities in a step whose tracer kernel cannot correct them");
     constexpr int TWL = sizeof(real) == 8 ? 3 : 6;   // (the headline instance: held to 80 VGPRs, six waves per SIMD)
-    constexpr int TW7 = sizeof(real) == 8 ? 2 : 3;   // (the order-7 windows: 9 register pairs per direction)
+    constexpr int TW7 = sizeof(real) == 8 ? 2 : 5;   // (the order-7 windows: 9 register pairs per direction; 90-96 VGPRs without a spill)
     auto kern = m->tracer_order == 7
                     ? (g.cv.on ? (ahead ? k_tracer_tendencies_v5<TW7, true, true, false, true, false, 7> : k_tracer_tendencies_v5<TW7, false, true, false, true, false, 7>)
                        : m->immersed ? (ahead ? k_tracer_tendencies_v5<TW7, true, true, false, false, false, 7> : k_tracer_tendencies_v5<TW7, false, true, false, false, false, 7>)
