@@ -56,7 +56,7 @@ ABI_SYMBOLS = [
 # gb25_option (include/gb25.h)
 OPTION_IDS = {"kernels": 0, "ab2_lookahead": 1, "subcycle_lookahead": 2, "subcycle_block": 3, "fill_fused": 4,
               "two_streams": 5, "store_pressure": 6, "split_tendencies": 7, "pressure_precision": 8, "immersed_kernels": 9, "fold_fills": 10,
-              "lazy_corrector": 11, "momentum_chunk_levels": 12, "tracer_chunk_levels": 13}
+              "lazy_corrector": 11, "momentum_chunk_levels": 12, "tracer_chunk_levels": 13, "tracers_first": 14}
 UNIQUE_ID_BYTES = 128
 # int32 fn(void *user, int32 buffer_set, const void *send_w, const void *send_e, void *recv_w, void *recv_e, int64 nbytes)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
@@ -116,7 +116,11 @@ def load_library(float_type="Float32"):
                     raise GB25Error(
                         f"{path} not found and building it failed ({e}): run `python -c 'import __graft_entry__ as g; "
                         "g.build()'` (hipcc --offload-arch=gfx950).  gb25_amd has no CPU fallback.") from e
-                raise GB25Error(f"{path} is older than its sources and rebuilding it failed: {e}") from e
+                # a loadable library exists (an rsync / checkout that touched the sources' mtimes on a box whose hipcc does
+                # not work, a read-only install): use it, loudly
+                import warnings
+                warnings.warn(f"gb25_amd: {path} is older than its sources and rebuilding it failed ({e}); "
+                              "loading the existing binary", RuntimeWarning)
     if not os.path.exists(path):
         raise GB25Error(f"{path} not found.  gb25_amd has no CPU fallback.")
     # One HIP runtime per process.  PyTorch ships its own copies of libamdhip64 / libhsa-runtime64 / librccl; were this

@@ -25,7 +25,12 @@ def build_library(force=False, verbose=False, float_types=("Float32", "Float64")
     ranks starting at once on a fresh checkout build it once and never dlopen a half-written file."""
     import fcntl
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+    try:   # (the lock next to the outputs; a read-only install still serialises its builders through the temp dir)
+        lock = open(os.path.join(_HERE, ".build.lock"), "w")
+    except OSError:
+        import tempfile
+        lock = open(os.path.join(tempfile.gettempdir(), "gb25_amd.build.lock"), "w")
+    with lock:
         fcntl.flock(lock, fcntl.LOCK_EX)          # other ranks wait here, then find the library up to date
         procs = []
         for ft in float_types:

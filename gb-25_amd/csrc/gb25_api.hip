@@ -95,6 +95,14 @@ struct gb25_model {
   hipStream_t baro_stream = nullptr;   // the look-ahead sub-cycle of a single domain: a stream of its own, so that the
                                        // pressure of the next step (side stream) need not queue behind its tail
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // Order of the two tendency kernels inside a composite step of a single domain (option TRACERS_FIRST, default 1): with the
+  // tracer kernel first, T and S of the next time level (its look-ahead) exist before the momentum kernel runs, so the next
+  // step's pressure -- forked off `ev_tend`, recorded right behind the momentum kernel's finish launch -- runs beside the
+  // next step's sub-cycle (a chain of short LDS phases that leaves HBM idle) instead of beside w.  ev_ts: T, S of this step
+  // and their halo cells are complete (side stream); the tracer kernel waits for it, the momentum kernel for ev_join.
+  hipEvent_t ev_ts = nullptr, ev_tend = nullptr;
+  int tracers_first = 1;
+  bool tend_forkable = false;       // the last tendency evaluation was a composite step's, tracers first: ev_tend covers both kernels
   bool two_streams = true;          // option TWO_STREAMS = 0: strictly sequential phases on one stream
   bool profile = false;
   int profile_only = -1;             // >= 0: time this kernel id alone (keeps the event records out of the other launches)
@@ -964,6 +972,7 @@ inline bool tendencies_split(const gb25_model* m) {
 gb25_status momentum_impl(gb25_model* m, int part = 0) {
   const Grid& g = m->g;
   int nbx, nb;
+  m->tend_forkable = false;
   if (part != 2) m->ahead_uv_valid = m->ahead_baro_valid = false;   // look-aheads made from the previous tendencies are void
   if (m->kernel_gen >= 2) {
     Timed t(m, GB25_K_GU);   // the fused G_u + G_v kernel is accounted under the "gu" timer
@@ -1048,6 +1057,7 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
 gb25_status tracers_impl(gb25_model* m) {
   const Grid& g = m->g;
   int nbx, nb;
+  m->tend_forkable = false;
   if (m->kernel_gen >= 2) {
     Timed t(m, GB25_K_TRACERS);
     nbx = (g.Nx + V3_OUT - 1) / V3_OUT;
@@ -1683,18 +1693,27 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
   // the sub-cycle reads G.U, G.V at interior points only (periodic wrap and walls are in the kernel): their halo
   // fill is for the state's sake and leaves the critical path when no kernel on this stream produced them
   if (!adopted && (s = fill_halos_2d(m, hG))) return s;
+  const bool ts_adopted = m->ahead_valid && (real)dt == m->ahead_dt && chi == m->ahead_chi;
+  // Everything the tracer branch reads was complete when the previous step's momentum kernel had finished (both
+  // look-aheads adopted, the tracer kernel ran before the momentum kernel, no closure whose implicit solve sits in between):
+  // the branch then starts behind THAT kernel -- beside this step's sub-cycle look-ahead, which is still in the queue of
+  // the main stream -- and not behind everything the main stream holds.  (Not across the zipper fold: the fill of G.U, G.V
+  // rewrites the eastern half of the fold line, which the sub-cycle reads.)
+  const bool early_fork = m->tend_forkable && adopted && ts_adopted && !m->catke && m->nu == 0 && m->kappa == 0 && !m->coupled &&
+                          !m->g.cv.north_fold;
+  m->tend_forkable = false;
   HIPCHK(hipEventRecord(m->ev_fork, main));
-  HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
+  HIPCHK(hipStreamWaitEvent(side, early_fork ? m->ev_tend : m->ev_fork, 0));
   // ---- tracer branch (side stream)
   m->stream = side;
   // (complete fills for the two steps after a host write, one per buffer of each alternating pair: see fold_fills)
   const bool complete = m->complete_fills_needed > 0;
   if (complete) m->complete_fills_needed -= 1;
-  const bool ts_adopted = m->ahead_valid && (real)dt == m->ahead_dt && chi == m->ahead_chi;
   s = ab2_tracers_impl(m, (real)dt, chi);
   // y/z/x halos of T, S -- unless the look-ahead that was just adopted wrote them itself
   if (!s && (complete || !(ts_adopted && m->ahead_ts_folded))) s = fill_halos_impl(m, true, false, 1, 2);
   if (!s && m->catke) s = fill_halos_impl(m, true, false, 1, 4);   // the TKE tracer
+  if (!s && hipEventRecord(m->ev_ts, side) != hipSuccess) s = fail(m, GB25_ERR_HIP, "hipEventRecord(ev_ts) failed");
   if (!s) s = compute_p_impl(m, INT_MIN, INT_MIN, 0, -1, true);
   if (!s && adopted) s = fill_halos_2d(m, hG);
   m->stream = main;
@@ -1741,9 +1760,18 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     if (which && (s = fill_halos_impl(m, true, false, which, 1))) return s;
   }
   if ((s = compute_w_impl(m))) return s;
-  // ---- join: the tendencies need w, u, v and the pressure differences, T, S
+  // ---- join: the tendencies need w, u, v and T, S (the tracers) / the pressure differences (the momentum)
+  const bool tracers_first = m->tracers_first != 0;
+  if (tracers_first) {
+    HIPCHK(hipStreamWaitEvent(main, m->ev_ts, 0));
+    if ((s = tracers_impl(m))) return s;
+  }
   HIPCHK(hipStreamWaitEvent(main, m->ev_join, 0));
   if ((s = momentum_impl(m))) return s;
+  if (tracers_first) {
+    HIPCHK(hipEventRecord(m->ev_tend, main));
+    m->tend_forkable = true;
+  }
   if (m->baro_ahead && m->ahead_uv_valid && !m->ptr_exposed) {
     // G.U, G.V of the next step exist now, and with them everything its split-explicit sub-cycle needs: it runs here,
     // into the partner buffers, and leaves the head of the next step (where the corrector waits for it).
@@ -1770,7 +1798,7 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     }
     m->ahead_baro_valid = true;
   }
-  if ((s = tracers_impl(m))) return s;
+  if (!tracers_first && (s = tracers_impl(m))) return s;
   if ((s = catke_update_impl(m))) return s;
   return atmosphere_ocean_fluxes_impl(m);   // (a coupled model: the fluxes the NEXT evaluation of the tendencies sees)
 }
@@ -1861,6 +1889,8 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_baro, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_mom, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&m->ev_ts, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&m->ev_tend, hipEventDisableTiming));
 
   m->stream = m->own_stream;
   m->last_dt = cfg->dt;
@@ -2041,6 +2071,8 @@ void gb25_destroy(gb25_model* m) {
   if (m->ev_join) hipEventDestroy(m->ev_join);
   if (m->ev_baro) hipEventDestroy(m->ev_baro);
   if (m->ev_mom) hipEventDestroy(m->ev_mom);
+  if (m->ev_ts) hipEventDestroy(m->ev_ts);
+  if (m->ev_tend) hipEventDestroy(m->ev_tend);
   if (m->own_stream) hipStreamDestroy(m->own_stream);
   delete m;
 }
@@ -2506,6 +2538,7 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
   if (m->baro_stream) HIPCHK(hipStreamSynchronize(m->baro_stream));
   if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
   m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+  m->tend_forkable = false;
   switch (opt) {
     case GB25_OPT_KERNELS:
       if (v != 1 && v != 2) return fail(m, GB25_ERR_INVALID_ARGUMENT, "GB25_OPT_KERNELS: 1 (direct stencil) or 2 (default)");
@@ -2538,6 +2571,7 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
       m->complete_fills_needed = 2;
       return GB25_OK;
     case GB25_OPT_LAZY_CORRECTOR: m->lazy_corrector = v != 0; return GB25_OK;
+    case GB25_OPT_TRACERS_FIRST: m->tracers_first = v != 0; return GB25_OK;
     case GB25_OPT_MOMENTUM_CHUNK_LEVELS:
     case GB25_OPT_TRACER_CHUNK_LEVELS:
       if (v < 6 || v > 4096) return fail(m, GB25_ERR_INVALID_ARGUMENT, "chunk levels: 6 or more");
@@ -2578,6 +2612,7 @@ gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
     case GB25_OPT_LAZY_CORRECTOR: *v = m->lazy_corrector; break;
     case GB25_OPT_MOMENTUM_CHUNK_LEVELS: *v = m->mom_chunk_levels; break;
     case GB25_OPT_TRACER_CHUNK_LEVELS: *v = m->trc_chunk_levels; break;
+    case GB25_OPT_TRACERS_FIRST: *v = m->tracers_first; break;
     default: return GB25_ERR_INVALID_ARGUMENT;
   }
   return GB25_OK;
@@ -2735,8 +2770,10 @@ gb25_status gb25_save_state(gb25_model* m, const char* directory, const char* la
   z.add_array("time", "<f8", {}, &m->time);
   z.add_array("rank", "<i8", {}, &meta[1]);
   z.add_array("nranks", "<i8", {}, &meta[2]);
-  static const struct { const char* name; gb25_field id; } fs[] = {
-      {"u", GB25_U}, {"v", GB25_V}, {"w", GB25_W}, {"eta", GB25_ETA}, {"T", GB25_T}, {"S", GB25_S}};
+  // Oceananigans.fields(model): velocities, free surface, tracers -- (T, S), and e with closure = CATKEVerticalDiffusivity()
+  struct Member { const char* name; gb25_field id; };
+  std::vector<Member> fs = {{"u", GB25_U}, {"v", GB25_V}, {"w", GB25_W}, {"eta", GB25_ETA}, {"T", GB25_T}, {"S", GB25_S}};
+  if (m->catke) fs.push_back({"e", GB25_E});
   std::string names;
   std::vector<real> host;
   for (auto& fld : fs) {

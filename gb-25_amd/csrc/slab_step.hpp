@@ -936,7 +936,8 @@ gb25_status group_refresh(SlabGroup* G) {
 
 // (The comm stream is an ordinary stream.  A high-priority one -- tried so that it would not share a hardware queue with
 // the slab's side stream -- made the 180-column step 2.3x slower beside RCCL's kernel.  What helps is more hardware queues
-// for the process: GPU_MAX_HW_QUEUES=8, which bench.py and gb25_amd set by default before the runtime starts.)
+// for the process: GPU_MAX_HW_QUEUES=8, which bench.py and tools/slab_selfring.py set before the runtime starts (one model per
+// process; the Python package itself leaves the runtime's default alone, see bench.py).)
 // Builds the exchange context of `n` slabs (n > 1 only with the local transport).  Takes ownership of `tr`.
 gb25_status group_create(gb25_model* const* slabs, int n, Transport* tr) {
   gb25_model* m = slabs[0];

@@ -5,8 +5,10 @@ The reference couples ClimaOcean's `ocean_simulation` on the TripolarGrid with G
 `SimilarityTheoryFluxes(solver_stop_criteria = FixedIterations(5))` inside an `OceanSeaIceModel`.  Here the host side -- this
 file -- builds the atmosphere and interpolates it to the ocean's cell centres; the per-step work (the similarity-theory flux
 solve per surface cell and the top flux boundary conditions it feeds) runs in the library (`gb25_set_prescribed_atmosphere`,
-`k_similarity_fluxes`).  What `ocean_simulation` adds beyond `baroclinic_instability_model` + CATKE (7th-order tracer
-advection, quadratic bottom drag) is not built; DESIGN.md says so.
+`k_similarity_fluxes`).  What `ocean_simulation` adds beyond `baroclinic_instability_model` + CATKE -- WENO(order = 7)
+tracer advection, the quadratic bottom drag, its closure parameters -- is in the library too (`gb25_set_tracer_advection_order`,
+`gb25_set_bottom_drag`, `default_ocean_closure`); all of it restated from memory of ClimaOcean 0.5.10, which is not in
+/root/reference: parity unpinned (DESIGN.md sections 0 and 4).
 """
 import numpy as np
 

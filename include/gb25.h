@@ -128,6 +128,10 @@ typedef enum {
   GB25_OPT_MOMENTUM_CHUNK_LEVELS, /* [12] levels a block of the momentum tendency kernel marches through (>= 6); also the
                                     association of the column integrals of u, v: results change in the last bits */
   GB25_OPT_TRACER_CHUNK_LEVELS,  /* [12] the same for the tracer tendency kernel (bitwise neutral) */
+  GB25_OPT_TRACERS_FIRST,        /* [1] single domain, composite steps: the tracer tendency kernel before the momentum kernel, so
+                                    that the next step's pressure (it needs the tracer look-ahead's T, S) can run beside the next
+                                    step's sub-cycle; 0: momentum first (src/precompile.jl:48-50 lists them in that order; the
+                                    two evaluations are independent of each other) */
   GB25_OPT_COUNT
 } gb25_option;
 

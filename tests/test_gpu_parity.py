@@ -462,7 +462,8 @@ def test_fills_folded_into_their_producers_are_bitwise_neutral(shape, halo):
 
 @pytest.mark.parametrize("opts", [dict(two_streams=0), dict(subcycle_block=3), dict(subcycle_block=1),
                                   dict(store_pressure=1), dict(ab2_lookahead=2, subcycle_lookahead=1),
-                                  dict(subcycle_lookahead=2), dict(fold_fills=0)])
+                                  dict(subcycle_lookahead=2), dict(fold_fills=0), dict(tracers_first=0),
+                                  dict(tracers_first=0, lazy_corrector=0)])
 def test_schedule_options_are_bitwise_neutral(opts):
     """Every schedule switch of gb25_set_option (single stream, 3 substeps per launch, pHY' stored every step, tracer
     look-ahead only) gives the bits of the default schedule, through a changed dt and an option flipped mid-run.  One
@@ -556,3 +557,4 @@ def test_minimum_sizes_and_halos(shape, halo):
     _, report = gb.compare_states(r, v, rtol=SQRT_EPS32, include_halos=False, verbose=False)
     bad = [(q["name"], q["rel"]) for q in report if not q["rel"] <= SQRT_EPS32]
     assert not bad, bad
+
