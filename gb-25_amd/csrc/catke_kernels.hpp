@@ -181,16 +181,18 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
   }
 }
 // TripolarGrid: the rows beyond the zipper fold of the diffusivity fields and of J^b (cell-centred in x and y, no sign
-// change): (i, Ny-1+q) <- (Nx-1-i, Ny-q), q = 1 .. H, over every parent column (source column wrapped periodically), which
+// change): (i, Ny-1+q) <- (Nx-1-i, Ny-1-q), q = 1 .. H (q = 0: the pivot row's eastern copy <- its western image: k_fill_fold), over
+// every parent column (source column wrapped periodically), which
 // replaces the zero-gradient northern layer k_catke_diffusivities wrote.  blockIdx.z: face levels 0 .. Nz of the three
 // kappa, levels -1 .. Nz of L^e (its bottom / top layer on those rows), then J^b.
 __global__ void k_catke_fold(Grid g, real* __restrict__ KU, real* __restrict__ KC, real* __restrict__ KE,
                              real* __restrict__ Le, real* __restrict__ Jb) {
   const int ip = blockIdx.x * blockDim.x + threadIdx.x;
   if (ip >= g.sx) return;
-  const int i = ip - g.H, q = blockIdx.y + 1, z = blockIdx.z, Nz = g.Nz;
-  const int isrc = (((g.Nx - 1 - i) % g.Nx) + g.Nx) % g.Nx;
-  const int jd = g.Ny - 1 + q, js = g.Ny - q;
+  const int i = ip - g.H, q = blockIdx.y, z = blockIdx.z, Nz = g.Nz;   // q = 0: the pivot row's eastern copy <- its image
+  const int iw = ((i % g.Nx) + g.Nx) % g.Nx, isrc = g.Nx - 1 - iw;
+  if (q == 0 && !fold_pivot_slave(iw, g.Nx, false)) return;
+  const int jd = g.Ny - 1 + q, js = g.Ny - 1 - q;
   if (z <= Nz) {
     const int od = ic(g, i, jd, z), os = ic(g, isrc, js, z);
     KU[od] = KU[os];
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_var(Grid g, ImplicitV
   const int z = blockIdx.z, Nz = g.Nz;
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   const bool vsh = MODE == 0 && z == 1, pair = MODE == 1 && z == 0, tke = MODE == 1 && z == 1;
-  if (i >= g.Nx || j >= (vsh ? g.Ny + g.cv.north_fold : g.Ny)) return;
+  if (i >= g.Nx || j >= (vsh ? g.Ny : g.Ny)) return;
   const int o2 = i2(g, i, j), kf = implicit_var_first_level<IMM, MODE>(g, z, o2, j);
   real* Fa = MODE == 0 ? A.f[z] : (pair ? A.f[2] : A.f[4]);
   real* Fb = A.f[3];
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_var_stream(Grid g, Im
   const int z = blockIdx.z, Nz = g.Nz;
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   const bool vsh = MODE == 0 && z == 1, pair = MODE == 1 && z == 0, tke = MODE == 1 && z == 1;
-  if (i >= g.Nx || j >= (vsh ? g.Ny + g.cv.north_fold : g.Ny)) return;
+  if (i >= g.Nx || j >= (vsh ? g.Ny : g.Ny)) return;
   const int o2 = i2(g, i, j), kf = implicit_var_first_level<IMM, MODE>(g, z, o2, j);
   real* Fa = MODE == 0 ? A.f[z] : (pair ? A.f[2] : A.f[4]);
   real* Fb = A.f[3];

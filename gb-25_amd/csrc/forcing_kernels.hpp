@@ -122,7 +122,7 @@ template <bool IMM>
 __global__ void k_bottom_drag_flux(Grid g, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ Ju,
                                    real* __restrict__ Jv, real Cd, int i_first, int n) {
   const int i = i_first + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= i_first + n || j >= g.Ny + g.cv.north_fold) return;
+  if (i >= i_first + n || j >= g.Ny) return;
   const int o2 = i2(g, i, j);
   int ku = 0, kv = 0;
   if (IMM) {

@@ -82,8 +82,11 @@ struct gb25_model {
   int Ns = 0;
   double dtau_frac = 0;
   std::vector<double> weights;
-  // wide-halo barotropic work arrays (slab mode)
-  int W = 0;
+  // work arrays of the sub-cycle: widened by W columns either side on a slab (wide halos, filled once per step), tall by Wy
+  // rows beyond the pivot row on a folded grid (images of the rows south of it, filled once per step); a single folded
+  // domain has W = 0
+  int W = 0, Wy = 0;
+  real* tall_buf = nullptr;          // single folded domain: the buffer its image rows pass through (k_tall_rows)
   Field wide[2][3];  // [pingpong][eta,U,V]
   Field wideG[2];    // GU, GV
   Field wideBar[3];  // running averages on the wide domain
@@ -380,14 +383,16 @@ double quad_area(const GNode& a, const GNode& b, const GNode& c, const GNode& d,
 }
 
 // The 14 horizontal metrics (gb25_metric2 order) and the physical coordinates of the cell centre at GLOBAL column ig,
-// row j (any integers: halo rows and columns are generated like interior ones; rows beyond the fold are the mirrored
-// cells).  grid_type 2: the lat-lon metrics; 3, 4: the tripolar grid.
-void curv_metrics_at(const gb25_model* m, int ig, int j, double out[GB25_M2_COUNT], double* lam_c, double* phi_c) {
+// row j (any integers: halo rows and columns are generated like interior ones).  grid_type 2: the lat-lon metrics; 3, 4: the
+// tripolar grid, whose Ny rows of cell centres run from the southern edge to 90 degrees (Oceananigans' TripolarGrid:
+// range(southernmost_latitude, 90, length = Ny); "the north pole is a Center point"), the y faces half a spacing south of them.
+// `own` rows only (j <= Ny - 1 on the tripolar grid): curv_metrics_at maps the rows beyond the pivot row onto their images.
+void curv_metrics_own(const gb25_model* m, int ig, int j, double out[GB25_M2_COUNT], double* lam_c, double* phi_c) {
   const gb25_config& c = m->cfg;
   const bool tri = c.grid_type >= GB25_GRID_TRIPOLAR;
   const double d2r = M_PI / 180.0, R = c.radius;
   const double lam0 = tri ? 70.0 : c.lon_west, dlam = (tri ? 360.0 : (c.lon_east - c.lon_west)) / c.Nx;
-  const double phiN = tri ? 90.0 : c.lat_north, dphi = (phiN - c.lat_south) / c.Ny;
+  const double phiN = tri ? 90.0 : c.lat_north, dphi = (phiN - c.lat_south) / (tri ? c.Ny - 1 : c.Ny);
   if (!tri) {
     const int a = m->metric_off_j + j;
     out[GB25_M2_DXFC] = out[GB25_M2_DXCC] = m->h_metric[GB25_M_DXC][a];
@@ -404,7 +409,7 @@ void curv_metrics_at(const gb25_model* m, int ig, int j, double out[GB25_M2_COUN
   }
   // computational coordinates of the four node families around the 0-based (ig, j)
   const double lf = lam0 + ig * dlam, lc = lam0 + (ig + 0.5) * dlam;
-  const double pf = c.lat_south + j * dphi, pc = c.lat_south + (j + 0.5) * dphi;
+  const double pc = c.lat_south + j * dphi, pf = pc - 0.5 * dphi;
   auto N = [](double l, double p) { return tripolar_node(l, p); };
   const GNode cc = N(lc, pc), fc = N(lf, pc), cf = N(lc, pf), ff = N(lf, pf);
   const GNode fc_e = N(lf + dlam, pc), ff_e = N(lf + dlam, pf), cc_w = N(lc - dlam, pc), cf_w = N(lc - dlam, pf);
@@ -427,19 +432,28 @@ void curv_metrics_at(const gb25_model* m, int ig, int j, double out[GB25_M2_COUN
   out[GB25_M2_PHICC] = cc.phi;
   if (lam_c) *lam_c = cc.lam;
   if (phi_c) *phi_c = cc.phi;
-  if (j == c.Ny) {
-    // The y faces on the fold line are shared by the two halves of the row: face ig IS face Nx-1-ig.  The generator reaches
-    // it along two different index paths; both halves get the western half's numbers, to the last bit (the blocked
-    // sub-cycle advances images of the cells beyond the fold and relies on it).
-    const int iw = ((ig % c.Nx) + c.Nx) % c.Nx;
-    if (2 * iw >= c.Nx) {
-      double w[GB25_M2_COUNT];
-      curv_metrics_at(m, c.Nx - 1 - iw, j, w, nullptr, nullptr);
-      out[GB25_M2_DXCF] = w[GB25_M2_DXCF];
-      out[GB25_M2_DYCF] = w[GB25_M2_DYCF];
-      out[GB25_M2_AZCF] = w[GB25_M2_AZCF];
-    }
+}
+// ... at any row: beyond the pivot row of a folded grid (j >= Ny) the metric of a location is the metric of its image --
+// cell rows and y-face rows mirror about the centres of row Ny-1, x faces as ig -> (Nx - ig) mod Nx (kernels.hpp, k_fill_fold).
+// The images are COPIES of interior numbers (a host-supplied grid is treated the same way), so a metric and its image agree
+// to the last bit whatever generated them.
+void curv_metrics_at(const gb25_model* m, int ig, int j, double out[GB25_M2_COUNT], double* lam_c, double* phi_c) {
+  const gb25_config& c = m->cfg;
+  if (c.grid_type < GB25_GRID_TRIPOLAR || j < c.Ny) {
+    curv_metrics_own(m, ig, j, out, lam_c, phi_c);
+    return;
   }
+  const int iw = ((ig % c.Nx) + c.Nx) % c.Nx, icc = c.Nx - 1 - iw, ifc = iw == 0 ? 0 : c.Nx - iw;
+  const int jc = 2 * (c.Ny - 1) - j, jf = 2 * c.Ny - 1 - j;
+  double A[GB25_M2_COUNT], B[GB25_M2_COUNT], C[GB25_M2_COUNT], D[GB25_M2_COUNT];
+  curv_metrics_own(m, icc, jc, A, lam_c, phi_c);   // (c,c)
+  curv_metrics_own(m, ifc, jc, B, nullptr, nullptr);   // (f,c)
+  curv_metrics_own(m, icc, jf, C, nullptr, nullptr);   // (c,f)
+  curv_metrics_own(m, ifc, jf, D, nullptr, nullptr);   // (f,f)
+  out[GB25_M2_DXCC] = A[GB25_M2_DXCC]; out[GB25_M2_DYCC] = A[GB25_M2_DYCC]; out[GB25_M2_AZCC] = A[GB25_M2_AZCC]; out[GB25_M2_PHICC] = A[GB25_M2_PHICC];
+  out[GB25_M2_DXFC] = B[GB25_M2_DXFC]; out[GB25_M2_DYFC] = B[GB25_M2_DYFC]; out[GB25_M2_AZFC] = B[GB25_M2_AZFC];
+  out[GB25_M2_DXCF] = C[GB25_M2_DXCF]; out[GB25_M2_DYCF] = C[GB25_M2_DYCF]; out[GB25_M2_AZCF] = C[GB25_M2_AZCF];
+  out[GB25_M2_DXFF] = D[GB25_M2_DXFF]; out[GB25_M2_DYFF] = D[GB25_M2_DYFF]; out[GB25_M2_AZFF] = D[GB25_M2_AZFF]; out[GB25_M2_FFF] = D[GB25_M2_FFF];
 }
 
 // Fills m->h_curv (the local slab's columns, halo columns by their own global index) and uploads what the kernels read
@@ -489,16 +503,17 @@ gb25_status build_curv_grid(gb25_model* m) {
   cv.north_fold = tri ? 1 : 0;
   return GB25_OK;
 }
-// The metrics of the split-explicit sub-cycle on the WIDENED slab (columns [-W, Nx + W), pitch Nx + 2W, rows like a
-// (c,f) field).  Global columns are wrapped into [0, Nx_global): the sub-cycle of a single domain wraps its indices the
-// same way, so that a decomposition reads the very numbers the single domain reads.
+// The metrics of the split-explicit sub-cycle on the work arrays of a slab (WIDENED: columns [-W, Nx + W), pitch Nx + 2W) and
+// of a folded grid (TALL: Wy more rows beyond the pivot row, whose metrics are those of their images; a single folded domain
+// has W = 0).  Global columns are wrapped into [0, Nx_global): the sub-cycle of a single domain wraps its indices the same
+// way, so that a decomposition reads the very numbers the single domain reads.
 gb25_status build_curv_wide(gb25_model* m) {
   const gb25_config& c = m->cfg;
-  const int Nx = m->Nx, Ny = c.Ny, H = c.halo, W = m->W, wsx = Nx + 2 * W, sy = Ny + 2 * H + 1;
+  const int Nx = m->Nx, Ny = c.Ny, H = c.halo, W = m->W, wsx = Nx + 2 * W, sy = Ny + 2 * H + 1 + m->Wy;
   auto wrap = [&](int ig) { return ((ig % c.Nx) + c.Nx) % c.Nx; };
   std::vector<real> t[5];
   for (auto& a : t) a.assign((size_t)wsx * sy, real(0.));
-  for (int j = -H; j <= Ny + H; j++)
+  for (int j = -H; j <= Ny + H + m->Wy; j++)
     for (int i = -W; i < Nx + W; i++) {
       const size_t o = (size_t)(i + W) + (size_t)wsx * (j + H);
       double v[GB25_M2_COUNT];
@@ -510,27 +525,8 @@ gb25_status build_curv_wide(gb25_model* m) {
       t[4][o] = (real)(1.0 / v[GB25_M2_DYCF]);
     }
   for (int q = 0; q < 5; q++) {
-    HIPCHK(hipMalloc(&m->d_wideM[q], t[q].size() * sizeof(real)));
+    if (!m->d_wideM[q]) HIPCHK(hipMalloc(&m->d_wideM[q], t[q].size() * sizeof(real)));
     HIPCHK(hipMemcpy(m->d_wideM[q], t[q].data(), t[q].size() * sizeof(real), hipMemcpyHostToDevice));
-  }
-  if (m->g.cv.north_fold) {
-    // the cell that (own wide column a, row Ny-1) mirrors onto: global column Nx_global - 1 - ig, row Ny-1
-    std::vector<real> mir((size_t)6 * wsx, real(0.));
-    for (int i = -W; i < Nx + W; i++) {
-      const int igm = wrap(c.Nx - 1 - (i + c.rank * Nx)), a = i + W;
-      double v[GB25_M2_COUNT], ve[GB25_M2_COUNT], vn[GB25_M2_COUNT];
-      curv_metrics_at(m, igm, Ny - 1, v, nullptr, nullptr);
-      curv_metrics_at(m, wrap(igm + 1), Ny - 1, ve, nullptr, nullptr);
-      curv_metrics_at(m, igm, Ny, vn, nullptr, nullptr);
-      mir[a] = (real)v[GB25_M2_DYFC];
-      mir[(size_t)wsx + a] = (real)ve[GB25_M2_DYFC];
-      mir[(size_t)2 * wsx + a] = (real)v[GB25_M2_DXCF];
-      mir[(size_t)3 * wsx + a] = (real)vn[GB25_M2_DXCF];
-      mir[(size_t)4 * wsx + a] = (real)(1.0 / v[GB25_M2_AZCC]);
-      mir[(size_t)5 * wsx + a] = (real)(1.0 / vn[GB25_M2_DYCF]);
-    }
-    HIPCHK(hipMalloc(&m->d_wideM[5], mir.size() * sizeof(real)));
-    HIPCHK(hipMemcpy(m->d_wideM[5], mir.data(), mir.size() * sizeof(real), hipMemcpyHostToDevice));
   }
   return GB25_OK;
 }
@@ -641,7 +637,7 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
     if (nfold && j >= Ny) {
       // the mirrored cell: GLOBAL column Nx_global - 1 - ig, usually another rank's -- the bottom is a function of the
       // global position, evaluated here (a slab sees its partner's bottom without any exchange)
-      const int il = c.Nx - 1 - (i + c.rank * Nx) - c.rank * Nx, jm = 2 * Ny - 1 - j;
+      const int il = c.Nx - 1 - (i + c.rank * Nx) - c.rank * Nx, jm = 2 * (Ny - 1) - j;   // (the fold pivots on the centres of row Ny-1)
       return jm < 0 ? 255 : level(zb(il, jm));
     }
     if (j < 0 || j >= Ny) return 255;
@@ -698,10 +694,10 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
   if ((s = upload(rHc.data(), rHc.size() * sizeof(real), (void**)&m->d_H[3]))) return s;
   m->g.im.ordA = m->d_ord[0]; m->g.im.ordB = m->d_ord[1]; m->g.im.ordC = m->d_ord[2]; m->g.im.ordD = m->d_ord[3];
   m->g.im.Hfc = m->d_H[0]; m->g.im.Hcf = m->d_H[1]; m->g.im.rHfc = m->d_H[2]; m->g.im.rHcf = m->d_H[3];
-  if (m->slab) {   // the same depths on the widened barotropic slab: columns [-W, Nx + W)
+  if (m->slab || nfold) {   // the same depths on the work arrays of the sub-cycle: widened slab / tall folded grid
     const int W = m->W, wsx = Nx + 2 * W;
-    std::vector<real> wf((size_t)wsx * sy, 0), wc(wf.size(), 0);
-    for (int j = 0; j <= Ny; j++)
+    std::vector<real> wf((size_t)wsx * (sy + m->Wy), 0), wc(wf.size(), 0);
+    for (int j = 0; j <= Ny + m->Wy; j++)
       for (int i = -W; i < Nx + W; i++) {
         const size_t o = (size_t)(i + W) + (size_t)wsx * (j + H);
         wf[o] = (real)std::min(depth(i - 1, j), depth(i, j));
@@ -731,7 +727,7 @@ double gaussian_islands_bottom(const gb25_model* m, int i_local, int j) {
     // the first mountain's longitude: without this only its eastern half would exist)
     double lam, phi;
     if (c.grid_type >= GB25_GRID_TRIPOLAR) {   // (the centre node alone: this runs for every column of the bottom tables)
-      const GNode cc = tripolar_node(70.0 + (ig + 0.5) * (360.0 / c.Nx), c.lat_south + (j + 0.5) * ((90.0 - c.lat_south) / c.Ny));
+      const GNode cc = tripolar_node(70.0 + (ig + 0.5) * (360.0 / c.Nx), c.lat_south + j * ((90.0 - c.lat_south) / (c.Ny - 1)));
       lam = cc.lam;
       phi = cc.phi;
     } else {
@@ -797,8 +793,9 @@ Halo2 halo2_G(gb25_model* m) {   // the barotropic forcing G.U, G.V
 inline bool producers_fold(const gb25_model* m) {
   return !m->slab && m->fold_fills && !m->g.cv.north_fold && m->nu == 0 && m->kappa == 0 && !m->catke && m->tracer_order == 5;
 }
-// rows of y faces that are stepped: the fold line is one
-inline int v_rows(const Grid& g) { return g.Ny + g.cv.north_fold; }
+// rows of y faces a launch covers (face 0 is the southern wall; the faces beyond the last row of cells are a wall or, on a
+// folded grid, halo cells)
+inline int v_rows(const Grid& g) { return g.Ny; }
 
 // y/z boundary layers (always local) and, for a single slab, the periodic x copy.
 // extended: also treat the x-halo columns (slab mode, after the neighbours' columns were unpacked).
@@ -819,7 +816,7 @@ gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, i
     if (which == 2) return fill_halos_2d(m, h2);
     if (which == 1) h2.n = 0;
     hipLaunchKernelGGL(k_fill_yz, dim3((g.Nx + 255) / 256, g.Nz + 1 + g.Ny), b, 0, st, g, h3, h2, 0, g.Nx);
-    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H, g.Nz + 2 + (h2.n ? 1 : 0)), b, 0, st, g, h3, h2);
+    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H + 1, g.Nz + 2 + (h2.n ? 1 : 0)), b, 0, st, g, h3, h2);
     const int rows_c = g.sy_c * (g.Nz + 2 * g.H), rows_v = g.sy_v * (g.Nz + 2 * g.H);
     hipLaunchKernelGGL(k_fill_x, dim3((unsigned)(((long)rows_v * 2 * g.H + 255) / 256), 4 + h2.n), b, 0, st, g, h3, h2,
                        rows_c, rows_v);
@@ -864,7 +861,7 @@ gb25_status fill_halos_2d(gb25_model* m, Halo2 h2) {
   g2.Nz = 0;
   hipLaunchKernelGGL(k_fill_y, dim3((g.Nx + 255) / 256, 1), b, 0, m->stream, g2, none, h2, 0, g.Nx);
   if (g.cv.north_fold && !m->slab)   // (a slab's rows beyond the fold come from its partner rank: slab_step.hpp)
-    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H, 1), b, 0, m->stream, g, none, h2);
+    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H + 1, 1), b, 0, m->stream, g, none, h2);
   if (g.x_periodic) {
     long threads = (long)g.sy_v * 2 * g.H;
     hipLaunchKernelGGL(k_fill_x, dim3((unsigned)((threads + 255) / 256), 4 + h2.n), b, 0, m->stream, g2, none, h2, 0,
@@ -1268,6 +1265,24 @@ gb25_status ab2_local_impl(gb25_model* m, real dt, real chi) {
 // group 1), every substep computes on [-W+1, Nx+W-1) and the invalid rim never reaches the interior.
 // ahead (single slab only): read eta, U, V where they are and G.U, G.V from the momentum look-ahead, write the new
 // eta, U, V and the averages into the partner buffers.
+// the image rows of the sub-cycle's tall work arrays (folded grid): pack the rows south of the pivot row / unpack into the rows
+// beyond it.  A slab exchanges the buffer with its partner rank in between (slab_step.hpp, group 8); a single domain unpacks
+// what it packed.
+int64_t tall_buffer_elems(const gb25_model* m) { return (int64_t)5 * (m->Wy + 1) * (m->Nx + 2 * m->W); }
+gb25_status tall_rows_impl(gb25_model* m, real* buf, bool pack) {
+  const Grid& g = m->g;
+  TallRows T{};
+  for (int q = 0; q < 3; q++) T.p[q] = m->wide[0][q].d;
+  T.p[3] = m->wideG[0].d;
+  T.p[4] = m->wideG[1].d;
+  T.sx = g.Nx + 2 * m->W; T.xo = m->W; T.Wy = m->Wy; T.wrap = m->slab ? 0 : 1;
+  const dim3 gr((T.sx + 255) / 256, m->Wy + 1, 5);
+  if (pack) hipLaunchKernelGGL(k_tall_rows<true>, gr, dim3(256), 0, m->stream, g, T, buf, m->cfg.rank * g.Nx, m->cfg.Nx);
+  else hipLaunchKernelGGL(k_tall_rows<false>, gr, dim3(256), 0, m->stream, g, T, buf, m->cfg.rank * g.Nx, m->cfg.Nx);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+
 gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
   const Grid& g = m->g;
   if (m->baro_inflight && !ahead) {
@@ -1276,15 +1291,16 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     HIPCHK(hipStreamWaitEvent(m->stream, m->ev_baro, 0));
     m->baro_inflight = false;
   }
-  if (m->slab && g.cv.north_fold)
-    return fail(m, GB25_ERR_STATE, "internal: the sub-cycle of a slab of a folded grid runs substep by substep (slab_step.hpp)");
   Timed t(m, GB25_K_BAROTROPIC);
   m->last_baro_folded = false;
-  const bool wide = m->slab;
+  // work arrays: a slab's are widened in x (filled by the exchange of group 1 / 3 before this is called), a folded grid's are
+  // tall (image rows beyond the pivot row: a slab's come from its partner before this is called, a single domain's below)
+  const bool wide = m->slab || g.cv.north_fold;
   const real dtau = (real)m->dtau_frac * dt;
   dim3 b(64, 4);
   Baro bb;
   real *cur[3], *nxt[3], *other[3], *out[3];
+  bb.jhi = g.Ny + m->Wy;
   if (!wide) {
     size_t nbar = m->f[GB25_ETA_BAR].elems() + m->f[GB25_U_BAR].elems() + m->f[GB25_V_BAR].elems();
     if (m->baro_block <= 1)   // (the blocked kernels start their averages from zero themselves)
@@ -1301,7 +1317,24 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     bb.sx = g.sx; bb.xo = g.H; bb.ilo = 0; bb.ihi = g.Nx; bb.wrap = 1;
     bb.Hfc = m->d_H[0]; bb.Hcf = m->d_H[1];
   } else {
-    if (m->baro_block <= 1 || g.cv.on)
+    const int wsx = g.Nx + 2 * m->W;
+    if (!m->slab) {
+      // single folded domain: the state and the forcing into the work arrays, then the image rows beyond the pivot row
+      InteriorCopies C{};
+      int rmax = 0;
+      for (int q = 0; q < 5; q++) {
+        const Field& src = q < 3 ? m->f[GB25_ETA + q] : (ahead ? m->ahead_G[q - 3] : m->f[GB25_GN_BT_U + q - 3]);
+        C.dst[q] = q < 3 ? m->wide[0][q].d : m->wideG[q - 3].d; C.dsx[q] = wsx; C.dxo[q] = m->W;
+        C.src[q] = src.d; C.ssx[q] = g.sx; C.sxo[q] = g.H; C.rows[q] = src.ny;
+        rmax = std::max(rmax, src.ny);
+      }
+      C.n = 5;
+      hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, rmax, C.n), dim3(256), 0, m->stream, C, g.Nx);
+      gb25_status s;
+      if ((s = tall_rows_impl(m, m->tall_buf, true))) return s;
+      if ((s = tall_rows_impl(m, m->tall_buf, false))) return s;
+    }
+    if (m->baro_block <= 1)
       HIPCHK(hipMemsetAsync(m->wideBar[0].d, 0,
                             (m->wideBar[0].elems() + m->wideBar[1].elems() + m->wideBar[2].elems()) * sizeof(real),
                             m->stream));
@@ -1311,36 +1344,48 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     }
     bb.etab = m->wideBar[0].d; bb.Ub = m->wideBar[1].d; bb.Vb = m->wideBar[2].d;
     bb.GU = m->wideG[0].d; bb.GV = m->wideG[1].d;
-    bb.sx = g.Nx + 2 * m->W; bb.xo = m->W; bb.ilo = -m->W + 1; bb.ihi = g.Nx + m->W - 1; bb.wrap = 0;
+    bb.sx = wsx; bb.xo = m->W;
+    if (m->slab) { bb.ilo = -m->W + 1; bb.ihi = g.Nx + m->W - 1; bb.wrap = 0; }
+    else { bb.ilo = 0; bb.ihi = g.Nx; bb.wrap = 1; }
     bb.Hfc = m->d_wideH[0]; bb.Hcf = m->d_wideH[1];
   }
   const bool imm = m->immersed;
   bool finalize_after = false;
-  // temporally blocked: the lat-lon kernel (row metrics; single domain and widened slabs), or its curvilinear sibling
-  // (single domain; a widened curvilinear slab advances substep by substep)
-  const bool blocked_curv = m->baro_block > 1 && g.cv.on && !wide;
-  const bool blocked = (m->baro_block > 1 && !g.cv.on) || blocked_curv;
+  // temporally blocked: the lat-lon kernel (row metrics) or its curvilinear sibling (per-point metrics); on canonical arrays
+  // (single domain), widened slabs and the tall arrays of a folded grid alike
+  const bool blocked_curv = m->baro_block > 1 && g.cv.on;
+  const bool blocked = m->baro_block > 1;
+  const CurvBaro cb = wide ? CurvBaro{m->d_wideM[0], m->d_wideM[1], m->d_wideM[2], m->d_wideM[3], m->d_wideM[4]}
+                           : CurvBaro{g.cv.dyfc, g.cv.dxcf, g.cv.razcc, g.cv.rdxfc, g.cv.rdycf};
+  const int rows = bb.jhi + (g.cv.north_fold ? 1 : 0);   // (folded: the face row behind the last advanced row is carried along)
+  auto fill_multi = [&](BaroMulti& bm, int s, int Sk) {
+    bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
+    bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
+    bm.b = bb;
+    bm.ns = std::min(Sk, m->Ns - s);
+    bm.first = s == 0;
+    bm.last = s + Sk >= m->Ns;
+    if (bm.first && bm.last && !wide && !ahead) {
+      // a sub-cycle short enough for ONE launch would read and write the canonical eta, U, V in the same launch
+      bm.last = 0;
+      finalize_after = true;
+    }
+    bm.eta_out = out[0]; bm.U_out = out[1]; bm.V_out = out[2];
+    bm.eb_out = bm.ub_out = bm.vb_out = nullptr;
+    bm.fold = 0;
+    bm.out_halo = m->slab ? g.H : 0;   // (a widened slab also writes the x halo columns of the new eta, U, V)
+    if (wide) {
+      const Field* fb = ahead ? m->ahead_bar : &m->f[GB25_ETA_BAR];
+      bm.eb_out = fb[0].d; bm.ub_out = fb[1].d; bm.vb_out = fb[2].d;
+    }
+    for (int q = 0; q < BT_SMAX; q++) bm.w[q] = (s + q < m->Ns) ? (real)m->weights[s + q] : real(0.);
+  };
   if (blocked_curv) {
     constexpr int Sk = 5, TYc = 17;
-    dim3 gm((g.Nx + BT_TX - 1) / BT_TX, (v_rows(g) + TYc - 1) / TYc);
-    const CurvBaro cb{g.cv.dyfc, g.cv.dxcf, g.cv.razcc, g.cv.rdxfc, g.cv.rdycf, nullptr, nullptr, 0, g.Nx};
+    dim3 gm((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX, (rows + TYc - 1) / TYc);
     for (int s = 0; s < m->Ns; s += Sk) {
       BaroMulti bm;
-      bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
-      bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
-      bm.b = bb;
-      bm.ns = std::min(Sk, m->Ns - s);
-      bm.first = s == 0;
-      bm.last = s + Sk >= m->Ns;
-      if (bm.first && bm.last && !ahead) {   // (one launch would read and write the canonical eta, U, V)
-        bm.last = 0;
-        finalize_after = true;
-      }
-      bm.eta_out = out[0]; bm.U_out = out[1]; bm.V_out = out[2];
-      bm.eb_out = bm.ub_out = bm.vb_out = nullptr;
-      bm.fold = 0;
-      bm.out_halo = 0;
-      for (int q = 0; q < BT_SMAX; q++) bm.w[q] = (s + q < m->Ns) ? (real)m->weights[s + q] : real(0.);
+      fill_multi(bm, s, Sk);
       hipLaunchKernelGGL((k_barotropic_multi_curv<Sk, TYc>), gm, dim3(BT_NT), 0, m->stream, g, bm, cb, dtau);
       for (int q = 0; q < 3; q++) { real* w_ = nxt[q]; nxt[q] = other[q]; other[q] = w_; cur[q] = w_; }
     }
@@ -1356,40 +1401,19 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     const int Sk = S <= 3 ? 3 : (S <= 5 ? 5 : 7);
     for (int s = 0; s < m->Ns; s += Sk) {
       BaroMulti bm;
-      bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
-      bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
-      bm.b = bb;
-      bm.ns = std::min(Sk, m->Ns - s);
-      bm.first = s == 0;
-      bm.last = s + Sk >= m->Ns;
-      if (bm.first && bm.last && !wide && !ahead) {
-        // a sub-cycle short enough for ONE launch would read and write the canonical eta, U, V in the same launch
-        bm.last = 0;
-        finalize_after = true;
-      }
-      bm.eta_out = out[0]; bm.U_out = out[1]; bm.V_out = out[2];
-      bm.eb_out = bm.ub_out = bm.vb_out = nullptr;
+      fill_multi(bm, s, Sk);
       bm.fold = (!wide && producers_fold(m) && m->composite && bm.last) ? 1 : 0;
-      bm.out_halo = wide ? g.H : 0;   // (a widened slab also writes the x halo columns of the new eta, U, V)
       if (bm.last) m->last_baro_folded = bm.fold != 0;
-      if (wide) {
-        const Field* fb = ahead ? m->ahead_bar : &m->f[GB25_ETA_BAR];
-        bm.eb_out = fb[0].d; bm.ub_out = fb[1].d; bm.vb_out = fb[2].d;
-      }
-      for (int q = 0; q < BT_SMAX; q++) bm.w[q] = (s + q < m->Ns) ? (real)m->weights[s + q] : real(0.);
       hipLaunchKernelGGL(kern, gm, dim3(BT_NT), 0, m->stream, g, bm, dtau);
       for (int q = 0; q < 3; q++) { real* w_ = nxt[q]; nxt[q] = other[q]; other[q] = w_; cur[q] = w_; }
     }
   } else {
-    dim3 gr = grid2(bb.ihi - bb.ilo, v_rows(g), b);
-    const CurvBaro cb = wide ? CurvBaro{m->d_wideM[0], m->d_wideM[1], m->d_wideM[2], m->d_wideM[3], m->d_wideM[4], nullptr,
-                                        nullptr, m->cfg.rank * g.Nx, m->cfg.Nx}
-                             : CurvBaro{g.cv.dyfc, g.cv.dxcf, g.cv.razcc, g.cv.rdxfc, g.cv.rdycf, nullptr, nullptr, 0, g.Nx};
+    dim3 gr = grid2(bb.ihi - bb.ilo, g.cv.on ? rows : g.Ny, b);
     for (int s = 0; s < m->Ns; s++) {
       bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
       bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
       if (g.cv.on)
-        hipLaunchKernelGGL(k_barotropic_substep_curv<false>, gr, b, 0, m->stream, g, bb, cb, dtau, (real)m->weights[s]);
+        hipLaunchKernelGGL(k_barotropic_substep_curv, gr, b, 0, m->stream, g, bb, cb, dtau, (real)m->weights[s]);
       else
         hipLaunchKernelGGL(imm ? k_barotropic_substep<true> : k_barotropic_substep<false>, gr, b, 0, m->stream, g, bb, dtau,
                            (real)m->weights[s]);
@@ -1401,9 +1425,9 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     return GB25_OK;
   }
   dim3 gi = grid2(g.Nx, v_rows(g), b);
-  if (wide) gi = grid2(g.Nx + 2 * g.H, v_rows(g), b);   // (with the x halo columns: nothing is exchanged after the sub-cycle)
+  if (m->slab) gi = grid2(g.Nx + 2 * g.H, v_rows(g), b);   // (with the x halo columns: nothing is exchanged after the sub-cycle)
   hipLaunchKernelGGL(k_barotropic_finalize, gi, b, 0, m->stream, g, out[0], out[1], out[2], bb.etab, bb.Ub, bb.Vb,
-                     bb.sx, bb.xo, wide ? g.H : 0);
+                     bb.sx, bb.xo, m->slab ? g.H : 0);
   if (wide) {  // publish the averages in the canonical filtered-state arrays (compared by compare_states)
     InteriorCopies C{};
     int rmax = 0;
@@ -1530,13 +1554,13 @@ gb25_status catke_update_impl(gb25_model* m) {
   // J^b: on a slab it was made right after the AB2 update of T, S and travelled with the 3-D bundle (slab_step.hpp)
   if (!m->slab) catke_surface_flux_impl(m);
   // a slab computes kappa in the one halo column / fold row the implicit solves of u / v read (k_catke_diffusivities)
-  const int i_lo = m->slab ? -1 : 0, j_hi = g.Ny + ((m->slab && g.cv.north_fold) ? 1 : 0);
+  const int i_lo = m->slab ? -1 : 0, j_hi = g.Ny;
   hipLaunchKernelGGL(m->immersed ? k_catke_diffusivities<true> : k_catke_diffusivities<false>,
                      grid2(g.Nx - i_lo, j_hi, b), b, 0, m->stream, g, catke_parameters(m), m->f[GB25_U].d, m->f[GB25_V].d,
                      m->f[GB25_E].d, m->catke_b.d, m->f[GB25_JB].d, m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d,
                      m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_GN_E].d, i_lo, j_hi);
   if (g.cv.north_fold && !m->slab)   // the rows beyond the zipper
-    hipLaunchKernelGGL(k_catke_fold, dim3((g.sx + 255) / 256, g.H, g.Nz + 3), dim3(256), 0, m->stream, g,
+    hipLaunchKernelGGL(k_catke_fold, dim3((g.sx + 255) / 256, g.H + 1, g.Nz + 3), dim3(256), 0, m->stream, g,
                        m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_JB].d);
   LAUNCHCHK();
   return GB25_OK;
@@ -1604,7 +1628,7 @@ gb25_status atmosphere_ocean_fluxes_impl(gb25_model* m) {
     }
   Atmosphere A;
   for (int q = 0; q < 7; q++) A.a[q] = m->d_atm[q];
-  const int j_hi = g.Ny + g.cv.north_fold;
+  const int j_hi = g.Ny;
   dim3 b(64, 4);
   hipLaunchKernelGGL(m->immersed ? k_similarity_fluxes<true> : k_similarity_fluxes<false>, grid2(g.Nx + 1, j_hi + 1, b), b, 0,
                      m->stream, m->g, A, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_T].d, m->f[GB25_S].d, m->d_tau[0],
@@ -1962,20 +1986,25 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   if ((s = alloc_field(m, m->corr[1], sx, m->f[GB25_BT_V].ny, 1))) return s;
   if ((s = alloc_field(m, m->colsum[0], sx, m->f[GB25_BT_U].ny, 1))) return s;
   if ((s = alloc_field(m, m->colsum[1], sx, m->f[GB25_BT_V].ny, 1))) return s;
-  if (m->slab) {
-    // wide enough that after the Ns substeps the valid region still covers the slab's x HALO columns of eta, U, V: they are
-    // computed here like the neighbour computes them (same inputs, same arithmetic) and no exchange follows the sub-cycle
-    m->W = m->Ns + 1 + m->cfg.halo;
-    if (m->Nx < m->W)
-      return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab width %d is narrower than the barotropic halo %d", m->Nx, m->W);
+  if (m->slab || m->g.cv.north_fold) {
+    if (m->slab) {
+      // wide enough that after the Ns substeps the valid region still covers the slab's x HALO columns of eta, U, V: they are
+      // computed here like the neighbour computes them (same inputs, same arithmetic) and no exchange follows the sub-cycle
+      m->W = m->Ns + 1 + m->cfg.halo;
+      if (m->Nx < m->W)
+        return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab width %d is narrower than the barotropic halo %d", m->Nx, m->W);
+    }
+    // folded grid: image rows beyond the pivot row, enough that what the last row's missing neighbour spoils (one row per
+    // substep) never reaches the pivot row
+    if (m->g.cv.north_fold) m->Wy = std::min(m->Ns + 1, m->cfg.Ny - 2);
     const int wsx = m->Nx + 2 * m->W;
     for (int a = 0; a < 2; a++)
       for (int q = 0; q < 3; q++)
-        if ((s = alloc_field(m, m->wide[a][q], wsx, m->f[GB25_ETA + q].ny, 1))) return s;
+        if ((s = alloc_field(m, m->wide[a][q], wsx, m->f[GB25_ETA + q].ny + m->Wy, 1))) return s;
     {   // the three running averages are one allocation, zeroed by one memset per step
       size_t tot = 0;
       for (int q = 0; q < 3; q++) {
-        m->wideBar[q].nx = wsx; m->wideBar[q].ny = m->f[GB25_ETA + q].ny; m->wideBar[q].nz = 1;
+        m->wideBar[q].nx = wsx; m->wideBar[q].ny = m->f[GB25_ETA + q].ny + m->Wy; m->wideBar[q].nz = 1;
         tot += m->wideBar[q].elems();
       }
       real* base = nullptr;
@@ -1986,9 +2015,10 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
         base += m->wideBar[q].elems();
       }
     }
-    if ((s = alloc_field(m, m->wideG[0], wsx, m->f[GB25_GN_BT_U].ny, 1))) return s;
-    if ((s = alloc_field(m, m->wideG[1], wsx, m->f[GB25_GN_BT_V].ny, 1))) return s;
+    if ((s = alloc_field(m, m->wideG[0], wsx, m->f[GB25_GN_BT_U].ny + m->Wy, 1))) return s;
+    if ((s = alloc_field(m, m->wideG[1], wsx, m->f[GB25_GN_BT_V].ny + m->Wy, 1))) return s;
     if (m->g.cv.on && (s = build_curv_wide(m))) return s;
+    if (m->Wy && !m->slab) HIPCHK(hipMalloc(&m->tall_buf, (size_t)5 * (m->Wy + 1) * wsx * sizeof(real)));
   }
   if (cfg->grid_type == GB25_GRID_LAT_LON_GAUSSIAN_ISLANDS || cfg->grid_type == GB25_GRID_TRIPOLAR_GAUSSIAN_ISLANDS) {
     if (cfg->Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "an immersed boundary needs Nz <= 254 (8-bit level tables)");
@@ -2018,6 +2048,7 @@ void gb25_destroy(gb25_model* m) {
     for (Field* p : {&m->pp[q], &m->pp2[q], &m->ahead_eta[q]})
       if (p->d) hipFree(p->d);
   if (m->bars_ahead) hipFree(m->bars_ahead);
+  if (m->tall_buf) hipFree(m->tall_buf);
   for (auto& p : m->colsum)
     if (p.d) hipFree(p.d);
   for (auto& p : m->corr)
@@ -2735,11 +2766,7 @@ gb25_status gb25_lookahead_state(const gb25_model* m, int32_t* velocities_ready,
 int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int32_t ready, char* out, int64_t cap) {
   if (nslabs < 1) return -1;
   TraceOps ops(nslabs, adopted != 0, ready != 0);
-  if (first & 2) {          // (bit 1 of `first`: a folded grid with the default three-substep trace)
-    ops.fold = true;
-    ops.nsub = 3;
-    ops.adopted = ops.ready = false;
-  }
+  if (first & 2) ops.fold = true;   // (bit 1 of `first`: a folded grid)
   if (first & 4) ops.is_coupled = true;   // (bit 2: a coupled model -- data-free forcing)
   bool in_flight = (first & 8) != 0;      // (bit 3: the previous step left the look-ahead chain in flight)
   first &= 1;

@@ -138,37 +138,35 @@ __global__ void k_fill_x(Grid g, Halo3 f3, Halo2 f2, int rows_c, int rows_v) {
   }
 }
 
-// Zipper fold along the northern edge of the tripolar grid (Oceananigans' fold boundary condition, restated; convention in
-// DESIGN.md): the fold line is the row of y faces Ny between the two poles, which sit on the x faces 0 and Nx/2.  Cell
-// (i, Ny-1+q) beyond it is the image of cell (Nx-1-i, Ny-q); x faces mirror as i -> (Nx-i) mod Nx, y faces as row
-// Ny+q -> Ny-q; vector components change sign.  The y faces ON the fold line are seen from both sides, v(i) = -v(Nx-1-i):
-// both are stepped and the eastern copy is overwritten with minus its partner here.  The bottom / top layer of the rows
-// beyond the fold is filled too (the hydrostatic integral of those rows starts in the top halo level).  Reads interior
-// rows and levels only: independent of the y / z fill, before the periodic x copy.
-// grid: (ceil(Nx/256), H, Nz + 2 | 1); blockIdx.z = level + 1 of the 3-D fields, the last slice does the 2-D fields
+// Zipper fold along the northern edge of the tripolar grid: Oceananigans' fold_north_{center,face}_{center,face}!, restated
+// from memory of v0.96 [UPSTREAM-UNVERIFIED] (oracle/gb25_oracle.c: fold_rows_levels).  The fold pivots on the CENTRES of the
+// last row of cells, Ny-1 here (0-based), between the two poles, which sit on the x faces 0 and Nx/2:
+//   cell (i, Ny-1+q)   <-  s  cell (Nx-1-i, Ny-1-q)          x face (i, Ny-1+q)  <-  s' x face ((Nx-i) mod Nx, Ny-1-q)
+//   y face (i, Ny-1+q) <-  s  y face (Nx-1-i, Ny-q)          q = 1..H;  s = -1 for vector components; s' = s except on the
+//                                                            x face that wraps (i = 0), which keeps its sign
+// Row Ny-1 is held twice -- cell (i, Ny-1) IS cell (Nx-1-i, Ny-1) -- and both copies are stepped; the copy in the eastern
+// half is overwritten with the image of the western one here (q = 0; the x face that is its own image is left alone).
+// The bottom / top layer of the rows written is filled too (the hydrostatic integral of the rows beyond the fold starts in the
+// top halo level).  Reads interior rows and levels only: independent of the y / z fill, before the periodic x copy.
+__device__ __forceinline__ int fold_src_column(int ig, int Nxg, bool xface) { return xface ? (ig == 0 ? 0 : Nxg - ig) : Nxg - 1 - ig; }
+__device__ __forceinline__ real fold_sign(int ig, bool xface, bool neg) { return (neg && !(xface && ig == 0)) ? -real(1.) : real(1.); }
+// does the fill overwrite (ig, row Ny-1) with its image?  the eastern half, except the face that maps onto itself
+__device__ __forceinline__ bool fold_pivot_slave(int ig, int Nxg, bool xface) { return xface ? 2 * ig > Nxg : 2 * ig >= Nxg; }
+// grid: (ceil(Nx/256), H + 1, Nz + 2 | 1); blockIdx.y = q; blockIdx.z = level + 1 of the 3-D fields, the last slice does the 2-D fields
 __global__ void k_fill_fold(Grid g, Halo3 f3, Halo2 f2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.Nx) return;
-  const int q = blockIdx.y;   // 0 .. H-1
+  const int q = blockIdx.y;   // 0 .. H
   const bool twod = (int)blockIdx.z == (f3.n ? g.Nz + 2 : 0);
   const int k = (int)blockIdx.z - 1, ks = min(max(k, 0), g.Nz - 1);
   const int n = twod ? f2.n : f3.n;
   for (int f = 0; f < n; f++) {
     real* c = twod ? f2.p[f] : f3.p[f];
-    const bool is_v = twod ? f2.is_v[f] : f3.is_v[f], xf = twod ? f2.xf[f] : f3.xf[f];
-    const real sg = (twod ? f2.neg[f] : f3.neg[f]) ? -real(1.) : real(1.);
-    const int isrc = xf ? (i == 0 ? 0 : g.Nx - i) : g.Nx - 1 - i;
-    int jd, js;
-    if (is_v) {
-      jd = g.Ny + q; js = g.Ny - q;
-      if (q == 0 && i < g.Nx / 2) {          // western half of the fold line: stepped values stay ...
-        if (twod || (k >= 0 && k < g.Nz)) continue;
-        c[iv(g, i, jd, k)] = c[iv(g, i, jd, ks)];   // ... and get their bottom / top layer
-        continue;
-      }
-    } else {
-      jd = g.Ny + q; js = g.Ny - 1 - q;
-    }
+    const bool is_v = twod ? f2.is_v[f] : f3.is_v[f], xf = twod ? f2.xf[f] : f3.xf[f], neg = twod ? f2.neg[f] : f3.neg[f];
+    if (q == 0 && (is_v || !fold_pivot_slave(i, g.Nx, xf))) continue;
+    const int isrc = fold_src_column(i, g.Nx, xf);
+    const real sg = fold_sign(i, xf, neg);
+    const int jd = g.Ny - 1 + q, js = is_v ? g.Ny - q : g.Ny - 1 - q;
     if (twod) c[i2(g, i, jd)] = sg * c[i2(g, isrc, js)];
     else if (is_v) c[iv(g, i, jd, k)] = sg * c[iv(g, isrc, js, ks)];
     else c[ic(g, i, jd, k)] = sg * c[ic(g, isrc, js, ks)];
@@ -176,16 +174,16 @@ __global__ void k_fill_fold(Grid g, Halo3 f3, Halo2 f2) {
 }
 
 // The same fold on a slab of a decomposition: the cells beyond the fold are the images of cells of the PARTNER rank
-// P-1-r (mirrored in x), which sends the H rows next to its fold line -- all its parent columns, every interior level --
-// and receives ours.  Buffer layout per field: [level][q][parent column], q = 0 .. H-1 counting rows away from the fold
-// line (cell rows Ny-1-q; y-face rows Ny-q, q = 0 being the fold line itself); 3-D fields first, then the 2-D ones.
+// P-1-r (mirrored in x), which sends its pivot row and the H rows south of it -- all its parent columns, every interior
+// level -- and receives ours.  Buffer layout per field: [level][q][parent column], q = 0 .. H: cell rows Ny-1-q, y-face rows
+// Ny-q (q = 0 unused for them); 3-D fields first, then the 2-D ones.
 struct FoldFields {
   real* p[9];
   int is_v[9], xf[9], neg[9], nz[9];   // nz: interior levels (1: a 2-D field)
   long off[9];                          // element offset of the field in the exchange buffer
   int n;
 };
-// grid: (ceil(sx/256), H, sum of nz)
+// grid: (ceil(sx/256), H + 1, sum of nz)
 __global__ void k_fold_pack(Grid g, FoldFields F, real* __restrict__ buf) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
   if (a >= g.sx) return;
@@ -194,57 +192,59 @@ __global__ void k_fold_pack(Grid g, FoldFields F, real* __restrict__ buf) {
   const bool twod = F.nz[f] == 1;
   const int row = (F.is_v[f] ? g.Ny - q : g.Ny - 1 - q) + g.H;
   const long pl = F.is_v[f] ? g.pl_v : g.pl_c;
-  buf[F.off[f] + ((long)k * g.H + q) * g.sx + a] = F.p[f][a + (long)g.sx * row + (twod ? 0 : pl * (k + g.H))];
+  buf[F.off[f] + ((long)k * (g.H + 1) + q) * g.sx + a] = F.p[f][a + (long)g.sx * row + (twod ? 0 : pl * (k + g.H))];
 }
-// grid: (ceil(sx/256), H, sum of (nz + 2 | 1)): the 3-D fields also get the bottom / top layer of the rows beyond the fold.
-// ig0: global column of local column 0; Nxg: global Nx (the fold line's eastern half takes minus its partner).
+// grid: (ceil(sx/256), H + 1, sum of (nz + 2 | 1)): the 3-D fields also get the bottom / top layer of the rows written.
+// ig0: global column of local column 0; Nxg: global Nx (which half of the pivot row a column is in; the x face that wraps).
 __global__ void k_fold_unpack(Grid g, FoldFields F, const real* __restrict__ buf, int ig0, int Nxg) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
   if (a >= g.sx) return;
   int f = 0, kk = blockIdx.z;
   while (kk >= (F.nz[f] == 1 ? 1 : F.nz[f] + 2)) kk -= (F.nz[f] == 1 ? 1 : F.nz[f] + 2), f++;
-  const bool twod = F.nz[f] == 1, is_v = F.is_v[f] != 0;
+  const bool twod = F.nz[f] == 1, is_v = F.is_v[f] != 0, xf = F.xf[f] != 0;
   const int k = twod ? 0 : kk - 1, ks = twod ? 0 : min(max(k, 0), g.Nz - 1);
-  const int am = F.xf[f] ? g.sx - a : g.sx - 1 - a;      // the partner's parent column of the mirrored cell / face
+  const int am = xf ? g.sx - a : g.sx - 1 - a;             // the partner's parent column of the mirrored cell / face
   if (am >= g.sx) return;                                   // (the westernmost x face of the halo: never read)
-  const real sg = F.neg[f] ? -real(1.) : real(1.);
+  int ig = ig0 + a - g.H;
+  ig = ((ig % Nxg) + Nxg) % Nxg;
+  if (q == 0 && (is_v || !fold_pivot_slave(ig, Nxg, xf))) return;
+  const real sg = fold_sign(ig, xf, F.neg[f] != 0);
   const long pl = is_v ? g.pl_v : g.pl_c;
-  real* c = F.p[f];
-  const int jd = g.Ny + q + g.H;                            // destination parent row
-  const long od = a + (long)g.sx * jd + (twod ? 0 : pl * (k + g.H));
-  if (is_v && q == 0) {
-    // the fold line itself: the western half keeps what it stepped (and gets its bottom / top layer), the eastern
-    // half is minus its partner
-    int ig = ig0 + a - g.H;
-    ig = ((ig % Nxg) + Nxg) % Nxg;
-    if (2 * ig < Nxg) {
-      if (!twod && (k < 0 || k >= g.Nz)) c[od] = c[a + (long)g.sx * jd + pl * (ks + g.H)];
-      return;
-    }
-  }
-  c[od] = sg * buf[F.off[f] + ((long)ks * g.H + q) * g.sx + am];
-}
-// the five rows of the widened barotropic arrays that the partner's fold-line faces need in a substep (CurvBaro::img)
-__global__ void k_fold_rows_pack(Grid g, const real* __restrict__ eta, const real* __restrict__ U, const real* __restrict__ V,
-                                 const real* __restrict__ GV, int wsx, real* __restrict__ buf) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= wsx) return;
-  const long r1 = (long)wsx * (g.Ny - 1 + g.H), r0 = (long)wsx * (g.Ny + g.H);
-  buf[a] = eta[r1 + a];
-  buf[wsx + a] = U[r1 + a];
-  buf[2 * wsx + a] = V[r1 + a];
-  buf[3 * wsx + a] = V[r0 + a];
-  buf[4 * wsx + a] = GV[r0 + a];
+  const int jd = g.Ny - 1 + q + g.H;                        // destination parent row
+  F.p[f][a + (long)g.sx * jd + (twod ? 0 : pl * (k + g.H))] = sg * buf[F.off[f] + ((long)ks * (g.H + 1) + q) * g.sx + am];
 }
 
-// G.V on the eastern half of the fold line <- minus the partner's (what the fold fill of G.U, G.V does on a single domain);
-// img: the partner's rows as it sent them for the sub-cycle (row 4 = its fold-line G.V on the widened layout, halo W)
-__global__ void k_fold_line_GV(Grid g, real* __restrict__ GV, const real* __restrict__ img, int wsx, int W, int ig0, int Nxg) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= g.Nx) return;
-  int ig = ((ig0 + i) % Nxg + Nxg) % Nxg;
-  if (2 * ig < Nxg) return;
-  GV[i2(g, i, g.Ny)] = -img[4 * wsx + (wsx - 1 - (i + W))];
+// The split-explicit sub-cycle on a folded grid runs on TALL arrays: the barotropic work arrays (widened in x on a slab) with
+// Wy more rows beyond the pivot row, filled ONCE per step with the images of the rows south of it, as Oceananigans extends
+// the halo of its free surface on the TripolarGrid to the number of substeps: eta, U, V and the forcing G.U, G.V; then the
+// Ns substeps need nothing from beyond the fold (what the missing neighbour of the last row spoils moves one row per substep
+// and never reaches the pivot row).  The images' sources belong to the partner rank P-1-r on a slab (pack -> exchange ->
+// unpack); a single domain packs and unpacks its own buffer.  Buffer: [array 0..4][q = 1..Wy+1][array column].
+struct TallRows {
+  real* p[5];          // eta, U, V, G.U, G.V (geometry: pitch sx, first row -H)
+  int sx, xo, Wy;      // pitch, array column of i = 0, rows beyond the pivot row (the y-face arrays take one more)
+  int wrap;            // single domain: the x face beyond the last column is face 0
+};
+// grid: (ceil(sx/256), Wy + 1, 5)
+template <bool PACK>
+__global__ void k_tall_rows(Grid g, TallRows T, real* __restrict__ buf, int ig0, int Nxg) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y + 1, f = blockIdx.z;
+  if (a >= T.sx) return;
+  const bool is_v = f == 2 || f == 4, xf = f == 1 || f == 3;
+  if (q > T.Wy && !is_v) return;
+  real* c = T.p[f];
+  const long bo = ((long)f * (T.Wy + 1) + (q - 1)) * T.sx;
+  if (PACK) {
+    buf[bo + a] = c[a + (long)T.sx * ((is_v ? g.Ny - q : g.Ny - 1 - q) + g.H)];
+    return;
+  }
+  int am = xf ? T.sx - a : T.sx - 1 - a;   // the source's array column in the sender's (mirrored) layout
+  if (xf && T.wrap) am = (a == T.xo) ? T.xo : 2 * T.xo + g.Nx - a;   // single domain (pitch Nx + 2 xo): face i <- face (Nx - i) mod Nx
+  else if (!xf && T.wrap) am = 2 * T.xo + g.Nx - 1 - a;
+  if (am < 0 || am >= T.sx) return;
+  int ig = ig0 + a - T.xo;
+  ig = ((ig % Nxg) + Nxg) % Nxg;
+  c[a + (long)T.sx * (g.Ny - 1 + q + g.H)] = fold_sign(ig, xf, f != 0) * buf[bo + am];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, real* __restrict
                                                         real chi, int kchunks) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny + g.cv.north_fold) return;
+  if (i >= g.Nx || j >= g.Ny) return;
   const bool urow = j < g.Ny;   // (zipper fold: the row of y faces on the fold line is stepped, v only)
   const real C1 = real(1.5) + chi, C2 = real(0.5) + chi;
   const real ne = (chi != -real(0.5)) ? real(1.) : real(0.);
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void k_ab2_velocities_finish(Grid g, const rea
                                                                real* __restrict__ Vsum) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny + g.cv.north_fold) return;
+  if (i >= g.Nx || j >= g.Ny) return;
   const int o2 = i2(g, i, j);
   real t[4];
 #pragma unroll
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical(Grid g, real* __restr
   const int i = blockIdx.x * T + tid, j = blockIdx.y;
   const bool vsh = kind == 0 && f == 1;
   // rows: cells 0 .. Ny-1; y faces 1 .. Ny-1 and, with the zipper fold, the fold line Ny (the wall faces stay zero)
-  if (i >= g.Nx || (vsh ? (j > g.Ny - 1 + g.cv.north_fold) : (j >= g.Ny))) return;
+  if (i >= g.Nx || (vsh ? (j > g.Ny - 1) : (j >= g.Ny))) return;
   const int o2 = i2(g, i, j);
   int kf = 0;
   if (IMM) {
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_reg(Grid g, ImplicitF
   const int f = blockIdx.z, Nz = g.Nz;
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   const bool vsh = A.vshape[f] != 0;
-  if (i >= g.Nx || (vsh ? (j > g.Ny - 1 + g.cv.north_fold) : (j >= g.Ny))) return;
+  if (i >= g.Nx || (vsh ? (j > g.Ny - 1) : (j >= g.Ny))) return;
   const int o2 = i2(g, i, j);
   int kf = 0;
   if (IMM) {
@@ -1057,6 +1057,8 @@ struct Baro {
   // geometry of these 2-D arrays: row pitch, array column of i = 0, computed range [ilo, ihi), and
   // whether i-1 / i+1 wrap around the periodic domain (single slab) or simply reach into the wide halo
   int sx, xo, ilo, ihi, wrap;
+  // rows [0, jhi) are advanced: Ny, or Ny + Wy on the tall arrays of a folded grid (whose rows beyond the pivot row are images)
+  int jhi;
 };
 __device__ __forceinline__ int bi(const Grid& g, const Baro& b, int i, int j) { return (i + b.xo) + b.sx * (j + g.H); }
 __device__ __forceinline__ real eta_step(const Grid& g, const Baro& b, int i, int j, real dtau) {
@@ -1072,7 +1074,7 @@ template <bool IMM>
 __global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, real dtau, real wgt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x + b.ilo;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= b.ihi || j >= g.Ny) return;
+  if (i >= b.ihi || j >= g.Ny) return;   // (the lat-lon grid has walls: b.jhi == Ny)
   int im = (b.wrap && i == 0) ? g.Nx - 1 : i - 1;
   real e = eta_step(g, b, i, j, dtau);
   real ew = eta_step(g, b, im, j, dtau);
@@ -1091,23 +1093,13 @@ __global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, real
   b.Vb[o] += wgt * Vn;
 }
 // Orthogonal curvilinear grid (tables always present): the same substep with the face lengths and areas from 2-D metric
-// arrays laid out like the Baro arrays (canonical on a single domain, widened on a slab).  With the zipper fold the
-// launch has one more row of threads for the y faces ON the fold line.  eta beyond the fold is the image of row Ny-1 of
-// the MIRRORED columns: on a single domain those are read in place (REMOTE = false); on a slab they belong to the partner
-// rank P-1-r, which sends its rows Ny-1 of eta, U, V and its fold-line rows of V and G.V once per substep (REMOTE = true:
-// `img`, five rows of the partner's widened arrays as it holds them -- the mirror of array column a is sx-1-a) while the
-// metrics of the mirrored cells come from the grid generator (`mir`).  West of the half-way meridian a fold-line face
-// takes its own new value, east of it minus its partner's (computed here a second time: no ordering between threads or
-// ranks needed), so the transports match to the last bit and a decomposition gives the bits of the single domain.
-// (No contraction into FMAs in this kernel: the mirrored cell's new eta is formed by two different code paths -- in place
-// on a single domain, from the partner's rows on a slab -- and must come out the same to the last bit.)
+// arrays laid out like the Baro arrays (canonical on a single domain, widened on a slab, tall on a folded grid: there the
+// rows [Ny, jhi) beyond the pivot row are images, filled once per step -- k_tall_rows -- and advanced like any other row;
+// the last row reads V of the face row beyond it, which is never advanced).
+// (No contraction into FMAs in this kernel and in its temporally blocked sibling: the two are interchangeable bit for bit.)
 #pragma clang fp contract(off)
 struct CurvBaro {
   const real *dyfc, *dxcf, *razcc, *rdxfc, *rdycf;   // geometry of the Baro arrays (pitch b.sx, column offset b.xo)
-  const real* img;       // REMOTE: [5][b.sx] = eta, U, V of row Ny-1, V and G.V of the fold line, partner's layout
-  const real* mir;       // REMOTE: [6][b.sx] by OWN array column: dyfc_w, dyfc_e, dxcf_s, dxcf_n, razcc of the mirrored cell
-                         //         of row Ny-1, rdycf of the mirrored fold-line face
-  int ig0, Nxg;          // global column of local column 0, global Nx (which half of the fold line a face is on)
 };
 __device__ __forceinline__ real eta_step_curv(const Grid& g, const Baro& b, const CurvBaro& c, int i, int j, real dtau) {
   const int ip = (b.wrap && i == g.Nx - 1) ? 0 : i + 1, o = bi(g, b, i, j), oe = bi(g, b, ip, j);
@@ -1118,57 +1110,13 @@ __device__ __forceinline__ real eta_step_curv(const Grid& g, const Baro& b, cons
   else dyV = c.dxcf[o + b.sx] * b.V0[o + b.sx] - c.dxcf[o] * b.V0[o];
   return b.eta0[o] - dtau * (dxU + dyV) * c.razcc[o];
 }
-// new eta of the cell that local column i of row Ny-1 mirrors onto.  vn: V on the fold line above THAT cell (old value)
-template <bool REMOTE>
-__device__ __forceinline__ real eta_step_mirror(const Grid& g, const Baro& b, const CurvBaro& c, int i, real vn, real dtau) {
-  if (!REMOTE) return eta_step_curv(g, b, c, g.Nx - 1 - i, g.Ny - 1, dtau);
-  const int a = i + b.xo, am = b.sx - 1 - a;   // own array column, the partner's array column of the mirrored cell
-  const real* M = c.mir + a;
-  const real e0 = c.img[am], uw = c.img[b.sx + am], ue = c.img[b.sx + am + 1], vs = c.img[2 * b.sx + am];
-  const real dxU = M[b.sx] * ue - M[0] * uw;
-  const real dyV = M[3 * b.sx] * vn - M[2 * b.sx] * vs;
-  return e0 - dtau * (dxU + dyV) * M[4 * b.sx];
-}
-// new V of the fold-line face of local column i (own = true) or of the face it mirrors onto (own = false)
-template <bool REMOTE>
-__device__ __forceinline__ real fold_line_V(const Grid& g, const Baro& b, const CurvBaro& c, int i, bool own, real dtau) {
-  const int j = g.Ny, o = bi(g, b, i, j);
-  const real e_here = eta_step_curv(g, b, c, i, j - 1, dtau);          // cell (i, Ny-1)
-  if (own) {
-    // (V on the fold line above the mirrored cell is minus the own one: antisymmetric since the last fill / substep)
-    const real e_mir = eta_step_mirror<REMOTE>(g, b, c, i, REMOTE ? c.img[3 * b.sx + (b.sx - 1 - (i + b.xo))] : real(0.), dtau);
-    const real dye = (e_mir - e_here) * c.rdycf[o];
-    return b.V0[o] + dtau * (-g.g * b.Hcf[o] * dye + b.GV[o]);
-  }
-  // the partner's face: its own cell is the mirrored one, its image cell is (i, Ny-1)
-  real V0p, GVp, rdy;
-  if (REMOTE) {
-    const int am = b.sx - 1 - (i + b.xo);
-    V0p = c.img[3 * b.sx + am];
-    GVp = c.img[4 * b.sx + am];
-    rdy = c.mir[5 * b.sx + i + b.xo];
-  } else {
-    const int om = bi(g, b, g.Nx - 1 - i, j);
-    V0p = b.V0[om];
-    GVp = b.GV[om];
-    rdy = c.rdycf[om];
-  }
-  const real e_mir = eta_step_mirror<REMOTE>(g, b, c, i, V0p, dtau);
-  const real dye = (e_here - e_mir) * rdy;
-  return V0p + dtau * (-g.g * b.Hcf[o] * dye + GVp);   // (the static depth of a fold-line face is the same from both sides)
-}
-template <bool REMOTE>
 __global__ __launch_bounds__(256) void k_barotropic_substep_curv(Grid g, Baro b, CurvBaro c, real dtau, real wgt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x + b.ilo;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= b.ihi || j >= g.Ny + g.cv.north_fold) return;
+  if (i >= b.ihi || j > b.jhi) return;
   const int o = bi(g, b, i, j);
-  if (j == g.Ny) {
-    int ig = c.ig0 + i;                     // (a widened slab reaches beyond [0, Nxg))
-    ig = ((ig % c.Nxg) + c.Nxg) % c.Nxg;
-    const real Vn = (2 * ig < c.Nxg) ? fold_line_V<REMOTE>(g, b, c, i, true, dtau) : -fold_line_V<REMOTE>(g, b, c, i, false, dtau);
-    b.V1[o] = Vn;
-    b.Vb[o] += wgt * Vn;
+  if (j == b.jhi) {   // folded grid: the face row behind the last advanced row is carried along unchanged
+    if (g.cv.north_fold) b.V1[o] = b.V0[o];
     return;
   }
   const int im = (b.wrap && i == 0) ? g.Nx - 1 : i - 1;
@@ -1324,7 +1272,7 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
         real Vn = V[ly][lx] + dtau * (GVs[ly][lx] - ghc[q] * dye);
         U[ly][lx] = Un;
         V[ly][lx] = Vn;
-        if (own[q]) {
+        if (own[q] == 1) {
           au[q] += wgt * Un;
           av[q] += wgt * Vn;
         }
@@ -1378,17 +1326,12 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
     }
 }
 
-// The temporally blocked sub-cycle on an orthogonal curvilinear grid (single domain, periodic in x), zipper fold included.
+// The temporally blocked sub-cycle on an orthogonal curvilinear grid: single domain (periodic in x), widened slab, and the
+// tall arrays of a folded grid (rows [0, jhi) advanced, the face row jhi read only).
 // Arithmetic per point is that of k_barotropic_substep_curv, operation for operation (no FMA contraction either), so the two
-// are interchangeable bit for bit -- the slabs of a folded grid advance substep by substep with that kernel.  Differences
-// from the lat-lon version above: the five metrics and the two depths a point needs are per-point registers; the products
-// dyfc U and dxcf V that the eta update differences live in LDS (FU, FV) in place of G.U, G.V (registers here).
-// The fold: rows Ny .. Ny+S of a tile are IMAGES of the cells beyond the fold line -- cell (i, Ny+q) is cell
-// (Nx-1-i, Ny-1-q), x faces Nx-i, y faces rows Ny-q, transports with the sign flipped -- loaded (values, metrics, depths)
-// from those interior cells and advanced by the same formulas: with every operand the exact negative / equal of its
-// source's, an image evolves into the exact image of the evolved source.  The fold line itself: the western half is
-// stepped, the eastern half starts from minus its partner (as k_barotropic_substep_curv forms it) and evolves likewise.
-// (curv_metrics_at makes the fold-line metrics of the two halves the same numbers.)
+// are interchangeable bit for bit.  Differences from the lat-lon version above: the five metrics and the two depths a point
+// needs are per-point registers; the products dyfc U and dxcf V that the eta update differences live in LDS (FU, FV) in place
+// of G.U, G.V (registers here).
 #pragma clang fp contract(off)
 template <int BT_S, int BT_TY>
 __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, BaroMulti bm, CurvBaro c, real dtau) {
@@ -1398,11 +1341,12 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
   __builtin_amdgcn_s_setprio(3);
   const Baro& b = bm.b;
   const int tid = threadIdx.x, Nx = g.Nx, Ny = g.Ny;
-  const int i0 = blockIdx.x * BT_TX, j0 = blockIdx.y * BT_TY;
-  const bool fold = g.cv.north_fold != 0;
-  const int jtop = fold ? Ny + BT_S + 1 : Ny;   // rows [0, jtop) exist (beyond the fold line: as far as a ring reaches)
+  const int i0 = b.ilo + blockIdx.x * BT_TX, j0 = blockIdx.y * BT_TY;
+  const bool open_north = g.cv.north_fold != 0;   // no wall behind the last advanced row: the face row jhi exists (read only)
+  const int jtop = b.jhi + (open_north ? 1 : 0);
+  const int lo = -b.xo, hi = b.sx - b.xo - 1;     // valid array columns (slab mode: clamp; garbage stays in the rim)
   int po[BT_PPT];                               // element offset of the point in the scratch / average arrays (-1: none)
-  unsigned char own[BT_PPT];                    // bit 0: eta, U are this block's to write; bit 1: V
+  unsigned char own[BT_PPT];                    // this block writes the point back
   real ae[BT_PPT], au[BT_PPT], av[BT_PPT], gu[BT_PPT], gv[BT_PPT];
   real mrazcc[BT_PPT], mdyfc[BT_PPT], mdxcf[BT_PPT], mrdxfc[BT_PPT], mrdycf[BT_PPT], nghf[BT_PPT], nghc[BT_PPT];
   real le[BT_PPT], lu[BT_PPT], lv[BT_PPT];   // (the loaded tile on its way to LDS)
@@ -1412,46 +1356,42 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
     const int ly = p / BT_RX, lx = p - ly * BT_RX;
     const int ig = i0 - BT_S + lx, jg = j0 - BT_S + ly;
     const bool exists = (p < BT_NP) && jg >= 0 && jg < jtop;
-    int ii = ig % Nx;
-    if (ii < 0) ii += Nx;
-    // where the point's cell-, x-face- and y-face-located quantities live (an image: its source beyond the fold)
-    int ci = ii, cj = jg, ui = ii, uj = jg, vi = ii, vj = jg;
-    real su = real(1.), sv = real(1.);
-    if (jg >= Ny) {
-      ci = Nx - 1 - ii; cj = 2 * Ny - 1 - jg;
-      ui = ii == 0 ? 0 : Nx - ii; uj = cj; su = -real(1.);
+    int ii = ig;
+    if (b.wrap) {
+      ii = ii % Nx;
+      if (ii < 0) ii += Nx;
+    } else {
+      ii = max(lo, min(hi, ii));
     }
-    if (jg > Ny) {
-      vi = Nx - 1 - ii; vj = 2 * Ny - jg; sv = -real(1.);
-    } else if (jg == Ny && 2 * ii >= Nx) {
-      vi = Nx - 1 - ii; sv = -real(1.);
-    }
-    const bool in_tile = exists && lx >= BT_S && lx < BT_S + BT_TX && ly >= BT_S && ly < BT_S + BT_TY && ig < Nx;
-    own[q] = (unsigned char)((in_tile && jg < Ny ? 1 : 0) | (in_tile && jg < Ny + (fold ? 1 : 0) ? 2 : 0));
-    po[q] = exists ? bi(g, b, ii, min(jg, Ny)) : -1;
+    const bool in_tile = exists && lx >= BT_S && lx < BT_S + BT_TX && ly >= BT_S && ly < BT_S + BT_TY && ig < b.ihi;
+    own[q] = (unsigned char)((in_tile && jg < b.jhi) ? 1 : (in_tile ? 2 : 0));   // 2: the face row jhi, V carried along unchanged
+    po[q] = exists ? bi(g, b, ii, jg) : -1;
     // (loads only in this loop: the tile goes to LDS once every load of the thread's points is in flight)
     le[q] = lu[q] = lv[q] = real(0.);
     gu[q] = gv[q] = real(0.);
     mrazcc[q] = mdyfc[q] = mdxcf[q] = mrdxfc[q] = mrdycf[q] = nghf[q] = nghc[q] = real(0.);
     if (exists) {
-      const int oc = bi(g, b, ci, cj), ou = bi(g, b, ui, uj), ov = bi(g, b, vi, vj);
-      le[q] = b.eta0[oc];
-      lu[q] = su * b.U0[ou];
-      lv[q] = sv * b.V0[ov];
-      gu[q] = su * b.GU[ou];
-      gv[q] = sv * b.GV[ov];
-      mrazcc[q] = c.razcc[oc];
-      mdyfc[q] = c.dyfc[ou];
-      mrdxfc[q] = c.rdxfc[ou];
-      nghf[q] = -g.g * b.Hfc[ou];
-      mdxcf[q] = c.dxcf[ov];
-      mrdycf[q] = c.rdycf[ov];
-      nghc[q] = -g.g * b.Hcf[jg == Ny ? bi(g, b, ii, Ny) : ov];   // (the fold line: the face's own depth, as the one-substep kernel)
+      const int o = po[q];
+      lv[q] = b.V0[o];
+      mdxcf[q] = c.dxcf[o];
+      if (jg < b.jhi) {
+        le[q] = b.eta0[o];
+        lu[q] = b.U0[o];
+        gu[q] = b.GU[o];
+        gv[q] = b.GV[o];
+        mrazcc[q] = c.razcc[o];
+        mdyfc[q] = c.dyfc[o];
+        mrdxfc[q] = c.rdxfc[o];
+        nghf[q] = -g.g * b.Hfc[o];
+        mrdycf[q] = c.rdycf[o];
+        nghc[q] = -g.g * b.Hcf[o];
+      }
     }
     ae[q] = au[q] = av[q] = real(0.);
-    if (!bm.first && po[q] >= 0) {
-      if (own[q] & 1) { ae[q] = b.etab[po[q]]; au[q] = b.Ub[po[q]]; }
-      if (own[q] & 2) av[q] = b.Vb[po[q]];
+    if (!bm.first && own[q] == 1) {
+      ae[q] = b.etab[po[q]];
+      au[q] = b.Ub[po[q]];
+      av[q] = b.Vb[po[q]];
     }
   }
 #pragma unroll
@@ -1473,8 +1413,8 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
     for (int q = 0; q < BT_PPT; q++) {
       const int p = tid + q * BT_NT;
       const int ly = p / BT_RX, lx = p - ly * BT_RX, jg = j0 - BT_S + ly;
-      const bool wall = !fold && jg == Ny - 1;
-      if (po[q] >= 0 && lx < BT_RX - 1 && (ly < BT_RY - 1 || wall)) {
+      const bool wall = !open_north && jg == Ny - 1;
+      if (po[q] >= 0 && jg < b.jhi && lx < BT_RX - 1 && (ly < BT_RY - 1 || wall)) {
         const real dxU = FU[ly][lx + 1] - FU[ly][lx];
         real dyV;
         if (wall) dyV = -FV[ly][lx];
@@ -1482,7 +1422,7 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
         else dyV = FV[ly + 1][lx] - FV[ly][lx];
         const real e = E[ly][lx] - dtau * (dxU + dyV) * mrazcc[q];
         E[ly][lx] = e;
-        if (own[q] & 1) ae[q] += wgt * e;
+        if (own[q] == 1) ae[q] += wgt * e;
       }
     }
     __syncthreads();
@@ -1491,7 +1431,7 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
     for (int q = 0; q < BT_PPT; q++) {
       const int p = tid + q * BT_NT;
       const int ly = p / BT_RX, lx = p - ly * BT_RX, jg = j0 - BT_S + ly;
-      if (po[q] >= 0 && lx >= 1 && (ly >= 1 || jg == 0)) {
+      if (po[q] >= 0 && jg < b.jhi && lx >= 1 && (ly >= 1 || jg == 0)) {
         const real e = E[ly][lx];
         const real dxe = (e - E[ly][lx - 1]) * mrdxfc[q];
         real dye = real(0.);
@@ -1502,27 +1442,40 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
         V[ly][lx] = Vn;
         FU[ly][lx] = mdyfc[q] * Un;
         FV[ly][lx] = mdxcf[q] * Vn;
-        if (own[q] & 1) au[q] += wgt * Un;
-        if (own[q] & 2) av[q] += wgt * Vn;
+        if (own[q] == 1) {
+          au[q] += wgt * Un;
+          av[q] += wgt * Vn;
+        }
       }
     }
     __syncthreads();
   }
 #pragma unroll
   for (int q = 0; q < BT_PPT; q++)
-    if (own[q]) {
+    if (own[q] == 2) {
+      b.V1[po[q]] = (&V[0][0])[tid + q * BT_NT];
+    } else if (own[q]) {
       const int p = tid + q * BT_NT, o = po[q];
-      if (own[q] & 1) {
-        b.eta1[o] = (&E[0][0])[p];
-        b.U1[o] = (&U[0][0])[p];
-        b.etab[o] = ae[q];
-        b.Ub[o] = au[q];
-      }
+      b.eta1[o] = (&E[0][0])[p];
+      b.U1[o] = (&U[0][0])[p];
       b.V1[o] = (&V[0][0])[p];
+      b.etab[o] = ae[q];
+      b.Ub[o] = au[q];
       b.Vb[o] = av[q];
-      if (bm.last) {   // eta, U, V <- the averages, in the canonical arrays (the same geometry on a single domain)
-        if (own[q] & 1) { bm.eta_out[o] = ae[q]; bm.U_out[o] = au[q]; }
-        bm.V_out[o] = av[q];
+      if (bm.last) {   // eta, U, V <- the averages, in arrays of the canonical layout (and the filtered state, when the
+        const int ly = p / BT_RX, lx = p - ly * BT_RX;   // averages live in work arrays of another geometry)
+        const int ig = i0 - BT_S + lx, jg = j0 - BT_S + ly;
+        if (jg < Ny && ig >= -bm.out_halo && ig < Nx + bm.out_halo) {
+          const int oc = i2(g, ig, jg);
+          bm.eta_out[oc] = ae[q];
+          bm.U_out[oc] = au[q];
+          bm.V_out[oc] = av[q];
+          if (bm.eb_out) {
+            bm.eb_out[oc] = ae[q];
+            bm.ub_out[oc] = au[q];
+            bm.vb_out[oc] = av[q];
+          }
+        }
       }
     }
 }
@@ -1533,7 +1486,7 @@ __global__ void k_barotropic_finalize(Grid g, real* eta, real* U, real* V, const
                                       const real* Vb, int src_sx, int src_xo, int halo) {
   int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - halo;   // (halo > 0: a widened slab, its x halo columns included)
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx + halo || j >= g.Ny + g.cv.north_fold) return;
+  if (i >= g.Nx + halo || j >= g.Ny) return;
   int o = i2(g, i, j), q = (i + src_xo) + src_sx * (j + g.H);
   V[o] = Vb[q];
   if (j >= g.Ny) return;   // (the fold line carries y faces only)
@@ -1564,7 +1517,7 @@ __global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const real* __r
                                                          real* __restrict__ V) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny + g.cv.north_fold) return;
+  if (i >= g.Nx || j >= g.Ny) return;
   int o = ic(g, i, min(j, g.Ny - 1), 0), ov = iv(g, i, j, 0);
   real su = g.dzc[0] * u[o], sv = g.dzc[0] * v[ov];
   for (int k = 1; k < g.Nz; k++) {
@@ -1591,7 +1544,7 @@ __global__ __launch_bounds__(256) void k_corrector_cells(Grid g, real* __restric
   // columns i0 .. i0+ni-1 with a gap of `skip` columns from index skip_from on (the two x-halo strips of a slab in one
   // launch: their column integrals arrived with the 3-D bundle, computed by the columns' owner)
   const int idx = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
-  if (idx >= ni || j >= g.Ny + g.cv.north_fold) return;
+  if (idx >= ni || j >= g.Ny) return;
   int i = i0 + idx;
   if (i >= skip_from) i += skip;
   const int o2 = i2(g, i, j);
@@ -1685,7 +1638,7 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
                                                    int i0, int ni, int kchunks, int skip_from, int skip) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= ni || j >= g.Ny + g.cv.north_fold) return;
+  if (i >= ni || j >= g.Ny) return;
   i += i0;
   if (i >= skip_from) i += skip;   // (the two x-halo strips of a slab in one launch: skip the interior)
   if (j >= g.Ny) {   // zipper fold: the y faces on the fold line, v only (never with FOLD)
@@ -1815,7 +1768,7 @@ __global__ __launch_bounds__(256) void k_mask_immersed(Grid g, real* __restrict_
                                                        real* __restrict__ U, real* __restrict__ V) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j > g.Ny) return;
+  if (i >= g.Nx || j > g.Ny || (j == g.Ny && g.cv.north_fold)) return;   // (the y faces beyond the pivot row are halo cells)
   const int o2 = i2(g, i, j);
   const unsigned A = g.im.ordA[o2], C = g.im.ordC[o2];
   // v faces: j = 0 and j = Ny are walls (peripheral on the underlying grid); in between KPV levels touch the solid

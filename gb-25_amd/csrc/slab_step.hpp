@@ -28,8 +28,12 @@
 //   stage 5   Ns split-explicit substeps on the widened slab into the partner buffers of eta,U,V, filtered state; the slab
 //             is wide enough that the x HALO columns of the new eta,U,V come out valid too: nothing is exchanged after it
 //   The next stage 0 adopts them.  When a look-ahead is not valid (first step, changed dt, host writes) the same work
-//   runs inside the step instead: group 1 (= 3), stage 1 (= 5), on the critical path.  (Groups 2 and 4 -- H columns of the
-//   new eta,U,V -- remain for the initial state and on a folded grid, whose sub-cycle advances substep by substep.)
+//   runs inside the step instead: group 1 (= 3), stage 1 (= 5), on the critical path.  (Group 2 -- H columns of eta,U,V --
+//   remains for the initial state.)
+//   Folded (tripolar) grid: the work arrays of the sub-cycle are also TALL -- Wy rows beyond the pivot row, the images of the
+//   partner rank's rows south of it -- so between stage 1 / 5 (which then only copies the interiors) and the substeps
+//   (stage 16 / 56) one more exchange, group 8, carries those rows to the partner: ONE partner exchange per step for the
+//   sub-cycle, none inside it.  Group 6 is the partner exchange of the 3-D bundle's rows (and of eta, U, V).
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -124,9 +128,9 @@ gb25_status pack_unpack(gb25_model* m, int group, real* const buf[2], bool pack)
 }
 
 // ---- zipper fold of a decomposed tripolar grid: the partner rank P-1-r holds the cells beyond this slab's fold line -----
-// buffer set 3: the H rows next to the fold line of u, v, T, S (CATKE: e, J^b too) and eta, U, V (all parent columns,
-// interior levels);
-// buffer set 4: five rows of the widened barotropic arrays, once per substep (CurvBaro::img, kernels.hpp)
+// buffer set 3: the pivot row and the H rows south of it of u, v, T, S (CATKE: e, J^b too) and eta, U, V (all parent
+// columns, interior levels);
+// buffer set 4: the Wy (+1) rows south of the pivot row of the sub-cycle's work arrays eta, U, V, G.U, G.V (TallRows, kernels.hpp)
 FoldFields fold_fields(gb25_model* m) {
   FoldFields F{};
   const Grid& g = m->g;
@@ -134,7 +138,7 @@ FoldFields fold_fields(gb25_model* m) {
   auto add = [&](real* p, int is_v, int xf, int neg, int nz) {
     const int f = F.n++;
     F.p[f] = p; F.is_v[f] = is_v; F.xf[f] = xf; F.neg[f] = neg; F.nz[f] = nz; F.off[f] = off;
-    off += (long)nz * g.H * g.sx;
+    off += (long)nz * (g.H + 1) * g.sx;
   };
   add(m->f[GB25_U].d, 0, 1, 1, g.Nz);
   add(m->f[GB25_V].d, 1, 0, 1, g.Nz);
@@ -157,29 +161,23 @@ int fold_levels(const FoldFields& F, bool with_layers) {   // blockIdx.z extent 
 int64_t fold_buffer_elems(gb25_model* m, int b) {
   const Grid& g = m->g;
   if (!g.cv.north_fold) return 1;
-  return b == 3 ? (int64_t)g.H * g.sx * fold_levels(fold_fields(m), false) : (int64_t)5 * (g.Nx + 2 * m->W);
+  return b == 3 ? (int64_t)(g.H + 1) * g.sx * fold_levels(fold_fields(m), false) : tall_buffer_elems(m);
 }
 gb25_status fold_pack(gb25_model* m, real* buf) {
   const Grid& g = m->g;
   FoldFields F = fold_fields(m);
-  hipLaunchKernelGGL(k_fold_pack, dim3((g.sx + 255) / 256, g.H, fold_levels(F, false)), dim3(256), 0, m->stream, g, F, buf);
+  hipLaunchKernelGGL(k_fold_pack, dim3((g.sx + 255) / 256, g.H + 1, fold_levels(F, false)), dim3(256), 0, m->stream, g, F, buf);
   LAUNCHCHK();
   return GB25_OK;
 }
 gb25_status fold_unpack(gb25_model* m, const real* buf) {
   const Grid& g = m->g;
   FoldFields F = fold_fields(m);
-  hipLaunchKernelGGL(k_fold_unpack, dim3((g.sx + 255) / 256, g.H, fold_levels(F, true)), dim3(256), 0, m->stream, g, F, buf,
+  hipLaunchKernelGGL(k_fold_unpack, dim3((g.sx + 255) / 256, g.H + 1, fold_levels(F, true)), dim3(256), 0, m->stream, g, F, buf,
                      m->cfg.rank * m->Nx, m->cfg.Nx);
   LAUNCHCHK();
   return GB25_OK;
 }
-
-// the sub-cycle of a slab of a folded grid, one substep per call (defined after SlabGroup: they use its buffers)
-gb25_status barotropic_fold_begin(gb25_model* m);
-gb25_status barotropic_fold_rows(gb25_model* m, int sub);
-gb25_status barotropic_fold_substep(gb25_model* m, int sub, real dt);
-gb25_status barotropic_fold_end(gb25_model* m, real dt);
 
 // ---- the stages of one slab's time step (see the header of this file) -------------------------------------------------
 gb25_status slab_stage(gb25_model* m, int stage, int euler) {
@@ -225,17 +223,19 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
     }
     return GB25_OK;
-  } else if (stage == 1 || stage == 5) {
+  } else if (stage == 1 || stage == 5 || stage == 16 || stage == 56) {
     // stage 1: group 1 has been unpacked into the wide halos: copy the interiors, sub-cycle, publish.
     // stage 5: the same for the NEXT step (look-ahead): group 3 has been unpacked, G.U, G.V come from the momentum
     //          look-ahead, the results go to the partner buffers of eta, U, V and of the filtered state.
-    const bool ahead = stage == 5;
+    // Folded grid: stage 1 / 5 end after the interior copy (the image rows beyond the pivot row travel next: group 8),
+    // stage 16 / 56 do the rest.
+    const bool ahead = stage == 5 || stage == 56, second_half = stage == 16 || stage == 56;
     if (ahead && !m->ahead_uv_valid) return fail(m, GB25_ERR_STATE, "stage 5 without a velocity look-ahead");
     if (!ahead && m->baro_adopted) return fail(m, GB25_ERR_STATE, "stage 1 after stage 0 adopted the sub-cycle");
     std::vector<Piece> ps;
     int nc = 0;
     group_pieces(m, ahead ? 3 : 1, ps, &nc);
-    {
+    if (!second_half) {
       InteriorCopies C{};
       int rmax = 0;
       for (auto& p : ps) {
@@ -248,6 +248,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
                          g.Nx);
     }
     LAUNCHCHK();
+    if (g.cv.north_fold && !second_half) return GB25_OK;
     if (ahead) {
       if ((s = barotropic_impl(m, m->ahead_uv_dt, true))) return s;
       Halo2 h2;
@@ -308,29 +309,6 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     if ((s = tracers_impl(m))) return s;
     if ((s = catke_update_impl(m))) return s;
     return atmosphere_ocean_fluxes_impl(m);
-  } else if (stage == 10) {
-    // folded grid, sub-cycle inside the step: group 1 has been unpacked into the wide halos: copy the interiors, zero the
-    // running averages
-    std::vector<Piece> ps;
-    int nc = 0;
-    group_pieces(m, 1, ps, &nc);
-    InteriorCopies C{};
-    int rmax = 0;
-    for (auto& p : ps) {
-      const int q = C.n++;
-      C.dst[q] = p.dst; C.dsx[q] = p.dst_sx; C.dxo[q] = p.dst_xo;
-      C.src[q] = p.src; C.ssx[q] = p.src_sx; C.sxo[q] = p.src_xo; C.rows[q] = (int)p.rows;
-      rmax = std::max(rmax, (int)p.rows);
-    }
-    hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, rmax, C.n), dim3(256), 0, m->stream, C, g.Nx);
-    LAUNCHCHK();
-    return barotropic_fold_begin(m);
-  } else if (stage == 11) {
-    return barotropic_fold_end(m, (real)dt);
-  } else if (stage >= 100 && stage < 100 + 4096) {
-    return barotropic_fold_rows(m, stage - 100);            // pack the rows the partner's fold-line faces need in this substep
-  } else if (stage >= 5000 && stage < 5000 + 4096) {
-    return barotropic_fold_substep(m, stage - 5000, (real)dt);
   }
   return fail(m, GB25_ERR_INVALID_ARGUMENT, "unknown stage %d", stage);
 }
@@ -363,7 +341,6 @@ struct StepOps {
   virtual bool subcycle_adopted(int s) = 0;
   virtual bool coupled() { return false; }   // a prescribed atmosphere is set (data-free forcing)
   virtual bool folded() = 0;          // zipper fold: exchanges with the partner rank (buffer sets 3 and 4; groups 6 and 7)
-  virtual int substeps() = 0;
   virtual gb25_status record(int slot, bool on_comm) = 0;
   virtual gb25_status wait(int slot, bool comm_waits) = 0;
 };
@@ -400,27 +377,24 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
   SEQ(o.record(1, true));      // (packed)
   SEQ(o.exchange(0, true));
   if (!adopted && o.folded()) {
-    // zipper fold: the fold-line faces of a slab need rows of the partner rank P-1-r in every substep, so the slabs advance
-    // substep by substep: pack five rows, exchange with the partner (buffer set 4), one substep on the widened slab
-    EACH(o.unpack(s, 1, false));
-    EACH(o.stage(s, 10, euler, false));
-    for (int sub = 0; sub < o.substeps(); sub++) {
-      EACH(o.stage(s, 100 + sub, euler, false));
-      SEQ(o.exchange(7, false));
-      EACH(o.stage(s, 5000 + sub, euler, false));
+    // zipper fold: the work arrays are tall as well as wide.  Once every slab has its wide halo columns, the rows south of
+    // the pivot row go to the partner rank P-1-r (group 8) and become its image rows beyond the pivot row; then the substeps
+    // run with no further exchange
+    for (int s = 0; s < n; s++) {
+      SEQ(o.unpack(s, 1, false));
+      SEQ(o.stage(s, 1, euler, false));      // (folded: the interior copy only)
+      SEQ(o.pack(s, 8, false));
     }
-    EACH(o.stage(s, 11, euler, false));
-    EACH(o.pack(s, 2, false));
+    SEQ(o.exchange(8, false));
+    for (int s = 0; s < n; s++) {
+      SEQ(o.unpack(s, 8, false));
+      SEQ(o.stage(s, 16, euler, false));
+    }
   } else if (!adopted) {       // ... and is in flight while the sub-cycle runs here (it leaves the x halo columns of the
     for (int s = 0; s < n; s++) {   // new eta, U, V behind as well: the slab is widened by Ns + 1 + H columns, no group 2)
       SEQ(o.unpack(s, 1, false));
       SEQ(o.stage(s, 1, euler, false));
     }
-  }
-  if (!adopted && o.folded()) {
-    SEQ(o.record(2, false));
-    SEQ(o.wait(2, true));      // eta, U, V columns leave behind the bundle on the second stream
-    SEQ(o.exchange(2, true));
   }
   SEQ(o.wait(1, false));       // the corrector rewrites the columns the bundle was packed from
   if (in_flight && adopted)    // ... and reads the adopted sub-cycle: the look-ahead chain has finished (event 4 sits
@@ -428,7 +402,6 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
   EACH(o.stage(s, 2, euler, false));   // own columns + interior tendencies, while the exchanges are in flight
   SEQ(o.record(3, true));
   SEQ(o.wait(3, false));       // the halo columns have arrived
-  if (!adopted && o.folded()) EACH(o.unpack(s, 2, false));
   if (o.folded()) {
     // the rows beyond the fold come from the partner once every slab has its x halos and y/z layers (the partner sends
     // its halo columns too: the corners), then the rest of update_state!
@@ -460,6 +433,14 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
     for (int s = 0; s < n; s++) {
       SEQ(o.unpack(s, 3, true));
       SEQ(o.stage(s, 5, euler, true));   // (x halo columns of the new eta, U, V included: nothing to exchange after it)
+      if (o.folded()) SEQ(o.pack(s, 8, true));
+    }
+    if (o.folded()) {                    // the image rows beyond the pivot row, then the substeps
+      SEQ(o.exchange(8, true));
+      for (int s = 0; s < n; s++) {
+        SEQ(o.unpack(s, 8, true));
+        SEQ(o.stage(s, 56, euler, true));
+      }
     }
     SEQ(o.record(4, true));
     lookahead_in_flight = true;
@@ -530,11 +511,9 @@ struct TraceOps : StepOps {
   bool adopted, ready;
   std::string log;
   bool fold = false, is_coupled = false;
-  int nsub = 21;
   TraceOps(int n_, bool a, bool r) : nslabs(n_), adopted(a), ready(r) {}
   bool folded() override { return fold; }
   bool coupled() override { return is_coupled; }
-  int substeps() override { return nsub; }
   void add(const char* fmt, ...) {
     char buf[96];
     va_list ap;
@@ -589,8 +568,8 @@ struct SlabGroup {
 
 namespace {
 
-// (groups 6, 7: the partner exchanges of a folded grid -- the rows next to the fold line; the sub-cycle's rows)
-inline int buffer_set(int group) { return group == 6 ? 3 : group == 7 ? 4 : group == 0 ? 0 : ((group == 1 || group == 3) ? 1 : 2); }
+// (groups 6, 8: the partner exchanges of a folded grid -- the rows next to the pivot row; the image rows of the sub-cycle)
+inline int buffer_set(int group) { return group == 6 ? 3 : group == 8 ? 4 : group == 0 ? 0 : ((group == 1 || group == 3) ? 1 : 2); }
 
 // several slabs of one decomposition in this process, all on one device: a ring of device-to-device copies
 struct LocalRingTransport : Transport {
@@ -726,70 +705,6 @@ struct CallbackTransport : Transport {
   }
 };
 
-// ---- the sub-cycle of a slab of a folded grid (stages 10, 100 + sub, 5000 + sub, 11) ---------------------------------
-// Widened arrays as on the lat-lon grid (one wide-halo exchange per step, no x exchange inside), one launch per substep
-// (k_barotropic_substep_curv<true>), and before each of them the five rows the partner's fold-line faces need.
-gb25_status barotropic_fold_begin(gb25_model* m) {
-  HIPCHK(hipMemsetAsync(m->wideBar[0].d, 0,
-                        (m->wideBar[0].elems() + m->wideBar[1].elems() + m->wideBar[2].elems()) * sizeof(real), m->stream));
-  m->fold_flip = 0;
-  return GB25_OK;
-}
-gb25_status barotropic_fold_rows(gb25_model* m, int) {
-  const Grid& g = m->g;
-  SlabGroup* G = m->group;
-  const int wsx = g.Nx + 2 * m->W, a = m->fold_flip;
-  hipLaunchKernelGGL(k_fold_rows_pack, dim3((wsx + 255) / 256), dim3(256), 0, m->stream, g, m->wide[a][0].d, m->wide[a][1].d,
-                     m->wide[a][2].d, m->wideG[1].d, wsx, G->send[m->group_index][4][0]);
-  LAUNCHCHK();
-  return GB25_OK;
-}
-gb25_status barotropic_fold_substep(gb25_model* m, int sub, real dt) {
-  const Grid& g = m->g;
-  SlabGroup* G = m->group;
-  const int a = m->fold_flip;
-  Baro bb;
-  bb.eta0 = m->wide[a][0].d; bb.U0 = m->wide[a][1].d; bb.V0 = m->wide[a][2].d;
-  bb.eta1 = m->wide[a ^ 1][0].d; bb.U1 = m->wide[a ^ 1][1].d; bb.V1 = m->wide[a ^ 1][2].d;
-  bb.etab = m->wideBar[0].d; bb.Ub = m->wideBar[1].d; bb.Vb = m->wideBar[2].d;
-  bb.GU = m->wideG[0].d; bb.GV = m->wideG[1].d;
-  bb.sx = g.Nx + 2 * m->W; bb.xo = m->W; bb.ilo = -m->W + 1; bb.ihi = g.Nx + m->W - 1; bb.wrap = 0;
-  bb.Hfc = m->d_wideH[0]; bb.Hcf = m->d_wideH[1];
-  const CurvBaro cb{m->d_wideM[0], m->d_wideM[1], m->d_wideM[2], m->d_wideM[3], m->d_wideM[4],
-                    G->recv[m->group_index][4][0], m->d_wideM[5], m->cfg.rank * g.Nx, m->cfg.Nx};
-  dim3 b(64, 4);
-  Timed t(m, GB25_K_BAROTROPIC);
-  hipLaunchKernelGGL(k_barotropic_substep_curv<true>, grid2(bb.ihi - bb.ilo, v_rows(g), b), b, 0, m->stream, g, bb, cb,
-                     (real)m->dtau_frac * dt, (real)m->weights[sub]);
-  LAUNCHCHK();
-  m->fold_flip ^= 1;
-  return GB25_OK;
-}
-gb25_status barotropic_fold_end(gb25_model* m, real dt) {
-  const Grid& g = m->g;
-  dim3 b(64, 4);
-  const int wsx = g.Nx + 2 * m->W;
-  hipLaunchKernelGGL(k_barotropic_finalize, grid2(g.Nx, v_rows(g), b), b, 0, m->stream, g, m->f[GB25_ETA].d, m->f[GB25_BT_U].d,
-                     m->f[GB25_BT_V].d, m->wideBar[0].d, m->wideBar[1].d, m->wideBar[2].d, wsx, m->W, 0);
-  InteriorCopies C{};
-  int rmax = 0;
-  for (int q = 0; q < 3; q++) {   // publish the averages in the canonical filtered-state arrays
-    Field& dst = m->f[GB25_ETA_BAR + q];
-    C.dst[q] = dst.d; C.dsx[q] = dst.nx; C.dxo[q] = g.H;
-    C.src[q] = m->wideBar[q].d; C.ssx[q] = wsx; C.sxo[q] = m->W; C.rows[q] = dst.ny;
-    rmax = std::max(rmax, dst.ny);
-  }
-  C.n = 3;
-  hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, rmax, C.n), dim3(256), 0, m->stream, C, g.Nx);
-  // the state's G.V on the fold line: antisymmetric, as the fold fill of G.U, G.V leaves it on a single domain
-  hipLaunchKernelGGL(k_fold_line_GV, dim3((g.Nx + 255) / 256), dim3(256), 0, m->stream, g, m->f[GB25_GN_BT_V].d,
-                     m->group->recv[m->group_index][4][0], wsx, m->W, m->cfg.rank * g.Nx, m->cfg.Nx);
-  LAUNCHCHK();
-  m->time += (double)dt;
-  m->iteration += 1;
-  return fill_halos_impl(m, false, false, 2);   // y layer of the new eta, U, V; their x columns are group 2
-}
-
 // the real StepOps: the slabs of a SlabGroup
 struct GroupOps : StepOps {
   SlabGroup& G;
@@ -808,11 +723,11 @@ struct GroupOps : StepOps {
   }
   bool folded() override { return G.slabs[0]->g.cv.north_fold != 0; }
   bool coupled() override { return G.slabs[0]->coupled; }
-  int substeps() override { return G.slabs[0]->Ns; }
   gb25_status pack(int s, int group, bool c) override {
     OnStream on(G.slabs[s], st(c));
     const int b = buffer_set(group);
     if (group == 6) return fold_pack(G.slabs[s], G.send[s][b][0]);
+    if (group == 8) return tall_rows_impl(G.slabs[s], G.send[s][b][0], true);
     if (group == 0) G.slabs[s]->halo_colsum_valid = G.slabs[s]->colsum_valid;   // (every slab alike: same calls, same state)
     real* buf[2] = {G.send[s][b][0], G.send[s][b][1]};
     return pack_unpack(G.slabs[s], group, buf, true);
@@ -821,6 +736,7 @@ struct GroupOps : StepOps {
     OnStream on(G.slabs[s], st(c));
     const int b = buffer_set(group);
     if (group == 6) return fold_unpack(G.slabs[s], G.recv[s][b][0]);
+    if (group == 8) return tall_rows_impl(G.slabs[s], G.recv[s][b][0], false);
     real* buf[2] = {G.recv[s][b][0], G.recv[s][b][1]};
     return pack_unpack(G.slabs[s], group, buf, false);
   }
@@ -866,7 +782,7 @@ struct GroupOps : StepOps {
   }
   bool velocities_ready(int s) override {
     gb25_model* m = G.slabs[s];
-    return m->ahead_uv_valid && m->baro_ahead && !m->ptr_exposed && !m->g.cv.north_fold;
+    return m->ahead_uv_valid && m->baro_ahead && !m->ptr_exposed;
   }
   bool subcycle_adopted(int s) override { return G.slabs[s]->baro_adopted; }
   gb25_status record(int slot, bool c) override {

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   const int i0 = bx * V2_TX, j0 = by * V2_TY;
   const int i = i0 + tx, j = j0 + ty;
   // rows of y faces that have a tendency: with the zipper fold the fold line (row Ny) is one of them
-  const int jv_last = CURV ? g.Ny - 1 + g.cv.north_fold : g.Ny - 1;
+  const int jv_last = CURV ? g.Ny - 1 : g.Ny - 1;
   const bool inside_u = (i < g.Nx) && (j < g.Ny), inside_v = (i < g.Nx) && (j <= jv_last);
   const int ic_ = min(i, g.Nx - 1), jc_ = min(j, jv_last);   // ragged tiles: threads past the edge work on a duplicate
   const int sx = g.sx, pc = g.pl_c, pv = g.pl_v, H = g.H;

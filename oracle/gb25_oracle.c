@@ -111,9 +111,11 @@ typedef struct {
   REAL *dxfc2, *dxcc2, *dxcf2, *dxff2, *dyfc2, *dycc2, *dycf2, *dyff2, *azcc2, *azfc2, *azcf2, *azff2, *fff2, *phicc2;
   double *lamcc_d, *phicc_d; /* cell-centre coordinates in degrees (double), interior Nx x Ny, for analytic bottoms */
 } model;
-/* number of prognostic rows of the y-face fields: with the zipper fold the face ON the fold line (row Ny+1) is a face
- * between two rows of cells like any other and is stepped; at a wall it is not */
-#define NYV (m->Ny + (m->north_fold ? 1 : 0))
+/* number of prognostic rows of the y-face fields: Ny whatever the northern edge is.  The zipper fold pivots on the ROW OF
+ * CELL CENTRES Ny (Oceananigans' TripolarGrid: the centres run from the southernmost latitude to 90 degrees, "the north pole
+ * is a Center point"; topology (Periodic, RightConnected, Bounded), so a y-face field has Ny rows): the y faces Ny+1 beyond
+ * that row are halo cells, the images of the faces Ny. */
+#define NYV (m->Ny)
 
 /* ---------------------------------------------------------------- accessors */
 #define HH (m->H)
@@ -166,7 +168,7 @@ static void alloc_field(model *m, int id, int extra_y, int extra_z, int twod) {
 static inline int inactive_cell(const model *m, int i, int j, int k) {
   if (m->north_fold && j > m->Ny) {   /* beyond the fold: the cell it is the image of */
     i = m->Nx - i + 1;
-    j = 2 * m->Ny + 1 - j;
+    j = 2 * m->Ny - j;
   }
   if (j < 1 || j > m->Ny || k < 1 || k > m->Nz) return 1;
   if (i < 1 - m->H) i = 1 - m->H;              /* (beyond the x halo: never reached by an interior stencil) */
@@ -206,7 +208,7 @@ static void set_bottom(model *m, const double *zb /* Nx*Ny, i fastest */) {
     if (im < 1 - H) im = 1 - H;
     if (im > Nx + H) im = Nx + H;
     KB(i, 0) = KB(i, 1);
-    KB(i, Ny + 1) = m->north_fold ? KB(im, Ny) : KB(i, Ny);
+    KB(i, Ny + 1) = m->north_fold ? KB(im, Ny - 1) : KB(i, Ny);
   }
   for (int j = 0; j <= Ny + 1; j++)
     for (int i = 1 - H; i <= Nx + H; i++) {
@@ -391,8 +393,11 @@ static void build_curv_grid(model *m, const gb25o_config *c) {
   const int tri = c->grid_type >= 3;
   const double lam0 = tri ? TRIPOLAR_POLE_LON : c->lon_west;
   const double dlam = (tri ? 360.0 : (c->lon_east - c->lon_west)) / Nx;
-  const double phiN = tri ? 90.0 : c->lat_north, dphi = (phiN - c->lat_south) / Ny;
-  for (int j = 1 - H; j <= Ny + H + 1; j++)
+  /* tripolar: the Ny rows of cell centres run from the southern edge to 90 degrees (Oceananigans' TripolarGrid:
+   * range(southernmost_latitude, 90, length = Ny)), the faces half a spacing south of them; the rows beyond row Ny are
+   * its images and are filled from the interior below */
+  const double phiN = tri ? 90.0 : c->lat_north, dphi = (phiN - c->lat_south) / (tri ? Ny - 1 : Ny);
+  for (int j = 1 - H; j <= (tri ? Ny : Ny + H + 1); j++)
     for (int i = 1 - H; i <= Nx + H; i++) {
       if (!tri) {
         M2(dxfc2, i, j) = M2(dxcc2, i, j) = MJ(dxc, j);
@@ -406,7 +411,7 @@ static void build_curv_grid(model *m, const gb25o_config *c) {
       }
       /* computational coordinates of the four node families around (i, j) */
       const double lf = lam0 + (i - 1) * dlam, lc = lam0 + (i - 0.5) * dlam;
-      const double pf = c->lat_south + (j - 1) * dphi, pc = c->lat_south + (j - 0.5) * dphi;
+      const double pc = c->lat_south + (j - 1) * dphi, pf = pc - 0.5 * dphi;
 #define NODE(l, p) tripolar_node(l, p)
       gnode cc = NODE(lc, pc), fc = NODE(lf, pc), cf = NODE(lc, pf), ff = NODE(lf, pf);
       gnode fc_e = NODE(lf + dlam, pc), ff_e = NODE(lf + dlam, pf), cc_w = NODE(lc - dlam, pc), cf_w = NODE(lc - dlam, pf);
@@ -433,6 +438,19 @@ static void build_curv_grid(model *m, const gb25o_config *c) {
       }
 #undef NODE
     }
+  if (tri)   /* rows beyond the pivot row: the metric of a location there is the metric of its image (all positive scalars) */
+    for (int j = Ny + 1; j <= Ny + H + 1; j++)
+      for (int i = 1 - H; i <= Nx + H; i++) {
+        const int iw = (((i - 1) % Nx) + Nx) % Nx + 1;    /* the interior column this column is (the periodic image of) */
+        const int ic = Nx - iw + 1, ifx = (Nx - iw + 2 > Nx) ? Nx - iw + 2 - Nx : Nx - iw + 2;
+        const int jc = 2 * Ny - j, jf = 2 * Ny + 1 - j;   /* rows of cell centres / of y faces mirror about the centres of row Ny */
+        M2(dxcc2, i, j) = M2(dxcc2, ic, jc); M2(dycc2, i, j) = M2(dycc2, ic, jc); M2(azcc2, i, j) = M2(azcc2, ic, jc);
+        M2(phicc2, i, j) = M2(phicc2, ic, jc);
+        M2(dxfc2, i, j) = M2(dxfc2, ifx, jc); M2(dyfc2, i, j) = M2(dyfc2, ifx, jc); M2(azfc2, i, j) = M2(azfc2, ifx, jc);
+        M2(dxcf2, i, j) = M2(dxcf2, ic, jf); M2(dycf2, i, j) = M2(dycf2, ic, jf); M2(azcf2, i, j) = M2(azcf2, ic, jf);
+        M2(dxff2, i, j) = M2(dxff2, ifx, jf); M2(dyff2, i, j) = M2(dyff2, ifx, jf); M2(azff2, i, j) = M2(azff2, ifx, jf);
+        M2(fff2, i, j) = M2(fff2, ifx, jf);
+      }
   if (!tri)
     for (int j = 1; j <= Ny; j++)
       for (int i = 1; i <= Nx; i++) {
@@ -859,16 +877,22 @@ static void fill_periodic_x(const model *m, fld *F) {
     }
   }
 }
-/* Zipper fold at the northern edge of the tripolar grid (Oceananigans' fold_north_* functions, restated
- * [UPSTREAM-UNVERIFIED]; the convention used here is stated in DESIGN.md): the fold line is the row of y faces Ny+1, it
- * runs between the two north poles, which sit on the x faces i = 1 and i = Nx/2 + 1.  The cell (i, Ny+q) beyond it is
- * the image of cell (Nx-i+1, Ny-q+1); x faces mirror as i -> Nx-i+2, y faces as j -> 2(Ny+1)-j; vector components
- * change sign.  The y faces ON the fold line are each seen from both sides: v(i) = -v(Nx-i+1); both are stepped, the
- * copy in the eastern half is overwritten with minus its partner (exact antisymmetry, fluxes match to the last bit). */
+/* Zipper fold at the northern edge of the tripolar grid: Oceananigans' fold_north_{center,face}_{center,face}! of its
+ * zipper boundary condition, restated from memory of v0.96 [UPSTREAM-UNVERIFIED].  The fold pivots on the CENTRES of row
+ * Ny ("the Ny line is duplicated"), between the two north poles, which sit on the x faces i = 1 and i = Nx/2 + 1:
+ *   (c,c):  c[i, Ny+j] = s c[Nx-i+1, Ny-j]            (f,c):  c[i, Ny+j] = s' c[i', Ny-j],   i' = Nx-i+2
+ *   (c,f):  c[i, Ny+j] = s c[Nx-i+1, Ny-j+1]          where i' > Nx wraps to i' - Nx and takes s' = |s| ("for periodic
+ *                                                      elements we change the sign"), s' = s otherwise,
+ * j = 1..H, s = -1 for vector components.  Row Ny itself is held twice -- cell (i, Ny) IS cell (Nx-i+1, Ny) -- and both
+ * copies are stepped; the copy in the eastern half is overwritten with the image of the western one at every fill
+ * (restatement choice: keeps the two consistent; the x face that is its own image is left alone). */
 static inline int fold_i(const model *m, int i, int xface) {
   int ip = xface ? m->Nx - i + 2 : m->Nx - i + 1;
   if (ip > m->Nx) ip -= m->Nx;
   return ip;
+}
+static inline REAL fold_sign(const model *m, int i, int xface, REAL sgn) {
+  return (xface && m->Nx - i + 2 > m->Nx && sgn < 0) ? -sgn : sgn;
 }
 static void fold_rows_levels(model *m, int id, int twod, int is_v, int xface, REAL sgn, int nlev) {
   int Nx = m->Nx, Ny = m->Ny, H = m->H, k0 = 1, k1 = twod ? 1 : nlev;
@@ -876,12 +900,15 @@ static void fold_rows_levels(model *m, int id, int twod, int is_v, int xface, RE
     REAL *base = twod ? m->f[id].p : m->f[id].p + (long)m->f[id].sx * m->f[id].sy * (k - 1 + H);
 #define AF(i, j) base[((long)(i)-1 + H) + (long)m->f[id].sx * ((long)(j)-1 + H)]
     if (is_v) {
-      for (int i = Nx / 2 + 1; i <= Nx; i++) AF(i, Ny + 1) = sgn * AF(fold_i(m, i, 0), Ny + 1);   /* the pivot row */
-      for (int q = 1; q < H; q++)
-        for (int i = 1; i <= Nx; i++) AF(i, Ny + 1 + q) = sgn * AF(fold_i(m, i, 0), Ny + 1 - q);
-    } else {
       for (int q = 1; q <= H; q++)
-        for (int i = 1; i <= Nx; i++) AF(i, Ny + q) = sgn * AF(fold_i(m, i, xface), Ny + 1 - q);
+        for (int i = 1; i <= Nx; i++) AF(i, Ny + q) = sgn * AF(fold_i(m, i, 0), Ny + 1 - q);
+    } else {
+      for (int i = Nx / 2 + 1; i <= Nx; i++) {   /* the pivot row: the eastern copy <- the image of the western one */
+        const int ip = fold_i(m, i, xface);
+        if (ip != i) AF(i, Ny) = fold_sign(m, i, xface, sgn) * AF(ip, Ny);
+      }
+      for (int q = 1; q <= H; q++)
+        for (int i = 1; i <= Nx; i++) AF(i, Ny + q) = fold_sign(m, i, xface, sgn) * AF(fold_i(m, i, xface), Ny - q);
     }
 #undef AF
   }
@@ -1048,10 +1075,6 @@ void FN(compute_momentum_tendencies)(void *h) {
         A3(F_GNU, i, j, k) = immersed_peripheral_u(m, i, j, k) ? (REAL)0 : Gu_at(m, i, j, k);
         A3(F_GNV, i, j, k) = immersed_peripheral_v(m, i, j, k) ? (REAL)0 : Gv_at(m, i, j, k);
       }
-  if (m->north_fold) /* the y faces on the fold line */
-    for (int k = 1; k <= m->Nz; k++)
-      for (int i = 1; i <= m->Nx; i++)
-        A3(F_GNV, i, m->Ny + 1, k) = immersed_peripheral_v(m, i, m->Ny + 1, k) ? (REAL)0 : Gv_at(m, i, m->Ny + 1, k);
 }
 static REAL tracer_flux(const model *m, int dir, int i, int j, int k, fn3 c) {
   if (dir == DX) {
@@ -1504,12 +1527,6 @@ static void barotropic_mode(model *m, int idU, int idV) {
       A2(idU, i, j) = su;
       A2(idV, i, j) = sv;
     }
-  if (m->north_fold)
-    for (int i = 1; i <= m->Nx; i++) {
-      REAL sv = DZC(1) * A3(F_V, i, m->Ny + 1, 1);
-      for (int k = 2; k <= m->Nz; k++) sv += DZC(k) * A3(F_V, i, m->Ny + 1, k);
-      A2(idV, i, m->Ny + 1) = sv;
-    }
 }
 static inline REAL ab2_G(const model *m, int gn, int gm, int i, int j, int k, REAL chi) {
   REAL C1 = (REAL)1.5 + chi, C2 = (REAL)0.5 + chi;
@@ -1528,12 +1545,6 @@ static void free_surface_tendency(model *m, REAL chi) {
       }
       A2(F_GBU, i, j) = su;
       A2(F_GBV, i, j) = sv;
-    }
-  if (m->north_fold)
-    for (int i = 1; i <= m->Nx; i++) {
-      REAL sv = DZC(1) * ab2_G(m, F_GNV, F_GMV, i, m->Ny + 1, 1, chi);
-      for (int k = 2; k <= m->Nz; k++) sv += DZC(k) * ab2_G(m, F_GNV, F_GMV, i, m->Ny + 1, k, chi);
-      A2(F_GBV, i, m->Ny + 1) = sv;
     }
   fill_halo_2d(m, F_GBU, 0, 1, -1);
   fill_halo_2d(m, F_GBV, 1, 0, -1);
@@ -1555,7 +1566,82 @@ static void ab2_field(model *m, int id, int gn, int gm, REAL dt, REAL chi, int v
         }
       }
 }
+/* The sub-cycle on a folded grid.  The pivot row's cells need V on the y faces beyond them in every substep; as
+ * Oceananigans does for its TripolarGrid (the free surface's halo in y is extended to the number of substeps and filled
+ * ONCE per step), the state is copied to arrays with Wy = Ns + 1 more rows beyond row Ny, those rows are filled with the
+ * images of the rows below it (values, forcing, metrics, depths), and the Ns substeps run on all Ny + Wy rows with no
+ * further fill: what the missing neighbour of the last row spoils moves one row per substep and never reaches row Ny. */
+static void step_free_surface_fold(model *m, REAL dt) {
+  const int Nx = m->Nx, Ny = m->Ny;
+  int Wy = m->Ns + 1;
+  if (Wy > Ny - 2) Wy = Ny - 2;
+  const int NT = Ny + Wy;
+  const REAL dtau = m->dtau_frac * dt;
+  const size_t n = (size_t)Nx * (NT + 2);
+  REAL *buf = (REAL *)calloc(12 * n, sizeof(REAL));
+  REAL *e = buf, *U = e + n, *V = U + n, *GU = V + n, *GV = GU + n, *hf = GV + n, *hc = hf + n, *dyfc = hc + n,
+       *dxcf = dyfc + n, *azcc = dxcf + n, *dxfc = azcc + n, *dycf = dxfc + n;
+#define TT(a, i, j) a[((long)(i)-1) + (long)Nx * ((long)(j)-1)]
+  for (int j = 1; j <= NT + 1; j++)
+    for (int i = 1; i <= Nx; i++) {
+      int ic = i, ifx = i, jc = j, jf = j;
+      REAL su = 1, sv = 1;
+      if (j > Ny) {
+        ic = fold_i(m, i, 0); ifx = fold_i(m, i, 1);
+        jc = 2 * Ny - j; jf = 2 * Ny + 1 - j;
+        su = fold_sign(m, i, 1, (REAL)-1); sv = -1;
+      }
+      TT(e, i, j) = A2(F_ETA, ic, jc);
+      TT(U, i, j) = su * A2(F_BU, ifx, jc);  TT(GU, i, j) = su * A2(F_GBU, ifx, jc);
+      TT(V, i, j) = sv * A2(F_BV, ic, jf);   TT(GV, i, j) = sv * A2(F_GBV, ic, jf);
+      TT(hf, i, j) = H2(Hfc, ifx, jc);       TT(hc, i, j) = H2(Hcf, ic, jf);
+      TT(dyfc, i, j) = DYFC(ifx, jc);        TT(dxfc, i, j) = DXFC(ifx, jc);
+      TT(dxcf, i, j) = DXCF(ic, jf);         TT(dycf, i, j) = DYCF(ic, jf);
+      TT(azcc, i, j) = AZCC(ic, jc);
+    }
+  for (int id = F_ETAB; id <= F_VB; id++)
+    memset(m->f[id].p, 0, sizeof(REAL) * (size_t)m->f[id].sx * m->f[id].sy);
+  for (int s = 0; s < m->Ns; s++) {
+    const REAL wgt = m->wts[s];
+#pragma omp parallel for schedule(static)
+    for (int j = 1; j <= NT; j++)
+      for (int i = 1; i <= Nx; i++) {
+        const int ip = (i == Nx) ? 1 : i + 1;
+        const REAL dxU = TT(dyfc, ip, j) * TT(U, ip, j) - TT(dyfc, i, j) * TT(U, i, j);
+        const REAL dyV = (j == 1) ? TT(dxcf, i, 2) * TT(V, i, 2) : TT(dxcf, i, j + 1) * TT(V, i, j + 1) - TT(dxcf, i, j) * TT(V, i, j);
+        TT(e, i, j) -= dtau * (dxU + dyV) / TT(azcc, i, j);
+      }
+#pragma omp parallel for schedule(static)
+    for (int j = 1; j <= NT; j++)
+      for (int i = 1; i <= Nx; i++) {
+        const int im = (i == 1) ? Nx : i - 1;
+        const REAL dxe = (TT(e, i, j) - TT(e, im, j)) / TT(dxfc, i, j);
+        const REAL dye = (j == 1) ? 0 : (TT(e, i, j) - TT(e, i, j - 1)) / TT(dycf, i, j);
+        const REAL Un = TT(U, i, j) + dtau * (-m->g * TT(hf, i, j) * dxe + TT(GU, i, j));
+        const REAL Vn = TT(V, i, j) + dtau * (-m->g * TT(hc, i, j) * dye + TT(GV, i, j));
+        TT(U, i, j) = Un;
+        TT(V, i, j) = Vn;
+        if (j <= Ny) {
+          A2(F_ETAB, i, j) += wgt * TT(e, i, j);
+          A2(F_UB, i, j) += wgt * Un;
+          A2(F_VB, i, j) += wgt * Vn;
+        }
+      }
+  }
+  for (int j = 1; j <= Ny; j++)
+    for (int i = 1; i <= Nx; i++) {
+      A2(F_ETA, i, j) = A2(F_ETAB, i, j);
+      A2(F_BU, i, j) = A2(F_UB, i, j);
+      A2(F_BV, i, j) = A2(F_VB, i, j);
+    }
+#undef TT
+  free(buf);
+}
 static void step_free_surface(model *m, REAL dt) {
+  if (m->north_fold) {
+    step_free_surface_fold(m, dt);
+    return;
+  }
   int Nx = m->Nx, Ny = m->Ny;
   REAL dtau = m->dtau_frac * dt;
   for (int id = F_ETAB; id <= F_VB; id++)
@@ -1567,7 +1653,7 @@ static void step_free_surface(model *m, REAL dt) {
       for (int i = 1; i <= Nx; i++) {
         int ip = (i == Nx) ? 1 : i + 1;
         REAL dxU = DYFC(ip, j) * A2(F_BU, ip, j) - DYFC(i, j) * A2(F_BU, i, j);
-        REAL dyV = (j == Ny && !m->north_fold) ? -(DXCF(i, j) * A2(F_BV, i, j))
+        REAL dyV = (j == Ny) ? -(DXCF(i, j) * A2(F_BV, i, j))
                  : (j == 1)  ? DXCF(i, 2) * A2(F_BV, i, 2)
                              : DXCF(i, j + 1) * A2(F_BV, i, j + 1) - DXCF(i, j) * A2(F_BV, i, j);
         A2(F_ETA, i, j) -= dtau * (dxU + dyV) / AZCC(i, j);
@@ -1587,17 +1673,6 @@ static void step_free_surface(model *m, REAL dt) {
         A2(F_BU, i, j) = Un;
         A2(F_BV, i, j) = Vn;
       }
-    if (m->north_fold) {
-      /* the y faces on the fold line: eta beyond the fold is the image of row Ny; then exact antisymmetry */
-      for (int i = 1; i <= Nx; i++) {
-        int j = Ny + 1, ifo = fold_i(m, i, 0);
-        REAL dye = (A2(F_ETA, ifo, Ny) - A2(F_ETA, i, Ny)) / DYCF(i, j);
-        REAL Vn = A2(F_BV, i, j) + dtau * (-m->g * H2(Hcf, i, j) * dye + A2(F_GBV, i, j));
-        A2(F_BV, i, j) = Vn;
-      }
-      for (int i = Nx / 2 + 1; i <= Nx; i++) A2(F_BV, i, Ny + 1) = -A2(F_BV, fold_i(m, i, 0), Ny + 1);
-      for (int i = 1; i <= Nx; i++) A2(F_VB, i, Ny + 1) += wgt * A2(F_BV, i, Ny + 1);
-    }
   }
   for (int j = 1; j <= Ny; j++)
     for (int i = 1; i <= Nx; i++) {
@@ -1605,8 +1680,6 @@ static void step_free_surface(model *m, REAL dt) {
       A2(F_BU, i, j) = A2(F_UB, i, j);
       A2(F_BV, i, j) = A2(F_VB, i, j);
     }
-  if (m->north_fold)
-    for (int i = 1; i <= Nx; i++) A2(F_BV, i, Ny + 1) = A2(F_VB, i, Ny + 1);
 }
 void FN(ab2_step)(void *h, double dt_, int euler) {
   model *m = (model *)h;
@@ -1645,13 +1718,6 @@ void FN(correct_and_cache)(void *h) {
           A3(F_U, i, j, k) = A3(F_U, i, j, k) + (A2(F_BU, i, j) - A2(F_UB, i, j)) / H2(Hfc, i, j);
         if (!immersed_peripheral_v(m, i, j, k))
           A3(F_V, i, j, k) = A3(F_V, i, j, k) + (A2(F_BV, i, j) - A2(F_VB, i, j)) / (j == 1 ? m->Lz : H2(Hcf, i, j));
-      }
-  if (m->north_fold)
-    for (int k = 1; k <= m->Nz; k++)
-      for (int i = 1; i <= m->Nx; i++) {
-        int j = m->Ny + 1;
-        if (!immersed_peripheral_v(m, i, j, k))
-          A3(F_V, i, j, k) = A3(F_V, i, j, k) + (A2(F_BV, i, j) - A2(F_VB, i, j)) / H2(Hcf, i, j);
       }
   for (int q = 0; q < 4; q++)
     for (int k = 1; k <= m->Nz; k++)
@@ -1769,7 +1835,7 @@ static int ao_coupled(const model *m) {
 void FN(compute_atmosphere_ocean_fluxes)(void *h) {
   model *m = (model *)h;
   if (!ao_coupled(m)) return;
-  int Nx = m->Nx, Ny = m->Ny, Nz = m->Nz, jtop = Ny + (m->north_fold ? 1 : 0);
+  int Nx = m->Nx, Ny = m->Ny, Nz = m->Nz, jtop = Ny;
   const fld *Fc = &m->f[F_T];
   long n2 = (long)Fc->sx * Fc->sy;
   double *tx = (double *)calloc(n2, sizeof(double)), *ty = (double *)calloc(n2, sizeof(double));

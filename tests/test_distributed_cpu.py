@@ -107,10 +107,11 @@ def test_time_step_sequencing_in_step_subcycle():
 
 
 def test_time_step_sequencing_on_a_folded_grid():
-    """Tripolar grid in slabs: the rows beyond a slab's fold line belong to the mirrored rank.  The sub-cycle advances
-    substep by substep (five rows from the partner before each: buffer set 4, "exchange 7"), the rows next to the fold line
-    of u, v, T, S, eta, U, V travel once per step ("exchange 6") after the x halos and y/z layers of EVERY slab are in
-    place (the partner sends its halo columns too) and before w, pressure and the tendencies."""
+    """Tripolar grid in slabs: the rows beyond a slab's pivot row belong to the mirrored rank.  The sub-cycle's work arrays are
+    tall as well as wide: after the wide-halo exchange and the interior copy (stage 1) the rows south of the pivot row go to
+    the partner ONCE ("exchange 8", buffer set 4), then all substeps run without any exchange (stage 16); the rows next to the
+    pivot row of u, v, T, S, eta, U, V travel once per step ("exchange 6") after the x halos and y/z layers of EVERY slab are
+    in place (the partner sends its halo columns too) and before w, pressure and the tendencies."""
     lib = load_library("Float32")
     need = lib.gb25_debug_sequence(3, 2, 0, 0, None, 0)
     buf = ctypes.create_string_buffer(need)
@@ -119,14 +120,25 @@ def test_time_step_sequencing_on_a_folded_grid():
     mine = _ops_of_slab(log, 1)
     assert mine == [("stage", 0, "main"), ("pack", 1, "main"), ("exchange", 1, "main"),
                     ("pack", 0, "comm"), ("exchange", 0, "comm"),
-                    ("unpack", 1, "main"), ("stage", 10, "main"),
-                    ("stage", 100, "main"), ("exchange", 7, "main"), ("stage", 5000, "main"),
-                    ("stage", 101, "main"), ("exchange", 7, "main"), ("stage", 5001, "main"),
-                    ("stage", 102, "main"), ("exchange", 7, "main"), ("stage", 5002, "main"),
-                    ("stage", 11, "main"), ("pack", 2, "main"), ("exchange", 2, "comm"),
+                    ("unpack", 1, "main"), ("stage", 1, "main"), ("pack", 8, "main"), ("exchange", 8, "main"),
+                    ("unpack", 8, "main"), ("stage", 16, "main"),
                     ("stage", 2, "main"),
-                    ("unpack", 2, "main"), ("unpack", 0, "main"), ("stage", 30, "main"), ("pack", 6, "main"),
+                    ("unpack", 0, "main"), ("stage", 30, "main"), ("pack", 6, "main"),
                     ("exchange", 6, "main"), ("unpack", 6, "main"), ("stage", 31, "main"), ("stage", 4, "main")]
+    assert not any(e[:2] in (("exchange", 7), ("exchange", 2)) for e in log)
+    # ... and with the look-aheads: the NEXT step's sub-cycle on the second stream, its two exchanges included
+    need = lib.gb25_debug_sequence(3, 2, 1, 1, None, 0)
+    buf = ctypes.create_string_buffer(need)
+    lib.gb25_debug_sequence(3, 2, 1, 1, buf, need)
+    ahead = [tuple(int(t) if t.lstrip("-").isdigit() else t for t in line.split()) for line in buf.value.decode().splitlines()]
+    mine = _ops_of_slab(ahead, 1)
+    assert mine == [("stage", 0, "main"), ("pack", 0, "comm"), ("exchange", 0, "comm"), ("stage", 2, "main"),
+                    ("unpack", 0, "main"), ("stage", 30, "main"), ("pack", 6, "main"), ("exchange", 6, "main"),
+                    ("unpack", 6, "main"), ("stage", 31, "main"),
+                    ("pack", 3, "comm"), ("exchange", 3, "comm"), ("unpack", 3, "comm"), ("stage", 5, "comm"),
+                    ("pack", 8, "comm"), ("exchange", 8, "comm"), ("unpack", 8, "comm"), ("stage", 56, "comm"),
+                    ("stage", 4, "main")]
+    assert ahead[-1] == ("lookahead_in_flight", 1)
     # every slab has packed its rows before the partner exchange and no slab unpacks before it
     ex = [i for i, e in enumerate(log) if e[:2] == ("exchange", 6)]
     assert len(ex) == 1

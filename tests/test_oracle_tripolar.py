@@ -5,7 +5,8 @@ construction of this repository's own; topology, pole positions, fold and metric
  * the lat-lon metrics sent through the curvilinear code path reproduce the plain model bit for bit;
  * geometry: the cells tile the sphere north of 80 S, the poles sit at (70 E, 55 N) and (250 E, 55 N) on x faces 1 and
    Nx/2+1, metrics are symmetric under the fold, the grid is the lat-lon grid south of 55 N;
- * the fold: halo rows are the (signed) images, the y faces on the fold line are exactly antisymmetric;
+ * the fold pivots on the centres of row Ny (Oceananigans' convention): halo rows are the (signed) images, the pivot row is
+   held twice and kept consistent by the fill;
  * conservation across the fold, rest state, mirror symmetry of the first tendencies away from the mountains;
  * the bare tripolar grid needs its islands (the poles are singular points of the coordinates)."""
 import math
@@ -38,29 +39,37 @@ def test_tripolar_geometry():
     m = make_oracle(Nx, Ny, 6, 600.0, grid_type="tripolar")
     g = lambda name, i, j: m.backend.metric2(name, i, j)
     az = np.array([[g("azcc", i, j) for j in range(1, Ny + 1)] for i in range(1, Nx + 1)])
-    assert az.sum() == pytest.approx(2 * math.pi * R * R * (1 + math.sin(math.radians(80))), rel=2e-5)
+    # Ny rows of cell centres from 80 S to 90 N (the fold pivots on the centres of row Ny), faces half a spacing south of
+    # them: the cells tile the sphere north of 80 S - dphi / 2, the pivot row's cells -- each held twice -- counted once
+    dphi = 170.0 / (Ny - 1)
+    tiled = az[:, :Ny - 1].sum() + 0.5 * az[:, Ny - 1].sum()
+    assert tiled == pytest.approx(2 * math.pi * R * R * (1 + math.sin(math.radians(80 + dphi / 2))), rel=2e-5)
     # south of the poles' latitude: the lat-lon grid (rows whose cells end below 55 N)
-    lat = make_oracle(Nx, Ny, 6, 600.0, lat_north=90.0)
-    dphi = 170.0 / Ny
+    dlam = math.radians(360.0 / Nx)
     for j in range(1, int((55 + 80) / dphi)):
-        assert g("phicc", 5, j) == pytest.approx(-80 + (j - 0.5) * dphi)
-        assert g("dycc", 5, j) == pytest.approx(lat.backend.metric2("dycc", 5, j), rel=1e-9)
-        assert g("azcc", 5, j) == pytest.approx(lat.backend.metric2("azcc", 5, j), rel=2e-3)   # (quadrilateral vs zone)
-    # symmetric under the fold: (i, Ny + q) is the image of (Nx - i + 1, Ny - q + 1); x faces mirror as i -> Nx - i + 2
+        phic = -80 + (j - 1) * dphi
+        assert g("phicc", 5, j) == pytest.approx(phic)
+        assert g("dycc", 5, j) == pytest.approx(R * math.radians(dphi), rel=1e-9)
+        zone = R * R * dlam * (math.sin(math.radians(phic + dphi / 2)) - math.sin(math.radians(phic - dphi / 2)))
+        assert g("azcc", 5, j) == pytest.approx(zone, rel=2e-3)   # (quadrilateral vs zone)
+    # symmetric under the fold: cell (i, Ny + q) is the image of (Nx - i + 1, Ny - q), y faces Ny + q of Ny - q + 1,
+    # x faces mirror as i -> Nx - i + 2 (metrics beyond the pivot row ARE those of their images)
     for i in range(1, Nx + 1):
         for q in (1, 2, 3):
-            assert g("azcc", i, Ny + q) == pytest.approx(g("azcc", Nx - i + 1, Ny - q + 1), rel=1e-12)
-            assert g("dycc", i, Ny + q) == pytest.approx(g("dycc", Nx - i + 1, Ny - q + 1), rel=1e-12)
+            assert g("azcc", i, Ny + q) == g("azcc", Nx - i + 1, Ny - q)
+            assert g("dycc", i, Ny + q) == g("dycc", Nx - i + 1, Ny - q)
+            assert g("dxcf", i, Ny + q) == g("dxcf", Nx - i + 1, Ny - q + 1)
         ip = Nx - i + 2 if i > 1 else 1
-        assert g("dyfc", i, Ny + 1) == pytest.approx(g("dyfc", ip, Ny), rel=1e-12)
-    # the y faces on the fold line are shared by a column and its image
+        assert g("dyfc", i, Ny + 1) == g("dyfc", ip, Ny - 1)
+    # the pivot row is held twice: cell (i, Ny) is cell (Nx - i + 1, Ny)
     for i in range(1, Nx + 1):
-        assert g("dxcf", i, Ny + 1) == pytest.approx(g("dxcf", Nx - i + 1, Ny + 1), rel=1e-12)
+        assert g("azcc", i, Ny) == pytest.approx(g("azcc", Nx - i + 1, Ny), rel=1e-9)
+        assert g("phicc", i, Ny) == pytest.approx(g("phicc", Nx - i + 1, Ny), abs=1e-9)
     # the coordinate lines meet at the two poles: the x faces 1 and Nx/2 + 1 of the cap rows (clamped metrics there)
     assert g("dyfc", 1, Ny) == 100.0 and g("dyfc", Nx // 2 + 1, Ny) == 100.0 and g("dyfc", 10, Ny) > 1e4
-    # rows bend north away from the poles: the top row runs from the poles' latitude to the symmetry meridian near 87 N
+    # the centres of the pivot row lie ON the fold line: from the poles' latitude up to the pole at the symmetry meridian
     top = np.array([g("phicc", i, Ny) for i in range(1, Nx + 1)])
-    assert 55 < top.min() < 60 and 86 < top.max() < 90
+    assert 55 < top.min() < 60 and 86 < top.max() <= 90
     assert top.argmax() in (Nx // 4 - 1, Nx // 4) or top.argmax() in (3 * Nx // 4 - 1, 3 * Nx // 4)
 
 
@@ -85,7 +94,7 @@ def test_bare_tripolar_grid_needs_its_islands():
     assert np.isfinite(m.velocities.u.interior).all() and np.abs(m.velocities.u.interior).max() < 2.0
 
 
-def test_fold_halos_and_pivot_antisymmetry():
+def test_fold_halos_and_the_pivot_row():
     Nx, Ny, Nz, H = 72, 36, 8, 8
     m = islands()
     gb.set_baroclinic_instability(m)
@@ -93,17 +102,24 @@ def test_fold_halos_and_pivot_antisymmetry():
     gb.first_time_step(m)
     gb.loop(m, 4)
     m.backend.fill_halo_regions()
-    T, u, v = (m.backend.get_field(n, True) for n in ("T", "u", "v"))
+    T, u, v, eta, U, V = (m.backend.get_field(n, True) for n in ("T", "u", "v", "eta", "U", "V"))
     ii = np.arange(Nx)
+    iu = (Nx - ii) % Nx                                    # x faces: i -> Nx - i + 2 (1-based), wrapping onto face 1
+    su = np.where(ii == 0, 1.0, -1.0)[:, None]             # ("for periodic elements we change the sign")
     for q in range(1, 4):
-        # cells: (i, Ny + q) <- (Nx - i + 1, Ny - q + 1); 0-based parent indices below
-        assert np.array_equal(T[H + ii, H + Ny - 1 + q, H:-H], T[H + Nx - 1 - ii, H + Ny - q, H:-H])
-        assert np.array_equal(u[H + ii, H + Ny - 1 + q, H:-H], -u[H + (Nx - ii) % Nx, H + Ny - q, H:-H])
-        assert np.array_equal(v[H + ii, H + Ny + q, H:-H], -v[H + Nx - 1 - ii, H + Ny - q, H:-H])
-    piv = v[H:H + Nx, H + Ny, H:-H]
-    assert np.array_equal(piv, -piv[::-1]) and np.abs(piv).max() > 0
-    V = m.backend.get_field("V", True)[H:H + Nx, H + Ny, 0]
-    assert np.array_equal(V, -V[::-1])
+        # cells: (i, Ny + q) <- (Nx - i + 1, Ny - q); y faces: (i, Ny + q) <- -(Nx - i + 1, Ny - q + 1); 0-based parents below
+        assert np.array_equal(T[H + ii, H + Ny - 1 + q, H:-H], T[H + Nx - 1 - ii, H + Ny - 1 - q, H:-H])
+        assert np.array_equal(u[H + ii, H + Ny - 1 + q, H:-H], su * u[H + iu, H + Ny - 1 - q, H:-H])
+        assert np.array_equal(v[H + ii, H + Ny - 1 + q, H:-H], -v[H + Nx - 1 - ii, H + Ny - q, H:-H])
+        assert np.array_equal(eta[H + ii, H + Ny - 1 + q, 0], eta[H + Nx - 1 - ii, H + Ny - 1 - q, 0])
+        assert np.array_equal(U[H + ii, H + Ny - 1 + q, 0], su[:, 0] * U[H + iu, H + Ny - 1 - q, 0])
+        assert np.array_equal(V[H + ii, H + Ny - 1 + q, 0], -V[H + Nx - 1 - ii, H + Ny - q, 0])
+    # the pivot row after a fill: the eastern copy is the image of the western one
+    piv = T[H:H + Nx, H + Ny - 1, H:-H]
+    assert np.array_equal(piv, piv[::-1]) and np.abs(piv).max() > 0
+    pu = u[H:H + Nx, H + Ny - 1, H:-H]
+    assert np.array_equal(pu[Nx // 2 + 1:], -pu[iu[Nx // 2 + 1:]])
+    assert np.abs(v[H:H + Nx, H + Ny - 1, H:-H]).max() > 0   # (the y faces of the pivot row are ordinary faces)
 
 
 def test_tracer_budget_closes_across_the_fold():
@@ -116,14 +132,16 @@ def test_tracer_budget_closes_across_the_fold():
     b = m.backend
     az = np.array([[b.metric2("azcc", i, j) for j in range(1, Ny + 1)] for i in range(1, Nx + 1)])
     dz = np.array([b.metric("dzc", k) for k in range(1, Nz + 1)])
-    V = az[:, :, None] * dz[None, None, :]
+    once = np.ones(Ny)
+    once[Ny - 1] = 0.5                 # the pivot row's cells are held twice: counted once
+    V = az[:, :, None] * dz[None, None, :] * once[None, :, None]
     G = m.timestepper.Gn.T.interior
     total = (V * G).sum()
     wtop = m.velocities.w.interior[:, :, Nz]
     Tp = m.tracers.T.parent
     H = 8
     c_in, c_halo = Tp[H:-H, H:-H, H + Nz - 1], Tp[H:-H, H:-H, H + Nz]
-    top_flux = (az * wtop * np.where(wtop > 0, c_in, c_halo)).sum()
+    top_flux = (az * once[None, :] * wtop * np.where(wtop > 0, c_in, c_halo)).sum()
     assert abs(total + top_flux) < 1e-11 * np.abs(V * G).sum()
     # a constant tracer has no tendency anywhere (continuity and advection see the same fluxes, across the fold too)
     kb = np.array([[b.bottom_info("kbot", i, j) for j in range(1, Ny + 1)] for i in range(1, Nx + 1)], int)
@@ -159,5 +177,5 @@ def test_first_step_is_mirror_symmetric_away_from_the_mountains():
     far = np.zeros(Nx, bool)
     far[9:28] = far[45:64] = True                  # >= 9 columns (45 degrees) from both mountain meridians
     assert np.abs(Gv - Gv[::-1])[far].max() < 1e-12 * np.abs(Gv).max()
-    assert np.abs(Gv[far][:, Ny - 3:Ny + 1]).max() > 0          # ... including the rows next to and on the fold line
+    assert np.abs(Gv[far][:, Ny - 3:Ny]).max() > 0          # ... including the rows next to the fold
     # (after a step the sub-cycle has carried the mountains' asymmetry 21 columns far: nothing sharp left to check)
