@@ -785,6 +785,7 @@ Halo2 halo2_G(gb25_model* m) {   // the barotropic forcing G.U, G.V
   h.p[0] = m->f[GB25_GN_BT_U].d; h.is_v[0] = 0; h.xf[0] = 1; h.neg[0] = 1;
   h.p[1] = m->f[GB25_GN_BT_V].d; h.is_v[1] = 1; h.neg[1] = 1;
   h.n = 2;
+  h.nopivot = 1;
   return h;
 }
 // the single-domain producers write the halo cells derived from their output themselves (option FOLD_FILLS) -- not across
@@ -2137,10 +2138,13 @@ gb25_status gb25_field_dims(const gb25_model* m, gb25_field id, int include_halo
   const Field& F = m->f[id];
   if (!F.d) return GB25_ERR_INVALID_ARGUMENT;   // (a field of CATKE on a model whose closure is not CATKE)
   const int H = m->cfg.halo;
+  // A y-face field of a folded grid has Ny rows ((Periodic, RightConnected, Bounded): the faces beyond the last row of cells are
+  // halo cells), so its parent has Ny + 2H rows like a cell-centred one; the device arrays keep the row a Bounded grid needs.
+  const int ny = F.ny - ((m->g.cv.north_fold && is_v_shaped(id)) ? 1 : 0);
   if (include_halos) {
-    d[0] = F.nx; d[1] = F.ny; d[2] = F.nz;
+    d[0] = F.nx; d[1] = ny; d[2] = F.nz;
   } else {
-    d[0] = F.nx - 2 * H; d[1] = F.ny - 2 * H; d[2] = is_2d(id) ? 1 : F.nz - 2 * H;
+    d[0] = F.nx - 2 * H; d[1] = ny - 2 * H; d[2] = is_2d(id) ? 1 : F.nz - 2 * H;
   }
   return GB25_OK;
 }
@@ -2158,14 +2162,14 @@ static gb25_status copy_field(gb25_model* m, gb25_field id, real* host, int incl
     if (m->baro_stream) HIPCHK(hipStreamSynchronize(m->baro_stream));
     if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
   }
-  if (include_halos) {
+  int32_t d[3];
+  gb25_field_dims(m, id, include_halos, d);
+  if (include_halos && d[1] == F.ny) {
     if (to_device) HIPCHK(hipMemcpy(F.d, host, F.elems() * sizeof(real), hipMemcpyHostToDevice));
     else HIPCHK(hipMemcpy(host, F.d, F.elems() * sizeof(real), hipMemcpyDeviceToHost));
     return GB25_OK;
   }
-  const int H = m->cfg.halo;
-  int32_t d[3];
-  gb25_field_dims(m, id, 0, d);
+  const int H = include_halos ? 0 : m->cfg.halo;
   hipMemcpy3DParms p = {};
   hipPitchedPtr dev = make_hipPitchedPtr(F.d, (size_t)F.nx * sizeof(real), F.nx, F.ny);
   hipPitchedPtr hst = make_hipPitchedPtr(host, (size_t)d[0] * sizeof(real), d[0], d[1]);
@@ -2454,7 +2458,9 @@ gb25_status gb25_set_top_flux(gb25_model* m, gb25_field f, const void* host) {
     HIPCHK(hipMalloc(&m->d_top_flux[q], n2 * sizeof(real)));
     HIPCHK(hipMemset(m->d_top_flux[q], 0, n2 * sizeof(real)));
   }
-  const int H = m->cfg.halo, nxi = F.nx - 2 * H, nyi = F.ny - 2 * H;
+  int32_t di[3];
+  gb25_field_dims(m, f, 0, di);   // (the interior of the field's horizontal location: Ny rows of y faces on a folded grid)
+  const int H = m->cfg.halo, nxi = di[0], nyi = di[1];
   HIPCHK(hipMemcpy2D(m->d_top_flux[q] + (size_t)H * F.nx + H, (size_t)F.nx * sizeof(real), host, (size_t)nxi * sizeof(real),
                      (size_t)nxi * sizeof(real), nyi, hipMemcpyHostToDevice));
   m->g.top_flux[q] = m->d_top_flux[q];
@@ -2506,7 +2512,9 @@ gb25_status gb25_get_top_flux(gb25_model* m, gb25_field f, void* host) {
   if (!m->g.top_flux[q]) return fail(m, GB25_ERR_STATE, "no top flux boundary condition is set for this field");
   HIPCHK(hipStreamSynchronize(m->stream));
   const Field& F = m->f[f];
-  const int H = m->cfg.halo, nxi = F.nx - 2 * H, nyi = F.ny - 2 * H;
+  int32_t di[3];
+  gb25_field_dims(m, f, 0, di);
+  const int H = m->cfg.halo, nxi = di[0], nyi = di[1];
   HIPCHK(hipMemcpy2D(host, (size_t)nxi * sizeof(real), m->g.top_flux[q] + (size_t)H * F.nx + H, (size_t)F.nx * sizeof(real),
                      (size_t)nxi * sizeof(real), nyi, hipMemcpyDeviceToHost));
   return GB25_OK;

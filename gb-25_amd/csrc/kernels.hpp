@@ -53,6 +53,7 @@ struct Halo2 {
   int is_v[3];
   int n;
   int xf[3], neg[3];
+  int nopivot;   // zipper fold: leave the pivot row's eastern copy alone
 };
 
 // south/north layer of the four 3-D fields + all 2-D fields over columns [i0, i0+ni).
@@ -163,7 +164,8 @@ __global__ void k_fill_fold(Grid g, Halo3 f3, Halo2 f2) {
   for (int f = 0; f < n; f++) {
     real* c = twod ? f2.p[f] : f3.p[f];
     const bool is_v = twod ? f2.is_v[f] : f3.is_v[f], xf = twod ? f2.xf[f] : f3.xf[f], neg = twod ? f2.neg[f] : f3.neg[f];
-    if (q == 0 && (is_v || !fold_pivot_slave(i, g.Nx, xf))) continue;
+    // (the forcing G.U, G.V keeps both copies of the pivot row as they were computed: nopivot)
+    if (q == 0 && (is_v || (twod && f2.nopivot) || !fold_pivot_slave(i, g.Nx, xf))) continue;
     const int isrc = fold_src_column(i, g.Nx, xf);
     const real sg = fold_sign(i, xf, neg);
     const int jd = g.Ny - 1 + q, js = is_v ? g.Ny - q : g.Ny - 1 - q;

@@ -251,7 +251,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     if (g.cv.north_fold && !second_half) return GB25_OK;
     if (ahead) {
       if ((s = barotropic_impl(m, m->ahead_uv_dt, true))) return s;
-      Halo2 h2;
+      Halo2 h2{};
       for (int q = 0; q < 3; q++) { h2.p[q] = m->ahead_eta[q].d; h2.is_v[q] = q == 2; }
       h2.n = 3;
       // y layer, x halo columns included: the widened sub-cycle computed those like the neighbour did (no group 4)

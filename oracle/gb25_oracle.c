@@ -533,9 +533,13 @@ void FN(destroy)(void *h) {
   free(m);
 }
 REAL *FN(field_ptr)(void *h, int id) { return ((model *)h)->f[id].p; }
+/* d[0..2]: the parent dims; d[3]: rows per plane in memory.  A y-face field of a folded grid has Ny rows -- the faces beyond
+ * the last row of cells are halo cells -- so its parent has Ny + 2H rows; the arrays keep the row a Bounded grid needs. */
 void FN(field_dims)(void *h, int id, int *d) {
   model *m = (model *)h;
-  d[0] = m->f[id].sx; d[1] = m->f[id].sy; d[2] = m->f[id].sz;
+  const int vshaped = m->f[id].sy == m->Ny + 2 * m->H + 1;
+  d[0] = m->f[id].sx; d[1] = m->f[id].sy - ((m->north_fold && vshaped) ? 1 : 0); d[2] = m->f[id].sz;
+  d[3] = m->f[id].sy;
 }
 /* metric id: 0 phif 1 phic 2 dxc 3 dxf 4 azc 5 azf 6 fcor 7 zf 8 zc 9 dzc 10 dzf; value at logical index */
 double FN(metric)(void *h, int id, int idx) {
@@ -896,6 +900,7 @@ static inline REAL fold_sign(const model *m, int i, int xface, REAL sgn) {
 }
 static void fold_rows_levels(model *m, int id, int twod, int is_v, int xface, REAL sgn, int nlev) {
   int Nx = m->Nx, Ny = m->Ny, H = m->H, k0 = 1, k1 = twod ? 1 : nlev;
+  const int pivot = !(id == F_GBU || id == F_GBV);   /* (the forcing G.U, G.V keeps both copies of the pivot row as computed) */
   for (int k = k0; k <= k1; k++) {
     REAL *base = twod ? m->f[id].p : m->f[id].p + (long)m->f[id].sx * m->f[id].sy * (k - 1 + H);
 #define AF(i, j) base[((long)(i)-1 + H) + (long)m->f[id].sx * ((long)(j)-1 + H)]
@@ -903,7 +908,7 @@ static void fold_rows_levels(model *m, int id, int twod, int is_v, int xface, RE
       for (int q = 1; q <= H; q++)
         for (int i = 1; i <= Nx; i++) AF(i, Ny + q) = sgn * AF(fold_i(m, i, 0), Ny + 1 - q);
     } else {
-      for (int i = Nx / 2 + 1; i <= Nx; i++) {   /* the pivot row: the eastern copy <- the image of the western one */
+      for (int i = Nx / 2 + 1; pivot && i <= Nx; i++) {   /* the pivot row: the eastern copy <- the image of the western one */
         const int ip = fold_i(m, i, xface);
         if (ip != i) AF(i, Ny) = fold_sign(m, i, xface, sgn) * AF(ip, Ny);
       }
@@ -1178,7 +1183,7 @@ void FN(set_top_flux)(void *h, int q, const double *J) {
   if (!J) return;
   const fld *F = &m->f[gid[q]];
   m->top_flux[q] = (REAL *)calloc((size_t)F->sx * F->sy, sizeof(REAL));
-  int ny = m->Ny + (q == 1 ? 1 : 0);
+  int ny = m->Ny + ((q == 1 && !m->north_fold) ? 1 : 0);
   for (int j = 1; j <= ny; j++)
     for (int i = 1; i <= m->Nx; i++)
       m->top_flux[q][((long)i - 1 + HH) + (long)F->sx * ((long)j - 1 + HH)] = (REAL)J[(i - 1) + (long)m->Nx * (j - 1)];
@@ -1187,7 +1192,7 @@ void FN(get_top_flux)(void *h, int q, double *J) {
   model *m = (model *)h;
   const int gid[4] = {F_GNU, F_GNV, F_GNT, F_GNS};
   const fld *F = &m->f[gid[q]];
-  int ny = m->Ny + (q == 1 ? 1 : 0);
+  int ny = m->Ny + ((q == 1 && !m->north_fold) ? 1 : 0);
   for (int j = 1; j <= ny; j++)
     for (int i = 1; i <= m->Nx; i++)
       J[(i - 1) + (long)m->Nx * (j - 1)] = m->top_flux[q] ? (double)m->top_flux[q][((long)i - 1 + HH) + (long)F->sx * ((long)j - 1 + HH)] : 0.0;

@@ -119,10 +119,10 @@ class OracleBackend:
 
     # ---- fields
     def _view(self, name):
-        d = (C.c_int * 3)()
+        d = (C.c_int * 4)()
         self._fn("field_dims")(self.h, FIELD_IDS[name], d)
         p = self._fn("field_ptr")(self.h, FIELD_IDS[name])
-        a = np.ctypeslib.as_array(p, shape=(d[2], d[1], d[0]))
+        a = np.ctypeslib.as_array(p, shape=(d[2], d[3], d[0]))[:, :d[1], :]   # (a y-face field of a folded grid: Ny + 2H of its rows)
         return a.transpose(2, 1, 0)  # [i, j, k] view of the oracle's memory
 
     def field_dims(self, name, include_halos=True):
