@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
   }
 }
 // TripolarGrid: the rows beyond the zipper fold of the diffusivity fields and of J^b (cell-centred in x and y, no sign
-// change): (i, Ny-1+q) <- (Nx-1-i, Ny-1-q), q = 1 .. H (q = 0: the pivot row's eastern copy <- its western image: k_fill_fold), over
+// change): (i, Ny-1+q) <- (Nx-1-i, Ny-1-q), q = 1 .. H, over
 // every parent column (source column wrapped periodically), which
 // replaces the zero-gradient northern layer k_catke_diffusivities wrote.  blockIdx.z: face levels 0 .. Nz of the three
 // kappa, levels -1 .. Nz of L^e (its bottom / top layer on those rows), then J^b.
@@ -189,9 +189,8 @@ __global__ void k_catke_fold(Grid g, real* __restrict__ KU, real* __restrict__ K
                              real* __restrict__ Le, real* __restrict__ Jb) {
   const int ip = blockIdx.x * blockDim.x + threadIdx.x;
   if (ip >= g.sx) return;
-  const int i = ip - g.H, q = blockIdx.y, z = blockIdx.z, Nz = g.Nz;   // q = 0: the pivot row's eastern copy <- its image
+  const int i = ip - g.H, q = blockIdx.y + 1, z = blockIdx.z, Nz = g.Nz;
   const int iw = ((i % g.Nx) + g.Nx) % g.Nx, isrc = g.Nx - 1 - iw;
-  if (q == 0 && !fold_pivot_slave(iw, g.Nx, false)) return;
   const int jd = g.Ny - 1 + q, js = g.Ny - 1 - q;
   if (z <= Nz) {
     const int od = ic(g, i, jd, z), os = ic(g, isrc, js, z);

@@ -785,7 +785,6 @@ Halo2 halo2_G(gb25_model* m) {   // the barotropic forcing G.U, G.V
   h.p[0] = m->f[GB25_GN_BT_U].d; h.is_v[0] = 0; h.xf[0] = 1; h.neg[0] = 1;
   h.p[1] = m->f[GB25_GN_BT_V].d; h.is_v[1] = 1; h.neg[1] = 1;
   h.n = 2;
-  h.nopivot = 1;
   return h;
 }
 // the single-domain producers write the halo cells derived from their output themselves (option FOLD_FILLS) -- not across
@@ -817,7 +816,7 @@ gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, i
     if (which == 2) return fill_halos_2d(m, h2);
     if (which == 1) h2.n = 0;
     hipLaunchKernelGGL(k_fill_yz, dim3((g.Nx + 255) / 256, g.Nz + 1 + g.Ny), b, 0, st, g, h3, h2, 0, g.Nx);
-    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H + 1, g.Nz + 2 + (h2.n ? 1 : 0)), b, 0, st, g, h3, h2);
+    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H, g.Nz + 2 + (h2.n ? 1 : 0)), b, 0, st, g, h3, h2);
     const int rows_c = g.sy_c * (g.Nz + 2 * g.H), rows_v = g.sy_v * (g.Nz + 2 * g.H);
     hipLaunchKernelGGL(k_fill_x, dim3((unsigned)(((long)rows_v * 2 * g.H + 255) / 256), 4 + h2.n), b, 0, st, g, h3, h2,
                        rows_c, rows_v);
@@ -862,7 +861,7 @@ gb25_status fill_halos_2d(gb25_model* m, Halo2 h2) {
   g2.Nz = 0;
   hipLaunchKernelGGL(k_fill_y, dim3((g.Nx + 255) / 256, 1), b, 0, m->stream, g2, none, h2, 0, g.Nx);
   if (g.cv.north_fold && !m->slab)   // (a slab's rows beyond the fold come from its partner rank: slab_step.hpp)
-    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H + 1, 1), b, 0, m->stream, g, none, h2);
+    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H, 1), b, 0, m->stream, g, none, h2);
   if (g.x_periodic) {
     long threads = (long)g.sy_v * 2 * g.H;
     hipLaunchKernelGGL(k_fill_x, dim3((unsigned)((threads + 255) / 256), 4 + h2.n), b, 0, m->stream, g2, none, h2, 0,
@@ -1561,7 +1560,7 @@ gb25_status catke_update_impl(gb25_model* m) {
                      m->f[GB25_E].d, m->catke_b.d, m->f[GB25_JB].d, m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d,
                      m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_GN_E].d, i_lo, j_hi);
   if (g.cv.north_fold && !m->slab)   // the rows beyond the zipper
-    hipLaunchKernelGGL(k_catke_fold, dim3((g.sx + 255) / 256, g.H + 1, g.Nz + 3), dim3(256), 0, m->stream, g,
+    hipLaunchKernelGGL(k_catke_fold, dim3((g.sx + 255) / 256, g.H, g.Nz + 3), dim3(256), 0, m->stream, g,
                        m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_JB].d);
   LAUNCHCHK();
   return GB25_OK;

@@ -53,7 +53,6 @@ struct Halo2 {
   int is_v[3];
   int n;
   int xf[3], neg[3];
-  int nopivot;   // zipper fold: leave the pivot row's eastern copy alone
 };
 
 // south/north layer of the four 3-D fields + all 2-D fields over columns [i0, i0+ni).
@@ -145,27 +144,24 @@ __global__ void k_fill_x(Grid g, Halo3 f3, Halo2 f2, int rows_c, int rows_v) {
 //   cell (i, Ny-1+q)   <-  s  cell (Nx-1-i, Ny-1-q)          x face (i, Ny-1+q)  <-  s' x face ((Nx-i) mod Nx, Ny-1-q)
 //   y face (i, Ny-1+q) <-  s  y face (Nx-1-i, Ny-q)          q = 1..H;  s = -1 for vector components; s' = s except on the
 //                                                            x face that wraps (i = 0), which keeps its sign
-// Row Ny-1 is held twice -- cell (i, Ny-1) IS cell (Nx-1-i, Ny-1) -- and both copies are stepped; the copy in the eastern
-// half is overwritten with the image of the western one here (q = 0; the x face that is its own image is left alone).
+// Row Ny-1 is held twice -- cell (i, Ny-1) IS cell (Nx-1-i, Ny-1) ("the Ny line is duplicated") -- and both copies are
+// stepped; neither is overwritten with the other (as the fill functions of v0.96 are recalled; a later upstream fix that
+// slaves one copy to the other is NOT restated: it would need the partner's pivot row BEFORE the barotropic corrector).
 // The bottom / top layer of the rows written is filled too (the hydrostatic integral of the rows beyond the fold starts in the
 // top halo level).  Reads interior rows and levels only: independent of the y / z fill, before the periodic x copy.
 __device__ __forceinline__ int fold_src_column(int ig, int Nxg, bool xface) { return xface ? (ig == 0 ? 0 : Nxg - ig) : Nxg - 1 - ig; }
 __device__ __forceinline__ real fold_sign(int ig, bool xface, bool neg) { return (neg && !(xface && ig == 0)) ? -real(1.) : real(1.); }
-// does the fill overwrite (ig, row Ny-1) with its image?  the eastern half, except the face that maps onto itself
-__device__ __forceinline__ bool fold_pivot_slave(int ig, int Nxg, bool xface) { return xface ? 2 * ig > Nxg : 2 * ig >= Nxg; }
-// grid: (ceil(Nx/256), H + 1, Nz + 2 | 1); blockIdx.y = q; blockIdx.z = level + 1 of the 3-D fields, the last slice does the 2-D fields
+// grid: (ceil(Nx/256), H, Nz + 2 | 1); blockIdx.y = q - 1; blockIdx.z = level + 1 of the 3-D fields, the last slice does the 2-D fields
 __global__ void k_fill_fold(Grid g, Halo3 f3, Halo2 f2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.Nx) return;
-  const int q = blockIdx.y;   // 0 .. H
+  const int q = blockIdx.y + 1;   // 1 .. H
   const bool twod = (int)blockIdx.z == (f3.n ? g.Nz + 2 : 0);
   const int k = (int)blockIdx.z - 1, ks = min(max(k, 0), g.Nz - 1);
   const int n = twod ? f2.n : f3.n;
   for (int f = 0; f < n; f++) {
     real* c = twod ? f2.p[f] : f3.p[f];
     const bool is_v = twod ? f2.is_v[f] : f3.is_v[f], xf = twod ? f2.xf[f] : f3.xf[f], neg = twod ? f2.neg[f] : f3.neg[f];
-    // (the forcing G.U, G.V keeps both copies of the pivot row as they were computed: nopivot)
-    if (q == 0 && (is_v || (twod && f2.nopivot) || !fold_pivot_slave(i, g.Nx, xf))) continue;
     const int isrc = fold_src_column(i, g.Nx, xf);
     const real sg = fold_sign(i, xf, neg);
     const int jd = g.Ny - 1 + q, js = is_v ? g.Ny - q : g.Ny - 1 - q;
@@ -176,30 +172,30 @@ __global__ void k_fill_fold(Grid g, Halo3 f3, Halo2 f2) {
 }
 
 // The same fold on a slab of a decomposition: the cells beyond the fold are the images of cells of the PARTNER rank
-// P-1-r (mirrored in x), which sends its pivot row and the H rows south of it -- all its parent columns, every interior
-// level -- and receives ours.  Buffer layout per field: [level][q][parent column], q = 0 .. H: cell rows Ny-1-q, y-face rows
-// Ny-q (q = 0 unused for them); 3-D fields first, then the 2-D ones.
+// P-1-r (mirrored in x), which sends the H rows south of its pivot row -- all its parent columns, every interior level --
+// and receives ours.  Buffer layout per field: [level][q - 1][parent column], q = 1 .. H: cell rows Ny-1-q, y-face rows
+// Ny-q; 3-D fields first, then the 2-D ones.
 struct FoldFields {
   real* p[9];
   int is_v[9], xf[9], neg[9], nz[9];   // nz: interior levels (1: a 2-D field)
   long off[9];                          // element offset of the field in the exchange buffer
   int n;
 };
-// grid: (ceil(sx/256), H + 1, sum of nz)
+// grid: (ceil(sx/256), H, sum of nz)
 __global__ void k_fold_pack(Grid g, FoldFields F, real* __restrict__ buf) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y + 1;
   if (a >= g.sx) return;
   int f = 0, k = blockIdx.z;
   while (k >= F.nz[f]) k -= F.nz[f++];
   const bool twod = F.nz[f] == 1;
   const int row = (F.is_v[f] ? g.Ny - q : g.Ny - 1 - q) + g.H;
   const long pl = F.is_v[f] ? g.pl_v : g.pl_c;
-  buf[F.off[f] + ((long)k * (g.H + 1) + q) * g.sx + a] = F.p[f][a + (long)g.sx * row + (twod ? 0 : pl * (k + g.H))];
+  buf[F.off[f] + ((long)k * g.H + (q - 1)) * g.sx + a] = F.p[f][a + (long)g.sx * row + (twod ? 0 : pl * (k + g.H))];
 }
-// grid: (ceil(sx/256), H + 1, sum of (nz + 2 | 1)): the 3-D fields also get the bottom / top layer of the rows written.
-// ig0: global column of local column 0; Nxg: global Nx (which half of the pivot row a column is in; the x face that wraps).
+// grid: (ceil(sx/256), H, sum of (nz + 2 | 1)): the 3-D fields also get the bottom / top layer of the rows written.
+// ig0: global column of local column 0; Nxg: global Nx (the x face that wraps keeps its sign).
 __global__ void k_fold_unpack(Grid g, FoldFields F, const real* __restrict__ buf, int ig0, int Nxg) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y + 1;
   if (a >= g.sx) return;
   int f = 0, kk = blockIdx.z;
   while (kk >= (F.nz[f] == 1 ? 1 : F.nz[f] + 2)) kk -= (F.nz[f] == 1 ? 1 : F.nz[f] + 2), f++;
@@ -209,11 +205,10 @@ __global__ void k_fold_unpack(Grid g, FoldFields F, const real* __restrict__ buf
   if (am >= g.sx) return;                                   // (the westernmost x face of the halo: never read)
   int ig = ig0 + a - g.H;
   ig = ((ig % Nxg) + Nxg) % Nxg;
-  if (q == 0 && (is_v || !fold_pivot_slave(ig, Nxg, xf))) return;
   const real sg = fold_sign(ig, xf, F.neg[f] != 0);
   const long pl = is_v ? g.pl_v : g.pl_c;
   const int jd = g.Ny - 1 + q + g.H;                        // destination parent row
-  F.p[f][a + (long)g.sx * jd + (twod ? 0 : pl * (k + g.H))] = sg * buf[F.off[f] + ((long)ks * (g.H + 1) + q) * g.sx + am];
+  F.p[f][a + (long)g.sx * jd + (twod ? 0 : pl * (k + g.H))] = sg * buf[F.off[f] + ((long)ks * g.H + (q - 1)) * g.sx + am];
 }
 
 // The split-explicit sub-cycle on a folded grid runs on TALL arrays: the barotropic work arrays (widened in x on a slab) with

@@ -128,7 +128,7 @@ gb25_status pack_unpack(gb25_model* m, int group, real* const buf[2], bool pack)
 }
 
 // ---- zipper fold of a decomposed tripolar grid: the partner rank P-1-r holds the cells beyond this slab's fold line -----
-// buffer set 3: the pivot row and the H rows south of it of u, v, T, S (CATKE: e, J^b too) and eta, U, V (all parent
+// buffer set 3: the H rows south of the pivot row of u, v, T, S (CATKE: e, J^b too) and eta, U, V (all parent
 // columns, interior levels);
 // buffer set 4: the Wy (+1) rows south of the pivot row of the sub-cycle's work arrays eta, U, V, G.U, G.V (TallRows, kernels.hpp)
 FoldFields fold_fields(gb25_model* m) {
@@ -138,7 +138,7 @@ FoldFields fold_fields(gb25_model* m) {
   auto add = [&](real* p, int is_v, int xf, int neg, int nz) {
     const int f = F.n++;
     F.p[f] = p; F.is_v[f] = is_v; F.xf[f] = xf; F.neg[f] = neg; F.nz[f] = nz; F.off[f] = off;
-    off += (long)nz * (g.H + 1) * g.sx;
+    off += (long)nz * g.H * g.sx;
   };
   add(m->f[GB25_U].d, 0, 1, 1, g.Nz);
   add(m->f[GB25_V].d, 1, 0, 1, g.Nz);
@@ -161,19 +161,19 @@ int fold_levels(const FoldFields& F, bool with_layers) {   // blockIdx.z extent 
 int64_t fold_buffer_elems(gb25_model* m, int b) {
   const Grid& g = m->g;
   if (!g.cv.north_fold) return 1;
-  return b == 3 ? (int64_t)(g.H + 1) * g.sx * fold_levels(fold_fields(m), false) : tall_buffer_elems(m);
+  return b == 3 ? (int64_t)g.H * g.sx * fold_levels(fold_fields(m), false) : tall_buffer_elems(m);
 }
 gb25_status fold_pack(gb25_model* m, real* buf) {
   const Grid& g = m->g;
   FoldFields F = fold_fields(m);
-  hipLaunchKernelGGL(k_fold_pack, dim3((g.sx + 255) / 256, g.H + 1, fold_levels(F, false)), dim3(256), 0, m->stream, g, F, buf);
+  hipLaunchKernelGGL(k_fold_pack, dim3((g.sx + 255) / 256, g.H, fold_levels(F, false)), dim3(256), 0, m->stream, g, F, buf);
   LAUNCHCHK();
   return GB25_OK;
 }
 gb25_status fold_unpack(gb25_model* m, const real* buf) {
   const Grid& g = m->g;
   FoldFields F = fold_fields(m);
-  hipLaunchKernelGGL(k_fold_unpack, dim3((g.sx + 255) / 256, g.H + 1, fold_levels(F, true)), dim3(256), 0, m->stream, g, F, buf,
+  hipLaunchKernelGGL(k_fold_unpack, dim3((g.sx + 255) / 256, g.H, fold_levels(F, true)), dim3(256), 0, m->stream, g, F, buf,
                      m->cfg.rank * m->Nx, m->cfg.Nx);
   LAUNCHCHK();
   return GB25_OK;

@@ -33,6 +33,13 @@ class Field:
 
     def set(self, array, include_halos=False):
         a = np.asarray(array)
+        if not include_halos and a.ndim >= 2:
+            # A y-face field of a folded (tripolar) grid has Ny rows -- topology (Periodic, RightConnected, Bounded): the
+            # faces beyond the last row of cells are halo cells.  An array shaped for a Bounded y (Ny + 1 rows) is
+            # accepted and its last row, which the fold fill would overwrite anyway, is dropped.
+            want = self._b.field_dims(self.name, False)
+            if a.shape[0] == want[0] and a.shape[1] == want[1] + 1:
+                a = np.ascontiguousarray(a[:, :want[1]])
         self._b.set_field(self.name, a, include_halos)
 
     def set_parent(self, array):

@@ -888,8 +888,8 @@ static void fill_periodic_x(const model *m, fld *F) {
  *   (c,f):  c[i, Ny+j] = s c[Nx-i+1, Ny-j+1]          where i' > Nx wraps to i' - Nx and takes s' = |s| ("for periodic
  *                                                      elements we change the sign"), s' = s otherwise,
  * j = 1..H, s = -1 for vector components.  Row Ny itself is held twice -- cell (i, Ny) IS cell (Nx-i+1, Ny) -- and both
- * copies are stepped; the copy in the eastern half is overwritten with the image of the western one at every fill
- * (restatement choice: keeps the two consistent; the x face that is its own image is left alone). */
+ * copies are stepped; neither is overwritten with the other (as the fill functions of v0.96 are recalled; a later upstream
+ * fix that slaves one copy to the other is not restated). */
 static inline int fold_i(const model *m, int i, int xface) {
   int ip = xface ? m->Nx - i + 2 : m->Nx - i + 1;
   if (ip > m->Nx) ip -= m->Nx;
@@ -900,7 +900,6 @@ static inline REAL fold_sign(const model *m, int i, int xface, REAL sgn) {
 }
 static void fold_rows_levels(model *m, int id, int twod, int is_v, int xface, REAL sgn, int nlev) {
   int Nx = m->Nx, Ny = m->Ny, H = m->H, k0 = 1, k1 = twod ? 1 : nlev;
-  const int pivot = !(id == F_GBU || id == F_GBV);   /* (the forcing G.U, G.V keeps both copies of the pivot row as computed) */
   for (int k = k0; k <= k1; k++) {
     REAL *base = twod ? m->f[id].p : m->f[id].p + (long)m->f[id].sx * m->f[id].sy * (k - 1 + H);
 #define AF(i, j) base[((long)(i)-1 + H) + (long)m->f[id].sx * ((long)(j)-1 + H)]
@@ -908,10 +907,6 @@ static void fold_rows_levels(model *m, int id, int twod, int is_v, int xface, RE
       for (int q = 1; q <= H; q++)
         for (int i = 1; i <= Nx; i++) AF(i, Ny + q) = sgn * AF(fold_i(m, i, 0), Ny + 1 - q);
     } else {
-      for (int i = Nx / 2 + 1; pivot && i <= Nx; i++) {   /* the pivot row: the eastern copy <- the image of the western one */
-        const int ip = fold_i(m, i, xface);
-        if (ip != i) AF(i, Ny) = fold_sign(m, i, xface, sgn) * AF(ip, Ny);
-      }
       for (int q = 1; q <= H; q++)
         for (int i = 1; i <= Nx; i++) AF(i, Ny + q) = fold_sign(m, i, xface, sgn) * AF(fold_i(m, i, xface), Ny - q);
     }

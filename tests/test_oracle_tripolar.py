@@ -6,7 +6,7 @@ construction of this repository's own; topology, pole positions, fold and metric
  * geometry: the cells tile the sphere north of 80 S, the poles sit at (70 E, 55 N) and (250 E, 55 N) on x faces 1 and
    Nx/2+1, metrics are symmetric under the fold, the grid is the lat-lon grid south of 55 N;
  * the fold pivots on the centres of row Ny (Oceananigans' convention): halo rows are the (signed) images, the pivot row is
-   held twice and kept consistent by the fill;
+   held twice (both copies stepped);
  * conservation across the fold, rest state, mirror symmetry of the first tendencies away from the mountains;
  * the bare tripolar grid needs its islands (the poles are singular points of the coordinates)."""
 import math
@@ -114,11 +114,10 @@ def test_fold_halos_and_the_pivot_row():
         assert np.array_equal(eta[H + ii, H + Ny - 1 + q, 0], eta[H + Nx - 1 - ii, H + Ny - 1 - q, 0])
         assert np.array_equal(U[H + ii, H + Ny - 1 + q, 0], su[:, 0] * U[H + iu, H + Ny - 1 - q, 0])
         assert np.array_equal(V[H + ii, H + Ny - 1 + q, 0], -V[H + Nx - 1 - ii, H + Ny - q, 0])
-    # the pivot row after a fill: the eastern copy is the image of the western one
+    # the pivot row is held twice and both copies are stepped: started from a state that is a function of position (and
+    # noise, which is not) the two stay close but are not slaved to each other
     piv = T[H:H + Nx, H + Ny - 1, H:-H]
-    assert np.array_equal(piv, piv[::-1]) and np.abs(piv).max() > 0
-    pu = u[H:H + Nx, H + Ny - 1, H:-H]
-    assert np.array_equal(pu[Nx // 2 + 1:], -pu[iu[Nx // 2 + 1:]])
+    assert np.abs(piv).max() > 0 and np.abs(piv - piv[::-1]).max() < 1e-2 * np.abs(piv).max()
     assert np.abs(v[H:H + Nx, H + Ny - 1, H:-H]).max() > 0   # (the y faces of the pivot row are ordinary faces)
 
 
@@ -127,7 +126,11 @@ def test_tracer_budget_closes_across_the_fold():
     m = islands(dt=10.0)
     set_noisy_velocities(m, amplitude=0.1)
     rng = np.random.default_rng(1)
-    m.set(T=10 + rng.random((Nx, Ny, Nz)), S=35 + 0 * rng.random((Nx, Ny, Nz)))
+    T0 = 10 + rng.random((Nx, Ny, Nz))
+    T0[:, Ny - 1] = 0.5 * (T0[:, Ny - 1] + T0[::-1, Ny - 1])   # the pivot row's two copies of a cell hold the same value
+    u0, v0 = m.velocities.u.interior, m.velocities.v.interior
+    u0[Nx // 2 + 1:, Ny - 1] = -u0[(Nx - np.arange(Nx // 2 + 1, Nx)) % Nx, Ny - 1]
+    m.set(T=T0, S=35 + 0 * rng.random((Nx, Ny, Nz)), u=u0)
     gb.update_state(m)
     b = m.backend
     az = np.array([[b.metric2("azcc", i, j) for j in range(1, Ny + 1)] for i in range(1, Nx + 1)])

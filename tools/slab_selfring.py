@@ -13,11 +13,13 @@ ap.add_argument("--size", type=int, nargs=2, default=[720, 48], metavar=("Ny", "
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--dt", type=float, default=240.0)
 ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--grid-type", type=int, default=0, help="gb25_grid_type: 0 lat-lon, 1 lat-lon + islands, 3 tripolar, 4 tripolar + islands (the rank is then its own fold partner too)")
 a = ap.parse_args()
 import numpy as np
 import gb25_amd as gb
 from gb25_amd.distributed import SlabModel
-m = SlabModel(a.columns, a.size[0], a.size[1], dt=a.dt, rank=0, nranks=1, slab_mode=1, transport="rccl")
+m = SlabModel(a.columns, a.size[0], a.size[1], dt=a.dt, rank=0, nranks=1, slab_mode=1, transport="rccl",
+              **(dict(grid_type=a.grid_type) if a.grid_type else {}))
 for kv in a.opt:
     k, v = kv.split("=")
     m.backend.set_option(k, int(v))
@@ -29,4 +31,4 @@ t0 = time.perf_counter()
 gb.loop(m, a.steps)
 m.backend.synchronize()
 t = (time.perf_counter() - t0) / a.steps
-print(f"{a.columns} columns x {a.size[0]} x {a.size[1]}: {1e3 * t:.3f} ms per step ({1 / t:.0f} steps/s per rank)", flush=True)
+print(f"{a.columns} columns x {a.size[0]} x {a.size[1]} grid_type {a.grid_type}: {1e3 * t:.3f} ms per step ({1 / t:.0f} steps/s per rank)", flush=True)
