@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "gb25_compute_momentum_tendencies", "gb25_compute_tracer_tendencies", "gb25_compute_boundary_tendencies",
     "gb25_compute_tendencies", "gb25_ab2_step", "gb25_correct_velocities_and_cache_previous_tendencies",
     "gb25_update_state", "gb25_first_time_step", "gb25_time_step", "gb25_loop",
-    "gb25_set_option", "gb25_get_option", "gb25_set_bottom_height", "gb25_get_bottom_info", "gb25_set_top_flux",
+    "gb25_set_option", "gb25_get_option", "gb25_set_bottom_height", "gb25_set_curvilinear_grid", "gb25_set_vertical_faces", "gb25_get_bottom_info", "gb25_set_top_flux",
     "gb25_comm_unique_id", "gb25_comm_init_rccl", "gb25_comm_init_local", "gb25_comm_init_callback", "gb25_comm_finalize",
     "gb25_lookahead_state", "gb25_debug_sequence", "gb25_save_state",
     "gb25_profile_enable", "gb25_profile_reset", "gb25_profile_get",
@@ -171,6 +171,8 @@ def load_library(float_type="Float32"):
     lib.gb25_save_state.argtypes = [P, C.c_char_p, C.c_char_p]
     lib.gb25_set_top_flux.argtypes = [P, C.c_int, P]
     lib.gb25_set_bottom_height.argtypes = [P, P]
+    lib.gb25_set_curvilinear_grid.argtypes = [P, P, C.c_int32, C.c_int32]
+    lib.gb25_set_vertical_faces.argtypes = [P, C.POINTER(C.c_double), C.c_int32]
     lib.gb25_get_bottom_info.argtypes = [P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     lib.gb25_set_option.argtypes = [P, C.c_int, C.c_int32]
     lib.gb25_get_option.argtypes = [P, C.c_int, C.POINTER(C.c_int32)]
@@ -413,11 +415,29 @@ class HipBackend:
 
     # ---- immersed boundary
     def set_bottom_height(self, zb):
-        """GridFittedBottom(zb): bottom height at the interior cell centres, shape (Nx, Ny)."""
+        """GridFittedBottom(zb): bottom height at the GLOBAL cell centres, shape (Nx_global, Ny) (a slab takes its columns,
+        its neighbours' and its fold partner's from it: every rank passes the same array)."""
         a = np.ascontiguousarray(np.asarray(zb, dtype=np.float64).T)      # i fastest
-        if a.shape != (self.cfg.Ny, self.cfg.Nx // self.cfg.nranks):
-            raise ValueError(f"bottom height: expected shape ({self.cfg.Nx // self.cfg.nranks}, {self.cfg.Ny})")
+        if a.shape != (self.cfg.Ny, self.cfg.Nx):
+            raise ValueError(f"bottom height: expected shape ({self.cfg.Nx}, {self.cfg.Ny})")
         self._call("gb25_set_bottom_height", a.ctypes.data_as(C.c_void_p))
+
+    # ---- the host's grid
+    def set_curvilinear_grid(self, metrics):
+        """metrics: {name: array} for the 14 names of METRIC2_IDS (dxfc ... azff, fff, phicc), each the parent array over the
+        GLOBAL grid, shape (Nx_global + 2H, Ny + 2H) or (Nx_global + 2H, Ny + 2H + 1) -- grid.Δxᶠᶜᵃ etc. of the host's grid."""
+        H = self.cfg.halo
+        arrs = [np.ascontiguousarray(np.asarray(metrics[n], dtype=np.float64).T) for n in METRIC2_IDS]
+        ny, nx = arrs[0].shape
+        if nx != self.cfg.Nx + 2 * H or any(a.shape != (ny, nx) for a in arrs):
+            raise ValueError(f"metrics: {len(METRIC2_IDS)} arrays of shape ({self.cfg.Nx + 2 * H}, {self.cfg.Ny + 2 * H} [+ 1])")
+        ptrs = (C.POINTER(C.c_double) * len(arrs))(*[a.ctypes.data_as(C.POINTER(C.c_double)) for a in arrs])
+        self._call("gb25_set_curvilinear_grid", ptrs, nx, ny)
+
+    def set_vertical_faces(self, zf):
+        """grid.z faces, bottom to top: Nz + 1 values."""
+        a = np.ascontiguousarray(np.asarray(zf, dtype=np.float64))
+        self._call("gb25_set_vertical_faces", a.ctypes.data_as(C.POINTER(C.c_double)), int(a.size))
 
     def bottom_info(self, which, i, j):
         """1-based (i, j) like the Julia sources; which: kbot | Hfc | Hcf."""

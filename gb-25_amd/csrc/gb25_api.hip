@@ -77,6 +77,11 @@ struct gb25_model {
   // orthogonal curvilinear grid (grid_type >= 2): the 14 horizontal metrics by location, fp64, parent layout of a (c,f)
   // field (gb25_get_metric2); cell-centre coordinates in degrees for analytic bottoms
   std::vector<double> h_curv[GB25_M2_COUNT];
+  // The HOST's grid (gb25_set_curvilinear_grid, gb25_set_vertical_faces, gb25_set_bottom_height): the 14 horizontal metrics
+  // over the GLOBAL parent extent ((Nx_global + 2H) x (Ny + 2H + 1) doubles each, i fastest), the Nz + 1 vertical faces, the
+  // bottom height at the global cell centres.  Empty: the built-in generators of cfg.grid_type.
+  std::vector<double> host_curv[GB25_M2_COUNT];
+  std::vector<double> host_zf, host_bottom;
   int metric_off_j = 0, metric_off_k = 0;
   // substepping
   int Ns = 0;
@@ -287,11 +292,15 @@ gb25_status build_grid(gb25_model* m) {
     if (a + 1 < nj) azc[a] = R * R * dlam * d2r * (std::sin(phif[a + 1] * d2r) - std::sin(phif[a] * d2r));
     if (a > 0) azf[a] = R * R * dlam * d2r * (std::sin(phic[a] * d2r) - std::sin(phic[a - 1] * d2r));
   }
-  // vertical faces: z_k ~ exp(k/h), k = 1..Nz+1, mapped to [0, -depth] and reversed
+  // vertical faces: z_k ~ exp(k/h), k = 1..Nz+1, mapped to [0, -depth] and reversed (exponential_z_faces, src/model_utils.jl:
+  // 56-62) -- or the host's own faces (gb25_set_vertical_faces)
   std::vector<double> zint(Nz + 1);
   const double h = c.zexp_h, e1 = std::exp(1.0 / h), eN = std::exp((Nz + 1.0) / h);
   for (int k = 1; k <= Nz + 1; k++) zint[Nz + 1 - k] = -c.depth * (std::exp(k / h) - e1) / (eN - e1);
   zint[Nz] = 0.0;
+  if (!m->host_zf.empty()) zint = m->host_zf;
+  // the faces are numbers of the model's float type (a Float32 host holds Float32 faces); centres and spacings derive from them
+  for (double& z : zint) z = (double)(real)z;
   std::vector<double>&zf = m->h_metric[GB25_M_ZF], &zc = m->h_metric[GB25_M_ZC], &dzc = m->h_metric[GB25_M_DZC],
   &dzf = m->h_metric[GB25_M_DZF];
   zf.assign(nk + 1, 0); zc.assign(nk, 0); dzc.assign(nk, 0); dzf.assign(nk, 0);
@@ -393,6 +402,16 @@ void curv_metrics_own(const gb25_model* m, int ig, int j, double out[GB25_M2_COU
   const double d2r = M_PI / 180.0, R = c.radius;
   const double lam0 = tri ? 70.0 : c.lon_west, dlam = (tri ? 360.0 : (c.lon_east - c.lon_west)) / c.Nx;
   const double phiN = tri ? 90.0 : c.lat_north, dphi = (phiN - c.lat_south) / (tri ? c.Ny - 1 : c.Ny);
+  if (!m->host_curv[0].empty()) {
+    // the host's arrays: halo columns as the host holds them (its periodic images), columns beyond them wrapped
+    const int H = c.halo, gsx = c.Nx + 2 * H;
+    const int col = (ig >= -H && ig < c.Nx + H) ? ig + H : ((ig % c.Nx) + c.Nx) % c.Nx + H;
+    const size_t o = (size_t)col + (size_t)gsx * (size_t)(std::min(std::max(j, -H), c.Ny + H) + H);
+    for (int q = 0; q < GB25_M2_COUNT; q++) out[q] = m->host_curv[q][o];
+    if (lam_c) *lam_c = 0.0;   // (not among the metrics: an analytic bottom cannot be placed on a host grid -- gb25_set_bottom_height)
+    if (phi_c) *phi_c = out[GB25_M2_PHICC];
+    return;
+  }
   if (!tri) {
     const int a = m->metric_off_j + j;
     out[GB25_M2_DXFC] = out[GB25_M2_DXCC] = m->h_metric[GB25_M_DXC][a];
@@ -470,7 +489,9 @@ gb25_status build_curv_grid(gb25_model* m) {
       const size_t o = (size_t)(i + H) + (size_t)sx * (j + H);
       double v[GB25_M2_COUNT];
       curv_metrics_at(m, i + c.rank * Nx, j, v, nullptr, nullptr);
-      for (int q = 0; q < GB25_M2_COUNT; q++) at(q)[o] = v[q];
+      // (numbers of the model's float type, as a host's grid holds them: reciprocals below are those of the rounded values, so
+      // that what gb25_get_metric2 hands out, fed back through gb25_set_curvilinear_grid, is the same grid to the last bit)
+      for (int q = 0; q < GB25_M2_COUNT; q++) at(q)[o] = (double)(real)v[q];
     }
   Curv& cv = m->g.cv;
   gb25_status s;
@@ -520,9 +541,9 @@ gb25_status build_curv_wide(gb25_model* m) {
       curv_metrics_at(m, wrap(i + c.rank * Nx), j, v, nullptr, nullptr);
       t[0][o] = (real)v[GB25_M2_DYFC];
       t[1][o] = (real)v[GB25_M2_DXCF];
-      t[2][o] = (real)(1.0 / v[GB25_M2_AZCC]);
-      t[3][o] = (real)(1.0 / v[GB25_M2_DXFC]);
-      t[4][o] = (real)(1.0 / v[GB25_M2_DYCF]);
+      t[2][o] = (real)(1.0 / (double)(real)v[GB25_M2_AZCC]);
+      t[3][o] = (real)(1.0 / (double)(real)v[GB25_M2_DXFC]);
+      t[4][o] = (real)(1.0 / (double)(real)v[GB25_M2_DYCF]);
     }
   for (int q = 0; q < 5; q++) {
     if (!m->d_wideM[q]) HIPCHK(hipMalloc(&m->d_wideM[q], t[q].size() * sizeof(real)));
@@ -1845,6 +1866,48 @@ gb25_status initialize_impl(gb25_model* m) {
   return fill_halos_2d(m, halo2_prognostic(m));
 }
 
+// The bottom tables from whatever the bottom currently is: the host's bottom height (gb25_set_bottom_height, global cell centres),
+// the analytic mountains of grid_type, or nothing (flat: tables only where the kernels take everything from tables).
+gb25_status rebuild_bottom(gb25_model* m) {
+  const gb25_config& c = m->cfg;
+  const bool islands = c.grid_type == GB25_GRID_LAT_LON_GAUSSIAN_ISLANDS || c.grid_type == GB25_GRID_TRIPOLAR_GAUSSIAN_ISLANDS;
+  if (!m->host_bottom.empty() || islands || m->g.cv.on) {
+    if (c.Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "an immersed boundary / a curvilinear grid needs Nz <= 254 (8-bit level tables)");
+  }
+  if (!m->host_bottom.empty()) {
+    const int Nxg = c.Nx, i0 = c.rank * m->Nx;
+    gb25_status s = build_bottom(m, [&](int i, int j) { return m->host_bottom[(size_t)((((i + i0) % Nxg) + Nxg) % Nxg) + (size_t)Nxg * j]; });
+    if (s) return s;
+    if (m->slab) m->immersed = true;   // (every slab of a decomposition runs the kernel variants its neighbours run)
+    return GB25_OK;
+  }
+  if (islands) {
+    if (!m->host_curv[0].empty())
+      return fail(m, GB25_ERR_STATE, "grid_type = gaussian_islands places its mountains by the built-in generator's coordinates: "
+                                     "with a host grid pass the bottom height too (gb25_set_bottom_height)");
+    gb25_status s = build_bottom(m, [&](int i, int j) { return gaussian_islands_bottom(m, i, j); });
+    m->immersed = true;   // (every slab of a decomposition runs the kernel variants the single domain runs, mountains or not)
+    return s;
+  }
+  // the curvilinear kernels take every reconstruction order and mask from the tables (that is also where the fold's
+  // "north is not a wall" lives): a flat bottom is a bottom nothing touches
+  if (m->g.cv.on) return build_bottom(m, [&](int, int) { return -1e30; });
+  return GB25_OK;
+}
+// everything in flight finishes and every look-ahead is void: the grid under the model is about to change
+gb25_status quiesce_for_grid_change(gb25_model* m) {
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(m->own_stream));
+  HIPCHK(hipStreamSynchronize(m->side_stream));
+  if (m->baro_stream) HIPCHK(hipStreamSynchronize(m->baro_stream));
+  m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+  m->colsum_valid = m->halo_colsum_valid = false;
+  m->tend_forkable = false;
+  m->complete_fills_needed = 2;
+  m->implicit_key[0][0] = m->implicit_key[1][0] = -1.0;   // (the elimination tables of a closure hold the old spacings)
+  return GB25_OK;
+}
+
 }  // namespace
 
 #include "slab_step.hpp"
@@ -2020,16 +2083,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     if (m->g.cv.on && (s = build_curv_wide(m))) return s;
     if (m->Wy && !m->slab) HIPCHK(hipMalloc(&m->tall_buf, (size_t)5 * (m->Wy + 1) * wsx * sizeof(real)));
   }
-  if (cfg->grid_type == GB25_GRID_LAT_LON_GAUSSIAN_ISLANDS || cfg->grid_type == GB25_GRID_TRIPOLAR_GAUSSIAN_ISLANDS) {
-    if (cfg->Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "an immersed boundary needs Nz <= 254 (8-bit level tables)");
-    if ((s = build_bottom(m, [&](int i, int j) { return gaussian_islands_bottom(m, i, j); }))) return s;
-    m->immersed = true;   // (every slab of a decomposition runs the kernel variants the single domain runs, mountains or not)
-  } else if (m->g.cv.on) {
-    // the curvilinear kernels take every reconstruction order and mask from the tables (that is also where the fold's
-    // "north is not a wall" lives): a flat bottom is a bottom nothing touches
-    if (cfg->Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "curvilinear grids need Nz <= 254 (8-bit level tables)");
-    if ((s = build_bottom(m, [&](int, int) { return -1e30; }))) return s;
-  }
+  if ((s = rebuild_bottom(m))) return s;
   HIPCHK(hipDeviceSynchronize());
   return GB25_OK;
 }
@@ -2396,16 +2450,65 @@ gb25_status gb25_mask_immersed_fields(gb25_model* m) {
 gb25_status gb25_set_bottom_height(gb25_model* m, const double* zb) {
   CHECK_MODEL(m);
   if (!zb) return GB25_ERR_INVALID_ARGUMENT;
-  if (m->slab) return fail(m, GB25_ERR_STATE, "gb25_set_bottom_height is for single-domain models; slabs use grid_type");
-  if (m->cfg.Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "an immersed boundary needs Nz <= 254 (8-bit level tables)");
-  HIPCHK(hipStreamSynchronize(m->stream));
-  HIPCHK(hipStreamSynchronize(m->side_stream));
-  if (m->baro_stream) HIPCHK(hipStreamSynchronize(m->baro_stream));
-  const int Nx = m->Nx;
-  gb25_status s = build_bottom(m, [&](int i, int j) { return zb[(size_t)(((i % Nx) + Nx) % Nx) + (size_t)Nx * j]; });
+  if (gb25_status s = collective_guard(m, 7, 0, zb[0])) return s;   // (synchronises the exchange stream of a decomposed model)
+  if (gb25_status s = quiesce_for_grid_change(m)) return s;
+  if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
+  m->host_bottom.assign(zb, zb + (size_t)m->cfg.Nx * m->cfg.Ny);   // GLOBAL cell centres (a slab picks its columns, its
+  gb25_status s = rebuild_bottom(m);                                 // neighbours' and its fold partner's)
   if (s) return s;
   if (m->kernel_gen == 1 && m->immersed) m->kernel_gen = 2;
-  return gb25_mask_immersed_fields(m);
+  return m->slab ? mask_impl(m) : gb25_mask_immersed_fields(m);
+}
+// ---- the host's horizontal grid
+gb25_status gb25_set_curvilinear_grid(gb25_model* m, const double* const* metrics, int32_t nx, int32_t ny) {
+  CHECK_MODEL(m);
+  const gb25_config& c = m->cfg;
+  const int H = c.halo, gsx = c.Nx + 2 * H, gsy = c.Ny + 2 * H + 1;
+  if (!m->g.cv.on)
+    return fail(m, GB25_ERR_STATE, "the model steps a LatitudeLongitudeGrid with row tables: create it with a curvilinear grid_type "
+                                   "(lat_lon_as_curvilinear, tripolar, gaussian_islands) to hand it 2-D metrics");
+  if (!metrics || nx != gsx || (ny != gsy && ny != gsy - 1))
+    return fail(m, GB25_ERR_INVALID_ARGUMENT, "gb25_set_curvilinear_grid: %d arrays of (Nx_global + 2 halo) x (Ny + 2 halo [+ 1]) = "
+                                              "%d x %d [%d] doubles, got %d x %d", (int)GB25_M2_COUNT, gsx, gsy - 1, gsy, (int)nx, (int)ny);
+  for (int q = 0; q < GB25_M2_COUNT; q++)
+    if (!metrics[q]) return fail(m, GB25_ERR_INVALID_ARGUMENT, "gb25_set_curvilinear_grid: metric %d is null", q);
+  if (gb25_status s = collective_guard(m, 8, (unsigned)ny, metrics[0][(size_t)H + (size_t)gsx * H])) return s;
+  if (gb25_status s = quiesce_for_grid_change(m)) return s;
+  if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
+  for (int q = 0; q < GB25_M2_COUNT; q++) {
+    std::vector<double>& a = m->host_curv[q];
+    a.assign((size_t)gsx * gsy, 0.0);
+    std::memcpy(a.data(), metrics[q], (size_t)gsx * ny * sizeof(double));
+    if (ny < gsy) std::memcpy(a.data() + (size_t)gsx * ny, a.data() + (size_t)gsx * (ny - 1), (size_t)gsx * sizeof(double));   // (never read)
+    // lengths and areas must be positive on the rows the kernels divide by
+    if (q != GB25_M2_FFF && q != GB25_M2_PHICC)
+      for (int j = 0; j < c.Ny; j++)
+        for (int i = 0; i < c.Nx; i++)
+          if (!(a[(size_t)(i + H) + (size_t)gsx * (j + H)] > 0.0)) {
+            for (auto& h : m->host_curv) h.clear();
+            return fail(m, GB25_ERR_INVALID_ARGUMENT, "gb25_set_curvilinear_grid: metric %d is not positive at interior point (%d, %d)", q, i, j);
+          }
+  }
+  gb25_status s;
+  if ((s = build_curv_grid(m))) return s;
+  if ((m->slab || m->g.cv.north_fold) && (s = build_curv_wide(m))) return s;
+  return GB25_OK;
+}
+// ---- the host's vertical grid: grid.z faces, bottom to top (exponential_z_faces(Nz, depth, h) in the reference: src/model_utils.jl:56-62)
+gb25_status gb25_set_vertical_faces(gb25_model* m, const double* zf, int32_t n) {
+  CHECK_MODEL(m);
+  if (!zf || n != m->cfg.Nz + 1) return fail(m, GB25_ERR_INVALID_ARGUMENT, "gb25_set_vertical_faces: Nz + 1 = %d faces, bottom to top", m->cfg.Nz + 1);
+  for (int k = 0; k < m->cfg.Nz; k++)
+    if (!(zf[k + 1] > zf[k])) return fail(m, GB25_ERR_INVALID_ARGUMENT, "gb25_set_vertical_faces: faces must increase (face %d)", k + 1);
+  if (gb25_status s = collective_guard(m, 9, (unsigned)n, zf[0])) return s;
+  if (gb25_status s = quiesce_for_grid_change(m)) return s;
+  if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
+  m->host_zf.assign(zf, zf + n);
+  gb25_status s;
+  if ((s = build_grid(m))) return s;          // (row tables again too: small)
+  if ((s = build_eos_tables(m))) return s;
+  if ((s = rebuild_bottom(m))) return s;
+  return mask_impl(m);
 }
 // which: 0 = number of immersed cells of column (i, j) (0-based local indices), 1 = static depth at the U face,
 // 2 = at the V face

@@ -201,11 +201,29 @@ gb25_status gb25_get_metric2(const gb25_model *m, gb25_metric2 id, double *value
 gb25_status gb25_get_substepping(const gb25_model *m, int32_t *n_effective, double *dtau_fraction,
                                  double *weights /* >= substeps entries */);
 
-/* ---- immersed boundary: ImmersedBoundaryGrid(grid, GridFittedBottom(bottom_height)) (src/model_utils.jl:134-146).
- *      gb25_set_bottom_height replaces the bottom of a single-domain model by an arbitrary one (Nx x Ny doubles at the
- *      cell centres, i fastest; metres, negative down) and masks the fields; decomposed models take an analytic
- *      grid_type, evaluated for halo columns too.  gb25_get_bottom_info (diagnostic; 0-based local i, j): which = 0 the
- *      number of immersed cells of the column, 1 / 2 the static column depth at its U / V face. */
+/* ---- the HOST's grid.  In the reference the grid is built by Oceananigans on the Julia side and handed to the model:
+ *      TripolarGrid(arch; size, halo, z) wrapped in ImmersedBoundaryGrid(grid, GridFittedBottom(gaussian_islands)) with
+ *      z = exponential_z_faces(Nz, depth) (src/model_utils.jl:56-62,129-146).  gb25_create builds stand-ins from cfg.grid_type
+ *      (an analytic bipolar cap, not necessarily Oceananigans' coordinate lines); a host that has the real grid passes it:
+ *
+ *      gb25_set_curvilinear_grid: the 14 horizontal metrics in gb25_metric2 order -- grid.Δxᶠᶜᵃ, Δxᶜᶜᵃ, Δxᶜᶠᵃ, Δxᶠᶠᵃ, Δyᶠᶜᵃ, Δyᶜᶜᵃ,
+ *        Δyᶜᶠᵃ, Δyᶠᶠᵃ, Azᶜᶜᵃ, Azᶠᶜᵃ, Azᶜᶠᵃ, Azᶠᶠᵃ, the Coriolis parameter at (f,f) and the latitude of the cell centres φᶜᶜᵃ [degrees]
+ *        -- each the PARENT array over the GLOBAL grid as fp64, (nx, ny) = (Nx_global + 2 halo, Ny + 2 halo [+ 1]), i fastest
+ *        (ny = Ny + 2 halo is what a (Periodic, RightConnected, Bounded) grid holds; a Bounded y has one more row of y faces).
+ *        x halo columns are taken as the host holds them; on a folded grid the rows beyond the pivot row are taken from the
+ *        interior by the fold's own rule (cell rows and y-face rows mirror about the centres of the last row of cells, x
+ *        faces as i -> Nx - i + 2), whatever the host's halo rows hold.  The model must have been created with a curvilinear
+ *        grid_type (2, 3, 4).  A slab of a decomposition takes its columns -- halo, widened and fold-partner columns
+ *        included -- from the same global arrays.
+ *      gb25_set_vertical_faces: the Nz + 1 faces of grid.z, bottom to top [m]; spacings, the TEOS-10 level tables, the bottom's
+ *        level tables and a closure's elimination tables are rebuilt.
+ *      gb25_set_bottom_height: GridFittedBottom(bottom_height): Nx_global x Ny doubles at the GLOBAL cell centres, i fastest
+ *        [m, negative down]; replaces the bottom of grid_type, masks the fields.
+ *      All three are collective on a decomposed model, void every look-ahead and may be called in any order before (or
+ *      between) steps.  gb25_get_bottom_info (diagnostic; 0-based local i, j): which = 0 the number of immersed cells of the
+ *      column, 1 / 2 the static column depth at its U / V face. */
+gb25_status gb25_set_curvilinear_grid(gb25_model *m, const double *const *metrics /* [GB25_M2_COUNT] */, int32_t nx, int32_t ny);
+gb25_status gb25_set_vertical_faces(gb25_model *m, const double *z_faces, int32_t n /* Nz + 1 */);
 gb25_status gb25_set_bottom_height(gb25_model *m, const double *bottom_height);
 gb25_status gb25_get_bottom_info(const gb25_model *m, int32_t which, int32_t i, int32_t j, double *value);
 

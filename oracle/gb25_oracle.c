@@ -110,6 +110,7 @@ typedef struct {
   int curv, north_fold;
   REAL *dxfc2, *dxcc2, *dxcf2, *dxff2, *dyfc2, *dycc2, *dycf2, *dyff2, *azcc2, *azfc2, *azcf2, *azff2, *fff2, *phicc2;
   double *lamcc_d, *phicc_d; /* cell-centre coordinates in degrees (double), interior Nx x Ny, for analytic bottoms */
+  double *zb_last;           /* the bottom height the level tables were last made from (Nx x Ny): re-materialised when z changes */
 } model;
 /* number of prognostic rows of the y-face fields: Ny whatever the northern edge is.  The zipper fold pivots on the ROW OF
  * CELL CENTRES Ny (Oceananigans' TripolarGrid: the centres run from the southernmost latitude to 90 degrees, "the north pole
@@ -185,6 +186,11 @@ static inline int immersed_peripheral_v(const model *m, int i, int j, int k) {
 /* bottom heights at the cell centres of the interior columns -> kbot and the static column depths */
 static void set_bottom(model *m, const double *zb /* Nx*Ny, i fastest */) {
   int Nx = m->Nx, Ny = m->Ny, Nz = m->Nz, H = m->H, sx = Nx + 2 * H;
+  if (zb != m->zb_last) {
+    free(m->zb_last);
+    m->zb_last = (double *)malloc(sizeof(double) * (size_t)Nx * Ny);
+    memcpy(m->zb_last, zb, sizeof(double) * (size_t)Nx * Ny);
+  }
   long n2 = (long)sx * (Ny + 2 * H + 1);
   for (long q = 0; q < n2; q++) { m->kbot[q] = 0; m->Hcc[q] = m->Hfc[q] = m->Hcf[q] = 0; }
   m->immersed = 0;
@@ -247,6 +253,39 @@ static void gaussian_islands(model *m, const gb25o_config *c, double *zb) {
     }
 }
 
+/* the vertical grid from its Nz + 1 faces, bottom to top (the host's grid.z: gb25_set_vertical_faces of the library) */
+static void set_vertical(model *m, const double *zint_in) {
+  int H = m->H, Nz = m->Nz, nk = Nz + 2 * H + 2 * PAD + 2;
+  /* the faces are numbers of the model's float type (a Float32 host holds Float32 faces); centres and spacings derive from them */
+  double zint[512];
+  for (int k = 0; k <= Nz; k++) zint[k] = (double)(REAL)zint_in[k];
+  double *zf = (double *)calloc(nk + 1, sizeof(double));
+  double *zc = (double *)calloc(nk, sizeof(double));
+  /* faces incl. halos: constant extension with the first/last interior spacing */
+  int off = H + PAD; /* array index of logical k=1 */
+  double dlo = zint[1] - zint[0], dhi = zint[Nz] - zint[Nz - 1];
+  for (int a = 0; a <= nk; a++) {
+    int k = a + 1 - off; /* logical face index */
+    if (k < 1) zf[a] = zint[0] + (k - 1) * dlo;
+    else if (k > Nz + 1) zf[a] = zint[Nz] + (k - Nz - 1) * dhi;
+    else zf[a] = zint[k - 1];
+  }
+  for (int a = 0; a < nk; a++) zc[a] = 0.5 * (zf[a] + zf[a + 1]);
+  free(m->zf); free(m->zc); free(m->dzc); free(m->dzf);
+  m->zf = (REAL *)calloc(nk + 1, sizeof(REAL));
+  m->zc = (REAL *)calloc(nk, sizeof(REAL));
+  m->dzc = (REAL *)calloc(nk, sizeof(REAL));
+  m->dzf = (REAL *)calloc(nk, sizeof(REAL));
+  for (int a = 0; a <= nk; a++) m->zf[a] = (REAL)zf[a];
+  for (int a = 0; a < nk; a++) {
+    m->zc[a] = (REAL)zc[a];
+    m->dzc[a] = (REAL)(zf[a + 1] - zf[a]);
+    m->dzf[a] = (REAL)(a > 0 ? zc[a] - zc[a - 1] : zc[1] - zc[0]);
+  }
+  m->Lz = (REAL)(zint[Nz] - zint[0]);
+  free(zf);
+  free(zc);
+}
 /* ---------------------------------------------------------------- grid
  * simple_latitude_longitude_grid: /root/reference/src/model_utils.jl:56-65.
  * exponential_z_faces (ClimaOcean 0.5.10, restated): k = 1..Nz+1,
@@ -255,7 +294,7 @@ static void gaussian_islands(model *m, const gb25o_config *c, double *zb) {
  */
 static void build_grid(model *m, const gb25o_config *c) {
   int H = m->H, Ny = m->Ny, Nz = m->Nz;
-  int nj = Ny + 2 * H + 2 * PAD + 2, nk = Nz + 2 * H + 2 * PAD + 2;
+  int nj = Ny + 2 * H + 2 * PAD + 2;
   double *phif = (double *)calloc(nj, sizeof(double));
   double *phic = (double *)calloc(nj, sizeof(double));
   m->phif = (REAL *)calloc(nj, sizeof(REAL));
@@ -289,9 +328,7 @@ static void build_grid(model *m, const gb25o_config *c) {
   free(phif);
   free(phic);
 
-  /* vertical */
-  double *zf = (double *)calloc(nk + 1, sizeof(double));
-  double *zc = (double *)calloc(nk, sizeof(double));
+  /* vertical: exponential_z_faces(Nz, depth, h) */
   double *zint = (double *)calloc(Nz + 1, sizeof(double));
   double h = c->zexp_h;
   double e1 = exp(1.0 / h), eN = exp((Nz + 1.0) / h);
@@ -300,29 +337,7 @@ static void build_grid(model *m, const gb25o_config *c) {
     zint[Nz + 1 - k] = zk;                                 /* reversed: zint[0] = -depth */
   }
   zint[Nz] = 0.0;
-  /* faces incl. halos: constant extension with the first/last interior spacing */
-  int off = H + PAD; /* array index of logical k=1 */
-  double dlo = zint[1] - zint[0], dhi = zint[Nz] - zint[Nz - 1];
-  for (int a = 0; a <= nk; a++) {
-    int k = a + 1 - off; /* logical face index */
-    if (k < 1) zf[a] = zint[0] + (k - 1) * dlo;
-    else if (k > Nz + 1) zf[a] = zint[Nz] + (k - Nz - 1) * dhi;
-    else zf[a] = zint[k - 1];
-  }
-  for (int a = 0; a < nk; a++) zc[a] = 0.5 * (zf[a] + zf[a + 1]);
-  m->zf = (REAL *)calloc(nk + 1, sizeof(REAL));
-  m->zc = (REAL *)calloc(nk, sizeof(REAL));
-  m->dzc = (REAL *)calloc(nk, sizeof(REAL));
-  m->dzf = (REAL *)calloc(nk, sizeof(REAL));
-  for (int a = 0; a <= nk; a++) m->zf[a] = (REAL)zf[a];
-  for (int a = 0; a < nk; a++) {
-    m->zc[a] = (REAL)zc[a];
-    m->dzc[a] = (REAL)(zf[a + 1] - zf[a]);
-    m->dzf[a] = (REAL)(a > 0 ? zc[a] - zc[a - 1] : zc[1] - zc[0]);
-  }
-  m->Lz = (REAL)(zint[Nz] - zint[0]);
-  free(zf);
-  free(zc);
+  set_vertical(m, zint);
   free(zint);
 }
 
@@ -377,6 +392,23 @@ static double tri_area(gnode a, gnode b, gnode c) {
 static double quad_area(gnode a, gnode b, gnode c, gnode d, double R) {
   double A = R * R * (tri_area(a, b, c) + tri_area(a, c, d));
   return A > 1e4 ? A : 1e4;
+}
+/* rows beyond the pivot row of a folded grid: the metric of a location there is the metric of its image (all positive
+ * scalars; copies of interior numbers, whatever generated those) */
+static void mirror_metric_rows(model *m) {
+  int Nx = m->Nx, Ny = m->Ny, H = m->H;
+  for (int j = Ny + 1; j <= Ny + H + 1; j++)
+    for (int i = 1 - H; i <= Nx + H; i++) {
+      const int iw = (((i - 1) % Nx) + Nx) % Nx + 1;    /* the interior column this column is (the periodic image of) */
+      const int ic = Nx - iw + 1, ifx = (Nx - iw + 2 > Nx) ? Nx - iw + 2 - Nx : Nx - iw + 2;
+      const int jc = 2 * Ny - j, jf = 2 * Ny + 1 - j;   /* rows of cell centres / of y faces mirror about the centres of row Ny */
+      M2(dxcc2, i, j) = M2(dxcc2, ic, jc); M2(dycc2, i, j) = M2(dycc2, ic, jc); M2(azcc2, i, j) = M2(azcc2, ic, jc);
+      M2(phicc2, i, j) = M2(phicc2, ic, jc);
+      M2(dxfc2, i, j) = M2(dxfc2, ifx, jc); M2(dyfc2, i, j) = M2(dyfc2, ifx, jc); M2(azfc2, i, j) = M2(azfc2, ifx, jc);
+      M2(dxcf2, i, j) = M2(dxcf2, ic, jf); M2(dycf2, i, j) = M2(dycf2, ic, jf); M2(azcf2, i, j) = M2(azcf2, ic, jf);
+      M2(dxff2, i, j) = M2(dxff2, ifx, jf); M2(dyff2, i, j) = M2(dyff2, ifx, jf); M2(azff2, i, j) = M2(azff2, ifx, jf);
+      M2(fff2, i, j) = M2(fff2, ifx, jf);
+    }
 }
 /* grid_type 2: the lat-lon metrics copied into the 2-D arrays (the curvilinear code path must then reproduce the plain
  * one bit for bit); 3, 4: the tripolar grid */
@@ -438,19 +470,7 @@ static void build_curv_grid(model *m, const gb25o_config *c) {
       }
 #undef NODE
     }
-  if (tri)   /* rows beyond the pivot row: the metric of a location there is the metric of its image (all positive scalars) */
-    for (int j = Ny + 1; j <= Ny + H + 1; j++)
-      for (int i = 1 - H; i <= Nx + H; i++) {
-        const int iw = (((i - 1) % Nx) + Nx) % Nx + 1;    /* the interior column this column is (the periodic image of) */
-        const int ic = Nx - iw + 1, ifx = (Nx - iw + 2 > Nx) ? Nx - iw + 2 - Nx : Nx - iw + 2;
-        const int jc = 2 * Ny - j, jf = 2 * Ny + 1 - j;   /* rows of cell centres / of y faces mirror about the centres of row Ny */
-        M2(dxcc2, i, j) = M2(dxcc2, ic, jc); M2(dycc2, i, j) = M2(dycc2, ic, jc); M2(azcc2, i, j) = M2(azcc2, ic, jc);
-        M2(phicc2, i, j) = M2(phicc2, ic, jc);
-        M2(dxfc2, i, j) = M2(dxfc2, ifx, jc); M2(dyfc2, i, j) = M2(dyfc2, ifx, jc); M2(azfc2, i, j) = M2(azfc2, ifx, jc);
-        M2(dxcf2, i, j) = M2(dxcf2, ic, jf); M2(dycf2, i, j) = M2(dycf2, ic, jf); M2(azcf2, i, j) = M2(azcf2, ic, jf);
-        M2(dxff2, i, j) = M2(dxff2, ifx, jf); M2(dyff2, i, j) = M2(dyff2, ifx, jf); M2(azff2, i, j) = M2(azff2, ifx, jf);
-        M2(fff2, i, j) = M2(fff2, ifx, jf);
-      }
+  if (tri) mirror_metric_rows(m);
   if (!tri)
     for (int j = 1; j <= Ny; j++)
       for (int i = 1; i <= Nx; i++) {
@@ -568,6 +588,33 @@ int FN(substep_info)(void *h, double *dtau_frac, double *w) {
 }
 /* bottom height at the interior cell centres (Nx*Ny doubles, i fastest); GridFittedBottom(zb) */
 void FN(set_bottom_height)(void *h, const double *zb) { set_bottom((model *)h, zb); }
+/* the host's grid (gb25_set_curvilinear_grid / gb25_set_vertical_faces of the library): the 14 horizontal metrics in the
+ * library's gb25_metric2 order, each the parent array (Nx + 2H) x ny doubles, ny = Ny + 2H or Ny + 2H + 1; on a folded grid
+ * the rows beyond the pivot row are taken from the interior by the fold's rule */
+int FN(set_curvilinear_grid)(void *h, const double *const *metrics, int ny) {
+  model *m = (model *)h;
+  if (!m->curv) return 1;
+  int Nx = m->Nx, Ny = m->Ny, H = m->H, sx = Nx + 2 * H, sy = Ny + 2 * H + 1;
+  REAL *arr[] = {m->dxfc2, m->dxcc2, m->dxcf2, m->dxff2, m->dyfc2, m->dycc2, m->dycf2, m->dyff2,
+                 m->azcc2, m->azfc2, m->azcf2, m->azff2, m->fff2, m->phicc2};
+  if (ny != sy && ny != sy - 1) return 2;
+  for (int q = 0; q < 14; q++) {
+    for (long o = 0; o < (long)sx * ny; o++) arr[q][o] = (REAL)metrics[q][o];
+    if (ny < sy)
+      for (int i = 0; i < sx; i++) arr[q][(long)sx * ny + i] = arr[q][(long)sx * (ny - 1) + i];
+  }
+  if (m->north_fold) mirror_metric_rows(m);
+  for (int j = 1; j <= Ny; j++)
+    for (int i = 1; i <= Nx; i++) m->phicc_d[(i - 1) + (size_t)Nx * (j - 1)] = metrics[13][((long)i - 1 + H) + (long)sx * ((long)j - 1 + H)];
+  return 0;
+}
+int FN(set_vertical_faces)(void *h, const double *zint, int n) {
+  model *m = (model *)h;
+  if (n != m->Nz + 1) return 1;
+  set_vertical(m, zint);
+  if (m->zb_last) set_bottom(m, m->zb_last);   /* the bottom is materialised on the new levels */
+  return 0;
+}
 /* which: 0 kbot, 1 Hcc, 2 Hfc, 3 Hcf at logical (i, j) */
 double FN(bottom_info)(void *h, int which, int i, int j) {
   model *m = (model *)h;

@@ -228,6 +228,32 @@ class OracleBackend:
         if self._fn("is_immersed")(C.c_void_p(self.h)):
             self._call("mask_immersed_fields")
 
+    def set_curvilinear_grid(self, metrics):
+        """Same call as HipBackend.set_curvilinear_grid (the oracle is a single domain: global = local)."""
+        from gb25_amd.binding import METRIC2_IDS
+        arrs = [np.ascontiguousarray(np.asarray(metrics[n], dtype=np.float64).T) for n in METRIC2_IDS]
+        ptrs = (C.POINTER(C.c_double) * len(arrs))(*[a.ctypes.data_as(C.POINTER(C.c_double)) for a in arrs])
+        f = self._fn("set_curvilinear_grid")
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        if f(self.h, ptrs, arrs[0].shape[0]) != 0:
+            raise ValueError("set_curvilinear_grid: not a curvilinear grid, or arrays of the wrong shape")
+
+    def set_vertical_faces(self, zf):
+        a = np.ascontiguousarray(np.asarray(zf, dtype=np.float64))
+        f = self._fn("set_vertical_faces")
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        if f(self.h, a.ctypes.data_as(C.c_void_p), int(a.size)) != 0:
+            raise ValueError("set_vertical_faces: Nz + 1 faces")
+        if self._fn("is_immersed")(C.c_void_p(self.h)):
+            self._call("mask_immersed_fields")
+
+    def metric2_array(self, name):
+        """One horizontal metric as the parent array (Nx + 2H, Ny + 2H + 1), like HipBackend.metric2(name)."""
+        H = self.H
+        return np.array([[self.metric2(name, i, j) for j in range(1 - H, self.cfg.Ny + H + 2)] for i in range(1 - H, self.cfg.Nx + H + 1)])
+
     def bottom_info(self, which, i, j):
         f = self._fn("bottom_info")
         f.restype = C.c_double

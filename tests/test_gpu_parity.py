@@ -66,7 +66,11 @@ def test_grid_metrics_and_substepping_match_oracle():
     for name, idxs in (("dxc", range(-5, 72)), ("dxf", range(-5, 72)), ("azc", range(-5, 71)), ("azf", range(-4, 72)),
                        ("fcor", range(1, 66)), ("zc", range(-3, 13)), ("dzc", range(-3, 13)), ("dzf", range(-2, 13))):
         for i in idxs:
-            assert r.backend.metric(name, i) == np.float32(v.backend.metric(name, i)), (name, i)
+            want = np.float32(v.backend.metric(name, i))
+            # (the vertical faces are Float32 numbers here and the centres / spacings derive from THOSE: within an ulp of a
+            # FACE -- 5e-4 m at 4 km -- of the Float64 oracle's numbers)
+            tol = 2 * float(np.spacing(np.float32(6000.0))) if name in ("zc", "dzc", "dzf") else 0.0
+            assert abs(r.backend.metric(name, i) - want) <= tol, (name, i)
     nr, fr, wr = r.backend.substepping()
     nv, fv, wv = v.backend.substepping()
     assert nr == nv == 21 and fr == fv
