@@ -191,10 +191,40 @@ end
 set_catke_parameters!(m::Model, p::CatkeParameters) =
     check(m, ccall((:gb25_set_catke_parameters, m.lib), Cint, (Ptr{Cvoid}, Ptr{CatkeParameters}), m.ptr, Ref(p)),
           "gb25_set_catke_parameters")
-# GridFittedBottom(bottom_height): heights at the cell centres of the interior columns, (Nx, Ny)
+# GridFittedBottom(bottom_height): heights at the GLOBAL cell centres, (Nx_global, Ny) (every rank passes the same array)
 set_bottom_height!(m::Model, zb::AbstractMatrix) =
     check(m, ccall((:gb25_set_bottom_height, m.lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), m.ptr, convert(Matrix{Float64}, zb)),
           "gb25_set_bottom_height")
+
+# ---- the HOST's grid: the model steps on Oceananigans' own numbers, not on the library's stand-in generators.
+# `grid` is the underlying OrthogonalSphericalShellGrid (TripolarGrid(arch; size, halo, z), src/model_utils.jl:134-137) built on
+# CPU() over the GLOBAL domain; the 14 arrays go in gb25_metric2 order as the parents of grid.Δxᶠᶜᵃ ..., (Nx + 2H, Ny + 2H).
+function set_curvilinear_grid!(m::Model, grid; Ω = 7.292115e-5)
+    P(name) = convert(Matrix{Float64}, collect(parent(getproperty(grid, name)))[:, :, 1])
+    fff = 2Ω .* sind.(P(:φᶠᶠᵃ))                                   # HydrostaticSphericalCoriolis at (Face, Face)
+    arrays = [P(:Δxᶠᶜᵃ), P(:Δxᶜᶜᵃ), P(:Δxᶜᶠᵃ), P(:Δxᶠᶠᵃ), P(:Δyᶠᶜᵃ), P(:Δyᶜᶜᵃ), P(:Δyᶜᶠᵃ), P(:Δyᶠᶠᵃ),
+              P(:Azᶜᶜᵃ), P(:Azᶠᶜᵃ), P(:Azᶜᶠᵃ), P(:Azᶠᶠᵃ), fff, P(:φᶜᶜᵃ)]
+    nx, ny = size(arrays[1])
+    ptrs = [pointer(a) for a in arrays]
+    GC.@preserve arrays check(m, ccall((:gb25_set_curvilinear_grid, m.lib), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Int32, Int32),
+                                       m.ptr, ptrs, nx, ny), "gb25_set_curvilinear_grid")
+end
+# grid.z faces, bottom to top: exponential_z_faces(Nz, depth) in the reference (src/model_utils.jl:56-62)
+function set_vertical_faces!(m::Model, grid)
+    Nz, Hz = grid.Nz, grid.Hz
+    zf = convert(Vector{Float64}, collect(parent(grid.z.cᵃᵃᶠ))[Hz + 1:Hz + Nz + 1])
+    check(m, ccall((:gb25_set_vertical_faces, m.lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32), m.ptr, zf, length(zf)),
+          "gb25_set_vertical_faces")
+end
+# everything an ImmersedBoundaryGrid(TripolarGrid, GridFittedBottom) holds (src/model_utils.jl:129-146), in one call
+function set_grid!(m::Model, ibg)
+    grid = ibg.underlying_grid
+    set_curvilinear_grid!(m, grid)
+    set_vertical_faces!(m, grid)
+    Hx, Hy = grid.Hx, grid.Hy
+    zb = collect(parent(ibg.immersed_boundary.bottom_height))[Hx + 1:Hx + grid.Nx, Hy + 1:Hy + grid.Ny, 1]
+    set_bottom_height!(m, zb)
+end
 # gb25_metric2: horizontal metrics of an orthogonal curvilinear grid (grid_type >= 2) by location
 const METRIC2 = (dxfc = 0, dxcc = 1, dxcf = 2, dxff = 3, dyfc = 4, dycc = 5, dycf = 6, dyff = 7,
                  azcc = 8, azfc = 9, azcf = 10, azff = 11, fff = 12, phicc = 13)

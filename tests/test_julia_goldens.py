@@ -53,6 +53,28 @@ def case_model_kw(path):
     return {}
 
 
+METRIC_FILES = {"dxfc": "Δxᶠᶜᵃ", "dxcc": "Δxᶜᶜᵃ", "dxcf": "Δxᶜᶠᵃ", "dxff": "Δxᶠᶠᵃ", "dyfc": "Δyᶠᶜᵃ", "dycc": "Δyᶜᶜᵃ", "dycf": "Δyᶜᶠᵃ",
+                "dyff": "Δyᶠᶠᵃ", "azcc": "Azᶜᶜᵃ", "azfc": "Azᶠᶜᵃ", "azcf": "Azᶜᶠᵃ", "azff": "Azᶠᶠᵃ", "phicc": "φᶜᶜᵃ"}
+
+
+def apply_host_grid(model, path):
+    """A case dumped on a curvilinear grid (dump_curvilinear_grid of tools/dump_goldens.jl) carries the reference's OWN grid:
+    the model then steps on it -- gb25_set_curvilinear_grid / gb25_set_vertical_faces / gb25_set_bottom_height -- instead of on
+    the library's stand-in generator, exactly what a Julia host does (julia/GB25HIP.jl, set_grid!)."""
+    gdir = os.path.join(path, "grid")
+    if not os.path.exists(os.path.join(gdir, "Δxᶠᶜᵃ.npy")):
+        return False
+    two = lambda a: a[:, :, 0] if a.ndim == 3 else a
+    metrics = {k: two(np.load(os.path.join(gdir, f + ".npy"))).astype(np.float64) for k, f in METRIC_FILES.items()}
+    metrics["fff"] = 2 * 7.292115e-5 * np.sin(np.radians(two(np.load(os.path.join(gdir, "φᶠᶠᵃ.npy"))).astype(np.float64)))
+    Nx, Ny, Nz = model.grid.size
+    H = model.grid.halo[0]
+    model.backend.set_curvilinear_grid(metrics)
+    model.backend.set_vertical_faces(np.load(os.path.join(gdir, "zf.npy")).ravel()[H:H + Nz + 1])
+    model.backend.set_bottom_height(two(np.load(os.path.join(gdir, "bottom_height.npy")))[H:H + Nx, H:H + Ny])
+    return True
+
+
 def load(path, checkpoint, fname):
     a = np.load(os.path.join(path, checkpoint, fname + ".npy"))
     return a[:, :, None] if a.ndim == 2 else a
@@ -77,6 +99,7 @@ def compare(model, path, checkpoint, rtol, names=FIELDS):
 
 def run_protocol(model, path, rtol):
     """The reference's six checkpoints; returns {checkpoint: [(field, rel, 1-based index of the worst cell)]}."""
+    apply_host_grid(model, path)
     for fname in PROGNOSTIC:
         if not os.path.exists(os.path.join(path, "1_beginning", fname + ".npy")):
             continue   # (e: catke_* cases only)
