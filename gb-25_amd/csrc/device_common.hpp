@@ -61,6 +61,11 @@ struct Curv {
 // the levels the fills write.
 struct LazyCorr {
   const real *du, *dv;
+  // w ON THE FLY (option W_ON_THE_FLY, only together with the above): the tendency kernels do not read w at all -- within a
+  // chunk of levels they carry it up from the divergence of the very transports they hold (w(k+1) = w(k) - div(k) / Az), and
+  // take w at the chunk's first level from `wbase` (k_w_bases, kernels.hpp): [chunk][parent layout of a 2-D (c,f) field]
+  const real* wbase;
+  int wplane;
 };
 
 struct Grid {

@@ -161,6 +161,13 @@ struct gb25_model {
   Field corr[2];
   bool uv_lazy = false;
   int lazy_corrector = 1;            // option LAZY_CORRECTOR
+  // ... and with it w ON THE FLY (option W_ON_THE_FLY): in those steps the tendency kernels carry w up their chunks of levels
+  // from the divergence of the transports they hold; no k_compute_w launch, no w traffic.  wbase: w at the first level of every
+  // chunk (k_w_bases).  While w_stale is set the field w in memory is the one of an earlier step (recomputed with the
+  // velocities: materialize_uv).  Results agree with the stand-alone w to round-off, not to the last bit.
+  real* wbase = nullptr;
+  int w_fly = 1;
+  bool w_stale = false, w_fly_now = false;
   // levels a block of the momentum / tracer tendency kernel marches through (options MOMENTUM_CHUNK_LEVELS,
   // TRACER_CHUNK_LEVELS): fewer, longer chunks amortise the start-up of the vertical windows, more chunks fill the chip.
   // The momentum chunking is also the association of every column integral of u, v (all their producers share it).
@@ -906,7 +913,7 @@ gb25_status compute_w_impl(gb25_model* m, int part = 0) {
   const int ey = g.Ny + 2 * g.H - 2;
   // narrow strips: 16 columns x 16 rows per block instead of 64 x 4 (a 64-wide block would be three-quarters empty)
   dim3 b = (na + nbcols) >= 64 ? dim3(64, 4) : dim3(16, 16);
-  const LazyCorr lz{m->corr[0].d, m->corr[1].d};
+  const LazyCorr lz{m->corr[0].d, m->corr[1].d, m->wbase, m->g.sx * m->g.sy_v};
   auto kw = k_compute_w<false, false>;
   if (m->uv_lazy) kw = k_compute_w<false, true>;
   else if (g.cv.on) kw = k_compute_w<true, false>;
@@ -1028,13 +1035,14 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
                          m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d, m->d_bottom_flux[0], m->d_bottom_flux[1],
                          (real)m->bottom_drag, i_first, n);
     }
-    const LazyCorr lz{m->corr[0].d, m->corr[1].d};
+    const LazyCorr lz{m->corr[0].d, m->corr[1].d, m->wbase, m->g.sx * m->g.sy_v};
     if (m->uv_lazy && !(ahead && nx.fold && part == 0))
       return fail(m, GB25_ERR_STATE, "internal: uncorrected velocities in a step whose momentum kernel cannot correct them");
     const bool drag = m->bottom_drag != 0;
     auto k5 = drag ? (g.cv.on ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, true, false, true> : k_momentum_tendencies_v5<MW, TYm, false, true, true, false, true>)
                       : m->immersed ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, false, false, true> : k_momentum_tendencies_v5<MW, TYm, false, true, false, false, true>)
                                     : (ahead ? k_momentum_tendencies_v5<MW, TYm, true, false, false, false, true> : k_momentum_tendencies_v5<MW, TYm, false, false, false, false, true>))
+              : (m->uv_lazy && ahead && m->w_fly_now) ? k_momentum_tendencies_v5<MW, TYm, true, false, false, true, false, true>
               : (m->uv_lazy && ahead) ? k_momentum_tendencies_v5<MW, TYm, true, false, false, true>
               : g.cv.on ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true, true>)
               : m->immersed ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true>)
@@ -1092,7 +1100,7 @@ gb25_status tracers_impl(gb25_model* m) {
       nx.C1 = real(1.5) + (real)m->cfg.chi; nx.C2 = real(0.5) + (real)m->cfg.chi;
     }
     const bool fold = ahead && producers_fold(m);
-    const LazyCorr lz{m->corr[0].d, m->corr[1].d};
+    const LazyCorr lz{m->corr[0].d, m->corr[1].d, m->wbase, m->g.sx * m->g.sy_v};
     if (m->uv_lazy && !(ahead && fold))
       return fail(m, GB25_ERR_STATE, "internal: uncorrected velocities in a step whose tracer kernel cannot correct them");
     constexpr int TWL = sizeof(real) == 8 ? 3 : 6;   // (the headline instance: held to 80 VGPRs, six waves per SIMD)
@@ -1101,6 +1109,7 @@ gb25_status tracers_impl(gb25_model* m) {
                     ? (g.cv.on ? (ahead ? k_tracer_tendencies_v5<TW7, true, true, false, true, false, 7> : k_tracer_tendencies_v5<TW7, false, true, false, true, false, 7>)
                        : m->immersed ? (ahead ? k_tracer_tendencies_v5<TW7, true, true, false, false, false, 7> : k_tracer_tendencies_v5<TW7, false, true, false, false, false, 7>)
                                      : (ahead ? k_tracer_tendencies_v5<TW7, true, false, false, false, false, 7> : k_tracer_tendencies_v5<TW7, false, false, false, false, false, 7>))
+                : (m->uv_lazy && ahead && fold && m->w_fly_now) ? k_tracer_tendencies_v5<TWL, true, false, true, false, true, 5, true>
                 : (m->uv_lazy && ahead && fold) ? k_tracer_tendencies_v5<TWL, true, false, true, false, true>
                 : g.cv.on ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false, true>)
                                  : k_tracer_tendencies_v5<TW, false, true, false, true>)
@@ -1688,9 +1697,14 @@ gb25_status materialize_uv(gb25_model* m) {
   const Grid& g = m->g;
   dim3 b(64, 4);
   hipLaunchKernelGGL(k_apply_correction, grid2(g.sx, g.sy_v, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                     LazyCorr{m->corr[0].d, m->corr[1].d});
+                     LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0});
   LAUNCHCHK();
   m->uv_lazy = false;
+  m->w_fly_now = false;
+  if (m->w_stale) {   // the steps behind carried w inside their tendency kernels: the field itself, from the corrected velocities
+    m->w_stale = false;
+    return compute_w_impl(m);
+  }
   return GB25_OK;
 }
 // may this step leave u, v uncorrected in memory?  Flat lat-lon single domain, both look-aheads on and able to write
@@ -1793,6 +1807,14 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     LAUNCHCHK();
     m->uv_lazy = true;
     m->colsum_valid = false;
+    // w on the fly: the chunkings of the two tendency kernels must be the one the partial sums were made with
+    m->w_fly_now = m->w_fly && std::max(1, g.Nz / m->trc_chunk_levels) == mom_kchunks(m);
+    if (m->w_fly_now) {
+      hipLaunchKernelGGL(k_w_bases, grid2(g.Nx + 4, g.Ny + 4, b), b, 0, main, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
+                         LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0}, m->wbase);
+      LAUNCHCHK();
+      m->w_stale = true;
+    }
     for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);   // cache_previous_tendencies!
     m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
   } else if ((s = corrector_impl(m, true))) {
@@ -1804,7 +1826,7 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     const int which = (uv_fresh ? 0 : 1) | ((eta_halos_fresh && !complete) ? 0 : 2);
     if (which && (s = fill_halos_impl(m, true, false, which, 1))) return s;
   }
-  if ((s = compute_w_impl(m))) return s;
+  if (!(lazy && m->w_fly_now) && (s = compute_w_impl(m))) return s;
   // ---- join: the tendencies need w, u, v and T, S (the tracers) / the pressure differences (the momentum)
   const bool tracers_first = m->tracers_first != 0;
   if (tracers_first) {
@@ -2044,6 +2066,8 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     const size_t np = (size_t)4 * std::max(1, m->g.Nz / 6) * m->g.sx * m->g.sy_v;   // (room for chunks of 6 levels)
     HIPCHK(hipMalloc(&m->uv_partials, np * sizeof(real)));
     HIPCHK(hipMemset(m->uv_partials, 0, np * sizeof(real)));
+    HIPCHK(hipMalloc(&m->wbase, (np / 4) * sizeof(real)));
+    HIPCHK(hipMemset(m->wbase, 0, (np / 4) * sizeof(real)));
   }
   if ((s = alloc_field(m, m->corr[0], sx, m->f[GB25_BT_V].ny, 1))) return s;
   if ((s = alloc_field(m, m->corr[1], sx, m->f[GB25_BT_V].ny, 1))) return s;
@@ -2111,6 +2135,7 @@ void gb25_destroy(gb25_model* m) {
     for (Field* p : {&m->ahead[q], &m->ahead_uv[q], &m->ahead_G[q], &m->ahead_colsum[q]})
       if (p->d) hipFree(p->d);
   if (m->uv_partials) hipFree(m->uv_partials);
+  if (m->wbase) hipFree(m->wbase);
   for (auto p : m->d_ord)
     if (p) hipFree(p);
   for (auto p : m->d_H)
@@ -2713,6 +2738,7 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
       return GB25_OK;
     case GB25_OPT_LAZY_CORRECTOR: m->lazy_corrector = v != 0; return GB25_OK;
     case GB25_OPT_TRACERS_FIRST: m->tracers_first = v != 0; return GB25_OK;
+    case GB25_OPT_W_ON_THE_FLY: m->w_fly = v != 0; return GB25_OK;
     case GB25_OPT_MOMENTUM_CHUNK_LEVELS:
     case GB25_OPT_TRACER_CHUNK_LEVELS:
       if (v < 6 || v > 4096) return fail(m, GB25_ERR_INVALID_ARGUMENT, "chunk levels: 6 or more");
@@ -2754,6 +2780,7 @@ gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
     case GB25_OPT_MOMENTUM_CHUNK_LEVELS: *v = m->mom_chunk_levels; break;
     case GB25_OPT_TRACER_CHUNK_LEVELS: *v = m->trc_chunk_levels; break;
     case GB25_OPT_TRACERS_FIRST: *v = m->tracers_first; break;
+    case GB25_OPT_W_ON_THE_FLY: *v = m->w_fly; break;
     default: return GB25_ERR_INVALID_ARGUMENT;
   }
   return GB25_OK;

@@ -1598,6 +1598,41 @@ __global__ __launch_bounds__(256) void k_corrector_2d(Grid g, const real* __rest
   if (j == 0) store_x_images(g, du, o2 - g.sx, a, xw, xe);
   if (j == g.Ny - 1) store_x_images(g, du, o2 + g.sx, a, xw, xe);
 }
+// w at the first level of every chunk of levels of the tendency kernels, for w ON THE FLY (LazyCorr::wbase): from the chunk
+// integrals of u dz, v dz the momentum look-ahead left in P (of the uncorrected velocities: + du, dv times the chunk's
+// thickness), differenced like the continuity equation.  One thread per column of the range the momentum kernel's w tile
+// reaches: [-2, Nx + 2) x [-2, Ny + 2).  Halo columns are periodic images; in y the velocities hold one mirrored layer of u,
+// zero on and beyond the wall faces of v, zeros deeper -- as the fills leave them.
+// (w within a chunk then follows level by level inside the kernels: the association differs from k_compute_w's single
+// march up the column, results agree to round-off, not to the last bit.)
+__global__ __launch_bounds__(256) void k_w_bases(Grid g, const real* __restrict__ P, int kchunks, int plane2, LazyCorr lz,
+                                                 real* __restrict__ wbase) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 2, j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 2;
+  if (i >= g.Nx + 2 || j >= g.Ny + 2) return;
+  const long q = (long)kchunks * plane2;
+  const int klen = (g.Nz + kchunks - 1) / kchunks;
+  auto wrap = [&](int ii) { return ii < 0 ? ii + g.Nx : (ii >= g.Nx ? ii - g.Nx : ii); };
+  const int o2 = i2(g, i, j);
+  const bool urow = j >= -1 && j <= g.Ny;                       // rows whose u is not identically zero (interior + one layer)
+  const int ju = min(max(j, 0), g.Ny - 1);
+  const int ow = i2(g, wrap(i), ju), oe = i2(g, wrap(i + 1), ju);
+  const bool vs_ok = j >= 1 && j <= g.Ny - 1, vn_ok = j + 1 >= 1 && j + 1 <= g.Ny - 1;
+  const int os = i2(g, wrap(i), min(max(j, 0), g.Ny)), on = i2(g, wrap(i), min(max(j + 1, 0), g.Ny));
+  const real dxs = g.dxf[j], dxn = g.dxf[j + 1], raz = g.razc[j], dy = g.dy;
+  real w = real(0.);
+  wbase[o2] = w;
+  for (int c = 0; c + 1 < kchunks; c++) {
+    real Z = real(0.);
+    for (int k = c * klen; k < min(g.Nz, (c + 1) * klen); k++) Z += g.dzc[k];
+    const real* Pu = P + 2 * q + (long)c * plane2;
+    const real* Pv = P + 3 * q + (long)c * plane2;
+    const real ue = urow ? Pu[oe] + lz.du[oe] * Z : real(0.), uw = urow ? Pu[ow] + lz.du[ow] * Z : real(0.);
+    const real vn = vn_ok ? Pv[on] + lz.dv[on] * Z : real(0.), vs = vs_ok ? Pv[os] + lz.dv[os] * Z : real(0.);
+    const real div = (dy * ue - dy * uw) + (dxn * vn - dxs * vs);
+    w = w - div * raz;
+    wbase[(long)(c + 1) * plane2 + o2] = w;
+  }
+}
 // u += du, v += dv over the whole parent extent in x and y, levels -1 .. Nz: what the consumers saw becomes what memory holds
 __global__ __launch_bounds__(256) void k_apply_correction(Grid g, real* __restrict__ u, real* __restrict__ v, LazyCorr lz) {
   const int ip = blockIdx.x * blockDim.x + threadIdx.x, jp = blockIdx.y * blockDim.y + threadIdx.y;   // parent indices

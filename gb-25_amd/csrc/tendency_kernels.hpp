@@ -94,13 +94,18 @@ struct UvAhead {
 // as it is loaded -- tile elements (their du, dv are k-independent: registers) and the own column's vertical window.
 // DRAG: the quadratic bottom drag's flux boundary condition (Grid.bottom_flux) enters the first free level (an instance of its
 // own: the hook cost the default instances a few spilled registers)
-template <int MINW, int V2_TY, bool AHEAD, bool IMM, bool CURV = false, bool LAZY = false, bool DRAG = false>
+// WFLY (with LAZY): w is not read -- the thread that derives the divergence pieces DU, DV of a (c,c,c) point in phase 1 also
+// carries that point's w up the chunk, w(k+1) = w(k) - (DU + DV) / Az, and puts it into the w tile; w at the chunk's first
+// level comes from lz.wbase (k_w_bases).  Saves the 4.6 B per cell of the w tile and, with the tracer kernel doing the same,
+// the whole k_compute_w launch of a step.
+template <int MINW, int V2_TY, bool AHEAD, bool IMM, bool CURV = false, bool LAZY = false, bool DRAG = false, bool WFLY = false>
 __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     Grid g, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ w,
     const real* __restrict__ dpx, const real* __restrict__ dpy, real* __restrict__ Gu, real* __restrict__ Gv,
     TileCols tc, int kchunks, int nb, UvAhead next, LazyCorr lz) {
   static_assert(!CURV || IMM, "the curvilinear variant takes its orders from the tables");
   static_assert(!LAZY || (!IMM && !CURV), "the corrector is applied inside its consumers on the flat lat-lon grid only");
+  static_assert(!WFLY || LAZY, "w on the fly rides on the corrector inside its consumers");
   __shared__ MomentumLds<V2_TY> lds;
   __shared__ typename std::conditional<CURV, MomentumMetricLds<V2_TY>, NoLds>::type mt;
   __shared__ typename std::conditional<LAZY, MomentumCorrLds<V2_TY>, NoLds>::type cr;
@@ -193,8 +198,10 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     // (the bottom face k0 of the chunk is the top face of level k0-1; face 0 carries w = 0 whatever the order)
     if (IMM) level_orders(max(k0 - 1, 0));
     const real ax_m2 = CURV ? g.cv.azcc[om - 2] : Az, ax_m1 = CURV ? g.cv.azcc[om - 1] : Az, ax_p1 = CURV ? g.cv.azcc[om + 1] : Az;
-    real wu = sym_interp(s4f_xw, ax_m2 * w[o - 2], ax_m1 * w[o - 1], Az * w[o], ax_p1 * w[o + 1]);
-    real wv = sym_interp(s4f_yw, az_m2 * w[o - 2 * sx], az_m1 * w[o - sx], Az * w[o], az_p1 * w[o + sx]);
+    // (WFLY: w of the chunk's first level from the 2-D bases; face 0 carries w = 0)
+    const real* w0 = WFLY ? lz.wbase + (long)kc * lz.wplane + i2(g, ic_, jc_) : w + o;
+    real wu = sym_interp(s4f_xw, ax_m2 * w0[-2], ax_m1 * w0[-1], Az * w0[0], ax_p1 * w0[1]);
+    real wv = sym_interp(s4f_yw, az_m2 * w0[-2 * sx], az_m1 * w0[-sx], Az * w0[0], az_p1 * w0[sx]);
     fzu = wu * biased6<false>(ord, wu > real(0.), uz, uz, uz);
     fzv = wv * biased6<false>(ord, wv > real(0.), vz, vz, vz);
   }
@@ -263,9 +270,11 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
         ru[q] = at(ub, (unsigned)eu_off[q]);
         rv[q] = at(vb, (unsigned)eu_off[q]);
       }
+    if constexpr (!WFLY) {
 #pragma unroll
-    for (int q = 0; q < NEW; q++)
-      if (ew_off[q] >= 0) rw[q] = at(wb, (unsigned)ew_off[q]);
+      for (int q = 0; q < NEW; q++)
+        if (ew_off[q] >= 0) rw[q] = at(wb, (unsigned)ew_off[q]);
+    }
     rpw = at(dpx, oob);   // p'(i) - p'(i-1) and p'(j) - p'(j-1), differenced in fp64 by k_compute_p
     rps = at(dpy, oob);
   };
@@ -284,9 +293,11 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
           V0[eu_lds[q]] = rv[q];
         }
       }
+    if constexpr (!WFLY) {
 #pragma unroll
-    for (int q = 0; q < NEW; q++)
-      if (ew_off[q] >= 0) W0[ew_lds[q]] = CURV ? azw[q] * rw[q] : rw[q];
+      for (int q = 0; q < NEW; q++)
+        if (ew_off[q] >= 0) W0[ew_lds[q]] = CURV ? azw[q] * rw[q] : rw[q];
+    }
   };
   real sAu = real(0.), sAv = real(0.), sIu = real(0.), sIv = real(0.);   // AHEAD: this chunk's column sums
   // AHEAD with next.fold: does this tile hold cells with a periodic x image or a y layer to write?
@@ -306,6 +317,21 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     mdxc[tid] = g.dxc[j0 - 3 + tid];
     mdxf[tid] = g.dxf[j0 - 3 + tid];
     if (tid < MD_Y) mrazf[tid] = g.razf[j0 - 2 + tid];
+  }
+  // WFLY: this thread's (c,c,c) points of phase 1 (the same e = tid + q NT every level) carry their w; the w tile is the
+  // (c,c,c) tile without its first row / column and its last row
+  constexpr int NPT = (MD_X * MD_Y + NT - 1) / NT;
+  __shared__ real mrazc[WFLY ? MD_Y : 1];
+  real wk[NPT];
+  if constexpr (WFLY) {
+    if (tid < MD_Y) mrazc[tid] = g.razc[j0 - 3 + tid];
+#pragma unroll
+    for (int q = 0; q < NPT; q++) {
+      const int e = tid + q * NT, py = e / MD_X, px = e - py * MD_X;
+      // (clamped like the tiles: the last rows / columns of a ragged tile are never used)
+      const int gi = min(i0 - 3 + px, g.Nx + H - 1), gj = min(j0 - 3 + py, g.Ny + H - 1);
+      wk[q] = (e < MD_X * MD_Y) ? lz.wbase[(long)kc * lz.wplane + i2(g, gi, gj)] : real(0.);
+    }
   }
   fetch(k0, ob);
   stash(k0 & 1);
@@ -327,8 +353,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     }
     // ---- phase 1: derived quantities, once per point.  (row, column) of a point and the row metrics come from the
     // small LDS tables filled once per block: an integer division and five global loads per point and level otherwise
-    for (int e = tid; e < MD_X * MD_Y; e += NT) {
-      int py, px;
+    auto derive = [&](int e, int& py, int& px) -> real {   // returns the point's divergence piece DU + DV
       if constexpr (CURV) {
         py = e / MD_X;
         px = e - py * MD_X;
@@ -350,13 +375,34 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
         lds.VQ[py][px] = real(0.5) * (vw + vc);
       }
       // (c,c,c) point (i0-3+px, j0-3+py)
+      real du_, dv_;
       if constexpr (CURV) {
-        lds.DU[py][px] = mt.dyfc[py][px + 1] * dz * lds.U[par][py][px + 1] - mt.dyfc[py][px] * dz * lds.U[par][py][px];
-        lds.DV[py][px] = mt.dxcf[py + 1][px] * dz * lds.V[par][py + 1][px] - mt.dxcf[py][px] * dz * lds.V[par][py][px];
+        du_ = mt.dyfc[py][px + 1] * dz * lds.U[par][py][px + 1] - mt.dyfc[py][px] * dz * lds.U[par][py][px];
+        dv_ = mt.dxcf[py + 1][px] * dz * lds.V[par][py + 1][px] - mt.dxcf[py][px] * dz * lds.V[par][py][px];
       } else {
         const real Ax = dy * dz;
-        lds.DU[py][px] = Ax * lds.U[par][py][px + 1] - Ax * lds.U[par][py][px];
-        lds.DV[py][px] = mdxf[py + 1] * dz * lds.V[par][py + 1][px] - mdxf[py] * dz * lds.V[par][py][px];
+        du_ = Ax * lds.U[par][py][px + 1] - Ax * lds.U[par][py][px];
+        dv_ = mdxf[py + 1] * dz * lds.V[par][py + 1][px] - mdxf[py] * dz * lds.V[par][py][px];
+      }
+      lds.DU[py][px] = du_;
+      lds.DV[py][px] = dv_;
+      return du_ + dv_;
+    };
+    if constexpr (WFLY) {
+#pragma unroll
+      for (int q = 0; q < NPT; q++) {
+        const int e = tid + q * NT;
+        if (e < MD_X * MD_Y) {
+          int py, px;
+          const real div = derive(e, py, px);
+          wk[q] = wk[q] - div * mrazc[py];               // w on the top face of level k
+          if (py >= 1 && py <= MW_Y && px >= 1 && px <= MW_X) lds.W[par][py - 1][px - 1] = wk[q];
+        }
+      }
+    } else {
+      for (int e = tid; e < MD_X * MD_Y; e += NT) {
+        int py, px;
+        derive(e, py, px);
       }
     }
     __syncthreads();
@@ -628,7 +674,10 @@ struct Ab2Ahead {
 // LAZY: the barotropic correction of this step is added to u and v as they are loaded (see k_momentum_tendencies_v5).
 // ORD: 5 = WENO(order = 5) (baroclinic_instability_model); 7 = WENO(order = 7) (ClimaOcean's ocean_simulation): windows of
 // 2R = 8 values per face (R = 4), the order-5 path next to walls and the immersed boundary (biased8, device_common.hpp).
-template <bool AHEAD, bool IMM, bool FOLD, bool CURV = false, bool LAZY = false, int ORD = 5>
+// WFLY (with LAZY): w is not read; Az w on the top face follows from the divergence of the transports the lane holds anyway --
+// Az w(k+1) = Az w(k) - [(Axu(i+1) - Axu(i)) + (Ayn - Ays)], the east face's transport from the next lane -- starting from
+// lz.wbase at the chunk's first level (k_w_bases).  Continuity and advection then see the very same transports.
+template <bool AHEAD, bool IMM, bool FOLD, bool CURV = false, bool LAZY = false, int ORD = 5, bool WFLY = false>
 __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restrict__ u, const real* __restrict__ v,
                                             const real* __restrict__ w, const real* __restrict__ T,
                                             const real* __restrict__ S, real* __restrict__ GT, real* __restrict__ GS,
@@ -698,8 +747,10 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
 #pragma unroll
   for (int m = 0; m < 2 * R + 1; m++) cz[m] = v2(bload(bT, vo, CZ(m)), bload(bS, vo, CZ(m)));
   real2v fz;
+  real Azw_cur;                                // WFLY: Az w on the bottom face of the current level
   {
-    real Azw = Az * bload(bw, vo, cc);
+    real Azw = WFLY ? Az * lz.wbase[(long)kc * lz.wplane + om] : Az * bload(bw, vo, cc);
+    Azw_cur = Azw;
     int ord = zorder(k0 - kbt, Nzc);
     fz = Azw * recon(ord, Azw > real(0.), cz);
   }
@@ -715,7 +766,13 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
     const real Axu = dy * dz * (LAZY ? bload(bu, vo, cc) + du_l : bload(bu, vo, cc));
     const real Ays = dxf_s * dz * (LAZY ? bload(bv, vov, 0) + dv_s : bload(bv, vov, 0));
     const real Ayn = dxf_n * dz * (LAZY ? bload(bv, vov, sx * SZ) + dv_n : bload(bv, vov, sx * SZ));
-    const real Azw = Az * bload(bw, vo, cc + pc * SZ);
+    real Azw;
+    if constexpr (WFLY) {
+      Azw = Azw_cur - ((__shfl_down(Axu, 1) - Axu) + (Ayn - Ays));
+      Azw_cur = Azw;
+    } else {
+      Azw = Az * bload(bw, vo, cc + pc * SZ);
+    }
     real2v q[2 * R + 1];
 #pragma unroll
     for (int m = 0; m < 2 * R; m++) q[m] = v2(bload(bT, vo + m * SZ, (R * pc + R * sx) * SZ), bload(bS, vo + m * SZ, (R * pc + R * sx) * SZ));
@@ -772,14 +829,14 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
 #undef CY
 #undef CX
 }
-template <int MINW, bool AHEAD, bool IMM, bool FOLD = false, bool CURV = false, bool LAZY = false, int ORD = 5>
+template <int MINW, bool AHEAD, bool IMM, bool FOLD = false, bool CURV = false, bool LAZY = false, int ORD = 5, bool WFLY = false>
 __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, const real* __restrict__ u,
                                                               const real* __restrict__ v,
                                                               const real* __restrict__ w,
                                                               const real* __restrict__ T, const real* __restrict__ S,
                                                               real* __restrict__ GT, real* __restrict__ GS, int nbx,
                                                               int kchunks, int nb, Ab2Ahead next, LazyCorr lz) {
-  tracer_tile<AHEAD, IMM, FOLD, CURV, LAZY, ORD>(g, u, v, w, T, S, GT, GS, nbx, kchunks, next, xcd_remap(blockIdx.x, nb), lz);
+  tracer_tile<AHEAD, IMM, FOLD, CURV, LAZY, ORD, WFLY>(g, u, v, w, T, S, GT, GS, nbx, kchunks, next, xcd_remap(blockIdx.x, nb), lz);
 }
 
 // =============================================================================================

@@ -132,6 +132,13 @@ typedef enum {
                                     that the next step's pressure (it needs the tracer look-ahead's T, S) can run beside the next
                                     step's sub-cycle; 0: momentum first (src/precompile.jl:48-50 lists them in that order; the
                                     two evaluations are independent of each other) */
+  GB25_OPT_W_ON_THE_FLY,         /* [1] with LAZY_CORRECTOR, between the steps of one gb25_loop call: the tendency kernels do not read w;
+                                    they carry it up their chunks of levels from the divergence of the transports they hold, starting
+                                    from 2-D chunk bases made from the column integrals of the velocity look-ahead.  No k_compute_w
+                                    launch and no w traffic in those steps; the field w is recomputed from the velocities when the
+                                    call returns.  Like KERNELS this changes results in the LAST BITS (another association of the
+                                    vertical sum): comparisons that must be bit-exact (a decomposition against the single domain)
+                                    switch it off */
   GB25_OPT_COUNT
 } gb25_option;
 

@@ -120,7 +120,7 @@ def test_lookaheads_bitwise_at_full_size():
     benchmark size, where the concurrent kernels really do overlap for milliseconds: 8 steps, every prognostic field and
     tendency bit for bit."""
     a = fresh_model(ab2_lookahead=0)
-    b = fresh_model()
+    b = fresh_model(w_on_the_fly=0)        # (w on the fly changes the last bits by design)
     u0 = (1e-2 * counter_rng((NX, NY, NZ), 42, 1)).astype(np.float32)
     for m in (a, b):
         gb.set_baroclinic_instability(m)
@@ -144,7 +144,7 @@ def test_slabs_at_the_benchmark_size_bitwise():
     from gb25_amd.distributed import LocalSlabEnsemble
     names = ("u", "v", "w", "T", "S", "eta", "U", "V", "eta_bar", "U_bar", "V_bar", "Gn.u", "Gn.v", "Gn.T", "Gn.S",
              "Gm.u", "Gm.T", "Gn.U", "Gn.V")
-    single = fresh_model()
+    single = fresh_model(w_on_the_fly=0)   # (bit for bit: the slabs compute w with the stand-alone kernel)
     gb.set_baroclinic_instability(single)
     u0 = (1e-2 * counter_rng((NX, NY, NZ), 42, 1)).astype(np.float32)
     v0 = (1e-2 * counter_rng((NX, NY + 1, NZ), 42, 2)).astype(np.float32)

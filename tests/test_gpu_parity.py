@@ -329,7 +329,8 @@ def test_ab2_lookahead_is_bitwise_neutral():
     across everything that must invalidate the look-ahead: a changed dt, host writes into T / G, an Euler restart,
     phase-by-phase driving, and a handed-out device pointer."""
     a = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0, options=dict(ab2_lookahead=0))
-    on = dict(ab2_lookahead=1, subcycle_lookahead=1)      # (the sub-cycle look-ahead is off by default on grids this small)
+    # (the sub-cycle look-ahead is off by default on grids this small; w on the fly changes the last bits by design)
+    on = dict(ab2_lookahead=1, subcycle_lookahead=1, w_on_the_fly=0)
     b = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0, options=on)
     c = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0, options=on)   # will hand out its T pointer
     names = ALL_FIELDS
@@ -384,7 +385,7 @@ def test_lookaheads_are_bitwise_neutral_over_a_longer_run():
     partner buffers, the pointer exchanges and the work that runs beside the tendency kernels on the side stream must
     not change a bit (a missing stream dependency shows up here as a difference that comes and goes)."""
     a = gb.baroclinic_instability_model(gb.GPU(), 360, 180, 24, dt=600.0, options=dict(ab2_lookahead=0))
-    b = gb.baroclinic_instability_model(gb.GPU(), 360, 180, 24, dt=600.0, options=dict(subcycle_lookahead=1))
+    b = gb.baroclinic_instability_model(gb.GPU(), 360, 180, 24, dt=600.0, options=dict(subcycle_lookahead=1, w_on_the_fly=0))
     for m in (a, b):
         gb.set_baroclinic_instability(m)
         set_noisy_velocities(m, 0.05)
@@ -436,7 +437,7 @@ def test_fills_folded_into_their_producers_are_bitwise_neutral(shape, halo):
     models = []
     for fold in (0, 1):
         m = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=300.0, halo=(halo,) * 3,
-                                            options=dict(fold_fills=fold, subcycle_lookahead=1))
+                                            options=dict(fold_fills=fold, subcycle_lookahead=1, w_on_the_fly=0))
         gb.set_baroclinic_instability(m)
         set_noisy_velocities(m, 0.05)
         for n, seed in (("T", 5), ("u", 6), ("v", 7), ("eta", 8), ("V", 9)):
@@ -473,8 +474,8 @@ def test_schedule_options_are_bitwise_neutral(opts):
     look-ahead only) gives the bits of the default schedule, through a changed dt and an option flipped mid-run.  One
     launch per substep (subcycle_block = 1) is a different kernel that divides by the metrics where the blocked one
     multiplies by their reciprocals: equal to round-off."""
-    a = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0)
-    b = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0, options=opts)
+    a = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0, options=dict(w_on_the_fly=0))
+    b = gb.baroclinic_instability_model(gb.GPU(), 150, 70, 12, dt=600.0, options=dict(opts, w_on_the_fly=0))
     for k, v in opts.items():
         assert b.backend.get_option(k) == v
     for m in (a, b):
@@ -508,7 +509,7 @@ def test_the_corrector_inside_its_consumers_is_bitwise_neutral(shape, halo, floa
     models = []
     for lazy in (0, 1):
         m = gb.baroclinic_instability_model(gb.GPU(float_type=float_type), Nx, Ny, Nz, dt=300.0, halo=(halo,) * 3,
-                                            options=dict(lazy_corrector=lazy, subcycle_lookahead=1))
+                                            options=dict(lazy_corrector=lazy, subcycle_lookahead=1, w_on_the_fly=0))
         assert m.backend.get_option("lazy_corrector") == lazy
         gb.set_baroclinic_instability(m)
         set_noisy_velocities(m, 0.05)
@@ -562,3 +563,37 @@ def test_minimum_sizes_and_halos(shape, halo):
     bad = [(q["name"], q["rel"]) for q in report if not q["rel"] <= SQRT_EPS32]
     assert not bad, bad
 
+
+
+@pytest.mark.parametrize("float_type", ["Float32", "Float64"])
+@pytest.mark.parametrize("shape", [(150, 70, 24), (1440, 90, 48)])
+def test_w_on_the_fly_agrees_to_round_off(shape, float_type):
+    """Option w_on_the_fly (the default beside the lazy corrector): between the steps of one loop! call the tendency kernels
+    carry w up their chunks of levels themselves -- from the divergence of the transports they hold, starting from 2-D bases
+    made of the look-ahead's column integrals -- instead of reading the field a k_compute_w launch left.  Another association
+    of the same vertical sum: round-off, not bits.  After 25 steps every field agrees with the stand-alone path to a few
+    hundred ulps of its norm, the field w the call leaves behind included (it is recomputed from the final velocities), and
+    a constant tracer stays constant."""
+    Nx, Ny, Nz = shape
+    eps = float(np.finfo(np.float32 if float_type == "Float32" else np.float64).eps)
+    models = []
+    for fly in (0, 1):
+        m = gb.baroclinic_instability_model(gb.GPU(float_type=float_type), Nx, Ny, Nz, dt=300.0,
+                                            options=dict(w_on_the_fly=fly, subcycle_lookahead=1))
+        gb.set_baroclinic_instability(m)
+        set_noisy_velocities(m, 0.05)
+        m.set(S=np.full((Nx, Ny, Nz), 35.0, m.backend.dtype))       # a constant tracer
+        gb.first_time_step(m)
+        gb.loop(m, 24)
+        models.append(m)
+    a, b = models
+    assert b.backend.lookahead_state()[0]
+    for n in ALL_FIELDS:
+        if n in ("Gn.S", "Gm.S"):     # (round-off noise around zero on one side, exactly zero on the other: below)
+            continue
+        x, y = a.backend.get_field(n, True), b.backend.get_field(n, True)
+        assert rel(x, y) < 2000 * eps, (n, rel(x, y))
+    assert rel(a.backend.get_field("w", True), b.backend.get_field("w", True)) < 200 * eps
+    for m in (a, b):   # a constant tracer stays constant: continuity and advection see the same transports either way
+        assert np.abs(m.backend.get_field("Gn.S", False)).max() < 1e3 * eps * 35.0 * 1e-3
+        assert np.abs(m.backend.get_field("S", False) - 35.0).max() < 50 * eps * 35.0
