@@ -348,7 +348,9 @@ struct Buf {
 };
 __device__ __forceinline__ Buf make_buf(const real* p, long elems) {
   Buf b;
-  b.r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(elems * (long)sizeof(real)), 0x00020000);
+  // (num_records is a 32-bit byte count; a view never needs more than the planes a block touches)
+  const long bytes = elems * (long)sizeof(real);
+  b.r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(bytes < 0x7fffffffL ? bytes : 0x7fffffffL), 0x00020000);
   return b;
 }
 __device__ __forceinline__ float bload_(const Buf& b, int voff, int soff, float) {

@@ -1011,6 +1011,7 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
       if (part == 1) tc = TileCols{hi - 1, hi - 1, 1, 0};
       else tc = TileCols{1 + nbx - hi, 1, 0, hi};
     }
+    tc.cr = ChunkRange{0, kchunks, 0};
     nb = tc.n * nby * kchunks;
     // waves/SIMD the register allocator is held to: 4 (128 VGPRs) in fp32; fp64 operands are register pairs,
     // so the Float64 build asks for 2 (256 VGPRs) instead of spilling
@@ -1047,9 +1048,29 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
               : g.cv.on ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true, true>)
               : m->immersed ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true>)
                             : (ahead ? k_momentum_tendencies_v5<MW, TYm, true, false> : k_momentum_tendencies_v5<MW, TYm, false, false>);
-    if (nb > 0)
-      hipLaunchKernelGGL(k5, dim3(nb), dim3(V2_TX, TYm), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                         m->f[GB25_W].d, m->dpx.d, m->dpy.d, m->f[GB25_GN_U].d, m->f[GB25_GN_V].d, tc, kchunks, nb, nx, lz);
+    if (nb > 0) {
+      // The kernel's per-lane offsets are 32-bit BYTE offsets from the array pointers.  An array beyond that reach (4.4 GB per
+      // field for config 5 as one domain) takes several launches, each a run of chunks of levels whose planes -- stencil and
+      // halo layers included -- lie within 2 GB of pointers rebased by `kofs` planes.  Normally: one launch, kofs = 0.
+      const int klen = (g.Nz + kchunks - 1) / kchunks;
+      const double plane_bytes = (double)g.pl_v * sizeof(real), reach = 2147483648.0;
+      const bool small = (double)m->f[GB25_W].elems() * sizeof(real) < reach;
+      for (int c0 = 0; c0 < kchunks;) {
+        // the lowest plane a run starting with chunk c0 touches: three levels below its first one, or a bottom halo layer
+        const int kofs = small ? 0 : std::max(0, c0 * klen + g.H - 4);
+        int c1 = c0 + 1;   // (a run takes every following chunk whose highest plane -- window, w, top halo layer -- is within reach)
+        while (c1 < kchunks && (std::min(g.Nz, (c1 + 1) * klen) + g.H + 5 - kofs) * plane_bytes < reach) c1++;
+        tc.cr = ChunkRange{c0, c1 - c0, kofs};
+        const long oc_ = (long)g.pl_c * kofs, ov_ = (long)g.pl_v * kofs;
+        UvAhead nr = nx;
+        if (ahead) { nr.GmU += oc_; nr.GmV += ov_; nr.un += oc_; nr.vn += ov_; }
+        const int nbr = tc.n * nby * (c1 - c0);
+        hipLaunchKernelGGL(k5, dim3(nbr), dim3(V2_TX, TYm), 0, m->stream, g, m->f[GB25_U].d + oc_, m->f[GB25_V].d + ov_,
+                           m->f[GB25_W].d + oc_, m->dpx.d + oc_, m->dpy.d + oc_, m->f[GB25_GN_U].d + oc_, m->f[GB25_GN_V].d + ov_,
+                           tc, kchunks, nbr, nr, lz);
+        c0 = c1;
+      }
+    }
     t.stop();   // the timer covers the tendency kernel alone
     if (ahead && part != 1) {
       dim3 b(64, 4);
@@ -1969,13 +1990,16 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   m->slab = cfg->nranks > 1 || cfg->slab_mode == 1;
   if (m->Nx < cfg->halo) return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab narrower than the halo");
   {
-    // the kernels address a parent array with 32-bit element indices and 32-bit byte offsets (buffer addressing)
-    const double bytes = (double)(m->Nx + 2 * cfg->halo) * (cfg->Ny + 2 * cfg->halo + 1) * (cfg->Nz + 2 * cfg->halo + 1) *
-                         sizeof(real);
-    if (bytes >= 2147483648.0)
+    // The kernels address a parent array with 32-bit ELEMENT indices; the tendency kernels with 32-bit BYTE offsets from the
+    // first plane their block touches (tendency_kernels.hpp): a chunk of levels plus its stencil planes must stay below 2 GB.
+    const double plane = (double)(m->Nx + 2 * cfg->halo) * (cfg->Ny + 2 * cfg->halo + 1);
+    const double elems = plane * (cfg->Nz + 2 * cfg->halo + 1);
+    const int kchunks = std::max(1, cfg->Nz / 12), klen = (cfg->Nz + kchunks - 1) / kchunks;
+    if (elems >= 2147483648.0 || plane * (klen + 10) * sizeof(real) >= 2147483648.0)
       return fail(m, GB25_ERR_INVALID_ARGUMENT,
-                  "a %dx%dx%d slab needs %.1f GB per 3-D array; the kernels address at most 2 GB per array: decompose "
-                  "in x (nranks) so that the local slab is narrower", m->Nx, cfg->Ny, cfg->Nz, bytes / 1e9);
+                  "a %dx%dx%d slab has %.2g elements per 3-D array (%.1f GB) and %.2g per plane; the kernels index at most 2^31 "
+                  "elements per array and %d planes of 2 GB together: decompose in x (nranks) so that the local slab is narrower",
+                  m->Nx, cfg->Ny, cfg->Nz, elems, elems * sizeof(real) / 1e9, plane, klen + 10);
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)

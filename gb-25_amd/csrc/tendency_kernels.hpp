@@ -66,8 +66,14 @@ struct MomentumCorrLds {
 // a decomposition launches its interior tile columns (which read own columns only) while the x-halo bundle is still
 // travelling, and the edge columns {0} + {last} afterwards (interior_tendency_kernel_parameters +
 // complete_communication_and_compute_buffer!, GB-25 src/precompile.jl:67,72): same tiles, same arithmetic, same bits.
+// ... and which chunks of levels: [first, first + count) of the kchunks chunks, with the array pointers rebased by kofs planes
+// (arrays beyond 4 GB take two or more launches; one launch with kofs = 0 otherwise).
+struct ChunkRange {
+  int first, count, kofs;
+};
 struct TileCols {
   int n, nlead, bx0, bx1;
+  ChunkRange cr;
 };
 __device__ __forceinline__ int tile_column(const TileCols& tc, int q) { return q < tc.nlead ? tc.bx0 + q : tc.bx1 + (q - tc.nlead); }
 
@@ -112,7 +118,8 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   constexpr int MU_Y = V2_TY + 6, MW_Y = V2_TY + 3, MD_Y = V2_TY + 5;
   const int L = xcd_remap(blockIdx.x, nb);
   const int r = L / tc.n, bx = tile_column(tc, L - r * tc.n);
-  const int kc = r % kchunks, by = r / kchunks;
+  const ChunkRange cr_ = tc.cr;                       // (the chunks of levels this launch covers: all of them, normally)
+  const int kc = cr_.first + r % cr_.count, by = r / cr_.count;
   const int klen = (g.Nz + kchunks - 1) / kchunks;
   const int k0 = kc * klen, k1 = min(g.Nz, k0 + klen);
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * V2_TX + tx;
@@ -164,7 +171,10 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   };
 
   // threads of a ragged edge tile work on a clamped (duplicate) column so that every address stays in bounds
-  int o = ic(g, ic_, jc_, k0), ov = iv(g, ic_, jc_, k0);
+  // Arrays beyond 4 GB (config 5 as one domain: 4.4 GB per field): the per-lane offsets are 32-bit BYTE offsets, so the host
+  // hands such a launch array pointers rebased by `kofs` planes and a sub-range of the chunks of levels that stays within
+  // reach of them (momentum_impl); plane indices below count from the rebased pointers.  kofs = 0 otherwise.
+  int o = ic(g, ic_, jc_, k0 - cr_.kofs), ov = iv(g, ic_, jc_, k0 - cr_.kofs);
   // (uniform base pointer + 32-bit per-lane byte offset: the accesses take the scalar-base addressing form and need no
   // 64-bit address arithmetic per lane; the own cell's byte offsets ob / obv serve every centre- / v-shaped array)
   auto at = [](const real* base, unsigned byte_off) {
@@ -261,9 +271,9 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   // (uniform base pointer + 32-bit per-lane byte offset: the loads take the scalar-base addressing form and need no
   // 64-bit address arithmetic per lane)
   auto fetch = [&](int k, unsigned oob) {   // oob: byte offset of the own cell at level k
-    const real* ub = u + (tile_u + pc * (k + H));
-    const real* vb = v + (tile_u + pv * (k + H));
-    const real* wb = w + (tile_w + pc * (k + 1 + H));
+    const real* ub = u + (tile_u + pc * (k + H - cr_.kofs));
+    const real* vb = v + (tile_u + pv * (k + H - cr_.kofs));
+    const real* wb = w + (tile_w + pc * (k + 1 + H - cr_.kofs));
 #pragma unroll
     for (int q = 0; q < NEU; q++)
       if (eu_off[q] >= 0) {
@@ -722,19 +732,23 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
   // buffer views (device_common.hpp): one per-lane byte offset for the centre-shaped arrays, one for v
   constexpr int SZ = (int)sizeof(real);
   const long nzp = g.Nz + 2 * g.H;
-  const Buf bT = make_buf(T, pc * nzp), bS = make_buf(S, pc * nzp), bu = make_buf(u, pc * nzp),
-            bw = make_buf(w, pc * (nzp + 1)), bv = make_buf(v, pv * nzp), bGT = make_buf(GT, pc * nzp),
-            bGS = make_buf(GS, pc * nzp);
+  // (arrays beyond 2 GB: the descriptors start at the plane of the stencil's lowest corner, level k0 - R, and the per-lane
+  // byte offsets count from there: a chunk of levels spans (levels + 2R + 1) planes)
+  const long pb = k0 + g.H - R;                 // first plane of the views (>= 0: H >= R)
+  const Buf bT = make_buf(T + pc * pb, pc * (nzp - pb)), bS = make_buf(S + pc * pb, pc * (nzp - pb)),
+            bu = make_buf(u + pc * pb, pc * (nzp - pb)), bw = make_buf(w + pc * pb, pc * (nzp + 1 - pb)),
+            bv = make_buf(v + pv * (pb + R), pv * (nzp - pb - R)), bGT = make_buf(GT + pc * pb, pc * (nzp - pb)),
+            bGS = make_buf(GS + pc * pb, pc * (nzp - pb));
   Buf bGmT = bT, bGmS = bT, bTn = bT, bSn = bT;
   if (AHEAD) {
-    bGmT = make_buf(next.GmT, pc * nzp); bGmS = make_buf(next.GmS, pc * nzp);
-    bTn = make_buf(next.Tn, pc * nzp);   bSn = make_buf(next.Sn, pc * nzp);
+    bGmT = make_buf(next.GmT + pc * pb, pc * (nzp - pb)); bGmS = make_buf(next.GmS + pc * pb, pc * (nzp - pb));
+    bTn = make_buf(next.Tn + pc * pb, pc * (nzp - pb));   bSn = make_buf(next.Sn + pc * pb, pc * (nzp - pb));
   }
   // lanes past the east edge work on a clamped (duplicate) column.  `vo` addresses the (-3,-3,-3) corner of the
   // cell's stencil so that every displacement below is a non-negative byte count (needs H >= 3, as WENO5 does).
   const int cc = (R * pc + R * sx + R) * SZ;                    // corner -> cell
-  int vo = (ic(g, min(i, g.Nx), j, k0)) * SZ - cc;
-  int vov = iv(g, min(i, g.Nx), j, k0) * SZ;
+  int vo = ic(g, min(i, g.Nx), j, R - g.H) * SZ - cc;   // (level k0 is plane R of the views)
+  int vov = iv(g, min(i, g.Nx), j, -g.H) * SZ;           // (... and plane 0 of v's)
 #define CZ(m) (((m) * pc + R * sx + R) * SZ)                     // (0, 0, m-R)
 #define CY(m) ((R * pc + (m) * sx + R) * SZ)                     // (0, m-R, 0)
 #define CX(m) ((R * pc + R * sx) * SZ), ((m) * SZ)               // (m-R, 0, 0): uniform part, immediate part
@@ -890,11 +904,13 @@ __device__ __forceinline__ void tracer_tile_single(const Grid& g, const real* __
   const int Nzc0 = g.Nz - kbt[0], Nzc1 = g.Nz - kbt[1];
   constexpr int SZ = (int)sizeof(real);
   const long nzp = g.Nz + 2 * g.H;
-  const Buf bE = make_buf(E, pc * nzp), bu = make_buf(u, pc * nzp), bw = make_buf(w, pc * (nzp + 1)), bv = make_buf(v, pv * nzp),
-            bG = make_buf(GE, pc * nzp);
+  const long pb = k0 + g.H - R;                 // (views from the plane of the stencil's lowest corner: see tracer_tile)
+  const Buf bE = make_buf(E + pc * pb, pc * (nzp - pb)), bu = make_buf(u + pc * pb, pc * (nzp - pb)),
+            bw = make_buf(w + pc * pb, pc * (nzp + 1 - pb)), bv = make_buf(v + pv * (pb + R), pv * (nzp - pb - R)),
+            bG = make_buf(GE + pc * pb, pc * (nzp - pb));
   const int cc = (R * pc + R * sx + R) * SZ;
-  int vo0 = ic(g, c0, j, k0) * SZ - cc, vo1 = ic(g, c1, j, k0) * SZ - cc;
-  int vv0 = iv(g, c0, j, k0) * SZ, vv1 = iv(g, c1, j, k0) * SZ;
+  int vo0 = ic(g, c0, j, R - g.H) * SZ - cc, vo1 = ic(g, c1, j, R - g.H) * SZ - cc;
+  int vv0 = iv(g, c0, j, -g.H) * SZ, vv1 = iv(g, c1, j, -g.H) * SZ;
   auto ld2 = [&](const Buf& b, int a0, int a1, int so) { return v2(bload(b, a0, so), bload(b, a1, so)); };
   auto zorder = [](int f, int N) { return ORD == 7 ? biased_order_face7(f, N) : biased_order_face(f, N); };
   auto ord3 = [](int k, int K7_, int K5_, int K3_) { return ORD == 7 ? order_from7(k, K7_, K5_, K3_) : order_from(k, K5_, K3_); };
