@@ -64,6 +64,27 @@ def measured_traffic(kernel, size, prefer=None):
     return None, None
 
 
+def measured_valu_instructions(kernel, size, prefer=None):
+    """Wave-level VALU instructions per launch of `kernel` (SQ_INSTS_VALU of the committed `rocprofv3 --pmc` pass,
+    profiles/r*_pmc_sq.csv; only files of this grid size are named so).  None when no such measurement is committed."""
+    import csv
+    import glob
+    if tuple(size) != (1440, 720, 48):
+        return None, None
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.csv")))):
+        try:
+            prefix = KERNEL_SYMBOL.get(kernel, kernel)
+            rows = [r for r in csv.DictReader(open(f)) if r["Counter"] == "SQ_INSTS_VALU" and r["Kernel"].startswith(prefix)]
+            if prefer:
+                rows = [r for r in rows if r["Kernel"].endswith(tuple(prefer))] or rows
+            if rows:
+                best = max(rows, key=lambda r: int(float(r["Launches"])))
+                return float(best["MeanValue"]), os.path.basename(f)
+        except Exception:
+            pass
+    return None, None
+
+
 def counter_rng(shape, seed, salt):
     n = int(np.prod(shape))
     with np.errstate(over="ignore"):
@@ -316,12 +337,27 @@ def main():
                     and b.get_option("ab2_lookahead") == 1 and b.get_option("fold_fills") and b.get_option("two_streams"))
             if lazy and "ab2_velocities" not in kernels:
                 alg["momentum"] += 4 * 4
+                if b.get_option("w_on_the_fly"):
+                    alg["momentum"] -= 4      # ... and w is not read: carried up the chunk from the divergence (a10: 4R + 1W -> 3R + 1W)
+                    alg["tracers"] -= 4
             bytes_per_launch = alg[dom] * cells
             achieved = bytes_per_launch / (timed[dom]["avg_ms"] * 1e-3) / 1e9
-            traffic, traffic_src = measured_traffic(dom, (locNx, Ny, Nz), prefer=(", true, false>", ", true>") if (lazy and dom == "momentum") else None)
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            # (the template instance the timed loop runs: ..., LAZY, DRAG, WFLY> = "true, false, true>" with w on the fly)
+            inst = (", true, false, true>", ", true, false, false>", ", true, false>", ", true>") if (lazy and dom == "momentum") else None
+            traffic, traffic_src = measured_traffic(dom, (locNx, Ny, Nz), prefer=inst)
+            # What bounds the kernel: the tendency kernels are VALU-issue bound -- a wave64 fp32 VALU instruction occupies its
+            # SIMD for 4 cycles (profiles/r03_valu_rate_noslp.txt), so the ceiling is 1024 SIMDs x 2.4 GHz / 4 instructions/s;
+            # valu_frac = committed SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x 2.4 GHz x the live launch time).
+            # `achieved` / `frac` stay the contract's algorithmic-bytes numbers; `traffic_frac` is what the kernel really pulls.
+            insts, insts_src = measured_valu_instructions(dom, (locNx, Ny, Nz), prefer=inst)
+            valu_frac = (insts * 4.0 / (1024 * 2.4e9) / (timed[dom]["avg_ms"] * 1e-3)) if insts else None
+            bound = "valu" if (valu_frac is not None and traffic is not None and
+                               valu_frac > traffic / (timed[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) else "hbm"
+            out["roofline"] = {"bound": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "traffic_source": traffic_src,
+                               "valu_frac": valu_frac, "valu_instructions_per_launch": insts, "valu_source": insts_src,
+                               "valu_peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction",
                                # what the kernel really pulls from HBM (PMC bytes / live launch time): the tendency
                                # kernels are VALU-issue bound, the fused rows make `achieved` exceed this
                                "traffic_GBps": (traffic / (timed[dom]["avg_ms"] * 1e-3) / 1e9) if traffic else None,
