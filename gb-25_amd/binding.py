@@ -85,7 +85,7 @@ class Config(C.Structure):
         ("lat_south", C.c_double), ("lat_north", C.c_double), ("lon_west", C.c_double), ("lon_east", C.c_double),
         ("depth", C.c_double), ("zexp_h", C.c_double),
         ("g", C.c_double), ("Omega", C.c_double), ("radius", C.c_double), ("rho0", C.c_double),
-        ("slab_mode", C.c_int32), ("grid_type", C.c_int32),
+        ("slab_mode", C.c_int32), ("grid_type", C.c_int32), ("ranks_y", C.c_int32),
     ]
 
 
@@ -227,6 +227,11 @@ class HipBackend:
                 self.lib.gb25_destroy(self.h)
                 self.h = None
             raise GB25Error(f"gb25_create: status {st}: {msg}")
+        # Partition(Rx, Ry, 1): rank = ry Rx + rx owns Nx / Rx columns and Ny / Ry rows
+        self.Ry = max(1, int(cfg.ranks_y))
+        self.Rx = cfg.nranks // self.Ry
+        self.rx, self.ry = cfg.rank % self.Rx, cfg.rank // self.Rx
+        self.Nx_local, self.Ny_local = cfg.Nx // self.Rx, cfg.Ny // self.Ry
         self._keep = []            # ctypes callbacks handed to the library
         for k, v in (options or {}).items():
             self.set_option(k, v)
@@ -332,7 +337,7 @@ class HipBackend:
             self._call("gb25_set_prescribed_atmosphere", f, None)
             return
         H = self.cfg.halo
-        a = np.ascontiguousarray(np.asarray(values, np.float64).reshape(self.cfg.Nx // self.cfg.nranks + 2 * H, self.cfg.Ny + 2 * H).T)
+        a = np.ascontiguousarray(np.asarray(values, np.float64).reshape(self.Nx_local + 2 * H, self.Ny_local + 2 * H).T)
         self._call("gb25_set_prescribed_atmosphere", f, a.ctypes.data_as(C.c_void_p))
 
     def compute_atmosphere_ocean_fluxes(self):
@@ -353,7 +358,7 @@ class HipBackend:
     def metric2(self, name):
         """One horizontal metric of a curvilinear grid (grid_type >= 2): (Nx + 2H, Ny + 2H + 1) float64, [i, j]."""
         H = self.cfg.halo
-        shape = (self.cfg.Ny + 2 * H + 1, self.cfg.Nx // self.cfg.nranks + 2 * H)
+        shape = (self.Ny_local + 2 * H + 1, self.Nx_local + 2 * H)
         out = np.empty(shape, np.float64)
         self._call("gb25_get_metric2", METRIC2_IDS.index(name), out.ctypes.data_as(C.POINTER(C.c_double)), out.size)
         return out.T

@@ -74,6 +74,11 @@ struct Grid {
   int pl_c, pl_v;         // plane strides      = sx*(Ny+2H), sx*(Ny+2H+1)
   int sy_c, sy_v;         // parent y extents
   int x_periodic;         // 1: single slab, x halos are filled by local periodic copy
+  // y: local row indices of the GLOBAL southern and northern wall faces.  Single domain and x slabs: 0 and Ny.  A rank of a
+  // 2-D (x, y) decomposition owns the rows [j0, j0 + Ny) of the global grid: jws = -j0, jwn = Ny_global - j0, so that every
+  // wall test and every wall-adjacent order reduction is the global one wherever it is evaluated (halo rows included); a side
+  // without a wall gets its halo rows from the neighbour.  Folded grid: no northern wall, jwn = 1 << 20.
+  int jws, jwn;
   real dy, g, rho0, Lz;
   // metric tables, pointers are pre-offset so that index 0 is the first interior cell/face
   const real *dxc, *dxf, *azc, *azf, *fcor, *phic;  // by j   (valid j: -H-2 .. Ny+H+2)

@@ -38,6 +38,11 @@ struct EventPair {
 struct gb25_model {
   gb25_config cfg;
   int Nx = 0;  // local slab width
+  // 2-D (x, y) decomposition, Partition(Rx, Ry, 1) of the reference (sharding/sharded_baroclinic_instability_simulation_run.jl:
+  // 65-72): rank = ry Rx + rx owns the columns [rx Nx, (rx + 1) Nx) and the rows [j0, j0 + Ny) of the global grid.  Ry = 1: x slabs.
+  int Ny = 0;  // local rows (cfg.Ny / Ry)
+  int Rx = 1, Ry = 1, rx = 0, ry = 0, j0 = 0;
+  bool ys_open = false, yn_open = false;   // a southern / northern neighbour rank exists (no wall on that side)
   Grid g;
   Field f[GB25_FIELD_COUNT];
   Field pp[3];                   // ping-pong partners of eta, U, V
@@ -90,7 +95,7 @@ struct gb25_model {
   // work arrays of the sub-cycle: widened by W columns either side on a slab (wide halos, filled once per step), tall by Wy
   // rows beyond the pivot row on a folded grid (images of the rows south of it, filled once per step); a single folded
   // domain has W = 0
-  int W = 0, Wy = 0;
+  int W = 0, Wy = 0, Wys = 0;        // (Wys: rows below row 0 -- the southern neighbour's, 2-D decomposition)
   real* tall_buf = nullptr;          // single folded domain: the buffer its image rows pass through (k_tall_rows)
   Field wide[2][3];  // [pingpong][eta,U,V]
   Field wideG[2];    // GU, GV
@@ -138,7 +143,7 @@ struct gb25_model {
   // immersed boundary (GridFittedBottom): first active level per column on the columns [-kb_E, Nx + kb_E) x [0, Ny)
   // (host), the folded tables of device_common.hpp (device), the depths of the wide barotropic arrays of a slab
   bool immersed = false;             // some cell is immersed: the IMM kernel variants run
-  int kb_E = 0;
+  int kb_E = 0, kb_Ey = 0;           // (kbot: pitch Nx + 2 kb_E, row of local row j: j + kb_Ey)
   std::vector<int> kbot;
   unsigned* d_ord[4] = {nullptr, nullptr, nullptr, nullptr};
   real* d_H[4] = {nullptr, nullptr, nullptr, nullptr};   // Hfc, Hcf, rHfc, rHcf (parent layout of a (c,f) field)
@@ -275,20 +280,22 @@ gb25_status upload_table(gb25_model* m, const std::vector<double>& h, int off, c
 
 gb25_status build_grid(gb25_model* m) {
   const gb25_config& c = m->cfg;
-  const int H = c.halo, Ny = c.Ny, Nz = c.Nz;
-  const int nj = Ny + 2 * H + 2 * PAD + 2, nk = Nz + 2 * H + 2 * PAD + 2;
-  const int offj = H + PAD, offk = H + PAD;  // table index of 0-based logical index 0
+  const int H = c.halo, Ny = m->Ny, Nz = c.Nz;
+  // (the row tables of a rank of a 2-D decomposition also cover the rows its sub-cycle is widened by)
+  const int padj = PAD + (m->Ry > 1 ? c.substeps + 2 + H + 8 : 0);
+  const int nj = Ny + 2 * H + 2 * padj + 2, nk = Nz + 2 * H + 2 * PAD + 2;
+  const int offj = H + padj, offk = H + PAD;  // table index of 0-based logical index 0
   m->metric_off_j = offj;
   m->metric_off_k = offk;
   const double d2r = M_PI / 180.0;
-  const double dlam = (c.lon_east - c.lon_west) / c.Nx, dphi = (c.lat_north - c.lat_south) / Ny, R = c.radius;
+  const double dlam = (c.lon_east - c.lon_west) / c.Nx, dphi = (c.lat_north - c.lat_south) / c.Ny, R = c.radius;
   std::vector<double>&phif = m->h_metric[GB25_M_PHIF], &phic = m->h_metric[GB25_M_PHIC],
   &dxc = m->h_metric[GB25_M_DXC], &dxf = m->h_metric[GB25_M_DXF], &azc = m->h_metric[GB25_M_AZC],
   &azf = m->h_metric[GB25_M_AZF], &fcor = m->h_metric[GB25_M_FCOR];
   phif.assign(nj, 0); phic.assign(nj, 0); dxc.assign(nj, 0); dxf.assign(nj, 0);
   azc.assign(nj, 0); azf.assign(nj, 0); fcor.assign(nj, 0);
   for (int a = 0; a < nj; a++) {
-    int j = a - offj;  // 0-based face / centre index
+    int j = a - offj + m->j0;  // 0-based GLOBAL face / centre index
     phif[a] = c.lat_south + j * dphi;
     phic[a] = c.lat_south + (j + 0.5) * dphi;
   }
@@ -327,6 +334,8 @@ gb25_status build_grid(gb25_model* m) {
   g.sy_c = Ny + 2 * H; g.sy_v = Ny + 2 * H + 1;
   g.pl_c = g.sx * g.sy_c; g.pl_v = g.sx * g.sy_v;
   g.x_periodic = !m->slab;
+  g.jws = -m->j0;
+  g.jwn = c.grid_type >= GB25_GRID_TRIPOLAR ? (1 << 20) : c.Ny - m->j0;
   g.dy = (real)(R * dphi * d2r);
   g.g = (real)c.g; g.rho0 = (real)c.rho0; g.Lz = (real)(zint[Nz] - zint[0]);
   gb25_status s;
@@ -420,7 +429,7 @@ void curv_metrics_own(const gb25_model* m, int ig, int j, double out[GB25_M2_COU
     return;
   }
   if (!tri) {
-    const int a = m->metric_off_j + j;
+    const int a = m->metric_off_j + j - m->j0;   // (the row tables are indexed by LOCAL row)
     out[GB25_M2_DXFC] = out[GB25_M2_DXCC] = m->h_metric[GB25_M_DXC][a];
     out[GB25_M2_DXCF] = out[GB25_M2_DXFF] = m->h_metric[GB25_M_DXF][a];
     out[GB25_M2_DYFC] = out[GB25_M2_DYCC] = out[GB25_M2_DYCF] = out[GB25_M2_DYFF] = R * dphi * d2r;
@@ -486,16 +495,17 @@ void curv_metrics_at(const gb25_model* m, int ig, int j, double out[GB25_M2_COUN
 // (device_common.hpp, Curv).
 gb25_status build_curv_grid(gb25_model* m) {
   const gb25_config& c = m->cfg;
-  const int Nx = m->Nx, Ny = c.Ny, H = c.halo, sx = Nx + 2 * H, sy = Ny + 2 * H + 1;
+  const int Nx = m->Nx, Ny = m->Ny, H = c.halo, sx = Nx + 2 * H, sy = Ny + 2 * H + 1;
   const size_t n2 = (size_t)sx * sy;
-  const bool tri = c.grid_type >= GB25_GRID_TRIPOLAR;
+  // (the fold is the northern edge of the top row of ranks only)
+  const bool tri = c.grid_type >= GB25_GRID_TRIPOLAR && !m->yn_open;
   for (auto& a : m->h_curv) a.assign(n2, 0.0);
   auto at = [&](int id) -> std::vector<double>& { return m->h_curv[id]; };
   for (int j = -H; j <= Ny + H; j++)
     for (int i = -H; i < Nx + H; i++) {
       const size_t o = (size_t)(i + H) + (size_t)sx * (j + H);
       double v[GB25_M2_COUNT];
-      curv_metrics_at(m, i + c.rank * Nx, j, v, nullptr, nullptr);
+      curv_metrics_at(m, i + m->rx * Nx, j + m->j0, v, nullptr, nullptr);
       // (numbers of the model's float type, as a host's grid holds them: reciprocals below are those of the rounded values, so
       // that what gb25_get_metric2 hands out, fed back through gb25_set_curvilinear_grid, is the same grid to the last bit)
       for (int q = 0; q < GB25_M2_COUNT; q++) at(q)[o] = (double)(real)v[q];
@@ -537,15 +547,15 @@ gb25_status build_curv_grid(gb25_model* m) {
 // way, so that a decomposition reads the very numbers the single domain reads.
 gb25_status build_curv_wide(gb25_model* m) {
   const gb25_config& c = m->cfg;
-  const int Nx = m->Nx, Ny = c.Ny, H = c.halo, W = m->W, wsx = Nx + 2 * W, sy = Ny + 2 * H + 1 + m->Wy;
+  const int Nx = m->Nx, Ny = m->Ny, H = c.halo, W = m->W, wsx = Nx + 2 * W, sy = Ny + 2 * H + 1 + m->Wy + m->Wys;
   auto wrap = [&](int ig) { return ((ig % c.Nx) + c.Nx) % c.Nx; };
   std::vector<real> t[5];
   for (auto& a : t) a.assign((size_t)wsx * sy, real(0.));
-  for (int j = -H; j <= Ny + H + m->Wy; j++)
+  for (int j = -H - m->Wys; j <= Ny + H + m->Wy; j++)
     for (int i = -W; i < Nx + W; i++) {
-      const size_t o = (size_t)(i + W) + (size_t)wsx * (j + H);
+      const size_t o = (size_t)(i + W) + (size_t)wsx * (j + H + m->Wys);
       double v[GB25_M2_COUNT];
-      curv_metrics_at(m, wrap(i + c.rank * Nx), j, v, nullptr, nullptr);
+      curv_metrics_at(m, wrap(i + m->rx * Nx), j + m->j0, v, nullptr, nullptr);
       t[0][o] = (real)v[GB25_M2_DYFC];
       t[1][o] = (real)v[GB25_M2_DXCF];
       t[2][o] = (real)(1.0 / (double)(real)v[GB25_M2_AZCC]);
@@ -633,17 +643,20 @@ void build_substeps(gb25_model* m) {
 }
 
 // GridFittedBottom(bottom_height) -> first active level per column -> the folded tables (device_common.hpp, Immersed).
-// zb(i, j): bottom height at the centre of LOCAL column i (any i in [-E, Nx + E)), row j in [0, Ny).
+// zb(i, j): bottom height at the centre of LOCAL column i (any i in [-E, Nx + E)), GLOBAL row j in [0, Ny_global).
 // Restated from Oceananigans.ImmersedBoundaries [UPSTREAM-UNVERIFIED]; oracle/gb25_oracle.c states the same rules cell
 // by cell (inactive_cell / stencil_active) and tests/test_gpu_immersed.py compares the two.
 template <class ZB>
 gb25_status build_bottom(gb25_model* m, ZB zb) {
   const gb25_config& c = m->cfg;
-  const int Nx = m->Nx, Ny = c.Ny, Nz = c.Nz, H = c.halo, offk = m->metric_off_k;
+  const int Nx = m->Nx, Ny = m->Ny, Nz = c.Nz, H = c.halo, offk = m->metric_off_k, j0 = m->j0;
   const int E = std::max(H, m->W) + 4, ksx = Nx + 2 * E;
+  // (rows: the own ones and, on a rank of a 2-D decomposition, the neighbours' rows its stencils and its widened sub-cycle reach)
+  const int Ey = m->Ry > 1 ? H + std::max(m->Wy, m->Wys) + 6 : 0;
   const std::vector<double>&zc = m->h_metric[GB25_M_ZC], &zf = m->h_metric[GB25_M_ZF];
   m->kb_E = E;
-  m->kbot.assign((size_t)ksx * Ny, 0);
+  m->kb_Ey = Ey;
+  m->kbot.assign((size_t)ksx * (Ny + 2 * Ey), 255);
   bool any = false;
   auto level = [&](double b) {   // number of immersed cells of a column whose bottom is at height b
     int kb = 0;
@@ -651,12 +664,14 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
       if ((double)(real)zc[offk + k] <= b) kb = k + 1;   // z_center <= bottom: immersed (CenterImmersedCondition)
     return kb;
   };
-  for (int j = 0; j < Ny; j++)
+  for (int j = -Ey; j < Ny + Ey; j++) {
+    if (j + j0 < 0 || j + j0 >= c.Ny) continue;   // (beyond the walls / the fold: below)
     for (int i = -E; i < Nx + E; i++) {
-      const int kb = level(zb(i, j));
-      m->kbot[(size_t)(i + E) + (size_t)ksx * j] = kb;
-      any = any || kb > 0;
+      const int kb = level(zb(i, j + j0));
+      m->kbot[(size_t)(i + E) + (size_t)ksx * (j + Ey)] = kb;
+      any = any || (kb > 0 && j >= 0 && j < Ny);
     }
+  }
   m->immersed = any;
   // level from which cell (i, j) is active; rows beyond the walls never are; rows beyond the zipper fold are the images
   // of the cells they mirror
@@ -665,23 +680,24 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
     if (nfold && j >= Ny) {
       // the mirrored cell: GLOBAL column Nx_global - 1 - ig, usually another rank's -- the bottom is a function of the
       // global position, evaluated here (a slab sees its partner's bottom without any exchange)
-      const int il = c.Nx - 1 - (i + c.rank * Nx) - c.rank * Nx, jm = 2 * (Ny - 1) - j;   // (the fold pivots on the centres of row Ny-1)
+      const int il = c.Nx - 1 - (i + m->rx * Nx) - m->rx * Nx, jm = 2 * (c.Ny - 1) - (j + j0);   // (the fold pivots on the centres of row Ny-1)
       return jm < 0 ? 255 : level(zb(il, jm));
     }
-    if (j < 0 || j >= Ny) return 255;
-    return m->kbot[(size_t)(std::min(std::max(i, -E), Nx + E - 1) + E) + (size_t)ksx * j];
+    if (j + j0 < 0 || j + j0 >= c.Ny) return 255;
+    return m->kbot[(size_t)(std::min(std::max(i, -E), Nx + E - 1) + E) + (size_t)ksx * (j + Ey)];
   };
   auto node_x = [&](int q, int j) { return std::min(thr(q - 1, j), thr(q, j)); };   // face node: inactive when BOTH cells are
   auto node_y = [&](int i, int q) { return std::min(thr(i, q - 1), thr(i, q)); };
   auto depth = [&](int i, int j) -> double {   // static column depth: top face - materialised bottom
-    const int jj = (nfold && j >= Ny) ? j : std::min(std::max(j, 0), Ny - 1);
+    const int jj = (nfold && j >= Ny) ? j : std::min(std::max(j + j0, 0), c.Ny - 1) - j0;
     const int kb = thr(i, jj);
     return (double)(real)zf[offk + Nz] - (double)(real)zf[offk + kb];
   };
   const int sx = Nx + 2 * H, sy = Ny + 2 * H + 1;
   std::vector<unsigned> A((size_t)sx * sy, 0), B(A.size(), 0), C(A.size(), 0), D(A.size(), 0);
   std::vector<real> Hf(A.size(), 0), Hc(A.size(), 0), rHf(A.size(), 0), rHc(A.size(), 0);
-  for (int j = 0; j <= Ny; j++)
+  // (rows: the own ones; with a neighbour rank on a side, that side's halo rows too -- the corrector runs there as well)
+  for (int j = (m->ys_open ? -H : 0); j <= (m->yn_open ? Ny + H : Ny); j++)
     for (int i = -H; i < Nx + H; i++) {
       const size_t o = (size_t)(i + H) + (size_t)sx * (j + H);
       int KX5 = 0, KX3 = 0, KY5 = 0, KY3 = 0, KXC5 = 0, KXC3 = 0, KYC5 = 0, KYC3 = 0;
@@ -692,7 +708,7 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
       const int kc = std::min(thr(i, j), Nz);   // (the extra face row j = Ny has no cells: its kc is never used)
       const int KPU = std::max(thr(i - 1, j), thr(i, j));
       // wall faces: the plain grid's business (the fold line is no wall)
-      const int KPV = (j == 0 || (j >= Ny && !nfold)) ? 0 : std::min(std::max(thr(i, j - 1), thr(i, j)), 255);
+      const int KPV = (j + j0 == 0 || (j + j0 >= c.Ny && !nfold)) ? 0 : std::min(std::max(thr(i, j - 1), thr(i, j)), 255);
       A[o] = (unsigned)kc | (unsigned)KX5 << 8 | (unsigned)KX3 << 16 | (unsigned)KY5 << 24;
       B[o] = (unsigned)KY3 | (unsigned)KXC5 << 8 | (unsigned)KXC3 << 16 | (unsigned)KYC5 << 24;
       C[o] = (unsigned)KYC3 | (unsigned)std::min(KPU, 255) << 8 | (unsigned)KPV << 16;
@@ -704,7 +720,7 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
       Hc[o] = (real)hc;
       rHf[o] = hf > 0 ? (real)(1.0 / hf) : real(0.);
       // (the v face on the southern wall never moves; its correction divides by the full depth as on the plain grid)
-      rHc[o] = j == 0 ? (real)(1.0 / ((double)(real)zf[offk + Nz] - (double)(real)zf[offk])) : (hc > 0 ? (real)(1.0 / hc) : real(0.));
+      rHc[o] = j + j0 == 0 ? (real)(1.0 / ((double)(real)zf[offk + Nz] - (double)(real)zf[offk])) : (hc > 0 ? (real)(1.0 / hc) : real(0.));
     }
   auto upload = [&](const void* h, size_t bytes, void** d) -> gb25_status {
     if (!*d) HIPCHK(hipMalloc(d, bytes));
@@ -724,10 +740,10 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
   m->g.im.Hfc = m->d_H[0]; m->g.im.Hcf = m->d_H[1]; m->g.im.rHfc = m->d_H[2]; m->g.im.rHcf = m->d_H[3];
   if (m->slab || nfold) {   // the same depths on the work arrays of the sub-cycle: widened slab / tall folded grid
     const int W = m->W, wsx = Nx + 2 * W;
-    std::vector<real> wf((size_t)wsx * (sy + m->Wy), 0), wc(wf.size(), 0);
-    for (int j = 0; j <= Ny + m->Wy; j++)
+    std::vector<real> wf((size_t)wsx * (sy + m->Wy + m->Wys), 0), wc(wf.size(), 0);
+    for (int j = -m->Wys; j <= Ny + m->Wy; j++)
       for (int i = -W; i < Nx + W; i++) {
-        const size_t o = (size_t)(i + W) + (size_t)wsx * (j + H);
+        const size_t o = (size_t)(i + W) + (size_t)wsx * (j + H + m->Wys);
         wf[o] = (real)std::min(depth(i - 1, j), depth(i, j));
         wc[o] = (real)std::min(depth(i, j - 1), depth(i, j));
       }
@@ -743,7 +759,7 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
 double gaussian_islands_bottom(const gb25_model* m, int i_local, int j) {
   const gb25_config& c = m->cfg;
   const double dlam = (c.lon_east - c.lon_west) / c.Nx, dphi = (c.lat_north - c.lat_south) / c.Ny;
-  int ig = (i_local + c.rank * m->Nx) % c.Nx;
+  int ig = (i_local + m->rx * m->Nx) % c.Nx;
   if (ig < 0) ig += c.Nx;
   auto mtn = [](double l, double p, double l1, double p1) {
     const double d = 5;
@@ -843,7 +859,7 @@ gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, i
   if (g.cv.north_fold && !m->slab) {   // y / z layers, the rows beyond the fold, then the periodic x copy over all of them
     if (which == 2) return fill_halos_2d(m, h2);
     if (which == 1) h2.n = 0;
-    hipLaunchKernelGGL(k_fill_yz, dim3((g.Nx + 255) / 256, g.Nz + 1 + g.Ny), b, 0, st, g, h3, h2, 0, g.Nx);
+    hipLaunchKernelGGL(k_fill_yz, dim3((g.Nx + 255) / 256, g.Nz + 1 + g.Ny), b, 0, st, g, h3, h2, 0, g.Nx, 0);
     hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H, g.Nz + 2 + (h2.n ? 1 : 0)), b, 0, st, g, h3, h2);
     const int rows_c = g.sy_c * (g.Nz + 2 * g.H), rows_v = g.sy_v * (g.Nz + 2 * g.H);
     hipLaunchKernelGGL(k_fill_x, dim3((unsigned)(((long)rows_v * 2 * g.H + 255) / 256), 4 + h2.n), b, 0, st, g, h3, h2,
@@ -868,7 +884,10 @@ gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, i
     LAUNCHCHK();
     return GB25_OK;
   }
-  hipLaunchKernelGGL(k_fill_yz, dim3((ni + 255) / 256, g.Nz + 1 + g.Ny), b, 0, st, g, h3, h2, i0, ni);
+  // (z layers: the own rows; `extended` on a rank of a 2-D decomposition: the halo rows of its open sides too -- they arrived
+  // with the neighbours' rows, interior levels only)
+  const int jlo = (extended && m->ys_open) ? -g.H : 0, jhi = (extended && m->yn_open) ? g.Ny + g.H : g.Ny;
+  hipLaunchKernelGGL(k_fill_yz, dim3((ni + 255) / 256, g.Nz + 1 + (jhi - jlo)), b, 0, st, g, h3, h2, i0, ni, jlo);
   if (with_x && g.x_periodic) {
     int rows_c = g.sy_c * (g.Nz + 2 * g.H), rows_v = g.sy_v * (g.Nz + 2 * g.H);
     long threads = (long)rows_v * 2 * g.H;
@@ -989,7 +1008,7 @@ inline int interior_tile_columns_end(const Grid& g) {
 }
 inline bool tendencies_split(const gb25_model* m) {
   return m->slab && m->split_tendencies && m->two_streams && m->pressure_bits == 64 && m->kernel_gen >= 2 &&
-         interior_tile_columns_end(m->g) > 1 && !m->g.cv.north_fold;   // (the rows beyond a fold arrive last)
+         interior_tile_columns_end(m->g) > 1 && !m->g.cv.north_fold && m->Ry == 1;   // (the rows beyond a fold / of a neighbour in y arrive last)
 }
 
 // part: 0 = every tile column; 1 = the interior tile columns (a12: launched before the x-halo bundle has arrived);
@@ -1326,10 +1345,10 @@ gb25_status tall_rows_impl(gb25_model* m, real* buf, bool pack) {
   for (int q = 0; q < 3; q++) T.p[q] = m->wide[0][q].d;
   T.p[3] = m->wideG[0].d;
   T.p[4] = m->wideG[1].d;
-  T.sx = g.Nx + 2 * m->W; T.xo = m->W; T.Wy = m->Wy; T.wrap = m->slab ? 0 : 1;
+  T.sx = g.Nx + 2 * m->W; T.xo = m->W; T.yo = g.H + m->Wys; T.Wy = m->Wy; T.wrap = m->slab ? 0 : 1;
   const dim3 gr((T.sx + 255) / 256, m->Wy + 1, 5);
-  if (pack) hipLaunchKernelGGL(k_tall_rows<true>, gr, dim3(256), 0, m->stream, g, T, buf, m->cfg.rank * g.Nx, m->cfg.Nx);
-  else hipLaunchKernelGGL(k_tall_rows<false>, gr, dim3(256), 0, m->stream, g, T, buf, m->cfg.rank * g.Nx, m->cfg.Nx);
+  if (pack) hipLaunchKernelGGL(k_tall_rows<true>, gr, dim3(256), 0, m->stream, g, T, buf, m->rx * g.Nx, m->cfg.Nx);
+  else hipLaunchKernelGGL(k_tall_rows<false>, gr, dim3(256), 0, m->stream, g, T, buf, m->rx * g.Nx, m->cfg.Nx);
   LAUNCHCHK();
   return GB25_OK;
 }
@@ -1351,7 +1370,10 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
   dim3 b(64, 4);
   Baro bb;
   real *cur[3], *nxt[3], *other[3], *out[3];
+  bb.jlo = -m->Wys;
   bb.jhi = g.Ny + m->Wy;
+  bb.yo = g.H + m->Wys;
+  bb.top_open = (g.cv.north_fold || m->yn_open) ? 1 : 0;
   if (!wide) {
     size_t nbar = m->f[GB25_ETA_BAR].elems() + m->f[GB25_U_BAR].elems() + m->f[GB25_V_BAR].elems();
     if (m->baro_block <= 1)   // (the blocked kernels start their averages from zero themselves)
@@ -1408,7 +1430,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
   const bool blocked = m->baro_block > 1;
   const CurvBaro cb = wide ? CurvBaro{m->d_wideM[0], m->d_wideM[1], m->d_wideM[2], m->d_wideM[3], m->d_wideM[4]}
                            : CurvBaro{g.cv.dyfc, g.cv.dxcf, g.cv.razcc, g.cv.rdxfc, g.cv.rdycf};
-  const int rows = bb.jhi + (g.cv.north_fold ? 1 : 0);   // (folded: the face row behind the last advanced row is carried along)
+  const int rows = bb.jhi - bb.jlo + (bb.top_open ? 1 : 0);   // (no wall: the face row behind the last advanced row is carried along)
   auto fill_multi = [&](BaroMulti& bm, int s, int Sk) {
     bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
     bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
@@ -1425,6 +1447,8 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     bm.eb_out = bm.ub_out = bm.vb_out = nullptr;
     bm.fold = 0;
     bm.out_halo = m->slab ? g.H : 0;   // (a widened slab also writes the x halo columns of the new eta, U, V)
+    bm.out_js = m->ys_open ? -g.H : 0;   // (... and a rank of a 2-D decomposition the halo rows of its open sides)
+    bm.out_jn = m->yn_open ? g.Ny + g.H : g.Ny;
     if (wide) {
       const Field* fb = ahead ? m->ahead_bar : &m->f[GB25_ETA_BAR];
       bm.eb_out = fb[0].d; bm.ub_out = fb[1].d; bm.vb_out = fb[2].d;
@@ -1445,7 +1469,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     const int S = std::min(m->baro_block, (int)BT_SMAX);
     constexpr int TYb = 16, TY5 = 17;   // (5 substeps per launch: 64 x 17 tiles keep LDS under 40 KB -- four blocks per CU)
     const int tyb = (S > 3 && S <= 5) ? TY5 : TYb;
-    dim3 gm((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX, (g.Ny + tyb - 1) / tyb);
+    dim3 gm((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX, (bb.jhi - bb.jlo + tyb - 1) / tyb);
     void (*kern)(Grid, BaroMulti, real) =
         imm ? (S <= 3 ? k_barotropic_multi<3, TYb, true> : (S <= 5 ? k_barotropic_multi<5, TY5, true> : k_barotropic_multi<7, TYb, true>))
             : (S <= 3 ? k_barotropic_multi<3, TYb, false> : (S <= 5 ? k_barotropic_multi<5, TY5, false> : k_barotropic_multi<7, TYb, false>));
@@ -1459,7 +1483,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
       for (int q = 0; q < 3; q++) { real* w_ = nxt[q]; nxt[q] = other[q]; other[q] = w_; cur[q] = w_; }
     }
   } else {
-    dim3 gr = grid2(bb.ihi - bb.ilo, g.cv.on ? rows : g.Ny, b);
+    dim3 gr = grid2(bb.ihi - bb.ilo, g.cv.on ? rows : bb.jhi - bb.jlo, b);
     for (int s = 0; s < m->Ns; s++) {
       bb.eta0 = cur[0]; bb.U0 = cur[1]; bb.V0 = cur[2];
       bb.eta1 = nxt[0]; bb.U1 = nxt[1]; bb.V1 = nxt[2];
@@ -1475,17 +1499,18 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     LAUNCHCHK();
     return GB25_OK;
   }
-  dim3 gi = grid2(g.Nx, v_rows(g), b);
-  if (m->slab) gi = grid2(g.Nx + 2 * g.H, v_rows(g), b);   // (with the x halo columns: nothing is exchanged after the sub-cycle)
+  const int fjs = m->ys_open ? -g.H : 0, fjn = m->yn_open ? g.Ny + g.H : g.Ny;
+  dim3 gi = grid2(g.Nx, fjn - fjs, b);
+  if (m->slab) gi = grid2(g.Nx + 2 * g.H, fjn - fjs, b);   // (with the x halo columns: nothing is exchanged after the sub-cycle)
   hipLaunchKernelGGL(k_barotropic_finalize, gi, b, 0, m->stream, g, out[0], out[1], out[2], bb.etab, bb.Ub, bb.Vb,
-                     bb.sx, bb.xo, m->slab ? g.H : 0);
+                     bb.sx, bb.xo, wide ? bb.yo : g.H, m->slab ? g.H : 0, fjs, fjn);
   if (wide) {  // publish the averages in the canonical filtered-state arrays (compared by compare_states)
     InteriorCopies C{};
     int rmax = 0;
     for (int q = 0; q < 3; q++) {
       Field& dst = ahead ? m->ahead_bar[q] : m->f[GB25_ETA_BAR + q];
       C.dst[q] = dst.d; C.dsx[q] = dst.nx; C.dxo[q] = g.H;
-      C.src[q] = m->wideBar[q].d; C.ssx[q] = bb.sx; C.sxo[q] = bb.xo; C.rows[q] = dst.ny;
+      C.src[q] = m->wideBar[q].d + (size_t)m->Wys * bb.sx; C.ssx[q] = bb.sx; C.sxo[q] = bb.xo; C.rows[q] = dst.ny;
       rmax = std::max(rmax, dst.ny);
     }
     C.n = 3;
@@ -1519,19 +1544,24 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
     // the integrals came with the 3-D bundle (group 0 carries the owner's; marching 16 columns x Ny threads up 48 levels
     // for them was 36 us of latency on the critical path of a 180-column rank)
     const bool cells_halo = m->slab && part == 2 && use_colsum && m->halo_colsum_valid;
-    if ((m->slab && part == 1 && cs) || cells_halo) {
-      hipLaunchKernelGGL(m->immersed ? k_corrector_cells<true> : k_corrector_cells<false>,
-                         dim3((ni + 63) / 64, (v_rows(g) + 3) / 4, g.Nz), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                         m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->colsum[0].d,
-                         m->colsum[1].d, i0, ni, skip_from, skip);
-    } else {
-      auto kern = m->immersed ? (fold ? k_corrector<true, true> : k_corrector<true, false>)
-                              : (fold ? k_corrector<false, true> : k_corrector<false, false>);
-      hipLaunchKernelGGL(kern, grid2(ni, v_rows(g), b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                         m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d,
-                         cs ? m->colsum[0].d : nullptr, cs ? m->colsum[1].d : nullptr, i0, ni, mom_kchunks(m),
-                         skip_from, skip);
-    }
+    const bool cells = (m->slab && part == 1 && cs) || cells_halo;
+    auto launch = [&](int i0_, int ni_, int skf, int sk, int jr0, int nj, int jskf, int jsk) {
+      if (cells) {
+        hipLaunchKernelGGL(m->immersed ? k_corrector_cells<true> : k_corrector_cells<false>,
+                           dim3((ni_ + 63) / 64, (nj + 3) / 4, g.Nz), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                           m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->colsum[0].d,
+                           m->colsum[1].d, i0_, ni_, skf, sk, jr0, nj, jskf, jsk);
+      } else {
+        auto kern = m->immersed ? (fold ? k_corrector<true, true> : k_corrector<true, false>)
+                                : (fold ? k_corrector<false, true> : k_corrector<false, false>);
+        hipLaunchKernelGGL(kern, grid2(ni_, nj, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                           m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d,
+                           cs ? m->colsum[0].d : nullptr, cs ? m->colsum[1].d : nullptr, i0_, ni_, mom_kchunks(m),
+                           skf, sk, jr0, nj, jskf, jsk);
+      }
+    };
+    // rows: the own ones (the halo rows of a rank of a 2-D decomposition arrive corrected: group 10 travels after this)
+    launch(i0, ni, skip_from, skip, 0, g.Ny, INT_MAX, 0);
     LAUNCHCHK();
   }
   if (part == 2) return GB25_OK;
@@ -1918,7 +1948,7 @@ gb25_status rebuild_bottom(gb25_model* m) {
     if (c.Nz > 254) return fail(m, GB25_ERR_INVALID_ARGUMENT, "an immersed boundary / a curvilinear grid needs Nz <= 254 (8-bit level tables)");
   }
   if (!m->host_bottom.empty()) {
-    const int Nxg = c.Nx, i0 = c.rank * m->Nx;
+    const int Nxg = c.Nx, i0 = m->rx * m->Nx;
     gb25_status s = build_bottom(m, [&](int i, int j) { return m->host_bottom[(size_t)((((i + i0) % Nxg) + Nxg) % Nxg) + (size_t)Nxg * j]; });
     if (s) return s;
     if (m->slab) m->immersed = true;   // (every slab of a decomposition runs the kernel variants its neighbours run)
@@ -1970,7 +2000,7 @@ void gb25_default_config(gb25_config* c, int32_t Nx, int32_t Ny, int32_t Nz) {
   c->lat_south = -80; c->lat_north = 80; c->lon_west = 0; c->lon_east = 360;
   c->depth = 4000; c->zexp_h = 30;
   c->g = 9.80665; c->Omega = 7.292115e-5; c->radius = 6371e3; c->rho0 = 1020.0;
-  c->slab_mode = 0; c->grid_type = GB25_GRID_LAT_LON;
+  c->slab_mode = 0; c->grid_type = GB25_GRID_LAT_LON; c->ranks_y = 1;
 }
 
 gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
@@ -1980,26 +2010,42 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   gb25_default_catke_parameters(&m->catke_par);
   *out = m;  // returned even on failure so the caller can read the error string, then destroy
   m->cfg = *cfg;
+  m->Ry = cfg->ranks_y > 1 ? cfg->ranks_y : 1;
   if (cfg->Nx < 8 || cfg->Ny < 8 || cfg->Nz < 4 || cfg->halo < 4 || cfg->substeps < 1 || cfg->substeps > 4096 ||
-      cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks || cfg->Nx % cfg->nranks != 0)
+      cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks || cfg->nranks % m->Ry != 0 ||
+      cfg->Nx % (cfg->nranks / m->Ry) != 0 || cfg->Ny % m->Ry != 0)
     return fail(m, GB25_ERR_INVALID_ARGUMENT,
-                "invalid configuration: need Nx,Ny >= 8, Nz >= 4, halo >= 4, 1 <= substeps <= 4096, Nx %% nranks == 0");
+                "invalid configuration: need Nx,Ny >= 8, Nz >= 4, halo >= 4, 1 <= substeps <= 4096, nranks = Rx ranks_y, "
+                "Nx %% Rx == 0, Ny %% ranks_y == 0");
   if (cfg->slab_mode < 0 || cfg->slab_mode > 1)
     return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab_mode must be 0 (x halos by exchange iff nranks > 1) or 1 (always)");
-  m->Nx = cfg->Nx / cfg->nranks;
+  m->Rx = cfg->nranks / m->Ry;
+  m->rx = cfg->rank % m->Rx;
+  m->ry = cfg->rank / m->Rx;
+  m->Nx = cfg->Nx / m->Rx;
+  m->Ny = cfg->Ny / m->Ry;
+  m->j0 = m->ry * m->Ny;
+  m->ys_open = m->ry > 0;
+  m->yn_open = m->ry < m->Ry - 1;
   m->slab = cfg->nranks > 1 || cfg->slab_mode == 1;
   if (m->Nx < cfg->halo) return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab narrower than the halo");
+  if (m->Ry > 1) {
+    // a rank of a 2-D decomposition steps on the plain staged sequence: no interior / edge split of the tendencies, no early
+    // pressure, the sub-cycle inside its own step
+    m->split_tendencies = 0;
+    if (m->Ny < cfg->halo + 2) return fail(m, GB25_ERR_INVALID_ARGUMENT, "a rank's band of rows is narrower than the halo");
+  }
   {
     // The kernels address a parent array with 32-bit ELEMENT indices; the tendency kernels with 32-bit BYTE offsets from the
     // first plane their block touches (tendency_kernels.hpp): a chunk of levels plus its stencil planes must stay below 2 GB.
-    const double plane = (double)(m->Nx + 2 * cfg->halo) * (cfg->Ny + 2 * cfg->halo + 1);
+    const double plane = (double)(m->Nx + 2 * cfg->halo) * (m->Ny + 2 * cfg->halo + 1);
     const double elems = plane * (cfg->Nz + 2 * cfg->halo + 1);
     const int kchunks = std::max(1, cfg->Nz / 12), klen = (cfg->Nz + kchunks - 1) / kchunks;
     if (elems >= 2147483648.0 || plane * (klen + 10) * sizeof(real) >= 2147483648.0)
       return fail(m, GB25_ERR_INVALID_ARGUMENT,
                   "a %dx%dx%d slab has %.2g elements per 3-D array (%.1f GB) and %.2g per plane; the kernels index at most 2^31 "
                   "elements per array and %d planes of 2 GB together: decompose in x (nranks) so that the local slab is narrower",
-                  m->Nx, cfg->Ny, cfg->Nz, elems, elems * sizeof(real) / 1e9, plane, klen + 10);
+                  m->Nx, m->Ny, cfg->Nz, elems, elems * sizeof(real) / 1e9, plane, klen + 10);
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -2032,6 +2078,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   // A slab of a decomposition always uses it: there it also takes two exchanges off the critical path.
   // (gb25_set_option changes any of these defaults; nothing is read from the environment.)
   m->baro_ahead = (m->slab || (long)cfg->Nx * cfg->Ny * cfg->Nz >= 8000000L) ? 1 : 0;
+  if (m->Ry > 1) m->baro_ahead = 0;
   gb25_status s;
   if ((s = build_grid(m))) return s;
   if ((s = build_eos_tables(m))) return s;
@@ -2040,7 +2087,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     return fail(m, GB25_ERR_INVALID_ARGUMENT, "grid_type %d: 0 lat-lon, 1 lat-lon with the Gaussian islands, 2 lat-lon "
                 "through the curvilinear kernels, 3 tripolar, 4 tripolar with the Gaussian islands", cfg->grid_type);
   if (cfg->grid_type >= GB25_GRID_LAT_LON_AS_CURVILINEAR) {
-    if (cfg->grid_type >= GB25_GRID_TRIPOLAR && (cfg->Nx % 2 || cfg->Ny < 2 * cfg->halo))
+    if (cfg->grid_type >= GB25_GRID_TRIPOLAR && (cfg->Nx % 2 || m->Ny < 2 * cfg->halo))
       return fail(m, GB25_ERR_INVALID_ARGUMENT, "the tripolar grid needs an even Nx and Ny >= 2 halo (the fold maps columns onto columns)");
     if ((s = build_curv_grid(m))) return s;
   }
@@ -2048,17 +2095,17 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   for (int id = 0; id < GB25_FIELD_COUNT; id++) {
     if (id >= GB25_ETA_BAR && id <= GB25_V_BAR) continue;  // allocated contiguously below
     if (is_catke_field(id)) continue;   // (allocated when the closure is switched on)
-    int ny = cfg->Ny + 2 * H + (is_v_shaped(id) ? 1 : 0);
+    int ny = m->Ny + 2 * H + (is_v_shaped(id) ? 1 : 0);
     int nz = is_2d(id) ? 1 : cfg->Nz + 2 * H + (id == GB25_W ? 1 : 0);
     if ((s = alloc_field(m, m->f[id], sx, ny, nz))) return s;
   }
   {
-    size_t nc = (size_t)sx * (cfg->Ny + 2 * H), nv = (size_t)sx * (cfg->Ny + 2 * H + 1);
+    size_t nc = (size_t)sx * (m->Ny + 2 * H), nv = (size_t)sx * (m->Ny + 2 * H + 1);
     HIPCHK(hipMalloc(&m->bars, (2 * nc + nv) * sizeof(real)));
     HIPCHK(hipMemset(m->bars, 0, (2 * nc + nv) * sizeof(real)));
-    Field& e = m->f[GB25_ETA_BAR]; e.d = m->bars; e.nx = sx; e.ny = cfg->Ny + 2 * H; e.nz = 1;
-    Field& u = m->f[GB25_U_BAR]; u.d = m->bars + nc; u.nx = sx; u.ny = cfg->Ny + 2 * H; u.nz = 1;
-    Field& v = m->f[GB25_V_BAR]; v.d = m->bars + 2 * nc; v.nx = sx; v.ny = cfg->Ny + 2 * H + 1; v.nz = 1;
+    Field& e = m->f[GB25_ETA_BAR]; e.d = m->bars; e.nx = sx; e.ny = m->Ny + 2 * H; e.nz = 1;
+    Field& u = m->f[GB25_U_BAR]; u.d = m->bars + nc; u.nx = sx; u.ny = m->Ny + 2 * H; u.nz = 1;
+    Field& v = m->f[GB25_V_BAR]; v.d = m->bars + 2 * nc; v.nx = sx; v.ny = m->Ny + 2 * H + 1; v.nz = 1;
   }
   for (int q = 0; q < 3; q++) {
     if ((s = alloc_field(m, m->pp[q], sx, m->f[GB25_ETA + q].ny, 1))) return s;
@@ -2107,15 +2154,20 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     }
     // folded grid: image rows beyond the pivot row, enough that what the last row's missing neighbour spoils (one row per
     // substep) never reaches the pivot row
-    if (m->g.cv.north_fold) m->Wy = std::min(m->Ns + 1, m->cfg.Ny - 2);
-    const int wsx = m->Nx + 2 * m->W;
+    if (m->g.cv.north_fold) m->Wy = std::min(m->Ns + 1, m->Ny - 2);
+    // 2-D decomposition: wide halos in y as in x on the sides where a neighbour rank exists
+    if (m->yn_open) m->Wy = m->W;
+    if (m->ys_open) m->Wys = m->W;
+    if ((m->yn_open || m->ys_open) && m->Ny < m->W)
+      return fail(m, GB25_ERR_INVALID_ARGUMENT, "a rank's band of %d rows is narrower than the barotropic halo %d", m->Ny, m->W);
+    const int wsx = m->Nx + 2 * m->W, wy = m->Wy + m->Wys;
     for (int a = 0; a < 2; a++)
       for (int q = 0; q < 3; q++)
-        if ((s = alloc_field(m, m->wide[a][q], wsx, m->f[GB25_ETA + q].ny + m->Wy, 1))) return s;
+        if ((s = alloc_field(m, m->wide[a][q], wsx, m->f[GB25_ETA + q].ny + wy, 1))) return s;
     {   // the three running averages are one allocation, zeroed by one memset per step
       size_t tot = 0;
       for (int q = 0; q < 3; q++) {
-        m->wideBar[q].nx = wsx; m->wideBar[q].ny = m->f[GB25_ETA + q].ny + m->Wy; m->wideBar[q].nz = 1;
+        m->wideBar[q].nx = wsx; m->wideBar[q].ny = m->f[GB25_ETA + q].ny + wy; m->wideBar[q].nz = 1;
         tot += m->wideBar[q].elems();
       }
       real* base = nullptr;
@@ -2126,8 +2178,8 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
         base += m->wideBar[q].elems();
       }
     }
-    if ((s = alloc_field(m, m->wideG[0], wsx, m->f[GB25_GN_BT_U].ny + m->Wy, 1))) return s;
-    if ((s = alloc_field(m, m->wideG[1], wsx, m->f[GB25_GN_BT_V].ny + m->Wy, 1))) return s;
+    if ((s = alloc_field(m, m->wideG[0], wsx, m->f[GB25_GN_BT_U].ny + wy, 1))) return s;
+    if ((s = alloc_field(m, m->wideG[1], wsx, m->f[GB25_GN_BT_V].ny + wy, 1))) return s;
     if (m->g.cv.on && (s = build_curv_wide(m))) return s;
     if (m->Wy && !m->slab) HIPCHK(hipMalloc(&m->tall_buf, (size_t)5 * (m->Wy + 1) * wsx * sizeof(real)));
   }
@@ -2242,7 +2294,7 @@ gb25_status gb25_field_dims(const gb25_model* m, gb25_field id, int include_halo
   const int H = m->cfg.halo;
   // A y-face field of a folded grid has Ny rows ((Periodic, RightConnected, Bounded): the faces beyond the last row of cells are
   // halo cells), so its parent has Ny + 2H rows like a cell-centred one; the device arrays keep the row a Bounded grid needs.
-  const int ny = F.ny - ((m->g.cv.north_fold && is_v_shaped(id)) ? 1 : 0);
+  const int ny = F.ny - (((m->g.cv.north_fold || m->yn_open) && is_v_shaped(id)) ? 1 : 0);   // (likewise below a northern neighbour rank)
   if (include_halos) {
     d[0] = F.nx; d[1] = ny; d[2] = F.nz;
   } else {
@@ -2436,7 +2488,7 @@ gb25_status gb25_set_closure_catke(gb25_model* m, int32_t on) {
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(m->side_stream));
   if (on && !m->f[GB25_E].d) {
-    const int H = m->cfg.halo, sx = m->Nx + 2 * H, sy = m->cfg.Ny + 2 * H, nz = m->cfg.Nz + 2 * H;
+    const int H = m->cfg.halo, sx = m->Nx + 2 * H, sy = m->Ny + 2 * H, nz = m->cfg.Nz + 2 * H;
     gb25_status s;
     for (int id = GB25_E; id <= GB25_JB; id++) {
       const bool faces = id >= GB25_KAPPA_U && id <= GB25_KAPPA_E;
@@ -2562,10 +2614,13 @@ gb25_status gb25_set_vertical_faces(gb25_model* m, const double* zf, int32_t n) 
 // which: 0 = number of immersed cells of column (i, j) (0-based local indices), 1 = static depth at the U face,
 // 2 = at the V face
 gb25_status gb25_get_bottom_info(const gb25_model* m, int32_t which, int32_t i, int32_t j, double* value) {
-  if (!m || !value || j < 0 || j >= m->cfg.Ny || i < 0 || i >= m->Nx || which < 0 || which > 2) return GB25_ERR_INVALID_ARGUMENT;
+  if (!m || !value || j < 0 || j >= m->Ny || i < 0 || i >= m->Nx || which < 0 || which > 2) return GB25_ERR_INVALID_ARGUMENT;
   if (m->kbot.empty()) { *value = which == 0 ? 0.0 : (double)m->g.Lz; return GB25_OK; }
   const int E = m->kb_E, ksx = m->Nx + 2 * E, offk = m->metric_off_k, Nz = m->cfg.Nz;
-  auto kb = [&](int ii, int jj) { return m->kbot[(size_t)(ii + E) + (size_t)ksx * std::min(std::max(jj, 0), m->cfg.Ny - 1)]; };
+  auto kb = [&](int ii, int jj) {
+    const int jl = std::min(std::max(jj + m->j0, 0), m->cfg.Ny - 1) - m->j0;   // (clamped at the walls; a neighbour's row otherwise)
+    return m->kbot[(size_t)(ii + E) + (size_t)ksx * (std::min(std::max(jl, -m->kb_Ey), m->Ny + m->kb_Ey - 1) + m->kb_Ey)];
+  };
   auto depth = [&](int ii, int jj) { return (double)(real)m->h_metric[GB25_M_ZF][offk + Nz] - (double)(real)m->h_metric[GB25_M_ZF][offk + kb(ii, jj)]; };
   *value = which == 0 ? (double)kb(i, j) : which == 1 ? std::min(depth(i - 1, j), depth(i, j)) : std::min(depth(i, j - 1), depth(i, j));
   return GB25_OK;
@@ -2779,7 +2834,7 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
       }
       {
         bool any = false;
-        for (int kb : m->kbot) any = any || kb > 0;
+        for (int kb : m->kbot) any = any || (kb > 0 && kb < 255);
         m->immersed = any || v != 0;
       }
       return GB25_OK;
@@ -2862,7 +2917,7 @@ gb25_status gb25_comm_init_local(gb25_model* const* slabs, int32_t n) {
   for (int s = 0; s < n; s++) {
     if (!slabs[s]) return GB25_ERR_INVALID_ARGUMENT;
     const gb25_config &a = slabs[s]->cfg, &b = m->cfg;
-    if (a.nranks != n || a.rank != s || a.device != b.device || a.Nx != b.Nx || a.Ny != b.Ny || a.Nz != b.Nz ||
+    if (a.nranks != n || a.rank != s || a.device != b.device || a.Nx != b.Nx || a.Ny != b.Ny || a.Nz != b.Nz || a.ranks_y != b.ranks_y ||
         a.halo != b.halo || a.substeps != b.substeps)
       return fail(m, GB25_ERR_INVALID_ARGUMENT,
                   "gb25_comm_init_local wants the %d slabs of ONE decomposition in rank order on one device (slab %d does "
@@ -2929,6 +2984,7 @@ int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int3
   TraceOps ops(nslabs, adopted != 0, ready != 0);
   if (first & 2) ops.fold = true;   // (bit 1 of `first`: a folded grid)
   if (first & 4) ops.is_coupled = true;   // (bit 2: a coupled model -- data-free forcing)
+  if (first & 16) ops.mesh = true;        // (bit 4: a 2-D decomposition -- y halos from the southern / northern neighbour)
   bool in_flight = (first & 8) != 0;      // (bit 3: the previous step left the look-ahead chain in flight)
   first &= 1;
   if (first) sequence_first_time_step(ops, in_flight);
@@ -2972,8 +3028,10 @@ gb25_status gb25_save_state(gb25_model* m, const char* directory, const char* la
       z.close();
       return s;
     }
-    const int64_t i0 = (int64_t)m->cfg.rank * m->Nx;
-    const int64_t slice[6] = {i0, i0 + d[0], 0, d[1], 0, d[2]}, gshape[3] = {m->cfg.Nx, d[1], d[2]};
+    const int64_t i0 = (int64_t)m->rx * m->Nx, j0 = m->j0;
+    // (global rows: Ny, + 1 for a y-face field of a grid with a northern wall)
+    const int64_t gny = (int64_t)m->cfg.Ny + ((is_v_shaped(fld.id) && m->cfg.grid_type < GB25_GRID_TRIPOLAR) ? 1 : 0);
+    const int64_t slice[6] = {i0, i0 + d[0], j0, j0 + d[1], 0, d[2]}, gshape[3] = {m->cfg.Nx, m->Ry > 1 ? gny : d[1], d[2]};
     z.add_array(std::string(fld.name) + ".data", sizeof(real) == 8 ? "<f8" : "<f4", {d[0], d[1], d[2]}, host.data());
     z.add_array(std::string(fld.name) + ".slice", "<i8", {6}, slice);
     z.add_array(std::string(fld.name) + ".global_shape", "<i8", {3}, gshape);

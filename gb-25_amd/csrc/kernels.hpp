@@ -57,36 +57,40 @@ struct Halo2 {
 
 // south/north layer of the four 3-D fields + all 2-D fields over columns [i0, i0+ni).
 // grid: (ceil(ni/256), Nz + 1)
+// (a side without a wall -- the fold line; the open sides of a rank of a 2-D decomposition -- has no layer to fill: its halo rows
+// are images / the neighbour's rows)
 __device__ __forceinline__ void fill_y_body(const Grid& g, const Halo3& f3, const Halo2& f2, int i0, int ni, int k) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ni) return;
   i += i0;
+  const bool south = g.jws == 0, north = g.jwn == g.Ny && !g.cv.north_fold;
   if (k < g.Nz) {
     for (int q = 0; q < f3.n; q++) {
       real* c = f3.p[q];
       if (f3.is_v[q]) {  // v: faces 0 and Ny are walls (Ny: unless it is the fold line -- k_fill_fold)
-        c[iv(g, i, 0, k)] = real(0.);
-        if (!g.cv.north_fold) c[iv(g, i, g.Ny, k)] = real(0.);
+        if (south) c[iv(g, i, 0, k)] = real(0.);
+        if (north) c[iv(g, i, g.Ny, k)] = real(0.);
       } else {
-        c[ic(g, i, -1, k)] = c[ic(g, i, 0, k)];
-        if (!g.cv.north_fold) c[ic(g, i, g.Ny, k)] = c[ic(g, i, g.Ny - 1, k)];
+        if (south) c[ic(g, i, -1, k)] = c[ic(g, i, 0, k)];
+        if (north) c[ic(g, i, g.Ny, k)] = c[ic(g, i, g.Ny - 1, k)];
       }
     }
   } else {
     for (int q = 0; q < f2.n; q++) {
       real* c = f2.p[q];
       if (f2.is_v[q]) {
-        c[i2(g, i, 0)] = real(0.);
-        if (!g.cv.north_fold) c[i2(g, i, g.Ny)] = real(0.);
+        if (south) c[i2(g, i, 0)] = real(0.);
+        if (north) c[i2(g, i, g.Ny)] = real(0.);
       } else {
-        c[i2(g, i, -1)] = c[i2(g, i, 0)];
-        if (!g.cv.north_fold) c[i2(g, i, g.Ny)] = c[i2(g, i, g.Ny - 1)];
+        if (south) c[i2(g, i, -1)] = c[i2(g, i, 0)];
+        if (north) c[i2(g, i, g.Ny)] = c[i2(g, i, g.Ny - 1)];
       }
     }
   }
 }
 __global__ void k_fill_y(Grid g, Halo3 f3, Halo2 f2, int i0, int ni) { fill_y_body(g, f3, f2, i0, ni, blockIdx.y); }
-// bottom/top layer of the four 3-D fields over columns [i0, i0+ni).  grid: (ceil(ni/256), Ny)
+// bottom/top layer of the four 3-D fields over columns [i0, i0+ni).  grid: (ceil(ni/256), rows): row j = jlo + blockIdx.y
+// (rows [0, Ny); a rank of a 2-D decomposition also does the halo rows of its open sides once they have arrived)
 __device__ __forceinline__ void fill_z_body(const Grid& g, const Halo3& f3, int i0, int ni, int j) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ni) return;
@@ -96,21 +100,21 @@ __device__ __forceinline__ void fill_z_body(const Grid& g, const Halo3& f3, int 
     if (f3.is_v[q]) {
       // (row 0 is the wall face: the y fill zeroes it at every level, and copying that zero is spelled out here so
       // that this fill does not depend on the other one having run)
-      c[iv(g, i, j, -1)] = (j == 0) ? real(0.) : c[iv(g, i, j, 0)];
-      c[iv(g, i, j, g.Nz)] = (j == 0) ? real(0.) : c[iv(g, i, j, g.Nz - 1)];
+      c[iv(g, i, j, -1)] = (j == g.jws) ? real(0.) : c[iv(g, i, j, 0)];
+      c[iv(g, i, j, g.Nz)] = (j == g.jws) ? real(0.) : c[iv(g, i, j, g.Nz - 1)];
     } else {
       c[ic(g, i, j, -1)] = c[ic(g, i, j, 0)];
       c[ic(g, i, j, g.Nz)] = c[ic(g, i, j, g.Nz - 1)];
     }
   }
 }
-__global__ void k_fill_z(Grid g, Halo3 f3, int i0, int ni) { fill_z_body(g, f3, i0, ni, blockIdx.y); }
+__global__ void k_fill_z(Grid g, Halo3 f3, int i0, int ni, int jlo) { fill_z_body(g, f3, i0, ni, jlo + (int)blockIdx.y); }
 // both in one launch: they touch disjoint cells and neither reads what the other writes.
-// grid: (ceil(ni/256), Nz + 1 + Ny)
-__global__ void k_fill_yz(Grid g, Halo3 f3, Halo2 f2, int i0, int ni) {
+// grid: (ceil(ni/256), Nz + 1 + rows of the z part)
+__global__ void k_fill_yz(Grid g, Halo3 f3, Halo2 f2, int i0, int ni, int jlo) {
   const int b = blockIdx.y;
   if (b <= g.Nz) fill_y_body(g, f3, f2, i0, ni, b);
-  else fill_z_body(g, f3, i0, ni, b - (g.Nz + 1));
+  else fill_z_body(g, f3, i0, ni, jlo + b - (g.Nz + 1));
 }
 // periodic x for one array of `rows` parent rows: thread = (q in 0..2H-1, row)
 __device__ __forceinline__ void periodic_row(const Grid& g, real* c, long row, int q) {
@@ -219,7 +223,7 @@ __global__ void k_fold_unpack(Grid g, FoldFields F, const real* __restrict__ buf
 // unpack); a single domain packs and unpacks its own buffer.  Buffer: [array 0..4][q = 1..Wy+1][array column].
 struct TallRows {
   real* p[5];          // eta, U, V, G.U, G.V (geometry: pitch sx, first row -H)
-  int sx, xo, Wy;      // pitch, array column of i = 0, rows beyond the pivot row (the y-face arrays take one more)
+  int sx, xo, yo, Wy;  // pitch, array column of i = 0, array row of j = 0, rows beyond the pivot row (the y-face arrays take one more)
   int wrap;            // single domain: the x face beyond the last column is face 0
 };
 // grid: (ceil(sx/256), Wy + 1, 5)
@@ -232,7 +236,7 @@ __global__ void k_tall_rows(Grid g, TallRows T, real* __restrict__ buf, int ig0,
   real* c = T.p[f];
   const long bo = ((long)f * (T.Wy + 1) + (q - 1)) * T.sx;
   if (PACK) {
-    buf[bo + a] = c[a + (long)T.sx * ((is_v ? g.Ny - q : g.Ny - 1 - q) + g.H)];
+    buf[bo + a] = c[a + (long)T.sx * ((is_v ? g.Ny - q : g.Ny - 1 - q) + T.yo)];
     return;
   }
   int am = xf ? T.sx - a : T.sx - 1 - a;   // the source's array column in the sender's (mirrored) layout
@@ -241,7 +245,7 @@ __global__ void k_tall_rows(Grid g, TallRows T, real* __restrict__ buf, int ig0,
   if (am < 0 || am >= T.sx) return;
   int ig = ig0 + a - T.xo;
   ig = ((ig % Nxg) + Nxg) % Nxg;
-  c[a + (long)T.sx * (g.Ny - 1 + q + g.H)] = fold_sign(ig, xf, f != 0) * buf[bo + am];
+  c[a + (long)T.sx * (g.Ny - 1 + q + T.yo)] = fold_sign(ig, xf, f != 0) * buf[bo + am];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(256) void k_tracer_tendencies(Grid g, const real* _
   const real dz = g.dzc[k];
   const real Ax = g.dy * dz, Ays = g.dxf[j] * dz, Ayn = g.dxf[j + 1] * dz, Az = g.azc[j];
   const real uw = u[o], ue = u[o + 1], vs = v[ov], vn = v[ov + g.sx], wb = w[o], wt = w[o + g.pl_c];
-  const int oys = biased_order_face(j, g.Ny), oyn = biased_order_face(j + 1, g.Ny);
+  const int oys = biased_order_face(j - g.jws, g.jwn - g.jws), oyn = biased_order_face(j + 1 - g.jws, g.jwn - g.jws);
   const int ozb = biased_order_face(k, g.Nz), ozt = biased_order_face(k + 1, g.Nz);
   const real rV = g.razc[j] * g.rdzc[k];
   GT[o] = -(tracer_div(g, T, o, Ax, uw, ue, Ays, Ayn, vs, vn, Az, wb, wt, oys, oyn, ozb, ozt) * rV);
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(256) void k_gu(Grid g, const real* __restrict__ u, 
     uq[m] = real(0.5) * (us + uc);
     vq[m] = real(0.5) * (vw + vc);
   }
-  const real zetaR = biased6<true>(biased_order_center(j, g.Ny), vhat > real(0.), zq, uq, vq);
+  const real zetaR = biased6<true>(biased_order_center(j - g.jws, g.jwn - g.jws), vhat > real(0.), zq, uq, vq);
   const real hadv = -vhat * zetaR;
 
   // self-upwinded divergence flux
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(256) void k_gu(Grid g, const real* __restrict__ u, 
     real vc = v[ov + (m - 1) * sx], vw = v[ov - 1 + (m - 1) * sx];
     a4[m] = real(0.5) * vc * vc - real(0.5) * vw * vw;
   }
-  const real dKv = sym_interp(sym4_center(j, g.Ny), a4[0], a4[1], a4[2], a4[3]);
+  const real dKv = sym_interp(sym4_center(j - g.jws, g.jwn - g.jws), a4[0], a4[1], a4[2], a4[3]);
   const real bern = (dKu + dKv) * rdxc_j;
 
   const real cor = -real(0.5) * (g.fcor[j] + g.fcor[j + 1]) * vhat;
@@ -718,8 +722,8 @@ __global__ __launch_bounds__(256) void k_gv(Grid g, const real* __restrict__ u, 
     Dv[m] = g.dxf[jc + 1] * dz * v7[m + 1] - g.dxf[jc] * dz * v7[m];
     Dd[m] = Du[m] + Dv[m];
   }
-  const int of = biased_order_face(j, g.Ny);
-  const bool s4 = sym4_face(j, g.Ny);
+  const int of = biased_order_face(j - g.jws, g.jwn - g.jws);
+  const bool s4 = sym4_face(j - g.jws, g.jwn - g.jws);
   const real dus = sym_interp(s4, Du[1], Du[2], Du[3], Du[4]);
   const real dvR = biased6<false>(of, vhat > real(0.), Dv, Dd, Dd);
   const real phi = vhat * (dus + dvR);
@@ -812,8 +816,8 @@ __global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, real* __restrict
     GU[o2] = SU;
     Usum[o2] = IU;
   }
-  GV[o2] = (j == 0) ? real(0.) : SV;  // the wall face is a peripheral node
-  Vsum[o2] = (j == 0) ? real(0.) : IV;  // v on the wall face is reset to zero by the halo fill before the corrector
+  GV[o2] = (j == g.jws) ? real(0.) : SV;  // the wall face is a peripheral node
+  Vsum[o2] = (j == g.jws) ? real(0.) : IV;  // v on the wall face is reset to zero by the halo fill before the corrector
 }
 // Second half of the velocity look-ahead: adds up the per-chunk column sums the momentum kernel left in P
 // (layout [quantity 0..3][chunk][2-D parent]) in chunk order.
@@ -837,8 +841,8 @@ __global__ __launch_bounds__(256) void k_ab2_velocities_finish(Grid g, const rea
     GU[o2] = t[0];
     Usum[o2] = t[2];
   }
-  GV[o2] = (j == 0) ? real(0.) : t[1];
-  Vsum[o2] = (j == 0) ? real(0.) : t[3];
+  GV[o2] = (j == g.jws) ? real(0.) : t[1];
+  Vsum[o2] = (j == g.jws) ? real(0.) : t[3];
 }
 
 // =============================================================================================
@@ -884,7 +888,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical(Grid g, real* __restr
   real* F = f ? fb : fa;
   real* S = f ? sum_b : sum_a;
   const real dK = dt * (f ? Kb : Ka);
-  const bool solve = dK != real(0.) && kf < Nz && !(vsh && j == 0);
+  const bool solve = dK != real(0.) && kf < Nz && !(vsh && j == g.jws);
   if (!solve && S == nullptr) return;
   const int pl = vsh ? g.pl_v : g.pl_c, o0 = vsh ? iv(g, i, j, 0) : ic(g, i, j, 0);
 #pragma unroll 8
@@ -918,7 +922,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical(Grid g, real* __restr
       for (int k = k0; k < k1; k++) q = (k == k0) ? g.dzc[k] * col[k * T + tid] : rfma(g.dzc[k], col[k * T + tid], q);
       tot = (k0 == 0) ? q : tot + q;
     }
-    S[o2] = (vsh && j == 0) ? real(0.) : tot;
+    S[o2] = (vsh && j == g.jws) ? real(0.) : tot;
   }
 }
 
@@ -952,7 +956,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_reg(Grid g, ImplicitF
   real x[NZT];
 #pragma unroll
   for (int k = 0; k < NZT; k++) x[k] = (k < Nz) ? F[o0 + k * pl] : real(0.);
-  if (kf < Nz && !(vsh && j == 0)) {
+  if (kf < Nz && !(vsh && j == g.jws)) {
     const real* rb = A.rb[f] + kf * Nz;
     const real* gm = A.gm[f] + kf * Nz;
     const real* lo = A.lo[f];
@@ -983,7 +987,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_reg(Grid g, ImplicitF
           kk = 0;
         }
       }
-    A.sum[f][o2] = (vsh && j == 0) ? real(0.) : tot;
+    A.sum[f][o2] = (vsh && j == g.jws) ? real(0.) : tot;
   }
 }
 
@@ -1054,30 +1058,33 @@ struct Baro {
   // geometry of these 2-D arrays: row pitch, array column of i = 0, computed range [ilo, ihi), and
   // whether i-1 / i+1 wrap around the periodic domain (single slab) or simply reach into the wide halo
   int sx, xo, ilo, ihi, wrap;
-  // rows [0, jhi) are advanced: Ny, or Ny + Wy on the tall arrays of a folded grid (whose rows beyond the pivot row are images)
-  int jhi;
+  // rows [jlo, jhi) are advanced: [0, Ny); up to Ny + Wy on the tall arrays of a folded grid (whose rows beyond the pivot row
+  // are images); on a rank of a 2-D decomposition from -Wy / up to Ny + Wy on the sides where a neighbour's rows were received
+  // (wide halos in y, as in x).  yo: array row of j = 0.  top_open: no wall behind row jhi - 1 -- the face row jhi exists and is
+  // read (a fold's is an image and is carried through the ping-pong; a neighbour's is rim)
+  int jlo, jhi, yo, top_open;
 };
-__device__ __forceinline__ int bi(const Grid& g, const Baro& b, int i, int j) { return (i + b.xo) + b.sx * (j + g.H); }
+__device__ __forceinline__ int bi(const Grid& g, const Baro& b, int i, int j) { return (i + b.xo) + b.sx * (j + b.yo); }
 __device__ __forceinline__ real eta_step(const Grid& g, const Baro& b, int i, int j, real dtau) {
   int ip = (b.wrap && i == g.Nx - 1) ? 0 : i + 1;
   real dxU = g.dy * b.U0[bi(g, b, ip, j)] - g.dy * b.U0[bi(g, b, i, j)];
   real dyV;
-  if (j == g.Ny - 1) dyV = -(g.dxf[j] * b.V0[bi(g, b, i, j)]);
-  else if (j == 0) dyV = g.dxf[1] * b.V0[bi(g, b, i, 1)];
+  if (j == g.jwn - 1) dyV = -(g.dxf[j] * b.V0[bi(g, b, i, j)]);
+  else if (j == g.jws) dyV = g.dxf[j + 1] * b.V0[bi(g, b, i, j + 1)];
   else dyV = g.dxf[j + 1] * b.V0[bi(g, b, i, j + 1)] - g.dxf[j] * b.V0[bi(g, b, i, j)];
   return b.eta0[bi(g, b, i, j)] - dtau * (dxU + dyV) / g.azc[j];
 }
 template <bool IMM>
 __global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, real dtau, real wgt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x + b.ilo;
-  int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= b.ihi || j >= g.Ny) return;   // (the lat-lon grid has walls: b.jhi == Ny)
+  int j = blockIdx.y * blockDim.y + threadIdx.y + b.jlo;
+  if (i >= b.ihi || j >= b.jhi) return;
   int im = (b.wrap && i == 0) ? g.Nx - 1 : i - 1;
   real e = eta_step(g, b, i, j, dtau);
   real ew = eta_step(g, b, im, j, dtau);
   real dxe = (e - ew) / g.dxc[j];
   real dye = real(0.);
-  if (j > 0) dye = (e - eta_step(g, b, i, j - 1, dtau)) / g.dy;
+  if (j != g.jws) dye = (e - eta_step(g, b, i, j - 1, dtau)) / g.dy;
   int o = bi(g, b, i, j);
   // (next to land the face has no depth: no pressure force, and G.U is zero there, so the transport stays zero)
   real Un = b.U0[o] + dtau * (-g.g * (IMM ? b.Hfc[o] : g.Lz) * dxe + b.GU[o]);
@@ -1102,25 +1109,25 @@ __device__ __forceinline__ real eta_step_curv(const Grid& g, const Baro& b, cons
   const int ip = (b.wrap && i == g.Nx - 1) ? 0 : i + 1, o = bi(g, b, i, j), oe = bi(g, b, ip, j);
   const real dxU = c.dyfc[oe] * b.U0[oe] - c.dyfc[o] * b.U0[o];
   real dyV;
-  if (j == g.Ny - 1 && !g.cv.north_fold) dyV = -(c.dxcf[o] * b.V0[o]);
-  else if (j == 0) dyV = c.dxcf[o + b.sx] * b.V0[o + b.sx];
+  if (j == g.jwn - 1 && !g.cv.north_fold) dyV = -(c.dxcf[o] * b.V0[o]);
+  else if (j == g.jws) dyV = c.dxcf[o + b.sx] * b.V0[o + b.sx];
   else dyV = c.dxcf[o + b.sx] * b.V0[o + b.sx] - c.dxcf[o] * b.V0[o];
   return b.eta0[o] - dtau * (dxU + dyV) * c.razcc[o];
 }
 __global__ __launch_bounds__(256) void k_barotropic_substep_curv(Grid g, Baro b, CurvBaro c, real dtau, real wgt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x + b.ilo;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y + b.jlo;
   if (i >= b.ihi || j > b.jhi) return;
   const int o = bi(g, b, i, j);
-  if (j == b.jhi) {   // folded grid: the face row behind the last advanced row is carried along unchanged
-    if (g.cv.north_fold) b.V1[o] = b.V0[o];
+  if (j == b.jhi) {   // no wall there: the face row behind the last advanced row is carried along unchanged
+    if (b.top_open) b.V1[o] = b.V0[o];
     return;
   }
   const int im = (b.wrap && i == 0) ? g.Nx - 1 : i - 1;
   const real e = eta_step_curv(g, b, c, i, j, dtau);
   const real dxe = (e - eta_step_curv(g, b, c, im, j, dtau)) * c.rdxfc[o];
   real dye = real(0.);
-  if (j > 0) dye = (e - eta_step_curv(g, b, c, i, j - 1, dtau)) * c.rdycf[o];
+  if (j != g.jws) dye = (e - eta_step_curv(g, b, c, i, j - 1, dtau)) * c.rdycf[o];
   const real Un = b.U0[o] + dtau * (-g.g * b.Hfc[o] * dxe + b.GU[o]);
   const real Vn = b.V0[o] + dtau * (-g.g * b.Hcf[o] * dye + b.GV[o]);
   b.eta1[o] = e;
@@ -1152,6 +1159,7 @@ struct BaroMulti {
   // eta, U, V (periodic x images, y layer, zero on the wall faces of V): no fill launch for them in the step
   int fold;
   int out_halo;   // widened slab: the last launch writes eta, U, V of this many x halo columns too (nothing is exchanged after it)
+  int out_js, out_jn;   // ... of the rows [out_js, out_jn): [0, Ny), with the halo rows of the open sides of a rank of a 2-D decomposition
 };
 // (3 waves per SIMD: at 1440x720 the launch has 540 blocks; with the 173 VGPRs the 7-substep variant took when left alone
 // only two blocks fit a CU, 512 on the chip, and the last 28 blocks were a second round that doubled the launch time)
@@ -1168,10 +1176,10 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
   __builtin_amdgcn_s_setprio(3);
   const Baro& b = bm.b;
   const int tid = threadIdx.x;
-  const int i0 = b.ilo + blockIdx.x * BT_TX, j0 = blockIdx.y * BT_TY;
+  const int i0 = b.ilo + blockIdx.x * BT_TX, j0 = b.jlo + blockIdx.y * BT_TY;
   if (tid <= BT_RY) {
-    // rows beyond the metric tables (|jg| > Ny + H + 2) do not exist in the domain; their entries are never used
-    const int jg = max(-(g.H + 2), min(g.Ny + g.H + 2, j0 - BT_S + tid));
+    // rows beyond the metric tables do not exist in the domain; their entries are never used
+    const int jg = max(b.jlo - (g.H + 2), min(b.jhi + g.H + 2, j0 - BT_S + tid));
     Mdxf[tid] = g.dxf[jg];
     if (tid < BT_RY) {
       Mrazc[tid] = g.razc[jg];
@@ -1192,7 +1200,7 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
     const int ig = i0 - BT_S + lx, jg = j0 - BT_S + ly;
     pl[q] = p;
     pj[q] = jg;
-    const bool exists = (p < BT_NP) && jg >= 0 && jg < g.Ny;
+    const bool exists = (p < BT_NP) && jg >= b.jlo && jg < b.jhi;
     int ii = ig;
     if (b.wrap) {
       ii = ii % g.Nx;
@@ -1243,11 +1251,11 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
     for (int q = 0; q < BT_PPT; q++) {
       const int p = pl[q], jg = pj[q];
       const int ly = p / BT_RX, lx = p - ly * BT_RX;
-      if (po[q] >= 0 && lx < BT_RX - 1 && (ly < BT_RY - 1 || jg == g.Ny - 1)) {
+      if (po[q] >= 0 && lx < BT_RX - 1 && (ly < BT_RY - 1 || jg == g.jwn - 1)) {
         real dxU = dyc * U[ly][lx + 1] - dyc * U[ly][lx];
         real dyV;
-        if (jg == g.Ny - 1) dyV = -(Mdxf[ly] * V[ly][lx]);
-        else if (jg == 0) dyV = Mdxf[ly + 1] * V[ly + 1][lx];
+        if (jg == g.jwn - 1) dyV = -(Mdxf[ly] * V[ly][lx]);
+        else if (jg == g.jws) dyV = Mdxf[ly + 1] * V[ly + 1][lx];
         else dyV = Mdxf[ly + 1] * V[ly + 1][lx] - Mdxf[ly] * V[ly][lx];
         real e = E[ly][lx] - dtau * (dxU + dyV) * Mrazc[ly];
         E[ly][lx] = e;
@@ -1260,11 +1268,11 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
     for (int q = 0; q < BT_PPT; q++) {
       const int p = pl[q], jg = pj[q];
       const int ly = p / BT_RX, lx = p - ly * BT_RX;
-      if (po[q] >= 0 && lx >= 1 && (ly >= 1 || jg == 0)) {
+      if (po[q] >= 0 && lx >= 1 && (ly >= 1 || jg == g.jws)) {
         real e = E[ly][lx];
         real dxe = (e - E[ly][lx - 1]) * Mrdxc[ly];
         real dye = real(0.);
-        if (jg > 0) dye = (e - E[ly - 1][lx]) * rdy;
+        if (jg != g.jws) dye = (e - E[ly - 1][lx]) * rdy;
         real Un = U[ly][lx] + dtau * (GUs[ly][lx] - ghf[q] * dxe);
         real Vn = V[ly][lx] + dtau * (GVs[ly][lx] - ghc[q] * dye);
         U[ly][lx] = Un;
@@ -1290,7 +1298,8 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
       if (bm.last) {
         const int ly = p / BT_RX, lx = p - ly * BT_RX;
         const int ig = i0 - BT_S + lx;
-        if (ig >= -bm.out_halo && ig < g.Nx + bm.out_halo) {   // (a widened slab also owns columns outside the canonical array)
+        // (a widened slab also owns columns -- and, in a 2-D decomposition, rows -- outside the canonical array)
+        if (ig >= -bm.out_halo && ig < g.Nx + bm.out_halo && pj[q] >= bm.out_js && pj[q] < bm.out_jn) {
           const int oc = i2(g, ig, pj[q]);
           if (bm.fold) {
             const int jg = pj[q];
@@ -1338,8 +1347,8 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
   __builtin_amdgcn_s_setprio(3);
   const Baro& b = bm.b;
   const int tid = threadIdx.x, Nx = g.Nx, Ny = g.Ny;
-  const int i0 = b.ilo + blockIdx.x * BT_TX, j0 = blockIdx.y * BT_TY;
-  const bool open_north = g.cv.north_fold != 0;   // no wall behind the last advanced row: the face row jhi exists (read only)
+  const int i0 = b.ilo + blockIdx.x * BT_TX, j0 = b.jlo + blockIdx.y * BT_TY;
+  const bool open_north = b.top_open != 0;   // no wall behind the last advanced row: the face row jhi exists (read only)
   const int jtop = b.jhi + (open_north ? 1 : 0);
   const int lo = -b.xo, hi = b.sx - b.xo - 1;     // valid array columns (slab mode: clamp; garbage stays in the rim)
   int po[BT_PPT];                               // element offset of the point in the scratch / average arrays (-1: none)
@@ -1352,7 +1361,7 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
     const int p = tid + q * BT_NT;
     const int ly = p / BT_RX, lx = p - ly * BT_RX;
     const int ig = i0 - BT_S + lx, jg = j0 - BT_S + ly;
-    const bool exists = (p < BT_NP) && jg >= 0 && jg < jtop;
+    const bool exists = (p < BT_NP) && jg >= b.jlo && jg < jtop;
     int ii = ig;
     if (b.wrap) {
       ii = ii % Nx;
@@ -1410,12 +1419,12 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
     for (int q = 0; q < BT_PPT; q++) {
       const int p = tid + q * BT_NT;
       const int ly = p / BT_RX, lx = p - ly * BT_RX, jg = j0 - BT_S + ly;
-      const bool wall = !open_north && jg == Ny - 1;
+      const bool wall = jg == g.jwn - 1 && !g.cv.north_fold;
       if (po[q] >= 0 && jg < b.jhi && lx < BT_RX - 1 && (ly < BT_RY - 1 || wall)) {
         const real dxU = FU[ly][lx + 1] - FU[ly][lx];
         real dyV;
         if (wall) dyV = -FV[ly][lx];
-        else if (jg == 0) dyV = FV[ly + 1][lx];
+        else if (jg == g.jws) dyV = FV[ly + 1][lx];
         else dyV = FV[ly + 1][lx] - FV[ly][lx];
         const real e = E[ly][lx] - dtau * (dxU + dyV) * mrazcc[q];
         E[ly][lx] = e;
@@ -1428,11 +1437,11 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
     for (int q = 0; q < BT_PPT; q++) {
       const int p = tid + q * BT_NT;
       const int ly = p / BT_RX, lx = p - ly * BT_RX, jg = j0 - BT_S + ly;
-      if (po[q] >= 0 && jg < b.jhi && lx >= 1 && (ly >= 1 || jg == 0)) {
+      if (po[q] >= 0 && jg < b.jhi && lx >= 1 && (ly >= 1 || jg == g.jws)) {
         const real e = E[ly][lx];
         const real dxe = (e - E[ly][lx - 1]) * mrdxfc[q];
         real dye = real(0.);
-        if (jg > 0) dye = (e - E[ly - 1][lx]) * mrdycf[q];
+        if (jg != g.jws) dye = (e - E[ly - 1][lx]) * mrdycf[q];
         const real Un = U[ly][lx] + dtau * (nghf[q] * dxe + gu[q]);
         const real Vn = V[ly][lx] + dtau * (nghc[q] * dye + gv[q]);
         U[ly][lx] = Un;
@@ -1462,7 +1471,7 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
       if (bm.last) {   // eta, U, V <- the averages, in arrays of the canonical layout (and the filtered state, when the
         const int ly = p / BT_RX, lx = p - ly * BT_RX;   // averages live in work arrays of another geometry)
         const int ig = i0 - BT_S + lx, jg = j0 - BT_S + ly;
-        if (jg < Ny && ig >= -bm.out_halo && ig < Nx + bm.out_halo) {
+        if (jg >= bm.out_js && jg < bm.out_jn && ig >= -bm.out_halo && ig < Nx + bm.out_halo) {
           const int oc = i2(g, ig, jg);
           bm.eta_out[oc] = ae[q];
           bm.U_out[oc] = au[q];
@@ -1479,14 +1488,14 @@ __global__ __launch_bounds__(BT_NT, 3) void k_barotropic_multi_curv(Grid g, Baro
 #pragma clang fp contract(fast)
 
 // eta, U, V <- time averages on the interior (source arrays may be the wide work arrays)
+// rows [js, jn): [0, Ny), with the halo rows of the open sides of a rank of a 2-D decomposition
 __global__ void k_barotropic_finalize(Grid g, real* eta, real* U, real* V, const real* etab, const real* Ub,
-                                      const real* Vb, int src_sx, int src_xo, int halo) {
+                                      const real* Vb, int src_sx, int src_xo, int src_yo, int halo, int js, int jn) {
   int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - halo;   // (halo > 0: a widened slab, its x halo columns included)
-  int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx + halo || j >= g.Ny) return;
-  int o = i2(g, i, j), q = (i + src_xo) + src_sx * (j + g.H);
+  int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) + js;
+  if (i >= g.Nx + halo || j >= jn) return;
+  int o = i2(g, i, j), q = (i + src_xo) + src_sx * (j + src_yo);
   V[o] = Vb[q];
-  if (j >= g.Ny) return;   // (the fold line carries y faces only)
   eta[o] = etab[q];
   U[o] = Ub[q];
 }
@@ -1537,15 +1546,18 @@ __global__ __launch_bounds__(256) void k_corrector_cells(Grid g, real* __restric
                                                          const real* __restrict__ U, const real* __restrict__ V,
                                                          real* __restrict__ Ub, real* __restrict__ Vb,
                                                          const real* __restrict__ Usum, const real* __restrict__ Vsum,
-                                                         int i0, int ni, int skip_from, int skip) {
+                                                         int i0, int ni, int skip_from, int skip, int jr0, int nj,
+                                                         int jskip_from, int jskip) {
   // columns i0 .. i0+ni-1 with a gap of `skip` columns from index skip_from on (the two x-halo strips of a slab in one
-  // launch: their column integrals arrived with the 3-D bundle, computed by the columns' owner)
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
-  if (idx >= ni || j >= g.Ny) return;
-  int i = i0 + idx;
+  // launch: their column integrals arrived with the 3-D bundle, computed by the columns' owner); rows likewise (jr0, nj,
+  // jskip_from, jskip: [0, Ny), or the halo rows of the open sides of a rank of a 2-D decomposition)
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, jy = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
+  if (idx >= ni || jy >= nj) return;
+  int i = i0 + idx, j = jr0 + jy;
   if (i >= skip_from) i += skip;
+  if (j >= jskip_from) j += jskip;
   const int o2 = i2(g, i, j);
-  const bool urow = j < g.Ny;   // (zipper fold: the fold line carries y faces only)
+  const bool urow = true;
   const real su = Usum[o2], sv = Vsum[o2];
   if (k == 0) {
     if (urow) Ub[o2] = su;
@@ -1667,40 +1679,21 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
                                                    const real* __restrict__ U, const real* __restrict__ V,
                                                    real* __restrict__ Ub, real* __restrict__ Vb,
                                                    const real* __restrict__ Usum, const real* __restrict__ Vsum,
-                                                   int i0, int ni, int kchunks, int skip_from, int skip) {
+                                                   int i0, int ni, int kchunks, int skip_from, int skip, int jr0, int nj,
+                                                   int jskip_from, int jskip) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= ni || j >= g.Ny) return;
+  if (i >= ni || j >= nj) return;
   i += i0;
   if (i >= skip_from) i += skip;   // (the two x-halo strips of a slab in one launch: skip the interior)
-  if (j >= g.Ny) {   // zipper fold: the y faces on the fold line, v only (never with FOLD)
-    const int o2 = i2(g, i, j);
-    int ov = iv(g, i, j, 0);
-    real sv = real(0.);
-    if (Vsum != nullptr && i >= 0 && i < g.Nx) {
-      sv = Vsum[o2];
-    } else {
-      const int klen = (g.Nz + kchunks - 1) / kchunks;
-      for (int k0 = 0; k0 < g.Nz; k0 += klen) {
-        const int k1 = min(g.Nz, k0 + klen);
-        real pv = real(0.);
-        for (int k = k0; k < k1; k++, ov += g.pl_v) pv = (k == k0) ? g.dzc[k] * v[ov] : rfma(g.dzc[k], v[ov], pv);
-        sv = (k0 == 0) ? pv : sv + pv;
-      }
-    }
-    if (i >= 0 && i < g.Nx) Vb[o2] = sv;
-    const real dv = (V[o2] - sv) * (IMM ? g.im.rHcf[o2] : g.rLz);
-    const int KPV = IMM ? (int)((g.im.ordC[o2] >> 16) & 255) : 0;
-    ov = iv(g, i, j, 0);
-    for (int k = 0; k < g.Nz; k++, ov += g.pl_v)
-      if (k >= KPV) v[ov] = v[ov] + dv;
-    return;
-  }
+  j += jr0;                        // (rows likewise: [0, Ny), or the halo rows of the open sides of a rank of a 2-D decomposition)
+  if (j >= jskip_from) j += jskip;
+  const bool own = i >= 0 && i < g.Nx && j >= 0 && j < g.Ny;
   const int o0 = ic(g, i, j, 0), ov0 = iv(g, i, j, 0);
   const int o2 = i2(g, i, j);
   int o = o0, ov = ov0;
   real su = real(0.), sv = real(0.);
-  if (Usum != nullptr && i >= 0 && i < g.Nx) {
+  if (Usum != nullptr && own) {
     // interior column: the integrals were accumulated by the AB2 kernel / the momentum kernel's look-ahead
     su = Usum[o2];
     sv = Vsum[o2];
@@ -1721,7 +1714,7 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
       sv = (k0 == 0) ? pv : sv + pv;
     }
   }
-  if (i >= 0 && i < g.Nx) {
+  if (own) {
     Ub[o2] = su;
     Vb[o2] = sv;
   }
@@ -1800,11 +1793,12 @@ __global__ __launch_bounds__(256) void k_mask_immersed(Grid g, real* __restrict_
                                                        real* __restrict__ U, real* __restrict__ V) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j > g.Ny || (j == g.Ny && g.cv.north_fold)) return;   // (the y faces beyond the pivot row are halo cells)
+  // (the y faces beyond the pivot row are halo cells; so is face row Ny of a rank whose northern neighbour owns it)
+  if (i >= g.Nx || j > g.Ny || (j == g.Ny && (g.cv.north_fold || g.jwn != g.Ny))) return;
   const int o2 = i2(g, i, j);
   const unsigned A = g.im.ordA[o2], C = g.im.ordC[o2];
   // v faces: j = 0 and j = Ny are walls (peripheral on the underlying grid); in between KPV levels touch the solid
-  const bool wall = j == 0 || (j == g.Ny && !g.cv.north_fold);   // (the fold line is no wall)
+  const bool wall = j == g.jws || (j == g.jwn && !g.cv.north_fold);   // (the fold line is no wall)
   const int kpv = wall ? g.Nz : (int)((C >> 16) & 255);
   int ov = iv(g, i, j, 0);
   for (int k = 0; k < min(kpv, g.Nz); k++, ov += g.pl_v) v[ov] = real(0.);
@@ -1840,6 +1834,30 @@ __global__ void k_move_columns(ColumnPieces P) {
   real* a = P.arr[f] + row * P.sx[f] + P.i0[f] + q;
   if (PACK) P.buf[f][t] = *a;
   else *a = P.buf[f][t];
+}
+
+// y halo exchange of a 2-D decomposition: pack the rows next to a northern / southern edge, unpack into the halo rows.  Whole
+// rows move (every parent column: the x halo columns the western / eastern neighbours sent are the corner cells of the
+// diagonal neighbours).  ONE launch moves every field of a group on one side (blockIdx.z = piece).
+// buffer layout per piece: [plane][row][column].
+struct RowPieces {
+  real* arr[16];
+  real* buf[16];
+  int sx[16], r0[16];     // row pitch = columns moved; first array row of the strip
+  long pl[16];            // plane stride (elements)
+  int k0[16], nz[16];     // first plane and number of planes (1: a 2-D array)
+  int n, nrows;
+};
+template <bool PACK>
+__global__ void k_move_rows(RowPieces P) {
+  const int f = blockIdx.z, kz = blockIdx.y;
+  if (f >= P.n || kz >= P.nz[f]) return;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)P.sx[f] * P.nrows;
+  if (t >= n) return;
+  real* a = P.arr[f] + (long)(P.k0[f] + kz) * P.pl[f] + (long)P.r0[f] * P.sx[f] + t;   // (the rows of a strip are contiguous)
+  if (PACK) P.buf[f][(long)kz * n + t] = *a;
+  else *a = P.buf[f][(long)kz * n + t];
 }
 
 }  // namespace gb25

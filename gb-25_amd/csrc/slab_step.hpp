@@ -79,13 +79,14 @@ void group_pieces(gb25_model* m, int group, std::vector<Piece>& out, int* ncols)
   } else {
     *ncols = m->W;
     const int wsx = m->Nx + 2 * m->W;
+    const size_t up = (size_t)m->Wys * wsx;   // (2-D decomposition: the work arrays start Wys rows below the canonical ones)
     for (int q = 0; q < 3; q++) {
       Field& F = m->f[GB25_ETA + q];
-      out.push_back({F.d, m->wide[0][q].d, sx, H, wsx, m->W, (long)F.ny});
+      out.push_back({F.d, m->wide[0][q].d + up, sx, H, wsx, m->W, (long)F.ny});
     }
     for (int q = 0; q < 2; q++) {
       Field& F = group == 1 ? m->f[GB25_GN_BT_U + q] : m->ahead_G[q];
-      out.push_back({F.d, m->wideG[q].d, sx, H, wsx, m->W, (long)F.ny});
+      out.push_back({F.d, m->wideG[q].d + up, sx, H, wsx, m->W, (long)F.ny});
     }
   }
 }
@@ -123,6 +124,61 @@ gb25_status pack_unpack(gb25_model* m, int group, real* const buf[2], bool pack)
   dim3 gr((unsigned)((max_n + 255) / 256), (unsigned)P.n);
   if (pack) hipLaunchKernelGGL(k_move_columns<true>, gr, dim3(256), 0, m->stream, P);
   else hipLaunchKernelGGL(k_move_columns<false>, gr, dim3(256), 0, m->stream, P);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+
+// ---- y halos of a 2-D (x, y) decomposition: whole rows (every parent column) to the southern / northern neighbour ------------
+// group 10: H rows of u, v, T, S (interior levels) -- after group 0 and the barotropic corrector of the own rows (x halo columns
+//           included: the corners), so that the rows arrive corrected, as the rows beyond a fold do (group 6);
+// group 11: W rows of the sub-cycle's work arrays eta, U, V, G.U, G.V (all widened columns) -- after group 1 and the interior copy;
+// group 12: H rows of eta, U, V (initial state) -- after group 2.      13, 14: the same for the sub-cycle look-ahead.
+// side 0: southern edge / halo, side 1: northern.  Rows [0, n) / [Ny - n, Ny) are packed, [-n, 0) / [Ny, Ny + n) unpacked.
+inline bool y_neighbour(const gb25_model* m, int side) { return side == 0 ? m->ys_open : m->yn_open; }
+void row_pieces(gb25_model* m, int group, int side, bool pack, real* buf, RowPieces& P) {
+  const Grid& g = m->g;
+  const int H = g.H;
+  P = RowPieces{};
+  size_t off = 0;
+  auto add = [&](real* arr, int sx, int yoff, long pl, int k0, int nz, int nrows) {
+    const int f = P.n++;
+    const int j = pack ? (side == 0 ? 0 : g.Ny - nrows) : (side == 0 ? -nrows : g.Ny);
+    P.arr[f] = arr; P.buf[f] = buf + off; P.sx[f] = sx; P.r0[f] = j + yoff; P.pl[f] = pl; P.k0[f] = k0; P.nz[f] = nz;
+    P.nrows = nrows;
+    off += (size_t)nz * nrows * sx;
+  };
+  if (group == 10) {
+    for (int id : {GB25_U, GB25_V, GB25_T, GB25_S}) {
+      Field& F = m->f[id];
+      add(F.d, g.sx, H, (long)g.sx * F.ny, H, g.Nz, H);
+    }
+  } else if (group == 11 || group == 13) {
+    const int wsx = g.Nx + 2 * m->W;
+    for (int q = 0; q < 3; q++) add(m->wide[0][q].d, wsx, H + m->Wys, 0, 0, 1, m->W);
+    for (int q = 0; q < 2; q++) add(m->wideG[q].d, wsx, H + m->Wys, 0, 0, 1, m->W);
+  } else {
+    for (int q = 0; q < 3; q++) add((group == 12 ? m->f[GB25_ETA + q] : m->ahead_eta[q]).d, g.sx, H, 0, 0, 1, H);
+  }
+}
+int64_t row_buffer_elems(gb25_model* m, int group) {
+  if (m->Ry < 2) return 1;
+  RowPieces P;
+  row_pieces(m, group, 0, true, nullptr, P);
+  int64_t t = 0;
+  for (int f = 0; f < P.n; f++) t += (int64_t)P.nz[f] * P.nrows * P.sx[f];
+  return t;
+}
+gb25_status move_rows(gb25_model* m, int group, real* const buf[2], bool pack) {
+  for (int side = 0; side < 2; side++) {
+    if (!y_neighbour(m, side)) continue;
+    RowPieces P;
+    row_pieces(m, group, side, pack, buf[side], P);
+    int nzmax = 1, sxmax = 0;
+    for (int f = 0; f < P.n; f++) { nzmax = std::max(nzmax, P.nz[f]); sxmax = std::max(sxmax, P.sx[f]); }
+    const dim3 gr((unsigned)(((long)sxmax * P.nrows + 255) / 256), nzmax, P.n);
+    if (pack) hipLaunchKernelGGL(k_move_rows<true>, gr, dim3(256), 0, m->stream, P);
+    else hipLaunchKernelGGL(k_move_rows<false>, gr, dim3(256), 0, m->stream, P);
+  }
   LAUNCHCHK();
   return GB25_OK;
 }
@@ -174,7 +230,7 @@ gb25_status fold_unpack(gb25_model* m, const real* buf) {
   const Grid& g = m->g;
   FoldFields F = fold_fields(m);
   hipLaunchKernelGGL(k_fold_unpack, dim3((g.sx + 255) / 256, g.H, fold_levels(F, true)), dim3(256), 0, m->stream, g, F, buf,
-                     m->cfg.rank * m->Nx, m->cfg.Nx);
+                     m->rx * m->Nx, m->cfg.Nx);
   LAUNCHCHK();
   return GB25_OK;
 }
@@ -187,7 +243,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
   const real chi = euler ? -real(0.5) : (real)m->cfg.chi;
   const bool split = tendencies_split(m);
   // own columns' pressure early, on the side stream (not on a folded grid: the rows beyond the fold arrive last)
-  const bool p_early = m->two_streams && m->pressure_bits == 64 && !g.cv.north_fold;
+  const bool p_early = m->two_streams && m->pressure_bits == 64 && !g.cv.north_fold && m->Ry == 1;
   if (stage == 0) {
     // AB2 update of u,v,T,S + barotropic forcing, then the y/z boundary layers of the 3-D bundle so that its packed
     // x columns (group 0) can travel WHILE the own columns are corrected
@@ -248,7 +304,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
                          g.Nx);
     }
     LAUNCHCHK();
-    if (g.cv.north_fold && !second_half) return GB25_OK;
+    if ((g.cv.north_fold || m->Ry > 1) && !second_half) return GB25_OK;   // (more rows of the work arrays travel next)
     if (ahead) {
       if ((s = barotropic_impl(m, m->ahead_uv_dt, true))) return s;
       Halo2 h2{};
@@ -274,12 +330,16 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     if ((s = compute_w_impl(m, 1))) return s;
     HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));       // the own columns' pressure differences (side stream)
     return momentum_impl(m, 1);
+  } else if (stage == 32) {
+    // 2-D decomposition: group 0 has been unpacked; the corrector on the x-halo columns of the own rows, so that the rows that
+    // leave for the southern / northern neighbour next (group 10) are corrected over their whole width
+    return corrector_impl(m, true, 2);
   } else if (stage == 3 || stage == 30 || stage == 31) {
     // groups 2 and 0 have been unpacked: corrector on the x-halo columns, then update_state without any
     // further exchange (y/z layers re-filled over the extended x range; w and p recomputed in the halos).
     // Folded grid: stage 30 = up to the y/z layers, then the rows beyond the fold arrive from the partner, stage 31 = the rest.
     if (stage != 31) {
-      if ((s = corrector_impl(m, true, 2))) return s;
+      if (m->Ry == 1 && (s = corrector_impl(m, true, 2))) return s;   // (2-D decomposition: done in stage 32)
       // the interior pressure pass of stage 0 must be over before the fills touch T, S and before the west strip
       // rewrites column 0 (it has been for a while: the exchanges and the sub-cycle ran in between)
       if (p_early) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
@@ -340,7 +400,8 @@ struct StepOps {
   virtual bool velocities_ready(int s) = 0;
   virtual bool subcycle_adopted(int s) = 0;
   virtual bool coupled() { return false; }   // a prescribed atmosphere is set (data-free forcing)
-  virtual bool folded() = 0;          // zipper fold: exchanges with the partner rank (buffer sets 3 and 4; groups 6 and 7)
+  virtual bool folded() = 0;          // zipper fold: exchanges with the partner rank (buffer sets 3 and 4; groups 6 and 8)
+  virtual bool mesh_y() { return false; }   // 2-D decomposition: y halos from the southern / northern neighbour (groups 10 - 14)
   virtual gb25_status record(int slot, bool on_comm) = 0;
   virtual gb25_status wait(int slot, bool comm_waits) = 0;
 };
@@ -376,18 +437,22 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
   EACH(o.pack(s, 0, true));
   SEQ(o.record(1, true));      // (packed)
   SEQ(o.exchange(0, true));
-  if (!adopted && o.folded()) {
+  if (!adopted && (o.folded() || o.mesh_y())) {
     // zipper fold: the work arrays are tall as well as wide.  Once every slab has its wide halo columns, the rows south of
     // the pivot row go to the partner rank P-1-r (group 8) and become its image rows beyond the pivot row; then the substeps
-    // run with no further exchange
+    // run with no further exchange.  2-D decomposition: likewise the W rows next to an open side go to the southern /
+    // northern neighbour (group 11), with the wide halo columns just received: the corners
     for (int s = 0; s < n; s++) {
       SEQ(o.unpack(s, 1, false));
-      SEQ(o.stage(s, 1, euler, false));      // (folded: the interior copy only)
-      SEQ(o.pack(s, 8, false));
+      SEQ(o.stage(s, 1, euler, false));      // (the interior copy only)
+      if (o.mesh_y()) SEQ(o.pack(s, 11, false));
+      if (o.folded()) SEQ(o.pack(s, 8, false));
     }
-    SEQ(o.exchange(8, false));
+    if (o.mesh_y()) SEQ(o.exchange(11, false));
+    if (o.folded()) SEQ(o.exchange(8, false));
     for (int s = 0; s < n; s++) {
-      SEQ(o.unpack(s, 8, false));
+      if (o.mesh_y()) SEQ(o.unpack(s, 11, false));
+      if (o.folded()) SEQ(o.unpack(s, 8, false));
       SEQ(o.stage(s, 16, euler, false));
     }
   } else if (!adopted) {       // ... and is in flight while the sub-cycle runs here (it leaves the x halo columns of the
@@ -402,11 +467,21 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
   EACH(o.stage(s, 2, euler, false));   // own columns + interior tendencies, while the exchanges are in flight
   SEQ(o.record(3, true));
   SEQ(o.wait(3, false));       // the halo columns have arrived
+  if (o.mesh_y()) {
+    // 2-D decomposition: the H rows next to an open side, with the x halo columns just received (the corners)
+    for (int s = 0; s < n; s++) {
+      SEQ(o.unpack(s, 0, false));
+      SEQ(o.stage(s, 32, euler, false));   // (the corrector on the x halo columns: the rows leave corrected)
+      SEQ(o.pack(s, 10, false));
+    }
+    SEQ(o.exchange(10, false));
+    EACH(o.unpack(s, 10, false));
+  }
   if (o.folded()) {
     // the rows beyond the fold come from the partner once every slab has its x halos and y/z layers (the partner sends
     // its halo columns too: the corners), then the rest of update_state!
     for (int s = 0; s < n; s++) {
-      SEQ(o.unpack(s, 0, false));
+      if (!o.mesh_y()) SEQ(o.unpack(s, 0, false));
       SEQ(o.stage(s, 30, euler, false));
       SEQ(o.pack(s, 6, false));
     }
@@ -417,7 +492,7 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
     }
   } else {
     for (int s = 0; s < n; s++) {
-      SEQ(o.unpack(s, 0, false));
+      if (!o.mesh_y()) SEQ(o.unpack(s, 0, false));
       SEQ(o.stage(s, 3, euler, false));
     }
   }
@@ -433,12 +508,15 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
     for (int s = 0; s < n; s++) {
       SEQ(o.unpack(s, 3, true));
       SEQ(o.stage(s, 5, euler, true));   // (x halo columns of the new eta, U, V included: nothing to exchange after it)
+      if (o.mesh_y()) SEQ(o.pack(s, 13, true));
       if (o.folded()) SEQ(o.pack(s, 8, true));
     }
-    if (o.folded()) {                    // the image rows beyond the pivot row, then the substeps
-      SEQ(o.exchange(8, true));
+    if (o.folded() || o.mesh_y()) {      // the neighbours' rows / the image rows beyond the pivot row, then the substeps
+      if (o.mesh_y()) SEQ(o.exchange(13, true));
+      if (o.folded()) SEQ(o.exchange(8, true));
       for (int s = 0; s < n; s++) {
-        SEQ(o.unpack(s, 8, true));
+        if (o.mesh_y()) SEQ(o.unpack(s, 13, true));
+        if (o.folded()) SEQ(o.unpack(s, 8, true));
         SEQ(o.stage(s, 56, euler, true));
       }
     }
@@ -464,10 +542,26 @@ gb25_status sequence_first_time_step(StepOps& o, bool& lookahead_in_flight) {
   }
   SEQ(o.exchange(0, false));
   SEQ(o.exchange(2, false));
-  if (o.folded()) {
+  if (o.mesh_y()) {
     for (int s = 0; s < n; s++) {
       SEQ(o.unpack(s, 0, false));
       SEQ(o.unpack(s, 2, false));
+      SEQ(o.pack(s, 10, false));
+      SEQ(o.pack(s, 12, false));
+    }
+    SEQ(o.exchange(10, false));
+    SEQ(o.exchange(12, false));
+    for (int s = 0; s < n; s++) {
+      SEQ(o.unpack(s, 10, false));
+      SEQ(o.unpack(s, 12, false));
+    }
+  }
+  if (o.folded()) {
+    for (int s = 0; s < n; s++) {
+      if (!o.mesh_y()) {
+        SEQ(o.unpack(s, 0, false));
+        SEQ(o.unpack(s, 2, false));
+      }
       SEQ(o.local(s, 3));          // mask, y/z layers over the extended columns
       SEQ(o.pack(s, 6, false));
     }
@@ -478,8 +572,10 @@ gb25_status sequence_first_time_step(StepOps& o, bool& lookahead_in_flight) {
     }
   } else {
     for (int s = 0; s < n; s++) {
-      SEQ(o.unpack(s, 0, false));
-      SEQ(o.unpack(s, 2, false));
+      if (!o.mesh_y()) {
+        SEQ(o.unpack(s, 0, false));
+        SEQ(o.unpack(s, 2, false));
+      }
       SEQ(o.local(s, 2));
     }
   }
@@ -510,9 +606,10 @@ struct TraceOps : StepOps {
   int nslabs;
   bool adopted, ready;
   std::string log;
-  bool fold = false, is_coupled = false;
+  bool fold = false, is_coupled = false, mesh = false;
   TraceOps(int n_, bool a, bool r) : nslabs(n_), adopted(a), ready(r) {}
   bool folded() override { return fold; }
+  bool mesh_y() override { return mesh; }
   bool coupled() override { return is_coupled; }
   void add(const char* fmt, ...) {
     char buf[96];
@@ -557,10 +654,12 @@ struct SlabGroup {
   hipStream_t main = nullptr, comm = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   Transport* transport = nullptr;
-  // [slab][buffer set][side: 0 west, 1 east]; sets 3, 4 go to the fold partner (side 0 only)
-  std::vector<std::array<std::array<real*, 2>, 5>> send, recv;
-  size_t elems[5] = {0, 0, 0, 0, 0};      // elements per side of buffer set b in an exchange
-  size_t capacity[5] = {0, 0, 0, 0, 0};   // ... and allocated
+  // [slab][buffer set][side: 0 west, 1 east]; sets 3, 4 go to the fold partner (side 0 only); sets 5, 6, 7 to the southern
+  // (side 0) and northern (side 1) neighbour of a 2-D decomposition
+  static constexpr int NSETS = 8;
+  std::vector<std::array<std::array<real*, 2>, NSETS>> send, recv;
+  size_t elems[NSETS] = {0, 0, 0, 0, 0, 0, 0, 0};      // elements per side of buffer set b in an exchange
+  size_t capacity[NSETS] = {0, 0, 0, 0, 0, 0, 0, 0};   // ... and allocated
   bool lookahead_in_flight = false;
   // neighbour handshake of the collective mutators (see collective_guard)
   unsigned long long *tok_dev = nullptr, *tok_host = nullptr;
@@ -569,26 +668,40 @@ struct SlabGroup {
 namespace {
 
 // (groups 6, 8: the partner exchanges of a folded grid -- the rows next to the pivot row; the image rows of the sub-cycle)
-inline int buffer_set(int group) { return group == 6 ? 3 : group == 8 ? 4 : group == 0 ? 0 : ((group == 1 || group == 3) ? 1 : 2); }
+inline int buffer_set(int group) {
+  if (group >= 10) return group == 10 ? 5 : ((group == 11 || group == 13) ? 6 : 7);   // (the y halos of a 2-D decomposition)
+  return group == 6 ? 3 : group == 8 ? 4 : group == 0 ? 0 : ((group == 1 || group == 3) ? 1 : 2);
+}
+inline int set_sides(int b) { return (b == 3 || b == 4) ? 1 : 2; }
+// rank = ry Rx + rx: the ring neighbours within the row, the neighbours in the column, the fold partner within the top row
+struct MeshPos {
+  int Rx, Ry, rx, ry;
+  explicit MeshPos(const gb25_model* m) : Rx(m->Rx), Ry(m->Ry), rx(m->rx), ry(m->ry) {}
+  MeshPos(int Rx_, int Ry_, int rank) : Rx(Rx_), Ry(Ry_), rx(rank % Rx_), ry(rank / Rx_) {}
+  int west() const { return ry * Rx + (rx + Rx - 1) % Rx; }
+  int east() const { return ry * Rx + (rx + 1) % Rx; }
+  int south() const { return ry > 0 ? (ry - 1) * Rx + rx : -1; }
+  int north() const { return ry < Ry - 1 ? (ry + 1) * Rx + rx : -1; }
+  int partner() const { return ry * Rx + (Rx - 1 - rx); }
+};
 
 // several slabs of one decomposition in this process, all on one device: a ring of device-to-device copies
 struct LocalRingTransport : Transport {
   const char* name() const override { return "local"; }
   gb25_status exchange(SlabGroup& G, int b, size_t nbytes, hipStream_t st) override {
     const int P = (int)G.slabs.size();
-    if (b >= 3) {   // zipper fold: slab r <-> slab P-1-r (the middle slab of an odd count is its own partner)
-      for (int r = 0; r < P; r++) {
-        gb25_model* m = G.slabs[r];
-        HIPCHK(hipMemcpyAsync(G.recv[P - 1 - r][b][0], G.send[r][b][0], nbytes, hipMemcpyDeviceToDevice, st));
-      }
-      return GB25_OK;
-    }
     for (int r = 0; r < P; r++) {
       gb25_model* m = G.slabs[r];
-      const int west = (r + P - 1) % P, east = (r + 1) % P;
-      // my west pack -> west neighbour's east halo; my east pack -> east neighbour's west halo
-      HIPCHK(hipMemcpyAsync(G.recv[west][b][1], G.send[r][b][0], nbytes, hipMemcpyDeviceToDevice, st));
-      HIPCHK(hipMemcpyAsync(G.recv[east][b][0], G.send[r][b][1], nbytes, hipMemcpyDeviceToDevice, st));
+      const MeshPos q(m);
+      if (b == 3 || b == 4) {   // zipper fold: slab rx <-> slab Rx-1-rx of the top row (the middle slab of an odd count is its own partner)
+        if (m->g.cv.north_fold) HIPCHK(hipMemcpyAsync(G.recv[q.partner()][b][0], G.send[r][b][0], nbytes, hipMemcpyDeviceToDevice, st));
+      } else if (b >= 5) {      // my southern pack -> the southern neighbour's northern halo; my northern pack -> ... southern halo
+        if (q.south() >= 0) HIPCHK(hipMemcpyAsync(G.recv[q.south()][b][1], G.send[r][b][0], nbytes, hipMemcpyDeviceToDevice, st));
+        if (q.north() >= 0) HIPCHK(hipMemcpyAsync(G.recv[q.north()][b][0], G.send[r][b][1], nbytes, hipMemcpyDeviceToDevice, st));
+      } else {                  // my west pack -> west neighbour's east halo; my east pack -> east neighbour's west halo
+        HIPCHK(hipMemcpyAsync(G.recv[q.west()][b][1], G.send[r][b][0], nbytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(G.recv[q.east()][b][0], G.send[r][b][1], nbytes, hipMemcpyDeviceToDevice, st));
+      }
     }
     return GB25_OK;
   }
@@ -660,7 +773,8 @@ struct RcclTransport : Transport {
     if (comm) rccl().CommDestroy(comm);
   }
   gb25_status send_recv(gb25_model* m, const void* sw, const void* se, void* rw, void* re, size_t nbytes, hipStream_t st) {
-    const int west = (rank + nranks - 1) % nranks, east = (rank + 1) % nranks;
+    const MeshPos q(m);
+    const int west = q.west(), east = q.east();
     RcclApi& R = rccl();
     NCCLCHK(R.GroupStart());
     NCCLCHK(R.Send(sw, nbytes, ncclInt8, west, comm, st));
@@ -671,9 +785,23 @@ struct RcclTransport : Transport {
     return GB25_OK;
   }
   gb25_status exchange(SlabGroup& G, int b, size_t nbytes, hipStream_t st) override {
-    if (b >= 3) {   // zipper fold: the partner is rank P-1-r
+    if (b >= 5) {   // 2-D decomposition: the southern and the northern neighbour, where they exist
       gb25_model* m = G.slabs[0];
-      const int partner = nranks - 1 - rank;
+      const MeshPos q(m);
+      RcclApi& R = rccl();
+      if (q.south() < 0 && q.north() < 0) return GB25_OK;
+      NCCLCHK(R.GroupStart());
+      if (q.south() >= 0) NCCLCHK(R.Send(G.send[0][b][0], nbytes, ncclInt8, q.south(), comm, st));
+      if (q.north() >= 0) NCCLCHK(R.Send(G.send[0][b][1], nbytes, ncclInt8, q.north(), comm, st));
+      if (q.north() >= 0) NCCLCHK(R.Recv(G.recv[0][b][1], nbytes, ncclInt8, q.north(), comm, st));
+      if (q.south() >= 0) NCCLCHK(R.Recv(G.recv[0][b][0], nbytes, ncclInt8, q.south(), comm, st));
+      NCCLCHK(R.GroupEnd());
+      return GB25_OK;
+    }
+    if (b >= 3) {   // zipper fold: the partner is the mirrored rank of the (top) row
+      gb25_model* m = G.slabs[0];
+      if (!m->g.cv.north_fold) return GB25_OK;
+      const int partner = MeshPos(m).partner();
       if (partner == rank) {
         HIPCHK(hipMemcpyAsync(G.recv[0][b][0], G.send[0][b][0], nbytes, hipMemcpyDeviceToDevice, st));
         return GB25_OK;
@@ -698,8 +826,14 @@ struct CallbackTransport : Transport {
     gb25_model* m = G.slabs[0];
     HIPCHK(hipStreamSynchronize(st));   // the packs are complete
     // (buffer sets 3, 4: to and from the fold partner rank P-1-r; the east pointers are null)
-    const int rc = b >= 3 ? fn(user, b, G.send[0][b][0], nullptr, G.recv[0][b][0], nullptr, (int64_t)nbytes)
-                          : fn(user, b, G.send[0][b][0], G.send[0][b][1], G.recv[0][b][0], G.recv[0][b][1], (int64_t)nbytes);
+    // (buffer sets 5 - 7: to and from the southern [west pointers] and northern [east pointers] neighbour of a 2-D
+    // decomposition; null where there is none)
+    if ((b == 3 || b == 4) && !m->g.cv.north_fold) return GB25_OK;
+    int rc;
+    if (b == 3 || b == 4) rc = fn(user, b, G.send[0][b][0], nullptr, G.recv[0][b][0], nullptr, (int64_t)nbytes);
+    else if (b >= 5) rc = fn(user, b, m->ys_open ? G.send[0][b][0] : nullptr, m->yn_open ? G.send[0][b][1] : nullptr,
+                             m->ys_open ? G.recv[0][b][0] : nullptr, m->yn_open ? G.recv[0][b][1] : nullptr, (int64_t)nbytes);
+    else rc = fn(user, b, G.send[0][b][0], G.send[0][b][1], G.recv[0][b][0], G.recv[0][b][1], (int64_t)nbytes);
     if (rc != 0) return fail(m, GB25_ERR_COMM, "the host's exchange callback failed with code %d (buffer set %d)", rc, b);
     return GB25_OK;
   }
@@ -721,13 +855,23 @@ struct GroupOps : StepOps {
     OnStream on(G.slabs[s], st(c));
     return slab_stage(G.slabs[s], stage, euler);
   }
-  bool folded() override { return G.slabs[0]->g.cv.north_fold != 0; }
+  bool folded() override {   // (2-D decomposition: the top row of ranks only; the others skip the partner's groups)
+    for (gb25_model* m : G.slabs)
+      if (m->g.cv.north_fold) return true;
+    return false;
+  }
+  bool mesh_y() override { return G.slabs[0]->Ry > 1; }
   bool coupled() override { return G.slabs[0]->coupled; }
   gb25_status pack(int s, int group, bool c) override {
     OnStream on(G.slabs[s], st(c));
     const int b = buffer_set(group);
+    if ((group == 6 || group == 8) && !G.slabs[s]->g.cv.north_fold) return GB25_OK;
     if (group == 6) return fold_pack(G.slabs[s], G.send[s][b][0]);
     if (group == 8) return tall_rows_impl(G.slabs[s], G.send[s][b][0], true);
+    if (group >= 10) {
+      real* rb[2] = {G.send[s][b][0], G.send[s][b][1]};
+      return move_rows(G.slabs[s], group, rb, true);
+    }
     if (group == 0) G.slabs[s]->halo_colsum_valid = G.slabs[s]->colsum_valid;   // (every slab alike: same calls, same state)
     real* buf[2] = {G.send[s][b][0], G.send[s][b][1]};
     return pack_unpack(G.slabs[s], group, buf, true);
@@ -735,8 +879,13 @@ struct GroupOps : StepOps {
   gb25_status unpack(int s, int group, bool c) override {
     OnStream on(G.slabs[s], st(c));
     const int b = buffer_set(group);
+    if ((group == 6 || group == 8) && !G.slabs[s]->g.cv.north_fold) return GB25_OK;
     if (group == 6) return fold_unpack(G.slabs[s], G.recv[s][b][0]);
     if (group == 8) return tall_rows_impl(G.slabs[s], G.recv[s][b][0], false);
+    if (group >= 10) {
+      real* rb[2] = {G.recv[s][b][0], G.recv[s][b][1]};
+      return move_rows(G.slabs[s], group, rb, false);
+    }
     real* buf[2] = {G.recv[s][b][0], G.recv[s][b][1]};
     return pack_unpack(G.slabs[s], group, buf, false);
   }
@@ -835,7 +984,7 @@ gb25_status group_refresh(SlabGroup* G) {
     HIPCHK(hipStreamSynchronize(G->main));
     if (need > G->capacity[b]) {
       for (int s = 0; s < n; s++)
-        for (int side = 0; side < (b < 3 ? 2 : 1); side++) {
+        for (int side = 0; side < set_sides(b); side++) {
           if (G->send[s][b][side]) hipFree(G->send[s][b][side]);
           if (G->recv[s][b][side]) hipFree(G->recv[s][b][side]);
           G->send[s][b][side] = G->recv[s][b][side] = nullptr;
@@ -881,13 +1030,19 @@ gb25_status group_create(gb25_model* const* slabs, int n, Transport* tr) {
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) st = GB25_ERR_HIP;
     if (st) break;
     for (int b = 0; b < 3; b++) G->elems[b] = (size_t)halo_buffer_elems(m, b);
-    for (int b = 3; b < 5; b++) G->elems[b] = (size_t)fold_buffer_elems(m, b);
-    for (int b = 0; b < 5; b++) G->capacity[b] = G->elems[b];
+    // (2-D decomposition: the top row of ranks folds, the others do not; every slab gets buffers of the size a folded one needs)
+    for (int b = 3; b < 5; b++)
+      for (int s = 0; s < n; s++) G->elems[b] = std::max(G->elems[b], (size_t)fold_buffer_elems(slabs[s], b));
+    for (int b = 5; b < SlabGroup::NSETS; b++) G->elems[b] = (size_t)row_buffer_elems(m, b == 5 ? 10 : (b == 6 ? 11 : 12));
+    for (int b = 0; b < SlabGroup::NSETS; b++) G->capacity[b] = G->elems[b];
     G->send.resize(n);
     G->recv.resize(n);
     for (int s = 0; s < n && !st; s++)
-      for (int b = 0; b < 5 && !st; b++)
-        for (int side = 0; side < (b < 3 ? 2 : 1) && !st; side++) {
+      for (int b = 0; b < SlabGroup::NSETS && !st; b++)
+        for (int side = 0; side < 2; side++) G->send[s][b][side] = G->recv[s][b][side] = nullptr;
+    for (int s = 0; s < n && !st; s++)
+      for (int b = 0; b < SlabGroup::NSETS && !st; b++)
+        for (int side = 0; side < set_sides(b) && !st; side++) {
           G->send[s][b][side] = G->recv[s][b][side] = nullptr;
           if (hipMalloc(&G->send[s][b][side], G->elems[b] * sizeof(real)) != hipSuccess ||
               hipMalloc(&G->recv[s][b][side], G->elems[b] * sizeof(real)) != hipSuccess)

@@ -145,8 +145,10 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   const real Az = CURV ? g.cv.azcc[om] : g.azc[j];
   const real az_m2 = CURV ? g.cv.azcc[om - 2 * sx] : g.azc[j - 2], az_m1 = CURV ? g.cv.azcc[om - sx] : g.azc[j - 1],
              az_p1 = CURV ? g.cv.azcc[om + sx] : g.azc[j + 1];
-  int oc_y = biased_order_center(j, g.Ny), of_y = biased_order_face(j, g.Ny);
-  bool s4c_y = sym4_center(j, g.Ny), s4f_y = sym4_face(j, g.Ny);
+  // (rows counted from the global southern wall: a rank of a 2-D decomposition reduces orders where the single domain does)
+  const int jw_ = j - g.jws, Nyw_ = g.jwn - g.jws;
+  int oc_y = biased_order_center(jw_, Nyw_), of_y = biased_order_face(jw_, Nyw_);
+  bool s4c_y = sym4_center(jw_, Nyw_), s4f_y = sym4_face(jw_, Nyw_);
   // orders / switches that are constants of the plain grid (x is periodic) and per-level quantities with a bottom
   int oc_x = 5, of_x = 5;
   bool s4c_x = true, s4f_x = true, s4f_xw = true, s4f_yw = s4f_y;
@@ -573,13 +575,13 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
       // compute_hydrostatic_boundary_tendency_contributions!: top flux boundary conditions (wind stress)
       const int o2 = i2(g, ic_, jc_);
       if (g.top_flux[0]) gu = gu - g.top_flux[0][o2] * rdz;
-      if (g.top_flux[1] && j > 0) gv = gv - g.top_flux[1][o2] * rdz;
+      if (g.top_flux[1] && j != g.jws) gv = gv - g.top_flux[1][o2] * rdz;
     }
     if (DRAG && g.bottom_flux[0] != nullptr) {
       // quadratic bottom drag: the bottom flux boundary condition enters the first free level of the face's column
       const int o2 = i2(g, ic_, jc_);
       if (k == (IMM ? KPU : 0)) gu = gu + g.bottom_flux[0][o2] * rdz;
-      if (k == (IMM ? KPV : 0) && j > 0) gv = gv + g.bottom_flux[1][o2] * rdz;
+      if (k == (IMM ? KPV : 0) && j != g.jws) gv = gv + g.bottom_flux[1][o2] * rdz;
     }
     if (IMM) {   // faces that touch the solid: no tendency (their velocity is masked and stays zero)
       if (k < KPU) gu = real(0.);
@@ -714,8 +716,9 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
   }
   constexpr int R = ORD == 7 ? 4 : 3;   // reach of the reconstruction stencils
   static_assert(ORD == 5 || ORD == 7, "WENO(order = 5) or WENO(order = 7)");
-  int oys = ORD == 7 ? biased_order_face7(j, g.Ny) : biased_order_face(j, g.Ny);
-  int oyn = ORD == 7 ? biased_order_face7(j + 1, g.Ny) : biased_order_face(j + 1, g.Ny), ox = ORD;
+  const int jw_ = j - g.jws, Nyw_ = g.jwn - g.jws;   // (rows counted from the global southern wall)
+  int oys = ORD == 7 ? biased_order_face7(jw_, Nyw_) : biased_order_face(jw_, Nyw_);
+  int oyn = ORD == 7 ? biased_order_face7(jw_ + 1, Nyw_) : biased_order_face(jw_ + 1, Nyw_), ox = ORD;
   int kbt = 0, KX5 = 0, KX3 = 0, KY5 = 0, KY3 = 0, KY5n = 0, KY3n = 0, KX7 = 0, KY7 = 0, KY7n = 0;
   if (IMM) {
     const int o2 = i2(g, min(i, g.Nx), j);
@@ -884,8 +887,9 @@ __device__ __forceinline__ void tracer_tile_single(const Grid& g, const real* __
   const real2v dy = CURV ? m2(g.cv.dyfc, 0) : real2v(g.dy), Az = CURV ? m2(g.cv.azcc, 0) : real2v(g.azc[j]);
   const real2v dxf_s = CURV ? m2(g.cv.dxcf, 0) : real2v(g.dxf[j]), dxf_n = CURV ? m2(g.cv.dxcf, g.sx) : real2v(g.dxf[j + 1]);
   const real2v razc_j = CURV ? m2(g.cv.razcc, 0) : real2v(g.razc[j]);
-  const int oys_w = ORD == 7 ? biased_order_face7(j, g.Ny) : biased_order_face(j, g.Ny);
-  const int oyn_w = ORD == 7 ? biased_order_face7(j + 1, g.Ny) : biased_order_face(j + 1, g.Ny);
+  const int jw_ = j - g.jws, Nyw_ = g.jwn - g.jws;   // (rows counted from the global southern wall)
+  const int oys_w = ORD == 7 ? biased_order_face7(jw_, Nyw_) : biased_order_face(jw_, Nyw_);
+  const int oyn_w = ORD == 7 ? biased_order_face7(jw_ + 1, Nyw_) : biased_order_face(jw_ + 1, Nyw_);
   int kbt[2] = {0, 0}, KX5[2] = {0, 0}, KX3[2] = {0, 0}, KY5[2] = {0, 0}, KY3[2] = {0, 0}, KY5n[2] = {0, 0}, KY3n[2] = {0, 0};
   int KX7[2] = {0, 0}, KY7[2] = {0, 0}, KY7n[2] = {0, 0};
   if (IMM) {

@@ -19,7 +19,7 @@ import torch
 
 from .binding import HipBackend
 from .model import HydrostaticFreeSurfaceModel
-from .sharding import slab_neighbours
+from .sharding import mesh_neighbours, slab_neighbours
 
 WEST, EAST = 0, 1
 
@@ -31,11 +31,13 @@ class TorchDistributedTransport:
     With two ranks both neighbours are the same peer and messages between one pair match in posting order,
     so the peer's FIRST send (its west pack) must meet our FIRST receive (our east halo)."""
 
-    def __init__(self, rank, nranks, dist=None):
+    def __init__(self, rank, nranks, dist=None, ranks_y=1):
         import torch.distributed as tdist
         self.dist = dist or tdist
         self.rank, self.nranks = rank, nranks
-        self.west, self.east = slab_neighbours(rank, nranks)
+        # Partition(Rx, Ry, 1): the ring runs within the rank's row; south / north are None beyond the walls
+        nb = mesh_neighbours(rank, nranks // max(1, ranks_y), max(1, ranks_y))
+        self.west, self.east, self.south, self.north, self.partner = (nb[k] for k in ("west", "east", "south", "north", "partner"))
 
     def exchange(self, send_west, send_east, recv_west, recv_east):
         d = self.dist
@@ -58,7 +60,7 @@ class TorchDistributedTransport:
     def exchange_partner(self, send, recv):
         """Zipper fold of a decomposed tripolar grid: slab r <-> slab P-1-r (buffer sets 3 and 4 of the library)."""
         d = self.dist
-        partner = self.nranks - 1 - self.rank
+        partner = self.partner
         if partner == self.rank:
             recv.copy_(send)
             return
@@ -70,6 +72,27 @@ class TorchDistributedTransport:
             req.wait()
         if stage:
             dev.copy_(recv)
+            torch.cuda.current_stream().synchronize()
+
+
+    def exchange_y(self, send_south, send_north, recv_south, recv_north):
+        """y halos of a 2-D decomposition (buffer sets 5 - 7 of the library): my southern pack -> the southern neighbour's
+        northern halo, my northern pack -> the northern neighbour's southern halo; None where there is no neighbour."""
+        d = self.dist
+        pairs = [(send_south, recv_south, self.south), (send_north, recv_north, self.north)]
+        pairs = [(s_, r_, peer) for s_, r_, peer in pairs if peer is not None]
+        if not pairs:
+            return
+        stage = pairs[0][0].is_cuda and d.get_backend() != "nccl"
+        dev = [r_ for _, r_, _ in pairs]
+        if stage:
+            pairs = [(s_.cpu(), torch.empty_like(s_, device="cpu"), peer) for s_, _, peer in pairs]
+        ops = [d.P2POp(d.isend, s_, peer) for s_, _, peer in pairs] + [d.P2POp(d.irecv, r_, peer) for _, r_, peer in reversed(pairs)]
+        for req in d.batch_isend_irecv(ops):
+            req.wait()
+        if stage:
+            for t, (_, r_, _) in zip(dev, pairs):
+                t.copy_(r_)
             torch.cuda.current_stream().synchronize()
 
 
@@ -102,12 +125,14 @@ class SlabModel(HydrostaticFreeSurfaceModel):
                ncclSend/ncclRecv on its second HIP stream;  "host" -- torch.distributed point-to-point through the
                library's callback transport (gloo rehearsal)."""
 
-    def __init__(self, Nx_global, Ny, Nz, *, dt, rank, nranks, device=0, halo=8, substeps=30, transport=None, **kw):
+    def __init__(self, Nx_global, Ny, Nz, *, dt, rank, nranks, device=0, halo=8, substeps=30, transport=None, ranks_y=1, **kw):
         import torch.distributed as dist
+        # ranks_y > 1: Partition(nranks / ranks_y, ranks_y, 1), rank = ry Rx + rx; the fields are the rank's window of columns
+        # AND rows
         backend = HipBackend(Nx_global, Ny, Nz, dt=dt, halo=halo, substeps=substeps, device=device, rank=rank,
-                             nranks=nranks, **kw)
-        super().__init__(backend, Nx_global // nranks, Ny, Nz, halo)
-        self.rank, self.nranks = rank, nranks
+                             nranks=nranks, ranks_y=ranks_y, **kw)
+        super().__init__(backend, backend.Nx_local, backend.Ny_local, Nz, halo)
+        self.rank, self.nranks, self.ranks_y = rank, nranks, ranks_y
         if transport is None:
             transport = "rccl" if (nranks == 1 or dist.get_backend() == "nccl") else "host"
         self.transport_kind = transport
@@ -115,10 +140,16 @@ class SlabModel(HydrostaticFreeSurfaceModel):
             uid = backend.comm_unique_id() if nranks == 1 else share_unique_id(backend, rank)
             backend.comm_init_rccl(uid)
         elif transport == "host":
-            self._ring = TorchDistributedTransport(rank, nranks)
+            self._ring = TorchDistributedTransport(rank, nranks, ranks_y=ranks_y)
             dev = torch.device("cuda", device)
 
             def exchange(buffer_set, sw, se, rw, re, nbytes):
+                if buffer_set >= 5:      # y halos: (south, north) in the place of (west, east); null where there is no neighbour
+                    t = lambda p: _as_tensor(p, nbytes, dev) if p else None
+                    self._ring.exchange_y(t(sw), t(se), t(rw), t(re))
+                    if torch.cuda.is_available():
+                        torch.cuda.current_stream().synchronize()
+                    return
                 if buffer_set >= 3:      # to and from the fold partner (the east pointers are null)
                     self._ring.exchange_partner(_as_tensor(sw, nbytes, dev), _as_tensor(rw, nbytes, dev))
                     if torch.cuda.is_available():
@@ -135,17 +166,24 @@ class LocalSlabEnsemble:
     """P slabs of one global model stepped in lock-step inside ONE process on one GPU: the library's local transport
     (ring of device-to-device copies), the same stages, pack / unpack kernels and two streams as the RCCL path."""
 
-    def __init__(self, Nx_global, Ny, Nz, P, *, dt, device=0, **kw):
-        self.P, self.Nx_loc = P, Nx_global // P
-        self.backends = [HipBackend(Nx_global, Ny, Nz, dt=dt, device=device, rank=r, nranks=P, **kw) for r in range(P)]
+    def __init__(self, Nx_global, Ny, Nz, P, *, dt, device=0, ranks_y=1, **kw):
+        # ranks_y > 1: a 2-D decomposition, Partition(P / ranks_y, ranks_y, 1); rank = ry Rx + rx
+        self.P, self.Ry, self.Rx = P, ranks_y, P // ranks_y
+        self.Nx_loc, self.Ny_loc = Nx_global // self.Rx, Ny // ranks_y
+        self.backends = [HipBackend(Nx_global, Ny, Nz, dt=dt, device=device, rank=r, nranks=P, ranks_y=ranks_y, **kw)
+                         for r in range(P)]
         HipBackend.comm_init_local(self.backends)
 
     def scatter(self, name, global_interior):
-        for r, b in enumerate(self.backends):
-            b.set_field(name, np.ascontiguousarray(global_interior[r * self.Nx_loc:(r + 1) * self.Nx_loc]), False)
+        for b in self.backends:
+            d = b.field_dims(name, False)      # (a y-face field has one row more on the ranks that hold the northern wall)
+            i0, j0 = b.rx * self.Nx_loc, b.ry * self.Ny_loc
+            b.set_field(name, np.ascontiguousarray(global_interior[i0:i0 + d[0], j0:j0 + d[1]]), False)
 
     def gather(self, name):
-        return np.concatenate([b.get_field(name, False) for b in self.backends], axis=0)
+        rows = [np.concatenate([self.backends[ry * self.Rx + rx].get_field(name, False) for rx in range(self.Rx)], axis=0)
+                for ry in range(self.Ry)]
+        return rows[0] if self.Ry == 1 else np.concatenate(rows, axis=1)
 
     def set_option(self, name, value):
         for b in self.backends:

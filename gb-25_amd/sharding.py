@@ -25,3 +25,12 @@ def factors(N):
 def slab_neighbours(rank, nranks):
     """(west, east) ranks of an x-slab on the periodic ring."""
     return (rank - 1) % nranks, (rank + 1) % nranks
+
+
+def mesh_neighbours(rank, Rx, Ry):
+    """Neighbours of rank = ry Rx + rx in a Partition(Rx, Ry, 1) mesh: the periodic ring in x within the row, the southern and
+    northern rank of the column (None beyond the walls / the fold), the fold partner within the row (mirrored in x)."""
+    rx, ry = rank % Rx, rank // Rx
+    return dict(west=ry * Rx + (rx - 1) % Rx, east=ry * Rx + (rx + 1) % Rx,
+                south=(ry - 1) * Rx + rx if ry > 0 else None, north=(ry + 1) * Rx + rx if ry < Ry - 1 else None,
+                partner=ry * Rx + (Rx - 1 - rx))

@@ -85,6 +85,9 @@ typedef struct {
                               neighbour -- the self-ring that runs the exchange code path on one GPU) */
   int32_t grid_type;    /* gb25_grid_type: grid_type = :simple_lat_lon | :gaussian_islands
                               (src/baroclinic_instability_model.jl:19,59-65) */
+  int32_t ranks_y;      /* Partition(Rx, Ry, 1) (sharding/sharded_baroclinic_instability_simulation_run.jl:65-72): Ry, the
+                              ranks along y; 0 or 1 = x slabs only.  nranks = Rx Ry, rank = ry Rx + rx; the rank owns the
+                              columns [rx Nx/Rx, (rx+1) Nx/Rx) and the rows [ry Ny/Ry, (ry+1) Ny/Ry) */
 } gb25_config;
 
 typedef enum {

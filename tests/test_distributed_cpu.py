@@ -223,3 +223,92 @@ def test_a_step_behind_a_look_ahead_chain_in_flight():
     log = _raw_sequence(3, 8, adopted=0, ready=0)
     idx = lambda *e: log.index(e)
     assert idx("stage", 0, "slab", 2, "euler", 0, "main") < idx("wait", 4, "main") < idx("pack", 1, "slab", 0, "main")
+
+
+def _mesh_worker(rank, Rx, Ry, port, n, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    world = Rx * Ry
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gb25_amd.sharding import mesh_neighbours
+        t = TorchDistributedTransport(rank, world, ranks_y=Ry)
+        nb = mesh_neighbours(rank, Rx, Ry)
+        for rep in range(2):
+            # x: the ring within the row
+            sw = torch.full((n,), rank * 100 + 10 + rep, dtype=torch.float32)
+            se = torch.full((n,), rank * 100 + 20 + rep, dtype=torch.float32)
+            rw, re = torch.empty(n), torch.empty(n)
+            t.exchange(sw, se, rw, re)
+            assert torch.all(rw == nb["west"] * 100 + 20 + rep) and torch.all(re == nb["east"] * 100 + 10 + rep), rank
+            # y: south / north where they exist (no wrap: walls / the fold)
+            ss = torch.full((n,), rank * 100 + 30 + rep, dtype=torch.float32) if nb["south"] is not None else None
+            sn = torch.full((n,), rank * 100 + 40 + rep, dtype=torch.float32) if nb["north"] is not None else None
+            rs = torch.empty(n) if nb["south"] is not None else None
+            rn = torch.empty(n) if nb["north"] is not None else None
+            t.exchange_y(ss, sn, rs, rn)
+            if rs is not None:
+                assert torch.all(rs == nb["south"] * 100 + 40 + rep), (rank, rs[0].item())   # southern halo <- the NORTHERN pack of the rank below
+            if rn is not None:
+                assert torch.all(rn == nb["north"] * 100 + 30 + rep), (rank, rn[0].item())
+            # the fold partner: mirrored in x within the row
+            sp = torch.full((n,), rank * 100 + 50 + rep, dtype=torch.float32)
+            rp = torch.empty(n)
+            t.exchange_partner(sp, rp)
+            assert torch.all(rp == nb["partner"] * 100 + 50 + rep), rank
+        results[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mesh_exchange_gloo_world_size_4():
+    """Partition(2, 2, 1): rank = ry Rx + rx; the x ring closes within a row, y neighbours exist only inside the domain, the
+    fold partner is the mirrored rank of the same row."""
+    from gb25_amd.sharding import mesh_neighbours
+    assert mesh_neighbours(0, 2, 2) == dict(west=1, east=1, south=None, north=2, partner=1)
+    assert mesh_neighbours(5, 4, 2) == dict(west=4, east=6, south=1, north=None, partner=6)
+    ctx = mp.get_context("spawn")
+    results = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_mesh_worker, args=(r, 2, 2, port, 500, results)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert all(results.get(r) for r in range(4))
+
+
+def test_time_step_sequencing_of_a_2d_decomposition():
+    """Partition(Rx, Ry, 1): every exchange in x is followed by the exchange of whole ROWS with the southern / northern
+    neighbour, which then carry the x halo columns just received (the corners of the diagonal neighbours): the work arrays of
+    the sub-cycle after their wide halo columns and the interior copy ("exchange 11" after group 1 and stage 1, the substeps in
+    stage 16), the 3-D bundle after group 0 AND the barotropic corrector of the own rows' x halo columns (stage 32), so that
+    the rows arrive corrected ("exchange 10"); on the top row of a tripolar mesh the fold partner's groups 8 and 6 ride along."""
+    log = _raw_sequence(4, 16)
+    mine = _ops_of_slab(log, 2)
+    assert mine == [("stage", 0, "main"), ("pack", 1, "main"), ("exchange", 1, "main"),
+                    ("pack", 0, "comm"), ("exchange", 0, "comm"),
+                    ("unpack", 1, "main"), ("stage", 1, "main"), ("pack", 11, "main"), ("exchange", 11, "main"),
+                    ("unpack", 11, "main"), ("stage", 16, "main"),
+                    ("stage", 2, "main"),
+                    ("unpack", 0, "main"), ("stage", 32, "main"), ("pack", 10, "main"), ("exchange", 10, "main"),
+                    ("unpack", 10, "main"), ("stage", 3, "main"), ("stage", 4, "main")]
+    for grp in (10, 11):     # every slab has packed before the exchange, none unpacks before it
+        ex = [i for i, e in enumerate(log) if e[:2] == ("exchange", grp)]
+        assert len(ex) == 1
+        assert all(i < ex[0] for i, e in enumerate(log) if e[:2] == ("pack", grp))
+        assert all(i > ex[0] for i, e in enumerate(log) if e[:2] == ("unpack", grp))
+    # tripolar mesh: the partner's groups between the y exchange and the rest of update_state!
+    fold = _ops_of_slab(_raw_sequence(4, 16 | 2), 3)
+    assert fold == [("stage", 0, "main"), ("pack", 1, "main"), ("exchange", 1, "main"),
+                    ("pack", 0, "comm"), ("exchange", 0, "comm"),
+                    ("unpack", 1, "main"), ("stage", 1, "main"), ("pack", 11, "main"), ("pack", 8, "main"),
+                    ("exchange", 11, "main"), ("exchange", 8, "main"), ("unpack", 11, "main"), ("unpack", 8, "main"),
+                    ("stage", 16, "main"), ("stage", 2, "main"),
+                    ("unpack", 0, "main"), ("stage", 32, "main"), ("pack", 10, "main"), ("exchange", 10, "main"),
+                    ("unpack", 10, "main"), ("stage", 30, "main"), ("pack", 6, "main"), ("exchange", 6, "main"),
+                    ("unpack", 6, "main"), ("stage", 31, "main"), ("stage", 4, "main")]
+    # first_time_step!: the initial state's rows follow its columns
+    first = _raw_sequence(4, 16 | 1)
+    names = [(e[0], e[1]) for e in first if e[0] in ("exchange",)]
+    assert names[:4] == [("exchange", 0), ("exchange", 2), ("exchange", 10), ("exchange", 12)]
