@@ -36,18 +36,24 @@ def _compare(ens, single, what):
             raise AssertionError((what, n, float(np.nanmax(np.abs(a - b))), len(bad), bad[:4].tolist(), bad[-2:].tolist()))
 
 
-@pytest.mark.parametrize("Rx,Ry,Nz,grid_type", [(2, 2, 8, 0), (1, 2, 8, 0), (2, 3, 24, 0), (2, 2, 8, 1)])
+@pytest.mark.parametrize("Rx,Ry,Nz,grid_type", [(2, 2, 8, 0), (1, 2, 8, 0), (2, 3, 24, 0), (2, 2, 8, 1), (2, 2, 8, 2), (2, 2, 8, 3),
+                                                (2, 2, 8, 4), (3, 2, 24, 4), (1, 3, 8, 4)])
 def test_mesh_reproduces_single_domain_bitwise(Rx, Ry, Nz, grid_type):
-    Nx, Ny, dt = 128, 48 * Ry, 600.0
+    Nx, Ny, dt = (192 if Rx == 3 else 128), 48 * Ry, 600.0
     kw = dict(grid_type=grid_type)
     single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt, grid_type=GRID_NAMES[grid_type])
-    init = _initial(Nx, Ny, Nz, single, Ny + 1)
+    init = _initial(Nx, Ny, Nz, single, Ny if grid_type >= 3 else Ny + 1)   # (a folded grid has Ny rows of y faces)
     ens = LocalSlabEnsemble(Nx, Ny, Nz, Rx * Ry, dt=dt, ranks_y=Ry, slab_mode=1, **kw)
     for n, a in init.items():
         ens.scatter(n, a)
     gb.first_time_step(single)
     ens.first_time_step()
     _compare(ens, single, "first step")
+    if grid_type == 3:       # (the bare tripolar grid is singular at its poles: NaNs spread from there; compared all the same)
+        gb.time_step(single)
+        ens.time_step()
+        _compare(ens, single, "second step")
+        return
     gb.loop(single, 6)
     ens.loop(6)
     _compare(ens, single, "6 steps")
