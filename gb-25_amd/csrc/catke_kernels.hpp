@@ -48,8 +48,9 @@ __global__ void k_catke_surface_flux(Grid g, const real* __restrict__ T, const r
   // (a slab of a decomposition: the x halo columns and the rows beyond a zipper fold arrive with the 3-D bundle)
   const bool xw = g.x_periodic && i < g.H, xe = g.x_periodic && i >= g.Nx - g.H;
   store_x_images(g, Jb, o2, (real)J, xw, xe);
-  if (j == 0) store_x_images(g, Jb, o2 - g.sx, (real)J, xw, xe);
-  if (j == g.Ny - 1 && !(g.cv.north_fold && !g.x_periodic)) store_x_images(g, Jb, o2 + g.sx, (real)J, xw, xe);
+  // (the y layers exist next to walls only: a rank of a 2-D decomposition gets the rows of its open sides from the neighbour)
+  if (j == 0 && g.jws == 0) store_x_images(g, Jb, o2 - g.sx, (real)J, xw, xe);
+  if (j == g.Ny - 1 && (g.jwn == g.Ny || g.cv.north_fold) && !(g.cv.north_fold && !g.x_periodic)) store_x_images(g, Jb, o2 + g.sx, (real)J, xw, xe);
 }
 struct CatkeFace {
   real ku, kc, ke, lD, P, wb;
@@ -60,18 +61,20 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
                                                              const real* __restrict__ b, const real* __restrict__ Jb,
                                                              real* __restrict__ KU, real* __restrict__ KC,
                                                              real* __restrict__ KE, real* __restrict__ Le,
-                                                             real* __restrict__ Ge, int i_lo, int j_hi) {
+                                                             real* __restrict__ Ge, int i_lo, int j_hi, int j_lo) {
   // Columns i_lo .. Nx-1, rows 0 .. j_hi-1.  Single domain: the interior (0, Ny), the halo cells written as images.  A slab
   // of a decomposition: i_lo = -1 and, with the zipper fold, j_hi = Ny + 1 -- the one halo column / row whose kappa_u the
   // implicit solves of u (averaged in x) and of v (in y, on the fold line) read is COMPUTED here from the halo columns of
   // e, u, v, N^2 and J^b (all of them exchanged already), bit for bit what its owner computes, instead of exchanged.
-  const int i = i_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = blockIdx.y * blockDim.y + threadIdx.y;
+  // (2-D decomposition: j_lo = -1 below a southern neighbour -- kappa_u of that row is averaged into the v faces of row 0)
+  const int i = i_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = j_lo + (int)(blockIdx.y * blockDim.y + threadIdx.y);
   if (i >= g.Nx || j >= j_hi) return;
-  const bool own = i >= 0 && j < g.Ny;
+  const bool own = i >= 0 && j >= 0 && j < g.Ny;
   const int Nz = g.Nz, o2 = i2(g, i, j), pc = g.pl_c, pv = g.pl_v;
   const int kc0 = IMM ? min((int)(g.im.ordA[o2] & 255), Nz) : 0;   // first active level of the column
   const bool xw = g.x_periodic && i < g.H, xe = g.x_periodic && i >= g.Nx - g.H;
-  const bool ys = own && j == 0, yn = own && j == g.Ny - 1 && j_hi == g.Ny;
+  // (the y layers exist next to walls only)
+  const bool ys = own && j == 0 && g.jws == 0, yn = own && j == g.Ny - 1 && j_hi == g.Ny && (g.jwn == g.Ny || g.cv.north_fold);
   auto put = [&](real* a, int o, real x) {   // the cell and the halo cells its fill derives from it (a14)
     store_x_images(g, a, o, x, xw, xe);
     if (ys) store_x_images(g, a, o - g.sx, x, xw, xe);
@@ -229,7 +232,7 @@ __device__ __forceinline__ int implicit_var_first_level(const Grid& g, int z, in
     const unsigned w = MODE == 1 ? g.im.ordA[o2] : g.im.ordC[o2] >> (z == 0 ? 8 : 16);
     kf = min((int)(w & 255), g.Nz);
   }
-  if (MODE == 0 && z == 1 && j == 0) kf = g.Nz;   // (the wall face: nothing to solve, its column integral is zero)
+  if (MODE == 0 && z == 1 && j == g.jws) kf = g.Nz;   // (the wall face: nothing to solve, its column integral is zero)
   return kf;
 }
 // column integral of u / v with the chunked association every other producer of these sums uses
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_var(Grid g, ImplicitV
       Fa[o0 + k * pl] = a[k];
       if (MODE == 1 && pair) Fb[o0 + k * pl] = b[k];
     }
-  if (MODE == 0 && A.sum[z] != nullptr) A.sum[z][o2] = (vsh && j == 0) ? real(0.) : tot;
+  if (MODE == 0 && A.sum[z] != nullptr) A.sum[z][o2] = (vsh && j == g.jws) ? real(0.) : tot;
 }
 // Any Nz (the register kernel stops at 64 levels): the same elimination streamed through HBM.  Forward sweep: the
 // eliminated right-hand side goes back into the field, the factors into a scratch array; backward sweep reads both.
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_var_stream(Grid g, Im
   }
   if (MODE == 0 && A.sum[z] != nullptr) {
     const real tot = implicit_var_colsum(g, A.kchunks, [&](int k) { return Fa[o0 + k * pl]; });
-    A.sum[z][o2] = (vsh && j == 0) ? real(0.) : tot;
+    A.sum[z][o2] = (vsh && j == g.jws) ? real(0.) : tot;
   }
 }
 

@@ -141,7 +141,7 @@ __global__ void k_bottom_drag_flux(Grid g, const real* __restrict__ u, const rea
   }
   {
     real J = real(0.);
-    if (j >= 1 && kv < g.Nz) {
+    if (j != g.jws && kv < g.Nz) {   // (the face on the southern wall never moves)
       const int o = ic(g, i, j, kv), ov = iv(g, i, j, kv);
       const real vv = v[ov], ub = (u[o - g.sx] + u[o - g.sx + 1] + u[o] + u[o + 1]) / real(4.);
       J = -Cd * vv * sqrt(vv * vv + ub * ub);

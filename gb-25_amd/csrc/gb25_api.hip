@@ -1635,11 +1635,11 @@ gb25_status catke_update_impl(gb25_model* m) {
   // J^b: on a slab it was made right after the AB2 update of T, S and travelled with the 3-D bundle (slab_step.hpp)
   if (!m->slab) catke_surface_flux_impl(m);
   // a slab computes kappa in the one halo column / fold row the implicit solves of u / v read (k_catke_diffusivities)
-  const int i_lo = m->slab ? -1 : 0, j_hi = g.Ny;
+  const int i_lo = m->slab ? -1 : 0, j_hi = g.Ny, j_lo = m->ys_open ? -1 : 0;   // (... and the row below a southern neighbour's edge)
   hipLaunchKernelGGL(m->immersed ? k_catke_diffusivities<true> : k_catke_diffusivities<false>,
-                     grid2(g.Nx - i_lo, j_hi, b), b, 0, m->stream, g, catke_parameters(m), m->f[GB25_U].d, m->f[GB25_V].d,
+                     grid2(g.Nx - i_lo, j_hi - j_lo, b), b, 0, m->stream, g, catke_parameters(m), m->f[GB25_U].d, m->f[GB25_V].d,
                      m->f[GB25_E].d, m->catke_b.d, m->f[GB25_JB].d, m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d,
-                     m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_GN_E].d, i_lo, j_hi);
+                     m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_GN_E].d, i_lo, j_hi, j_lo);
   if (g.cv.north_fold && !m->slab)   // the rows beyond the zipper
     hipLaunchKernelGGL(k_catke_fold, dim3((g.sx + 255) / 256, g.H, g.Nz + 3), dim3(256), 0, m->stream, g,
                        m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_JB].d);
@@ -2030,8 +2030,8 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   m->slab = cfg->nranks > 1 || cfg->slab_mode == 1;
   if (m->Nx < cfg->halo) return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab narrower than the halo");
   if (m->Ry > 1) {
-    // a rank of a 2-D decomposition steps on the plain staged sequence: no interior / edge split of the tendencies, no early
-    // pressure, the sub-cycle inside its own step
+    // a rank of a 2-D decomposition steps on the staged sequence without the interior / edge split of the tendencies and
+    // without the early pressure of the own columns
     m->split_tendencies = 0;
     if (m->Ny < cfg->halo + 2) return fail(m, GB25_ERR_INVALID_ARGUMENT, "a rank's band of rows is narrower than the halo");
   }
@@ -2078,7 +2078,6 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   // A slab of a decomposition always uses it: there it also takes two exchanges off the critical path.
   // (gb25_set_option changes any of these defaults; nothing is read from the environment.)
   m->baro_ahead = (m->slab || (long)cfg->Nx * cfg->Ny * cfg->Nz >= 8000000L) ? 1 : 0;
-  if (m->Ry > 1) m->baro_ahead = 0;
   gb25_status s;
   if ((s = build_grid(m))) return s;
   if ((s = build_eos_tables(m))) return s;

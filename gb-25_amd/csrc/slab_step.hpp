@@ -148,10 +148,12 @@ void row_pieces(gb25_model* m, int group, int side, bool pack, real* buf, RowPie
     off += (size_t)nz * nrows * sx;
   };
   if (group == 10) {
-    for (int id : {GB25_U, GB25_V, GB25_T, GB25_S}) {
+    for (int id : {GB25_U, GB25_V, GB25_T, GB25_S, GB25_E}) {
+      if (id == GB25_E && !m->catke) continue;   // (CATKE: the TKE tracer, and J^b for kappa in the first halo row)
       Field& F = m->f[id];
       add(F.d, g.sx, H, (long)g.sx * F.ny, H, g.Nz, H);
     }
+    if (m->catke) add(m->f[GB25_JB].d, g.sx, H, 0, 0, 1, H);
   } else if (group == 11 || group == 13) {
     const int wsx = g.Nx + 2 * m->W;
     for (int q = 0; q < 3; q++) add(m->wide[0][q].d, wsx, H + m->Wys, 0, 0, 1, m->W);
@@ -589,6 +591,11 @@ gb25_status sequence_first_time_step(StepOps& o, bool& lookahead_in_flight) {
     }
     SEQ(o.exchange(0, false));
     EACH(o.unpack(s, 0, false));
+    if (o.mesh_y()) {
+      EACH(o.pack(s, 10, false));
+      SEQ(o.exchange(10, false));
+      EACH(o.unpack(s, 10, false));
+    }
     if (o.folded()) {
       EACH(o.pack(s, 6, false));
       SEQ(o.exchange(6, false));
@@ -976,9 +983,10 @@ void group_destroy(SlabGroup* G) {
 gb25_status group_refresh(SlabGroup* G) {
   gb25_model* m = G->slabs[0];
   const int n = (int)G->slabs.size();
-  for (int b : {0, 3}) {
+  for (int b : {0, 3, 5}) {
     size_t need = 0;
-    for (gb25_model* q : G->slabs) need = std::max(need, (size_t)(b == 0 ? halo_buffer_elems(q, 0) : fold_buffer_elems(q, 3)));
+    for (gb25_model* q : G->slabs)
+      need = std::max(need, (size_t)(b == 0 ? halo_buffer_elems(q, 0) : b == 3 ? fold_buffer_elems(q, 3) : row_buffer_elems(q, 10)));
     if (need == G->elems[b]) continue;
     HIPCHK(hipStreamSynchronize(G->comm));
     HIPCHK(hipStreamSynchronize(G->main));

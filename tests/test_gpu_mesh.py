@@ -58,3 +58,68 @@ def test_mesh_reproduces_single_domain_bitwise(Rx, Ry, Nz, grid_type):
     ens.loop(6)
     _compare(ens, single, "6 steps")
     assert np.abs(single.velocities.u.interior).max() > 1e-2      # a developed, non-trivial flow
+    # the staged path took the look-ahead route: the last stage 0 adopted the sub-cycle prepared beside the previous tracer
+    # kernel (its wide halos in x AND y exchanged on the second stream), and the next one is already prepared
+    assert all(b.lookahead_state() == (True, True) for b in ens.backends)
+
+
+def test_mesh_with_bottom_drag_and_weno7_tracers():
+    """What ocean_simulation adds to the momentum and tracer kernels (quadratic bottom drag, WENO(order = 7) tracer advection:
+    a stencil of four rows either side) on a 2 x 2 mesh of the tripolar grid with the islands."""
+    Nx, Ny, Nz, dt = 128, 96, 8, 600.0
+    single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt, grid_type="gaussian_islands")
+    init = _initial(Nx, Ny, Nz, single, Ny)
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, 4, dt=dt, ranks_y=2, slab_mode=1, grid_type=4)
+    for b in [single.backend] + ens.backends:
+        b.set_bottom_drag(0.003)
+        b.set_tracer_advection_order(7)
+    for n, a in init.items():
+        ens.scatter(n, a)
+    gb.first_time_step(single)
+    ens.first_time_step()
+    gb.loop(single, 5)
+    ens.loop(5)
+    _compare(ens, single, "5 steps")
+
+
+def test_config4_physics_on_a_mesh():
+    """BASELINE.json configs[3] in the decomposition the reference runs it in -- Partition(Rx, Ry, 1) -- at a reduced size: the
+    data-free climate model (tripolar grid with the islands, CATKE with the TKE tracer and J^b in the bundles, the analytic
+    atmosphere with similarity-theory fluxes after every step, quadratic bottom drag, WENO(order = 7) tracers) on a 2 x 2 mesh
+    against the single domain, bit for bit.  kappa and the fluxes of the first halo row / column are computed locally from
+    exchanged halos, never exchanged."""
+    from gb25_amd.data_free import ATMOSPHERE_FIELDS
+    Nx, Ny, Nz, dt, Rx, Ry, H = 128, 96, 8, 30.0, 2, 2, 8
+    m = gb.data_free_ocean_climate_model_init(gb.GPU(), Nz=Nz, dt=dt, size=(Nx, Ny))
+    rng = np.random.default_rng(9)
+    m.set(u=(0.3 * rng.standard_normal((Nx, Ny, Nz))).astype(np.float32), v=(0.3 * rng.standard_normal((Nx, Ny, Nz))).astype(np.float32))
+    names = ("u", "v", "T", "S", "e", "eta")
+    init = {n: m.backend.get_field(n, False) for n in names}
+    atm = gb.analytic_atmosphere()
+    gb.first_time_step(m)
+    gb.loop(m, 5)
+    out = names + ("U", "V", "kappa_u", "kappa_c", "Gn.T", "Gn.u", "Gn.e", "w")
+    ref = {n: m.backend.get_field(n, False) for n in out}
+    flux = {n: m.backend.top_flux(n) for n in ("u", "v", "T", "S")}
+    m.backend.close()
+    assert all(np.isfinite(a).all() for a in ref.values()) and ref["kappa_u"].max() > 0 and np.abs(flux["u"]).max() > 1e-6
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, Rx * Ry, dt=dt, ranks_y=Ry, grid_type=4)
+    for b in ens.backends:
+        b.set_catke(True)
+        b.set_catke_parameters(**gb.default_ocean_closure().parameters)
+        b.set_bottom_drag(0.003)
+        b.set_tracer_advection_order(7)
+        lp = np.asarray(b.metric2("phicc"))[:, : b.Ny_local + 2 * H]
+        for n in ATMOSPHERE_FIELDS:
+            b.set_prescribed_atmosphere(n, atm.interpolate(n, np.zeros_like(lp), lp))
+    for n, a in init.items():
+        ens.scatter(n, a)
+    ens.first_time_step()
+    ens.loop(5)
+    for n, a in ref.items():
+        got = ens.gather(n)
+        assert got.shape == a.shape and np.array_equal(got, a), (n, float(np.abs(got - a).max()), np.argwhere(got != a)[:3].tolist())
+    for n, a in flux.items():
+        rows = [np.concatenate([ens.backends[ry * Rx + rx].top_flux(n) for rx in range(Rx)], axis=0) for ry in range(Ry)]
+        assert np.array_equal(np.concatenate(rows, axis=1), a), n
+    ens.close()
