@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--size", type=int, nargs=3, default=[1440, 720, 48], metavar=("Nx", "Ny", "Nz"))
     ap.add_argument("--dt", type=float, default=240.0)
+    ap.add_argument("--mesh", default=None, metavar="RxxRy",
+                    help="N > 1: a 2-D decomposition, Partition(Rx, Ry, 1) with Rx Ry = N (e.g. 4x2; default: N x slabs)")
     ap.add_argument("--weak", action="store_true", help="N > 1: every rank a full --size slab of an N times wider grid")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="library option for A/B runs (gb25_set_option), e.g. --opt subcycle_lookahead=0")
@@ -187,15 +189,18 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-        if gNx % world:
-            raise SystemExit(f"Nx = {gNx} is not divisible by {world} ranks")
+        Rx, Ry = (int(t) for t in args.mesh.lower().split("x")) if args.mesh else (world, 1)
+        if Rx * Ry != world:
+            raise SystemExit(f"--mesh {args.mesh} is not {world} ranks")
+        if gNx % Rx or Ny % Ry:
+            raise SystemExit(f"Nx = {gNx}, Ny = {Ny} are not divisible by the {Rx} x {Ry} mesh")
         if args.weak:
             # the zonal spacing shrinks with the rank count, so the time step shrinks with it (constant barotropic
             # Courant number, as the reference's resolution-dependent dt: simulations/ocean_climate_simulation.jl:50-51)
             args.dt = args.dt / world
         gt = {"simple_lat_lon": 0, "gaussian_islands_lat_lon": 1, "lat_lon_as_curvilinear": 2, "tripolar": 3,
               "gaussian_islands": 4}[args.grid_type]
-        model = SlabModel(gNx, Ny, Nz, dt=args.dt, rank=rank, nranks=world, device=local_rank,
+        model = SlabModel(gNx, Ny, Nz, dt=args.dt, rank=rank, nranks=world, device=local_rank, ranks_y=Ry,
                           **(dict(grid_type=gt) if gt else {}))
         if args.closure == "catke":
             model.backend.set_catke(True)
@@ -213,7 +218,8 @@ def main():
         model = gb.baroclinic_instability_model(gb.GPU(local_rank), Nx, Ny, Nz, dt=args.dt, grid_type=args.grid_type,
                                                 closure=closure)
         barrier = lambda: None
-    locNx = gNx // world
+        Rx, Ry = 1, 1
+    locNx, locNy = gNx // Rx, Ny // Ry
     b = model.backend
     for kv in args.opt:
         name, val = kv.split("=")
@@ -236,8 +242,11 @@ def main():
         gb.set_baroclinic_instability(model)
     ush, vsh = model.velocities.u.shape, model.velocities.v.shape
     # (the global noise field, cut into the rank's columns: the same initial state whatever the rank count)
-    u0 = (1e-3 * counter_rng((gNx,) + tuple(ush[1:]), 42, 1)).astype(np.float32)[rank * locNx:(rank + 1) * locNx]
-    v0 = (1e-3 * counter_rng((gNx,) + tuple(vsh[1:]), 42, 2)).astype(np.float32)[rank * locNx:(rank + 1) * locNx]
+    # (a y-face field has one row more where the northern edge is a wall: on the ranks of the top row of a lat-lon mesh)
+    i0, j0 = (rank % Rx) * locNx, (rank // Rx) * locNy
+    gvy = Ny + (0 if args.grid_type in ("tripolar", "gaussian_islands") else 1)
+    u0 = (1e-3 * counter_rng((gNx, Ny, ush[2]), 42, 1)).astype(np.float32)[i0:i0 + ush[0], j0:j0 + ush[1]]
+    v0 = (1e-3 * counter_rng((gNx, gvy, vsh[2]), 42, 2)).astype(np.float32)[i0:i0 + vsh[0], j0:j0 + vsh[1]]
     model.set(u=u0, v=v0)
     del u0, v0
     gb.first_time_step(model)
@@ -295,7 +304,7 @@ def main():
             kernels.setdefault(k, v)
 
     if rank == 0:
-        cells = locNx * Ny * Nz                    # per GPU (= per launch of a kernel)
+        cells = locNx * locNy * Nz                 # per GPU (= per launch of a kernel)
         steps_per_s = args.steps / elapsed
         out = {
             "metric": "model time-steps/sec", "value": steps_per_s, "unit": "steps/s", "n_gpus": world,
@@ -306,9 +315,9 @@ def main():
                                    f"halo 8, SplitExplicit(30), {'WENO5 momentum / WENO7 tracers' if args.data_free else 'WENO5'}, TEOS10, dt={args.dt:g}s"
                                    + (f", closure {args.closure}" if args.closure else "")
                                    + (", data-free forcing (similarity-theory fluxes every step)" if args.data_free else ""),
-                       "grid": [gNx, Ny, Nz], "cells_per_gpu": cells, "local_columns": locNx,
-                       "parallelism": (f"x-slab x{world}, RCCL send/recv inside the library"
-                                       if world > 1 else "single GPU"),
+                       "grid": [gNx, Ny, Nz], "cells_per_gpu": cells, "local_columns": locNx, "local_rows": locNy,
+                       "parallelism": ((f"{Rx} x {Ry} mesh (Partition(Rx, Ry, 1))" if Ry > 1 else f"x-slab x{world}")
+                                       + ", RCCL send/recv inside the library" if world > 1 else "single GPU"),
                        "transport": getattr(model, "transport_kind", None),
                        "simulated_years_per_day": steps_per_s * args.dt / 365.0},
             "finite": finite,
@@ -344,12 +353,12 @@ def main():
             achieved = bytes_per_launch / (timed[dom]["avg_ms"] * 1e-3) / 1e9
             # (the template instance the timed loop runs: ..., LAZY, DRAG, WFLY> = "true, false, true>" with w on the fly)
             inst = (", true, false, true>", ", true, false, false>", ", true, false>", ", true>") if (lazy and dom == "momentum") else None
-            traffic, traffic_src = measured_traffic(dom, (locNx, Ny, Nz), prefer=inst)
+            traffic, traffic_src = measured_traffic(dom, (locNx, locNy, Nz), prefer=inst)
             # What bounds the kernel: the tendency kernels are VALU-issue bound -- a wave64 fp32 VALU instruction occupies its
             # SIMD for 4 cycles (profiles/r03_valu_rate_noslp.txt), so the ceiling is 1024 SIMDs x 2.4 GHz / 4 instructions/s;
             # valu_frac = committed SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x 2.4 GHz x the live launch time).
             # `achieved` / `frac` stay the contract's algorithmic-bytes numbers; `traffic_frac` is what the kernel really pulls.
-            insts, insts_src = measured_valu_instructions(dom, (locNx, Ny, Nz), prefer=inst)
+            insts, insts_src = measured_valu_instructions(dom, (locNx, locNy, Nz), prefer=inst)
             valu_frac = (insts * 4.0 / (1024 * 2.4e9) / (timed[dom]["avg_ms"] * 1e-3)) if insts else None
             bound = "valu" if (valu_frac is not None and traffic is not None and
                                valu_frac > traffic / (timed[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) else "hbm"

@@ -59,6 +59,8 @@ Base.@kwdef mutable struct Config
     slab_mode::Int32 = 0
     grid_type::Int32 = 0            # gb25_grid_type: 0 = :simple_lat_lon, 1 = the Gaussian islands on the lat-lon grid,
                                     # 3 = TripolarGrid, 4 = :gaussian_islands (TripolarGrid + GridFittedBottom)
+    ranks_y::Int32 = 1              # Partition(Rx, Ry, 1) (sharding/sharded_baroclinic_instability_simulation_run.jl:65-72):
+                                    # Ry; nranks = Rx Ry, rank = ry Rx + rx; 1: x slabs
 end
 
 mutable struct Model{FT}

@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_multiprocess.py: one rank of an x-slab run (launched by torch.distributed.run)."""
+"""Worker of tests/test_gpu_multiprocess.py: one rank of an x-slab or mesh run (launched by torch.distributed.run)."""
 import os
 import sys
 
@@ -19,13 +19,17 @@ if __name__ == "__main__":
     torch.cuda.set_device(0)
     dist.init_process_group(os.environ.get("GB25_DIST_BACKEND", "gloo"))
     grid_type = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    ranks_y = int(sys.argv[7]) if len(sys.argv) > 7 else 1     # Partition(world / ranks_y, ranks_y, 1)
     kw = dict(grid_type=grid_type) if grid_type else {}
-    m = SlabModel(Nx, Ny, Nz, dt=600.0, rank=rank, nranks=world, device=0, **kw)   # gloo => the host-callback transport
-    nloc = Nx // world
+    m = SlabModel(Nx, Ny, Nz, dt=600.0, rank=rank, nranks=world, device=0, ranks_y=ranks_y, **kw)   # gloo => the host-callback transport
+    b = m.backend
+    i0, j0 = b.rx * b.Nx_local, b.ry * b.Ny_local
     gb.set_baroclinic_instability(m)
     u0 = (1e-2 * counter_rng((Nx, Ny, Nz), 42, 1)).astype(np.float32)
     v0 = (1e-2 * counter_rng((Nx, Ny + 1, Nz), 42, 2)).astype(np.float32)
-    m.set(u=u0[rank * nloc:(rank + 1) * nloc], v=v0[rank * nloc:(rank + 1) * nloc])
+    du, dv = b.field_dims("u", False), b.field_dims("v", False)   # (the rank's window: its columns and rows of the global arrays)
+    b.set_field("u", np.ascontiguousarray(u0[i0:i0 + du[0], j0:j0 + du[1]]), False)
+    b.set_field("v", np.ascontiguousarray(v0[i0:i0 + dv[0], j0:j0 + dv[1]]), False)
     gb.first_time_step(m)
     gb.loop(m, nsteps - 1)
     m.synchronize()

@@ -68,3 +68,31 @@ def test_bench_two_ranks_prints_contract_line():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "strong" and out["finite"]
     assert out["config"]["grid"] == [128, 48, 8] and out["config"]["local_columns"] == 64 and out["value"] > 0
+
+
+def test_four_rank_mesh_on_the_folded_grid_matches_single_domain(tmp_path):
+    """Partition(2, 2, 1) of grid_type = :gaussian_islands in four processes (the host-callback transport over gloo): the ring
+    within each row, the rows to the southern / northern neighbour (buffer sets 5 - 7), the fold partner within the top row."""
+    Nx, Ny, Nz, nsteps = 128, 96, 8, 4
+    res = _launch([os.path.join(ROOT, "tests", "mp_slab_worker.py"), str(tmp_path), str(Nx), str(Ny), str(Nz),
+                   str(nsteps), "4", "2"], {}, nproc=4)
+    assert res.returncode == 0, res.stderr[-3000:]
+    single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=600.0, grid_type="gaussian_islands")
+    gb.set_baroclinic_instability(single)
+    single.set(u=(1e-2 * counter_rng((Nx, Ny, Nz), 42, 1)).astype(np.float32),
+               v=(1e-2 * counter_rng((Nx, Ny + 1, Nz), 42, 2)).astype(np.float32))
+    gb.first_time_step(single)
+    gb.loop(single, nsteps - 1)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(4)]
+    for n in parts[0].files:
+        got = np.concatenate([np.concatenate([parts[ry * 2 + rx][n] for rx in range(2)], axis=0) for ry in range(2)], axis=1)
+        assert np.array_equal(got, single.backend.get_field(n, False)), n
+
+
+def test_bench_mesh_prints_contract_line():
+    res = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "4", "--mesh", "2x2", "--steps", "3", "--warmup", "1", "--size",
+                   "128", "96", "8", "--no-cpu-baseline"], {}, nproc=4)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and out["finite"] and out["config"]["local_columns"] == 64 and out["config"]["local_rows"] == 48
+    assert "2 x 2 mesh" in out["config"]["parallelism"] and out["value"] > 0
