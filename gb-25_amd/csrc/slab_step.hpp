@@ -34,6 +34,11 @@
 //   partner rank's rows south of it -- so between stage 1 / 5 (which then only copies the interiors) and the substeps
 //   (stage 16 / 56) one more exchange, group 8, carries those rows to the partner: ONE partner exchange per step for the
 //   sub-cycle, none inside it.  Group 6 is the partner exchange of the 3-D bundle's rows (and of eta, U, V).
+//   2-D decomposition (Partition(Rx, Ry, 1), cfg.ranks_y > 1): every exchange in x is followed by the exchange of whole rows with
+//   the southern / northern neighbour, which carry the x halo columns just received (the corners): group 11 / 13 after group
+//   1 / 3 and the interior copy (the work arrays are widened in y as in x), group 10 after group 0 and the corrector of the own
+//   rows' x halo columns (stage 32: the rows arrive corrected), group 12 after group 2.  The fold partner is the mirrored rank of
+//   the top row.  No interior / edge split of the tendencies and no early pressure on such a rank.
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>

@@ -346,7 +346,13 @@ gb25_status gb25_loop(gb25_model *m, int32_t n_inner);
  *      Setters of a decomposed model (gb25_set_field, gb25_set_dt, gb25_set_option, gb25_set_baroclinic_instability,
  *      gb25_field_device_ptr) are COLLECTIVE: every rank makes the same call in the same order, like set!(model, ...)
  *      on a Distributed grid.  With the RCCL transport they shake hands with both neighbours and return
- *      GB25_ERR_STATE on a mismatch. */
+ *      GB25_ERR_STATE on a mismatch.
+ *
+ *      2-D decomposition (cfg.ranks_y = Ry > 1; Partition(Rx, Ry, 1), config 4 of the reference: 4 x 2): rank = ry Rx + rx
+ *      owns a window of columns AND rows; Nx, Ny stay the global sizes, every field is the window (a y-face field has one
+ *      row more only on the ranks below a wall).  Every exchange in x is followed by one of whole rows with the southern /
+ *      northern neighbour (rank -/+ Rx; none beyond the walls and the fold); the fold partner of a top-row rank is the
+ *      mirrored rank of that row.  Same calls, same transports. */
 #define GB25_UNIQUE_ID_BYTES 128
 /* rank 0 calls this and hands the 128 bytes to every rank by whatever means the host has (MPI_Bcast, a torch.distributed
  * store, a file): ncclGetUniqueId */
@@ -355,15 +361,17 @@ gb25_status gb25_comm_unique_id(void *id_out);
  * slab_mode == 1 is the self-ring. */
 gb25_status gb25_comm_init_rccl(gb25_model *m, const void *unique_id);
 /* all `n` slabs of one decomposition live in THIS process on one device (tests of decomposition invariance; also a
- * single-process multi-slab run): slabs[r] must have cfg.rank == r, cfg.nranks == n.  The composites called on ANY of
+ * single-process multi-slab run): slabs[r] must have cfg.rank == r, cfg.nranks == n (and the same ranks_y).  The composites called on ANY of
  * them step all of them in lock-step; the exchange is a ring of device-to-device copies. */
 gb25_status gb25_comm_init_local(gb25_model *const *slabs, int32_t n);
 /* the host moves the buffers: fn is called once per exchange with device pointers of this slab's two packed sends and
  * two receive buffers (nbytes each); it must return 0 after recv_west holds the west neighbour's send_east and
  * recv_east the east neighbour's send_west.  The library synchronises the issuing stream before the call (no overlap):
  * a rehearsal transport for setups where RCCL cannot run (two ranks on one device).  buffer_set 3 and 4 (tripolar grid
- * only) are exchanges with the FOLD PARTNER, rank nranks-1-rank: send_west goes to it, recv_west must hold what it sent,
- * the east pointers are NULL. */
+ * only) are exchanges with the FOLD PARTNER, rank nranks-1-rank (2-D decomposition: the mirrored rank of the same row):
+ * send_west goes to it, recv_west must hold what it sent, the east pointers are NULL.  buffer_set 5, 6, 7 (2-D decomposition
+ * only) are the y halos: the "west" pointers belong to the SOUTHERN neighbour (rank - Rx), the "east" pointers to the
+ * NORTHERN one (rank + Rx); a side without a neighbour has NULL pointers. */
 typedef int32_t (*gb25_exchange_fn)(void *user, int32_t buffer_set, const void *send_west, const void *send_east,
                                     void *recv_west, void *recv_east, int64_t nbytes);
 gb25_status gb25_comm_init_callback(gb25_model *m, gb25_exchange_fn fn, void *user);
@@ -373,7 +381,7 @@ gb25_status gb25_comm_finalize(gb25_model *m);
 gb25_status gb25_lookahead_state(const gb25_model *m, int32_t *velocities_ready, int32_t *subcycle_adopted);
 /* The order of operations of one time step (bit 0 of `first`: of first_time_step!; bit 1: on a folded grid; bit 2: of a
  * coupled model; bit 3: with the previous step's look-ahead chain still in flight) of `nslabs` slabs as text, without
- * touching a GPU (tests of the sequencing on CPU-only machines).  Returns the bytes needed, incl. the terminator. */
+ * touching a GPU; bit 4: of a 2-D decomposition (tests of the sequencing on CPU-only machines).  Returns the bytes needed, incl. the terminator. */
 int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int32_t ready, char *out, int64_t cap);
 
 /* ---- state dump: save_model_state(dir, model, arch; label) (src/sharded_io.jl:70-96,122-138; called after each loop

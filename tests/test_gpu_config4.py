@@ -1,8 +1,8 @@
 """BASELINE.json configs[3] at its full size: the data-free climate model -- 1440x720x60 on the TripolarGrid with the Gaussian
 islands, CATKE, the analytic atmosphere with similarity-theory fluxes after every step (GB-25
 src/data_free_ocean_climate_model.jl:12-70 at the resolution of simulations/ocean_climate_simulation.jl).  The reference
-decomposes it 4x2 over eight GPUs; here it is a single domain and eight x slabs of 180 columns -- all on the ONE GPU of this
-box, the library's local transport -- which must agree bit for bit (fold partner exchanges, e and J^b in the bundles, kappa
+decomposes it 4x2 over eight GPUs; here it is a single domain, eight x slabs of 180 columns and the 4 x 2 mesh itself -- all on
+the ONE GPU of this box, the library's local transport -- which must agree bit for bit (fold partner exchanges, e and J^b in the bundles, kappa
 and the fluxes of the halo column computed locally)."""
 import numpy as np
 import pytest
@@ -16,7 +16,8 @@ NX, NY, NZ, DT, H = 1440, 720, 60, 30.0, 8
 FIELDS = ("u", "v", "T", "S", "e", "eta", "U", "V", "kappa_u", "Gn.u", "Gn.T", "Gn.e")
 
 
-def test_config4_grid_single_domain_and_eight_slabs():
+@pytest.fixture(scope="module")
+def reference():
     m = gb.data_free_ocean_climate_model_init(gb.GPU(), Nz=NZ, dt=DT, size=(NX, NY))
     init = {n: m.backend.get_field(n, False) for n in ("T", "S")}
     gb.first_time_step(m)
@@ -27,15 +28,22 @@ def test_config4_grid_single_domain_and_eight_slabs():
     for n, a in ref.items():
         assert np.isfinite(a).all(), n
     assert np.abs(ref["u"]).max() > 1e-6 and np.abs(flux["u"]).max() > 1e-6 and ref["kappa_u"].max() > 0
-    P = 8
-    ens = LocalSlabEnsemble(NX, NY, NZ, P, dt=DT, grid_type=4)
+    return init, ref, flux
+
+
+@pytest.mark.parametrize("Rx,Ry", [(8, 1), (4, 2)])
+def test_config4_grid_single_domain_and_eight_ranks(reference, Rx, Ry):
+    """(8, 1): eight x slabs of 180 columns; (4, 2): the reference's own decomposition of this configuration,
+    Partition(4, 2, 1) -- ranks of 360 columns x 360 rows, the fold partners within the top row."""
+    init, ref, flux = reference
+    ens = LocalSlabEnsemble(NX, NY, NZ, Rx * Ry, dt=DT, grid_type=4, ranks_y=Ry)
     atm = gb.analytic_atmosphere()
     for b in ens.backends:
         b.set_catke(True)
         b.set_catke_parameters(**gb.default_ocean_closure().parameters)
         b.set_bottom_drag(0.003)
         b.set_tracer_advection_order(7)
-        phi = np.asarray(b.metric2("phicc"))[:, : NY + 2 * H]
+        phi = np.asarray(b.metric2("phicc"))[:, : b.Ny_local + 2 * H]
         for n in ATMOSPHERE_FIELDS:
             b.set_prescribed_atmosphere(n, atm.interpolate(n, np.zeros_like(phi), phi))
     for n, a in init.items():
@@ -45,5 +53,6 @@ def test_config4_grid_single_domain_and_eight_slabs():
     for n, a in ref.items():
         assert np.array_equal(ens.gather(n), a), n
     for n, a in flux.items():
-        assert np.array_equal(np.concatenate([b.top_flux(n) for b in ens.backends], axis=0), a), n
+        rows = [np.concatenate([ens.backends[ry * Rx + rx].top_flux(n) for rx in range(Rx)], axis=0) for ry in range(Ry)]
+        assert np.array_equal(np.concatenate(rows, axis=1), a), n
     ens.close()
