@@ -140,6 +140,8 @@ struct gb25_model {
   int complete_fills_needed = 2;
   bool ahead_ts_folded = false, ahead_eta_folded = false, last_baro_folded = false;
   int split_tendencies = 1;          // slab of a decomposition: interior tile columns before the x-halo bundle has arrived
+  int baro_whole = 1;                // narrow slab: the whole sub-cycle in one launch (option SUBCYCLE_WHOLE)
+  int sub_priority = 0;              // slab: the stream of the look-ahead's substeps is a high-priority one (read when the exchange context is built)
   // immersed boundary (GridFittedBottom): first active level per column on the columns [-kb_E, Nx + kb_E) x [0, Ny)
   // (host), the folded tables of device_common.hpp (device), the depths of the wide barotropic arrays of a slab
   bool immersed = false;             // some cell is immersed: the IMM kernel variants run
@@ -1455,6 +1457,25 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     }
     for (int q = 0; q < BT_SMAX; q++) bm.w[q] = (s + q < m->Ns) ? (real)m->weights[s + q] : real(0.);
   };
+  // a narrow slab: fewer tiles than the chip has CUs -- the whole sub-cycle in ONE launch (k_barotropic_whole)
+  constexpr int NSW = 21;   // (the substeps of SplitExplicitFreeSurface(substeps = 30); other counts take the blocked launches)
+  const int wtiles = ((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX) * ((bb.jhi - bb.jlo + BW_TY - 1) / BW_TY);
+  // (Float32: 125 KB of LDS; the Float64 build would need 250 KB)
+  if (blocked && !g.cv.on && m->slab && m->baro_whole && m->Ns == NSW && wtiles <= m->n_cu && sizeof(real) == 4) {
+    auto kern = imm ? k_barotropic_whole<NSW, true> : k_barotropic_whole<NSW, false>;
+    const size_t lds = (size_t)5 * (BT_TX + 2 * NSW) * (BW_TY + 2 * NSW) * sizeof(real);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[imm ? 1 : 0]) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set[imm ? 1 : 0] = true;
+    }
+    BaroMulti bm;
+    fill_multi(bm, 0, NSW);
+    dim3 gm((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX, (bb.jhi - bb.jlo + BW_TY - 1) / BW_TY);
+    hipLaunchKernelGGL(kern, gm, dim3(BW_NT), lds, m->stream, g, bm, dtau);
+    LAUNCHCHK();
+    return GB25_OK;
+  }
   if (blocked_curv) {
     constexpr int Sk = 5, TYc = 17;
     dim3 gm((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX, (rows + TYc - 1) / TYc);
@@ -2282,7 +2303,7 @@ gb25_status gb25_synchronize(gb25_model* m) {
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(m->side_stream));
   if (m->baro_stream) HIPCHK(hipStreamSynchronize(m->baro_stream));   // the sub-cycle look-ahead may still be running there
-  if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));   // (a slab's runs on the second stream of its context)
+  if (m->group) HIPCHK(m->group->sync_side());   // (a slab's runs on the second stream of its context)
   return GB25_OK;
 }
 
@@ -2313,7 +2334,7 @@ static gb25_status copy_field(gb25_model* m, gb25_field id, real* host, int incl
   if (to_device) {   // a look-ahead may still be reading the old values
     HIPCHK(hipStreamSynchronize(m->side_stream));
     if (m->baro_stream) HIPCHK(hipStreamSynchronize(m->baro_stream));
-    if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
+    if (m->group) HIPCHK(m->group->sync_side());
   }
   int32_t d[3];
   gb25_field_dims(m, id, include_halos, d);
@@ -2552,7 +2573,7 @@ gb25_status gb25_set_bottom_height(gb25_model* m, const double* zb) {
   if (!zb) return GB25_ERR_INVALID_ARGUMENT;
   if (gb25_status s = collective_guard(m, 7, 0, zb[0])) return s;   // (synchronises the exchange stream of a decomposed model)
   if (gb25_status s = quiesce_for_grid_change(m)) return s;
-  if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
+  if (m->group) HIPCHK(m->group->sync_side());
   m->host_bottom.assign(zb, zb + (size_t)m->cfg.Nx * m->cfg.Ny);   // GLOBAL cell centres (a slab picks its columns, its
   gb25_status s = rebuild_bottom(m);                                 // neighbours' and its fold partner's)
   if (s) return s;
@@ -2574,7 +2595,7 @@ gb25_status gb25_set_curvilinear_grid(gb25_model* m, const double* const* metric
     if (!metrics[q]) return fail(m, GB25_ERR_INVALID_ARGUMENT, "gb25_set_curvilinear_grid: metric %d is null", q);
   if (gb25_status s = collective_guard(m, 8, (unsigned)ny, metrics[0][(size_t)H + (size_t)gsx * H])) return s;
   if (gb25_status s = quiesce_for_grid_change(m)) return s;
-  if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
+  if (m->group) HIPCHK(m->group->sync_side());
   for (int q = 0; q < GB25_M2_COUNT; q++) {
     std::vector<double>& a = m->host_curv[q];
     a.assign((size_t)gsx * gsy, 0.0);
@@ -2602,7 +2623,7 @@ gb25_status gb25_set_vertical_faces(gb25_model* m, const double* zf, int32_t n) 
     if (!(zf[k + 1] > zf[k])) return fail(m, GB25_ERR_INVALID_ARGUMENT, "gb25_set_vertical_faces: faces must increase (face %d)", k + 1);
   if (gb25_status s = collective_guard(m, 9, (unsigned)n, zf[0])) return s;
   if (gb25_status s = quiesce_for_grid_change(m)) return s;
-  if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
+  if (m->group) HIPCHK(m->group->sync_side());
   m->host_zf.assign(zf, zf + n);
   gb25_status s;
   if ((s = build_grid(m))) return s;          // (row tables again too: small)
@@ -2780,7 +2801,7 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(m->side_stream));
   if (m->baro_stream) HIPCHK(hipStreamSynchronize(m->baro_stream));
-  if (m->group) HIPCHK(hipStreamSynchronize(m->group->comm));
+  if (m->group) HIPCHK(m->group->sync_side());
   m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
   m->tend_forkable = false;
   switch (opt) {
@@ -2817,6 +2838,8 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
     case GB25_OPT_LAZY_CORRECTOR: m->lazy_corrector = v != 0; return GB25_OK;
     case GB25_OPT_TRACERS_FIRST: m->tracers_first = v != 0; return GB25_OK;
     case GB25_OPT_W_ON_THE_FLY: m->w_fly = v != 0; return GB25_OK;
+    case GB25_OPT_SUB_STREAM_PRIORITY: m->sub_priority = v != 0; return GB25_OK;
+    case GB25_OPT_SUBCYCLE_WHOLE: m->baro_whole = v != 0; return GB25_OK;
     case GB25_OPT_MOMENTUM_CHUNK_LEVELS:
     case GB25_OPT_TRACER_CHUNK_LEVELS:
       if (v < 6 || v > 4096) return fail(m, GB25_ERR_INVALID_ARGUMENT, "chunk levels: 6 or more");
@@ -2859,6 +2882,8 @@ gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
     case GB25_OPT_TRACER_CHUNK_LEVELS: *v = m->trc_chunk_levels; break;
     case GB25_OPT_TRACERS_FIRST: *v = m->tracers_first; break;
     case GB25_OPT_W_ON_THE_FLY: *v = m->w_fly; break;
+    case GB25_OPT_SUB_STREAM_PRIORITY: *v = m->sub_priority; break;
+    case GB25_OPT_SUBCYCLE_WHOLE: *v = m->baro_whole; break;
     default: return GB25_ERR_INVALID_ARGUMENT;
   }
   return GB25_OK;

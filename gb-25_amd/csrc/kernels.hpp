@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_barotropic_substep_curv(Grid g, Baro b,
 // ring absorbs the one-cell-per-substep growth of the dependency cone), keeps the running averages in registers
 // and writes everything back once.  Per-point arithmetic and summation order are those of k_barotropic_substep.
 // ---------------------------------------------------------------------------------------------
-constexpr int BT_TX = 64, BT_NT = 256, BT_SMAX = 8;
+constexpr int BT_TX = 64, BT_NT = 256, BT_SMAX = 24;   // (24: the whole sub-cycle in one launch, k_barotropic_whole)
 struct BaroMulti {
   Baro b;
   real w[BT_SMAX];
@@ -1327,6 +1327,138 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
             bm.ub_out[oc] = au[q];
             bm.vb_out[oc] = av[q];
           }
+        }
+      }
+    }
+}
+
+// The WHOLE sub-cycle in one launch, for the narrow slabs of a decomposition: a 180-column rank has 172 tiles -- fewer blocks
+// than the chip has CUs -- and its five blocked launches above (20 us each, dependent) are 100 us on the critical path of a
+// 600 us step.  Here a block of 1024 threads holds its (64 x 17) tile with a ring of NS cells (NS = every substep: 21 with
+// SplitExplicitFreeSurface(substeps = 30)) in 125 KB of LDS -- one block per CU -- and advances all NS substeps between
+// barriers; substep s only touches the points the tile's final state still depends on (ring distance <= NS - 1 - s: half the
+// point updates of the full ring).  Per-point arithmetic, summation order and outputs are those of k_barotropic_multi's
+// first-and-last launch.  Dynamic LDS: 5 (64 + 2 NS) (BW_TY + 2 NS) reals.
+constexpr int BW_NT = 1024, BW_TY = 17;
+template <int NS, bool IMM>
+__global__ __launch_bounds__(BW_NT) void k_barotropic_whole(Grid g, BaroMulti bm, real dtau) {
+  constexpr int RX = BT_TX + 2 * NS, RY = BW_TY + 2 * NS, NP = RX * RY, PPT = (NP + BW_NT - 1) / BW_NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char bw_lds[];
+  real* E = reinterpret_cast<real*>(bw_lds);
+  real *U = E + NP, *V = U + NP, *GUs = V + NP, *GVs = GUs + NP;
+  __shared__ real Mdxf[RY + 1], Mrazc[RY], Mrdxc[RY];
+  __builtin_amdgcn_s_setprio(3);
+  const Baro& b = bm.b;
+  const int tid = threadIdx.x;
+  const int i0 = b.ilo + blockIdx.x * BT_TX, j0 = b.jlo + blockIdx.y * BW_TY;
+  if (tid <= RY) {
+    const int jg = max(b.jlo - (g.H + 2), min(b.jhi + g.H + 2, j0 - NS + tid));
+    Mdxf[tid] = g.dxf[jg];
+    if (tid < RY) {
+      Mrazc[tid] = g.razc[jg];
+      Mrdxc[tid] = g.rdxc[jg];
+    }
+  }
+  const real gH = g.g * g.Lz, rdy = g.rdy, dyc = g.dy;
+  const int lo = -b.xo, hi = b.sx - b.xo - 1;
+  int po[PPT];            // global element offset of the point (-1: none)
+  short dist[PPT];        // ring distance from the own tile (0: own); 127: never computed
+  real ae[PPT], au[PPT], av[PPT], ghf[PPT], ghc[PPT];
+#pragma unroll
+  for (int q = 0; q < PPT; q++) {
+    const int p = tid + q * BW_NT;
+    const int ly = p / RX, lx = p - ly * RX;
+    const int ig = i0 - NS + lx, jg = j0 - NS + ly;
+    const bool exists = (p < NP) && jg >= b.jlo && jg < b.jhi;
+    int ii = ig;
+    if (b.wrap) {
+      ii = ii % g.Nx;
+      if (ii < 0) ii += g.Nx;
+    } else {
+      ii = max(lo, min(hi, ii));
+    }
+    po[q] = exists ? bi(g, b, ii, jg) : -1;
+    const int dx = lx < NS ? NS - lx : (lx >= NS + BT_TX ? lx - (NS + BT_TX - 1) : 0);
+    const int dy = ly < NS ? NS - ly : (ly >= NS + BW_TY ? ly - (NS + BW_TY - 1) : 0);
+    dist[q] = (short)(p < NP ? max(dx, dy) : 127);
+    real le = real(0.), lu = real(0.), lv = real(0.), lgu = real(0.), lgv = real(0.);
+    ghf[q] = ghc[q] = gH;
+    if (exists) {
+      le = b.eta0[po[q]];
+      lu = b.U0[po[q]];
+      lv = b.V0[po[q]];
+      lgu = b.GU[po[q]];
+      lgv = b.GV[po[q]];
+      if (IMM) {
+        ghf[q] = g.g * b.Hfc[po[q]];
+        ghc[q] = g.g * b.Hcf[po[q]];
+      }
+    }
+    if (p < NP) {
+      E[p] = le; U[p] = lu; V[p] = lv; GUs[p] = lgu; GVs[p] = lgv;
+    }
+    ae[q] = au[q] = av[q] = real(0.);
+  }
+  __syncthreads();
+  for (int s = 0; s < bm.ns; s++) {
+    const real wgt = bm.w[s];
+    // Points farther out no longer matter to the tile: U, V of the state this substep produces are needed out to ring distance
+    // `reach`, and they read the NEW eta one cell further west / south
+    const int reach = NS - 1 - s;
+    // ---- eta with the old transports (needs U(i+1), V(j+1))
+#pragma unroll
+    for (int q = 0; q < PPT; q++) {
+      const int p = tid + q * BW_NT;
+      const int ly = p / RX, lx = p - ly * RX, jg = j0 - NS + ly;
+      if (po[q] >= 0 && dist[q] <= reach + 1 && lx < RX - 1 && (ly < RY - 1 || jg == g.jwn - 1)) {
+        real dxU = dyc * U[p + 1] - dyc * U[p];
+        real dyV;
+        if (jg == g.jwn - 1) dyV = -(Mdxf[ly] * V[p]);
+        else if (jg == g.jws) dyV = Mdxf[ly + 1] * V[p + RX];
+        else dyV = Mdxf[ly + 1] * V[p + RX] - Mdxf[ly] * V[p];
+        real e = E[p] - dtau * (dxU + dyV) * Mrazc[ly];
+        E[p] = e;
+        if (dist[q] == 0) ae[q] += wgt * e;
+      }
+    }
+    __syncthreads();
+    // ---- U, V with the new eta (needs eta(i-1), eta(j-1))
+#pragma unroll
+    for (int q = 0; q < PPT; q++) {
+      const int p = tid + q * BW_NT;
+      const int ly = p / RX, lx = p - ly * RX, jg = j0 - NS + ly;
+      if (po[q] >= 0 && dist[q] <= reach && lx >= 1 && (ly >= 1 || jg == g.jws)) {
+        real e = E[p];
+        real dxe = (e - E[p - 1]) * Mrdxc[ly];
+        real dye = real(0.);
+        if (jg != g.jws) dye = (e - E[p - RX]) * rdy;
+        real Un = U[p] + dtau * (GUs[p] - ghf[q] * dxe);
+        real Vn = V[p] + dtau * (GVs[p] - ghc[q] * dye);
+        U[p] = Un;
+        V[p] = Vn;
+        if (dist[q] == 0) {
+          au[q] += wgt * Un;
+          av[q] += wgt * Vn;
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < PPT; q++)
+    if (po[q] >= 0 && dist[q] == 0) {
+      const int p = tid + q * BW_NT;
+      const int ly = p / RX, lx = p - ly * RX;
+      const int ig = i0 - NS + lx, jg = j0 - NS + ly;
+      if (ig < b.ihi && ig >= -bm.out_halo && ig < g.Nx + bm.out_halo && jg >= bm.out_js && jg < bm.out_jn) {
+        const int oc = i2(g, ig, jg);
+        bm.eta_out[oc] = ae[q];
+        bm.U_out[oc] = au[q];
+        bm.V_out[oc] = av[q];
+        if (bm.eb_out) {
+          bm.eb_out[oc] = ae[q];
+          bm.ub_out[oc] = au[q];
+          bm.vb_out[oc] = av[q];
         }
       }
     }

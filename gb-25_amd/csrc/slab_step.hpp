@@ -345,25 +345,34 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     // groups 2 and 0 have been unpacked: corrector on the x-halo columns, then update_state without any
     // further exchange (y/z layers re-filled over the extended x range; w and p recomputed in the halos).
     // Folded grid: stage 30 = up to the y/z layers, then the rows beyond the fold arrive from the partner, stage 31 = the rest.
-    if (stage != 31) {
-      if (m->Ry == 1 && (s = corrector_impl(m, true, 2))) return s;   // (2-D decomposition: done in stage 32)
-      // the interior pressure pass of stage 0 must be over before the fills touch T, S and before the west strip
-      // rewrites column 0 (it has been for a while: the exchanges and the sub-cycle ran in between)
-      if (p_early) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
-      if ((s = fill_halos_impl(m, false, true))) return s;
-      if (m->catke && (s = fill_halos_impl(m, false, true, 1, 4))) return s;
-      if (stage == 30) return GB25_OK;
-    }
-    if (p_early) {   // the two pressure strips run beside w (side stream)
+    // (a closure's fields travel in the bundle as well and its fills follow: the strips keep their old place behind them)
+    const bool strips_first = p_early && !m->catke;
+    auto pressure_strips = [&]() -> gb25_status {
       hipStream_t main = m->stream;
       HIPCHK(hipEventRecord(m->ev_fork, main));
       HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
       m->stream = m->side_stream;
-      s = compute_p_impl(m, -g.H + 1, 0, g.Nx, g.Nx + g.H - 2, true);   // west strip (redoes column 0) + east strip
+      gb25_status r = compute_p_impl(m, -g.H + 1, 0, g.Nx, g.Nx + g.H - 2, true);   // west strip (redoes column 0) + east strip
       m->stream = main;
-      if (s) return s;
+      if (r) return r;
       HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
+      return GB25_OK;
+    };
+    if (stage != 31) {
+      if (strips_first) {
+        // the two pressure strips next to the x halos start as soon as the bundle is unpacked: T, S of the halo columns arrived
+        // complete (their y/z layers were filled by their owner before it packed them), and the side stream runs them behind the
+        // interior pass of stage 0 -- beside the corrector, the fills and w of the edge strips instead of after them
+        if ((s = pressure_strips())) return s;
+      }
+      if (m->Ry == 1 && (s = corrector_impl(m, true, 2))) return s;   // (2-D decomposition: done in stage 32)
+      // (with the early strips T and S are left alone here: their layers are in place, own columns since stage 0)
+      if (p_early && !strips_first) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));   // (the interior pass reads T, S)
+      if ((s = fill_halos_impl(m, false, true, 3, strips_first ? 1 : 3))) return s;
+      if (m->catke && (s = fill_halos_impl(m, false, true, 1, 4))) return s;
+      if (stage == 30) return GB25_OK;
     }
+    if (p_early && !strips_first && (s = pressure_strips())) return s;   // (beside w)
     if ((s = compute_w_impl(m, split ? 2 : 0))) return s;
     if (p_early) {
       HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
@@ -396,21 +405,24 @@ gb25_status update_state_local_impl(gb25_model* m) {   // update_state! without 
 // Everything a step of the slabs driven by this process does, in issue order.  Streams: `main` (on_comm = false) and
 // `comm`; record(slot, on_comm) marks everything issued so far on a stream, wait(slot, comm_waits) makes the other (or
 // the same) stream wait for that mark.  No host synchronisation anywhere.
+// Streams by number: 0 = main, 1 = comm (the exchanges: packs, transfers, unpacks), 2 = sub (the substeps of the sub-cycle
+// look-ahead: on a stream of their own so that the next step's bundle -- posted on the comm stream right behind stage 0 -- does
+// not queue behind five sub-cycle launches it has nothing to do with; 95 us of a 180-column rank's 640).
 struct StepOps {
   virtual ~StepOps() {}
   virtual int n() const = 0;
-  virtual gb25_status stage(int s, int stage, int euler, bool on_comm) = 0;
-  virtual gb25_status pack(int s, int group, bool on_comm) = 0;
-  virtual gb25_status unpack(int s, int group, bool on_comm) = 0;
-  virtual gb25_status exchange(int group, bool on_comm) = 0;   // every slab's packs -> its neighbours' receive buffers
+  virtual gb25_status stage(int s, int stage, int euler, int on) = 0;
+  virtual gb25_status pack(int s, int group, int on) = 0;
+  virtual gb25_status unpack(int s, int group, int on) = 0;
+  virtual gb25_status exchange(int group, int on) = 0;   // every slab's packs -> its neighbours' receive buffers
   virtual gb25_status local(int s, int what) = 0;              // 0: initialize!, 1: y/z halo layers, 2: update_state! (local)
   virtual bool velocities_ready(int s) = 0;
   virtual bool subcycle_adopted(int s) = 0;
   virtual bool coupled() { return false; }   // a prescribed atmosphere is set (data-free forcing)
   virtual bool folded() = 0;          // zipper fold: exchanges with the partner rank (buffer sets 3 and 4; groups 6 and 8)
   virtual bool mesh_y() { return false; }   // 2-D decomposition: y halos from the southern / northern neighbour (groups 10 - 14)
-  virtual gb25_status record(int slot, bool on_comm) = 0;
-  virtual gb25_status wait(int slot, bool comm_waits) = 0;
+  virtual gb25_status record(int slot, int on) = 0;
+  virtual gb25_status wait(int slot, int waiter) = 0;
 };
 #define SEQ(call)            \
   do {                       \
@@ -512,22 +524,30 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
     SEQ(o.wait(2, true));
     EACH(o.pack(s, 3, true));
     SEQ(o.exchange(3, true));
-    for (int s = 0; s < n; s++) {
-      SEQ(o.unpack(s, 3, true));
-      SEQ(o.stage(s, 5, euler, true));   // (x halo columns of the new eta, U, V included: nothing to exchange after it)
-      if (o.mesh_y()) SEQ(o.pack(s, 13, true));
-      if (o.folded()) SEQ(o.pack(s, 8, true));
-    }
-    if (o.folded() || o.mesh_y()) {      // the neighbours' rows / the image rows beyond the pivot row, then the substeps
-      if (o.mesh_y()) SEQ(o.exchange(13, true));
-      if (o.folded()) SEQ(o.exchange(8, true));
+    if (o.folded() || o.mesh_y()) {
       for (int s = 0; s < n; s++) {
-        if (o.mesh_y()) SEQ(o.unpack(s, 13, true));
-        if (o.folded()) SEQ(o.unpack(s, 8, true));
-        SEQ(o.stage(s, 56, euler, true));
+        SEQ(o.unpack(s, 3, 1));
+        SEQ(o.stage(s, 5, euler, 1));    // (the interior copy only)
+        if (o.mesh_y()) SEQ(o.pack(s, 13, 1));
+        if (o.folded()) SEQ(o.pack(s, 8, 1));
       }
+      // the neighbours' rows / the image rows beyond the pivot row, then the substeps on their own stream
+      if (o.mesh_y()) SEQ(o.exchange(13, 1));
+      if (o.folded()) SEQ(o.exchange(8, 1));
+      for (int s = 0; s < n; s++) {
+        if (o.mesh_y()) SEQ(o.unpack(s, 13, 1));
+        if (o.folded()) SEQ(o.unpack(s, 8, 1));
+      }
+      SEQ(o.record(5, 1));
+      SEQ(o.wait(5, 2));
+      EACH(o.stage(s, 56, euler, 2));
+    } else {
+      EACH(o.unpack(s, 3, 1));
+      SEQ(o.record(5, 1));
+      SEQ(o.wait(5, 2));
+      EACH(o.stage(s, 5, euler, 2));     // (x halo columns of the new eta, U, V included: nothing to exchange after it)
     }
-    SEQ(o.record(4, true));
+    SEQ(o.record(4, 2));
     lookahead_in_flight = true;
   }
   EACH(o.stage(s, 4, euler, false));
@@ -537,6 +557,7 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
 gb25_status sequence_first_time_step(StepOps& o, bool& lookahead_in_flight) {
   const int n = o.n();
   if (lookahead_in_flight) {
+    SEQ(o.wait(4, 0));             // (the chain's last launches, on the sub stream)
     SEQ(o.record(3, true));
     SEQ(o.wait(3, false));
     lookahead_in_flight = false;
@@ -632,12 +653,12 @@ struct TraceOps : StepOps {
     log += buf;
     log += '\n';
   }
-  static const char* st(bool on_comm) { return on_comm ? "comm" : "main"; }
+  static const char* st(int on) { return on == 2 ? "sub" : on == 1 ? "comm" : "main"; }
   int n() const override { return nslabs; }
-  gb25_status stage(int s, int stage, int euler, bool c) override { add("stage %d slab %d euler %d %s", stage, s, euler, st(c)); return GB25_OK; }
-  gb25_status pack(int s, int group, bool c) override { add("pack %d slab %d %s", group, s, st(c)); return GB25_OK; }
-  gb25_status unpack(int s, int group, bool c) override { add("unpack %d slab %d %s", group, s, st(c)); return GB25_OK; }
-  gb25_status exchange(int group, bool c) override { add("exchange %d %s", group, st(c)); return GB25_OK; }
+  gb25_status stage(int s, int stage, int euler, int c) override { add("stage %d slab %d euler %d %s", stage, s, euler, st(c)); return GB25_OK; }
+  gb25_status pack(int s, int group, int c) override { add("pack %d slab %d %s", group, s, st(c)); return GB25_OK; }
+  gb25_status unpack(int s, int group, int c) override { add("unpack %d slab %d %s", group, s, st(c)); return GB25_OK; }
+  gb25_status exchange(int group, int c) override { add("exchange %d %s", group, st(c)); return GB25_OK; }
   gb25_status local(int s, int what) override {
     static const char* names[] = {"initialize", "fill_local", "update_state_local", "mask_fill_local", "auxiliaries_tendencies_local",
                                   "first_fluxes_local", "tendencies_local"};
@@ -646,8 +667,8 @@ struct TraceOps : StepOps {
   }
   bool velocities_ready(int) override { return ready; }
   bool subcycle_adopted(int) override { return adopted; }
-  gb25_status record(int slot, bool c) override { add("record %d %s", slot, st(c)); return GB25_OK; }
-  gb25_status wait(int slot, bool comm_waits) override { add("wait %d %s", slot, st(comm_waits)); return GB25_OK; }
+  gb25_status record(int slot, int c) override { add("record %d %s", slot, st(c)); return GB25_OK; }
+  gb25_status wait(int slot, int waiter) override { add("wait %d %s", slot, st(waiter)); return GB25_OK; }
 };
 
 // ---- transports ------------------------------------------------------------------------------------------------------
@@ -663,8 +684,14 @@ struct Transport {
 // The slabs this process drives, their exchange buffers, the second stream and the transport.
 struct SlabGroup {
   std::vector<gb25_model*> slabs;
-  hipStream_t main = nullptr, comm = nullptr;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t main = nullptr, comm = nullptr, sub = nullptr;   // (sub: the substeps of the sub-cycle look-ahead)
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // everything the second and third stream hold is over (host writes, grid changes, collective setters)
+  hipError_t sync_side() {
+    hipError_t e = comm ? hipStreamSynchronize(comm) : hipSuccess;
+    if (e == hipSuccess && sub) e = hipStreamSynchronize(sub);
+    return e;
+  }
   Transport* transport = nullptr;
   // [slab][buffer set][side: 0 west, 1 east]; sets 3, 4 go to the fold partner (side 0 only); sets 5, 6, 7 to the southern
   // (side 0) and northern (side 1) neighbour of a 2-D decomposition
@@ -862,8 +889,8 @@ struct GroupOps : StepOps {
     OnStream(gb25_model* m_, hipStream_t st) : m(m_), saved(m_->stream) { m->stream = st; }
     ~OnStream() { m->stream = saved; }
   };
-  hipStream_t st(bool on_comm) const { return on_comm ? G.comm : G.main; }
-  gb25_status stage(int s, int stage, int euler, bool c) override {
+  hipStream_t st(int on) const { return on == 2 ? G.sub : on == 1 ? G.comm : G.main; }
+  gb25_status stage(int s, int stage, int euler, int c) override {
     OnStream on(G.slabs[s], st(c));
     return slab_stage(G.slabs[s], stage, euler);
   }
@@ -874,7 +901,7 @@ struct GroupOps : StepOps {
   }
   bool mesh_y() override { return G.slabs[0]->Ry > 1; }
   bool coupled() override { return G.slabs[0]->coupled; }
-  gb25_status pack(int s, int group, bool c) override {
+  gb25_status pack(int s, int group, int c) override {
     OnStream on(G.slabs[s], st(c));
     const int b = buffer_set(group);
     if ((group == 6 || group == 8) && !G.slabs[s]->g.cv.north_fold) return GB25_OK;
@@ -888,7 +915,7 @@ struct GroupOps : StepOps {
     real* buf[2] = {G.send[s][b][0], G.send[s][b][1]};
     return pack_unpack(G.slabs[s], group, buf, true);
   }
-  gb25_status unpack(int s, int group, bool c) override {
+  gb25_status unpack(int s, int group, int c) override {
     OnStream on(G.slabs[s], st(c));
     const int b = buffer_set(group);
     if ((group == 6 || group == 8) && !G.slabs[s]->g.cv.north_fold) return GB25_OK;
@@ -901,7 +928,7 @@ struct GroupOps : StepOps {
     real* buf[2] = {G.recv[s][b][0], G.recv[s][b][1]};
     return pack_unpack(G.slabs[s], group, buf, false);
   }
-  gb25_status exchange(int group, bool c) override {
+  gb25_status exchange(int group, int c) override {
     const int b = buffer_set(group);
     return G.transport->exchange(G, b, G.elems[b] * sizeof(real), st(c));
   }
@@ -946,21 +973,21 @@ struct GroupOps : StepOps {
     return m->ahead_uv_valid && m->baro_ahead && !m->ptr_exposed;
   }
   bool subcycle_adopted(int s) override { return G.slabs[s]->baro_adopted; }
-  gb25_status record(int slot, bool c) override {
+  gb25_status record(int slot, int c) override {
     gb25_model* m = G.slabs[0];
     HIPCHK(hipEventRecord(G.ev[slot], st(c)));
     return GB25_OK;
   }
-  gb25_status wait(int slot, bool comm_waits) override {
+  gb25_status wait(int slot, int waiter) override {
     gb25_model* m = G.slabs[0];
-    HIPCHK(hipStreamWaitEvent(st(comm_waits), G.ev[slot], 0));
+    HIPCHK(hipStreamWaitEvent(st(waiter), G.ev[slot], 0));
     return GB25_OK;
   }
 };
 
 void group_destroy(SlabGroup* G) {
   if (!G) return;
-  if (G->comm) hipStreamSynchronize(G->comm);
+  G->sync_side();
   if (G->main) hipStreamSynchronize(G->main);
   delete G->transport;
   for (auto& s : G->send)
@@ -974,6 +1001,7 @@ void group_destroy(SlabGroup* G) {
   for (hipEvent_t e : G->ev)
     if (e) hipEventDestroy(e);
   if (G->comm) hipStreamDestroy(G->comm);
+  if (G->sub) hipStreamDestroy(G->sub);
   if (G->tok_dev) hipFree(G->tok_dev);
   if (G->tok_host) hipHostFree(G->tok_host);
   for (gb25_model* m : G->slabs) {
@@ -993,7 +1021,7 @@ gb25_status group_refresh(SlabGroup* G) {
     for (gb25_model* q : G->slabs)
       need = std::max(need, (size_t)(b == 0 ? halo_buffer_elems(q, 0) : b == 3 ? fold_buffer_elems(q, 3) : row_buffer_elems(q, 10)));
     if (need == G->elems[b]) continue;
-    HIPCHK(hipStreamSynchronize(G->comm));
+    HIPCHK(G->sync_side());
     HIPCHK(hipStreamSynchronize(G->main));
     if (need > G->capacity[b]) {
       for (int s = 0; s < n; s++)
@@ -1038,7 +1066,15 @@ gb25_status group_create(gb25_model* const* slabs, int n, Transport* tr) {
   gb25_status st = GB25_OK;
   do {
     if (hipSetDevice(m->cfg.device) != hipSuccess ||
-        hipStreamCreateWithFlags(&G->comm, hipStreamNonBlocking) != hipSuccess) { st = GB25_ERR_HIP; break; }
+        hipStreamCreateWithFlags(&G->comm, hipStreamNonBlocking) != hipSuccess ||
+        [&]() {
+          // the substeps' few blocks should not queue behind what is left of the tracer kernel's grid: highest priority
+          // (option SUB_STREAM_PRIORITY = 0: an ordinary stream)
+          int least = 0, greatest = 0;
+          if (m->sub_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            return hipStreamCreateWithPriority(&G->sub, hipStreamNonBlocking, greatest);
+          return hipStreamCreateWithFlags(&G->sub, hipStreamNonBlocking);
+        }() != hipSuccess) { st = GB25_ERR_HIP; break; }
     for (auto& e : G->ev)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) st = GB25_ERR_HIP;
     if (st) break;
@@ -1089,7 +1125,7 @@ gb25_status collective_guard(gb25_model* m, unsigned op, unsigned arg, double pa
   unsigned long long* h = G->tok_host;
   h[0] = h[2] = ((unsigned long long)op << 32) | arg;
   h[1] = h[3] = bits;
-  HIPCHK(hipStreamSynchronize(G->comm));   // a look-ahead still in flight belongs to the state this call is about to void
+  HIPCHK(G->sync_side());   // a look-ahead still in flight belongs to the state this call is about to void
   HIPCHK(hipMemcpyAsync(G->tok_dev, h, 4 * sizeof *h, hipMemcpyHostToDevice, G->main));
   gb25_status s = R->send_recv(m, G->tok_dev, G->tok_dev + 2, G->tok_dev + 4, G->tok_dev + 6, 2 * sizeof *h, G->main);
   if (s) return s;

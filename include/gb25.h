@@ -142,6 +142,12 @@ typedef enum {
                                     call returns.  Like KERNELS this changes results in the LAST BITS (another association of the
                                     vertical sum): comparisons that must be bit-exact (a decomposition against the single domain)
                                     switch it off */
+  GB25_OPT_SUB_STREAM_PRIORITY,  /* [0] slab of a decomposition: the substeps of the sub-cycle look-ahead run on a HIGH-PRIORITY stream (their
+                                    few blocks could be dispatched ahead of what is left of the tracer kernel's grid -- measured: no difference); 0: an ordinary stream.
+                                    Read when the exchange context is built (gb25_comm_init_*) */
+  GB25_OPT_SUBCYCLE_WHOLE,       /* [1] slab of a decomposition with fewer sub-cycle tiles than the device has CUs (a 180-column rank): all
+                                    substeps in ONE launch, the tile and a ring as wide as the sub-cycle is long in 125 KB of LDS;
+                                    0: the blocked launches (SUBCYCLE_BLOCK) */
   GB25_OPT_COUNT
 } gb25_option;
 

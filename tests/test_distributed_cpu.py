@@ -136,7 +136,7 @@ def test_time_step_sequencing_on_a_folded_grid():
                     ("unpack", 0, "main"), ("stage", 30, "main"), ("pack", 6, "main"), ("exchange", 6, "main"),
                     ("unpack", 6, "main"), ("stage", 31, "main"),
                     ("pack", 3, "comm"), ("exchange", 3, "comm"), ("unpack", 3, "comm"), ("stage", 5, "comm"),
-                    ("pack", 8, "comm"), ("exchange", 8, "comm"), ("unpack", 8, "comm"), ("stage", 56, "comm"),
+                    ("pack", 8, "comm"), ("exchange", 8, "comm"), ("unpack", 8, "comm"), ("stage", 56, "sub"),
                     ("stage", 4, "main")]
     assert ahead[-1] == ("lookahead_in_flight", 1)
     # every slab has packed its rows before the partner exchange and no slab unpacks before it
@@ -158,12 +158,13 @@ def test_time_step_sequencing_on_a_folded_grid():
 def test_time_step_sequencing_with_the_subcycle_lookahead():
     """When the previous step left a valid look-ahead, stage 0 adopts the sub-cycle: groups 1, 2 and stage 1 vanish
     from the step; after the momentum tendencies (stage 3) the NEXT sub-cycle is prepared beside the tracer
-    tendencies on the second stream: group 3 -> stage 5."""
+    tendencies: group 3 on the second stream, then stage 5 -- the substeps -- on a third one, so that the next step's bundle,
+    posted on the second stream right behind stage 0, does not queue behind five sub-cycle launches."""
     log = _sequence(3, adopted=True, ready=True)
     mine = _ops_of_slab(log, 1)
     assert mine == [("stage", 0, "main"), ("pack", 0, "comm"), ("exchange", 0, "comm"), ("stage", 2, "main"),
                     ("unpack", 0, "main"), ("stage", 3, "main"),
-                    ("pack", 3, "comm"), ("exchange", 3, "comm"), ("unpack", 3, "comm"), ("stage", 5, "comm"),
+                    ("pack", 3, "comm"), ("exchange", 3, "comm"), ("unpack", 3, "comm"), ("stage", 5, "sub"),
                     ("stage", 4, "main")]      # (no group 4: the widened sub-cycle leaves the x halo columns behind too)
     assert [e[1] for e in log if e[0] == "exchange"] == [0, 3]
     assert log[-1] == ("lookahead_in_flight", 1)
@@ -173,6 +174,10 @@ def test_time_step_sequencing_with_the_subcycle_lookahead():
     i_wait = max(i for i, e in enumerate(log) if e == ("wait", 2, "comm"))
     i_pack3 = min(i for i, e in enumerate(log) if e[:2] == ("pack", 3))
     assert i_mom < i_rec < i_wait < i_pack3
+    # ... the substeps behind the unpacked wide halos (event 5: comm -> sub), and the chain's end is event 4 on the sub stream
+    i_un3 = max(i for i, e in enumerate(log) if e[:2] == ("unpack", 3))
+    i_st5 = min(i for i, e in enumerate(log) if e[:2] == ("stage", 5))
+    assert i_un3 < log.index(("record", 5, "comm")) < log.index(("wait", 5, "sub")) < i_st5 < log.index(("record", 4, "sub"))
 
 
 def test_first_time_step_sequencing():
@@ -219,7 +224,7 @@ def test_a_step_behind_a_look_ahead_chain_in_flight():
     w = idx("wait", 4, "main")
     assert idx("stage", 0, "slab", 2, "euler", 0, "main") < w < idx("stage", 2, "slab", 0, "euler", 0, "main")
     assert idx("exchange", 0, "comm") < w                                  # the bundle is on its way by then
-    assert ("record", 4, "comm") in log and log[-1] == ("lookahead_in_flight", 1)
+    assert ("record", 4, "sub") in log and log[-1] == ("lookahead_in_flight", 1)
     log = _raw_sequence(3, 8, adopted=0, ready=0)
     idx = lambda *e: log.index(e)
     assert idx("stage", 0, "slab", 2, "euler", 0, "main") < idx("wait", 4, "main") < idx("pack", 1, "slab", 0, "main")

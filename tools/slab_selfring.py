@@ -18,11 +18,10 @@ a = ap.parse_args()
 import numpy as np
 import gb25_amd as gb
 from gb25_amd.distributed import SlabModel
+# (options go in at creation: some are read when the exchange context is built)
 m = SlabModel(a.columns, a.size[0], a.size[1], dt=a.dt, rank=0, nranks=1, slab_mode=1, transport="rccl",
+              options={kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.opt},
               **(dict(grid_type=a.grid_type) if a.grid_type else {}))
-for kv in a.opt:
-    k, v = kv.split("=")
-    m.backend.set_option(k, int(v))
 gb.set_baroclinic_instability(m)
 gb.first_time_step(m)
 gb.loop(m, 20)
