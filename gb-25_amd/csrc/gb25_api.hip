@@ -1355,7 +1355,10 @@ gb25_status tall_rows_impl(gb25_model* m, real* buf, bool pack) {
   return GB25_OK;
 }
 
-gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
+// own: (slab) the interior columns of eta, U, V, G.U, G.V still sit in the canonical arrays -- copied into the work arrays here,
+// or read in place by the one-launch kernel; layers_done: set when the kernel also wrote the y layers of the new eta, U, V
+gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false, const InteriorCopies* own = nullptr,
+                            bool* layers_done = nullptr) {
   const Grid& g = m->g;
   if (m->baro_inflight && !ahead) {
     // a look-ahead that is not being adopted (changed dt, ...) may still be running on the side stream, and it uses
@@ -1451,6 +1454,8 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     bm.out_halo = m->slab ? g.H : 0;   // (a widened slab also writes the x halo columns of the new eta, U, V)
     bm.out_js = m->ys_open ? -g.H : 0;   // (... and a rank of a 2-D decomposition the halo rows of its open sides)
     bm.out_jn = m->yn_open ? g.Ny + g.H : g.Ny;
+    for (int q = 0; q < 5; q++) bm.own_src[q] = nullptr;
+    bm.layers = 0;
     if (wide) {
       const Field* fb = ahead ? m->ahead_bar : &m->f[GB25_ETA_BAR];
       bm.eb_out = fb[0].d; bm.ub_out = fb[1].d; bm.vb_out = fb[2].d;
@@ -1461,7 +1466,13 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
   constexpr int NSW = 21;   // (the substeps of SplitExplicitFreeSurface(substeps = 30); other counts take the blocked launches)
   const int wtiles = ((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX) * ((bb.jhi - bb.jlo + BW_TY - 1) / BW_TY);
   // (Float32: 125 KB of LDS; the Float64 build would need 250 KB)
-  if (blocked && !g.cv.on && m->slab && m->baro_whole && m->Ns == NSW && wtiles <= m->n_cu && sizeof(real) == 4) {
+  const bool whole = blocked && !g.cv.on && m->slab && m->baro_whole && m->Ns == NSW && wtiles <= m->n_cu && sizeof(real) == 4;
+  // (the one-launch kernel reads the own columns in place only when it writes elsewhere -- the look-ahead's partner buffers;
+  // inside its own step the results go into the very arrays other blocks are still loading their rings from)
+  const bool in_place = whole && own && own->n == 5 && ahead;
+  if (own && !in_place)
+    hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, g.sy_v, own->n), dim3(256), 0, m->stream, *own, g.Nx);
+  if (whole) {
     auto kern = imm ? k_barotropic_whole<NSW, true> : k_barotropic_whole<NSW, false>;
     const size_t lds = (size_t)5 * (BT_TX + 2 * NSW) * (BW_TY + 2 * NSW) * sizeof(real);
     static bool attr_set[2] = {false, false};
@@ -1471,6 +1482,12 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false) {
     }
     BaroMulti bm;
     fill_multi(bm, 0, NSW);
+    if (in_place)
+      for (int q = 0; q < 5; q++) bm.own_src[q] = own->src[q];
+    if (own) {
+      bm.layers = 1;
+      if (layers_done) *layers_done = true;
+    }
     dim3 gm((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX, (bb.jhi - bb.jlo + BW_TY - 1) / BW_TY);
     hipLaunchKernelGGL(kern, gm, dim3(BW_NT), lds, m->stream, g, bm, dtau);
     LAUNCHCHK();

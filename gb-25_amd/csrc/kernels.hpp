@@ -1160,6 +1160,11 @@ struct BaroMulti {
   int fold;
   int out_halo;   // widened slab: the last launch writes eta, U, V of this many x halo columns too (nothing is exchanged after it)
   int out_js, out_jn;   // ... of the rows [out_js, out_jn): [0, Ny), with the halo rows of the open sides of a rank of a 2-D decomposition
+  // k_barotropic_whole only: the own columns [0, Nx) of eta, U, V, G.U, G.V are read from these arrays of the canonical layout
+  // instead of the work arrays (no interior-copy launch; null: the work arrays hold everything), and the y layers next to the
+  // walls of the new eta, U, V are written with them (no fill launch after the sub-cycle)
+  const real* own_src[5];
+  int layers;
 };
 // (3 waves per SIMD: at 1440x720 the launch has 540 blocks; with the 173 VGPRs the 7-substep variant took when left alone
 // only two blocks fit a CU, 512 on the chip, and the last 28 blocks were a second round that doubled the launch time)
@@ -1384,11 +1389,20 @@ __global__ __launch_bounds__(BW_NT) void k_barotropic_whole(Grid g, BaroMulti bm
     real le = real(0.), lu = real(0.), lv = real(0.), lgu = real(0.), lgv = real(0.);
     ghf[q] = ghc[q] = gH;
     if (exists) {
-      le = b.eta0[po[q]];
-      lu = b.U0[po[q]];
-      lv = b.V0[po[q]];
-      lgu = b.GU[po[q]];
-      lgv = b.GV[po[q]];
+      if (bm.own_src[0] != nullptr && ig >= 0 && ig < g.Nx) {   // (own column: straight from the canonical arrays)
+        const int oc = i2(g, ig, jg);
+        le = bm.own_src[0][oc];
+        lu = bm.own_src[1][oc];
+        lv = bm.own_src[2][oc];
+        lgu = bm.own_src[3][oc];
+        lgv = bm.own_src[4][oc];
+      } else {
+        le = b.eta0[po[q]];
+        lu = b.U0[po[q]];
+        lv = b.V0[po[q]];
+        lgu = b.GU[po[q]];
+        lgv = b.GV[po[q]];
+      }
       if (IMM) {
         ghf[q] = g.g * b.Hfc[po[q]];
         ghc[q] = g.g * b.Hcf[po[q]];
@@ -1459,6 +1473,18 @@ __global__ __launch_bounds__(BW_NT) void k_barotropic_whole(Grid g, BaroMulti bm
           bm.eb_out[oc] = ae[q];
           bm.ub_out[oc] = au[q];
           bm.vb_out[oc] = av[q];
+        }
+        if (bm.layers) {   // what the y fill of the new eta, U, V would write next to the walls (fill_y_body)
+          if (jg == g.jws) {
+            bm.eta_out[oc - g.sx] = ae[q];
+            bm.U_out[oc - g.sx] = au[q];
+            bm.V_out[oc] = real(0.);
+          }
+          if (jg == g.jwn - 1) {
+            bm.eta_out[oc + g.sx] = ae[q];
+            bm.U_out[oc + g.sx] = au[q];
+            bm.V_out[oc + g.sx] = real(0.);
+          }
         }
       }
     }

@@ -298,8 +298,9 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     std::vector<Piece> ps;
     int nc = 0;
     group_pieces(m, ahead ? 3 : 1, ps, &nc);
+    const bool two_halves = g.cv.north_fold || m->Ry > 1;   // (more rows of the work arrays travel between the copy and the substeps)
+    InteriorCopies C{};
     if (!second_half) {
-      InteriorCopies C{};
       int rmax = 0;
       for (auto& p : ps) {
         const int q = C.n++;
@@ -307,26 +308,29 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
         C.src[q] = p.src; C.ssx[q] = p.src_sx; C.sxo[q] = p.src_xo; C.rows[q] = (int)p.rows;
         rmax = std::max(rmax, (int)p.rows);
       }
-      hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, rmax, C.n), dim3(256), 0, m->stream, C,
-                         g.Nx);
+      // (a plain slab hands the copy to the sub-cycle: its one-launch kernel reads the own columns where they are)
+      if (two_halves)
+        hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, rmax, C.n), dim3(256), 0, m->stream, C, g.Nx);
     }
     LAUNCHCHK();
-    if ((g.cv.north_fold || m->Ry > 1) && !second_half) return GB25_OK;   // (more rows of the work arrays travel next)
+    if (two_halves && !second_half) return GB25_OK;
+    const InteriorCopies* own = two_halves ? nullptr : &C;
+    bool layers_done = false;
     if (ahead) {
-      if ((s = barotropic_impl(m, m->ahead_uv_dt, true))) return s;
+      if ((s = barotropic_impl(m, m->ahead_uv_dt, true, own, &layers_done))) return s;
       Halo2 h2{};
       for (int q = 0; q < 3; q++) { h2.p[q] = m->ahead_eta[q].d; h2.is_v[q] = q == 2; }
       h2.n = 3;
       // y layer, x halo columns included: the widened sub-cycle computed those like the neighbour did (no group 4)
-      if ((s = fill_halos_impl(m, false, true, 2, 3, nullptr, true, &h2))) return s;
+      if (!layers_done && (s = fill_halos_impl(m, false, true, 2, 3, nullptr, true, &h2))) return s;
       m->ahead_baro_valid = true;
       return GB25_OK;
     }
-    if ((s = barotropic_impl(m, (real)dt))) return s;
+    if ((s = barotropic_impl(m, (real)dt, false, own, &layers_done))) return s;
     m->time += dt;
     m->iteration += 1;
     // y layer of the new eta, U, V, x halo columns included (computed by the widened sub-cycle: no group 2)
-    return fill_halos_impl(m, false, true, 2);
+    return layers_done ? GB25_OK : fill_halos_impl(m, false, true, 2);
   } else if (stage == 2) {
     // Everything that needs nothing from the neighbours runs while the exchanges are in flight: the barotropic
     // corrector on the slab's own columns and, when the tendency kernels are split (a12), the y/z layers and w of the
