@@ -13,9 +13,14 @@ ap.add_argument("--size", type=int, nargs=2, default=[720, 48], metavar=("Ny", "
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--dt", type=float, default=240.0)
 ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--lib", default=None, help="another build of libgb25hip.so (A/B on the same box)")
 ap.add_argument("--grid-type", type=int, default=0, help="gb25_grid_type: 0 lat-lon, 1 lat-lon + islands, 3 tripolar, 4 tripolar + islands (the rank is then its own fold partner too)")
 a = ap.parse_args()
 import numpy as np
+if a.lib:
+    os.environ["GB25_LIB"] = "1"           # (no rebuild check: the file is what it is)
+    import gb25_amd.binding as _bind
+    _bind.LIB_PATHS["Float32"] = os.path.abspath(a.lib)
 import gb25_amd as gb
 from gb25_amd.distributed import SlabModel
 # (options go in at creation: some are read when the exchange context is built)
