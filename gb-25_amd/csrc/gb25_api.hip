@@ -167,6 +167,7 @@ struct gb25_model {
   // v in memory lack them (only between the steps of one composite call: gb25_loop applies them before it returns)
   Field corr[2];
   bool uv_lazy = false;
+  bool step_lazy = false;            // slab: this step keeps the corrector inside its consumers (decided in stage 0)
   int lazy_corrector = 1;            // option LAZY_CORRECTOR
   // ... and with it w ON THE FLY (option W_ON_THE_FLY): in those steps the tendency kernels carry w up their chunks of levels
   // from the divergence of the transports they hold; no k_compute_w launch, no w traffic.  wbase: w at the first level of every
@@ -1058,7 +1059,8 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
                          (real)m->bottom_drag, i_first, n);
     }
     const LazyCorr lz{m->corr[0].d, m->corr[1].d, m->wbase, m->g.sx * m->g.sy_v};
-    if (m->uv_lazy && !(ahead && nx.fold && part == 0))
+    // (single domain: the kernel also writes the halo images of the next u, v; a slab's come with the next bundle)
+    if (m->uv_lazy && !(ahead && (m->slab || (nx.fold && part == 0))))
       return fail(m, GB25_ERR_STATE, "internal: uncorrected velocities in a step whose momentum kernel cannot correct them");
     const bool drag = m->bottom_drag != 0;
     auto k5 = drag ? (g.cv.on ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, true, false, true> : k_momentum_tendencies_v5<MW, TYm, false, true, true, false, true>)
@@ -1143,7 +1145,7 @@ gb25_status tracers_impl(gb25_model* m) {
     }
     const bool fold = ahead && producers_fold(m);
     const LazyCorr lz{m->corr[0].d, m->corr[1].d, m->wbase, m->g.sx * m->g.sy_v};
-    if (m->uv_lazy && !(ahead && fold))
+    if (m->uv_lazy && !(ahead && (fold || m->slab)))
       return fail(m, GB25_ERR_STATE, "internal: uncorrected velocities in a step whose tracer kernel cannot correct them");
     constexpr int TWL = sizeof(real) == 8 ? 3 : 6;   // (the headline instance: held to 80 VGPRs, six waves per SIMD)
     constexpr int TW7 = sizeof(real) == 8 ? 2 : 5;   // (the order-7 windows: 9 register pairs per direction; 90-96 VGPRs without a spill)
@@ -1153,6 +1155,8 @@ gb25_status tracers_impl(gb25_model* m) {
                                      : (ahead ? k_tracer_tendencies_v5<TW7, true, false, false, false, false, 7> : k_tracer_tendencies_v5<TW7, false, false, false, false, false, 7>))
                 : (m->uv_lazy && ahead && fold && m->w_fly_now) ? k_tracer_tendencies_v5<TWL, true, false, true, false, true, 5, true>
                 : (m->uv_lazy && ahead && fold) ? k_tracer_tendencies_v5<TWL, true, false, true, false, true>
+                : (m->uv_lazy && ahead && m->w_fly_now) ? k_tracer_tendencies_v5<TWL, true, false, false, false, true, 5, true>   // (slab)
+                : (m->uv_lazy && ahead) ? k_tracer_tendencies_v5<TWL, true, false, false, false, true>
                 : g.cv.on ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false, true>)
                                  : k_tracer_tendencies_v5<TW, false, true, false, true>)
                 : m->immersed ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false>)
@@ -1803,6 +1807,14 @@ inline bool lazy_corrector_ok(const gb25_model* m) {
          m->ab2_ahead == 1 && !m->ptr_exposed && m->pressure_bits == 64;
 }
 
+// ... and a slab of an x decomposition: the same kernels without the halo images (its x halos come with the bundles, and with
+// them the neighbours' column integrals: du, dv of the halo columns are computed locally)
+inline bool slab_lazy_ok(const gb25_model* m) {
+  return m->slab && m->Ry == 1 && m->lazy_corrector && !m->coupled && m->bottom_drag == 0 && m->tracer_order == 5 && m->two_streams &&
+         !m->immersed && !m->g.cv.on && m->kernel_gen >= 2 && m->ab2_ahead == 1 && !m->ptr_exposed && m->pressure_bits == 64 &&
+         m->nu == 0 && m->kappa == 0 && !m->catke;
+}
+
 // One time step on a single slab.  Two HIP streams: the tracer branch (AB2 of T,S -> their halos -> hydrostatic
 // pressure: HBM- then fp64-bound) is independent of the velocity branch (AB2 of u,v -> split-explicit sub-cycle,
 // which is latency-bound -> halos -> corrector -> halos -> w) until the tendencies need both, so it runs on a
@@ -1892,7 +1904,8 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     dim3 b(64, 4);
     Timed t(m, GB25_K_CORRECTOR);
     hipLaunchKernelGGL(k_corrector_2d, grid2(g.Nx, g.Ny + 1, b), b, 0, main, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
-                       m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d);
+                       m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d,
+                       0, g.Nx, INT_MAX, 0);
     LAUNCHCHK();
     m->uv_lazy = true;
     m->colsum_valid = false;
@@ -3002,6 +3015,9 @@ gb25_status gb25_loop(gb25_model* m, int32_t n) {
     GroupOps ops(*m->group);
     for (int it = 0; it < n; it++)
       if (gb25_status s = sequence_time_step(ops, 0, m->group->lookahead_in_flight)) return s;
+    // (steps that kept the corrector inside its consumers: memory holds the corrected velocities when the call returns)
+    for (gb25_model* q : m->group->slabs)
+      if (gb25_status s = materialize_uv(q)) return fail(m, s, "%s", q->err.c_str());
     return GB25_OK;
   }
   for (int it = 0; it < n; it++)

@@ -1747,21 +1747,28 @@ __global__ __launch_bounds__(256) void k_corrector_cells(Grid g, real* __restric
 // u, v in a step -- w, the momentum tendencies (which also produce the next u, v), the tracer tendencies -- add it as they
 // load.  Memory then holds the uncorrected velocities until the composite call returns (k_apply_correction).
 // Same operands, same additions: the same bits as the sweep.
+// A slab of a decomposition (x_periodic = 0) runs it over its own columns first and, once the bundle has brought the
+// neighbours' column integrals, over its x halo columns [i0, i0 + ni) with a gap of `skip` columns from `skip_from` on; no
+// periodic images there.
 __global__ __launch_bounds__(256) void k_corrector_2d(Grid g, const real* __restrict__ U, const real* __restrict__ V,
                                                       const real* __restrict__ Usum, const real* __restrict__ Vsum,
                                                       real* __restrict__ Ub, real* __restrict__ Vb, real* __restrict__ du,
-                                                      real* __restrict__ dv) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j > g.Ny) return;
+                                                      real* __restrict__ dv, int i0, int ni, int skip_from, int skip) {
+  const int ix = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (ix >= ni || j > g.Ny) return;
+  int i = i0 + ix;
+  if (i >= skip_from) i += skip;
   const int o2 = i2(g, i, j);
-  const bool xw = i < g.H, xe = i >= g.Nx - g.H;
+  const bool xw = g.x_periodic && i < g.H, xe = g.x_periodic && i >= g.Nx - g.H;
   if (j == g.Ny) {   // the northern wall face of v
     store_x_images(g, dv, o2, real(0.), xw, xe);
     return;
   }
   const real su = Usum[o2], sv = Vsum[o2];
-  Ub[o2] = su;
-  Vb[o2] = sv;
+  if (i >= 0 && i < g.Nx) {
+    Ub[o2] = su;
+    Vb[o2] = sv;
+  }
   const real a = (U[o2] - su) * g.rLz, b = j == 0 ? real(0.) : (V[o2] - sv) * g.rLz;
   store_x_images(g, du, o2, a, xw, xe);
   store_x_images(g, dv, o2, b, xw, xe);

@@ -257,6 +257,12 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     const bool uv_adopted = m->ahead_uv_valid && (real)dt == m->ahead_uv_dt && chi == m->ahead_uv_chi;
     m->baro_adopted = uv_adopted && m->ahead_baro_valid;
     m->ahead_baro_valid = false;
+    // The corrector inside its consumers (as on a single domain, time_step_impl): when everything this step needs was made
+    // ahead of time, no sweep over u and v -- 2-D kernels leave du, dv (own columns in stage 2, halo columns in stage 3 from the
+    // column integrals the bundle carries) and the kernels that read u, v add them.  Memory holds the uncorrected velocities
+    // until the composite call returns (gb25_loop).
+    m->step_lazy = uv_adopted && m->baro_adopted && slab_lazy_ok(m);
+    if (!m->step_lazy && (s = materialize_uv(m))) return s;   // (the sweeps below expect corrected velocities)
     if ((s = ab2_local_impl(m, (real)dt, chi))) return s;
     if (m->catke) catke_surface_flux_impl(m);   // J^b of the new T, S: its halo columns travel with group 0
     if (m->baro_adopted) {
@@ -335,9 +341,24 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     // Everything that needs nothing from the neighbours runs while the exchanges are in flight: the barotropic
     // corrector on the slab's own columns and, when the tendency kernels are split (a12), the y/z layers and w of the
     // own columns and the momentum tendencies of the interior tile columns.
-    if ((s = corrector_impl(m, true, 1))) return s;
+    if (m->step_lazy) {
+      if (!m->colsum_valid) return fail(m, GB25_ERR_STATE, "internal: a lazy step without the column integrals of u, v");
+      dim3 b(64, 4);
+      Timed t(m, GB25_K_CORRECTOR);
+      hipLaunchKernelGGL(k_corrector_2d, grid2(g.Nx, g.Ny + 1, b), b, 0, m->stream, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
+                         m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d,
+                         0, g.Nx, INT_MAX, 0);
+      LAUNCHCHK();
+      m->uv_lazy = true;
+      m->colsum_valid = false;
+      for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);   // cache_previous_tendencies!
+      m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+    } else if ((s = corrector_impl(m, true, 1))) {
+      return s;
+    }
     if (!split) return GB25_OK;
-    if ((s = fill_halos_impl(m, false, false, 1, 1))) return s;   // y/z layers of the corrected u, v, own columns
+    // y/z layers of the corrected u, v, own columns (lazy: the layers of the uncorrected ones are in place since stage 0)
+    if (!m->step_lazy && (s = fill_halos_impl(m, false, false, 1, 1))) return s;
     if ((s = compute_w_impl(m, 1))) return s;
     HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));       // the own columns' pressure differences (side stream)
     return momentum_impl(m, 1);
@@ -369,10 +390,21 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
         // interior pass of stage 0 -- beside the corrector, the fills and w of the edge strips instead of after them
         if ((s = pressure_strips())) return s;
       }
-      if (m->Ry == 1 && (s = corrector_impl(m, true, 2))) return s;   // (2-D decomposition: done in stage 32)
+      if (m->step_lazy) {
+        // du, dv of the x halo columns: the neighbours' column integrals came with the bundle, the new U, V of those columns
+        // from the widened sub-cycle; their y/z layers of u, v arrived filled -- nothing else to do
+        if (!m->halo_colsum_valid) return fail(m, GB25_ERR_STATE, "internal: a lazy step without the neighbours' column integrals");
+        dim3 b(16, 16);
+        hipLaunchKernelGGL(k_corrector_2d, grid2(2 * g.H, g.Ny + 1, b), b, 0, m->stream, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
+                           m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d,
+                           -g.H, 2 * g.H, 0, g.Nx);
+        LAUNCHCHK();
+      } else if (m->Ry == 1 && (s = corrector_impl(m, true, 2))) {   // (2-D decomposition: done in stage 32)
+        return s;
+      }
       // (with the early strips T and S are left alone here: their layers are in place, own columns since stage 0)
       if (p_early && !strips_first) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));   // (the interior pass reads T, S)
-      if ((s = fill_halos_impl(m, false, true, 3, strips_first ? 1 : 3))) return s;
+      if (!(m->step_lazy && strips_first) && (s = fill_halos_impl(m, false, true, 3, strips_first ? 1 : 3))) return s;
       if (m->catke && (s = fill_halos_impl(m, false, true, 1, 4))) return s;
       if (stage == 30) return GB25_OK;
     }
