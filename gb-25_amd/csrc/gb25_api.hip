@@ -1815,6 +1815,10 @@ inline bool slab_lazy_ok(const gb25_model* m) {
          m->nu == 0 && m->kappa == 0 && !m->catke;
 }
 
+inline bool slab_wfly_ok(const gb25_model* m) {   // (the chunkings of the two tendency kernels must be the one the chunk sums were made with)
+  return slab_lazy_ok(m) && m->w_fly && std::max(1, m->g.Nz / m->trc_chunk_levels) == mom_kchunks(m);
+}
+
 // One time step on a single slab.  Two HIP streams: the tracer branch (AB2 of T,S -> their halos -> hydrostatic
 // pressure: HBM- then fp64-bound) is independent of the velocity branch (AB2 of u,v -> split-explicit sub-cycle,
 // which is latency-bound -> halos -> corrector -> halos -> w) until the tendencies need both, so it runs on a
@@ -1913,7 +1917,7 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     m->w_fly_now = m->w_fly && std::max(1, g.Nz / m->trc_chunk_levels) == mom_kchunks(m);
     if (m->w_fly_now) {
       hipLaunchKernelGGL(k_w_bases, grid2(g.Nx + 4, g.Ny + 4, b), b, 0, main, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
-                         LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0}, m->wbase);
+                         LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0}, m->wbase, -2, g.Nx + 4, INT_MAX, 0);
       LAUNCHCHK();
       m->w_stale = true;
     }

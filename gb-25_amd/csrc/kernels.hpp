@@ -1782,13 +1782,18 @@ __global__ __launch_bounds__(256) void k_corrector_2d(Grid g, const real* __rest
 // zero on and beyond the wall faces of v, zeros deeper -- as the fills leave them.
 // (w within a chunk then follows level by level inside the kernels: the association differs from k_compute_w's single
 // march up the column, results agree to round-off, not to the last bit.)
+// A slab of a decomposition (x_periodic = 0: no wrap, the halo columns of P and of du, dv are the neighbours', brought by the
+// bundle) runs it over its columns [0, Nx - 2] before the interior momentum pass overwrites P there, and over the columns next
+// to the x halos -- [i0, i0 + ni) with a gap of `skip` from `skip_from` on -- once the bundle has arrived.
 __global__ __launch_bounds__(256) void k_w_bases(Grid g, const real* __restrict__ P, int kchunks, int plane2, LazyCorr lz,
-                                                 real* __restrict__ wbase) {
-  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 2, j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 2;
-  if (i >= g.Nx + 2 || j >= g.Ny + 2) return;
+                                                 real* __restrict__ wbase, int i0, int ni, int skip_from, int skip) {
+  const int ix = blockIdx.x * blockDim.x + threadIdx.x, j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 2;
+  if (ix >= ni || j >= g.Ny + 2) return;
+  int i = i0 + ix;
+  if (i >= skip_from) i += skip;
   const long q = (long)kchunks * plane2;
   const int klen = (g.Nz + kchunks - 1) / kchunks;
-  auto wrap = [&](int ii) { return ii < 0 ? ii + g.Nx : (ii >= g.Nx ? ii - g.Nx : ii); };
+  auto wrap = [&](int ii) { return !g.x_periodic ? ii : (ii < 0 ? ii + g.Nx : (ii >= g.Nx ? ii - g.Nx : ii)); };
   const int o2 = i2(g, i, j);
   const bool urow = j >= -1 && j <= g.Ny;                       // rows whose u is not identically zero (interior + one layer)
   const int ju = min(max(j, 0), g.Ny - 1);

@@ -75,6 +75,15 @@ void group_pieces(gb25_model* m, int group, std::vector<Piece>& out, int* ncols)
       }
       // the column integrals of u, v (the corrector's): the receiver corrects its halo columns cell by cell with them
       for (int q = 0; q < 2; q++) out.push_back({m->colsum[q].d, m->colsum[q].d, sx, H, sx, H, (long)m->colsum[q].ny});
+      // ... and their sums over the momentum kernel's chunks of levels (w on the fly: the chunk bases of w next to the x halos)
+      if (slab_wfly_ok(m)) {
+        const int kch = mom_kchunks(m);
+        const long plane2 = (long)m->g.sx * m->g.sy_v;
+        for (int q = 2; q < 4; q++) {
+          real* P = m->uv_partials + (long)q * kch * plane2;
+          out.push_back({P, P, sx, H, sx, H, (long)kch * m->g.sy_v});
+        }
+      }
     } else {
       for (int q = 0; q < 3; q++) {
         Field& F = group == 2 ? m->f[GB25_ETA + q] : m->ahead_eta[q];
@@ -262,6 +271,8 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     // column integrals the bundle carries) and the kernels that read u, v add them.  Memory holds the uncorrected velocities
     // until the composite call returns (gb25_loop).
     m->step_lazy = uv_adopted && m->baro_adopted && slab_lazy_ok(m);
+    // ... and with it w on the fly: no k_compute_w launch, the tendency kernels carry w up their chunks of levels from 2-D bases
+    m->w_fly_now = m->step_lazy && slab_wfly_ok(m);
     if (!m->step_lazy && (s = materialize_uv(m))) return s;   // (the sweeps below expect corrected velocities)
     if ((s = ab2_local_impl(m, (real)dt, chi))) return s;
     if (m->catke) catke_surface_flux_impl(m);   // J^b of the new T, S: its halo columns travel with group 0
@@ -351,6 +362,14 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       LAUNCHCHK();
       m->uv_lazy = true;
       m->colsum_valid = false;
+      if (m->w_fly_now) {
+        // chunk bases of w on the columns [0, Nx - 2] (their u faces are own columns), before the interior momentum pass
+        // overwrites the chunk sums they are made from
+        hipLaunchKernelGGL(k_w_bases, grid2(g.Nx - 1, g.Ny + 4, b), b, 0, m->stream, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
+                           LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0}, m->wbase, 0, g.Nx - 1, INT_MAX, 0);
+        LAUNCHCHK();
+        m->w_stale = true;
+      }
       for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);   // cache_previous_tendencies!
       m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
     } else if ((s = corrector_impl(m, true, 1))) {
@@ -359,7 +378,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     if (!split) return GB25_OK;
     // y/z layers of the corrected u, v, own columns (lazy: the layers of the uncorrected ones are in place since stage 0)
     if (!m->step_lazy && (s = fill_halos_impl(m, false, false, 1, 1))) return s;
-    if ((s = compute_w_impl(m, 1))) return s;
+    if (!m->w_fly_now && (s = compute_w_impl(m, 1))) return s;
     HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));       // the own columns' pressure differences (side stream)
     return momentum_impl(m, 1);
   } else if (stage == 32) {
@@ -398,6 +417,9 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
         hipLaunchKernelGGL(k_corrector_2d, grid2(2 * g.H, g.Ny + 1, b), b, 0, m->stream, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
                            m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d,
                            -g.H, 2 * g.H, 0, g.Nx);
+        if (m->w_fly_now)   // the chunk bases of w on the columns -2, -1 and Nx - 1, Nx, Nx + 1 (the w tiles reach two columns out)
+          hipLaunchKernelGGL(k_w_bases, grid2(5, g.Ny + 4, b), b, 0, m->stream, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
+                             LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0}, m->wbase, -2, 5, 0, g.Nx - 1);
         LAUNCHCHK();
       } else if (m->Ry == 1 && (s = corrector_impl(m, true, 2))) {   // (2-D decomposition: done in stage 32)
         return s;
@@ -409,7 +431,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       if (stage == 30) return GB25_OK;
     }
     if (p_early && !strips_first && (s = pressure_strips())) return s;   // (beside w)
-    if ((s = compute_w_impl(m, split ? 2 : 0))) return s;
+    if (!m->w_fly_now && (s = compute_w_impl(m, split ? 2 : 0))) return s;
     if (p_early) {
       HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
     } else {

@@ -21,7 +21,7 @@ if __name__ == "__main__":
     grid_type = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     ranks_y = int(sys.argv[7]) if len(sys.argv) > 7 else 1     # Partition(world / ranks_y, ranks_y, 1)
     kw = dict(grid_type=grid_type) if grid_type else {}
-    m = SlabModel(Nx, Ny, Nz, dt=600.0, rank=rank, nranks=world, device=0, ranks_y=ranks_y, **kw)   # gloo => the host-callback transport
+    m = SlabModel(Nx, Ny, Nz, dt=600.0, rank=rank, nranks=world, device=0, ranks_y=ranks_y, options=dict(w_on_the_fly=0), **kw)   # gloo => the host-callback transport
     b = m.backend
     i0, j0 = b.rx * b.Nx_local, b.ry * b.Ny_local
     gb.set_baroclinic_instability(m)

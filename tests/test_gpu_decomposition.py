@@ -13,6 +13,10 @@ pytestmark = pytest.mark.gpu
 
 FIELDS = ["u", "v", "w", "T", "S", "eta", "U", "V", "eta_bar", "U_bar", "V_bar", "Gn.u", "Gn.v", "Gn.T", "Gn.S",
           "Gm.u", "Gm.v", "pHY"]
+# Bit-for-bit comparisons run the slabs with w from the stand-alone kernel, as the small single domains of these tests compute
+# it: w carried inside the tendency kernels (the default beside the corrector inside its consumers) is another association of
+# the vertical sum -- the same numbers to round-off, test_w_on_the_fly_on_slabs.
+EXACT = dict(w_on_the_fly=0)
 
 
 def _initial(Nx, Ny, Nz, single):
@@ -31,7 +35,7 @@ def test_slabs_reproduce_single_domain_bitwise(P, Nz):
     Nx, Ny, dt = 128, 48, 600.0
     single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt)
     init = _initial(Nx, Ny, Nz, single)
-    ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt)
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, options=EXACT)
     for n, a in init.items():
         ens.scatter(n, a)
     gb.first_time_step(single)
@@ -64,7 +68,7 @@ def test_slabs_fall_back_when_a_lookahead_is_not_adopted(float_type):
     dtype = np.float64 if float_type == "Float64" else np.float32
     single = gb.baroclinic_instability_model(gb.GPU(float_type=float_type), Nx, Ny, Nz, dt=dt)
     init = _initial(Nx, Ny, Nz, single)
-    ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, float_type=float_type)
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, float_type=float_type, options=EXACT)
     for n, a in init.items():
         ens.scatter(n, a.astype(dtype))
     gb.first_time_step(single)
@@ -102,7 +106,7 @@ def test_rccl_self_ring_equals_periodic_domain(split):
     single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt)
     init = _initial(Nx, Ny, Nz, single)
     ring = SlabModel(Nx, Ny, Nz, dt=dt, rank=0, nranks=1, slab_mode=1, transport="rccl",
-                     options=dict(split_tendencies=split))
+                     options=dict(EXACT, split_tendencies=split))
     for n, a in init.items():
         ring.backend.set_field(n, a, False)
     for m in (single, ring):
@@ -129,7 +133,7 @@ def test_split_tendencies_is_bitwise_neutral_on_ragged_slabs():
     slabs of 160 columns (2.5 tiles), 129 (the interior shrinks to one tile) and 66 (no interior at all)."""
     for Nx, P in ((480, 3), (258, 2), (132, 2)):
         Ny, Nz, dt = 40, 12, 600.0
-        ens = [LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, options=dict(split_tendencies=sp)) for sp in (0, 1)]
+        ens = [LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, options=dict(EXACT, split_tendencies=sp)) for sp in (0, 1)]
         single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt)
         init = _initial(Nx, Ny, Nz, single)
         for e in ens:
@@ -153,7 +157,7 @@ def test_state_dump_through_the_abi_and_offline_gather(tmp_path):
     Nx, Ny, Nz, P, dt = 128, 48, 8, 4, 600.0
     single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt)
     init = _initial(Nx, Ny, Nz, single)
-    ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt)
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, options=EXACT)
     for n, a in init.items():
         ens.scatter(n, a)
     gb.first_time_step(single)
@@ -172,3 +176,30 @@ def test_state_dump_through_the_abi_and_offline_gather(tmp_path):
     one = gb.load_all_fields(str(tmp_path / "single"))
     assert np.array_equal(one["T"], got["T"]) and one["iteration"] == 4
     ens.close()
+
+
+def test_w_on_the_fly_on_slabs():
+    """The default schedule of a slab in steady state: the corrector inside its consumers and w carried inside the tendency
+    kernels (no k_corrector sweep, no k_compute_w launch; the chunk bases of w next to the x halos from the chunk sums the bundle
+    carries).  Against the same slabs with w from the stand-alone kernel: the same numbers to round-off (another association of
+    the vertical sum), every field -- and the field w itself, recomputed when the call returns, from velocities that agree."""
+    Nx, Ny, Nz, P, dt = 384, 48, 36, 2, 600.0      # three chunks of levels, three tile columns per slab (interior + edges)
+    single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt)
+    init = _initial(Nx, Ny, Nz, single)
+    single.backend.close()
+    out = {}
+    for fly in (1, 0):
+        ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, options=dict(w_on_the_fly=fly))
+        for n, a in init.items():
+            ens.scatter(n, a)
+        ens.first_time_step()
+        ens.loop(12)
+        assert all(b.lookahead_state() == (True, True) for b in ens.backends)
+        out[fly] = {n: ens.gather(n).astype(np.float64) for n in FIELDS}
+        ens.close()
+    worst = {}
+    for n in FIELDS:
+        a, b = out[1][n], out[0][n]
+        worst[n] = float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
+    assert max(worst.values()) < 2e-5, worst
+    assert any(v > 0 for v in worst.values()), "w on the fly did not run on the slabs"   # (else the two runs are the same bits)

@@ -156,7 +156,7 @@ def test_slabs_at_the_benchmark_size_bitwise():
     single.backend.close()
     assert np.abs(ref["u"]).max() > 1e-2 and np.isfinite(ref["Gn.u"]).all()
     for P in (2, 4, 8):
-        ens = LocalSlabEnsemble(NX, NY, NZ, P, dt=240.0)
+        ens = LocalSlabEnsemble(NX, NY, NZ, P, dt=240.0, options=dict(w_on_the_fly=0))
         for n, a in (("u", u0), ("v", v0), ("T", T0), ("S", S0)):
             ens.scatter(n, a)
         ens.first_time_step()
