@@ -271,6 +271,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     // column integrals the bundle carries) and the kernels that read u, v add them.  Memory holds the uncorrected velocities
     // until the composite call returns (gb25_loop).
     m->step_lazy = uv_adopted && m->baro_adopted && slab_lazy_ok(m);
+    m->lazy_head_done = false;
     // ... and with it w on the fly: no k_compute_w launch, the tendency kernels carry w up their chunks of levels from 2-D bases
     m->w_fly_now = m->step_lazy && slab_wfly_ok(m);
     if (!m->step_lazy && (s = materialize_uv(m))) return s;   // (the sweeps below expect corrected velocities)
@@ -348,11 +349,15 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     m->iteration += 1;
     // y layer of the new eta, U, V, x halo columns included (computed by the widened sub-cycle: no group 2)
     return layers_done ? GB25_OK : fill_halos_impl(m, false, true, 2);
-  } else if (stage == 2) {
+  } else if (stage == 2 || stage == 20) {
     // Everything that needs nothing from the neighbours runs while the exchanges are in flight: the barotropic
     // corrector on the slab's own columns and, when the tendency kernels are split (a12), the y/z layers and w of the
     // own columns and the momentum tendencies of the interior tile columns.
-    if (m->step_lazy) {
+    // (stage 20: the head of a lazy step -- du, dv and the chunk bases of w -- ahead of the wait for the packed bundle)
+    if (stage == 2 && m->lazy_head_done) {
+      // (stage 20 did the corrector's part)
+    } else if (m->step_lazy) {
+      m->lazy_head_done = stage == 20;
       if (!m->colsum_valid) return fail(m, GB25_ERR_STATE, "internal: a lazy step without the column integrals of u, v");
       dim3 b(64, 4);
       Timed t(m, GB25_K_CORRECTOR);
@@ -375,7 +380,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     } else if ((s = corrector_impl(m, true, 1))) {
       return s;
     }
-    if (!split) return GB25_OK;
+    if (stage == 20 || !split) return GB25_OK;
     // y/z layers of the corrected u, v, own columns (lazy: the layers of the uncorrected ones are in place since stage 0)
     if (!m->step_lazy && (s = fill_halos_impl(m, false, false, 1, 1))) return s;
     if (!m->w_fly_now && (s = compute_w_impl(m, 1))) return s;
@@ -478,6 +483,7 @@ struct StepOps {
   virtual bool subcycle_adopted(int s) = 0;
   virtual bool coupled() { return false; }   // a prescribed atmosphere is set (data-free forcing)
   virtual bool folded() = 0;          // zipper fold: exchanges with the partner rank (buffer sets 3 and 4; groups 6 and 8)
+  virtual bool lazy() { return false; }     // this step keeps the corrector inside its consumers (known after stage 0)
   virtual bool mesh_y() { return false; }   // 2-D decomposition: y halos from the southern / northern neighbour (groups 10 - 14)
   virtual gb25_status record(int slot, int on) = 0;
   virtual gb25_status wait(int slot, int waiter) = 0;
@@ -538,9 +544,18 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
       SEQ(o.stage(s, 1, euler, false));
     }
   }
-  SEQ(o.wait(1, false));       // the corrector rewrites the columns the bundle was packed from
-  if (in_flight && adopted)    // ... and reads the adopted sub-cycle: the look-ahead chain has finished (event 4 sits
-    SEQ(o.wait(4, false));     // behind the chain, ahead of this step's bundle on the same stream)
+  if (o.lazy()) {
+    // the corrector inside its consumers writes nothing the bundle is packed from: du, dv and the chunk bases of w of the own
+    // columns (stage 20) need the adopted sub-cycle only; the interior momentum pass, which overwrites chunk sums the bundle
+    // carries, waits for the pack
+    if (in_flight && adopted) SEQ(o.wait(4, false));
+    EACH(o.stage(s, 20, euler, false));
+    SEQ(o.wait(1, false));
+  } else {
+    SEQ(o.wait(1, false));       // the corrector rewrites the columns the bundle was packed from
+    if (in_flight && adopted)    // ... and reads the adopted sub-cycle: the look-ahead chain has finished (event 4 sits
+      SEQ(o.wait(4, false));     // behind the chain, ahead of this step's bundle on the same stream)
+  }
   EACH(o.stage(s, 2, euler, false));   // own columns + interior tendencies, while the exchanges are in flight
   SEQ(o.record(3, true));
   SEQ(o.wait(3, false));       // the halo columns have arrived
@@ -697,10 +712,11 @@ struct TraceOps : StepOps {
   int nslabs;
   bool adopted, ready;
   std::string log;
-  bool fold = false, is_coupled = false, mesh = false;
+  bool fold = false, is_coupled = false, mesh = false, is_lazy = false;
   TraceOps(int n_, bool a, bool r) : nslabs(n_), adopted(a), ready(r) {}
   bool folded() override { return fold; }
   bool mesh_y() override { return mesh; }
+  bool lazy() override { return is_lazy; }
   bool coupled() override { return is_coupled; }
   void add(const char* fmt, ...) {
     char buf[96];
@@ -958,6 +974,11 @@ struct GroupOps : StepOps {
     return false;
   }
   bool mesh_y() override { return G.slabs[0]->Ry > 1; }
+  bool lazy() override {
+    for (gb25_model* m : G.slabs)
+      if (!m->step_lazy) return false;
+    return true;
+  }
   bool coupled() override { return G.slabs[0]->coupled; }
   gb25_status pack(int s, int group, int c) override {
     OnStream on(G.slabs[s], st(c));

@@ -317,3 +317,16 @@ def test_time_step_sequencing_of_a_2d_decomposition():
     first = _raw_sequence(4, 16 | 1)
     names = [(e[0], e[1]) for e in first if e[0] in ("exchange",)]
     assert names[:4] == [("exchange", 0), ("exchange", 2), ("exchange", 10), ("exchange", 12)]
+
+
+def test_time_step_sequencing_of_a_lazy_step():
+    """A steady-state slab step keeps the barotropic corrector inside its consumers: du, dv and the chunk bases of w of the own
+    columns (stage 20) write nothing the bundle is packed from, so they run as soon as the adopted sub-cycle is complete -- ahead
+    of the wait for the packed bundle (event 1), which the interior momentum pass (stage 2) still honours."""
+    log = _raw_sequence(3, 8 | 32, adopted=1, ready=1)
+    idx = lambda *e: log.index(e)
+    assert idx("wait", 4, "main") < idx("stage", 20, "slab", 0, "euler", 0, "main") < idx("stage", 20, "slab", 2, "euler", 0, "main") \
+        < idx("wait", 1, "main") < idx("stage", 2, "slab", 0, "euler", 0, "main")
+    plain = _raw_sequence(3, 8, adopted=1, ready=1)
+    assert not any(e[:2] == ("stage", 20) for e in plain)
+    assert plain.index(("wait", 1, "main")) < plain.index(("wait", 4, "main"))
