@@ -167,6 +167,7 @@ struct gb25_model {
   // v in memory lack them (only between the steps of one composite call: gb25_loop applies them before it returns)
   Field corr[2];
   bool uv_lazy = false;
+  bool lazy_head_done = false;       // ... and its du, dv, chunk bases of w are made (stage 20)
   bool step_lazy = false;            // slab: this step keeps the corrector inside its consumers (decided in stage 0)
   int lazy_corrector = 1;            // option LAZY_CORRECTOR
   // ... and with it w ON THE FLY (option W_ON_THE_FLY): in those steps the tendency kernels carry w up their chunks of levels
@@ -3045,6 +3046,7 @@ int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int3
   TraceOps ops(nslabs, adopted != 0, ready != 0);
   if (first & 2) ops.fold = true;   // (bit 1 of `first`: a folded grid)
   if (first & 4) ops.is_coupled = true;   // (bit 2: a coupled model -- data-free forcing)
+  if (first & 32) ops.is_lazy = true;     // (bit 5: a step that keeps the corrector inside its consumers)
   if (first & 16) ops.mesh = true;        // (bit 4: a 2-D decomposition -- y halos from the southern / northern neighbour)
   bool in_flight = (first & 8) != 0;      // (bit 3: the previous step left the look-ahead chain in flight)
   first &= 1;

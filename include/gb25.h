@@ -387,7 +387,8 @@ gb25_status gb25_comm_finalize(gb25_model *m);
 gb25_status gb25_lookahead_state(const gb25_model *m, int32_t *velocities_ready, int32_t *subcycle_adopted);
 /* The order of operations of one time step (bit 0 of `first`: of first_time_step!; bit 1: on a folded grid; bit 2: of a
  * coupled model; bit 3: with the previous step's look-ahead chain still in flight) of `nslabs` slabs as text, without
- * touching a GPU; bit 4: of a 2-D decomposition (tests of the sequencing on CPU-only machines).  Returns the bytes needed, incl. the terminator. */
+ * touching a GPU; bit 4: of a 2-D decomposition; bit 5: of a step that keeps the corrector inside its consumers (tests of the
+ * sequencing on CPU-only machines).  Returns the bytes needed, incl. the terminator. */
 int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int32_t ready, char *out, int64_t cap);
 
 /* ---- state dump: save_model_state(dir, model, arch; label) (src/sharded_io.jl:70-96,122-138; called after each loop
