@@ -123,3 +123,25 @@ def test_config4_physics_on_a_mesh():
         rows = [np.concatenate([ens.backends[ry * Rx + rx].top_flux(n) for rx in range(Rx)], axis=0) for ry in range(Ry)]
         assert np.array_equal(np.concatenate(rows, axis=1), a), n
     ens.close()
+
+
+def test_state_dump_of_a_mesh_and_offline_gather(tmp_path):
+    """save_model_state / load_all_fields (src/sharded_io.jl:122-138,198-213) on a 2 x 2 mesh: every rank writes its window --
+    columns AND rows -- with its slice of the global array; the offline gather is the single domain."""
+    Nx, Ny, Nz, dt = 128, 96, 8, 600.0
+    single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt)
+    init = _initial(Nx, Ny, Nz, single, Ny + 1)
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, 4, dt=dt, ranks_y=2)
+    for n, a in init.items():
+        ens.scatter(n, a)
+    gb.first_time_step(single)
+    ens.first_time_step()
+    gb.loop(single, 2)
+    ens.loop(2)
+    for b in ens.backends:
+        b.save_state(str(tmp_path), "mesh")
+    got = gb.load_all_fields(str(tmp_path / "mesh"))
+    assert got["iteration"] == 3
+    for n in ("u", "v", "w", "eta", "T", "S"):
+        ref = single.backend.get_field(n, False)
+        assert got[n].shape == ref.shape and np.array_equal(got[n], ref), n
