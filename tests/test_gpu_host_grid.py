@@ -97,15 +97,17 @@ def test_a_different_host_grid_steps_like_the_oracle(grid_type, float_type):
     assert np.abs(r.velocities.u.interior).max() > 1e-3 and np.isfinite(r.backend.get_field("eta", False)).all()
 
 
-@pytest.mark.parametrize("grid_type,P", [("tripolar", 2), ("tripolar", 4), ("lat_lon_as_curvilinear", 3)])
-def test_slabs_take_their_columns_from_the_hosts_global_arrays(grid_type, P):
+@pytest.mark.parametrize("grid_type,P,Ry,Ny", [("tripolar", 2, 1, 44), ("tripolar", 4, 1, 44), ("lat_lon_as_curvilinear", 3, 1, 44),
+                                               ("tripolar", 4, 2, 88), ("lat_lon_as_curvilinear", 4, 2, 88)])
+def test_slabs_take_their_columns_from_the_hosts_global_arrays(grid_type, P, Ry, Ny):
+    """... and the ranks of a 2-D mesh (Ry = 2) their columns AND rows: every rank is handed the same GLOBAL arrays."""
     from gb25_amd.distributed import LocalSlabEnsemble
     from helpers import make_oracle
-    Nx, Ny, Nz, dt = 192, 44, 10, 300.0
+    Nx, Nz, dt = 192, 10, 300.0
     v = make_oracle(Nx, Ny, Nz, dt, grid_type=grid_type)
     metrics, zf, zb = another_grid(v, Nx, Ny, Nz, grid_type == "tripolar")
     single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt, grid_type=grid_type)
-    ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, grid_type={"tripolar": 3, "lat_lon_as_curvilinear": 2}[grid_type])
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, P, dt=dt, ranks_y=Ry, grid_type={"tripolar": 3, "lat_lon_as_curvilinear": 2}[grid_type])
     for b in [single.backend] + list(ens.backends):
         b.set_curvilinear_grid(metrics)
         b.set_vertical_faces(zf)
@@ -121,4 +123,4 @@ def test_slabs_take_their_columns_from_the_hosts_global_arrays(grid_type, P):
     ens.loop(4)
     for n in ALL:
         a, b = ens.gather(n), single.backend.get_field(n, False)
-        assert np.array_equal(a, b), (grid_type, P, n, float(np.abs(a - b).max()))
+        assert a.shape == b.shape and np.array_equal(a, b), (grid_type, P, Ry, n, float(np.abs(a - b).max()))

@@ -145,3 +145,28 @@ def test_state_dump_of_a_mesh_and_offline_gather(tmp_path):
     for n in ("u", "v", "w", "eta", "T", "S"):
         ref = single.backend.get_field(n, False)
         assert got[n].shape == ref.shape and np.array_equal(got[n], ref), n
+
+
+def test_mesh_in_float64_with_implicit_vertical_diffusion():
+    """The Float64 library and the closure the reference keeps beside `closure = nothing`
+    (VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(), kappa, nu), src/baroclinic_instability_model.jl:31) on a
+    2 x 2 mesh: the implicit solves are column-local, the wall face of v is where the GLOBAL grid has it."""
+    Nx, Ny, Nz, dt = 128, 96, 12, 600.0
+    single = gb.baroclinic_instability_model(gb.GPU(float_type="Float64"), Nx, Ny, Nz, dt=dt)
+    gb.set_baroclinic_instability(single)
+    u0 = 1e-2 * counter_rng((Nx, Ny, Nz), 42, 1)
+    v0 = 1e-2 * counter_rng((Nx, Ny + 1, Nz), 42, 2)
+    single.set(u=u0.astype(np.float32).astype(np.float64), v=v0.astype(np.float32).astype(np.float64))
+    init = {n: single.backend.get_field(n, False) for n in ("u", "v", "T", "S", "eta")}
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, 4, dt=dt, ranks_y=2, float_type="Float64")
+    for b in [single.backend] + ens.backends:
+        b.set_vertical_diffusivity(1e-2, 1e-3)
+    for n, a in init.items():
+        ens.scatter(n, a)
+    gb.first_time_step(single)
+    ens.first_time_step()
+    gb.loop(single, 5)
+    ens.loop(5)
+    for n in FIELDS:
+        a, b = ens.gather(n), single.backend.get_field(n, False)
+        assert a.dtype == np.float64 and a.shape == b.shape and np.array_equal(a, b), (n, float(np.abs(a - b).max()))
