@@ -1469,8 +1469,11 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false, const In
   };
   // a narrow slab: fewer tiles than the chip has CUs -- the whole sub-cycle in ONE launch (k_barotropic_whole)
   constexpr int NSW = 21;   // (the substeps of SplitExplicitFreeSurface(substeps = 30); other counts take the blocked launches)
-  const int wtiles = ((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX) * ((bb.jhi - bb.jlo + BW_TY - 1) / BW_TY);
-  // (Float32: 125 KB of LDS; the Float64 build would need 250 KB)
+  const int wcols = (bb.ihi - bb.ilo + BT_TX - 1) / BT_TX, wrows = bb.jhi - bb.jlo;
+  // rows per tile: 17 (125 KB of LDS) or, when only that brings the tile count under the number of CUs, 24 (140 KB)
+  const int wty = wcols * ((wrows + 16) / 17) <= m->n_cu ? 17 : 24;
+  const int wtiles = wcols * ((wrows + wty - 1) / wty);
+  // (Float32: the Float64 build would need twice the LDS)
   const bool whole = blocked && !g.cv.on && m->slab && m->baro_whole && m->Ns == NSW && wtiles <= m->n_cu && sizeof(real) == 4;
   // (the one-launch kernel reads the own columns in place only when it writes elsewhere -- the look-ahead's partner buffers;
   // inside its own step the results go into the very arrays other blocks are still loading their rings from)
@@ -1478,12 +1481,14 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false, const In
   if (own && !in_place)
     hipLaunchKernelGGL(k_copy_interior_columns, dim3((g.Nx + 255) / 256, g.sy_v, own->n), dim3(256), 0, m->stream, *own, g.Nx);
   if (whole) {
-    auto kern = imm ? k_barotropic_whole<NSW, true> : k_barotropic_whole<NSW, false>;
-    const size_t lds = (size_t)5 * (BT_TX + 2 * NSW) * (BW_TY + 2 * NSW) * sizeof(real);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[imm ? 1 : 0]) {
+    void (*kern)(Grid, BaroMulti, real) =
+        wty == 17 ? (imm ? k_barotropic_whole<NSW, true, 17> : k_barotropic_whole<NSW, false, 17>)
+                  : (imm ? k_barotropic_whole<NSW, true, 24> : k_barotropic_whole<NSW, false, 24>);
+    const size_t lds = (size_t)5 * (BT_TX + 2 * NSW) * (wty + 2 * NSW) * sizeof(real);
+    static bool attr_set[2][2] = {{false, false}, {false, false}};
+    if (!attr_set[imm ? 1 : 0][wty == 17 ? 0 : 1]) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set[imm ? 1 : 0] = true;
+      attr_set[imm ? 1 : 0][wty == 17 ? 0 : 1] = true;
     }
     BaroMulti bm;
     fill_multi(bm, 0, NSW);
@@ -1493,7 +1498,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false, const In
       bm.layers = 1;
       if (layers_done) *layers_done = true;
     }
-    dim3 gm((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX, (bb.jhi - bb.jlo + BW_TY - 1) / BW_TY);
+    dim3 gm(wcols, (wrows + wty - 1) / wty);
     hipLaunchKernelGGL(kern, gm, dim3(BW_NT), lds, m->stream, g, bm, dtau);
     LAUNCHCHK();
     return GB25_OK;

@@ -1344,8 +1344,9 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
 // barriers; substep s only touches the points the tile's final state still depends on (ring distance <= NS - 1 - s: half the
 // point updates of the full ring).  Per-point arithmetic, summation order and outputs are those of k_barotropic_multi's
 // first-and-last launch.  Dynamic LDS: 5 (64 + 2 NS) (BW_TY + 2 NS) reals.
-constexpr int BW_NT = 1024, BW_TY = 17;
-template <int NS, bool IMM>
+// (BW_TY rows per tile: 17, or 24 -- 140 KB of LDS -- when that brings a wider slab's tile count under the number of CUs)
+constexpr int BW_NT = 1024;
+template <int NS, bool IMM, int BW_TY = 17>
 __global__ __launch_bounds__(BW_NT) void k_barotropic_whole(Grid g, BaroMulti bm, real dtau) {
   constexpr int RX = BT_TX + 2 * NS, RY = BW_TY + 2 * NS, NP = RX * RY, PPT = (NP + BW_NT - 1) / BW_NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char bw_lds[];
