@@ -35,7 +35,7 @@ KERNEL_IDS = {"fill_halos": 0, "compute_w": 1, "compute_p": 2, "gu": 3, "gv": 4,
 # every symbol include/gb25.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "gb25_default_config", "gb25_create", "gb25_destroy", "gb25_last_error_string", "gb25_version",
-    "gb25_real_bytes",
+    "gb25_real_bytes", "gb25_config_bytes", "gb25_catke_parameters_bytes",
     "gb25_set_stream", "gb25_use_own_stream", "gb25_synchronize", "gb25_field_dims", "gb25_set_field", "gb25_get_field",
     "gb25_field_device_ptr", "gb25_get_metric", "gb25_get_metric2", "gb25_get_substepping", "gb25_set_vertical_diffusivity",
     "gb25_get_vertical_diffusivity", "gb25_set_closure_catke", "gb25_set_prescribed_atmosphere",
@@ -196,6 +196,11 @@ def load_library(float_type="Float32"):
     lib.gb25_real_bytes.restype = C.c_int32
     if lib.gb25_real_bytes() != np.dtype(DTYPES[float_type]).itemsize:
         raise GB25Error(f"{path} holds {lib.gb25_real_bytes()}-byte elements, expected {float_type}")
+    lib.gb25_config_bytes.restype = lib.gb25_catke_parameters_bytes.restype = C.c_int32
+    if lib.gb25_config_bytes() != C.sizeof(Config) or lib.gb25_catke_parameters_bytes() != C.sizeof(CatkeParameters):
+        raise GB25Error(f"{path}: gb25_config is {lib.gb25_config_bytes()} bytes there and {C.sizeof(Config)} in this binding "
+                        f"(gb25_catke_parameters: {lib.gb25_catke_parameters_bytes()} / {C.sizeof(CatkeParameters)}): "
+                        "the library and gb25_amd/binding.py are of different versions")
     _libs[float_type] = lib
     return lib
 

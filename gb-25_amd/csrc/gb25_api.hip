@@ -2052,6 +2052,8 @@ extern "C" {
 
 const char* gb25_version(void) { return sizeof(real) == 8 ? "gb25hip 0.2 (gfx950, Float64)" : "gb25hip 0.2 (gfx950, Float32)"; }
 int32_t gb25_real_bytes(void) { return (int32_t)sizeof(real); }
+int32_t gb25_config_bytes(void) { return (int32_t)sizeof(gb25_config); }
+int32_t gb25_catke_parameters_bytes(void) { return (int32_t)sizeof(gb25_catke_parameters); }
 
 void gb25_default_config(gb25_config* c, int32_t Nx, int32_t Ny, int32_t Nz) {
   memset(c, 0, sizeof *c);

@@ -183,6 +183,10 @@ void gb25_destroy(gb25_model *m);
 const char *gb25_last_error_string(const gb25_model *m); /* valid until the next call on m */
 const char *gb25_version(void);
 int32_t gb25_real_bytes(void); /* sizeof one field element of THIS library: 4 (Float32) or 8 (Float64) */
+/* sizeof(gb25_config) and sizeof(gb25_catke_parameters) as THIS library was built: a binding in another language checks its
+ * mirror of the structs against them before the first gb25_create (a field added here must not shift silently there) */
+int32_t gb25_config_bytes(void);
+int32_t gb25_catke_parameters_bytes(void);
 
 /* Run all kernels of this model on the caller's HIP stream (a hipStream_t passed as void*; NULL is HIP's
  * default stream, which is what torch.cuda.current_stream() is unless the host changed it).  Lets a host

@@ -90,6 +90,9 @@ function create(::Type{FT}, cfg::Config) where {FT<:Union{Float32,Float64}}
     lib = LIBS[FT]
     nbytes = ccall((:gb25_real_bytes, lib), Int32, ())
     nbytes == sizeof(FT) || throw(GB25Error("$lib holds $(nbytes)-byte elements, expected $FT"))
+    # the mirror of gb25_config must be the library's struct, field for field (a field added there must not shift silently here)
+    cbytes = ccall((:gb25_config_bytes, lib), Int32, ())
+    cbytes == sizeof(Config) || throw(GB25Error("gb25_config is $cbytes bytes in $lib and $(sizeof(Config)) in this binding"))
     out = Ref{Ptr{Cvoid}}(C_NULL)
     st = ccall((:gb25_create, lib), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, out)
     m = Model{FT}(out[], lib, cfg)

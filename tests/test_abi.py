@@ -40,6 +40,9 @@ def test_config_struct_layout_matches_header(lib):
     assert (cfg.lat_south, cfg.lat_north, cfg.depth, cfg.zexp_h) == (-80.0, 80.0, 4000.0, 30.0)
     assert (cfg.g, cfg.Omega, cfg.radius, cfg.rho0, cfg.chi) == (9.80665, 7.292115e-5, 6371e3, 1020.0, 0.1)
     assert lib.gb25_version().decode().startswith("gb25hip")
+    # the library states the size of its structs: a binding whose mirror has another size refuses to load it
+    assert lib.gb25_config_bytes() == ctypes.sizeof(binding.Config) and cfg.ranks_y == 1
+    assert lib.gb25_catke_parameters_bytes() == ctypes.sizeof(binding.CatkeParameters)
 
 
 def test_no_cpu_fallback_without_device(lib):
