@@ -170,3 +170,21 @@ def test_mesh_in_float64_with_implicit_vertical_diffusion():
     for n in FIELDS:
         a, b = ens.gather(n), single.backend.get_field(n, False)
         assert a.dtype == np.float64 and a.shape == b.shape and np.array_equal(a, b), (n, float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize("grid_type", [0, 4])
+def test_mesh_with_ragged_tiles_and_the_narrowest_bands(grid_type):
+    """Ranks of 90 columns x 33 rows (ragged 64-wide tiles, bands barely wider than the sub-cycle's halo of 30 rows) on a 2 x 2
+    mesh, 3 x 2 on the tripolar grid with its fold partners (1, 3) <-> (3, 3) and the self-partner in the middle."""
+    Rx, Ry = (2, 2) if grid_type == 0 else (3, 2)
+    Nx, Ny, Nz, dt = 90 * Rx, 66, 10, 600.0
+    single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt, grid_type=GRID_NAMES[grid_type])
+    init = _initial(Nx, Ny, Nz, single, Ny if grid_type >= 3 else Ny + 1)
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, Rx * Ry, dt=dt, ranks_y=Ry, **(dict(grid_type=grid_type) if grid_type else {}))
+    for n, a in init.items():
+        ens.scatter(n, a)
+    gb.first_time_step(single)
+    ens.first_time_step()
+    gb.loop(single, 7)
+    ens.loop(7)
+    _compare(ens, single, "8 steps")
