@@ -96,3 +96,13 @@ def test_bench_mesh_prints_contract_line():
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 4 and out["finite"] and out["config"]["local_columns"] == 64 and out["config"]["local_rows"] == 48
     assert "2 x 2 mesh" in out["config"]["parallelism"] and out["value"] > 0
+
+
+def test_bench_data_free_on_a_mesh():
+    """BASELINE configs[3]'s workload (data-free climate model) in its reference decomposition, as bench.py launches it -- at a
+    reduced size, four ranks 2 x 2 on one GPU: the line `bench.py --gpus 8 --mesh 4x2 --data-free --size 1440 720 60` prints."""
+    res = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "4", "--mesh", "2x2", "--data-free", "--steps", "3", "--warmup", "1",
+                   "--size", "128", "96", "8", "--no-cpu-baseline"], {}, nproc=4)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and out["finite"] and "data-free" in out["config"]["workload"] and "2 x 2 mesh" in out["config"]["parallelism"]
