@@ -1813,10 +1813,10 @@ inline bool lazy_corrector_ok(const gb25_model* m) {
          m->ab2_ahead == 1 && !m->ptr_exposed && m->pressure_bits == 64;
 }
 
-// ... and a slab of an x decomposition: the same kernels without the halo images (its x halos come with the bundles, and with
-// them the neighbours' column integrals: du, dv of the halo columns are computed locally)
+// ... and a slab of an x decomposition or a rank of a 2-D one: the same kernels without the halo images (its halos come with the
+// bundles, and with them the neighbours' column integrals: du, dv of the halo columns / rows are computed locally)
 inline bool slab_lazy_ok(const gb25_model* m) {
-  return m->slab && m->Ry == 1 && m->lazy_corrector && !m->coupled && m->bottom_drag == 0 && m->tracer_order == 5 && m->two_streams &&
+  return m->slab && m->lazy_corrector && !m->coupled && m->bottom_drag == 0 && m->tracer_order == 5 && m->two_streams &&
          !m->immersed && !m->g.cv.on && m->kernel_gen >= 2 && m->ab2_ahead == 1 && !m->ptr_exposed && m->pressure_bits == 64 &&
          m->nu == 0 && m->kappa == 0 && !m->catke;
 }
@@ -1915,7 +1915,7 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     Timed t(m, GB25_K_CORRECTOR);
     hipLaunchKernelGGL(k_corrector_2d, grid2(g.Nx, g.Ny + 1, b), b, 0, main, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
                        m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d,
-                       0, g.Nx, INT_MAX, 0);
+                       0, g.Nx, INT_MAX, 0, 0, g.Ny + 1);
     LAUNCHCHK();
     m->uv_lazy = true;
     m->colsum_valid = false;

@@ -1754,27 +1754,31 @@ __global__ __launch_bounds__(256) void k_corrector_cells(Grid g, real* __restric
 __global__ __launch_bounds__(256) void k_corrector_2d(Grid g, const real* __restrict__ U, const real* __restrict__ V,
                                                       const real* __restrict__ Usum, const real* __restrict__ Vsum,
                                                       real* __restrict__ Ub, real* __restrict__ Vb, real* __restrict__ du,
-                                                      real* __restrict__ dv, int i0, int ni, int skip_from, int skip) {
-  const int ix = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (ix >= ni || j > g.Ny) return;
+                                                      real* __restrict__ dv, int i0, int ni, int skip_from, int skip, int jr0,
+                                                      int nj) {
+  // rows [jr0, jr0 + nj): [0, Ny]; a rank of a 2-D decomposition: with the halo rows of its open sides (their column integrals and
+  // their new U, V arrived like those of the halo columns).  Walls are where the GLOBAL grid has them (Grid::jws, jwn).
+  const int ix = blockIdx.x * blockDim.x + threadIdx.x, jy = blockIdx.y * blockDim.y + threadIdx.y;
+  if (ix >= ni || jy >= nj) return;
   int i = i0 + ix;
   if (i >= skip_from) i += skip;
+  const int j = jr0 + jy;
   const int o2 = i2(g, i, j);
   const bool xw = g.x_periodic && i < g.H, xe = g.x_periodic && i >= g.Nx - g.H;
-  if (j == g.Ny) {   // the northern wall face of v
+  if (j == g.jwn) {   // the northern wall face of v
     store_x_images(g, dv, o2, real(0.), xw, xe);
     return;
   }
   const real su = Usum[o2], sv = Vsum[o2];
-  if (i >= 0 && i < g.Nx) {
+  if (i >= 0 && i < g.Nx && j >= 0 && j < g.Ny) {
     Ub[o2] = su;
     Vb[o2] = sv;
   }
-  const real a = (U[o2] - su) * g.rLz, b = j == 0 ? real(0.) : (V[o2] - sv) * g.rLz;
+  const real a = (U[o2] - su) * g.rLz, b = j == g.jws ? real(0.) : (V[o2] - sv) * g.rLz;
   store_x_images(g, du, o2, a, xw, xe);
   store_x_images(g, dv, o2, b, xw, xe);
-  if (j == 0) store_x_images(g, du, o2 - g.sx, a, xw, xe);
-  if (j == g.Ny - 1) store_x_images(g, du, o2 + g.sx, a, xw, xe);
+  if (j == g.jws) store_x_images(g, du, o2 - g.sx, a, xw, xe);
+  if (j == g.jwn - 1) store_x_images(g, du, o2 + g.sx, a, xw, xe);
 }
 // w at the first level of every chunk of levels of the tendency kernels, for w ON THE FLY (LazyCorr::wbase): from the chunk
 // integrals of u dz, v dz the momentum look-ahead left in P (of the uncorrected velocities: + du, dv times the chunk's
@@ -1796,11 +1800,13 @@ __global__ __launch_bounds__(256) void k_w_bases(Grid g, const real* __restrict_
   const int klen = (g.Nz + kchunks - 1) / kchunks;
   auto wrap = [&](int ii) { return !g.x_periodic ? ii : (ii < 0 ? ii + g.Nx : (ii >= g.Nx ? ii - g.Nx : ii)); };
   const int o2 = i2(g, i, j);
-  const bool urow = j >= -1 && j <= g.Ny;                       // rows whose u is not identically zero (interior + one layer)
-  const int ju = min(max(j, 0), g.Ny - 1);
+  // (walls where the GLOBAL grid has them: Grid::jws, jwn; the rows of an open side of a rank of a 2-D decomposition are the
+  // neighbour's and hold what it holds)
+  const bool urow = j >= g.jws - 1 && j <= g.jwn;               // rows whose u is not identically zero (interior + one layer)
+  const int ju = min(max(j, g.jws), g.jwn - 1);
   const int ow = i2(g, wrap(i), ju), oe = i2(g, wrap(i + 1), ju);
-  const bool vs_ok = j >= 1 && j <= g.Ny - 1, vn_ok = j + 1 >= 1 && j + 1 <= g.Ny - 1;
-  const int os = i2(g, wrap(i), min(max(j, 0), g.Ny)), on = i2(g, wrap(i), min(max(j + 1, 0), g.Ny));
+  const bool vs_ok = j >= g.jws + 1 && j <= g.jwn - 1, vn_ok = j + 1 >= g.jws + 1 && j + 1 <= g.jwn - 1;
+  const int os = i2(g, wrap(i), min(max(j, g.jws), g.jwn)), on = i2(g, wrap(i), min(max(j + 1, g.jws), g.jwn));
   const real dxs = g.dxf[j], dxn = g.dxf[j + 1], raz = g.razc[j], dy = g.dy;
   real w = real(0.);
   wbase[o2] = w;

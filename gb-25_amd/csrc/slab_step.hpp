@@ -168,6 +168,16 @@ void row_pieces(gb25_model* m, int group, int side, bool pack, real* buf, RowPie
       add(F.d, g.sx, H, (long)g.sx * F.ny, H, g.Nz, H);
     }
     if (m->catke) add(m->f[GB25_JB].d, g.sx, H, 0, 0, 1, H);
+    if (slab_lazy_ok(m)) {
+      // the corrector inside its consumers: the column integrals of u, v of the rows (the receiver's du, dv there) and, for w on
+      // the fly, their sums over the chunks of levels
+      for (int q = 0; q < 2; q++) add(m->colsum[q].d, g.sx, H, 0, 0, 1, H);
+      if (slab_wfly_ok(m)) {
+        const int kch = mom_kchunks(m);
+        const long plane2 = (long)g.sx * g.sy_v;
+        for (int q = 2; q < 4; q++) add(m->uv_partials + (long)q * kch * plane2, g.sx, H, plane2, 0, kch, H);
+      }
+    }
   } else if (group == 11 || group == 13) {
     const int wsx = g.Nx + 2 * m->W;
     for (int q = 0; q < 3; q++) add(m->wide[0][q].d, wsx, H + m->Wys, 0, 0, 1, m->W);
@@ -361,13 +371,16 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       if (!m->colsum_valid) return fail(m, GB25_ERR_STATE, "internal: a lazy step without the column integrals of u, v");
       dim3 b(64, 4);
       Timed t(m, GB25_K_CORRECTOR);
-      hipLaunchKernelGGL(k_corrector_2d, grid2(g.Nx, g.Ny + 1, b), b, 0, m->stream, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
-                         m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d,
-                         0, g.Nx, INT_MAX, 0);
+      // (a rank of a 2-D decomposition has no interior pass: du, dv and the chunk bases of w over its whole extended range at
+      // once, in stage 3, when every halo is in)
+      if (m->Ry == 1)
+        hipLaunchKernelGGL(k_corrector_2d, grid2(g.Nx, g.Ny + 1, b), b, 0, m->stream, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
+                           m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d,
+                           0, g.Nx, INT_MAX, 0, 0, g.Ny + 1);
       LAUNCHCHK();
       m->uv_lazy = true;
-      m->colsum_valid = false;
-      if (m->w_fly_now) {
+      if (m->Ry == 1) m->colsum_valid = false;
+      if (m->w_fly_now && m->Ry == 1) {
         // chunk bases of w on the columns [0, Nx - 2] (their u faces are own columns), before the interior momentum pass
         // overwrites the chunk sums they are made from
         hipLaunchKernelGGL(k_w_bases, grid2(g.Nx - 1, g.Ny + 4, b), b, 0, m->stream, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
@@ -389,7 +402,8 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
   } else if (stage == 32) {
     // 2-D decomposition: group 0 has been unpacked; the corrector on the x-halo columns of the own rows, so that the rows that
     // leave for the southern / northern neighbour next (group 10) are corrected over their whole width
-    return corrector_impl(m, true, 2);
+    // (a lazy step: the rows leave uncorrected, like the columns; the receiver makes du, dv of its halo rows itself)
+    return m->step_lazy ? GB25_OK : corrector_impl(m, true, 2);
   } else if (stage == 3 || stage == 30 || stage == 31) {
     // groups 2 and 0 have been unpacked: corrector on the x-halo columns, then update_state without any
     // further exchange (y/z layers re-filled over the extended x range; w and p recomputed in the halos).
@@ -418,14 +432,31 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
         // du, dv of the x halo columns: the neighbours' column integrals came with the bundle, the new U, V of those columns
         // from the widened sub-cycle; their y/z layers of u, v arrived filled -- nothing else to do
         if (!m->halo_colsum_valid) return fail(m, GB25_ERR_STATE, "internal: a lazy step without the neighbours' column integrals");
-        dim3 b(16, 16);
-        hipLaunchKernelGGL(k_corrector_2d, grid2(2 * g.H, g.Ny + 1, b), b, 0, m->stream, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
-                           m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d,
-                           -g.H, 2 * g.H, 0, g.Nx);
-        if (m->w_fly_now)   // the chunk bases of w on the columns -2, -1 and Nx - 1, Nx, Nx + 1 (the w tiles reach two columns out)
-          hipLaunchKernelGGL(k_w_bases, grid2(5, g.Ny + 4, b), b, 0, m->stream, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
-                             LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0}, m->wbase, -2, 5, 0, g.Nx - 1);
-        LAUNCHCHK();
+        if (m->Ry > 1) {
+          // 2-D decomposition: everything at once -- own cells, halo columns, halo rows of the open sides (corners included)
+          dim3 b(64, 4);
+          // rows: from the southern halo rows (or row 0) to the last northern halo row of the cell-shaped arrays (or the wall face)
+          const int hs = m->ys_open ? g.H : 0, nj = hs + g.Ny + (m->yn_open ? g.H : 1);
+          hipLaunchKernelGGL(k_corrector_2d, grid2(g.Nx + 2 * g.H, nj, b), b, 0, m->stream, g, m->f[GB25_BT_U].d,
+                             m->f[GB25_BT_V].d, m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d,
+                             m->corr[1].d, -g.H, g.Nx + 2 * g.H, INT_MAX, 0, -hs, nj);
+          m->colsum_valid = false;
+          if (m->w_fly_now) {
+            hipLaunchKernelGGL(k_w_bases, grid2(g.Nx + 4, g.Ny + 4, b), b, 0, m->stream, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
+                               LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0}, m->wbase, -2, g.Nx + 4, INT_MAX, 0);
+            m->w_stale = true;
+          }
+          LAUNCHCHK();   // (the bottom / top layers of the halo rows, which arrived with their interior levels: the fill below)
+        } else {
+          dim3 b(16, 16);
+          hipLaunchKernelGGL(k_corrector_2d, grid2(2 * g.H, g.Ny + 1, b), b, 0, m->stream, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
+                             m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d,
+                             -g.H, 2 * g.H, 0, g.Nx, 0, g.Ny + 1);
+          if (m->w_fly_now)   // the chunk bases of w on the columns -2, -1 and Nx - 1, Nx, Nx + 1 (the w tiles reach two columns out)
+            hipLaunchKernelGGL(k_w_bases, grid2(5, g.Ny + 4, b), b, 0, m->stream, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
+                               LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0}, m->wbase, -2, 5, 0, g.Nx - 1);
+          LAUNCHCHK();
+        }
       } else if (m->Ry == 1 && (s = corrector_impl(m, true, 2))) {   // (2-D decomposition: done in stage 32)
         return s;
       }

@@ -15,6 +15,10 @@ FIELDS = ["u", "v", "w", "T", "S", "eta", "U", "V", "eta_bar", "U_bar", "V_bar",
           "Gm.u", "Gm.v", "pHY"]
 
 
+# Bit-for-bit comparisons run the ranks with w from the stand-alone kernel, as the small single domains of these tests compute it
+# (w carried inside the tendency kernels -- the default of a flat lat-lon rank in steady state -- is another association of the
+# vertical sum: test_w_on_the_fly_on_a_mesh).
+EXACT = dict(w_on_the_fly=0)
 GRID_NAMES = {0: "simple_lat_lon", 1: "gaussian_islands_lat_lon", 2: "lat_lon_as_curvilinear", 3: "tripolar", 4: "gaussian_islands"}
 
 
@@ -43,7 +47,7 @@ def test_mesh_reproduces_single_domain_bitwise(Rx, Ry, Nz, grid_type):
     kw = dict(grid_type=grid_type)
     single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt, grid_type=GRID_NAMES[grid_type])
     init = _initial(Nx, Ny, Nz, single, Ny if grid_type >= 3 else Ny + 1)   # (a folded grid has Ny rows of y faces)
-    ens = LocalSlabEnsemble(Nx, Ny, Nz, Rx * Ry, dt=dt, ranks_y=Ry, slab_mode=1, **kw)
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, Rx * Ry, dt=dt, ranks_y=Ry, slab_mode=1, options=EXACT, **kw)
     for n, a in init.items():
         ens.scatter(n, a)
     gb.first_time_step(single)
@@ -131,7 +135,7 @@ def test_state_dump_of_a_mesh_and_offline_gather(tmp_path):
     Nx, Ny, Nz, dt = 128, 96, 8, 600.0
     single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt)
     init = _initial(Nx, Ny, Nz, single, Ny + 1)
-    ens = LocalSlabEnsemble(Nx, Ny, Nz, 4, dt=dt, ranks_y=2)
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, 4, dt=dt, ranks_y=2, options=EXACT)
     for n, a in init.items():
         ens.scatter(n, a)
     gb.first_time_step(single)
@@ -158,7 +162,7 @@ def test_mesh_in_float64_with_implicit_vertical_diffusion():
     v0 = 1e-2 * counter_rng((Nx, Ny + 1, Nz), 42, 2)
     single.set(u=u0.astype(np.float32).astype(np.float64), v=v0.astype(np.float32).astype(np.float64))
     init = {n: single.backend.get_field(n, False) for n in ("u", "v", "T", "S", "eta")}
-    ens = LocalSlabEnsemble(Nx, Ny, Nz, 4, dt=dt, ranks_y=2, float_type="Float64")
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, 4, dt=dt, ranks_y=2, float_type="Float64", options=EXACT)
     for b in [single.backend] + ens.backends:
         b.set_vertical_diffusivity(1e-2, 1e-3)
     for n, a in init.items():
@@ -180,7 +184,7 @@ def test_mesh_with_ragged_tiles_and_the_narrowest_bands(grid_type):
     Nx, Ny, Nz, dt = 90 * Rx, 66, 10, 600.0
     single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt, grid_type=GRID_NAMES[grid_type])
     init = _initial(Nx, Ny, Nz, single, Ny if grid_type >= 3 else Ny + 1)
-    ens = LocalSlabEnsemble(Nx, Ny, Nz, Rx * Ry, dt=dt, ranks_y=Ry, **(dict(grid_type=grid_type) if grid_type else {}))
+    ens = LocalSlabEnsemble(Nx, Ny, Nz, Rx * Ry, dt=dt, ranks_y=Ry, options=EXACT, **(dict(grid_type=grid_type) if grid_type else {}))
     for n, a in init.items():
         ens.scatter(n, a)
     gb.first_time_step(single)
@@ -188,3 +192,26 @@ def test_mesh_with_ragged_tiles_and_the_narrowest_bands(grid_type):
     gb.loop(single, 7)
     ens.loop(7)
     _compare(ens, single, "8 steps")
+
+
+def test_w_on_the_fly_on_a_mesh():
+    """The steady-state schedule of a flat lat-lon rank of a 2-D decomposition: the corrector inside its consumers (du, dv over the
+    rank's whole extended range -- halo columns AND rows -- from the column integrals the bundles carry) and w carried inside the
+    tendency kernels.  Against the same mesh with w from the stand-alone kernel: the same numbers to round-off."""
+    Nx, Ny, Nz, dt = 256, 96, 36, 600.0      # three chunks of levels
+    single = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt)
+    init = _initial(Nx, Ny, Nz, single, Ny + 1)
+    single.backend.close()
+    out = {}
+    for fly in (1, 0):
+        ens = LocalSlabEnsemble(Nx, Ny, Nz, 4, dt=dt, ranks_y=2, options=dict(w_on_the_fly=fly))
+        for n, a in init.items():
+            ens.scatter(n, a)
+        ens.first_time_step()
+        ens.loop(12)
+        assert all(b.lookahead_state() == (True, True) for b in ens.backends)
+        out[fly] = {n: ens.gather(n).astype(np.float64) for n in FIELDS}
+        ens.close()
+    worst = {n: float(np.linalg.norm((out[1][n] - out[0][n]).ravel()) / max(np.linalg.norm(out[0][n].ravel()), 1e-300)) for n in FIELDS}
+    assert max(worst.values()) < 2e-5, worst
+    assert any(v > 0 for v in worst.values()), "w on the fly did not run on the mesh"
