@@ -114,6 +114,9 @@ struct gb25_model {
   // next step's sub-cycle (a chain of short LDS phases that leaves HBM idle) instead of beside w.  ev_ts: T, S of this step
   // and their halo cells are complete (side stream); the tracer kernel waits for it, the momentum kernel for ev_join.
   hipEvent_t ev_ts = nullptr, ev_tend = nullptr;
+  hipEvent_t ev_strips = nullptr;    // slab: the pressure strips next to the x halos are done (exchange stream, stage 33)
+  bool strips_issued = false;
+  int early_strips = 1;              // option EARLY_STRIPS
   int tracers_first = 1;
   bool tend_forkable = false;       // the last tendency evaluation was a composite step's, tracers first: ev_tend covers both kernels
   bool two_streams = true;          // option TWO_STREAMS = 0: strictly sequential phases on one stream
@@ -2133,6 +2136,7 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   HIPCHK(hipEventCreateWithFlags(&m->ev_mom, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_ts, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_tend, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&m->ev_strips, hipEventDisableTiming));
 
   m->stream = m->own_stream;
   m->last_dt = cfg->dt;
@@ -2321,6 +2325,7 @@ void gb25_destroy(gb25_model* m) {
   if (m->ev_mom) hipEventDestroy(m->ev_mom);
   if (m->ev_ts) hipEventDestroy(m->ev_ts);
   if (m->ev_tend) hipEventDestroy(m->ev_tend);
+  if (m->ev_strips) hipEventDestroy(m->ev_strips);
   if (m->own_stream) hipStreamDestroy(m->own_stream);
   delete m;
 }
@@ -2882,6 +2887,7 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
     case GB25_OPT_W_ON_THE_FLY: m->w_fly = v != 0; return GB25_OK;
     case GB25_OPT_SUB_STREAM_PRIORITY: m->sub_priority = v != 0; return GB25_OK;
     case GB25_OPT_SUBCYCLE_WHOLE: m->baro_whole = v != 0; return GB25_OK;
+    case GB25_OPT_EARLY_STRIPS: m->early_strips = v != 0; return GB25_OK;
     case GB25_OPT_MOMENTUM_CHUNK_LEVELS:
     case GB25_OPT_TRACER_CHUNK_LEVELS:
       if (v < 6 || v > 4096) return fail(m, GB25_ERR_INVALID_ARGUMENT, "chunk levels: 6 or more");
@@ -2926,6 +2932,7 @@ gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
     case GB25_OPT_W_ON_THE_FLY: *v = m->w_fly; break;
     case GB25_OPT_SUB_STREAM_PRIORITY: *v = m->sub_priority; break;
     case GB25_OPT_SUBCYCLE_WHOLE: *v = m->baro_whole; break;
+    case GB25_OPT_EARLY_STRIPS: *v = m->early_strips; break;
     default: return GB25_ERR_INVALID_ARGUMENT;
   }
   return GB25_OK;
@@ -3053,6 +3060,7 @@ int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int3
   TraceOps ops(nslabs, adopted != 0, ready != 0);
   if (first & 2) ops.fold = true;   // (bit 1 of `first`: a folded grid)
   if (first & 4) ops.is_coupled = true;   // (bit 2: a coupled model -- data-free forcing)
+  if (first & 64) ops.early = true;       // (bit 6: plain x slabs whose bundle is unpacked on the exchange stream)
   if (first & 32) ops.is_lazy = true;     // (bit 5: a step that keeps the corrector inside its consumers)
   if (first & 16) ops.mesh = true;        // (bit 4: a 2-D decomposition -- y halos from the southern / northern neighbour)
   bool in_flight = (first & 8) != 0;      // (bit 3: the previous step left the look-ahead chain in flight)

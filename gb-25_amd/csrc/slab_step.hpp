@@ -261,6 +261,12 @@ gb25_status fold_unpack(gb25_model* m, const real* buf) {
   return GB25_OK;
 }
 
+// the pressure strips next to the x halos on the exchange stream, right behind the unpacked bundle (plain x slabs, no closure
+// whose fields and fills sit in between)
+inline bool strips_on_comm(const gb25_model* m) {
+  return m->early_strips && m->two_streams && m->pressure_bits == 64 && !m->g.cv.north_fold && m->Ry == 1 && !m->catke;
+}
+
 // ---- the stages of one slab's time step (see the header of this file) -------------------------------------------------
 gb25_status slab_stage(gb25_model* m, int stage, int euler) {
   const Grid& g = m->g;
@@ -399,6 +405,14 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     if (!m->w_fly_now && (s = compute_w_impl(m, 1))) return s;
     HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));       // the own columns' pressure differences (side stream)
     return momentum_impl(m, 1);
+  } else if (stage == 33) {
+    // (issued on the exchange stream behind the unpack of group 0) the two pressure strips: T, S of the halo columns are in; the
+    // interior pass of stage 0 (side stream: event ev_join) must be over -- the west strip redoes its column 0
+    HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+    if ((s = compute_p_impl(m, -g.H + 1, 0, g.Nx, g.Nx + g.H - 2, true))) return s;
+    HIPCHK(hipEventRecord(m->ev_strips, m->stream));
+    m->strips_issued = true;
+    return GB25_OK;
   } else if (stage == 32) {
     // 2-D decomposition: group 0 has been unpacked; the corrector on the x-halo columns of the own rows, so that the rows that
     // leave for the southern / northern neighbour next (group 10) are corrected over their whole width
@@ -410,6 +424,8 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     // Folded grid: stage 30 = up to the y/z layers, then the rows beyond the fold arrive from the partner, stage 31 = the rest.
     // (a closure's fields travel in the bundle as well and its fills follow: the strips keep their old place behind them)
     const bool strips_first = p_early && !m->catke;
+    const bool strips_done = m->strips_issued;   // (stage 33 ran them on the exchange stream)
+    m->strips_issued = false;
     auto pressure_strips = [&]() -> gb25_status {
       hipStream_t main = m->stream;
       HIPCHK(hipEventRecord(m->ev_fork, main));
@@ -422,7 +438,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       return GB25_OK;
     };
     if (stage != 31) {
-      if (strips_first) {
+      if (strips_first && !strips_done) {
         // the two pressure strips next to the x halos start as soon as the bundle is unpacked: T, S of the halo columns arrived
         // complete (their y/z layers were filled by their owner before it packed them), and the side stream runs them behind the
         // interior pass of stage 0 -- beside the corrector, the fills and w of the edge strips instead of after them
@@ -468,7 +484,9 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     }
     if (p_early && !strips_first && (s = pressure_strips())) return s;   // (beside w)
     if (!m->w_fly_now && (s = compute_w_impl(m, split ? 2 : 0))) return s;
-    if (p_early) {
+    if (strips_done) {
+      HIPCHK(hipStreamWaitEvent(m->stream, m->ev_strips, 0));
+    } else if (p_early) {
       HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
     } else {
       if ((s = compute_p_impl(m))) return s;
@@ -515,6 +533,9 @@ struct StepOps {
   virtual bool coupled() { return false; }   // a prescribed atmosphere is set (data-free forcing)
   virtual bool folded() = 0;          // zipper fold: exchanges with the partner rank (buffer sets 3 and 4; groups 6 and 8)
   virtual bool lazy() { return false; }     // this step keeps the corrector inside its consumers (known after stage 0)
+  // plain x slabs: the bundle is unpacked on the exchange stream right behind its transfer, and the two pressure strips next to
+  // the x halos follow it there (stage 33) -- beside the interior momentum pass instead of in front of the edge pass
+  virtual bool early_unpack() { return false; }
   virtual bool mesh_y() { return false; }   // 2-D decomposition: y halos from the southern / northern neighbour (groups 10 - 14)
   virtual gb25_status record(int slot, int on) = 0;
   virtual gb25_status wait(int slot, int waiter) = 0;
@@ -551,6 +572,12 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
   EACH(o.pack(s, 0, true));
   SEQ(o.record(1, true));      // (packed)
   SEQ(o.exchange(0, true));
+  const bool early = o.early_unpack();
+  if (early)
+    for (int s = 0; s < n; s++) {
+      SEQ(o.unpack(s, 0, true));          // (halo columns only: nothing the main stream touches before it waits for event 3)
+      SEQ(o.stage(s, 33, euler, true));
+    }
   if (!adopted && (o.folded() || o.mesh_y())) {
     // zipper fold: the work arrays are tall as well as wide.  Once every slab has its wide halo columns, the rows south of
     // the pivot row go to the partner rank P-1-r (group 8) and become its image rows beyond the pivot row; then the substeps
@@ -615,7 +642,7 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
     }
   } else {
     for (int s = 0; s < n; s++) {
-      if (!o.mesh_y()) SEQ(o.unpack(s, 0, false));
+      if (!o.mesh_y() && !early) SEQ(o.unpack(s, 0, false));
       SEQ(o.stage(s, 3, euler, false));
     }
   }
@@ -743,11 +770,12 @@ struct TraceOps : StepOps {
   int nslabs;
   bool adopted, ready;
   std::string log;
-  bool fold = false, is_coupled = false, mesh = false, is_lazy = false;
+  bool fold = false, is_coupled = false, mesh = false, is_lazy = false, early = false;
   TraceOps(int n_, bool a, bool r) : nslabs(n_), adopted(a), ready(r) {}
   bool folded() override { return fold; }
   bool mesh_y() override { return mesh; }
   bool lazy() override { return is_lazy; }
+  bool early_unpack() override { return early; }
   bool coupled() override { return is_coupled; }
   void add(const char* fmt, ...) {
     char buf[96];
@@ -1008,6 +1036,11 @@ struct GroupOps : StepOps {
   bool lazy() override {
     for (gb25_model* m : G.slabs)
       if (!m->step_lazy) return false;
+    return true;
+  }
+  bool early_unpack() override {
+    for (gb25_model* m : G.slabs)
+      if (!strips_on_comm(m)) return false;
     return true;
   }
   bool coupled() override { return G.slabs[0]->coupled; }

@@ -148,6 +148,9 @@ typedef enum {
   GB25_OPT_SUBCYCLE_WHOLE,       /* [1] slab of a decomposition with fewer sub-cycle tiles than the device has CUs (a 180-column rank): all
                                     substeps in ONE launch, the tile and a ring as wide as the sub-cycle is long in 125 KB of LDS;
                                     0: the blocked launches (SUBCYCLE_BLOCK) */
+  GB25_OPT_EARLY_STRIPS,         /* [1] x slab of a decomposition: the bundle is unpacked on the exchange stream right behind its transfer
+                                    and the pressure strips next to the x halos follow it there, beside the interior momentum pass;
+                                    0: unpack and strips on the main stream when it gets there */
   GB25_OPT_COUNT
 } gb25_option;
 
@@ -391,8 +394,8 @@ gb25_status gb25_comm_finalize(gb25_model *m);
 gb25_status gb25_lookahead_state(const gb25_model *m, int32_t *velocities_ready, int32_t *subcycle_adopted);
 /* The order of operations of one time step (bit 0 of `first`: of first_time_step!; bit 1: on a folded grid; bit 2: of a
  * coupled model; bit 3: with the previous step's look-ahead chain still in flight) of `nslabs` slabs as text, without
- * touching a GPU; bit 4: of a 2-D decomposition; bit 5: of a step that keeps the corrector inside its consumers (tests of the
- * sequencing on CPU-only machines).  Returns the bytes needed, incl. the terminator. */
+ * touching a GPU; bit 4: of a 2-D decomposition; bit 5: of a step that keeps the corrector inside its consumers; bit 6: with the
+ * bundle unpacked on the exchange stream (tests of the sequencing on CPU-only machines).  Returns the bytes needed, incl. the terminator. */
 int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int32_t ready, char *out, int64_t cap);
 
 /* ---- state dump: save_model_state(dir, model, arch; label) (src/sharded_io.jl:70-96,122-138; called after each loop

@@ -330,3 +330,16 @@ def test_time_step_sequencing_of_a_lazy_step():
     plain = _raw_sequence(3, 8, adopted=1, ready=1)
     assert not any(e[:2] == ("stage", 20) for e in plain)
     assert plain.index(("wait", 1, "main")) < plain.index(("wait", 4, "main"))
+
+
+def test_time_step_sequencing_with_the_bundle_unpacked_on_the_exchange_stream():
+    """Plain x slabs: the halo columns are unpacked on the exchange stream right behind the transfer of the bundle and the two
+    pressure strips next to the x halos (stage 33) follow them there -- beside the own-column work of stage 2 on the main stream,
+    which waits for both (event 3) only in front of stage 3."""
+    log = _raw_sequence(2, 8 | 32 | 64, adopted=1, ready=1)
+    mine = _ops_of_slab(log, 1)
+    i = mine.index(("exchange", 0, "comm"))
+    assert mine[i + 1:i + 3] == [("unpack", 0, "comm"), ("stage", 33, "comm")]
+    assert mine.index(("stage", 33, "comm")) < mine.index(("stage", 20, "main")) < mine.index(("stage", 2, "main")) < mine.index(("stage", 3, "main"))
+    assert ("unpack", 0, "main") not in mine
+    assert log.index(("record", 3, "comm")) < log.index(("wait", 3, "main")) < log.index(("stage", 3, "slab", 0, "euler", 0, "main"))
