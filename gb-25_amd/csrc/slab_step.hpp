@@ -533,9 +533,11 @@ struct StepOps {
   virtual bool coupled() { return false; }   // a prescribed atmosphere is set (data-free forcing)
   virtual bool folded() = 0;          // zipper fold: exchanges with the partner rank (buffer sets 3 and 4; groups 6 and 8)
   virtual bool lazy() { return false; }     // this step keeps the corrector inside its consumers (known after stage 0)
-  // plain x slabs: the bundle is unpacked on the exchange stream right behind its transfer, and the two pressure strips next to
-  // the x halos follow it there (stage 33) -- beside the interior momentum pass instead of in front of the edge pass
+  // the bundle is unpacked on the exchange stream right behind its transfer (halo columns only: nothing the main stream touches
+  // before it waits for event 3); on plain x slabs the two pressure strips next to the x halos follow it there (stage 33) --
+  // beside the interior momentum pass instead of in front of the edge pass
   virtual bool early_unpack() { return false; }
+  virtual bool early_strips() { return false; }
   virtual bool mesh_y() { return false; }   // 2-D decomposition: y halos from the southern / northern neighbour (groups 10 - 14)
   virtual gb25_status record(int slot, int on) = 0;
   virtual gb25_status wait(int slot, int waiter) = 0;
@@ -575,8 +577,8 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
   const bool early = o.early_unpack();
   if (early)
     for (int s = 0; s < n; s++) {
-      SEQ(o.unpack(s, 0, true));          // (halo columns only: nothing the main stream touches before it waits for event 3)
-      SEQ(o.stage(s, 33, euler, true));
+      SEQ(o.unpack(s, 0, true));
+      if (o.early_strips()) SEQ(o.stage(s, 33, euler, true));
     }
   if (!adopted && (o.folded() || o.mesh_y())) {
     // zipper fold: the work arrays are tall as well as wide.  Once every slab has its wide halo columns, the rows south of
@@ -620,7 +622,7 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
   if (o.mesh_y()) {
     // 2-D decomposition: the H rows next to an open side, with the x halo columns just received (the corners)
     for (int s = 0; s < n; s++) {
-      SEQ(o.unpack(s, 0, false));
+      if (!early) SEQ(o.unpack(s, 0, false));
       SEQ(o.stage(s, 32, euler, false));   // (the corrector on the x halo columns: the rows leave corrected)
       SEQ(o.pack(s, 10, false));
     }
@@ -631,7 +633,7 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
     // the rows beyond the fold come from the partner once every slab has its x halos and y/z layers (the partner sends
     // its halo columns too: the corners), then the rest of update_state!
     for (int s = 0; s < n; s++) {
-      if (!o.mesh_y()) SEQ(o.unpack(s, 0, false));
+      if (!o.mesh_y() && !early) SEQ(o.unpack(s, 0, false));
       SEQ(o.stage(s, 30, euler, false));
       SEQ(o.pack(s, 6, false));
     }
@@ -776,6 +778,7 @@ struct TraceOps : StepOps {
   bool mesh_y() override { return mesh; }
   bool lazy() override { return is_lazy; }
   bool early_unpack() override { return early; }
+  bool early_strips() override { return early && !fold && !mesh; }
   bool coupled() override { return is_coupled; }
   void add(const char* fmt, ...) {
     char buf[96];
@@ -1039,6 +1042,11 @@ struct GroupOps : StepOps {
     return true;
   }
   bool early_unpack() override {
+    for (gb25_model* m : G.slabs)
+      if (!m->early_strips || !m->two_streams) return false;
+    return true;
+  }
+  bool early_strips() override {
     for (gb25_model* m : G.slabs)
       if (!strips_on_comm(m)) return false;
     return true;
