@@ -951,7 +951,7 @@ gb25_status compute_w_impl(gb25_model* m, int part = 0) {
 // Hydrostatic pressure on columns [i_first, i_last] (default: the whole extended range -H+1 .. Nx+H-2; column
 // i_first - 1 is read as the west neighbour of the first x difference), optionally on a second range as well.
 gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = INT_MIN, int i_first_b = 0,
-                           int i_last_b = -1, bool may_skip_p = false) {
+                           int i_last_b = -1, bool may_skip_p = false, int j_first = INT_MIN, int j_last = INT_MIN) {
   const Grid& g = m->g;
   const real *Tsrc = m->f[GB25_T].d, *Ssrc = m->f[GB25_S].d;
   real *dpx_out = m->dpx.d, *dpy_out = m->dpy.d;
@@ -982,7 +982,11 @@ gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = IN
   dim3 b(64, 4);
   const int ncol = i_last - i_first + 2;   // written columns + the helper column
   const int ncol_b = i_last_b >= i_first_b ? i_last_b - i_first_b + 2 : 0;
-  const int nrow = g.Ny + 2 * g.H - 2;     // rows -H+1 .. Ny+H-2
+  if (j_first == INT_MIN) {                // rows -H+1 .. Ny+H-2
+    j_first = -g.H + 1;
+    j_last = g.Ny + g.H - 2;
+  }
+  const int nrow = j_last - j_first + 1;
   const int tiles_a = (ncol + 62) / 63, tiles_b = (ncol_b + 62) / 63;
   // strips and narrow slabs: one row per thread (4x the waves, short chains) -- with four rows per thread a 180-column
   // slab is 138 blocks on 256 CUs and the fp64 chains run at their latency (0.14 ms, against 0.31 ms for 1440 columns)
@@ -990,12 +994,12 @@ gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = IN
     dim3 gr(tiles_a + tiles_b, (nrow + 3) / 4);
     auto kern = write_p ? k_compute_p<1, true> : k_compute_p<1, false>;
     hipLaunchKernelGGL(kern, gr, b, 0, m->stream, g, Tsrc, Ssrc, m->f[GB25_PHY].d, dpx_out, dpy_out, i_first, i_last,
-                       i_first_b, i_last_b, tiles_a, n2);
+                       i_first_b, i_last_b, tiles_a, n2, j_first, j_last);
   } else {
     dim3 gr(tiles_a + tiles_b, (nrow + PR * 4 - 1) / (PR * 4));
     auto kern = write_p ? k_compute_p<PR, true> : k_compute_p<PR, false>;
     hipLaunchKernelGGL(kern, gr, b, 0, m->stream, g, Tsrc, Ssrc, m->f[GB25_PHY].d, dpx_out, dpy_out, i_first, i_last,
-                       i_first_b, i_last_b, tiles_a, n2);
+                       i_first_b, i_last_b, tiles_a, n2, j_first, j_last);
   }
   LAUNCHCHK();
   return GB25_OK;

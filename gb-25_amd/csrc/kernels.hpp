@@ -420,7 +420,9 @@ template <int PR_, bool WRITE_P>
 __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restrict__ T, const real* __restrict__ S,
                                                    real* __restrict__ p, real* __restrict__ dpx,
                                                    real* __restrict__ dpy, int i_first, int i_last, int i_first_b,
-                                                   int i_last_b, int tiles_a, real* __restrict__ n2) {
+                                                   int i_last_b, int tiles_a, real* __restrict__ n2, int j_first, int j_last) {
+  // rows [j_first, j_last] are written (the whole extended range: -H+1 .. Ny+H-2; a rank of a 2-D decomposition redoes row 0
+  // -- whose y difference reads the southern neighbour's row -- once that row has arrived)
   // n2 (CATKE, else null): N^2 = db/dz on the faces between the cells, from the very buoyancies of the integral and
   // differenced in fp64 like the pressure, stored at the index of the cell above the face (k_catke_buoyancy's layout).
   // an optional second column range [i_first_b, i_last_b] takes the tiles from tiles_a on (both strips of a slab in
@@ -432,8 +434,8 @@ __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restric
     i_last = i_last_b;
   }
   const int i = i_first - 1 + ((int)blockIdx.x - (second ? tiles_a : 0)) * 63 + lane;   // lane 0: helper column
-  const int jb = -g.H + 1 + (blockIdx.y * blockDim.y + threadIdx.y) * PR_;    // first of this thread's PR rows
-  const int imax = i_last, jmax = g.Ny + g.H - 2;
+  const int jb = j_first + (blockIdx.y * blockDim.y + threadIdx.y) * PR_;     // first of this thread's PR rows
+  const int imax = i_last, jmax = j_last;
   if (jb > jmax) return;                                                    // whole wave leaves together
   const int ic_ = min(i, g.Nx + g.H - 1);                                    // clamp: addresses stay in the parent
   const int Nz = g.Nz;

@@ -264,7 +264,7 @@ gb25_status fold_unpack(gb25_model* m, const real* buf) {
 // the pressure strips next to the x halos on the exchange stream, right behind the unpacked bundle (plain x slabs, no closure
 // whose fields and fills sit in between)
 inline bool strips_on_comm(const gb25_model* m) {
-  return m->early_strips && m->two_streams && m->pressure_bits == 64 && !m->g.cv.north_fold && m->Ry == 1 && !m->catke;
+  return m->early_strips && m->two_streams && m->pressure_bits == 64 && m->Ry == 1 && !m->catke;
 }
 
 // ---- the stages of one slab's time step (see the header of this file) -------------------------------------------------
@@ -274,8 +274,10 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
   const double dt = m->last_dt;
   const real chi = euler ? -real(0.5) : (real)m->cfg.chi;
   const bool split = tendencies_split(m);
-  // own columns' pressure early, on the side stream (not on a folded grid: the rows beyond the fold arrive last)
-  const bool p_early = m->two_streams && m->pressure_bits == 64 && !g.cv.north_fold && m->Ry == 1;
+  // own columns' pressure early, on the side stream.  (A folded slab too: the pressure of a cell and its differences to the west
+  // and south never look north -- what arrives last, the rows beyond the fold, is no input of theirs; the pressure of halo cells
+  // is not stored inside a composite step.)
+  const bool p_early = m->two_streams && m->pressure_bits == 64 && m->Ry == 1;
   if (stage == 0) {
     // AB2 update of u,v,T,S + barotropic forcing, then the y/z boundary layers of the 3-D bundle so that its packed
     // x columns (group 0) can travel WHILE the own columns are corrected
@@ -425,7 +427,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     // (a closure's fields travel in the bundle as well and its fills follow: the strips keep their old place behind them)
     const bool strips_first = p_early && !m->catke;
     const bool strips_done = m->strips_issued;   // (stage 33 ran them on the exchange stream)
-    m->strips_issued = false;
+    if (stage != 30) m->strips_issued = false;
     auto pressure_strips = [&]() -> gb25_status {
       hipStream_t main = m->stream;
       HIPCHK(hipEventRecord(m->ev_fork, main));
