@@ -2964,8 +2964,11 @@ gb25_status gb25_comm_init_rccl(gb25_model* m, const void* unique_id) {
   ncclUniqueId id;
   memcpy(&id, unique_id, sizeof id);
   (void)hipGetLastError();   // (RCCL reports a stale, already-handled HIP error of this process as "unhandled cuda error")
-  ncclResult_t r = rccl().CommInitRank(&tr->comm, tr->nranks, id, tr->rank);
-  if (r != ncclSuccess && tr->nranks == 1) {
+  // GB25_REHEARSE_ALONE=1: this rank of a decomposition runs alone, its neighbours are itself (a timing proxy, not a simulation)
+  const char* solo = getenv("GB25_REHEARSE_ALONE");
+  tr->alone = solo && solo[0] == '1' && tr->nranks > 1;
+  ncclResult_t r = tr->alone ? ncclInvalidArgument : rccl().CommInitRank(&tr->comm, tr->nranks, id, tr->rank);
+  if (r != ncclSuccess && (tr->nranks == 1 || tr->alone)) {
     // a one-rank communicator (the self-ring) needs nobody's agreement: once more with a fresh id
     (void)hipGetLastError();
     if (rccl().GetUniqueId(&id) == ncclSuccess) r = rccl().CommInitRank(&tr->comm, 1, id, 0);

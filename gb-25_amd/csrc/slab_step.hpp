@@ -277,6 +277,8 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
   // own columns' pressure early, on the side stream.  (A folded slab too: the pressure of a cell and its differences to the west
   // and south never look north -- what arrives last, the rows beyond the fold, is no input of theirs; the pressure of halo cells
   // is not stored inside a composite step.)
+  // (a rank of a 2-D decomposition computes its pressure in one pass once all halos are in: the early pass plus a one-row strip
+  // for the y difference of row 0 measured slower on the one-rank proxy, 0.566 against 0.537 ms -- profiles/r03_tuning_log.md)
   const bool p_early = m->two_streams && m->pressure_bits == 64 && m->Ry == 1;
   if (stage == 0) {
     // AB2 update of u,v,T,S + barotropic forcing, then the y/z boundary layers of the 3-D bundle so that its packed
@@ -945,13 +947,17 @@ RcclApi& rccl() {
 struct RcclTransport : Transport {
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
+  // rehearsal of ONE rank of a decomposition alone on one device (tools/slab_selfring.py --mesh): a communicator of size one, every
+  // neighbour is the rank itself -- the messages of a group match in posting order, so a southern pack lands in the northern halo
+  bool alone = false;
+  int peer(int r) const { return alone ? 0 : r; }
   const char* name() const override { return "rccl"; }
   ~RcclTransport() override {
     if (comm) rccl().CommDestroy(comm);
   }
   gb25_status send_recv(gb25_model* m, const void* sw, const void* se, void* rw, void* re, size_t nbytes, hipStream_t st) {
     const MeshPos q(m);
-    const int west = q.west(), east = q.east();
+    const int west = peer(q.west()), east = peer(q.east());
     RcclApi& R = rccl();
     NCCLCHK(R.GroupStart());
     NCCLCHK(R.Send(sw, nbytes, ncclInt8, west, comm, st));
@@ -968,10 +974,10 @@ struct RcclTransport : Transport {
       RcclApi& R = rccl();
       if (q.south() < 0 && q.north() < 0) return GB25_OK;
       NCCLCHK(R.GroupStart());
-      if (q.south() >= 0) NCCLCHK(R.Send(G.send[0][b][0], nbytes, ncclInt8, q.south(), comm, st));
-      if (q.north() >= 0) NCCLCHK(R.Send(G.send[0][b][1], nbytes, ncclInt8, q.north(), comm, st));
-      if (q.north() >= 0) NCCLCHK(R.Recv(G.recv[0][b][1], nbytes, ncclInt8, q.north(), comm, st));
-      if (q.south() >= 0) NCCLCHK(R.Recv(G.recv[0][b][0], nbytes, ncclInt8, q.south(), comm, st));
+      if (q.south() >= 0) NCCLCHK(R.Send(G.send[0][b][0], nbytes, ncclInt8, peer(q.south()), comm, st));
+      if (q.north() >= 0) NCCLCHK(R.Send(G.send[0][b][1], nbytes, ncclInt8, peer(q.north()), comm, st));
+      if (q.north() >= 0) NCCLCHK(R.Recv(G.recv[0][b][1], nbytes, ncclInt8, peer(q.north()), comm, st));
+      if (q.south() >= 0) NCCLCHK(R.Recv(G.recv[0][b][0], nbytes, ncclInt8, peer(q.south()), comm, st));
       NCCLCHK(R.GroupEnd());
       return GB25_OK;
     }
@@ -979,7 +985,7 @@ struct RcclTransport : Transport {
       gb25_model* m = G.slabs[0];
       if (!m->g.cv.north_fold) return GB25_OK;
       const int partner = MeshPos(m).partner();
-      if (partner == rank) {
+      if (partner == rank || alone) {
         HIPCHK(hipMemcpyAsync(G.recv[0][b][0], G.send[0][b][0], nbytes, hipMemcpyDeviceToDevice, st));
         return GB25_OK;
       }

@@ -14,6 +14,7 @@ module only
     on one device).
 No collective is needed in a time step: every rank talks to its west and east neighbour only.
 """
+import os
 import numpy as np
 import torch
 
@@ -134,10 +135,12 @@ class SlabModel(HydrostaticFreeSurfaceModel):
         super().__init__(backend, backend.Nx_local, backend.Ny_local, Nz, halo)
         self.rank, self.nranks, self.ranks_y = rank, nranks, ranks_y
         if transport is None:
-            transport = "rccl" if (nranks == 1 or dist.get_backend() == "nccl") else "host"
+            transport = "rccl" if (nranks == 1 or os.environ.get("GB25_REHEARSE_ALONE") == "1" or dist.get_backend() == "nccl") else "host"
         self.transport_kind = transport
         if transport == "rccl":
-            uid = backend.comm_unique_id() if nranks == 1 else share_unique_id(backend, rank)
+            # (GB25_REHEARSE_ALONE=1: one rank of a decomposition alone in its process, its own neighbour on every side)
+            alone = nranks == 1 or os.environ.get("GB25_REHEARSE_ALONE") == "1"
+            uid = backend.comm_unique_id() if alone else share_unique_id(backend, rank)
             backend.comm_init_rccl(uid)
         elif transport == "host":
             self._ring = TorchDistributedTransport(rank, nranks, ranks_y=ranks_y)
