@@ -584,6 +584,15 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
       SEQ(o.unpack(s, 0, true));
       if (o.early_strips()) SEQ(o.stage(s, 33, euler, true));
     }
+  // 2-D decomposition, a step that keeps the corrector inside its consumers: the rows leave as they are (stage 32 has nothing to
+  // do), so their exchange follows the bundle on the exchange stream instead of waiting for the main stream to get there (one
+  // cross-stream hop less: 0.538 -> 0.504 ms per step of a 360 x 360 rank, tools/slab_selfring.py --mesh 4 2)
+  const bool rows_early = early && o.mesh_y() && o.lazy();
+  if (rows_early) {
+    EACH(o.pack(s, 10, true));
+    SEQ(o.exchange(10, true));
+    EACH(o.unpack(s, 10, true));
+  }
   if (!adopted && (o.folded() || o.mesh_y())) {
     // zipper fold: the work arrays are tall as well as wide.  Once every slab has its wide halo columns, the rows south of
     // the pivot row go to the partner rank P-1-r (group 8) and become its image rows beyond the pivot row; then the substeps
@@ -623,7 +632,7 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
   EACH(o.stage(s, 2, euler, false));   // own columns + interior tendencies, while the exchanges are in flight
   SEQ(o.record(3, true));
   SEQ(o.wait(3, false));       // the halo columns have arrived
-  if (o.mesh_y()) {
+  if (o.mesh_y() && !rows_early) {
     // 2-D decomposition: the H rows next to an open side, with the x halo columns just received (the corners)
     for (int s = 0; s < n; s++) {
       if (!early) SEQ(o.unpack(s, 0, false));

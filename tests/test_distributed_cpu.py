@@ -343,3 +343,24 @@ def test_time_step_sequencing_with_the_bundle_unpacked_on_the_exchange_stream():
     assert mine.index(("stage", 33, "comm")) < mine.index(("stage", 20, "main")) < mine.index(("stage", 2, "main")) < mine.index(("stage", 3, "main"))
     assert ("unpack", 0, "main") not in mine
     assert log.index(("record", 3, "comm")) < log.index(("wait", 3, "main")) < log.index(("stage", 3, "slab", 0, "euler", 0, "main"))
+
+
+def test_time_step_sequencing_of_a_lazy_step_of_a_2d_decomposition():
+    """A rank of a 2-D decomposition in its steady state (corrector inside its consumers, bundle unpacked on the exchange stream):
+    the rows leave as they are -- stage 32 has nothing to correct -- so their pack, transfer and unpack follow the unpacked bundle on
+    the exchange stream; the main stream meets them once (event 3) in front of stage 3, and nothing of group 10 is left on it."""
+    log = _raw_sequence(4, 8 | 16 | 32 | 64, adopted=1, ready=1)
+    mine = _ops_of_slab(log, 2)
+    i = mine.index(("exchange", 0, "comm"))
+    assert mine[i + 1:i + 5] == [("unpack", 0, "comm"), ("pack", 10, "comm"), ("exchange", 10, "comm"), ("unpack", 10, "comm")]
+    assert not any(e in mine for e in (("pack", 10, "main"), ("unpack", 10, "main"), ("unpack", 0, "main"), ("stage", 32, "main")))
+    ex = [k for k, e in enumerate(log) if e[:2] == ("exchange", 10)]
+    assert len(ex) == 1
+    assert all(k < ex[0] for k, e in enumerate(log) if e[:2] == ("pack", 10))       # every rank packs before the transfer
+    assert all(k > ex[0] for k, e in enumerate(log) if e[:2] == ("unpack", 10))
+    assert all(k < ex[0] for k, e in enumerate(log) if e[:2] == ("unpack", 0))      # ... with its corners in
+    assert ex[0] < log.index(("record", 3, "comm")) < log.index(("wait", 3, "main")) < log.index(("stage", 3, "slab", 0, "euler", 0, "main"))
+    # a step with the stand-alone corrector: the rows wait for stage 32 on the main stream, as before
+    plain = _ops_of_slab(_raw_sequence(4, 8 | 16 | 64, adopted=1, ready=1), 2)
+    j = plain.index(("stage", 32, "main"))
+    assert plain[j + 1:j + 4] == [("pack", 10, "main"), ("exchange", 10, "main"), ("unpack", 10, "main")]
