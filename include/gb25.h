@@ -371,7 +371,9 @@ gb25_status gb25_loop(gb25_model *m, int32_t n_inner);
  * store, a file): ncclGetUniqueId */
 gb25_status gb25_comm_unique_id(void *id_out);
 /* every rank, with the same id: ncclCommInitRank(nranks = cfg.nranks, rank = cfg.rank) on cfg.device.  nranks == 1 with
- * slab_mode == 1 is the self-ring. */
+ * slab_mode == 1 is the self-ring.  With GB25_REHEARSE_ALONE=1 in the environment a rank of ANY decomposition gets a communicator
+ * of size one and is its own neighbour on every side (a timing proxy of one rank with a GPU to itself -- tools/slab_selfring.py
+ * --mesh; what crosses the seams is not a simulation's data). */
 gb25_status gb25_comm_init_rccl(gb25_model *m, const void *unique_id);
 /* all `n` slabs of one decomposition live in THIS process on one device (tests of decomposition invariance; also a
  * single-process multi-slab run): slabs[r] must have cfg.rank == r, cfg.nranks == n (and the same ranks_y).  The composites called on ANY of
