@@ -22,6 +22,12 @@ __global__ void k(float* out, int iters, float a, float b) {
         if (OP == 0) x[q] = x[q] * A + B;       // fma (contracted)
         if (OP == 1) x[q] = x[q] * A;           // mul
         if (OP == 2) x[q] = x[q] + B;           // add
+        if constexpr (OP == 3 && W<T>::n == 1) x[q] = __builtin_amdgcn_rcpf(x[q]);                 // v_rcp_f32
+        if constexpr (OP == 4 && W<T>::n == 1) x[q] = __builtin_amdgcn_sqrtf(x[q]);                // v_sqrt_f32
+        if constexpr (OP == 5 && W<T>::n == 1) x[q] = x[q] > B ? A : x[q];                         // v_cmp + v_cndmask
+        if constexpr (OP == 6 && W<T>::n == 1) {                                                   // one v_rcp_f32 among three fmas
+          x[q] = (r & 3) == 0 ? __builtin_amdgcn_rcpf(x[q]) : x[q] * A + B;
+        }
       }
     }
   }
@@ -62,5 +68,10 @@ int main() {
   run<v2f, 0, 1>("v_pk_fma_f32", d);   run<v2f, 0, 4>("v_pk_fma_f32", d);
   run<v2f, 1, 1>("v_pk_mul_f32", d);   run<v2f, 1, 4>("v_pk_mul_f32", d);
   run<v2f, 2, 1>("v_pk_add_f32", d);   run<v2f, 2, 4>("v_pk_add_f32", d);
+  // transcendentals and selects (what the WENO weights are made of besides multiply-adds)
+  run<float, 3, 1>("v_rcp_f32", d);    run<float, 3, 4>("v_rcp_f32", d);
+  run<float, 4, 1>("v_sqrt_f32", d);   run<float, 4, 4>("v_sqrt_f32", d);
+  run<float, 5, 1>("v_cmp+v_cndmask", d); run<float, 5, 4>("v_cmp+v_cndmask", d);
+  run<float, 6, 4>("1 rcp : 3 fma", d);
   return 0;
 }
