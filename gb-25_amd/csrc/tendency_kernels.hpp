@@ -353,6 +353,12 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   for (int k = k0; k < k1; k++) {
     const int par = k & 1;
     const real dz = g.dzc[k];
+    // Wave priority by phase: the short phases that end in a barrier (the loads of the next level, the derived tiles; at the end of
+    // the iteration the stash of the loaded tiles) go ahead of the long arithmetic phase of the three other blocks on the CU -- a
+    // wave that reaches its barrier late holds up its whole block, a wave in the arithmetic phase that issues a few cycles later
+    // holds up nobody.  Momentum launch 1.231 -> 1.203 ms at 1440x720x48 (-2.3 %; the reverse assignment +1.6 %), same box,
+    // alternating runs (profiles/r03_tuning_log.md).
+    __builtin_amdgcn_s_setprio(3);
     // ---- phase 0: issue the loads of the next level's tiles (consumed at the end of this iteration)
     const bool more = (k + 1 < k1);
     if (more) fetch(k + 1, ob + (unsigned)pc * SZ);
@@ -418,6 +424,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
       }
     }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
     // ---- phase 2: the two tendencies of cell (i,j,k)
     // tile accessors relative to (i,j)
 #define UT(di, dj) lds.U[par][ty + 3 + (dj)][tx + 3 + (di)]
@@ -635,6 +642,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     }
     uz[6] = unew;
     vz[6] = vnew;
+    __builtin_amdgcn_s_setprio(3);
     if (more) {
       stash(par ^ 1);
       pw_ = rpw;
