@@ -27,8 +27,8 @@ __global__ void k_catke_buoyancy(Grid g, const real* __restrict__ T, const real*
   if (i >= g.Nx || j >= g.Ny) return;
   const int o = ic(g, i, j, k), ob = o - g.pl_c;
   const double gr = -(double)g.g / (double)g.rho0, sc = 0.875 / 35.16504;
-  const double bk = gr * teos10_level(g.eos + 28 * k, sqrt(((double)S[o] + 32.0) * sc), (double)T[o] * 0.025);
-  const double bb = gr * teos10_level(g.eos + 28 * (k - 1), sqrt(((double)S[ob] + 32.0) * sc), (double)T[ob] * 0.025);
+  const double bk = gr * teos10_level(g.eos + 28 * k, sqrt_pos(((double)S[o] + 32.0) * sc), (double)T[o] * 0.025);
+  const double bb = gr * teos10_level(g.eos + 28 * (k - 1), sqrt_pos(((double)S[ob] + 32.0) * sc), (double)T[ob] * 0.025);
   n2[o] = (real)((bk - bb) / g.dzf_d[k]);
 }
 __global__ void k_catke_surface_flux(Grid g, const real* __restrict__ T, const real* __restrict__ S, real* __restrict__ Jb) {
@@ -40,7 +40,7 @@ __global__ void k_catke_surface_flux(Grid g, const real* __restrict__ T, const r
     const int o = ic(g, i, j, g.Nz - 1);
     const double sc = 0.875 / 35.16504, d = 1e-2, Tc = (double)T[o], Sc = (double)S[o];
     const double* c = g.eos + 28 * (g.Nz - 1);
-    auto rho = [&](double t, double s) { return teos10_level(c, sqrt((s + 32.0) * sc), t * 0.025); };
+    auto rho = [&](double t, double s) { return teos10_level(c, sqrt_pos((s + 32.0) * sc), t * 0.025); };
     const double drdT = (rho(Tc + d, Sc) - rho(Tc - d, Sc)) / (2 * d), drdS = (rho(Tc, Sc + d) - rho(Tc, Sc - d)) / (2 * d);
     const double JT = g.top_flux[2] ? (double)g.top_flux[2][o2] : 0.0, JS = g.top_flux[3] ? (double)g.top_flux[3][o2] : 0.0;
     J = (double)g.g * (-drdT * JT - drdS * JS) / (double)g.rho0;

@@ -424,6 +424,21 @@ __device__ __forceinline__ real sym_interp(bool fourth, real q0, real q1, real q
 // ---------------------------------------------------------------------------------------------
 // rho - rho0 at one level from the folded table: 28 coefficients ordered j-major (t-power), i ascending (s-power):
 // [P_0(s): 7][P_1: 6][P_2: 5][P_3: 4][P_4: 3][P_5: 2][P_6: 1];  rho' = sum_j t^j P_j(s).  All in fp64.
+// sqrt of a positive, normal double: the seed and the Newton sequence of the compiler's own expansion of sqrt(double) (so the
+// same bits) without its range scaling (two v_ldexp_f64) and its selects for 0 / inf / denormals -- a third of the expansion,
+// 25 of the 421 fp64-rate instructions of a level of the pressure kernel, which runs at its fp64 issue limit.  The argument of
+// the equation of state, (S + 32) * 0.0249 with S in g/kg, is of order one.
+__device__ __forceinline__ double sqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
 __device__ __forceinline__ double teos10_level(const double* __restrict__ c, double s, double t) {
   double p0 = c[0] + s * (c[1] + s * (c[2] + s * (c[3] + s * (c[4] + s * (c[5] + s * c[6])))));
   double p1 = c[7] + s * (c[8] + s * (c[9] + s * (c[10] + s * (c[11] + s * c[12]))));

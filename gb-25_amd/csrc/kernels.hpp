@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restric
     const int j = min(jb - 1 + r, g.Ny + g.H - 1);    // r = 0 is the helper row south of the thread's rows
     o[r] = ic(g, ic_, j, Nz);
     // b in the first halo cell above the surface: mirrored geopotential height (table row Nz)
-    bup[r] = gr * teos10_level(g.eos + 28 * Nz, sqrt(((double)S[o[r]] + 32.0) * sc), (double)T[o[r]] * 0.025);
+    bup[r] = gr * teos10_level(g.eos + 28 * Nz, sqrt_pos(((double)S[o[r]] + 32.0) * sc), (double)T[o[r]] * 0.025);
     pk[r] = 0.0;
   }
   for (int k = Nz - 1; k >= 0; k--) {
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restric
 #pragma unroll
     for (int r = 0; r <= PR_; r++) {
       o[r] -= g.pl_c;
-      double bk = gr * teos10_level(c, sqrt(((double)S[o[r]] + 32.0) * sc), (double)T[o[r]] * 0.025);
+      double bk = gr * teos10_level(c, sqrt_pos(((double)S[o[r]] + 32.0) * sc), (double)T[o[r]] * 0.025);
       pk[r] = pk[r] - 0.5 * (bk + bup[r]) * dz;
       dbz[r] = (bup[r] - bk) / dz;
       bup[r] = bk;
