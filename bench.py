@@ -11,6 +11,14 @@ resident in HBM before the timed region starts.
 N > 1 is launched by the driver with torch.distributed.run, one rank per GPU: the SAME Nx x Ny x Nz grid (BASELINE.json:
 1440x720x48 at 1/2/4/8 GPUs) cut into N x-slabs, i.e. strong scaling; --weak gives every rank its own Nx x Ny x Nz slab of
 an (N Nx) x Ny x Nz grid instead (the reference's own scaling protocol, sharding/sharded_..._run.jl:82-88).
+
+Time step: 120 s by default (--dt).  The reference's scaling runs step with dt = 1 s (sharding/sharded_..._run.jl:91), its
+quarter-degree climate script quotes 240 s; the cost of a step does not depend on dt, but the state does: with this initial
+condition (S = -5e-3 z: N = 6e-3 / s, first internal mode 7.8 m/s) and 4.9 km between the cells of the rows at 80 degrees,
+AB2 is unstable there from about 200 s on -- at 240 s w grows along the two walls from step 20 and the fields stop being
+finite near step 55 (tools/stability_probe.py; 120 s and 150 s: finite and unremarkable through 600 steps).  A state full of
+NaNs also steps 2 % FASTER than a finite one (fewer toggling bits, higher clocks), so lines longer than 50 steps at 240 s
+flattered the number; `finite` in the output line says which kind of run it was.
 """
 import argparse
 import json
@@ -136,7 +144,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--size", type=int, nargs=3, default=[1440, 720, 48], metavar=("Nx", "Ny", "Nz"))
-    ap.add_argument("--dt", type=float, default=240.0)
+    ap.add_argument("--dt", type=float, default=120.0)
     ap.add_argument("--mesh", default=None, metavar="RxxRy",
                     help="N > 1: a 2-D decomposition, Partition(Rx, Ry, 1) with Rx Ry = N (e.g. 4x2; default: N x slabs)")
     ap.add_argument("--weak", action="store_true", help="N > 1: every rank a full --size slab of an N times wider grid")

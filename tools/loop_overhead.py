@@ -13,7 +13,7 @@ for f in ("gb25_set_baroclinic_instability", "gb25_first_time_step", "gb25_synch
 lib.gb25_loop.argtypes = [P, C.c_int32]
 cfg = Config()
 lib.gb25_default_config(C.byref(cfg), 1440, 720, 48)
-cfg.dt = 240.0
+cfg.dt = 120.0
 h = P()
 assert lib.gb25_create(C.byref(cfg), C.byref(h)) == 0
 lib.gb25_set_baroclinic_instability(h)

@@ -8,7 +8,7 @@ sys.path.insert(0, ".")
 import gb25_amd as gb
 from gb25_amd.distributed import LocalSlabEnsemble
 
-Nx, Ny, Nz, dt, steps = 1440, 720, 48, 240.0, 20
+Nx, Ny, Nz, dt, steps = 1440, 720, 48, 120.0, 20
 m = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt)
 gb.set_baroclinic_instability(m)
 gb.first_time_step(m); gb.loop(m, 5); m.synchronize()

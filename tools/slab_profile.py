@@ -3,7 +3,7 @@ import sys, time
 sys.path.insert(0, "/root/repo")
 from gb25_amd.distributed import LocalSlabEnsemble
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-e = LocalSlabEnsemble(1440, 720, 48, P, dt=240.0)
+e = LocalSlabEnsemble(1440, 720, 48, P, dt=120.0)
 for b in e.backends:
     b.set_baroclinic_instability()
 e.first_time_step(); e.loop(3); e.synchronize()

@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--columns", type=int, default=180)
 ap.add_argument("--size", type=int, nargs=2, default=[720, 48], metavar=("Ny", "Nz"))
 ap.add_argument("--steps", type=int, default=200)
-ap.add_argument("--dt", type=float, default=240.0)
+ap.add_argument("--dt", type=float, default=120.0)
 ap.add_argument("--opt", action="append", default=[])
 ap.add_argument("--lib", default=None, help="another build of libgb25hip.so (A/B on the same box)")
 ap.add_argument("--grid-type", type=int, default=0, help="gb25_grid_type: 0 lat-lon, 1 lat-lon + islands, 3 tripolar, 4 tripolar + islands (the rank is then its own fold partner too)")
