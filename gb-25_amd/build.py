@@ -41,8 +41,12 @@ def build_library(force=False, verbose=False, float_types=("Float32", "Float64")
             # -fno-slp-vectorize: hipcc otherwise packs neighbouring scalar f32 ops into v_pk_* pairs, which on these
             # stencil kernels costs ~140 v_mov per kernel and 20-30 VGPRs for no throughput gain; measured 177 -> 217
             # steps/s at 1440x720x48 (profiles/r01_tuning_log.md).  Values that are born as pairs are packed by hand.
+            # -amdgpu-use-amdgpu-trackers: the scheduler measures register pressure with the AMDGPU-specific trackers; the
+            # schedules it then picks for the two tendency kernels at their register limits are better: momentum launch 1.2144
+            # -> 1.1965 ms, 421.9 -> 424.2 steps/s (same box, three alternating triples with the max-ilp strategy as the third
+            # variant: 409; profiles/r03_tuning_log.md).  Scheduling only: no arithmetic changes.
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-                   "-fno-slp-vectorize", f"-DGB25_REAL={ctype}", "-o", tmp] + SOURCES + ["-ldl"]
+                   "-fno-slp-vectorize", "-mllvm", "-amdgpu-use-amdgpu-trackers", f"-DGB25_REAL={ctype}", "-o", tmp] + SOURCES + ["-ldl"]
             if verbose:
                 print(" ".join(cmd))
             procs.append((cmd, subprocess.Popen(cmd), tmp, out))

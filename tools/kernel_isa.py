@@ -7,7 +7,7 @@ SRC = os.path.join(ROOT, "gb-25_amd", "csrc", "gb25_api.hip")
 pat, t = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "float")
 with tempfile.TemporaryDirectory() as d:
     out = os.path.join(d, "k.s")
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-use-amdgpu-trackers",
                     "-Wno-unused-value", "-Wno-pass-failed", f"-DGB25_REAL={t}", "--cuda-device-only", "-S", SRC,
                     "-o", out], check=True, capture_output=True)
     lines = open(out).read().split("\n")

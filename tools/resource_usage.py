@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gb-25_amd", "csrc", "gb25_api.hip")
 for t in sys.argv[1:] or ["float", "double"]:
     with tempfile.TemporaryDirectory() as d:
-        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-use-amdgpu-trackers",
                             "-Wno-unused-value", "-Wno-pass-failed", f"-DGB25_REAL={t}", "--cuda-device-only", "-c",
                             "-Rpass-analysis=kernel-resource-usage", SRC, "-o", os.path.join(d, "o.o")],
                            capture_output=True, text=True)
