@@ -426,7 +426,7 @@ __device__ __forceinline__ real sym_interp(bool fourth, real q0, real q1, real q
 // [P_0(s): 7][P_1: 6][P_2: 5][P_3: 4][P_4: 3][P_5: 2][P_6: 1];  rho' = sum_j t^j P_j(s).  All in fp64.
 // sqrt of a positive, normal double: the seed and the Newton sequence of the compiler's own expansion of sqrt(double) (so the
 // same bits) without its range scaling (two v_ldexp_f64) and its selects for 0 / inf / denormals -- a third of the expansion,
-// 25 of the 421 fp64-rate instructions of a level of the pressure kernel, which runs at its fp64 issue limit.  The argument of
+// 50 of the 421 instructions of a level of the pressure kernel (five evaluations), whose time is its dependent fp64 chains.  The argument of
 // the equation of state, (S + 32) * 0.0249 with S in g/kg, is of order one.
 __device__ __forceinline__ double sqrt_pos(double x) {
   const double y = __builtin_amdgcn_rsq(x);

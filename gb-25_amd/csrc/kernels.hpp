@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void k_compute_w(Grid g, const real* __restric
 // dpx = p'(i)-p'(i-1) and dpy = p'(j)-p'(j-1) (small numbers, fp32 storage is then harmless).
 // Mapping: a wave is 64 consecutive columns of which lane 0 only feeds lane 1's west difference (tiles advance by
 // 63); a thread marches R = 4 adjacent rows plus the row south of them at once, which also gives the fp64 EOS
-// chains 5-way instruction-level parallelism.  fp64 VALU is half rate on gfx950; the depth dependence of the
+// chains 5-way instruction-level parallelism.  (v_fma_f64 issues at the full rate on gfx950 -- tools/micro/pk_rate.hip -- the kernel's time is the latency of its chains); the depth dependence of the
 // 55-term polynomial is folded per level on the host (28 fp64 FMAs per evaluation).
 constexpr int PR = 4;   // rows per thread of the full-range launch
 // Columns [i_first, i_last] are written (whole extended range: -H+1 .. Nx+H-2; a slab of a decomposition does

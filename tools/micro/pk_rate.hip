@@ -7,6 +7,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <class T> struct W { static constexpr int n = 1; };
 template <> struct W<v2f> { static constexpr int n = 2; };
+template <> struct W<double> { static constexpr int n = 1; };
 
 template <class T, int OP, int ILP>
 __global__ void k(float* out, int iters, float a, float b) {
@@ -22,10 +23,10 @@ __global__ void k(float* out, int iters, float a, float b) {
         if (OP == 0) x[q] = x[q] * A + B;       // fma (contracted)
         if (OP == 1) x[q] = x[q] * A;           // mul
         if (OP == 2) x[q] = x[q] + B;           // add
-        if constexpr (OP == 3 && W<T>::n == 1) x[q] = __builtin_amdgcn_rcpf(x[q]);                 // v_rcp_f32
-        if constexpr (OP == 4 && W<T>::n == 1) x[q] = __builtin_amdgcn_sqrtf(x[q]);                // v_sqrt_f32
+        if constexpr (OP == 3 && sizeof(T) == 4) x[q] = __builtin_amdgcn_rcpf(x[q]);                 // v_rcp_f32
+        if constexpr (OP == 4 && sizeof(T) == 4) x[q] = __builtin_amdgcn_sqrtf(x[q]);                // v_sqrt_f32
         if constexpr (OP == 5 && W<T>::n == 1) x[q] = x[q] > B ? A : x[q];                         // v_cmp + v_cndmask
-        if constexpr (OP == 6 && W<T>::n == 1) {                                                   // one v_rcp_f32 among three fmas
+        if constexpr (OP == 6 && sizeof(T) == 4) {                                                   // one v_rcp_f32 among three fmas
           x[q] = (r & 3) == 0 ? __builtin_amdgcn_rcpf(x[q]) : x[q] * A + B;
         }
       }
@@ -35,7 +36,7 @@ __global__ void k(float* out, int iters, float a, float b) {
 #pragma unroll
   for (int q = 0; q < ILP; q++) s += x[q];
   float r;
-  if constexpr (W<T>::n == 2) r = s.x + s.y; else r = s;
+  if constexpr (W<T>::n == 2) r = s.x + s.y; else r = (float)s;
   if (r == 123.456f) out[0] = r;
 }
 
@@ -73,5 +74,8 @@ int main() {
   run<float, 4, 1>("v_sqrt_f32", d);   run<float, 4, 4>("v_sqrt_f32", d);
   run<float, 5, 1>("v_cmp+v_cndmask", d); run<float, 5, 4>("v_cmp+v_cndmask", d);
   run<float, 6, 4>("1 rcp : 3 fma", d);
+  // fp64 (the pressure kernel's arithmetic)
+  run<double, 0, 1>("v_fma_f64", d);   run<double, 0, 4>("v_fma_f64", d);
+  run<double, 1, 4>("v_mul_f64", d);   run<double, 2, 4>("v_add_f64", d);
   return 0;
 }
