@@ -988,9 +988,21 @@ gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = IN
   }
   const int nrow = j_last - j_first + 1;
   const int tiles_a = (ncol + 62) / 63, tiles_b = (ncol_b + 62) / 63;
-  // strips and narrow slabs: one row per thread (4x the waves, short chains) -- with four rows per thread a 180-column
-  // slab is 138 blocks on 256 CUs and the fp64 chains run at their latency (0.14 ms, against 0.31 ms for 1440 columns)
-  if ((tiles_a + tiles_b) * ((nrow + PR * 4 - 1) / (PR * 4)) < 1024) {
+  // strips and narrow slabs: with four rows per thread a 180-column slab is 138 blocks on 256 CUs and the fp64 chains run at
+  // their latency (0.14 ms, against 0.31 ms for 1440 columns): one row per thread (4x the waves, 2.03 evaluations per cell).
+  // The narrowest of them on the lat-lon grid take the tile form: a wave = 16 columns x 4 rows, one evaluation per thread and
+  // level, 15 x 3 written cells (a block of four waves: 12 rows) -- 5.6x the waves of the four-row form, 1.42 evaluations per
+  // cell, rows of 64 B.  Same box, one rank alone: 180 columns 0.497 -> 0.484 ms per step, 360: 0.808 -> 0.794, the 4 x 2 mesh
+  // rank 0.518 -> 0.510; but 720 columns 1.358 -> 1.401 and the folded grid's slabs 0.614 -> 0.617 (180) and 0.978 -> 1.018 (360)
+  // beside their heavier curvilinear neighbours: those keep the one-row form.
+  const bool narrow = (tiles_a + tiles_b) * ((nrow + PR * 4 - 1) / (PR * 4)) < 1024;
+  if (narrow && !g.cv.on && ncol + ncol_b <= 400) {
+    const int ta = (i_last - i_first + 1 + 14) / 15, tb = ncol_b ? (i_last_b - i_first_b + 1 + 14) / 15 : 0;
+    dim3 gr(ta + tb, (nrow + 11) / 12);
+    auto kern = write_p ? k_compute_p_tile<true> : k_compute_p_tile<false>;
+    hipLaunchKernelGGL(kern, gr, b, 0, m->stream, g, Tsrc, Ssrc, m->f[GB25_PHY].d, dpx_out, dpy_out, i_first, i_last,
+                       i_first_b, i_last_b, ta, n2, j_first, j_last);
+  } else if (narrow) {
     dim3 gr(tiles_a + tiles_b, (nrow + 3) / 4);
     auto kern = write_p ? k_compute_p<1, true> : k_compute_p<1, false>;
     hipLaunchKernelGGL(kern, gr, b, 0, m->stream, g, Tsrc, Ssrc, m->f[GB25_PHY].d, dpx_out, dpy_out, i_first, i_last,

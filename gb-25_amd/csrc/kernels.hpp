@@ -412,8 +412,9 @@ __global__ __launch_bounds__(256) void k_compute_w(Grid g, const real* __restric
 constexpr int PR = 4;   // rows per thread of the full-range launch
 // Columns [i_first, i_last] are written (whole extended range: -H+1 .. Nx+H-2; a slab of a decomposition does
 // its interior early and the strips next to the x halos once those have arrived).
-// PR_: rows per thread.  4 for the full range (five evaluations per level share one helper row); 1 for the narrow
-// strips of a slab, which have too few waves to hide latency behind each other and want short per-level chains.
+// PR_: rows per thread.  4 for the full range (five evaluations per level share one helper row); 1 for the narrow launches of
+// a decomposition, which have too few waves to hide latency behind each other and want short per-level chains (the narrowest of
+// them on the lat-lon grid take k_compute_p_tile below).
 // WRITE_P = false: only the two differences the momentum kernel consumes are stored; pHY' itself is a diagnostic
 // that the host side then materialises on demand (gb25_api.hip, phy_stale).
 template <int PR_, bool WRITE_P>
@@ -473,6 +474,50 @@ __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restric
         dpy[o[r]] = (real)(pk[r] - pk[r - 1]);
         if (n2 != nullptr && k < Nz - 1) n2[o[r] + g.pl_c] = (real)dbz[r];
       }
+    }
+  }
+}
+// The same pressure for the narrow launches of a decomposition (a slab's own columns, the strips next to its halos), which have
+// too few waves to hide the latency of their chains: a wave is a tile of 16 columns x 4 rows -- lane = 16 ly + lx -- whose first
+// column and first row are the helpers of the two differences, both fetched by lane shuffles; ONE evaluation per thread and
+// level, 1.42 per written cell (45 of 64 lanes write) against 2.03 for the one-row form of k_compute_p (a helper row per
+// thread), and 1.4 x the waves.  Same operands, same operations per cell: the same bits.
+template <bool WRITE_P>
+__global__ __launch_bounds__(256) void k_compute_p_tile(Grid g, const real* __restrict__ T, const real* __restrict__ S,
+                                                        real* __restrict__ p, real* __restrict__ dpx, real* __restrict__ dpy,
+                                                        int i_first, int i_last, int i_first_b, int i_last_b, int tiles_a,
+                                                        real* __restrict__ n2, int j_first, int j_last) {
+  const int lane = threadIdx.x, lx = lane & 15, ly = lane >> 4;
+  const bool second = (int)blockIdx.x >= tiles_a;
+  if (second) {
+    i_first = i_first_b;
+    i_last = i_last_b;
+  }
+  const int i = i_first - 1 + ((int)blockIdx.x - (second ? tiles_a : 0)) * 15 + lx;            // lx = 0: helper column
+  const int j = j_first - 1 + (int)(blockIdx.y * blockDim.y + threadIdx.y) * 3 + ly;           // ly = 0: helper row
+  if (j_first + (int)(blockIdx.y * blockDim.y + threadIdx.y) * 3 > j_last) return;             // whole wave leaves together
+  const int Nz = g.Nz;
+  const double gr = -(double)g.g / (double)g.rho0;
+  const double sc = 0.875 / 35.16504;
+  int o = ic(g, min(i, g.Nx + g.H - 1), min(j, g.Ny + g.H - 1), Nz);                           // clamp: addresses stay in the parent
+  const bool writes = lx >= 1 && ly >= 1 && i <= i_last && j <= j_last;
+  // b in the first halo cell above the surface: mirrored geopotential height (table row Nz)
+  double bup = gr * teos10_level(g.eos + 28 * Nz, sqrt_pos(((double)S[o] + 32.0) * sc), (double)T[o] * 0.025);
+  double pk = 0.0;
+  for (int k = Nz - 1; k >= 0; k--) {
+    const double* c = g.eos + 28 * k;
+    const double dz = g.dzf_d[k + 1];
+    o -= g.pl_c;
+    const double bk = gr * teos10_level(c, sqrt_pos(((double)S[o] + 32.0) * sc), (double)T[o] * 0.025);
+    pk = pk - 0.5 * (bk + bup) * dz;
+    const double dbz = (bup - bk) / dz;
+    bup = bk;
+    const double pw = __shfl_up(pk, 1), ps = __shfl_up(pk, 16);
+    if (writes) {
+      if (WRITE_P) p[o] = (real)pk;
+      dpx[o] = (real)(pk - pw);
+      dpy[o] = (real)(pk - ps);
+      if (n2 != nullptr && k < Nz - 1) n2[o + g.pl_c] = (real)dbz;
     }
   }
 }
