@@ -23,6 +23,7 @@ FIELD_IDS = {
     "Gn.U": 20, "Gn.V": 21,
     # closure = CATKEVerticalDiffusivity() only
     "e": 22, "Gn.e": 23, "Gm.e": 24, "kappa_u": 25, "kappa_c": 26, "kappa_e": 27, "Le": 28, "Jb": 29,
+    "previous_u": 30, "previous_v": 31,   # diffusivity_fields.previous_velocities (CATKE)
 }
 METRIC2_IDS = ["dxfc", "dxcc", "dxcf", "dxff", "dyfc", "dycc", "dycf", "dyff", "azcc", "azfc", "azcf", "azff", "fff", "phicc"]
 METRIC_IDS = {"phif": 0, "phic": 1, "dxc": 2, "dxf": 3, "azc": 4, "azf": 5, "fcor": 6,
@@ -56,7 +57,8 @@ ABI_SYMBOLS = [
 # gb25_option (include/gb25.h)
 OPTION_IDS = {"kernels": 0, "ab2_lookahead": 1, "subcycle_lookahead": 2, "subcycle_block": 3, "fill_fused": 4,
               "two_streams": 5, "store_pressure": 6, "split_tendencies": 7, "pressure_precision": 8, "immersed_kernels": 9, "fold_fills": 10,
-              "lazy_corrector": 11, "momentum_chunk_levels": 12, "tracer_chunk_levels": 13, "tracers_first": 14, "w_on_the_fly": 15, "sub_stream_priority": 16, "subcycle_whole": 17, "early_strips": 18}
+              "lazy_corrector": 11, "momentum_chunk_levels": 12, "tracer_chunk_levels": 13, "tracers_first": 14, "w_on_the_fly": 15, "sub_stream_priority": 16, "subcycle_whole": 17, "early_strips": 18,
+              "catke_stale_e_halos": 19}
 UNIQUE_ID_BYTES = 128
 # int32 fn(void *user, int32 buffer_set, const void *send_w, const void *send_e, void *recv_w, void *recv_e, int64 nbytes)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
@@ -67,13 +69,15 @@ class CatkeParameters(C.Structure):
     _fields_ = [("Cs", C.c_double), ("Cb", C.c_double), ("Csp", C.c_double), ("CRid", C.c_double), ("CRi0", C.c_double),
                 ("Chi", C.c_double * 4), ("Clo", C.c_double * 4), ("Cun", C.c_double * 4), ("Cc", C.c_double * 4),
                 ("Ce", C.c_double * 4), ("CWu", C.c_double), ("CWw", C.c_double), ("minimum_tke", C.c_double),
-                ("minimum_convective_buoyancy_flux", C.c_double), ("negative_tke_damping_time_scale", C.c_double)]
+                ("minimum_convective_buoyancy_flux", C.c_double), ("negative_tke_damping_time_scale", C.c_double),
+                ("CWeps", C.c_double)]
 
     def as_list(self):
         out = [self.Cs, self.Cb, self.Csp, self.CRid, self.CRi0]
         for a in (self.Chi, self.Clo, self.Cun, self.Cc, self.Ce):
             out += list(a)
-        return out + [self.CWu, self.CWw, self.minimum_tke, self.minimum_convective_buoyancy_flux, self.negative_tke_damping_time_scale]
+        return out + [self.CWu, self.CWw, self.minimum_tke, self.minimum_convective_buoyancy_flux, self.negative_tke_damping_time_scale,
+                      self.CWeps]
 
 
 class Config(C.Structure):
@@ -94,6 +98,12 @@ class GB25Error(RuntimeError):
 
 
 _libs = {}
+_stale_loaded = set()   # float types whose library was loaded although its sources are newer
+
+
+def library_stale(float_type="Float32"):
+    """True when load_library fell back to a binary older than its sources (no compiler on the host, or GB25_ALLOW_STALE=1)."""
+    return float_type in _stale_loaded
 
 
 def load_library(float_type="Float32"):
@@ -116,11 +126,19 @@ def load_library(float_type="Float32"):
                     raise GB25Error(
                         f"{path} not found and building it failed ({e}): run `python -c 'import __graft_entry__ as g; "
                         "g.build()'` (hipcc --offload-arch=gfx950).  gb25_amd has no CPU fallback.") from e
-                # a loadable library exists (an rsync / checkout that touched the sources' mtimes on a box whose hipcc does
-                # not work, a read-only install): use it, loudly
+                # A loadable library exists but is older than its sources.  Loading it would let tests and bench.py report
+                # numbers of a build that is not HEAD, so that is an error -- unless there is no compiler at all on this
+                # host (FileNotFoundError: a box that only runs what was built elsewhere) or the caller opts in with
+                # GB25_ALLOW_STALE=1.  Either way the fact is recorded (library_stale(), bench.py's "library_stale").
+                no_compiler = isinstance(e, FileNotFoundError)
+                if not (no_compiler or os.environ.get("GB25_ALLOW_STALE") == "1"):
+                    raise GB25Error(
+                        f"{path} is older than its sources and rebuilding it failed ({e}).  Fix the build, or set "
+                        "GB25_ALLOW_STALE=1 (or GB25_LIB=1 to skip the check) to load the existing binary.") from e
                 import warnings
                 warnings.warn(f"gb25_amd: {path} is older than its sources and rebuilding it failed ({e}); "
                               "loading the existing binary", RuntimeWarning)
+                _stale_loaded.add(float_type)
     if not os.path.exists(path):
         raise GB25Error(f"{path} not found.  gb25_amd has no CPU fallback.")
     # One HIP runtime per process.  PyTorch ships its own copies of libamdhip64 / libhsa-runtime64 / librccl; were this

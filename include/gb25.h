@@ -60,6 +60,9 @@ typedef enum {
    * model.diffusivity_fields as src/correctness.jl:60-67 compares them: kappa_u, kappa_c, kappa_e at (Center, Center,
    * Face) [Nz + 1 levels], L^e at cell centres, the surface buoyancy flux J^b (2-D) */
   GB25_E, GB25_GN_E, GB25_GM_E, GB25_KAPPA_U, GB25_KAPPA_C, GB25_KAPPA_E, GB25_LE, GB25_JB,
+  /* ... and diffusivity_fields.previous_velocities (u, v at the previous compute_diffusivities!: CATKE's shear production
+   * is centred between them and the current ones); not in the compared set, exposed for state transfer and tests */
+  GB25_PREV_U, GB25_PREV_V,
   GB25_FIELD_COUNT
 } gb25_field;
 
@@ -151,6 +154,9 @@ typedef enum {
   GB25_OPT_EARLY_STRIPS,         /* [1] x slab of a decomposition: the bundle is unpacked on the exchange stream right behind its transfer
                                     and the pressure strips next to the x halos follow it there, beside the interior momentum pass;
                                     0: unpack and strips on the main stream when it gets there */
+  GB25_OPT_CATKE_STALE_E_HALOS,  /* [0] closure = CATKE, single domain: 1 = the halo cells of e are NOT refilled after e is stepped inside
+                                    compute_diffusivities! (Oceananigans as recalled: the tendencies that follow see halos one e step old);
+                                    0 = refilled.  A RESTATEMENT choice, not a schedule: it changes results */
   GB25_OPT_COUNT
 } gb25_option;
 
@@ -313,6 +319,7 @@ typedef struct {
   double Cc[4], Ce[4];             /* convective and entrainment lengths */
   double CWu, CWw;                 /* surface TKE flux: friction velocity and convective velocity terms */
   double minimum_tke, minimum_convective_buoyancy_flux, negative_tke_damping_time_scale;
+  double CWeps;                    /* bottom TKE flux J^e = -CWeps e^(3/2), implicit in the bottom cell (CATKEEquation's C^W_epsilon = 1) */
 } gb25_catke_parameters;
 void gb25_default_catke_parameters(gb25_catke_parameters *p);
 gb25_status gb25_set_catke_parameters(gb25_model *m, const gb25_catke_parameters *p);

@@ -64,6 +64,7 @@ enum {
   /* closure = CATKEVerticalDiffusivity(): the TKE tracer e with its tendencies, the diffusivity fields the reference
    * compares (kappa_u, kappa_c, kappa_e at (c,c,f); L^e at (c,c,c); J^b 2-D: /root/reference/src/correctness.jl:60-67) */
   F_E, F_GNE, F_GME, F_KU, F_KC, F_KE, F_LE, F_JB,
+  F_UM, F_VM, /* diffusivity_fields.previous_velocities: u, v at the previous compute_diffusivities! (CATKE's shear production) */
   F_COUNT
 };
 
@@ -107,6 +108,8 @@ typedef struct {
   REAL nu, kappa;
   int catke; /* closure = CATKEVerticalDiffusivity() */
   void *catke_params; /* its parameters when they are not the defaults (catke_par, below) */
+  double catke_prev_time;   /* diffusivity_fields.previous_compute_time */
+  int catke_stale_e_halos;  /* 1: the halos of e are NOT refilled after the e step inside compute_diffusivities! (upstream as recalled) */
   int curv, north_fold;
   REAL *dxfc2, *dxcc2, *dxcf2, *dxff2, *dyfc2, *dycc2, *dycf2, *dyff2, *azcc2, *azfc2, *azcf2, *azff2, *fff2, *phicc2;
   double *lamcc_d, *phicc_d; /* cell-centre coordinates in degrees (double), interior Nx x Ny, for analytic bottoms */
@@ -529,7 +532,7 @@ void *FN(create)(const gb25o_config *c) {
     free(zb);
   }
   for (int id = 0; id < F_COUNT; id++) {
-    int isv = (id == F_V || id == F_GNV || id == F_GMV || id == F_BV || id == F_VB || id == F_GBV);
+    int isv = (id == F_V || id == F_GNV || id == F_GMV || id == F_BV || id == F_VB || id == F_GBV || id == F_VM);
     int isw = (id == F_W || id == F_KU || id == F_KC || id == F_KE);
     int twod = (id >= F_ETA && id <= F_GBV) || id == F_JB;
     alloc_field(m, id, isv, isw, twod);
@@ -633,11 +636,7 @@ long FN(get_iteration)(void *h) { return ((model *)h)->iter; }
 #ifndef PREAL
 #define PREAL REAL /* precision of the equation of state and of the hydrostatic integral */
 #endif
-static inline PREAL teos10_rho(PREAL Theta, PREAL Sa, PREAL Z) {
-  const PREAL t = Theta * (PREAL)0.025;
-  const PREAL s = (PREAL)sqrt((double)((Sa + (PREAL)32.0) * (PREAL)(0.875 / 35.16504)));
-  const PREAL z = -Z * (PREAL)1e-4;
-  const PREAL R000 = 8.0189615746e+02, R100 = 8.6672408165e+02, R200 = -1.7864682637e+03,
+static const PREAL R000 = 8.0189615746e+02, R100 = 8.6672408165e+02, R200 = -1.7864682637e+03,
              R300 = 2.0375295546e+03, R400 = -1.2849161071e+03, R500 = 4.3227585684e+02,
              R600 = -6.0579916612e+01, R010 = 2.6010145068e+01, R110 = -6.5281885265e+01,
              R210 = 8.1770425108e+01, R310 = -5.6888046321e+01, R410 = 1.7681814114e+01,
@@ -655,8 +654,12 @@ static inline PREAL teos10_rho(PREAL Theta, PREAL Sa, PREAL Z) {
              R202 = 2.5019633244e+00, R012 = 2.0564311499e+00, R112 = -2.1311365518e-01,
              R022 = -1.2419983026e+00, R003 = -2.3342758797e-02, R103 = -1.8507636718e-02,
              R013 = 3.7969820455e-01;
-  const PREAL R00 = 4.6494977072e+01, R01 = -5.2099962525e+00, R02 = 2.2601900708e-01,
+static const PREAL R00 = 4.6494977072e+01, R01 = -5.2099962525e+00, R02 = 2.2601900708e-01,
              R03 = 6.4326772569e-02, R04 = 1.5616995503e-02, R05 = -1.7243708991e-03;
+static inline PREAL teos10_rho(PREAL Theta, PREAL Sa, PREAL Z) {
+  const PREAL t = Theta * (PREAL)0.025;
+  const PREAL s = (PREAL)sqrt((double)((Sa + (PREAL)32.0) * (PREAL)(0.875 / 35.16504)));
+  const PREAL z = -Z * (PREAL)1e-4;
   PREAL r3 = R013 * t + R103 * s + R003;
   PREAL r2 = (R022 * t + R112 * s + R012) * t + (R202 * s + R102) * s + R002;
   PREAL r1 = (((R041 * t + R131 * s + R031) * t + (R221 * s + R121) * s + R021) * t +
@@ -672,6 +675,50 @@ static inline PREAL teos10_rho(PREAL Theta, PREAL Sa, PREAL Z) {
   return rz + rp;
 }
 double FN(teos10_rho)(double T, double S, double Z) { return (double)teos10_rho((PREAL)(REAL)T, (PREAL)(REAL)S, (PREAL)(REAL)Z); }
+/* thermal_sensitivity = -d rho / d Theta and haline_sensitivity = d rho / d S_A of the same polynomial, differentiated term
+ * by term (SeawaterPolynomials tabulates these derivatives as polynomials of their own: the same numbers up to the rounding of
+ * its tables).  thermal_expansion = a / reference_density, haline_contraction = b / reference_density. */
+static inline void teos10_sensitivities(PREAL Theta, PREAL Sa, PREAL Z, PREAL *a, PREAL *b) {
+  const PREAL t = Theta * (PREAL)0.025;
+  const PREAL s = (PREAL)sqrt((double)((Sa + (PREAL)32.0) * (PREAL)(0.875 / 35.16504)));
+  const PREAL z = -Z * (PREAL)1e-4;
+  /* the coefficient of t^j of r_k as a polynomial in s, and its derivative */
+  const PREAL A00 = (((((R600 * s + R500) * s + R400) * s + R300) * s + R200) * s + R100), dA00 = ((((6 * R600 * s + 5 * R500) * s + 4 * R400) * s + 3 * R300) * s + 2 * R200) * s + R100;
+  (void)A00;
+  const PREAL A10 = ((((R510 * s + R410) * s + R310) * s + R210) * s + R110) * s + R010, dA10 = (((5 * R510 * s + 4 * R410) * s + 3 * R310) * s + 2 * R210) * s + R110;
+  const PREAL A20 = (((R420 * s + R320) * s + R220) * s + R120) * s + R020, dA20 = ((4 * R420 * s + 3 * R320) * s + 2 * R220) * s + R120;
+  const PREAL A30 = ((R330 * s + R230) * s + R130) * s + R030, dA30 = (3 * R330 * s + 2 * R230) * s + R130;
+  const PREAL A40 = (R240 * s + R140) * s + R040, dA40 = 2 * R240 * s + R140;
+  const PREAL A50 = R150 * s + R050, dA50 = R150;
+  const PREAL A60 = R060;
+  const PREAL dA01 = ((4 * R401 * s + 3 * R301) * s + 2 * R201) * s + R101;
+  const PREAL A11 = ((R311 * s + R211) * s + R111) * s + R011, dA11 = (3 * R311 * s + 2 * R211) * s + R111;
+  const PREAL A21 = (R221 * s + R121) * s + R021, dA21 = 2 * R221 * s + R121;
+  const PREAL A31 = R131 * s + R031, dA31 = R131;
+  const PREAL A41 = R041;
+  const PREAL dA02 = 2 * R202 * s + R102;
+  const PREAL A12 = R112 * s + R012, dA12 = R112;
+  const PREAL A22 = R022;
+  const PREAL dA03 = R103, A13 = R013;
+  /* d r_k / d t and d r_k / d s */
+  const PREAL r0t = ((((6 * A60 * t + 5 * A50) * t + 4 * A40) * t + 3 * A30) * t + 2 * A20) * t + A10;
+  const PREAL r1t = ((4 * A41 * t + 3 * A31) * t + 2 * A21) * t + A11;
+  const PREAL r2t = 2 * A22 * t + A12;
+  const PREAL r3t = A13;
+  const PREAL r0s = ((((dA50 * t + dA40) * t + dA30) * t + dA20) * t + dA10) * t + dA00;
+  const PREAL r1s = ((dA31 * t + dA21) * t + dA11) * t + dA01;
+  const PREAL r2s = dA12 * t + dA02;
+  const PREAL r3s = dA03;
+  const PREAL drdt = ((r3t * z + r2t) * z + r1t) * z + r0t, drds = ((r3s * z + r2s) * z + r1s) * z + r0s;
+  *a = -(drdt * (PREAL)0.025);
+  *b = drds * ((PREAL)(0.875 / 35.16504) / ((PREAL)2 * s));
+}
+/* (tests) out[0] = -d rho / d Theta, out[1] = d rho / d S_A */
+void FN(teos10_sensitivities)(double T, double S, double Z, double *out) {
+  PREAL a, b;
+  teos10_sensitivities((PREAL)(REAL)T, (PREAL)(REAL)S, (PREAL)(REAL)Z, &a, &b);
+  out[0] = (double)a; out[1] = (double)b;
+}
 
 /* geopotential height of a cell centre, mirrored through the boundary outside 1..Nz
  * (Oceananigans Z^ccc, restated). */
@@ -1368,29 +1415,54 @@ void FN(set_vertical_diffusivity)(void *h, double nu, double kappa) {
 
 /* ---------------------------------------------------------------- CATKE
  * closure = CATKEVerticalDiffusivity() (/root/reference/sharding/less_simple_sharding_problem.jl:84-93,
- * /root/reference/src/baroclinic_instability_model.jl:30,50-51; compared fields /root/reference/src/correctness.jl:60-67),
- * Oceananigans.TurbulenceClosures.TKEBasedVerticalDiffusivities restated [UPSTREAM-UNVERIFIED] after Wagner et al.
- * (2025), "Formulation and calibration of CATKE, a one-equation parameterization for microscale ocean mixing".
+ * /root/reference/src/baroclinic_instability_model.jl:30,50-51; compared fields /root/reference/src/correctness.jl:60-67).
+ * Restated [UPSTREAM-UNVERIFIED] in the STRUCTURE of Oceananigans 0.96 (TurbulenceClosures/.../TKEBasedVerticalDiffusivities:
+ * catke_vertical_diffusivity.jl, catke_mixing_length.jl, catke_equation.jl, time_step_catke_equation.jl,
+ * tke_top_boundary_condition.jl) as recalled -- the package is not in /root/reference -- with the calibrated constants of
+ * Wagner et al. (2025), "Formulation and calibration of CATKE, a one-equation parameterization for microscale ocean mixing".
  *
- *   de/dt = -div(u e) + d/dz(kappa_e de/dz) + kappa_u S^2 - kappa_c N^2 - e^(3/2)/l_D,   kappa_psi = l_psi sqrt(e)
+ * compute_diffusivities!(diffusivities, closure::CATKE, model), called by compute_auxiliaries! inside update_state!:
+ *   1. dt_c = clock.time - previous_compute_time                       (the time the surface-flux filter advances by)
+ *   2. if isfinite(clock.last_dt): time_step_catke_equation!(model)    -- GB-25 sets clock.last_dt = dt when it builds the model
+ *        (src/baroclinic_instability_model.jl:82), so e is stepped in EVERY update_state!, the first one included.
+ *        substep_turbulent_kinetic_energy! per cell, from the state as it is (kappa_u, kappa_c, J^b: the fields of the
+ *        previous compute; e, T, S, u, v: current; u-, v-: the velocities of the previous compute):
+ *          kappa_e  <- kappa_e(c,c,f) of the current state
+ *          wb       = Iz(-kappa_c N^2);  P = shear_production(kappa_u; u-, u+, v-, v+)
+ *          L^e      = min(wb, 0)/e [e > e_min] - omega - [on the bottom] C^W_eps sqrt(max(e, 0))/dz,
+ *                     omega = e < 0 ? 1/tau_neg : sqrt|e| / l_D(c,c,c)
+ *          G_total  = G^n.e (the "slow" tendency: advection + the top TKE flux, left by compute_tendencies!) + P + max(wb, 0)
+ *          e       += dt ((3/2 + chi) G_total - (1/2 + chi) G^-.e);  G^-.e <- G_total        (chi = 0.1 always: no Euler step here)
+ *        then implicit_step!(e): (1 - dt dz kappa_e dz - dt L^e) e_new = e.
+ *        ab2_step! skips e and cache_previous_tendencies! skips G^-.e.
+ *   3. u-, v- <- u, v (parents)
+ *   4. compute_average_surface_buoyancy_flux!: J^b* = g (alpha J^T - beta J^S) from the top flux boundary conditions,
+ *        J^b+ = max(J^b_min, J^b, J^b*), t* = cbrt(l_D(i,j,Nz)^2 / J^b+), eps = dt_c / t*, J^b <- (J^b + eps J^b*)/(1 + eps)
+ *   5. compute_CATKE_diffusivities!: kappa_u, kappa_c, kappa_e at the faces k = 1 .. Nz from the new e.
+ * then fill_halo_regions!(diffusivity_fields; only_local_halos = true) (/root/reference/src/precompile.jl:37,117-119).
  *
- * At (c,c,f) faces, with e, N^2 = db/dz, S^2 = Ix((du/dz)^2) + Iy((dv/dz)^2), Ri = N^2/S^2 there, w* = sqrt(max(e,0)):
- *   stable length     l* = min(C^s d_surface, C^b d_bottom, wstar / N)                                  (N^2 > 0, else no N limit)
- *   stability fn      sigma_psi(Ri) = C^un_psi (Ri < 0);  C^lo_psi + (C^hi_psi - C^lo_psi) step((Ri - CRi0)/CRid) (Ri >= 0)
- *   convective length l^h = C^c_psi w*^3 / J^b+ * max(0, 1 - C^sp sqrt(S^2) w*^2 / J^b+)  where J^b > J^b_min and N^2 < 0;
- *                     l^e = C^e_psi J^b+ / (w* N^2 + J^b_min) just below such a layer (N^2 >= 0 here, < 0 above)
- *   l_psi = max(l_conv, sigma_psi l*);   dissipation: l_D = max(l_conv(C^c_D, C^e_D), l* / sigma_D(Ri))
- * TKE equation per cell: P = Iz(kappa_u S^2); wb = Iz(-kappa_c N^2); omega = sqrt|e| / Iz(l_D);
- *   explicit: P + max(wb, 0) (+ the surface flux -(C^W_u* u*^3 + C^W_wD w_D^3) in the top cell);
- *   implicit linear term L^e = -omega + min(wb, 0)/e [e > e_min] - [e < 0]/tau_neg.
- * Restatement choices of this file: the surface buoyancy flux J^b is the instantaneous one (no time filter); with the
- * default no-flux boundary conditions J^b = 0 and u* = 0; N^2 and S^2 vanish on the bottom and top faces; e steps like the
- * other tracers (AB2 of advection + explicit TKE terms, then the implicit solve with kappa_e and L^e), T, S with kappa_c,
- * u, v with kappa_u averaged to their columns. */
+ * Mixing lengths at (c,c,f), with w* = Iz sqrt(max(e_min, e)), w*^2 = Iz max(e_min, e), w*^3 = Iz max(e_min, e)^(3/2),
+ * N^2 = g (alpha(Iz T, Iz S, z_f) dz T - beta dz S) (SeawaterBuoyancy's dz_b; differences across an immersed face vanish),
+ * S^2 = Ix (dz u)^2 + Iy (dz v)^2, Ri = N^2/S^2 (0 where N^2 = 0):
+ *   stable length     l* = min(C^s depth, C^b height above the bottom, wstar / N [N^2 > 0])
+ *   stability fn      sigma_psi(Ri) = C^un_psi (Ri < 0);  C^lo_psi + (C^hi_psi - C^lo_psi) clamp((Ri - CRi0)/CRid, 0, 1) (Ri >= 0)
+ *   convective length l^c = max(0, eps^sp C^c_psi w*^3/(J^b + J^b_min)) where J^b > J^b_min and N^2 < 0,
+ *                     l^e = max(0, eps^sp C^e_psi J^b/(w* N^2 + J^b_min)) where J^b > J^b_min, N^2 > 0 and N^2 < 0 on the face above,
+ *                     eps^sp = 1 - C^sp sqrt(S^2) w*^2/(J^b + J^b_min)
+ *   l_psi = min(H, max(sigma_psi l*, l^conv)), H = the static column depth;   kappa_psi = l_psi w*
+ * Dissipation length at (c,c,c): min(H, max(lstar(c,c,c) / sigma_D(Ri(c,c,c)), Iz l^conv(C^c_D, C^e_D))), with N^2 and S^2
+ * averaged to the centre and w* = sqrt(max(e_min, e)) of the cell.
+ *
+ * Choices this restatement had to make where the recalled source leaves room (a Julia dump of the `catke_*` case of
+ * tools/dump_goldens.jl settles them): the in-place update of e inside substep_turbulent_kinetic_energy! is read as
+ * "every cell sees the OLD e of its neighbours" (what the traced/functional Reactant program computes; a serial CPU loop
+ * over k would see the new e of the level below); the halos of e are refilled after the e step (option, default on:
+ * upstream, as recalled, leaves them one e step stale until the next update_state!; a decomposition cannot reproduce that
+ * at its internal boundaries); L^e = 0 and J^b = 0 in immersed cells / land columns (upstream would divide 0 by 0 there). */
 typedef struct {
   REAL Cs, Cb, Csp, CRid, CRi0;
   REAL Chi[4], Clo[4], Cun[4], Cc[4], Ce[4]; /* psi = u, c, e, D */
-  REAL CWu, CWw, emin, Jbmin, tau_neg;
+  REAL CWu, CWw, emin, Jbmin, tau_neg, CWeps;
 } catke_par;
 static const catke_par CATKE_DEFAULT = {
   (REAL)1.131, (REAL)0.28, (REAL)0.505, (REAL)1.02, (REAL)0.254,
@@ -1399,14 +1471,14 @@ static const catke_par CATKE_DEFAULT = {
   {(REAL)0.370, (REAL)0.369, (REAL)1.447, (REAL)0.923},
   {(REAL)3.705, (REAL)4.793, (REAL)3.642, (REAL)3.254},
   {(REAL)0.0, (REAL)0.112, (REAL)0.0, (REAL)0.0},
-  (REAL)3.179, (REAL)0.383, (REAL)1e-9, (REAL)1e-11, (REAL)60.0};
+  (REAL)3.179, (REAL)0.383, (REAL)1e-9, (REAL)1e-11, (REAL)60.0, (REAL)1.0};
 
 static inline const catke_par *catke_parameters_of(const model *m) {
   return m->catke_params ? (const catke_par *)m->catke_params : &CATKE_DEFAULT;
 }
 #define CATKE (*catke_parameters_of(m))
 /* the parameters as 31 doubles in the order of gb25_catke_parameters (include/gb25.h): Cs, Cb, Csp, CRid, CRi0, Chi[4], Clo[4],
- * Cun[4], Cc[4], Ce[4], CWu, CWw, minimum TKE, minimum convective buoyancy flux, damping time scale of negative TKE */
+ * Cun[4], Cc[4], Ce[4], CWu, CWw, minimum TKE, minimum convective buoyancy flux, damping time scale of negative TKE, CWeps */
 void FN(set_catke_parameters)(void *h, const double *p) {
   model *m = (model *)h;
   if (!m->catke_params) m->catke_params = malloc(sizeof(catke_par));
@@ -1416,6 +1488,7 @@ void FN(set_catke_parameters)(void *h, const double *p) {
     c->Chi[q] = (REAL)p[5 + q]; c->Clo[q] = (REAL)p[9 + q]; c->Cun[q] = (REAL)p[13 + q]; c->Cc[q] = (REAL)p[17 + q]; c->Ce[q] = (REAL)p[21 + q];
   }
   c->CWu = (REAL)p[25]; c->CWw = (REAL)p[26]; c->emin = (REAL)p[27]; c->Jbmin = (REAL)p[28]; c->tau_neg = (REAL)p[29];
+  c->CWeps = (REAL)p[30];
 }
 static inline REAL catke_step(REAL x, REAL c, REAL w) {
   REAL t = (x - c) / w;
@@ -1425,95 +1498,209 @@ static inline REAL catke_sigma(const model *m, int psi, REAL Ri) {
   if (Ri < 0) return CATKE.Cun[psi];
   return CATKE.Clo[psi] + (CATKE.Chi[psi] - CATKE.Clo[psi]) * catke_step(Ri, CATKE.CRi0, CATKE.CRid);
 }
-/* N^2 at face k (between cells k-1 and k; 1-based), zero on the boundary faces and next to the solid */
-static inline REAL catke_N2(const model *m, int i, int j, int k) {
-  if (k <= 1 || k > m->Nz || inactive_cell(m, i, j, k - 1) || inactive_cell(m, i, j, k)) return 0;
-  return (REAL)((buoyancy(m, i, j, k) - buoyancy(m, i, j, k - 1)) / (PREAL)DZF(k));
+/* both cells of the (c,c,f) face k (between the cells k-1 and k) are active */
+static inline int catke_open_face(const model *m, int i, int j, int k) {
+  return k >= 2 && k <= m->Nz && !inactive_cell(m, i, j, k - 1) && !inactive_cell(m, i, j, k);
 }
-static inline REAL catke_S2(const model *m, int i, int j, int k) {
+/* dz_b(i, j, k, grid, ::SeawaterBuoyancy, tracers) = g (alpha dzT - beta dzS) at (c,c,f), alpha and beta at the vertically
+ * averaged T, S and the depth of the face; the vertical differences of T, S vanish across a face that touches the solid, and
+ * on the bottom / top faces by the no-flux halo fill */
+static inline REAL catke_N2(const model *m, int i, int j, int k) {
+  if (!catke_open_face(m, i, j, k)) return 0;
+  PREAL Tl = (PREAL)A3(F_T, i, j, k - 1), Th = (PREAL)A3(F_T, i, j, k), Sl = (PREAL)A3(F_S, i, j, k - 1), Sh = (PREAL)A3(F_S, i, j, k);
+  PREAL a, b;
+  teos10_sensitivities((Tl + Th) / (PREAL)2, (Sl + Sh) / (PREAL)2, (PREAL)MK(zf, k), &a, &b);
+  PREAL rdz = (PREAL)1 / (PREAL)DZF(k);
+  return (REAL)((PREAL)m->g * (a * ((Th - Tl) * rdz) - b * ((Sh - Sl) * rdz)) / (PREAL)m->rho0);
+}
+/* dz at (f,c,f) / (c,f,f) of a velocity component: zero where one of the two nodes it differences is an inactive node (both
+ * cells beside it inactive), and on the bottom / top faces */
+static inline REAL catke_dzu(const model *m, int id, int i, int j, int k) {
   if (k <= 1 || k > m->Nz) return 0;
-  REAL uw = (A3(F_U, i, j, k) - A3(F_U, i, j, k - 1)) / DZF(k), ue = (A3(F_U, i + 1, j, k) - A3(F_U, i + 1, j, k - 1)) / DZF(k);
-  REAL vs = (A3(F_V, i, j, k) - A3(F_V, i, j, k - 1)) / DZF(k), vn = (A3(F_V, i, j + 1, k) - A3(F_V, i, j + 1, k - 1)) / DZF(k);
+  if ((inactive_cell(m, i - 1, j, k) && inactive_cell(m, i, j, k)) || (inactive_cell(m, i - 1, j, k - 1) && inactive_cell(m, i, j, k - 1))) return 0;
+  return (A3(id, i, j, k) - A3(id, i, j, k - 1)) / DZF(k);
+}
+static inline REAL catke_dzv(const model *m, int id, int i, int j, int k) {
+  if (k <= 1 || k > m->Nz) return 0;
+  if ((inactive_cell(m, i, j - 1, k) && inactive_cell(m, i, j, k)) || (inactive_cell(m, i, j - 1, k - 1) && inactive_cell(m, i, j, k - 1))) return 0;
+  return (A3(id, i, j, k) - A3(id, i, j, k - 1)) / DZF(k);
+}
+/* shear(c,c,f) = Ix (dz u)^2 + Iy (dz v)^2 of the current velocities */
+static inline REAL catke_S2(const model *m, int i, int j, int k) {
+  REAL uw = catke_dzu(m, F_U, i, j, k), ue = catke_dzu(m, F_U, i + 1, j, k);
+  REAL vs = catke_dzv(m, F_V, i, j, k), vn = catke_dzv(m, F_V, i, j + 1, k);
   return (uw * uw + ue * ue) / (REAL)2 + (vs * vs + vn * vn) / (REAL)2;
 }
-typedef struct { REAL ku, kc, ke, lD, P, wb; } catke_face;
+static inline REAL catke_tke_floor(const model *m, int i, int j, int k) {   /* max(minimum_tke, e) */
+  REAL e = A3(F_E, i, j, k);
+  return e > CATKE.emin ? e : CATKE.emin;
+}
+static inline REAL catke_zbottom(const model *m, int i, int j) { return MK(zf, KB(i, j) + 1); }
+typedef struct { REAL ku, kc, ke, convD, N2, S2; } catke_face;
 static catke_face catke_at_face(const model *m, int i, int j, int k) {
   catke_face f = {0, 0, 0, 0, 0, 0};
-  int Nz = m->Nz;
-  if (k <= 1 || k > Nz || inactive_cell(m, i, j, k - 1) || inactive_cell(m, i, j, k)) return f;
-  REAL ef = (A3(F_E, i, j, k - 1) + A3(F_E, i, j, k)) / (REAL)2;
-  REAL ep = ef > 0 ? ef : 0, ws = (REAL)sqrt((double)ep);
-  REAL N2 = catke_N2(m, i, j, k), S2 = catke_S2(m, i, j, k);
-  REAL Ri = (N2 == 0) ? 0 : N2 / S2;
-  REAL d_up = CATKE.Cs * (MK(zf, Nz + 1) - MK(zf, k)), d_dn = CATKE.Cb * (MK(zf, k) - MK(zf, KB(i, j) + 1));
+  const int Nz = m->Nz;
+  if (k <= 1 || k > Nz) return f;
+  f.S2 = catke_S2(m, i, j, k);
+  if (!catke_open_face(m, i, j, k)) return f;   /* (there l* = 0 -- no height above the bottom -- and N^2 = 0: every length vanishes) */
+  const REAL el = catke_tke_floor(m, i, j, k - 1), eh = catke_tke_floor(m, i, j, k);
+  const REAL wl = (REAL)sqrt((double)el), wh = (REAL)sqrt((double)eh);
+  const REAL ws = (wl + wh) / (REAL)2, ws2 = (wl * wl + wh * wh) / (REAL)2, ws3 = (wl * wl * wl + wh * wh * wh) / (REAL)2;
+  const REAL N2 = catke_N2(m, i, j, k), N2above = catke_N2(m, i, j, k + 1), S2 = f.S2;
+  f.N2 = N2;
+  const REAL Ri = (N2 == 0) ? 0 : N2 / S2;
+  REAL d_up = CATKE.Cs * (MK(zf, Nz + 1) - MK(zf, k)), d_dn = CATKE.Cb * (MK(zf, k) - catke_zbottom(m, i, j));
+  if (d_up < 0) d_up = 0;
+  if (d_dn < 0) d_dn = 0;
   REAL ls = d_up < d_dn ? d_up : d_dn;
   if (N2 > 0) {
     REAL lN = ws / (REAL)sqrt((double)N2);
     if (lN < ls) ls = lN;
   }
-  REAL Jb = A2(F_JB, i, j), Jbp = Jb > CATKE.Jbmin ? Jb : CATKE.Jbmin;
-  REAL N2above = catke_N2(m, i, j, k + 1);
-  int convecting = (Jb > CATKE.Jbmin) && (N2 < 0), entraining = (Jb > CATKE.Jbmin) && (N2 >= 0) && (N2above < 0);
-  REAL lconv[4];
-  for (int p = 0; p < 4; p++) {
-    REAL lh = CATKE.Cc[p] * ws * ws * ws / Jbp;
-    REAL esp = (REAL)1 - CATKE.Csp * (REAL)sqrt((double)S2) * ws * ws / Jbp;
-    lh *= esp > 0 ? esp : 0;
-    REAL le = CATKE.Ce[p] * Jbp / (ws * N2 + CATKE.Jbmin);
-    lconv[p] = convecting ? lh : (entraining ? le : 0);
+  const REAL Hcol = H2(Hcc, i, j), Jb = A2(F_JB, i, j), Jbe = CATKE.Jbmin;
+  const int convecting = (Jb > Jbe) && (N2 < 0), entraining = (Jb > Jbe) && (N2 > 0) && (N2above < 0);
+  REAL lconv[4] = {0, 0, 0, 0};
+  if (convecting || entraining) {
+    const REAL Sp = (REAL)sqrt((double)S2) * ws2 / (Jb + Jbe), esp = (REAL)1 - CATKE.Csp * Sp;
+    for (int p = 0; p < 4; p++) {
+      REAL l = convecting ? CATKE.Cc[p] * ws3 / (Jb + Jbe) : CATKE.Ce[p] * Jb / (ws * N2 + Jbe);
+      l *= esp;
+      lconv[p] = l > 0 ? l : 0;
+    }
   }
   REAL lpsi[3];
   for (int p = 0; p < 3; p++) {
     REAL l = catke_sigma(m, p, Ri) * ls;
-    lpsi[p] = lconv[p] > l ? lconv[p] : l;
+    l = lconv[p] > l ? lconv[p] : l;
+    lpsi[p] = l < Hcol ? l : Hcol;
   }
   f.ku = lpsi[0] * ws; f.kc = lpsi[1] * ws; f.ke = lpsi[2] * ws;
-  REAL lD = ls / catke_sigma(m, 3, Ri);
-  f.lD = lconv[3] > lD ? lconv[3] : lD;
-  f.P = f.ku * S2;
-  f.wb = -f.kc * N2;
+  f.convD = lconv[3];
   return f;
 }
-/* J^b = g (alpha J^T - beta J^S) at the surface from the top flux boundary conditions of T and S (zero without them);
- * alpha, beta by centred differences of the equation of state in fp64 */
-static void catke_surface_buoyancy_flux(model *m) {
-  for (int j = 1; j <= m->Ny; j++)
-    for (int i = 1; i <= m->Nx; i++) {
-      double Jb = 0;
-      if (m->top_flux[2] || m->top_flux[3]) {
-        long o = ((long)i - 1 + HH) + (long)m->f[F_T].sx * ((long)j - 1 + HH);
-        double T = A3(F_T, i, j, m->Nz), S = A3(F_S, i, j, m->Nz), Z = MK(zc, m->Nz), d = 1e-2;
-        double drdT = ((double)teos10_rho((PREAL)(T + d), (PREAL)S, (PREAL)Z) - (double)teos10_rho((PREAL)(T - d), (PREAL)S, (PREAL)Z)) / (2 * d);
-        double drdS = ((double)teos10_rho((PREAL)T, (PREAL)(S + d), (PREAL)Z) - (double)teos10_rho((PREAL)T, (PREAL)(S - d), (PREAL)Z)) / (2 * d);
-        double JT = m->top_flux[2] ? m->top_flux[2][o] : 0, JS = m->top_flux[3] ? m->top_flux[3][o] : 0;
-        Jb = (double)m->g * (-drdT * JT - drdS * JS) / (double)m->rho0;   /* alpha = -rho_T/rho0, beta = rho_S/rho0 */
-      }
-      A2(F_JB, i, j) = (REAL)Jb;
-    }
-  fill_halo_2d(m, F_JB, 0, 0, 1);
+/* dissipation_length_scale(c,c,c) of the active cell k from its two faces */
+static REAL catke_dissipation_length(const model *m, int i, int j, int k, const catke_face *lo, const catke_face *hi) {
+  const REAL lh = (lo->convD + hi->convD) / (REAL)2;
+  const REAL N2 = (lo->N2 + hi->N2) / (REAL)2, S2 = (lo->S2 + hi->S2) / (REAL)2;
+  const REAL Ri = (N2 == 0) ? 0 : N2 / S2;
+  REAL d_up = CATKE.Cs * (MK(zf, m->Nz + 1) - MK(zc, k)), d_dn = CATKE.Cb * (MK(zc, k) - catke_zbottom(m, i, j));
+  if (d_up < 0) d_up = 0;
+  if (d_dn < 0) d_dn = 0;
+  REAL ls = d_up < d_dn ? d_up : d_dn;
+  if (N2 > 0) {
+    REAL lN = (REAL)sqrt((double)catke_tke_floor(m, i, j, k)) / (REAL)sqrt((double)N2);
+    if (lN < ls) ls = lN;
+  }
+  ls = ls / catke_sigma(m, 3, Ri);
+  const REAL l = lh > ls ? lh : ls, Hcol = H2(Hcc, i, j);
+  return l < Hcol ? l : Hcol;
 }
-/* compute_diffusivities!: kappa_u, kappa_c, kappa_e on the faces, L^e in the cells, then their halos
- * (fill_halo_regions!(model.diffusivity_fields; only_local_halos = true), /root/reference/src/precompile.jl:37,117-119) */
-static void catke_compute_diffusivities(model *m) {
-  int Nz = m->Nz;
-  catke_surface_buoyancy_flux(m);
+/* top_buoyancy_flux: J^b* = g (alpha J^T - beta J^S) of the instantaneous top flux boundary conditions of T and S (zero
+ * without them), alpha and beta at the surface cell */
+static REAL catke_top_buoyancy_flux(const model *m, int i, int j) {
+  if (!(m->top_flux[2] || m->top_flux[3]) || inactive_cell(m, i, j, m->Nz)) return 0;
+  long o = ((long)i - 1 + HH) + (long)m->f[F_T].sx * ((long)j - 1 + HH);
+  PREAL a, b;
+  teos10_sensitivities((PREAL)A3(F_T, i, j, m->Nz), (PREAL)A3(F_S, i, j, m->Nz), (PREAL)MK(zc, m->Nz), &a, &b);
+  PREAL JT = m->top_flux[2] ? (PREAL)m->top_flux[2][o] : 0, JS = m->top_flux[3] ? (PREAL)m->top_flux[3][o] : 0;
+  return (REAL)((PREAL)m->g * (a * JT - b * JS) / (PREAL)m->rho0);
+}
+/* shear_production(c,c,c): Ix of [Iz(nu dz u- dzf dz u+) + Iz(nu dz u+ dzf dz u+)] / (2 dzc) at the x faces, likewise in y;
+ * nu = kappa_u of the previous compute averaged to the face's column */
+static inline REAL catke_dz_nu_uu(const model *m, int ida, int i, int j, int k) {
+  REAL nu = (A3(F_KU, i - 1, j, k) + A3(F_KU, i, j, k)) / (REAL)2;
+  return nu * catke_dzu(m, ida, i, j, k) * DZF(k) * catke_dzu(m, F_U, i, j, k);
+}
+static inline REAL catke_dz_nu_vv(const model *m, int ida, int i, int j, int k) {
+  REAL nu = (A3(F_KU, i, j - 1, k) + A3(F_KU, i, j, k)) / (REAL)2;
+  return nu * catke_dzv(m, ida, i, j, k) * DZF(k) * catke_dzv(m, F_V, i, j, k);
+}
+static inline REAL catke_Px(const model *m, int i, int j, int k) {
+  REAL n = (catke_dz_nu_uu(m, F_UM, i, j, k) + catke_dz_nu_uu(m, F_UM, i, j, k + 1)) / (REAL)2;
+  REAL p = (catke_dz_nu_uu(m, F_U, i, j, k) + catke_dz_nu_uu(m, F_U, i, j, k + 1)) / (REAL)2;
+  return (n + p) / ((REAL)2 * DZC(k));
+}
+static inline REAL catke_Py(const model *m, int i, int j, int k) {
+  REAL n = (catke_dz_nu_vv(m, F_VM, i, j, k) + catke_dz_nu_vv(m, F_VM, i, j, k + 1)) / (REAL)2;
+  REAL p = (catke_dz_nu_vv(m, F_V, i, j, k) + catke_dz_nu_vv(m, F_V, i, j, k + 1)) / (REAL)2;
+  return (n + p) / ((REAL)2 * DZC(k));
+}
+/* time_step_catke_equation!(model): substep_turbulent_kinetic_energy! + implicit_step!(e) with dt = clock.last_dt */
+static void catke_time_step_tke(model *m) {
+  const int Nx = m->Nx, Ny = m->Ny, Nz = m->Nz;
+  const REAL dt = m->dt, C1 = (REAL)1.5 + m->chi, C2 = (REAL)0.5 + m->chi;
+  REAL *enew = (REAL *)malloc(sizeof(REAL) * (size_t)Nx * Ny * Nz);
+#pragma omp parallel for schedule(static)
+  for (int j = 1; j <= Ny; j++)
+    for (int i = 1; i <= Nx; i++) {
+      catke_face lo = catke_at_face(m, i, j, 1);
+      A3(F_KE, i, j, 1) = 0;
+      for (int k = 1; k <= Nz; k++) {
+        catke_face hi = catke_at_face(m, i, j, k + 1);
+        A3(F_KE, i, j, k + 1) = hi.ke;
+        const REAL e = A3(F_E, i, j, k);
+        REAL L = 0, en = e;
+        if (!inactive_cell(m, i, j, k)) {
+          const REAL wb = (-(A3(F_KC, i, j, k) * lo.N2) + -(A3(F_KC, i, j, k + 1) * hi.N2)) / (REAL)2;
+          const REAL wbm = wb < 0 ? wb : 0, wbp = wb > 0 ? wb : 0;
+          const REAL lD = catke_dissipation_length(m, i, j, k, &lo, &hi);
+          const REAL omega = e < 0 ? (REAL)1 / CATKE.tau_neg : (REAL)sqrt(fabs((double)e)) / lD;
+          const int on_bottom = inactive_cell(m, i, j, k - 1);
+          const REAL ep = e > 0 ? e : 0;
+          const REAL divJ = on_bottom ? -(CATKE.CWeps * (REAL)sqrt((double)ep) / DZC(k)) : 0;
+          L = (e > CATKE.emin ? wbm / e : 0) - omega + divJ;
+          const REAL P = (catke_Px(m, i, j, k) + catke_Px(m, i + 1, j, k)) / (REAL)2 + (catke_Py(m, i, j, k) + catke_Py(m, i, j + 1, k)) / (REAL)2;
+          const REAL total = A3(F_GNE, i, j, k) + (P + wbp);
+          en = e + dt * (C1 * total - C2 * A3(F_GME, i, j, k));
+          A3(F_GME, i, j, k) = total;
+        }
+        A3(F_LE, i, j, k) = L;
+        enew[(i - 1) + (size_t)Nx * ((j - 1) + (size_t)Ny * (k - 1))] = en;
+        lo = hi;
+      }
+    }
+  for (int k = 1; k <= Nz; k++)
+    for (int j = 1; j <= Ny; j++)
+      for (int i = 1; i <= Nx; i++) A3(F_E, i, j, k) = enew[(i - 1) + (size_t)Nx * ((j - 1) + (size_t)Ny * (k - 1))];
+  free(enew);
+  implicit_step_field_catke(m, F_E, 3, dt);
+}
+/* compute_average_surface_buoyancy_flux!: the surface buoyancy flux filtered over the convective time scale t* */
+static void catke_average_surface_buoyancy_flux(model *m, double dt_since) {
+  const int Nz = m->Nz;
 #pragma omp parallel for schedule(static)
   for (int j = 1; j <= m->Ny; j++)
     for (int i = 1; i <= m->Nx; i++) {
-      catke_face lo = catke_at_face(m, i, j, 1);
+      if (inactive_cell(m, i, j, Nz)) { A2(F_JB, i, j) = 0; continue; }
+      const REAL Jstar = catke_top_buoyancy_flux(m, i, j), J = A2(F_JB, i, j);
+      catke_face lo = catke_at_face(m, i, j, Nz), hi = catke_at_face(m, i, j, Nz + 1);
+      const REAL lD = catke_dissipation_length(m, i, j, Nz, &lo, &hi);
+      REAL Jp = CATKE.Jbmin;
+      if (J > Jp) Jp = J;
+      if (Jstar > Jp) Jp = Jstar;
+      const REAL tstar = (REAL)cbrt((double)(lD * lD / Jp)), eps = (REAL)dt_since / tstar;
+      A2(F_JB, i, j) = (J + eps * Jstar) / ((REAL)1 + eps);
+    }
+  fill_halo_2d(m, F_JB, 0, 0, 1);
+}
+/* compute_diffusivities!: see the header of this section; then the halos of the diffusivity fields
+ * (fill_halo_regions!(model.diffusivity_fields; only_local_halos = true), /root/reference/src/precompile.jl:37,117-119) */
+static void catke_compute_diffusivities(model *m) {
+  int Nz = m->Nz;
+  const double dt_since = m->time - m->catke_prev_time;
+  m->catke_prev_time = m->time;
+  catke_time_step_tke(m);   /* (clock.last_dt is finite from the model's construction on: src/baroclinic_instability_model.jl:82) */
+  if (!m->catke_stale_e_halos) fill_halo_3d(m, F_E, 0, 0, 1);
+  memcpy(m->f[F_UM].p, m->f[F_U].p, sizeof(REAL) * (size_t)m->f[F_U].sx * m->f[F_U].sy * m->f[F_U].sz);
+  memcpy(m->f[F_VM].p, m->f[F_V].p, sizeof(REAL) * (size_t)m->f[F_V].sx * m->f[F_V].sy * m->f[F_V].sz);
+  catke_average_surface_buoyancy_flux(m, dt_since);
+#pragma omp parallel for schedule(static)
+  for (int j = 1; j <= m->Ny; j++)
+    for (int i = 1; i <= m->Nx; i++) {
       A3(F_KU, i, j, 1) = A3(F_KC, i, j, 1) = A3(F_KE, i, j, 1) = 0;
-      for (int k = 1; k <= Nz; k++) {
-        catke_face hi = catke_at_face(m, i, j, k + 1);
-        A3(F_KU, i, j, k + 1) = hi.ku; A3(F_KC, i, j, k + 1) = hi.kc; A3(F_KE, i, j, k + 1) = hi.ke;
-        REAL e = A3(F_E, i, j, k), L = 0;
-        if (!inactive_cell(m, i, j, k)) {
-          REAL lD = (lo.lD + hi.lD) / (REAL)2, wb = (lo.wb + hi.wb) / (REAL)2;
-          REAL omega = lD > 0 ? (REAL)sqrt(fabs((double)e)) / lD : 0;
-          REAL wbm = wb < 0 ? wb : 0;
-          L = -omega + (e > CATKE.emin ? wbm / e : 0) - (e < 0 ? (REAL)1 / CATKE.tau_neg : 0);
-        }
-        A3(F_LE, i, j, k) = L;
-        lo = hi;
+      for (int k = 2; k <= Nz + 1; k++) {
+        catke_face f = catke_at_face(m, i, j, k);
+        A3(F_KU, i, j, k) = f.ku; A3(F_KC, i, j, k) = f.kc; A3(F_KE, i, j, k) = f.ke;
       }
     }
   /* a14: zero-gradient y layer and periodic x of the face-located diffusivities (no z layer: the boundary faces carry
@@ -1529,22 +1716,14 @@ static void catke_compute_diffusivities(model *m) {
   }
   fill_halo_3d(m, F_LE, 0, 0, 1);
 }
-/* G^n.e = -div(u e) + shear production + the positive part of the buoyancy flux + the surface TKE flux */
+/* the "slow" tendency of e that compute_tendencies! leaves in G^n.e: -div(u e) and the top boundary condition of e,
+ * Q^e = -C^W_u* u*^3 - C^W_wD w_D^3 (tke_top_boundary_condition.jl), w_D^3 = max(J^b*, 0) dz with the INSTANTANEOUS J^b* */
 static void catke_tke_tendency(model *m) {
   int Nz = m->Nz;
   tracer_tendency(m, F_GNE, f_E);
 #pragma omp parallel for schedule(static)
   for (int j = 1; j <= m->Ny; j++)
     for (int i = 1; i <= m->Nx; i++) {
-      catke_face lo = catke_at_face(m, i, j, 1);
-      for (int k = 1; k <= Nz; k++) {
-        catke_face hi = catke_at_face(m, i, j, k + 1);
-        if (!inactive_cell(m, i, j, k)) {
-          REAL wb = (lo.wb + hi.wb) / (REAL)2;
-          A3(F_GNE, i, j, k) += (lo.P + hi.P) / (REAL)2 + (wb > 0 ? wb : 0);
-        }
-        lo = hi;
-      }
       if (!inactive_cell(m, i, j, Nz)) {
         long o = ((long)i - 1 + HH) + (long)m->f[F_U].sx * ((long)j - 1 + HH), ov = ((long)i - 1 + HH) + (long)m->f[F_V].sx * ((long)j - 1 + HH);
         /* u* from the boundary-condition values at (i, j), not interpolated to the cell centre: Oceananigans'
@@ -1552,13 +1731,14 @@ static void catke_tke_tendency(model *m) {
         REAL Ju = m->top_flux[0] ? m->top_flux[0][o] : 0;
         REAL Jv = m->top_flux[1] ? m->top_flux[1][ov] : 0;
         REAL us2 = (REAL)sqrt((double)(Ju * Ju + Jv * Jv)), us3 = us2 * (REAL)sqrt((double)us2);   /* u*^2, u*^3 */
-        REAL Jb = A2(F_JB, i, j), wD3 = (Jb > 0 ? Jb : 0) * DZC(Nz);
+        REAL Jb = catke_top_buoyancy_flux(m, i, j), wD3 = (Jb > 0 ? Jb : 0) * DZC(Nz);
         REAL Qe = -(CATKE.CWu * us3 + CATKE.CWw * wD3);
         A3(F_GNE, i, j, Nz) -= Qe / DZC(Nz);
       }
     }
 }
 void FN(set_catke)(void *h, int on) { ((model *)h)->catke = on != 0; }
+void FN(set_catke_stale_e_halos)(void *h, int on) { ((model *)h)->catke_stale_e_halos = on != 0; }
 
 /* ---------------------------------------------------------------- AB2 + free surface
  * ab2_step!(model, dt) -- /root/reference/src/precompile.jl:39,121-123 (appendix A.4, A.7). */
@@ -1741,13 +1921,11 @@ void FN(ab2_step)(void *h, double dt_, int euler) {
   ab2_field(m, F_S, F_GNS, F_GMS, dt, chi, 0);
   implicit_step_field(m, F_T, 2, m->kappa, dt);
   implicit_step_field(m, F_S, 2, m->kappa, dt);
-  if (m->catke) {   /* (the diffusivity fields are those of the last update_state!) */
+  if (m->catke) {   /* (the diffusivity fields are those of the last update_state!; e is skipped: stepped inside compute_diffusivities!) */
     implicit_step_field_catke(m, F_U, 0, dt);
     implicit_step_field_catke(m, F_V, 1, dt);
     implicit_step_field_catke(m, F_T, 2, dt);
     implicit_step_field_catke(m, F_S, 2, dt);
-    ab2_field(m, F_E, F_GNE, F_GME, dt, chi, 0);
-    implicit_step_field_catke(m, F_E, 3, dt);
   }
   step_free_surface(m, dt);
 }
@@ -1770,10 +1948,7 @@ void FN(correct_and_cache)(void *h) {
     for (int k = 1; k <= m->Nz; k++)
       for (int j = 1; j <= (q == 1 ? NYV : m->Ny); j++)
         for (int i = 1; i <= m->Nx; i++) A3(F_GMU + q, i, j, k) = A3(F_GNU + q, i, j, k);
-  if (m->catke)
-    for (int k = 1; k <= m->Nz; k++)
-      for (int j = 1; j <= m->Ny; j++)
-        for (int i = 1; i <= m->Nx; i++) A3(F_GME, i, j, k) = A3(F_GNE, i, j, k);
+  /* (closure = CATKE: G^-.e is written by the e step itself -- cache_previous_tendencies! skips e) */
 }
 /* initialize!(model): barotropic velocities from the 3-D velocities + their halos */
 void FN(initialize)(void *h) {

@@ -30,6 +30,7 @@ FIELD_IDS = {
     "eta": 14, "U": 15, "V": 16, "eta_bar": 17, "U_bar": 18, "V_bar": 19, "Gn.U": 20, "Gn.V": 21,
     # closure = CATKEVerticalDiffusivity(): the TKE tracer and the diffusivity fields (src/correctness.jl:60-67)
     "e": 22, "Gn.e": 23, "Gm.e": 24, "kappa_u": 25, "kappa_c": 26, "kappa_e": 27, "Le": 28, "Jb": 29,
+    "previous_u": 30, "previous_v": 31,
 }
 METRIC_IDS = {"phif": 0, "phic": 1, "dxc": 2, "dxf": 3, "azc": 4, "azf": 5, "fcor": 6,
               "zf": 7, "zc": 8, "dzc": 9, "dzf": 10}
@@ -184,6 +185,25 @@ class OracleBackend:
         f.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         f(self.h, a)
 
+    def set_option(self, name, value):
+        """The restatement choices the library exposes as options (same names); its schedule options mean nothing here."""
+        fn = {"catke_stale_e_halos": "set_catke_stale_e_halos"}.get(name)
+        if fn is None:
+            raise KeyError(f"the oracle has no option {name!r}")
+        f = self._fn(fn)
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int]
+        f(self.h, int(value))
+
+    def teos10_sensitivities(self, T, S, Z):
+        """(-d rho / d Theta, d rho / d S_A) of the oracle's TEOS-10 polynomial."""
+        f = self._fn("teos10_sensitivities")
+        f.restype = None
+        f.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
+        out = (C.c_double * 2)()
+        f(float(T), float(S), float(Z), out)
+        return out[0], out[1]
+
     def set_vertical_diffusivity(self, nu, kappa):
         f = self._fn("set_vertical_diffusivity")
         f.restype = None
@@ -276,6 +296,15 @@ class OracleBackend:
             return
         a = np.ascontiguousarray(np.asarray(J, dtype=np.float64).reshape(self.field_dims(name, False)[:2]).T)
         f(self.h, q, a.ctypes.data_as(C.c_void_p))
+
+    def get_top_flux(self, name):
+        f = self._fn("get_top_flux")
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        nx, ny = self.field_dims(name, False)[:2]
+        a = np.zeros((ny, nx), dtype=np.float64)
+        f(self.h, {"u": 0, "v": 1, "T": 2, "S": 3}[name], a.ctypes.data_as(C.c_void_p))
+        return np.ascontiguousarray(a.T)
+
     def set_tracer_advection_order(self, order):
         f = self._fn("set_tracer_advection_order")
         f.restype = None

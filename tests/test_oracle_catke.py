@@ -1,7 +1,8 @@
 """Known-answer pins of the CATKE restatement (oracle): closure = CATKEVerticalDiffusivity() of
 src/baroclinic_instability_model.jl:30 / sharding/less_simple_sharding_problem.jl:84-93 -- SURVEY.md section 8f.2.
 [UPSTREAM-UNVERIFIED: formulas and calibrated constants after Wagner et al. (2025); no Oceananigans here to compare with.]
- * the diffusivities against an independent numpy statement of the mixing-length formulas;
+ * the diffusivities, the TKE step inside compute_diffusivities! and the filtered surface buoyancy flux against an independent
+   numpy statement of the formulas (tests/catke_spec.py); alpha and beta against finite differences of the polynomial;
  * with no TKE, no shear and stable stratification nothing mixes; TKE decays at the dissipation rate;
  * wind stress: surface TKE flux -> TKE, diffusivities, a deepening mixed layer; tracer column integrals conserved;
  * surface cooling: convective branch (J^b > 0, N^2 < 0) switches on;
@@ -12,15 +13,7 @@ import pytest
 import gb25_amd as gb
 from helpers import make_oracle, set_noisy_velocities
 
-P = dict(Cs=1.131, Cb=0.28, Csp=0.505, CRid=1.02, CRi0=0.254,
-         Chi=(0.242, 0.098, 0.548, 0.579), Clo=(0.361, 0.198, 7.863, 1.604), Cun=(0.370, 0.369, 1.447, 0.923),
-         Cc=(3.705, 4.793, 3.642, 3.254), Ce=(0.0, 0.112, 0.0, 0.0), Jbmin=1e-11)
-
-
-def sigma(p, Ri):
-    if Ri < 0:
-        return P["Cun"][p]
-    return P["Clo"][p] + (P["Chi"][p] - P["Clo"][p]) * min(1.0, max(0.0, (Ri - P["CRi0"]) / P["CRid"]))
+import catke_spec as spec
 
 
 def catke_model(Nx=16, Ny=12, Nz=16, dt=60.0, **kw):
@@ -36,45 +29,90 @@ def stratified(m, N2=1e-5):
     return zc
 
 
-def test_diffusivities_match_an_independent_statement_of_the_formulas():
-    Nx, Ny, Nz = 16, 12, 16
-    m = catke_model(Nx, Ny, Nz)
+def developed(Nx=12, Ny=10, Nz=14, dt=120.0, steps=4):
+    """a model a few steps into a wind- and cooling-driven run: every term of the TKE equation is alive"""
+    m = catke_model(Nx, Ny, Nz, dt=dt, depth=150.0)
     zc = stratified(m, 2e-5)
     rng = np.random.default_rng(0)
-    e = 1e-4 * rng.random((Nx, Ny, Nz)) + 1e-6
-    u = 0.05 * rng.standard_normal((Nx, Ny, Nz))
-    m.set(e=e, u=u)
+    T = m.tracers.T.interior.copy()
+    T[:, :, -3:] = T[:, :, -4:-3] - 0.05 * (1 + np.arange(3))   # a statically unstable skin under the cooled surface: N^2 < 0 on the top faces
+    m.set(e=1e-4 * rng.random((Nx, Ny, Nz)) + 1e-6, u=0.05 * rng.standard_normal((Nx, Ny, Nz)), T=T,
+          S=np.broadcast_to(35.0 - 2e-3 * zc, (Nx, Ny, Nz)).copy())
+    gb.set_top_flux(m, u=np.full((Nx, Ny), -1e-4), T=1e-5 + 4e-5 * rng.random((Nx, Ny)))
+    gb.first_time_step(m)
+    gb.loop(m, steps)
+    return m
+
+
+def test_sensitivities_are_the_derivatives_of_the_polynomial():
+    m = catke_model()
+    for (T, S, Z) in ((10.0, 35.0, -1000.0), (25.0, 33.0, -5.0), (2.0, 36.5, -3500.0)):
+        a, b = m.backend.teos10_sensitivities(T, S, Z)
+        h = 1e-4
+        fa = -(m.backend.teos10_rho(T + h, S, Z) - m.backend.teos10_rho(T - h, S, Z)) / (2 * h)
+        fb = (m.backend.teos10_rho(T, S + h, Z) - m.backend.teos10_rho(T, S - h, Z)) / (2 * h)
+        assert a == pytest.approx(fa, rel=1e-6) and b == pytest.approx(fb, rel=1e-6)
+    a, b = m.backend.teos10_sensitivities(10.0, 35.0, -1000.0)
+    assert 1.5e-4 < a / 1020.0 < 2.0e-4 and 7.0e-4 < b / 1020.0 < 8.0e-4      # thermal expansion / haline contraction of sea water
+
+
+def test_diffusivities_match_an_independent_statement_of_the_formulas():
+    m = developed()
+    st = spec.State(m)                     # kappa of the last compute_diffusivities! were made from exactly this e, J^b, u, v, T, S
+    F = spec.face_quantities(st)
+    for name, key in (("ku", "kappa_u"), ("kc", "kappa_c"), ("ke", "kappa_e")):
+        got = getattr(m.diffusivity_fields, key).interior
+        assert np.allclose(got, F[name], rtol=2e-6, atol=1e-14), (name, np.abs(got - F[name]).max())
+        assert np.all(got[:, :, 0] == 0) and np.all(got[:, :, -1] == 0) and np.all(got >= 0) and got.max() > 1e-4
+    Jb = m.diffusivity_fields.Jb.interior.reshape(F["N2"].shape[:2])
+    assert Jb.min() > 1e-9                  # the cooling has been felt
+    conv = (F["N2"] < 0) & (Jb[:, :, None] > 1e-11)
+    assert conv.any()                       # ... and the convective branch is exercised by this state
+
+
+def test_the_tke_step_matches_an_independent_statement():
+    """time_step_catke_equation!: the e step of the NEXT update_state! from the state as it is (old kappa_u, kappa_c, J^b,
+    previous velocities), redone in numpy: shear production between the previous and the current velocities, buoyancy flux
+    split into its explicit and implicit parts, dissipation and the bottom flux on the diagonal, AB2 with chi = 0.1, one
+    tridiagonal solve with the new kappa_e."""
+    m = developed()
+    st = spec.State(m)
+    assert np.abs(st.um - st.u).max() == 0          # compute_diffusivities! left u- = u behind ...
+    dt = 120.0
+    # ... so move the velocities on, as a time step would between two computes
+    rng = np.random.default_rng(5)
+    Nx, Ny, Nz = m.grid.size
+    m.set(u=m.velocities.u.interior + 0.01 * rng.standard_normal((Nx, Ny, Nz)))
+    m.backend.fill_halo_regions()
+    st = spec.State(m)
+    want = spec.tke_step(st, dt)
     gb.update_state(m)
-    zf = np.array([m.backend.metric("zf", k) for k in range(1, Nz + 2)])
-    dzf = np.array([m.backend.metric("dzf", k) for k in range(1, Nz + 2)])
-    ku, kc, ke = (getattr(m.diffusivity_fields, n).interior for n in ("kappa_u", "kappa_c", "kappa_e"))
-    T = m.tracers.T.parent
-    from oracle_backend import oracle_lib
-    H = 8
-    up = m.velocities.u.parent
-    checked = 0
-    for (i, j) in ((3, 4), (10, 7), (0, 0)):
-        for k in range(1, Nz):                      # interior faces (0-based face k between cells k-1 and k)
-            # buoyancy through the oracle's own equation of state (pinned separately by the TEOS-10 check value)
-            rho = lambda kk: m.backend.teos10_rho(T[H + i, H + j, H + kk], 35.0, zc[kk])
-            b = lambda kk: -9.80665 * (rho(kk) - 1020.0) / 1020.0
-            N2 = (b(k) - b(k - 1)) / dzf[k]
-            duw = (up[H + i, H + j, H + k] - up[H + i, H + j, H + k - 1]) / dzf[k]
-            due = (up[H + i + 1, H + j, H + k] - up[H + i + 1, H + j, H + k - 1]) / dzf[k]
-            S2 = 0.5 * (duw ** 2 + due ** 2)
-            ef = 0.5 * (e[i, j, k - 1] + e[i, j, k])
-            ws = np.sqrt(max(ef, 0.0))
-            Ri = 0.0 if N2 == 0 else N2 / S2
-            ls = min(P["Cs"] * (zf[Nz] - zf[k]), P["Cb"] * (zf[k] - zf[0]))
-            if N2 > 0:
-                ls = min(ls, ws / np.sqrt(N2))
-            for p, arr in ((0, ku), (1, kc), (2, ke)):
-                assert arr[i, j, k] == pytest.approx(sigma(p, Ri) * ls * ws, rel=1e-9), (i, j, k, p)
-            checked += 1
-    assert checked == 3 * (Nz - 1)
-    for arr in (ku, kc, ke):
-        assert np.all(arr[:, :, 0] == 0) and np.all(arr[:, :, Nz] == 0) and np.all(arr >= 0)
-    assert np.all(m.diffusivity_fields.Le.interior < 0) and np.all(m.diffusivity_fields.Jb.interior == 0)
+    e = m.tracers.e.interior
+    assert np.allclose(e, want["e"], rtol=3e-6, atol=1e-13), np.abs(e - want["e"]).max()
+    assert np.allclose(m.backend.get_field("Gm.e", False), want["Gm"], rtol=3e-6, atol=1e-16)
+    assert np.allclose(m.diffusivity_fields.Le.interior, want["Le"], rtol=3e-6, atol=1e-14)
+    P = spec.shear_production(st)
+    assert P.max() > 1e-9 and np.abs(want["e"] - st.cells(st.e)).max() > 1e-7     # the test moved something
+    # G^n.e holds the SLOW tendency only: advection and the surface TKE flux (positive in the top cell, wind + cooling)
+    Gn = m.backend.get_field("Gn.e", False)
+    assert Gn[:, :, -1].min() > 0 and np.abs(Gn[:, :, 2:-2]).max() < 1e-2 * Gn[:, :, -1].max()
+
+
+def test_the_surface_buoyancy_flux_is_filtered_over_the_convective_time_scale():
+    m = developed(steps=2)
+    Jb_old = np.array(m.backend.get_field("Jb", True), dtype=np.float64)
+    gb.time_step(m)
+    st = spec.State(m)
+    st.Jb = Jb_old
+    Nx, Ny, Nz = m.grid.size
+    T, S = st.cells(st.T)[:, :, -1], st.cells(st.S)[:, :, -1]
+    al, _ = spec.sensitivities(st, T, S, st.zc[-1])
+    JT = m.backend.get_top_flux("T")
+    want = spec.filtered_surface_flux(st, st.cells(st.e), spec.G * al * JT, 120.0)
+    got = m.diffusivity_fields.Jb.interior.reshape(want.shape)
+    assert np.allclose(got, want, rtol=1e-6), np.abs(got / want - 1).max()
+    inst = spec.G * al * JT
+    assert np.all(got < inst) and np.all(got > 0.02 * inst)      # still catching up with the instantaneous flux
 
 
 def test_quiescent_stratified_fluid_does_not_mix_and_tke_decays():
@@ -103,7 +141,7 @@ def test_wind_stress_deepens_a_mixed_layer_and_conserves_heat():
     ku = m.diffusivity_fields.kappa_u.interior
     assert e[:, :, -1].min() > 1e-5 and e[:, :, 0].max() < 1e-12  # TKE near the surface, none at depth
     assert e[:, :, -3].min() > 1e-6                               # ... and it has worked its way down three cells
-    assert ku[:, :, Nz - 1].min() > 5e-4 and ku[:, :, 2].max() < 1e-9
+    assert ku[:, :, Nz - 1].min() > 5e-4 and ku[:, :, 2].max() < 5e-7     # (at depth: the floor sqrt(e_min) N^-1 of the stable length)
     # the top levels have been stirred: the stratification there is weaker than it was
     top = slice(Nz - 2, Nz)
     assert np.abs(np.diff(T[:, :, top], axis=-1)).mean() < 0.75 * np.abs(np.diff(T0[:, :, top], axis=-1)).mean()
