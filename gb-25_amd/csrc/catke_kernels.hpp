@@ -4,75 +4,327 @@
 #pragma once
 // =============================================================================================
 // closure = CATKEVerticalDiffusivity() (GB-25 src/baroclinic_instability_model.jl:30,50-51; sharding/
-// less_simple_sharding_problem.jl:84-93; compared fields src/correctness.jl:60-67).  The formulas are those of
-// oracle/gb25_oracle.c (catke_at_face: Oceananigans' TKE-based closure restated [UPSTREAM-UNVERIFIED] after Wagner et al.
-// 2025); single domain, lat-lon grid (flat or with a GridFittedBottom).
-//   k_catke_buoyancy        b = -g rho'(T, S, z) / rho0 per cell (the equation of state in fp64, as the pressure kernel)
-//   k_catke_surface_flux    J^b = g (alpha J^T - beta J^S) from the top flux boundary conditions (zero without them)
-//   k_catke_diffusivities   one thread per column, marching up the faces: kappa_u, kappa_c, kappa_e, L^e with the halo cells
-//                           their fill derives (a14), and the explicit TKE terms added to G^n.e (shear production, positive
-//                           buoyancy flux, surface TKE flux)
-//   k_implicit_vertical_var the tridiagonal solve with these diffusivity fields (u, v, T, S, e in one launch)
+// less_simple_sharding_problem.jl:84-93; compared fields src/correctness.jl:60-67).  The formulas and their order are those of
+// oracle/gb25_oracle.c (the CATKE section's header: Oceananigans 0.96's structure as recalled, [UPSTREAM-UNVERIFIED]).
+// What compute_diffusivities! does inside update_state!, kernel by kernel:
+//   k_catke_n2              N^2 = g (alpha dzT - beta dzS) on the faces, alpha and beta of TEOS-10 at the face (fp64)
+//   k_catke_tke_step        time_step_catke_equation!, first half: per column the new kappa_e, L^e, the fast TKE terms (shear
+//                           production between the previous and the current velocities with the OLD kappa_u, buoyancy flux with
+//                           the OLD kappa_c) and the AB2 update e* = e + dt (C1 (G^n.e + fast) - C2 G^-.e), G^-.e <- the total
+//   k_implicit_vertical_var ... second half: (1 - dt dz kappa_e dz - dt L^e) e = e*           (MODE 1, the e slice alone)
+//   [halos of e; previous velocities <- velocities]
+//   k_catke_surface_flux    compute_average_surface_buoyancy_flux!: J^b filtered over t* = cbrt(l_D^2 / J^b+); also the top
+//                           boundary condition of e (the surface TKE flux) as a 2-D source for G^n.e
+//   k_catke_diffusivities   compute_CATKE_diffusivities!: kappa_u, kappa_c, kappa_e from the new e, with the halo cells their
+//                           fill derives (a14)
+// and compute_tendencies! adds: k_tracer_tendencies_single (-div(u e) into G^n.e) + k_catke_add_top_source.
 // =============================================================================================
 struct CatkePar {
   real Cs, Cb, Csp, CRid, CRi0;
   real Chi[4], Clo[4], Cun[4], Cc[4], Ce[4];   // psi = u, c, e, D
-  real CWu, CWw, emin, Jbmin, tau_neg;
+  real CWu, CWw, emin, Jbmin, tau_neg, CWeps;
 };
-// N^2 at face k (between cells k-1 and k; k = blockIdx.z + 1), stored at the index of cell k.  Both buoyancies and their
-// difference in fp64 (as the pressure kernel differences its pressure): in a mixed layer the difference of two Float32
-// buoyancies is a handful of ulps, and the stratification-limited mixing length goes with N^-1.
-__global__ void k_catke_buoyancy(Grid g, const real* __restrict__ T, const real* __restrict__ S, real* __restrict__ n2) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z + 1;
-  if (i >= g.Nx || j >= g.Ny) return;
-  const int o = ic(g, i, j, k), ob = o - g.pl_c;
-  const double gr = -(double)g.g / (double)g.rho0, sc = 0.875 / 35.16504;
-  const double bk = gr * teos10_level(g.eos + 28 * k, sqrt_pos(((double)S[o] + 32.0) * sc), (double)T[o] * 0.025);
-  const double bb = gr * teos10_level(g.eos + 28 * (k - 1), sqrt_pos(((double)S[ob] + 32.0) * sc), (double)T[ob] * 0.025);
-  n2[o] = (real)((bk - bb) / g.dzf_d[k]);
+// -d rho / d Theta and d rho / d S_A from a folded level table (teos10_level's layout), differentiated term by term
+__device__ __forceinline__ void teos10_level_sens(const double* __restrict__ c, double s, double t, double& a, double& b) {
+  const double p1 = c[7] + s * (c[8] + s * (c[9] + s * (c[10] + s * (c[11] + s * c[12]))));
+  const double p2 = c[13] + s * (c[14] + s * (c[15] + s * (c[16] + s * c[17])));
+  const double p3 = c[18] + s * (c[19] + s * (c[20] + s * c[21]));
+  const double p4 = c[22] + s * (c[23] + s * c[24]);
+  const double p5 = c[25] + s * c[26];
+  const double p6 = c[27];
+  const double d0 = c[1] + s * (2.0 * c[2] + s * (3.0 * c[3] + s * (4.0 * c[4] + s * (5.0 * c[5] + s * (6.0 * c[6])))));
+  const double d1 = c[8] + s * (2.0 * c[9] + s * (3.0 * c[10] + s * (4.0 * c[11] + s * (5.0 * c[12]))));
+  const double d2 = c[14] + s * (2.0 * c[15] + s * (3.0 * c[16] + s * (4.0 * c[17])));
+  const double d3 = c[19] + s * (2.0 * c[20] + s * (3.0 * c[21]));
+  const double d4 = c[23] + s * (2.0 * c[24]);
+  const double d5 = c[26];
+  const double rt = p1 + t * (2.0 * p2 + t * (3.0 * p3 + t * (4.0 * p4 + t * (5.0 * p5 + t * (6.0 * p6)))));
+  const double rs = d0 + t * (d1 + t * (d2 + t * (d3 + t * (d4 + t * d5))));
+  a = -(rt * 0.025);
+  b = rs * ((0.875 / 35.16504) / (2.0 * s));
 }
-__global__ void k_catke_surface_flux(Grid g, const real* __restrict__ T, const real* __restrict__ S, real* __restrict__ Jb) {
+// N^2 at face k (between cells k-1 and k; k = blockIdx.z + 1 in 1 .. Nz-1), stored at the index of cell k; zero where the face
+// touches the solid.  Columns [i_lo, i_lo + ni), rows [j_lo, j_lo + nj): a rank of a decomposition computes the first halo
+// column / row too (kappa there is COMPUTED, not exchanged).  alpha, beta and the differences in fp64: in a mixed layer the
+// difference of two Float32 temperatures is a handful of ulps, and the stratification-limited length goes with N^-1.
+template <bool IMM>
+__global__ void k_catke_n2(Grid g, const real* __restrict__ T, const real* __restrict__ S, real* __restrict__ n2, int i_lo,
+                           int j_lo, int ni, int nj) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z + 1;
+  if (a >= ni || b >= nj) return;
+  const int i = i_lo + a, j = j_lo + b;
+  const int o = ic(g, i, j, k), ob = o - g.pl_c;
+  const int kc0 = IMM ? min((int)(g.im.ordA[i2(g, i, j)] & 255), g.Nz) : 0;
+  real r = real(0.);
+  if (k > kc0) {
+    const double Tl = (double)T[ob], Th = (double)T[o], Sl = (double)S[ob], Sh = (double)S[o], sc = 0.875 / 35.16504;
+    double al, be;
+    teos10_level_sens(g.eosf + 28 * k, sqrt_pos(((Sl + Sh) * 0.5 + 32.0) * sc), (Tl + Th) * 0.5 * 0.025, al, be);
+    const double rdz = 1.0 / g.dzf_d[k];
+    r = (real)((double)g.g * (al * ((Th - Tl) * rdz) - be * ((Sh - Sl) * rdz)) / (double)g.rho0);
+  }
+  n2[o] = r;
+}
+// per-column context of the CATKE column kernels
+struct CatkeColumn {
+  int kc0;                   // first active level
+  int NUw, NUe, NVs, NVn;    // first level from which the u faces i, i+1 / the v faces j, j+1 are active nodes
+  real zt, zbot, Hcol, jb;
+};
+template <bool IMM>
+__device__ __forceinline__ CatkeColumn catke_column(const Grid& g, int i, int j, int o2, real jb) {
+  CatkeColumn q;
+  q.kc0 = IMM ? min((int)(g.im.ordA[o2] & 255), g.Nz) : 0;
+  q.NUw = q.NUe = q.NVs = q.NVn = 0;
+  if (IMM) {
+    q.NUw = (int)((g.im.ordD[o2] >> 16) & 255); q.NUe = (int)((g.im.ordD[o2 + 1] >> 16) & 255);
+    q.NVs = (int)((g.im.ordD[o2] >> 24) & 255); q.NVn = (int)((g.im.ordD[o2 + g.sx] >> 24) & 255);
+  }
+  q.zt = g.zc[g.Nz - 1] + real(0.5) * g.dzc[g.Nz - 1];
+  real zb = g.zc[0] - real(0.5) * g.dzc[0];
+  for (int l = 0; l < q.kc0; l++) zb += g.dzc[l];
+  q.zbot = zb;
+  q.Hcol = q.zt - zb;
+  q.jb = jb;
+  return q;
+}
+struct CatkeLengths { real ku, kc, ke, convD; };
+// the mixing lengths of an OPEN (c,c,f) face (both cells active): el, eh = max(e_min, e) of the cells below and above
+__device__ __forceinline__ CatkeLengths catke_face_eval(const CatkePar& c, const CatkeColumn& q, real el, real eh, real N2,
+                                                        real N2above, real S2, real zf) {
+  const real wl = sqrt(el), wh = sqrt(eh);
+  const real ws = (wl + wh) / real(2.), ws2 = (wl * wl + wh * wh) / real(2.), ws3 = (wl * wl * wl + wh * wh * wh) / real(2.);
+  const real Ri = (N2 == real(0.)) ? real(0.) : N2 / S2;
+  real dup = c.Cs * (q.zt - zf), ddn = c.Cb * (zf - q.zbot);
+  dup = dup < real(0.) ? real(0.) : dup;
+  ddn = ddn < real(0.) ? real(0.) : ddn;
+  real ls = dup < ddn ? dup : ddn;
+  if (N2 > real(0.)) {
+    const real lN = ws / sqrt(N2);
+    ls = lN < ls ? lN : ls;
+  }
+  const real jb = q.jb, jbe = c.Jbmin;
+  const bool convecting = jb > jbe && N2 < real(0.), entraining = jb > jbe && N2 > real(0.) && N2above < real(0.);
+  real lconv[4] = {real(0.), real(0.), real(0.), real(0.)};
+  if (convecting || entraining) {
+    const real Sp = sqrt(S2) * ws2 / (jb + jbe), esp = real(1.) - c.Csp * Sp;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      real l = convecting ? c.Cc[p] * ws3 / (jb + jbe) : c.Ce[p] * jb / (ws * N2 + jbe);
+      l *= esp;
+      lconv[p] = l > real(0.) ? l : real(0.);
+    }
+  }
+  real tstep = (Ri - c.CRi0) / c.CRid;
+  tstep = tstep < real(0.) ? real(0.) : (tstep > real(1.) ? real(1.) : tstep);
+  real lpsi[3];
+#pragma unroll
+  for (int p = 0; p < 3; p++) {
+    const real sg = Ri < real(0.) ? c.Cun[p] : c.Clo[p] + (c.Chi[p] - c.Clo[p]) * tstep;
+    real l = sg * ls;
+    l = lconv[p] > l ? lconv[p] : l;
+    lpsi[p] = l < q.Hcol ? l : q.Hcol;
+  }
+  CatkeLengths r;
+  r.ku = lpsi[0] * ws; r.kc = lpsi[1] * ws; r.ke = lpsi[2] * ws;
+  r.convD = lconv[3];
+  return r;
+}
+// dissipation_length_scale(c,c,c) of an active cell from the N^2, S^2 and convective dissipation lengths of its two faces
+__device__ __forceinline__ real catke_dissipation_length(const CatkePar& c, const CatkeColumn& q, real e, real zc, real N2lo,
+                                                         real N2hi, real S2lo, real S2hi, real cDlo, real cDhi) {
+  const real lh = (cDlo + cDhi) / real(2.), N2 = (N2lo + N2hi) / real(2.), S2 = (S2lo + S2hi) / real(2.);
+  const real Ri = (N2 == real(0.)) ? real(0.) : N2 / S2;
+  real dup = c.Cs * (q.zt - zc), ddn = c.Cb * (zc - q.zbot);
+  dup = dup < real(0.) ? real(0.) : dup;
+  ddn = ddn < real(0.) ? real(0.) : ddn;
+  real ls = dup < ddn ? dup : ddn;
+  if (N2 > real(0.)) {
+    const real ef = e > c.emin ? e : c.emin;
+    const real lN = sqrt(ef) / sqrt(N2);
+    ls = lN < ls ? lN : ls;
+  }
+  real tstep = (Ri - c.CRi0) / c.CRid;
+  tstep = tstep < real(0.) ? real(0.) : (tstep > real(1.) ? real(1.) : tstep);
+  const real sg = Ri < real(0.) ? c.Cun[3] : c.Clo[3] + (c.Chi[3] - c.Clo[3]) * tstep;
+  ls = ls / sg;
+  const real l = lh > ls ? lh : ls;
+  return l < q.Hcol ? l : q.Hcol;
+}
+// the vertical derivatives of u at the x faces i, i+1 and of v at the y faces j, j+1 of column (i, j) on face kf (1 .. Nz-1):
+// zero where one of the two nodes is an inactive node (both cells beside it inactive)
+struct CatkeShear { real uw, ue, vs, vn; };
+__device__ __forceinline__ CatkeShear catke_dz_velocities(const Grid& g, const CatkeColumn& q, const real* __restrict__ u,
+                                                          const real* __restrict__ v, int oc, int ov, int kf) {
+  // oc, ov: offsets of cell (i, j, kf) in a cell-shaped / v-shaped array
+  const real rdz = g.rdzf[kf];
+  CatkeShear d;
+  d.uw = kf > q.NUw ? (u[oc] - u[oc - g.pl_c]) * rdz : real(0.);
+  d.ue = kf > q.NUe ? (u[oc + 1] - u[oc + 1 - g.pl_c]) * rdz : real(0.);
+  d.vs = kf > q.NVs ? (v[ov] - v[ov - g.pl_v]) * rdz : real(0.);
+  d.vn = kf > q.NVn ? (v[ov + g.sx] - v[ov + g.sx - g.pl_v]) * rdz : real(0.);
+  return d;
+}
+// time_step_catke_equation!, first half (see the header).  One thread per own column, marching up; e is updated in place (a
+// column reads nobody else's e, and the old e of a cell is last needed by the face above it, evaluated before the cell).
+template <bool IMM>
+__global__ __launch_bounds__(256) void k_catke_tke_step(Grid g, CatkePar c, real dt, real C1, real C2,
+                                                        const real* __restrict__ u, const real* __restrict__ v,
+                                                        const real* __restrict__ um, const real* __restrict__ vm,
+                                                        real* __restrict__ e, const real* __restrict__ n2,
+                                                        const real* __restrict__ Jb, const real* __restrict__ KU,
+                                                        const real* __restrict__ KC, real* __restrict__ KE,
+                                                        real* __restrict__ Le, const real* __restrict__ Gn,
+                                                        real* __restrict__ Gm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= g.Nx || j >= g.Ny) return;
-  const int o2 = i2(g, i, j);
-  double J = 0.0;
-  if (g.top_flux[2] || g.top_flux[3]) {
-    const int o = ic(g, i, j, g.Nz - 1);
-    const double sc = 0.875 / 35.16504, d = 1e-2, Tc = (double)T[o], Sc = (double)S[o];
-    const double* c = g.eos + 28 * (g.Nz - 1);
-    auto rho = [&](double t, double s) { return teos10_level(c, sqrt_pos((s + 32.0) * sc), t * 0.025); };
-    const double drdT = (rho(Tc + d, Sc) - rho(Tc - d, Sc)) / (2 * d), drdS = (rho(Tc, Sc + d) - rho(Tc, Sc - d)) / (2 * d);
-    const double JT = g.top_flux[2] ? (double)g.top_flux[2][o2] : 0.0, JS = g.top_flux[3] ? (double)g.top_flux[3][o2] : 0.0;
-    J = (double)g.g * (-drdT * JT - drdS * JS) / (double)g.rho0;
-  }
-  // (a slab of a decomposition: the x halo columns and the rows beyond a zipper fold arrive with the 3-D bundle)
+  const int Nz = g.Nz, o2 = i2(g, i, j), pc = g.pl_c, pv = g.pl_v;
+  const CatkeColumn q = catke_column<IMM>(g, i, j, o2, Jb[o2]);
   const bool xw = g.x_periodic && i < g.H, xe = g.x_periodic && i >= g.Nx - g.H;
-  store_x_images(g, Jb, o2, (real)J, xw, xe);
-  // (the y layers exist next to walls only: a rank of a 2-D decomposition gets the rows of its open sides from the neighbour)
-  if (j == 0 && g.jws == 0) store_x_images(g, Jb, o2 - g.sx, (real)J, xw, xe);
-  if (j == g.Ny - 1 && (g.jwn == g.Ny || g.cv.north_fold) && !(g.cv.north_fold && !g.x_periodic)) store_x_images(g, Jb, o2 + g.sx, (real)J, xw, xe);
+  const bool ys = j == 0 && g.jws == 0, yn = j == g.Ny - 1 && (g.jwn == g.Ny || g.cv.north_fold);
+  auto put = [&](real* a, int o, real x) {   // the cell and the halo cells its fill derives from it (a14)
+    store_x_images(g, a, o, x, xw, xe);
+    if (ys) store_x_images(g, a, o - g.sx, x, xw, xe);
+    if (yn) store_x_images(g, a, o + g.sx, x, xw, xe);
+  };
+  int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
+  KE[o] = real(0.);
+  real zf = g.zc[0] - real(0.5) * g.dzc[0];
+  // the face below the current cell: N^2, S^2, the convective dissipation length, -kappa_c N^2, the shear-production sum
+  real N2lo = real(0.), S2lo = real(0.), cDlo = real(0.), wblo = real(0.), PFlo = real(0.);
+  real ecur = e[o];
+  for (int k = 0; k < Nz; k++) {
+    const int kf = k + 1, of = o + pc, ovf = ov + pv;
+    zf += g.dzc[k];
+    real N2hi = real(0.), S2hi = real(0.), cDhi = real(0.), wbhi = real(0.), PFhi = real(0.), kehi = real(0.);
+    real enext = real(0.);
+    if (kf < Nz) {
+      enext = e[of];
+      const CatkeShear d = catke_dz_velocities(g, q, u, v, of, ovf, kf), dm = catke_dz_velocities(g, q, um, vm, of, ovf, kf);
+      S2hi = (d.uw * d.uw + d.ue * d.ue) / real(2.) + (d.vs * d.vs + d.vn * d.vn) / real(2.);
+      const real kuc = KU[of];
+      const real nw = (KU[of - 1] + kuc) / real(2.), ne = (kuc + KU[of + 1]) / real(2.);
+      const real ns = (KU[of - g.sx] + kuc) / real(2.), nn = (kuc + KU[of + g.sx]) / real(2.);
+      const real dzf = g.dzf[kf];
+      // (nu dz u- dzf dz u+) + (nu dz u+ dzf dz u+), averaged over the two x faces, plus the same over the two y faces
+      const real fw = (nw * dm.uw * dzf * d.uw) + (nw * d.uw * dzf * d.uw), fe = (ne * dm.ue * dzf * d.ue) + (ne * d.ue * dzf * d.ue);
+      const real fs = (ns * dm.vs * dzf * d.vs) + (ns * d.vs * dzf * d.vs), fn = (nn * dm.vn * dzf * d.vn) + (nn * d.vn * dzf * d.vn);
+      PFhi = (fw + fe) / real(2.) + (fs + fn) / real(2.);
+      if (kf > q.kc0) {
+        N2hi = n2[of];
+        const real el = ecur > c.emin ? ecur : c.emin, eh = enext > c.emin ? enext : c.emin;
+        const CatkeLengths L = catke_face_eval(c, q, el, eh, N2hi, n2[of + pc], S2hi, zf);
+        kehi = L.ke;
+        cDhi = L.convD;
+        wbhi = -(KC[of] * N2hi);
+      }
+    }
+    KE[of] = kehi;
+    real Lk = real(0.);
+    if (k >= q.kc0) {
+      const real ek = ecur, wb = (wblo + wbhi) / real(2.);
+      const real wbm = wb < real(0.) ? wb : real(0.), wbp = wb > real(0.) ? wb : real(0.);
+      const real lD = catke_dissipation_length(c, q, ek, g.zc[k], N2lo, N2hi, S2lo, S2hi, cDlo, cDhi);
+      const real omega = ek < real(0.) ? real(1.) / c.tau_neg : sqrt(rabs(ek)) / lD;
+      const real ep = ek > real(0.) ? ek : real(0.);
+      const real divJ = k == q.kc0 ? -(c.CWeps * sqrt(ep) / g.dzc[k]) : real(0.);      // (the bottom cell of the column)
+      Lk = (ek > c.emin ? wbm / ek : real(0.)) - omega + divJ;
+      const real P = ((PFlo + PFhi) / real(2.)) / (real(2.) * g.dzc[k]);
+      const real total = Gn[o] + (P + wbp);
+      e[o] = ek + dt * (C1 * total - C2 * Gm[o]);
+      Gm[o] = total;
+    }
+    put(Le, o, Lk);
+    if (k == 0) store_x_images(g, Le, o - pc, Lk, xw, xe);        // bottom / top layer (interior rows only, like the fill)
+    if (k == Nz - 1) store_x_images(g, Le, o + pc, Lk, xw, xe);
+    N2lo = N2hi; S2lo = S2hi; cDlo = cDhi; wblo = wbhi; PFlo = PFhi;
+    ecur = enext;
+    o = of;
+    ov = ovf;
+  }
 }
-struct CatkeFace {
-  real ku, kc, ke, lD, P, wb;
-};
+// compute_average_surface_buoyancy_flux! on the own columns (+ the halo cells the fill derives): J^b* from the top flux
+// boundary conditions of T, S and the surface cell's alpha, beta; the dissipation length of the top cell from the NEW e and
+// the OLD J^b; J^b <- (J^b + eps J^b*) / (1 + eps), eps = dt_since / cbrt(l_D^2 / max(J^b_min, J^b, J^b*)).  Land: zero.
+// Also leaves the top boundary condition of e, (C^W_u* u*^3 + C^W_wD max(J^b*, 0) dz) / dz, for k_catke_add_top_source.
+template <bool IMM>
+__global__ void k_catke_surface_flux(Grid g, CatkePar c, real dt_since, const real* __restrict__ u, const real* __restrict__ v,
+                                     const real* __restrict__ T, const real* __restrict__ S, const real* __restrict__ e,
+                                     const real* __restrict__ n2, real* __restrict__ Jb, real* __restrict__ src) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const int Nz = g.Nz, o2 = i2(g, i, j), k = Nz - 1, o = ic(g, i, j, k), ov = iv(g, i, j, k);
+  const real J = Jb[o2];
+  const CatkeColumn q = catke_column<IMM>(g, i, j, o2, J);
+  real Jnew = real(0.), source = real(0.);
+  if (q.kc0 < Nz) {
+    double Js = 0.0;
+    if (g.top_flux[2] || g.top_flux[3]) {
+      double al, be;
+      teos10_level_sens(g.eos + 28 * k, sqrt_pos(((double)S[o] + 32.0) * (0.875 / 35.16504)), (double)T[o] * 0.025, al, be);
+      const double JT = g.top_flux[2] ? (double)g.top_flux[2][o2] : 0.0, JS = g.top_flux[3] ? (double)g.top_flux[3][o2] : 0.0;
+      Js = (double)g.g * (al * JT - be * JS) / (double)g.rho0;
+    }
+    const real Jstar = (real)Js;
+    // the face below the top cell (kf = Nz-1) and the surface face (nothing there)
+    real N2lo = real(0.), S2lo = real(0.), cDlo = real(0.);
+    const real ek = e[o];
+    if (k >= 1) {
+      const CatkeShear d = catke_dz_velocities(g, q, u, v, o, ov, k);
+      S2lo = (d.uw * d.uw + d.ue * d.ue) / real(2.) + (d.vs * d.vs + d.vn * d.vn) / real(2.);
+      if (k > q.kc0) {
+        N2lo = n2[o];
+        const real eb = e[o - g.pl_c];
+        const real el = eb > c.emin ? eb : c.emin, eh = ek > c.emin ? ek : c.emin;
+        cDlo = catke_face_eval(c, q, el, eh, N2lo, real(0.), S2lo, g.zc[k] - real(0.5) * g.dzc[k]).convD;
+      }
+    }
+    const real lD = catke_dissipation_length(c, q, ek, g.zc[k], N2lo, real(0.), S2lo, real(0.), cDlo, real(0.));
+    real Jp = c.Jbmin;
+    Jp = J > Jp ? J : Jp;
+    Jp = Jstar > Jp ? Jstar : Jp;
+    const real tstar = cbrt(lD * lD / Jp), eps = dt_since / tstar;
+    Jnew = (J + eps * Jstar) / (real(1.) + eps);
+    // u* from the boundary-condition values AT (i, j), as Oceananigans' friction_velocity takes them
+    const real Ju = g.top_flux[0] ? g.top_flux[0][o2] : real(0.);
+    const real Jv = g.top_flux[1] ? g.top_flux[1][o2] : real(0.);
+    const real us2 = sqrt(Ju * Ju + Jv * Jv), us3 = us2 * sqrt(us2);
+    const real wD3 = (Jstar > real(0.) ? Jstar : real(0.)) * g.dzc[k];
+    source = (c.CWu * us3 + c.CWw * wD3) / g.dzc[k];
+  }
+  src[o2] = source;
+  // (a rank of a decomposition: the x halo columns / rows of its open sides / the rows beyond a zipper fold arrive by exchange)
+  const bool xw = g.x_periodic && i < g.H, xe = g.x_periodic && i >= g.Nx - g.H;
+  store_x_images(g, Jb, o2, Jnew, xw, xe);
+  // (the y layers exist next to walls only)
+  if (j == 0 && g.jws == 0) store_x_images(g, Jb, o2 - g.sx, Jnew, xw, xe);
+  if (j == g.Ny - 1 && (g.jwn == g.Ny || g.cv.north_fold) && !(g.cv.north_fold && !g.x_periodic)) store_x_images(g, Jb, o2 + g.sx, Jnew, xw, xe);
+}
+// G^n.e of the top cell += the surface TKE flux / dz (the top boundary condition of e: compute_boundary_tendencies)
+__global__ void k_catke_add_top_source(Grid g, const real* __restrict__ src, real* __restrict__ Ge) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const int o = ic(g, i, j, g.Nz - 1);
+  Ge[o] = Ge[o] + src[i2(g, i, j)];
+}
+// compute_CATKE_diffusivities!: kappa_u, kappa_c, kappa_e on the faces 1 .. Nz-1 (zero on the bottom and top faces and where
+// the face touches the solid).
 template <bool IMM>
 __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c, const real* __restrict__ u,
                                                              const real* __restrict__ v, const real* __restrict__ e,
-                                                             const real* __restrict__ b, const real* __restrict__ Jb,
+                                                             const real* __restrict__ n2, const real* __restrict__ Jb,
                                                              real* __restrict__ KU, real* __restrict__ KC,
-                                                             real* __restrict__ KE, real* __restrict__ Le,
-                                                             real* __restrict__ Ge, int i_lo, int j_hi, int j_lo) {
-  // Columns i_lo .. Nx-1, rows 0 .. j_hi-1.  Single domain: the interior (0, Ny), the halo cells written as images.  A slab
-  // of a decomposition: i_lo = -1 and, with the zipper fold, j_hi = Ny + 1 -- the one halo column / row whose kappa_u the
-  // implicit solves of u (averaged in x) and of v (in y, on the fold line) read is COMPUTED here from the halo columns of
-  // e, u, v, N^2 and J^b (all of them exchanged already), bit for bit what its owner computes, instead of exchanged.
-  // (2-D decomposition: j_lo = -1 below a southern neighbour -- kappa_u of that row is averaged into the v faces of row 0)
+                                                             real* __restrict__ KE, int i_lo, int i_hi, int j_lo, int j_hi) {
+  // Columns i_lo .. i_hi-1, rows j_lo .. j_hi-1.  Single domain: the interior, the halo cells written as images.  A rank of a
+  // decomposition: the first halo column on either side (and the first halo row of an open side / beyond the zipper fold) as
+  // well -- kappa_u there is averaged into the implicit solves of u, v and into the shear production of the edge columns, and
+  // is COMPUTED from the exchanged halos of e, u, v, T, S and J^b, bit for bit what its owner computes, instead of exchanged.
   const int i = i_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = j_lo + (int)(blockIdx.y * blockDim.y + threadIdx.y);
-  if (i >= g.Nx || j >= j_hi) return;
-  const bool own = i >= 0 && j >= 0 && j < g.Ny;
+  if (i >= i_hi || j >= j_hi) return;
+  const bool own = i >= 0 && i < g.Nx && j >= 0 && j < g.Ny;
   const int Nz = g.Nz, o2 = i2(g, i, j), pc = g.pl_c, pv = g.pl_v;
-  const int kc0 = IMM ? min((int)(g.im.ordA[o2] & 255), Nz) : 0;   // first active level of the column
-  const bool xw = g.x_periodic && i < g.H, xe = g.x_periodic && i >= g.Nx - g.H;
+  const CatkeColumn q = catke_column<IMM>(g, i, j, o2, Jb[o2]);
+  const bool xw = own && g.x_periodic && i < g.H, xe = own && g.x_periodic && i >= g.Nx - g.H;
   // (the y layers exist next to walls only)
   const bool ys = own && j == 0 && g.jws == 0, yn = own && j == g.Ny - 1 && j_hi == g.Ny && (g.jwn == g.Ny || g.cv.north_fold);
   auto put = [&](real* a, int o, real x) {   // the cell and the halo cells its fill derives from it (a14)
@@ -80,107 +332,28 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
     if (ys) store_x_images(g, a, o - g.sx, x, xw, xe);
     if (yn) store_x_images(g, a, o + g.sx, x, xw, xe);
   };
-  const real zt = g.zc[Nz - 1] + real(0.5) * g.dzc[Nz - 1];          // surface
-  const real jb = Jb[o2], jbp = jb > c.Jbmin ? jb : c.Jbmin, rjbp = real(1.) / jbp, rCRid = real(1.) / c.CRid;
-  const bool cooled = jb > c.Jbmin;
-  // A window of three levels travels up the column: what a cell level contributes -- e, u on its two x faces, v on its two
-  // y faces, N^2 on the face below it (zero on the boundary faces and next to the solid) -- is loaded two levels AHEAD of
-  // its use, so the loads of a level are in flight during the arithmetic of the level below (a first version loaded and
-  // used level by level and ran at the latency of 48 dependent round trips).
-  struct Level { real e, uw, ue, vs, vn, n2; };
-  auto load_level = [&](int k, int oc_, int ov_) -> Level {
-    Level L = {real(0.), real(0.), real(0.), real(0.), real(0.), real(0.)};
-    if (k < Nz) {
-      L.e = e[oc_]; L.uw = u[oc_]; L.ue = u[oc_ + 1]; L.vs = v[ov_]; L.vn = v[ov_ + g.sx];
-      if (k > kc0) L.n2 = b[oc_];
-    }
-    return L;
-  };
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
-  CatkeFace lo = {real(0.), real(0.), real(0.), real(0.), real(0.), real(0.)};
   put(KU, o, real(0.)); put(KC, o, real(0.)); put(KE, o, real(0.));
-  real zf_k = g.zc[0] - real(0.5) * g.dzc[0], zbot = zf_k;            // z of face 0; bottom of the column
-  for (int q = 0; q < kc0; q++) zbot += g.dzc[q];
-  Level cur = load_level(0, o, ov), nxt = load_level(1, o + pc, ov + pv);
+  real zf = g.zc[0] - real(0.5) * g.dzc[0];
+  real ecur = e[o];
   for (int k = 0; k < Nz; k++) {
-    const Level pre = load_level(k + 2, o + 2 * pc, ov + 2 * pv);
-    const real ge = own ? Ge[o] : real(0.);
-    // ---- face k+1 (top of cell k)
-    zf_k += g.dzc[k];
-    CatkeFace hi = {real(0.), real(0.), real(0.), real(0.), real(0.), real(0.)};
-    const int kf = k + 1;
-    if (kf > kc0 && kf < Nz) {
-      const real rdz = g.rdzf[kf];
-      const real ef = (cur.e + nxt.e) / real(2.), ep = ef > real(0.) ? ef : real(0.), ws = sqrt(ep);
-      const real uw = (nxt.uw - cur.uw) * rdz, ue = (nxt.ue - cur.ue) * rdz;
-      const real vs = (nxt.vs - cur.vs) * rdz, vn = (nxt.vn - cur.vn) * rdz;
-      const real S2 = (uw * uw + ue * ue) / real(2.) + (vs * vs + vn * vn) / real(2.);
-      const real N2 = nxt.n2, N2above = pre.n2;
-      const real Ri = (N2 == real(0.)) ? real(0.) : N2 / S2;
-      const real dup = c.Cs * (zt - zf_k), ddn = c.Cb * (zf_k - zbot);
-      real ls = dup < ddn ? dup : ddn;
-      if (N2 > real(0.)) {
-        const real lN = ws / sqrt(N2);
-        ls = lN < ls ? lN : ls;
+    const int kf = k + 1, of = o + pc, ovf = ov + pv;
+    zf += g.dzc[k];
+    CatkeLengths L = {real(0.), real(0.), real(0.), real(0.)};
+    real enext = real(0.);
+    if (kf < Nz) {
+      enext = e[of];
+      if (kf > q.kc0) {
+        const CatkeShear d = catke_dz_velocities(g, q, u, v, of, ovf, kf);
+        const real S2 = (d.uw * d.uw + d.ue * d.ue) / real(2.) + (d.vs * d.vs + d.vn * d.vn) / real(2.);
+        const real el = ecur > c.emin ? ecur : c.emin, eh = enext > c.emin ? enext : c.emin;
+        L = catke_face_eval(c, q, el, eh, n2[of], n2[of + pc], S2, zf);
       }
-      // convective lengths: l^h_psi = C^c_psi w*^3 / J^b+ * max(0, 1 - C^sp sqrt(S^2) w*^2 / J^b+) where the column loses
-      // buoyancy and N^2 < 0; l^e_psi = C^e_psi J^b+ / (w* N^2 + J^b_min) in the stable level just below such a layer.
-      // The factor common to the four psi is formed once (and only in columns with J^b > J^b_min at all).
-      real conv_scale = real(0.);
-      bool entraining = false;
-      if (cooled) {
-        if (N2 < real(0.)) {
-          const real esp = real(1.) - c.Csp * sqrt(S2) * ws * ws * rjbp;
-          conv_scale = ws * ws * ws * rjbp * (esp > real(0.) ? esp : real(0.));
-        } else if (N2above < real(0.)) {
-          entraining = true;
-          conv_scale = jbp / (ws * N2 + c.Jbmin);
-        }
-      }
-      // stability functions: one step function of Ri for the four psi
-      real tstep = (Ri - c.CRi0) * rCRid;
-      tstep = tstep < real(0.) ? real(0.) : (tstep > real(1.) ? real(1.) : tstep);
-      real lpsi[4];
-#pragma unroll
-      for (int p = 0; p < 4; p++) {
-        const real lconv = (entraining ? c.Ce[p] : c.Cc[p]) * conv_scale;
-        const real sg = Ri < real(0.) ? c.Cun[p] : c.Clo[p] + (c.Chi[p] - c.Clo[p]) * tstep;
-        const real lst = p < 3 ? sg * ls : ls / sg;
-        lpsi[p] = lconv > lst ? lconv : lst;
-      }
-      hi.ku = lpsi[0] * ws; hi.kc = lpsi[1] * ws; hi.ke = lpsi[2] * ws; hi.lD = lpsi[3];
-      hi.P = hi.ku * S2;
-      hi.wb = -hi.kc * N2;
     }
-    put(KU, o + pc, hi.ku); put(KC, o + pc, hi.kc); put(KE, o + pc, hi.ke);
-    // ---- cell k (own columns: the halo ones are there for their kappa only)
-    real L = real(0.);
-    if (own && k >= kc0) {
-      const real ek = cur.e, lD = (lo.lD + hi.lD) / real(2.), wb = (lo.wb + hi.wb) / real(2.);
-      const real omega = lD > real(0.) ? sqrt(rabs(ek)) / lD : real(0.);
-      const real wbm = wb < real(0.) ? wb : real(0.);
-      L = -omega + (ek > c.emin ? wbm / ek : real(0.)) - (ek < real(0.) ? real(1.) / c.tau_neg : real(0.));
-      real src = (lo.P + hi.P) / real(2.) + (wb > real(0.) ? wb : real(0.));
-      if (k == Nz - 1) {   // the surface TKE flux: -(C^W_u* u*^3 + C^W_wD w_D^3), into the top cell
-        // (friction velocity from the boundary-condition values AT (i, j), as Oceananigans' friction_velocity takes them)
-        const real Ju = g.top_flux[0] ? g.top_flux[0][o2] : real(0.);
-        const real Jv = g.top_flux[1] ? g.top_flux[1][o2] : real(0.);
-        const real us2 = sqrt(Ju * Ju + Jv * Jv), us3 = us2 * sqrt(us2);
-        const real wD3 = (jb > real(0.) ? jb : real(0.)) * g.dzc[k];
-        src += (c.CWu * us3 + c.CWw * wD3) / g.dzc[k];
-      }
-      Ge[o] = ge + src;
-    }
-    if (own) {
-      put(Le, o, L);
-      if (k == 0) store_x_images(g, Le, o - pc, L, xw, xe);        // bottom / top layer (interior rows only, like the fill)
-      if (k == Nz - 1) store_x_images(g, Le, o + pc, L, xw, xe);
-    }
-    lo = hi;
-    cur = nxt;
-    nxt = pre;
-    o += pc;
-    ov += pv;
+    put(KU, of, L.ku); put(KC, of, L.kc); put(KE, of, L.ke);
+    ecur = enext;
+    o = of;
+    ov = ovf;
   }
 }
 // TripolarGrid: the rows beyond the zipper fold of the diffusivity fields and of J^b (cell-centred in x and y, no sign
@@ -223,6 +396,7 @@ struct ImplicitVarFields {
   real dt, C1, C2;
   real* sum[2];                // column integrals of the new u, v (the look-ahead's predate the solve)
   int kchunks;
+  int z0;                      // first slice of the launch (MODE 1: 0 = T with S [+ e], 1 = e alone)
   real* gam[2];                // streaming kernel only: the factors of the two blockIdx.z slices ((c,f,c)-shaped scratch)
 };
 template <bool IMM, int MODE>
@@ -252,7 +426,7 @@ __device__ __forceinline__ real implicit_var_colsum(const Grid& g, int kchunks, 
 }
 template <int NZT, bool IMM, int MODE>
 __global__ __launch_bounds__(256) void k_implicit_vertical_var(Grid g, ImplicitVarFields A) {
-  const int z = blockIdx.z, Nz = g.Nz;
+  const int z = blockIdx.z + A.z0, Nz = g.Nz;
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   const bool vsh = MODE == 0 && z == 1, pair = MODE == 1 && z == 0, tke = MODE == 1 && z == 1;
   if (i >= g.Nx || j >= (vsh ? g.Ny : g.Ny)) return;
@@ -340,14 +514,14 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_var(Grid g, ImplicitV
 // 7 instead of 3 accesses per cell and field, ~30 registers, loads independent of the chain (unrolled by 4).
 template <bool IMM, int MODE>
 __global__ __launch_bounds__(256) void k_implicit_vertical_var_stream(Grid g, ImplicitVarFields A) {
-  const int z = blockIdx.z, Nz = g.Nz;
+  const int z = blockIdx.z + A.z0, Nz = g.Nz;
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   const bool vsh = MODE == 0 && z == 1, pair = MODE == 1 && z == 0, tke = MODE == 1 && z == 1;
   if (i >= g.Nx || j >= (vsh ? g.Ny : g.Ny)) return;
   const int o2 = i2(g, i, j), kf = implicit_var_first_level<IMM, MODE>(g, z, o2, j);
   real* Fa = MODE == 0 ? A.f[z] : (pair ? A.f[2] : A.f[4]);
   real* Fb = A.f[3];
-  real* G = A.gam[z];
+  real* G = A.gam[blockIdx.z];
   const real* K = MODE == 0 ? A.KU : (pair ? A.KC : A.KE);
   const int pl = vsh ? g.pl_v : g.pl_c, o0 = vsh ? iv(g, i, j, 0) : ic(g, i, j, 0), oc = ic(g, i, j, 0), pc = g.pl_c;
   const int og = iv(g, i, j, 0), pg = g.pl_v;              // the scratch array has the larger of the two shapes

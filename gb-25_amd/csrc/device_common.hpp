@@ -39,7 +39,8 @@ __device__ __forceinline__ double rtanh(double x) { return tanh(x); }
 struct Immersed {
   const unsigned *ordA, *ordB, *ordC;
   const unsigned* ordD;   // WENO(order = 7) tracer advection: first level from which the eight-cell stencil of the x face /
-                          // the y face is fully active (bits 0-7 / 8-15)
+                          // the y face is fully active (bits 0-7 / 8-15); bits 16-23 / 24-31: first level from which the u face /
+                          // the v face is an ACTIVE node (min of the two columns' kc: CATKE's conditional vertical differences)
   const real *Hfc, *Hcf, *rHfc, *rHcf;
 };
 __device__ __forceinline__ int order_from(int k, int K5, int K3) { return k >= K5 ? 5 : (k >= K3 ? 3 : 1); }
@@ -87,6 +88,7 @@ struct Grid {
   real rdy, rLz;
   // TEOS-10 folded per level: rho'(s,t) = sum_{i+j<=6} eos[k][idx(i,j)] s^i t^j, k = 0..Nz (Nz = mirrored halo level)
   const double* eos;
+  const double* eosf;                                // the same folded at the depths of the faces k = 0..Nz (CATKE: alpha, beta of N^2)
   const double* dzf_d;                               // dzf in fp64 for the hydrostatic integral, by k (0..Nz)
   Immersed im;                                       // (null pointers on a grid without bathymetry)
   // FluxBoundaryCondition at the top of u, v, T, S (null: the default no-flux): 2-D arrays with the parent layout of a

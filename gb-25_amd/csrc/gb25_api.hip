@@ -189,7 +189,10 @@ struct gb25_model {
   bool catke = false;                // closure = CATKEVerticalDiffusivity(): the fields GB25_E .. GB25_JB exist
   Field catke_b, catke_scratch;      // N^2 on the faces; the unused half of the two-wide tracer kernel's output
   gb25_catke_parameters catke_par;   // (gb25_default_catke_parameters at creation)
-  bool n2_fresh = false;             // catke_b holds N^2 of the current T, S (written by the pressure kernel)
+  Field catke_src;                   // 2-D: the top boundary condition of e (surface TKE flux / dz of the top cell)
+  double catke_prev_time = 0;        // diffusivity_fields.previous_compute_time
+  bool catke_stale_e_halos = false;  // option CATKE_STALE_E_HALOS
+  bool n2_fresh = false;             // (unused since N^2 = g (alpha dzT - beta dzS) has a kernel of its own)
   Field catke_gam[2];                // Nz > 64: the elimination factors of the streamed implicit solve
   real* d_implicit[2] = {nullptr, nullptr};   // elimination tables of the implicit solve for (u, v) and (T, S): lo | 1/beta | gamma
   double implicit_key[2][2] = {{0, 0}, {0, 0}};   // the (dt, K) they were built for
@@ -223,10 +226,10 @@ gb25_status fail(gb25_model* m, gb25_status s, const char* fmt, ...) {
 
 bool is_v_shaped(int id) {
   return id == GB25_V || id == GB25_GN_V || id == GB25_GM_V || id == GB25_BT_V || id == GB25_V_BAR ||
-         id == GB25_GN_BT_V;
+         id == GB25_GN_BT_V || id == GB25_PREV_V;
 }
 bool is_2d(int id) { return (id >= GB25_ETA && id <= GB25_GN_BT_V) || id == GB25_JB; }
-bool is_catke_field(int id) { return id >= GB25_E && id <= GB25_JB; }
+bool is_catke_field(int id) { return id >= GB25_E && id <= GB25_PREV_V; }
 
 // --- profiling helpers -----------------------------------------------------------------------
 struct Timed {
@@ -599,13 +602,11 @@ const double kEosR0[6] = {4.6494977072e+01, -5.2099962525e+00, 2.2601900708e-01,
 
 gb25_status build_eos_tables(gb25_model* m) {
   const int Nz = m->cfg.Nz, offk = m->metric_off_k;
-  const std::vector<double>&zc = m->h_metric[GB25_M_ZC], &dzf = m->h_metric[GB25_M_DZF];
-  std::vector<double> tab((size_t)28 * (Nz + 1), 0.0), dz(Nz + 1);
-  for (int k = 0; k <= Nz; k++) {
-    // geopotential height of level k; the halo level above the surface is mirrored (Oceananigans Z^ccc)
-    double Z = (k < Nz) ? zc[offk + k] : zc[offk + Nz - 1] - dzf[offk + Nz - 1];
-    double zeta = -Z * 1e-4;
-    double* c = &tab[(size_t)28 * k];
+  const std::vector<double>&zc = m->h_metric[GB25_M_ZC], &dzf = m->h_metric[GB25_M_DZF], &zf = m->h_metric[GB25_M_ZF];
+  // [28 (Nz+1): levels][28 (Nz+1): faces][Nz+1: dzf]
+  std::vector<double> tab((size_t)56 * (Nz + 1), 0.0), dz(Nz + 1);
+  auto fold = [&](double Z, double* c) {
+    const double zeta = -Z * 1e-4;
     for (const EosTerm& t : kEos) {
       int base = 0;
       for (int j = 0; j < t.j; j++) base += 7 - j;
@@ -614,6 +615,11 @@ gb25_status build_eos_tables(gb25_model* m) {
     double r0 = 0;
     for (int q = 5; q >= 0; q--) r0 = (r0 + kEosR0[q]) * zeta;
     c[0] += r0 - m->cfg.rho0;
+  };
+  for (int k = 0; k <= Nz; k++) {
+    // geopotential height of level k; the halo level above the surface is mirrored (Oceananigans Z^ccc)
+    fold((k < Nz) ? zc[offk + k] : zc[offk + Nz - 1] - dzf[offk + Nz - 1], &tab[(size_t)28 * k]);
+    fold((double)(real)zf[offk + k], &tab[(size_t)28 * (Nz + 1 + k)]);   // (Z^ccf: the face itself, a number of the model's float type)
     dz[k] = dzf[offk + k];
   }
   double* d = nullptr;
@@ -622,6 +628,7 @@ gb25_status build_eos_tables(gb25_model* m) {
   HIPCHK(hipMemcpy(d + tab.size(), dz.data(), dz.size() * sizeof(double), hipMemcpyHostToDevice));
   m->dev_tables.push_back(reinterpret_cast<real*>(d));
   m->g.eos = d;
+  m->g.eosf = d + (size_t)28 * (Nz + 1);
   m->g.dzf_d = d + tab.size();
   return GB25_OK;
 }
@@ -721,7 +728,8 @@ gb25_status build_bottom(gb25_model* m, ZB zb) {
       C[o] = (unsigned)KYC3 | (unsigned)std::min(KPU, 255) << 8 | (unsigned)KPV << 16;
       int KX7 = 0, KY7 = 0;   // WENO(order = 7) tracer advection: the eight cells around the x face / the y face
       for (int q = -4; q <= 3; q++) { KX7 = std::max(KX7, thr(i + q, j)); KY7 = std::max(KY7, thr(i, j + q)); }
-      D[o] = (unsigned)std::min(KX7, 255) | (unsigned)std::min(KY7, 255) << 8;
+      D[o] = (unsigned)std::min(KX7, 255) | (unsigned)std::min(KY7, 255) << 8 |
+             (unsigned)std::min(node_x(i, j), 255) << 16 | (unsigned)std::min(node_y(i, j), 255) << 24;
       const double hf = std::min(depth(i - 1, j), depth(i, j)), hc = std::min(depth(i, j - 1), depth(i, j));
       Hf[o] = (real)hf;
       Hc[o] = (real)hc;
@@ -970,8 +978,8 @@ gb25_status compute_p_impl(gb25_model* m, int i_first = INT_MIN, int i_last = IN
     LAUNCHCHK();
     return GB25_OK;
   }
-  real* n2 = m->catke ? m->catke_b.d : nullptr;   // CATKE's N^2 comes out of the same buoyancies
-  m->n2_fresh = n2 != nullptr;
+  real* n2 = nullptr;   // (CATKE's N^2 is SeawaterBuoyancy's dz_b -- alpha dzT - beta dzS -- not a difference of buoyancies: k_catke_n2)
+  m->n2_fresh = false;
   const bool write_p = !may_skip_p || m->phy_pinned;
   m->phy_stale = !write_p;
   if (i_first == INT_MIN) {
@@ -1204,7 +1212,7 @@ gb25_status tracers_impl(gb25_model* m) {
   return GB25_OK;
 }
 
-gb25_status catke_implicit_impl(gb25_model* m, int mode, real dt, real chi = real(0.));   // (with CATKE's diffusivity fields: below)
+gb25_status catke_implicit_impl(gb25_model* m, int mode, real dt, real chi = real(0.), int z0 = 0, int nz = -1);   // (with CATKE's diffusivity fields: below)
 // implicit_step! of a pair of fields (kind 0: u, v with nu, the corrector's column integrals rewritten; 1: T, S with kappa)
 gb25_status implicit_tables(gb25_model* m, int kind, double dt, double K) {
   if (m->d_implicit[kind] && m->implicit_key[kind][0] == dt && m->implicit_key[kind][1] == K) return GB25_OK;
@@ -1314,8 +1322,8 @@ gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
   if (m->catke) return catke_implicit_impl(m, 0, dt);
   return implicit_vertical_impl(m, 0, dt);
 }
-// the implicit solves of T, S (one elimination) and e with CATKE's diffusivity fields; e <- e + dt (C1 G^n.e - C2 G^-.e)
-// happens as its column is loaded
+// the implicit solve of T, S (one elimination) with CATKE's kappa_c.  e is NOT stepped here: ab2_step! skips it, it is
+// stepped inside compute_diffusivities! (catke_diffusivities_impl)
 gb25_status catke_tracers_impl(gb25_model* m, real dt, real chi) { return catke_implicit_impl(m, 1, dt, chi); }
 gb25_status ab2_tracers_impl(gb25_model* m, real dt, real chi) {
   const Grid& g = m->g;
@@ -1636,7 +1644,7 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
   // cache_previous_tendencies!: G^- <- G^n is a pointer exchange; the next tendency evaluation
   // overwrites the (old G^-) buffers that now carry the G^n name.
   for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);
-  if (m->catke) std::swap(m->f[GB25_GN_E].d, m->f[GB25_GM_E].d);
+  // (closure = CATKE: G^-.e is written by the e step itself -- cache_previous_tendencies! skips e)
   m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;   // the look-aheads used the tendency pairs as they were before
   return GB25_OK;
 }
@@ -1666,20 +1674,89 @@ CatkePar catke_parameters(const gb25_model* m) {
   }
   c.CWu = (real)p.CWu; c.CWw = (real)p.CWw; c.emin = (real)p.minimum_tke; c.Jbmin = (real)p.minimum_convective_buoyancy_flux;
   c.tau_neg = (real)p.negative_tke_damping_time_scale;
+  c.CWeps = (real)p.CWeps;
   return c;
 }
-// J^b = g (alpha J^T - beta J^S) of the model's own columns from the top fluxes and the surface T, S
-void catke_surface_flux_impl(gb25_model* m) {
+// The extended range on which a rank of a decomposition COMPUTES N^2 and the diffusivities: the first halo column on either
+// side, the first halo row of an open side and the row beyond a zipper fold (single domain: the interior, halos by images)
+struct CatkeRange { int i_lo, i_hi, j_lo, j_hi; };
+inline CatkeRange catke_range(const gb25_model* m) {
   const Grid& g = m->g;
-  dim3 b(64, 4);
-  hipLaunchKernelGGL(k_catke_surface_flux, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d,
-                     m->f[GB25_JB].d);
+  CatkeRange r;
+  r.i_lo = m->slab ? -1 : 0;
+  r.i_hi = g.Nx + (m->slab ? 1 : 0);
+  r.j_lo = m->ys_open ? -1 : 0;
+  r.j_hi = g.Ny + ((m->yn_open || (m->slab && g.cv.north_fold)) ? 1 : 0);
+  return r;
 }
-gb25_status catke_update_impl(gb25_model* m) {
+gb25_status catke_implicit_impl(gb25_model* m, int mode, real dt, real chi, int z0, int nz);
+// compute_diffusivities!(diffusivities, closure::CATKE, model), first part: N^2 of the current T, S, the e step
+// (time_step_catke_equation!: k_catke_tke_step + the implicit solve of e) on the own columns, J^b filtered.
+// What follows needs the halos of e and J^b: catke_diffusivities_finish_impl.
+gb25_status catke_tke_step_impl(gb25_model* m) {
   if (!m->catke) return GB25_OK;
   Timed t_closure(m, GB25_K_CLOSURE);
   const Grid& g = m->g;
-  // -div(u e) into G^n.e: one tracer, the two halves of the packed arithmetic on two columns of it (k_tracer_tendencies_single)
+  const CatkeRange r = catke_range(m);
+  dim3 b(64, 4);
+  {
+    const int ni = r.i_hi - r.i_lo, nj = r.j_hi - r.j_lo;
+    hipLaunchKernelGGL(m->immersed ? k_catke_n2<true> : k_catke_n2<false>, dim3((ni + 63) / 64, (nj + 3) / 4, g.Nz - 1), b, 0,
+                       m->stream, g, m->f[GB25_T].d, m->f[GB25_S].d, m->catke_b.d, r.i_lo, r.j_lo, ni, nj);
+  }
+  // dt = clock.last_dt (finite from the model's construction on: GB-25 src/baroclinic_instability_model.jl:82), chi = 0.1 always
+  const real dt = (real)m->last_dt, chi = (real)m->cfg.chi;
+  hipLaunchKernelGGL(m->immersed ? k_catke_tke_step<true> : k_catke_tke_step<false>, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g,
+                     catke_parameters(m), dt, real(1.5) + chi, real(0.5) + chi, m->f[GB25_U].d, m->f[GB25_V].d,
+                     m->f[GB25_PREV_U].d, m->f[GB25_PREV_V].d, m->f[GB25_E].d, m->catke_b.d, m->f[GB25_JB].d,
+                     m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_GN_E].d,
+                     m->f[GB25_GM_E].d);
+  LAUNCHCHK();
+  if (gb25_status s = catke_implicit_impl(m, 1, dt, chi, 1, 1)) return s;   // (the e slice alone)
+  // previous velocities <- velocities (parents): D2D copies behind the kernel that read them
+  HIPCHK(hipMemcpyAsync(m->f[GB25_PREV_U].d, m->f[GB25_U].d, m->f[GB25_U].elems() * sizeof(real), hipMemcpyDeviceToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->f[GB25_PREV_V].d, m->f[GB25_V].d, m->f[GB25_V].elems() * sizeof(real), hipMemcpyDeviceToDevice, m->stream));
+  const double dt_since = m->time - m->catke_prev_time;
+  m->catke_prev_time = m->time;
+  hipLaunchKernelGGL(m->immersed ? k_catke_surface_flux<true> : k_catke_surface_flux<false>, grid2(g.Nx, g.Ny, b), b, 0, m->stream,
+                     g, catke_parameters(m), (real)dt_since, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_T].d, m->f[GB25_S].d,
+                     m->f[GB25_E].d, m->catke_b.d, m->f[GB25_JB].d, m->catke_src.d);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+// ... second part, once the halo cells of the new e (and, on a rank of a decomposition, of J^b) are in place: kappa_u, kappa_c,
+// kappa_e with the halo cells their fill derives (a14).
+gb25_status catke_diffusivities_finish_impl(gb25_model* m) {
+  if (!m->catke) return GB25_OK;
+  Timed t_closure(m, GB25_K_CLOSURE);
+  const Grid& g = m->g;
+  const CatkeRange r = catke_range(m);
+  dim3 b(64, 4);
+  hipLaunchKernelGGL(m->immersed ? k_catke_diffusivities<true> : k_catke_diffusivities<false>,
+                     grid2(r.i_hi - r.i_lo, r.j_hi - r.j_lo, b), b, 0, m->stream, g, catke_parameters(m), m->f[GB25_U].d,
+                     m->f[GB25_V].d, m->f[GB25_E].d, m->catke_b.d, m->f[GB25_JB].d, m->f[GB25_KAPPA_U].d,
+                     m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, r.i_lo, r.i_hi, r.j_lo, r.j_hi);
+  if (g.cv.north_fold && !m->slab)   // the rows beyond the zipper
+    hipLaunchKernelGGL(k_catke_fold, dim3((g.sx + 255) / 256, g.H, g.Nz + 3), dim3(256), 0, m->stream, g,
+                       m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_JB].d);
+  LAUNCHCHK();
+  return GB25_OK;
+}
+// compute_diffusivities! on a single domain: the two parts with the halo fill of the new e between them (option
+// CATKE_STALE_E_HALOS: without it -- Oceananigans as recalled; the bottom / top layers of e are never read)
+gb25_status catke_diffusivities_impl(gb25_model* m) {
+  if (!m->catke) return GB25_OK;
+  gb25_status s;
+  if ((s = catke_tke_step_impl(m))) return s;
+  if (!m->catke_stale_e_halos && (s = fill_halos_impl(m, true, false, 1, 4))) return s;
+  return catke_diffusivities_finish_impl(m);
+}
+// what compute_tendencies! leaves in G^n.e: the SLOW tendency of e -- -div(u e) (one tracer, the two halves of the packed
+// arithmetic on two columns of it: k_tracer_tendencies_single) and the top boundary condition of e (the surface TKE flux)
+gb25_status catke_tendency_impl(gb25_model* m) {
+  if (!m->catke) return GB25_OK;
+  Timed t_closure(m, GB25_K_CLOSURE);
+  const Grid& g = m->g;
   {
     const int nbx = (g.Nx + V3_PAIR - 1) / V3_PAIR, nby = (g.Ny + 3) / 4, kchunks = std::max(1, g.Nz / m->trc_chunk_levels);
     const int nb = nbx * nby * kchunks;
@@ -1696,36 +1773,30 @@ gb25_status catke_update_impl(gb25_model* m) {
                        m->f[GB25_GN_E].d, nbx, kchunks, nb);
   }
   dim3 b(64, 4);
-  if (!m->n2_fresh)   // (normally the pressure kernel of this state left N^2 behind: compute_p_impl)
-    hipLaunchKernelGGL(k_catke_buoyancy, dim3((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz - 1), b, 0, m->stream, g,
-                       m->f[GB25_T].d, m->f[GB25_S].d, m->catke_b.d);   // (N^2 on the interior faces 1 .. Nz-1)
-  // J^b: on a slab it was made right after the AB2 update of T, S and travelled with the 3-D bundle (slab_step.hpp)
-  if (!m->slab) catke_surface_flux_impl(m);
-  // a slab computes kappa in the one halo column / fold row the implicit solves of u / v read (k_catke_diffusivities)
-  const int i_lo = m->slab ? -1 : 0, j_hi = g.Ny, j_lo = m->ys_open ? -1 : 0;   // (... and the row below a southern neighbour's edge)
-  hipLaunchKernelGGL(m->immersed ? k_catke_diffusivities<true> : k_catke_diffusivities<false>,
-                     grid2(g.Nx - i_lo, j_hi - j_lo, b), b, 0, m->stream, g, catke_parameters(m), m->f[GB25_U].d, m->f[GB25_V].d,
-                     m->f[GB25_E].d, m->catke_b.d, m->f[GB25_JB].d, m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d,
-                     m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_GN_E].d, i_lo, j_hi, j_lo);
-  if (g.cv.north_fold && !m->slab)   // the rows beyond the zipper
-    hipLaunchKernelGGL(k_catke_fold, dim3((g.sx + 255) / 256, g.H, g.Nz + 3), dim3(256), 0, m->stream, g,
-                       m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_JB].d);
+  hipLaunchKernelGGL(k_catke_add_top_source, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->catke_src.d, m->f[GB25_GN_E].d);
   LAUNCHCHK();
   return GB25_OK;
 }
-// implicit_step! with CATKE's diffusivity fields.  mode 0: u, v (and the corrector's column integrals); 1: T with S, and
-// e with its AB2 update
-gb25_status catke_implicit_impl(gb25_model* m, int mode, real dt, real chi) {
+// single domain: compute_diffusivities! followed by the slow tendency of e (where update_state! has both at its end)
+gb25_status catke_update_impl(gb25_model* m) {
+  if (!m->catke) return GB25_OK;
+  gb25_status s = catke_diffusivities_impl(m);
+  return s ? s : catke_tendency_impl(m);
+}
+// implicit_step! with CATKE's diffusivity fields.  mode 0: u, v (and the corrector's column integrals); 1: slice 0 = T with S
+// (ab2_step!), slice 1 = e (inside compute_diffusivities!: e holds e* already).  z0, nz: the slices of this launch
+// (default: both of mode 0, slice 0 of mode 1)
+gb25_status catke_implicit_impl(gb25_model* m, int mode, real dt, real chi, int z0, int nz) {
+  if (nz < 0) nz = mode == 0 ? 2 : 1;
   const Grid& g = m->g;
   Timed t_implicit(m, GB25_K_IMPLICIT);
   ImplicitVarFields A{};
   A.f[0] = m->f[GB25_U].d; A.f[1] = m->f[GB25_V].d; A.f[2] = m->f[GB25_T].d; A.f[3] = m->f[GB25_S].d; A.f[4] = m->f[GB25_E].d;
   A.KU = m->f[GB25_KAPPA_U].d; A.KC = m->f[GB25_KAPPA_C].d; A.KE = m->f[GB25_KAPPA_E].d; A.Le = m->f[GB25_LE].d;
   A.dt = dt;
-  if (mode == 1) {
-    A.GnE = m->f[GB25_GN_E].d; A.GmE = m->f[GB25_GM_E].d;
-    A.C1 = real(1.5) + chi; A.C2 = real(0.5) + chi;
-  }
+  A.GnE = A.GmE = nullptr;   // (e arrives with its AB2 update done: k_catke_tke_step)
+  A.C1 = real(1.5) + chi; A.C2 = real(0.5) + chi;
+  A.z0 = z0;
   A.sum[0] = mode == 0 ? m->colsum[0].d : nullptr;
   A.sum[1] = mode == 0 ? m->colsum[1].d : nullptr;
   A.kchunks = mom_kchunks(m);
@@ -1749,7 +1820,7 @@ gb25_status catke_implicit_impl(gb25_model* m, int mode, real dt, real chi) {
 #undef VARK
   dim3 b(64, 4);
   const int rows = mode == 0 ? v_rows(g) : g.Ny;   // (with the zipper fold v has the fold line too)
-  hipLaunchKernelGGL(kern, dim3((g.Nx + 63) / 64, (rows + 3) / 4, 2), b, 0, m->stream, g, A);
+  hipLaunchKernelGGL(kern, dim3((g.Nx + 63) / 64, (rows + 3) / 4, nz), b, 0, m->stream, g, A);
   LAUNCHCHK();
   if (mode == 0) m->colsum_valid = true;
   return GB25_OK;
@@ -1901,7 +1972,9 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
   s = ab2_tracers_impl(m, (real)dt, chi);
   // y/z/x halos of T, S -- unless the look-ahead that was just adopted wrote them itself
   if (!s && (complete || !(ts_adopted && m->ahead_ts_folded))) s = fill_halos_impl(m, true, false, 1, 2);
-  if (!s && m->catke) s = fill_halos_impl(m, true, false, 1, 4);   // the TKE tracer
+  // (closure = CATKE: e is not stepped by ab2_step!; its halos were refilled after its step inside compute_diffusivities! --
+  // unless the option keeps them stale there, as Oceananigans does as recalled: then they are filled here, with the others)
+  if (!s && m->catke && m->catke_stale_e_halos) s = fill_halos_impl(m, true, false, 1, 4);
   if (!s && hipEventRecord(m->ev_ts, side) != hipSuccess) s = fail(m, GB25_ERR_HIP, "hipEventRecord(ev_ts) failed");
   if (!s) s = compute_p_impl(m, INT_MIN, INT_MIN, 0, -1, true);
   if (!s && adopted) s = fill_halos_2d(m, hG);
@@ -2314,6 +2387,7 @@ void gb25_destroy(gb25_model* m) {
     if (p) hipFree(p);
   if (m->catke_b.d) hipFree(m->catke_b.d);
   if (m->catke_scratch.d) hipFree(m->catke_scratch.d);
+  if (m->catke_src.d) hipFree(m->catke_src.d);
   for (auto& F : m->catke_gam) if (F.d) hipFree(F.d);
   for (int a = 0; a < 2; a++) {
     for (auto& w : m->wide[a])
@@ -2573,11 +2647,12 @@ gb25_status gb25_set_closure_catke(gb25_model* m, int32_t on) {
   if (on && !m->f[GB25_E].d) {
     const int H = m->cfg.halo, sx = m->Nx + 2 * H, sy = m->Ny + 2 * H, nz = m->cfg.Nz + 2 * H;
     gb25_status s;
-    for (int id = GB25_E; id <= GB25_JB; id++) {
+    for (int id = GB25_E; id <= GB25_PREV_V; id++) {
       const bool faces = id >= GB25_KAPPA_U && id <= GB25_KAPPA_E;
-      if ((s = alloc_field(m, m->f[id], sx, sy, id == GB25_JB ? 1 : nz + (faces ? 1 : 0)))) return s;
+      if ((s = alloc_field(m, m->f[id], sx, sy + (is_v_shaped(id) ? 1 : 0), id == GB25_JB ? 1 : nz + (faces ? 1 : 0)))) return s;
     }
     if ((s = alloc_field(m, m->catke_b, sx, sy, nz))) return s;
+    if ((s = alloc_field(m, m->catke_src, sx, sy, 1))) return s;
     if ((s = alloc_field(m, m->catke_scratch, sx, sy, nz))) return s;
   }
   m->catke = on != 0;
@@ -2594,12 +2669,13 @@ void gb25_default_catke_parameters(gb25_catke_parameters* p) {
   for (int q = 0; q < 4; q++) { p->Chi[q] = hi[q]; p->Clo[q] = lo[q]; p->Cun[q] = un[q]; p->Cc[q] = cc[q]; p->Ce[q] = ce[q]; }
   p->CWu = 3.179; p->CWw = 0.383;
   p->minimum_tke = 1e-9; p->minimum_convective_buoyancy_flux = 1e-11; p->negative_tke_damping_time_scale = 60.0;
+  p->CWeps = 1.0;
 }
 gb25_status gb25_set_catke_parameters(gb25_model* m, const gb25_catke_parameters* p) {
   CHECK_MODEL(m);
   if (!p) return GB25_ERR_INVALID_ARGUMENT;
-  if (!(p->CRid > 0) || !(p->negative_tke_damping_time_scale > 0) || !(p->minimum_convective_buoyancy_flux > 0))
-    return fail(m, GB25_ERR_INVALID_ARGUMENT, "CATKE parameters: CRid, the damping time scale and the minimum convective buoyancy flux must be positive");
+  if (!(p->CRid > 0) || !(p->negative_tke_damping_time_scale > 0) || !(p->minimum_convective_buoyancy_flux > 0) || !(p->minimum_tke > 0))
+    return fail(m, GB25_ERR_INVALID_ARGUMENT, "CATKE parameters: CRid, the damping time scale, the minimum convective buoyancy flux and the minimum TKE must be positive");
   if (gb25_status s = collective_guard(m, 10, 0, p->Cb)) return s;
   m->catke_par = *p;
   m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
@@ -2716,7 +2792,10 @@ gb25_status gb25_fill_halo_regions(gb25_model* m) {
 gb25_status gb25_compute_auxiliaries(gb25_model* m) {
   CHECK_MODEL(m);
   gb25_status s = compute_w_impl(m);
-  return s ? s : compute_p_impl(m);
+  if (!s) s = compute_p_impl(m);
+  // (closure = CATKE: compute_diffusivities! is the third auxiliary -- it steps e and makes kappa_u, kappa_c, kappa_e, L^e, J^b)
+  if (!s && m->catke && m->slab) return fail(m, GB25_ERR_STATE, "gb25_compute_auxiliaries with CATKE: phase-by-phase driving is for single-domain models");
+  return s ? s : catke_diffusivities_impl(m);
 }
 gb25_status gb25_fill_diffusivity_halos(gb25_model* m) { CHECK_MODEL(m); return GB25_OK; }
 gb25_status gb25_compute_momentum_tendencies(gb25_model* m) { CHECK_MODEL(m); return momentum_impl(m); }
@@ -2837,7 +2916,8 @@ gb25_status gb25_compute_atmosphere_ocean_fluxes(gb25_model* m) {
 gb25_status gb25_compute_tendencies(gb25_model* m) {
   CHECK_MODEL(m);
   gb25_status s = momentum_impl(m);
-  return s ? s : tracers_impl(m);
+  if (!s) s = tracers_impl(m);
+  return s ? s : catke_tendency_impl(m);   // (closure = CATKE: the slow tendency of e)
 }
 gb25_status gb25_ab2_step(gb25_model* m, double dt, int euler) {
   CHECK_MODEL(m);
@@ -2904,6 +2984,10 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
     case GB25_OPT_SUB_STREAM_PRIORITY: m->sub_priority = v != 0; return GB25_OK;
     case GB25_OPT_SUBCYCLE_WHOLE: m->baro_whole = v != 0; return GB25_OK;
     case GB25_OPT_EARLY_STRIPS: m->early_strips = v != 0; return GB25_OK;
+    case GB25_OPT_CATKE_STALE_E_HALOS:
+      if (v != 0 && m->slab) return fail(m, GB25_ERR_STATE, "catke_stale_e_halos: a decomposition cannot leave the halos of e stale at its internal boundaries");
+      m->catke_stale_e_halos = v != 0;
+      return GB25_OK;
     case GB25_OPT_MOMENTUM_CHUNK_LEVELS:
     case GB25_OPT_TRACER_CHUNK_LEVELS:
       if (v < 6 || v > 4096) return fail(m, GB25_ERR_INVALID_ARGUMENT, "chunk levels: 6 or more");
@@ -2949,6 +3033,7 @@ gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
     case GB25_OPT_SUB_STREAM_PRIORITY: *v = m->sub_priority; break;
     case GB25_OPT_SUBCYCLE_WHOLE: *v = m->baro_whole; break;
     case GB25_OPT_EARLY_STRIPS: *v = m->early_strips; break;
+    case GB25_OPT_CATKE_STALE_E_HALOS: *v = m->catke_stale_e_halos; break;
     default: return GB25_ERR_INVALID_ARGUMENT;
   }
   return GB25_OK;
@@ -3085,6 +3170,7 @@ int64_t gb25_debug_sequence(int32_t nslabs, int32_t first, int32_t adopted, int3
   if (first & 64) ops.early = true;       // (bit 6: plain x slabs whose bundle is unpacked on the exchange stream)
   if (first & 32) ops.is_lazy = true;     // (bit 5: a step that keeps the corrector inside its consumers)
   if (first & 16) ops.mesh = true;        // (bit 4: a 2-D decomposition -- y halos from the southern / northern neighbour)
+  if (first & 128) ops.is_catke = true;   // (bit 7: closure = CATKE -- the halos of e and J^b travel inside update_state!)
   bool in_flight = (first & 8) != 0;      // (bit 3: the previous step left the look-ahead chain in flight)
   first &= 1;
   if (first) sequence_first_time_step(ops, in_flight);

@@ -65,11 +65,21 @@ struct Piece {
 };
 void group_pieces(gb25_model* m, int group, std::vector<Piece>& out, int* ncols) {
   const int H = m->cfg.halo, sx = m->Nx + 2 * H;
+  if (group == 20) {
+    // closure = CATKE: the TKE tracer after its step inside compute_diffusivities!, and the filtered J^b (kappa of the first
+    // halo column is COMPUTED from them)
+    *ncols = H;
+    if (!m->catke) return;
+    for (int id : {GB25_E, GB25_JB}) {
+      Field& F = m->f[id];
+      out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
+    }
+    return;
+  }
   if (group == 0 || group == 2 || group == 4) {
     *ncols = H;
     if (group == 0) {
-      for (int id : {GB25_U, GB25_V, GB25_T, GB25_S, GB25_E, GB25_JB}) {
-        if (id >= GB25_E && !m->catke) continue;   // CATKE: the TKE tracer, and J^b for kappa in the first halo column
+      for (int id : {GB25_U, GB25_V, GB25_T, GB25_S}) {
         Field& F = m->f[id];
         out.push_back({F.d, F.d, sx, H, sx, H, (long)F.ny * F.nz});
       }
@@ -110,7 +120,7 @@ int64_t halo_buffer_elems(gb25_model* m, int group) {
   group_pieces(m, group, ps, &nc);
   int64_t t = 0;
   for (auto& p : ps) t += p.rows * nc;
-  return t;
+  return t > 0 ? t : 1;
 }
 // Both sides of a group in ONE launch (a group is up to ten small strips); buf[side] = that side's contiguous buffer.
 gb25_status pack_unpack(gb25_model* m, int group, real* const buf[2], bool pack) {
@@ -161,13 +171,17 @@ void row_pieces(gb25_model* m, int group, int side, bool pack, real* buf, RowPie
     P.nrows = nrows;
     off += (size_t)nz * nrows * sx;
   };
-  if (group == 10) {
-    for (int id : {GB25_U, GB25_V, GB25_T, GB25_S, GB25_E}) {
-      if (id == GB25_E && !m->catke) continue;   // (CATKE: the TKE tracer, and J^b for kappa in the first halo row)
+  if (group == 21) {   // (CATKE: the TKE tracer after its step, and J^b for kappa in the first halo row)
+    if (m->catke) {
+      Field& F = m->f[GB25_E];
+      add(F.d, g.sx, H, (long)g.sx * F.ny, H, g.Nz, H);
+      add(m->f[GB25_JB].d, g.sx, H, 0, 0, 1, H);
+    }
+  } else if (group == 10) {
+    for (int id : {GB25_U, GB25_V, GB25_T, GB25_S}) {
       Field& F = m->f[id];
       add(F.d, g.sx, H, (long)g.sx * F.ny, H, g.Nz, H);
     }
-    if (m->catke) add(m->f[GB25_JB].d, g.sx, H, 0, 0, 1, H);
     if (slab_lazy_ok(m)) {
       // the corrector inside its consumers: the column integrals of u, v of the rows (the receiver's du, dv there) and, for w on
       // the fly, their sums over the chunks of levels
@@ -192,13 +206,14 @@ int64_t row_buffer_elems(gb25_model* m, int group) {
   row_pieces(m, group, 0, true, nullptr, P);
   int64_t t = 0;
   for (int f = 0; f < P.n; f++) t += (int64_t)P.nz[f] * P.nrows * P.sx[f];
-  return t;
+  return t > 0 ? t : 1;
 }
 gb25_status move_rows(gb25_model* m, int group, real* const buf[2], bool pack) {
   for (int side = 0; side < 2; side++) {
     if (!y_neighbour(m, side)) continue;
     RowPieces P;
     row_pieces(m, group, side, pack, buf[side], P);
+    if (P.n == 0) continue;
     int nzmax = 1, sxmax = 0;
     for (int f = 0; f < P.n; f++) { nzmax = std::max(nzmax, P.nz[f]); sxmax = std::max(sxmax, P.sx[f]); }
     const dim3 gr((unsigned)(((long)sxmax * P.nrows + 255) / 256), nzmax, P.n);
@@ -213,7 +228,7 @@ gb25_status move_rows(gb25_model* m, int group, real* const buf[2], bool pack) {
 // buffer set 3: the H rows south of the pivot row of u, v, T, S (CATKE: e, J^b too) and eta, U, V (all parent
 // columns, interior levels);
 // buffer set 4: the Wy (+1) rows south of the pivot row of the sub-cycle's work arrays eta, U, V, G.U, G.V (TallRows, kernels.hpp)
-FoldFields fold_fields(gb25_model* m) {
+FoldFields fold_fields(gb25_model* m, bool closure = false) {   // closure: group 22 -- e and J^b after the e step
   FoldFields F{};
   const Grid& g = m->g;
   long off = 0;
@@ -222,6 +237,13 @@ FoldFields fold_fields(gb25_model* m) {
     F.p[f] = p; F.is_v[f] = is_v; F.xf[f] = xf; F.neg[f] = neg; F.nz[f] = nz; F.off[f] = off;
     off += (long)nz * g.H * g.sx;
   };
+  if (closure) {
+    if (m->catke) {
+      add(m->f[GB25_E].d, 0, 0, 0, g.Nz);
+      add(m->f[GB25_JB].d, 0, 0, 0, 1);
+    }
+    return F;
+  }
   add(m->f[GB25_U].d, 0, 1, 1, g.Nz);
   add(m->f[GB25_V].d, 1, 0, 1, g.Nz);
   add(m->f[GB25_T].d, 0, 0, 0, g.Nz);
@@ -229,10 +251,6 @@ FoldFields fold_fields(gb25_model* m) {
   add(m->f[GB25_ETA].d, 0, 0, 0, 1);
   add(m->f[GB25_BT_U].d, 0, 1, 1, 1);
   add(m->f[GB25_BT_V].d, 1, 0, 1, 1);
-  if (m->catke) {
-    add(m->f[GB25_E].d, 0, 0, 0, g.Nz);
-    add(m->f[GB25_JB].d, 0, 0, 0, 1);
-  }
   return F;
 }
 int fold_levels(const FoldFields& F, bool with_layers) {   // blockIdx.z extent of k_fold_pack / k_fold_unpack
@@ -243,18 +261,21 @@ int fold_levels(const FoldFields& F, bool with_layers) {   // blockIdx.z extent 
 int64_t fold_buffer_elems(gb25_model* m, int b) {
   const Grid& g = m->g;
   if (!g.cv.north_fold) return 1;
+  if (b == 10) return std::max<int64_t>(1, (int64_t)g.H * g.sx * fold_levels(fold_fields(m, true), false));
   return b == 3 ? (int64_t)g.H * g.sx * fold_levels(fold_fields(m), false) : tall_buffer_elems(m);
 }
-gb25_status fold_pack(gb25_model* m, real* buf) {
+gb25_status fold_pack(gb25_model* m, real* buf, bool closure = false) {
   const Grid& g = m->g;
-  FoldFields F = fold_fields(m);
+  FoldFields F = fold_fields(m, closure);
+  if (F.n == 0) return GB25_OK;
   hipLaunchKernelGGL(k_fold_pack, dim3((g.sx + 255) / 256, g.H, fold_levels(F, false)), dim3(256), 0, m->stream, g, F, buf);
   LAUNCHCHK();
   return GB25_OK;
 }
-gb25_status fold_unpack(gb25_model* m, const real* buf) {
+gb25_status fold_unpack(gb25_model* m, const real* buf, bool closure = false) {
   const Grid& g = m->g;
-  FoldFields F = fold_fields(m);
+  FoldFields F = fold_fields(m, closure);
+  if (F.n == 0) return GB25_OK;
   hipLaunchKernelGGL(k_fold_unpack, dim3((g.sx + 255) / 256, g.H, fold_levels(F, true)), dim3(256), 0, m->stream, g, F, buf,
                      m->rx * m->Nx, m->cfg.Nx);
   LAUNCHCHK();
@@ -265,6 +286,22 @@ gb25_status fold_unpack(gb25_model* m, const real* buf) {
 // whose fields and fills sit in between)
 inline bool strips_on_comm(const gb25_model* m) {
   return m->early_strips && m->two_streams && m->pressure_bits == 64 && m->Ry == 1 && !m->catke;
+}
+
+// closure = CATKE on a rank of a decomposition.  compute_diffusivities! steps e on the own columns (time_step_catke_equation!)
+// and filters J^b there; the diffusivities of the first halo column / row and the advection of e then need the NEW e and J^b of
+// the neighbours: one more exchange per update_state! (groups 20: x columns, 21: rows of a 2-D decomposition, 22: the rows
+// beyond a zipper fold), between these two halves.
+gb25_status catke_step_local(gb25_model* m) {
+  gb25_status s;
+  if ((s = catke_tke_step_impl(m))) return s;
+  return fill_halos_impl(m, false, false, 1, 4);   // y/z layers of the new e on the own columns: the packed columns travel complete
+}
+gb25_status catke_finish_local(gb25_model* m) {
+  gb25_status s;
+  if ((s = fill_halos_impl(m, false, true, 1, 4))) return s;   // y/z layers of e over the extended range (the halo rows' bottom / top layers)
+  if ((s = catke_diffusivities_finish_impl(m))) return s;
+  return catke_tendency_impl(m);
 }
 
 // ---- the stages of one slab's time step (see the header of this file) -------------------------------------------------
@@ -296,7 +333,6 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
     m->w_fly_now = m->step_lazy && slab_wfly_ok(m);
     if (!m->step_lazy && (s = materialize_uv(m))) return s;   // (the sweeps below expect corrected velocities)
     if ((s = ab2_local_impl(m, (real)dt, chi))) return s;
-    if (m->catke) catke_surface_flux_impl(m);   // J^b of the new T, S: its halo columns travel with group 0
     if (m->baro_adopted) {
       // the sub-cycle of this step, its wide-halo exchange and the exchange of the new eta, U, V columns all ran
       // beside the last tracer kernel (stage 5): adopt the results, stage 1 and groups 1, 2 are skipped
@@ -309,7 +345,6 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       m->iteration += 1;
     }
     if ((s = fill_halos_impl(m, false, false, 1))) return s;
-    if (m->catke && (s = fill_halos_impl(m, false, false, 1, 4))) return s;   // (the TKE tracer's y/z layers)
     if (p_early) {
       // T, S of the slab's own columns are final from here on: their pressure (fp64-bound) runs on the side stream
       // beside the exchanges and the sub-cycle; the strips next to the x halos follow in stage 3.  The first x
@@ -483,7 +518,6 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       // (with the early strips T and S are left alone here: their layers are in place, own columns since stage 0)
       if (p_early && !strips_first) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));   // (the interior pass reads T, S)
       if (!(m->step_lazy && strips_first) && (s = fill_halos_impl(m, false, true, 3, strips_first ? 1 : 3))) return s;
-      if (m->catke && (s = fill_halos_impl(m, false, true, 1, 4))) return s;
       if (stage == 30) return GB25_OK;
     }
     if (p_early && !strips_first && (s = pressure_strips())) return s;   // (beside w)
@@ -499,7 +533,11 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
   } else if (stage == 4) {
     // the tracer tendencies; the look-ahead of the next sub-cycle (groups 3, 4 and stage 5) runs beside them
     if ((s = tracers_impl(m))) return s;
-    if ((s = catke_update_impl(m))) return s;
+    if (m->catke) return catke_step_local(m);   // (the rest after the halos of the new e and J^b: stage 41)
+    return atmosphere_ocean_fluxes_impl(m);
+  } else if (stage == 41) {
+    // closure = CATKE: groups 20 - 22 have been unpacked -- the diffusivities and the slow tendency of e, then the fluxes
+    if ((s = catke_finish_local(m))) return s;
     return atmosphere_ocean_fluxes_impl(m);
   }
   return fail(m, GB25_ERR_INVALID_ARGUMENT, "unknown stage %d", stage);
@@ -509,12 +547,11 @@ gb25_status update_state_local_impl(gb25_model* m) {   // update_state! without 
   gb25_status s;
   if ((s = mask_impl(m))) return s;   // (own columns; the halo columns arrived masked by their owners)
   if ((s = fill_halos_impl(m, false, m->slab))) return s;
-  if (m->catke && (s = fill_halos_impl(m, false, m->slab, 1, 4))) return s;
   if ((s = compute_w_impl(m))) return s;
   if ((s = compute_p_impl(m))) return s;
   if ((s = momentum_impl(m))) return s;
   if ((s = tracers_impl(m))) return s;
-  return catke_update_impl(m);
+  return m->catke ? catke_step_local(m) : GB25_OK;   // (the sequencer goes on with groups 20 - 22 and catke_finish_local)
 }
 
 // ---- sequencing ------------------------------------------------------------------------------------------------------
@@ -535,6 +572,7 @@ struct StepOps {
   virtual bool velocities_ready(int s) = 0;
   virtual bool subcycle_adopted(int s) = 0;
   virtual bool coupled() { return false; }   // a prescribed atmosphere is set (data-free forcing)
+  virtual bool catke() { return false; }     // closure = CATKE: the halos of the new e, J^b travel inside update_state! (groups 20 - 22)
   virtual bool folded() = 0;          // zipper fold: exchanges with the partner rank (buffer sets 3 and 4; groups 6 and 8)
   virtual bool lazy() { return false; }     // this step keeps the corrector inside its consumers (known after stage 0)
   // the bundle is unpacked on the exchange stream right behind its transfer (halo columns only: nothing the main stream touches
@@ -554,6 +592,24 @@ struct StepOps {
 #define EACH(expr)                         \
   for (int s = 0; s < n; s++) SEQ(expr)
 
+// closure = CATKE: e was stepped and J^b filtered on the own columns; their halos, then the second half of compute_diffusivities!
+// and the slow tendency of e (`finish`: a stage of the step, or local operation 7 inside first_time_step!)
+gb25_status sequence_catke_halos(StepOps& o, int n) {
+  EACH(o.pack(s, 20, false));
+  SEQ(o.exchange(20, false));
+  EACH(o.unpack(s, 20, false));
+  if (o.mesh_y()) {       // whole rows, with the x halo columns just received (the corners)
+    EACH(o.pack(s, 21, false));
+    SEQ(o.exchange(21, false));
+    EACH(o.unpack(s, 21, false));
+  }
+  if (o.folded()) {
+    EACH(o.pack(s, 22, false));
+    SEQ(o.exchange(22, false));
+    EACH(o.unpack(s, 22, false));
+  }
+  return GB25_OK;
+}
 gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight) {
   const int n = o.n();
   // The previous step may have left the look-ahead chain (group 3, stage 5) running on the second stream.  Stage 0 touches
@@ -697,6 +753,10 @@ gb25_status sequence_time_step(StepOps& o, int euler, bool& lookahead_in_flight)
     lookahead_in_flight = true;
   }
   EACH(o.stage(s, 4, euler, false));
+  if (o.catke()) {
+    SEQ(sequence_catke_halos(o, n));
+    EACH(o.stage(s, 41, euler, false));
+  }
   return GB25_OK;
 }
 // first_time_step!: initialize!, update_state!, then an Euler step (GB-25 src/timestepping_utils.jl:21-27)
@@ -753,27 +813,19 @@ gb25_status sequence_first_time_step(StepOps& o, bool& lookahead_in_flight) {
       SEQ(o.local(s, 2));
     }
   }
+  if (o.catke()) {
+    SEQ(sequence_catke_halos(o, n));
+    EACH(o.local(s, 7));
+  }
   if (o.coupled()) {
     // a coupled model (data-free forcing) updates its state at iteration 0: the atmosphere-ocean fluxes of the initial state,
-    // J^b from them, once more through the bundles (J^b of the halo column / the fold rows), then the diffusivities and
-    // tendencies that see them
-    for (int s = 0; s < n; s++) {
-      SEQ(o.local(s, 5));
-      SEQ(o.pack(s, 0, false));
-    }
-    SEQ(o.exchange(0, false));
-    EACH(o.unpack(s, 0, false));
-    if (o.mesh_y()) {
-      EACH(o.pack(s, 10, false));
-      SEQ(o.exchange(10, false));
-      EACH(o.unpack(s, 10, false));
-    }
-    if (o.folded()) {
-      EACH(o.pack(s, 6, false));
-      SEQ(o.exchange(6, false));
-      EACH(o.unpack(s, 6, false));
-    }
+    // then the tendencies (and, with CATKE, another compute_diffusivities!) that see them
+    EACH(o.local(s, 5));
     EACH(o.local(s, 6));
+    if (o.catke()) {
+      SEQ(sequence_catke_halos(o, n));
+      EACH(o.local(s, 7));
+    }
   }
   return sequence_time_step(o, 1, lookahead_in_flight);
 }
@@ -785,7 +837,7 @@ struct TraceOps : StepOps {
   int nslabs;
   bool adopted, ready;
   std::string log;
-  bool fold = false, is_coupled = false, mesh = false, is_lazy = false, early = false;
+  bool fold = false, is_coupled = false, mesh = false, is_lazy = false, early = false, is_catke = false;
   TraceOps(int n_, bool a, bool r) : nslabs(n_), adopted(a), ready(r) {}
   bool folded() override { return fold; }
   bool mesh_y() override { return mesh; }
@@ -793,6 +845,7 @@ struct TraceOps : StepOps {
   bool early_unpack() override { return early; }
   bool early_strips() override { return early && !fold && !mesh; }
   bool coupled() override { return is_coupled; }
+  bool catke() override { return is_catke; }
   void add(const char* fmt, ...) {
     char buf[96];
     va_list ap;
@@ -810,7 +863,7 @@ struct TraceOps : StepOps {
   gb25_status exchange(int group, int c) override { add("exchange %d %s", group, st(c)); return GB25_OK; }
   gb25_status local(int s, int what) override {
     static const char* names[] = {"initialize", "fill_local", "update_state_local", "mask_fill_local", "auxiliaries_tendencies_local",
-                                  "first_fluxes_local", "tendencies_local"};
+                                  "first_fluxes_local", "tendencies_local", "catke_finish_local"};
     add("%s slab %d main", names[what], s);
     return GB25_OK;
   }
@@ -844,10 +897,11 @@ struct SlabGroup {
   Transport* transport = nullptr;
   // [slab][buffer set][side: 0 west, 1 east]; sets 3, 4 go to the fold partner (side 0 only); sets 5, 6, 7 to the southern
   // (side 0) and northern (side 1) neighbour of a 2-D decomposition
-  static constexpr int NSETS = 8;
+  // sets 8, 9, 10: closure = CATKE -- e and J^b after the e step: x columns (west / east), rows (south / north), fold partner
+  static constexpr int NSETS = 11;
   std::vector<std::array<std::array<real*, 2>, NSETS>> send, recv;
-  size_t elems[NSETS] = {0, 0, 0, 0, 0, 0, 0, 0};      // elements per side of buffer set b in an exchange
-  size_t capacity[NSETS] = {0, 0, 0, 0, 0, 0, 0, 0};   // ... and allocated
+  size_t elems[NSETS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // elements per side of buffer set b in an exchange
+  size_t capacity[NSETS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // ... and allocated
   bool lookahead_in_flight = false;
   // neighbour handshake of the collective mutators (see collective_guard)
   unsigned long long *tok_dev = nullptr, *tok_host = nullptr;
@@ -857,10 +911,13 @@ namespace {
 
 // (groups 6, 8: the partner exchanges of a folded grid -- the rows next to the pivot row; the image rows of the sub-cycle)
 inline int buffer_set(int group) {
+  if (group >= 20) return group - 12;   // (closure = CATKE: groups 20, 21, 22 -> sets 8, 9, 10)
   if (group >= 10) return group == 10 ? 5 : ((group == 11 || group == 13) ? 6 : 7);   // (the y halos of a 2-D decomposition)
   return group == 6 ? 3 : group == 8 ? 4 : group == 0 ? 0 : ((group == 1 || group == 3) ? 1 : 2);
 }
-inline int set_sides(int b) { return (b == 3 || b == 4) ? 1 : 2; }
+// whom a buffer set travels to: 0 the west / east ring neighbours, 1 the fold partner, 2 the southern / northern neighbour
+inline int set_kind(int b) { return (b == 3 || b == 4 || b == 10) ? 1 : ((b >= 5 && b <= 7) || b == 9) ? 2 : 0; }
+inline int set_sides(int b) { return set_kind(b) == 1 ? 1 : 2; }
 // rank = ry Rx + rx: the ring neighbours within the row, the neighbours in the column, the fold partner within the top row
 struct MeshPos {
   int Rx, Ry, rx, ry;
@@ -881,9 +938,9 @@ struct LocalRingTransport : Transport {
     for (int r = 0; r < P; r++) {
       gb25_model* m = G.slabs[r];
       const MeshPos q(m);
-      if (b == 3 || b == 4) {   // zipper fold: slab rx <-> slab Rx-1-rx of the top row (the middle slab of an odd count is its own partner)
+      if (set_kind(b) == 1) {   // zipper fold: slab rx <-> slab Rx-1-rx of the top row (the middle slab of an odd count is its own partner)
         if (m->g.cv.north_fold) HIPCHK(hipMemcpyAsync(G.recv[q.partner()][b][0], G.send[r][b][0], nbytes, hipMemcpyDeviceToDevice, st));
-      } else if (b >= 5) {      // my southern pack -> the southern neighbour's northern halo; my northern pack -> ... southern halo
+      } else if (set_kind(b) == 2) {      // my southern pack -> the southern neighbour's northern halo; my northern pack -> ... southern halo
         if (q.south() >= 0) HIPCHK(hipMemcpyAsync(G.recv[q.south()][b][1], G.send[r][b][0], nbytes, hipMemcpyDeviceToDevice, st));
         if (q.north() >= 0) HIPCHK(hipMemcpyAsync(G.recv[q.north()][b][0], G.send[r][b][1], nbytes, hipMemcpyDeviceToDevice, st));
       } else {                  // my west pack -> west neighbour's east halo; my east pack -> east neighbour's west halo
@@ -977,7 +1034,7 @@ struct RcclTransport : Transport {
     return GB25_OK;
   }
   gb25_status exchange(SlabGroup& G, int b, size_t nbytes, hipStream_t st) override {
-    if (b >= 5) {   // 2-D decomposition: the southern and the northern neighbour, where they exist
+    if (set_kind(b) == 2) {   // 2-D decomposition: the southern and the northern neighbour, where they exist
       gb25_model* m = G.slabs[0];
       const MeshPos q(m);
       RcclApi& R = rccl();
@@ -990,7 +1047,7 @@ struct RcclTransport : Transport {
       NCCLCHK(R.GroupEnd());
       return GB25_OK;
     }
-    if (b >= 3) {   // zipper fold: the partner is the mirrored rank of the (top) row
+    if (set_kind(b) == 1) {   // zipper fold: the partner is the mirrored rank of the (top) row
       gb25_model* m = G.slabs[0];
       if (!m->g.cv.north_fold) return GB25_OK;
       const int partner = MeshPos(m).partner();
@@ -1020,10 +1077,11 @@ struct CallbackTransport : Transport {
     // (buffer sets 3, 4: to and from the fold partner rank P-1-r; the east pointers are null)
     // (buffer sets 5 - 7: to and from the southern [west pointers] and northern [east pointers] neighbour of a 2-D
     // decomposition; null where there is none)
-    if ((b == 3 || b == 4) && !m->g.cv.north_fold) return GB25_OK;
+    const int kind = set_kind(b);
+    if (kind == 1 && !m->g.cv.north_fold) return GB25_OK;
     int rc;
-    if (b == 3 || b == 4) rc = fn(user, b, G.send[0][b][0], nullptr, G.recv[0][b][0], nullptr, (int64_t)nbytes);
-    else if (b >= 5) rc = fn(user, b, m->ys_open ? G.send[0][b][0] : nullptr, m->yn_open ? G.send[0][b][1] : nullptr,
+    if (kind == 1) rc = fn(user, b, G.send[0][b][0], nullptr, G.recv[0][b][0], nullptr, (int64_t)nbytes);
+    else if (kind == 2) rc = fn(user, b, m->ys_open ? G.send[0][b][0] : nullptr, m->yn_open ? G.send[0][b][1] : nullptr,
                              m->ys_open ? G.recv[0][b][0] : nullptr, m->yn_open ? G.recv[0][b][1] : nullptr, (int64_t)nbytes);
     else rc = fn(user, b, G.send[0][b][0], G.send[0][b][1], G.recv[0][b][0], G.recv[0][b][1], (int64_t)nbytes);
     if (rc != 0) return fail(m, GB25_ERR_COMM, "the host's exchange callback failed with code %d (buffer set %d)", rc, b);
@@ -1069,13 +1127,14 @@ struct GroupOps : StepOps {
     return true;
   }
   bool coupled() override { return G.slabs[0]->coupled; }
+  bool catke() override { return G.slabs[0]->catke; }
   gb25_status pack(int s, int group, int c) override {
     OnStream on(G.slabs[s], st(c));
     const int b = buffer_set(group);
-    if ((group == 6 || group == 8) && !G.slabs[s]->g.cv.north_fold) return GB25_OK;
-    if (group == 6) return fold_pack(G.slabs[s], G.send[s][b][0]);
+    if ((group == 6 || group == 8 || group == 22) && !G.slabs[s]->g.cv.north_fold) return GB25_OK;
+    if (group == 6 || group == 22) return fold_pack(G.slabs[s], G.send[s][b][0], group == 22);
     if (group == 8) return tall_rows_impl(G.slabs[s], G.send[s][b][0], true);
-    if (group >= 10) {
+    if ((group >= 10 && group < 20) || group == 21) {
       real* rb[2] = {G.send[s][b][0], G.send[s][b][1]};
       return move_rows(G.slabs[s], group, rb, true);
     }
@@ -1086,10 +1145,10 @@ struct GroupOps : StepOps {
   gb25_status unpack(int s, int group, int c) override {
     OnStream on(G.slabs[s], st(c));
     const int b = buffer_set(group);
-    if ((group == 6 || group == 8) && !G.slabs[s]->g.cv.north_fold) return GB25_OK;
-    if (group == 6) return fold_unpack(G.slabs[s], G.recv[s][b][0]);
+    if ((group == 6 || group == 8 || group == 22) && !G.slabs[s]->g.cv.north_fold) return GB25_OK;
+    if (group == 6 || group == 22) return fold_unpack(G.slabs[s], G.recv[s][b][0], group == 22);
     if (group == 8) return tall_rows_impl(G.slabs[s], G.recv[s][b][0], false);
-    if (group >= 10) {
+    if ((group >= 10 && group < 20) || group == 21) {
       real* rb[2] = {G.recv[s][b][0], G.recv[s][b][1]};
       return move_rows(G.slabs[s], group, rb, false);
     }
@@ -1104,16 +1163,12 @@ struct GroupOps : StepOps {
     gb25_model* m = G.slabs[s];
     if (what == 0) return initialize_impl(m);
     if (what == 1) {
-      if (gb25_status s_ = fill_halos_impl(m, false)) return s_;
-      if (!m->catke) return GB25_OK;
-      catke_surface_flux_impl(m);   // (J^b travels with group 0)
-      return fill_halos_impl(m, false, false, 1, 4);
+      return fill_halos_impl(m, false);
     }
     if (what == 3) {
       gb25_status s_;
       if ((s_ = mask_impl(m))) return s_;
-      if ((s_ = fill_halos_impl(m, false, true))) return s_;
-      return m->catke ? fill_halos_impl(m, false, true, 1, 4) : GB25_OK;
+      return fill_halos_impl(m, false, true);
     }
     if (what == 4) {
       gb25_status s_;
@@ -1121,19 +1176,16 @@ struct GroupOps : StepOps {
       if ((s_ = compute_p_impl(m))) return s_;
       if ((s_ = momentum_impl(m))) return s_;
       if ((s_ = tracers_impl(m))) return s_;
-      return catke_update_impl(m);
+      return m->catke ? catke_step_local(m) : GB25_OK;
     }
-    if (what == 5) {   // coupled model, iteration 0: fluxes of the initial state and J^b of the own columns
-      if (gb25_status s_ = atmosphere_ocean_fluxes_impl(m)) return s_;
-      if (m->catke) catke_surface_flux_impl(m);
-      return GB25_OK;
-    }
+    if (what == 5) return atmosphere_ocean_fluxes_impl(m);   // coupled model, iteration 0: fluxes of the initial state
     if (what == 6) {
       gb25_status s_;
       if ((s_ = momentum_impl(m))) return s_;
       if ((s_ = tracers_impl(m))) return s_;
-      return catke_update_impl(m);
+      return m->catke ? catke_step_local(m) : GB25_OK;
     }
+    if (what == 7) return catke_finish_local(m);
     return update_state_local_impl(m);
   }
   bool velocities_ready(int s) override {
@@ -1179,15 +1231,16 @@ void group_destroy(SlabGroup* G) {
   delete G;
 }
 
-// The bundles of group 0 and of the fold rows carry more fields once a closure adds them (CATKE: e, J^b): sizes again, larger
-// buffers if needed.  Called at the head of the composites; every rank made the same (collective) setter calls.
+// The bundle of group 0 carries more once an option adds the chunk sums of u, v to it, and a closure brings exchanges of its
+// own (CATKE: e, J^b -- sets 8 - 10): sizes again, larger buffers if needed.  Called at the head of the composites; every rank made the same (collective) setter calls.
 gb25_status group_refresh(SlabGroup* G) {
   gb25_model* m = G->slabs[0];
   const int n = (int)G->slabs.size();
-  for (int b : {0, 3, 5}) {
+  for (int b : {0, 3, 5, 8, 9, 10}) {   // (8 - 10: closure = CATKE switched on after the context was built -- its sets grow from one element)
     size_t need = 0;
     for (gb25_model* q : G->slabs)
-      need = std::max(need, (size_t)(b == 0 ? halo_buffer_elems(q, 0) : b == 3 ? fold_buffer_elems(q, 3) : row_buffer_elems(q, 10)));
+      need = std::max(need, (size_t)(b == 0 ? halo_buffer_elems(q, 0) : b == 3 ? fold_buffer_elems(q, 3) : b == 5 ? row_buffer_elems(q, 10)
+                                     : b == 8 ? halo_buffer_elems(q, 20) : b == 10 ? fold_buffer_elems(q, 10) : row_buffer_elems(q, 21)));
     if (need == G->elems[b]) continue;
     HIPCHK(G->sync_side());
     HIPCHK(hipStreamSynchronize(G->main));
@@ -1250,7 +1303,10 @@ gb25_status group_create(gb25_model* const* slabs, int n, Transport* tr) {
     // (2-D decomposition: the top row of ranks folds, the others do not; every slab gets buffers of the size a folded one needs)
     for (int b = 3; b < 5; b++)
       for (int s = 0; s < n; s++) G->elems[b] = std::max(G->elems[b], (size_t)fold_buffer_elems(slabs[s], b));
-    for (int b = 5; b < SlabGroup::NSETS; b++) G->elems[b] = (size_t)row_buffer_elems(m, b == 5 ? 10 : (b == 6 ? 11 : 12));
+    for (int b = 5; b < 8; b++) G->elems[b] = (size_t)row_buffer_elems(m, b == 5 ? 10 : (b == 6 ? 11 : 12));
+    G->elems[8] = (size_t)halo_buffer_elems(m, 20);
+    G->elems[9] = (size_t)row_buffer_elems(m, 21);
+    for (int s = 0; s < n; s++) G->elems[10] = std::max(G->elems[10], (size_t)fold_buffer_elems(slabs[s], 10));
     for (int b = 0; b < SlabGroup::NSETS; b++) G->capacity[b] = G->elems[b];
     G->send.resize(n);
     G->recv.resize(n);

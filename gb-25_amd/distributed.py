@@ -147,13 +147,16 @@ class SlabModel(HydrostaticFreeSurfaceModel):
             dev = torch.device("cuda", device)
 
             def exchange(buffer_set, sw, se, rw, re, nbytes):
-                if buffer_set >= 5:      # y halos: (south, north) in the place of (west, east); null where there is no neighbour
+                # whom a buffer set travels to (set_kind in csrc/slab_step.hpp): 0 - 2, 8: the west / east ring neighbours;
+                # 3, 4, 10: the fold partner; 5 - 7, 9: the southern / northern neighbour (8 - 10: CATKE's e and J^b)
+                kind = 1 if buffer_set in (3, 4, 10) else 2 if buffer_set in (5, 6, 7, 9) else 0
+                if kind == 2:            # y halos: (south, north) in the place of (west, east); null where there is no neighbour
                     t = lambda p: _as_tensor(p, nbytes, dev) if p else None
                     self._ring.exchange_y(t(sw), t(se), t(rw), t(re))
                     if torch.cuda.is_available():
                         torch.cuda.current_stream().synchronize()
                     return
-                if buffer_set >= 3:      # to and from the fold partner (the east pointers are null)
+                if kind == 1:            # to and from the fold partner (the east pointers are null)
                     self._ring.exchange_partner(_as_tensor(sw, nbytes, dev), _as_tensor(rw, nbytes, dev))
                     if torch.cuda.is_available():
                         torch.cuda.current_stream().synchronize()

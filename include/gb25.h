@@ -393,7 +393,9 @@ gb25_status gb25_comm_init_local(gb25_model *const *slabs, int32_t n);
  * only) are exchanges with the FOLD PARTNER, rank nranks-1-rank (2-D decomposition: the mirrored rank of the same row):
  * send_west goes to it, recv_west must hold what it sent, the east pointers are NULL.  buffer_set 5, 6, 7 (2-D decomposition
  * only) are the y halos: the "west" pointers belong to the SOUTHERN neighbour (rank - Rx), the "east" pointers to the
- * NORTHERN one (rank + Rx); a side without a neighbour has NULL pointers. */
+ * NORTHERN one (rank + Rx); a side without a neighbour has NULL pointers.  buffer_set 8, 9, 10 (closure = CATKE only: the TKE
+ * tracer and J^b after their step inside compute_diffusivities!) go to the ring neighbours, to the southern / northern neighbours
+ * and to the fold partner respectively, with the pointer conventions above. */
 typedef int32_t (*gb25_exchange_fn)(void *user, int32_t buffer_set, const void *send_west, const void *send_east,
                                     void *recv_west, void *recv_east, int64_t nbytes);
 gb25_status gb25_comm_init_callback(gb25_model *m, gb25_exchange_fn fn, void *user);

@@ -201,18 +201,31 @@ def _raw_sequence(nslabs, first, adopted=0, ready=0):
 
 def test_first_time_step_of_a_coupled_model():
     """Data-free forcing on slabs: after the ordinary update_state! every slab computes the atmosphere-ocean fluxes of the
-    initial state and its J^b, the 3-D bundle travels once more (J^b of the halo column), then the diffusivities and
-    tendencies that see the fluxes; only then the Euler step."""
+    initial state (the first halo column's are COMPUTED, nothing travels), then the tendencies that see them; only then the
+    Euler step.  With closure = CATKE every update_state! has an exchange of its own inside: e is stepped and J^b filtered on
+    the own columns (compute_diffusivities!), their halos travel (group 20; rows 21 on a mesh, the fold partner 22), then the
+    diffusivities of the first halo column and the slow tendency of e."""
     log = _raw_sequence(2, 1 | 4)
     names = [e[0] for e in log]
     i_state = names.index("update_state_local")
     i_flux = names.index("first_fluxes_local")
     i_tend = names.index("tendencies_local")
     ex0 = [i for i, e in enumerate(log) if e[:2] == ("exchange", 0)]
-    assert i_state < i_flux < i_tend and len(ex0) == 3                    # initial halos, J^b, the Euler step's bundle
-    assert i_flux < ex0[1] < i_tend < ex0[2]
+    assert i_state < i_flux < i_tend and len(ex0) == 2                    # initial halos, the Euler step's bundle
+    assert i_tend < ex0[1] and not [e for e in log if e[:2] == ("exchange", 20)]
     plain = _raw_sequence(2, 1)
     assert "first_fluxes_local" not in [e[0] for e in plain]
+    # the same with CATKE (bit 7): three update_state! (initial, coupled iteration 0, the Euler step), each with its exchange
+    log = _raw_sequence(2, 1 | 4 | 128)
+    ex20 = [i for i, e in enumerate(log) if e[:2] == ("exchange", 20)]
+    fin = [i for i, e in enumerate(log) if e[0] == "catke_finish_local" and e[2] == 0] + \
+          [i for i, e in enumerate(log) if e[:4] == ("stage", 41, "slab", 0)]
+    assert len(ex20) == 3 and len(fin) == 3 and all(a < b for a, b in zip(ex20, fin))
+    assert log.index(("stage", 4, "slab", 1, "euler", 1, "main")) < ex20[2] < log.index(("stage", 41, "slab", 0, "euler", 1, "main"))
+    # a folded 2-D decomposition: columns, then whole rows (the corners ride along), then the fold partner
+    log = _raw_sequence(2, 2 | 16 | 128, adopted=1, ready=1)
+    order = [e[1] for e in log if e[0] == "exchange" and e[1] >= 20]
+    assert order == [20, 21, 22]
 
 
 def test_a_step_behind_a_look_ahead_chain_in_flight():
