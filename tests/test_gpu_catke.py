@@ -43,12 +43,28 @@ def test_diffusivity_fields_match_the_oracle(float_type, tol):
     included (a14: the fill of the diffusivity fields)."""
     r, v = make_pair(40, 44, 16, dt=120.0, float_type=float_type, depth=200.0, closure=CATKE())
     start(r, v, wind=-1e-4, heat=5e-5)
+    names = ("kappa_u", "kappa_c", "kappa_e", "Le", "Jb", "e", "Gn.e", "Gm.e", "Gn.T", "Gn.u", "previous_u", "previous_v")
     for m in (r, v):
         gb.update_state(m)
-    for n in ("kappa_u", "kappa_c", "kappa_e", "Le", "Jb", "Gn.e", "Gn.T", "Gn.u"):
+    for n in names:
         a, b = r.backend.get_field(n, True), v.backend.get_field(n, True)
         assert rel(a, b) < tol, (n, rel(a, b))
-    assert r.diffusivity_fields.kappa_u.interior.max() > 1e-5 and r.diffusivity_fields.Jb.interior.min() > 1e-8
+    # (the first compute_diffusivities! has stepped e with nothing to produce it yet and left J^b alone: no time has passed)
+    assert r.diffusivity_fields.kappa_u.interior.max() > 1e-5 and r.diffusivity_fields.Jb.interior.max() == 0
+    # a second one right away steps e again, now with shear production and buoyancy flux from the diffusivities of the first ...
+    for m in (r, v):
+        gb.update_state(m)
+    for n in names:
+        a, b = r.backend.get_field(n, True), v.backend.get_field(n, True)
+        assert rel(a, b) < 4 * tol, (n, rel(a, b))
+    # ... and after two time steps the surface buoyancy flux has come through its filter
+    for m in (r, v):
+        gb.first_time_step(m)
+        gb.time_step(m)
+    for n in names:
+        a, b = r.backend.get_field(n, True), v.backend.get_field(n, True)
+        assert rel(a, b) < (1e-8 if float_type == "Float64" else 5e-4), (n, rel(a, b))
+    assert r.diffusivity_fields.Jb.interior.min() > 1e-9
 
 
 @pytest.mark.parametrize("float_type", ["Float64", "Float32"])
@@ -99,12 +115,13 @@ def test_stepping_with_catke_matches_the_oracle(case, float_type):
                     "Le < 0 (dissipation wins)": lambda m: m.diffusivity_fields.Le.interior < 0,
                     "Jb > 0 (cooled)": lambda m: m.diffusivity_fields.Jb.interior > 0}
         agree = {k: float(np.mean(f(r) == f(v))) for k, f in switches.items()}
-        assert all(a >= 0.999 for a in agree.values()), agree
+        # (e > e_min: under pure cooling the TKE below the convecting layer decays to the floor and sits within round-off of it)
+        assert all(a >= (0.998 if k.startswith("e >") else 0.999) for k, a in agree.items()), agree
         # (the measured numbers behind DESIGN.md section 0's table of the closure fields)
         import json, os
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-        path = os.path.join(root, "gpurun_out", "r03_catke_fp32.json")
+        path = os.path.join(root, "gpurun_out", "r04_catke_fp32.json")
         doc = json.load(open(path)) if os.path.exists(path) else {}
         doc[case] = {"size": list(size), "steps": 31, "rtol_reference": SQRT_EPS32,
                      "hip_f32_vs_oracle_f64": {q["name"]: q["rel"] for q in report},
@@ -126,8 +143,9 @@ def test_catke_fields_exist_only_with_the_closure():
 @pytest.mark.parametrize("grid_type,P", [("simple_lat_lon", 3), ("gaussian_islands_lat_lon", 2), ("gaussian_islands", 2),
                                          ("gaussian_islands", 4)])
 def test_catke_on_slabs_is_the_single_domain_bit_for_bit(grid_type, P):
-    """x slabs with CATKE: e and J^b ride in the 3-D bundle (and in the fold rows of a tripolar grid), kappa in the one halo
-    column / fold row the implicit solves read is computed locally from exchanged halos -- no further exchange."""
+    """x slabs with CATKE: e is stepped and J^b filtered on the own columns inside compute_diffusivities!, their halos travel
+    (one exchange per update_state!: columns, and the rows beyond a zipper fold), kappa in the first halo column on either side
+    / the fold row is computed locally from the exchanged halos."""
     from gb25_amd.distributed import LocalSlabEnsemble
     Nx, Ny, Nz, dt = 192, 44, 12, 300.0
     depth = 4000.0 if "islands" in grid_type else 200.0
