@@ -10,7 +10,9 @@ resident in HBM before the timed region starts.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size Nx Ny Nz] [--weak] [--no-cpu-baseline]
 N > 1 is launched by the driver with torch.distributed.run, one rank per GPU: the SAME Nx x Ny x Nz grid (BASELINE.json:
 1440x720x48 at 1/2/4/8 GPUs) cut into N x-slabs, i.e. strong scaling; --weak gives every rank its own Nx x Ny x Nz slab of
-an (N Nx) x Ny x Nz grid instead (the reference's own scaling protocol, sharding/sharded_..._run.jl:82-88).
+an (N Nx) x Ny x Nz grid instead (the reference's own scaling protocol, sharding/sharded_..._run.jl:82-88).  Started
+WITHOUT a launcher (no WORLD_SIZE in the environment) `--gpus N` starts its own N ranks: a `torch.distributed.run` child
+process, before this process has touched the GPU, whose output (rank 0's JSON line) and exit code are relayed.
 
 Time step: 120 s by default (--dt).  The reference's scaling runs step with dt = 1 s (sharding/sharded_..._run.jl:91), its
 quarter-degree climate script quotes 240 s; the cost of a step does not depend on dt, but the state does: with this initial
@@ -74,11 +76,13 @@ def measured_traffic(kernel, size, prefer=None):
 
 def measured_valu_instructions(kernel, size, prefer=None):
     """Wave-level VALU instructions per launch of `kernel` (SQ_INSTS_VALU of the committed `rocprofv3 --pmc` pass,
-    profiles/r*_pmc_sq.csv; only files of this grid size are named so).  None when no such measurement is committed."""
+    profiles/r*_pmc_sq.csv; only files of this grid size are named so) and the shader clock the chip held under that kernel
+    in that pass (GRBM_GUI_ACTIVE, summed over the 8 XCDs, / 8 / the kernel's duration).  None when no such measurement is
+    committed."""
     import csv
     import glob
     if tuple(size) != (1440, 720, 48):
-        return None, None
+        return None, None, None
     for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.csv")))):
         try:
             prefix = KERNEL_SYMBOL.get(kernel, kernel)
@@ -87,10 +91,14 @@ def measured_valu_instructions(kernel, size, prefer=None):
                 rows = [r for r in rows if r["Kernel"].endswith(tuple(prefer))] or rows
             if rows:
                 best = max(rows, key=lambda r: int(float(r["Launches"])))
-                return float(best["MeanValue"]), os.path.basename(f)
+                clock = None
+                for r in csv.DictReader(open(f)):
+                    if r["Counter"] == "GRBM_GUI_ACTIVE" and r["Kernel"] == best["Kernel"] and float(r["MeanDurationNs"]) > 0:
+                        clock = float(r["MeanValue"]) / 8.0 / float(r["MeanDurationNs"]) * 1e9
+                return float(best["MeanValue"]), os.path.basename(f), clock
         except Exception:
             pass
-    return None, None
+    return None, None, None
 
 
 def counter_rng(shape, seed, salt):
@@ -141,8 +149,8 @@ def cpu_baseline(Nx, Ny, Nz, dt, budget_s=25.0, max_steps=50, grid_type="simple_
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 100: a timed region the driver's GPU samples can see)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 5)")
     ap.add_argument("--size", type=int, nargs=3, default=[1440, 720, 48], metavar=("Nx", "Ny", "Nz"))
     ap.add_argument("--dt", type=float, default=120.0)
     ap.add_argument("--mesh", default=None, metavar="RxxRy",
@@ -166,17 +174,42 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timers")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 100
+    if args.warmup is None:
+        args.warmup = 5
     if args.data_free:
         args.grid_type, args.closure, args.dt = "gaussian_islands", "catke", 30.0
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # No launcher around us: start the N ranks ourselves.  A CHILD process (never a re-exec: this process may not replace
+        # itself once anything GPU-side is loaded, and a child keeps the exit code honest), started before torch or the library is
+        # imported here, so this process never initialises the GPU.  Rank 0 of the child prints the JSON line on our stdout.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"bench.py: --gpus {args.gpus} without a launcher: starting {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     import torch
     import gb25_amd as gb
+    from gb25_amd.binding import library_stale
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N, or no launcher at all)")
+    rehearsal = os.environ.get("GB25_ALL_ON_DEVICE0") == "1"
+    if world > 1 and not rehearsal and torch.cuda.device_count() < world:     # (device_count does not initialise the GPU)
+        raise SystemExit(f"bench.py --gpus {world}: this host shows {torch.cuda.device_count()} GPU(s).  RCCL needs one device per "
+                         "rank; to REHEARSE the multi-process path on fewer devices set GB25_DIST_BACKEND=gloo "
+                         "GB25_ALL_ON_DEVICE0=1 (host-callback transport; not a measurement)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if os.environ.get("GB25_ALL_ON_DEVICE0") == "1":   # 1-GPU rehearsal of the multi-process path (tests only)
@@ -299,10 +332,14 @@ def main():
     if scratch is not None:
         scratch.backend.close()
 
+    rank_ms = [1e3 * elapsed / args.steps]
+    transport, rccl_ranks = (b.comm_info() if world > 1 else ("none", 0))
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [1e3 * float(t.item()) / args.steps for t in every]
+        elapsed = max(float(t.item()) for t in every)          # the contract: the MAX over ranks
 
     finite = bool(np.isfinite(model.free_surface.eta.interior).all())
     kernels = {}
@@ -327,8 +364,13 @@ def main():
                        "parallelism": ((f"{Rx} x {Ry} mesh (Partition(Rx, Ry, 1))" if Ry > 1 else f"x-slab x{world}")
                                        + ", RCCL send/recv inside the library" if world > 1 else "single GPU"),
                        "transport": getattr(model, "transport_kind", None),
+                       # the size of the communicator AS RCCL REPORTS IT (ncclCommCount): n_gpus ranks really talked to each
+                       # other only if this equals n_gpus (0: no RCCL communicator -- single GPU, or the gloo rehearsal)
+                       "rccl_ranks": rccl_ranks,
                        "simulated_years_per_day": steps_per_s * args.dt / 365.0},
             "finite": finite,
+            "ms_per_step_by_rank": rank_ms,
+            "library_stale": bool(library_stale("Float32")),   # True: the loaded binary is older than its sources (binding.load_library)
         }
         if kernels and "gv" not in kernels and "gu" in kernels:
             kernels["momentum"] = kernels.pop("gu")     # the fused G_u + G_v kernel reports under the "gu" timer
@@ -363,18 +405,21 @@ def main():
             inst = (", true, false, true>", ", true, false, false>", ", true, false>", ", true>") if (lazy and dom == "momentum") else None
             traffic, traffic_src = measured_traffic(dom, (locNx, locNy, Nz), prefer=inst)
             # What bounds the kernel: the tendency kernels are VALU-issue bound -- a wave64 fp32 VALU instruction occupies its
-            # SIMD for 4 cycles (profiles/r03_valu_rate_noslp.txt), so the ceiling is 1024 SIMDs x 2.4 GHz / 4 instructions/s;
-            # valu_frac = committed SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x 2.4 GHz x the live launch time).
+            # SIMD for 4 cycles (profiles/r03_valu_rate_noslp.txt), so the ceiling is 1024 SIMDs x clock / 4 instructions/s;
+            # valu_frac = committed SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x clock x the live launch time), the clock
+            # being what the chip held under this kernel in the counter pass (GRBM_GUI_ACTIVE: ~2.1-2.3 GHz, not the 2.4 GHz ceiling).
             # `achieved` / `frac` stay the contract's algorithmic-bytes numbers; `traffic_frac` is what the kernel really pulls.
-            insts, insts_src = measured_valu_instructions(dom, (locNx, locNy, Nz), prefer=inst)
-            valu_frac = (insts * 4.0 / (1024 * 2.4e9) / (timed[dom]["avg_ms"] * 1e-3)) if insts else None
+            insts, insts_src, clock = measured_valu_instructions(dom, (locNx, locNy, Nz), prefer=inst)
+            clock = clock or 2.4e9      # (the clock the chip held under this kernel in the counter pass; 2.4 GHz is its ceiling)
+            valu_frac = (insts * 4.0 / (1024 * clock) / (timed[dom]["avg_ms"] * 1e-3)) if insts else None
             bound = "valu" if (valu_frac is not None and traffic is not None and
                                valu_frac > traffic / (timed[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) else "hbm"
             out["roofline"] = {"bound": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "traffic_source": traffic_src,
                                "valu_frac": valu_frac, "valu_instructions_per_launch": insts, "valu_source": insts_src,
-                               "valu_peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction",
+                               "valu_peak": f"1024 SIMDs x {clock / 1e9:.2f} GHz (GRBM_GUI_ACTIVE of the counter pass) / 4 cycles per wave64 instruction",
+                               "valu_clock_GHz": clock / 1e9,
                                # what the kernel really pulls from HBM (PMC bytes / live launch time): the tendency
                                # kernels are VALU-issue bound, the fused rows make `achieved` exceed this
                                "traffic_GBps": (traffic / (timed[dom]["avg_ms"] * 1e-3) / 1e9) if traffic else None,

@@ -51,6 +51,7 @@ ABI_SYMBOLS = [
     "gb25_update_state", "gb25_first_time_step", "gb25_time_step", "gb25_loop",
     "gb25_set_option", "gb25_get_option", "gb25_set_bottom_height", "gb25_set_curvilinear_grid", "gb25_set_vertical_faces", "gb25_get_bottom_info", "gb25_set_top_flux",
     "gb25_comm_unique_id", "gb25_comm_init_rccl", "gb25_comm_init_local", "gb25_comm_init_callback", "gb25_comm_finalize",
+    "gb25_comm_info", "gb25_debug_exchange_plan",
     "gb25_lookahead_state", "gb25_debug_sequence", "gb25_save_state",
     "gb25_profile_enable", "gb25_profile_reset", "gb25_profile_get",
 ]
@@ -58,7 +59,7 @@ ABI_SYMBOLS = [
 OPTION_IDS = {"kernels": 0, "ab2_lookahead": 1, "subcycle_lookahead": 2, "subcycle_block": 3, "fill_fused": 4,
               "two_streams": 5, "store_pressure": 6, "split_tendencies": 7, "pressure_precision": 8, "immersed_kernels": 9, "fold_fills": 10,
               "lazy_corrector": 11, "momentum_chunk_levels": 12, "tracer_chunk_levels": 13, "tracers_first": 14, "w_on_the_fly": 15, "sub_stream_priority": 16, "subcycle_whole": 17, "early_strips": 18,
-              "catke_stale_e_halos": 19}
+              "catke_stale_e_halos": 19, "comm_timeout_seconds": 20}
 UNIQUE_ID_BYTES = 128
 # int32 fn(void *user, int32 buffer_set, const void *send_w, const void *send_e, void *recv_w, void *recv_e, int64 nbytes)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
@@ -195,6 +196,9 @@ def load_library(float_type="Float32"):
     lib.gb25_set_option.argtypes = [P, C.c_int, C.c_int32]
     lib.gb25_get_option.argtypes = [P, C.c_int, C.POINTER(C.c_int32)]
     lib.gb25_comm_unique_id.argtypes = [P]
+    lib.gb25_comm_info.argtypes = [P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.gb25_debug_exchange_plan.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int64]
+    lib.gb25_debug_exchange_plan.restype = C.c_int64
     lib.gb25_comm_init_rccl.argtypes = [P, P]
     lib.gb25_comm_init_local.argtypes = [C.POINTER(P), C.c_int32]
     lib.gb25_comm_init_callback.argtypes = [P, EXCHANGE_FN, P]
@@ -501,6 +505,12 @@ class HipBackend:
         if len(unique_id) != UNIQUE_ID_BYTES:
             raise ValueError("unique id must be 128 bytes")
         self._call("gb25_comm_init_rccl", C.c_char_p(bytes(unique_id)))
+
+    def comm_info(self):
+        """(transport, comm_ranks): "none" | "rccl" | "local" | "callback", and the communicator's size as RCCL reports it."""
+        t, n = C.c_int32(0), C.c_int32(0)
+        self._call("gb25_comm_info", C.byref(t), C.byref(n))
+        return ("none", "rccl", "local", "callback")[t.value], n.value
 
     def comm_init_callback(self, fn):
         """fn(buffer_set, send_west, send_east, recv_west, recv_east, nbytes) with device pointers as integers."""

@@ -14,7 +14,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace gb25;
@@ -190,6 +195,7 @@ struct gb25_model {
   Field catke_b, catke_scratch;      // N^2 on the faces; the unused half of the two-wide tracer kernel's output
   gb25_catke_parameters catke_par;   // (gb25_default_catke_parameters at creation)
   Field catke_src;                   // 2-D: the top boundary condition of e (surface TKE flux / dz of the top cell)
+  int comm_timeout_s = 180;          // option COMM_TIMEOUT_SECONDS
   double catke_prev_time = 0;        // diffusivity_fields.previous_compute_time
   bool catke_stale_e_halos = false;  // option CATKE_STALE_E_HALOS
   bool n2_fresh = false;             // (unused since N^2 = g (alpha dzT - beta dzS) has a kernel of its own)
@@ -2984,6 +2990,10 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
     case GB25_OPT_SUB_STREAM_PRIORITY: m->sub_priority = v != 0; return GB25_OK;
     case GB25_OPT_SUBCYCLE_WHOLE: m->baro_whole = v != 0; return GB25_OK;
     case GB25_OPT_EARLY_STRIPS: m->early_strips = v != 0; return GB25_OK;
+    case GB25_OPT_COMM_TIMEOUT_SECONDS:
+      if (v < 1) return fail(m, GB25_ERR_INVALID_ARGUMENT, "comm_timeout_seconds: at least 1");
+      m->comm_timeout_s = v;
+      return GB25_OK;
     case GB25_OPT_CATKE_STALE_E_HALOS:
       if (v != 0 && m->slab) return fail(m, GB25_ERR_STATE, "catke_stale_e_halos: a decomposition cannot leave the halos of e stale at its internal boundaries");
       m->catke_stale_e_halos = v != 0;
@@ -3034,6 +3044,7 @@ gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
     case GB25_OPT_SUBCYCLE_WHOLE: *v = m->baro_whole; break;
     case GB25_OPT_EARLY_STRIPS: *v = m->early_strips; break;
     case GB25_OPT_CATKE_STALE_E_HALOS: *v = m->catke_stale_e_halos; break;
+    case GB25_OPT_COMM_TIMEOUT_SECONDS: *v = m->comm_timeout_s; break;
     default: return GB25_ERR_INVALID_ARGUMENT;
   }
   return GB25_OK;
@@ -3064,7 +3075,32 @@ gb25_status gb25_comm_init_rccl(gb25_model* m, const void* unique_id) {
   // GB25_REHEARSE_ALONE=1: this rank of a decomposition runs alone, its neighbours are itself (a timing proxy, not a simulation)
   const char* solo = getenv("GB25_REHEARSE_ALONE");
   tr->alone = solo && solo[0] == '1' && tr->nranks > 1;
-  ncclResult_t r = tr->alone ? ncclInvalidArgument : rccl().CommInitRank(&tr->comm, tr->nranks, id, tr->rank);
+  // ncclCommInitRank blocks until every rank of the communicator has called it: a rank that never arrives (a crashed process, a
+  // launcher that started fewer ranks than --gpus says) would leave the others waiting for ever.  It runs on a helper thread and
+  // this one waits for it with a bound (option COMM_TIMEOUT_SECONDS); past it the call fails with the rank -- the helper thread
+  // is abandoned, the process is expected to exit.
+  ncclResult_t r = ncclInvalidArgument;
+  if (!tr->alone) {
+    struct InitState { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t r = ncclSuccess; ncclComm_t comm = nullptr; };
+    auto st = std::make_shared<InitState>();
+    const int dev = m->cfg.device, nr = tr->nranks, rk = tr->rank;
+    std::thread([st, id, dev, nr, rk]() {
+      (void)hipSetDevice(dev);
+      ncclComm_t c = nullptr;
+      const ncclResult_t rr = rccl().CommInitRank(&c, nr, id, rk);
+      std::lock_guard<std::mutex> lk(st->mu);
+      st->r = rr; st->comm = c; st->done = true;
+      st->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(st->mu);
+    if (!st->cv.wait_for(lk, std::chrono::seconds(m->comm_timeout_s), [&] { return st->done; })) {
+      delete tr;
+      return fail(m, GB25_ERR_COMM, "rank %d of %d: ncclCommInitRank did not return within %d s -- not every rank of the communicator "
+                  "called it (were all %d processes started, with the same unique id?)", rk, nr, m->comm_timeout_s, nr);
+    }
+    r = st->r;
+    tr->comm = st->comm;
+  }
   if (r != ncclSuccess && (tr->nranks == 1 || tr->alone)) {
     // a one-rank communicator (the self-ring) needs nobody's agreement: once more with a fresh id
     (void)hipGetLastError();
@@ -3077,7 +3113,69 @@ gb25_status gb25_comm_init_rccl(gb25_model* m, const void* unique_id) {
                 rccl().GetErrorString(r));
   }
   gb25_model* one[1] = {m};
-  return group_create(one, 1, tr);
+  if (gb25_status s = group_create(one, 1, tr)) return s;
+  // The first exchange with every peer this rank will ever talk to -- the ring neighbours, the rows' neighbours of a 2-D
+  // decomposition, the fold partner -- a few bytes each, bounded by the same timeout: a peer that built another decomposition (or
+  // none) shows here, with the rank and the buffer set, instead of as a hang in the first time step.
+  SlabGroup* G = m->group;
+  for (int b : {0, 5, 3}) {
+    if ((b == 5 && m->Ry < 2) || (b == 3 && !m->g.cv.north_fold)) continue;
+    const size_t nbytes = std::min<size_t>(16, G->elems[b] * sizeof(real));
+    if (gb25_status s = tr->exchange(*G, b, nbytes, G->main)) return s;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t q;
+    while ((q = hipStreamQuery(G->main)) == hipErrorNotReady) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(m->comm_timeout_s))
+        return fail(m, GB25_ERR_COMM, "rank %d of %d (%d x %d): the first exchange of buffer set %d (%s) did not complete within %d s",
+                    m->cfg.rank, m->cfg.nranks, m->Rx, m->Ry, b, b == 0 ? "west / east ring neighbours" : b == 5 ? "southern / northern neighbours" : "fold partner",
+                    m->comm_timeout_s);
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    if (q != hipSuccess) return fail(m, GB25_ERR_HIP, "the first exchange of buffer set %d failed: %s", b, hipGetErrorString(q));
+  }
+  return GB25_OK;
+}
+// What the exchange context of this model is: transport 0 none, 1 RCCL, 2 local ring (all slabs in this process), 3 host callback;
+// comm_ranks: the size of the communicator AS RCCL REPORTS IT (ncclCommCount; 0 without RCCL) -- bench.py prints it so that a
+// scaling line says how many ranks really talked to each other
+gb25_status gb25_comm_info(const gb25_model* m, int32_t* transport, int32_t* comm_ranks) {
+  if (!m) return GB25_ERR_INVALID_ARGUMENT;
+  int t = 0, n = 0;
+  if (m->group && m->group->transport) {
+    const std::string name = m->group->transport->name();
+    t = name == "rccl" ? 1 : name == "local" ? 2 : 3;
+    if (t == 1) {
+      RcclTransport* R = static_cast<RcclTransport*>(m->group->transport);
+      if (R->comm && rccl().CommCount(R->comm, &n) != ncclSuccess) n = -1;
+    }
+  }
+  if (transport) *transport = t;
+  if (comm_ranks) *comm_ranks = n;
+  return GB25_OK;
+}
+// The sends and receives ONE rank of an Rx x Ry decomposition posts for exchange group `group`, in posting order, as text:
+// "send <peer> <side>" / "recv <peer> <side>" per line ("copy" when the rank is its own fold partner).  No GPU is touched: this is
+// RcclTransport::exchange's own plan (exchange_plan).  folded_grid: the GLOBAL grid has a zipper fold (only the top row of ranks folds).
+int64_t gb25_debug_exchange_plan(int32_t Rx, int32_t Ry, int32_t rank, int32_t folded_grid, int32_t group, char* out, int64_t cap) {
+  if (Rx < 1 || Ry < 1 || rank < 0 || rank >= Rx * Ry) return -1;
+  const MeshPos q(Rx, Ry, rank);
+  const bool fold = folded_grid != 0 && q.ry == Ry - 1;
+  const int b = buffer_set(group);
+  std::string log;
+  if (set_kind(b) == 1 && fold && q.partner() == rank) log = "copy\n";
+  else if (!(set_kind(b) == 1 && !fold) && !(set_kind(b) == 2 && Ry < 2))
+    for (const PlanOp& op : exchange_plan(q, fold, b)) {
+      char line[48];
+      snprintf(line, sizeof line, "%s %d %d\n", op.send ? "send" : "recv", op.peer, op.side);
+      log += line;
+    }
+  const int64_t need = (int64_t)log.size() + 1;
+  if (out && cap > 0) {
+    const int64_t ncopy = std::min<int64_t>(cap - 1, (int64_t)log.size());
+    memcpy(out, log.data(), (size_t)ncopy);
+    out[ncopy] = 0;
+  }
+  return need;
 }
 gb25_status gb25_comm_init_callback(gb25_model* m, gb25_exchange_fn fn, void* user) {
   CHECK_MODEL(m);

@@ -959,6 +959,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -983,12 +984,13 @@ struct RcclApi {
     GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
     CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
     CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    CommCount = (decltype(CommCount))sym("ncclCommCount");
     Send = (decltype(Send))sym("ncclSend");
     Recv = (decltype(Recv))sym("ncclRecv");
     GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
     GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
     GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-    if (!GetUniqueId || !CommInitRank || !CommDestroy || !Send || !Recv || !GroupStart || !GroupEnd || !GetErrorString) {
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !CommCount || !Send || !Recv || !GroupStart || !GroupEnd || !GetErrorString) {
       lib = nullptr;
       return false;
     }
@@ -1005,6 +1007,33 @@ RcclApi& rccl() {
     if (r_ != ncclSuccess)                                                                                        \
       return fail(m, GB25_ERR_COMM, "%s:%d: %s failed: %s", __FILE__, __LINE__, #call, rccl().GetErrorString(r_)); \
   } while (0)
+
+// What one rank posts inside ONE ncclGroup for buffer set b, in posting order: (send?, peer rank, side of the buffer set).  The
+// single place that knows the protocol -- RcclTransport::exchange posts exactly this, gb25_debug_exchange_plan prints it, and the
+// CPU tests prove from it that every rank's ordered sends to a peer mirror that peer's ordered receives (tests/test_distributed_cpu.py).
+struct PlanOp { bool send; int peer; int side; };
+inline std::vector<PlanOp> exchange_plan(const MeshPos& q, bool north_fold, int b) {
+  std::vector<PlanOp> p;
+  const int kind = set_kind(b);
+  if (kind == 2) {          // 2-D decomposition: the southern and the northern neighbour, where they exist
+    if (q.south() >= 0) p.push_back({true, q.south(), 0});
+    if (q.north() >= 0) p.push_back({true, q.north(), 1});
+    if (q.north() >= 0) p.push_back({false, q.north(), 1});
+    if (q.south() >= 0) p.push_back({false, q.south(), 0});
+  } else if (kind == 1) {   // zipper fold: the partner is the mirrored rank of the (top) row; a rank that is its own partner copies
+    const int self = q.ry * q.Rx + q.rx;
+    if (north_fold && q.partner() != self) {
+      p.push_back({true, q.partner(), 0});
+      p.push_back({false, q.partner(), 0});
+    }
+  } else {                  // the ring: sends [west pack, east pack], receives [east halo, west halo]
+    p.push_back({true, q.west(), 0});
+    p.push_back({true, q.east(), 1});
+    p.push_back({false, q.east(), 1});
+    p.push_back({false, q.west(), 0});
+  }
+  return p;
+}
 
 // one slab per process, one process per GPU: the ring neighbours are ranks rank-1 and rank+1 of the communicator.
 // Posting order is part of the protocol: sends [west pack, east pack], receives [east halo, west halo].  With two
@@ -1034,35 +1063,25 @@ struct RcclTransport : Transport {
     return GB25_OK;
   }
   gb25_status exchange(SlabGroup& G, int b, size_t nbytes, hipStream_t st) override {
-    if (set_kind(b) == 2) {   // 2-D decomposition: the southern and the northern neighbour, where they exist
-      gb25_model* m = G.slabs[0];
-      const MeshPos q(m);
-      RcclApi& R = rccl();
-      if (q.south() < 0 && q.north() < 0) return GB25_OK;
-      NCCLCHK(R.GroupStart());
-      if (q.south() >= 0) NCCLCHK(R.Send(G.send[0][b][0], nbytes, ncclInt8, peer(q.south()), comm, st));
-      if (q.north() >= 0) NCCLCHK(R.Send(G.send[0][b][1], nbytes, ncclInt8, peer(q.north()), comm, st));
-      if (q.north() >= 0) NCCLCHK(R.Recv(G.recv[0][b][1], nbytes, ncclInt8, peer(q.north()), comm, st));
-      if (q.south() >= 0) NCCLCHK(R.Recv(G.recv[0][b][0], nbytes, ncclInt8, peer(q.south()), comm, st));
-      NCCLCHK(R.GroupEnd());
-      return GB25_OK;
-    }
-    if (set_kind(b) == 1) {   // zipper fold: the partner is the mirrored rank of the (top) row
-      gb25_model* m = G.slabs[0];
+    gb25_model* m = G.slabs[0];
+    const MeshPos q(m);
+    if (set_kind(b) == 1) {
       if (!m->g.cv.north_fold) return GB25_OK;
-      const int partner = MeshPos(m).partner();
-      if (partner == rank || alone) {
+      if (q.partner() == rank || alone) {   // (its own partner: the middle slab of an odd count, the self-ring)
         HIPCHK(hipMemcpyAsync(G.recv[0][b][0], G.send[0][b][0], nbytes, hipMemcpyDeviceToDevice, st));
         return GB25_OK;
       }
-      RcclApi& R = rccl();
-      NCCLCHK(R.GroupStart());
-      NCCLCHK(R.Send(G.send[0][b][0], nbytes, ncclInt8, partner, comm, st));
-      NCCLCHK(R.Recv(G.recv[0][b][0], nbytes, ncclInt8, partner, comm, st));
-      NCCLCHK(R.GroupEnd());
-      return GB25_OK;
     }
-    return send_recv(G.slabs[0], G.send[0][b][0], G.send[0][b][1], G.recv[0][b][0], G.recv[0][b][1], nbytes, st);
+    const std::vector<PlanOp> plan = exchange_plan(q, m->g.cv.north_fold != 0, b);
+    if (plan.empty()) return GB25_OK;
+    RcclApi& R = rccl();
+    NCCLCHK(R.GroupStart());
+    for (const PlanOp& op : plan) {
+      if (op.send) NCCLCHK(R.Send(G.send[0][b][op.side], nbytes, ncclInt8, peer(op.peer), comm, st));
+      else NCCLCHK(R.Recv(G.recv[0][b][op.side], nbytes, ncclInt8, peer(op.peer), comm, st));
+    }
+    NCCLCHK(R.GroupEnd());
+    return GB25_OK;
   }
 };
 

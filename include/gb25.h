@@ -157,6 +157,8 @@ typedef enum {
   GB25_OPT_CATKE_STALE_E_HALOS,  /* [0] closure = CATKE, single domain: 1 = the halo cells of e are NOT refilled after e is stepped inside
                                     compute_diffusivities! (Oceananigans as recalled: the tendencies that follow see halos one e step old);
                                     0 = refilled.  A RESTATEMENT choice, not a schedule: it changes results */
+  GB25_OPT_COMM_TIMEOUT_SECONDS, /* [180] gb25_comm_init_rccl: bound on ncclCommInitRank and on the first exchange with every peer; past it
+                                    the call returns GB25_ERR_COMM naming the rank and the buffer set instead of hanging */
   GB25_OPT_COUNT
 } gb25_option;
 
@@ -400,6 +402,12 @@ typedef int32_t (*gb25_exchange_fn)(void *user, int32_t buffer_set, const void *
                                     void *recv_west, void *recv_east, int64_t nbytes);
 gb25_status gb25_comm_init_callback(gb25_model *m, gb25_exchange_fn fn, void *user);
 gb25_status gb25_comm_finalize(gb25_model *m);
+/* transport: 0 none, 1 RCCL, 2 local ring, 3 host callback; comm_ranks: the communicator's size as RCCL reports it
+ * (ncclCommCount; 0 without RCCL).  Either pointer may be NULL. */
+gb25_status gb25_comm_info(const gb25_model *m, int32_t *transport, int32_t *comm_ranks);
+/* (tests) the sends / receives one rank of an Rx x Ry decomposition posts for an exchange group, in posting order, as text;
+ * returns the bytes needed incl. the terminator.  No GPU is touched. */
+int64_t gb25_debug_exchange_plan(int32_t Rx, int32_t Ry, int32_t rank, int32_t folded_grid, int32_t group, char *out, int64_t cap);
 /* velocities_ready: the momentum look-ahead of the next step exists (its sub-cycle can run beside the tracer kernel);
  * subcycle_adopted: the last step adopted the sub-cycle look-ahead instead of sub-cycling inside the step. */
 gb25_status gb25_lookahead_state(const gb25_model *m, int32_t *velocities_ready, int32_t *subcycle_adopted);

@@ -377,3 +377,56 @@ def test_time_step_sequencing_of_a_lazy_step_of_a_2d_decomposition():
     plain = _ops_of_slab(_raw_sequence(4, 8 | 16 | 64, adopted=1, ready=1), 2)
     j = plain.index(("stage", 32, "main"))
     assert plain[j + 1:j + 4] == [("pack", 10, "main"), ("exchange", 10, "main"), ("unpack", 10, "main")]
+
+
+def _exchange_plan(Rx, Ry, rank, folded_grid, group):
+    lib = load_library("Float32")
+    need = lib.gb25_debug_exchange_plan(Rx, Ry, rank, int(folded_grid), group, None, 0)
+    assert need > 0
+    buf = ctypes.create_string_buffer(need)
+    lib.gb25_debug_exchange_plan(Rx, Ry, rank, int(folded_grid), group, buf, need)
+    return [(op, int(peer), int(side)) for op, peer, side in (line.split() for line in buf.value.decode().splitlines() if line != "copy")]
+
+
+@pytest.mark.parametrize("Rx,Ry", [(8, 1), (4, 2), (2, 4), (2, 1), (3, 1), (1, 2), (3, 2)])
+@pytest.mark.parametrize("folded_grid", [False, True])
+def test_every_rank_sends_what_its_peer_receives(Rx, Ry, folded_grid):
+    """The RCCL transport has never run on more than one GPU (no such box): what CAN be proved without one is that the
+    point-to-point protocol is consistent.  For every rank of the decomposition the library prints the order of operations of a
+    step (gb25_debug_sequence: the same sequencer that drives the GPU) and, per exchange group, the sends and receives that rank
+    posts in posting order (gb25_debug_exchange_plan: RcclTransport::exchange's own plan).  NCCL / RCCL match the k-th send of a
+    to b with the k-th receive b posts from a.  So for every ordered pair of ranks, over the whole step and stream by stream: as
+    many sends as receives, the same exchange groups in the same order, and the packed side of the sender landing in the halo of
+    the facing side (my west pack -> your east halo; my southern rows -> your northern halo; fold partners: pack -> image rows).
+    Covers x slabs (P = 8, 2 and an odd 3: the middle slab is its own fold partner), the 4 x 2 and 2 x 4 meshes of config 4, a
+    1 x 2 mesh (its own west and east neighbour) and 3 x 2, with and without the zipper fold (only the top row of ranks folds),
+    first steps, steady steps with both look-aheads, lazy steps, closure = CATKE, the coupled model."""
+    P = Rx * Ry
+    variants = [dict(first=1), dict(first=0), dict(first=0, adopted=1, ready=1), dict(first=0, adopted=1, ready=1, extra=32 | 64),
+                dict(first=0, adopted=1, ready=1, extra=128), dict(first=1, extra=4 | 128), dict(first=0, adopted=0, ready=1, extra=8)]
+    for var in variants:
+        sends, recvs = {}, {}     # (a, b, stream) -> [(group, side)] in posting order; stream "*" = the host's issue order
+        for r in range(P):
+            top = r // Rx == Ry - 1
+            flags = var["first"] | var.get("extra", 0) | (2 if (folded_grid and top) else 0) | (16 if Ry > 1 else 0)
+            log = _raw_sequence(1, flags, var.get("adopted", 0), var.get("ready", 0))
+            for e in log:
+                if e[0] != "exchange":
+                    continue
+                group, stream = e[1], e[2]
+                for op, peer, side in _exchange_plan(Rx, Ry, r, folded_grid, group):
+                    book = sends if op == "send" else recvs
+                    key = (r, peer) if op == "send" else (peer, r)          # always (sender, receiver)
+                    for st in (stream, "*"):
+                        book.setdefault(key + (st,), []).append((group, side))
+        assert set(sends) == set(recvs), (var, sorted(set(sends) ^ set(recvs))[:4])
+        for key, sent in sends.items():
+            got = recvs[key]
+            assert [g for g, _ in sent] == [g for g, _ in got], (var, key, sent, got)      # same groups, same order
+            for (g, s_side), (_, r_side) in zip(sent, got):
+                partner_kind = g in (6, 8, 22)
+                assert r_side == (s_side if partner_kind else 1 - s_side), (var, key, g, s_side, r_side)
+        # every rank takes part in the ring exchanges; only the top row of a folded grid talks to a fold partner
+        assert any(g == 0 for k, v in sends.items() if k[2] == "*" for g, _ in v)
+        folds = {k[0] for k, v in sends.items() for g, _ in v if g in (6, 8, 22)}
+        assert all(a // Rx == Ry - 1 for a in folds) and (not folds or folded_grid)

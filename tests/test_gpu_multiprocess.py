@@ -106,3 +106,26 @@ def test_bench_data_free_on_a_mesh():
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 4 and out["finite"] and "data-free" in out["config"]["workload"] and "2 x 2 mesh" in out["config"]["parallelism"]
+
+
+def test_bench_starts_its_own_ranks_when_nobody_launched_it():
+    """`python bench.py --gpus 2` with no launcher around it (no WORLD_SIZE): it starts a torch.distributed.run child with two
+    ranks before touching the GPU itself and relays the rank-0 line and the exit code -- what a driver that runs N > 1 the way
+    it runs N = 1 gets.  (Rehearsal environment: both ranks on the one device, gloo + host-callback transport: rccl_ranks = 0.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GB25_DIST_BACKEND="gloo", GB25_ALL_ON_DEVICE0="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size",
+                          "128", "48", "8"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["finite"] and out["value"] > 0
+    assert out["config"]["rccl_ranks"] == 0 and out["config"]["transport"] == "host"
+    assert len(out["ms_per_step_by_rank"]) == 2 and abs(max(out["ms_per_step_by_rank"]) - out["ms_per_step"]) < 1e-9
+    assert out["library_stale"] is False
+    # ... and without the rehearsal environment on a one-GPU box it refuses with a message instead of hanging in RCCL
+    env.pop("GB25_DIST_BACKEND"); env.pop("GB25_ALL_ON_DEVICE0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--size", "128", "48", "8"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert res.returncode != 0 and "REHEARSE" in res.stderr
