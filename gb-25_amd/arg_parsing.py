@@ -1,7 +1,8 @@
 """CLI flags of the reference's run scripts (GB-25 src/arg_parsing.jl:9-46,54-82): `--grid-x/-y/-z` are PER-DEVICE
 totals including halos (interior Nx = grid-x * Rx - 2H, sharding/sharded_..._run.jl:82-88); `--float-type` selects
-the model float type.  Only Float32 has a HIP implementation here (BASELINE.json's configurations are all fp32);
-the multifloat flags are Reactant features and are accepted but unused."""
+the model float type.  Float32 (BASELINE.json's configurations) and Float64 (the reference's default) have a HIP library each
+(libgb25hip.so / libgb25hip_f64.so, one source built twice); Float16 / BFloat16 are parsed as the reference parses them and
+rejected at model construction.  The multifloat flags are Reactant features and are accepted but unused."""
 import argparse
 
 _FLOAT_TYPES = {"Float64": "f64", "f64": "f64", "Float32": "f32", "f32": "f32", "Float16": "f16", "f16": "f16",

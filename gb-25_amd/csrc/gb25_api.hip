@@ -5,6 +5,7 @@
 // (GB-25 src/precompile.jl:31-42) and exposes the per-phase entry points.
 // There is no CPU fallback: without a HIP device gb25_create fails with GB25_ERR_NO_DEVICE.
 #include "../../include/gb25.h"
+#include <dlfcn.h>
 #include "kernels.hpp"
 #include "tendency_kernels.hpp"
 
@@ -195,7 +196,9 @@ struct gb25_model {
   Field catke_b, catke_scratch;      // N^2 on the faces; the unused half of the two-wide tracer kernel's output
   gb25_catke_parameters catke_par;   // (gb25_default_catke_parameters at creation)
   Field catke_src;                   // 2-D: the top boundary condition of e (surface TKE flux / dz of the top cell)
+  bool whole_attr_set[2][2] = {{false, false}, {false, false}};   // k_barotropic_whole's dynamic-LDS attribute, per instance, on THIS model's device
   int comm_timeout_s = 180;          // option COMM_TIMEOUT_SECONDS
+  bool roctx_ranges = true;          // option ROCTX_RANGES
   double catke_prev_time = 0;        // diffusivity_fields.previous_compute_time
   bool catke_stale_e_halos = false;  // option CATKE_STALE_E_HALOS
   bool n2_fresh = false;             // (unused since N^2 = g (alpha dzT - beta dzS) has a kernel of its own)
@@ -238,12 +241,63 @@ bool is_2d(int id) { return (id >= GB25_ETA && id <= GB25_GN_BT_V) || id == GB25
 bool is_catke_field(int id) { return id >= GB25_E && id <= GB25_PREV_V; }
 
 // --- profiling helpers -----------------------------------------------------------------------
+// Named ranges for a profiler's timeline, as the reference wraps its entry points in Reactant.Profiler.annotate("first_time_step" /
+// "time_step" / "loop") (GB-25 src/timestepping_utils.jl:22,30,38): roctx ranges around the composites and around the issue of
+// every phase of src/precompile.jl:31-42, so that a `rocprofv3 --kernel-trace --marker-trace` of gb25_loop shows which phase a
+// kernel belongs to.  The marker library is resolved at run time (rocprofv3 preloads librocprofiler-sdk-roctx; the legacy
+// libroctx64 serves the older tools); without one the ranges cost a null-pointer test.  Option ROCTX_RANGES = 0 turns them off.
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  RoctxApi() {
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      void* lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) continue;
+      push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+      pop = (int (*)())dlsym(lib, "roctxRangePop");
+      if (push && pop) return;
+      push = nullptr; pop = nullptr;
+    }
+  }
+};
+inline RoctxApi& roctx() {
+  static RoctxApi api;
+  return api;
+}
+struct Range {
+  bool on;
+  Range(const gb25_model* m, const char* name) : on(m->roctx_ranges && roctx().push != nullptr) {
+    if (on) roctx().push(name);
+  }
+  ~Range() {
+    if (on) roctx().pop();
+  }
+};
+// the phase a kernel timer belongs to (src/precompile.jl:31-42; ":" + what inside the phase)
+inline const char* phase_name(int k) {
+  switch (k) {
+    case GB25_K_FILL_HALOS: return "tupled_fill_halo_regions";
+    case GB25_K_COMPUTE_W: return "compute_auxiliaries:w";
+    case GB25_K_COMPUTE_P: return "compute_auxiliaries:pHY";
+    case GB25_K_CLOSURE: return "compute_auxiliaries:diffusivities";
+    case GB25_K_GU: case GB25_K_GV: return "compute_tendencies:momentum";
+    case GB25_K_TRACERS: return "compute_tendencies:tracers";
+    case GB25_K_AB2_VELOCITIES: return "ab2_step:velocities";
+    case GB25_K_AB2_TRACERS: return "ab2_step:tracers";
+    case GB25_K_BAROTROPIC: return "ab2_step:free_surface";
+    case GB25_K_IMPLICIT: return "ab2_step:implicit_step";
+    case GB25_K_CORRECTOR: return "correct_velocities_and_cache_previous_tendencies";
+    case GB25_K_FLUXES: return "compute_atmosphere_ocean_fluxes";
+    default: return "gb25";
+  }
+}
 struct Timed {
   gb25_model* m;
   int k;
   EventPair ev;
   bool on;
-  Timed(gb25_model* m_, int k_) : m(m_), k(k_), on(m_->profile && (m_->profile_only < 0 || m_->profile_only == k_)) {
+  Range range;
+  Timed(gb25_model* m_, int k_) : m(m_), k(k_), on(m_->profile && (m_->profile_only < 0 || m_->profile_only == k_)), range(m_, phase_name(k_)) {
     // one kernel alone: every fourth launch is timed (the event records cost the step ~1.6 % when every launch carries them)
     if (on && m->profile_only == k_ && (m->prof_seen[k_]++ & 3) != 0) on = false;
     if (!on) return;
@@ -1518,10 +1572,11 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false, const In
         wty == 17 ? (imm ? k_barotropic_whole<NSW, true, 17> : k_barotropic_whole<NSW, false, 17>)
                   : (imm ? k_barotropic_whole<NSW, true, 24> : k_barotropic_whole<NSW, false, 24>);
     const size_t lds = (size_t)5 * (BT_TX + 2 * NSW) * (wty + 2 * NSW) * sizeof(real);
-    static bool attr_set[2][2] = {{false, false}, {false, false}};
-    if (!attr_set[imm ? 1 : 0][wty == 17 ? 0 : 1]) {
+    // (the attribute belongs to the DEVICE: kept per model, not per process -- a host driving several GPUs from one process, or
+    // two threads, must not skip it on the second device)
+    if (!m->whole_attr_set[imm ? 1 : 0][wty == 17 ? 0 : 1]) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set[imm ? 1 : 0][wty == 17 ? 0 : 1] = true;
+      m->whole_attr_set[imm ? 1 : 0][wty == 17 ? 0 : 1] = true;
     }
     BaroMulti bm;
     fill_multi(bm, 0, NSW);
@@ -1658,7 +1713,8 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
 // mask_immersed_model_fields! (src/precompile.jl:34): a sweep of its own only where the kernels of a composite step do
 // not already guarantee the zeros (update_state!, initialize!, after host writes)
 gb25_status mask_impl(gb25_model* m) {
-  if (!m->immersed) return GB25_OK;   // (the wall faces of v are the halo fill's business on the plain grid)
+  if (!m->immersed) return GB25_OK;
+  Range r_mask(m, "mask_immersed_model_fields");   // (the wall faces of v are the halo fill's business on the plain grid)
   const Grid& g = m->g;
   dim3 b(64, 4);
   hipLaunchKernelGGL(k_mask_immersed, grid2(g.Nx, g.Ny + 1, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
@@ -2315,7 +2371,14 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
     }
     // folded grid: image rows beyond the pivot row, enough that what the last row's missing neighbour spoils (one row per
     // substep) never reaches the pivot row
-    if (m->g.cv.north_fold) m->Wy = std::min(m->Ns + 1, m->Ny - 2);
+    // (Oceananigans errors when the extended halo of its free surface exceeds the grid; so does this: with fewer rows the spoiled
+    // rows would reach the pivot row and eta, U, V next to the fold would be wrong without a word)
+    if (m->g.cv.north_fold) {
+      if (m->Ny - 2 < m->Ns + 1)
+        return fail(m, GB25_ERR_INVALID_ARGUMENT, "a folded grid needs Ny >= %d rows per rank for its %d effective substeps (the sub-cycle's "
+                    "image rows beyond the pivot row: Ns + 1 of them, made from the rows south of it); this rank has %d", m->Ns + 3, m->Ns, m->Ny);
+      m->Wy = m->Ns + 1;
+    }
     // 2-D decomposition: wide halos in y as in x on the sides where a neighbour rank exists
     if (m->yn_open) m->Wy = m->W;
     if (m->ys_open) m->Wys = m->W;
@@ -2990,6 +3053,7 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
     case GB25_OPT_SUB_STREAM_PRIORITY: m->sub_priority = v != 0; return GB25_OK;
     case GB25_OPT_SUBCYCLE_WHOLE: m->baro_whole = v != 0; return GB25_OK;
     case GB25_OPT_EARLY_STRIPS: m->early_strips = v != 0; return GB25_OK;
+    case GB25_OPT_ROCTX_RANGES: m->roctx_ranges = v != 0; return GB25_OK;
     case GB25_OPT_COMM_TIMEOUT_SECONDS:
       if (v < 1) return fail(m, GB25_ERR_INVALID_ARGUMENT, "comm_timeout_seconds: at least 1");
       m->comm_timeout_s = v;
@@ -3001,6 +3065,15 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
     case GB25_OPT_MOMENTUM_CHUNK_LEVELS:
     case GB25_OPT_TRACER_CHUNK_LEVELS:
       if (v < 6 || v > 4096) return fail(m, GB25_ERR_INVALID_ARGUMENT, "chunk levels: 6 or more");
+      {
+        // the tendency kernels reach one chunk of levels plus its stencil planes with 32-bit byte offsets (gb25_create checks the
+        // default chunking): the chosen one must stay within that reach too
+        const double plane = (double)(m->Nx + 2 * m->cfg.halo) * (m->Ny + 2 * m->cfg.halo + 1);
+        const int kchunks = std::max(1, m->cfg.Nz / v), klen = (m->cfg.Nz + kchunks - 1) / kchunks;
+        if (plane * (klen + 10) * sizeof(real) >= 2147483648.0)
+          return fail(m, GB25_ERR_INVALID_ARGUMENT, "chunks of %d levels (+ 10 stencil planes of %.3g elements) exceed the 2 GB the tendency "
+                      "kernels address from one base: choose fewer levels per chunk", klen, plane);
+      }
       (opt == GB25_OPT_MOMENTUM_CHUNK_LEVELS ? m->mom_chunk_levels : m->trc_chunk_levels) = v;
       m->colsum_valid = false;
       return GB25_OK;
@@ -3045,6 +3118,7 @@ gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
     case GB25_OPT_EARLY_STRIPS: *v = m->early_strips; break;
     case GB25_OPT_CATKE_STALE_E_HALOS: *v = m->catke_stale_e_halos; break;
     case GB25_OPT_COMM_TIMEOUT_SECONDS: *v = m->comm_timeout_s; break;
+    case GB25_OPT_ROCTX_RANGES: *v = m->roctx_ranges; break;
     default: return GB25_ERR_INVALID_ARGUMENT;
   }
   return GB25_OK;
@@ -3217,6 +3291,7 @@ static gb25_status need_group(gb25_model* m, const char* what) {
 // On a slab these step every slab of the exchange context in lock-step (one slab per process with RCCL).
 gb25_status gb25_first_time_step(gb25_model* m) {
   CHECK_MODEL(m);
+  Range r_first(m, "first_time_step");
   gb25_status s;
   if (m->slab) {
     if ((s = need_group(m, "gb25_first_time_step"))) return s;
@@ -3228,9 +3303,18 @@ gb25_status gb25_first_time_step(gb25_model* m) {
   if ((s = first_fluxes_impl(m))) return s;
   return time_step_impl(m, 1);
 }
-gb25_status gb25_time_step(gb25_model* m) { return gb25_loop(m, 1); }
+static gb25_status loop_impl(gb25_model* m, int32_t n);
+gb25_status gb25_time_step(gb25_model* m) {
+  CHECK_MODEL(m);
+  Range r_step(m, "time_step");
+  return loop_impl(m, 1);
+}
 gb25_status gb25_loop(gb25_model* m, int32_t n) {
   CHECK_MODEL(m);
+  Range r_loop(m, "loop");
+  return loop_impl(m, n);
+}
+static gb25_status loop_impl(gb25_model* m, int32_t n) {
   if (m->slab) {
     if (gb25_status s = need_group(m, "gb25_loop")) return s;
     GroupOps ops(*m->group);

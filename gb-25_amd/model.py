@@ -37,8 +37,13 @@ class Field:
             # A y-face field of a folded (tripolar) grid has Ny rows -- topology (Periodic, RightConnected, Bounded): the
             # faces beyond the last row of cells are halo cells.  An array shaped for a Bounded y (Ny + 1 rows) is
             # accepted and its last row, which the fold fill would overwrite anyway, is dropped.
+            # Only there: a y-face field (v and its tendencies, V, G.V, ...) whose grid has no wall at the northern edge -- the
+            # zipper fold, or a northern neighbour rank of a 2-D decomposition.  Any other array with a row too many is a
+            # wrongly shaped array and is passed through, so that the backend rejects it.
             want = self._b.field_dims(self.name, False)
-            if a.shape[0] == want[0] and a.shape[1] == want[1] + 1:
+            y_face = self.name in ("v", "Gn.v", "Gm.v", "V", "V_bar", "Gn.V", "previous_v")
+            no_wall = y_face and want[1] == self._b.field_dims("T", False)[1]      # (a Bounded y gives a y-face field one row more than a cell field)
+            if no_wall and a.shape[0] == want[0] and a.shape[1] == want[1] + 1:
                 a = np.ascontiguousarray(a[:, :want[1]])
         self._b.set_field(self.name, a, include_halos)
 

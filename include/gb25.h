@@ -159,6 +159,9 @@ typedef enum {
                                     0 = refilled.  A RESTATEMENT choice, not a schedule: it changes results */
   GB25_OPT_COMM_TIMEOUT_SECONDS, /* [180] gb25_comm_init_rccl: bound on ncclCommInitRank and on the first exchange with every peer; past it
                                     the call returns GB25_ERR_COMM naming the rank and the buffer set instead of hanging */
+  GB25_OPT_ROCTX_RANGES,         /* [1] roctx ranges named like the reference's profiler annotations ("first_time_step", "time_step", "loop":
+                                    src/timestepping_utils.jl:22,30,38) around the composites, and one per phase of src/precompile.jl:31-42
+                                    around the issue of its kernels (rocprofv3 --marker-trace); free when no marker library is loaded */
   GB25_OPT_COUNT
 } gb25_option;
 

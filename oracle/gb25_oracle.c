@@ -519,6 +519,10 @@ void *FN(create)(const gb25o_config *c) {
   build_grid(m, c);
   if (c->grid_type >= 2) build_curv_grid(m, c);
   build_substeps(m, c->substeps);
+  if (m->north_fold && m->Ny - 2 < m->Ns + 1) {   /* the sub-cycle's image rows beyond the pivot row (step_free_surface_fold) need Ns + 1 rows south of it */
+    free(m);
+    return NULL;
+  }
   {
     long n2 = (long)(m->Nx + 2 * m->H) * (m->Ny + 2 * m->H + 1);
     m->kbot = (int *)calloc(n2, sizeof(int));
@@ -1800,8 +1804,7 @@ static void ab2_field(model *m, int id, int gn, int gm, REAL dt, REAL chi, int v
  * further fill: what the missing neighbour of the last row spoils moves one row per substep and never reaches row Ny. */
 static void step_free_surface_fold(model *m, REAL dt) {
   const int Nx = m->Nx, Ny = m->Ny;
-  int Wy = m->Ns + 1;
-  if (Wy > Ny - 2) Wy = Ny - 2;
+  const int Wy = m->Ns + 1;   /* (create refuses grids with fewer than Ns + 3 rows) */
   const int NT = Ny + Wy;
   const REAL dtau = m->dtau_frac * dt;
   const size_t n = (size_t)Nx * (NT + 2);

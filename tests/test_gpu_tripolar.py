@@ -284,3 +284,14 @@ def test_folded_slabs_with_closure_and_fluxes(float_type):
         a, b = ens.gather(name), single.backend.get_field(name, False)
         assert np.array_equal(a, b), (float_type, name, float(np.abs(a - b).max()))
     ens.close()
+
+
+def test_a_folded_grid_too_short_for_its_sub_cycle_is_refused():
+    """(see tests/test_oracle_tripolar.py) Ny < Ns + 3 on a folded grid is an error at construction, not a silent clip."""
+    from gb25_amd.binding import GB25Error
+    with pytest.raises(GB25Error, match="folded grid needs"):
+        gb.baroclinic_instability_model(gb.GPU(), 48, 20, 6, dt=600.0, grid_type="tripolar")
+    m = gb.baroclinic_instability_model(gb.GPU(), 48, 24, 6, dt=600.0, grid_type="gaussian_islands")
+    gb.set_baroclinic_instability(m)
+    gb.first_time_step(m)
+    assert np.isfinite(m.free_surface.eta.interior).all()

@@ -182,3 +182,16 @@ def test_first_step_is_mirror_symmetric_away_from_the_mountains():
     assert np.abs(Gv - Gv[::-1])[far].max() < 1e-12 * np.abs(Gv).max()
     assert np.abs(Gv[far][:, Ny - 3:Ny]).max() > 0          # ... including the rows next to the fold
     # (after a step the sub-cycle has carried the mountains' asymmetry 21 columns far: nothing sharp left to check)
+
+
+def test_a_folded_grid_too_short_for_its_sub_cycle_is_refused():
+    """The sub-cycle of a folded grid runs on arrays extended beyond the pivot row by Ns + 1 image rows, made from as many rows
+    south of it: with Ny < Ns + 3 (21 effective substeps of 30: 24 rows) what the open top of those arrays spoils would reach
+    the pivot row.  Oceananigans errors when the extended halo of its free surface exceeds the grid; so do the oracle and the
+    library (tests/test_gpu_tripolar.py) instead of clipping the rows silently."""
+    with pytest.raises(RuntimeError):
+        make_oracle(48, 20, 6, 600.0, grid_type="tripolar")
+    m = make_oracle(48, 24, 6, 600.0, grid_type="gaussian_islands")          # (Ns + 3 rows: the smallest that works)
+    assert m.grid.size == (48, 24, 6)
+    m = make_oracle(48, 20, 6, 600.0, grid_type="tripolar", substeps=20)     # fewer substeps, fewer rows
+    assert m.grid.size == (48, 20, 6)
