@@ -186,6 +186,7 @@ struct gb25_model {
   real* wbase = nullptr;
   int w_fly = 1;
   bool w_stale = false, w_fly_now = false;
+  bool corr_out = false;             // corrector_impl: the sweep also writes du, dv of the own columns into corr[0], corr[1]
   // levels a block of the momentum / tracer tendency kernel marches through (options MOMENTUM_CHUNK_LEVELS,
   // TRACER_CHUNK_LEVELS): fewer, longer chunks amortise the start-up of the vertical windows, more chunks fill the chip.
   // The momentum chunking is also the association of every column integral of u, v (all their producers share it).
@@ -1156,6 +1157,10 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
                                     : (ahead ? k_momentum_tendencies_v5<MW, TYm, true, false, false, false, true> : k_momentum_tendencies_v5<MW, TYm, false, false, false, false, true>))
               : (m->uv_lazy && ahead && m->w_fly_now) ? k_momentum_tendencies_v5<MW, TYm, true, false, false, true, false, true>
               : (m->uv_lazy && ahead) ? k_momentum_tendencies_v5<MW, TYm, true, false, false, true>
+              // (w on the fly beside the corrector's sweep: memory holds the corrected velocities, only w is not read)
+              : (ahead && m->w_fly_now && part == 0) ? (g.cv.on ? k_momentum_tendencies_v5<MW, TYm, true, true, true, false, false, true>
+                                                        : m->immersed ? k_momentum_tendencies_v5<MW, TYm, true, true, false, false, false, true>
+                                                                      : k_momentum_tendencies_v5<MW, TYm, true, false, false, false, false, true>)
               : g.cv.on ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true, true>)
               : m->immersed ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true> : k_momentum_tendencies_v5<MW, TYm, false, true>)
                             : (ahead ? k_momentum_tendencies_v5<MW, TYm, true, false> : k_momentum_tendencies_v5<MW, TYm, false, false>);
@@ -1245,6 +1250,10 @@ gb25_status tracers_impl(gb25_model* m) {
                 : (m->uv_lazy && ahead && fold) ? k_tracer_tendencies_v5<TWL, true, false, true, false, true>
                 : (m->uv_lazy && ahead && m->w_fly_now) ? k_tracer_tendencies_v5<TWL, true, false, false, false, true, 5, true>   // (slab)
                 : (m->uv_lazy && ahead) ? k_tracer_tendencies_v5<TWL, true, false, false, false, true>
+                // (w on the fly beside the corrector's sweep)
+                : (ahead && m->w_fly_now) ? (g.cv.on ? (fold ? k_tracer_tendencies_v5<TW, true, true, true, true, false, 5, true> : k_tracer_tendencies_v5<TW, true, true, false, true, false, 5, true>)
+                                             : m->immersed ? (fold ? k_tracer_tendencies_v5<TW, true, true, true, false, false, 5, true> : k_tracer_tendencies_v5<TW, true, true, false, false, false, 5, true>)
+                                                           : (fold ? k_tracer_tendencies_v5<TW, true, false, true, false, false, 5, true> : k_tracer_tendencies_v5<TW, true, false, false, false, false, 5, true>))
                 : g.cv.on ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false, true>)
                                  : k_tracer_tendencies_v5<TW, false, true, false, true>)
                 : m->immersed ? (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, true, true> : k_tracer_tendencies_v5<TW, true, true, false>)
@@ -1693,7 +1702,7 @@ gb25_status corrector_impl(gb25_model* m, bool use_colsum = false, int part = 0)
         hipLaunchKernelGGL(kern, grid2(ni_, nj, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
                            m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d,
                            cs ? m->colsum[0].d : nullptr, cs ? m->colsum[1].d : nullptr, i0_, ni_, mom_kchunks(m),
-                           skf, sk, jr0, nj, jskf, jsk);
+                           skf, sk, jr0, nj, jskf, jsk, m->corr_out ? m->corr[0].d : nullptr, m->corr_out ? m->corr[1].d : nullptr);
       }
     };
     // rows: the own ones (the halo rows of a rank of a 2-D decomposition arrive corrected: group 10 travels after this)
@@ -1943,16 +1952,19 @@ gb25_status ab2_step_impl(gb25_model* m, double dt, int euler) {
 }
 
 // u, v <- u + du, v + dv: ends the state in which the corrector lives inside its consumers (before a composite call returns)
-gb25_status materialize_uv(gb25_model* m) {
-  if (!m->uv_lazy) return GB25_OK;
-  const Grid& g = m->g;
-  dim3 b(64, 4);
-  hipLaunchKernelGGL(k_apply_correction, grid2(g.sx, g.sy_v, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
-                     LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0});
-  LAUNCHCHK();
-  m->uv_lazy = false;
+// need_w = false: the step that follows carries w inside its tendency kernels as well (w on the fly beside the corrector's sweep):
+// the field w stays stale
+gb25_status materialize_uv(gb25_model* m, bool need_w = true) {
+  if (m->uv_lazy) {
+    const Grid& g = m->g;
+    dim3 b(64, 4);
+    hipLaunchKernelGGL(k_apply_correction, grid2(g.sx, g.sy_v, b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
+                       LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0});
+    LAUNCHCHK();
+    m->uv_lazy = false;
+  }
   m->w_fly_now = false;
-  if (m->w_stale) {   // the steps behind carried w inside their tendency kernels: the field itself, from the corrected velocities
+  if (need_w && m->w_stale) {   // the steps behind carried w inside their tendency kernels: the field itself, from the corrected velocities
     m->w_stale = false;
     return compute_w_impl(m);
   }
@@ -1963,6 +1975,16 @@ gb25_status materialize_uv(gb25_model* m) {
 inline bool lazy_corrector_ok(const gb25_model* m) {
   return m->lazy_corrector && !m->coupled && m->bottom_drag == 0 && m->tracer_order == 5 && m->two_streams && producers_fold(m) && !m->immersed && !m->g.cv.on && m->kernel_gen >= 2 &&
          m->ab2_ahead == 1 && !m->ptr_exposed && m->pressure_bits == 64;
+}
+
+// w on the fly beside the corrector's SWEEP (round 4): the grids the corrector-inside-its-consumers instances do not exist for --
+// a GridFittedBottom, the curvilinear grids, the zipper fold -- still drop the k_compute_w launch: the sweep leaves du, dv of the
+// own columns as a by-product, k_w_bases turns the look-ahead's chunk integrals + du, dv into w at the chunk boundaries, and the
+// WFLY instances of the two tendency kernels carry w up their chunks.  Single domain, between the steps of one gb25_loop call.
+inline bool wfly_sweep_ok(const gb25_model* m) {
+  return m->w_fly && !m->slab && !m->coupled && m->bottom_drag == 0 && m->tracer_order == 5 && m->two_streams && m->kernel_gen >= 2 &&
+         m->ab2_ahead == 1 && !m->ptr_exposed && m->nu == 0 && m->kappa == 0 && !m->catke &&
+         std::max(1, m->g.Nz / m->trc_chunk_levels) == mom_kchunks(m);
 }
 
 // ... and a slab of an x decomposition or a rank of a 2-D one: the same kernels without the halo images (its halos come with the
@@ -2009,7 +2031,9 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
   // The corrector inside its consumers: when everything this step needs was made ahead of time (u, v, the sub-cycle) and
   // another step follows, no sweep over u and v at all -- a 2-D kernel leaves du, dv and w, the tendency kernels add them.
   const bool lazy = more && adopted && baro_adopted && m->complete_fills_needed == 0 && lazy_corrector_ok(m);
-  if (!lazy && (s = materialize_uv(m))) return s;   // (the stand-alone kernels below expect corrected velocities)
+  // ... or the sweep stays and only w moves into the tendency kernels (the look-ahead's chunk integrals must be this step's)
+  const bool wfly_sweep = !lazy && more && adopted && m->complete_fills_needed == 0 && wfly_sweep_ok(m);
+  if (!lazy && (s = materialize_uv(m, !wfly_sweep))) return s;   // (the stand-alone kernels below expect corrected velocities)
   if ((s = ab2_velocities_impl(m, (real)dt, chi))) return s;
   Halo2 hG = halo2_G(m);
   // the sub-cycle reads G.U, G.V at interior points only (periodic wrap and walls are in the kernel): their halo
@@ -2076,15 +2100,29 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     // w on the fly: the chunkings of the two tendency kernels must be the one the partial sums were made with
     m->w_fly_now = m->w_fly && std::max(1, g.Nz / m->trc_chunk_levels) == mom_kchunks(m);
     if (m->w_fly_now) {
-      hipLaunchKernelGGL(k_w_bases, grid2(g.Nx + 4, g.Ny + 4, b), b, 0, main, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
+      hipLaunchKernelGGL((k_w_bases<false, false>), grid2(g.Nx + 4, g.Ny + 4, b), b, 0, main, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
                          LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0}, m->wbase, -2, g.Nx + 4, INT_MAX, 0);
       LAUNCHCHK();
       m->w_stale = true;
     }
     for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);   // cache_previous_tendencies!
     m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
-  } else if ((s = corrector_impl(m, true))) {
-    return s;
+  } else {
+    m->corr_out = wfly_sweep;      // (the sweep leaves du, dv of the own columns behind for k_w_bases)
+    s = corrector_impl(m, true);
+    m->corr_out = false;
+    if (s) return s;
+    m->w_fly_now = wfly_sweep;
+    if (wfly_sweep) {
+      const Grid& g = m->g;
+      dim3 b(64, 4);
+      const LazyCorr lc{m->corr[0].d, m->corr[1].d, nullptr, 0};
+      auto kb = g.cv.on ? k_w_bases<true, true> : (m->immersed ? k_w_bases<true, false> : k_w_bases<false, false>);
+      hipLaunchKernelGGL(kb, grid2(g.Nx + 4, g.Ny + 4, b), b, 0, main, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v, lc,
+                         m->wbase, -2, g.Nx + 4, INT_MAX, 0);
+      LAUNCHCHK();
+      m->w_stale = true;
+    }
   }
   {
     // u, v and eta, U, V -- whatever their last writers (the corrector, the sub-cycle's last launch) did not fill
@@ -2092,7 +2130,7 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     const int which = (uv_fresh ? 0 : 1) | ((eta_halos_fresh && !complete) ? 0 : 2);
     if (which && (s = fill_halos_impl(m, true, false, which, 1))) return s;
   }
-  if (!(lazy && m->w_fly_now) && (s = compute_w_impl(m))) return s;
+  if (!((lazy || wfly_sweep) && m->w_fly_now) && (s = compute_w_impl(m))) return s;
   // ---- join: the tendencies need w, u, v and T, S (the tracers) / the pressure differences (the momentum)
   const bool tracers_first = m->tracers_first != 0;
   if (tracers_first) {

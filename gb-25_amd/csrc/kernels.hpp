@@ -1837,6 +1837,12 @@ __global__ __launch_bounds__(256) void k_corrector_2d(Grid g, const real* __rest
 // A slab of a decomposition (x_periodic = 0: no wrap, the halo columns of P and of du, dv are the neighbours', brought by the
 // bundle) runs it over its columns [0, Nx - 2] before the interior momentum pass overwrites P there, and over the columns next
 // to the x halos -- [i0, i0 + ni) with a gap of `skip` from `skip_from` on -- once the bundle has arrived.
+// IMM: the correction of a face acts from its first free level KPU / KPV on (the faces below touch the solid and stay zero), so
+// du, dv count with the thickness of the chunk's levels from there on; static column depths are in du, dv already.
+// CURV: the face lengths and the area per point.  With the zipper fold (single domain) the rows beyond the pivot row are the
+// images of the cells south of it: w(i, Ny-1+q) = w(Nx-1-i, Ny-1-q), evaluated AT the source cell -- whose northern y face,
+// when it lies beyond the pivot row, is the image -v(Nx-1-i', Ny-1).
+template <bool IMM, bool CURV>
 __global__ __launch_bounds__(256) void k_w_bases(Grid g, const real* __restrict__ P, int kchunks, int plane2, LazyCorr lz,
                                                  real* __restrict__ wbase, int i0, int ni, int skip_from, int skip) {
   const int ix = blockIdx.x * blockDim.x + threadIdx.x, j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 2;
@@ -1847,24 +1853,52 @@ __global__ __launch_bounds__(256) void k_w_bases(Grid g, const real* __restrict_
   const int klen = (g.Nz + kchunks - 1) / kchunks;
   auto wrap = [&](int ii) { return !g.x_periodic ? ii : (ii < 0 ? ii + g.Nx : (ii >= g.Nx ? ii - g.Nx : ii)); };
   const int o2 = i2(g, i, j);
+  const bool fold = CURV && g.cv.north_fold;
+  // the cell whose w this is (beyond a zipper fold: the cell it is the image of)
+  int ci = i, cj = j;
+  if (fold && j > g.Ny - 1) {
+    ci = g.Nx - 1 - wrap(i);
+    cj = 2 * (g.Ny - 1) - j;
+  }
   // (walls where the GLOBAL grid has them: Grid::jws, jwn; the rows of an open side of a rank of a 2-D decomposition are the
   // neighbour's and hold what it holds)
-  const bool urow = j >= g.jws - 1 && j <= g.jwn;               // rows whose u is not identically zero (interior + one layer)
-  const int ju = min(max(j, g.jws), g.jwn - 1);
-  const int ow = i2(g, wrap(i), ju), oe = i2(g, wrap(i + 1), ju);
-  const bool vs_ok = j >= g.jws + 1 && j <= g.jwn - 1, vn_ok = j + 1 >= g.jws + 1 && j + 1 <= g.jwn - 1;
-  const int os = i2(g, wrap(i), min(max(j, g.jws), g.jwn)), on = i2(g, wrap(i), min(max(j + 1, g.jws), g.jwn));
-  const real dxs = g.dxf[j], dxn = g.dxf[j + 1], raz = g.razc[j], dy = g.dy;
+  const bool urow = cj >= g.jws - 1 && cj <= g.jwn;               // rows whose u is not identically zero (interior + one layer)
+  const int ju = min(max(cj, g.jws), g.jwn - 1);
+  const int ow = i2(g, wrap(ci), ju), oe = i2(g, wrap(ci + 1), ju);
+  const bool vs_ok = cj >= g.jws + 1 && cj <= g.jwn - 1, vn_ok = cj + 1 >= g.jws + 1 && cj + 1 <= g.jwn - 1;
+  int os = i2(g, wrap(ci), min(max(cj, g.jws), g.jwn)), on = i2(g, wrap(ci), min(max(cj + 1, g.jws), g.jwn));
+  real sn = real(1.);
+  if (fold && cj + 1 > g.Ny - 1) {   // the y face beyond the pivot row: (ci, Ny) <- -(Nx-1-ci, Ny-1)
+    on = i2(g, g.Nx - 1 - wrap(ci), g.Ny - 1);
+    sn = -real(1.);
+  }
+  const int oc = i2(g, wrap(ci), min(max(cj, -g.H), g.Ny + g.H - 1));
+  const real dxs = CURV ? g.cv.dxcf[os] : g.dxf[cj], dxn = CURV ? g.cv.dxcf[on] : g.dxf[cj + 1];
+  const real dye = CURV ? g.cv.dyfc[oe] : g.dy, dyw = CURV ? g.cv.dyfc[ow] : g.dy;
+  const real raz = CURV ? g.cv.razcc[oc] : g.razc[cj];
+  int Ke = 0, Kw = 0, Ks = 0, Kn = 0;
+  if (IMM) {
+    Ke = (int)((g.im.ordC[oe] >> 8) & 255); Kw = (int)((g.im.ordC[ow] >> 8) & 255);
+    Ks = (int)((g.im.ordC[os] >> 16) & 255); Kn = (int)((g.im.ordC[on] >> 16) & 255);
+  }
+  const real due = lz.du ? lz.du[oe] : real(0.), duw = lz.du ? lz.du[ow] : real(0.);
+  const real dvs = lz.dv ? lz.dv[os] : real(0.), dvn = lz.dv ? lz.dv[on] : real(0.);
   real w = real(0.);
   wbase[o2] = w;
   for (int c = 0; c + 1 < kchunks; c++) {
-    real Z = real(0.);
-    for (int k = c * klen; k < min(g.Nz, (c + 1) * klen); k++) Z += g.dzc[k];
+    real Ze = real(0.), Zw = real(0.), Zs = real(0.), Zn = real(0.);
+    for (int k = c * klen; k < min(g.Nz, (c + 1) * klen); k++) {
+      const real dz = g.dzc[k];
+      if (!IMM || k >= Ke) Ze += dz;
+      if (!IMM || k >= Kw) Zw += dz;
+      if (!IMM || k >= Ks) Zs += dz;
+      if (!IMM || k >= Kn) Zn += dz;
+    }
     const real* Pu = P + 2 * q + (long)c * plane2;
     const real* Pv = P + 3 * q + (long)c * plane2;
-    const real ue = urow ? Pu[oe] + lz.du[oe] * Z : real(0.), uw = urow ? Pu[ow] + lz.du[ow] * Z : real(0.);
-    const real vn = vn_ok ? Pv[on] + lz.dv[on] * Z : real(0.), vs = vs_ok ? Pv[os] + lz.dv[os] * Z : real(0.);
-    const real div = (dy * ue - dy * uw) + (dxn * vn - dxs * vs);
+    const real ue = urow ? Pu[oe] + due * Ze : real(0.), uw = urow ? Pu[ow] + duw * Zw : real(0.);
+    const real vn = vn_ok ? sn * (Pv[on] + dvn * Zn) : real(0.), vs = vs_ok ? Pv[os] + dvs * Zs : real(0.);
+    const real div = (dye * ue - dyw * uw) + (dxn * vn - dxs * vs);
     w = w - div * raz;
     wbase[(long)(c + 1) * plane2 + o2] = w;
   }
@@ -1904,7 +1938,9 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
                                                    real* __restrict__ Ub, real* __restrict__ Vb,
                                                    const real* __restrict__ Usum, const real* __restrict__ Vsum,
                                                    int i0, int ni, int kchunks, int skip_from, int skip, int jr0, int nj,
-                                                   int jskip_from, int jskip) {
+                                                   int jskip_from, int jskip, real* __restrict__ du_out = nullptr,
+                                                   real* __restrict__ dv_out = nullptr) {
+  // du_out, dv_out (or null): the correction of the own columns as 2-D fields, for w on the fly beside the sweep (k_w_bases)
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= ni || j >= nj) return;
@@ -1943,6 +1979,10 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
     Vb[o2] = sv;
   }
   const real du = (U[o2] - su) * (IMM ? g.im.rHfc[o2] : g.rLz), dv = (V[o2] - sv) * (IMM ? g.im.rHcf[o2] : g.rLz);
+  if (own && du_out != nullptr) {
+    du_out[o2] = du;
+    dv_out[o2] = dv;
+  }
   int KPU = 0, KPV = 0;
   if (IMM) {
     const unsigned C = g.im.ordC[o2];

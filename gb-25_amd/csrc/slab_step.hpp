@@ -428,7 +428,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       if (m->w_fly_now && m->Ry == 1) {
         // chunk bases of w on the columns [0, Nx - 2] (their u faces are own columns), before the interior momentum pass
         // overwrites the chunk sums they are made from
-        hipLaunchKernelGGL(k_w_bases, grid2(g.Nx - 1, g.Ny + 4, b), b, 0, m->stream, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
+        hipLaunchKernelGGL((k_w_bases<false, false>), grid2(g.Nx - 1, g.Ny + 4, b), b, 0, m->stream, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
                            LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0}, m->wbase, 0, g.Nx - 1, INT_MAX, 0);
         LAUNCHCHK();
         m->w_stale = true;
@@ -497,7 +497,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
                              m->corr[1].d, -g.H, g.Nx + 2 * g.H, INT_MAX, 0, -hs, nj);
           m->colsum_valid = false;
           if (m->w_fly_now) {
-            hipLaunchKernelGGL(k_w_bases, grid2(g.Nx + 4, g.Ny + 4, b), b, 0, m->stream, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
+            hipLaunchKernelGGL((k_w_bases<false, false>), grid2(g.Nx + 4, g.Ny + 4, b), b, 0, m->stream, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
                                LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0}, m->wbase, -2, g.Nx + 4, INT_MAX, 0);
             m->w_stale = true;
           }
@@ -508,7 +508,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
                              m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d,
                              -g.H, 2 * g.H, 0, g.Nx, 0, g.Ny + 1);
           if (m->w_fly_now)   // the chunk bases of w on the columns -2, -1 and Nx - 1, Nx, Nx + 1 (the w tiles reach two columns out)
-            hipLaunchKernelGGL(k_w_bases, grid2(5, g.Ny + 4, b), b, 0, m->stream, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
+            hipLaunchKernelGGL((k_w_bases<false, false>), grid2(5, g.Ny + 4, b), b, 0, m->stream, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v,
                                LazyCorr{m->corr[0].d, m->corr[1].d, nullptr, 0}, m->wbase, -2, 5, 0, g.Nx - 1);
           LAUNCHCHK();
         }

@@ -100,10 +100,11 @@ struct UvAhead {
 // as it is loaded -- tile elements (their du, dv are k-independent: registers) and the own column's vertical window.
 // DRAG: the quadratic bottom drag's flux boundary condition (Grid.bottom_flux) enters the first free level (an instance of its
 // own: the hook cost the default instances a few spilled registers)
-// WFLY (with LAZY): w is not read -- the thread that derives the divergence pieces DU, DV of a (c,c,c) point in phase 1 also
+// WFLY: w is not read -- the thread that derives the divergence pieces DU, DV of a (c,c,c) point in phase 1 also
 // carries that point's w up the chunk, w(k+1) = w(k) - (DU + DV) / Az, and puts it into the w tile; w at the chunk's first
 // level comes from lz.wbase (k_w_bases).  Saves the 4.6 B per cell of the w tile and, with the tracer kernel doing the same,
-// the whole k_compute_w launch of a step.
+// the whole k_compute_w launch of a step.  With or without LAZY (round 4: the grids with a bottom and the curvilinear ones keep the
+// corrector's sweep but not the w launch); CURV: the tile holds Az w, so Az w is what is carried: Az w(k+1) = Az w(k) - (DU + DV).
 template <int MINW, int V2_TY, bool AHEAD, bool IMM, bool CURV = false, bool LAZY = false, bool DRAG = false, bool WFLY = false>
 __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     Grid g, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ w,
@@ -111,7 +112,6 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     TileCols tc, int kchunks, int nb, UvAhead next, LazyCorr lz) {
   static_assert(!CURV || IMM, "the curvilinear variant takes its orders from the tables");
   static_assert(!LAZY || (!IMM && !CURV), "the corrector is applied inside its consumers on the flat lat-lon grid only");
-  static_assert(!WFLY || LAZY, "w on the fly rides on the corrector inside its consumers");
   __shared__ MomentumLds<V2_TY> lds;
   __shared__ typename std::conditional<CURV, MomentumMetricLds<V2_TY>, NoLds>::type mt;
   __shared__ typename std::conditional<LAZY, MomentumCorrLds<V2_TY>, NoLds>::type cr;
@@ -333,16 +333,17 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
   // WFLY: this thread's (c,c,c) points of phase 1 (the same e = tid + q NT every level) carry their w; the w tile is the
   // (c,c,c) tile without its first row / column and its last row
   constexpr int NPT = (MD_X * MD_Y + NT - 1) / NT;
-  __shared__ real mrazc[WFLY ? MD_Y : 1];
+  __shared__ real mrazc[(WFLY && !CURV) ? MD_Y : 1];
   real wk[NPT];
   if constexpr (WFLY) {
-    if (tid < MD_Y) mrazc[tid] = g.razc[j0 - 3 + tid];
+    if (!CURV && tid < MD_Y) mrazc[tid] = g.razc[j0 - 3 + tid];
 #pragma unroll
     for (int q = 0; q < NPT; q++) {
       const int e = tid + q * NT, py = e / MD_X, px = e - py * MD_X;
       // (clamped like the tiles: the last rows / columns of a ragged tile are never used)
       const int gi = min(i0 - 3 + px, g.Nx + H - 1), gj = min(j0 - 3 + py, g.Ny + H - 1);
       wk[q] = (e < MD_X * MD_Y) ? lz.wbase[(long)kc * lz.wplane + i2(g, gi, gj)] : real(0.);
+      if constexpr (CURV) wk[q] = wk[q] * g.cv.azcc[i2(g, gi, gj)];   // (the curvilinear tile holds Az w)
     }
   }
   fetch(k0, ob);
@@ -413,7 +414,8 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
         if (e < MD_X * MD_Y) {
           int py, px;
           const real div = derive(e, py, px);
-          wk[q] = wk[q] - div * mrazc[py];               // w on the top face of level k
+          if constexpr (CURV) wk[q] = wk[q] - div;       // Az w on the top face of level k
+          else wk[q] = wk[q] - div * mrazc[py];          // w on the top face of level k
           if (py >= 1 && py <= MW_Y && px >= 1 && px <= MW_X) lds.W[par][py - 1][px - 1] = wk[q];
         }
       }
@@ -694,7 +696,7 @@ struct Ab2Ahead {
 // LAZY: the barotropic correction of this step is added to u and v as they are loaded (see k_momentum_tendencies_v5).
 // ORD: 5 = WENO(order = 5) (baroclinic_instability_model); 7 = WENO(order = 7) (ClimaOcean's ocean_simulation): windows of
 // 2R = 8 values per face (R = 4), the order-5 path next to walls and the immersed boundary (biased8, device_common.hpp).
-// WFLY (with LAZY): w is not read; Az w on the top face follows from the divergence of the transports the lane holds anyway --
+// WFLY: w is not read; Az w on the top face follows from the divergence of the transports the lane holds anyway --
 // Az w(k+1) = Az w(k) - [(Axu(i+1) - Axu(i)) + (Ayn - Ays)], the east face's transport from the next lane -- starting from
 // lz.wbase at the chunk's first level (k_w_bases).  Continuity and advection then see the very same transports.
 template <bool AHEAD, bool IMM, bool FOLD, bool CURV = false, bool LAZY = false, int ORD = 5, bool WFLY = false>

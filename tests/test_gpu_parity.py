@@ -597,3 +597,43 @@ def test_w_on_the_fly_agrees_to_round_off(shape, float_type):
     for m in (a, b):   # a constant tracer stays constant: continuity and advection see the same transports either way
         assert np.abs(m.backend.get_field("Gn.S", False)).max() < 1e3 * eps * 35.0 * 1e-3
         assert np.abs(m.backend.get_field("S", False) - 35.0).max() < 50 * eps * 35.0
+
+
+@pytest.mark.parametrize("float_type", ["Float32", "Float64"])
+@pytest.mark.parametrize("grid_type,shape", [("gaussian_islands_lat_lon", (150, 70, 24)), ("lat_lon_as_curvilinear", (150, 70, 24)),
+                                             ("gaussian_islands", (144, 64, 24)),   # (the bare tripolar grid is singular at its poles)
+                                             ("simple_lat_lon", (150, 70, 24))])
+def test_w_on_the_fly_beside_the_sweeping_corrector(grid_type, shape, float_type):
+    """Round 4: the grids whose kernel instances keep the corrector's sweep -- a GridFittedBottom, the curvilinear grids, the
+    zipper fold -- drop the k_compute_w launch all the same: the sweep leaves du, dv as 2-D fields, k_w_bases makes w at the chunk
+    boundaries from the look-ahead's chunk integrals (masked thicknesses next to the bottom, image rows beyond the fold), the
+    tendency kernels carry w up their chunks.  (The flat grid takes this path with lazy_corrector = 0.)  Same criterion as the
+    lazy path's test: every field within a few hundred ulps of its norm after 25 steps, the field w the call leaves behind
+    included, and a constant tracer stays constant where nothing is immersed."""
+    Nx, Ny, Nz = shape
+    eps = float(np.finfo(np.float32 if float_type == "Float32" else np.float64).eps)
+    models = []
+    for fly in (0, 1):
+        m = gb.baroclinic_instability_model(gb.GPU(float_type=float_type), Nx, Ny, Nz, dt=300.0, grid_type=grid_type,
+                                            options=dict(w_on_the_fly=fly, subcycle_lookahead=1, lazy_corrector=0))
+        gb.set_baroclinic_instability(m)
+        set_noisy_velocities(m, 0.05)
+        m.set(S=np.full((Nx, Ny, Nz), 35.0, m.backend.dtype))       # a constant tracer
+        gb.first_time_step(m)
+        m.backend.profile_enable(True)
+        m.backend.profile_reset()
+        gb.loop(m, 24)
+        models.append(m)
+    a, b = models
+    assert b.backend.lookahead_state()[0]
+    # (the stand-alone path launches k_compute_w every step; on the fly: once, when the call returns)
+    assert a.backend.profile_get("compute_w")[0] >= 24 and b.backend.profile_get("compute_w")[0] <= 3
+    for n in ALL_FIELDS:
+        if n in ("Gn.S", "Gm.S"):
+            continue
+        x, y = a.backend.get_field(n, True), b.backend.get_field(n, True)
+        assert np.isfinite(y).all() and rel(x, y) < 4000 * eps, (n, rel(x, y))
+    assert rel(a.backend.get_field("w", True), b.backend.get_field("w", True)) < 400 * eps
+    if "islands" not in grid_type:
+        for m in (a, b):
+            assert np.abs(m.backend.get_field("S", False) - 35.0).max() < 50 * eps * 35.0
