@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
 OPTION_IDS = {"kernels": 0, "ab2_lookahead": 1, "subcycle_lookahead": 2, "subcycle_block": 3, "fill_fused": 4,
               "two_streams": 5, "store_pressure": 6, "split_tendencies": 7, "pressure_precision": 8, "immersed_kernels": 9, "fold_fills": 10,
               "lazy_corrector": 11, "momentum_chunk_levels": 12, "tracer_chunk_levels": 13, "tracers_first": 14, "w_on_the_fly": 15, "sub_stream_priority": 16, "subcycle_whole": 17, "early_strips": 18,
-              "catke_stale_e_halos": 19, "comm_timeout_seconds": 20, "roctx_ranges": 21}
+              "catke_stale_e_halos": 19, "comm_timeout_seconds": 20, "roctx_ranges": 21, "substep_order": 22, "fold_pivot_slaved": 23}
 UNIQUE_ID_BYTES = 128
 # int32 fn(void *user, int32 buffer_set, const void *send_w, const void *send_e, void *recv_w, void *recv_e, int64 nbytes)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)

@@ -55,6 +55,7 @@ struct Curv {
   const real *rdxfc, *rdycf, *razcc, *razfc, *razcf, *razff;
   const real *fbar_u, *fbar_v, *phicc;
   int on, north_fold;
+  int pivot_slaved;   // option FOLD_PIVOT_SLAVED: the fold fill also writes the eastern half of the pivot row (image of its western half)
 };
 
 // The barotropic correction of the current step when it is applied inside the kernels that read u and v instead of by a

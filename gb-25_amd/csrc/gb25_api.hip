@@ -200,6 +200,7 @@ struct gb25_model {
   bool whole_attr_set[2][2] = {{false, false}, {false, false}};   // k_barotropic_whole's dynamic-LDS attribute, per instance, on THIS model's device
   int comm_timeout_s = 180;          // option COMM_TIMEOUT_SECONDS
   bool roctx_ranges = true;          // option ROCTX_RANGES
+  int substep_order = 0;             // option SUBSTEP_ORDER
   double catke_prev_time = 0;        // diffusivity_fields.previous_compute_time
   bool catke_stale_e_halos = false;  // option CATKE_STALE_E_HALOS
   bool n2_fresh = false;             // (unused since N^2 = g (alpha dzT - beta dzS) has a kernel of its own)
@@ -936,7 +937,7 @@ gb25_status fill_halos_impl(gb25_model* m, bool with_x, bool extended = false, i
     if (which == 2) return fill_halos_2d(m, h2);
     if (which == 1) h2.n = 0;
     hipLaunchKernelGGL(k_fill_yz, dim3((g.Nx + 255) / 256, g.Nz + 1 + g.Ny), b, 0, st, g, h3, h2, 0, g.Nx, 0);
-    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H, g.Nz + 2 + (h2.n ? 1 : 0)), b, 0, st, g, h3, h2);
+    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H + g.cv.pivot_slaved, g.Nz + 2 + (h2.n ? 1 : 0)), b, 0, st, g, h3, h2);
     const int rows_c = g.sy_c * (g.Nz + 2 * g.H), rows_v = g.sy_v * (g.Nz + 2 * g.H);
     hipLaunchKernelGGL(k_fill_x, dim3((unsigned)(((long)rows_v * 2 * g.H + 255) / 256), 4 + h2.n), b, 0, st, g, h3, h2,
                        rows_c, rows_v);
@@ -984,7 +985,7 @@ gb25_status fill_halos_2d(gb25_model* m, Halo2 h2) {
   g2.Nz = 0;
   hipLaunchKernelGGL(k_fill_y, dim3((g.Nx + 255) / 256, 1), b, 0, m->stream, g2, none, h2, 0, g.Nx);
   if (g.cv.north_fold && !m->slab)   // (a slab's rows beyond the fold come from its partner rank: slab_step.hpp)
-    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H, 1), b, 0, m->stream, g, none, h2);
+    hipLaunchKernelGGL(k_fill_fold, dim3((g.Nx + 255) / 256, g.H + g.cv.pivot_slaved, 1), b, 0, m->stream, g, none, h2);
   if (g.x_periodic) {
     long threads = (long)g.sy_v * 2 * g.H;
     hipLaunchKernelGGL(k_fill_x, dim3((unsigned)((threads + 255) / 256), 4 + h2.n), b, 0, m->stream, g2, none, h2, 0,
@@ -1469,6 +1470,8 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false, const In
   }
   Timed t(m, GB25_K_BAROTROPIC);
   m->last_baro_folded = false;
+  // (option SUBSTEP_ORDER = 1 exists in the one-substep-per-launch kernel only: the temporally blocked ones keep the default order)
+  const int bblock = m->substep_order ? 1 : m->baro_block;
   // work arrays: a slab's are widened in x (filled by the exchange of group 1 / 3 before this is called), a folded grid's are
   // tall (image rows beyond the pivot row: a slab's come from its partner before this is called, a single domain's below)
   const bool wide = m->slab || g.cv.north_fold;
@@ -1482,7 +1485,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false, const In
   bb.top_open = (g.cv.north_fold || m->yn_open) ? 1 : 0;
   if (!wide) {
     size_t nbar = m->f[GB25_ETA_BAR].elems() + m->f[GB25_U_BAR].elems() + m->f[GB25_V_BAR].elems();
-    if (m->baro_block <= 1)   // (the blocked kernels start their averages from zero themselves)
+    if (bblock <= 1)   // (the blocked kernels start their averages from zero themselves)
       HIPCHK(hipMemsetAsync(ahead ? m->bars_ahead : m->bars, 0, nbar * sizeof(real), m->stream));
     // the state the sub-cycle starts from is only read; the substeps alternate between two scratch sets
     for (int q = 0; q < 3; q++) {
@@ -1513,7 +1516,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false, const In
       if ((s = tall_rows_impl(m, m->tall_buf, true))) return s;
       if ((s = tall_rows_impl(m, m->tall_buf, false))) return s;
     }
-    if (m->baro_block <= 1)
+    if (bblock <= 1)
       HIPCHK(hipMemsetAsync(m->wideBar[0].d, 0,
                             (m->wideBar[0].elems() + m->wideBar[1].elems() + m->wideBar[2].elems()) * sizeof(real),
                             m->stream));
@@ -1532,8 +1535,8 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false, const In
   bool finalize_after = false;
   // temporally blocked: the lat-lon kernel (row metrics) or its curvilinear sibling (per-point metrics); on canonical arrays
   // (single domain), widened slabs and the tall arrays of a folded grid alike
-  const bool blocked_curv = m->baro_block > 1 && g.cv.on;
-  const bool blocked = m->baro_block > 1;
+  const bool blocked_curv = bblock > 1 && g.cv.on;
+  const bool blocked = bblock > 1;
   const CurvBaro cb = wide ? CurvBaro{m->d_wideM[0], m->d_wideM[1], m->d_wideM[2], m->d_wideM[3], m->d_wideM[4]}
                            : CurvBaro{g.cv.dyfc, g.cv.dxcf, g.cv.razcc, g.cv.rdxfc, g.cv.rdycf};
   const int rows = bb.jhi - bb.jlo + (bb.top_open ? 1 : 0);   // (no wall: the face row behind the last advanced row is carried along)
@@ -1611,7 +1614,7 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false, const In
     }
   } else if (blocked) {
     // temporally blocked: S substeps per launch on (64 x TY) tiles
-    const int S = std::min(m->baro_block, (int)BT_SMAX);
+    const int S = std::min(bblock, (int)BT_SMAX);
     constexpr int TYb = 16, TY5 = 17;   // (5 substeps per launch: 64 x 17 tiles keep LDS under 40 KB -- four blocks per CU)
     const int tyb = (S > 3 && S <= 5) ? TY5 : TYb;
     dim3 gm((bb.ihi - bb.ilo + BT_TX - 1) / BT_TX, (bb.jhi - bb.jlo + tyb - 1) / tyb);
@@ -1635,8 +1638,9 @@ gb25_status barotropic_impl(gb25_model* m, real dt, bool ahead = false, const In
       if (g.cv.on)
         hipLaunchKernelGGL(k_barotropic_substep_curv, gr, b, 0, m->stream, g, bb, cb, dtau, (real)m->weights[s]);
       else
-        hipLaunchKernelGGL(imm ? k_barotropic_substep<true> : k_barotropic_substep<false>, gr, b, 0, m->stream, g, bb, dtau,
-                           (real)m->weights[s]);
+        hipLaunchKernelGGL(m->substep_order ? (imm ? k_barotropic_substep<true, 1> : k_barotropic_substep<false, 1>)
+                                            : (imm ? k_barotropic_substep<true> : k_barotropic_substep<false>),
+                           gr, b, 0, m->stream, g, bb, dtau, (real)m->weights[s]);
       for (int q = 0; q < 3; q++) { real* w_ = nxt[q]; nxt[q] = other[q]; other[q] = w_; cur[q] = w_; }
     }
   }
@@ -3092,6 +3096,16 @@ gb25_status gb25_set_option(gb25_model* m, gb25_option opt, int32_t v) {
     case GB25_OPT_SUBCYCLE_WHOLE: m->baro_whole = v != 0; return GB25_OK;
     case GB25_OPT_EARLY_STRIPS: m->early_strips = v != 0; return GB25_OK;
     case GB25_OPT_ROCTX_RANGES: m->roctx_ranges = v != 0; return GB25_OK;
+    case GB25_OPT_SUBSTEP_ORDER:
+      if (v != 0 && v != 1) return fail(m, GB25_ERR_INVALID_ARGUMENT, "substep_order: 0 (eta, then U, V) or 1 (U, V, then eta)");
+      if (v == 1 && m->g.cv.on) return fail(m, GB25_ERR_STATE, "substep_order = 1 is built for the LatitudeLongitudeGrid kernels only (the oracle has it on every grid)");
+      m->substep_order = v;
+      return GB25_OK;
+    case GB25_OPT_FOLD_PIVOT_SLAVED:
+      if (v != 0 && !m->g.cv.north_fold) return fail(m, GB25_ERR_STATE, "fold_pivot_slaved: this grid has no zipper fold");
+      if (v != 0 && m->slab) return fail(m, GB25_ERR_STATE, "fold_pivot_slaved is built for the single domain only (a slab's eastern half of the pivot row belongs to its partner rank)");
+      m->g.cv.pivot_slaved = v != 0 ? 1 : 0;
+      return GB25_OK;
     case GB25_OPT_COMM_TIMEOUT_SECONDS:
       if (v < 1) return fail(m, GB25_ERR_INVALID_ARGUMENT, "comm_timeout_seconds: at least 1");
       m->comm_timeout_s = v;
@@ -3157,6 +3171,8 @@ gb25_status gb25_get_option(const gb25_model* m, gb25_option opt, int32_t* v) {
     case GB25_OPT_CATKE_STALE_E_HALOS: *v = m->catke_stale_e_halos; break;
     case GB25_OPT_COMM_TIMEOUT_SECONDS: *v = m->comm_timeout_s; break;
     case GB25_OPT_ROCTX_RANGES: *v = m->roctx_ranges; break;
+    case GB25_OPT_SUBSTEP_ORDER: *v = m->substep_order; break;
+    case GB25_OPT_FOLD_PIVOT_SLAVED: *v = m->g.cv.pivot_slaved; break;
     default: return GB25_ERR_INVALID_ARGUMENT;
   }
   return GB25_OK;

@@ -159,13 +159,17 @@ __device__ __forceinline__ real fold_sign(int ig, bool xface, bool neg) { return
 __global__ void k_fill_fold(Grid g, Halo3 f3, Halo2 f2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.Nx) return;
-  const int q = blockIdx.y + 1;   // 1 .. H
+  // q = 1 .. H; with option FOLD_PIVOT_SLAVED one more slice, q = 0: the pivot row itself -- held twice, cell (i, Ny-1) IS cell
+  // (Nx-1-i, Ny-1) -- whose eastern half becomes the image of its western half (cells i >= Nx/2; x faces i > Nx/2: the face
+  // Nx/2 is a pole and its own image).  [the later upstream fix as recalled; UPSTREAM-UNVERIFIED]
+  const int q = (int)blockIdx.y + 1 - g.cv.pivot_slaved;
   const bool twod = (int)blockIdx.z == (f3.n ? g.Nz + 2 : 0);
   const int k = (int)blockIdx.z - 1, ks = min(max(k, 0), g.Nz - 1);
   const int n = twod ? f2.n : f3.n;
   for (int f = 0; f < n; f++) {
     real* c = twod ? f2.p[f] : f3.p[f];
     const bool is_v = twod ? f2.is_v[f] : f3.is_v[f], xf = twod ? f2.xf[f] : f3.xf[f], neg = twod ? f2.neg[f] : f3.neg[f];
+    if (q == 0 && (is_v || i < g.Nx / 2 + (xf ? 1 : 0))) continue;
     const int isrc = fold_src_column(i, g.Nx, xf);
     const real sg = fold_sign(i, xf, neg);
     const int jd = g.Ny - 1 + q, js = is_v ? g.Ny - q : g.Ny - 1 - q;
@@ -1121,11 +1125,43 @@ __device__ __forceinline__ real eta_step(const Grid& g, const Baro& b, int i, in
   else dyV = g.dxf[j + 1] * b.V0[bi(g, b, i, j + 1)] - g.dxf[j] * b.V0[bi(g, b, i, j)];
   return b.eta0[bi(g, b, i, j)] - dtau * (dxU + dyV) / g.azc[j];
 }
+// ORDER = 1 (option SUBSTEP_ORDER; SURVEY A.7: the order of the two halves of a substep changed between upstream releases): U, V
+// first, from the old eta, then eta from the NEW U, V -- the thread recomputes the new transports on the four faces of its cell.
 template <bool IMM>
+__device__ __forceinline__ real U_step(const Grid& g, const Baro& b, int i, int j, real dtau) {
+  const int im = (b.wrap && i == 0) ? g.Nx - 1 : i - 1, o = bi(g, b, i, j);
+  const real dxe = (b.eta0[o] - b.eta0[bi(g, b, im, j)]) / g.dxc[j];
+  return b.U0[o] + dtau * (-g.g * (IMM ? b.Hfc[o] : g.Lz) * dxe + b.GU[o]);
+}
+template <bool IMM>
+__device__ __forceinline__ real V_step(const Grid& g, const Baro& b, int i, int j, real dtau) {
+  const int o = bi(g, b, i, j);
+  real dye = real(0.);
+  if (j != g.jws) dye = (b.eta0[o] - b.eta0[bi(g, b, i, j - 1)]) / g.dy;
+  return b.V0[o] + dtau * (-g.g * (IMM ? b.Hcf[o] : g.Lz) * dye + b.GV[o]);
+}
+template <bool IMM, int ORDER = 0>
 __global__ __launch_bounds__(256) void k_barotropic_substep(Grid g, Baro b, real dtau, real wgt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x + b.ilo;
   int j = blockIdx.y * blockDim.y + threadIdx.y + b.jlo;
   if (i >= b.ihi || j >= b.jhi) return;
+  if constexpr (ORDER == 1) {
+    const int ip = (b.wrap && i == g.Nx - 1) ? 0 : i + 1, o = bi(g, b, i, j);
+    const real Un = U_step<IMM>(g, b, i, j, dtau), Ue = U_step<IMM>(g, b, ip, j, dtau), Vn = V_step<IMM>(g, b, i, j, dtau);
+    const real dxU = g.dy * Ue - g.dy * Un;
+    real dyV;
+    if (j == g.jwn - 1) dyV = -(g.dxf[j] * Vn);                                             // the northern wall face carries nothing
+    else if (j == g.jws) dyV = g.dxf[j + 1] * V_step<IMM>(g, b, i, j + 1, dtau);
+    else dyV = g.dxf[j + 1] * V_step<IMM>(g, b, i, j + 1, dtau) - g.dxf[j] * Vn;
+    const real e = b.eta0[o] - dtau * (dxU + dyV) / g.azc[j];
+    b.eta1[o] = e;
+    b.U1[o] = Un;
+    b.V1[o] = Vn;
+    b.etab[o] += wgt * e;
+    b.Ub[o] += wgt * Un;
+    b.Vb[o] += wgt * Vn;
+    return;
+  }
   int im = (b.wrap && i == 0) ? g.Nx - 1 : i - 1;
   real e = eta_step(g, b, i, j, dtau);
   real ew = eta_step(g, b, im, j, dtau);

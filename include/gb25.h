@@ -162,6 +162,14 @@ typedef enum {
   GB25_OPT_ROCTX_RANGES,         /* [1] roctx ranges named like the reference's profiler annotations ("first_time_step", "time_step", "loop":
                                     src/timestepping_utils.jl:22,30,38) around the composites, and one per phase of src/precompile.jl:31-42
                                     around the issue of its kernels (rocprofv3 --marker-trace); free when no marker library is loaded */
+  /* Two more RESTATEMENT choices (like CATKE_STALE_E_HALOS they change results; a Julia dump of tools/dump_goldens.jl decides them
+   * without new kernel work; the oracle has both on every grid): */
+  GB25_OPT_SUBSTEP_ORDER,        /* [0] the two halves of a split-explicit substep: 0 = eta from the old U, V, then U, V from the new eta;
+                                    1 = U, V from the old eta, then eta from the new U, V (the order changed between
+                                    upstream releases).  1: LatitudeLongitudeGrid only, one substep per launch */
+  GB25_OPT_FOLD_PIVOT_SLAVED,    /* [0] TripolarGrid, single domain: 1 = every fold fill also overwrites the eastern half of the pivot row
+                                    (cell centres of the last row, held twice) with the image of its western half, as a later upstream
+                                    fix does as recalled; 0 = both copies are stepped independently */
   GB25_OPT_COUNT
 } gb25_option;
 

@@ -109,6 +109,8 @@ typedef struct {
   int catke; /* closure = CATKEVerticalDiffusivity() */
   void *catke_params; /* its parameters when they are not the defaults (catke_par, below) */
   double catke_prev_time;   /* diffusivity_fields.previous_compute_time */
+  int substep_order;        /* 0: eta with the old U, V, then U, V with the new eta (default); 1: U, V first, then eta with the new U, V */
+  int fold_pivot_slaved;    /* 1: the fold fill also overwrites the eastern half of the pivot row with the image of its western half */
   int catke_stale_e_halos;  /* 1: the halos of e are NOT refilled after the e step inside compute_diffusivities! (upstream as recalled) */
   int curv, north_fold;
   REAL *dxfc2, *dxcc2, *dxcf2, *dxff2, *dyfc2, *dycc2, *dycf2, *dyff2, *azcc2, *azfc2, *azcf2, *azff2, *fff2, *phicc2;
@@ -1007,6 +1009,10 @@ static void fold_rows_levels(model *m, int id, int twod, int is_v, int xface, RE
     } else {
       for (int q = 1; q <= H; q++)
         for (int i = 1; i <= Nx; i++) AF(i, Ny + q) = fold_sign(m, i, xface, sgn) * AF(fold_i(m, i, xface), Ny - q);
+      /* option (the later upstream fix, as recalled): the pivot row is held twice -- its eastern half becomes the image of
+       * its western half (cells i > Nx/2; x faces i > Nx/2 + 1: the face Nx/2 + 1 is a pole and its own image) */
+      if (m->fold_pivot_slaved)
+        for (int i = Nx / 2 + 1 + (xface ? 1 : 0); i <= Nx; i++) AF(i, Ny) = fold_sign(m, i, xface, sgn) * AF(fold_i(m, i, xface), Ny);
     }
 #undef AF
   }
@@ -1743,6 +1749,8 @@ static void catke_tke_tendency(model *m) {
 }
 void FN(set_catke)(void *h, int on) { ((model *)h)->catke = on != 0; }
 void FN(set_catke_stale_e_halos)(void *h, int on) { ((model *)h)->catke_stale_e_halos = on != 0; }
+void FN(set_substep_order)(void *h, int order) { ((model *)h)->substep_order = order != 0; }
+void FN(set_fold_pivot_slaved)(void *h, int on) { ((model *)h)->fold_pivot_slaved = on != 0; }
 
 /* ---------------------------------------------------------------- AB2 + free surface
  * ab2_step!(model, dt) -- /root/reference/src/precompile.jl:39,121-123 (appendix A.4, A.7). */
@@ -1833,29 +1841,33 @@ static void step_free_surface_fold(model *m, REAL dt) {
     memset(m->f[id].p, 0, sizeof(REAL) * (size_t)m->f[id].sx * m->f[id].sy);
   for (int s = 0; s < m->Ns; s++) {
     const REAL wgt = m->wts[s];
+    for (int half = 0; half < 2; half++) {   /* (the order of the two halves: see step_free_surface) */
+      if ((half == 0) == (m->substep_order == 0)) {
 #pragma omp parallel for schedule(static)
-    for (int j = 1; j <= NT; j++)
-      for (int i = 1; i <= Nx; i++) {
-        const int ip = (i == Nx) ? 1 : i + 1;
-        const REAL dxU = TT(dyfc, ip, j) * TT(U, ip, j) - TT(dyfc, i, j) * TT(U, i, j);
-        const REAL dyV = (j == 1) ? TT(dxcf, i, 2) * TT(V, i, 2) : TT(dxcf, i, j + 1) * TT(V, i, j + 1) - TT(dxcf, i, j) * TT(V, i, j);
-        TT(e, i, j) -= dtau * (dxU + dyV) / TT(azcc, i, j);
+        for (int j = 1; j <= NT; j++)
+          for (int i = 1; i <= Nx; i++) {
+            const int ip = (i == Nx) ? 1 : i + 1;
+            const REAL dxU = TT(dyfc, ip, j) * TT(U, ip, j) - TT(dyfc, i, j) * TT(U, i, j);
+            const REAL dyV = (j == 1) ? TT(dxcf, i, 2) * TT(V, i, 2) : TT(dxcf, i, j + 1) * TT(V, i, j + 1) - TT(dxcf, i, j) * TT(V, i, j);
+            TT(e, i, j) -= dtau * (dxU + dyV) / TT(azcc, i, j);
+          }
+      } else {
+#pragma omp parallel for schedule(static)
+        for (int j = 1; j <= NT; j++)
+          for (int i = 1; i <= Nx; i++) {
+            const int im = (i == 1) ? Nx : i - 1;
+            const REAL dxe = (TT(e, i, j) - TT(e, im, j)) / TT(dxfc, i, j);
+            const REAL dye = (j == 1) ? 0 : (TT(e, i, j) - TT(e, i, j - 1)) / TT(dycf, i, j);
+            TT(U, i, j) = TT(U, i, j) + dtau * (-m->g * TT(hf, i, j) * dxe + TT(GU, i, j));
+            TT(V, i, j) = TT(V, i, j) + dtau * (-m->g * TT(hc, i, j) * dye + TT(GV, i, j));
+          }
       }
-#pragma omp parallel for schedule(static)
-    for (int j = 1; j <= NT; j++)
+    }
+    for (int j = 1; j <= Ny; j++)
       for (int i = 1; i <= Nx; i++) {
-        const int im = (i == 1) ? Nx : i - 1;
-        const REAL dxe = (TT(e, i, j) - TT(e, im, j)) / TT(dxfc, i, j);
-        const REAL dye = (j == 1) ? 0 : (TT(e, i, j) - TT(e, i, j - 1)) / TT(dycf, i, j);
-        const REAL Un = TT(U, i, j) + dtau * (-m->g * TT(hf, i, j) * dxe + TT(GU, i, j));
-        const REAL Vn = TT(V, i, j) + dtau * (-m->g * TT(hc, i, j) * dye + TT(GV, i, j));
-        TT(U, i, j) = Un;
-        TT(V, i, j) = Vn;
-        if (j <= Ny) {
-          A2(F_ETAB, i, j) += wgt * TT(e, i, j);
-          A2(F_UB, i, j) += wgt * Un;
-          A2(F_VB, i, j) += wgt * Vn;
-        }
+        A2(F_ETAB, i, j) += wgt * TT(e, i, j);
+        A2(F_UB, i, j) += wgt * TT(U, i, j);
+        A2(F_VB, i, j) += wgt * TT(V, i, j);
       }
   }
   for (int j = 1; j <= Ny; j++)
@@ -1878,30 +1890,38 @@ static void step_free_surface(model *m, REAL dt) {
     memset(m->f[id].p, 0, sizeof(REAL) * (size_t)m->f[id].sx * m->f[id].sy);
   for (int s = 0; s < m->Ns; s++) {
     REAL wgt = m->wts[s];
+    /* the two halves of a forward-backward substep; which comes first is an option (the order changed between
+     * upstream releases): 0 = eta from the old U, V, then U, V from the new eta; 1 = U, V from the old eta, then eta from them */
+    for (int half = 0; half < 2; half++) {
+      if ((half == 0) == (m->substep_order == 0)) {
 #pragma omp parallel for schedule(static)
-    for (int j = 1; j <= Ny; j++)
-      for (int i = 1; i <= Nx; i++) {
-        int ip = (i == Nx) ? 1 : i + 1;
-        REAL dxU = DYFC(ip, j) * A2(F_BU, ip, j) - DYFC(i, j) * A2(F_BU, i, j);
-        REAL dyV = (j == Ny) ? -(DXCF(i, j) * A2(F_BV, i, j))
-                 : (j == 1)  ? DXCF(i, 2) * A2(F_BV, i, 2)
-                             : DXCF(i, j + 1) * A2(F_BV, i, j + 1) - DXCF(i, j) * A2(F_BV, i, j);
-        A2(F_ETA, i, j) -= dtau * (dxU + dyV) / AZCC(i, j);
+        for (int j = 1; j <= Ny; j++)
+          for (int i = 1; i <= Nx; i++) {
+            int ip = (i == Nx) ? 1 : i + 1;
+            REAL dxU = DYFC(ip, j) * A2(F_BU, ip, j) - DYFC(i, j) * A2(F_BU, i, j);
+            REAL dyV = (j == Ny) ? -(DXCF(i, j) * A2(F_BV, i, j))
+                     : (j == 1)  ? DXCF(i, 2) * A2(F_BV, i, 2)
+                                 : DXCF(i, j + 1) * A2(F_BV, i, j + 1) - DXCF(i, j) * A2(F_BV, i, j);
+            A2(F_ETA, i, j) -= dtau * (dxU + dyV) / AZCC(i, j);
+          }
+      } else {
+#pragma omp parallel for schedule(static)
+        for (int j = 1; j <= Ny; j++)
+          for (int i = 1; i <= Nx; i++) {
+            int im = (i == 1) ? Nx : i - 1;
+            REAL dxe = (A2(F_ETA, i, j) - A2(F_ETA, im, j)) / DXFC(i, j);
+            REAL dye = (j == 1) ? 0 : (A2(F_ETA, i, j) - A2(F_ETA, i, j - 1)) / DYCF(i, j);
+            /* static column depth at the face: min of the two columns (0 next to land: no pressure force, and G.U is 0) */
+            A2(F_BU, i, j) = A2(F_BU, i, j) + dtau * (-m->g * H2(Hfc, i, j) * dxe + A2(F_GBU, i, j));
+            A2(F_BV, i, j) = A2(F_BV, i, j) + dtau * (-m->g * H2(Hcf, i, j) * dye + A2(F_GBV, i, j));
+          }
       }
-#pragma omp parallel for schedule(static)
+    }
     for (int j = 1; j <= Ny; j++)
       for (int i = 1; i <= Nx; i++) {
-        int im = (i == 1) ? Nx : i - 1;
-        REAL dxe = (A2(F_ETA, i, j) - A2(F_ETA, im, j)) / DXFC(i, j);
-        REAL dye = (j == 1) ? 0 : (A2(F_ETA, i, j) - A2(F_ETA, i, j - 1)) / DYCF(i, j);
-        /* static column depth at the face: min of the two columns (0 next to land: no pressure force, and G.U is 0) */
-        REAL Un = A2(F_BU, i, j) + dtau * (-m->g * H2(Hfc, i, j) * dxe + A2(F_GBU, i, j));
-        REAL Vn = A2(F_BV, i, j) + dtau * (-m->g * H2(Hcf, i, j) * dye + A2(F_GBV, i, j));
         A2(F_ETAB, i, j) += wgt * A2(F_ETA, i, j);
-        A2(F_UB, i, j) += wgt * Un;
-        A2(F_VB, i, j) += wgt * Vn;
-        A2(F_BU, i, j) = Un;
-        A2(F_BV, i, j) = Vn;
+        A2(F_UB, i, j) += wgt * A2(F_BU, i, j);
+        A2(F_VB, i, j) += wgt * A2(F_BV, i, j);
       }
   }
   for (int j = 1; j <= Ny; j++)

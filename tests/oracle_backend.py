@@ -187,7 +187,8 @@ class OracleBackend:
 
     def set_option(self, name, value):
         """The restatement choices the library exposes as options (same names); its schedule options mean nothing here."""
-        fn = {"catke_stale_e_halos": "set_catke_stale_e_halos"}.get(name)
+        fn = {"catke_stale_e_halos": "set_catke_stale_e_halos", "substep_order": "set_substep_order",
+              "fold_pivot_slaved": "set_fold_pivot_slaved"}.get(name)
         if fn is None:
             raise KeyError(f"the oracle has no option {name!r}")
         f = self._fn(fn)

@@ -637,3 +637,31 @@ def test_w_on_the_fly_beside_the_sweeping_corrector(grid_type, shape, float_type
     if "islands" not in grid_type:
         for m in (a, b):
             assert np.abs(m.backend.get_field("S", False) - 35.0).max() < 50 * eps * 35.0
+
+
+@pytest.mark.parametrize("float_type,tol", [("Float32", SQRT_EPS32), ("Float64", 1e-9)])
+@pytest.mark.parametrize("grid_type", ["simple_lat_lon", "gaussian_islands_lat_lon"])
+def test_substep_order_option_matches_the_oracle(grid_type, float_type, tol):
+    """Option substep_order = 1 (U, V from the old eta, then eta from the new U, V -- the other order of the two halves of a
+    split-explicit substep) in the library and in the oracle: same criterion as the default order.  And the option
+    does change the answer (the default is untouched: every other test runs on it)."""
+    r, v = make_pair(64, 40, 8, dt=600.0, float_type=float_type, grid_type=grid_type)
+    for m in (r, v):
+        m.backend.set_option("substep_order", 1)
+    gb.set_baroclinic_instability(v)
+    set_noisy_velocities(v, 1e-2)
+    gb.sync_states(r, v)
+    for m in (r, v):
+        gb.first_time_step(m)
+        gb.loop(m, 5)
+    assert_states_close(r, v, state_rtol=tol, tendency_rtol=tol, label=f"substep_order = 1, {grid_type}")
+    d, _ = make_pair(64, 40, 8, dt=600.0, float_type=float_type, grid_type=grid_type)
+    gb.sync_states(d, v)      # (any state would do: one step from it in the default order)
+    e = gb.baroclinic_instability_model(gb.GPU(float_type=float_type), 64, 40, 8, dt=600.0, grid_type=grid_type,
+                                        options=dict(substep_order=1))
+    gb.sync_states(e, v)
+    for m in (d, e):
+        gb.first_time_step(m)
+    assert rel(d.free_surface.eta.interior, e.free_surface.eta.interior) > 1e-5
+    with pytest.raises(gb.GB25Error):
+        gb.baroclinic_instability_model(gb.GPU(), 48, 24, 6, dt=600.0, grid_type="gaussian_islands", options=dict(substep_order=1))

@@ -295,3 +295,25 @@ def test_a_folded_grid_too_short_for_its_sub_cycle_is_refused():
     gb.set_baroclinic_instability(m)
     gb.first_time_step(m)
     assert np.isfinite(m.free_surface.eta.interior).all()
+
+
+@pytest.mark.parametrize("float_type,tol", [("Float32", 3.4527e-4), ("Float64", 1e-9)])
+def test_fold_pivot_slaved_option_matches_the_oracle(float_type, tol):
+    """Option fold_pivot_slaved (the later upstream fix as recalled: every fold fill overwrites the eastern half of the pivot
+    row with the image of the western half) in the library and in the oracle; afterwards the two halves are exact images."""
+    from helpers import assert_states_close, make_pair, set_noisy_velocities
+    r, v = make_pair(48, 24, 6, dt=600.0, float_type=float_type, grid_type="gaussian_islands")
+    for m in (r, v):
+        m.backend.set_option("fold_pivot_slaved", 1)
+    gb.set_baroclinic_instability(v)
+    set_noisy_velocities(v, 1e-3)          # (noise: the two copies of the pivot row would drift apart without the option)
+    gb.sync_states(r, v)
+    for m in (r, v):
+        gb.first_time_step(m)
+        gb.loop(m, 4)
+    assert_states_close(r, v, state_rtol=tol, tendency_rtol=tol, label="fold_pivot_slaved")
+    r.backend.fill_halo_regions()
+    T, u = r.backend.get_field("T", False), r.backend.get_field("u", False)
+    Nx = T.shape[0]
+    assert np.array_equal(T[Nx // 2:, -1], T[:Nx // 2, -1][::-1])
+    assert np.array_equal(u[Nx // 2 + 1:, -1], -u[1:Nx // 2, -1][::-1])

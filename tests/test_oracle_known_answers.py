@@ -296,3 +296,28 @@ def test_top_flux_boundary_conditions():
     gb.set_top_flux(m, T=None, u=None)
     gb.update_state(m)
     assert np.abs(m.timestepper.Gn.T.interior[:, :, -1] - 0.0).max() < 1e-12    # only advection of the tiny state left
+
+
+def test_substep_order_is_a_second_order_difference():
+    """Option substep_order (the order of the two halves of a forward-backward substep changed between upstream
+    releases; a Julia dump decides): 0 = eta from the old U, V, then U, V from the new eta; 1 = U, V first.  Both are the same
+    forward-backward scheme started half a substep apart: the barotropic gravity wave keeps its speed, and the two answers differ
+    by O(dtau) of the signal, not more."""
+    import gb25_amd as gb
+    from helpers import make_oracle, set_noisy_velocities
+    out = []
+    for order in (0, 1):
+        m = make_oracle(48, 32, 6, 600.0)
+        m.backend.set_option("substep_order", order)
+        gb.set_baroclinic_instability(m)
+        set_noisy_velocities(m, 1e-2)
+        Nx, Ny, _ = m.grid.size
+        x, y = np.meshgrid(np.arange(Nx), np.arange(Ny), indexing="ij")
+        m.set(eta=0.1 * np.exp(-((x - 24.0) ** 2 + (y - 16.0) ** 2) / 18.0))
+        gb.first_time_step(m)
+        gb.loop(m, 3)
+        out.append({n: m.backend.get_field(n, False).copy() for n in ("eta", "U", "V", "u")})
+    for n in out[0]:
+        a, b = out[0][n], out[1][n]
+        d = np.linalg.norm(a - b) / np.linalg.norm(a)
+        assert 1e-6 < d < 0.2, (n, d)            # different, but the same wave

