@@ -359,6 +359,9 @@ def main():
             "config": {"workload": f"baroclinic_instability_model {gNx}x{Ny}x{Nz} {GRID_NAMES[args.grid_type]}, "
                                    f"halo 8, SplitExplicit(30), {'WENO5 momentum / WENO7 tracers' if args.data_free else 'WENO5'}, TEOS10, dt={args.dt:g}s"
                                    + (f", closure {args.closure}" if args.closure else "")
+                                   # (the library's built-in islands / tripolar generator: the reference's mtn1 / mtn2 at ITS grid's
+                                   # coordinates come through gb25_set_bottom_height / gb25_set_curvilinear_grid from a Julia host)
+                                   + (", STAND-IN grid and bathymetry (built-in generator)" if args.grid_type != "simple_lat_lon" else "")
                                    + (", data-free forcing (similarity-theory fluxes every step)" if args.data_free else ""),
                        "grid": [gNx, Ny, Nz], "cells_per_gpu": cells, "local_columns": locNx, "local_rows": locNy,
                        "parallelism": ((f"{Rx} x {Ry} mesh (Partition(Rx, Ry, 1))" if Ry > 1 else f"x-slab x{world}")
