@@ -28,11 +28,16 @@ const FIELD = (u = 0, v = 1, w = 2, T = 3, S = 4, pHY = 5,
                Gn_u = 6, Gn_v = 7, Gn_T = 8, Gn_S = 9, Gm_u = 10, Gm_v = 11, Gm_T = 12, Gm_S = 13,
                eta = 14, U = 15, V = 16, eta_bar = 17, U_bar = 18, V_bar = 19, Gn_U = 20, Gn_V = 21,
                # closure = CATKEVerticalDiffusivity() (exist after set_closure_catke!)
-               e = 22, Gn_e = 23, Gm_e = 24, κu = 25, κc = 26, κe = 27, Le = 28, Jb = 29)
+               e = 22, Gn_e = 23, Gm_e = 24, κu = 25, κc = 26, κe = 27, Le = 28, Jb = 29,
+               # diffusivity_fields.previous_velocities (u, v at the previous compute_diffusivities!)
+               previous_u = 30, previous_v = 31)
 # gb25_option
 const OPTION = (kernels = 0, ab2_lookahead = 1, subcycle_lookahead = 2, subcycle_block = 3, fill_fused = 4,
                 two_streams = 5, store_pressure = 6, split_tendencies = 7, pressure_precision = 8,
-                immersed_kernels = 9, fold_fills = 10, lazy_corrector = 11, momentum_chunk_levels = 12, tracer_chunk_levels = 13)
+                immersed_kernels = 9, fold_fills = 10, lazy_corrector = 11, momentum_chunk_levels = 12, tracer_chunk_levels = 13,
+                tracers_first = 14, w_on_the_fly = 15, sub_stream_priority = 16, subcycle_whole = 17, early_strips = 18,
+                # restatement choices a Julia dump settles (DESIGN.md section 0), and two run-time knobs
+                catke_stale_e_halos = 19, comm_timeout_seconds = 20, roctx_ranges = 21, substep_order = 22, fold_pivot_slaved = 23)
 
 # mirror of gb25_config; isbits, passed by reference
 Base.@kwdef mutable struct Config
@@ -187,6 +192,7 @@ struct CatkeParameters
     Chi::NTuple{4, Float64}; Clo::NTuple{4, Float64}; Cun::NTuple{4, Float64}; Cc::NTuple{4, Float64}; Ce::NTuple{4, Float64}
     CWu::Float64; CWw::Float64
     minimum_tke::Float64; minimum_convective_buoyancy_flux::Float64; negative_tke_damping_time_scale::Float64
+    CWeps::Float64      # bottom TKE flux coefficient (CATKEEquation's Cᵂϵ)
 end
 function default_catke_parameters(lib)
     p = Ref{CatkeParameters}()
