@@ -23,6 +23,7 @@ struct CatkePar {
   real Cs, Cb, Csp, CRid, CRi0;
   real Chi[4], Clo[4], Cun[4], Cc[4], Ce[4];   // psi = u, c, e, D
   real CWu, CWw, emin, Jbmin, tau_neg, CWeps;
+  real rCRid, rtau_neg;      // reciprocals (host)
 };
 // -d rho / d Theta and d rho / d S_A from a folded level table (teos10_level's layout), differentiated term by term
 __device__ __forceinline__ void teos10_level_sens(const double* __restrict__ c, double s, double t, double& a, double& b) {
@@ -70,6 +71,7 @@ struct CatkeColumn {
   int kc0;                   // first active level
   int NUw, NUe, NVs, NVn;    // first level from which the u faces i, i+1 / the v faces j, j+1 are active nodes
   real zt, zbot, Hcol, jb;
+  real rjb;                  // 1 / (J^b + J^b_min): the convective lengths divide by it four times per face
 };
 template <bool IMM>
 __device__ __forceinline__ CatkeColumn catke_column(const Grid& g, int i, int j, int o2, real jb) {
@@ -86,6 +88,7 @@ __device__ __forceinline__ CatkeColumn catke_column(const Grid& g, int i, int j,
   q.zbot = zb;
   q.Hcol = q.zt - zb;
   q.jb = jb;
+  q.rjb = real(0.);          // (the caller sets it: it needs the closure's parameters)
   return q;
 }
 struct CatkeLengths { real ku, kc, ke, convD; };
@@ -107,15 +110,18 @@ __device__ __forceinline__ CatkeLengths catke_face_eval(const CatkePar& c, const
   const bool convecting = jb > jbe && N2 < real(0.), entraining = jb > jbe && N2 > real(0.) && N2above < real(0.);
   real lconv[4] = {real(0.), real(0.), real(0.), real(0.)};
   if (convecting || entraining) {
-    const real Sp = sqrt(S2) * ws2 / (jb + jbe), esp = real(1.) - c.Csp * Sp;
+    // (one reciprocal per column and one per face instead of five divisions: the f32 division is a ten-instruction sequence and
+    // this function was half of the column kernels' 490 instructions per level)
+    const real Sp = sqrt(S2) * ws2 * q.rjb, esp = real(1.) - c.Csp * Sp;
+    const real scale = convecting ? ws3 * q.rjb : jb / (ws * N2 + jbe);
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      real l = convecting ? c.Cc[p] * ws3 / (jb + jbe) : c.Ce[p] * jb / (ws * N2 + jbe);
+      real l = (convecting ? c.Cc[p] : c.Ce[p]) * scale;
       l *= esp;
       lconv[p] = l > real(0.) ? l : real(0.);
     }
   }
-  real tstep = (Ri - c.CRi0) / c.CRid;
+  real tstep = (Ri - c.CRi0) * c.rCRid;
   tstep = tstep < real(0.) ? real(0.) : (tstep > real(1.) ? real(1.) : tstep);
   real lpsi[3];
 #pragma unroll
@@ -144,7 +150,7 @@ __device__ __forceinline__ real catke_dissipation_length(const CatkePar& c, cons
     const real lN = sqrt(ef) / sqrt(N2);
     ls = lN < ls ? lN : ls;
   }
-  real tstep = (Ri - c.CRi0) / c.CRid;
+  real tstep = (Ri - c.CRi0) * c.rCRid;
   tstep = tstep < real(0.) ? real(0.) : (tstep > real(1.) ? real(1.) : tstep);
   const real sg = Ri < real(0.) ? c.Cun[3] : c.Clo[3] + (c.Chi[3] - c.Clo[3]) * tstep;
   ls = ls / sg;
@@ -158,17 +164,20 @@ __device__ __forceinline__ CatkeShear catke_dz_velocities(const Grid& g, const C
                                                           const real* __restrict__ v, int oc, int ov, int kf) {
   // oc, ov: offsets of cell (i, j, kf) in a cell-shaped / v-shaped array
   const real rdz = g.rdzf[kf];
+  // (every load unconditional -- the masks are per lane, and a load inside a divergent branch is issued behind it -- then selects)
+  const real a = (u[oc] - u[oc - g.pl_c]) * rdz, b = (u[oc + 1] - u[oc + 1 - g.pl_c]) * rdz;
+  const real c = (v[ov] - v[ov - g.pl_v]) * rdz, e = (v[ov + g.sx] - v[ov + g.sx - g.pl_v]) * rdz;
   CatkeShear d;
-  d.uw = kf > q.NUw ? (u[oc] - u[oc - g.pl_c]) * rdz : real(0.);
-  d.ue = kf > q.NUe ? (u[oc + 1] - u[oc + 1 - g.pl_c]) * rdz : real(0.);
-  d.vs = kf > q.NVs ? (v[ov] - v[ov - g.pl_v]) * rdz : real(0.);
-  d.vn = kf > q.NVn ? (v[ov + g.sx] - v[ov + g.sx - g.pl_v]) * rdz : real(0.);
+  d.uw = kf > q.NUw ? a : real(0.);
+  d.ue = kf > q.NUe ? b : real(0.);
+  d.vs = kf > q.NVs ? c : real(0.);
+  d.vn = kf > q.NVn ? e : real(0.);
   return d;
 }
 // time_step_catke_equation!, first half (see the header).  One thread per own column, marching up; e is updated in place (a
 // column reads nobody else's e, and the old e of a cell is last needed by the face above it, evaluated before the cell).
 template <bool IMM>
-__global__ __launch_bounds__(256) void k_catke_tke_step(Grid g, CatkePar c, real dt, real C1, real C2,
+__global__ __launch_bounds__(256, 6) void k_catke_tke_step(Grid g, CatkePar c, real dt, real C1, real C2,
                                                         const real* __restrict__ u, const real* __restrict__ v,
                                                         const real* __restrict__ um, const real* __restrict__ vm,
                                                         real* __restrict__ e, const real* __restrict__ n2,
@@ -179,7 +188,8 @@ __global__ __launch_bounds__(256) void k_catke_tke_step(Grid g, CatkePar c, real
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= g.Nx || j >= g.Ny) return;
   const int Nz = g.Nz, o2 = i2(g, i, j), pc = g.pl_c, pv = g.pl_v;
-  const CatkeColumn q = catke_column<IMM>(g, i, j, o2, Jb[o2]);
+  CatkeColumn q = catke_column<IMM>(g, i, j, o2, Jb[o2]);
+  q.rjb = real(1.) / (q.jb + c.Jbmin);
   const bool xw = g.x_periodic && i < g.H, xe = g.x_periodic && i >= g.Nx - g.H;
   const bool ys = j == 0 && g.jws == 0, yn = j == g.Ny - 1 && (g.jwn == g.Ny || g.cv.north_fold);
   auto put = [&](real* a, int o, real x) {   // the cell and the halo cells its fill derives from it (a14)
@@ -210,28 +220,31 @@ __global__ __launch_bounds__(256) void k_catke_tke_step(Grid g, CatkePar c, real
       const real fw = (nw * dm.uw * dzf * d.uw) + (nw * d.uw * dzf * d.uw), fe = (ne * dm.ue * dzf * d.ue) + (ne * d.ue * dzf * d.ue);
       const real fs = (ns * dm.vs * dzf * d.vs) + (ns * d.vs * dzf * d.vs), fn = (nn * dm.vn * dzf * d.vn) + (nn * d.vn * dzf * d.vn);
       PFhi = (fw + fe) / real(2.) + (fs + fn) / real(2.);
-      if (kf > q.kc0) {
-        N2hi = n2[of];
-        const real el = ecur > c.emin ? ecur : c.emin, eh = enext > c.emin ? enext : c.emin;
-        const CatkeLengths L = catke_face_eval(c, q, el, eh, N2hi, n2[of + pc], S2hi, zf);
-        kehi = L.ke;
-        cDhi = L.convD;
-        wbhi = -(KC[of] * N2hi);
-      }
+      // (loads and the evaluation for every lane, the mask of the solid applied to the results: N^2 is stored as zero on the
+      // faces that touch the solid, so the loaded values are harmless there)
+      const real n2f = n2[of], n2a = n2[of + pc], kcf = KC[of];
+      const real el = ecur > c.emin ? ecur : c.emin, eh = enext > c.emin ? enext : c.emin;
+      const CatkeLengths L = catke_face_eval(c, q, el, eh, n2f, n2a, S2hi, zf);
+      const bool open = kf > q.kc0;
+      N2hi = open ? n2f : real(0.);
+      kehi = open ? L.ke : real(0.);
+      cDhi = open ? L.convD : real(0.);
+      wbhi = open ? -(kcf * n2f) : real(0.);
     }
     KE[of] = kehi;
     real Lk = real(0.);
+    const real gn = Gn[o], gm = Gm[o];
     if (k >= q.kc0) {
       const real ek = ecur, wb = (wblo + wbhi) / real(2.);
       const real wbm = wb < real(0.) ? wb : real(0.), wbp = wb > real(0.) ? wb : real(0.);
       const real lD = catke_dissipation_length(c, q, ek, g.zc[k], N2lo, N2hi, S2lo, S2hi, cDlo, cDhi);
-      const real omega = ek < real(0.) ? real(1.) / c.tau_neg : sqrt(rabs(ek)) / lD;
+      const real omega = ek < real(0.) ? c.rtau_neg : sqrt(rabs(ek)) / lD;
       const real ep = ek > real(0.) ? ek : real(0.);
-      const real divJ = k == q.kc0 ? -(c.CWeps * sqrt(ep) / g.dzc[k]) : real(0.);      // (the bottom cell of the column)
+      const real divJ = k == q.kc0 ? -(c.CWeps * sqrt(ep) * g.rdzc[k]) : real(0.);      // (the bottom cell of the column)
       Lk = (ek > c.emin ? wbm / ek : real(0.)) - omega + divJ;
-      const real P = ((PFlo + PFhi) / real(2.)) / (real(2.) * g.dzc[k]);
-      const real total = Gn[o] + (P + wbp);
-      e[o] = ek + dt * (C1 * total - C2 * Gm[o]);
+      const real P = ((PFlo + PFhi) / real(2.)) * (real(0.5) * g.rdzc[k]);
+      const real total = gn + (P + wbp);
+      e[o] = ek + dt * (C1 * total - C2 * gm);
       Gm[o] = total;
     }
     put(Le, o, Lk);
@@ -255,7 +268,8 @@ __global__ void k_catke_surface_flux(Grid g, CatkePar c, real dt_since, const re
   if (i >= g.Nx || j >= g.Ny) return;
   const int Nz = g.Nz, o2 = i2(g, i, j), k = Nz - 1, o = ic(g, i, j, k), ov = iv(g, i, j, k);
   const real J = Jb[o2];
-  const CatkeColumn q = catke_column<IMM>(g, i, j, o2, J);
+  CatkeColumn q = catke_column<IMM>(g, i, j, o2, J);
+  q.rjb = real(1.) / (q.jb + c.Jbmin);
   real Jnew = real(0.), source = real(0.);
   if (q.kc0 < Nz) {
     double Js = 0.0;
@@ -310,7 +324,7 @@ __global__ void k_catke_add_top_source(Grid g, const real* __restrict__ src, rea
 // compute_CATKE_diffusivities!: kappa_u, kappa_c, kappa_e on the faces 1 .. Nz-1 (zero on the bottom and top faces and where
 // the face touches the solid).
 template <bool IMM>
-__global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c, const real* __restrict__ u,
+__global__ __launch_bounds__(256, 6) void k_catke_diffusivities(Grid g, CatkePar c, const real* __restrict__ u,
                                                              const real* __restrict__ v, const real* __restrict__ e,
                                                              const real* __restrict__ n2, const real* __restrict__ Jb,
                                                              real* __restrict__ KU, real* __restrict__ KC,
@@ -323,7 +337,8 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
   if (i >= i_hi || j >= j_hi) return;
   const bool own = i >= 0 && i < g.Nx && j >= 0 && j < g.Ny;
   const int Nz = g.Nz, o2 = i2(g, i, j), pc = g.pl_c, pv = g.pl_v;
-  const CatkeColumn q = catke_column<IMM>(g, i, j, o2, Jb[o2]);
+  CatkeColumn q = catke_column<IMM>(g, i, j, o2, Jb[o2]);
+  q.rjb = real(1.) / (q.jb + c.Jbmin);
   const bool xw = own && g.x_periodic && i < g.H, xe = own && g.x_periodic && i >= g.Nx - g.H;
   // (the y layers exist next to walls only)
   const bool ys = own && j == 0 && g.jws == 0, yn = own && j == g.Ny - 1 && j_hi == g.Ny && (g.jwn == g.Ny || g.cv.north_fold);
@@ -343,12 +358,11 @@ __global__ __launch_bounds__(256) void k_catke_diffusivities(Grid g, CatkePar c,
     real enext = real(0.);
     if (kf < Nz) {
       enext = e[of];
-      if (kf > q.kc0) {
-        const CatkeShear d = catke_dz_velocities(g, q, u, v, of, ovf, kf);
-        const real S2 = (d.uw * d.uw + d.ue * d.ue) / real(2.) + (d.vs * d.vs + d.vn * d.vn) / real(2.);
-        const real el = ecur > c.emin ? ecur : c.emin, eh = enext > c.emin ? enext : c.emin;
-        L = catke_face_eval(c, q, el, eh, n2[of], n2[of + pc], S2, zf);
-      }
+      const CatkeShear d = catke_dz_velocities(g, q, u, v, of, ovf, kf);
+      const real S2 = (d.uw * d.uw + d.ue * d.ue) / real(2.) + (d.vs * d.vs + d.vn * d.vn) / real(2.);
+      const real el = ecur > c.emin ? ecur : c.emin, eh = enext > c.emin ? enext : c.emin;
+      const CatkeLengths Lf = catke_face_eval(c, q, el, eh, n2[of], n2[of + pc], S2, zf);   // (for every lane; the solid's mask below)
+      if (kf > q.kc0) L = Lf;
     }
     put(KU, of, L.ku); put(KC, of, L.kc); put(KE, of, L.ke);
     ecur = enext;

@@ -1750,6 +1750,8 @@ CatkePar catke_parameters(const gb25_model* m) {
   c.CWu = (real)p.CWu; c.CWw = (real)p.CWw; c.emin = (real)p.minimum_tke; c.Jbmin = (real)p.minimum_convective_buoyancy_flux;
   c.tau_neg = (real)p.negative_tke_damping_time_scale;
   c.CWeps = (real)p.CWeps;
+  c.rCRid = (real)(1.0 / p.CRid);
+  c.rtau_neg = (real)(1.0 / p.negative_tke_damping_time_scale);
   return c;
 }
 // The extended range on which a rank of a decomposition COMPUTES N^2 and the diffusivities: the first halo column on either
@@ -2322,7 +2324,15 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   // run in order -- a rocprof trace of eight slabs in one process, 25 streams, shows the exchange stream and the main
   // stream taking turns.  A slab has three: own, side, and the exchange stream of its context; the stream of
   // SUBCYCLE_LOOKAHEAD = 2 is created on demand.)
+#ifdef GB25_SIDE_PRIO
+  {   // (tools/build_variant.sh experiment: the side stream -- the pressure branch -- at the LOWEST / main at the highest priority)
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(hipStreamCreateWithPriority(&m->side_stream, hipStreamNonBlocking, GB25_SIDE_PRIO > 0 ? least : greatest));
+  }
+#else
   HIPCHK(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+#endif
   HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->ev_baro, hipEventDisableTiming));

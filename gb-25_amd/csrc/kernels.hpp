@@ -421,15 +421,17 @@ constexpr int PR = 4;   // rows per thread of the full-range launch
 // them on the lat-lon grid take k_compute_p_tile below).
 // WRITE_P = false: only the two differences the momentum kernel consumes are stored; pHY' itself is a diagnostic
 // that the host side then materialises on demand (gb25_api.hip, phy_stale).
+#ifndef GB25_P_MINW
+#define GB25_P_MINW 1   // (tools/build_variant.sh: waves per SIMD the register allocator of the pressure kernel is held to)
+#endif
 template <int PR_, bool WRITE_P>
-__global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restrict__ T, const real* __restrict__ S,
+__global__ __launch_bounds__(256, GB25_P_MINW) void k_compute_p(Grid g, const real* __restrict__ T, const real* __restrict__ S,
                                                    real* __restrict__ p, real* __restrict__ dpx,
                                                    real* __restrict__ dpy, int i_first, int i_last, int i_first_b,
                                                    int i_last_b, int tiles_a, real* __restrict__ n2, int j_first, int j_last) {
   // rows [j_first, j_last] are written (the whole extended range: -H+1 .. Ny+H-2; a rank of a 2-D decomposition redoes row 0
   // -- whose y difference reads the southern neighbour's row -- once that row has arrived)
-  // n2 (CATKE, else null): N^2 = db/dz on the faces between the cells, from the very buoyancies of the integral and
-  // differenced in fp64 like the pressure, stored at the index of the cell above the face (k_catke_buoyancy's layout).
+  // (n2: unused since round 4 -- CATKE's N^2 is SeawaterBuoyancy's dz_b, alpha dzT - beta dzS: k_catke_n2)
   // an optional second column range [i_first_b, i_last_b] takes the tiles from tiles_a on (both strips of a slab in
   // one launch)
   const int lane = threadIdx.x;
@@ -459,13 +461,11 @@ __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restric
   for (int k = Nz - 1; k >= 0; k--) {
     const double* c = g.eos + 28 * k;
     const double dz = g.dzf_d[k + 1];
-    double dbz[PR_ + 1];
 #pragma unroll
     for (int r = 0; r <= PR_; r++) {
       o[r] -= g.pl_c;
       double bk = gr * teos10_level(c, sqrt_pos(((double)S[o[r]] + 32.0) * sc), (double)T[o[r]] * 0.025);
       pk[r] = pk[r] - 0.5 * (bk + bup[r]) * dz;
-      dbz[r] = (bup[r] - bk) / dz;
       bup[r] = bk;
     }
 #pragma unroll
@@ -476,7 +476,6 @@ __global__ __launch_bounds__(256) void k_compute_p(Grid g, const real* __restric
         if (WRITE_P) p[o[r]] = (real)pk[r];
         dpx[o[r]] = (real)(pk[r] - pw);
         dpy[o[r]] = (real)(pk[r] - pk[r - 1]);
-        if (n2 != nullptr && k < Nz - 1) n2[o[r] + g.pl_c] = (real)dbz[r];
       }
     }
   }
@@ -514,14 +513,12 @@ __global__ __launch_bounds__(256) void k_compute_p_tile(Grid g, const real* __re
     o -= g.pl_c;
     const double bk = gr * teos10_level(c, sqrt_pos(((double)S[o] + 32.0) * sc), (double)T[o] * 0.025);
     pk = pk - 0.5 * (bk + bup) * dz;
-    const double dbz = (bup - bk) / dz;
     bup = bk;
     const double pw = __shfl_up(pk, 1), ps = __shfl_up(pk, 16);
     if (writes) {
       if (WRITE_P) p[o] = (real)pk;
       dpx[o] = (real)(pk - pw);
       dpy[o] = (real)(pk - ps);
-      if (n2 != nullptr && k < Nz - 1) n2[o + g.pl_c] = (real)dbz;
     }
   }
 }
