@@ -1988,7 +1988,9 @@ inline bool lazy_corrector_ok(const gb25_model* m) {
 // own columns as a by-product, k_w_bases turns the look-ahead's chunk integrals + du, dv into w at the chunk boundaries, and the
 // WFLY instances of the two tendency kernels carry w up their chunks.  Single domain, between the steps of one gb25_loop call.
 inline bool wfly_sweep_ok(const gb25_model* m) {
-  return m->w_fly && !m->slab && !m->coupled && m->bottom_drag == 0 && m->tracer_order == 5 && m->two_streams && m->kernel_gen >= 2 &&
+  // (like the corrector inside its consumers it rides on the sub-cycle look-ahead -- on by default from 8 M cells on: small models
+  // keep the stand-alone w, bit for bit what their decompositions compute)
+  return m->w_fly && m->baro_ahead != 0 && !m->slab && !m->coupled && m->bottom_drag == 0 && m->tracer_order == 5 && m->two_streams && m->kernel_gen >= 2 &&
          m->ab2_ahead == 1 && !m->ptr_exposed && m->nu == 0 && m->kappa == 0 && !m->catke &&
          std::max(1, m->g.Nz / m->trc_chunk_levels) == mom_kchunks(m);
 }

@@ -36,7 +36,8 @@ def run(P, steps):
 
 
 def run_single(steps):
-    m = gb.baroclinic_instability_model(gb.GPU(), NX, NY, NZ, dt=DT, grid_type="gaussian_islands")
+    # (bit for bit against the slabs: w from the stand-alone kernel, as they compute it -- w on the fly changes the last bits)
+    m = gb.baroclinic_instability_model(gb.GPU(), NX, NY, NZ, dt=DT, grid_type="gaussian_islands", options=dict(w_on_the_fly=0))
     gb.set_baroclinic_instability(m)
     gb.first_time_step(m)
     gb.loop(m, steps)
