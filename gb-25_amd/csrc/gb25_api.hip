@@ -187,6 +187,12 @@ struct gb25_model {
   int w_fly = 1;
   bool w_stale = false, w_fly_now = false;
   bool corr_out = false;             // corrector_impl: the sweep also writes du, dv of the own columns into corr[0], corr[1]
+  // The corrector through the tracer kernel (round 4; grids with a bottom / curvilinear / folded, single domain): du, dv as 2-D
+  // fields; the tracer kernel -- first in the step, and every u, v is some cell's west / south face -- adds them as it loads and
+  // writes the corrected velocities into this second pair of arrays, which then BECOME u, v (pointer exchange) and get their halo
+  // cells from the ordinary fill; the momentum kernel reads corrected velocities like any other.  No sweep over u and v.
+  Field uvc[2];
+  bool uv_corr_pending = false;      // this step's tracer kernel writes the corrected velocities
   // levels a block of the momentum / tracer tendency kernel marches through (options MOMENTUM_CHUNK_LEVELS,
   // TRACER_CHUNK_LEVELS): fewer, longer chunks amortise the start-up of the vertical windows, more chunks fill the chip.
   // The momentum chunking is also the association of every column integral of u, v (all their producers share it).
@@ -1251,6 +1257,9 @@ gb25_status tracers_impl(gb25_model* m) {
                 : (m->uv_lazy && ahead && fold) ? k_tracer_tendencies_v5<TWL, true, false, true, false, true>
                 : (m->uv_lazy && ahead && m->w_fly_now) ? k_tracer_tendencies_v5<TWL, true, false, false, false, true, 5, true>   // (slab)
                 : (m->uv_lazy && ahead) ? k_tracer_tendencies_v5<TWL, true, false, false, false, true>
+                // (the corrector through the tracer kernel: adds du, dv as it loads, writes the corrected u, v; w on the fly)
+                : (ahead && m->w_fly_now && m->uv_corr_pending) ? (g.cv.on ? k_tracer_tendencies_v5<TW, true, true, false, true, true, 5, true, true>
+                                                                            : k_tracer_tendencies_v5<TW, true, true, false, false, true, 5, true, true>)
                 // (w on the fly beside the corrector's sweep)
                 : (ahead && m->w_fly_now) ? (g.cv.on ? (fold ? k_tracer_tendencies_v5<TW, true, true, true, true, false, 5, true> : k_tracer_tendencies_v5<TW, true, true, false, true, false, 5, true>)
                                              : m->immersed ? (fold ? k_tracer_tendencies_v5<TW, true, true, true, false, false, 5, true> : k_tracer_tendencies_v5<TW, true, true, false, false, false, 5, true>)
@@ -1261,7 +1270,12 @@ gb25_status tracers_impl(gb25_model* m) {
                                      : k_tracer_tendencies_v5<TW, false, true, false>)
                             : (ahead ? (fold ? k_tracer_tendencies_v5<TW, true, false, true> : k_tracer_tendencies_v5<TW, true, false, false>)
                                      : k_tracer_tendencies_v5<TW, false, false, false>);
-    m->ahead_ts_folded = fold;
+    if (m->uv_corr_pending) {
+      if (!(ahead && m->w_fly_now && m->tracer_order == 5 && m->uvc[0].d)) return fail(m, GB25_ERR_STATE, "internal: no tracer kernel instance writes the corrected velocities here");
+      nx.uc = m->uvc[0].d;
+      nx.vc = m->uvc[1].d;
+    }
+    m->ahead_ts_folded = fold && !m->uv_corr_pending;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64, 4), 0, m->stream, g, m->f[GB25_U].d,
                        m->f[GB25_V].d, m->f[GB25_W].d, m->f[GB25_T].d, m->f[GB25_S].d, m->f[GB25_GN_T].d,
                        m->f[GB25_GN_S].d, nbx, kchunks, nb, nx, lz);
@@ -1269,6 +1283,13 @@ gb25_status tracers_impl(gb25_model* m) {
     m->ahead_valid = ahead;
     m->ahead_dt = nx.dt;
     m->ahead_chi = (real)m->cfg.chi;
+    if (m->uv_corr_pending) {
+      // the arrays the kernel wrote ARE u, v from here on (the uncorrected ones become the scratch pair of the next step), and
+      // their halo cells come from the ordinary fill -- y / z layers, the rows beyond a zipper fold, the periodic x copy
+      m->uv_corr_pending = false;
+      for (int q = 0; q < 2; q++) std::swap(m->f[GB25_U + q].d, m->uvc[q].d);
+      if (gb25_status s = fill_halos_impl(m, true, false, 1, 1)) return s;
+    }
     return GB25_OK;
   }
   m->ahead_valid = false;   // only the packed kernel looks ahead
@@ -1987,12 +2008,18 @@ inline bool lazy_corrector_ok(const gb25_model* m) {
 // a GridFittedBottom, the curvilinear grids, the zipper fold -- still drop the k_compute_w launch: the sweep leaves du, dv of the
 // own columns as a by-product, k_w_bases turns the look-ahead's chunk integrals + du, dv into w at the chunk boundaries, and the
 // WFLY instances of the two tendency kernels carry w up their chunks.  Single domain, between the steps of one gb25_loop call.
+// ... and the sweep itself through the tracer kernel (above: uvc): everything wfly_sweep_ok asks for, the tracer kernel first
+inline bool lazy_through_tracers_ok(const gb25_model* m);
 inline bool wfly_sweep_ok(const gb25_model* m) {
   // (like the corrector inside its consumers it rides on the sub-cycle look-ahead -- on by default from 8 M cells on: small models
   // keep the stand-alone w, bit for bit what their decompositions compute)
   return m->w_fly && m->baro_ahead != 0 && !m->slab && !m->coupled && m->bottom_drag == 0 && m->tracer_order == 5 && m->two_streams && m->kernel_gen >= 2 &&
          m->ab2_ahead == 1 && !m->ptr_exposed && m->nu == 0 && m->kappa == 0 && !m->catke &&
          std::max(1, m->g.Nz / m->trc_chunk_levels) == mom_kchunks(m);
+}
+
+inline bool lazy_through_tracers_ok(const gb25_model* m) {
+  return m->lazy_corrector && wfly_sweep_ok(m) && (m->immersed || m->g.cv.on) && m->tracers_first != 0 && m->pressure_bits == 64;
 }
 
 // ... and a slab of an x decomposition or a rank of a 2-D one: the same kernels without the halo images (its halos come with the
@@ -2040,8 +2067,10 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
   // another step follows, no sweep over u and v at all -- a 2-D kernel leaves du, dv and w, the tendency kernels add them.
   const bool lazy = more && adopted && baro_adopted && m->complete_fills_needed == 0 && lazy_corrector_ok(m);
   // ... or the sweep stays and only w moves into the tendency kernels (the look-ahead's chunk integrals must be this step's)
-  const bool wfly_sweep = !lazy && more && adopted && m->complete_fills_needed == 0 && wfly_sweep_ok(m);
-  if (!lazy && (s = materialize_uv(m, !wfly_sweep))) return s;   // (the stand-alone kernels below expect corrected velocities)
+  // ... or the tracer kernel applies it and writes the corrected velocities (grids with a bottom, curvilinear, folded) ...
+  const bool lazy_t = !lazy && more && adopted && baro_adopted && m->complete_fills_needed == 0 && lazy_through_tracers_ok(m);
+  const bool wfly_sweep = !lazy && !lazy_t && more && adopted && m->complete_fills_needed == 0 && wfly_sweep_ok(m);
+  if (!lazy && (s = materialize_uv(m, !(wfly_sweep || lazy_t)))) return s;   // (the stand-alone kernels below expect corrected velocities)
   if ((s = ab2_velocities_impl(m, (real)dt, chi))) return s;
   Halo2 hG = halo2_G(m);
   // the sub-cycle reads G.U, G.V at interior points only (periodic wrap and walls are in the kernel): their halo
@@ -2099,7 +2128,7 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     const Grid& g = m->g;
     dim3 b(64, 4);
     Timed t(m, GB25_K_CORRECTOR);
-    hipLaunchKernelGGL(k_corrector_2d, grid2(g.Nx, g.Ny + 1, b), b, 0, main, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
+    hipLaunchKernelGGL(k_corrector_2d<false>, grid2(g.Nx, g.Ny + 1, b), b, 0, main, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
                        m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d,
                        0, g.Nx, INT_MAX, 0, 0, g.Ny + 1);
     LAUNCHCHK();
@@ -2113,6 +2142,42 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
       LAUNCHCHK();
       m->w_stale = true;
     }
+    for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);   // cache_previous_tendencies!
+    m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
+  } else if (lazy_t) {
+    const Grid& g = m->g;
+    dim3 b(64, 4);
+    Timed t(m, GB25_K_CORRECTOR);
+    for (int q = 0; q < 2; q++)
+      if (!m->uvc[q].d && (s = alloc_field(m, m->uvc[q], m->f[GB25_U + q].nx, m->f[GB25_U + q].ny, m->f[GB25_U + q].nz))) return s;
+    // du, dv on the own faces (rows of y faces: [0, Ny) on a folded grid, [0, Ny] below a wall) ...
+    hipLaunchKernelGGL(m->immersed ? k_corrector_2d<true> : k_corrector_2d<false>, grid2(g.Nx, g.Ny + (g.cv.north_fold ? 0 : 1), b), b, 0, main, g,
+                       m->f[GB25_BT_U].d, m->f[GB25_BT_V].d, m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d,
+                       m->corr[0].d, m->corr[1].d, 0, g.Nx, INT_MAX, 0, 0, g.Ny + (g.cv.north_fold ? 0 : 1));
+    LAUNCHCHK();
+    // ... and their halo cells as the fills derive them (the rows beyond a zipper fold: images with the sign of a vector component)
+    if (g.cv.north_fold) {
+      Halo2 hc{};
+      hc.p[0] = m->corr[0].d; hc.is_v[0] = 0; hc.xf[0] = 1; hc.neg[0] = 1;
+      hc.p[1] = m->corr[1].d; hc.is_v[1] = 1; hc.xf[1] = 0; hc.neg[1] = 1;
+      hc.n = 2;
+      if ((s = fill_halos_2d(m, hc))) return s;
+    }
+    m->colsum_valid = false;
+    m->w_fly_now = true;
+    {
+      const LazyCorr lc{m->corr[0].d, m->corr[1].d, nullptr, 0};
+      auto kb = g.cv.on ? k_w_bases<true, true> : (m->immersed ? k_w_bases<true, false> : k_w_bases<false, false>);
+      hipLaunchKernelGGL(kb, grid2(g.Nx + 4, g.Ny + 4, b), b, 0, main, g, m->uv_partials, mom_kchunks(m), g.sx * g.sy_v, lc,
+                         m->wbase, -2, g.Nx + 4, INT_MAX, 0);
+      LAUNCHCHK();
+    }
+    m->w_stale = true;
+    m->uv_corr_pending = true;
+    // (the two strips of halo cells of the uncorrected u, v the tracer kernel reads: k_uncorrected_edges)
+    hipLaunchKernelGGL(k_uncorrected_edges, dim3((std::max(g.Nx, g.Ny) + 255) / 256, g.Nz, g.cv.north_fold ? 3 : 2), dim3(256), 0, main, g,
+                       m->f[GB25_U].d, m->f[GB25_V].d);
+    LAUNCHCHK();
     for (int q = 0; q < 4; q++) std::swap(m->f[GB25_GN_U + q].d, m->f[GB25_GM_U + q].d);   // cache_previous_tendencies!
     m->ahead_valid = m->ahead_uv_valid = m->ahead_baro_valid = false;
   } else {
@@ -2134,11 +2199,13 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
   }
   {
     // u, v and eta, U, V -- whatever their last writers (the corrector, the sub-cycle's last launch) did not fill
-    const bool uv_fresh = lazy || (producers_fold(m) && m->composite && !complete);
+    // (lazy_t: u, v get their halo cells behind the tracer kernel, which writes their corrected interior: tracers_impl)
+    const bool uv_fresh = lazy || lazy_t || (producers_fold(m) && m->composite && !complete);
     const int which = (uv_fresh ? 0 : 1) | ((eta_halos_fresh && !complete) ? 0 : 2);
     if (which && (s = fill_halos_impl(m, true, false, which, 1))) return s;
   }
-  if (!((lazy || wfly_sweep) && m->w_fly_now) && (s = compute_w_impl(m))) return s;
+  if (!((lazy || wfly_sweep || lazy_t) && m->w_fly_now) && (s = compute_w_impl(m))) return s;
+  if (lazy_t && !m->tracers_first) return fail(m, GB25_ERR_STATE, "internal: the corrector through the tracer kernel needs the tracer kernel first");
   // ---- join: the tendencies need w, u, v and T, S (the tracers) / the pressure differences (the momentum)
   const bool tracers_first = m->tracers_first != 0;
   if (tracers_first) {
@@ -2511,6 +2578,7 @@ void gb25_destroy(gb25_model* m) {
   if (m->catke_b.d) hipFree(m->catke_b.d);
   if (m->catke_scratch.d) hipFree(m->catke_scratch.d);
   if (m->catke_src.d) hipFree(m->catke_src.d);
+  for (auto& F : m->uvc) if (F.d) hipFree(F.d);
   for (auto& F : m->catke_gam) if (F.d) hipFree(F.d);
   for (int a = 0; a < 2; a++) {
     for (auto& w : m->wide[a])

@@ -1831,6 +1831,9 @@ __global__ __launch_bounds__(256) void k_corrector_cells(Grid g, real* __restric
 // A slab of a decomposition (x_periodic = 0) runs it over its own columns first and, once the bundle has brought the
 // neighbours' column integrals, over its x halo columns [i0, i0 + ni) with a gap of `skip` columns from `skip_from` on; no
 // periodic images there.
+// IMM (round 4: the grids with a bottom and the curvilinear ones): the static column depth at the face instead of Lz (zero where
+// the face has no depth); the rows beyond a zipper fold and every other halo cell of du, dv come from the 2-D fill that follows.
+template <bool IMM>
 __global__ __launch_bounds__(256) void k_corrector_2d(Grid g, const real* __restrict__ U, const real* __restrict__ V,
                                                       const real* __restrict__ Usum, const real* __restrict__ Vsum,
                                                       real* __restrict__ Ub, real* __restrict__ Vb, real* __restrict__ du,
@@ -1854,11 +1857,27 @@ __global__ __launch_bounds__(256) void k_corrector_2d(Grid g, const real* __rest
     Ub[o2] = su;
     Vb[o2] = sv;
   }
-  const real a = (U[o2] - su) * g.rLz, b = j == g.jws ? real(0.) : (V[o2] - sv) * g.rLz;
+  const real a = (U[o2] - su) * (IMM ? g.im.rHfc[o2] : g.rLz);
+  const real b = j == g.jws ? real(0.) : (V[o2] - sv) * (IMM ? g.im.rHcf[o2] : g.rLz);
   store_x_images(g, du, o2, a, xw, xe);
   store_x_images(g, dv, o2, b, xw, xe);
   if (j == g.jws) store_x_images(g, du, o2 - g.sx, a, xw, xe);
   if (j == g.jwn - 1) store_x_images(g, du, o2 + g.sx, a, xw, xe);
+}
+// The corrector through the tracer kernel (gb25_api.hip: uvc): that kernel reads the UNCORRECTED u, v of the adopted look-ahead,
+// whose halo cells nobody has written -- and needs exactly two strips of them: u on the x face Nx (the east face of the last
+// column: the periodic image of face 0) and, on a folded grid, v on the y faces Ny (beyond the pivot row: -v(Nx-1-i, Ny-1)).
+// And v on the southern wall face: the look-ahead wrote v + dt G_v there like on any other face; it is zero (the fill's business).
+// blockIdx.z = 0: the column of u; 1: the wall row of v; 2: the row of v beyond the fold.
+__global__ void k_uncorrected_edges(Grid g, real* __restrict__ u, real* __restrict__ v) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (blockIdx.z == 0) {
+    if (a < g.Ny && g.x_periodic) u[ic(g, g.Nx, a, k)] = u[ic(g, 0, a, k)];
+  } else if (blockIdx.z == 1) {
+    if (a < g.Nx && g.jws >= 0 && g.jws < g.Ny) v[iv(g, a, g.jws, k)] = real(0.);
+  } else if (g.cv.north_fold && a < g.Nx) {
+    v[iv(g, a, g.Ny, k)] = -v[iv(g, g.Nx - 1 - a, g.Ny - 1, k)];
+  }
 }
 // w at the first level of every chunk of levels of the tendency kernels, for w ON THE FLY (LazyCorr::wbase): from the chunk
 // integrals of u dz, v dz the momentum look-ahead left in P (of the uncorrected velocities: + du, dv times the chunk's

@@ -419,7 +419,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
       // (a rank of a 2-D decomposition has no interior pass: du, dv and the chunk bases of w over its whole extended range at
       // once, in stage 3, when every halo is in)
       if (m->Ry == 1)
-        hipLaunchKernelGGL(k_corrector_2d, grid2(g.Nx, g.Ny + 1, b), b, 0, m->stream, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
+        hipLaunchKernelGGL(k_corrector_2d<false>, grid2(g.Nx, g.Ny + 1, b), b, 0, m->stream, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
                            m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d,
                            0, g.Nx, INT_MAX, 0, 0, g.Ny + 1);
       LAUNCHCHK();
@@ -492,7 +492,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
           dim3 b(64, 4);
           // rows: from the southern halo rows (or row 0) to the last northern halo row of the cell-shaped arrays (or the wall face)
           const int hs = m->ys_open ? g.H : 0, nj = hs + g.Ny + (m->yn_open ? g.H : 1);
-          hipLaunchKernelGGL(k_corrector_2d, grid2(g.Nx + 2 * g.H, nj, b), b, 0, m->stream, g, m->f[GB25_BT_U].d,
+          hipLaunchKernelGGL(k_corrector_2d<false>, grid2(g.Nx + 2 * g.H, nj, b), b, 0, m->stream, g, m->f[GB25_BT_U].d,
                              m->f[GB25_BT_V].d, m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d,
                              m->corr[1].d, -g.H, g.Nx + 2 * g.H, INT_MAX, 0, -hs, nj);
           m->colsum_valid = false;
@@ -504,7 +504,7 @@ gb25_status slab_stage(gb25_model* m, int stage, int euler) {
           LAUNCHCHK();   // (the bottom / top layers of the halo rows, which arrived with their interior levels: the fill below)
         } else {
           dim3 b(16, 16);
-          hipLaunchKernelGGL(k_corrector_2d, grid2(2 * g.H, g.Ny + 1, b), b, 0, m->stream, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
+          hipLaunchKernelGGL(k_corrector_2d<false>, grid2(2 * g.H, g.Ny + 1, b), b, 0, m->stream, g, m->f[GB25_BT_U].d, m->f[GB25_BT_V].d,
                              m->colsum[0].d, m->colsum[1].d, m->f[GB25_U_BAR].d, m->f[GB25_V_BAR].d, m->corr[0].d, m->corr[1].d,
                              -g.H, 2 * g.H, 0, g.Nx, 0, g.Ny + 1);
           if (m->w_fly_now)   // the chunk bases of w on the columns -2, -1 and Nx - 1, Nx, Nx + 1 (the w tiles reach two columns out)

@@ -673,6 +673,11 @@ struct Ab2Ahead {
   const real *GmT, *GmS;
   real *Tn, *Sn;
   real dt, C1, C2;
+  // WCORR (with LAZY): the kernel also WRITES the corrected velocities it forms -- u + du on the west face, v + dv on the south
+  // face of its cell -- into a second pair of arrays (interior cells; their halo cells by the fill that follows).  Every u, v is
+  // some cell's west / south face, so this replaces the corrector's sweep over u and v (2R + 2W per cell) by two stores here,
+  // and the momentum kernel that follows reads corrected velocities like any other.
+  real *uc, *vc;
 };
 
 // =============================================================================================
@@ -699,7 +704,7 @@ struct Ab2Ahead {
 // WFLY: w is not read; Az w on the top face follows from the divergence of the transports the lane holds anyway --
 // Az w(k+1) = Az w(k) - [(Axu(i+1) - Axu(i)) + (Ayn - Ays)], the east face's transport from the next lane -- starting from
 // lz.wbase at the chunk's first level (k_w_bases).  Continuity and advection then see the very same transports.
-template <bool AHEAD, bool IMM, bool FOLD, bool CURV = false, bool LAZY = false, int ORD = 5, bool WFLY = false>
+template <bool AHEAD, bool IMM, bool FOLD, bool CURV = false, bool LAZY = false, int ORD = 5, bool WFLY = false, bool WCORR = false>
 __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restrict__ u, const real* __restrict__ v,
                                             const real* __restrict__ w, const real* __restrict__ T,
                                             const real* __restrict__ S, real* __restrict__ GT, real* __restrict__ GS,
@@ -718,11 +723,18 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
   const real dy = CURV ? g.cv.dyfc[om] : g.dy, Az = CURV ? g.cv.azcc[om] : g.azc[j];
   const real dxf_s = CURV ? g.cv.dxcf[om] : g.dxf[j], dxf_n = CURV ? g.cv.dxcf[om + g.sx] : g.dxf[j + 1];
   const real razc_j = CURV ? g.cv.razcc[om] : g.razc[j];
+  static_assert(!WCORR || LAZY, "the corrected velocities are what the lazy loads form");
   real du_l = real(0.), dv_s = real(0.), dv_n = real(0.);
+  // (with a bottom the correction acts from the face's first free level on: the faces below touch the solid and stay zero)
+  int KPUl = 0, KPVs = 0, KPVn = 0;
   if (LAZY) {
     du_l = lz.du[om];
     dv_s = lz.dv[om];
     dv_n = lz.dv[om + g.sx];
+    if (IMM) {
+      const unsigned C = g.im.ordC[om], Cn = g.im.ordC[om + g.sx];
+      KPUl = (C >> 8) & 255; KPVs = (C >> 16) & 255; KPVn = (Cn >> 16) & 255;
+    }
   }
   constexpr int R = ORD == 7 ? 4 : 3;   // reach of the reconstruction stencils
   static_assert(ORD == 5 || ORD == 7, "WENO(order = 5) or WENO(order = 7)");
@@ -752,6 +764,11 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
             bu = make_buf(u + pc * pb, pc * (nzp - pb)), bw = make_buf(w + pc * pb, pc * (nzp + 1 - pb)),
             bv = make_buf(v + pv * (pb + R), pv * (nzp - pb - R)), bGT = make_buf(GT + pc * pb, pc * (nzp - pb)),
             bGS = make_buf(GS + pc * pb, pc * (nzp - pb));
+  Buf buc = bu, bvc = bv;
+  if (WCORR) {
+    buc = make_buf(next.uc + pc * pb, pc * (nzp - pb));
+    bvc = make_buf(next.vc + pv * (pb + R), pv * (nzp - pb - R));
+  }
   Buf bGmT = bT, bGmS = bT, bTn = bT, bSn = bT;
   if (AHEAD) {
     bGmT = make_buf(next.GmT + pc * pb, pc * (nzp - pb)); bGmS = make_buf(next.GmS + pc * pb, pc * (nzp - pb));
@@ -790,9 +807,19 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
       oys = ORD == 7 ? order_from7(k, KY7, KY5, KY3) : order_from(k, KY5, KY3);
       oyn = ORD == 7 ? order_from7(k, KY7n, KY5n, KY3n) : order_from(k, KY5n, KY3n);
     }
-    const real Axu = dy * dz * (LAZY ? bload(bu, vo, cc) + du_l : bload(bu, vo, cc));
-    const real Ays = dxf_s * dz * (LAZY ? bload(bv, vov, 0) + dv_s : bload(bv, vov, 0));
-    const real Ayn = dxf_n * dz * (LAZY ? bload(bv, vov, sx * SZ) + dv_n : bload(bv, vov, sx * SZ));
+    real u_l = bload(bu, vo, cc), v_s = bload(bv, vov, 0), v_n = bload(bv, vov, sx * SZ);
+    if (LAZY) {
+      u_l = (!IMM || k >= KPUl) ? u_l + du_l : u_l;
+      v_s = (!IMM || k >= KPVs) ? v_s + dv_s : v_s;
+      v_n = (!IMM || k >= KPVn) ? v_n + dv_n : v_n;
+    }
+    if (WCORR && writes) {
+      bstore(buc, vo, cc, u_l);
+      bstore(bvc, vov, 0, v_s);
+    }
+    const real Axu = dy * dz * u_l;
+    const real Ays = dxf_s * dz * v_s;
+    const real Ayn = dxf_n * dz * v_n;
     real Azw;
     if constexpr (WFLY) {
       Azw = Azw_cur - ((__shfl_down(Axu, 1) - Axu) + (Ayn - Ays));
@@ -856,14 +883,14 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
 #undef CY
 #undef CX
 }
-template <int MINW, bool AHEAD, bool IMM, bool FOLD = false, bool CURV = false, bool LAZY = false, int ORD = 5, bool WFLY = false>
+template <int MINW, bool AHEAD, bool IMM, bool FOLD = false, bool CURV = false, bool LAZY = false, int ORD = 5, bool WFLY = false, bool WCORR = false>
 __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, const real* __restrict__ u,
                                                               const real* __restrict__ v,
                                                               const real* __restrict__ w,
                                                               const real* __restrict__ T, const real* __restrict__ S,
                                                               real* __restrict__ GT, real* __restrict__ GS, int nbx,
                                                               int kchunks, int nb, Ab2Ahead next, LazyCorr lz) {
-  tracer_tile<AHEAD, IMM, FOLD, CURV, LAZY, ORD, WFLY>(g, u, v, w, T, S, GT, GS, nbx, kchunks, next, xcd_remap(blockIdx.x, nb), lz);
+  tracer_tile<AHEAD, IMM, FOLD, CURV, LAZY, ORD, WFLY, WCORR>(g, u, v, w, T, S, GT, GS, nbx, kchunks, next, xcd_remap(blockIdx.x, nb), lz);
 }
 
 // =============================================================================================
