@@ -813,10 +813,6 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
       v_s = (!IMM || k >= KPVs) ? v_s + dv_s : v_s;
       v_n = (!IMM || k >= KPVn) ? v_n + dv_n : v_n;
     }
-    if (WCORR && writes) {
-      bstore(buc, vo, cc, u_l);
-      bstore(bvc, vov, 0, v_s);
-    }
     const real Axu = dy * dz * u_l;
     const real Ays = dxf_s * dz * v_s;
     const real Ayn = dxf_n * dz * v_n;
@@ -851,6 +847,10 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
       }
       bstore(bGT, vo, cc, G.x);
       bstore(bGS, vo, cc, G.y);
+      if (WCORR) {   // (with the level's other stores: a store ahead of the window loads would sit in front of them in the memory counter)
+        bstore(buc, vo, cc, u_l);
+        bstore(bvc, vov, 0, v_s);
+      }
       if (AHEAD) {   // T, S of the NEXT step while T, S (cz[3]) and the new tendency are in registers
         const real tn = ab2_advance(cz[R].x, G.x, bload(bGmT, vo, cc), next.dt, next.C1, next.C2);
         const real sn = ab2_advance(cz[R].y, G.y, bload(bGmS, vo, cc), next.dt, next.C1, next.C2);
