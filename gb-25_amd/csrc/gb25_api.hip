@@ -2358,6 +2358,16 @@ gb25_status gb25_create(const gb25_config* cfg, gb25_model** out) {
   m->ys_open = m->ry > 0;
   m->yn_open = m->ry < m->Ry - 1;
   m->slab = cfg->nranks > 1 || cfg->slab_mode == 1;
+  {
+    // Levels per chunk of the two tendency kernels (options MOMENTUM_ / TRACER_CHUNK_LEVELS): 24 where that still leaves four
+    // rounds of blocks on the chip's 1024 block slots -- 1440 x 720 x 48: two chunks per column instead of four, +1.3 % steps/s
+    // (415.5 -> 420.9 on one box; 1440 x 720 x 60 with the islands 280 -> 285.5), the start-up of a chunk's march paid half as
+    // often --, 12 on narrower models: a 180-column rank of an 8-way decomposition would drop to one round and 0.47 -> 0.53 ms
+    // per step (tools/slab_selfring.py).  The chunking is the association of the column integrals of u, v: results differ in the
+    // last bits between the two, so a bit-for-bit comparison of a wide single domain with its narrow ranks pins the options.
+    const int nbx = (m->Nx + 63) / 64, nby = (m->Ny + 3) / 4;
+    if ((long)nbx * nby * std::max(1, cfg->Nz / 24) >= 4096) m->mom_chunk_levels = m->trc_chunk_levels = 24;
+  }
   if (m->Nx < cfg->halo) return fail(m, GB25_ERR_INVALID_ARGUMENT, "slab narrower than the halo");
   if (m->Ry > 1) {
     // a rank of a 2-D decomposition steps on the staged sequence without the interior / edge split of the tendencies and

@@ -131,9 +131,11 @@ typedef enum {
   GB25_OPT_LAZY_CORRECTOR,       /* [1] single flat lat-lon domain, between the steps of one gb25_loop call: the barotropic
                                     correction of u, v is added by the kernels that read them instead of by a sweep over
                                     u and v (same bits; memory holds the corrected velocities when the call returns) */
-  GB25_OPT_MOMENTUM_CHUNK_LEVELS, /* [12] levels a block of the momentum tendency kernel marches through (>= 6); also the
-                                    association of the column integrals of u, v: results change in the last bits */
-  GB25_OPT_TRACER_CHUNK_LEVELS,  /* [12] the same for the tracer tendency kernel (bitwise neutral) */
+  GB25_OPT_MOMENTUM_CHUNK_LEVELS, /* [24 on models wide enough for four rounds of blocks with it -- 1440 x 720 x 48 --, else 12] levels a
+                                    block of the momentum tendency kernel marches through (>= 6); also the association of the
+                                    column integrals of u, v: results change in the last bits (a bit-for-bit comparison of a wide
+                                    single domain with its narrow ranks pins it on both sides) */
+  GB25_OPT_TRACER_CHUNK_LEVELS,  /* [like MOMENTUM_CHUNK_LEVELS] the same for the tracer tendency kernel (bitwise neutral) */
   GB25_OPT_TRACERS_FIRST,        /* [1] single domain, composite steps: the tracer tendency kernel before the momentum kernel, so
                                     that the next step's pressure (it needs the tracer look-ahead's T, S) can run beside the next
                                     step's sub-cycle; 0: momentum first (src/precompile.jl:48-50 lists them in that order; the

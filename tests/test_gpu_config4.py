@@ -19,6 +19,8 @@ FIELDS = ("u", "v", "T", "S", "e", "eta", "U", "V", "kappa_u", "Gn.u", "Gn.T", "
 @pytest.fixture(scope="module")
 def reference():
     m = gb.data_free_ocean_climate_model_init(gb.GPU(), Nz=NZ, dt=DT, size=(NX, NY))
+    for o in ("momentum_chunk_levels", "tracer_chunk_levels"):      # (the chunking of its narrower ranks: bit for bit)
+        m.backend.set_option(o, 12)
     init = {n: m.backend.get_field(n, False) for n in ("T", "S")}
     gb.first_time_step(m)
     gb.loop(m, 3)

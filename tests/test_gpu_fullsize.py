@@ -145,7 +145,9 @@ def test_slabs_at_the_benchmark_size_bitwise():
     from gb25_amd.distributed import LocalSlabEnsemble
     names = ("u", "v", "w", "T", "S", "eta", "U", "V", "eta_bar", "U_bar", "V_bar", "Gn.u", "Gn.v", "Gn.T", "Gn.S",
              "Gm.u", "Gm.T", "Gn.U", "Gn.V")
-    single = fresh_model(w_on_the_fly=0)   # (bit for bit: the slabs compute w with the stand-alone kernel)
+    # (bit for bit: the slabs compute w with the stand-alone kernel, and their narrower tendency launches march chunks of 12
+    # levels where the wide single domain's default is 24: the association of the column integrals of u, v)
+    single = fresh_model(w_on_the_fly=0, momentum_chunk_levels=12, tracer_chunk_levels=12)
     gb.set_baroclinic_instability(single)
     u0 = (1e-2 * counter_rng((NX, NY, NZ), 42, 1)).astype(np.float32)
     v0 = (1e-2 * counter_rng((NX, NY + 1, NZ), 42, 2)).astype(np.float32)
@@ -157,7 +159,7 @@ def test_slabs_at_the_benchmark_size_bitwise():
     single.backend.close()
     assert np.abs(ref["u"]).max() > 1e-2 and np.isfinite(ref["Gn.u"]).all()
     for P in (2, 4, 8):
-        ens = LocalSlabEnsemble(NX, NY, NZ, P, dt=DT, options=dict(w_on_the_fly=0))
+        ens = LocalSlabEnsemble(NX, NY, NZ, P, dt=DT, options=dict(w_on_the_fly=0, momentum_chunk_levels=12, tracer_chunk_levels=12))
         for n, a in (("u", u0), ("v", v0), ("T", T0), ("S", S0)):
             ens.scatter(n, a)
         ens.first_time_step()
