@@ -92,18 +92,28 @@ __device__ __forceinline__ CatkeColumn catke_column(const Grid& g, int i, int j,
   return q;
 }
 struct CatkeLengths { real ku, kc, ke, convD; };
-// the mixing lengths of an OPEN (c,c,f) face (both cells active): el, eh = max(e_min, e) of the cells below and above
-__device__ __forceinline__ CatkeLengths catke_face_eval(const CatkePar& c, const CatkeColumn& q, real el, real eh, real N2,
+// Square roots and quotients of the column kernels.  Float32: the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 (as the WENO weights
+// take their reciprocals, device_common.hpp) -- the correctly rounded sequences clang emits for sqrtf and '/' are 10-14
+// instructions each, and a level of k_catke_tke_step has eight of the one and seven of the other (a third of its 500 instructions);
+// operands are e >= e_min, N^2, S^2, lengths: normal numbers, or zeros whose quotients the callers guard.  Float64: the true ones.
+#ifndef GB25_CATKE_FAST
+#define GB25_CATKE_FAST 0
+#endif
+__device__ __forceinline__ float csqrt(float x) { return GB25_CATKE_FAST ? __builtin_amdgcn_sqrtf(x) : sqrt(x); }
+__device__ __forceinline__ double csqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float cdiv(float a, float b) { return GB25_CATKE_FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+__device__ __forceinline__ double cdiv(double a, double b) { return a / b; }
+// the mixing lengths of an OPEN (c,c,f) face (both cells active): wl, wh = sqrt(max(e_min, e)) of the cells below and above
+__device__ __forceinline__ CatkeLengths catke_face_eval(const CatkePar& c, const CatkeColumn& q, real wl, real wh, real N2,
                                                         real N2above, real S2, real zf) {
-  const real wl = sqrt(el), wh = sqrt(eh);
   const real ws = (wl + wh) / real(2.), ws2 = (wl * wl + wh * wh) / real(2.), ws3 = (wl * wl * wl + wh * wh * wh) / real(2.);
-  const real Ri = (N2 == real(0.)) ? real(0.) : N2 / S2;
+  const real Ri = (N2 == real(0.)) ? real(0.) : cdiv(N2, S2);
   real dup = c.Cs * (q.zt - zf), ddn = c.Cb * (zf - q.zbot);
   dup = dup < real(0.) ? real(0.) : dup;
   ddn = ddn < real(0.) ? real(0.) : ddn;
   real ls = dup < ddn ? dup : ddn;
   if (N2 > real(0.)) {
-    const real lN = ws / sqrt(N2);
+    const real lN = cdiv(ws, csqrt(N2));
     ls = lN < ls ? lN : ls;
   }
   const real jb = q.jb, jbe = c.Jbmin;
@@ -112,8 +122,8 @@ __device__ __forceinline__ CatkeLengths catke_face_eval(const CatkePar& c, const
   if (convecting || entraining) {
     // (one reciprocal per column and one per face instead of five divisions: the f32 division is a ten-instruction sequence and
     // this function was half of the column kernels' 490 instructions per level)
-    const real Sp = sqrt(S2) * ws2 * q.rjb, esp = real(1.) - c.Csp * Sp;
-    const real scale = convecting ? ws3 * q.rjb : jb / (ws * N2 + jbe);
+    const real Sp = csqrt(S2) * ws2 * q.rjb, esp = real(1.) - c.Csp * Sp;
+    const real scale = convecting ? ws3 * q.rjb : cdiv(jb, ws * N2 + jbe);
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       real l = (convecting ? c.Cc[p] : c.Ce[p]) * scale;
@@ -137,36 +147,43 @@ __device__ __forceinline__ CatkeLengths catke_face_eval(const CatkePar& c, const
   return r;
 }
 // dissipation_length_scale(c,c,c) of an active cell from the N^2, S^2 and convective dissipation lengths of its two faces
-__device__ __forceinline__ real catke_dissipation_length(const CatkePar& c, const CatkeColumn& q, real e, real zc, real N2lo,
+// (wc = sqrt(max(e_min, e)) of the cell: the face evaluations hold it already)
+__device__ __forceinline__ real catke_dissipation_length(const CatkePar& c, const CatkeColumn& q, real wc, real zc, real N2lo,
                                                          real N2hi, real S2lo, real S2hi, real cDlo, real cDhi) {
   const real lh = (cDlo + cDhi) / real(2.), N2 = (N2lo + N2hi) / real(2.), S2 = (S2lo + S2hi) / real(2.);
-  const real Ri = (N2 == real(0.)) ? real(0.) : N2 / S2;
+  const real Ri = (N2 == real(0.)) ? real(0.) : cdiv(N2, S2);
   real dup = c.Cs * (q.zt - zc), ddn = c.Cb * (zc - q.zbot);
   dup = dup < real(0.) ? real(0.) : dup;
   ddn = ddn < real(0.) ? real(0.) : ddn;
   real ls = dup < ddn ? dup : ddn;
   if (N2 > real(0.)) {
-    const real ef = e > c.emin ? e : c.emin;
-    const real lN = sqrt(ef) / sqrt(N2);
+    const real lN = cdiv(wc, csqrt(N2));
     ls = lN < ls ? lN : ls;
   }
   real tstep = (Ri - c.CRi0) * c.rCRid;
   tstep = tstep < real(0.) ? real(0.) : (tstep > real(1.) ? real(1.) : tstep);
   const real sg = Ri < real(0.) ? c.Cun[3] : c.Clo[3] + (c.Chi[3] - c.Clo[3]) * tstep;
-  ls = ls / sg;
+  ls = cdiv(ls, sg);
   const real l = lh > ls ? lh : ls;
   return l < q.Hcol ? l : q.Hcol;
 }
 // the vertical derivatives of u at the x faces i, i+1 and of v at the y faces j, j+1 of column (i, j) on face kf (1 .. Nz-1):
 // zero where one of the two nodes is an inactive node (both cells beside it inactive)
 struct CatkeShear { real uw, ue, vs, vn; };
-__device__ __forceinline__ CatkeShear catke_dz_velocities(const Grid& g, const CatkeColumn& q, const real* __restrict__ u,
-                                                          const real* __restrict__ v, int oc, int ov, int kf) {
-  // oc, ov: offsets of cell (i, j, kf) in a cell-shaped / v-shaped array
+// the four face velocities of column (i, j) on one level: oc, ov = offsets of cell (i, j, k) in a cell-shaped / v-shaped array.
+// The column kernels march up and keep the level below the face in registers: four loads per face and field instead of eight.
+__device__ __forceinline__ CatkeShear catke_face_velocities(const Grid& g, const real* __restrict__ u, const real* __restrict__ v,
+                                                            int oc, int ov) {
+  CatkeShear r;
+  r.uw = u[oc]; r.ue = u[oc + 1]; r.vs = v[ov]; r.vn = v[ov + g.sx];
+  return r;
+}
+__device__ __forceinline__ CatkeShear catke_dz_velocities(const Grid& g, const CatkeColumn& q, const CatkeShear& lo,
+                                                          const CatkeShear& hi, int kf) {
   const real rdz = g.rdzf[kf];
   // (every load unconditional -- the masks are per lane, and a load inside a divergent branch is issued behind it -- then selects)
-  const real a = (u[oc] - u[oc - g.pl_c]) * rdz, b = (u[oc + 1] - u[oc + 1 - g.pl_c]) * rdz;
-  const real c = (v[ov] - v[ov - g.pl_v]) * rdz, e = (v[ov + g.sx] - v[ov + g.sx - g.pl_v]) * rdz;
+  const real a = (hi.uw - lo.uw) * rdz, b = (hi.ue - lo.ue) * rdz;
+  const real c = (hi.vs - lo.vs) * rdz, e = (hi.vn - lo.vn) * rdz;
   CatkeShear d;
   d.uw = kf > q.NUw ? a : real(0.);
   d.ue = kf > q.NUe ? b : real(0.);
@@ -174,10 +191,17 @@ __device__ __forceinline__ CatkeShear catke_dz_velocities(const Grid& g, const C
   d.vn = kf > q.NVn ? e : real(0.);
   return d;
 }
+__device__ __forceinline__ CatkeShear catke_dz_velocities(const Grid& g, const CatkeColumn& q, const real* __restrict__ u,
+                                                          const real* __restrict__ v, int oc, int ov, int kf) {
+  return catke_dz_velocities(g, q, catke_face_velocities(g, u, v, oc - g.pl_c, ov - g.pl_v), catke_face_velocities(g, u, v, oc, ov), kf);
+}
 // time_step_catke_equation!, first half (see the header).  One thread per own column, marching up; e is updated in place (a
 // column reads nobody else's e, and the old e of a cell is last needed by the face above it, evaluated before the cell).
+#ifndef GB25_CATKE_MINW
+#define GB25_CATKE_MINW 4
+#endif
 template <bool IMM>
-__global__ __launch_bounds__(256, 6) void k_catke_tke_step(Grid g, CatkePar c, real dt, real C1, real C2,
+__global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_tke_step(Grid g, CatkePar c, real dt, real C1, real C2,
                                                         const real* __restrict__ u, const real* __restrict__ v,
                                                         const real* __restrict__ um, const real* __restrict__ vm,
                                                         real* __restrict__ e, const real* __restrict__ n2,
@@ -203,14 +227,22 @@ __global__ __launch_bounds__(256, 6) void k_catke_tke_step(Grid g, CatkePar c, r
   // the face below the current cell: N^2, S^2, the convective dissipation length, -kappa_c N^2, the shear-production sum
   real N2lo = real(0.), S2lo = real(0.), cDlo = real(0.), wblo = real(0.), PFlo = real(0.);
   real ecur = e[o];
+  // carried up the column: the face velocities of the level below the face, N^2 of the face (loaded as the face above of the
+  // one before), sqrt(max(e_min, e)) of the cell below
+  CatkeShear ulo = catke_face_velocities(g, u, v, o, ov), mlo = catke_face_velocities(g, um, vm, o, ov);
+  real n2f = Nz > 1 ? n2[o + pc] : real(0.);
+  real wcur = csqrt(ecur > c.emin ? ecur : c.emin);
   for (int k = 0; k < Nz; k++) {
     const int kf = k + 1, of = o + pc, ovf = ov + pv;
     zf += g.dzc[k];
     real N2hi = real(0.), S2hi = real(0.), cDhi = real(0.), wbhi = real(0.), PFhi = real(0.), kehi = real(0.);
-    real enext = real(0.);
+    real enext = real(0.), wnext = real(0.);
     if (kf < Nz) {
       enext = e[of];
-      const CatkeShear d = catke_dz_velocities(g, q, u, v, of, ovf, kf), dm = catke_dz_velocities(g, q, um, vm, of, ovf, kf);
+      const CatkeShear uhi = catke_face_velocities(g, u, v, of, ovf), mhi = catke_face_velocities(g, um, vm, of, ovf);
+      const CatkeShear d = catke_dz_velocities(g, q, ulo, uhi, kf), dm = catke_dz_velocities(g, q, mlo, mhi, kf);
+      ulo = uhi;
+      mlo = mhi;
       S2hi = (d.uw * d.uw + d.ue * d.ue) / real(2.) + (d.vs * d.vs + d.vn * d.vn) / real(2.);
       const real kuc = KU[of];
       const real nw = (KU[of - 1] + kuc) / real(2.), ne = (kuc + KU[of + 1]) / real(2.);
@@ -222,14 +254,15 @@ __global__ __launch_bounds__(256, 6) void k_catke_tke_step(Grid g, CatkePar c, r
       PFhi = (fw + fe) / real(2.) + (fs + fn) / real(2.);
       // (loads and the evaluation for every lane, the mask of the solid applied to the results: N^2 is stored as zero on the
       // faces that touch the solid, so the loaded values are harmless there)
-      const real n2f = n2[of], n2a = n2[of + pc], kcf = KC[of];
-      const real el = ecur > c.emin ? ecur : c.emin, eh = enext > c.emin ? enext : c.emin;
-      const CatkeLengths L = catke_face_eval(c, q, el, eh, n2f, n2a, S2hi, zf);
+      const real n2a = n2[of + pc], kcf = KC[of];
+      wnext = csqrt(enext > c.emin ? enext : c.emin);
+      const CatkeLengths L = catke_face_eval(c, q, wcur, wnext, n2f, n2a, S2hi, zf);
       const bool open = kf > q.kc0;
       N2hi = open ? n2f : real(0.);
       kehi = open ? L.ke : real(0.);
       cDhi = open ? L.convD : real(0.);
       wbhi = open ? -(kcf * n2f) : real(0.);
+      n2f = n2a;
     }
     KE[of] = kehi;
     real Lk = real(0.);
@@ -237,11 +270,14 @@ __global__ __launch_bounds__(256, 6) void k_catke_tke_step(Grid g, CatkePar c, r
     if (k >= q.kc0) {
       const real ek = ecur, wb = (wblo + wbhi) / real(2.);
       const real wbm = wb < real(0.) ? wb : real(0.), wbp = wb > real(0.) ? wb : real(0.);
-      const real lD = catke_dissipation_length(c, q, ek, g.zc[k], N2lo, N2hi, S2lo, S2hi, cDlo, cDhi);
-      const real omega = ek < real(0.) ? c.rtau_neg : sqrt(rabs(ek)) / lD;
+      const real lD = catke_dissipation_length(c, q, wcur, g.zc[k], N2lo, N2hi, S2lo, S2hi, cDlo, cDhi);
+      // (sqrt|e| and sqrt(max(e, 0)): the carried root where e >= e_min, which is nearly everywhere)
       const real ep = ek > real(0.) ? ek : real(0.);
-      const real divJ = k == q.kc0 ? -(c.CWeps * sqrt(ep) * g.rdzc[k]) : real(0.);      // (the bottom cell of the column)
-      Lk = (ek > c.emin ? wbm / ek : real(0.)) - omega + divJ;
+      const bool floored = !(ek >= c.emin);
+      const real wabs = floored ? csqrt(rabs(ek)) : wcur, wpos = floored ? csqrt(ep) : wcur;
+      const real omega = ek < real(0.) ? c.rtau_neg : cdiv(wabs, lD);
+      const real divJ = k == q.kc0 ? -(c.CWeps * wpos * g.rdzc[k]) : real(0.);      // (the bottom cell of the column)
+      Lk = (ek > c.emin ? cdiv(wbm, ek) : real(0.)) - omega + divJ;
       const real P = ((PFlo + PFhi) / real(2.)) * (real(0.5) * g.rdzc[k]);
       const real total = gn + (P + wbp);
       e[o] = ek + dt * (C1 * total - C2 * gm);
@@ -252,6 +288,7 @@ __global__ __launch_bounds__(256, 6) void k_catke_tke_step(Grid g, CatkePar c, r
     if (k == Nz - 1) store_x_images(g, Le, o + pc, Lk, xw, xe);
     N2lo = N2hi; S2lo = S2hi; cDlo = cDhi; wblo = wbhi; PFlo = PFhi;
     ecur = enext;
+    wcur = wnext;
     o = of;
     ov = ovf;
   }
@@ -290,10 +327,10 @@ __global__ void k_catke_surface_flux(Grid g, CatkePar c, real dt_since, const re
         N2lo = n2[o];
         const real eb = e[o - g.pl_c];
         const real el = eb > c.emin ? eb : c.emin, eh = ek > c.emin ? ek : c.emin;
-        cDlo = catke_face_eval(c, q, el, eh, N2lo, real(0.), S2lo, g.zc[k] - real(0.5) * g.dzc[k]).convD;
+        cDlo = catke_face_eval(c, q, csqrt(el), csqrt(eh), N2lo, real(0.), S2lo, g.zc[k] - real(0.5) * g.dzc[k]).convD;
       }
     }
-    const real lD = catke_dissipation_length(c, q, ek, g.zc[k], N2lo, real(0.), S2lo, real(0.), cDlo, real(0.));
+    const real lD = catke_dissipation_length(c, q, csqrt(ek > c.emin ? ek : c.emin), g.zc[k], N2lo, real(0.), S2lo, real(0.), cDlo, real(0.));
     real Jp = c.Jbmin;
     Jp = J > Jp ? J : Jp;
     Jp = Jstar > Jp ? Jstar : Jp;
@@ -324,7 +361,7 @@ __global__ void k_catke_add_top_source(Grid g, const real* __restrict__ src, rea
 // compute_CATKE_diffusivities!: kappa_u, kappa_c, kappa_e on the faces 1 .. Nz-1 (zero on the bottom and top faces and where
 // the face touches the solid).
 template <bool IMM>
-__global__ __launch_bounds__(256, 6) void k_catke_diffusivities(Grid g, CatkePar c, const real* __restrict__ u,
+__global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_diffusivities(Grid g, CatkePar c, const real* __restrict__ u,
                                                              const real* __restrict__ v, const real* __restrict__ e,
                                                              const real* __restrict__ n2, const real* __restrict__ Jb,
                                                              real* __restrict__ KU, real* __restrict__ KC,
@@ -351,21 +388,28 @@ __global__ __launch_bounds__(256, 6) void k_catke_diffusivities(Grid g, CatkePar
   put(KU, o, real(0.)); put(KC, o, real(0.)); put(KE, o, real(0.));
   real zf = g.zc[0] - real(0.5) * g.dzc[0];
   real ecur = e[o];
+  CatkeShear ulo = catke_face_velocities(g, u, v, o, ov);      // (carried up the column like k_catke_tke_step's)
+  real n2f = Nz > 1 ? n2[o + pc] : real(0.);
+  real wcur = csqrt(ecur > c.emin ? ecur : c.emin);
   for (int k = 0; k < Nz; k++) {
     const int kf = k + 1, of = o + pc, ovf = ov + pv;
     zf += g.dzc[k];
     CatkeLengths L = {real(0.), real(0.), real(0.), real(0.)};
-    real enext = real(0.);
+    real wnext = real(0.);
     if (kf < Nz) {
-      enext = e[of];
-      const CatkeShear d = catke_dz_velocities(g, q, u, v, of, ovf, kf);
+      const real enext = e[of];
+      const CatkeShear uhi = catke_face_velocities(g, u, v, of, ovf);
+      const CatkeShear d = catke_dz_velocities(g, q, ulo, uhi, kf);
+      ulo = uhi;
       const real S2 = (d.uw * d.uw + d.ue * d.ue) / real(2.) + (d.vs * d.vs + d.vn * d.vn) / real(2.);
-      const real el = ecur > c.emin ? ecur : c.emin, eh = enext > c.emin ? enext : c.emin;
-      const CatkeLengths Lf = catke_face_eval(c, q, el, eh, n2[of], n2[of + pc], S2, zf);   // (for every lane; the solid's mask below)
+      const real n2a = n2[of + pc];
+      wnext = csqrt(enext > c.emin ? enext : c.emin);
+      const CatkeLengths Lf = catke_face_eval(c, q, wcur, wnext, n2f, n2a, S2, zf);   // (for every lane; the solid's mask below)
+      n2f = n2a;
       if (kf > q.kc0) L = Lf;
     }
     put(KU, of, L.ku); put(KC, of, L.kc); put(KE, of, L.ke);
-    ecur = enext;
+    wcur = wnext;
     o = of;
     ov = ovf;
   }

@@ -208,6 +208,11 @@ struct gb25_model {
   bool roctx_ranges = true;          // option ROCTX_RANGES
   int substep_order = 0;             // option SUBSTEP_ORDER
   double catke_prev_time = 0;        // diffusivity_fields.previous_compute_time
+  // where diffusivity_fields.previous_velocities live (single domain: no copies in the steady state).  0: in their fields
+  // (GB25_PREV_U/V).  1: they ARE the current u, v (compute_diffusivities! just ended: u- <- u is pending).  2: in the
+  // look-ahead's partner buffers -- the AB2 step that followed adopted the look-ahead by exchanging pointers, and the buffers
+  // it left hold u, v as they were at the last compute_diffusivities!, halos included.  materialize_prev_uv brings them home.
+  int prev_uv_src = 0;
   bool catke_stale_e_halos = false;  // option CATKE_STALE_E_HALOS
   bool n2_fresh = false;             // (unused since N^2 = g (alpha dzT - beta dzS) has a kernel of its own)
   Field catke_gam[2];                // Nz > 64: the elimination factors of the streamed implicit solve
@@ -1112,6 +1117,7 @@ inline bool tendencies_split(const gb25_model* m) {
 
 // part: 0 = every tile column; 1 = the interior tile columns (a12: launched before the x-halo bundle has arrived);
 //       2 = the edge tile columns, then whatever follows the complete evaluation (the look-ahead's finish kernel).
+gb25_status materialize_prev_uv(gb25_model* m);
 gb25_status momentum_impl(gb25_model* m, int part = 0) {
   const Grid& g = m->g;
   int nbx, nb;
@@ -1137,6 +1143,8 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
     const bool ahead = m->ab2_ahead == 1 && !m->ptr_exposed;
     UvAhead nx{};
     const real dt = (real)m->last_dt, chi = (real)m->cfg.chi;
+    if (ahead && m->prev_uv_src == 2)   // (the partner buffers still hold CATKE's previous velocities: a caller of the single phases)
+      if (gb25_status s_ = materialize_prev_uv(m)) return s_;
     if (ahead) {   // predicted parameters of the next ab2_step!: the clock's dt and the model's chi
       nx.GmU = m->f[GB25_GM_U].d; nx.GmV = m->f[GB25_GM_V].d;
       nx.un = m->ahead_uv[0].d; nx.vn = m->ahead_uv[1].d;
@@ -1387,10 +1395,24 @@ gb25_status implicit_vertical_impl(gb25_model* m, int kind, real dt) {
   return GB25_OK;
 }
 
+// previous_velocities into their own fields (before anything writes the buffer they live in, and before the host looks)
+gb25_status materialize_prev_uv(gb25_model* m) {
+  if (m->prev_uv_src == 0 || !m->catke) return GB25_OK;
+  for (int q = 0; q < 2; q++) {
+    const real* src = m->prev_uv_src == 1 ? m->f[GB25_U + q].d : m->ahead_uv[q].d;
+    HIPCHK(hipMemcpyAsync(m->f[GB25_PREV_U + q].d, src, m->f[GB25_U + q].elems() * sizeof(real), hipMemcpyDeviceToDevice, m->stream));
+  }
+  m->prev_uv_src = 0;
+  return GB25_OK;
+}
 gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
   const Grid& g = m->g;
   if (m->ahead_uv_valid && dt == m->ahead_uv_dt && chi == m->ahead_uv_chi) {
     // the last momentum evaluation already advanced u and v with exactly these parameters: adopt its buffers
+    // (closure = CATKE: the buffers given up hold the velocities of the last compute_diffusivities!: its previous_velocities)
+    if (m->prev_uv_src == 2)
+      if (gb25_status s_ = materialize_prev_uv(m)) return s_;
+    if (m->prev_uv_src == 1) m->prev_uv_src = 2;
     for (int q = 0; q < 2; q++) {
       std::swap(m->f[GB25_U + q].d, m->ahead_uv[q].d);
       std::swap(m->f[GB25_GN_BT_U + q].d, m->ahead_G[q].d);
@@ -1402,6 +1424,8 @@ gb25_status ab2_velocities_impl(gb25_model* m, real dt, real chi) {
     return implicit_vertical_impl(m, 0, dt);
   }
   m->ahead_uv_valid = false;
+  if (m->prev_uv_src == 1)   // (u, v are about to be advanced in place)
+    if (gb25_status s_ = materialize_prev_uv(m)) return s_;
   dim3 b(64, 4);
   Timed t(m, GB25_K_AB2_VELOCITIES);
   hipLaunchKernelGGL(k_ab2_velocities, grid2(g.Nx, v_rows(g), b), b, 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d,
@@ -1804,16 +1828,23 @@ gb25_status catke_tke_step_impl(gb25_model* m) {
   }
   // dt = clock.last_dt (finite from the model's construction on: GB-25 src/baroclinic_instability_model.jl:82), chi = 0.1 always
   const real dt = (real)m->last_dt, chi = (real)m->cfg.chi;
+  const real* prev_uv[2];   // previous_velocities, wherever they are (prev_uv_src)
+  for (int q = 0; q < 2; q++)
+    prev_uv[q] = m->prev_uv_src == 1 ? m->f[GB25_U + q].d : m->prev_uv_src == 2 ? m->ahead_uv[q].d : m->f[GB25_PREV_U + q].d;
   hipLaunchKernelGGL(m->immersed ? k_catke_tke_step<true> : k_catke_tke_step<false>, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g,
                      catke_parameters(m), dt, real(1.5) + chi, real(0.5) + chi, m->f[GB25_U].d, m->f[GB25_V].d,
-                     m->f[GB25_PREV_U].d, m->f[GB25_PREV_V].d, m->f[GB25_E].d, m->catke_b.d, m->f[GB25_JB].d,
+                     prev_uv[0], prev_uv[1], m->f[GB25_E].d, m->catke_b.d, m->f[GB25_JB].d,
                      m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_GN_E].d,
                      m->f[GB25_GM_E].d);
   LAUNCHCHK();
   if (gb25_status s = catke_implicit_impl(m, 1, dt, chi, 1, 1)) return s;   // (the e slice alone)
-  // previous velocities <- velocities (parents): D2D copies behind the kernel that read them
-  HIPCHK(hipMemcpyAsync(m->f[GB25_PREV_U].d, m->f[GB25_U].d, m->f[GB25_U].elems() * sizeof(real), hipMemcpyDeviceToDevice, m->stream));
-  HIPCHK(hipMemcpyAsync(m->f[GB25_PREV_V].d, m->f[GB25_V].d, m->f[GB25_V].elems() * sizeof(real), hipMemcpyDeviceToDevice, m->stream));
+  // previous velocities <- velocities (parents).  Single domain with the look-ahead of u, v: nothing moves -- the next AB2 step
+  // adopts the look-ahead's buffers and leaves these behind untouched, which is where the next compute_diffusivities! finds them
+  // (prev_uv_src; 0.8 GB of copies per step at 1440x720x48 otherwise).  A rank of a decomposition, whose stages write the
+  // partner buffers ahead of this one, and models without the look-ahead: D2D copies behind the kernel that read them.
+  m->prev_uv_src = 1;
+  if (m->slab || m->ab2_ahead != 1 || m->ptr_exposed || !m->two_streams)
+    if (gb25_status s_ = materialize_prev_uv(m)) return s_;
   const double dt_since = m->time - m->catke_prev_time;
   m->catke_prev_time = m->time;
   hipLaunchKernelGGL(m->immersed ? k_catke_surface_flux<true> : k_catke_surface_flux<false>, grid2(g.Nx, g.Ny, b), b, 0, m->stream,
@@ -1963,9 +1994,11 @@ gb25_status update_state_impl(gb25_model* m) {
   if (m->catke && (s = fill_halos_impl(m, true, false, 1, 4))) return s;   // the TKE tracer
   if ((s = compute_w_impl(m))) return s;
   if ((s = compute_p_impl(m))) return s;
+  // (compute_diffusivities! ahead of the tendencies, as update_state! has them: neither reads what the other writes, and the
+  // e step must have read CATKE's previous velocities before the momentum kernel's look-ahead reuses their buffers)
+  if ((s = catke_update_impl(m))) return s;
   if ((s = momentum_impl(m))) return s;
-  if ((s = tracers_impl(m))) return s;
-  return catke_update_impl(m);
+  return tracers_impl(m);
 }
 
 gb25_status ab2_step_impl(gb25_model* m, double dt, int euler) {
@@ -2208,6 +2241,10 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
   if (lazy_t && !m->tracers_first) return fail(m, GB25_ERR_STATE, "internal: the corrector through the tracer kernel needs the tracer kernel first");
   // ---- join: the tendencies need w, u, v and T, S (the tracers) / the pressure differences (the momentum)
   const bool tracers_first = m->tracers_first != 0;
+  if (m->catke) {   // compute_diffusivities! + the slow tendency of e, ahead of the tendency kernels (see update_state_impl)
+    HIPCHK(hipStreamWaitEvent(main, m->ev_ts, 0));
+    if ((s = catke_update_impl(m))) return s;
+  }
   if (tracers_first) {
     HIPCHK(hipStreamWaitEvent(main, m->ev_ts, 0));
     if ((s = tracers_impl(m))) return s;
@@ -2245,7 +2282,6 @@ gb25_status time_step_impl(gb25_model* m, int euler, bool more = false) {
     m->ahead_baro_valid = true;
   }
   if (!tracers_first && (s = tracers_impl(m))) return s;
-  if ((s = catke_update_impl(m))) return s;
   return atmosphere_ocean_fluxes_impl(m);   // (a coupled model: the fluxes the NEXT evaluation of the tendencies sees)
 }
 // a coupled model at iteration 0: the fluxes of the initial state, then the tendencies again, which now see them
@@ -2253,9 +2289,9 @@ gb25_status first_fluxes_impl(gb25_model* m) {
   if (!m->coupled) return GB25_OK;
   gb25_status s;
   if ((s = atmosphere_ocean_fluxes_impl(m))) return s;
+  if ((s = catke_update_impl(m))) return s;
   if ((s = momentum_impl(m))) return s;
-  if ((s = tracers_impl(m))) return s;
-  return catke_update_impl(m);
+  return tracers_impl(m);
 }
 
 gb25_status initialize_impl(gb25_model* m) {
@@ -2667,6 +2703,7 @@ static gb25_status copy_field(gb25_model* m, gb25_field id, real* host, int incl
   if (to_device && (id == GB25_U || id == GB25_V)) m->colsum_valid = false;  // cached column integrals are stale
   if (m->uv_lazy)   // (only after a composite call that failed half-way: memory must hold the corrected velocities)
     if (gb25_status s = materialize_uv(m)) return s;
+  if (gb25_status s = materialize_prev_uv(m)) return s;   // (CATKE's previous velocities into their fields before the host reads or writes)
   Field& F = m->f[id];
   HIPCHK(hipStreamSynchronize(m->stream));
   if (to_device) {   // a look-ahead may still be reading the old values
@@ -2760,6 +2797,7 @@ gb25_status gb25_field_device_ptr(gb25_model* m, gb25_field id, void** dev) {
   if (gb25_status s = collective_guard(m, 2, (unsigned)id, 0.0)) return s;
   if (m->uv_lazy)
     if (gb25_status s = materialize_uv(m)) return s;
+  if (gb25_status s = materialize_prev_uv(m)) return s;
   if (id == GB25_U || id == GB25_V || id == GB25_T || id == GB25_S || (id >= GB25_GN_U && id <= GB25_GM_S) ||
       (id >= GB25_ETA && id <= GB25_GN_BT_V)) {
     // the host can now write prognostic fields or their tendencies behind our back: no more look-ahead for this
@@ -2856,6 +2894,7 @@ gb25_status gb25_set_closure_catke(gb25_model* m, int32_t on) {
     if ((s = alloc_field(m, m->catke_src, sx, sy, 1))) return s;
     if ((s = alloc_field(m, m->catke_scratch, sx, sy, nz))) return s;
   }
+  if (gb25_status s_ = materialize_prev_uv(m)) return s_;   // (while the closure still says where they are)
   m->catke = on != 0;
   m->n2_fresh = false;
   m->ahead_valid = false;

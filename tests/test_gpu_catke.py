@@ -159,7 +159,7 @@ def test_catke_on_slabs_is_the_single_domain_bit_for_bit(grid_type, P):
     init = {n: m.backend.get_field(n, False) for n in names}
     gb.first_time_step(m)
     gb.loop(m, 6)
-    out = ("u", "v", "T", "S", "e", "eta", "U", "V", "kappa_u", "kappa_c", "kappa_e", "Le", "Jb", "Gn.e")
+    out = ("u", "v", "T", "S", "e", "eta", "U", "V", "kappa_u", "kappa_c", "kappa_e", "Le", "Jb", "Gn.e", "previous_u", "previous_v")
     ref = {n: m.backend.get_field(n, False) for n in out}
     assert np.isfinite(ref["e"]).all() and ref["kappa_u"].max() > 1e-6
     m.backend.close()
@@ -177,6 +177,35 @@ def test_catke_on_slabs_is_the_single_domain_bit_for_bit(grid_type, P):
     bad = [n for n, a in ref.items() if not np.array_equal(ens.gather(n), a)]
     assert not bad, [(n, rel(ens.gather(n), ref[n])) for n in bad]
     ens.close()
+
+
+@pytest.mark.parametrize("grid_type", ["simple_lat_lon", "gaussian_islands"])
+def test_previous_velocities_move_by_pointer_exchange(grid_type):
+    """diffusivity_fields.previous_velocities on a single domain: no copies in the steady state -- the AB2 step adopts the
+    look-ahead's buffers and the ones it gives up ARE the velocities of the last compute_diffusivities! (gb25_api.hip,
+    prev_uv_src).  A loop of steps (the fields brought home once, when the host looks) against single steps with the host
+    looking after every one (a copy per step), bit for bit; u- = u after compute_diffusivities!, halos included."""
+    Nx, Ny, Nz, dt = 96, 44, 16, 300.0
+    depth = 4000.0 if "islands" in grid_type else 200.0
+    names = ("u", "v", "T", "e", "kappa_u", "kappa_e", "Le", "Jb", "Gm.e", "previous_u", "previous_v")
+    outs = []
+    for single_steps in (False, True):
+        m = gb.baroclinic_instability_model(gb.GPU(), Nx, Ny, Nz, dt=dt, depth=depth, grid_type=grid_type, closure=CATKE())
+        start(m, m, wind=-1e-4, heat=5e-5)
+        gb.first_time_step(m)
+        if single_steps:
+            for _ in range(7):
+                gb.time_step(m)
+                assert np.array_equal(m.backend.get_field("previous_u", True), m.backend.get_field("u", True))
+            gb.update_state(m)          # (twice in a row: the second e step sees u- = u)
+        else:
+            gb.loop(m, 7)
+            gb.update_state(m)
+        outs.append({n: m.backend.get_field(n, True) for n in names})
+        m.backend.close()
+    bad = [n for n in names if not np.array_equal(outs[0][n], outs[1][n])]
+    assert not bad, [(n, rel(outs[0][n], outs[1][n])) for n in bad]
+    assert np.array_equal(outs[0]["previous_v"], outs[0]["v"]) and np.abs(outs[0]["u"]).max() > 1e-3
 
 
 def test_catke_schedules_agree():
