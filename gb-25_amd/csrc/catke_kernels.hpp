@@ -454,6 +454,8 @@ struct ImplicitVarFields {
   real dt, C1, C2;
   real* sum[2];                // column integrals of the new u, v (the look-ahead's predate the solve)
   int kchunks;
+  real* P;                     // null, or the look-ahead's chunk sums (UvAhead::P): the sums of the NEW u dz, v dz per chunk of levels
+  int plane2;                  // replace the look-ahead's there (w on the fly: k_w_bases takes w at the chunk boundaries from them)
   int z0;                      // first slice of the launch (MODE 1: 0 = T with S [+ e], 1 = e alone)
   real* gam[2];                // streaming kernel only: the factors of the two blockIdx.z slices ((c,f,c)-shaped scratch)
 };
@@ -469,14 +471,16 @@ __device__ __forceinline__ int implicit_var_first_level(const Grid& g, int z, in
 }
 // column integral of u / v with the chunked association every other producer of these sums uses
 template <class Get>
-__device__ __forceinline__ real implicit_var_colsum(const Grid& g, int kchunks, Get x) {
+__device__ __forceinline__ real implicit_var_colsum(const Grid& g, int kchunks, Get x, real* part = nullptr, size_t pstride = 0, bool zero = false) {
   const int Nz = g.Nz, klen = (Nz + kchunks - 1) / kchunks;
   real tot = real(0.), q = real(0.);
-  int kk = 0;
+  int kk = 0, ch = 0;
   for (int k = 0; k < Nz; k++) {
     q = (kk == 0) ? g.dzc[k] * x(k) : rfma(g.dzc[k], x(k), q);
     if (++kk == klen || k == Nz - 1) {
       tot = (k < klen) ? q : tot + q;
+      if (part) part[(size_t)ch * pstride] = zero ? real(0.) : q;   // (the chunk's own sum: see ImplicitVarFields::P)
+      ch++;
       kk = 0;
     }
   }
@@ -548,13 +552,16 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_var(Grid g, ImplicitV
   if (MODE == 0 && A.sum[z] != nullptr) {   // (before the stores: the table loads below must not wait behind them)
     const int klen = (Nz + A.kchunks - 1) / A.kchunks;
     real q = real(0.);
-    int kk = 0;
+    int kk = 0, ch = 0;
+    const bool wall = vsh && j == g.jws;
 #pragma unroll
     for (int k = 0; k < NZT; k++)
       if (k < Nz) {
         q = (kk == 0) ? g.dzc[k] * a[k] : rfma(g.dzc[k], a[k], q);
         if (++kk == klen || k == Nz - 1) {
           tot = (k < klen) ? q : tot + q;
+          if (A.P) A.P[((size_t)(2 + z) * A.kchunks + ch) * A.plane2 + o2] = wall ? real(0.) : q;
+          ch++;
           kk = 0;
         }
       }
@@ -626,8 +633,10 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_var_stream(Grid g, Im
     }
   }
   if (MODE == 0 && A.sum[z] != nullptr) {
-    const real tot = implicit_var_colsum(g, A.kchunks, [&](int k) { return Fa[o0 + k * pl]; });
-    A.sum[z][o2] = (vsh && j == g.jws) ? real(0.) : tot;
+    const bool wall = vsh && j == g.jws;
+    const real tot = implicit_var_colsum(g, A.kchunks, [&](int k) { return Fa[o0 + k * pl]; },
+                                         A.P ? A.P + (size_t)(2 + z) * A.kchunks * A.plane2 + o2 : nullptr, (size_t)A.plane2, wall);
+    A.sum[z][o2] = wall ? real(0.) : tot;
   }
 }
 

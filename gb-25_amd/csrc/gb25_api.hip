@@ -1890,16 +1890,22 @@ gb25_status catke_tendency_impl(gb25_model* m) {
     const int nbx = (g.Nx + V3_PAIR - 1) / V3_PAIR, nby = (g.Ny + 3) / 4, kchunks = std::max(1, g.Nz / m->trc_chunk_levels);
     const int nb = nbx * nby * kchunks;
     constexpr int TW = sizeof(real) == 8 ? 2 : 4;
-    void (*kt)(Grid, const real*, const real*, const real*, const real*, real*, int, int, int) =
+    const bool fly = m->w_fly_now;   // (w on the fly: the field w is stale, the kernel carries w up its chunks like the two others)
+    if (fly && m->tracer_order != 5) return fail(m, GB25_ERR_STATE, "internal: no instance of the e advection carries w with WENO(order = 7)");
+    void (*kt)(Grid, const real*, const real*, const real*, const real*, real*, int, int, int, LazyCorr) =
         m->tracer_order == 7
             ? (g.cv.on       ? k_tracer_tendencies_single<TW, true, true, 7>
                : m->immersed ? k_tracer_tendencies_single<TW, true, false, 7>
                              : k_tracer_tendencies_single<TW, false, false, 7>)
+        : fly ? (g.cv.on       ? k_tracer_tendencies_single<TW, true, true, 5, true>
+                 : m->immersed ? k_tracer_tendencies_single<TW, true, false, 5, true>
+                               : k_tracer_tendencies_single<TW, false, false, 5, true>)
         : g.cv.on       ? k_tracer_tendencies_single<TW, true, true, 5>
         : m->immersed ? k_tracer_tendencies_single<TW, true, false, 5>
                       : k_tracer_tendencies_single<TW, false, false, 5>;
+    const LazyCorr lz{m->corr[0].d, m->corr[1].d, m->wbase, g.sx * g.sy_v};
     hipLaunchKernelGGL(kt, dim3(nb), dim3(64, 4), 0, m->stream, g, m->f[GB25_U].d, m->f[GB25_V].d, m->f[GB25_W].d, m->f[GB25_E].d,
-                       m->f[GB25_GN_E].d, nbx, kchunks, nb);
+                       m->f[GB25_GN_E].d, nbx, kchunks, nb, lz);
   }
   dim3 b(64, 4);
   hipLaunchKernelGGL(k_catke_add_top_source, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g, m->catke_src.d, m->f[GB25_GN_E].d);
@@ -1929,6 +1935,8 @@ gb25_status catke_implicit_impl(gb25_model* m, int mode, real dt, real chi, int 
   A.sum[0] = mode == 0 ? m->colsum[0].d : nullptr;
   A.sum[1] = mode == 0 ? m->colsum[1].d : nullptr;
   A.kchunks = mom_kchunks(m);
+  A.P = mode == 0 ? m->uv_partials : nullptr;   // (null without the look-ahead of u, v)
+  A.plane2 = g.sx * g.sy_v;
   const bool imm = m->immersed;
   void (*kern)(Grid, ImplicitVarFields);
 #define VARK(NZT) (mode == 0 ? (imm ? k_implicit_vertical_var<NZT, true, 0> : k_implicit_vertical_var<NZT, false, 0>) \
@@ -2047,12 +2055,15 @@ inline bool wfly_sweep_ok(const gb25_model* m) {
   // (like the corrector inside its consumers it rides on the sub-cycle look-ahead -- on by default from 8 M cells on: small models
   // keep the stand-alone w, bit for bit what their decompositions compute)
   return m->w_fly && m->baro_ahead != 0 && !m->slab && !m->coupled && m->bottom_drag == 0 && m->tracer_order == 5 && m->two_streams && m->kernel_gen >= 2 &&
-         m->ab2_ahead == 1 && !m->ptr_exposed && m->nu == 0 && m->kappa == 0 && !m->catke &&
+         m->ab2_ahead == 1 && !m->ptr_exposed && m->nu == 0 && m->kappa == 0 &&
+         // (closure = CATKE: the implicit solve of u, v that follows the AB2 update rewrites the look-ahead's chunk sums with
+         // those of the velocities it leaves: catke_implicit_impl, ImplicitVarFields::P; e is advected by a kernel that carries w too)
          std::max(1, m->g.Nz / m->trc_chunk_levels) == mom_kchunks(m);
 }
 
 inline bool lazy_through_tracers_ok(const gb25_model* m) {
-  return m->lazy_corrector && wfly_sweep_ok(m) && (m->immersed || m->g.cv.on) && m->tracers_first != 0 && m->pressure_bits == 64;
+  // (not with a closure: its kernels read u, v ahead of the tracer kernel that would write the corrected ones)
+  return m->lazy_corrector && wfly_sweep_ok(m) && !m->catke && (m->immersed || m->g.cv.on) && m->tracers_first != 0 && m->pressure_bits == 64;
 }
 
 // ... and a slab of an x decomposition or a rank of a 2-D one: the same kernels without the halo images (its halos come with the

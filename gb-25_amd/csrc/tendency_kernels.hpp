@@ -901,11 +901,13 @@ __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_v5(Grid g, cons
 // instruction idle: 1.73 ms for the third tracer against 1.95 ms for the first two at 1440 x 720 x 60 with WENO(order = 7).)
 // No look-ahead, no halo writes, no flux boundary condition: e has none of them.
 // =============================================================================================
+// WFLY: w is not read (the field is stale in a step that carries w inside its tendency kernels): Az w of both columns from the
+// divergence of their transports, the east faces' from the next lane, starting from lz.wbase -- as tracer_tile does.
 constexpr int V3_PAIR = 2 * V3_OUT;   // outputs per wavefront
-template <bool IMM, bool CURV, int ORD>
+template <bool IMM, bool CURV, int ORD, bool WFLY = false>
 __device__ __forceinline__ void tracer_tile_single(const Grid& g, const real* __restrict__ u, const real* __restrict__ v,
                                                    const real* __restrict__ w, const real* __restrict__ E,
-                                                   real* __restrict__ GE, int nbx, int kchunks, const int L) {
+                                                   real* __restrict__ GE, int nbx, int kchunks, const int L, const LazyCorr& lz) {
   constexpr int R = ORD == 7 ? 4 : 3;
   const int bx = L % nbx, r = L / nbx;
   const int kc = r % kchunks, by = r / kchunks;
@@ -961,8 +963,10 @@ __device__ __forceinline__ void tracer_tile_single(const Grid& g, const real* __
 #pragma unroll
   for (int m = 0; m < 2 * R + 1; m++) cz[m] = ld2(bE, vo0, vo1, CZ(m));
   real2v fz;
+  real2v Azw_cur;                              // WFLY: Az w on the bottom face of the current level
   {
-    const real2v Azw = Az * ld2(bw, vo0, vo1, cc);
+    const real2v Azw = WFLY ? Az * v2(lz.wbase[(long)kc * lz.wplane + om0], lz.wbase[(long)kc * lz.wplane + om1]) : Az * ld2(bw, vo0, vo1, cc);
+    Azw_cur = Azw;
     fz = Azw * biased_pair<ORD>(zorder(k0 - kbt[0], Nzc0), zorder(k0 - kbt[1], Nzc1), Azw.x > real(0.), Azw.y > real(0.), cz);
   }
   for (int k = k0; k < k1; k++) {
@@ -976,7 +980,13 @@ __device__ __forceinline__ void tracer_tile_single(const Grid& g, const real* __
     const real2v Axu = dy * dz * ld2(bu, vo0, vo1, cc);
     const real2v Ays = dxf_s * dz * ld2(bv, vv0, vv1, 0);
     const real2v Ayn = dxf_n * dz * ld2(bv, vv0, vv1, sx * SZ);
-    const real2v Azw = Az * ld2(bw, vo0, vo1, cc + pc * SZ);
+    real2v Azw;
+    if constexpr (WFLY) {
+      Azw = Azw_cur - ((v2(__shfl_down(Axu.x, 1), __shfl_down(Axu.y, 1)) - Axu) + (Ayn - Ays));
+      Azw_cur = Azw;
+    } else {
+      Azw = Az * ld2(bw, vo0, vo1, cc + pc * SZ);
+    }
     real2v q[2 * R + 1];
 #pragma unroll
     for (int m = 0; m < 2 * R; m++) q[m] = ld2(bE, vo0 + m * SZ, vo1 + m * SZ, (R * pc + R * sx) * SZ);
@@ -1002,13 +1012,13 @@ __device__ __forceinline__ void tracer_tile_single(const Grid& g, const real* __
 #undef CZ
 #undef CY
 }
-template <int MINW, bool IMM, bool CURV, int ORD>
+template <int MINW, bool IMM, bool CURV, int ORD, bool WFLY = false>
 __global__ __launch_bounds__(256, MINW) void k_tracer_tendencies_single(Grid g, const real* __restrict__ u,
                                                                        const real* __restrict__ v,
                                                                        const real* __restrict__ w,
                                                                        const real* __restrict__ E, real* __restrict__ GE,
-                                                                       int nbx, int kchunks, int nb) {
-  tracer_tile_single<IMM, CURV, ORD>(g, u, v, w, E, GE, nbx, kchunks, xcd_remap(blockIdx.x, nb));
+                                                                       int nbx, int kchunks, int nb, LazyCorr lz) {
+  tracer_tile_single<IMM, CURV, ORD, WFLY>(g, u, v, w, E, GE, nbx, kchunks, xcd_remap(blockIdx.x, nb), lz);
 }
 
 }  // namespace gb25

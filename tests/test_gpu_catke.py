@@ -208,6 +208,44 @@ def test_previous_velocities_move_by_pointer_exchange(grid_type):
     assert np.array_equal(outs[0]["previous_v"], outs[0]["v"]) and np.abs(outs[0]["u"]).max() > 1e-3
 
 
+@pytest.mark.parametrize("float_type", ["Float32", "Float64"])
+@pytest.mark.parametrize("grid_type,shape", [("simple_lat_lon", (150, 70, 24)), ("gaussian_islands_lat_lon", (150, 70, 24)),
+                                             ("gaussian_islands", (144, 64, 24))])
+def test_w_on_the_fly_with_catke(grid_type, shape, float_type):
+    """w on the fly beside the corrector's sweep with the closure on: the implicit solve of u, v rewrites the look-ahead's chunk
+    sums with those of the velocities it leaves (k_w_bases takes w at the chunk boundaries from them) and the advection of e
+    carries w like the two other tendency kernels -- no k_compute_w launch.  Against the stand-alone w: round-off (the vertical
+    sum is associated by chunks), amplified by the closure's switches to what the fp32 story of the closure fields states."""
+    Nx, Ny, Nz = shape
+    eps = float(np.finfo(np.float32 if float_type == "Float32" else np.float64).eps)
+    depth = 4000.0 if "islands" in grid_type else 400.0
+    models = []
+    for fly in (0, 1):
+        m = gb.baroclinic_instability_model(gb.GPU(float_type=float_type), Nx, Ny, Nz, dt=300.0, depth=depth, grid_type=grid_type,
+                                            closure=CATKE(), options=dict(w_on_the_fly=fly, subcycle_lookahead=1))
+        start(m, m, wind=-1e-4, heat=5e-5)
+        gb.first_time_step(m)
+        m.backend.profile_enable(True)
+        m.backend.profile_reset()
+        gb.loop(m, 12)
+        models.append(m)
+    a, b = models
+    assert a.backend.profile_get("compute_w")[0] >= 12 and b.backend.profile_get("compute_w")[0] <= 3
+    for n in ("u", "v", "T", "S", "eta", "U", "V", "Gn.u", "Gn.T", "Gn.e"):
+        x, y = a.backend.get_field(n, True), b.backend.get_field(n, True)
+        # (Float64: 1e-12 measured on the grids with mountains -- the closure's switches sit on top of the round-off of w)
+        assert np.isfinite(y).all() and rel(x, y) < (4000 * eps if float_type == "Float32" else 1e-11), (n, rel(x, y))
+    assert rel(a.backend.get_field("w", True), b.backend.get_field("w", True)) < (400 * eps if float_type == "Float32" else 1e-11)
+    # (Float32: N^2 of a mixed layer is a difference of temperatures a few ulps apart, and the stratification-limited lengths go
+    # with N^-1 -- the distances are those of the Float32 story of the closure fields, profiles/r04_catke_fp32.json)
+    got = {n: rel(a.backend.get_field(n, True), b.backend.get_field(n, True)) for n in ("e", "kappa_u", "kappa_c", "kappa_e", "Le")}
+    print(got)
+    lim = dict(e=2e-3, kappa_u=3e-2, kappa_c=3e-2, kappa_e=3e-2, Le=0.3) if float_type == "Float32" else dict.fromkeys(got, 1e-8)
+    assert all(np.isfinite(b.backend.get_field(n, True)).all() and got[n] < lim[n] for n in got), got
+    for m in models:
+        m.backend.close()
+
+
 def test_catke_schedules_agree():
     outs = []
     for opts in (dict(), dict(two_streams=0), dict(ab2_lookahead=0)):
