@@ -1167,7 +1167,11 @@ gb25_status momentum_impl(gb25_model* m, int part = 0) {
     if (m->uv_lazy && !(ahead && (m->slab || (nx.fold && part == 0))))
       return fail(m, GB25_ERR_STATE, "internal: uncorrected velocities in a step whose momentum kernel cannot correct them");
     const bool drag = m->bottom_drag != 0;
-    auto k5 = drag ? (g.cv.on ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, true, false, true> : k_momentum_tendencies_v5<MW, TYm, false, true, true, false, true>)
+    const bool fly_sweep = ahead && m->w_fly_now && part == 0 && !m->uv_lazy;   // (w on the fly beside the corrector's sweep)
+    auto k5 = (drag && fly_sweep) ? (g.cv.on ? k_momentum_tendencies_v5<MW, TYm, true, true, true, false, true, true>
+                                     : m->immersed ? k_momentum_tendencies_v5<MW, TYm, true, true, false, false, true, true>
+                                                   : k_momentum_tendencies_v5<MW, TYm, true, false, false, false, true, true>)
+              : drag ? (g.cv.on ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, true, false, true> : k_momentum_tendencies_v5<MW, TYm, false, true, true, false, true>)
                       : m->immersed ? (ahead ? k_momentum_tendencies_v5<MW, TYm, true, true, false, false, true> : k_momentum_tendencies_v5<MW, TYm, false, true, false, false, true>)
                                     : (ahead ? k_momentum_tendencies_v5<MW, TYm, true, false, false, false, true> : k_momentum_tendencies_v5<MW, TYm, false, false, false, false, true>))
               : (m->uv_lazy && ahead && m->w_fly_now) ? k_momentum_tendencies_v5<MW, TYm, true, false, false, true, false, true>
@@ -1257,7 +1261,11 @@ gb25_status tracers_impl(gb25_model* m) {
       return fail(m, GB25_ERR_STATE, "internal: uncorrected velocities in a step whose tracer kernel cannot correct them");
     constexpr int TWL = sizeof(real) == 8 ? 3 : 6;   // (the headline instance: held to 80 VGPRs, six waves per SIMD)
     constexpr int TW7 = sizeof(real) == 8 ? 2 : 5;   // (the order-7 windows: 9 register pairs per direction; 90-96 VGPRs without a spill)
-    auto kern = m->tracer_order == 7
+    auto kern = (m->tracer_order == 7 && ahead && m->w_fly_now)   // (w on the fly beside the corrector's sweep, WENO(order = 7))
+                    ? (g.cv.on ? k_tracer_tendencies_v5<TW7, true, true, false, true, false, 7, true>
+                       : m->immersed ? k_tracer_tendencies_v5<TW7, true, true, false, false, false, 7, true>
+                                     : k_tracer_tendencies_v5<TW7, true, false, false, false, false, 7, true>)
+                : m->tracer_order == 7
                     ? (g.cv.on ? (ahead ? k_tracer_tendencies_v5<TW7, true, true, false, true, false, 7> : k_tracer_tendencies_v5<TW7, false, true, false, true, false, 7>)
                        : m->immersed ? (ahead ? k_tracer_tendencies_v5<TW7, true, true, false, false, false, 7> : k_tracer_tendencies_v5<TW7, false, true, false, false, false, 7>)
                                      : (ahead ? k_tracer_tendencies_v5<TW7, true, false, false, false, false, 7> : k_tracer_tendencies_v5<TW7, false, false, false, false, false, 7>))
@@ -1891,9 +1899,12 @@ gb25_status catke_tendency_impl(gb25_model* m) {
     const int nb = nbx * nby * kchunks;
     constexpr int TW = sizeof(real) == 8 ? 2 : 4;
     const bool fly = m->w_fly_now;   // (w on the fly: the field w is stale, the kernel carries w up its chunks like the two others)
-    if (fly && m->tracer_order != 5) return fail(m, GB25_ERR_STATE, "internal: no instance of the e advection carries w with WENO(order = 7)");
     void (*kt)(Grid, const real*, const real*, const real*, const real*, real*, int, int, int, LazyCorr) =
-        m->tracer_order == 7
+        (m->tracer_order == 7 && fly)
+            ? (g.cv.on       ? k_tracer_tendencies_single<TW, true, true, 7, true>
+               : m->immersed ? k_tracer_tendencies_single<TW, true, false, 7, true>
+                             : k_tracer_tendencies_single<TW, false, false, 7, true>)
+        : m->tracer_order == 7
             ? (g.cv.on       ? k_tracer_tendencies_single<TW, true, true, 7>
                : m->immersed ? k_tracer_tendencies_single<TW, true, false, 7>
                              : k_tracer_tendencies_single<TW, false, false, 7>)
@@ -2054,7 +2065,9 @@ inline bool lazy_through_tracers_ok(const gb25_model* m);
 inline bool wfly_sweep_ok(const gb25_model* m) {
   // (like the corrector inside its consumers it rides on the sub-cycle look-ahead -- on by default from 8 M cells on: small models
   // keep the stand-alone w, bit for bit what their decompositions compute)
-  return m->w_fly && m->baro_ahead != 0 && !m->slab && !m->coupled && m->bottom_drag == 0 && m->tracer_order == 5 && m->two_streams && m->kernel_gen >= 2 &&
+  // (the sweep leaves corrected velocities in memory: the similarity-theory fluxes of a coupled model, the quadratic bottom drag and
+  // WENO(order = 7) tracers -- the data-free climate model -- read them like anything else; instances of the three tendency kernels exist)
+  return m->w_fly && m->baro_ahead != 0 && !m->slab && m->two_streams && m->kernel_gen >= 2 &&
          m->ab2_ahead == 1 && !m->ptr_exposed && m->nu == 0 && m->kappa == 0 &&
          // (closure = CATKE: the implicit solve of u, v that follows the AB2 update rewrites the look-ahead's chunk sums with
          // those of the velocities it leaves: catke_implicit_impl, ImplicitVarFields::P; e is advected by a kernel that carries w too)
@@ -2063,7 +2076,8 @@ inline bool wfly_sweep_ok(const gb25_model* m) {
 
 inline bool lazy_through_tracers_ok(const gb25_model* m) {
   // (not with a closure: its kernels read u, v ahead of the tracer kernel that would write the corrected ones)
-  return m->lazy_corrector && wfly_sweep_ok(m) && !m->catke && (m->immersed || m->g.cv.on) && m->tracers_first != 0 && m->pressure_bits == 64;
+  return m->lazy_corrector && wfly_sweep_ok(m) && !m->catke && !m->coupled && m->bottom_drag == 0 && m->tracer_order == 5 &&
+         (m->immersed || m->g.cv.on) && m->tracers_first != 0 && m->pressure_bits == 64;
 }
 
 // ... and a slab of an x decomposition or a rank of a 2-D one: the same kernels without the halo images (its halos come with the

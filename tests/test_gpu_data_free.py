@@ -74,6 +74,37 @@ def test_the_coupled_model_steps_like_the_oracle(float_type):
     assert np.abs(r.backend.top_flux("u")).max() > 1e-6
 
 
+@pytest.mark.parametrize("float_type", ["Float64", "Float32"])
+def test_w_on_the_fly_in_the_coupled_model(float_type):
+    """The data-free climate model with w on the fly beside the corrector's sweep (what a single domain of 8 M cells and more
+    runs between the steps of a loop): the instances of the three tendency kernels with the quadratic bottom drag, WENO(order = 7)
+    tracers and the closure's e carry w up their chunks, no k_compute_w launch.  Against the stand-alone w: round-off, with the
+    closure's switches on top (the limits of tests/test_gpu_catke.py::test_w_on_the_fly_with_catke)."""
+    eps = float(np.finfo(np.float32 if float_type == "Float32" else np.float64).eps)
+    models = []
+    for fly in (0, 1):
+        m = gb.data_free_ocean_climate_model_init(gb.GPU(float_type=float_type), resolution=4, Nz=24, dt=30.0,
+                                                  options=dict(w_on_the_fly=fly, subcycle_lookahead=1))
+        gb.first_time_step(m)
+        m.backend.profile_enable(True)
+        m.backend.profile_reset()
+        gb.loop(m, 12)
+        models.append(m)
+    a, b = models
+    assert a.backend.profile_get("compute_w")[0] >= 12 and b.backend.profile_get("compute_w")[0] <= 3
+    got = {n: rel(a.backend.get_field(n, True), b.backend.get_field(n, True))
+           for n in ("u", "v", "w", "T", "S", "eta", "Gn.u", "Gn.T", "Gn.e", "e", "kappa_u", "kappa_c", "Le")}
+    print(got)
+    loose = dict(e=2e-3, kappa_u=3e-2, kappa_c=3e-2, Le=0.3) if float_type == "Float32" else dict.fromkeys(("e", "kappa_u", "kappa_c", "Le"), 1e-8)
+    for n, r_ in got.items():
+        assert np.isfinite(b.backend.get_field(n, True)).all()
+        assert r_ < loose.get(n, 4000 * eps if float_type == "Float32" else 1e-11), (n, got)
+    for n in ("u", "T"):
+        assert rel(a.backend.top_flux(n), b.backend.top_flux(n)) < (1e-4 if float_type == "Float32" else 1e-10)
+    for m in models:
+        m.backend.close()
+
+
 def test_coupled_slabs_are_the_single_domain_bit_for_bit():
     """The fluxes of a slab's first halo column and fold row are computed from exchanged halos, never exchanged."""
     from gb25_amd.distributed import LocalSlabEnsemble
