@@ -203,6 +203,7 @@ struct gb25_model {
   Field catke_b, catke_scratch;      // N^2 on the faces; the unused half of the two-wide tracer kernel's output
   gb25_catke_parameters catke_par;   // (gb25_default_catke_parameters at creation)
   Field catke_src;                   // 2-D: the top boundary condition of e (surface TKE flux / dz of the top cell)
+  bool implicit_lds_raised[2] = {false, false};   // k_implicit_vertical's dynamic-LDS attribute (Nz > 128), likewise
   bool whole_attr_set[2][2] = {{false, false}, {false, false}};   // k_barotropic_whole's dynamic-LDS attribute, per instance, on THIS model's device
   int comm_timeout_s = 180;          // option COMM_TIMEOUT_SECONDS
   bool roctx_ranges = true;          // option ROCTX_RANGES
@@ -1390,10 +1391,10 @@ gb25_status implicit_vertical_impl(gb25_model* m, int kind, real dt) {
   const size_t lds = (size_t)(2 * T + 2) * g.Nz * sizeof(real);
   if (lds > 160 * 1024) return fail(m, GB25_ERR_INVALID_ARGUMENT, "the implicit vertical solve keeps a column in LDS: Nz = %d is too deep", g.Nz);
   auto kern = m->immersed ? k_implicit_vertical<true> : k_implicit_vertical<false>;
-  static bool raised[2] = {false, false};
-  if (lds > 64 * 1024 && !raised[m->immersed ? 1 : 0]) {
+  // (a function attribute is set per device: the flag lives in the model, not in the process)
+  if (lds > 64 * 1024 && !m->implicit_lds_raised[m->immersed ? 1 : 0]) {
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    raised[m->immersed ? 1 : 0] = true;
+    m->implicit_lds_raised[m->immersed ? 1 : 0] = true;
   }
   Timed tm(m, kind == 0 ? GB25_K_AB2_VELOCITIES : GB25_K_AB2_TRACERS);
   hipLaunchKernelGGL(kern, dim3((g.Nx + T - 1) / T, kind == 0 ? v_rows(g) : g.Ny, 2), dim3(T), lds, m->stream, g, a, b, kind, K, K,

@@ -170,3 +170,37 @@ def test_slabs_at_the_benchmark_size_bitwise():
             got = ens.gather(n)
             assert np.array_equal(got, ref[n]), (P, n, float(np.abs(got - ref[n]).max()))
         ens.close()
+
+
+def test_slabs_with_their_default_options_at_the_benchmark_size():
+    """What `bench.py --gpus N` runs: the ranks with their DEFAULT options -- the corrector inside its consumers, w on the fly,
+    chunks of 24 levels on the 720-column ranks of N = 2 and 12 on the narrower ones -- against the single domain with its
+    defaults.  Round-off, not bits (w on the fly associates the vertical sum by chunks, and the ranks' chunk bases come from
+    exchanged sums): every field within 2e-5 of its norm after first_time_step! + 5 steps, finite, the look-ahead route taken."""
+    from gb25_amd.distributed import LocalSlabEnsemble
+    names = ("u", "v", "w", "T", "S", "eta", "U", "V", "Gn.u", "Gn.T")
+    single = fresh_model()
+    gb.set_baroclinic_instability(single)
+    u0 = (1e-2 * counter_rng((NX, NY, NZ), 42, 1)).astype(np.float32)
+    v0 = (1e-2 * counter_rng((NX, NY + 1, NZ), 42, 2)).astype(np.float32)
+    single.set(u=u0, v=v0)
+    T0, S0 = single.tracers.T.interior, single.tracers.S.interior
+    gb.first_time_step(single)
+    gb.loop(single, 5)
+    assert single.backend.get_option("momentum_chunk_levels") == 24
+    ref = {n: single.backend.get_field(n, False) for n in names}
+    single.backend.close()
+    for P, chunk in ((2, 24), (8, 12)):
+        ens = LocalSlabEnsemble(NX, NY, NZ, P, dt=DT)
+        for n, a in (("u", u0), ("v", v0), ("T", T0), ("S", S0)):
+            ens.scatter(n, a)
+        ens.first_time_step()
+        ens.loop(5)
+        assert all(b.get_option("momentum_chunk_levels") == chunk and b.get_option("tracer_chunk_levels") == chunk for b in ens.backends)
+        assert all(b.lookahead_state() == (True, True) for b in ens.backends), P
+        for n in names:
+            got = ens.gather(n).astype(np.float64)
+            assert np.isfinite(got).all(), (P, n)
+            d = np.linalg.norm((got - ref[n]).ravel()) / np.linalg.norm(ref[n].astype(np.float64).ravel())
+            assert d < 2e-5, (P, n, d)
+        ens.close()
