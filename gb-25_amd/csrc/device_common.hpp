@@ -110,6 +110,13 @@ __device__ __forceinline__ int iv(const Grid& g, int i, int j, int k) {
 }
 __device__ __forceinline__ int i2(const Grid& g, int i, int j) { return (i + g.H) + g.sx * (j + g.H); }
 
+// A wave-uniform element of a table no kernel writes (the vertical spacings): through the constant address space it is a scalar
+// load (s_load_dword, lgkmcnt).  As a plain load inside a loop that also stores, clang makes it a VECTOR load -- and the wait for
+// it (vmcnt counts in order, and loads issued under an exec mask may not have been issued at all) waits for every load ahead of
+// it too: in the tendency kernels that was the whole batch of the next level's loads, every level.
+__device__ __forceinline__ real uniform_at(const real* p, int k) {
+  return *(const __attribute__((address_space(4))) real*)(p + k);
+}
 __device__ __forceinline__ float rfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double rfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 // ab2_step_field!: phi + dt (C1 G^n - C2 G^-).  Spelled with explicit FMAs so that every kernel that advances a

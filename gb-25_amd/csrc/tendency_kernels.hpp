@@ -353,7 +353,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
 
   for (int k = k0; k < k1; k++) {
     const int par = k & 1;
-    const real dz = g.dzc[k];
+    const real dz = uniform_at(g.dzc, k);
     // Wave priority by phase: the short phases that end in a barrier (the loads of the next level, the derived tiles; at the end of
     // the iteration the stash of the loaded tiles) go ahead of the long arithmetic phase of the three other blocks on the CU -- a
     // wave that reaches its barrier late holds up its whole block, a wave in the arithmetic phase that issues a few cycles later
@@ -364,12 +364,8 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     const bool more = (k + 1 < k1);
     if (more) fetch(k + 1, ob + (unsigned)pc * SZ);
     real unew = at(u, ob + 4u * (unsigned)pc * SZ), vnew = at(v, obv + 4u * (unsigned)pv * SZ);
-    if constexpr (LAZY) {
-      if (k + 4 <= g.Nz) {
-        unew = unew + cr.du[ty + 3][tx + 3];
-        vnew = vnew + cr.dv[ty + 3][tx + 3];
-      }
-    }
+    // (LAZY: their correction is added where they are consumed, at the end of the iteration -- added here, the wait for the two
+    // loads just issued was a wait for the whole batch of the next level's tile loads: the staging's pipeline, undone)
     // ---- phase 1: derived quantities, once per point.  (row, column) of a point and the row metrics come from the
     // small LDS tables filled once per block: an integer division and five global loads per point and level otherwise
     auto derive = [&](int e, int& py, int& px) -> real {   // returns the point's divergence piece DU + DV
@@ -436,7 +432,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
 #define DC(A, di, dj) lds.A[ty + 3 + (dj)][tx + 3 + (di)]
     real gu, gv;
     const int ozt = biased_order_face(k + 1 - kbt, Nzc);
-    const real rdz = g.rdzc[k];
+    const real rdz = uniform_at(g.rdzc, k);
     level_orders(k);
     {
       // Packed evaluation: the eight reconstructions of the cell are done as four PAIRS that share stencil shape
@@ -642,6 +638,12 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
       uz[m] = uz[m + 1];
       vz[m] = vz[m + 1];
     }
+    if constexpr (LAZY) {
+      if (k + 4 <= g.Nz) {
+        unew = unew + cr.du[ty + 3][tx + 3];
+        vnew = vnew + cr.dv[ty + 3][tx + 3];
+      }
+    }
     uz[6] = unew;
     vz[6] = vnew;
     __builtin_amdgcn_s_setprio(3);
@@ -801,13 +803,23 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
   // FOLD: does this wave hold cells with a periodic x image or a y layer to write?
   const bool fold_row = FOLD && (j == 0 || j == g.Ny - 1 || bx * V3_OUT < g.H || bx * V3_OUT + V3_OUT > g.Nx - g.H);
   for (int k = k0; k < k1; k++) {
-    const real dz = g.dzc[k];
+    const real dz = uniform_at(g.dzc, k), rdz = uniform_at(g.rdzc, k);   // (scalar loads: device_common.hpp)
     if (IMM) {
       ox = ORD == 7 ? order_from7(k, KX7, KX5, KX3) : order_from(k, KX5, KX3);
       oys = ORD == 7 ? order_from7(k, KY7, KY5, KY3) : order_from(k, KY5, KY3);
       oyn = ORD == 7 ? order_from7(k, KY7n, KY5n, KY3n) : order_from(k, KY5n, KY3n);
     }
     real u_l = bload(bu, vo, cc), v_s = bload(bv, vov, 0), v_n = bload(bv, vov, sx * SZ);
+    // Every load of the level is issued HERE, ahead of the first wait: the newest value of the vertical window (needed by the next
+    // level) and, AHEAD, the old tendencies the new T, S are advanced with.  Loaded where they are used -- the window value behind
+    // the level's stores, G^- inside the `writes` branch, one after the other -- each cost the wave a memory latency of its own:
+    // four sleeps per level instead of one (tools/kernel_isa.py: s_waitcnt vmcnt(0) x 4 in the loop).
+    const real2v cz_next = v2(bload(bT, vo, CZ(2 * R) + pc * SZ), bload(bS, vo, CZ(2 * R) + pc * SZ));
+    real gmT = real(0.), gmS = real(0.);
+    if (AHEAD) {
+      gmT = bload(bGmT, vo, cc);
+      gmS = bload(bGmS, vo, cc);
+    }
     if (LAZY) {
       u_l = (!IMM || k >= KPUl) ? u_l + du_l : u_l;
       v_s = (!IMM || k >= KPVs) ? v_s + dv_s : v_s;
@@ -829,6 +841,9 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
     const real2v fx = Axu * recon(IMM ? ox : ORD, Axu > real(0.), q);
 #pragma unroll
     for (int m = 0; m < 2 * R + 1; m++) q[m] = v2(bload(bT, vo, CY(m)), bload(bS, vo, CY(m)));
+    // (the two ends of the window are used by the full-order branch of one reconstruction each: left alone, the compiler sinks
+    // their loads INTO that branch -- the common one -- and waits for each separately: two more sleeps per level)
+    asm volatile("" : "+v"(q[0]), "+v"(q[2 * R]));
     const real2v fs = Ays * recon(oys, Ays > real(0.), q);
     const real2v fn = Ayn * recon(oyn, Ayn > real(0.), q + 1);
     // top face from the vertical window
@@ -837,13 +852,13 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
     // east faces = west faces of the next lane
     const real2v fe = v2(__shfl_down(fx.x, 1), __shfl_down(fx.y, 1));
     if (writes) {
-      const real rV = razc_j * g.rdzc[k];
+      const real rV = razc_j * rdz;
       real2v G = -(((fe - fx) + (fn - fs) + (ft - fz)) * rV);
       if (k == g.Nz - 1 && (g.top_flux[2] || g.top_flux[3]) && (!IMM || kbt < g.Nz)) {
         // compute_hydrostatic_boundary_tendency_contributions!: top flux boundary conditions (heat, fresh water)
         const int o2 = i2(g, i, j);
-        if (g.top_flux[2]) G.x = G.x - g.top_flux[2][o2] * g.rdzc[k];
-        if (g.top_flux[3]) G.y = G.y - g.top_flux[3][o2] * g.rdzc[k];
+        if (g.top_flux[2]) G.x = G.x - g.top_flux[2][o2] * rdz;
+        if (g.top_flux[3]) G.y = G.y - g.top_flux[3][o2] * rdz;
       }
       bstore(bGT, vo, cc, G.x);
       bstore(bGS, vo, cc, G.y);
@@ -852,8 +867,8 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
         bstore(bvc, vov, 0, v_s);
       }
       if (AHEAD) {   // T, S of the NEXT step while T, S (cz[3]) and the new tendency are in registers
-        const real tn = ab2_advance(cz[R].x, G.x, bload(bGmT, vo, cc), next.dt, next.C1, next.C2);
-        const real sn = ab2_advance(cz[R].y, G.y, bload(bGmS, vo, cc), next.dt, next.C1, next.C2);
+        const real tn = ab2_advance(cz[R].x, G.x, gmT, next.dt, next.C1, next.C2);
+        const real sn = ab2_advance(cz[R].y, G.y, gmS, next.dt, next.C1, next.C2);
         bstore(bTn, vo, cc, tn);
         bstore(bSn, vo, cc, sn);
         if (FOLD && (fold_row || k == 0 || k == g.Nz - 1)) {   // (wave-uniform: most waves and levels skip all of it)
@@ -877,7 +892,7 @@ __device__ __forceinline__ void tracer_tile(const Grid& g, const real* __restric
     vov += pv * SZ;
 #pragma unroll
     for (int m = 0; m < 2 * R; m++) cz[m] = cz[m + 1];
-    cz[2 * R] = v2(bload(bT, vo, CZ(2 * R)), bload(bS, vo, CZ(2 * R)));
+    cz[2 * R] = cz_next;
   }
 #undef CZ
 #undef CY
@@ -970,7 +985,7 @@ __device__ __forceinline__ void tracer_tile_single(const Grid& g, const real* __
     fz = Azw * biased_pair<ORD>(zorder(k0 - kbt[0], Nzc0), zorder(k0 - kbt[1], Nzc1), Azw.x > real(0.), Azw.y > real(0.), cz);
   }
   for (int k = k0; k < k1; k++) {
-    const real dz = g.dzc[k];
+    const real dz = uniform_at(g.dzc, k), rdz = uniform_at(g.rdzc, k);
     int ox0 = ORD, ox1 = ORD, os0 = oys_w, os1 = oys_w, on0 = oyn_w, on1 = oyn_w;
     if (IMM) {
       ox0 = ord3(k, KX7[0], KX5[0], KX3[0]); ox1 = ord3(k, KX7[1], KX5[1], KX3[1]);
@@ -999,7 +1014,7 @@ __device__ __forceinline__ void tracer_tile_single(const Grid& g, const real* __
                                              Azw.y > real(0.), cz + 1);
     // east faces = west faces of the next lane; lane 62's second column borders the NEXT wave's first, supplied by lane 63
     const real2v fe = v2(__shfl_down(fx.x, 1), __shfl_down(fx.y, 1));
-    const real2v G = -(((fe - fx) + (fn - fs) + (ft - fz)) * (razc_j * g.rdzc[k]));
+    const real2v G = -(((fe - fx) + (fn - fs) + (ft - fz)) * (razc_j * rdz));
     if (wr0) bstore(bG, vo0, cc, G.x);
     if (wr1) bstore(bG, vo1, cc, G.y);
     fz = ft;
