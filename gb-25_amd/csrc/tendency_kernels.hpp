@@ -992,6 +992,7 @@ __device__ __forceinline__ void tracer_tile_single(const Grid& g, const real* __
       os0 = ord3(k, KY7[0], KY5[0], KY3[0]); os1 = ord3(k, KY7[1], KY5[1], KY3[1]);
       on0 = ord3(k, KY7n[0], KY5n[0], KY3n[0]); on1 = ord3(k, KY7n[1], KY5n[1], KY3n[1]);
     }
+    const real2v cz_next = ld2(bE, vo0, vo1, CZ(2 * R) + pc * SZ);   // (with the level's other loads: see tracer_tile)
     const real2v Axu = dy * dz * ld2(bu, vo0, vo1, cc);
     const real2v Ays = dxf_s * dz * ld2(bv, vv0, vv1, 0);
     const real2v Ayn = dxf_n * dz * ld2(bv, vv0, vv1, sx * SZ);
@@ -1008,6 +1009,7 @@ __device__ __forceinline__ void tracer_tile_single(const Grid& g, const real* __
     const real2v fx = Axu * biased_pair<ORD>(ox0, ox1, Axu.x > real(0.), Axu.y > real(0.), q);
 #pragma unroll
     for (int m = 0; m < 2 * R + 1; m++) q[m] = ld2(bE, vo0, vo1, CY(m));
+    asm volatile("" : "+v"(q[0]), "+v"(q[2 * R]));   // (no load sunk into a branch of one reconstruction: see tracer_tile)
     const real2v fs = Ays * biased_pair<ORD>(os0, os1, Ays.x > real(0.), Ays.y > real(0.), q);
     const real2v fn = Ayn * biased_pair<ORD>(on0, on1, Ayn.x > real(0.), Ayn.y > real(0.), q + 1);
     const real2v ft = Azw * biased_pair<ORD>(zorder(k + 1 - kbt[0], Nzc0), zorder(k + 1 - kbt[1], Nzc1), Azw.x > real(0.),
@@ -1022,7 +1024,7 @@ __device__ __forceinline__ void tracer_tile_single(const Grid& g, const real* __
     vv0 += pv * SZ; vv1 += pv * SZ;
 #pragma unroll
     for (int m = 0; m < 2 * R; m++) cz[m] = cz[m + 1];
-    cz[2 * R] = ld2(bE, vo0, vo1, CZ(2 * R));
+    cz[2 * R] = cz_next;
   }
 #undef CZ
 #undef CY
