@@ -364,6 +364,8 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     const bool more = (k + 1 < k1);
     if (more) fetch(k + 1, ob + (unsigned)pc * SZ);
     real unew = at(u, ob + 4u * (unsigned)pc * SZ), vnew = at(v, obv + 4u * (unsigned)pv * SZ);
+    real gmu = real(0.), gmv = real(0.);
+    if (AHEAD) { gmu = at(next.GmU, ob); gmv = at(next.GmV, obv); }
     // (LAZY: their correction is added where they are consumed, at the end of the iteration -- added here, the wait for the two
     // loads just issued was a wait for the whole batch of the next level's tile loads: the staging's pipeline, undone)
     // ---- phase 1: derived quantities, once per point.  (row, column) of a point and the row metrics come from the
@@ -576,6 +578,13 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
 #undef WT
 #undef ZF
 #undef DC
+    if constexpr (LAZY) {
+      if (k + 4 <= g.Nz) {
+        unew = unew + cr.du[ty + 3][tx + 3];
+        vnew = vnew + cr.dv[ty + 3][tx + 3];
+      }
+    }
+    asm volatile("" : "+v"(unew), "+v"(vnew));
     if (k == g.Nz - 1 && (g.top_flux[0] || g.top_flux[1])) {
       // compute_hydrostatic_boundary_tendency_contributions!: top flux boundary conditions (wind stress)
       const int o2 = i2(g, ic_, jc_);
@@ -596,7 +605,7 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
       if (inside_u) put(Gu, ob, gu);
       put(Gv, obv, gv);
       if (AHEAD) {
-        const real au = rfma(next.C1, gu, -(next.C2 * at(next.GmU, ob))), av = rfma(next.C1, gv, -(next.C2 * at(next.GmV, obv)));
+        const real au = rfma(next.C1, gu, -(next.C2 * gmu)), av = rfma(next.C1, gv, -(next.C2 * gmv));
         const real un = rfma(next.dt, au, uz[3]);
         const real vn = (next.fold && j == 0) ? real(0.) : rfma(next.dt, av, vz[3]);   // (the southern wall face)
         if (inside_u) put(next.un, ob, un);
@@ -637,12 +646,6 @@ __global__ __launch_bounds__(V2_TX* V2_TY, MINW) void k_momentum_tendencies_v5(
     for (int m = 0; m < 6; m++) {
       uz[m] = uz[m + 1];
       vz[m] = vz[m + 1];
-    }
-    if constexpr (LAZY) {
-      if (k + 4 <= g.Nz) {
-        unew = unew + cr.du[ty + 3][tx + 3];
-        vnew = vnew + cr.dv[ty + 3][tx + 3];
-      }
     }
     uz[6] = unew;
     vz[6] = vnew;

@@ -1,5 +1,5 @@
 """Two builds of libgb25hip.so in ONE process on the same GPU, a fresh model per timed loop, alternating A, B, B, A, ...: the boxes of the pool (and
-one box from one process to the next) differ by more than most tuning steps gain.  python tools/ab_pair.py LIB_A LIB_B [Nx Ny Nz] [steps] [rounds]"""
+one box from one process to the next) differ by more than most tuning steps gain.  python tools/ab_pair.py LIB_A LIB_B [Nx Ny Nz] [steps] [rounds] [grid_type] [catke]"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gb25_amd.binding import Config
@@ -7,6 +7,8 @@ paths = [os.path.abspath(sys.argv[1]), os.path.abspath(sys.argv[2])]
 Nx, Ny, Nz = (int(x) for x in sys.argv[3:6]) if len(sys.argv) > 5 else (1440, 720, 48)
 steps = int(sys.argv[6]) if len(sys.argv) > 6 else 60
 rounds = int(sys.argv[7]) if len(sys.argv) > 7 else 8
+grid_type = int(sys.argv[8]) if len(sys.argv) > 8 else 0   # gb25_grid_type: 1 lat-lon + islands, 4 tripolar + islands
+catke = len(sys.argv) > 9 and sys.argv[9] == "catke"
 P = C.c_void_p
 libs = []
 for p in paths:
@@ -24,8 +26,12 @@ def timed(lib):
     cfg = Config()
     lib.gb25_default_config(C.byref(cfg), Nx, Ny, Nz)
     cfg.dt = 120.0
+    cfg.grid_type = grid_type
     h = P()
     assert lib.gb25_create(C.byref(cfg), C.byref(h)) == 0
+    if catke:
+        lib.gb25_set_closure_catke.argtypes = [P, C.c_int32]
+        assert lib.gb25_set_closure_catke(h, 1) == 0
     lib.gb25_set_baroclinic_instability(h)
     lib.gb25_first_time_step(h)
     lib.gb25_loop(h, 20)
