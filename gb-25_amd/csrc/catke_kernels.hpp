@@ -82,9 +82,9 @@ __device__ __forceinline__ CatkeColumn catke_column(const Grid& g, int i, int j,
     q.NUw = (int)((g.im.ordD[o2] >> 16) & 255); q.NUe = (int)((g.im.ordD[o2 + 1] >> 16) & 255);
     q.NVs = (int)((g.im.ordD[o2] >> 24) & 255); q.NVn = (int)((g.im.ordD[o2 + g.sx] >> 24) & 255);
   }
-  q.zt = g.zc[g.Nz - 1] + real(0.5) * g.dzc[g.Nz - 1];
-  real zb = g.zc[0] - real(0.5) * g.dzc[0];
-  for (int l = 0; l < q.kc0; l++) zb += g.dzc[l];
+  q.zt = uniform_at(g.zc, g.Nz - 1) + real(0.5) * uniform_at(g.dzc, g.Nz - 1);
+  real zb = uniform_at(g.zc, 0) - real(0.5) * uniform_at(g.dzc, 0);
+  for (int l = 0; l < q.kc0; l++) zb += uniform_at(g.dzc, l);
   q.zbot = zb;
   q.Hcol = q.zt - zb;
   q.jb = jb;
@@ -126,7 +126,9 @@ __device__ __forceinline__ CatkeLengths catke_face_eval(const CatkePar& c, const
     const real scale = convecting ? ws3 * q.rjb : cdiv(jb, ws * N2 + jbe);
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      real l = (convecting ? c.Cc[p] : c.Ce[p]) * scale;
+      // (both coefficients as kernel arguments, THEN the select: a select of the two arrays is a per-lane pointer and a vector load)
+      const real cc_ = c.Cc[p], ce_ = c.Ce[p];
+      real l = (convecting ? cc_ : ce_) * scale;
       l *= esp;
       lconv[p] = l > real(0.) ? l : real(0.);
     }
@@ -180,7 +182,7 @@ __device__ __forceinline__ CatkeShear catke_face_velocities(const Grid& g, const
 }
 __device__ __forceinline__ CatkeShear catke_dz_velocities(const Grid& g, const CatkeColumn& q, const CatkeShear& lo,
                                                           const CatkeShear& hi, int kf) {
-  const real rdz = g.rdzf[kf];
+  const real rdz = uniform_at(g.rdzf, kf);
   // (every load unconditional -- the masks are per lane, and a load inside a divergent branch is issued behind it -- then selects)
   const real a = (hi.uw - lo.uw) * rdz, b = (hi.ue - lo.ue) * rdz;
   const real c = (hi.vs - lo.vs) * rdz, e = (hi.vn - lo.vn) * rdz;
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_tke_step(Grid g,
   };
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
   KE[o] = real(0.);
-  real zf = g.zc[0] - real(0.5) * g.dzc[0];
+  real zf = uniform_at(g.zc, 0) - real(0.5) * uniform_at(g.dzc, 0);
   // the face below the current cell: N^2, S^2, the convective dissipation length, -kappa_c N^2, the shear-production sum
   real N2lo = real(0.), S2lo = real(0.), cDlo = real(0.), wblo = real(0.), PFlo = real(0.);
   real ecur = e[o];
@@ -234,9 +236,10 @@ __global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_tke_step(Grid g,
   real wcur = csqrt(ecur > c.emin ? ecur : c.emin);
   for (int k = 0; k < Nz; k++) {
     const int kf = k + 1, of = o + pc, ovf = ov + pv;
-    zf += g.dzc[k];
+    zf += uniform_at(g.dzc, k);
     real N2hi = real(0.), S2hi = real(0.), cDhi = real(0.), wbhi = real(0.), PFhi = real(0.), kehi = real(0.);
     real enext = real(0.), wnext = real(0.);
+    const real gn = Gn[o], gm = Gm[o];   // (with the level's other loads: behind the face's arithmetic they were a sleep of their own)
     if (kf < Nz) {
       enext = e[of];
       const CatkeShear uhi = catke_face_velocities(g, u, v, of, ovf), mhi = catke_face_velocities(g, um, vm, of, ovf);
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_tke_step(Grid g,
       const real kuc = KU[of];
       const real nw = (KU[of - 1] + kuc) / real(2.), ne = (kuc + KU[of + 1]) / real(2.);
       const real ns = (KU[of - g.sx] + kuc) / real(2.), nn = (kuc + KU[of + g.sx]) / real(2.);
-      const real dzf = g.dzf[kf];
+      const real dzf = uniform_at(g.dzf, kf);
       // (nu dz u- dzf dz u+) + (nu dz u+ dzf dz u+), averaged over the two x faces, plus the same over the two y faces
       const real fw = (nw * dm.uw * dzf * d.uw) + (nw * d.uw * dzf * d.uw), fe = (ne * dm.ue * dzf * d.ue) + (ne * d.ue * dzf * d.ue);
       const real fs = (ns * dm.vs * dzf * d.vs) + (ns * d.vs * dzf * d.vs), fn = (nn * dm.vn * dzf * d.vn) + (nn * d.vn * dzf * d.vn);
@@ -266,19 +269,18 @@ __global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_tke_step(Grid g,
     }
     KE[of] = kehi;
     real Lk = real(0.);
-    const real gn = Gn[o], gm = Gm[o];
     if (k >= q.kc0) {
       const real ek = ecur, wb = (wblo + wbhi) / real(2.);
       const real wbm = wb < real(0.) ? wb : real(0.), wbp = wb > real(0.) ? wb : real(0.);
-      const real lD = catke_dissipation_length(c, q, wcur, g.zc[k], N2lo, N2hi, S2lo, S2hi, cDlo, cDhi);
+      const real lD = catke_dissipation_length(c, q, wcur, uniform_at(g.zc, k), N2lo, N2hi, S2lo, S2hi, cDlo, cDhi);
       // (sqrt|e| and sqrt(max(e, 0)): the carried root where e >= e_min, which is nearly everywhere)
       const real ep = ek > real(0.) ? ek : real(0.);
       const bool floored = !(ek >= c.emin);
       const real wabs = floored ? csqrt(rabs(ek)) : wcur, wpos = floored ? csqrt(ep) : wcur;
       const real omega = ek < real(0.) ? c.rtau_neg : cdiv(wabs, lD);
-      const real divJ = k == q.kc0 ? -(c.CWeps * wpos * g.rdzc[k]) : real(0.);      // (the bottom cell of the column)
+      const real divJ = k == q.kc0 ? -(c.CWeps * wpos * uniform_at(g.rdzc, k)) : real(0.);      // (the bottom cell of the column)
       Lk = (ek > c.emin ? cdiv(wbm, ek) : real(0.)) - omega + divJ;
-      const real P = ((PFlo + PFhi) / real(2.)) * (real(0.5) * g.rdzc[k]);
+      const real P = ((PFlo + PFhi) / real(2.)) * (real(0.5) * uniform_at(g.rdzc, k));
       const real total = gn + (P + wbp);
       e[o] = ek + dt * (C1 * total - C2 * gm);
       Gm[o] = total;
@@ -327,10 +329,10 @@ __global__ void k_catke_surface_flux(Grid g, CatkePar c, real dt_since, const re
         N2lo = n2[o];
         const real eb = e[o - g.pl_c];
         const real el = eb > c.emin ? eb : c.emin, eh = ek > c.emin ? ek : c.emin;
-        cDlo = catke_face_eval(c, q, csqrt(el), csqrt(eh), N2lo, real(0.), S2lo, g.zc[k] - real(0.5) * g.dzc[k]).convD;
+        cDlo = catke_face_eval(c, q, csqrt(el), csqrt(eh), N2lo, real(0.), S2lo, uniform_at(g.zc, k) - real(0.5) * uniform_at(g.dzc, k)).convD;
       }
     }
-    const real lD = catke_dissipation_length(c, q, csqrt(ek > c.emin ? ek : c.emin), g.zc[k], N2lo, real(0.), S2lo, real(0.), cDlo, real(0.));
+    const real lD = catke_dissipation_length(c, q, csqrt(ek > c.emin ? ek : c.emin), uniform_at(g.zc, k), N2lo, real(0.), S2lo, real(0.), cDlo, real(0.));
     real Jp = c.Jbmin;
     Jp = J > Jp ? J : Jp;
     Jp = Jstar > Jp ? Jstar : Jp;
@@ -340,8 +342,8 @@ __global__ void k_catke_surface_flux(Grid g, CatkePar c, real dt_since, const re
     const real Ju = g.top_flux[0] ? g.top_flux[0][o2] : real(0.);
     const real Jv = g.top_flux[1] ? g.top_flux[1][o2] : real(0.);
     const real us2 = sqrt(Ju * Ju + Jv * Jv), us3 = us2 * sqrt(us2);
-    const real wD3 = (Jstar > real(0.) ? Jstar : real(0.)) * g.dzc[k];
-    source = (c.CWu * us3 + c.CWw * wD3) / g.dzc[k];
+    const real wD3 = (Jstar > real(0.) ? Jstar : real(0.)) * uniform_at(g.dzc, k);
+    source = (c.CWu * us3 + c.CWw * wD3) / uniform_at(g.dzc, k);
   }
   src[o2] = source;
   // (a rank of a decomposition: the x halo columns / rows of its open sides / the rows beyond a zipper fold arrive by exchange)
@@ -386,14 +388,14 @@ __global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_diffusivities(Gr
   };
   int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
   put(KU, o, real(0.)); put(KC, o, real(0.)); put(KE, o, real(0.));
-  real zf = g.zc[0] - real(0.5) * g.dzc[0];
+  real zf = uniform_at(g.zc, 0) - real(0.5) * uniform_at(g.dzc, 0);
   real ecur = e[o];
   CatkeShear ulo = catke_face_velocities(g, u, v, o, ov);      // (carried up the column like k_catke_tke_step's)
   real n2f = Nz > 1 ? n2[o + pc] : real(0.);
   real wcur = csqrt(ecur > c.emin ? ecur : c.emin);
   for (int k = 0; k < Nz; k++) {
     const int kf = k + 1, of = o + pc, ovf = ov + pv;
-    zf += g.dzc[k];
+    zf += uniform_at(g.dzc, k);
     CatkeLengths L = {real(0.), real(0.), real(0.), real(0.)};
     real wnext = real(0.);
     if (kf < Nz) {
@@ -476,7 +478,7 @@ __device__ __forceinline__ real implicit_var_colsum(const Grid& g, int kchunks, 
   real tot = real(0.), q = real(0.);
   int kk = 0, ch = 0;
   for (int k = 0; k < Nz; k++) {
-    q = (kk == 0) ? g.dzc[k] * x(k) : rfma(g.dzc[k], x(k), q);
+    q = (kk == 0) ? uniform_at(g.dzc, k) * x(k) : rfma(uniform_at(g.dzc, k), x(k), q);
     if (++kk == klen || k == Nz - 1) {
       tot = (k < klen) ? q : tot + q;
       if (part) part[(size_t)ch * pstride] = zero ? real(0.) : q;   // (the chunk's own sum: see ImplicitVarFields::P)
@@ -526,12 +528,12 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_var(Grid g, ImplicitV
   for (int k = 0; k < NZT; k++)
     if (k < Nz && k >= kf) {
       const real ktop = A.dt * (MODE == 0 ? (b[k] + gm[k]) / real(2.) : gm[k]);   // dt kappa at the top face of level k
-      const real t = (k == kf) ? real(0.) : -(kup * g.rdzf[k]);    // coupling through face k, without the cell height
-      const real lo = t * g.rdzc[k];
-      const real up = -(ktop * g.rdzc[k]) * g.rdzf[k + 1];         // (ktop = 0 at the top level)
+      const real t = (k == kf) ? real(0.) : -(kup * uniform_at(g.rdzf, k));    // coupling through face k, without the cell height
+      const real lo = t * uniform_at(g.rdzc, k);
+      const real up = -(ktop * uniform_at(g.rdzc, k)) * uniform_at(g.rdzf, k + 1);         // (ktop = 0 at the top level)
       real dg = real(1.) - lo - up;
       if (MODE == 1 && tke) dg -= A.dt * b[k];
-      const real gk = (t * g.rdzc[k - 1]) * rbet;                   // upper coefficient of the level below / its pivot
+      const real gk = (t * uniform_at(g.rdzc, k - 1)) * rbet;                   // upper coefficient of the level below / its pivot
       rbet = rcp(dg - lo * gk);                                     // (k = kf: t = lo = gk = 0)
       pa = (a[k] - lo * pa) * rbet;
       a[k] = pa;
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_var(Grid g, ImplicitV
 #pragma unroll
     for (int k = 0; k < NZT; k++)
       if (k < Nz) {
-        q = (kk == 0) ? g.dzc[k] * a[k] : rfma(g.dzc[k], a[k], q);
+        q = (kk == 0) ? uniform_at(g.dzc, k) * a[k] : rfma(uniform_at(g.dzc, k), a[k], q);
         if (++kk == klen || k == Nz - 1) {
           tot = (k < klen) ? q : tot + q;
           if (A.P) A.P[((size_t)(2 + z) * A.kchunks + ch) * A.plane2 + o2] = wall ? real(0.) : q;
@@ -607,11 +609,11 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_var_stream(Grid g, Im
       const int of = oc + (k + 1) * pc;
       ktop = A.dt * (MODE == 0 ? (K[of + nb] + K[of]) / real(2.) : K[of]);
     }
-    const real t = (k == kf) ? real(0.) : -(kup * g.rdzf[k]);
-    const real lo = t * g.rdzc[k];
-    const real up = -(ktop * g.rdzc[k]) * g.rdzf[k + 1];
+    const real t = (k == kf) ? real(0.) : -(kup * uniform_at(g.rdzf, k));
+    const real lo = t * uniform_at(g.rdzc, k);
+    const real up = -(ktop * uniform_at(g.rdzc, k)) * uniform_at(g.rdzf, k + 1);
     const real dg = real(1.) - lo - up - le;
-    const real gk = (t * g.rdzc[k - 1]) * rbet;
+    const real gk = (t * uniform_at(g.rdzc, k - 1)) * rbet;
     rbet = rcp(dg - lo * gk);
     pa = (xa - lo * pa) * rbet;
     Fa[o0 + k * pl] = pa;

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void k_compute_w(Grid g, const real* __restric
   }
 #pragma unroll 8
   for (int k = 0; k < g.Nz; k++) {
-    real dz = g.dzc[k];
+    real dz = uniform_at(g.dzc, k);
     real div = LAZY ? (dye * dz * (u[o + 1] + due) - dyw * dz * (u[o] + duw)) + (dxn * dz * (v[ov + g.sx] + dvn) - dxs * dz * (v[ov] + dvs))
                     : (dye * dz * u[o + 1] - dyw * dz * u[o]) + (dxn * dz * v[ov + g.sx] - dxs * dz * v[ov]);
     wk = wk - div * raz;
@@ -574,16 +574,16 @@ __global__ __launch_bounds__(256) void k_compute_p_literal(Grid g, const real* _
     return -(g.g * (rho - g.rho0)) / g.rho0;
   };
   int o = ic(g, i, j, Nz);
-  real bup = buoy(o, g.zc[Nz - 1] - real(1.) * g.dzf[Nz - 1]);   // mirrored height of the first cell above the surface
+  real bup = buoy(o, uniform_at(g.zc, Nz - 1) - real(1.) * uniform_at(g.dzf, Nz - 1));   // mirrored height of the first cell above the surface
   o -= g.pl_c;
-  real bk = buoy(o, g.zc[Nz - 1]);
-  real pk = -((bk + bup) / real(2.)) * g.dzf[Nz];
+  real bk = buoy(o, uniform_at(g.zc, Nz - 1));
+  real pk = -((bk + bup) / real(2.)) * uniform_at(g.dzf, Nz);
   p[o] = pk;
   for (int k = Nz - 2; k >= 0; k--) {
     o -= g.pl_c;
     bup = bk;
-    bk = buoy(o, g.zc[k]);
-    pk = pk - ((bk + bup) / real(2.)) * g.dzf[k + 1];
+    bk = buoy(o, uniform_at(g.zc, k));
+    pk = pk - ((bk + bup) / real(2.)) * uniform_at(g.dzf, k + 1);
     p[o] = pk;
   }
 }
@@ -630,12 +630,12 @@ __global__ __launch_bounds__(256) void k_tracer_tendencies(Grid g, const real* _
   if (!t.ok) return;
   const int i = t.i, j = t.j, k = t.k;
   const int o = ic(g, i, j, k), ov = iv(g, i, j, k);
-  const real dz = g.dzc[k];
+  const real dz = uniform_at(g.dzc, k);
   const real Ax = g.dy * dz, Ays = g.dxf[j] * dz, Ayn = g.dxf[j + 1] * dz, Az = g.azc[j];
   const real uw = u[o], ue = u[o + 1], vs = v[ov], vn = v[ov + g.sx], wb = w[o], wt = w[o + g.pl_c];
   const int oys = biased_order_face(j - g.jws, g.jwn - g.jws), oyn = biased_order_face(j + 1 - g.jws, g.jwn - g.jws);
   const int ozb = biased_order_face(k, g.Nz), ozt = biased_order_face(k + 1, g.Nz);
-  const real rV = g.razc[j] * g.rdzc[k];
+  const real rV = g.razc[j] * uniform_at(g.rdzc, k);
   GT[o] = -(tracer_div(g, T, o, Ax, uw, ue, Ays, Ayn, vs, vn, Az, wb, wt, oys, oyn, ozb, ozt) * rV);
   GS[o] = -(tracer_div(g, S, o, Ax, uw, ue, Ays, Ayn, vs, vn, Az, wb, wt, oys, oyn, ozb, ozt) * rV);
 }
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256) void k_gu(Grid g, const real* __restrict__ u, 
   const int i = t.i, j = t.j, k = t.k;
   const int o = ic(g, i, j, k), ov = iv(g, i, j, k);
   const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
-  const real dy = g.dy, dz = g.dzc[k];
+  const real dy = g.dy, dz = uniform_at(g.dzc, k);
   const real dxf_s = g.dxf[j], dxf_n = g.dxf[j + 1], rdxc_j = g.rdxc[j];
 
   // advecting v at (f,c,c)
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void k_gu(Grid g, const real* __restrict__ u, 
     for (int m = 0; m < 6; m++) q[m] = u[o + (tt + m - 3) * pc];
     fz[tt] = wt * biased6<false>(biased_order_face(k + tt, g.Nz), wt > real(0.), q, q, q);
   }
-  const real vadv = (phi + (fz[1] - fz[0])) * (g.razc[j] * g.rdzc[k]);
+  const real vadv = (phi + (fz[1] - fz[0])) * (g.razc[j] * uniform_at(g.rdzc, k));
 
   // Bernoulli head
   real Ku[6], su[6];
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256) void k_gv(Grid g, const real* __restrict__ u, 
   const int i = t.i, j = t.j, k = t.k;
   const int o = ic(g, i, j, k), ov = iv(g, i, j, k);
   const int sx = g.sx, pc = g.pl_c, pv = g.pl_v;
-  const real dy = g.dy, dz = g.dzc[k];
+  const real dy = g.dy, dz = uniform_at(g.dzc, k);
 
   // advecting u at (c,f,c)
   const real uhat = (real(0.5) * (dy * u[o - sx] + dy * u[o - sx + 1]) + real(0.5) * (dy * u[o] + dy * u[o + 1])) * real(0.5) * g.rdy;
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256) void k_gv(Grid g, const real* __restrict__ u, 
     for (int m = 0; m < 6; m++) q[m] = v[ov + (tt + m - 3) * pv];
     fz[tt] = wt * biased6<false>(biased_order_face(k + tt, g.Nz), wt > real(0.), q, q, q);
   }
-  const real vadv = (phi + (fz[1] - fz[0])) * (razf * g.rdzc[k]);
+  const real vadv = (phi + (fz[1] - fz[0])) * (razf * uniform_at(g.rdzc, k));
 
   // Bernoulli head
   real Kv[6], sv[6];
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(256) void k_ab2_velocities(Grid g, real* __restrict
     real su = real(0.), sv = real(0.), iu = real(0.), iv_ = real(0.);
 #pragma unroll 4
     for (int k = k0; k < k1; k++) {
-      real dz = g.dzc[k];
+      real dz = uniform_at(g.dzc, k);
       real gu = rfma(C1, Gnu[o], -((C2 * Gmu[o]) * ne));
       real gv = rfma(C1, Gnv[ov], -((C2 * Gmv[ov]) * ne));
       real un = rfma(dt, gu, u[o]), vn = rfma(dt, gv, v[ov]);
@@ -919,8 +919,8 @@ __global__ __launch_bounds__(256) void k_implicit_vertical(Grid g, real* __restr
   real* cdn = gam + (size_t)Nz * T;    // cdn[k] = 1 / (dz^c_k dz^f_k): coupling of level k to the level below
   real* cup = cdn + Nz;                // cup[k] = 1 / (dz^c_k dz^f_{k+1}): to the level above
   for (int k = tid; k < Nz; k += T) {
-    cdn[k] = real(1.) / (g.dzc[k] * g.dzf[k]);
-    cup[k] = real(1.) / (g.dzc[k] * g.dzf[k + 1]);
+    cdn[k] = real(1.) / (uniform_at(g.dzc, k) * uniform_at(g.dzf, k));
+    cup[k] = real(1.) / (uniform_at(g.dzc, k) * uniform_at(g.dzf, k + 1));
   }
   __syncthreads();
   const int i = blockIdx.x * T + tid, j = blockIdx.y;
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical(Grid g, real* __restr
     for (int k0 = 0; k0 < Nz; k0 += klen) {
       const int k1 = min(Nz, k0 + klen);
       real q = real(0.);
-      for (int k = k0; k < k1; k++) q = (k == k0) ? g.dzc[k] * col[k * T + tid] : rfma(g.dzc[k], col[k * T + tid], q);
+      for (int k = k0; k < k1; k++) q = (k == k0) ? uniform_at(g.dzc, k) * col[k * T + tid] : rfma(uniform_at(g.dzc, k), col[k * T + tid], q);
       tot = (k0 == 0) ? q : tot + q;
     }
     S[o2] = (vsh && j == g.jws) ? real(0.) : tot;
@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_reg(Grid g, ImplicitF
 #pragma unroll
     for (int k = 0; k < NZT; k++)
       if (k < Nz) {
-        p = (kk == 0) ? g.dzc[k] * x[k] : rfma(g.dzc[k], x[k], p);
+        p = (kk == 0) ? uniform_at(g.dzc, k) * x[k] : rfma(uniform_at(g.dzc, k), x[k], p);
         if (++kk == klen || k == Nz - 1) {
           tot = (k < klen) ? p : tot + p;
           kk = 0;
@@ -1764,12 +1764,12 @@ __global__ __launch_bounds__(256) void k_barotropic_mode(Grid g, const real* __r
   int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= g.Nx || j >= g.Ny) return;
   int o = ic(g, i, min(j, g.Ny - 1), 0), ov = iv(g, i, j, 0);
-  real su = g.dzc[0] * u[o], sv = g.dzc[0] * v[ov];
+  real su = uniform_at(g.dzc, 0) * u[o], sv = uniform_at(g.dzc, 0) * v[ov];
   for (int k = 1; k < g.Nz; k++) {
     o += g.pl_c;
     ov += g.pl_v;
-    su += g.dzc[k] * u[o];
-    sv += g.dzc[k] * v[ov];
+    su += uniform_at(g.dzc, k) * u[o];
+    sv += uniform_at(g.dzc, k) * v[ov];
   }
   if (j < g.Ny) U[i2(g, i, j)] = su;
   V[i2(g, i, j)] = sv;
@@ -1940,7 +1940,7 @@ __global__ __launch_bounds__(256) void k_w_bases(Grid g, const real* __restrict_
   for (int c = 0; c + 1 < kchunks; c++) {
     real Ze = real(0.), Zw = real(0.), Zs = real(0.), Zn = real(0.);
     for (int k = c * klen; k < min(g.Nz, (c + 1) * klen); k++) {
-      const real dz = g.dzc[k];
+      const real dz = uniform_at(g.dzc, k);
       if (!IMM || k >= Ke) Ze += dz;
       if (!IMM || k >= Kw) Zw += dz;
       if (!IMM || k >= Ks) Zs += dz;
@@ -2017,8 +2017,8 @@ __global__ __launch_bounds__(256) void k_corrector(Grid g, real* __restrict__ u,
       const int k1 = min(g.Nz, k0 + klen);
       real pu = real(0.), pv = real(0.);
       for (int k = k0; k < k1; k++) {
-        pu = (k == k0) ? g.dzc[k] * u[o] : rfma(g.dzc[k], u[o], pu);
-        pv = (k == k0) ? g.dzc[k] * v[ov] : rfma(g.dzc[k], v[ov], pv);
+        pu = (k == k0) ? uniform_at(g.dzc, k) * u[o] : rfma(uniform_at(g.dzc, k), u[o], pu);
+        pv = (k == k0) ? uniform_at(g.dzc, k) * v[ov] : rfma(uniform_at(g.dzc, k), v[ov], pv);
         o += g.pl_c;
         ov += g.pl_v;
       }
@@ -2092,7 +2092,7 @@ __global__ void k_set_baroclinic_instability(Grid g, real* __restrict__ T, real*
   int j = blockIdx.y;
   int k = blockIdx.z;
   if (i >= g.Nx) return;
-  real phi = g.cv.on ? g.cv.phicc[i2(g, i, j)] : g.phic[j], z = g.zc[k];
+  real phi = g.cv.on ? g.cv.phicc[i2(g, i, j)] : g.phic[j], z = uniform_at(g.zc, k);
   real step = (real(1.) - rtanh((rabs(phi) - real(40.)) / real(5.))) / real(2.);
   int o = ic(g, i, j, k);
   T[o] = (real(30.) + real(1e-3) * z) * step;
