@@ -1262,15 +1262,6 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
   const Baro& b = bm.b;
   const int tid = threadIdx.x;
   const int i0 = b.ilo + blockIdx.x * BT_TX, j0 = b.jlo + blockIdx.y * BT_TY;
-  if (tid <= BT_RY) {
-    // rows beyond the metric tables do not exist in the domain; their entries are never used
-    const int jg = max(b.jlo - (g.H + 2), min(b.jhi + g.H + 2, j0 - BT_S + tid));
-    Mdxf[tid] = g.dxf[jg];
-    if (tid < BT_RY) {
-      Mrazc[tid] = g.razc[jg];
-      Mrdxc[tid] = g.rdxc[jg];
-    }
-  }
   const real gH = g.g * g.Lz, rdy = g.rdy, dyc = g.dy;
   const int lo = -b.xo, hi = b.sx - b.xo - 1;   // valid array columns (slab mode: clamp; garbage stays in the rim)
   int pl[BT_PPT], pj[BT_PPT], po[BT_PPT];       // LDS index, global row, global element offset (-1: no such point)
@@ -1315,6 +1306,19 @@ __global__ __launch_bounds__(BT_NT, (BT_S <= 5 ? 4 : 3)) void k_barotropic_multi
       ae[q] = b.etab[po[q]];
       au[q] = b.Ub[po[q]];
       av[q] = b.Vb[po[q]];
+    }
+  }
+  // (the row metrics BEHIND the tile loads: ahead of them, the first wave of the block waited for three table loads one after the
+  // other before it issued its share of the tile -- and the block's first barrier waited for that wave)
+  if (tid <= BT_RY) {
+    // rows beyond the metric tables do not exist in the domain; their entries are never used
+    const int jg = max(b.jlo - (g.H + 2), min(b.jhi + g.H + 2, j0 - BT_S + tid));
+    real m0 = g.dxf[jg], m1 = g.razc[jg], m2 = g.rdxc[jg];
+    asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2));   // (one batch: the compiler sinks the last two into the branch below)
+    Mdxf[tid] = m0;
+    if (tid < BT_RY) {
+      Mrazc[tid] = m1;
+      Mrdxc[tid] = m2;
     }
   }
 #pragma unroll
@@ -1437,19 +1441,15 @@ __global__ __launch_bounds__(BW_NT) void k_barotropic_whole(Grid g, BaroMulti bm
   const Baro& b = bm.b;
   const int tid = threadIdx.x;
   const int i0 = b.ilo + blockIdx.x * BT_TX, j0 = b.jlo + blockIdx.y * BW_TY;
-  if (tid <= RY) {
-    const int jg = max(b.jlo - (g.H + 2), min(b.jhi + g.H + 2, j0 - NS + tid));
-    Mdxf[tid] = g.dxf[jg];
-    if (tid < RY) {
-      Mrazc[tid] = g.razc[jg];
-      Mrdxc[tid] = g.rdxc[jg];
-    }
-  }
   const real gH = g.g * g.Lz, rdy = g.rdy, dyc = g.dy;
   const int lo = -b.xo, hi = b.sx - b.xo - 1;
   int po[PPT];            // global element offset of the point (-1: none)
   short dist[PPT];        // ring distance from the own tile (0: own); 127: never computed
   real ae[PPT], au[PPT], av[PPT], ghf[PPT], ghc[PPT];
+  // (loads only in this loop, the values wait in registers until every load of the thread's points is in flight: stored to LDS
+  // point by point, each point's five loads were waited for before the next point's were issued -- seven round trips at the
+  // head of a 50 us kernel that a narrow rank has on its critical path; k_barotropic_multi does the same)
+  real tle[PPT], tlu[PPT], tlv[PPT], tlgu[PPT], tlgv[PPT];
 #pragma unroll
   for (int q = 0; q < PPT; q++) {
     const int p = tid + q * BW_NT;
@@ -1489,10 +1489,25 @@ __global__ __launch_bounds__(BW_NT) void k_barotropic_whole(Grid g, BaroMulti bm
         ghc[q] = g.g * b.Hcf[po[q]];
       }
     }
-    if (p < NP) {
-      E[p] = le; U[p] = lu; V[p] = lv; GUs[p] = lgu; GVs[p] = lgv;
-    }
+    tle[q] = le; tlu[q] = lu; tlv[q] = lv; tlgu[q] = lgu; tlgv[q] = lgv;
     ae[q] = au[q] = av[q] = real(0.);
+  }
+  if (tid <= RY) {   // (the row metrics behind the tile loads, in one batch)
+    const int jg = max(b.jlo - (g.H + 2), min(b.jhi + g.H + 2, j0 - NS + tid));
+    real m0 = g.dxf[jg], m1 = g.razc[jg], m2 = g.rdxc[jg];
+    asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2));
+    Mdxf[tid] = m0;
+    if (tid < RY) {
+      Mrazc[tid] = m1;
+      Mrdxc[tid] = m2;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PPT; q++) {
+    const int p = tid + q * BW_NT;
+    if (p < NP) {
+      E[p] = tle[q]; U[p] = tlu[q]; V[p] = tlv[q]; GUs[p] = tlgu[q]; GVs[p] = tlgv[q];
+    }
   }
   __syncthreads();
   for (int s = 0; s < bm.ns; s++) {
