@@ -197,8 +197,14 @@ __device__ __forceinline__ CatkeShear catke_dz_velocities(const Grid& g, const C
                                                           const real* __restrict__ v, int oc, int ov, int kf) {
   return catke_dz_velocities(g, q, catke_face_velocities(g, u, v, oc - g.pl_c, ov - g.pl_v), catke_face_velocities(g, u, v, oc, ov), kf);
 }
-// time_step_catke_equation!, first half (see the header).  One thread per own column, marching up; e is updated in place (a
-// column reads nobody else's e, and the old e of a cell is last needed by the face above it, evaluated before the cell).
+// time_step_catke_equation!, first half (see the header).  One thread per own column and CHUNK of levels (blockIdx.z), marching
+// up.  Nothing here is a recurrence -- what a level takes from the face below it is that face's own quantities -- so a chunk
+// starts one level early, evaluates the face under its first level exactly as the chunk below does, and goes on: the same
+// bits whatever the chunking.  A rank of a decomposition (360 x 360 columns: two waves per SIMD with one thread per column)
+// takes four chunks; a single domain of a million columns one.  e* goes to `e_out`: with one chunk that is e itself (a column
+// reads nobody else's e, and the old e of a cell is last needed by the face above it, evaluated before the cell); with
+// several, a scratch array -- the chunk above reads the OLD e of the level under its first -- from which the implicit solve
+// takes it (ImplicitVarFields::src_e).
 #ifndef GB25_CATKE_MINW
 #define GB25_CATKE_MINW 4
 #endif
@@ -206,7 +212,7 @@ template <bool IMM>
 __global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_tke_step(Grid g, CatkePar c, real dt, real C1, real C2,
                                                         const real* __restrict__ u, const real* __restrict__ v,
                                                         const real* __restrict__ um, const real* __restrict__ vm,
-                                                        real* __restrict__ e, const real* __restrict__ n2,
+                                                        const real* e, real* e_out, const real* __restrict__ n2,
                                                         const real* __restrict__ Jb, const real* __restrict__ KU,
                                                         const real* __restrict__ KC, real* __restrict__ KE,
                                                         real* __restrict__ Le, const real* __restrict__ Gn,
@@ -214,6 +220,9 @@ __global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_tke_step(Grid g,
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= g.Nx || j >= g.Ny) return;
   const int Nz = g.Nz, o2 = i2(g, i, j), pc = g.pl_c, pv = g.pl_v;
+  const int klen = (Nz + (int)gridDim.z - 1) / (int)gridDim.z, k0 = (int)blockIdx.z * klen, k1 = min(Nz, k0 + klen);
+  if (k0 >= k1) return;
+  const int ks = k0 > 0 ? k0 - 1 : 0;   // (the level whose top face is the face under the chunk's first level)
   CatkeColumn q = catke_column<IMM>(g, i, j, o2, Jb[o2]);
   q.rjb = real(1.) / (q.jb + c.Jbmin);
   const bool xw = g.x_periodic && i < g.H, xe = g.x_periodic && i >= g.Nx - g.H;
@@ -223,9 +232,10 @@ __global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_tke_step(Grid g,
     if (ys) store_x_images(g, a, o - g.sx, x, xw, xe);
     if (yn) store_x_images(g, a, o + g.sx, x, xw, xe);
   };
-  int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
-  KE[o] = real(0.);
+  int o = ic(g, i, j, ks), ov = iv(g, i, j, ks);
+  if (k0 == 0) KE[o] = real(0.);
   real zf = uniform_at(g.zc, 0) - real(0.5) * uniform_at(g.dzc, 0);
+  for (int l = 0; l < ks; l++) zf += uniform_at(g.dzc, l);   // (the face heights by the same running sum whatever the chunk)
   // the face below the current cell: N^2, S^2, the convective dissipation length, -kappa_c N^2, the shear-production sum
   real N2lo = real(0.), S2lo = real(0.), cDlo = real(0.), wblo = real(0.), PFlo = real(0.);
   real ecur = e[o];
@@ -234,7 +244,8 @@ __global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_tke_step(Grid g,
   CatkeShear ulo = catke_face_velocities(g, u, v, o, ov), mlo = catke_face_velocities(g, um, vm, o, ov);
   real n2f = Nz > 1 ? n2[o + pc] : real(0.);
   real wcur = csqrt(ecur > c.emin ? ecur : c.emin);
-  for (int k = 0; k < Nz; k++) {
+  for (int k = ks; k < k1; k++) {
+    const bool own = k >= k0;           // (false in the one level a chunk starts early: its top face only)
     const int kf = k + 1, of = o + pc, ovf = ov + pv;
     zf += uniform_at(g.dzc, k);
     real N2hi = real(0.), S2hi = real(0.), cDhi = real(0.), wbhi = real(0.), PFhi = real(0.), kehi = real(0.);
@@ -267,9 +278,9 @@ __global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_tke_step(Grid g,
       wbhi = open ? -(kcf * n2f) : real(0.);
       n2f = n2a;
     }
-    KE[of] = kehi;
+    if (own) KE[of] = kehi;
     real Lk = real(0.);
-    if (k >= q.kc0) {
+    if (own && k >= q.kc0) {
       const real ek = ecur, wb = (wblo + wbhi) / real(2.);
       const real wbm = wb < real(0.) ? wb : real(0.), wbp = wb > real(0.) ? wb : real(0.);
       const real lD = catke_dissipation_length(c, q, wcur, uniform_at(g.zc, k), N2lo, N2hi, S2lo, S2hi, cDlo, cDhi);
@@ -282,12 +293,14 @@ __global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_tke_step(Grid g,
       Lk = (ek > c.emin ? cdiv(wbm, ek) : real(0.)) - omega + divJ;
       const real P = ((PFlo + PFhi) / real(2.)) * (real(0.5) * uniform_at(g.rdzc, k));
       const real total = gn + (P + wbp);
-      e[o] = ek + dt * (C1 * total - C2 * gm);
+      e_out[o] = ek + dt * (C1 * total - C2 * gm);
       Gm[o] = total;
     }
-    put(Le, o, Lk);
-    if (k == 0) store_x_images(g, Le, o - pc, Lk, xw, xe);        // bottom / top layer (interior rows only, like the fill)
-    if (k == Nz - 1) store_x_images(g, Le, o + pc, Lk, xw, xe);
+    if (own) {
+      put(Le, o, Lk);
+      if (k == 0) store_x_images(g, Le, o - pc, Lk, xw, xe);        // bottom / top layer (interior rows only, like the fill)
+      if (k == Nz - 1) store_x_images(g, Le, o + pc, Lk, xw, xe);
+    }
     N2lo = N2hi; S2lo = S2hi; cDlo = cDhi; wblo = wbhi; PFlo = PFhi;
     ecur = enext;
     wcur = wnext;
@@ -386,14 +399,18 @@ __global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_diffusivities(Gr
     if (ys) store_x_images(g, a, o - g.sx, x, xw, xe);
     if (yn) store_x_images(g, a, o + g.sx, x, xw, xe);
   };
-  int o = ic(g, i, j, 0), ov = iv(g, i, j, 0);
-  put(KU, o, real(0.)); put(KC, o, real(0.)); put(KE, o, real(0.));
+  // (chunks of levels in blockIdx.z, as in k_catke_tke_step: level k makes the face above it from loads alone)
+  const int klen = (Nz + (int)gridDim.z - 1) / (int)gridDim.z, k0 = (int)blockIdx.z * klen, k1 = min(Nz, k0 + klen);
+  if (k0 >= k1) return;
+  int o = ic(g, i, j, k0), ov = iv(g, i, j, k0);
+  if (k0 == 0) { put(KU, o, real(0.)); put(KC, o, real(0.)); put(KE, o, real(0.)); }
   real zf = uniform_at(g.zc, 0) - real(0.5) * uniform_at(g.dzc, 0);
+  for (int l = 0; l < k0; l++) zf += uniform_at(g.dzc, l);
   real ecur = e[o];
   CatkeShear ulo = catke_face_velocities(g, u, v, o, ov);      // (carried up the column like k_catke_tke_step's)
   real n2f = Nz > 1 ? n2[o + pc] : real(0.);
   real wcur = csqrt(ecur > c.emin ? ecur : c.emin);
-  for (int k = 0; k < Nz; k++) {
+  for (int k = k0; k < k1; k++) {
     const int kf = k + 1, of = o + pc, ovf = ov + pv;
     zf += uniform_at(g.dzc, k);
     CatkeLengths L = {real(0.), real(0.), real(0.), real(0.)};
@@ -456,6 +473,7 @@ struct ImplicitVarFields {
   real dt, C1, C2;
   real* sum[2];                // column integrals of the new u, v (the look-ahead's predate the solve)
   int kchunks;
+  const real* src_e;           // null, or where k_catke_tke_step left e* (MODE 1, the e slice: the solve reads it there, writes e)
   real* P;                     // null, or the look-ahead's chunk sums (UvAhead::P): the sums of the NEW u dz, v dz per chunk of levels
   int plane2;                  // replace the look-ahead's there (w on the fly: k_w_bases takes w at the chunk boundaries from them)
   int z0;                      // first slice of the launch (MODE 1: 0 = T with S [+ e], 1 = e alone)
@@ -502,6 +520,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_var(Grid g, ImplicitV
   const int nb = MODE == 0 ? (z == 0 ? -1 : -g.sx) : 0;   // the second column kappa_u is averaged with
   real a[NZT], b[NZT], gm[NZT];
   const bool ab2 = tke && A.GnE != nullptr;
+  const real* Fsrc = (tke && A.src_e != nullptr) ? A.src_e : Fa;
   // ---- loads only, no arithmetic between them: every load of the column is in flight before the first wait
   if (MODE == 1 && ab2) {   // e* = e + dt (C1 G^n.e - C2 G^-.e) first (three arrays in, one out), then L^e and kappa_e
 #pragma unroll
@@ -517,7 +536,7 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_var(Grid g, ImplicitV
   }
 #pragma unroll
   for (int k = 0; k < NZT; k++) {
-    if (!(MODE == 1 && ab2)) a[k] = (k < Nz) ? Fa[o0 + k * pl] : real(0.);
+    if (!(MODE == 1 && ab2)) a[k] = (k < Nz) ? Fsrc[o0 + k * pl] : real(0.);
     const int of = oc + (k + 1) * pc;                      // the top face of level k
     gm[k] = (k < Nz - 1) ? K[of] : real(0.);
     if (MODE == 0) b[k] = (k < Nz - 1) ? K[of + nb] : real(0.);
@@ -598,9 +617,10 @@ __global__ __launch_bounds__(256) void k_implicit_vertical_var_stream(Grid g, Im
     for (int k = 0; k < kf; k++)
       Fa[o0 + k * pl] = ab2_advance(Fa[o0 + k * pl], A.GnE[o0 + k * pl], A.GmE[o0 + k * pl], A.dt, A.C1, A.C2);
   real rbet = real(1.), pa = real(0.), pb = real(0.), kup = real(0.);
+  const real* Fsrc = (tke && A.src_e != nullptr) ? A.src_e : Fa;
 #pragma unroll 4
   for (int k = kf; k < Nz; k++) {
-    real xa = Fa[o0 + k * pl], xb = real(0.), le = real(0.);
+    real xa = Fsrc[o0 + k * pl], xb = real(0.), le = real(0.);
     if (MODE == 1 && pair) xb = Fb[o0 + k * pl];
     if (MODE == 1 && tke) le = A.dt * A.Le[o0 + k * pl];
     if (MODE == 1 && ab2) xa = ab2_advance(xa, A.GnE[o0 + k * pl], A.GmE[o0 + k * pl], A.dt, A.C1, A.C2);

@@ -203,6 +203,7 @@ struct gb25_model {
   Field catke_b, catke_scratch;      // N^2 on the faces; the unused half of the two-wide tracer kernel's output
   gb25_catke_parameters catke_par;   // (gb25_default_catke_parameters at creation)
   Field catke_src;                   // 2-D: the top boundary condition of e (surface TKE flux / dz of the top cell)
+  real* catke_e_star = nullptr;   // where the last k_catke_tke_step left e* (e, or catke_scratch)
   bool implicit_lds_raised[2] = {false, false};   // k_implicit_vertical's dynamic-LDS attribute (Nz > 128), likewise
   bool whole_attr_set[2][2] = {{false, false}, {false, false}};   // k_barotropic_whole's dynamic-LDS attribute, per instance, on THIS model's device
   int comm_timeout_s = 180;          // option COMM_TIMEOUT_SECONDS
@@ -1811,6 +1812,12 @@ CatkePar catke_parameters(const gb25_model* m) {
 // The extended range on which a rank of a decomposition COMPUTES N^2 and the diffusivities: the first halo column on either
 // side, the first halo row of an open side and the row beyond a zipper fold (single domain: the interior, halos by images)
 struct CatkeRange { int i_lo, i_hi, j_lo, j_hi; };
+// chunks of levels of the CATKE column kernels: enough threads for ~10 waves per SIMD, at least 8 levels per chunk
+inline int catke_level_chunks(const gb25_model* m, long columns) {
+  int kch = 1;
+  while (kch < 8 && columns * kch < 600000L && m->g.Nz / (kch + 1) >= 8) kch++;
+  return kch;
+}
 inline CatkeRange catke_range(const gb25_model* m) {
   const Grid& g = m->g;
   CatkeRange r;
@@ -1840,9 +1847,14 @@ gb25_status catke_tke_step_impl(gb25_model* m) {
   const real* prev_uv[2];   // previous_velocities, wherever they are (prev_uv_src)
   for (int q = 0; q < 2; q++)
     prev_uv[q] = m->prev_uv_src == 1 ? m->f[GB25_U + q].d : m->prev_uv_src == 2 ? m->ahead_uv[q].d : m->f[GB25_PREV_U + q].d;
-  hipLaunchKernelGGL(m->immersed ? k_catke_tke_step<true> : k_catke_tke_step<false>, grid2(g.Nx, g.Ny, b), b, 0, m->stream, g,
+  // chunks of levels (catke_kernels.hpp): with fewer than ~600 k columns a thread per column leaves the chip short of waves
+  const int kch = catke_level_chunks(m, (long)g.Nx * g.Ny);
+  m->catke_e_star = kch > 1 ? m->catke_scratch.d : m->f[GB25_E].d;   // (where the implicit solve of e finds e*)
+  dim3 gt = grid2(g.Nx, g.Ny, b);
+  gt.z = kch;
+  hipLaunchKernelGGL(m->immersed ? k_catke_tke_step<true> : k_catke_tke_step<false>, gt, b, 0, m->stream, g,
                      catke_parameters(m), dt, real(1.5) + chi, real(0.5) + chi, m->f[GB25_U].d, m->f[GB25_V].d,
-                     prev_uv[0], prev_uv[1], m->f[GB25_E].d, m->catke_b.d, m->f[GB25_JB].d,
+                     prev_uv[0], prev_uv[1], m->f[GB25_E].d, m->catke_e_star, m->catke_b.d, m->f[GB25_JB].d,
                      m->f[GB25_KAPPA_U].d, m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, m->f[GB25_LE].d, m->f[GB25_GN_E].d,
                      m->f[GB25_GM_E].d);
   LAUNCHCHK();
@@ -1870,8 +1882,10 @@ gb25_status catke_diffusivities_finish_impl(gb25_model* m) {
   const Grid& g = m->g;
   const CatkeRange r = catke_range(m);
   dim3 b(64, 4);
+  dim3 gd = grid2(r.i_hi - r.i_lo, r.j_hi - r.j_lo, b);
+  gd.z = catke_level_chunks(m, (long)(r.i_hi - r.i_lo) * (r.j_hi - r.j_lo));
   hipLaunchKernelGGL(m->immersed ? k_catke_diffusivities<true> : k_catke_diffusivities<false>,
-                     grid2(r.i_hi - r.i_lo, r.j_hi - r.j_lo, b), b, 0, m->stream, g, catke_parameters(m), m->f[GB25_U].d,
+                     gd, b, 0, m->stream, g, catke_parameters(m), m->f[GB25_U].d,
                      m->f[GB25_V].d, m->f[GB25_E].d, m->catke_b.d, m->f[GB25_JB].d, m->f[GB25_KAPPA_U].d,
                      m->f[GB25_KAPPA_C].d, m->f[GB25_KAPPA_E].d, r.i_lo, r.i_hi, r.j_lo, r.j_hi);
   if (g.cv.north_fold && !m->slab)   // the rows beyond the zipper
@@ -1942,6 +1956,7 @@ gb25_status catke_implicit_impl(gb25_model* m, int mode, real dt, real chi, int 
   A.KU = m->f[GB25_KAPPA_U].d; A.KC = m->f[GB25_KAPPA_C].d; A.KE = m->f[GB25_KAPPA_E].d; A.Le = m->f[GB25_LE].d;
   A.dt = dt;
   A.GnE = A.GmE = nullptr;   // (e arrives with its AB2 update done: k_catke_tke_step)
+  A.src_e = (mode == 1 && z0 == 1) ? m->catke_e_star : nullptr;   // (... in e itself, or in the scratch array when the step ran in chunks of levels)
   A.C1 = real(1.5) + chi; A.C2 = real(0.5) + chi;
   A.z0 = z0;
   A.sum[0] = mode == 0 ? m->colsum[0].d : nullptr;

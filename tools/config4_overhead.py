@@ -18,7 +18,10 @@ t1 = (time.perf_counter() - t0) / steps
 print(f"single domain: {1e3 * t1:.2f} ms/step", flush=True)
 m.backend.close()
 atm = gb.analytic_atmosphere()
+only = os.environ.get("GB25_C4_ONLY")      # e.g. "4x2": that decomposition alone (for a profiler pass)
 for Rx, Ry in ((8, 1), (4, 2), (2, 4)):
+    if only and only != f"{Rx}x{Ry}":
+        continue
     ens = LocalSlabEnsemble(NX, NY, NZ, Rx * Ry, dt=DT, grid_type=4, ranks_y=Ry)
     for b in ens.backends:
         b.set_catke(True)
