@@ -410,13 +410,17 @@ __global__ __launch_bounds__(256, GB25_CATKE_MINW) void k_catke_diffusivities(Gr
   CatkeShear ulo = catke_face_velocities(g, u, v, o, ov);      // (carried up the column like k_catke_tke_step's)
   real n2f = Nz > 1 ? n2[o + pc] : real(0.);
   real wcur = csqrt(ecur > c.emin ? ecur : c.emin);
+  // (e of the level above comes one level early: its square root is the head of the face's arithmetic, and loaded with the level's
+  // other values the compiler waited for it alone, ahead of them -- a second sleep per level; the top halo layer exists in the parent)
+  real e_above = e[o + pc];
   for (int k = k0; k < k1; k++) {
     const int kf = k + 1, of = o + pc, ovf = ov + pv;
     zf += uniform_at(g.dzc, k);
     CatkeLengths L = {real(0.), real(0.), real(0.), real(0.)};
     real wnext = real(0.);
+    const real enext = e_above;
+    e_above = e[of + pc];
     if (kf < Nz) {
-      const real enext = e[of];
       const CatkeShear uhi = catke_face_velocities(g, u, v, of, ovf);
       const CatkeShear d = catke_dz_velocities(g, q, ulo, uhi, kf);
       ulo = uhi;
