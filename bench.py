@@ -152,7 +152,9 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 100: a timed region the driver's GPU samples can see)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 5)")
     ap.add_argument("--size", type=int, nargs=3, default=[1440, 720, 48], metavar=("Nx", "Ny", "Nz"))
-    ap.add_argument("--dt", type=float, default=120.0)
+    ap.add_argument("--dt", type=float, default=None,
+                    help="time step in seconds (default: 120 on the lat-lon grids; 60 on the tripolar ones, whose cells next to the poles "
+                         "leave the finite range before step 200 at 120 s -- the step's cost does not depend on it)")
     ap.add_argument("--mesh", default=None, metavar="RxxRy",
                     help="N > 1: a 2-D decomposition, Partition(Rx, Ry, 1) with Rx Ry = N (e.g. 4x2; default: N x slabs)")
     ap.add_argument("--weak", action="store_true", help="N > 1: every rank a full --size slab of an N times wider grid")
@@ -180,6 +182,8 @@ def main():
         args.warmup = 5
     if args.data_free:
         args.grid_type, args.closure, args.dt = "gaussian_islands", "catke", 30.0
+    if args.dt is None:
+        args.dt = 60.0 if args.grid_type in ("tripolar", "gaussian_islands") else 120.0
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # No launcher around us: start the N ranks ourselves.  A CHILD process (never a re-exec: this process may not replace
