@@ -61,7 +61,10 @@ typedef enum {
    * Face) [Nz + 1 levels], L^e at cell centres, the surface buoyancy flux J^b (2-D) */
   GB25_E, GB25_GN_E, GB25_GM_E, GB25_KAPPA_U, GB25_KAPPA_C, GB25_KAPPA_E, GB25_LE, GB25_JB,
   /* ... and diffusivity_fields.previous_velocities (u, v at the previous compute_diffusivities!: CATKE's shear production
-   * is centred between them and the current ones); not in the compared set, exposed for state transfer and tests */
+   * is centred between them and the current ones); not in the compared set, exposed for state transfer and tests.
+   * (A single domain keeps them, between calls, in whichever buffer already holds them -- u, v themselves right after
+   * compute_diffusivities!, the look-ahead's partner buffers after the AB2 step that followed -- and brings them into
+   * these fields when the host reads or writes any field or asks for a device pointer: gb25_api.hip, prev_uv_src.) */
   GB25_PREV_U, GB25_PREV_V,
   GB25_FIELD_COUNT
 } gb25_field;
